@@ -1,0 +1,228 @@
+"""Deterministic synthetic workloads for the ICP hot path.
+
+There is no network and the reference bundles no point clouds, so every bench and
+parity input is generated here: a "street canyon" scene (ground plane, two facades at y=+-12 m,
+end walls, random boxes), a local map sampled on its surfaces and pushed through the voxel-cap
+rule of mola::HashedVoxelPointCloud (lidar3d-default.yaml:233-235), and an HDL-64-like scan
+ray-cast from a known pose.  Pure numpy; PCG64 with fixed seeds, so inputs are identical here and
+on the GPU box.
+
+C2 (BASELINE.json configs[1]): workload_c2() -> N = 120 000 scan points vs M = 1 000 000 map
+points, voxel 1.0 m, cap 20, 20 ICP iterations with the sigma=2.0 schedule of
+lidar3d-default.yaml:190,198.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+FACADE_Y = 12.0
+FACADE_H = 15.0
+SENSOR_H = 1.73
+
+
+@dataclass
+class Scene:
+    half_extent: float  # ground is [-h, h]^2
+    end_wall_x: float   # end walls at x = +-end_wall_x (|y| <= FACADE_Y)
+    boxes: np.ndarray   # [B, 6] = xmin, ymin, zmin, xmax, ymax, zmax
+
+
+def make_scene(seed: int = 12345, half_extent: float = 120.0, n_boxes: int = 40) -> Scene:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    end_wall_x = half_extent - 10.0
+    boxes = []
+    while len(boxes) < n_boxes:
+        cx = rng.uniform(-end_wall_x + 6.0, end_wall_x - 6.0)
+        cy = rng.uniform(-FACADE_Y + 2.0, FACADE_Y - 2.0)
+        if rng.uniform() < 0.6:  # "car"
+            sx, sy, sz = rng.uniform(3.5, 4.8), rng.uniform(1.6, 2.0), rng.uniform(1.4, 1.9)
+        else:  # kiosk / small building
+            sx, sy, sz = rng.uniform(2.0, 8.0), rng.uniform(1.5, 3.0), rng.uniform(2.5, 6.0)
+        if np.hypot(cx, cy) < 8.0:  # keep the sensor's surroundings free
+            continue
+        boxes.append([cx - sx / 2, cy - sy / 2, 0.0, cx + sx / 2, cy + sy / 2, sz])
+    return Scene(half_extent, end_wall_x, np.asarray(boxes, dtype=np.float64))
+
+
+def _sample_surfaces(scene: Scene, n: int, rng: np.random.Generator, noise: float) -> np.ndarray:
+    h, ex = scene.half_extent, scene.end_wall_x
+    # surface list: (area, sampler)
+    areas, samplers = [], []
+
+    def add(area, fn):
+        areas.append(area)
+        samplers.append(fn)
+
+    add((2 * h) ** 2, lambda k: np.stack([rng.uniform(-h, h, k), rng.uniform(-h, h, k), np.zeros(k)], 1))
+    for s in (-1.0, 1.0):
+        add(2 * h * FACADE_H,
+            lambda k, s=s: np.stack([rng.uniform(-h, h, k), np.full(k, s * FACADE_Y), rng.uniform(0, FACADE_H, k)], 1))
+        add(2 * FACADE_Y * FACADE_H,
+            lambda k, s=s: np.stack([np.full(k, s * ex), rng.uniform(-FACADE_Y, FACADE_Y, k),
+                                     rng.uniform(0, FACADE_H, k)], 1))
+    for b in scene.boxes:
+        sx, sy, sz = b[3] - b[0], b[4] - b[1], b[5] - b[2]
+        # 4 sides + top, sampled as one surface by face areas
+        def box_fn(k, b=b, sx=sx, sy=sy, sz=sz):
+            fa = np.array([sx * sz, sx * sz, sy * sz, sy * sz, sx * sy])
+            f = rng.choice(5, size=k, p=fa / fa.sum())
+            u, v = rng.uniform(0, 1, k), rng.uniform(0, 1, k)
+            p = np.zeros((k, 3))
+            m = f == 0; p[m] = np.stack([b[0] + u[m] * sx, np.full(m.sum(), b[1]), b[2] + v[m] * sz], 1)
+            m = f == 1; p[m] = np.stack([b[0] + u[m] * sx, np.full(m.sum(), b[4]), b[2] + v[m] * sz], 1)
+            m = f == 2; p[m] = np.stack([np.full(m.sum(), b[0]), b[1] + u[m] * sy, b[2] + v[m] * sz], 1)
+            m = f == 3; p[m] = np.stack([np.full(m.sum(), b[3]), b[1] + u[m] * sy, b[2] + v[m] * sz], 1)
+            m = f == 4; p[m] = np.stack([b[0] + u[m] * sx, b[1] + v[m] * sy, np.full(m.sum(), b[5])], 1)
+            return p
+        add(2 * (sx + sy) * sz + sx * sy, box_fn)
+    areas = np.asarray(areas)
+    # vertical structure is what a lidar map is dense in: weight non-ground surfaces x4
+    wts = areas.copy()
+    wts[1:] *= 4.0
+    counts = rng.multinomial(n, wts / wts.sum())
+    pts = np.concatenate([fn(int(k)) for fn, k in zip(samplers, counts) if k > 0], 0)
+    pts += rng.normal(0.0, noise, pts.shape)
+    return pts[rng.permutation(len(pts))]
+
+
+def voxel_cap_filter(xyz: np.ndarray, voxel_size: float, cap: int) -> np.ndarray:
+    """Boolean mask of the points insertPoint() would keep (first `cap` per voxel, in order).
+    Data generation only -- NOT the product map build and NOT the oracle."""
+    k = np.floor(xyz.astype(np.float32) * (np.float32(1.0) / np.float32(voxel_size))).astype(np.int64)
+    key = ((k[:, 0] + (1 << 20)) << 42) | ((k[:, 1] + (1 << 20)) << 21) | (k[:, 2] + (1 << 20))
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    head = np.ones(len(ks), dtype=bool)
+    head[1:] = ks[1:] != ks[:-1]
+    start = np.maximum.accumulate(np.where(head, np.arange(len(ks)), 0))
+    rank = np.arange(len(ks)) - start
+    keep = np.zeros(len(ks), dtype=bool)
+    keep[order] = rank < cap if cap else True
+    return keep
+
+
+def make_map(scene: Scene, n_points: int, seed: int = 12345, voxel_size: float = 1.0, cap: int = 20,
+             noise: float = 0.02) -> np.ndarray:
+    """Exactly n_points fp32 map points, all of which survive the voxel-cap rule in this order."""
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    kept = np.zeros((0, 3), dtype=np.float32)
+    cand = np.zeros((0, 3), dtype=np.float32)
+    factor = 1.6
+    for _ in range(8):
+        cand = np.concatenate([cand, _sample_surfaces(scene, int(n_points * factor) - len(cand), rng, noise)
+                               .astype(np.float32)], 0)
+        keep = voxel_cap_filter(cand, voxel_size, cap)
+        if keep.sum() >= n_points:
+            kept = cand[keep][:n_points]
+            break
+        factor *= 1.5
+    if len(kept) != n_points:
+        raise RuntimeError("scene too small for the requested number of map points under the voxel cap")
+    return np.ascontiguousarray(kept, dtype=np.float32)
+
+
+def pose_from_ypr(p) -> np.ndarray:
+    """TPose3D (x,y,z,yaw,pitch,roll) -> row-major 3x4 [R|t] flattened (12 doubles), R=Rz*Ry*Rx."""
+    x, y, z, yaw, pitch, roll = [float(v) for v in p]
+    cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    return np.array([cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, x,
+                     sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr, y,
+                     -sp, cp * sr, cp * cr, z], dtype=np.float64)
+
+
+def make_scan(scene: Scene, pose_ypr, rings: int = 64, azimuths: int = 1875, seed: int = 54321,
+              max_range: float = 120.0, range_noise: float = 0.02) -> np.ndarray:
+    """Ray-cast an HDL-64-like sweep (ring-major order) from pose_ypr; returns LOCAL-frame fp32 points."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    T = pose_from_ypr(pose_ypr).reshape(3, 4)
+    R, o = T[:, :3], T[:, 3]
+    el = np.deg2rad(np.linspace(2.0, -24.8, rings))
+    az = np.linspace(-np.pi, np.pi, azimuths, endpoint=False)
+    E, A = np.meshgrid(el, az, indexing="ij")
+    d_local = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
+    d = d_local @ R.T
+    tmin = np.full(len(d), np.inf)
+    h, ex = scene.half_extent, scene.end_wall_x
+
+    def plane(axis, value, bounds):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (value - o[axis]) / d[:, axis]
+        p = o[None, :] + t[:, None] * d
+        ok = (t > 1e-6) & np.isfinite(t)
+        for ax, lo, hi in bounds:
+            ok &= (p[:, ax] >= lo) & (p[:, ax] <= hi)
+        np.minimum(tmin, np.where(ok, t, np.inf), out=tmin)
+
+    plane(2, 0.0, [(0, -h, h), (1, -h, h)])
+    for s in (-1.0, 1.0):
+        plane(1, s * FACADE_Y, [(0, -h, h), (2, 0.0, FACADE_H)])
+        plane(0, s * ex, [(1, -FACADE_Y, FACADE_Y), (2, 0.0, FACADE_H)])
+    for b in scene.boxes:  # slab test
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t0 = (b[None, :3] - o[None, :]) / d
+            t1 = (b[None, 3:] - o[None, :]) / d
+        tn = np.nanmax(np.minimum(t0, t1), axis=1)
+        tf = np.nanmin(np.maximum(t0, t1), axis=1)
+        ok = (tf >= tn) & (tn > 1e-6)
+        np.minimum(tmin, np.where(ok, tn, np.inf), out=tmin)
+    hit = tmin < max_range
+    rngs = tmin[hit] + rng.normal(0.0, range_noise, int(hit.sum()))
+    return np.ascontiguousarray(d_local[hit] * rngs[:, None], dtype=np.float32)
+
+
+def threshold_schedule(sigma: float, n_iters: int):
+    """Matcher threshold and robust-kernel parameter as functions of ICP_ITERATION
+    (lidar3d-default.yaml:198 and :190)."""
+    k = np.arange(n_iters, dtype=np.float64)
+    base = np.maximum(sigma, 2.0 * sigma - (2.0 * sigma - 0.5 * sigma) * k / 30.0)
+    return 2.0 * base, 0.5 * base
+
+
+@dataclass
+class Workload:
+    name: str
+    map_xyz: np.ndarray      # [M,3] fp32
+    scan_xyz: np.ndarray     # [N,3] fp32, local frame
+    pose_gt_ypr: np.ndarray  # TPose3D
+    guess_ypr: np.ndarray
+    T_gt: np.ndarray         # 12 doubles
+    T_guess: np.ndarray
+    voxel_size: float
+    cap: int
+    n_iters: int
+    threshold: np.ndarray
+    kernel_param: np.ndarray
+    sigma: float
+
+
+GUESS_PERTURBATION = np.array([0.5, 0.1, 0.02, np.deg2rad(1.0), np.deg2rad(0.2), np.deg2rad(0.2)])
+POSE_GT = np.array([2.5, -1.2, SENSOR_H, np.deg2rad(8.0), np.deg2rad(0.5), np.deg2rad(-0.3)])
+
+
+def make_workload(name: str, n_map: int, rings: int, azimuths: int, half_extent: float, n_boxes: int,
+                  n_iters: int = 20, sigma: float = 2.0, voxel_size: float = 1.0, cap: int = 20) -> Workload:
+    scene = make_scene(12345, half_extent, n_boxes)
+    m = make_map(scene, n_map, 12345, voxel_size, cap)
+    s = make_scan(scene, POSE_GT, rings, azimuths, 54321)
+    guess = POSE_GT + GUESS_PERTURBATION
+    thr, kp = threshold_schedule(sigma, n_iters)
+    return Workload(name, m, s, POSE_GT.copy(), guess, pose_from_ypr(POSE_GT), pose_from_ypr(guess), voxel_size, cap,
+                    n_iters, thr, kp, sigma)
+
+
+def workload_c2() -> Workload:
+    """BASELINE.json configs[1]: ~120k-pt scan vs 1M-pt map, 20 iterations."""
+    return make_workload("C2_120k_vs_1M", 1_000_000, 64, 1875, 120.0, 40)
+
+
+def workload_small() -> Workload:
+    """Reduced copy of C2 (2k-pt scan vs 20k-pt map): the committed golden fixture's generator."""
+    return make_workload("small_2k_vs_20k", 20_000, 16, 125, 25.0, 6)
+
+
+def workload_creal() -> Workload:
+    """What lidar3d-default.yaml actually feeds align(): a few-thousand-point decimated scan
+    (yaml:285-319) against the same 1M-pt map."""
+    return make_workload("Creal_6k_vs_1M", 1_000_000, 32, 192, 120.0, 40)

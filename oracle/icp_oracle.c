@@ -1,0 +1,824 @@
+/* icp_oracle.c -- CPU restatement of the mp2p_icp ICP::align() hot path.  See icp_oracle.h:
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (no golden vectors exist for this path in the
+ * reference; this restates SURVEY.md 8(a)+Appendix A, cross-checked by icp_oracle_np.py).
+ *
+ * Build: gcc -O3 -ffp-contract=off -fopenmp -shared -fPIC  (see oracle/Makefile).
+ * -ffp-contract=off is REQUIRED: the fp32 distance arithmetic and the double->float point
+ * transform are specified un-fused so that the HIP kernels can reproduce them bit for bit.
+ */
+#include "icp_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+
+/* ======================================================================================
+ * SE(3) helpers -- SURVEY Appendix A (mrpt::poses::CPose3D, Lie::SE<3>, Lie::SO<3>)
+ * ==================================================================================== */
+#define R_(T, i, j) ((T)[(i)*4 + (j)])
+#define t_(T, i) ((T)[(i)*4 + 3])
+
+void orc_pose_from_ypr(const double p[6], double T[12]) {
+  /* R = Rz(yaw)*Ry(pitch)*Rx(roll): TPose3D ordering, LidarOdometry.cpp:235 */
+  const double cy = cos(p[3]), sy = sin(p[3]);
+  const double cp = cos(p[4]), sp = sin(p[4]);
+  const double cr = cos(p[5]), sr = sin(p[5]);
+  R_(T, 0, 0) = cy * cp; R_(T, 0, 1) = cy * sp * sr - sy * cr; R_(T, 0, 2) = cy * sp * cr + sy * sr;
+  R_(T, 1, 0) = sy * cp; R_(T, 1, 1) = sy * sp * sr + cy * cr; R_(T, 1, 2) = sy * sp * cr - cy * sr;
+  R_(T, 2, 0) = -sp;     R_(T, 2, 1) = cp * sr;                R_(T, 2, 2) = cp * cr;
+  t_(T, 0) = p[0]; t_(T, 1) = p[1]; t_(T, 2) = p[2];
+}
+
+void orc_pose_to_ypr(const double T[12], double p[6]) {
+  p[0] = t_(T, 0); p[1] = t_(T, 1); p[2] = t_(T, 2);
+  const double c = hypot(R_(T, 0, 0), R_(T, 1, 0));
+  p[4] = atan2(-R_(T, 2, 0), c);
+  if (c > 1e-12) {
+    p[3] = atan2(R_(T, 1, 0), R_(T, 0, 0));
+    p[5] = atan2(R_(T, 2, 1), R_(T, 2, 2));
+  } else { /* gimbal lock: put everything in yaw */
+    p[3] = atan2(-R_(T, 0, 1), R_(T, 1, 1));
+    p[5] = 0.0;
+  }
+}
+
+void orc_pose_compose(const double A[12], const double B[12], double C[12]) {
+  double out[12];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++)
+      out[i * 4 + j] = R_(A, i, 0) * R_(B, 0, j) + R_(A, i, 1) * R_(B, 1, j) + R_(A, i, 2) * R_(B, 2, j);
+    out[i * 4 + 3] = R_(A, i, 0) * t_(B, 0) + R_(A, i, 1) * t_(B, 1) + R_(A, i, 2) * t_(B, 2) + t_(A, i);
+  }
+  memcpy(C, out, sizeof(out));
+}
+
+void orc_pose_inverse(const double A[12], double B[12]) {
+  double out[12];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) out[i * 4 + j] = R_(A, j, i);
+    out[i * 4 + 3] = -(R_(A, 0, i) * t_(A, 0) + R_(A, 1, i) * t_(A, 1) + R_(A, 2, i) * t_(A, 2));
+  }
+  memcpy(B, out, sizeof(out));
+}
+
+static void skew_sq_coeffs(double th, double* a, double* b, double* c) {
+  /* a = sin(th)/th, b = (1-cos th)/th^2, c = (th - sin th)/th^3, cancellation-free */
+  const double t2 = th * th;
+  if (th < 1e-2) {
+    *a = 1.0 - t2 / 6.0 * (1.0 - t2 / 20.0 * (1.0 - t2 / 42.0));
+    *b = 0.5 - t2 / 24.0 * (1.0 - t2 / 30.0 * (1.0 - t2 / 56.0));
+    *c = 1.0 / 6.0 - t2 / 120.0 * (1.0 - t2 / 42.0 * (1.0 - t2 / 72.0));
+  } else {
+    const double sh = sin(0.5 * th);
+    *a = sin(th) / th;
+    *b = 2.0 * sh * sh / t2;
+    *c = (th - sin(th)) / (t2 * th);
+  }
+}
+
+void orc_se3_exp(const double xi[6], double T[12]) {
+  const double wx = xi[3], wy = xi[4], wz = xi[5];
+  const double th = sqrt(wx * wx + wy * wy + wz * wz);
+  double a, b, c;
+  skew_sq_coeffs(th, &a, &b, &c);
+  const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+  double W2[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) W2[i * 3 + j] = W[i * 3 + 0] * W[0 * 3 + j] + W[i * 3 + 1] * W[1 * 3 + j] + W[i * 3 + 2] * W[2 * 3 + j];
+  double V[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const double I = (i == j) ? 1.0 : 0.0;
+      R_(T, i, j) = I + a * W[i * 3 + j] + b * W2[i * 3 + j];
+      V[i * 3 + j] = I + b * W[i * 3 + j] + c * W2[i * 3 + j];
+    }
+  for (int i = 0; i < 3; i++) t_(T, i) = V[i * 3 + 0] * xi[0] + V[i * 3 + 1] * xi[1] + V[i * 3 + 2] * xi[2];
+}
+
+void orc_so3_log(const double T[12], double w[3]) {
+  const double tr = R_(T, 0, 0) + R_(T, 1, 1) + R_(T, 2, 2);
+  double cth = 0.5 * (tr - 1.0);
+  if (cth > 1.0) cth = 1.0;
+  if (cth < -1.0) cth = -1.0;
+  const double vx = R_(T, 2, 1) - R_(T, 1, 2), vy = R_(T, 0, 2) - R_(T, 2, 0), vz = R_(T, 1, 0) - R_(T, 0, 1);
+  const double s2 = sqrt(vx * vx + vy * vy + vz * vz); /* = 2 sin(th) */
+  const double th = atan2(0.5 * s2, cth);
+  if (th < 1e-7) {
+    const double k = 0.5 * (1.0 + th * th / 6.0);
+    w[0] = k * vx; w[1] = k * vy; w[2] = k * vz;
+    return;
+  }
+  if (3.141592653589793 - th > 1e-6) {
+    const double k = th / s2;
+    w[0] = k * vx; w[1] = k * vy; w[2] = k * vz;
+    return;
+  }
+  /* near pi: axis from the largest diagonal of (R + I)/2 = n n^T (+O(pi-th)) */
+  double n[3];
+  const double d0 = R_(T, 0, 0), d1 = R_(T, 1, 1), d2 = R_(T, 2, 2);
+  int k = (d0 >= d1 && d0 >= d2) ? 0 : (d1 >= d2 ? 1 : 2);
+  const double nk = sqrt(fmax(0.0, 0.5 * (R_(T, k, k) + 1.0)));
+  n[k] = nk;
+  for (int j = 0; j < 3; j++)
+    if (j != k) n[j] = 0.25 * (R_(T, k, j) + R_(T, j, k)) / nk;
+  /* fix sign with the antisymmetric part when it is informative */
+  const double v[3] = {vx, vy, vz};
+  const double dot = n[0] * v[0] + n[1] * v[1] + n[2] * v[2];
+  const double sgn = (dot < 0.0) ? -1.0 : 1.0;
+  const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  for (int j = 0; j < 3; j++) w[j] = sgn * th * n[j] / nn;
+}
+
+void orc_se3_log(const double T[12], double xi[6]) {
+  double w[3];
+  orc_so3_log(T, w);
+  const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  /* V^-1 = I - W/2 + k W^2, k = (1 - th sin th / (2(1-cos th)))/th^2 */
+  double k;
+  if (th < 1e-2)
+    k = 1.0 / 12.0 + th * th / 720.0 + th * th * th * th / 30240.0;
+  else
+    k = (1.0 - 0.5 * th / tan(0.5 * th)) / (th * th);
+  const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  double W2[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) W2[i * 3 + j] = W[i * 3 + 0] * W[0 * 3 + j] + W[i * 3 + 1] * W[1 * 3 + j] + W[i * 3 + 2] * W[2 * 3 + j];
+  for (int i = 0; i < 3; i++) {
+    double acc = 0;
+    for (int j = 0; j < 3; j++) {
+      const double Vinv = ((i == j) ? 1.0 : 0.0) - 0.5 * W[i * 3 + j] + k * W2[i * 3 + j];
+      acc += Vinv * t_(T, j);
+    }
+    xi[i] = acc;
+  }
+  xi[3] = w[0]; xi[4] = w[1]; xi[5] = w[2];
+}
+
+/* ======================================================================================
+ * Local map -- mola::HashedVoxelPointCloud restated (yaml:228-242)
+ * ==================================================================================== */
+typedef struct {
+  int32_t k[3];
+  uint32_t n, cap;
+  float* xyz;    /* n x 3 interleaved, insertion order */
+  uint32_t* src; /* source index of each stored point */
+} voxel_t;
+
+struct orc_map {
+  orc_map_params p;
+  float inv_vs;
+  voxel_t* vox;
+  size_t n_vox, cap_vox;
+  int32_t* table; /* open addressing: voxel id or -1 */
+  size_t table_size; /* power of two */
+  size_t n_points;
+  uint64_t n_offered;
+  float bb_min[3], bb_max[3];
+};
+
+static inline uint64_t hash3(int32_t x, int32_t y, int32_t z) {
+  /* the classic 3-prime spatial hash; any hash gives identical results */
+  uint64_t h = ((uint64_t)(uint32_t)x * 73856093u) ^ ((uint64_t)(uint32_t)y * 19349663u) ^ ((uint64_t)(uint32_t)z * 83492791u);
+  h ^= h >> 15;
+  return h;
+}
+
+static inline int32_t coord2idx(const orc_map* m, float c) {
+  /* idx = floor(coord * (1/voxel_size)) (SURVEY Appendix A "Voxel indexing"); TRUNC is the
+   * alternative reading kept as a switch. */
+  const float s = c * m->inv_vs;
+  if (m->p.index_mode == ORC_INDEX_TRUNC) return (int32_t)s;
+  return (int32_t)floorf(s);
+}
+
+orc_map* orc_map_create(const orc_map_params* p) {
+  orc_map* m = (orc_map*)calloc(1, sizeof(orc_map));
+  m->p = *p;
+  m->inv_vs = 1.0f / p->voxel_size;
+  m->table_size = 1024;
+  m->table = (int32_t*)malloc(m->table_size * sizeof(int32_t));
+  for (size_t i = 0; i < m->table_size; i++) m->table[i] = -1;
+  m->cap_vox = 512;
+  m->vox = (voxel_t*)malloc(m->cap_vox * sizeof(voxel_t));
+  for (int i = 0; i < 3; i++) { m->bb_min[i] = INFINITY; m->bb_max[i] = -INFINITY; }
+  return m;
+}
+
+void orc_map_destroy(orc_map* m) {
+  if (!m) return;
+  for (size_t i = 0; i < m->n_vox; i++) { free(m->vox[i].xyz); free(m->vox[i].src); }
+  free(m->vox);
+  free(m->table);
+  free(m);
+}
+
+static inline const voxel_t* map_find(const orc_map* m, int32_t kx, int32_t ky, int32_t kz) {
+  const size_t mask = m->table_size - 1;
+  size_t h = hash3(kx, ky, kz) & mask;
+  for (;;) {
+    const int32_t id = m->table[h];
+    if (id < 0) return NULL;
+    const voxel_t* v = &m->vox[id];
+    if (v->k[0] == kx && v->k[1] == ky && v->k[2] == kz) return v;
+    h = (h + 1) & mask;
+  }
+}
+
+static void map_rehash(orc_map* m, size_t new_size) {
+  free(m->table);
+  m->table_size = new_size;
+  m->table = (int32_t*)malloc(new_size * sizeof(int32_t));
+  for (size_t i = 0; i < new_size; i++) m->table[i] = -1;
+  const size_t mask = new_size - 1;
+  for (size_t id = 0; id < m->n_vox; id++) {
+    const voxel_t* v = &m->vox[id];
+    size_t h = hash3(v->k[0], v->k[1], v->k[2]) & mask;
+    while (m->table[h] >= 0) h = (h + 1) & mask;
+    m->table[h] = (int32_t)id;
+  }
+}
+
+static voxel_t* map_find_or_create(orc_map* m, int32_t kx, int32_t ky, int32_t kz) {
+  size_t mask = m->table_size - 1;
+  size_t h = hash3(kx, ky, kz) & mask;
+  for (;;) {
+    const int32_t id = m->table[h];
+    if (id < 0) break;
+    voxel_t* v = &m->vox[id];
+    if (v->k[0] == kx && v->k[1] == ky && v->k[2] == kz) return v;
+    h = (h + 1) & mask;
+  }
+  if ((m->n_vox + 1) * 2 > m->table_size) {
+    map_rehash(m, m->table_size * 2);
+    mask = m->table_size - 1;
+    h = hash3(kx, ky, kz) & mask;
+    while (m->table[h] >= 0) h = (h + 1) & mask;
+  }
+  if (m->n_vox == m->cap_vox) {
+    m->cap_vox *= 2;
+    m->vox = (voxel_t*)realloc(m->vox, m->cap_vox * sizeof(voxel_t));
+  }
+  voxel_t* v = &m->vox[m->n_vox];
+  v->k[0] = kx; v->k[1] = ky; v->k[2] = kz;
+  v->n = 0;
+  v->cap = m->p.max_points_per_voxel ? m->p.max_points_per_voxel : 8;
+  v->xyz = (float*)malloc((size_t)v->cap * 3 * sizeof(float));
+  v->src = (uint32_t*)malloc((size_t)v->cap * sizeof(uint32_t));
+  m->table[h] = (int32_t)m->n_vox;
+  m->n_vox++;
+  return v;
+}
+
+void orc_map_insert(orc_map* m, const float* x, const float* y, const float* z, size_t n) {
+  /* HashedVoxelPointCloud::insertPoint: drop if the voxel already holds max_points_per_voxel
+   * (yaml:235); min_distance_between_points is 0 in both target pipelines (yaml:236). */
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t src = (uint32_t)(m->n_offered + i);
+    const float px = x[i], py = y[i], pz = z[i];
+    if (!isfinite(px) || !isfinite(py) || !isfinite(pz)) continue;
+    voxel_t* v = map_find_or_create(m, coord2idx(m, px), coord2idx(m, py), coord2idx(m, pz));
+    if (m->p.max_points_per_voxel && v->n >= m->p.max_points_per_voxel) continue;
+    if (v->n == v->cap) {
+      v->cap *= 2;
+      v->xyz = (float*)realloc(v->xyz, (size_t)v->cap * 3 * sizeof(float));
+      v->src = (uint32_t*)realloc(v->src, (size_t)v->cap * sizeof(uint32_t));
+    }
+    v->xyz[3 * v->n + 0] = px; v->xyz[3 * v->n + 1] = py; v->xyz[3 * v->n + 2] = pz;
+    v->src[v->n] = src;
+    v->n++;
+    m->n_points++;
+    if (px < m->bb_min[0]) m->bb_min[0] = px;
+    if (py < m->bb_min[1]) m->bb_min[1] = py;
+    if (pz < m->bb_min[2]) m->bb_min[2] = pz;
+    if (px > m->bb_max[0]) m->bb_max[0] = px;
+    if (py > m->bb_max[1]) m->bb_max[1] = py;
+    if (pz > m->bb_max[2]) m->bb_max[2] = pz;
+  }
+  m->n_offered += n;
+}
+
+size_t orc_map_num_points(const orc_map* m) { return m->n_points; }
+size_t orc_map_num_voxels(const orc_map* m) {
+  size_t c = 0; /* a voxel created by a dropped non-finite point cannot exist; all have n>=1 */
+  for (size_t i = 0; i < m->n_vox; i++) c += (m->vox[i].n > 0);
+  return c;
+}
+void orc_map_bbox(const orc_map* m, float mn[3], float mx[3]) {
+  memcpy(mn, m->bb_min, sizeof(float) * 3);
+  memcpy(mx, m->bb_max, sizeof(float) * 3);
+}
+
+static const orc_map* g_sort_map;
+static int cmp_vox(const void* a, const void* b) {
+  const voxel_t* va = &g_sort_map->vox[*(const uint32_t*)a];
+  const voxel_t* vb = &g_sort_map->vox[*(const uint32_t*)b];
+  for (int i = 0; i < 3; i++) {
+    if (va->k[i] < vb->k[i]) return -1;
+    if (va->k[i] > vb->k[i]) return 1;
+  }
+  return 0;
+}
+
+void orc_map_dump(const orc_map* m, float* x, float* y, float* z, uint32_t* src_idx, int32_t* vox_keys,
+                  uint32_t* vox_first, uint32_t* vox_count) {
+  uint32_t* order = (uint32_t*)malloc((m->n_vox + 1) * sizeof(uint32_t));
+  size_t nv = 0;
+  for (size_t i = 0; i < m->n_vox; i++)
+    if (m->vox[i].n > 0) order[nv++] = (uint32_t)i;
+  g_sort_map = m;
+  qsort(order, nv, sizeof(uint32_t), cmp_vox);
+  size_t o = 0;
+  for (size_t i = 0; i < nv; i++) {
+    const voxel_t* v = &m->vox[order[i]];
+    if (vox_keys) { vox_keys[3 * i] = v->k[0]; vox_keys[3 * i + 1] = v->k[1]; vox_keys[3 * i + 2] = v->k[2]; }
+    if (vox_first) vox_first[i] = (uint32_t)o;
+    if (vox_count) vox_count[i] = v->n;
+    for (uint32_t j = 0; j < v->n; j++, o++) {
+      if (x) x[o] = v->xyz[3 * j];
+      if (y) y[o] = v->xyz[3 * j + 1];
+      if (z) z[o] = v->xyz[3 * j + 2];
+      if (src_idx) src_idx[o] = v->src[j];
+    }
+  }
+  free(order);
+}
+
+int orc_map_nn_single(const orc_map* m, float qx, float qy, float qz, float out_pt[3], float* out_d2,
+                      uint32_t* out_src_idx, uint64_t* n_candidates, uint64_t* n_voxels_hit) {
+  /* nn_single_search: 3x3x3 block around voxel(q), reach independent of the matcher threshold
+   * (SURVEY App.B U3); scan order x outer, y middle, z inner (U2). */
+  const int32_t cx = coord2idx(m, qx), cy = coord2idx(m, qy), cz = coord2idx(m, qz);
+  float best = INFINITY;
+  int found = 0;
+  uint64_t nc = 0, nv = 0;
+  for (int32_t ix = cx - 1; ix <= cx + 1; ix++)
+    for (int32_t iy = cy - 1; iy <= cy + 1; iy++)
+      for (int32_t iz = cz - 1; iz <= cz + 1; iz++) {
+        const voxel_t* v = map_find(m, ix, iy, iz);
+        if (!v || v->n == 0) continue;
+        nv++;
+        nc += v->n;
+        for (uint32_t j = 0; j < v->n; j++) {
+          const float dx = v->xyz[3 * j] - qx, dy = v->xyz[3 * j + 1] - qy, dz = v->xyz[3 * j + 2] - qz;
+          const float d2 = (dx * dx + dy * dy) + dz * dz; /* fp32, un-fused, this order */
+          if (d2 < best) {
+            best = d2;
+            found = 1;
+            out_pt[0] = v->xyz[3 * j]; out_pt[1] = v->xyz[3 * j + 1]; out_pt[2] = v->xyz[3 * j + 2];
+            *out_src_idx = v->src[j];
+          }
+        }
+      }
+  if (n_candidates) *n_candidates += nc;
+  if (n_voxels_hit) *n_voxels_hit += nv;
+  *out_d2 = best;
+  return found;
+}
+
+/* ======================================================================================
+ * Matcher -- Matcher_Points_Base::transform_local_to_global + Matcher_Points_DistanceThreshold
+ * (yaml:195-204)
+ * ==================================================================================== */
+static inline void transform_pt(const double T[12], float lx, float ly, float lz, float* gx, float* gy, float* gz) {
+  /* CPose3D::composePoint: double pose x float point, result rounded to float (U4) */
+  const double x = lx, y = ly, z = lz;
+  *gx = (float)(((R_(T, 0, 0) * x + R_(T, 0, 1) * y) + R_(T, 0, 2) * z) + t_(T, 0));
+  *gy = (float)(((R_(T, 1, 0) * x + R_(T, 1, 1) * y) + R_(T, 1, 2) * z) + t_(T, 1));
+  *gz = (float)(((R_(T, 2, 0) * x + R_(T, 2, 1) * y) + R_(T, 2, 2) * z) + t_(T, 2));
+}
+
+size_t orc_match_points(const orc_map* m, const float* lx, const float* ly, const float* lz, size_t n,
+                        const double T[12], double threshold, double threshold_angular_deg,
+                        uint32_t* local_idx, uint32_t* global_idx, float* gx, float* gy, float* gz, float* d2,
+                        orc_match_stats* stats, int n_threads) {
+  /* const float maxDistForCorrespondenceSquared = square(double threshold); same for the angle */
+  const float thr2 = (float)(threshold * threshold);
+  const double ang = threshold_angular_deg * 3.14159265358979323846 / 180.0;
+  const float ang2 = (float)(ang * ang);
+  uint8_t* ok = (uint8_t*)malloc(n ? n : 1);
+  uint64_t nc = 0, nv = 0;
+  (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : 1) reduction(+ : nc, nv)
+#endif
+  for (long i = 0; i < (long)n; i++) {
+    float px, py, pz, q[3], dd;
+    uint32_t gi = 0;
+    transform_pt(T, lx[i], ly[i], lz[i], &px, &py, &pz);
+    const int found = orc_map_nn_single(m, px, py, pz, q, &dd, &gi, &nc, &nv);
+    const float norm2 = (px * px + py * py) + pz * pz;
+    const float lim = thr2 + ang2 * norm2;
+    ok[i] = (uint8_t)(found && dd < lim);
+    if (ok[i]) { gx[i] = q[0]; gy[i] = q[1]; gz[i] = q[2]; d2[i] = dd; global_idx[i] = gi; }
+  }
+  /* ordered compaction (ascending local index), in place */
+  size_t np = 0;
+  for (size_t i = 0; i < n; i++)
+    if (ok[i]) {
+      local_idx[np] = (uint32_t)i; global_idx[np] = global_idx[i];
+      gx[np] = gx[i]; gy[np] = gy[i]; gz[np] = gz[i]; d2[np] = d2[i];
+      np++;
+    }
+  free(ok);
+  if (stats) {
+    stats->potential_pairings = n; /* pcLocal.size() * pairingsPerPoint, counted before any test (U6) */
+    stats->n_candidates = nc;
+    stats->n_voxels_hit = nv;
+  }
+  return np;
+}
+
+/* ======================================================================================
+ * Solver -- optimal_tf_gauss_newton (Appendix A)
+ * ==================================================================================== */
+static inline double robust_weight(uint32_t kernel, double c, double e2) {
+  switch (kernel) {
+    case ORC_KERNEL_GM_C4: { const double c2 = c * c, d = c2 + e2; return (c2 * c2) / (d * d); }
+    case ORC_KERNEL_GM_KISS: { const double d = c + e2; return (c * c) / (d * d); }
+    case ORC_KERNEL_GM_BARRON: { const double d = e2 / (4.0 * c * c) + 1.0; return 1.0 / (d * d); }
+    case ORC_KERNEL_CAUCHY: { const double c2 = c * c; return c2 / (c2 + e2); }
+    case ORC_KERNEL_GM_C2: { const double c2 = c * c, d = c2 + e2; return c2 / (d * d); }
+    default: return 1.0;
+  }
+}
+
+typedef struct { double H[36]; double g[6]; double cost; } acc_t;
+
+static inline void acc_row(acc_t* a, const double J[6], double e, double w) {
+  for (int i = 0; i < 6; i++) {
+    a->g[i] += w * J[i] * e;
+    for (int j = 0; j < 6; j++) a->H[i * 6 + j] += w * J[i] * J[j];
+  }
+}
+
+static void accumulate_range(const orc_pairs_pt2pt* pp, size_t p0, size_t p1, const orc_pairs_pt2pl* pl, size_t q0,
+                             size_t q1, const orc_gn_params* p, const double T[12], acc_t* a) {
+  memset(a, 0, sizeof(*a));
+  for (size_t i = p0; i < p1; i++) {
+    const double l[3] = {pp->lx[i], pp->ly[i], pp->lz[i]};
+    const double q[3] = {pp->gx[i], pp->gy[i], pp->gz[i]};
+    double e[3];
+    for (int r = 0; r < 3; r++) e[r] = R_(T, r, 0) * l[0] + R_(T, r, 1) * l[1] + R_(T, r, 2) * l[2] + t_(T, r) - q[r];
+    const double e2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    const double w = p->weight_pt2pt * robust_weight(p->robust_kernel, p->robust_kernel_param, e2);
+    /* J = [R | -R [l]x]  (3x6), right perturbation T*exp(eps) */
+    for (int r = 0; r < 3; r++) {
+      const double Rr[3] = {R_(T, r, 0), R_(T, r, 1), R_(T, r, 2)};
+      double J[6];
+      J[0] = Rr[0]; J[1] = Rr[1]; J[2] = Rr[2];
+      /* -(Rr . [l]x): [l]x = [[0,-lz,ly],[lz,0,-lx],[-ly,lx,0]] */
+      J[3] = -(Rr[1] * l[2] - Rr[2] * l[1]);
+      J[4] = -(-Rr[0] * l[2] + Rr[2] * l[0]);
+      J[5] = -(Rr[0] * l[1] - Rr[1] * l[0]);
+      acc_row(a, J, e[r], w);
+    }
+    a->cost += w * e2;
+  }
+  if (pl)
+    for (size_t i = q0; i < q1; i++) {
+      const double l[3] = {pl->lx[i], pl->ly[i], pl->lz[i]};
+      const double c[3] = {pl->cx[i], pl->cy[i], pl->cz[i]};
+      const double nrm[3] = {pl->nx[i], pl->ny[i], pl->nz[i]};
+      double g3[3];
+      for (int r = 0; r < 3; r++) g3[r] = R_(T, r, 0) * l[0] + R_(T, r, 1) * l[1] + R_(T, r, 2) * l[2] + t_(T, r) - c[r];
+      const double e = nrm[0] * g3[0] + nrm[1] * g3[1] + nrm[2] * g3[2];
+      const double w = p->weight_pt2pl * robust_weight(p->robust_kernel, p->robust_kernel_param, e * e);
+      /* J = n^T [R | -R[l]x] */
+      double mloc[3]; /* R^T n */
+      for (int j = 0; j < 3; j++) mloc[j] = R_(T, 0, j) * nrm[0] + R_(T, 1, j) * nrm[1] + R_(T, 2, j) * nrm[2];
+      double J[6];
+      J[0] = mloc[0]; J[1] = mloc[1]; J[2] = mloc[2];
+      J[3] = l[1] * mloc[2] - l[2] * mloc[1];
+      J[4] = l[2] * mloc[0] - l[0] * mloc[2];
+      J[5] = l[0] * mloc[1] - l[1] * mloc[0];
+      acc_row(a, J, e, w);
+      a->cost += w * e * e;
+    }
+}
+
+/* Eigen-style LDL^T with diagonal pivoting; x = -H^-1 g (pseudo-inverse on zero pivots).
+ * Returns 0 if any pivot is non-finite. */
+static int ldlt_solve6(const double Hin[36], const double b[6], double x[6]) {
+  double A[36];
+  memcpy(A, Hin, sizeof(A));
+  int perm[6];
+  for (int i = 0; i < 6; i++) perm[i] = i;
+  for (int k = 0; k < 6; k++) {
+    int piv = k;
+    double best = fabs(A[k * 6 + k]);
+    for (int i = k + 1; i < 6; i++)
+      if (fabs(A[i * 6 + i]) > best) { best = fabs(A[i * 6 + i]); piv = i; }
+    if (piv != k) {
+      for (int j = 0; j < 6; j++) { double t = A[k * 6 + j]; A[k * 6 + j] = A[piv * 6 + j]; A[piv * 6 + j] = t; }
+      for (int j = 0; j < 6; j++) { double t = A[j * 6 + k]; A[j * 6 + k] = A[j * 6 + piv]; A[j * 6 + piv] = t; }
+      int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    const double d = A[k * 6 + k];
+    if (!isfinite(d)) return 0;
+    if (fabs(d) > 2.2250738585072014e-308) {
+      for (int i = k + 1; i < 6; i++) A[i * 6 + k] /= d;
+      for (int i = k + 1; i < 6; i++)
+        for (int j = k + 1; j <= i; j++) {
+          A[i * 6 + j] -= A[i * 6 + k] * d * A[j * 6 + k];
+          A[j * 6 + i] = A[i * 6 + j];
+        }
+    } else {
+      for (int i = k + 1; i < 6; i++) A[i * 6 + k] = 0.0;
+    }
+  }
+  double y[6];
+  for (int i = 0; i < 6; i++) y[i] = b[perm[i]];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < i; j++) y[i] -= A[i * 6 + j] * y[j];
+  for (int i = 0; i < 6; i++) {
+    const double d = A[i * 6 + i];
+    y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0;
+  }
+  for (int i = 5; i >= 0; i--)
+    for (int j = i + 1; j < 6; j++) y[i] -= A[j * 6 + i] * y[j];
+  for (int i = 0; i < 6; i++) x[perm[i]] = y[i];
+  for (int i = 0; i < 6; i++)
+    if (!isfinite(x[i])) return 0;
+  return 1;
+}
+
+static void prior_term(const orc_prior* prior, const double T[12], double H[36], double g[6]) {
+  /* e_p = log(T_prior^-1 (+) T) ; Jp = d e_p / d eps for T <- T*exp(eps), by central
+   * differences (U9: exact derivative up to O(h^2)). */
+  double Pinv[12], D[12], e0[6];
+  orc_pose_inverse(prior->mean, Pinv);
+  orc_pose_compose(Pinv, T, D);
+  orc_se3_log(D, e0);
+  double Jp[36];
+  const double h = 1e-6;
+  for (int j = 0; j < 6; j++) {
+    double xi[6] = {0, 0, 0, 0, 0, 0}, E[12], Dp[12], ep[6], em[6];
+    xi[j] = h;
+    orc_se3_exp(xi, E); orc_pose_compose(D, E, Dp); orc_se3_log(Dp, ep);
+    xi[j] = -h;
+    orc_se3_exp(xi, E); orc_pose_compose(D, E, Dp); orc_se3_log(Dp, em);
+    for (int i = 0; i < 6; i++) Jp[i * 6 + j] = (ep[i] - em[i]) / (2.0 * h);
+  }
+  double JtL[36]; /* Jp^T * Lambda */
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      double s = 0;
+      for (int k = 0; k < 6; k++) s += Jp[k * 6 + i] * prior->info[k * 6 + j];
+      JtL[i * 6 + j] = s;
+    }
+  for (int i = 0; i < 6; i++) {
+    double s = 0;
+    for (int k = 0; k < 6; k++) s += JtL[i * 6 + k] * e0[k];
+    g[i] += s;
+    for (int j = 0; j < 6; j++) {
+      double h2 = 0;
+      for (int k = 0; k < 6; k++) h2 += JtL[i * 6 + k] * Jp[k * 6 + j];
+      H[i * 6 + j] += h2;
+    }
+  }
+}
+
+int orc_gn_solve(const orc_pairs_pt2pt* pp, const orc_pairs_pt2pl* pl, const orc_gn_params* p, const orc_prior* prior,
+                 double T[12], orc_gn_step* trace, int n_threads) {
+  const size_t np = pp ? pp->n : 0, nl = pl ? pl->n : 0;
+  int nt = n_threads > 0 ? n_threads : 1;
+  if ((size_t)nt > np + nl) nt = (int)((np + nl) ? (np + nl) : 1);
+  acc_t* parts = (acc_t*)malloc(sizeof(acc_t) * (size_t)nt);
+  int steps = 0;
+  for (uint32_t it = 0; it < p->max_inner_iterations; it++) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+#endif
+    for (int t = 0; t < nt; t++) {
+      const size_t p0 = np * (size_t)t / (size_t)nt, p1 = np * (size_t)(t + 1) / (size_t)nt;
+      const size_t q0 = nl * (size_t)t / (size_t)nt, q1 = nl * (size_t)(t + 1) / (size_t)nt;
+      accumulate_range(pp, p0, p1, pl, q0, q1, p, T, &parts[t]);
+    }
+    acc_t a;
+    memset(&a, 0, sizeof(a));
+    for (int t = 0; t < nt; t++) { /* ordered join: deterministic for a given thread count */
+      for (int i = 0; i < 36; i++) a.H[i] += parts[t].H[i];
+      for (int i = 0; i < 6; i++) a.g[i] += parts[t].g[i];
+      a.cost += parts[t].cost;
+    }
+    if (prior) prior_term(prior, T, a.H, a.g);
+    if (trace) {
+      memcpy(trace[it].H, a.H, sizeof(a.H));
+      memcpy(trace[it].g, a.g, sizeof(a.g));
+      trace[it].err_norm_sqr = a.cost;
+      memset(trace[it].delta, 0, sizeof(trace[it].delta));
+      memcpy(trace[it].T_after, T, sizeof(double) * 12);
+    }
+    if (sqrt(a.cost) <= p->max_cost) break; /* "target error" early exit (U8) */
+    double x[6], delta[6];
+    if (!ldlt_solve6(a.H, a.g, x)) { free(parts); return -1; }
+    for (int i = 0; i < 6; i++) delta[i] = -x[i];
+    double E[12];
+    orc_se3_exp(delta, E);
+    orc_pose_compose(T, E, T); /* T <- T (+) exp(delta) */
+    steps++;
+    if (trace) { memcpy(trace[it].delta, delta, sizeof(delta)); memcpy(trace[it].T_after, T, sizeof(double) * 12); }
+    double dn = 0;
+    for (int i = 0; i < 6; i++) dn += delta[i] * delta[i];
+    if (sqrt(dn) < p->min_delta) break;
+  }
+  free(parts);
+  return steps;
+}
+
+/* ======================================================================================
+ * Covariance -- mp2p_icp::covariance
+ * ==================================================================================== */
+static int chol_inverse6(const double A[36], double Ainv[36]) {
+  double L[36] = {0};
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = A[i * 6 + j];
+      for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+      if (i == j) {
+        if (!(s > 0.0)) return 0;
+        L[i * 6 + i] = sqrt(s);
+      } else
+        L[i * 6 + j] = s / L[j * 6 + j];
+    }
+  for (int c = 0; c < 6; c++) {
+    double y[6], x[6];
+    for (int i = 0; i < 6; i++) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k];
+      y[i] = s / L[i * 6 + i];
+    }
+    for (int i = 5; i >= 0; i--) {
+      double s = y[i];
+      for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k];
+      x[i] = s / L[i * 6 + i];
+    }
+    for (int i = 0; i < 6; i++) Ainv[i * 6 + c] = x[i];
+  }
+  return 1;
+}
+
+void orc_covariance(const orc_pairs_pt2pt* pp, const orc_pairs_pt2pl* pl, const double T[12], double findif_xyz,
+                    double findif_ang, double cov[36], double AtA_out[36]) {
+  const size_t np = pp ? pp->n : 0, nl = pl ? pl->n : 0;
+  memset(cov, 0, sizeof(double) * 36);
+  if (np + nl == 0) {
+    for (int i = 0; i < 6; i++) cov[i * 6 + i] = 1e6;
+    if (AtA_out) memset(AtA_out, 0, sizeof(double) * 36);
+    return;
+  }
+  double x0[6];
+  orc_pose_to_ypr(T, x0);
+  double Tp[6][12], Tm[6][12], hh[6];
+  for (int j = 0; j < 6; j++) {
+    hh[j] = (j < 3) ? findif_xyz : findif_ang;
+    double x[6];
+    memcpy(x, x0, sizeof(x)); x[j] += hh[j]; orc_pose_from_ypr(x, Tp[j]);
+    memcpy(x, x0, sizeof(x)); x[j] -= hh[j]; orc_pose_from_ypr(x, Tm[j]);
+  }
+  double AtA[36] = {0};
+  for (size_t i = 0; i < np; i++) {
+    const double l[3] = {pp->lx[i], pp->ly[i], pp->lz[i]};
+    double A[3][6];
+    for (int j = 0; j < 6; j++)
+      for (int r = 0; r < 3; r++) {
+        const double fp = R_(Tp[j], r, 0) * l[0] + R_(Tp[j], r, 1) * l[1] + R_(Tp[j], r, 2) * l[2] + t_(Tp[j], r);
+        const double fm = R_(Tm[j], r, 0) * l[0] + R_(Tm[j], r, 1) * l[1] + R_(Tm[j], r, 2) * l[2] + t_(Tm[j], r);
+        A[r][j] = (fp - fm) / (2.0 * hh[j]); /* the constant -q cancels */
+      }
+    for (int r = 0; r < 3; r++)
+      for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) AtA[a * 6 + b] += A[r][a] * A[r][b];
+  }
+  for (size_t i = 0; i < nl; i++) {
+    const double l[3] = {pl->lx[i], pl->ly[i], pl->lz[i]};
+    const double nrm[3] = {pl->nx[i], pl->ny[i], pl->nz[i]};
+    double A[6];
+    for (int j = 0; j < 6; j++) {
+      double d = 0;
+      for (int r = 0; r < 3; r++) {
+        const double fp = R_(Tp[j], r, 0) * l[0] + R_(Tp[j], r, 1) * l[1] + R_(Tp[j], r, 2) * l[2] + t_(Tp[j], r);
+        const double fm = R_(Tm[j], r, 0) * l[0] + R_(Tm[j], r, 1) * l[1] + R_(Tm[j], r, 2) * l[2] + t_(Tm[j], r);
+        d += nrm[r] * (fp - fm);
+      }
+      A[j] = d / (2.0 * hh[j]);
+    }
+    for (int a = 0; a < 6; a++)
+      for (int b = 0; b < 6; b++) AtA[a * 6 + b] += A[a] * A[b];
+  }
+  if (AtA_out) memcpy(AtA_out, AtA, sizeof(AtA));
+  if (!chol_inverse6(AtA, cov)) {
+    /* singular Hessian: no information in some direction -> report "unknown" like the
+     * empty-pairings case */
+    memset(cov, 0, sizeof(double) * 36);
+    for (int i = 0; i < 6; i++) cov[i * 6 + i] = 1e6;
+  }
+}
+
+/* ======================================================================================
+ * ICP::align -- SURVEY 3.3 / 8a row a5 (call site LidarOdometry.cpp:961-962)
+ * ==================================================================================== */
+int orc_icp_align(const orc_map* m, const float* lx, const float* ly, const float* lz, size_t n,
+                  const double T_guess[12], const orc_icp_params* p, const orc_prior* prior, orc_icp_result* res,
+                  orc_icp_iter* trace, orc_pairs_out* final_pairs, int n_threads) {
+  memset(res, 0, sizeof(*res));
+  double T[12], Tprev[12];
+  memcpy(T, T_guess, sizeof(T));
+  memcpy(Tprev, T, sizeof(T));
+
+  const size_t na = n ? n : 1;
+  uint32_t* li = (uint32_t*)malloc(na * sizeof(uint32_t));
+  uint32_t* gi = (uint32_t*)malloc(na * sizeof(uint32_t));
+  float* gx = (float*)malloc(na * sizeof(float));
+  float* gy = (float*)malloc(na * sizeof(float));
+  float* gz = (float*)malloc(na * sizeof(float));
+  float* d2 = (float*)malloc(na * sizeof(float));
+  float* plx = (float*)malloc(na * sizeof(float));
+  float* ply = (float*)malloc(na * sizeof(float));
+  float* plz = (float*)malloc(na * sizeof(float));
+  size_t npairs = 0;
+  uint64_t potential = 0;
+  res->termination_reason = ORC_TERM_UNDEFINED;
+
+  uint32_t it;
+  for (it = 0; it < p->max_iterations; it++) {
+    /* ICP_ITERATION = it -> threshold / kernel param formulas (yaml:190,198) pre-evaluated */
+    orc_match_stats st;
+    npairs = orc_match_points(m, lx, ly, lz, n, T, p->threshold[it], p->threshold_angular_deg, li, gi, gx, gy, gz, d2,
+                              &st, n_threads);
+    potential = st.potential_pairings;
+    res->n_candidates_total += st.n_candidates;
+    if (npairs == 0) { res->termination_reason = ORC_TERM_NO_PAIRINGS; break; }
+    for (size_t k = 0; k < npairs; k++) { plx[k] = lx[li[k]]; ply[k] = ly[li[k]]; plz[k] = lz[li[k]]; }
+    orc_pairs_pt2pt pp = {plx, ply, plz, gx, gy, gz, npairs};
+    orc_gn_params gp = p->gn;
+    gp.robust_kernel_param = p->kernel_param[it];
+    const int ok = orc_gn_solve(&pp, NULL, &gp, prior, T, NULL, n_threads);
+    if (ok < 0) { res->termination_reason = ORC_TERM_SOLVER_ERROR; break; }
+    /* stall test on log(T_prev^-1 (+) T_new) (yaml:174-175) */
+    double Pinv[12], D[12], d[6];
+    orc_pose_inverse(Tprev, Pinv);
+    orc_pose_compose(Pinv, T, D);
+    orc_se3_log(D, d);
+    const double dtr = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const double drot = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    if (trace) {
+      memcpy(trace[it].T, T, sizeof(T));
+      trace[it].n_pairs = (uint32_t)npairs;
+      trace[it].threshold = p->threshold[it];
+      trace[it].kernel_param = p->kernel_param[it];
+      trace[it].delta_trans = dtr;
+      trace[it].delta_rot = drot;
+    }
+    if (!p->disable_stall_test && dtr < p->min_abs_step_trans && drot < p->min_abs_step_rot) {
+      res->termination_reason = ORC_TERM_STALLED;
+      break;
+    }
+    if (p->hook_enabled) {
+      /* LidarOdometry.cpp:932-949 */
+      double Cinv[12], S[12], w[3];
+      orc_pose_inverse(p->hook_checkpoint, Cinv);
+      orc_pose_compose(Cinv, T, S);
+      orc_so3_log(S, w);
+      const double ht = sqrt(t_(S, 0) * t_(S, 0) + t_(S, 1) * t_(S, 1) + t_(S, 2) * t_(S, 2));
+      const double hr = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      if (ht > p->hook_min_trans || hr > p->hook_min_rot) { res->termination_reason = ORC_TERM_HOOK_REQUEST; break; }
+    }
+    memcpy(Tprev, T, sizeof(T));
+  }
+  res->n_iterations = it;
+  if (it >= p->max_iterations) res->termination_reason = ORC_TERM_MAX_ITERATIONS;
+
+  memcpy(res->T, T, sizeof(T));
+  res->n_final_pairs = (uint32_t)npairs;
+  res->potential_pairings = potential;
+  res->quality = (npairs && potential) ? (double)npairs / (double)potential : 0.0; /* PairedRatio */
+  if (p->compute_covariance) {
+    orc_pairs_pt2pt pp = {plx, ply, plz, gx, gy, gz, npairs};
+    orc_covariance(&pp, NULL, T, p->cov_findif_xyz, p->cov_findif_ang, res->cov, NULL);
+  }
+  if (final_pairs) {
+    for (size_t k = 0; k < npairs; k++) {
+      if (final_pairs->local_idx) final_pairs->local_idx[k] = li[k];
+      if (final_pairs->global_idx) final_pairs->global_idx[k] = gi[k];
+      if (final_pairs->gx) final_pairs->gx[k] = gx[k];
+      if (final_pairs->gy) final_pairs->gy[k] = gy[k];
+      if (final_pairs->gz) final_pairs->gz[k] = gz[k];
+      if (final_pairs->d2) final_pairs->d2[k] = d2[k];
+    }
+  }
+  free(li); free(gi); free(gx); free(gy); free(gz); free(d2); free(plx); free(ply); free(plz);
+  return 0;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,207 @@
+/* icp_oracle.h -- CPU restatement ("oracle") of the per-scan ICP registration hot path
+ * that mola::LidarOdometry drives through mp2p_icp::ICP::align().
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it -- as the checker / the timed CPU baseline, never as
+ * the thing shipped.  The product path (libmolahip.so) neither links nor calls anything here.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in third-party packages that are not
+ * vendored in /root/reference and are not pinned anywhere (mp2p_icp, mola_metric_maps, mrpt;
+ * SURVEY.md section 0 and 8c), the reference cannot be built in this image, and its only tests
+ * for the path are two end-to-end replays whose inputs are external.  This file therefore
+ * restates the published algorithm of those packages (mp2p_icp ~1.6.x, mola_metric_maps ~1.2.x,
+ * MRPT 2.13/2.14, Oct 2024) as specified in SURVEY.md section 8(a) + Appendix A, anchored on the
+ * in-tree call sites cited per function below.  It is cross-checked by an independent float64
+ * numpy restatement (oracle/icp_oracle_np.py) and by analytical known-answer tests.
+ * Every upstream behaviour that could not be verified is a run-time switch.
+ *
+ * All citations "file:line" are relative to /root/reference.
+ */
+#ifndef ICP_ORACLE_H
+#define ICP_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums (values shared with include/molahip.h by convention, not by #include) ---- */
+enum { ORC_INDEX_FLOOR = 0, ORC_INDEX_TRUNC = 1 };
+enum {
+  ORC_KERNEL_NONE = 0,
+  ORC_KERNEL_GM_C4 = 1,    /* w = c^4/(c^2+e^2)^2     (SURVEY App.B U1 (i), default) */
+  ORC_KERNEL_GM_KISS = 2,  /* w = c^2/(c+e^2)^2       (U1 (ii))                     */
+  ORC_KERNEL_GM_BARRON = 3,/* w = 1/(e^2/(4c^2)+1)^2  (U1 (iii))                    */
+  ORC_KERNEL_CAUCHY = 4,   /* w = c^2/(c^2+e^2)                                      */
+  ORC_KERNEL_GM_C2 = 5     /* w = c^2/(c^2+e^2)^2     (un-normalised GM)             */
+};
+/* mp2p_icp::IterTermReason (in-tree users: LidarOdometry.cpp:970,1007,1019) */
+enum {
+  ORC_TERM_UNDEFINED = 0,
+  ORC_TERM_NO_PAIRINGS = 1,
+  ORC_TERM_SOLVER_ERROR = 2,
+  ORC_TERM_MAX_ITERATIONS = 3,
+  ORC_TERM_STALLED = 4,
+  ORC_TERM_QUALITY_CHECKPOINT_FAILED = 5,
+  ORC_TERM_HOOK_REQUEST = 6
+};
+
+/* ---- SE(3) helpers (mrpt::poses::CPose3D / Lie::SE<3>) -------------
+ * A pose is T[12] = row-major 3x4 [R | t].  Tangent ordering [v(3); w(3)], translation first
+ * (LidarOdometry.cpp:977-984).  ypr is MRPT's TPose3D (x,y,z,yaw,pitch,roll), R = Rz*Ry*Rx
+ * (LidarOdometry.cpp:235; lidar3d-default.yaml:368). */
+void orc_pose_from_ypr(const double xyzypr[6], double T[12]);
+void orc_pose_to_ypr(const double T[12], double xyzypr[6]);
+void orc_pose_compose(const double A[12], const double B[12], double AB[12]); /* A (+) B */
+void orc_pose_inverse(const double A[12], double Ainv[12]);
+void orc_se3_exp(const double xi[6], double T[12]);
+void orc_se3_log(const double T[12], double xi[6]);
+void orc_so3_log(const double T[12], double w[3]);
+
+/* ---- local map: mola::HashedVoxelPointCloud (lidar3d-default.yaml:228-242) ------------ */
+typedef struct orc_map orc_map;
+typedef struct {
+  float voxel_size;              /* creationOpts.voxel_size            (yaml:233) */
+  uint32_t max_points_per_voxel; /* insertOpts.max_points_per_voxel    (yaml:235); 0 = no cap */
+  uint32_t index_mode;           /* ORC_INDEX_FLOOR (SURVEY App.A) | ORC_INDEX_TRUNC */
+} orc_map_params;
+
+orc_map* orc_map_create(const orc_map_params* p);
+void orc_map_destroy(orc_map* m);
+/* insertPoint for n points in order; a point whose voxel already holds the cap is dropped.
+ * Non-finite points are dropped.  The "global index" of a stored point is its position in the
+ * concatenation of everything ever offered to orc_map_insert (its source index). */
+void orc_map_insert(orc_map* m, const float* x, const float* y, const float* z, size_t n);
+size_t orc_map_num_points(const orc_map* m);
+size_t orc_map_num_voxels(const orc_map* m);
+void orc_map_bbox(const orc_map* m, float mn[3], float mx[3]);
+/* Dump the stored points voxel by voxel, voxels ordered by (kx,ky,kz) ascending, in-voxel
+ * insertion order.  Arrays must hold orc_map_num_points() / orc_map_num_voxels() entries.
+ * Any pointer may be NULL. */
+void orc_map_dump(const orc_map* m, float* x, float* y, float* z, uint32_t* src_idx,
+                  int32_t* vox_keys /*[3*V]*/, uint32_t* vox_first /*[V]*/, uint32_t* vox_count /*[V]*/);
+
+/* NearestNeighborsCapable::nn_single_search on the 3x3x3 voxel block around voxel(q)
+ * (SURVEY 8a row a8): x outer / y middle / z inner, in-voxel insertion order, strict '<' keeps
+ * the first minimum.  Returns 1 if something was found.  n_candidates (may be NULL) is
+ * incremented by the number of distance evaluations, n_voxels_hit by non-empty voxels visited. */
+int orc_map_nn_single(const orc_map* m, float qx, float qy, float qz, float out_pt[3], float* out_d2,
+                      uint32_t* out_src_idx, uint64_t* n_candidates, uint64_t* n_voxels_hit);
+
+/* ---- matcher: mp2p_icp::Matcher_Points_DistanceThreshold (yaml:195-204), pairingsPerPoint=1,
+ * allowMatchAlreadyMatchedGlobalPoints=true.  Local points are transformed p' = (float)(R*l+t)
+ * with double pose; accepted iff d^2 < thr^2 + ang^2 * |p'|^2 (strict).  Pairs are emitted in
+ * ascending local index.  Returns the number of pairs.  Output arrays sized n. */
+typedef struct {
+  uint64_t potential_pairings;
+  uint64_t n_candidates;  /* distance evaluations (for the P-bar of SURVEY 8d) */
+  uint64_t n_voxels_hit;
+} orc_match_stats;
+size_t orc_match_points(const orc_map* m, const float* lx, const float* ly, const float* lz, size_t n,
+                        const double T[12], double threshold, double threshold_angular_deg,
+                        uint32_t* local_idx, uint32_t* global_idx, float* gx, float* gy, float* gz,
+                        float* d2, orc_match_stats* stats, int n_threads);
+
+/* ---- solver: mp2p_icp::Solver_GaussNewton / optimal_tf_gauss_newton (yaml:184-190) ------ */
+typedef struct {
+  const float *lx, *ly, *lz; /* local point, untransformed */
+  const float *gx, *gy, *gz; /* global point */
+  size_t n;
+} orc_pairs_pt2pt;
+typedef struct {
+  const float *lx, *ly, *lz;    /* local point */
+  const float *cx, *cy, *cz;    /* plane centroid */
+  const float *nx, *ny, *nz;    /* unit normal */
+  size_t n;
+} orc_pairs_pt2pl;
+typedef struct {
+  double mean[12]; /* T_prior */
+  double info[36]; /* 6x6 information, [v;w] ordering (LidarOdometry.cpp:859-875) */
+} orc_prior;
+typedef struct {
+  uint32_t max_inner_iterations; /* Solver_GaussNewton.maxIterations (yaml:187) */
+  uint32_t robust_kernel;        /* ORC_KERNEL_* (yaml:188) */
+  double robust_kernel_param;    /* c (yaml:190) */
+  double min_delta;              /* 1e-7 (U8) */
+  double max_cost;               /* 0 (U8) */
+  double weight_pt2pt, weight_pt2pl; /* pair weights, 1.0 */
+} orc_gn_params;
+/* Optional trace of each inner step: H (6x6 row-major), g (6), cost, delta (6). */
+typedef struct {
+  double H[36];
+  double g[6];
+  double err_norm_sqr;
+  double delta[6];
+  double T_after[12];
+} orc_gn_step;
+/* Returns the number of inner steps executed (solves done).  T_io: linearisation point in,
+ * solution out. */
+int orc_gn_solve(const orc_pairs_pt2pt* pp, const orc_pairs_pt2pl* pl, const orc_gn_params* p,
+                 const orc_prior* prior /*nullable*/, double T_io[12], orc_gn_step* trace /*nullable,
+                 [max_inner_iterations]*/, int n_threads);
+
+/* mp2p_icp::covariance: numeric Jacobian (central differences) of the stacked
+ * residual vector w.r.t. (x,y,z,yaw,pitch,roll); cov = (A^T A)^-1.  No pairings: diag(1e6). */
+void orc_covariance(const orc_pairs_pt2pt* pp, const orc_pairs_pt2pl* pl, const double T[12],
+                    double findif_xyz, double findif_ang, double cov[36], double AtA[36] /*nullable*/);
+
+/* ---- ICP::align (called at LidarOdometry.cpp:961-962) -------------- */
+typedef struct {
+  uint32_t max_iterations;     /* yaml:173 */
+  double min_abs_step_trans;   /* yaml:174 */
+  double min_abs_step_rot;     /* yaml:175 */
+  uint32_t disable_stall_test; /* C2 of SURVEY 8d runs exactly max_iterations */
+  /* matcher */
+  const double* threshold;     /* [max_iterations] value of the yaml:198 formula per ICP_ITERATION */
+  double threshold_angular_deg;/* yaml:200 */
+  /* solver */
+  const double* kernel_param;  /* [max_iterations] value of the yaml:190 formula */
+  orc_gn_params gn;            /* robust_kernel_param ignored (taken from kernel_param[k]) */
+  /* iteration hook emulation (LidarOdometry.cpp:923-952): stop when the pose moved more than
+   * hook_min_trans / hook_min_rot (rad) away from hook_checkpoint. */
+  uint32_t hook_enabled;
+  double hook_min_trans, hook_min_rot;
+  double hook_checkpoint[12];
+  /* covariance */
+  uint32_t compute_covariance;
+  double cov_findif_xyz, cov_findif_ang;
+} orc_icp_params;
+
+typedef struct {
+  double T[12];
+  uint32_t n_pairs;
+  double threshold, kernel_param;
+  double delta_trans, delta_rot;
+} orc_icp_iter;
+
+typedef struct {
+  double T[12];
+  double cov[36];
+  double quality;
+  uint32_t n_iterations;
+  uint32_t termination_reason;
+  uint32_t n_final_pairs;
+  uint64_t potential_pairings;
+  uint64_t n_candidates_total; /* sum over iterations, for P-bar */
+} orc_icp_result;
+
+/* final pairings (optional): arrays sized n_local */
+typedef struct {
+  uint32_t* local_idx;
+  uint32_t* global_idx;
+  float *gx, *gy, *gz, *d2;
+} orc_pairs_out;
+
+int orc_icp_align(const orc_map* m, const float* lx, const float* ly, const float* lz, size_t n,
+                  const double T_guess[12], const orc_icp_params* p, const orc_prior* prior,
+                  orc_icp_result* res, orc_icp_iter* trace /*nullable [max_iterations]*/,
+                  orc_pairs_out* final_pairs /*nullable*/, int n_threads);
+
+int orc_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
