@@ -1,0 +1,305 @@
+/* molahip.h -- C ABI of libmolahip: the MI355X-native (gfx950 / HIP) implementation of the per-scan
+ * ICP registration hot path that mola::LidarOdometry runs through mp2p_icp::ICP::align().
+ *
+ * This is the drop-in boundary.  No C++ or torch types cross it: opaque handles,
+ * plain pointers + sizes, POD structs, integer status codes.  Every entry point names the reference
+ * interface it stands in for ("file:line" is relative to /root/reference; [U] marks upstream classes
+ * that the reference selects by name from its YAML but does not vendor -- SURVEY.md 0.1).
+ * The C++ host layer (mola_lidar_odometry_amd/host/, namespace mp2p_icp_hip) and the mp2p_icp
+ * plugin adapter are thin wrappers over exactly these functions.
+ *
+ * Conventions
+ *  - Poses are `double T[12]`: row-major 3x4 [R|t] of "local wrt global" (the 3rd argument of
+ *    ICP::align, LidarOdometry.cpp:961-962; mrpt::poses::CPose3D).
+ *  - Tangent vectors / 6x6 matrices use [v(3); w(3)] ordering (LidarOdometry.cpp:977-984); the
+ *    covariance is in (x,y,z,yaw,pitch,roll) like mrpt::poses::CPose3DPDFGaussian.
+ *  - Point clouds are SoA float arrays (mrpt CPointsMap::getPointsBufferRef_{x,y,z} [U]).
+ *  - `mem` arguments say where the caller's arrays live: MH_MEM_HOST (borrowed for the call, copied)
+ *    or MH_MEM_DEVICE (HIP device pointers on the context's device, read in place).
+ *  - Every function returns mh_status (0 = OK), never throws, never aborts; a message for the last
+ *    failure on the calling thread is available from mh_last_error_string().
+ *  - One context = one HIP device + one stream.  Contexts are independent and may be driven from
+ *    different host threads; a single context (and the maps/scans created from it) must not be used
+ *    from two threads at once -- the reference itself keeps one align() in flight per LidarOdometry
+ *    instance (LidarOdometry.h:548-549, LidarOdometry.cpp:634).
+ *  - There is NO CPU fallback: without a HIP device mh_ctx_create fails with MH_ERR_NO_DEVICE.
+ */
+#ifndef MOLAHIP_H
+#define MOLAHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_API __attribute__((visibility("default")))
+
+#define MH_VERSION_MAJOR 0
+#define MH_VERSION_MINOR 1
+#define MH_VERSION_PATCH 0
+
+typedef int32_t mh_status;
+enum {
+  MH_OK = 0,
+  MH_ERR_INVALID_ARGUMENT = 1,
+  MH_ERR_HIP = 2,            /* a HIP runtime call failed; see mh_last_error_string() */
+  MH_ERR_OUT_OF_MEMORY = 3,
+  MH_ERR_OUT_OF_RANGE = 4,   /* a voxel index does not fit the 21-bit-per-axis key */
+  MH_ERR_NO_DEVICE = 5,
+  MH_ERR_UNSUPPORTED = 6,
+  MH_ERR_INTERNAL = 7
+};
+
+enum { MH_MEM_HOST = 0, MH_MEM_DEVICE = 1 };
+
+/* coordinate -> voxel index rule (FLOOR is the default) */
+enum { MH_INDEX_FLOOR = 0, MH_INDEX_TRUNC = 1 };
+
+/* mp2p_icp::RobustKernel [U] as selected at lidar3d-default.yaml:188.  The exact upstream form of
+ * GemanMcClure is unverified (SURVEY App.B U1), hence the variants. */
+enum {
+  MH_KERNEL_NONE = 0,
+  MH_KERNEL_GM_C4 = 1,     /* w = c^4/(c^2+e^2)^2  (default) */
+  MH_KERNEL_GM_KISS = 2,   /* w = c^2/(c+e^2)^2 */
+  MH_KERNEL_GM_BARRON = 3, /* w = 1/(e^2/(4c^2)+1)^2 */
+  MH_KERNEL_CAUCHY = 4,    /* w = c^2/(c^2+e^2) */
+  MH_KERNEL_GM_C2 = 5      /* w = c^2/(c^2+e^2)^2 */
+};
+
+/* mp2p_icp::IterTermReason [U] (used in-tree at LidarOdometry.cpp:970,1007,1019) */
+enum {
+  MH_TERM_UNDEFINED = 0,
+  MH_TERM_NO_PAIRINGS = 1,
+  MH_TERM_SOLVER_ERROR = 2,
+  MH_TERM_MAX_ITERATIONS = 3,
+  MH_TERM_STALLED = 4,
+  MH_TERM_QUALITY_CHECKPOINT_FAILED = 5,
+  MH_TERM_HOOK_REQUEST = 6
+};
+
+typedef struct mh_ctx mh_ctx;
+typedef struct mh_map mh_map;
+typedef struct mh_scan mh_scan;
+
+/* ------------------------------------------------------------------------------------------------
+ * Library / context
+ * ---------------------------------------------------------------------------------------------- */
+MH_API mh_status mh_version(uint32_t* major, uint32_t* minor, uint32_t* patch);
+MH_API const char* mh_last_error_string(void);
+MH_API const char* mh_status_string(mh_status s);
+MH_API mh_status mh_device_count(int32_t* n);
+
+/* `hip_stream`: a hipStream_t to run on (e.g. the caller's torch stream), or NULL to let the context
+ * create and own a non-blocking stream. */
+MH_API mh_status mh_ctx_create(int32_t device, void* hip_stream, mh_ctx** out);
+MH_API mh_status mh_ctx_destroy(mh_ctx* ctx);
+MH_API mh_status mh_ctx_synchronize(mh_ctx* ctx);
+MH_API mh_status mh_ctx_stream(mh_ctx* ctx, void** hip_stream_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Local map: the NN-search target.  Replaces mola::HashedVoxelPointCloud [U] as configured at
+ * lidar3d-default.yaml:228-242 (creationOpts.voxel_size :233, insertOpts.max_points_per_voxel :235)
+ * in its role as mrpt::maps::NearestNeighborsCapable [U] for the matcher.
+ * Device layout: open-addressing hash table of 16-byte slots {packed voxel key, first, count} plus
+ * voxel-contiguous 16-byte point records {x,y,z,source index}; see DESIGN.md.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  float voxel_size;              /* [m] > 0 */
+  uint32_t max_points_per_voxel; /* 0 = unlimited */
+  uint32_t index_mode;           /* MH_INDEX_* */
+  uint32_t reserved;
+} mh_map_params;
+
+typedef struct {
+  uint64_t n_points;   /* stored points (after the per-voxel cap) */
+  uint64_t n_offered;  /* points offered to the last build */
+  uint64_t n_voxels;   /* occupied voxels */
+  uint64_t table_size; /* hash slots (power of two) */
+  float bbox_min[3], bbox_max[3];
+  float voxel_size;
+  uint32_t max_points_per_voxel;
+} mh_map_info;
+
+MH_API mh_status mh_map_create(mh_ctx* ctx, const mh_map_params* params, mh_map** out);
+MH_API mh_status mh_map_destroy(mh_map* map);
+/* (Re)build from n points: equivalent to clear() + insertPoint() for each point in order
+ * (HashedVoxelPointCloud::insertPoint [U] via FilterMerge, lidar3d-default.yaml:362-368): a point whose
+ * voxel already holds max_points_per_voxel is dropped; non-finite points are dropped.  The "global
+ * index" reported by the NN search is the point's index in these arrays. */
+MH_API mh_status mh_map_build(mh_map* map, const float* x, const float* y, const float* z, size_t n, int32_t mem);
+MH_API mh_status mh_map_get_info(const mh_map* map, mh_map_info* info);
+/* Copy the stored content to HOST arrays (any may be NULL): points voxel by voxel, voxels in ascending
+ * (kx,ky,kz), in-voxel insertion order.  xyz/src_idx hold n_points entries, vox_* hold n_voxels. */
+MH_API mh_status mh_map_download(const mh_map* map, float* x, float* y, float* z, uint32_t* src_idx,
+                                 int32_t* vox_keys_xyz, uint32_t* vox_first, uint32_t* vox_count);
+
+/* ------------------------------------------------------------------------------------------------
+ * Scan: the local point layer handed to align() ("decimated_for_icp", lidar3d-default.yaml:204),
+ * untransformed, in the vehicle frame.
+ * ---------------------------------------------------------------------------------------------- */
+MH_API mh_status mh_scan_create(mh_ctx* ctx, const float* x, const float* y, const float* z, size_t n, int32_t mem,
+                                mh_scan** out);
+/* Replace the points (e.g. after the caller re-ran its de-skew, LidarOdometry.cpp:992-999). */
+MH_API mh_status mh_scan_update(mh_scan* scan, const float* x, const float* y, const float* z, size_t n, int32_t mem);
+MH_API mh_status mh_scan_destroy(mh_scan* scan);
+MH_API mh_status mh_scan_size(const mh_scan* scan, uint64_t* n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Matcher-granular path.  Replaces mp2p_icp::Matcher_Points_DistanceThreshold::implMatchOneLayer [U]
+ * (lidar3d-default.yaml:195-204; pairingsPerPoint 1, allowMatchAlreadyMatchedGlobalPoints true) on
+ * top of NearestNeighborsCapable::nn_single_search [U]: p' = (float)(R*l+t); NN over the 3x3x3 voxel
+ * block around voxel(p'); accepted iff d^2 < thr^2 + ang^2*|p'|^2.  Output = mp2p_icp::Pairings::
+ * paired_pt2pt [U] as SoA, compacted in ascending local index.  Output arrays hold scan-size entries,
+ * live in `mem`, and any of them may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t* local_idx;
+  uint32_t* global_idx;
+  float* gx;
+  float* gy;
+  float* gz;
+  float* d2; /* errorSquareAfterTransformation */
+} mh_pairs_out;
+
+typedef struct {
+  uint64_t n_pairs;
+  uint64_t potential_pairings; /* Pairings::potential_pairings [U] = scan size * pairingsPerPoint */
+} mh_match_info;
+
+MH_API mh_status mh_nn_search(const mh_map* map, const mh_scan* scan, const double T[12], double threshold,
+                              double threshold_angular_deg, const mh_pairs_out* out, int32_t mem,
+                              mh_match_info* info);
+/* Un-compacted variant: one entry per scan point; global_idx = 0xFFFFFFFF where nothing was found in
+ * the 27-voxel block (no threshold applied).  Arrays hold scan-size entries; any may be NULL. */
+MH_API mh_status mh_nn_search_dense(const mh_map* map, const mh_scan* scan, const double T[12], uint32_t* global_idx,
+                                    float* gx, float* gy, float* gz, float* d2, int32_t mem);
+
+/* ------------------------------------------------------------------------------------------------
+ * Solver-granular path.  Replaces mp2p_icp::Solver_GaussNewton::impl_optimal_pose /
+ * optimal_tf_gauss_newton [U] (lidar3d-default.yaml:184-190): robust-weighted point-to-point (3-row)
+ * and point-to-plane (1-row) terms, optional prior factor (LidarOdometry.cpp:859-875), 6x6 LDL^T,
+ * T <- T (+) exp(delta), repeated max_inner_iterations times on the same pairings.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *lx, *ly, *lz; /* local (untransformed) */
+  const float *gx, *gy, *gz; /* global */
+  size_t n;
+} mh_pairs_pt2pt;
+
+typedef struct {
+  const float *lx, *ly, *lz; /* local point */
+  const float *cx, *cy, *cz; /* plane centroid */
+  const float *nx, *ny, *nz; /* plane unit normal */
+  size_t n;
+} mh_pairs_pt2pl;
+
+typedef struct {
+  double mean[12]; /* prior pose (CPose3DPDFGaussianInf::mean) */
+  double info[36]; /* 6x6 information matrix, row-major (cov_inv) */
+} mh_prior;
+
+typedef struct {
+  uint32_t max_inner_iterations; /* Solver_GaussNewton maxIterations (yaml:187) */
+  uint32_t robust_kernel;        /* MH_KERNEL_* (yaml:188) */
+  double robust_kernel_param;    /* yaml:190 */
+  double min_delta;              /* inner early exit, 1e-7 */
+  double max_cost;               /* "target error" early exit, 0 */
+  double weight_pt2pt;           /* 1.0 */
+  double weight_pt2pl;           /* 1.0 */
+} mh_gn_params;
+
+typedef struct {
+  double H[36];
+  double g[6];
+  double err_norm_sqr;
+  double delta[6];
+  double T_after[12];
+} mh_gn_step;
+
+/* T_io: linearisation point in (SolverContext::guessRelativePose [U]), solution out.
+ * `n_steps` receives the number of solves performed; `trace` (nullable) holds max_inner_iterations
+ * entries.  Returns MH_OK with *solver_ok = 0 when the 6x6 solve produced non-finite values. */
+MH_API mh_status mh_gn_solve(mh_ctx* ctx, const mh_pairs_pt2pt* pt2pt, const mh_pairs_pt2pl* pt2pl, int32_t mem,
+                             const mh_gn_params* params, const mh_prior* prior, double T_io[12], int32_t* n_steps,
+                             int32_t* solver_ok, mh_gn_step* trace);
+
+/* Replaces mp2p_icp::covariance() [U] (result consumed at LidarOdometry.cpp:1009,1035-1036,2090):
+ * central-difference Jacobian of the stacked residuals wrt (x,y,z,yaw,pitch,roll), cov = (A^T A)^-1;
+ * diag(1e6) when there are no pairings or A^T A is singular. */
+MH_API mh_status mh_covariance(mh_ctx* ctx, const mh_pairs_pt2pt* pt2pt, const mh_pairs_pt2pl* pt2pl, int32_t mem,
+                               const double T[12], double findif_xyz, double findif_ang, double cov[36]);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused path.  Replaces mp2p_icp::ICP::align [U] as called at LidarOdometry.cpp:961-962 with the
+ * pipeline of lidar3d-default.yaml:162-209 (one Matcher_Points_DistanceThreshold, one
+ * Solver_GaussNewton, QualityEvaluator_PairedRatio).  The whole loop -- match, accumulate, 6x6 solve,
+ * stall test, hook test, quality, covariance -- runs on the device; the host only enqueues kernels and
+ * polls a termination flag every `poll_every` iterations.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t max_iterations;      /* mp2p_icp::Parameters::maxIterations (yaml:173) */
+  double min_abs_step_trans;    /* yaml:174 */
+  double min_abs_step_rot;      /* yaml:175 */
+  uint32_t disable_stall_test;  /* 1: run exactly max_iterations (BASELINE configs[1]) */
+  /* Per-iteration values of the run-time formulas of yaml:198 (matcher threshold) and yaml:190
+   * (robust kernel parameter), indexed by ICP_ITERATION; HOST arrays of max_iterations entries. */
+  const double* threshold;
+  const double* kernel_param;
+  double threshold_angular_deg; /* yaml:200 */
+  mh_gn_params gn;              /* robust_kernel_param ignored (kernel_param[k] is used) */
+  /* Device-side equivalent of the in-tree iteration hook (LidarOdometry.cpp:923-952): request a stop
+   * when the pose has moved more than hook_min_trans [m] or hook_min_rot [rad] from hook_checkpoint. */
+  uint32_t hook_enabled;
+  double hook_min_trans;
+  double hook_min_rot;
+  double hook_checkpoint[12];
+  uint32_t compute_covariance;
+  double cov_findif_xyz;        /* 1e-7 */
+  double cov_findif_ang;        /* 1e-7 */
+  uint32_t poll_every;          /* ICP iterations enqueued between host polls of the done flag; 0 = default */
+  uint32_t profile;             /* 1: time every match kernel with HIP events on the context stream */
+} mh_icp_params;
+
+typedef struct {
+  double T[12];
+  uint32_t n_pairs;
+  double threshold;
+  double kernel_param;
+  double delta_trans; /* |log(T_prev^-1 T_new)| translation part */
+  double delta_rot;
+} mh_icp_iter;
+
+typedef struct {
+  double T[12];                /* Results::optimal_tf.mean */
+  double cov[36];              /* Results::optimal_tf.cov (x,y,z,yaw,pitch,roll) */
+  double quality;              /* Results::quality (PairedRatio) */
+  uint32_t n_iterations;       /* Results::nIterations */
+  uint32_t termination_reason; /* Results::terminationReason, MH_TERM_* */
+  uint32_t n_final_pairs;
+  uint64_t potential_pairings;
+  /* profile == 1 only: */
+  uint32_t n_match_launches;
+  double match_kernel_ms;      /* sum of the match kernel durations */
+  double total_ms;             /* stream time of the whole align */
+} mh_icp_result;
+
+/* `trace` (nullable, HOST, max_iterations entries) receives one record per executed iteration;
+ * `final_pairs` (nullable, arrays in `pairs_mem`, scan-size entries) receives Results::finalPairings. */
+MH_API mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_icp_params* params,
+                              const double T_guess[12], const mh_prior* prior, mh_icp_result* result,
+                              mh_icp_iter* trace, const mh_pairs_out* final_pairs, int32_t pairs_mem);
+
+/* Many independent alignments, one per context/stream, interleaved from one host thread so that the
+ * kernels of different scans overlap on the device (one-scan-per-stream sharding).  Job i uses
+ * maps[i], scans[i] (which must belong to distinct contexts for overlap), guesses + 12*i, priors[i]
+ * (array or entries may be NULL), and writes results[i]. */
+MH_API mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_scan* const* scans,
+                                    const mh_icp_params* params, const double* T_guesses,
+                                    const mh_prior* const* priors, mh_icp_result* results);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOLAHIP_H */

@@ -1,0 +1,499 @@
+"""ctypes binding of libmolahip.so -- the C ABI declared in include/molahip.h.
+
+This is plumbing for tests and bench.py: every call goes straight through the C ABI, i.e. through
+exactly the entry points an mp2p_icp plugin adapter would bind.  There is no
+Python or CPU fallback: if the shared library is missing or no HIP device is present the calls
+raise (MolahipError / OSError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmolahip.so")
+
+MH_OK = 0
+MEM_HOST, MEM_DEVICE = 0, 1
+INDEX_FLOOR, INDEX_TRUNC = 0, 1
+KERNEL_NONE, KERNEL_GM_C4, KERNEL_GM_KISS, KERNEL_GM_BARRON, KERNEL_CAUCHY, KERNEL_GM_C2 = range(6)
+TERM_NAMES = ["Undefined", "NoPairings", "SolverError", "MaxIterations", "Stalled",
+              "QualityCheckpointFailed", "HookRequest"]
+NO_MATCH = 0xFFFFFFFF
+
+_FP = C.POINTER(C.c_float)
+_UP = C.POINTER(C.c_uint32)
+_DP = C.POINTER(C.c_double)
+
+
+class MolahipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"libmolahip status {status}: {msg}")
+        self.status = status
+
+
+class MapParams(C.Structure):
+    _fields_ = [("voxel_size", C.c_float), ("max_points_per_voxel", C.c_uint32), ("index_mode", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class MapInfo(C.Structure):
+    _fields_ = [("n_points", C.c_uint64), ("n_offered", C.c_uint64), ("n_voxels", C.c_uint64),
+                ("table_size", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
+                ("voxel_size", C.c_float), ("max_points_per_voxel", C.c_uint32)]
+
+
+class PairsOut(C.Structure):
+    _fields_ = [("local_idx", _UP), ("global_idx", _UP), ("gx", _FP), ("gy", _FP), ("gz", _FP), ("d2", _FP)]
+
+
+class MatchInfo(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("potential_pairings", C.c_uint64)]
+
+
+class PairsPt2Pt(C.Structure):
+    _fields_ = [("lx", _FP), ("ly", _FP), ("lz", _FP), ("gx", _FP), ("gy", _FP), ("gz", _FP), ("n", C.c_size_t)]
+
+
+class PairsPt2Pl(C.Structure):
+    _fields_ = [("lx", _FP), ("ly", _FP), ("lz", _FP), ("cx", _FP), ("cy", _FP), ("cz", _FP),
+                ("nx", _FP), ("ny", _FP), ("nz", _FP), ("n", C.c_size_t)]
+
+
+class Prior(C.Structure):
+    _fields_ = [("mean", C.c_double * 12), ("info", C.c_double * 36)]
+
+
+class GNParamsC(C.Structure):
+    _fields_ = [("max_inner_iterations", C.c_uint32), ("robust_kernel", C.c_uint32),
+                ("robust_kernel_param", C.c_double), ("min_delta", C.c_double), ("max_cost", C.c_double),
+                ("weight_pt2pt", C.c_double), ("weight_pt2pl", C.c_double)]
+
+
+class GNStep(C.Structure):
+    _fields_ = [("H", C.c_double * 36), ("g", C.c_double * 6), ("err_norm_sqr", C.c_double),
+                ("delta", C.c_double * 6), ("T_after", C.c_double * 12)]
+
+
+class ICPParamsC(C.Structure):
+    _fields_ = [("max_iterations", C.c_uint32), ("min_abs_step_trans", C.c_double), ("min_abs_step_rot", C.c_double),
+                ("disable_stall_test", C.c_uint32), ("threshold", _DP), ("kernel_param", _DP),
+                ("threshold_angular_deg", C.c_double), ("gn", GNParamsC), ("hook_enabled", C.c_uint32),
+                ("hook_min_trans", C.c_double), ("hook_min_rot", C.c_double), ("hook_checkpoint", C.c_double * 12),
+                ("compute_covariance", C.c_uint32), ("cov_findif_xyz", C.c_double), ("cov_findif_ang", C.c_double),
+                ("poll_every", C.c_uint32), ("profile", C.c_uint32)]
+
+
+class ICPIter(C.Structure):
+    _fields_ = [("T", C.c_double * 12), ("n_pairs", C.c_uint32), ("threshold", C.c_double),
+                ("kernel_param", C.c_double), ("delta_trans", C.c_double), ("delta_rot", C.c_double)]
+
+
+class ICPResult(C.Structure):
+    _fields_ = [("T", C.c_double * 12), ("cov", C.c_double * 36), ("quality", C.c_double),
+                ("n_iterations", C.c_uint32), ("termination_reason", C.c_uint32), ("n_final_pairs", C.c_uint32),
+                ("potential_pairings", C.c_uint64), ("n_match_launches", C.c_uint32),
+                ("match_kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+# every entry point include/molahip.h declares, with its ctypes signature
+_SIGNATURES = {
+    "mh_version": (C.c_int32, [_UP, _UP, _UP]),
+    "mh_last_error_string": (C.c_char_p, []),
+    "mh_status_string": (C.c_char_p, [C.c_int32]),
+    "mh_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
+    "mh_ctx_create": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mh_ctx_destroy": (C.c_int32, [C.c_void_p]),
+    "mh_ctx_synchronize": (C.c_int32, [C.c_void_p]),
+    "mh_ctx_stream": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mh_map_create": (C.c_int32, [C.c_void_p, C.POINTER(MapParams), C.POINTER(C.c_void_p)]),
+    "mh_map_destroy": (C.c_int32, [C.c_void_p]),
+    "mh_map_build": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
+    "mh_map_get_info": (C.c_int32, [C.c_void_p, C.POINTER(MapInfo)]),
+    "mh_map_download": (C.c_int32, [C.c_void_p, _FP, _FP, _FP, _UP, C.POINTER(C.c_int32), _UP, _UP]),
+    "mh_scan_create": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32,
+                                   C.POINTER(C.c_void_p)]),
+    "mh_scan_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
+    "mh_scan_destroy": (C.c_int32, [C.c_void_p]),
+    "mh_scan_size": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mh_nn_search": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_double, C.c_double, C.POINTER(PairsOut), C.c_int32,
+                                 C.POINTER(MatchInfo)]),
+    "mh_nn_search_dense": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int32]),
+    "mh_gn_solve": (C.c_int32, [C.c_void_p, C.POINTER(PairsPt2Pt), C.POINTER(PairsPt2Pl), C.c_int32,
+                                C.POINTER(GNParamsC), C.POINTER(Prior), _DP, C.POINTER(C.c_int32),
+                                C.POINTER(C.c_int32), C.POINTER(GNStep)]),
+    "mh_covariance": (C.c_int32, [C.c_void_p, C.POINTER(PairsPt2Pt), C.POINTER(PairsPt2Pl), C.c_int32, _DP, C.c_double,
+                                  C.c_double, _DP]),
+    "mh_icp_align": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(ICPParamsC), _DP, C.POINTER(Prior),
+                                 C.POINTER(ICPResult), C.POINTER(ICPIter), C.POINTER(PairsOut), C.c_int32]),
+    "mh_icp_align_batch": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(ICPParamsC),
+                                       _DP, C.POINTER(C.POINTER(Prior)), C.POINTER(ICPResult)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libmolahip.so (built by __graft_entry__.build() / csrc/Makefile).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _chk(status):
+    if status != MH_OK:
+        raise MolahipError(status, lib().mh_last_error_string().decode(errors="replace"))
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    st = lib().mh_device_count(C.byref(n))
+    return int(n.value) if st == MH_OK else 0
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _soa(xyz):
+    xyz = np.asarray(xyz, dtype=np.float32).reshape(-1, 3)
+    return _f32(xyz[:, 0]), _f32(xyz[:, 1]), _f32(xyz[:, 2])
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _T12(T):
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    if T.size == 16:
+        T = T.reshape(4, 4)[:3]
+    return np.ascontiguousarray(T.reshape(12))
+
+
+class Context:
+    """One HIP device + one stream (mh_ctx)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p()
+        _chk(lib().mh_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = device
+
+    def synchronize(self):
+        _chk(lib().mh_ctx_synchronize(self._h))
+
+    @property
+    def stream(self) -> int:
+        s = C.c_void_p()
+        _chk(lib().mh_ctx_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def close(self):
+        if self._h:
+            lib().mh_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Map:
+    """Device-resident voxel-hashed local map (stands in for mola::HashedVoxelPointCloud)."""
+
+    def __init__(self, ctx: Context, voxel_size=1.0, max_points_per_voxel=20, index_mode=INDEX_FLOOR):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        p = MapParams(voxel_size, max_points_per_voxel, index_mode, 0)
+        _chk(lib().mh_map_create(ctx._h, C.byref(p), C.byref(self._h)))
+
+    def build(self, xyz):
+        x, y, z = _soa(xyz)
+        _chk(lib().mh_map_build(self._h, _vp(x), _vp(y), _vp(z), len(x), MEM_HOST))
+        return self
+
+    def build_device(self, x_ptr, y_ptr, z_ptr, n):
+        _chk(lib().mh_map_build(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(z_ptr), n, MEM_DEVICE))
+        return self
+
+    def info(self) -> MapInfo:
+        i = MapInfo()
+        _chk(lib().mh_map_get_info(self._h, C.byref(i)))
+        return i
+
+    def download(self):
+        i = self.info()
+        n, v = int(i.n_points), int(i.n_voxels)
+        x, y, z = (np.zeros(max(n, 1), np.float32) for _ in range(3))
+        src = np.zeros(max(n, 1), np.uint32)
+        keys = np.zeros((max(v, 1), 3), np.int32)
+        first, count = np.zeros(max(v, 1), np.uint32), np.zeros(max(v, 1), np.uint32)
+        _chk(lib().mh_map_download(self._h, x.ctypes.data_as(_FP), y.ctypes.data_as(_FP), z.ctypes.data_as(_FP),
+                                   src.ctypes.data_as(_UP), keys.ctypes.data_as(C.POINTER(C.c_int32)),
+                                   first.ctypes.data_as(_UP), count.ctypes.data_as(_UP)))
+        return dict(xyz=np.stack([x[:n], y[:n], z[:n]], 1), src_idx=src[:n], vox_keys=keys[:v], vox_first=first[:v],
+                    vox_count=count[:v])
+
+    def close(self):
+        if self._h:
+            lib().mh_map_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scan:
+    """Device-resident local point layer (the `decimated_for_icp` layer handed to align())."""
+
+    def __init__(self, ctx: Context, xyz=None, device_ptrs=None, n=None):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        if device_ptrs is not None:
+            px, py, pz = device_ptrs
+            _chk(lib().mh_scan_create(ctx._h, C.c_void_p(px), C.c_void_p(py), C.c_void_p(pz), n, MEM_DEVICE,
+                                      C.byref(self._h)))
+            self.n = n
+        else:
+            x, y, z = _soa(xyz)
+            _chk(lib().mh_scan_create(ctx._h, _vp(x), _vp(y), _vp(z), len(x), MEM_HOST, C.byref(self._h)))
+            self.n = len(x)
+
+    @classmethod
+    def from_torch(cls, ctx: Context, x, y, z):
+        """x,y,z: contiguous float32 torch tensors on ctx's device (read in place, then copied)."""
+        import torch  # plumbing only
+        for t in (x, y, z):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        torch.cuda.current_stream(x.device).synchronize()
+        return cls(ctx, device_ptrs=(x.data_ptr(), y.data_ptr(), z.data_ptr()), n=x.numel())
+
+    def update(self, xyz):
+        x, y, z = _soa(xyz)
+        _chk(lib().mh_scan_update(self._h, _vp(x), _vp(y), _vp(z), len(x), MEM_HOST))
+        self.n = len(x)
+
+    def __len__(self):
+        n = C.c_uint64()
+        _chk(lib().mh_scan_size(self._h, C.byref(n)))
+        return int(n.value)
+
+    def close(self):
+        if self._h:
+            lib().mh_scan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def nn_search(m: Map, s: Scan, T, threshold, threshold_angular_deg=0.0):
+    n = max(s.n, 1)
+    li, gi = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    gx, gy, gz, d2 = (np.zeros(n, np.float32) for _ in range(4))
+    out = PairsOut(li.ctypes.data_as(_UP), gi.ctypes.data_as(_UP), gx.ctypes.data_as(_FP), gy.ctypes.data_as(_FP),
+                   gz.ctypes.data_as(_FP), d2.ctypes.data_as(_FP))
+    info = MatchInfo()
+    T = _T12(T)
+    _chk(lib().mh_nn_search(m._h, s._h, T.ctypes.data_as(_DP), float(threshold), float(threshold_angular_deg),
+                            C.byref(out), MEM_HOST, C.byref(info)))
+    k = int(info.n_pairs)
+    return dict(local_idx=li[:k].copy(), global_idx=gi[:k].copy(), global_xyz=np.stack([gx[:k], gy[:k], gz[:k]], 1),
+                d2=d2[:k].copy(), potential_pairings=int(info.potential_pairings))
+
+
+def nn_search_dense(m: Map, s: Scan, T):
+    n = max(s.n, 1)
+    gi = np.zeros(n, np.uint32)
+    gx, gy, gz, d2 = (np.zeros(n, np.float32) for _ in range(4))
+    T = _T12(T)
+    _chk(lib().mh_nn_search_dense(m._h, s._h, T.ctypes.data_as(_DP), _vp(gi), _vp(gx), _vp(gy), _vp(gz), _vp(d2),
+                                  MEM_HOST))
+    k = s.n
+    return dict(global_idx=gi[:k], global_xyz=np.stack([gx[:k], gy[:k], gz[:k]], 1), d2=d2[:k])
+
+
+@dataclass
+class GNParams:
+    max_inner_iterations: int = 2
+    robust_kernel: int = KERNEL_GM_C4
+    robust_kernel_param: float = 1.0
+    min_delta: float = 1e-7
+    max_cost: float = 0.0
+    weight_pt2pt: float = 1.0
+    weight_pt2pl: float = 1.0
+
+    def c(self):
+        return GNParamsC(self.max_inner_iterations, self.robust_kernel, self.robust_kernel_param, self.min_delta,
+                         self.max_cost, self.weight_pt2pt, self.weight_pt2pl)
+
+
+def _mk_prior(prior):
+    if prior is None:
+        return None
+    mean, info = prior
+    p = Prior()
+    p.mean[:] = list(_T12(mean))
+    p.info[:] = list(np.asarray(info, dtype=np.float64).reshape(36))
+    return p
+
+
+def _mk_pt2pt(local_xyz, global_xyz):
+    arrs = list(_soa(local_xyz)) + list(_soa(global_xyz))
+    return PairsPt2Pt(*[a.ctypes.data_as(_FP) for a in arrs], len(arrs[0])), arrs
+
+
+def _mk_pt2pl(local_xyz, centroid_xyz, normal_xyz):
+    arrs = list(_soa(local_xyz)) + list(_soa(centroid_xyz)) + list(_soa(normal_xyz))
+    return PairsPt2Pl(*[a.ctypes.data_as(_FP) for a in arrs], len(arrs[0])), arrs
+
+
+def gn_solve(ctx: Context, T, pt2pt=None, pt2pl=None, params: GNParams | None = None, prior=None):
+    params = params or GNParams()
+    gp = params.c()
+    pp, k1 = _mk_pt2pt(*pt2pt) if pt2pt is not None else (None, None)
+    pl, k2 = _mk_pt2pl(*pt2pl) if pt2pl is not None else (None, None)
+    pr = _mk_prior(prior)
+    Tio = _T12(T).copy()
+    n_steps, ok = C.c_int32(0), C.c_int32(1)
+    trace = (GNStep * max(1, params.max_inner_iterations))()
+    _chk(lib().mh_gn_solve(ctx._h, C.byref(pp) if pp else None, C.byref(pl) if pl else None, MEM_HOST, C.byref(gp),
+                           C.byref(pr) if pr else None, Tio.ctypes.data_as(_DP), C.byref(n_steps), C.byref(ok), trace))
+    steps = [dict(H=np.array(s.H).reshape(6, 6), g=np.array(s.g), err_norm_sqr=s.err_norm_sqr, delta=np.array(s.delta),
+                  T_after=np.array(s.T_after)) for s in trace]
+    return Tio, int(n_steps.value), bool(ok.value), steps
+
+
+def covariance(ctx: Context, T, pt2pt=None, pt2pl=None, findif_xyz=1e-7, findif_ang=1e-7):
+    pp, k1 = _mk_pt2pt(*pt2pt) if pt2pt is not None else (None, None)
+    pl, k2 = _mk_pt2pl(*pt2pl) if pt2pl is not None else (None, None)
+    T = _T12(T)
+    cov = np.zeros(36)
+    _chk(lib().mh_covariance(ctx._h, C.byref(pp) if pp else None, C.byref(pl) if pl else None, MEM_HOST,
+                             T.ctypes.data_as(_DP), findif_xyz, findif_ang, cov.ctypes.data_as(_DP)))
+    return cov.reshape(6, 6)
+
+
+@dataclass
+class ICPParams:
+    """mp2p_icp::Parameters + the matcher/solver settings of lidar3d-default.yaml:172-209."""
+    max_iterations: int = 300
+    min_abs_step_trans: float = 1e-4
+    min_abs_step_rot: float = 5e-5
+    disable_stall_test: bool = False
+    threshold: object = None
+    kernel_param: object = None
+    threshold_angular_deg: float = 0.0
+    gn: GNParams = field(default_factory=GNParams)
+    hook_enabled: bool = False
+    hook_min_trans: float = 0.15
+    hook_min_rot: float = float(np.deg2rad(0.75))
+    hook_checkpoint: object = None
+    compute_covariance: bool = True
+    cov_findif_xyz: float = 1e-7
+    cov_findif_ang: float = 1e-7
+    poll_every: int = 0
+    profile: bool = False
+
+    def c(self, T_guess):
+        thr = np.ascontiguousarray(np.broadcast_to(np.asarray(self.threshold, np.float64), (self.max_iterations,)))
+        kp = np.ascontiguousarray(np.broadcast_to(np.asarray(self.kernel_param, np.float64), (self.max_iterations,)))
+        cp = ICPParamsC()
+        cp.max_iterations = self.max_iterations
+        cp.min_abs_step_trans = self.min_abs_step_trans
+        cp.min_abs_step_rot = self.min_abs_step_rot
+        cp.disable_stall_test = int(self.disable_stall_test)
+        cp.threshold = thr.ctypes.data_as(_DP)
+        cp.kernel_param = kp.ctypes.data_as(_DP)
+        cp.threshold_angular_deg = self.threshold_angular_deg
+        cp.gn = self.gn.c()
+        cp.hook_enabled = int(self.hook_enabled)
+        cp.hook_min_trans = self.hook_min_trans
+        cp.hook_min_rot = self.hook_min_rot
+        chk = _T12(self.hook_checkpoint if self.hook_checkpoint is not None else T_guess)
+        cp.hook_checkpoint[:] = list(chk)
+        cp.compute_covariance = int(self.compute_covariance)
+        cp.cov_findif_xyz = self.cov_findif_xyz
+        cp.cov_findif_ang = self.cov_findif_ang
+        cp.poll_every = self.poll_every
+        cp.profile = int(self.profile)
+        return cp, (thr, kp)
+
+
+def _result_dict(res: ICPResult):
+    return dict(T=np.array(res.T), cov=np.array(res.cov).reshape(6, 6), quality=res.quality,
+                n_iterations=int(res.n_iterations), termination_reason=int(res.termination_reason),
+                n_final_pairs=int(res.n_final_pairs), potential_pairings=int(res.potential_pairings),
+                n_match_launches=int(res.n_match_launches), match_kernel_ms=res.match_kernel_ms, total_ms=res.total_ms)
+
+
+def icp_align(m: Map, s: Scan, T_guess, p: ICPParams, prior=None, want_trace=True, want_pairs=False):
+    cp, keep = p.c(T_guess)
+    T0 = _T12(T_guess)
+    res = ICPResult()
+    trace = (ICPIter * max(1, p.max_iterations))() if want_trace else None
+    pr = _mk_prior(prior)
+    po = None
+    if want_pairs:
+        n = max(s.n, 1)
+        li, gi = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        gx, gy, gz, d2 = (np.zeros(n, np.float32) for _ in range(4))
+        po = PairsOut(li.ctypes.data_as(_UP), gi.ctypes.data_as(_UP), gx.ctypes.data_as(_FP), gy.ctypes.data_as(_FP),
+                      gz.ctypes.data_as(_FP), d2.ctypes.data_as(_FP))
+    _chk(lib().mh_icp_align(m._h, s._h, C.byref(cp), T0.ctypes.data_as(_DP), C.byref(pr) if pr else None, C.byref(res),
+                            trace, C.byref(po) if po else None, MEM_HOST))
+    out = _result_dict(res)
+    if want_trace:
+        n_it = out["n_iterations"]
+        n_tr = min(p.max_iterations, n_it + 1)
+        if TERM_NAMES[out["termination_reason"]] in ("NoPairings", "SolverError"):
+            n_tr = n_it
+        out["trace"] = [dict(T=np.array(trace[i].T), n_pairs=int(trace[i].n_pairs), threshold=trace[i].threshold,
+                             kernel_param=trace[i].kernel_param, delta_trans=trace[i].delta_trans,
+                             delta_rot=trace[i].delta_rot) for i in range(n_tr)]
+    if want_pairs:
+        k = out["n_final_pairs"]
+        out["pairs"] = dict(local_idx=li[:k].copy(), global_idx=gi[:k].copy(),
+                            global_xyz=np.stack([gx[:k], gy[:k], gz[:k]], 1), d2=d2[:k].copy())
+    return out
+
+
+def icp_align_batch(maps, scans, T_guesses, p: ICPParams, priors=None):
+    """One alignment per (map, scan) pair; every scan must live in its own Context (its own stream)."""
+    n = len(scans)
+    T = np.ascontiguousarray(np.stack([_T12(t) for t in T_guesses]).reshape(n * 12))
+    cp, keep = p.c(T[:12])
+    mh = (C.c_void_p * n)(*[m._h for m in maps])
+    sh = (C.c_void_p * n)(*[s._h for s in scans])
+    res = (ICPResult * n)()
+    pr_arr = None
+    keep_pr = []
+    if priors is not None:
+        pr_arr = (C.POINTER(Prior) * n)()
+        for i, pr in enumerate(priors):
+            if pr is not None:
+                keep_pr.append(_mk_prior(pr))
+                pr_arr[i] = C.pointer(keep_pr[-1])
+    _chk(lib().mh_icp_align_batch(n, mh, sh, C.byref(cp), T.ctypes.data_as(_DP), pr_arr, res))
+    return [_result_dict(r) for r in res]

@@ -1,0 +1,1163 @@
+// mh_icp.hip -- the hot path: correspondence search, residual/Jacobian accumulation, 6x6 Gauss-Newton
+// solve and the ICP outer loop, all on the device (gfx950).
+//
+// Stands in for (all [U] = upstream classes the reference selects by name):
+//   mp2p_icp::ICP::align                                   <- LidarOdometry.cpp:961-962
+//   mp2p_icp::Matcher_Points_DistanceThreshold              <- lidar3d-default.yaml:195-204
+//   mola::HashedVoxelPointCloud::nn_single_search           <- lidar3d-default.yaml:228-242
+//   mp2p_icp::Solver_GaussNewton / optimal_tf_gauss_newton  <- lidar3d-default.yaml:184-190
+//   mp2p_icp::QualityEvaluator_PairedRatio                  <- lidar3d-default.yaml:206-209
+//   mp2p_icp::covariance                                    <- LidarOdometry.cpp:1009
+//
+// Kernel sequence per ICP iteration (everything stays in HBM/L2; the host never sees pairings):
+//   k_match<fused>   one lane per scan point: transform, 27-voxel NN, threshold test, store pairing,
+//                    robust weight + 18 fp64 moment sums, block reduction -> partials
+//   k_solve          one wave: ordered sum of partials, prior factor, LDL^T, T <- T(+)exp(delta),
+//                    inner/outer loop bookkeeping, stall + hook tests, termination flag
+//   k_accum          (inner GN steps >= 1) re-evaluate the SAME pairings at the new pose -> partials
+//   k_solve
+// No fp atomics anywhere: reductions are fixed-shape trees, so results are bitwise reproducible.
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "mh_nn_device.h"
+
+using namespace mh;
+
+constexpr uint32_t kBlock = 256;
+constexpr uint32_t kMaxGnTrace = 16;
+
+struct IcpDeviceState {
+  double T[12];
+  double T_prev[12];
+  uint32_t iter, inner, done, term_reason;
+  uint32_t n_pairs, n_iterations, solver_ok, n_solves;
+  uint32_t cov_done, pad0, pad1, pad2;
+  double cov[36];
+  double covD[72];  // (T(x+h_j) - T(x-h_j)) / (2 h_j), j = 0..5, 3x4 each
+};
+
+struct MatchK {
+  const double* thr;     // [max_iterations] device
+  const double* kparam;  // [max_iterations] device
+  float ang2;
+  uint32_t kernel;
+  double w_pt2pt;
+};
+
+struct SolveK {
+  uint32_t max_iterations, disable_stall, max_inner, has_prior;
+  double min_step_trans, min_step_rot, min_delta, max_cost;
+  uint32_t hook_enabled, pad;
+  double hook_trans, hook_rot;
+  double hook_chk_inv[12];
+  double prior_mean_inv[12];
+  double prior_info[36];
+  const double* thr;
+  const double* kparam;
+  mh_icp_iter* trace;
+  mh_gn_step* gn_trace;
+};
+
+struct PoseArg {
+  double m[12];
+};
+
+// ================================================================================================
+// k_match: correspondence search (+ first Gauss-Newton accumulation when FUSED)
+// ================================================================================================
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_match(const IcpDeviceState* __restrict__ st, PoseArg Targ, float thr2_arg,
+                                                  uint32_t apply_thr, MatchK k, const float* __restrict__ lx,
+                                                  const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                  MapView map, float4* __restrict__ pair_q,
+                                                  uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
+                                                  uint32_t pstride) {
+  __shared__ double lds[kBlock / 64][kAccN];
+  double T[12];
+  float thr2;
+  double kparam = 0.0;
+  if (FUSED) {
+    if (st->done) return;  // wave-uniform
+    const uint32_t it = st->iter;
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = st->T[i];
+    const double thr = k.thr[it];
+    thr2 = (float)(thr * thr);
+    kparam = k.kparam[it];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = Targ.m[i];
+    thr2 = thr2_arg;
+  }
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  Acc a;
+  acc_zero(a);
+  if (i < n) {
+    const float x = lx[i], y = ly[i], z = lz[i];
+    float px, py, pz;
+    transform_point(T, x, y, z, px, py, pz);
+    const NNResult r = nn_single_search(map, px, py, pz);
+    bool ok = r.found;
+    if (FUSED || apply_thr) {
+      const float n2 = (px * px + py * py) + pz * pz;
+      ok = ok && (r.d2 < thr2 + k.ang2 * n2);
+    }
+    pair_q[i] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
+    pair_gidx[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+    if (FUSED && ok) acc_pt2pt(a, T, x, y, z, r.pt.x, r.pt.y, r.pt.z, k.kernel, kparam, k.w_pt2pt);
+  }
+  if (FUSED) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < kAccN; j++) {
+      const double s = wave_sum(a.v[j]);
+      if (lane == 0) lds[wave][j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kAccN)
+      partials[threadIdx.x * pstride + blockIdx.x] =
+          ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+  }
+}
+
+// ================================================================================================
+// k_accum: point-to-point accumulation on stored pairings (inner GN steps, solver-granular path)
+// ================================================================================================
+__global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first, MatchK k,
+                                                  double kparam_fixed, uint32_t use_fixed, const float* __restrict__ lx,
+                                                  const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                  const float4* __restrict__ pair_q,
+                                                  const uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
+                                                  uint32_t pstride) {
+  __shared__ double lds[kBlock / 64][kAccN];
+  if (st->done) return;
+  if (!first && st->inner == 0) return;  // the previous solve already closed this ICP iteration
+  double T[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) T[i] = st->T[i];
+  const double kparam = use_fixed ? kparam_fixed : k.kparam[st->iter];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  Acc a;
+  acc_zero(a);
+  if (i < n && pair_gidx[i] != kNoMatch) {
+    const float4 q = pair_q[i];
+    acc_pt2pt(a, T, lx[i], ly[i], lz[i], q.x, q.y, q.z, k.kernel, kparam, k.w_pt2pt);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < kAccN; j++) {
+    const double s = wave_sum(a.v[j]);
+    if (lane == 0) lds[wave][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccN)
+    partials[threadIdx.x * pstride + blockIdx.x] =
+        ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+}
+
+// point-to-plane rows (Matcher_Point2Plane pairings, lidar3d-ndt.yaml:195-200): e = n.(R l + t - c),
+// J = [ (R^T n)^T | (l x R^T n)^T ].  Generic partial: 21 upper-triangle H + 6 g + cost + count.
+constexpr int kGenN = 29;
+__global__ __launch_bounds__(kBlock) void k_accum_pl(const IcpDeviceState* __restrict__ st, uint32_t kernel,
+                                                     double kparam, double wpair, const float* __restrict__ l3,
+                                                     const float* __restrict__ c3, const float* __restrict__ n3,
+                                                     uint32_t n, uint32_t stride, double* __restrict__ partials,
+                                                     uint32_t pstride) {
+  __shared__ double lds[kBlock / 64][kGenN];
+  if (st->done) return;
+  double T[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) T[i] = st->T[i];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  double v[kGenN];
+#pragma unroll
+  for (int j = 0; j < kGenN; j++) v[j] = 0.0;
+  if (i < n) {
+    const double lx = l3[i], ly = l3[stride + i], lz = l3[2 * stride + i];
+    const double cx = c3[i], cy = c3[stride + i], cz = c3[2 * stride + i];
+    const double nx = n3[i], ny = n3[stride + i], nz = n3[2 * stride + i];
+    const double gx = T[0] * lx + T[1] * ly + T[2] * lz + T[3] - cx;
+    const double gy = T[4] * lx + T[5] * ly + T[6] * lz + T[7] - cy;
+    const double gz = T[8] * lx + T[9] * ly + T[10] * lz + T[11] - cz;
+    const double e = nx * gx + ny * gy + nz * gz;
+    const double w = wpair * robust_weight(kernel, kparam, e * e);
+    double J[6];
+    J[0] = T[0] * nx + T[4] * ny + T[8] * nz;  // m = R^T n
+    J[1] = T[1] * nx + T[5] * ny + T[9] * nz;
+    J[2] = T[2] * nx + T[6] * ny + T[10] * nz;
+    J[3] = ly * J[2] - lz * J[1];
+    J[4] = lz * J[0] - lx * J[2];
+    J[5] = lx * J[1] - ly * J[0];
+    int q = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = a; b < 6; b++) v[q++] = w * J[a] * J[b];
+#pragma unroll
+    for (int a = 0; a < 6; a++) v[21 + a] = w * J[a] * e;
+    v[27] = w * e * e;
+    v[28] = 1.0;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < kGenN; j++) {
+    const double s = wave_sum(v[j]);
+    if (lane == 0) lds[wave][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kGenN)
+    partials[threadIdx.x * pstride + blockIdx.x] =
+        ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+}
+
+// ================================================================================================
+// k_solve: one wave.  Ordered reduction of the block partials, prior factor, LDL^T solve, SE(3)
+// retraction, inner/outer loop bookkeeping (optimal_tf_gauss_newton + the tail of ICP::align's loop).
+// ================================================================================================
+__global__ __launch_bounds__(64) void k_solve(IcpDeviceState* __restrict__ st, SolveK k, const double* __restrict__ partA,
+                                              uint32_t nA, uint32_t strideA, const double* __restrict__ partB,
+                                              uint32_t nB, uint32_t strideB) {
+  __shared__ double sh_log[13][6];
+  if (st->done) return;
+  const int lane = threadIdx.x;
+  double a[kAccN];
+#pragma unroll
+  for (int i = 0; i < kAccN; i++) {
+    double s = 0.0;
+    for (uint32_t b = lane; b < nA; b += 64) s += partA[i * strideA + b];
+    a[i] = wave_sum(s);
+  }
+  double gen[kGenN];
+#pragma unroll
+  for (int i = 0; i < kGenN; i++) {
+    double s = 0.0;
+    for (uint32_t b = lane; b < nB; b += 64) s += partB[i * strideB + b];
+    gen[i] = nB ? wave_sum(s) : 0.0;
+  }
+  Pose Tc;
+#pragma unroll
+  for (int i = 0; i < 12; i++) Tc.m[i] = st->T[i];
+  if (k.has_prior) {
+    // e_p = log(T_prior^-1 (+) T); d e_p / d eps for T*exp(eps) by central differences, one lane
+    // per perturbation (the exact derivative up to O(h^2); SURVEY App.B U9)
+    Pose Pinv;
+#pragma unroll
+    for (int i = 0; i < 12; i++) Pinv.m[i] = k.prior_mean_inv[i];
+    const Pose D = compose(Pinv, Tc);
+    if (lane < 13) {
+      double xi[6] = {0, 0, 0, 0, 0, 0};
+      if (lane < 12) xi[lane >> 1] = (lane & 1) ? -1e-6 : 1e-6;
+      const Pose Dp = compose(D, se3_exp(xi));
+      double lg[6];
+      se3_log(Dp, lg);
+      for (int i = 0; i < 6; i++) sh_log[lane][i] = lg[i];
+    }
+    __syncthreads();
+  }
+  if (lane != 0) return;
+
+  const uint32_t inner = st->inner;
+  const uint32_t it = st->iter;
+  const uint32_t n_pairs = (uint32_t)(a[17] + gen[28] + 0.5);
+  if (inner == 0) {
+    st->n_pairs = n_pairs;
+    if (n_pairs == 0) {  // ICP::align: "if (pairings.empty()) NoPairings; break"
+      st->term_reason = MH_TERM_NO_PAIRINGS;
+      st->n_iterations = it;
+      st->done = 1;
+      return;
+    }
+  }
+  // assemble the normal equations
+  double H[36], g[6];
+  for (int i = 0; i < 36; i++) H[i] = 0.0;
+  H[0] = H[7] = H[14] = a[0];
+  H[0 * 6 + 4] = a[3];  H[0 * 6 + 5] = -a[2];
+  H[1 * 6 + 3] = -a[3]; H[1 * 6 + 5] = a[1];
+  H[2 * 6 + 3] = a[2];  H[2 * 6 + 4] = -a[1];
+  H[3 * 6 + 3] = a[4]; H[4 * 6 + 4] = a[5]; H[5 * 6 + 5] = a[6];
+  H[3 * 6 + 4] = a[7]; H[3 * 6 + 5] = a[8]; H[4 * 6 + 5] = a[9];
+  {
+    int q = 0;
+    for (int r = 0; r < 6; r++)
+      for (int c = r; c < 6; c++) H[r * 6 + c] += gen[q++];
+  }
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < r; c++) H[r * 6 + c] = H[c * 6 + r];
+  for (int i = 0; i < 6; i++) g[i] = a[10 + i] + gen[21 + i];
+  const double cost = a[16] + gen[27];
+  if (k.has_prior) {
+    double Jp[36];
+    for (int j = 0; j < 6; j++)
+      for (int i = 0; i < 6; i++) Jp[i * 6 + j] = (sh_log[2 * j][i] - sh_log[2 * j + 1][i]) / 2e-6;
+    double JtL[36];
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) {
+        double s = 0.0;
+        for (int q = 0; q < 6; q++) s += Jp[q * 6 + i] * k.prior_info[q * 6 + j];
+        JtL[i * 6 + j] = s;
+      }
+    for (int i = 0; i < 6; i++) {
+      double s = 0.0;
+      for (int q = 0; q < 6; q++) s += JtL[i * 6 + q] * sh_log[12][q];
+      g[i] += s;
+      for (int j = 0; j < 6; j++) {
+        double h2 = 0.0;
+        for (int q = 0; q < 6; q++) h2 += JtL[i * 6 + q] * Jp[q * 6 + j];
+        H[i * 6 + j] += h2;
+      }
+    }
+  }
+  mh_gn_step* gt = (k.gn_trace && inner < kMaxGnTrace) ? &k.gn_trace[inner] : nullptr;
+  if (gt) {
+    for (int i = 0; i < 36; i++) gt->H[i] = H[i];
+    for (int i = 0; i < 6; i++) { gt->g[i] = g[i]; gt->delta[i] = 0.0; }
+    gt->err_norm_sqr = cost;
+    for (int i = 0; i < 12; i++) gt->T_after[i] = Tc.m[i];
+  }
+  bool inner_done = false;
+  if (sqrt(cost) <= k.max_cost) {
+    inner_done = true;  // "target error" early exit, no solve (App.B U8)
+  } else {
+    double x[6], delta[6];
+    if (!ldlt_solve6(H, g, x)) {
+      st->solver_ok = 0;
+      st->term_reason = MH_TERM_SOLVER_ERROR;
+      st->n_iterations = it;
+      st->done = 1;
+      return;
+    }
+    double dn = 0.0;
+    for (int i = 0; i < 6; i++) { delta[i] = -x[i]; dn += x[i] * x[i]; }
+    Tc = compose(Tc, se3_exp(delta));  // T <- T (+) exp(delta)
+    for (int i = 0; i < 12; i++) st->T[i] = Tc.m[i];
+    st->n_solves += 1;
+    if (gt) {
+      for (int i = 0; i < 6; i++) gt->delta[i] = delta[i];
+      for (int i = 0; i < 12; i++) gt->T_after[i] = Tc.m[i];
+    }
+    if (sqrt(dn) < k.min_delta) inner_done = true;
+  }
+  if (inner + 1 >= k.max_inner) inner_done = true;
+  if (!inner_done) {
+    st->inner = inner + 1;
+    return;
+  }
+  // ---- end of ICP iteration `it` (tail of the loop body of ICP::align) ----
+  st->inner = 0;
+  Pose Tp;
+  for (int i = 0; i < 12; i++) Tp.m[i] = st->T_prev[i];
+  double d[6];
+  se3_log(compose(inverse(Tp), Tc), d);
+  const double dtr = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const double drot = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+  if (k.trace) {
+    mh_icp_iter* tr = &k.trace[it];
+    for (int i = 0; i < 12; i++) tr->T[i] = Tc.m[i];
+    tr->n_pairs = st->n_pairs;
+    tr->threshold = k.thr ? k.thr[it] : 0.0;
+    tr->kernel_param = k.kparam ? k.kparam[it] : 0.0;
+    tr->delta_trans = dtr;
+    tr->delta_rot = drot;
+  }
+  if (!k.disable_stall && dtr < k.min_step_trans && drot < k.min_step_rot) {
+    st->term_reason = MH_TERM_STALLED;
+    st->n_iterations = it;
+    st->done = 1;
+    return;
+  }
+  if (k.hook_enabled) {
+    // LidarOdometry.cpp:932-949: delta = currentSolution (-) checkpoint
+    Pose Ci;
+    for (int i = 0; i < 12; i++) Ci.m[i] = k.hook_chk_inv[i];
+    const Pose S = compose(Ci, Tc);
+    double w[3];
+    so3_log(S, w);
+    const double ht = sqrt(S.t(0) * S.t(0) + S.t(1) * S.t(1) + S.t(2) * S.t(2));
+    const double hr = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (ht > k.hook_trans || hr > k.hook_rot) {
+      st->term_reason = MH_TERM_HOOK_REQUEST;
+      st->n_iterations = it;
+      st->done = 1;
+      return;
+    }
+  }
+  for (int i = 0; i < 12; i++) st->T_prev[i] = Tc.m[i];
+  st->iter = it + 1;
+  if (it + 1 >= k.max_iterations) {
+    st->term_reason = MH_TERM_MAX_ITERATIONS;
+    st->n_iterations = it + 1;
+    st->done = 1;
+  }
+}
+
+// ================================================================================================
+// Covariance (mp2p_icp::covariance [U]): A = d residuals / d (x,y,z,yaw,pitch,roll), cov = (A^T A)^-1
+// ================================================================================================
+constexpr int kCovN = 22;  // 21 upper-triangle + count
+
+__global__ void k_cov_prepare(IcpDeviceState* __restrict__ st, double hx, double ha, uint32_t force) {
+  if (!force && (!st->done || st->cov_done)) return;
+  const int j = threadIdx.x;
+  if (j >= 6) return;
+  Pose Tc;
+  for (int i = 0; i < 12; i++) Tc.m[i] = st->T[i];
+  double v[6];
+  pose_to_ypr(Tc, v);
+  const double h = j < 3 ? hx : ha;
+  double vp[6], vm[6];
+  for (int i = 0; i < 6; i++) { vp[i] = v[i]; vm[i] = v[i]; }
+  vp[j] += h;
+  vm[j] -= h;
+  const Pose P = pose_from_ypr(vp), M = pose_from_ypr(vm);
+  for (int i = 0; i < 12; i++) st->covD[j * 12 + i] = (P.m[i] - M.m[i]) / (2.0 * h);
+}
+
+__global__ __launch_bounds__(kBlock) void k_cov_accum(const IcpDeviceState* __restrict__ st, uint32_t force,
+                                                      const float* __restrict__ lx, const float* __restrict__ ly,
+                                                      const float* __restrict__ lz, uint32_t n,
+                                                      const uint32_t* __restrict__ pair_gidx,
+                                                      double* __restrict__ partials, uint32_t pstride) {
+  __shared__ double sD[72];
+  __shared__ double lds[kBlock / 64][kCovN];
+  if (!force && (!st->done || st->cov_done)) return;
+  if (threadIdx.x < 72) sD[threadIdx.x] = st->covD[threadIdx.x];
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  double v[kCovN];
+#pragma unroll
+  for (int j = 0; j < kCovN; j++) v[j] = 0.0;
+  if (i < n && pair_gidx[i] != kNoMatch) {
+    const double x = lx[i], y = ly[i], z = lz[i];
+    double A[3][6];
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+        A[r][j] = sD[j * 12 + r * 4] * x + sD[j * 12 + r * 4 + 1] * y + sD[j * 12 + r * 4 + 2] * z + sD[j * 12 + r * 4 + 3];
+    int q = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = a; b < 6; b++) v[q++] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b];
+    v[21] = 1.0;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < kCovN; j++) {
+    const double s = wave_sum(v[j]);
+    if (lane == 0) lds[wave][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kCovN)
+    partials[threadIdx.x * pstride + blockIdx.x] =
+        ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void k_cov_accum_pl(const IcpDeviceState* __restrict__ st,
+                                                         const float* __restrict__ l3, const float* __restrict__ n3,
+                                                         uint32_t n, uint32_t stride, double* __restrict__ partials,
+                                                         uint32_t pstride) {
+  __shared__ double sD[72];
+  __shared__ double lds[kBlock / 64][kCovN];
+  if (threadIdx.x < 72) sD[threadIdx.x] = st->covD[threadIdx.x];
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  double v[kCovN];
+#pragma unroll
+  for (int j = 0; j < kCovN; j++) v[j] = 0.0;
+  if (i < n) {
+    const double x = l3[i], y = l3[stride + i], z = l3[2 * stride + i];
+    const double nx = n3[i], ny = n3[stride + i], nz = n3[2 * stride + i];
+    double A[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      double r[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+        r[q] = sD[j * 12 + q * 4] * x + sD[j * 12 + q * 4 + 1] * y + sD[j * 12 + q * 4 + 2] * z + sD[j * 12 + q * 4 + 3];
+      A[j] = nx * r[0] + ny * r[1] + nz * r[2];
+    }
+    int q = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = a; b < 6; b++) v[q++] = A[a] * A[b];
+    v[21] = 1.0;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < kCovN; j++) {
+    const double s = wave_sum(v[j]);
+    if (lane == 0) lds[wave][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kCovN)
+    partials[threadIdx.x * pstride + blockIdx.x] =
+        ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void k_cov_finalize(IcpDeviceState* __restrict__ st, uint32_t force,
+                                                     const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
+                                                     const double* __restrict__ partB, uint32_t nB, uint32_t strideB) {
+  if (!force && (!st->done || st->cov_done)) return;
+  const int lane = threadIdx.x;
+  double a[kCovN];
+#pragma unroll
+  for (int i = 0; i < kCovN; i++) {
+    double s = 0.0;
+    for (uint32_t b = lane; b < nA; b += 64) s += partA[i * strideA + b];
+    double t = 0.0;
+    for (uint32_t b = lane; b < nB; b += 64) t += partB[i * strideB + b];
+    a[i] = wave_sum(s) + (nB ? wave_sum(t) : 0.0);
+  }
+  if (lane != 0) return;
+  double AtA[36], cov[36];
+  int q = 0;
+  for (int r = 0; r < 6; r++)
+    for (int c = r; c < 6; c++) {
+      AtA[r * 6 + c] = a[q];
+      AtA[c * 6 + r] = a[q];
+      q++;
+    }
+  bool ok = a[21] > 0.5 && chol_inverse6(AtA, cov);
+  if (ok)
+    for (int i = 0; i < 36; i++) ok = ok && isfinite(cov[i]);
+  for (int i = 0; i < 36; i++) st->cov[i] = ok ? cov[i] : ((i % 7 == 0) ? 1e6 : 0.0);
+  st->cov_done = 1;
+}
+
+// ================================================================================================
+// Pairing compaction: per-block count -> scan of block counts -> ballot/prefix scatter.
+// Output order = ascending local index (what a serial matcher emits).
+// ================================================================================================
+__global__ __launch_bounds__(kBlock) void k_count_valid(const uint32_t* __restrict__ gidx, uint32_t n,
+                                                        uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t wc[kBlock / 64];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const bool v = i < n && gidx[i] != kNoMatch;
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict__ counts, uint32_t nb,
+                                                      uint32_t* __restrict__ offsets, uint32_t* __restrict__ total) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t base = 0; base < nb; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t c = i < nb ? counts[i] : 0;
+    uint32_t incl = c;  // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up((int)incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t wpre = 0;
+    for (int w = 0; w < wave; w++) wpre += wsum[w];
+    if (i < nb) offsets[i] = carry + wpre + incl - c;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += wpre + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(kBlock) void k_compact(const uint32_t* __restrict__ gidx, const float4* __restrict__ pq,
+                                                    uint32_t n, const uint32_t* __restrict__ block_offsets,
+                                                    uint32_t* __restrict__ o_li, uint32_t* __restrict__ o_gi,
+                                                    float* __restrict__ o_x, float* __restrict__ o_y,
+                                                    float* __restrict__ o_z, float* __restrict__ o_d2) {
+  __shared__ uint32_t wc[kBlock / 64];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t gi = i < n ? gidx[i] : kNoMatch;
+  const bool v = gi != kNoMatch;
+  const unsigned long long m = __ballot(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wc[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (!v) return;
+  uint32_t pos = block_offsets[blockIdx.x] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; w++) pos += wc[w];
+  const float4 q = pq[i];
+  if (o_li) o_li[pos] = i;
+  if (o_gi) o_gi[pos] = gi;
+  if (o_x) o_x[pos] = q.x;
+  if (o_y) o_y[pos] = q.y;
+  if (o_z) o_z[pos] = q.z;
+  if (o_d2) o_d2[pos] = q.w;
+}
+
+// dense outputs of the un-compacted search
+__global__ void k_unpack_dense(const uint32_t* __restrict__ gidx, const float4* __restrict__ pq, uint32_t n,
+                               uint32_t* __restrict__ o_gi, float* __restrict__ o_x, float* __restrict__ o_y,
+                               float* __restrict__ o_z, float* __restrict__ o_d2) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 q = pq[i];
+  if (o_gi) o_gi[i] = gidx[i];
+  if (o_x) o_x[i] = q.x;
+  if (o_y) o_y[i] = q.y;
+  if (o_z) o_z[i] = q.z;
+  if (o_d2) o_d2[i] = q.w;
+}
+
+// solver-granular path: pack caller pairings into the pair buffers
+__global__ void k_pack_pairs(const float* __restrict__ g3, uint32_t n, uint32_t stride, float4* __restrict__ pq,
+                             uint32_t* __restrict__ gidx) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  pq[i] = make_float4(g3[i], g3[stride + i], g3[2 * stride + i], 0.f);
+  gidx[i] = i;
+}
+
+// ================================================================================================
+// Host side
+// ================================================================================================
+namespace {
+
+inline uint32_t nblk(size_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
+
+mh_status ensure_state(mh_ctx* ctx) {
+  if (!ctx->d_state) {
+    MH_HIP(hipMalloc((void**)&ctx->d_state, sizeof(IcpDeviceState)));
+    MH_HIP(hipHostMalloc((void**)&ctx->h_state, sizeof(IcpDeviceState), hipHostMallocDefault));
+  }
+  return MH_OK;
+}
+
+mh_status ensure_pair_buffers(mh_ctx* ctx, size_t n) {
+  const size_t nn = n ? n : 1;
+  MH_TRY(ctx->pair_q.reserve(nn * sizeof(float4)));
+  MH_TRY(ctx->pair_gidx.reserve(nn * sizeof(uint32_t)));
+  const size_t nb = nblk(nn);
+  MH_TRY(ctx->partials.reserve((size_t)kGenN * nb * sizeof(double)));
+  return MH_OK;
+}
+
+void init_state(IcpDeviceState* h, const double T[12]) {
+  memset(h, 0, sizeof(*h));
+  for (int i = 0; i < 12; i++) {
+    h->T[i] = T[i];
+    h->T_prev[i] = T[i];
+  }
+  h->solver_ok = 1;
+  for (int i = 0; i < 6; i++) h->cov[i * 7] = 1e6;
+}
+
+void fill_prior(SolveK& k, const mh_prior* prior) {
+  k.has_prior = prior ? 1u : 0u;
+  if (!prior) return;
+  Pose P;
+  for (int i = 0; i < 12; i++) P.m[i] = prior->mean[i];
+  const Pose Pi = inverse(P);
+  for (int i = 0; i < 12; i++) k.prior_mean_inv[i] = Pi.m[i];
+  for (int i = 0; i < 36; i++) k.prior_info[i] = prior->info[i];
+}
+
+bool pose_ok(const double T[12]) {
+  for (int i = 0; i < 12; i++)
+    if (!isfinite(T[i])) return false;
+  return true;
+}
+
+// compaction of the context's pair buffers into caller arrays; returns the number of pairs
+mh_status compact_pairs(mh_ctx* ctx, size_t n, const mh_pairs_out* out, int32_t mem, uint64_t* n_pairs_out) {
+  hipStream_t s = ctx->stream;
+  const uint32_t nb = nblk(n);
+  const size_t n4 = ((n + 63) / 64) * 64;
+  // layout: counts[nb] | offsets[nb] | total[1] | (host staging) li,gi,x,y,z,d2 [n4 each]
+  const size_t hdr = (((size_t)2 * nb + 1) * 4 + 255) / 256 * 256;
+  MH_TRY(ctx->compact.reserve(hdr + 6 * n4 * 4));
+  uint32_t* counts = ctx->compact.as<uint32_t>();
+  uint32_t* offsets = counts + nb;
+  uint32_t* total = offsets + nb;
+  char* stage = ctx->compact.as<char>() + hdr;
+  uint32_t *o_li, *o_gi;
+  float *o_x, *o_y, *o_z, *o_d2;
+  if (mem == MH_MEM_DEVICE) {
+    o_li = out->local_idx; o_gi = out->global_idx; o_x = out->gx; o_y = out->gy; o_z = out->gz; o_d2 = out->d2;
+  } else {
+    o_li = out->local_idx ? (uint32_t*)(stage) : nullptr;
+    o_gi = out->global_idx ? (uint32_t*)(stage + n4 * 4) : nullptr;
+    o_x = out->gx ? (float*)(stage + 2 * n4 * 4) : nullptr;
+    o_y = out->gy ? (float*)(stage + 3 * n4 * 4) : nullptr;
+    o_z = out->gz ? (float*)(stage + 4 * n4 * 4) : nullptr;
+    o_d2 = out->d2 ? (float*)(stage + 5 * n4 * 4) : nullptr;
+  }
+  uint32_t h_total = 0;
+  if (n) {
+    hipLaunchKernelGGL(k_count_valid, dim3(nb), dim3(kBlock), 0, s, ctx->pair_gidx.as<uint32_t>(), (uint32_t)n, counts);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, counts, nb, offsets, total);
+    hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kBlock), 0, s, ctx->pair_gidx.as<uint32_t>(), ctx->pair_q.as<float4>(),
+                       (uint32_t)n, offsets, o_li, o_gi, o_x, o_y, o_z, o_d2);
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipMemcpyAsync(&h_total, total, 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+  }
+  if (mem == MH_MEM_HOST && h_total) {
+    const size_t b = (size_t)h_total * 4;
+    if (out->local_idx) MH_HIP(hipMemcpy(out->local_idx, o_li, b, hipMemcpyDeviceToHost));
+    if (out->global_idx) MH_HIP(hipMemcpy(out->global_idx, o_gi, b, hipMemcpyDeviceToHost));
+    if (out->gx) MH_HIP(hipMemcpy(out->gx, o_x, b, hipMemcpyDeviceToHost));
+    if (out->gy) MH_HIP(hipMemcpy(out->gy, o_y, b, hipMemcpyDeviceToHost));
+    if (out->gz) MH_HIP(hipMemcpy(out->gz, o_z, b, hipMemcpyDeviceToHost));
+    if (out->d2) MH_HIP(hipMemcpy(out->d2, o_d2, b, hipMemcpyDeviceToHost));
+  }
+  if (n_pairs_out) *n_pairs_out = h_total;
+  return MH_OK;
+}
+
+// One alignment in flight on one context: enqueue / poll state machine shared by mh_icp_align and
+// mh_icp_align_batch.
+struct AlignJob {
+  const mh_map* map = nullptr;
+  const mh_scan* scan = nullptr;
+  mh_ctx* ctx = nullptr;
+  const mh_icp_params* p = nullptr;
+  mh_icp_result* res = nullptr;
+  mh_icp_iter* trace = nullptr;
+  MatchK mk{};
+  SolveK sk{};
+  uint32_t nb = 0, enqueued = 0, chunk = 0, prof_n = 0;
+  bool finished = false, trivial = false;
+
+  mh_status start(const mh_map* m, const mh_scan* sc, const mh_icp_params* prm, const double* T0, const mh_prior* prior,
+                  mh_icp_result* r, mh_icp_iter* tr) {
+    map = m; scan = sc; ctx = sc->ctx; p = prm; res = r; trace = tr;
+    memset(res, 0, sizeof(*res));
+    for (int i = 0; i < 12; i++) res->T[i] = T0[i];
+    for (int i = 0; i < 6; i++) res->cov[i * 7] = 1e6;
+    res->potential_pairings = scan->n;
+    if (p->max_iterations == 0 || scan->n == 0) {
+      // ICP::align with nothing to iterate on: no pairings, quality 0, cov = diag(1e6)
+      res->termination_reason = p->max_iterations == 0 ? MH_TERM_MAX_ITERATIONS : MH_TERM_NO_PAIRINGS;
+      finished = trivial = true;
+      return MH_OK;
+    }
+    MH_TRY(set_device(ctx));
+    MH_TRY(ensure_state(ctx));
+    MH_TRY(ensure_pair_buffers(ctx, scan->n));
+    hipStream_t s = ctx->stream;
+    const size_t mi = p->max_iterations;
+    MH_TRY(ctx->sched.reserve(2 * mi * sizeof(double)));
+    MH_HIP(hipMemcpyAsync(ctx->sched.p, p->threshold, mi * sizeof(double), hipMemcpyHostToDevice, s));
+    MH_HIP(hipMemcpyAsync(ctx->sched.as<double>() + mi, p->kernel_param, mi * sizeof(double), hipMemcpyHostToDevice, s));
+    if (trace) MH_TRY(ctx->trace.reserve(mi * sizeof(mh_icp_iter)));
+    init_state(ctx->h_state, T0);
+    MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpDeviceState), hipMemcpyHostToDevice, s));
+
+    const double ang = p->threshold_angular_deg * 3.14159265358979323846 / 180.0;
+    mk.thr = ctx->sched.as<double>();
+    mk.kparam = ctx->sched.as<double>() + mi;
+    mk.ang2 = (float)(ang * ang);
+    mk.kernel = p->gn.robust_kernel;
+    mk.w_pt2pt = p->gn.weight_pt2pt;
+    memset(&sk, 0, sizeof(sk));
+    sk.max_iterations = p->max_iterations;
+    sk.disable_stall = p->disable_stall_test;
+    sk.max_inner = p->gn.max_inner_iterations;
+    sk.min_step_trans = p->min_abs_step_trans;
+    sk.min_step_rot = p->min_abs_step_rot;
+    sk.min_delta = p->gn.min_delta;
+    sk.max_cost = p->gn.max_cost;
+    sk.hook_enabled = p->hook_enabled;
+    sk.hook_trans = p->hook_min_trans;
+    sk.hook_rot = p->hook_min_rot;
+    if (p->hook_enabled) {
+      Pose C;
+      for (int i = 0; i < 12; i++) C.m[i] = p->hook_checkpoint[i];
+      const Pose Ci = inverse(C);
+      for (int i = 0; i < 12; i++) sk.hook_chk_inv[i] = Ci.m[i];
+    }
+    fill_prior(sk, prior);
+    sk.thr = mk.thr;
+    sk.kparam = mk.kparam;
+    sk.trace = trace ? ctx->trace.as<mh_icp_iter>() : nullptr;
+    sk.gn_trace = nullptr;
+    nb = nblk(scan->n);
+    chunk = p->poll_every ? p->poll_every : 10;
+    enqueued = 0;
+    prof_n = 0;
+    if (p->profile) {
+      const uint32_t need = 2 * p->max_iterations;
+      if (ctx->prof_cap < need) {
+        hipEvent_t* ne = new (std::nothrow) hipEvent_t[need];
+        if (!ne) return fail(MH_ERR_OUT_OF_MEMORY, "host allocation failed");
+        for (uint32_t i = 0; i < ctx->prof_cap; i++) ne[i] = ctx->prof_ev[i];
+        for (uint32_t i = ctx->prof_cap; i < need; i++) MH_HIP(hipEventCreate(&ne[i]));
+        delete[] ctx->prof_ev;
+        ctx->prof_ev = ne;
+        ctx->prof_cap = need;
+      }
+      MH_HIP(hipEventRecord(ctx->ev_t0, s));
+    }
+    return MH_OK;
+  }
+
+  mh_status enqueue_chunk() {
+    if (finished) return MH_OK;
+    MH_TRY(set_device(ctx));
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t)scan->n;
+    const MapView mv = map->view();
+    const uint32_t m = (p->max_iterations - enqueued) < chunk ? (p->max_iterations - enqueued) : chunk;
+    PoseArg dummy{};
+    double* part = ctx->partials.as<double>();
+    for (uint32_t j = 0; j < m; j++) {
+      if (p->profile) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n], s));
+      hipLaunchKernelGGL(k_match<true>, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, mk, scan->x, scan->y,
+                         scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nb);
+      if (p->profile) {
+        MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));
+        prof_n++;
+      }
+      hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, ctx->d_state, sk, part, nb, nb, (const double*)nullptr, 0u, 0u);
+      for (uint32_t in = 1; in < p->gn.max_inner_iterations; in++) {
+        hipLaunchKernelGGL(k_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, mk, 0.0, 0u, scan->x, scan->y, scan->z,
+                           n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nb);
+        hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, ctx->d_state, sk, part, nb, nb, (const double*)nullptr, 0u,
+                           0u);
+      }
+    }
+    enqueued += m;
+    if (p->compute_covariance) {  // no-ops unless the loop has terminated
+      hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, p->cov_findif_xyz, p->cov_findif_ang, 0u);
+      hipLaunchKernelGGL(k_cov_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, scan->x, scan->y, scan->z, n,
+                         ctx->pair_gidx.as<uint32_t>(), part, nb);
+      hipLaunchKernelGGL(k_cov_finalize, dim3(1), dim3(64), 0, s, ctx->d_state, 0u, part, nb, nb, (const double*)nullptr,
+                         0u, 0u);
+    }
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
+    if (p->profile) MH_HIP(hipEventRecord(ctx->ev_t1, s));
+    MH_HIP(hipEventRecord(ctx->ev_poll, s));
+    return MH_OK;
+  }
+
+  // waits for the last enqueued chunk; sets finished when the device loop has terminated
+  mh_status poll() {
+    if (finished) return MH_OK;
+    MH_TRY(set_device(ctx));
+    MH_HIP(hipEventSynchronize(ctx->ev_poll));
+    const IcpDeviceState* h = ctx->h_state;
+    if (!h->done && enqueued < p->max_iterations) return MH_OK;
+    if (!h->done) return fail(MH_ERR_INTERNAL, "device ICP loop did not terminate after max_iterations");
+    finished = true;
+    for (int i = 0; i < 12; i++) res->T[i] = h->T[i];
+    if (p->compute_covariance)
+      for (int i = 0; i < 36; i++) res->cov[i] = h->cov[i];
+    res->n_iterations = h->n_iterations;
+    res->termination_reason = h->term_reason;
+    res->n_final_pairs = h->n_pairs;
+    res->potential_pairings = scan->n;
+    res->quality = (h->n_pairs && scan->n) ? (double)h->n_pairs / (double)scan->n : 0.0;  // PairedRatio
+    if (h->term_reason == MH_TERM_NO_PAIRINGS)
+      for (int i = 0; i < 36; i++) res->cov[i] = (i % 7 == 0) ? 1e6 : 0.0;
+    if (trace) {
+      const uint32_t cnt = h->n_iterations < p->max_iterations ? h->n_iterations + 1 : p->max_iterations;
+      memset(trace, 0, sizeof(mh_icp_iter) * p->max_iterations);
+      const uint32_t valid = (h->term_reason == MH_TERM_NO_PAIRINGS || h->term_reason == MH_TERM_SOLVER_ERROR)
+                                 ? h->n_iterations : cnt;
+      if (valid) MH_HIP(hipMemcpy(trace, ctx->trace.p, sizeof(mh_icp_iter) * valid, hipMemcpyDeviceToHost));
+    }
+    if (p->profile) {
+      float ms = 0.f;
+      double sum = 0.0;
+      // launches enqueued after termination are early-exit no-ops; time only the live ones
+      uint32_t live = h->n_iterations + ((h->term_reason == MH_TERM_MAX_ITERATIONS) ? 0u : 1u);
+      if (live > prof_n) live = prof_n;
+      for (uint32_t i = 0; i < live; i++) {
+        MH_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+        sum += ms;
+      }
+      res->n_match_launches = live;
+      res->match_kernel_ms = sum;
+      MH_HIP(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+      res->total_ms = ms;
+    }
+    return MH_OK;
+  }
+};
+
+mh_status check_align_args(const mh_map* map, const mh_scan* scan, const mh_icp_params* p, const double* T,
+                           const mh_icp_result* res) {
+  MH_REQUIRE(map && scan && p && T && res, "null argument");
+  MH_REQUIRE(map->ctx->device == scan->ctx->device, "map and scan live on different devices");
+  MH_REQUIRE(pose_ok(T), "non-finite initial guess");
+  MH_REQUIRE(p->max_iterations == 0 || (p->threshold && p->kernel_param), "threshold/kernel_param arrays are required");
+  MH_REQUIRE(p->gn.max_inner_iterations >= 1, "gn.max_inner_iterations must be >= 1");
+  MH_REQUIRE(p->gn.robust_kernel <= MH_KERNEL_GM_C2, "unknown robust kernel");
+  MH_REQUIRE(p->max_iterations < (1u << 20), "max_iterations too large");
+  return MH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_icp_params* params, const double T_guess[12],
+                       const mh_prior* prior, mh_icp_result* result, mh_icp_iter* trace, const mh_pairs_out* final_pairs,
+                       int32_t pairs_mem) {
+  MH_TRY(check_align_args(map, scan, params, T_guess, result));
+  MH_REQUIRE(!final_pairs || pairs_mem == MH_MEM_HOST || pairs_mem == MH_MEM_DEVICE, "bad mem space");
+  AlignJob job;
+  MH_TRY(job.start(map, scan, params, T_guess, prior, result, trace));
+  while (!job.finished) {
+    MH_TRY(job.enqueue_chunk());
+    MH_TRY(job.poll());
+  }
+  if (final_pairs && !job.trivial && result->n_final_pairs) {
+    uint64_t np = 0;
+    MH_TRY(compact_pairs(scan->ctx, scan->n, final_pairs, pairs_mem, &np));
+    if (np != result->n_final_pairs) return fail(MH_ERR_INTERNAL, "pair compaction count mismatch");
+  }
+  return MH_OK;
+}
+
+mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_scan* const* scans,
+                             const mh_icp_params* params, const double* T_guesses, const mh_prior* const* priors,
+                             mh_icp_result* results) {
+  MH_REQUIRE(n_jobs == 0 || (maps && scans && params && T_guesses && results), "null argument");
+  std::vector<AlignJob> jobs(n_jobs);
+  for (size_t i = 0; i < n_jobs; i++) {
+    MH_TRY(check_align_args(maps[i], scans[i], params, T_guesses + 12 * i, &results[i]));
+    for (size_t j = 0; j < i; j++)
+      MH_REQUIRE(scans[j]->ctx != scans[i]->ctx, "each job of a batch needs its own context");
+    MH_TRY(jobs[i].start(maps[i], scans[i], params, T_guesses + 12 * i, priors ? priors[i] : nullptr, &results[i],
+                         nullptr));
+  }
+  for (;;) {
+    bool any = false;
+    for (auto& j : jobs)
+      if (!j.finished) {
+        MH_TRY(j.enqueue_chunk());
+        any = true;
+      }
+    if (!any) break;
+    for (auto& j : jobs) MH_TRY(j.poll());
+  }
+  return MH_OK;
+}
+
+mh_status mh_nn_search(const mh_map* map, const mh_scan* scan, const double T[12], double threshold,
+                       double threshold_angular_deg, const mh_pairs_out* out, int32_t mem, mh_match_info* info) {
+  MH_REQUIRE(map && scan && T, "null argument");
+  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
+  MH_REQUIRE(map->ctx->device == scan->ctx->device, "map and scan live on different devices");
+  MH_REQUIRE(pose_ok(T), "non-finite pose");
+  mh_ctx* ctx = scan->ctx;
+  MH_TRY(set_device(ctx));
+  if (info) {
+    info->n_pairs = 0;
+    info->potential_pairings = scan->n;  // counted before any test (App.B U6)
+  }
+  if (scan->n == 0) return MH_OK;
+  MH_TRY(ensure_state(ctx));
+  MH_TRY(ensure_pair_buffers(ctx, scan->n));
+  PoseArg Ta;
+  for (int i = 0; i < 12; i++) Ta.m[i] = T[i];
+  MatchK mk{};
+  const double ang = threshold_angular_deg * 3.14159265358979323846 / 180.0;
+  mk.ang2 = (float)(ang * ang);
+  hipLaunchKernelGGL(k_match<false>, dim3(nblk(scan->n)), dim3(kBlock), 0, ctx->stream, ctx->d_state, Ta,
+                     (float)(threshold * threshold), 1u, mk, scan->x, scan->y, scan->z, (uint32_t)scan->n, map->view(),
+                     ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (double*)nullptr, 0u);
+  MH_HIP(hipGetLastError());
+  mh_pairs_out none{};
+  uint64_t np = 0;
+  MH_TRY(compact_pairs(ctx, scan->n, out ? out : &none, mem, &np));
+  if (info) info->n_pairs = np;
+  return MH_OK;
+}
+
+mh_status mh_nn_search_dense(const mh_map* map, const mh_scan* scan, const double T[12], uint32_t* global_idx, float* gx,
+                             float* gy, float* gz, float* d2, int32_t mem) {
+  MH_REQUIRE(map && scan && T, "null argument");
+  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
+  MH_REQUIRE(map->ctx->device == scan->ctx->device, "map and scan live on different devices");
+  MH_REQUIRE(pose_ok(T), "non-finite pose");
+  mh_ctx* ctx = scan->ctx;
+  MH_TRY(set_device(ctx));
+  const size_t n = scan->n;
+  if (n == 0) return MH_OK;
+  MH_TRY(ensure_state(ctx));
+  MH_TRY(ensure_pair_buffers(ctx, n));
+  PoseArg Ta;
+  for (int i = 0; i < 12; i++) Ta.m[i] = T[i];
+  MatchK mk{};
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(k_match<false>, dim3(nblk(n)), dim3(kBlock), 0, s, ctx->d_state, Ta, 0.f, 0u, mk, scan->x, scan->y,
+                     scan->z, (uint32_t)n, map->view(), ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+                     (double*)nullptr, 0u);
+  uint32_t* o_gi = global_idx;
+  float *o_x = gx, *o_y = gy, *o_z = gz, *o_d2 = d2;
+  const size_t n4 = ((n + 63) / 64) * 64;
+  if (mem == MH_MEM_HOST) {
+    MH_TRY(ctx->compact.reserve(5 * n4 * 4));
+    char* st = ctx->compact.as<char>();
+    o_gi = global_idx ? (uint32_t*)st : nullptr;
+    o_x = gx ? (float*)(st + n4 * 4) : nullptr;
+    o_y = gy ? (float*)(st + 2 * n4 * 4) : nullptr;
+    o_z = gz ? (float*)(st + 3 * n4 * 4) : nullptr;
+    o_d2 = d2 ? (float*)(st + 4 * n4 * 4) : nullptr;
+  }
+  hipLaunchKernelGGL(k_unpack_dense, dim3(nblk(n)), dim3(kBlock), 0, s, ctx->pair_gidx.as<uint32_t>(),
+                     ctx->pair_q.as<float4>(), (uint32_t)n, o_gi, o_x, o_y, o_z, o_d2);
+  MH_HIP(hipGetLastError());
+  MH_HIP(hipStreamSynchronize(s));
+  if (mem == MH_MEM_HOST) {
+    if (global_idx) MH_HIP(hipMemcpy(global_idx, o_gi, n * 4, hipMemcpyDeviceToHost));
+    if (gx) MH_HIP(hipMemcpy(gx, o_x, n * 4, hipMemcpyDeviceToHost));
+    if (gy) MH_HIP(hipMemcpy(gy, o_y, n * 4, hipMemcpyDeviceToHost));
+    if (gz) MH_HIP(hipMemcpy(gz, o_z, n * 4, hipMemcpyDeviceToHost));
+    if (d2) MH_HIP(hipMemcpy(d2, o_d2, n * 4, hipMemcpyDeviceToHost));
+  }
+  return MH_OK;
+}
+
+// ---- solver-granular entry points ---------------------------------------------------------------
+namespace {
+// stage 3 (or 6/9) SoA float arrays of n elements into one device buffer with a common stride
+mh_status stage_soa(mh_ctx* ctx, DevBuf& buf, const float* const* arrs, int count, size_t n, int32_t mem, size_t* stride_out) {
+  const size_t stride = ((n + 63) / 64) * 64;
+  MH_TRY(buf.reserve((size_t)count * stride * sizeof(float) + 256));
+  for (int a = 0; a < count; a++)
+    MH_TRY(stage_in(ctx, buf, (size_t)a * stride * sizeof(float), arrs[a], n * sizeof(float), mem));
+  *stride_out = stride;
+  return MH_OK;
+}
+}  // namespace
+
+mh_status mh_gn_solve(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt2pl* pl, int32_t mem,
+                      const mh_gn_params* p, const mh_prior* prior, double T_io[12], int32_t* n_steps, int32_t* solver_ok,
+                      mh_gn_step* trace) {
+  MH_REQUIRE(ctx && p && T_io, "null argument");
+  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
+  MH_REQUIRE(p->max_inner_iterations >= 1 && p->max_inner_iterations <= kMaxGnTrace, "max_inner_iterations out of [1,16]");
+  MH_REQUIRE(p->robust_kernel <= MH_KERNEL_GM_C2, "unknown robust kernel");
+  MH_REQUIRE(pose_ok(T_io), "non-finite linearisation point");
+  const size_t np = pp ? pp->n : 0, nl = pl ? pl->n : 0;
+  MH_REQUIRE(np == 0 || (pp->lx && pp->ly && pp->lz && pp->gx && pp->gy && pp->gz), "null pt2pt arrays");
+  MH_REQUIRE(nl == 0 || (pl->lx && pl->ly && pl->lz && pl->cx && pl->cy && pl->cz && pl->nx && pl->ny && pl->nz),
+             "null pt2pl arrays");
+  if (n_steps) *n_steps = 0;
+  if (solver_ok) *solver_ok = 1;
+  MH_TRY(set_device(ctx));
+  MH_TRY(ensure_state(ctx));
+  hipStream_t s = ctx->stream;
+  MH_HIP(hipStreamSynchronize(s));
+  // stage pairings: build_a = pt2pt (l xyz | g xyz), build_b = pt2pl (l | c | n)
+  size_t sp = 0, sl = 0;
+  if (np) {
+    const float* arrs[6] = {pp->lx, pp->ly, pp->lz, pp->gx, pp->gy, pp->gz};
+    MH_TRY(stage_soa(ctx, ctx->build_a, arrs, 6, np, mem, &sp));
+  }
+  if (nl) {
+    const float* arrs[9] = {pl->lx, pl->ly, pl->lz, pl->cx, pl->cy, pl->cz, pl->nx, pl->ny, pl->nz};
+    MH_TRY(stage_soa(ctx, ctx->build_b, arrs, 9, nl, mem, &sl));
+  }
+  MH_TRY(ensure_pair_buffers(ctx, np));
+  const uint32_t nbp = np ? nblk(np) : 0, nbl = nl ? nblk(nl) : 0;
+  MH_TRY(ctx->partials_b.reserve((size_t)kGenN * (nbl ? nbl : 1) * sizeof(double)));
+  MH_TRY(ctx->trace.reserve(sizeof(mh_gn_step) * kMaxGnTrace));
+  const float* L = ctx->build_a.as<float>();
+  if (np)
+    hipLaunchKernelGGL(k_pack_pairs, dim3(nbp), dim3(kBlock), 0, s, L + 3 * sp, (uint32_t)np, (uint32_t)sp,
+                       ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>());
+  init_state(ctx->h_state, T_io);
+  MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpDeviceState), hipMemcpyHostToDevice, s));
+  MatchK mk{};
+  mk.kernel = p->robust_kernel;
+  mk.w_pt2pt = p->weight_pt2pt;
+  SolveK sk;
+  memset(&sk, 0, sizeof(sk));
+  sk.max_iterations = 1;
+  sk.disable_stall = 1;
+  sk.max_inner = p->max_inner_iterations;
+  sk.min_delta = p->min_delta;
+  sk.max_cost = p->max_cost;
+  fill_prior(sk, prior);
+  sk.gn_trace = (mh_gn_step*)ctx->trace.p;
+  MH_HIP(hipMemsetAsync(ctx->trace.p, 0, sizeof(mh_gn_step) * kMaxGnTrace, s));
+  const float* P = ctx->build_b.as<float>();
+  for (uint32_t in = 0; in < p->max_inner_iterations; in++) {
+    if (np)
+      hipLaunchKernelGGL(k_accum, dim3(nbp), dim3(kBlock), 0, s, ctx->d_state, in == 0 ? 1u : 0u, mk,
+                         p->robust_kernel_param, 1u, L, L + sp, L + 2 * sp, (uint32_t)np, ctx->pair_q.as<float4>(),
+                         ctx->pair_gidx.as<uint32_t>(), ctx->partials.as<double>(), nbp);
+    if (nl)
+      hipLaunchKernelGGL(k_accum_pl, dim3(nbl), dim3(kBlock), 0, s, ctx->d_state, p->robust_kernel,
+                         p->robust_kernel_param, p->weight_pt2pl, P, P + 3 * sl, P + 6 * sl, (uint32_t)nl, (uint32_t)sl,
+                         ctx->partials_b.as<double>(), nbl);
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, ctx->d_state, sk, ctx->partials.as<double>(), nbp, nbp,
+                       ctx->partials_b.as<double>(), nbl, nbl);
+  }
+  MH_HIP(hipGetLastError());
+  MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
+  MH_HIP(hipStreamSynchronize(s));
+  const IcpDeviceState* h = ctx->h_state;
+  for (int i = 0; i < 12; i++) T_io[i] = h->T[i];
+  if (n_steps) *n_steps = (int32_t)h->n_solves;
+  if (solver_ok) *solver_ok = (int32_t)h->solver_ok;
+  if (trace) MH_HIP(hipMemcpy(trace, ctx->trace.p, sizeof(mh_gn_step) * p->max_inner_iterations, hipMemcpyDeviceToHost));
+  return MH_OK;
+}
+
+mh_status mh_covariance(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt2pl* pl, int32_t mem, const double T[12],
+                        double findif_xyz, double findif_ang, double cov[36]) {
+  MH_REQUIRE(ctx && T && cov, "null argument");
+  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
+  MH_REQUIRE(findif_xyz > 0 && findif_ang > 0, "finite-difference steps must be > 0");
+  MH_REQUIRE(pose_ok(T), "non-finite pose");
+  const size_t np = pp ? pp->n : 0, nl = pl ? pl->n : 0;
+  for (int i = 0; i < 36; i++) cov[i] = (i % 7 == 0) ? 1e6 : 0.0;
+  if (np + nl == 0) return MH_OK;  // "no pairings -> no estimation": diag(1e6)
+  MH_TRY(set_device(ctx));
+  MH_TRY(ensure_state(ctx));
+  hipStream_t s = ctx->stream;
+  MH_HIP(hipStreamSynchronize(s));
+  size_t sp = 0, sl = 0;
+  if (np) {
+    const float* arrs[3] = {pp->lx, pp->ly, pp->lz};
+    MH_TRY(stage_soa(ctx, ctx->build_a, arrs, 3, np, mem, &sp));
+  }
+  if (nl) {
+    const float* arrs[6] = {pl->lx, pl->ly, pl->lz, pl->nx, pl->ny, pl->nz};
+    MH_TRY(stage_soa(ctx, ctx->build_b, arrs, 6, nl, mem, &sl));
+  }
+  MH_TRY(ensure_pair_buffers(ctx, np));
+  const uint32_t nbp = np ? nblk(np) : 0, nbl = nl ? nblk(nl) : 0;
+  MH_TRY(ctx->partials_b.reserve((size_t)kGenN * (nbl ? nbl : 1) * sizeof(double)));
+  init_state(ctx->h_state, T);
+  MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpDeviceState), hipMemcpyHostToDevice, s));
+  if (np) MH_HIP(hipMemsetAsync(ctx->pair_gidx.p, 0, np * sizeof(uint32_t), s));  // all valid
+  hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, findif_xyz, findif_ang, 1u);
+  const float* L = ctx->build_a.as<float>();
+  const float* P = ctx->build_b.as<float>();
+  if (np)
+    hipLaunchKernelGGL(k_cov_accum, dim3(nbp), dim3(kBlock), 0, s, ctx->d_state, 1u, L, L + sp, L + 2 * sp, (uint32_t)np,
+                       ctx->pair_gidx.as<uint32_t>(), ctx->partials.as<double>(), nbp);
+  if (nl)
+    hipLaunchKernelGGL(k_cov_accum_pl, dim3(nbl), dim3(kBlock), 0, s, ctx->d_state, P, P + 3 * sl, (uint32_t)nl,
+                       (uint32_t)sl, ctx->partials_b.as<double>(), nbl);
+  hipLaunchKernelGGL(k_cov_finalize, dim3(1), dim3(64), 0, s, ctx->d_state, 1u, ctx->partials.as<double>(), nbp, nbp,
+                     ctx->partials_b.as<double>(), nbl, nbl);
+  MH_HIP(hipGetLastError());
+  MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
+  MH_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < 36; i++) cov[i] = ctx->h_state->cov[i];
+  return MH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+// mh_internal.h -- private structures shared by the libmolahip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+
+#include "../../include/molahip.h"
+#include "mh_se3.h"
+
+namespace mh {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+mh_status fail(mh_status s, const char* fmt, ...);
+
+#define MH_HIP(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess)                                                                             \
+      return mh::fail(_e == hipErrorOutOfMemory ? MH_ERR_OUT_OF_MEMORY : MH_ERR_HIP, "%s failed: %s (%s:%d)", \
+                      #expr, hipGetErrorString(_e), __FILE__, __LINE__);                              \
+  } while (0)
+
+#define MH_TRY(expr)               \
+  do {                             \
+    mh_status _s = (expr);         \
+    if (_s != MH_OK) return _s;    \
+  } while (0)
+
+#define MH_REQUIRE(cond, msg)                                                     \
+  do {                                                                            \
+    if (!(cond)) return mh::fail(MH_ERR_INVALID_ARGUMENT, "%s: %s", __func__, msg); \
+  } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  mh_status reserve(size_t need) {
+    if (need <= bytes) return MH_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    size_t cap = need + need / 4 + 256;
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess) return fail(MH_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+    bytes = cap;
+    return MH_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---- map layout in HBM -----------------------------------------------------------------------
+// One 16-byte slot per hash bucket: a single dwordx4 load answers "is voxel (kx,ky,kz) occupied,
+// and where are its points".  key packs 3 x 21-bit biased voxel indices; ~0 = empty.
+struct alignas(16) MapSlot {
+  unsigned long long key;
+  uint32_t first;  // index of the voxel's first point record
+  uint32_t count;  // number of point records (<= max_points_per_voxel)
+};
+static_assert(sizeof(MapSlot) == 16, "slot must be one dwordx4");
+
+constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr int kKeyBias = 1 << 20;
+
+struct MapView {
+  const MapSlot* slots;
+  const float4* pts;  // {x,y,z, bit-cast source index}, voxel-contiguous
+  uint32_t mask;      // table_size - 1
+  float inv_vs;
+  uint32_t trunc;     // index_mode == MH_INDEX_TRUNC
+};
+
+__host__ __device__ inline unsigned long long pack_key(int kx, int ky, int kz) {
+  return ((unsigned long long)(unsigned)(kx + kKeyBias) << 42) | ((unsigned long long)(unsigned)(ky + kKeyBias) << 21) |
+         (unsigned long long)(unsigned)(kz + kKeyBias);
+}
+__host__ __device__ inline void unpack_key(unsigned long long k, int& kx, int& ky, int& kz) {
+  kx = (int)((k >> 42) & 0x1FFFFF) - kKeyBias;
+  ky = (int)((k >> 21) & 0x1FFFFF) - kKeyBias;
+  kz = (int)(k & 0x1FFFFF) - kKeyBias;
+}
+__host__ __device__ inline uint32_t hash_key(unsigned long long k) {
+  return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 32);
+}
+__host__ __device__ inline bool key_in_range(int k) { return k > -kKeyBias + 1 && k < kKeyBias - 2; }
+
+}  // namespace mh
+
+// ---- opaque handle bodies ---------------------------------------------------------------------
+struct IcpDeviceState;  // mh_icp.hip
+
+struct mh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // scratch (grow-only), all on `device`
+  mh::DevBuf pair_q;      // float4 per scan point: NN point xyz + d2
+  mh::DevBuf pair_gidx;   // uint32 per scan point: source index or 0xFFFFFFFF
+  mh::DevBuf partials;    // per-block reduction partials (double)
+  mh::DevBuf partials_b;  // generic (pt2pl) partials
+  mh::DevBuf sched;       // threshold / kernel-param arrays (double)
+  mh::DevBuf trace;       // mh_icp_iter[max_iterations]
+  mh::DevBuf compact;     // compaction scratch (block counts / offsets) and staged outputs
+  mh::DevBuf staging;     // generic staging for host<->device array transfers
+  mh::DevBuf sort_tmp;    // rocprim temporary storage
+  mh::DevBuf build_a, build_b, build_c, build_d, build_e;  // map build scratch
+  IcpDeviceState* d_state = nullptr;
+  IcpDeviceState* h_state = nullptr;  // pinned mirror
+  hipEvent_t ev_poll = nullptr;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+  // profiling events for the match kernel (pairs), created lazily
+  hipEvent_t* prof_ev = nullptr;
+  uint32_t prof_cap = 0;
+};
+
+struct mh_map {
+  mh_ctx* ctx = nullptr;
+  mh_map_params params{};
+  float inv_vs = 1.f;
+  mh::DevBuf slots;      // MapSlot[table_size]
+  mh::DevBuf pts;        // float4[n_points]
+  mh::DevBuf vox_keys;   // uint64[n_voxels], ascending
+  mh::DevBuf vox_first;  // uint32[n_voxels]
+  mh::DevBuf vox_count;  // uint32[n_voxels]
+  uint64_t n_points = 0, n_offered = 0, n_voxels = 0, table_size = 0;
+  float bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
+  mh::MapView view() const {
+    mh::MapView v;
+    v.slots = slots.as<mh::MapSlot>();
+    v.pts = pts.as<float4>();
+    v.mask = (uint32_t)(table_size ? table_size - 1 : 0);
+    v.inv_vs = inv_vs;
+    v.trunc = params.index_mode == MH_INDEX_TRUNC;
+    return v;
+  }
+};
+
+struct mh_scan {
+  mh_ctx* ctx = nullptr;
+  mh::DevBuf xyz;  // own storage: x[n] | y[n] | z[n] (SoA, 256-byte aligned sections)
+  const float *x = nullptr, *y = nullptr, *z = nullptr;  // device pointers actually used
+  size_t n = 0;
+};
+
+namespace mh {
+mh_status set_device(const mh_ctx* ctx);
+// copy `n` elements of a caller array living in `mem` into device scratch (returns device ptr)
+mh_status stage_in(mh_ctx* ctx, DevBuf& buf, size_t offset_bytes, const void* src, size_t bytes, int32_t mem);
+}  // namespace mh

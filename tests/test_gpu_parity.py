@@ -1,0 +1,399 @@
+"""-m gpu: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Bars (north_star): bit-exact for the integer/index work (voxel contents, NN indices, fp32 d^2,
+pair counts, termination); fp64 solver quantities to ~1e-9 relative; final poses far inside the
+1e-4 m / 1e-4 rad tolerance (asserted at 1e-7)."""
+import numpy as np
+import pytest
+
+from mola_lidar_odometry_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+I12 = np.eye(4)[:3].reshape(12)
+POSE_TOL = 1e-7  # north_star allows 1e-4 m / 1e-4 rad; we hold the same iterates to 1e-7
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def small(ctx, oracle, small_workload):
+    w = small_workload
+    gm = capi.Map(ctx, w.voxel_size, w.cap).build(w.map_xyz)
+    om = oracle.Map(w.voxel_size, w.cap).insert(w.map_xyz)
+    gs = capi.Scan(ctx, w.scan_xyz)
+    return w, gm, om, gs
+
+
+def assert_maps_equal(g, o):
+    np.testing.assert_array_equal(g["vox_keys"], o["vox_keys"])
+    np.testing.assert_array_equal(g["vox_first"], o["vox_first"])
+    np.testing.assert_array_equal(g["vox_count"], o["vox_count"])
+    np.testing.assert_array_equal(g["src_idx"], o["src_idx"])
+    np.testing.assert_array_equal(g["xyz"], o["xyz"])
+
+
+# ---------------------------------------------------------------------------- map build
+@pytest.mark.parametrize("vs,cap,mode", [(1.0, 20, 0), (0.5, 3, 0), (1.7, 0, 0), (1.0, 20, 1), (0.25, 1, 0)])
+def test_map_build_bit_exact(ctx, oracle, vs, cap, mode):
+    rng = np.random.default_rng(int(vs * 100) + cap)
+    pts = np.concatenate([rng.normal(0, 6, (30000, 3)), rng.uniform(-0.5, 0.5, (5000, 3))]).astype(np.float32)
+    pts[17] = [np.nan, 0, 0]
+    pts[99] = [0, np.inf, 0]
+    g = capi.Map(ctx, vs, cap, mode).build(pts)
+    o = oracle.Map(vs, cap, mode).insert(pts)
+    i = g.info()
+    assert (i.n_points, i.n_voxels, i.n_offered) == (o.num_points, o.num_voxels, len(pts))
+    assert_maps_equal(g.download(), o.dump())
+    mn, mx = o.bbox()
+    np.testing.assert_array_equal(np.array(i.bbox_min), mn)
+    np.testing.assert_array_equal(np.array(i.bbox_max), mx)
+    assert i.table_size >= 2 * i.n_voxels and (i.table_size & (i.table_size - 1)) == 0
+
+
+def test_map_rebuild_and_empty(ctx, oracle):
+    g = capi.Map(ctx, 1.0, 20)
+    assert g.info().n_points == 0 and g.info().n_voxels == 0
+    g.build(np.random.default_rng(0).normal(0, 3, (1000, 3)))
+    n1 = g.info().n_points
+    g.build(np.zeros((0, 3), np.float32))
+    assert g.info().n_points == 0
+    pts = np.random.default_rng(1).normal(0, 3, (2000, 3)).astype(np.float32)
+    g.build(pts)
+    assert_maps_equal(g.download(), oracle.Map(1.0, 20).insert(pts).dump())
+    assert n1 > 0
+
+
+def test_map_out_of_range_is_an_error(ctx):
+    g = capi.Map(ctx, 0.001, 20)
+    with pytest.raises(capi.MolahipError) as e:
+        g.build(np.array([[0, 0, 0], [5000.0, 0, 0]], np.float32))
+    assert e.value.status == 4
+
+
+def test_map_build_from_device_pointers(ctx, oracle):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(5)
+    pts = rng.normal(0, 5, (5000, 3)).astype(np.float32)
+    t = [torch.from_numpy(np.ascontiguousarray(pts[:, i])).cuda() for i in range(3)]
+    torch.cuda.synchronize()
+    g = capi.Map(ctx, 1.0, 20).build_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), len(pts))
+    assert_maps_equal(g.download(), oracle.Map(1.0, 20).insert(pts).dump())
+
+
+# ---------------------------------------------------------------------------- NN / matcher
+def test_nn_dense_bit_exact(ctx, oracle, small):
+    w, gm, om, gs = small
+    d = capi.nn_search_dense(gm, gs, w.T_guess)
+    big = oracle.match_points(om, w.scan_xyz, w.T_guess, 1e9)  # no threshold: everything found pairs
+    found = d["global_idx"] != capi.NO_MATCH
+    np.testing.assert_array_equal(np.nonzero(found)[0], big["local_idx"])
+    np.testing.assert_array_equal(d["global_idx"][found], big["global_idx"])
+    np.testing.assert_array_equal(d["d2"][found], big["d2"])
+    np.testing.assert_array_equal(d["global_xyz"][found], big["global_xyz"])
+
+
+@pytest.mark.parametrize("thr,ang", [(8.0, 0.0), (0.6, 0.0), (0.3, 0.5), (0.05, 0.0)])
+def test_nn_search_compacted_bit_exact(ctx, oracle, small, thr, ang):
+    w, gm, om, gs = small
+    for T in (w.T_guess, w.T_gt):
+        g = capi.nn_search(gm, gs, T, thr, ang)
+        o = oracle.match_points(om, w.scan_xyz, T, thr, ang)
+        for k in ("local_idx", "global_idx", "d2", "global_xyz"):
+            np.testing.assert_array_equal(g[k], o[k])
+        assert g["potential_pairings"] == o["potential_pairings"] == len(w.scan_xyz)
+
+
+def test_nn_random_clouds_and_ragged_sizes(ctx, oracle):
+    rng = np.random.default_rng(3)
+    pts = rng.normal(0, 4, (20000, 3)).astype(np.float32)
+    gm = capi.Map(ctx, 0.8, 7).build(pts)
+    om = oracle.Map(0.8, 7).insert(pts)
+    T = oracle.se3_exp([0.3, -0.2, 0.1, 0.02, -0.01, 0.03])
+    for n in (1, 63, 64, 65, 255, 257, 1000, 4097):
+        q = rng.normal(0, 4, (n, 3)).astype(np.float32)
+        gs = capi.Scan(ctx, q)
+        g = capi.nn_search(gm, gs, T, 0.9)
+        o = oracle.match_points(om, q, T, 0.9)
+        for k in ("local_idx", "global_idx", "d2"):
+            np.testing.assert_array_equal(g[k], o[k])
+
+
+def test_nn_nonfinite_queries_and_empty_inputs(ctx, oracle):
+    pts = np.random.default_rng(2).normal(0, 2, (500, 3)).astype(np.float32)
+    gm = capi.Map(ctx, 1.0, 20).build(pts)
+    q = np.array([[0.1, 0.2, 0.3], [np.nan, 0, 0], [0, np.inf, 0], [100, 100, 100]], np.float32)
+    g = capi.nn_search(gm, capi.Scan(ctx, q), I12, 5.0)
+    assert g["local_idx"].tolist() == [0]
+    # empty scan / empty map
+    g = capi.nn_search(gm, capi.Scan(ctx, np.zeros((0, 3), np.float32)), I12, 5.0)
+    assert len(g["local_idx"]) == 0 and g["potential_pairings"] == 0
+    g = capi.nn_search(capi.Map(ctx, 1.0, 20), capi.Scan(ctx, q), I12, 5.0)
+    assert len(g["local_idx"]) == 0 and g["potential_pairings"] == 4
+
+
+def test_nn_voxel_boundary_and_negative_coords(ctx, oracle):
+    pts = np.array([[-0.2, 0.5, 0.5], [0.2, 0.5, 0.5], [-1.0, 0.0, 0.0], [2.9, 0.5, 0.5]], np.float32)
+    q = np.array([[0.0, 0.5, 0.5], [-1.0, 0.0, 0.0], [1.0, 0.5, 0.5], [-0.0, 0.5, 0.5], [0.999999, 0.5, 0.5]], np.float32)
+    for mode in (0, 1):
+        gm = capi.Map(ctx, 1.0, 20, mode).build(pts)
+        om = oracle.Map(1.0, 20, mode).insert(pts)
+        g = capi.nn_search(gm, capi.Scan(ctx, q), I12, 10.0)
+        o = oracle.match_points(om, q, I12, 10.0)
+        for k in ("local_idx", "global_idx", "d2"):
+            np.testing.assert_array_equal(g[k], o[k])
+
+
+# ---------------------------------------------------------------------------- solver
+def _pairs(rng, n, noise=0.05):
+    l = rng.normal(0, 10, (n, 3)).astype(np.float32)
+    Tt = np.asarray(__import__("oracle.oracle_c", fromlist=["x"]).se3_exp(
+        np.concatenate([rng.normal(0, 0.3, 3), rng.normal(0, 0.03, 3)]))).reshape(3, 4)
+    q = (l.astype(np.float64) @ Tt[:, :3].T + Tt[:, 3] + rng.normal(0, noise, (n, 3))).astype(np.float32)
+    return l, q
+
+
+def _planes(rng, n):
+    l = rng.normal(0, 10, (n, 3)).astype(np.float32)
+    nn = rng.normal(0, 1, (n, 3))
+    nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+    return l, (l + rng.normal(0, 0.2, (n, 3))).astype(np.float32), nn.astype(np.float32)
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("with_planes", [False, True])
+def test_gn_solve_matches_oracle(ctx, oracle, kernel, with_planes):
+    rng = np.random.default_rng(10 + kernel)
+    l, q = _pairs(rng, 3001)
+    pl = _planes(rng, 777) if with_planes else None
+    T0 = oracle.se3_exp([0.1, -0.05, 0.02, 0.01, -0.02, 0.005])
+    gp = capi.GNParams(max_inner_iterations=3, robust_kernel=kernel, robust_kernel_param=0.7)
+    op = oracle.GNParams(max_inner_iterations=3, robust_kernel=kernel, robust_kernel_param=0.7)
+    Tg, ng, ok, sg = capi.gn_solve(ctx, T0, (l, q), pl, gp)
+    To, no, so = oracle.gn_solve(T0, (l, q), pl, op)
+    assert ok and ng == no == 3
+    for a, b in zip(sg, so):
+        scale = np.abs(b["H"]).max()
+        np.testing.assert_allclose(a["H"], b["H"], rtol=1e-10, atol=1e-12 * scale)
+        np.testing.assert_allclose(a["g"], b["g"], rtol=1e-9, atol=1e-11 * np.abs(b["g"]).max())
+        np.testing.assert_allclose(a["err_norm_sqr"], b["err_norm_sqr"], rtol=1e-12)
+        np.testing.assert_allclose(a["delta"], b["delta"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(Tg, To, atol=1e-11)
+
+
+def test_gn_solve_prior_and_planes_only(ctx, oracle):
+    rng = np.random.default_rng(4)
+    l = np.stack([rng.uniform(-10, 10, 300), rng.uniform(-10, 10, 300), np.full(300, 0.1)], 1).astype(np.float32)
+    c = l.copy(); c[:, 2] = 0
+    nn = np.tile(np.array([0, 0, 1], np.float32), (300, 1))
+    Tp = oracle.se3_exp([0.05, -0.02, 0.0, 0, 0, 0.01])
+    Lam = np.diag([10, 10, 10, 100, 100, 100.0])
+    gp = capi.GNParams(max_inner_iterations=2, robust_kernel=0)
+    op = oracle.GNParams(max_inner_iterations=2, robust_kernel=0)
+    Tg, ng, ok, sg = capi.gn_solve(ctx, I12, None, (l, c, nn), gp, prior=(Tp, Lam))
+    To, no, so = oracle.gn_solve(I12, None, (l, c, nn), op, prior=(Tp, Lam))
+    assert ok and ng == no
+    np.testing.assert_allclose(sg[0]["H"], so[0]["H"], rtol=1e-8, atol=1e-7)
+    np.testing.assert_allclose(sg[0]["g"], so[0]["g"], rtol=1e-8, atol=1e-7)
+    np.testing.assert_allclose(Tg, To, atol=1e-10)
+    # rank-deficient without prior: finite output, same as the oracle's pivoted LDLT
+    Tg2, ng2, ok2, _ = capi.gn_solve(ctx, I12, None, (l, c, nn), gp)
+    To2, no2, _ = oracle.gn_solve(I12, None, (l, c, nn), op)
+    assert np.all(np.isfinite(Tg2))
+    if no2 >= 0 and ok2:
+        np.testing.assert_allclose(Tg2, To2, atol=1e-8)
+
+
+def test_gn_solve_empty_and_identity(ctx, oracle):
+    e = np.zeros((0, 3), np.float32)
+    Tg, n, ok, _ = capi.gn_solve(ctx, I12, (e, e), None, capi.GNParams())
+    assert n == 0 and ok and np.array_equal(Tg, I12)
+    l = np.random.default_rng(0).normal(0, 5, (100, 3)).astype(np.float32)
+    Tg, n, ok, _ = capi.gn_solve(ctx, I12, (l, l), None, capi.GNParams())
+    assert n == 0 and np.array_equal(Tg, I12)  # zero cost: early exit before any solve
+
+
+def test_covariance_matches_oracle(ctx, oracle):
+    rng = np.random.default_rng(9)
+    l, q = _pairs(rng, 5000)
+    pl = _planes(rng, 500)
+    T = oracle.se3_exp([0.3, 0.1, -0.2, 0.05, -0.02, 0.4])
+    for args in (((l, q), None), ((l, q), pl), (None, pl)):
+        cg = capi.covariance(ctx, T, *args)
+        co, _ = oracle.covariance(T, *args)
+        np.testing.assert_allclose(cg, co, rtol=2e-5, atol=1e-6 * np.abs(co).max())
+    e = np.zeros((0, 3), np.float32)
+    np.testing.assert_array_equal(capi.covariance(ctx, T, (e, e), None), np.eye(6) * 1e6)
+
+
+# ---------------------------------------------------------------------------- fused align
+def _params(mod, w, n_it=None, **kw):
+    n_it = n_it or w.n_iters
+    thr, kp = synth.threshold_schedule(w.sigma, n_it)
+    return mod.ICPParams(max_iterations=n_it, threshold=thr, kernel_param=kp, **kw)
+
+
+def assert_align_equal(g, o, pose_tol=POSE_TOL):
+    assert g["n_iterations"] == o["n_iterations"]
+    assert capi.TERM_NAMES[g["termination_reason"]] == capi.TERM_NAMES[o["termination_reason"]]
+    assert g["n_final_pairs"] == o["n_final_pairs"]
+    assert g["potential_pairings"] == o["potential_pairings"]
+    assert g["quality"] == o["quality"]
+    np.testing.assert_allclose(g["T"], o["T"], atol=pose_tol, rtol=0)
+
+
+def test_align_fixed_iterations_matches_oracle_with_trace(ctx, oracle, small):
+    w, gm, om, gs = small
+    g = capi.icp_align(gm, gs, w.T_guess, _params(capi, w, disable_stall_test=True), want_pairs=True)
+    o = oracle.icp_align(om, w.scan_xyz, w.T_guess, _params(oracle, w, disable_stall_test=True), want_pairs=True)
+    assert_align_equal(g, o, 1e-9)
+    assert len(g["trace"]) == len(o["trace"]) == w.n_iters
+    for a, b in zip(g["trace"], o["trace"]):
+        assert a["n_pairs"] == b["n_pairs"] and a["threshold"] == b["threshold"]
+        np.testing.assert_allclose(a["T"], b["T"], atol=1e-9)
+        np.testing.assert_allclose([a["delta_trans"], a["delta_rot"]], [b["delta_trans"], b["delta_rot"]], atol=1e-9)
+    for k in ("local_idx", "global_idx", "d2", "global_xyz"):
+        np.testing.assert_array_equal(g["pairs"][k], o["pairs"][k])
+    np.testing.assert_allclose(g["cov"], o["cov"], rtol=2e-5, atol=1e-6 * np.abs(o["cov"]).max())
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5])
+def test_align_all_kernels(ctx, oracle, small, kernel):
+    w, gm, om, gs = small
+    g = capi.icp_align(gm, gs, w.T_guess, _params(capi, w, 8, disable_stall_test=True,
+                                                  gn=capi.GNParams(robust_kernel=kernel)))
+    o = oracle.icp_align(om, w.scan_xyz, w.T_guess, _params(oracle, w, 8, disable_stall_test=True,
+                                                            gn=oracle.GNParams(robust_kernel=kernel)))
+    assert_align_equal(g, o)
+
+
+@pytest.mark.parametrize("inner", [1, 2, 4])
+def test_align_inner_iterations(ctx, oracle, small, inner):
+    w, gm, om, gs = small
+    g = capi.icp_align(gm, gs, w.T_guess, _params(capi, w, 6, disable_stall_test=True,
+                                                  gn=capi.GNParams(max_inner_iterations=inner)))
+    o = oracle.icp_align(om, w.scan_xyz, w.T_guess, _params(oracle, w, 6, disable_stall_test=True,
+                                                            gn=oracle.GNParams(max_inner_iterations=inner)))
+    assert_align_equal(g, o)
+
+
+@pytest.mark.parametrize("poll", [1, 3, 7, 64])
+def test_align_stall_termination_any_poll_interval(ctx, oracle, small, poll):
+    """yaml defaults: maxIterations 300, stall thresholds 1e-4 / 5e-5 (lidar3d-default.yaml:173-175).  The
+    termination iteration must equal the oracle's exactly whatever the host polling interval."""
+    w, gm, om, gs = small
+    g = capi.icp_align(gm, gs, w.T_guess, _params(capi, w, 300, poll_every=poll))
+    o = oracle.icp_align(om, w.scan_xyz, w.T_guess, _params(oracle, w, 300))
+    assert_align_equal(g, o)
+    assert capi.TERM_NAMES[g["termination_reason"]] in ("Stalled", "MaxIterations")
+    assert len(g["trace"]) == len(o["trace"])
+
+
+def test_align_hook_request(ctx, oracle, small):
+    w, gm, om, gs = small
+    kw = dict(disable_stall_test=True, hook_enabled=True, hook_min_trans=0.15, hook_min_rot=float(np.deg2rad(0.75)))
+    g = capi.icp_align(gm, gs, w.T_guess, _params(capi, w, **kw))
+    o = oracle.icp_align(om, w.scan_xyz, w.T_guess, _params(oracle, w, **kw))
+    assert capi.TERM_NAMES[g["termination_reason"]] == "HookRequest"
+    assert_align_equal(g, o)
+    # the caller's protocol (LidarOdometry.cpp:956-1007): re-run from the checkpoint with the remaining budget
+    rem = w.n_iters - g["n_iterations"]
+    g2 = capi.icp_align(gm, gs, g["T"], _params(capi, w, rem, **kw))
+    o2 = oracle.icp_align(om, w.scan_xyz, o["T"], _params(oracle, w, rem, **kw))
+    assert_align_equal(g2, o2)
+
+
+def test_align_with_prior(ctx, oracle, small):
+    w, gm, om, gs = small
+    Lam = np.diag([50, 50, 50, 500, 500, 500.0])
+    prior = (w.T_guess, Lam)
+    g = capi.icp_align(gm, gs, w.T_guess, _params(capi, w, 10, disable_stall_test=True), prior=prior)
+    o = oracle.icp_align(om, w.scan_xyz, w.T_guess, _params(oracle, w, 10, disable_stall_test=True), prior=prior)
+    assert_align_equal(g, o)
+    free = capi.icp_align(gm, gs, w.T_guess, _params(capi, w, 10, disable_stall_test=True))
+    assert np.linalg.norm(free["T"] - g["T"]) > 1e-4  # the prior does act
+
+
+def test_align_no_pairings_and_trivial_inputs(ctx, oracle):
+    gm = capi.Map(ctx, 1.0, 20).build(np.zeros((10, 3), np.float32))
+    far = np.full((5, 3), 50.0, np.float32)
+    p = capi.ICPParams(max_iterations=5, threshold=2.0, kernel_param=0.5)
+    g = capi.icp_align(gm, capi.Scan(ctx, far), I12, p)
+    assert capi.TERM_NAMES[g["termination_reason"]] == "NoPairings"
+    assert g["quality"] == 0.0 and g["n_iterations"] == 0 and g["n_final_pairs"] == 0
+    np.testing.assert_array_equal(g["cov"], np.eye(6) * 1e6)
+    np.testing.assert_array_equal(g["T"], I12)
+    # empty scan, max_iterations = 0
+    g = capi.icp_align(gm, capi.Scan(ctx, np.zeros((0, 3), np.float32)), I12, p)
+    assert capi.TERM_NAMES[g["termination_reason"]] == "NoPairings" and g["potential_pairings"] == 0
+    p0 = capi.ICPParams(max_iterations=0, threshold=np.zeros(0), kernel_param=np.zeros(0))
+    g = capi.icp_align(gm, capi.Scan(ctx, far), I12, p0)
+    assert capi.TERM_NAMES[g["termination_reason"]] == "MaxIterations" and g["quality"] == 0.0
+
+
+def test_align_identity_known_answer(ctx, oracle):
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-20, 20, (5000, 3)).astype(np.float32)
+    gm = capi.Map(ctx, 1.0, 20).build(pts)
+    scan = gm.download()["xyz"][::5]
+    g = capi.icp_align(gm, capi.Scan(ctx, scan), I12, capi.ICPParams(max_iterations=10, threshold=2.0, kernel_param=0.5))
+    np.testing.assert_array_equal(g["T"], I12)
+    assert g["quality"] == 1.0 and capi.TERM_NAMES[g["termination_reason"]] == "Stalled" and g["n_iterations"] == 0
+
+
+def test_align_invalid_arguments_are_status_codes(ctx, small):
+    w, gm, om, gs = small
+    bad = w.T_guess.copy(); bad[3] = np.nan
+    with pytest.raises(capi.MolahipError) as e:
+        capi.icp_align(gm, gs, bad, _params(capi, w))
+    assert e.value.status == 1
+    with pytest.raises(capi.MolahipError):
+        capi.icp_align(gm, gs, w.T_guess, _params(capi, w, gn=capi.GNParams(robust_kernel=99)))
+
+
+def test_align_batch_equals_single(ctx, oracle, small):
+    w, gm, om, gs = small
+    ctxs = [capi.Context(0) for _ in range(4)]
+    rng = np.random.default_rng(1)
+    scans, guesses, singles = [], [], []
+    p = _params(capi, w, 300)
+    for c in ctxs:
+        sub = w.scan_xyz[rng.permutation(len(w.scan_xyz))[:1500]]
+        guess = w.T_guess.copy(); guess[[3, 7]] += rng.normal(0, 0.1, 2)
+        scans.append(capi.Scan(c, sub)); guesses.append(guess)
+        singles.append(capi.icp_align(gm, capi.Scan(ctx, sub), guess, p, want_trace=False))
+    batch = capi.icp_align_batch([gm] * 4, scans, guesses, p)
+    for b, s in zip(batch, singles):
+        assert b["n_iterations"] == s["n_iterations"] and b["termination_reason"] == s["termination_reason"]
+        np.testing.assert_array_equal(b["T"], s["T"])  # bitwise: deterministic reductions
+        np.testing.assert_array_equal(b["cov"], s["cov"])
+
+
+def test_align_is_bitwise_reproducible(ctx, small):
+    w, gm, om, gs = small
+    p = _params(capi, w, disable_stall_test=True)
+    a = capi.icp_align(gm, gs, w.T_guess, p, want_trace=False)
+    b = capi.icp_align(gm, gs, w.T_guess, p, want_trace=False)
+    np.testing.assert_array_equal(a["T"], b["T"])
+    np.testing.assert_array_equal(a["cov"], b["cov"])
+
+
+def test_scan_update_reuses_handle(ctx, oracle, small):
+    w, gm, om, gs = small
+    s = capi.Scan(ctx, w.scan_xyz[:100])
+    s.update(w.scan_xyz[:1777])
+    assert len(s) == 1777
+    g = capi.nn_search(gm, s, w.T_guess, 1.0)
+    o = oracle.match_points(om, w.scan_xyz[:1777], w.T_guess, 1.0)
+    np.testing.assert_array_equal(g["global_idx"], o["global_idx"])
+
+
+def test_profile_fields(ctx, small):
+    w, gm, om, gs = small
+    r = capi.icp_align(gm, gs, w.T_guess, _params(capi, w, disable_stall_test=True, profile=True), want_trace=False)
+    assert r["n_match_launches"] == w.n_iters and r["match_kernel_ms"] > 0 and r["total_ms"] >= r["match_kernel_ms"]
