@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -144,6 +145,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise OSError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64; if torch is going
+        # to be used in this process (bench.py, device-pointer interop) it must be loaded FIRST so that
+        # libmolahip binds to the same runtime -- otherwise the second runtime finds "no HIP GPUs".
+        try:
+            import torch  # noqa: F401  (plumbing only; libmolahip itself does not depend on torch)
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
@@ -191,6 +199,7 @@ class Context:
         self._h = C.c_void_p()
         _chk(lib().mh_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.device = device
+        self._children = weakref.WeakSet()  # maps/scans must be destroyed before their context (C-ABI rule)
 
     def synchronize(self):
         _chk(lib().mh_ctx_synchronize(self._h))
@@ -203,6 +212,8 @@ class Context:
 
     def close(self):
         if self._h:
+            for child in list(self._children):
+                child.close()
             lib().mh_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -221,6 +232,7 @@ class Map:
         self._h = C.c_void_p()
         p = MapParams(voxel_size, max_points_per_voxel, index_mode, 0)
         _chk(lib().mh_map_create(ctx._h, C.byref(p), C.byref(self._h)))
+        ctx._children.add(self)
 
     def build(self, xyz):
         x, y, z = _soa(xyz)
@@ -276,6 +288,7 @@ class Scan:
             x, y, z = _soa(xyz)
             _chk(lib().mh_scan_create(ctx._h, _vp(x), _vp(y), _vp(z), len(x), MEM_HOST, C.byref(self._h)))
             self.n = len(x)
+        ctx._children.add(self)
 
     @classmethod
     def from_torch(cls, ctx: Context, x, y, z):

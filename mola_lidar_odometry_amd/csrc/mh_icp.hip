@@ -217,26 +217,56 @@ __global__ __launch_bounds__(kBlock) void k_accum_pl(const IcpDeviceState* __res
 // k_solve: one wave.  Ordered reduction of the block partials, prior factor, LDL^T solve, SE(3)
 // retraction, inner/outer loop bookkeeping (optimal_tf_gauss_newton + the tail of ICP::align's loop).
 // ================================================================================================
-__global__ __launch_bounds__(64) void k_solve(IcpDeviceState* __restrict__ st, SolveK k, const double* __restrict__ partA,
-                                              uint32_t nA, uint32_t strideA, const double* __restrict__ partB,
-                                              uint32_t nB, uint32_t strideB) {
+constexpr int kSolveThreads = 512;  // 2 waves per SIMD -> 256 VGPRs for the serial 6x6 code of thread 0
+
+// Ordered sum of `nvals` rows of a [nvals][stride] array of per-block partials over n blocks, by the
+// whole block: G = blockDim/nvals lanes per row, 8 independent loads in flight per lane, then
+// a fixed-order LDS pass.  Shape depends only on (n, nvals) -> bitwise reproducible.
+__device__ __forceinline__ void reduce_rows(const double* __restrict__ part, uint32_t n, uint32_t stride, int nvals,
+                                            double* __restrict__ out, double (*red)[64]) {
+  const int t = threadIdx.x;
+  int G = kSolveThreads / nvals;
+  if (G > 64) G = 64;
+  const int v = t / G, g = t % G;
+  if (v < nvals) {
+    const double* __restrict__ src = part + (size_t)v * stride;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+    uint32_t b = g;
+    for (; b + 7u * G < n; b += 8u * G) {  // 8 independent loads in flight per lane
+      const double v0 = src[b], v1 = src[b + G], v2 = src[b + 2u * G], v3 = src[b + 3u * G];
+      const double v4 = src[b + 4u * G], v5 = src[b + 5u * G], v6 = src[b + 6u * G], v7 = src[b + 7u * G];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
+    }
+    for (; b < n; b += G) s0 += src[b];
+    red[v][g] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+  }
+  __syncthreads();
+  if (t < nvals) {
+    double acc = 0.0;
+    for (int q = 0; q < G; q++) acc += red[t][q];
+    out[t] = acc;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restrict__ st, SolveK k,
+                                                         const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
+                                                         const double* __restrict__ partB, uint32_t nB,
+                                                         uint32_t strideB) {
+  __shared__ double red[kGenN][64];
+  __shared__ double totA[kAccN], totB[kGenN];
   __shared__ double sh_log[13][6];
   if (st->done) return;
   const int lane = threadIdx.x;
-  double a[kAccN];
+  if (nA)
+    reduce_rows(partA, nA, strideA, kAccN, totA, red);
+  if (nB)
+    reduce_rows(partB, nB, strideB, kGenN, totB, red);
+  double a[kAccN], gen[kGenN];
 #pragma unroll
-  for (int i = 0; i < kAccN; i++) {
-    double s = 0.0;
-    for (uint32_t b = lane; b < nA; b += 64) s += partA[i * strideA + b];
-    a[i] = wave_sum(s);
-  }
-  double gen[kGenN];
+  for (int i = 0; i < kAccN; i++) a[i] = nA ? totA[i] : 0.0;
 #pragma unroll
-  for (int i = 0; i < kGenN; i++) {
-    double s = 0.0;
-    for (uint32_t b = lane; b < nB; b += 64) s += partB[i * strideB + b];
-    gen[i] = nB ? wave_sum(s) : 0.0;
-  }
+  for (int i = 0; i < kGenN; i++) gen[i] = nB ? totB[i] : 0.0;
   Pose Tc;
 #pragma unroll
   for (int i = 0; i < 12; i++) Tc.m[i] = st->T[i];
@@ -249,10 +279,13 @@ __global__ __launch_bounds__(64) void k_solve(IcpDeviceState* __restrict__ st, S
     const Pose D = compose(Pinv, Tc);
     if (lane < 13) {
       double xi[6] = {0, 0, 0, 0, 0, 0};
-      if (lane < 12) xi[lane >> 1] = (lane & 1) ? -1e-6 : 1e-6;
+#pragma unroll
+      for (int j = 0; j < 6; j++)
+        if (lane < 12 && (lane >> 1) == j) xi[j] = (lane & 1) ? -1e-6 : 1e-6;
       const Pose Dp = compose(D, se3_exp(xi));
       double lg[6];
       se3_log(Dp, lg);
+#pragma unroll
       for (int i = 0; i < 6; i++) sh_log[lane][i] = lg[i];
     }
     __syncthreads();
@@ -500,21 +533,20 @@ __global__ __launch_bounds__(kBlock) void k_cov_accum_pl(const IcpDeviceState* _
         ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
 }
 
-__global__ __launch_bounds__(64) void k_cov_finalize(IcpDeviceState* __restrict__ st, uint32_t force,
-                                                     const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
-                                                     const double* __restrict__ partB, uint32_t nB, uint32_t strideB) {
+__global__ __launch_bounds__(kSolveThreads) void k_cov_finalize(IcpDeviceState* __restrict__ st, uint32_t force,
+                                                                const double* __restrict__ partA, uint32_t nA,
+                                                                uint32_t strideA, const double* __restrict__ partB,
+                                                                uint32_t nB, uint32_t strideB) {
+  __shared__ double red[kCovN][64];
+  __shared__ double totA[kCovN], totB[kCovN];
   if (!force && (!st->done || st->cov_done)) return;
   const int lane = threadIdx.x;
+  if (nA) reduce_rows(partA, nA, strideA, kCovN, totA, red);
+  if (nB) reduce_rows(partB, nB, strideB, kCovN, totB, red);
+  if (lane != 0) return;
   double a[kCovN];
 #pragma unroll
-  for (int i = 0; i < kCovN; i++) {
-    double s = 0.0;
-    for (uint32_t b = lane; b < nA; b += 64) s += partA[i * strideA + b];
-    double t = 0.0;
-    for (uint32_t b = lane; b < nB; b += 64) t += partB[i * strideB + b];
-    a[i] = wave_sum(s) + (nB ? wave_sum(t) : 0.0);
-  }
-  if (lane != 0) return;
+  for (int i = 0; i < kCovN; i++) a[i] = (nA ? totA[i] : 0.0) + (nB ? totB[i] : 0.0);
   double AtA[36], cov[36];
   int q = 0;
   for (int r = 0; r < 6; r++)
@@ -822,11 +854,11 @@ struct AlignJob {
         MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));
         prof_n++;
       }
-      hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, ctx->d_state, sk, part, nb, nb, (const double*)nullptr, 0u, 0u);
+      hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, sk, part, nb, nb, (const double*)nullptr, 0u, 0u);
       for (uint32_t in = 1; in < p->gn.max_inner_iterations; in++) {
         hipLaunchKernelGGL(k_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, mk, 0.0, 0u, scan->x, scan->y, scan->z,
                            n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nb);
-        hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, ctx->d_state, sk, part, nb, nb, (const double*)nullptr, 0u,
+        hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, sk, part, nb, nb, (const double*)nullptr, 0u,
                            0u);
       }
     }
@@ -835,7 +867,7 @@ struct AlignJob {
       hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, p->cov_findif_xyz, p->cov_findif_ang, 0u);
       hipLaunchKernelGGL(k_cov_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, scan->x, scan->y, scan->z, n,
                          ctx->pair_gidx.as<uint32_t>(), part, nb);
-      hipLaunchKernelGGL(k_cov_finalize, dim3(1), dim3(64), 0, s, ctx->d_state, 0u, part, nb, nb, (const double*)nullptr,
+      hipLaunchKernelGGL(k_cov_finalize, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, 0u, part, nb, nb, (const double*)nullptr,
                          0u, 0u);
     }
     MH_HIP(hipGetLastError());
@@ -1100,7 +1132,7 @@ mh_status mh_gn_solve(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt2p
       hipLaunchKernelGGL(k_accum_pl, dim3(nbl), dim3(kBlock), 0, s, ctx->d_state, p->robust_kernel,
                          p->robust_kernel_param, p->weight_pt2pl, P, P + 3 * sl, P + 6 * sl, (uint32_t)nl, (uint32_t)sl,
                          ctx->partials_b.as<double>(), nbl);
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, ctx->d_state, sk, ctx->partials.as<double>(), nbp, nbp,
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, sk, ctx->partials.as<double>(), nbp, nbp,
                        ctx->partials_b.as<double>(), nbl, nbl);
   }
   MH_HIP(hipGetLastError());
@@ -1151,7 +1183,7 @@ mh_status mh_covariance(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt
   if (nl)
     hipLaunchKernelGGL(k_cov_accum_pl, dim3(nbl), dim3(kBlock), 0, s, ctx->d_state, P, P + 3 * sl, (uint32_t)nl,
                        (uint32_t)sl, ctx->partials_b.as<double>(), nbl);
-  hipLaunchKernelGGL(k_cov_finalize, dim3(1), dim3(64), 0, s, ctx->d_state, 1u, ctx->partials.as<double>(), nbp, nbp,
+  hipLaunchKernelGGL(k_cov_finalize, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, 1u, ctx->partials.as<double>(), nbp, nbp,
                      ctx->partials_b.as<double>(), nbl, nbl);
   MH_HIP(hipGetLastError());
   MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));

@@ -9,6 +9,11 @@ namespace mh {
 
 constexpr uint32_t kNoMatch = 0xFFFFFFFFu;
 
+// native clang vectors: a plain dwordx4 load into registers (HIP's uint4/float4 are union structs whose
+// copies become memcpy's that keep arrays of them in scratch memory)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // p' = (float)(R*l + t): double pose x float point, rounded once to float
 // (Matcher_Points_Base::transform_local_to_global [U] -> CPose3D::composePoint; SURVEY App.B U4)
 __device__ __forceinline__ void transform_point(const double* __restrict__ T, float lx, float ly, float lz, float& gx,
@@ -25,7 +30,7 @@ __device__ __forceinline__ int voxel_of(float c, float inv_vs, uint32_t trunc) {
 }
 
 struct NNResult {
-  float4 pt;  // nearest map point {x,y,z,src}
+  f32x4 pt;   // nearest map point {x,y,z,src}
   float d2;
   bool found;
 };
@@ -33,53 +38,96 @@ struct NNResult {
 // NearestNeighborsCapable::nn_single_search [U] on the hashed voxel map: visit the 3x3x3 voxel block
 // around voxel(q) in x-outer / y-middle / z-inner order, points in insertion order, strict '<' keeps
 // the first minimum (SURVEY 8a row a8, App.B U2/U3).
+//
+// Memory-level parallelism is what this kernel lives on (one scan only fills ~2 waves per SIMD, so
+// the dependent-load chain per lane is the critical path):
+//  * all 27 hash slots are requested before any is inspected (27 independent dwordx4 loads);
+//  * point records are stored in ascending packed-key order with z in the low bits, so the records
+//    of the (up to) three z-neighbours of one (x,y) column are CONTIGUOUS in HBM: the 27 voxel
+//    scans collapse into 9 runs, visited in exactly the reference order;
+//  * each run is read four records at a time (indices clamped to the run, so the tail re-reads the
+//    last record, which a strict '<' can never select twice).
 __device__ __forceinline__ NNResult nn_single_search(const MapView& m, float qx, float qy, float qz) {
   NNResult r;
   r.d2 = __builtin_inff();
   r.found = false;
-  r.pt = make_float4(0.f, 0.f, 0.f, 0.f);
+  r.pt = (f32x4)(0.f);
   if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return r;
   const float lim = 1.0e6f;
   if (!(fabsf(qx * m.inv_vs) < lim && fabsf(qy * m.inv_vs) < lim && fabsf(qz * m.inv_vs) < lim)) return r;
   const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
-#pragma unroll 1
-  for (int ix = -1; ix <= 1; ix++) {
-#pragma unroll 1
-    for (int iy = -1; iy <= 1; iy++) {
-      // the three z-neighbours are probed together: three independent slot loads in flight
-      MapSlot s[3];
-      uint32_t h[3];
-      unsigned long long key[3];
+  const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
+  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);  // one dwordx4 per slot
+  u32x4 s[27];
 #pragma unroll
-      for (int iz = 0; iz < 3; iz++) {
-        key[iz] = pack_key(cx + ix, cy + iy, cz + iz - 1);
-        h[iz] = hash_key(key[iz]) & m.mask;
-        s[iz] = m.slots[h[iz]];
+  for (int c = 0; c < 27; c++) {
+    // key(cx+ix, cy+iy, cz+iz) = kbase + (ix+1)<<42 + (iy+1)<<21 + (iz+1): no carries inside the checked range
+    const unsigned long long key = kbase + ((unsigned long long)(c / 9) << 42) + ((unsigned long long)((c / 3) % 3) << 21) +
+                                   (unsigned long long)(c % 3);
+    s[c] = slots4[hash_key(key) & m.mask];
+  }
+  // resolve the 27 probes into 9 (first, count) runs right away: the slots die here, only 18
+  // registers stay live across the distance loops
+  uint32_t first9[9], cnt9[9];
+#pragma unroll
+  for (int col = 0; col < 9; col++) {
+    uint32_t first = 0, cnt = 0;
+#pragma unroll
+    for (int iz = 0; iz < 3; iz++) {
+      const int c = col * 3 + iz;
+      const unsigned long long key = kbase + ((unsigned long long)(c / 9) << 42) + ((unsigned long long)((c / 3) % 3) << 21) +
+                                     (unsigned long long)(c % 3);
+      u32x4 sl = s[c];  // {key lo, key hi, first, count}
+      unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
+      if (sk != key && sk != kEmptyKey) {  // rare: linear probing past a collision
+        uint32_t h = hash_key(key) & m.mask;
+        do {
+          h = (h + 1) & m.mask;
+          sl = slots4[h];
+          sk = ((unsigned long long)sl.y << 32) | sl.x;
+        } while (sk != key && sk != kEmptyKey);
       }
+      if (sk == key) {
+        if (cnt == 0) first = sl.z;
+        cnt += sl.w;
+      }
+    }
+    first9[col] = first;
+    cnt9[col] = cnt;
+  }
 #pragma unroll
-      for (int iz = 0; iz < 3; iz++) {
-        // linear probing until the key or an empty slot is met
-        while (s[iz].key != key[iz] && s[iz].key != kEmptyKey) {
-          h[iz] = (h[iz] + 1) & m.mask;
-          s[iz] = m.slots[h[iz]];
-        }
-        if (s[iz].key == key[iz]) {
-          const float4* __restrict__ p = m.pts + s[iz].first;
-          const uint32_t cnt = s[iz].count;
-          for (uint32_t j = 0; j < cnt; j++) {
-            const float4 c = p[j];
-            const float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order
-            if (d2 < r.d2) {
-              r.d2 = d2;
-              r.pt = c;
-              r.found = true;
-            }
-          }
-        }
+  for (int col = 0; col < 9; col++) {
+    const uint32_t first = first9[col], cnt = cnt9[col];
+    const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(m.pts) + first;
+    for (uint32_t j = 0; j < cnt; j += 4) {
+      const uint32_t last = cnt - 1;
+      const f32x4 c0 = p[j];
+      const f32x4 c1 = p[min(j + 1, last)];
+      const f32x4 c2 = p[min(j + 2, last)];
+      const f32x4 c3 = p[min(j + 3, last)];
+      {
+        const float dx = c0.x - qx, dy = c0.y - qy, dz = c0.z - qz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order
+        if (d2 < r.d2) { r.d2 = d2; r.pt = c0; }
+      }
+      {
+        const float dx = c1.x - qx, dy = c1.y - qy, dz = c1.z - qz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < r.d2) { r.d2 = d2; r.pt = c1; }
+      }
+      {
+        const float dx = c2.x - qx, dy = c2.y - qy, dz = c2.z - qz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < r.d2) { r.d2 = d2; r.pt = c2; }
+      }
+      {
+        const float dx = c3.x - qx, dy = c3.y - qy, dz = c3.z - qz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < r.d2) { r.d2 = d2; r.pt = c3; }
       }
     }
   }
+  r.found = r.d2 < __builtin_inff();
   return r;
 }
 

@@ -162,49 +162,80 @@ MH_HD int sym6(int i, int j) {
 
 // x = H^-1 b by LDL^T with diagonal pivoting (what Eigen's ldlt() does for the reference's
 // optimal_tf_gauss_newton); zero pivots give a zero component.  Returns false on non-finite results.
+// Written with compile-time indices only (the pivot swaps are predicated selects) so that on the
+// device the whole 6x6 stays in registers -- a runtime-indexed array would live in scratch memory.
+MH_HD void cswap(bool c, double& a, double& b) {
+  const double ta = c ? b : a, tb = c ? a : b;
+  a = ta;
+  b = tb;
+}
+
 MH_HD bool ldlt_solve6(const double Hfull[36], const double b[6], double x[6]) {
-  double A[36];
-  for (int i = 0; i < 36; i++) A[i] = Hfull[i];
-  int perm[6] = {0, 1, 2, 3, 4, 5};
-  const double tiny = 2.2250738585072014e-308;
-  for (int k = 0; k < 6; k++) {
-    int piv = k;
-    double best = fabs(A[k * 6 + k]);
-    for (int i = k + 1; i < 6; i++) {
-      const double v = fabs(A[i * 6 + i]);
-      if (v > best) { best = v; piv = i; }
-    }
-    if (piv != k) {
-      for (int j = 0; j < 6; j++) { const double tmp = A[k * 6 + j]; A[k * 6 + j] = A[piv * 6 + j]; A[piv * 6 + j] = tmp; }
-      for (int j = 0; j < 6; j++) { const double tmp = A[j * 6 + k]; A[j * 6 + k] = A[j * 6 + piv]; A[j * 6 + piv] = tmp; }
-      const int tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;
-    }
-    const double d = A[k * 6 + k];
-    if (!isfinite(d)) return false;
-    if (fabs(d) > tiny) {
-      for (int i = k + 1; i < 6; i++) A[i * 6 + k] /= d;
-      for (int i = k + 1; i < 6; i++)
-        for (int j = k + 1; j <= i; j++) {
-          A[i * 6 + j] -= A[i * 6 + k] * d * A[j * 6 + k];
-          A[j * 6 + i] = A[i * 6 + j];
-        }
-    } else {
-      for (int i = k + 1; i < 6; i++) A[i * 6 + k] = 0.0;
-    }
-  }
-  double y[6];
-  for (int i = 0; i < 6; i++) y[i] = b[perm[i]];
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j < i; j++) y[i] -= A[i * 6 + j] * y[j];
+  double A[6][6], y[6];
+  int piv[6];
+#pragma unroll
   for (int i = 0; i < 6; i++) {
-    const double d = A[i * 6 + i];
+#pragma unroll
+    for (int j = 0; j < 6; j++) A[i][j] = Hfull[i * 6 + j];
+    y[i] = b[i];
+  }
+  const double tiny = 2.2250738585072014e-308;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    int p = k;
+    double best = fabs(A[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double v = fabs(A[i][i]);
+      if (v > best) { best = v; p = i; }
+    }
+    piv[k] = p;
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const bool sw = (p == i);
+#pragma unroll
+      for (int j = 0; j < 6; j++) cswap(sw, A[k][j], A[i][j]);
+#pragma unroll
+      for (int j = 0; j < 6; j++) cswap(sw, A[j][k], A[j][i]);
+      cswap(sw, y[k], y[i]);
+    }
+    const double d = A[k][k];
+    ok = ok && isfinite(d);
+    const bool nz = fabs(d) > tiny;
+    const double inv = nz ? 1.0 / d : 0.0;
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) A[i][k] = nz ? A[i][k] * inv : 0.0;
+#pragma unroll
+    for (int i = k + 1; i < 6; i++)
+#pragma unroll
+      for (int j = k + 1; j <= i; j++) {
+        A[i][j] -= A[i][k] * d * A[j][k];
+        A[j][i] = A[i][j];
+      }
+  }
+  // forward, diagonal, backward
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const double d = A[i][i];
     y[i] = (fabs(d) > tiny) ? y[i] / d : 0.0;
   }
+#pragma unroll
   for (int i = 5; i >= 0; i--)
-    for (int j = i + 1; j < 6; j++) y[i] -= A[j * 6 + i] * y[j];
-  bool ok = true;
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) y[i] -= A[j][i] * y[j];
+  // undo the permutation: x = P^T y, swaps applied in reverse order
+#pragma unroll
+  for (int k = 5; k >= 0; k--)
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) cswap(piv[k] == i, y[k], y[i]);
+#pragma unroll
   for (int i = 0; i < 6; i++) {
-    x[perm[i]] = y[i];
+    x[i] = y[i];
     ok = ok && isfinite(y[i]);
   }
   return ok;
@@ -213,10 +244,14 @@ MH_HD bool ldlt_solve6(const double Hfull[36], const double b[6], double x[6]) {
 // inverse of an SPD 6x6 via Cholesky (mrpt inverse_LLt in mp2p_icp::covariance); false if not SPD
 MH_HD bool chol_inverse6(const double A[36], double Ainv[36]) {
   double L[36];
+#pragma unroll
   for (int i = 0; i < 36; i++) L[i] = 0.0;
+#pragma unroll
   for (int i = 0; i < 6; i++)
+#pragma unroll
     for (int j = 0; j <= i; j++) {
       double s = A[i * 6 + j];
+#pragma unroll
       for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
       if (i == j) {
         if (!(s > 0.0)) return false;
@@ -225,18 +260,24 @@ MH_HD bool chol_inverse6(const double A[36], double Ainv[36]) {
         L[i * 6 + j] = s / L[j * 6 + j];
       }
     }
+#pragma unroll
   for (int c = 0; c < 6; c++) {
     double y[6], x[6];
+#pragma unroll
     for (int i = 0; i < 6; i++) {
       double s = (i == c) ? 1.0 : 0.0;
+#pragma unroll
       for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k];
       y[i] = s / L[i * 6 + i];
     }
+#pragma unroll
     for (int i = 5; i >= 0; i--) {
       double s = y[i];
+#pragma unroll
       for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k];
       x[i] = s / L[i * 6 + i];
     }
+#pragma unroll
     for (int i = 0; i < 6; i++) Ainv[i * 6 + c] = x[i];
   }
   return true;
