@@ -89,7 +89,7 @@ __host__ __device__ inline void unpack_key(unsigned long long k, int& kx, int& k
   kz = (int)(k & 0x1FFFFF) - kKeyBias;
 }
 __host__ __device__ inline uint32_t hash_key(unsigned long long k) {
-  return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 32);
+  return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 32);  // Fibonacci hashing of the packed key
 }
 __host__ __device__ inline bool key_in_range(int k) { return k > -kKeyBias + 1 && k < kKeyBias - 2; }
 

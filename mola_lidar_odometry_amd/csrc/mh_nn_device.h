@@ -131,6 +131,281 @@ __device__ __forceinline__ NNResult nn_single_search(const MapView& m, float qx,
   return r;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Exact branch-and-bound version of nn_single_search (the production path).
+//
+// The reference scans all 27 voxels; the RESULT is the lexicographic minimum of (d2, scan position)
+// over the candidates, and because point records are stored in scan order (ascending packed key =
+// x outer / y middle / z inner, then insertion order) "scan position" is simply the record index.
+// That minimum does not change if a voxel is skipped whose every point is provably farther than
+// the best candidate found so far.  So: scan the query's own voxel first, then visit a neighbour
+// voxel only if a conservative lower bound of its distance can still beat (or tie) the current best:
+//     lb = gap_x^2 + gap_y^2 + gap_z^2 ,  gap = distance from q to the voxel's coordinate slab,
+// with the slab widened by a few ulps of the coordinate magnitude and the test relaxed by 1e-4, so
+// that fp32 rounding of either side can never prune a candidate with d2 <= best.  On the C2 workload
+// this evaluates ~35 candidates per point instead of ~175 and probes ~9 hash slots instead of 27,
+// with bit-identical output (tests/test_gpu_parity.py, incl. lattice/tie and boundary cases).
+// -------------------------------------------------------------------------------------------------
+struct Gaps {
+  float s[3];  // squared conservative gap to the slabs of voxel c-1, c, c+1 along one axis
+};
+
+__device__ __forceinline__ Gaps axis_gaps(float q, int c, float vs, uint32_t trunc) {
+  // coordinate range of voxel v: floor mode [v*vs, (v+1)*vs); trunc mode: v>0 same, v<0 ((v-1)*vs, v*vs],
+  // v==0 (-vs, vs).  hi(c-1) and lo(c+1) are what we need.
+  const int vm = c - 1, vp = c + 1;
+  const float hi_m = (float)((!trunc || vm >= 0) ? vm + 1 : vm) * vs;
+  const float lo_p = (float)((!trunc || vp > 0) ? vp : vp - 1) * vs;
+  const float margin = 1.0e-6f * ((float)(c < 0 ? -c : c) + 2.0f) * vs;  // >= 8 ulp of the coordinate
+  const float gm = fmaxf(0.f, (q - hi_m) - margin);
+  const float gp = fmaxf(0.f, (lo_p - q) - margin);
+  Gaps g;
+  g.s[0] = gm * gm;
+  g.s[1] = 0.f;
+  g.s[2] = gp * gp;
+  return g;
+}
+
+struct NNBest {
+  float d2;
+  uint32_t idx;  // record index in MapView::pts (== scan position)
+};
+
+__device__ __forceinline__ void nn_consider(const f32x4& c, uint32_t idx, float qx, float qy, float qz, NNBest& b) {
+  const float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
+  const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order (bit-exact with the oracle)
+  if (d2 < b.d2 || (d2 == b.d2 && idx < b.idx)) {
+    b.d2 = d2;
+    b.idx = idx;
+  }
+}
+
+// all records of one voxel, four predicated loads in flight
+__device__ __forceinline__ void nn_scan_voxel(const f32x4* __restrict__ pts, uint32_t first, uint32_t cnt, float qx,
+                                              float qy, float qz, NNBest& b) {
+  for (uint32_t j = 0; j < cnt; j += 4) {
+    const bool v1 = j + 1 < cnt, v2 = j + 2 < cnt, v3 = j + 3 < cnt;
+    const f32x4* __restrict__ p = pts + (first + j);
+    f32x4 c0 = p[0], c1 = c0, c2 = c0, c3 = c0;
+    if (v1) c1 = p[1];
+    if (v2) c2 = p[2];
+    if (v3) c3 = p[3];
+    nn_consider(c0, first + j, qx, qy, qz, b);
+    if (v1) nn_consider(c1, first + j + 1, qx, qy, qz, b);
+    if (v2) nn_consider(c2, first + j + 2, qx, qy, qz, b);
+    if (v3) nn_consider(c3, first + j + 3, qx, qy, qz, b);
+  }
+}
+
+// conservative lower bound of the squared distance from q to neighbour voxel `code` (= ix*9+iy*3+iz)
+__device__ __forceinline__ float nn_lower_bound(int code, const Gaps& gx, const Gaps& gy, const Gaps& gz) {
+  const int ix = (code * 57) >> 9;  // code / 9 for code < 27
+  const int r = code - 9 * ix;
+  const int iy = (r * 11) >> 5;     // r / 3 for r < 9
+  const int iz = r - 3 * iy;
+  const float sx = ix == 0 ? gx.s[0] : (ix == 1 ? 0.f : gx.s[2]);
+  const float sy = iy == 0 ? gy.s[0] : (iy == 1 ? 0.f : gy.s[2]);
+  const float sz = iz == 0 ? gz.s[0] : (iz == 1 ? 0.f : gz.s[2]);
+  return (sx + sy) + sz;
+}
+
+__device__ __forceinline__ unsigned long long nn_key_of(unsigned long long kbase, int code) {
+  const int ix = (code * 57) >> 9;
+  const int r = code - 9 * ix;
+  const int iy = (r * 11) >> 5;
+  const int iz = r - 3 * iy;
+  return kbase + ((unsigned long long)ix << 42) + ((unsigned long long)iy << 21) + (unsigned long long)iz;
+}
+
+__device__ __forceinline__ void nn_visit(const MapView& m, const u32x4* __restrict__ slots4, const f32x4* __restrict__ pts4,
+                                         unsigned long long key, u32x4 sl, float qx, float qy, float qz, NNBest& b) {
+  unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
+  if (sk != key && sk != kEmptyKey) {  // rare: linear probing past a collision
+    uint32_t h = hash_key(key) & m.mask;
+    do {
+      h = (h + 1) & m.mask;
+      sl = slots4[h];
+      sk = ((unsigned long long)sl.y << 32) | sl.x;
+    } while (sk != key && sk != kEmptyKey);
+  }
+  if (sk == key) nn_scan_voxel(pts4, sl.z, sl.w, qx, qy, qz, b);
+}
+
+__device__ __forceinline__ NNResult nn_search_pruned(const MapView& m, float qx, float qy, float qz) {
+  NNResult r;
+  r.d2 = __builtin_inff();
+  r.found = false;
+  r.pt = (f32x4)(0.f);
+  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return r;
+  const float lim = 1.0e6f;
+  if (!(fabsf(qx * m.inv_vs) < lim && fabsf(qy * m.inv_vs) < lim && fabsf(qz * m.inv_vs) < lim)) return r;
+  const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
+  const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
+  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
+  const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
+  const float vs = 1.0f / m.inv_vs;  // only used for bounds, which carry their own safety margin
+  const Gaps gx = axis_gaps(qx, cx, vs, m.trunc), gy = axis_gaps(qy, cy, vs, m.trunc), gz = axis_gaps(qz, cz, vs, m.trunc);
+  NNBest b;
+  b.d2 = __builtin_inff();
+  b.idx = 0xFFFFFFFFu;
+  // 1. the query's own voxel (code 13)
+  {
+    const unsigned long long key = nn_key_of(kbase, 13);
+    nn_visit(m, slots4, pts4, key, slots4[hash_key(key) & m.mask], qx, qy, qz, b);
+  }
+  // 2. the neighbours that can still hold a candidate with d2 <= best: bit `code` of `mask`
+  uint32_t mask = 0;
+#pragma unroll
+  for (int c = 0; c < 27; c++) {
+    if (c == 13) continue;
+    const float lb = (gx.s[c / 9] + gy.s[(c / 3) % 3]) + gz.s[c % 3];
+    if (!(lb * 0.9999f > b.d2)) mask |= 1u << c;
+  }
+  // faces first, then edges, then corners: nearer voxels tighten the bound for the farther ones
+  const uint32_t kFaces = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 14) | (1u << 16) | (1u << 22);
+  const uint32_t kCorners = (1u << 0) | (1u << 2) | (1u << 6) | (1u << 8) | (1u << 18) | (1u << 20) | (1u << 24) | (1u << 26);
+  const uint32_t kEdges = 0x07FFFFFFu & ~(kFaces | kCorners | (1u << 13));
+#pragma unroll 1
+  for (int cls = 0; cls < 3; cls++) {
+    uint32_t mm = mask & (cls == 0 ? kFaces : (cls == 1 ? kEdges : kCorners));
+    while (mm) {
+      // up to four probes in flight
+      int c0 = __builtin_ctz(mm), c1 = -1, c2 = -1, c3 = -1;
+      mm &= mm - 1;
+      if (mm) { c1 = __builtin_ctz(mm); mm &= mm - 1; }
+      if (mm) { c2 = __builtin_ctz(mm); mm &= mm - 1; }
+      if (mm) { c3 = __builtin_ctz(mm); mm &= mm - 1; }
+      const unsigned long long k0 = nn_key_of(kbase, c0), k1 = nn_key_of(kbase, c1 < 0 ? 0 : c1),
+                               k2 = nn_key_of(kbase, c2 < 0 ? 0 : c2), k3 = nn_key_of(kbase, c3 < 0 ? 0 : c3);
+      u32x4 s0 = slots4[hash_key(k0) & m.mask], s1 = s0, s2 = s0, s3 = s0;
+      if (c1 >= 0) s1 = slots4[hash_key(k1) & m.mask];
+      if (c2 >= 0) s2 = slots4[hash_key(k2) & m.mask];
+      if (c3 >= 0) s3 = slots4[hash_key(k3) & m.mask];
+      if (!(nn_lower_bound(c0, gx, gy, gz) * 0.9999f > b.d2)) nn_visit(m, slots4, pts4, k0, s0, qx, qy, qz, b);
+      if (c1 >= 0 && !(nn_lower_bound(c1, gx, gy, gz) * 0.9999f > b.d2)) nn_visit(m, slots4, pts4, k1, s1, qx, qy, qz, b);
+      if (c2 >= 0 && !(nn_lower_bound(c2, gx, gy, gz) * 0.9999f > b.d2)) nn_visit(m, slots4, pts4, k2, s2, qx, qy, qz, b);
+      if (c3 >= 0 && !(nn_lower_bound(c3, gx, gy, gz) * 0.9999f > b.d2)) nn_visit(m, slots4, pts4, k3, s3, qx, qy, qz, b);
+    }
+  }
+  if (b.idx != 0xFFFFFFFFu) {
+    r.pt = pts4[b.idx];
+    r.d2 = b.d2;
+    r.found = true;
+  }
+  return r;
+}
+
+// Quad-split variant: four adjacent lanes share one query and split its nine (x,y) columns in
+// reference order -- part 0: columns 0-2 (x-1), part 1: 3-4, part 2: 5-6, part 3: 7-8 -- so the
+// dependent-load chain per lane is ~4x shorter and four times as many waves are in flight.  The caller
+// merges the four partial results with quad_combine(), which keeps the FIRST minimum in column order,
+// i.e. exactly what the sequential scan would have kept.
+__device__ __forceinline__ void nn_search_cols(const MapView& m, float qx, float qy, float qz, int part, float& best_d2,
+                                               f32x4& best_pt) {
+  best_d2 = __builtin_inff();
+  best_pt = (f32x4)(0.f);
+  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return;
+  const float lim = 1.0e6f;
+  if (!(fabsf(qx * m.inv_vs) < lim && fabsf(qy * m.inv_vs) < lim && fabsf(qz * m.inv_vs) < lim)) return;
+  const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
+  const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
+  const int cb = part == 0 ? 0 : 2 * part + 1;  // first column of this part: 0,3,5,7
+  const int nc = part == 0 ? 3 : 2;
+  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
+  u32x4 s[9];
+  unsigned long long keys[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int col = cb + k;
+    const int ix = col >= 6 ? 2 : (col >= 3 ? 1 : 0);
+    const int iy = col - 3 * ix;
+    keys[k] = kbase + ((unsigned long long)ix << 42) + ((unsigned long long)iy << 21);
+#pragma unroll
+    for (int iz = 0; iz < 3; iz++) {
+      u32x4 v = (u32x4)(0xFFFFFFFFu);  // reads as an empty slot
+      if (k < nc) v = slots4[hash_key(keys[k] + iz) & m.mask];
+      s[k * 3 + iz] = v;
+    }
+  }
+  uint32_t first3[3], cnt3[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    uint32_t first = 0, cnt = 0;
+#pragma unroll
+    for (int iz = 0; iz < 3; iz++) {
+      const unsigned long long key = keys[k] + iz;
+      u32x4 sl = s[k * 3 + iz];
+      unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
+      if (sk != key && sk != kEmptyKey) {
+        uint32_t h = hash_key(key) & m.mask;
+        do {
+          h = (h + 1) & m.mask;
+          sl = slots4[h];
+          sk = ((unsigned long long)sl.y << 32) | sl.x;
+        } while (sk != key && sk != kEmptyKey);
+      }
+      if (sk == key) {
+        if (cnt == 0) first = sl.z;
+        cnt += sl.w;
+      }
+    }
+    first3[k] = first;
+    cnt3[k] = cnt;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const uint32_t cnt = cnt3[k];
+    const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(m.pts) + first3[k];
+    for (uint32_t j = 0; j < cnt; j += 4) {
+      const uint32_t last = cnt - 1;
+      const f32x4 c0 = p[j];
+      const f32x4 c1 = p[min(j + 1, last)];
+      const f32x4 c2 = p[min(j + 2, last)];
+      const f32x4 c3 = p[min(j + 3, last)];
+      {
+        const float dx = c0.x - qx, dy = c0.y - qy, dz = c0.z - qz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order
+        if (d2 < best_d2) { best_d2 = d2; best_pt = c0; }
+      }
+      {
+        const float dx = c1.x - qx, dy = c1.y - qy, dz = c1.z - qz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < best_d2) { best_d2 = d2; best_pt = c1; }
+      }
+      {
+        const float dx = c2.x - qx, dy = c2.y - qy, dz = c2.z - qz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < best_d2) { best_d2 = d2; best_pt = c2; }
+      }
+      {
+        const float dx = c3.x - qx, dy = c3.y - qy, dz = c3.z - qz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < best_d2) { best_d2 = d2; best_pt = c3; }
+      }
+    }
+  }
+}
+
+// merge the partial nearest neighbours of the four lanes of a quad; every lane ends with the result
+__device__ __forceinline__ void quad_combine(int part, float& d2, f32x4& pt) {
+#pragma unroll
+  for (int bit = 1; bit <= 2; bit <<= 1) {
+    const float od2 = __shfl_xor(d2, bit);
+    f32x4 opt;
+    opt.x = __shfl_xor(pt.x, bit);
+    opt.y = __shfl_xor(pt.y, bit);
+    opt.z = __shfl_xor(pt.z, bit);
+    opt.w = __shfl_xor(pt.w, bit);
+    // "lower" = earlier in the reference scan order; the later one only wins with a strictly smaller d2
+    const bool me_lower = (part & bit) == 0;
+    const bool take_other = me_lower ? (od2 < d2) : !(d2 < od2);
+    if (take_other) {
+      d2 = od2;
+      pt = opt;
+    }
+  }
+}
+
 // ---- robust kernels (mp2p_icp::create_robust_kernel [U], lidar3d-default.yaml:188-190) ---------
 __device__ __forceinline__ double robust_weight(uint32_t kernel, double c, double e2) {
   switch (kernel) {

@@ -149,6 +149,38 @@ def test_nn_voxel_boundary_and_negative_coords(ctx, oracle):
             np.testing.assert_array_equal(g[k], o[k])
 
 
+@pytest.mark.parametrize("vs,cap,mode,offset", [(1.0, 20, 0, 0.0), (0.3, 5, 0, 0.0), (2.5, 0, 0, 0.0), (1.0, 20, 1, 0.0),
+                                                (1.0, 20, 0, 50000.0), (0.7, 8, 0, -12345.0), (0.3, 20, 1, 3.0)])
+def test_nn_pruning_is_exact_on_adversarial_clouds(ctx, oracle, vs, cap, mode, offset):
+    """The production search prunes voxels with a conservative distance bound; its output must stay
+    bit-identical to the exhaustive 27-voxel scan of the oracle.  Adversarial inputs: lattice-aligned map
+    points and queries (exact distance ties in different voxels), queries exactly on voxel boundaries,
+    coordinates where fp32 spacing is coarse, voxel sizes whose reciprocal is inexact, trunc indexing."""
+    rng = np.random.default_rng(int(vs * 10) + cap + mode)
+    g = np.arange(-6, 6, 0.25, dtype=np.float32)
+    lattice = np.stack(np.meshgrid(g, g, g[:24], indexing="ij"), -1).reshape(-1, 3)
+    lattice = lattice[rng.permutation(len(lattice))[:40000]]
+    noise = rng.normal(0, 3, (20000, 3)).astype(np.float32)
+    pts = (np.concatenate([lattice, noise]) + np.float32(offset)).astype(np.float32)
+    gm = capi.Map(ctx, vs, cap, mode).build(pts)
+    om = oracle.Map(vs, cap, mode).insert(pts)
+    q_mid = (lattice[:3000] + np.float32(0.125)).astype(np.float32)          # equidistant from 8 lattice points
+    q_bnd = np.round(rng.uniform(-6, 6, (3000, 3)) / vs).astype(np.float32) * np.float32(vs)  # on voxel faces
+    q_bnd[:, 1] += rng.uniform(-0.5, 0.5, 3000).astype(np.float32)
+    q_rnd = rng.uniform(-7, 7, (4000, 3)).astype(np.float32)
+    q_far = rng.uniform(-30, 30, (500, 3)).astype(np.float32)                 # mostly empty neighbourhoods
+    q = (np.concatenate([q_mid, q_bnd, q_rnd, q_far]) + np.float32(offset)).astype(np.float32)
+    gs = capi.Scan(ctx, q)
+    for T in (I12, oracle.se3_exp([0.11, -0.07, 0.05, 0.002, -0.001, 0.003])):
+        d = capi.nn_search_dense(gm, gs, T)
+        o = oracle.match_points(om, q, T, 1e9)
+        found = d["global_idx"] != capi.NO_MATCH
+        np.testing.assert_array_equal(np.nonzero(found)[0], o["local_idx"])
+        np.testing.assert_array_equal(d["global_idx"][found], o["global_idx"])
+        np.testing.assert_array_equal(d["d2"][found], o["d2"])
+        np.testing.assert_array_equal(d["global_xyz"][found], o["global_xyz"])
+
+
 # ---------------------------------------------------------------------------- solver
 def _pairs(rng, n, noise=0.05):
     l = rng.normal(0, 10, (n, 3)).astype(np.float32)
