@@ -49,6 +49,7 @@ def main():
     import torch  # plumbing: process group, barrier, device selection
     import torch.distributed as dist
     from mola_lidar_odometry_amd import capi, synth
+    from mola_lidar_odometry_amd import dist as mdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -105,17 +106,10 @@ def main():
             match_launches += r["n_match_launches"]
     sync_all()
     dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # the trivial result gather: poses of the last step from every rank
-        poses = torch.tensor(np.stack([r["T"] for r in last]), dtype=torch.float64, device="cuda")
-        gathered = [torch.empty_like(poses) for _ in range(world)]
-        dist.all_gather(gathered, poses)
-        all_poses = torch.stack(gathered).cpu().numpy()
-    else:
-        all_poses = np.stack([r["T"] for r in last])[None]
+    dt = mdist.max_over_ranks(dt, device="cuda" if distributed else None)  # MAX over ranks
+    # the trivial result gather: poses of the last step from every rank, RCCL all_gather
+    gathered = mdist.gather_poses(np.stack([r["T"] for r in last]), device="cuda" if distributed else None)
+    all_poses = np.stack(gathered)
 
     scans_total = world * args.steps * S
     value = scans_total / dt
@@ -139,7 +133,19 @@ def main():
             om = oracle_c.Map(w.voxel_size, w.cap).insert(w.map_xyz)
             op = oracle_c.ICPParams(max_iterations=w.n_iters, disable_stall_test=True, threshold=w.threshold,
                                     kernel_param=w.kernel_param, compute_covariance=True)
-            cores = oracle_c.max_threads()
+            # pick the thread count that is fastest on THIS box (more threads than usable cores collapses
+            # OpenMP throughput); the count actually used is what "cores" reports
+            cores, best_t = 1, None
+            cal = oracle_c.ICPParams(max_iterations=2, disable_stall_test=True, threshold=w.threshold[:2],
+                                     kernel_param=w.kernel_param[:2], compute_covariance=False)
+            for nt in (1, 4, 8, 16, 32, 64, 128):
+                if nt > oracle_c.max_threads():
+                    break
+                tc = time.perf_counter()
+                oracle_c.icp_align(om, w.scan_xyz, guesses[0], cal, n_threads=nt)
+                tcal = time.perf_counter() - tc
+                if best_t is None or tcal < best_t:
+                    cores, best_t = nt, tcal
             n_done, t_cpu, o = 0, 0.0, None
             while t_cpu < args.cpu_seconds and n_done < 64:
                 tc = time.perf_counter()
@@ -170,9 +176,11 @@ def main():
                     "note": "event-timed on the kernel's own stream with the other streams' kernels running "
                             "concurrently; the working set is L2/Infinity-Cache resident, so algorithmic GB/s may "
                             "exceed HBM traffic"}
-            pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-            if os.path.exists(pmc):
-                roof["traffic"] = json.load(open(pmc)).get("k_match_fused_hbm_bytes_per_launch")
+            import glob
+            pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+            if pmc:  # HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (profiles/collect.sh)
+                roof["traffic"] = json.load(open(pmc[-1])).get("k_match_fused_hbm_bytes_per_launch")
+                roof["traffic_source"] = os.path.basename(pmc[-1])
         out["roofline"] = roof
         out["cpu_baseline"] = cpu
         out["gathered_poses"] = int(all_poses.shape[0] * all_poses.shape[1])

@@ -1,0 +1,337 @@
+// mp2p_icp_hip.h -- C++17 host layer above the C ABI (include/molahip.h).
+//
+// It mirrors, name for name and argument for argument, the part of the mp2p_icp plugin API [U] that
+// mola::LidarOdometry drives for the ICP hot path, so that code written against the reference's interface
+// reads the same here (the reference's own dependencies -- mp2p_icp, MRPT -- are absent from this image, so
+// this layer is self-contained; the adapter that derives from the REAL mp2p_icp classes is
+// host/adapters/mp2p_icp_plugin.cpp):
+//
+//   reference (file:line in /root/reference)                       here
+//   -------------------------------------------------------------  ------------------------------------------
+//   mp2p_icp::icp_pipeline_from_yaml   LidarOdometry.cpp:115-122    mp2p_icp_hip::icp_pipeline_from_yaml
+//   mp2p_icp::ICP::align               LidarOdometry.cpp:961-962    ICP::align (same argument order)
+//   ICP::setIterationHook              LidarOdometry.cpp:923-952    ICP::setIterationHook / setDeviceHook
+//   mp2p_icp::Parameters               lidar3d-default.yaml:172-182 Parameters
+//   mp2p_icp::Results / IterTermReason LidarOdometry.cpp:1009-1019  Results / IterTermReason
+//   Matcher_Points_DistanceThreshold   lidar3d-default.yaml:195-204 same name
+//   Solver_GaussNewton                 lidar3d-default.yaml:184-190 same name
+//   QualityEvaluator_PairedRatio       lidar3d-default.yaml:206-209 same name
+//   ParameterSource / Parameterizable  LidarOdometry.cpp:356,1571-1635  same names (run-time formulas)
+//   mola::HashedVoxelPointCloud        lidar3d-default.yaml:228-242 HashedVoxelPointCloud (device resident)
+//
+// Nothing here computes on the CPU: every numeric step is a call into libmolahip.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "molahip.h"
+
+namespace mp2p_icp_hip {
+
+// ---------------------------------------------------------------- poses (mrpt::poses stand-ins)
+struct TPose3D {
+  double x = 0, y = 0, z = 0, yaw = 0, pitch = 0, roll = 0;
+  static TPose3D Identity() { return {}; }
+};
+struct CPose3D {
+  double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};  // row-major [R|t]
+  CPose3D() = default;
+  explicit CPose3D(const TPose3D& p);
+  TPose3D asTPose() const;
+  CPose3D operator+(const CPose3D& b) const;  // composition a (+) b
+  CPose3D operator-(const CPose3D& b) const;  // inverse composition: b^-1 (+) a
+  double translationNorm() const;
+  double rotationAngle() const;  // |SO(3) log|
+};
+struct CPose3DPDFGaussian {
+  CPose3D mean;
+  double cov[36] = {0};  // (x,y,z,yaw,pitch,roll)
+};
+struct CPose3DPDFGaussianInf {
+  CPose3D mean;
+  double cov_inv[36] = {0};
+};
+
+// ---------------------------------------------------------------- tiny config tree (YAML subset)
+class Config {
+ public:
+  enum class Kind { Null, Scalar, Map, Seq };
+  Kind kind = Kind::Null;
+  std::string scalar;
+  std::vector<std::pair<std::string, Config>> map;
+  std::vector<Config> seq;
+
+  static Config FromYamlText(const std::string& text);  // comments, nesting, "- " sequences, {flow maps}, ${ENV|default}
+  static Config FromYamlFile(const std::string& path);
+  bool has(const std::string& key) const;
+  const Config& operator[](const std::string& key) const;  // throws if absent
+  const Config& at(size_t i) const { return seq.at(i); }
+  size_t size() const { return kind == Kind::Seq ? seq.size() : map.size(); }
+  std::string asString() const { return scalar; }
+  bool isNull() const { return kind == Kind::Null || (kind == Kind::Scalar && (scalar == "~" || scalar.empty())); }
+  std::string getOr(const std::string& key, const std::string& def) const;
+};
+
+// ---------------------------------------------------------------- run-time formulas (mp2p_icp::Parameterizable)
+double evaluate_expression(const std::string& expr, const std::map<std::string, double>& vars);
+
+class Parameterizable;
+class ParameterSource {
+ public:
+  void updateVariable(const std::string& name, double value) { vars_[name] = value; }
+  void updateVariables(const std::map<std::string, double>& v) {
+    for (auto& kv : v) vars_[kv.first] = kv.second;
+  }
+  void attach(Parameterizable& p) { attached_.push_back(&p); }
+  void realize();  // re-evaluates every declared formula of every attached object
+  const std::map<std::string, double>& getVariableValues() const { return vars_; }
+
+ private:
+  std::map<std::string, double> vars_;
+  std::vector<Parameterizable*> attached_;
+};
+
+class Parameterizable {
+ public:
+  virtual ~Parameterizable() = default;
+  void attachToParameterSource(ParameterSource& s) { s.attach(*this); }
+  void realizeWith(const std::map<std::string, double>& vars);
+  struct Declared {
+    std::string name, expr;
+    double* target;
+  };
+  const std::vector<Declared>& declaredParameters() const { return declared_; }
+
+ protected:
+  void declareParameter(const std::string& name, const std::string& expr, double* target) {
+    declared_.push_back({name, expr, target});
+  }
+  // DECLARE_PARAMETER_IN_REQ: the YAML value may be a number or a formula string
+  void parameterFromConfig(const Config& c, const std::string& name, double* target, bool required);
+
+ private:
+  std::vector<Declared> declared_;
+};
+
+// ---------------------------------------------------------------- device handles
+class DeviceContext {  // one HIP device + stream (mh_ctx)
+ public:
+  explicit DeviceContext(int device = 0);
+  ~DeviceContext();
+  DeviceContext(const DeviceContext&) = delete;
+  mh_ctx* get() const { return ctx_; }
+  static std::shared_ptr<DeviceContext> Default();  // process-wide context on device 0
+
+ private:
+  mh_ctx* ctx_ = nullptr;
+};
+
+[[noreturn]] void throw_status(mh_status s, const char* where);
+inline void check(mh_status s, const char* where) {
+  if (s != MH_OK) throw_status(s, where);  // std::runtime_error: what the reference catches at LidarOdometry.cpp:614-619
+}
+
+// ---------------------------------------------------------------- map layers
+struct Layer {
+  virtual ~Layer() = default;
+};
+// mrpt::maps::CPointsMap stand-in: host SoA, untransformed
+struct PointCloud : Layer {
+  std::vector<float> x, y, z;
+  size_t size() const { return x.size(); }
+  void insertPoint(float px, float py, float pz) { x.push_back(px); y.push_back(py); z.push_back(pz); }
+};
+// mola::HashedVoxelPointCloud stand-in, device resident (NearestNeighborsCapable role only)
+class HashedVoxelPointCloud : public Layer {
+ public:
+  HashedVoxelPointCloud(float voxel_size, uint32_t max_points_per_voxel,
+                        std::shared_ptr<DeviceContext> ctx = DeviceContext::Default());
+  ~HashedVoxelPointCloud() override;
+  void setPoints(const float* x, const float* y, const float* z, size_t n);  // clear + insertPoint for each
+  void insertPoints(const float* x, const float* y, const float* z, size_t n);  // keeps a host copy, rebuilds
+  size_t size() const;
+  size_t voxelCount() const;
+  mh_map* handle() const { return map_; }
+  const std::shared_ptr<DeviceContext>& context() const { return ctx_; }
+
+ private:
+  std::shared_ptr<DeviceContext> ctx_;
+  mh_map* map_ = nullptr;
+  std::vector<float> hx_, hy_, hz_;
+};
+struct metric_map_t {
+  std::map<std::string, std::shared_ptr<Layer>> layers;
+};
+
+// ---------------------------------------------------------------- pairings / results
+struct Pairings {  // mp2p_icp::Pairings::paired_pt2pt as SoA (+ pt2pl)
+  std::vector<uint32_t> localIdx, globalIdx;
+  std::vector<float> lx, ly, lz, gx, gy, gz, errSq;
+  // point-to-plane: local point, plane centroid, plane normal
+  std::vector<float> pl_lx, pl_ly, pl_lz, pl_cx, pl_cy, pl_cz, pl_nx, pl_ny, pl_nz;
+  size_t potential_pairings = 0;
+  bool empty() const { return localIdx.empty() && pl_lx.empty(); }
+  size_t size() const { return localIdx.size() + pl_lx.size(); }
+};
+enum class IterTermReason { Undefined = 0, NoPairings, SolverError, MaxIterations, Stalled, QualityCheckpointFailed, HookRequest };
+const char* enum2str(IterTermReason r);
+enum class RobustKernel { None = 0, GemanMcClure = 1, GemanMcClure_KISS = 2, GemanMcClure_Barron = 3, Cauchy = 4, GemanMcClure_C2 = 5 };
+
+struct Parameters {  // mp2p_icp::Parameters (lidar3d-default.yaml:172-182)
+  uint32_t maxIterations = 40;
+  double minAbsStep_trans = 5e-4;
+  double minAbsStep_rot = 1e-4;
+  bool generateDebugFiles = false;  // accepted, not honoured (no .icplog writer here): documented in INTEGRATION.md
+  void load_from(const Config& c);
+};
+struct Results {
+  CPose3DPDFGaussian optimal_tf;
+  double quality = 0;
+  size_t nIterations = 0;
+  IterTermReason terminationReason = IterTermReason::Undefined;
+  Pairings finalPairings;
+};
+struct OptimalTF_Result {
+  CPose3D optimalPose;
+};
+struct MatchContext {
+  uint32_t icpIteration = 0;
+};
+struct SolverContext {
+  std::optional<CPose3D> guessRelativePose;
+  std::optional<CPose3DPDFGaussianInf> prior;
+  uint32_t icpIteration = 0;
+};
+
+// ---------------------------------------------------------------- plugins
+class Matcher : public Parameterizable {
+ public:
+  using Ptr = std::shared_ptr<Matcher>;
+  uint32_t runFromIteration = 0, runUpToIteration = 0;  // 0 = no limit
+  bool enabled = true;
+  virtual void initialize(const Config& params) = 0;
+  // returns false if the matcher did not run for this iteration
+  bool match(const metric_map_t& pcGlobal, const metric_map_t& pcLocal, const CPose3D& localPose, const MatchContext& mc,
+             Pairings& out) const;
+
+ protected:
+  virtual void impl_match(const metric_map_t& pcGlobal, const metric_map_t& pcLocal, const CPose3D& localPose,
+                          const MatchContext& mc, Pairings& out) const = 0;
+};
+
+class Matcher_Points_DistanceThreshold : public Matcher {
+ public:
+  double threshold = 0.5;
+  double thresholdAngularDeg = 0;
+  uint32_t pairingsPerPoint = 1;
+  bool allowMatchAlreadyMatchedGlobalPoints = true;
+  struct LayerMatch {
+    std::string global, local;
+    double weight = 1.0;
+  };
+  std::vector<LayerMatch> pointLayerMatches;
+  void initialize(const Config& params) override;
+
+ protected:
+  void impl_match(const metric_map_t& pcGlobal, const metric_map_t& pcLocal, const CPose3D& localPose,
+                  const MatchContext& mc, Pairings& out) const override;
+};
+
+class Solver : public Parameterizable {
+ public:
+  using Ptr = std::shared_ptr<Solver>;
+  virtual void initialize(const Config& params) = 0;
+  virtual bool optimal_pose(const Pairings& p, OptimalTF_Result& out, const SolverContext& sc) const = 0;
+};
+
+class Solver_GaussNewton : public Solver {
+ public:
+  uint32_t maxIterations = 10;  // inner Gauss-Newton steps (lidar3d-default.yaml:187)
+  RobustKernel robustKernel = RobustKernel::None;
+  double robustKernelParam = 1.0;
+  double minDelta = 1e-7, maxCost = 0;
+  void initialize(const Config& params) override;
+  bool optimal_pose(const Pairings& p, OptimalTF_Result& out, const SolverContext& sc) const override;
+};
+
+class QualityEvaluator_PairedRatio {
+ public:
+  double evaluate(const Pairings& pairingsFromICP) const {
+    return pairingsFromICP.potential_pairings ? double(pairingsFromICP.size()) / double(pairingsFromICP.potential_pairings) : 0.0;
+  }
+};
+
+// ---------------------------------------------------------------- ICP
+class ICP {
+ public:
+  using Ptr = std::shared_ptr<ICP>;
+  struct IterationHook_Input {
+    uint32_t currentIteration = 0;
+    const OptimalTF_Result* currentSolution = nullptr;
+  };
+  struct IterationHook_Output {
+    bool request_stop = false;
+  };
+  using iteration_hook_t = std::function<IterationHook_Output(const IterationHook_Input&)>;
+
+  // ctx == nullptr: the process-wide default context is taken lazily at the first align() (so that pipelines
+  // can be built and inspected on a box without a GPU; computing always needs one)
+  explicit ICP(std::shared_ptr<DeviceContext> ctx = nullptr);
+  ~ICP();
+
+  // Same argument order as the call at LidarOdometry.cpp:961-962.
+  void align(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const TPose3D& initialGuessLocalWrtGlobal,
+             const Parameters& p, Results& result, const std::optional<CPose3DPDFGaussianInf>& prior = std::nullopt);
+
+  // arbitrary host callback: forces the matcher/solver-granular loop (one host round trip per iteration)
+  void setIterationHook(const iteration_hook_t& hook) { iteration_hook_ = hook; }
+  // the in-tree hook (LidarOdometry.cpp:923-952) as data: evaluated on the device inside the fused loop
+  void setDeviceHook(double min_trans, double min_rot_rad, const CPose3D& checkpoint);
+  void clearHooks();
+
+  std::vector<Matcher::Ptr>& matchers() { return matchers_; }
+  std::vector<Solver::Ptr>& solvers() { return solvers_; }
+  void attachToParameterSource(ParameterSource& s);
+  void initialize_matchers(const Config& seq);
+  void initialize_solvers(const Config& seq);
+  bool lastAlignUsedFusedPath() const { return last_fused_; }
+  void forceGenericPath(bool v) { force_generic_ = v; }
+
+ private:
+  bool can_fuse() const;
+  void align_fused(const PointCloud& local, const HashedVoxelPointCloud& global, const CPose3D& guess, const Parameters& p,
+                   Results& result, const std::optional<CPose3DPDFGaussianInf>& prior);
+  void align_generic(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const CPose3D& guess, const Parameters& p,
+                     Results& result, const std::optional<CPose3DPDFGaussianInf>& prior);
+  void realize_iteration(uint32_t k);
+
+  std::shared_ptr<DeviceContext> ctx_;
+  std::vector<Matcher::Ptr> matchers_;
+  std::vector<Solver::Ptr> solvers_;
+  QualityEvaluator_PairedRatio quality_;
+  iteration_hook_t iteration_hook_;
+  bool dev_hook_ = false;
+  double dev_hook_trans_ = 0, dev_hook_rot_ = 0;
+  CPose3D dev_hook_chk_;
+  ParameterSource* source_ = nullptr;
+  ParameterSource own_source_;
+  mh_scan* scan_ = nullptr;
+  bool last_fused_ = false, force_generic_ = false;
+};
+
+// class factory by name (mrpt::rtti::classFactory stand-in): "mp2p_icp::X" and "mp2p_icp_hip::X" both resolve
+Matcher::Ptr create_matcher(const std::string& class_name);
+Solver::Ptr create_solver(const std::string& class_name);
+
+// mp2p_icp::icp_pipeline_from_yaml: expects the keys class_name, params, solvers, matchers, quality
+// (the icp_settings_with_vel block of pipelines/lidar3d-default.yaml:162-209)
+std::tuple<ICP::Ptr, Parameters> icp_pipeline_from_yaml(const Config& icpParams, std::shared_ptr<DeviceContext> ctx = nullptr);
+
+}  // namespace mp2p_icp_hip

@@ -1,0 +1,528 @@
+// icp.cpp -- mp2p_icp_hip: the reference's plugin classes re-stated as thin drivers of the C ABI.
+// No arithmetic of the hot path happens here; see include/molahip.h for what each call replaces.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "mp2p_icp_hip/mp2p_icp_hip.h"
+
+namespace mp2p_icp_hip {
+
+// ================================================================== poses (host-side glue only)
+CPose3D::CPose3D(const TPose3D& p) {
+  const double cy = cos(p.yaw), sy = sin(p.yaw), cp = cos(p.pitch), sp = sin(p.pitch), cr = cos(p.roll), sr = sin(p.roll);
+  const double m[12] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, p.x,
+                        sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr, p.y,
+                        -sp,     cp * sr,                cp * cr,                p.z};
+  memcpy(T, m, sizeof(m));
+}
+
+TPose3D CPose3D::asTPose() const {
+  TPose3D p;
+  p.x = T[3]; p.y = T[7]; p.z = T[11];
+  const double c = std::hypot(T[0], T[4]);
+  p.pitch = atan2(-T[8], c);
+  if (c > 1e-12) {
+    p.yaw = atan2(T[4], T[0]);
+    p.roll = atan2(T[9], T[10]);
+  } else {
+    p.yaw = atan2(-T[1], T[5]);
+    p.roll = 0;
+  }
+  return p;
+}
+
+CPose3D CPose3D::operator+(const CPose3D& b) const {
+  CPose3D c;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) c.T[i * 4 + j] = T[i * 4] * b.T[j] + T[i * 4 + 1] * b.T[4 + j] + T[i * 4 + 2] * b.T[8 + j];
+    c.T[i * 4 + 3] = T[i * 4] * b.T[3] + T[i * 4 + 1] * b.T[7] + T[i * 4 + 2] * b.T[11] + T[i * 4 + 3];
+  }
+  return c;
+}
+
+CPose3D CPose3D::operator-(const CPose3D& b) const {  // b^-1 (+) a  (mrpt: a - b)
+  CPose3D bi;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) bi.T[i * 4 + j] = b.T[j * 4 + i];
+    bi.T[i * 4 + 3] = -(b.T[i] * b.T[3] + b.T[4 + i] * b.T[7] + b.T[8 + i] * b.T[11]);
+  }
+  return bi + *this;
+}
+
+double CPose3D::translationNorm() const { return std::sqrt(T[3] * T[3] + T[7] * T[7] + T[11] * T[11]); }
+
+double CPose3D::rotationAngle() const {
+  const double vx = T[9] - T[6], vy = T[2] - T[8], vz = T[4] - T[1];
+  const double s2 = std::sqrt(vx * vx + vy * vy + vz * vz);
+  double cth = 0.5 * (T[0] + T[5] + T[10] - 1.0);
+  cth = std::min(1.0, std::max(-1.0, cth));
+  return atan2(0.5 * s2, cth);
+}
+
+// |v| and |w| of log_SE3(d) = [V^-1 t; w]  
+static void se3_log_norms(const CPose3D& d, double& nt, double& nr) {
+  const double* T = d.T;
+  const double vx = T[9] - T[6], vy = T[2] - T[8], vz = T[4] - T[1];
+  const double s2 = std::sqrt(vx * vx + vy * vy + vz * vz);
+  const double th = d.rotationAngle();
+  double w[3] = {0, 0, 0};
+  if (s2 > 1e-300) {
+    const double k = (th < 1e-7) ? 0.5 * (1.0 + th * th / 6.0) : th / s2;
+    w[0] = k * vx; w[1] = k * vy; w[2] = k * vz;
+  }
+  const double th2 = th * th;
+  const double kk = th < 1e-2 ? 1.0 / 12.0 + th2 / 720.0 + th2 * th2 / 30240.0 : (1.0 - 0.5 * th / std::tan(0.5 * th)) / th2;
+  const double t[3] = {T[3], T[7], T[11]};
+  // V^-1 t = t - 0.5 w x t + kk w x (w x t)
+  const double c1[3] = {w[1] * t[2] - w[2] * t[1], w[2] * t[0] - w[0] * t[2], w[0] * t[1] - w[1] * t[0]};
+  const double c2[3] = {w[1] * c1[2] - w[2] * c1[1], w[2] * c1[0] - w[0] * c1[2], w[0] * c1[1] - w[1] * c1[0]};
+  double v[3];
+  for (int i = 0; i < 3; i++) v[i] = t[i] - 0.5 * c1[i] + kk * c2[i];
+  nt = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  nr = th;
+}
+
+const char* enum2str(IterTermReason r) {
+  static const char* n[] = {"Undefined", "NoPairings", "SolverError", "MaxIterations", "Stalled", "QualityCheckpointFailed",
+                            "HookRequest"};
+  return n[(int)r];
+}
+
+void throw_status(mh_status s, const char* where) {
+  throw std::runtime_error(std::string(where) + ": " + mh_status_string(s) + ": " + mh_last_error_string());
+}
+
+// ================================================================== device handles
+DeviceContext::DeviceContext(int device) { check(mh_ctx_create(device, nullptr, &ctx_), "mh_ctx_create"); }
+DeviceContext::~DeviceContext() { mh_ctx_destroy(ctx_); }
+
+std::shared_ptr<DeviceContext> DeviceContext::Default() {
+  static std::mutex mtx;
+  static std::weak_ptr<DeviceContext> weak;
+  std::lock_guard<std::mutex> lk(mtx);
+  auto sp = weak.lock();
+  if (!sp) {
+    sp = std::make_shared<DeviceContext>(0);
+    weak = sp;
+  }
+  return sp;
+}
+
+HashedVoxelPointCloud::HashedVoxelPointCloud(float voxel_size, uint32_t max_points_per_voxel, std::shared_ptr<DeviceContext> ctx)
+    : ctx_(std::move(ctx)) {
+  mh_map_params p{voxel_size, max_points_per_voxel, MH_INDEX_FLOOR, 0};
+  check(mh_map_create(ctx_->get(), &p, &map_), "mh_map_create");
+}
+HashedVoxelPointCloud::~HashedVoxelPointCloud() { mh_map_destroy(map_); }
+
+void HashedVoxelPointCloud::setPoints(const float* x, const float* y, const float* z, size_t n) {
+  hx_.assign(x, x + n);
+  hy_.assign(y, y + n);
+  hz_.assign(z, z + n);
+  check(mh_map_build(map_, hx_.data(), hy_.data(), hz_.data(), n, MH_MEM_HOST), "mh_map_build");
+}
+
+void HashedVoxelPointCloud::insertPoints(const float* x, const float* y, const float* z, size_t n) {
+  // insertPoint semantics need every earlier point (per-voxel cap in insertion order); until the device map
+  // grows an incremental insert the host keeps the offered points and rebuilds.
+  hx_.insert(hx_.end(), x, x + n);
+  hy_.insert(hy_.end(), y, y + n);
+  hz_.insert(hz_.end(), z, z + n);
+  check(mh_map_build(map_, hx_.data(), hy_.data(), hz_.data(), hx_.size(), MH_MEM_HOST), "mh_map_build");
+}
+
+size_t HashedVoxelPointCloud::size() const {
+  mh_map_info i;
+  check(mh_map_get_info(map_, &i), "mh_map_get_info");
+  return i.n_points;
+}
+size_t HashedVoxelPointCloud::voxelCount() const {
+  mh_map_info i;
+  check(mh_map_get_info(map_, &i), "mh_map_get_info");
+  return i.n_voxels;
+}
+
+// ================================================================== parameters
+static uint32_t to_u32(const std::string& s) { return (uint32_t)strtoul(s.c_str(), nullptr, 10); }
+static bool to_bool(const std::string& s) { return s == "true" || s == "True" || s == "1" || s == "yes"; }
+
+void Parameters::load_from(const Config& c) {
+  if (c.has("maxIterations")) maxIterations = to_u32(c["maxIterations"].asString());
+  if (c.has("minAbsStep_trans")) minAbsStep_trans = strtod(c["minAbsStep_trans"].asString().c_str(), nullptr);
+  if (c.has("minAbsStep_rot")) minAbsStep_rot = strtod(c["minAbsStep_rot"].asString().c_str(), nullptr);
+  if (c.has("generateDebugFiles")) generateDebugFiles = to_bool(c["generateDebugFiles"].asString());
+}
+
+// ================================================================== matcher
+bool Matcher::match(const metric_map_t& pcGlobal, const metric_map_t& pcLocal, const CPose3D& localPose,
+                    const MatchContext& mc, Pairings& out) const {
+  if (!enabled) return false;
+  if (runFromIteration != 0 && mc.icpIteration < runFromIteration) return false;
+  if (runUpToIteration != 0 && mc.icpIteration > runUpToIteration) return false;
+  impl_match(pcGlobal, pcLocal, localPose, mc, out);
+  return true;
+}
+
+void Matcher_Points_DistanceThreshold::initialize(const Config& c) {
+  parameterFromConfig(c, "threshold", &threshold, true);
+  parameterFromConfig(c, "thresholdAngularDeg", &thresholdAngularDeg, false);
+  if (c.has("pairingsPerPoint")) pairingsPerPoint = to_u32(c["pairingsPerPoint"].asString());
+  if (c.has("allowMatchAlreadyMatchedGlobalPoints"))
+    allowMatchAlreadyMatchedGlobalPoints = to_bool(c["allowMatchAlreadyMatchedGlobalPoints"].asString());
+  if (c.has("runFromIteration")) runFromIteration = to_u32(c["runFromIteration"].asString());
+  if (c.has("runUpToIteration")) runUpToIteration = to_u32(c["runUpToIteration"].asString());
+  pointLayerMatches.clear();
+  if (c.has("pointLayerMatches")) {
+    const Config& s = c["pointLayerMatches"];
+    for (size_t i = 0; i < s.size(); i++) {
+      LayerMatch lm;
+      lm.global = s.at(i)["global"].asString();
+      lm.local = s.at(i)["local"].asString();
+      lm.weight = strtod(s.at(i).getOr("weight", "1.0").c_str(), nullptr);
+      pointLayerMatches.push_back(lm);
+    }
+  }
+  if (pairingsPerPoint != 1)
+    throw std::runtime_error("Matcher_Points_DistanceThreshold: only pairingsPerPoint=1 is implemented on the device "
+                             "(the value both reference pipelines use)");
+}
+
+static const PointCloud& local_layer(const metric_map_t& m, const std::string& name) {
+  auto it = m.layers.find(name);
+  if (it == m.layers.end()) throw std::runtime_error("local layer '" + name + "' not found");
+  auto p = std::dynamic_pointer_cast<PointCloud>(it->second);
+  if (!p) throw std::runtime_error("local layer '" + name + "' is not a point cloud");
+  return *p;
+}
+static const HashedVoxelPointCloud& global_layer(const metric_map_t& m, const std::string& name) {
+  auto it = m.layers.find(name);
+  if (it == m.layers.end()) throw std::runtime_error("global layer '" + name + "' not found");
+  auto p = std::dynamic_pointer_cast<HashedVoxelPointCloud>(it->second);
+  if (!p) throw std::runtime_error("global layer '" + name + "' is not NearestNeighborsCapable on the device");
+  return *p;
+}
+
+void Matcher_Points_DistanceThreshold::impl_match(const metric_map_t& pcGlobal, const metric_map_t& pcLocal,
+                                                  const CPose3D& localPose, const MatchContext&, Pairings& out) const {
+  for (const auto& lm : pointLayerMatches) {
+    const PointCloud& loc = local_layer(pcLocal, lm.local);
+    const HashedVoxelPointCloud& glob = global_layer(pcGlobal, lm.global);
+    const size_t n = loc.size();
+    out.potential_pairings += n * pairingsPerPoint;
+    if (!n) continue;
+    mh_scan* scan = nullptr;
+    check(mh_scan_create(glob.context()->get(), loc.x.data(), loc.y.data(), loc.z.data(), n, MH_MEM_HOST, &scan), "mh_scan_create");
+    std::vector<uint32_t> li(n), gi(n);
+    std::vector<float> gx(n), gy(n), gz(n), d2(n);
+    mh_pairs_out po{li.data(), gi.data(), gx.data(), gy.data(), gz.data(), d2.data()};
+    mh_match_info info{};
+    const mh_status st = mh_nn_search(glob.handle(), scan, localPose.T, threshold, thresholdAngularDeg, &po, MH_MEM_HOST, &info);
+    mh_scan_destroy(scan);
+    check(st, "mh_nn_search");
+    for (size_t k = 0; k < info.n_pairs; k++) {
+      out.localIdx.push_back(li[k]);
+      out.globalIdx.push_back(gi[k]);
+      out.lx.push_back(loc.x[li[k]]);
+      out.ly.push_back(loc.y[li[k]]);
+      out.lz.push_back(loc.z[li[k]]);
+      out.gx.push_back(gx[k]);
+      out.gy.push_back(gy[k]);
+      out.gz.push_back(gz[k]);
+      out.errSq.push_back(d2[k]);
+    }
+  }
+}
+
+// ================================================================== solver
+static RobustKernel parse_kernel(std::string s) {
+  const size_t p = s.rfind("::");
+  if (p != std::string::npos) s = s.substr(p + 2);
+  if (s == "None") return RobustKernel::None;
+  if (s == "GemanMcClure") return RobustKernel::GemanMcClure;
+  if (s == "Cauchy") return RobustKernel::Cauchy;
+  if (s == "GemanMcClure_KISS") return RobustKernel::GemanMcClure_KISS;
+  if (s == "GemanMcClure_Barron") return RobustKernel::GemanMcClure_Barron;
+  if (s == "GemanMcClure_C2") return RobustKernel::GemanMcClure_C2;
+  throw std::runtime_error("unknown robustKernel '" + s + "'");
+}
+
+void Solver_GaussNewton::initialize(const Config& c) {
+  if (c.has("maxIterations")) maxIterations = to_u32(c["maxIterations"].asString());
+  if (c.has("robustKernel")) robustKernel = parse_kernel(c["robustKernel"].asString());
+  parameterFromConfig(c, "robustKernelParam", &robustKernelParam, false);
+  if (c.has("minDelta")) minDelta = strtod(c["minDelta"].asString().c_str(), nullptr);
+  if (c.has("maxCost")) maxCost = strtod(c["maxCost"].asString().c_str(), nullptr);
+}
+
+static mh_gn_params gn_params_of(const Solver_GaussNewton& s) {
+  mh_gn_params p{};
+  p.max_inner_iterations = s.maxIterations;
+  p.robust_kernel = (uint32_t)s.robustKernel;
+  p.robust_kernel_param = s.robustKernelParam;
+  p.min_delta = s.minDelta;
+  p.max_cost = s.maxCost;
+  p.weight_pt2pt = 1.0;
+  p.weight_pt2pl = 1.0;
+  return p;
+}
+
+static void fill_prior(const std::optional<CPose3DPDFGaussianInf>& prior, mh_prior& out) {
+  memcpy(out.mean, prior->mean.T, sizeof(out.mean));
+  memcpy(out.info, prior->cov_inv, sizeof(out.info));
+}
+
+bool Solver_GaussNewton::optimal_pose(const Pairings& p, OptimalTF_Result& out, const SolverContext& sc) const {
+  if (!sc.guessRelativePose) throw std::runtime_error("Solver_GaussNewton: guessRelativePose is required");
+  mh_pairs_pt2pt pp{p.lx.data(), p.ly.data(), p.lz.data(), p.gx.data(), p.gy.data(), p.gz.data(), p.localIdx.size()};
+  mh_pairs_pt2pl pl{p.pl_lx.data(), p.pl_ly.data(), p.pl_lz.data(), p.pl_cx.data(), p.pl_cy.data(), p.pl_cz.data(),
+                    p.pl_nx.data(), p.pl_ny.data(), p.pl_nz.data(), p.pl_lx.size()};
+  const mh_gn_params gp = gn_params_of(*this);
+  mh_prior pr;
+  if (sc.prior) fill_prior(sc.prior, pr);
+  double T[12];
+  memcpy(T, sc.guessRelativePose->T, sizeof(T));
+  int32_t n_steps = 0, ok = 1;
+  check(mh_gn_solve(DeviceContext::Default()->get(), &pp, &pl, MH_MEM_HOST, &gp, sc.prior ? &pr : nullptr, T, &n_steps, &ok, nullptr),
+        "mh_gn_solve");
+  memcpy(out.optimalPose.T, T, sizeof(T));
+  return ok != 0;
+}
+
+// ================================================================== factory
+Matcher::Ptr create_matcher(const std::string& cn) {
+  if (cn == "mp2p_icp::Matcher_Points_DistanceThreshold" || cn == "mp2p_icp_hip::Matcher_Points_DistanceThreshold")
+    return std::make_shared<Matcher_Points_DistanceThreshold>();
+  throw std::runtime_error("matcher class '" + cn + "' is not available in mp2p_icp_hip");
+}
+Solver::Ptr create_solver(const std::string& cn) {
+  if (cn == "mp2p_icp::Solver_GaussNewton" || cn == "mp2p_icp_hip::Solver_GaussNewton")
+    return std::make_shared<Solver_GaussNewton>();
+  throw std::runtime_error("solver class '" + cn + "' is not available in mp2p_icp_hip");
+}
+
+// ================================================================== ICP
+ICP::ICP(std::shared_ptr<DeviceContext> ctx) : ctx_(std::move(ctx)) {}
+ICP::~ICP() {
+  if (scan_) mh_scan_destroy(scan_);
+}
+
+void ICP::setDeviceHook(double min_trans, double min_rot_rad, const CPose3D& checkpoint) {
+  dev_hook_ = true;
+  dev_hook_trans_ = min_trans;
+  dev_hook_rot_ = min_rot_rad;
+  dev_hook_chk_ = checkpoint;
+}
+void ICP::clearHooks() {
+  dev_hook_ = false;
+  iteration_hook_ = nullptr;
+}
+
+void ICP::attachToParameterSource(ParameterSource& s) {
+  source_ = &s;
+  for (auto& m : matchers_) m->attachToParameterSource(s);
+  for (auto& v : solvers_) v->attachToParameterSource(s);
+}
+
+void ICP::initialize_matchers(const Config& seq) {
+  matchers_.clear();
+  for (size_t i = 0; i < seq.size(); i++) {
+    auto m = create_matcher(seq.at(i)["class"].asString());
+    m->initialize(seq.at(i)["params"]);
+    m->attachToParameterSource(own_source_);
+    matchers_.push_back(m);
+  }
+}
+void ICP::initialize_solvers(const Config& seq) {
+  solvers_.clear();
+  for (size_t i = 0; i < seq.size(); i++) {
+    auto s = create_solver(seq.at(i)["class"].asString());
+    s->initialize(seq.at(i)["params"]);
+    s->attachToParameterSource(own_source_);
+    solvers_.push_back(s);
+  }
+}
+
+// ICP::align updates "ICP_ITERATION" in the attached sources and re-realizes them every iteration [U]
+void ICP::realize_iteration(uint32_t k) {
+  std::map<std::string, double> vars = source_ ? source_->getVariableValues() : own_source_.getVariableValues();
+  vars["ICP_ITERATION"] = (double)k;
+  for (auto& m : matchers_) m->realizeWith(vars);
+  for (auto& s : solvers_) s->realizeWith(vars);
+}
+
+bool ICP::can_fuse() const {
+  if (force_generic_ || iteration_hook_) return false;
+  if (matchers_.size() != 1 || solvers_.size() != 1) return false;
+  auto m = std::dynamic_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_[0]);
+  auto s = std::dynamic_pointer_cast<Solver_GaussNewton>(solvers_[0]);
+  if (!m || !s) return false;
+  return m->enabled && m->runFromIteration == 0 && m->runUpToIteration == 0 && m->pairingsPerPoint == 1 &&
+         m->pointLayerMatches.size() == 1 && m->pointLayerMatches[0].weight == 1.0;
+}
+
+void ICP::align(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const TPose3D& guess, const Parameters& p,
+                Results& result, const std::optional<CPose3DPDFGaussianInf>& prior) {
+  result = Results();
+  const CPose3D g(guess);
+  if (can_fuse()) {
+    auto m = std::static_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_[0]);
+    last_fused_ = true;
+    align_fused(local_layer(pcLocal, m->pointLayerMatches[0].local), global_layer(pcGlobal, m->pointLayerMatches[0].global), g, p,
+                result, prior);
+  } else {
+    last_fused_ = false;
+    align_generic(pcLocal, pcGlobal, g, p, result, prior);
+  }
+}
+
+void ICP::align_fused(const PointCloud& local, const HashedVoxelPointCloud& global, const CPose3D& guess, const Parameters& p,
+                      Results& result, const std::optional<CPose3DPDFGaussianInf>& prior) {
+  auto m = std::static_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_[0]);
+  auto s = std::static_pointer_cast<Solver_GaussNewton>(solvers_[0]);
+  // the thresholds are functions of ICP_ITERATION only once the caller's variables are fixed for this call
+  // (LidarOdometry.cpp:1571-1635 publishes them before align): evaluate them for every iteration up front
+  std::vector<double> thr(p.maxIterations), kp(p.maxIterations);
+  for (uint32_t k = 0; k < p.maxIterations; k++) {
+    realize_iteration(k);
+    thr[k] = m->threshold;
+    kp[k] = s->robustKernelParam;
+  }
+  if (p.maxIterations) realize_iteration(0);
+  mh_icp_params ip{};
+  ip.max_iterations = p.maxIterations;
+  ip.min_abs_step_trans = p.minAbsStep_trans;
+  ip.min_abs_step_rot = p.minAbsStep_rot;
+  ip.threshold = thr.data();
+  ip.kernel_param = kp.data();
+  ip.threshold_angular_deg = m->thresholdAngularDeg;
+  ip.gn = gn_params_of(*s);
+  ip.hook_enabled = dev_hook_ ? 1u : 0u;
+  ip.hook_min_trans = dev_hook_trans_;
+  ip.hook_min_rot = dev_hook_rot_;
+  memcpy(ip.hook_checkpoint, dev_hook_chk_.T, sizeof(ip.hook_checkpoint));
+  ip.compute_covariance = 1;
+  ip.cov_findif_xyz = 1e-7;
+  ip.cov_findif_ang = 1e-7;
+  if (!scan_)
+    check(mh_scan_create(global.context()->get(), local.x.data(), local.y.data(), local.z.data(), local.size(), MH_MEM_HOST, &scan_),
+          "mh_scan_create");
+  else
+    check(mh_scan_update(scan_, local.x.data(), local.y.data(), local.z.data(), local.size(), MH_MEM_HOST), "mh_scan_update");
+  mh_prior pr;
+  if (prior) fill_prior(prior, pr);
+  mh_icp_result r{};
+  const size_t n = local.size();
+  std::vector<uint32_t> li(n), gi(n);
+  std::vector<float> gx(n), gy(n), gz(n), d2(n);
+  mh_pairs_out po{li.data(), gi.data(), gx.data(), gy.data(), gz.data(), d2.data()};
+  check(mh_icp_align(global.handle(), scan_, &ip, guess.T, prior ? &pr : nullptr, &r, nullptr, &po, MH_MEM_HOST), "mh_icp_align");
+  memcpy(result.optimal_tf.mean.T, r.T, sizeof(r.T));
+  memcpy(result.optimal_tf.cov, r.cov, sizeof(r.cov));
+  result.quality = r.quality;
+  result.nIterations = r.n_iterations;
+  result.terminationReason = (IterTermReason)r.termination_reason;
+  Pairings& fp = result.finalPairings;
+  fp.potential_pairings = r.potential_pairings;
+  for (uint32_t k = 0; k < r.n_final_pairs; k++) {
+    fp.localIdx.push_back(li[k]);
+    fp.globalIdx.push_back(gi[k]);
+    fp.lx.push_back(local.x[li[k]]);
+    fp.ly.push_back(local.y[li[k]]);
+    fp.lz.push_back(local.z[li[k]]);
+    fp.gx.push_back(gx[k]);
+    fp.gy.push_back(gy[k]);
+    fp.gz.push_back(gz[k]);
+    fp.errSq.push_back(d2[k]);
+  }
+}
+
+// matcher/solver-granular loop: the structure of mp2p_icp::ICP::align [U] with every numeric step on
+// the device; used for custom pipelines and arbitrary host iteration hooks
+void ICP::align_generic(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const CPose3D& guess, const Parameters& p,
+                        Results& result, const std::optional<CPose3DPDFGaussianInf>& prior) {
+  OptimalTF_Result cur;
+  cur.optimalPose = guess;
+  CPose3D prev = guess;
+  Pairings pairings;
+  for (result.nIterations = 0; result.nIterations < p.maxIterations; result.nIterations++) {
+    const uint32_t k = (uint32_t)result.nIterations;
+    realize_iteration(k);
+    MatchContext mc;
+    mc.icpIteration = k;
+    pairings = Pairings();
+    for (auto& m : matchers_) m->match(pcGlobal, pcLocal, cur.optimalPose, mc, pairings);
+    if (pairings.empty()) {
+      result.terminationReason = IterTermReason::NoPairings;
+      break;
+    }
+    SolverContext sc;
+    sc.guessRelativePose = cur.optimalPose;
+    sc.prior = prior;
+    sc.icpIteration = k;
+    bool ok = false;
+    for (auto& s : solvers_) {
+      ok = s->optimal_pose(pairings, cur, sc);
+      if (ok) break;
+    }
+    if (!ok) {
+      result.terminationReason = IterTermReason::SolverError;
+      break;
+    }
+    // stall test on log_SE3(prev^-1 (+) cur): |V^-1 t| and |w| (lidar3d-default.yaml:174-175)
+    double xi_t, xi_r;
+    se3_log_norms(cur.optimalPose - prev, xi_t, xi_r);
+    if (xi_t < p.minAbsStep_trans && xi_r < p.minAbsStep_rot) {
+      result.terminationReason = IterTermReason::Stalled;
+      break;
+    }
+    if (iteration_hook_) {
+      IterationHook_Input hi;
+      hi.currentIteration = k;
+      hi.currentSolution = &cur;
+      if (iteration_hook_(hi).request_stop) {
+        result.terminationReason = IterTermReason::HookRequest;
+        break;
+      }
+    } else if (dev_hook_) {
+      const CPose3D hd = cur.optimalPose - dev_hook_chk_;
+      if (hd.translationNorm() > dev_hook_trans_ || hd.rotationAngle() > dev_hook_rot_) {
+        result.terminationReason = IterTermReason::HookRequest;
+        break;
+      }
+    }
+    prev = cur.optimalPose;
+  }
+  if (result.nIterations >= p.maxIterations) result.terminationReason = IterTermReason::MaxIterations;
+  result.quality = pairings.empty() ? 0.0 : quality_.evaluate(pairings);
+  result.optimal_tf.mean = cur.optimalPose;
+  mh_pairs_pt2pt pp{pairings.lx.data(), pairings.ly.data(), pairings.lz.data(), pairings.gx.data(), pairings.gy.data(),
+                    pairings.gz.data(), pairings.localIdx.size()};
+  mh_pairs_pt2pl pl{pairings.pl_lx.data(), pairings.pl_ly.data(), pairings.pl_lz.data(), pairings.pl_cx.data(),
+                    pairings.pl_cy.data(), pairings.pl_cz.data(), pairings.pl_nx.data(), pairings.pl_ny.data(),
+                    pairings.pl_nz.data(), pairings.pl_lx.size()};
+  if (!ctx_) ctx_ = DeviceContext::Default();
+  check(mh_covariance(ctx_->get(), &pp, &pl, MH_MEM_HOST, cur.optimalPose.T, 1e-7, 1e-7, result.optimal_tf.cov), "mh_covariance");
+  result.finalPairings = std::move(pairings);
+}
+
+std::tuple<ICP::Ptr, Parameters> icp_pipeline_from_yaml(const Config& c, std::shared_ptr<DeviceContext> ctx) {
+  const std::string cn = c.getOr("class_name", "mp2p_icp::ICP");
+  if (cn != "mp2p_icp::ICP" && cn != "mp2p_icp_hip::ICP") throw std::runtime_error("ICP class '" + cn + "' is not available");
+  auto icp = std::make_shared<ICP>(std::move(ctx));
+  Parameters p;
+  if (c.has("params")) p.load_from(c["params"]);
+  icp->initialize_solvers(c["solvers"]);
+  icp->initialize_matchers(c["matchers"]);
+  if (c.has("quality")) {
+    const Config& q = c["quality"];
+    for (size_t i = 0; i < q.size(); i++) {
+      const std::string qc = q.at(i)["class"].asString();
+      if (qc != "mp2p_icp::QualityEvaluator_PairedRatio" && qc != "mp2p_icp_hip::QualityEvaluator_PairedRatio")
+        throw std::runtime_error("quality evaluator '" + qc + "' is not available");
+    }
+  }
+  return {icp, p};
+}
+
+}  // namespace mp2p_icp_hip

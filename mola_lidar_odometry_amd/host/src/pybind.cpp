@@ -1,0 +1,102 @@
+// pybind.cpp -- Python view of the C++ host layer, used by tests/test_host_layer.py so that the parity tests
+// drive ICP::align() exactly the way mola::LidarOdometry does (LidarOdometry.cpp:961-962).
+#include <pybind11/functional.h>
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "mp2p_icp_hip/mp2p_icp_hip.h"
+
+namespace py = pybind11;
+using namespace mp2p_icp_hip;
+
+static std::shared_ptr<PointCloud> make_cloud(py::array_t<float, py::array::c_style | py::array::forcecast> xyz) {
+  auto c = std::make_shared<PointCloud>();
+  auto r = xyz.unchecked<2>();
+  for (py::ssize_t i = 0; i < r.shape(0); i++) c->insertPoint(r(i, 0), r(i, 1), r(i, 2));
+  return c;
+}
+
+PYBIND11_MODULE(_mp2p_icp_hip, m) {
+  m.doc() = "mp2p_icp_hip: C++ host layer of libmolahip (mirrors the mp2p_icp plugin API)";
+  py::class_<TPose3D>(m, "TPose3D")
+      .def(py::init<>())
+      .def(py::init([](double x, double y, double z, double yaw, double pitch, double roll) { return TPose3D{x, y, z, yaw, pitch, roll}; }))
+      .def_readwrite("x", &TPose3D::x).def_readwrite("y", &TPose3D::y).def_readwrite("z", &TPose3D::z)
+      .def_readwrite("yaw", &TPose3D::yaw).def_readwrite("pitch", &TPose3D::pitch).def_readwrite("roll", &TPose3D::roll);
+  py::class_<CPose3D>(m, "CPose3D")
+      .def(py::init<>())
+      .def(py::init<const TPose3D&>())
+      .def_static("from_matrix", [](std::vector<double> T) { CPose3D p; if (T.size() != 12) throw std::runtime_error("need 12 values"); std::copy(T.begin(), T.end(), p.T); return p; })
+      .def("asTPose", &CPose3D::asTPose)
+      .def("matrix", [](const CPose3D& p) { return std::vector<double>(p.T, p.T + 12); })
+      .def("__add__", &CPose3D::operator+)
+      .def("__sub__", &CPose3D::operator-);
+  py::class_<CPose3DPDFGaussianInf>(m, "CPose3DPDFGaussianInf")
+      .def(py::init([](const CPose3D& mean, std::vector<double> info) {
+        CPose3DPDFGaussianInf p; p.mean = mean; if (info.size() != 36) throw std::runtime_error("need 36 values");
+        std::copy(info.begin(), info.end(), p.cov_inv); return p; }));
+  py::class_<Config>(m, "Config")
+      .def_static("FromYamlText", &Config::FromYamlText)
+      .def_static("FromYamlFile", &Config::FromYamlFile)
+      .def("has", &Config::has)
+      .def("__getitem__", [](const Config& c, const std::string& k) { return c[k]; })
+      .def("at", [](const Config& c, size_t i) { return c.at(i); })
+      .def("size", &Config::size)
+      .def("asString", &Config::asString);
+  m.def("evaluate_expression", &evaluate_expression);
+  py::class_<ParameterSource>(m, "ParameterSource")
+      .def(py::init<>())
+      .def("updateVariable", &ParameterSource::updateVariable)
+      .def("realize", &ParameterSource::realize);
+  py::class_<Layer, std::shared_ptr<Layer>>(m, "Layer");
+  py::class_<PointCloud, Layer, std::shared_ptr<PointCloud>>(m, "PointCloud")
+      .def(py::init(&make_cloud))
+      .def("size", &PointCloud::size);
+  py::class_<HashedVoxelPointCloud, Layer, std::shared_ptr<HashedVoxelPointCloud>>(m, "HashedVoxelPointCloud")
+      .def(py::init([](float vs, uint32_t cap) { return std::make_shared<HashedVoxelPointCloud>(vs, cap); }))
+      .def("setPoints", [](HashedVoxelPointCloud& h, py::array_t<float, py::array::c_style | py::array::forcecast> xyz) {
+        auto c = make_cloud(xyz); h.setPoints(c->x.data(), c->y.data(), c->z.data(), c->size()); })
+      .def("insertPoints", [](HashedVoxelPointCloud& h, py::array_t<float, py::array::c_style | py::array::forcecast> xyz) {
+        auto c = make_cloud(xyz); h.insertPoints(c->x.data(), c->y.data(), c->z.data(), c->size()); })
+      .def("size", &HashedVoxelPointCloud::size)
+      .def("voxelCount", &HashedVoxelPointCloud::voxelCount);
+  py::class_<metric_map_t>(m, "metric_map_t")
+      .def(py::init<>())
+      .def("set_layer", [](metric_map_t& mm, const std::string& n, std::shared_ptr<Layer> l) { mm.layers[n] = std::move(l); });
+  py::class_<Parameters>(m, "Parameters")
+      .def(py::init<>())
+      .def_readwrite("maxIterations", &Parameters::maxIterations)
+      .def_readwrite("minAbsStep_trans", &Parameters::minAbsStep_trans)
+      .def_readwrite("minAbsStep_rot", &Parameters::minAbsStep_rot);
+  py::enum_<IterTermReason>(m, "IterTermReason")
+      .value("Undefined", IterTermReason::Undefined).value("NoPairings", IterTermReason::NoPairings)
+      .value("SolverError", IterTermReason::SolverError).value("MaxIterations", IterTermReason::MaxIterations)
+      .value("Stalled", IterTermReason::Stalled).value("QualityCheckpointFailed", IterTermReason::QualityCheckpointFailed)
+      .value("HookRequest", IterTermReason::HookRequest);
+  py::class_<Results>(m, "Results")
+      .def(py::init<>())
+      .def_readonly("quality", &Results::quality)
+      .def_readonly("nIterations", &Results::nIterations)
+      .def_readonly("terminationReason", &Results::terminationReason)
+      .def("pose", [](const Results& r) { return std::vector<double>(r.optimal_tf.mean.T, r.optimal_tf.mean.T + 12); })
+      .def("cov", [](const Results& r) { return std::vector<double>(r.optimal_tf.cov, r.optimal_tf.cov + 36); })
+      .def("n_pairs", [](const Results& r) { return r.finalPairings.size(); })
+      .def("pair_global_idx", [](const Results& r) { return r.finalPairings.globalIdx; })
+      .def("pair_local_idx", [](const Results& r) { return r.finalPairings.localIdx; });
+  py::class_<ICP, std::shared_ptr<ICP>>(m, "ICP")
+      .def("align", [](ICP& icp, const metric_map_t& l, const metric_map_t& g, const TPose3D& guess, const Parameters& p,
+                       std::optional<CPose3DPDFGaussianInf> prior) { Results r; icp.align(l, g, guess, p, r, prior); return r; },
+           py::arg("pcLocal"), py::arg("pcGlobal"), py::arg("initialGuess"), py::arg("params"), py::arg("prior") = std::nullopt)
+      .def("attachToParameterSource", &ICP::attachToParameterSource)
+      .def("setDeviceHook", &ICP::setDeviceHook)
+      .def("clearHooks", &ICP::clearHooks)
+      .def("forceGenericPath", &ICP::forceGenericPath)
+      .def("lastAlignUsedFusedPath", &ICP::lastAlignUsedFusedPath)
+      .def("setIterationHook", [](ICP& icp, std::function<bool(uint32_t, std::vector<double>)> f) {
+        icp.setIterationHook([f](const ICP::IterationHook_Input& in) {
+          ICP::IterationHook_Output o;
+          o.request_stop = f(in.currentIteration, std::vector<double>(in.currentSolution->optimalPose.T, in.currentSolution->optimalPose.T + 12));
+          return o; }); });
+  m.def("icp_pipeline_from_yaml", [](const Config& c) { auto t = icp_pipeline_from_yaml(c); return py::make_tuple(std::get<0>(t), std::get<1>(t)); });
+}

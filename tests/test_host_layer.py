@@ -1,0 +1,186 @@
+"""C++ host layer (namespace mp2p_icp_hip): the mirror of the mp2p_icp plugin API that sits on the C ABI.
+
+CPU part: YAML-subset reader, ${ENV|default}, run-time formulas, pipeline construction by class name -- when
+/root/reference is present (this container only) the reference's own pipelines/lidar3d-default.yaml is fed in
+unchanged.  GPU part: ICP::align() driven exactly like LidarOdometry.cpp:961-962 and compared with the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from mola_lidar_odometry_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_YAML = "/root/reference/pipelines/lidar3d-default.yaml"
+OUR_YAML = os.path.join(ROOT, "pipelines", "lidar3d-default-hip.yaml")
+
+
+@pytest.fixture(scope="module")
+def hl():
+    import mola_lidar_odometry_amd.capi as capi
+    capi.lib()  # load libmolahip (and torch's HIP runtime first) before the extension resolves its symbols
+    from mola_lidar_odometry_amd import _mp2p_icp_hip
+    return _mp2p_icp_hip
+
+
+def test_expression_evaluator(hl):
+    ev = hl.evaluate_expression
+    assert ev("1+2*3", {}) == 7 and ev("-(2+3)^2", {}) == -25 and ev("max(1, 2, 3) - min(4, 5)", {}) == -1
+    assert ev("2.0*max(S, 2.0*S-(2.0*S-0.5*S)*K/30)", {"S": 2.0, "K": 10.0}) == pytest.approx(6.0)
+    assert ev("abs(-3)+sqrt(16)+clamp(5,0,2)", {}) == 9
+    with pytest.raises(RuntimeError):
+        ev("1+unknown_var", {})
+    with pytest.raises(RuntimeError):
+        ev("(1+2", {})
+
+
+def test_yaml_subset_and_env_substitution(hl, monkeypatch):
+    monkeypatch.setenv("MY_ITERS", "77")
+    c = hl.Config.FromYamlText("""
+a:
+  b: ${MY_ITERS|300}   # comment
+  c: ${NOT_SET_ANYWHERE|false}
+  d: '$f{max(0.5, min(1.0, 0.015*40))}'
+seq:
+  - class: X
+    params:
+      t: 'x # not a comment'
+  - {global: "g", local: "l", weight: 1.0}
+""")
+    assert c["a"]["b"].asString() == "77" and c["a"]["c"].asString() == "false"
+    assert float(c["a"]["d"].asString()) == pytest.approx(0.6)
+    assert c["seq"].size() == 2 and c["seq"].at(0)["class"].asString() == "X"
+    assert c["seq"].at(0)["params"]["t"].asString() == "x # not a comment"
+    assert c["seq"].at(1)["local"].asString() == "l"
+
+
+@pytest.mark.parametrize("path", [OUR_YAML, REF_YAML])
+def test_pipeline_from_yaml_builds_by_class_name(hl, path):
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present on this box")
+    cfg = hl.Config.FromYamlFile(path)["icp_settings_with_vel"]
+    icp, params = hl.icp_pipeline_from_yaml(cfg)
+    assert params.maxIterations == 300 and params.minAbsStep_trans == 1e-4 and params.minAbsStep_rot == 5e-5
+    # the two run-time formulas of the pipeline (yaml:190,198) evaluate to the known schedule
+    m = cfg["matchers"].at(0)["params"]
+    s = cfg["solvers"].at(0)["params"]
+    thr, kp = synth.threshold_schedule(2.0, 40)
+    for k in (0, 7, 20, 39):
+        v = {"ADAPTIVE_THRESHOLD_SIGMA": 2.0, "ICP_ITERATION": float(k)}
+        assert hl.evaluate_expression(m["threshold"].asString(), v) == pytest.approx(thr[k])
+        assert hl.evaluate_expression(s["robustKernelParam"].asString(), v) == pytest.approx(kp[k])
+    assert m["pointLayerMatches"].at(0)["global"].asString() == "localmap"
+    assert m["pointLayerMatches"].at(0)["local"].asString() == "decimated_for_icp"
+
+
+def test_unknown_class_is_an_error(hl):
+    cfg = hl.Config.FromYamlText("""
+class_name: mp2p_icp::ICP
+solvers:
+  - class: mp2p_icp::Solver_Horn
+    params:
+      ~
+matchers:
+  - class: mp2p_icp::Matcher_Points_DistanceThreshold
+    params:
+      threshold: 1.0
+""")
+    with pytest.raises(RuntimeError):
+        hl.icp_pipeline_from_yaml(cfg)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _maps(hl, w):
+    g = hl.metric_map_t()
+    hv = hl.HashedVoxelPointCloud(w.voxel_size, w.cap)
+    hv.setPoints(w.map_xyz)
+    g.set_layer("localmap", hv)
+    l = hl.metric_map_t()
+    l.set_layer("decimated_for_icp", hl.PointCloud(w.scan_xyz))
+    return l, g, hv
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("generic", [False, True])
+def test_icp_align_through_the_plugin_api_matches_oracle(hl, oracle, small_workload, generic):
+    """The call of LidarOdometry.cpp:961-962: icp->align(local, global, guess, params, result[, prior]) with the
+    pipeline built from YAML and ADAPTIVE_THRESHOLD_SIGMA fed through a ParameterSource (LidarOdometry.cpp:1601-1604)."""
+    w = small_workload
+    cfg = hl.Config.FromYamlFile(OUR_YAML)["icp_settings_with_vel"]
+    icp, params = hl.icp_pipeline_from_yaml(cfg)
+    src = hl.ParameterSource()
+    src.updateVariable("ADAPTIVE_THRESHOLD_SIGMA", w.sigma)
+    src.updateVariable("ICP_ITERATION", 0)
+    icp.attachToParameterSource(src)
+    src.realize()
+    icp.forceGenericPath(generic)
+    l, g, hv = _maps(hl, w)
+    assert hv.size() == len(w.map_xyz)
+    res = icp.align(l, g, hl.TPose3D(*w.guess_ypr), params)
+    assert icp.lastAlignUsedFusedPath() == (not generic)
+    thr, kp = synth.threshold_schedule(w.sigma, 300)
+    om = oracle.Map(w.voxel_size, w.cap).insert(w.map_xyz)
+    o = oracle.icp_align(om, w.scan_xyz, w.T_guess, oracle.ICPParams(max_iterations=300, threshold=thr, kernel_param=kp),
+                         want_pairs=True)
+    assert res.nIterations == o["n_iterations"]
+    assert res.terminationReason.name == oracle.TERM_NAMES[o["termination_reason"]]
+    np.testing.assert_allclose(res.pose(), o["T"], atol=1e-7)
+    assert res.quality == o["quality"] and res.n_pairs() == o["n_final_pairs"]
+    np.testing.assert_array_equal(res.pair_global_idx(), o["pairs"]["global_idx"])
+    np.testing.assert_allclose(np.reshape(res.cov(), (6, 6)), o["cov"], rtol=2e-5, atol=1e-6 * np.abs(o["cov"]).max())
+
+
+@pytest.mark.gpu
+def test_twist_hook_protocol_device_and_host_hooks_agree(hl, oracle, small_workload):
+    """The in-tree hook (LidarOdometry.cpp:923-952) as a device-side test and as an arbitrary host callback must stop
+    at the same iteration with the same pose; then the caller re-runs with the remaining budget (:956-967)."""
+    w = small_workload
+    cfg = hl.Config.FromYamlFile(OUR_YAML)["icp_settings_with_vel"]
+    l, g, _ = _maps(hl, w)
+    guess = hl.TPose3D(*w.guess_ypr)
+    results = []
+    for mode in ("device", "host"):
+        icp, params = hl.icp_pipeline_from_yaml(cfg)
+        src = hl.ParameterSource()
+        src.updateVariable("ADAPTIVE_THRESHOLD_SIGMA", w.sigma)
+        icp.attachToParameterSource(src)
+        params.maxIterations = 40
+        chk = hl.CPose3D(guess)
+        if mode == "device":
+            icp.setDeviceHook(0.15, float(np.deg2rad(0.75)), chk)
+        else:
+            def hook(it, T, chk=chk):
+                d = hl.CPose3D.from_matrix(T) - chk
+                t = np.asarray(d.matrix()).reshape(3, 4)
+                ang = np.arccos(np.clip((np.trace(t[:, :3]) - 1) / 2, -1, 1))
+                return bool(np.linalg.norm(t[:, 3]) > 0.15 or ang > np.deg2rad(0.75))
+            icp.setIterationHook(hook)
+        results.append(icp.align(l, g, guess, params))
+    a, b = results
+    assert a.terminationReason.name == b.terminationReason.name == "HookRequest"
+    assert a.nIterations == b.nIterations
+    np.testing.assert_allclose(a.pose(), b.pose(), atol=1e-9)
+    thr, kp = synth.threshold_schedule(w.sigma, 40)
+    om = oracle.Map(w.voxel_size, w.cap).insert(w.map_xyz)
+    o = oracle.icp_align(om, w.scan_xyz, w.T_guess, oracle.ICPParams(
+        max_iterations=40, threshold=thr, kernel_param=kp, hook_enabled=True, hook_min_trans=0.15,
+        hook_min_rot=float(np.deg2rad(0.75))))
+    assert a.nIterations == o["n_iterations"]
+    np.testing.assert_allclose(a.pose(), o["T"], atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_failures_surface_as_exceptions(hl, small_workload):
+    """The reference catches std::exception around the whole scan (LidarOdometry.cpp:614-619)."""
+    w = small_workload
+    cfg = hl.Config.FromYamlFile(OUR_YAML)["icp_settings_with_vel"]
+    icp, params = hl.icp_pipeline_from_yaml(cfg)
+    l, g, _ = _maps(hl, w)
+    with pytest.raises(RuntimeError):  # ADAPTIVE_THRESHOLD_SIGMA was never published
+        icp.align(l, g, hl.TPose3D(*w.guess_ypr), params)
+    empty = hl.metric_map_t()
+    src = hl.ParameterSource()
+    src.updateVariable("ADAPTIVE_THRESHOLD_SIGMA", 2.0)
+    icp.attachToParameterSource(src)
+    with pytest.raises(RuntimeError):  # layer missing
+        icp.align(empty, g, hl.TPose3D(*w.guess_ypr), params)
