@@ -66,6 +66,15 @@ struct PoseArg {
   double m[12];
 };
 
+// LDS hand-off between lanes of ONE wave: LDS operations of a wave execute in order, so only the compiler has to be
+// kept from moving the accesses across this point.
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
 // ================================================================================================
 // k_match: correspondence search (+ first Gauss-Newton accumulation when FUSED)
 // ================================================================================================
@@ -93,7 +102,8 @@ __global__ __launch_bounds__(kBlock) void k_match(const IcpDeviceState* __restri
     for (int i = 0; i < 12; i++) T[i] = Targ.m[i];
     thr2 = thr2_arg;
   }
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t bid = blockIdx.x;
+  const uint32_t i = bid * kBlock + threadIdx.x;
   Acc a;
   acc_zero(a);
   if (i < n) {
@@ -119,432 +129,286 @@ __global__ __launch_bounds__(kBlock) void k_match(const IcpDeviceState* __restri
     }
     __syncthreads();
     if (threadIdx.x < kAccN)
-      partials[threadIdx.x * pstride + blockIdx.x] =
+      partials[threadIdx.x * pstride + bid] =
           ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
   }
 }
 
 // ================================================================================================
-// k_match4: same contract as k_match<true>, four lanes per scan point (nn_search_cols + quad_combine)
-// ================================================================================================
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_match4(const IcpDeviceState* __restrict__ st, MatchK k,
-                                                    const float* __restrict__ lx, const float* __restrict__ ly,
-                                                    const float* __restrict__ lz, uint32_t n, MapView map,
-                                                    float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
-                                                    double* __restrict__ partials, uint32_t pstride) {
-  constexpr int NW = THREADS / 64;
-  __shared__ double lds[NW][kAccN];
-  if (st->done) return;  // wave-uniform
-  double T[12];
-  const uint32_t it = st->iter;
-#pragma unroll
-  for (int i = 0; i < 12; i++) T[i] = st->T[i];
-  const double thr = k.thr[it];
-  const float thr2 = (float)(thr * thr);
-  const double kparam = k.kparam[it];
-  const uint32_t t = blockIdx.x * THREADS + threadIdx.x;
-  const uint32_t q = t >> 2;
-  const int part = t & 3;
-  Acc a;
-  acc_zero(a);
-  float x = 0.f, y = 0.f, z = 0.f, px = 0.f, py = 0.f, pz = 0.f;
-  float d2 = __builtin_inff();
-  f32x4 pt = (f32x4)(0.f);
-  if (q < n) {
-    x = lx[q]; y = ly[q]; z = lz[q];
-    transform_point(T, x, y, z, px, py, pz);
-    nn_search_cols(map, px, py, pz, part, d2, pt);
-  }
-  quad_combine(part, d2, pt);
-  if (q < n && part == 0) {
-    const float n2 = (px * px + py * py) + pz * pz;
-    const bool ok = (d2 < __builtin_inff()) && (d2 < thr2 + k.ang2 * n2);
-    pair_q[q] = make_float4(pt.x, pt.y, pt.z, d2);
-    pair_gidx[q] = ok ? __float_as_uint(pt.w) : kNoMatch;
-    if (ok) acc_pt2pt(a, T, x, y, z, pt.x, pt.y, pt.z, k.kernel, kparam, k.w_pt2pt);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int j = 0; j < kAccN; j++) {
-    const double s = wave_sum(a.v[j]);
-    if (lane == 0) lds[wave][j] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < kAccN) {
-    double s = lds[0][threadIdx.x];
-#pragma unroll
-    for (int w = 1; w < NW; w++) s += lds[w][threadIdx.x];
-    partials[threadIdx.x * pstride + blockIdx.x] = s;
-  }
-}
-
-// ================================================================================================
-// k_matchq: LPQ adjacent lanes co-operate on ONE scan point.
+// k_matchr: "one 16-lane row per voxel run" version of the exact branch-and-bound search.
 //
-// Why: with one lane per point every lane of a wave gathers a different cache line, and the CU's
-// vector-L1 tag pipeline (about one line per clock) becomes the limit -- measured ~63 us per launch on
-// C2 no matter how the dependent-load chains are arranged.  Here the LPQ lanes of a group read LPQ
-// CONSECUTIVE 16-byte records of the same z-run, so one wave-level load touches 64/LPQ * (1..2) lines
-// instead of 64.  The 27 hash probes of a point are spread over the group's lanes as well.
-//   * group-local results are merged with a lexicographic (d2, scan position) minimum, which is the
-//     "first strict minimum in x/y/z/insertion order" of the reference;
-//   * blocks are persistent (grid-stride over chunks of 256/LPQ points) so the number of partial rows
-//     handed to k_solve is bounded by the grid size, not by the scan size.
+// Lessons of the instrumented k_matchw (s_memtime per phase, C2): a dependent round trip costs ~2k cycles here, so a
+// wave's time is (#round trips) x 2k + work; the item list cost 11k cycles to produce and the same-address LDS atomics
+// of consecutive items another ~10k.  This version keeps the pooling idea but drops the item list:
+//   * a wave owns QPW = 32 scan points (lanes 0..31 take the per-point decisions); twice as many, lighter waves also
+//     shorten the tail that the slowest wave imposes on a one-scan launch;
+//   * surviving voxel runs (split to <= 16 records) go to a per-wave run table {first, count | owner << 16} in LDS;
+//   * consumption is run-major: each 16-lane row takes one run, lane t loads record first+t (one coalesced 256-byte
+//     access per row), eight rows-steps (32 runs) are in flight before the first is looked at;
+//   * the row minimum of (d2 bits << 32 | record index) is taken with DPP row shifts (VALU only, no LDS traffic) and
+//     lane 0 of the row issues ONE ds_min_u64 for the run -- at most 4 atomics per step, to different owners.
+// Exactness is unchanged: integer order of the key == lexicographic (d2, scan position) == the reference's first strict
+// minimum; a voxel is skipped only if its conservative lower bound exceeds the best d2 already found.
 // ================================================================================================
-template <int LPQ>
-__global__ __launch_bounds__(kBlock) void k_matchq(const IcpDeviceState* __restrict__ st, MatchK k,
-                                                   const float* __restrict__ lx, const float* __restrict__ ly,
-                                                   const float* __restrict__ lz, uint32_t n, MapView map,
-                                                   float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
-                                                   double* __restrict__ partials, uint32_t pstride) {
-  constexpr int QPB = kBlock / LPQ;  // scan points per block per pass
-  constexpr int SPL = (27 + LPQ - 1) / LPQ;  // hash slots per lane
-  __shared__ double lds[kBlock / 64][kAccN];
-  __shared__ uint2 runs[QPB][28];  // per point: {first, count} of each of the 27 voxels
-  if (st->done) return;  // wave-uniform
-  double T[12];
-  const uint32_t it = st->iter;
-#pragma unroll
-  for (int i = 0; i < 12; i++) T[i] = st->T[i];
-  const double thr = k.thr[it];
-  const float thr2 = (float)(thr * thr);
-  const double kparam = k.kparam[it];
-  const int g = threadIdx.x / LPQ;  // group (= point) inside the block
-  const int sub = threadIdx.x % LPQ;
-  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(map.slots);
-  const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(map.pts);
-  Acc a;
-  acc_zero(a);
-  const uint32_t nchunks = (n + QPB - 1) / QPB;
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const uint32_t q = chunk * QPB + g;
-    float x = 0.f, y = 0.f, z = 0.f, px = 0.f, py = 0.f, pz = 0.f;
-    bool valid = false;
-    unsigned long long kbase = 0;
-    if (q < n) {
-      x = lx[q]; y = ly[q]; z = lz[q];
-      transform_point(T, x, y, z, px, py, pz);
-      const float lim = 1.0e6f;
-      valid = isfinite(px) && isfinite(py) && isfinite(pz) && fabsf(px * map.inv_vs) < lim &&
-              fabsf(py * map.inv_vs) < lim && fabsf(pz * map.inv_vs) < lim;
-      if (valid)
-        kbase = pack_key(voxel_of(px, map.inv_vs, map.trunc) - 1, voxel_of(py, map.inv_vs, map.trunc) - 1,
-                         voxel_of(pz, map.inv_vs, map.trunc) - 1);
-    }
-    // ---- hash probes: lane `sub` owns voxels c = sub, sub+LPQ, ... of the 27-block ----
-    u32x4 s[SPL];
-#pragma unroll
-    for (int r = 0; r < SPL; r++) {
-      const int c = sub + r * LPQ;
-      u32x4 v = (u32x4)(0xFFFFFFFFu);
-      if (valid && c < 27) {
-        const unsigned long long key = kbase + ((unsigned long long)(c / 9) << 42) +
-                                       ((unsigned long long)((c / 3) % 3) << 21) + (unsigned long long)(c % 3);
-        v = slots4[hash_key(key) & map.mask];
-      }
-      s[r] = v;
-    }
-#pragma unroll
-    for (int r = 0; r < SPL; r++) {
-      const int c = sub + r * LPQ;
-      if (c < 27) {
-        uint2 run = make_uint2(0u, 0u);
-        if (valid) {
-          const unsigned long long key = kbase + ((unsigned long long)(c / 9) << 42) +
-                                         ((unsigned long long)((c / 3) % 3) << 21) + (unsigned long long)(c % 3);
-          u32x4 sl = s[r];
-          unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
-          if (sk != key && sk != kEmptyKey) {  // rare: linear probing past a collision
-            uint32_t h = hash_key(key) & map.mask;
-            do {
-              h = (h + 1) & map.mask;
-              sl = slots4[h];
-              sk = ((unsigned long long)sl.y << 32) | sl.x;
-            } while (sk != key && sk != kEmptyKey);
-          }
-          if (sk == key) run = make_uint2(sl.z, sl.w);
-        }
-        runs[g][c] = run;
-      }
-    }
-    __syncthreads();
-    // ---- distance scan: the group walks the 9 z-runs in reference order, LPQ records per step ----
-    float best = __builtin_inff();
-    uint32_t best_seq = 0xFFFFFFFFu;
-    f32x4 bpt = (f32x4)(0.f);
-    uint32_t seq_base = 0;
-#pragma unroll 1
-    for (int col = 0; col < 9; col++) {
-      const uint2 r0 = runs[g][col * 3], r1 = runs[g][col * 3 + 1], r2 = runs[g][col * 3 + 2];
-      const uint32_t cnt = r0.y + r1.y + r2.y;
-      const uint32_t first = r0.y ? r0.x : (r1.y ? r1.x : r2.x);  // the three z-neighbours are contiguous
-      const f32x4* __restrict__ p = pts4 + first;
-      for (uint32_t j = sub; j < cnt; j += 2 * LPQ) {
-        const uint32_t j1 = j + LPQ;
-        const f32x4 c0 = p[j];
-        const f32x4 c1 = p[j1 < cnt ? j1 : j];
-        {
-          const float dx = c0.x - px, dy = c0.y - py, dz = c0.z - pz;
-          const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order
-          if (d2 < best) { best = d2; bpt = c0; best_seq = seq_base + j; }
-        }
-        {
-          const float dx = c1.x - px, dy = c1.y - py, dz = c1.z - pz;
-          const float d2 = (dx * dx + dy * dy) + dz * dz;
-          if (d2 < best) { best = d2; bpt = c1; best_seq = seq_base + j1; }
-        }
-      }
-      seq_base += cnt;
-    }
-    // ---- merge inside the group: min over (d2, scan position) ----
-#pragma unroll
-    for (int bit = 1; bit < LPQ; bit <<= 1) {
-      const float od2 = __shfl_xor(best, bit);
-      const uint32_t oseq = (uint32_t)__shfl_xor((int)best_seq, bit);
-      f32x4 opt;
-      opt.x = __shfl_xor(bpt.x, bit);
-      opt.y = __shfl_xor(bpt.y, bit);
-      opt.z = __shfl_xor(bpt.z, bit);
-      opt.w = __shfl_xor(bpt.w, bit);
-      if (od2 < best || (od2 == best && oseq < best_seq)) {
-        best = od2;
-        best_seq = oseq;
-        bpt = opt;
-      }
-    }
-    if (q < n && sub == 0) {
-      const float n2 = (px * px + py * py) + pz * pz;
-      const bool ok = valid && (best < __builtin_inff()) && (best < thr2 + k.ang2 * n2);
-      pair_q[q] = make_float4(bpt.x, bpt.y, bpt.z, best);
-      pair_gidx[q] = ok ? __float_as_uint(bpt.w) : kNoMatch;
-      if (ok) acc_pt2pt(a, T, x, y, z, bpt.x, bpt.y, bpt.z, k.kernel, kparam, k.w_pt2pt);
-    }
-    __syncthreads();  // runs[] is reused by the next chunk
+constexpr int kQPW = 32;       // scan points per wave
+constexpr int kRowLanes = 16;  // lanes co-operating on one run
+constexpr int kProbeCap = 12;  // neighbour probes per point per pass
+constexpr int kRunTab = kQPW * kProbeCap * 2;  // run-table entries per wave (a run of <= 32 records is <= 2 entries)
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
+}
+// min over the 16 lanes of a row, result valid in lane 0 of the row (row_shl:k = lane i reads lane i+k of its row)
+__device__ __forceinline__ unsigned long long row_min_u64(unsigned long long key) {
+#define MH_ROW_STEP(CTRL)                                                     \
+  {                                                                           \
+    const uint32_t lo = dpp_u32<CTRL>(0xFFFFFFFFu, (uint32_t)key);            \
+    const uint32_t hi = dpp_u32<CTRL>(0xFFFFFFFFu, (uint32_t)(key >> 32));    \
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;         \
+    key = o < key ? o : key;                                                  \
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int j = 0; j < kAccN; j++) {
-    const double sum = wave_sum(a.v[j]);
-    if (lane == 0) lds[wave][j] = sum;
-  }
-  __syncthreads();
-  if (threadIdx.x < kAccN)
-    partials[threadIdx.x * pstride + blockIdx.x] =
-        ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+  MH_ROW_STEP(0x101)
+  MH_ROW_STEP(0x102)
+  MH_ROW_STEP(0x104)
+  MH_ROW_STEP(0x108)
+#undef MH_ROW_STEP
+  return key;
 }
 
-// ================================================================================================
-// k_matchc: k_matchq with the latency chain taken out (PMC on k_matchq<8>: L1 hit rate 97 %, L1 tag
-// pipe ~45 % busy, waves waiting 66 % of their cycles -> latency-bound, not bandwidth-bound):
-//   * no block barriers: the lanes that exchange data (a group) always sit in one wave, LDS is in-order
-//     per wave, so a compiler-level wave barrier is enough;
-//   * phase A requests the first 2*LPQ records of ALL nine z-runs before looking at any of them
-//     (18 independent dwordx4 loads per lane in flight); only runs longer than 2*LPQ records need the
-//     sequential phase C;
-//   * the Gauss-Newton moments are not accumulated by the 1-in-LPQ "leader" lanes: results are parked in
-//     LDS and flushed 64 at a time with every lane busy, then wave-reduced into an LDS accumulator, so
-//     no fp64 accumulator registers stay live across the search loop.
-// ================================================================================================
-__device__ __forceinline__ void wave_sync_lds() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int LPQ>
-__global__ __launch_bounds__(kBlock) void k_matchc(const IcpDeviceState* __restrict__ st, MatchK k,
-                                                   const float* __restrict__ lx, const float* __restrict__ ly,
-                                                   const float* __restrict__ lz, uint32_t n, MapView map,
-                                                   float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
-                                                   double* __restrict__ partials, uint32_t pstride) {
-  constexpr int QPB = kBlock / LPQ;          // scan points per block per pass
-  constexpr int QPW = 64 / LPQ;              // ... per wave per pass
-  constexpr int SPL = (27 + LPQ - 1) / LPQ;  // hash slots per lane
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_matchr(const IcpDeviceState* __restrict__ st, PoseArg Targ, float thr2_arg,
+                                                   uint32_t apply_thr, MatchK k, const float* __restrict__ lx,
+                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                   MapView map, float4* __restrict__ pair_q,
+                                                   uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
+                                                   uint32_t pstride) {
   constexpr int NW = kBlock / 64;
-  __shared__ uint2 runs[QPB][28];            // per point: {first, count} of each of the 27 voxels
-  __shared__ float parked[NW][64][8];        // per wave: up to 64 finished pairings {l.xyz, q.xyz, ok}
-  __shared__ double wacc[NW][kAccN];         // per wave: running Gauss-Newton moments
-  if (st->done) return;  // wave-uniform
+  __shared__ float4 s_qpos[NW][kQPW];
+  __shared__ unsigned long long s_best[NW][kQPW];
+  __shared__ uint2 s_tab[NW][kRunTab];
+  __shared__ double lds[NW][kAccN];
   double T[12];
-  const uint32_t it = st->iter;
+  float thr2;
+  double kparam = 0.0;
+  if (FUSED) {
+    if (st->done) return;  // wave-uniform
+    const uint32_t it = st->iter;
 #pragma unroll
-  for (int i = 0; i < 12; i++) T[i] = st->T[i];
-  const double thr = k.thr[it];
-  const float thr2 = (float)(thr * thr);
-  const double kparam = k.kparam[it];
+    for (int i = 0; i < 12; i++) T[i] = st->T[i];
+    const double thr = k.thr[it];
+    thr2 = (float)(thr * thr);
+    kparam = k.kparam[it];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = Targ.m[i];
+    thr2 = thr2_arg;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = threadIdx.x / LPQ;  // group (= point) inside the block
-  const int gw = lane / LPQ;        // group inside the wave
-  const int sub = threadIdx.x % LPQ;
+  const bool owner_lane = lane < kQPW;
+  const uint32_t bid = blockIdx.x;
+  const uint32_t i = (bid * NW + wave) * kQPW + lane;  // scan point of an owner lane
   const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(map.slots);
   const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(map.pts);
-  if (lane < kAccN) wacc[wave][lane] = 0.0;
-  int n_parked = 0;  // wave-uniform
+  float4* qpos = s_qpos[wave];
+  unsigned long long* best = s_best[wave];
+  uint2* tab = s_tab[wave];
 
-  auto flush = [&](int count) {
-    // every lane takes one parked pairing; full-wave fp64 work, then an ordered wave reduction
-    wave_sync_lds();
-    Acc a;
-    acc_zero(a);
-    if (lane < count) {
-      const float* e = parked[wave][lane];
-      if (e[6] != 0.f) acc_pt2pt(a, T, e[0], e[1], e[2], e[3], e[4], e[5], k.kernel, kparam, k.w_pt2pt);
+  float x = 0.f, y = 0.f, z = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+  bool valid = false;
+  if (owner_lane && i < n) {
+    x = lx[i]; y = ly[i]; z = lz[i];
+    transform_point(T, x, y, z, px, py, pz);
+    const float lim = 1.0e6f;
+    valid = isfinite(px) && isfinite(py) && isfinite(pz) && fabsf(px * map.inv_vs) < lim && fabsf(py * map.inv_vs) < lim &&
+            fabsf(pz * map.inv_vs) < lim;
+  }
+  if (owner_lane) {
+    qpos[lane] = make_float4(px, py, pz, 0.f);
+    best[lane] = ~0ull;
+  }
+  unsigned long long kbase = 0;
+  Gaps gx, gy, gz;
+  gx.s[0] = gx.s[1] = gx.s[2] = gy.s[0] = gy.s[1] = gy.s[2] = gz.s[0] = gz.s[1] = gz.s[2] = 0.f;
+  if (valid) {
+    const int cx = voxel_of(px, map.inv_vs, map.trunc), cy = voxel_of(py, map.inv_vs, map.trunc), cz = voxel_of(pz, map.inv_vs, map.trunc);
+    kbase = pack_key(cx - 1, cy - 1, cz - 1);
+    const float vs = 1.0f / map.inv_vs;
+    gx = axis_gaps(px, cx, vs, map.trunc);
+    gy = axis_gaps(py, cy, vs, map.trunc);
+    gz = axis_gaps(pz, cz, vs, map.trunc);
+  }
+
+  // resolve a probed slot to {first, count} (count 0 = voxel absent); rare linear probing past collisions
+  auto resolve = [&](unsigned long long key, u32x4 sl) -> uint2 {
+    unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
+    if (sk != key && sk != kEmptyKey) {
+      uint32_t h = hash_key(key) & map.mask;
+      do {
+        h = (h + 1) & map.mask;
+        sl = slots4[h];
+        sk = ((unsigned long long)sl.y << 32) | sl.x;
+      } while (sk != key && sk != kEmptyKey);
     }
+    return sk == key ? make_uint2(sl.z, sl.w) : make_uint2(0u, 0u);
+  };
+  // a run longer than 32 records (only possible with max_points_per_voxel > 32 or 0) is scanned by its owner alone
+  auto scan_long_run = [&](uint2 r) {
+    NNBest b;
+    b.d2 = __builtin_inff();
+    b.idx = 0xFFFFFFFFu;
+    nn_scan_voxel(pts4, r.x, r.y, px, py, pz, b);
+    if (b.idx != 0xFFFFFFFFu) atomicMin(&best[lane], ((unsigned long long)__float_as_uint(b.d2) << 32) | b.idx);
+  };
+  // wave-wide exclusive prefix sum of a per-lane count
+  auto wave_excl = [&](uint32_t v, uint32_t& total) -> uint32_t {
+    uint32_t incl = v;
 #pragma unroll
-    for (int j = 0; j < kAccN; j++) {
-      const double sum = wave_sum(a.v[j]);
-      if (lane == 0) wacc[wave][j] += sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= off) incl += t;
+    }
+    total = (uint32_t)__shfl((int)incl, 63);
+    return incl - v;
+  };
+  // consume `R` run-table entries: one 16-lane row per entry, 8 row-steps (32 entries) of loads in flight
+  const int row = lane >> 4, tl = lane & (kRowLanes - 1);
+  auto consume = [&](uint32_t R) {
+    wave_sync_lds();
+    for (uint32_t base = 0; base < R; base += 32) {
+      uint2 e[8];
+      f32x4 rec[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t r = base + u * 4 + row;
+        e[u] = tab[r < R ? r : R - 1];
+        if (r >= R) e[u].y = 0;  // count 0: the row idles this step (the load below still goes to a valid record)
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t cnt = e[u].y & 0xFFFFu;
+        const uint32_t t = (uint32_t)tl < cnt ? (uint32_t)tl : (cnt ? cnt - 1 : 0u);
+        rec[u] = pts4[e[u].x + t];  // unconditional, clamped (see k_matchw)
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t cnt = e[u].y & 0xFFFFu, owner = e[u].y >> 16;
+        unsigned long long key = ~0ull;
+        if ((uint32_t)tl < cnt) {
+          const float4 q = qpos[owner];
+          const float dx = rec[u].x - q.x, dy = rec[u].y - q.y, dz = rec[u].z - q.z;
+          const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order
+          // NaN / inf never win ("d2 < best" is false for them in the reference)
+          if (d2 < __builtin_inff()) key = ((unsigned long long)__float_as_uint(d2) << 32) | (e[u].x + (uint32_t)tl);
+        }
+        key = row_min_u64(key);
+        if (tl == 0 && key != ~0ull) atomicMin(&best[owner], key);
+      }
     }
     wave_sync_lds();
   };
+  // append this lane's run (if any) to the table, split into <= 16-record entries
+  auto table_entries_of = [&](uint2 r) -> uint32_t { return r.y == 0 || r.y > 32 ? 0u : (r.y + 15u) >> 4; };
+  auto write_entries = [&](uint32_t pos, uint2 r) {
+    if (r.y == 0 || r.y > 32) return;
+    const uint32_t tag = (uint32_t)lane << 16;
+    tab[pos] = make_uint2(r.x, (r.y < 16 ? r.y : 16u) | tag);
+    if (r.y > 16) tab[pos + 1] = make_uint2(r.x + 16, (r.y - 16) | tag);
+  };
 
-  const uint32_t nchunks = (n + QPB - 1) / QPB;
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const uint32_t q = chunk * QPB + g;
-    float x = 0.f, y = 0.f, z = 0.f, px = 0.f, py = 0.f, pz = 0.f;
-    bool valid = false;
-    unsigned long long kbase = 0;
-    if (q < n) {
-      x = lx[q]; y = ly[q]; z = lz[q];
-      transform_point(T, x, y, z, px, py, pz);
-      const float lim = 1.0e6f;
-      valid = isfinite(px) && isfinite(py) && isfinite(pz) && fabsf(px * map.inv_vs) < lim &&
-              fabsf(py * map.inv_vs) < lim && fabsf(pz * map.inv_vs) < lim;
-      if (valid)
-        kbase = pack_key(voxel_of(px, map.inv_vs, map.trunc) - 1, voxel_of(py, map.inv_vs, map.trunc) - 1,
-                         voxel_of(pz, map.inv_vs, map.trunc) - 1);
+  // ---- 1. every point's own voxel (code 13) ----
+  {
+    uint2 r = make_uint2(0u, 0u);
+    if (valid) {
+      const unsigned long long key = nn_key_of(kbase, 13);
+      r = resolve(key, slots4[hash_key(key) & map.mask]);
+      if (r.y > 32) { scan_long_run(r); r.y = 0; }
     }
-    // ---- hash probes: lane `sub` owns voxels c = sub, sub+LPQ, ... of the 27-block ----
-    u32x4 s[SPL];
-#pragma unroll
-    for (int r = 0; r < SPL; r++) {
-      const int c = sub + r * LPQ;
-      u32x4 v = (u32x4)(0xFFFFFFFFu);
-      if (valid && c < 27) {
-        const unsigned long long key = kbase + ((unsigned long long)(c / 9) << 42) +
-                                       ((unsigned long long)((c / 3) % 3) << 21) + (unsigned long long)(c % 3);
-        v = slots4[hash_key(key) & map.mask];
-      }
-      s[r] = v;
-    }
-#pragma unroll
-    for (int r = 0; r < SPL; r++) {
-      const int c = sub + r * LPQ;
-      if (c < 27) {
-        uint2 run = make_uint2(0u, 0u);
-        if (valid) {
-          const unsigned long long key = kbase + ((unsigned long long)(c / 9) << 42) +
-                                         ((unsigned long long)((c / 3) % 3) << 21) + (unsigned long long)(c % 3);
-          u32x4 sl = s[r];
-          unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
-          if (sk != key && sk != kEmptyKey) {  // rare: linear probing past a collision
-            uint32_t h = hash_key(key) & map.mask;
-            do {
-              h = (h + 1) & map.mask;
-              sl = slots4[h];
-              sk = ((unsigned long long)sl.y << 32) | sl.x;
-            } while (sk != key && sk != kEmptyKey);
-          }
-          if (sk == key) run = make_uint2(sl.z, sl.w);
-        }
-        runs[g][c] = run;
-      }
-    }
-    wave_sync_lds();
-    // ---- the 9 z-runs of this point (records of the 3 z-neighbours are contiguous) ----
-    uint32_t first9[9], cnt9[9], seq9[9];
-    {
-      uint32_t seq = 0;
-#pragma unroll
-      for (int col = 0; col < 9; col++) {
-        const uint2 r0 = runs[g][col * 3], r1 = runs[g][col * 3 + 1], r2 = runs[g][col * 3 + 2];
-        cnt9[col] = r0.y + r1.y + r2.y;
-        first9[col] = r0.y ? r0.x : (r1.y ? r1.x : r2.x);
-        seq9[col] = seq;
-        seq += cnt9[col];
-      }
-    }
-    float best = __builtin_inff();
-    uint32_t best_seq = 0xFFFFFFFFu;
-    f32x4 bpt = (f32x4)(0.f);
-    auto consider = [&](const f32x4& c, uint32_t seq) {
-      const float dx = c.x - px, dy = c.y - py, dz = c.z - pz;
-      const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order
-      if (d2 < best || (d2 == best && seq < best_seq)) {
-        best = d2;
-        bpt = c;
-        best_seq = seq;
-      }
-    };
-    // ---- phase A: first 2*LPQ records of every run, all loads issued before any compare ----
-    f32x4 bufA[9], bufB[9];
-#pragma unroll
-    for (int col = 0; col < 9; col++) {
-      const f32x4* __restrict__ p = pts4 + first9[col];
-      bufA[col] = (f32x4)(0.f);
-      bufB[col] = (f32x4)(0.f);
-      if ((uint32_t)sub < cnt9[col]) bufA[col] = p[sub];
-      if ((uint32_t)(sub + LPQ) < cnt9[col]) bufB[col] = p[sub + LPQ];
-    }
-#pragma unroll
-    for (int col = 0; col < 9; col++) {
-      if ((uint32_t)sub < cnt9[col]) consider(bufA[col], seq9[col] + sub);
-      if ((uint32_t)(sub + LPQ) < cnt9[col]) consider(bufB[col], seq9[col] + sub + LPQ);
-    }
-    // ---- phase C: the tails of long runs ----
-#pragma unroll
-    for (int col = 0; col < 9; col++) {
-      const uint32_t cnt = cnt9[col];
-      const f32x4* __restrict__ p = pts4 + first9[col];
-      for (uint32_t j = sub + 2 * LPQ; j < cnt; j += 2 * LPQ) {
-        const uint32_t j1 = j + LPQ;
-        const f32x4 c0 = p[j];
-        const f32x4 c1 = p[j1 < cnt ? j1 : j];
-        consider(c0, seq9[col] + j);
-        if (j1 < cnt) consider(c1, seq9[col] + j1);
-      }
-    }
-    // ---- merge inside the group: min over (d2, scan position) == first strict minimum in scan order ----
-#pragma unroll
-    for (int bit = 1; bit < LPQ; bit <<= 1) {
-      const float od2 = __shfl_xor(best, bit);
-      const uint32_t oseq = (uint32_t)__shfl_xor((int)best_seq, bit);
-      f32x4 opt;
-      opt.x = __shfl_xor(bpt.x, bit);
-      opt.y = __shfl_xor(bpt.y, bit);
-      opt.z = __shfl_xor(bpt.z, bit);
-      opt.w = __shfl_xor(bpt.w, bit);
-      if (od2 < best || (od2 == best && oseq < best_seq)) {
-        best = od2;
-        best_seq = oseq;
-        bpt = opt;
-      }
-    }
-    if (sub == 0) {
-      bool ok = false;
-      if (q < n) {
-        const float n2 = (px * px + py * py) + pz * pz;
-        ok = valid && (best < __builtin_inff()) && (best < thr2 + k.ang2 * n2);
-        pair_q[q] = make_float4(bpt.x, bpt.y, bpt.z, best);
-        pair_gidx[q] = ok ? __float_as_uint(bpt.w) : kNoMatch;
-      }
-      float* e = parked[wave][n_parked + gw];
-      e[0] = x; e[1] = y; e[2] = z; e[3] = bpt.x; e[4] = bpt.y; e[5] = bpt.z; e[6] = ok ? 1.f : 0.f;
-    }
-    n_parked += QPW;
-    if (n_parked == 64) {
-      flush(64);
-      n_parked = 0;
-    }
+    uint32_t R;
+    const uint32_t pos = wave_excl(table_entries_of(r), R);
+    write_entries(pos, r);
+    if (R) consume(R);
+    else wave_sync_lds();
   }
-  if (n_parked) flush(n_parked);
-  __syncthreads();
-  if (threadIdx.x < kAccN) {
-    double sum = wacc[0][threadIdx.x];
+  // ---- 2. neighbours that can still hold a candidate with d2 <= best; all their probes go out together ----
+  uint32_t mask = valid ? (0x07FFFFFFu & ~(1u << 13)) : 0u;
+  while (__ballot(mask != 0)) {
+    float bestd2 = __builtin_inff();
+    if (owner_lane) {
+      bestd2 = __uint_as_float((uint32_t)(best[lane] >> 32));
+      if (!(bestd2 == bestd2)) bestd2 = __builtin_inff();  // 0xFFFFFFFF (nothing found yet) reads as NaN
+    }
+    {
+      uint32_t m2 = 0;
 #pragma unroll
-    for (int w = 1; w < NW; w++) sum += wacc[w][threadIdx.x];
-    partials[threadIdx.x * pstride + blockIdx.x] = sum;
+      for (int c = 0; c < 27; c++) {
+        if (c == 13) continue;
+        const float lb = (gx.s[c / 9] + gy.s[(c / 3) % 3]) + gz.s[c % 3];
+        if (!(lb * 0.9999f > bestd2)) m2 |= 1u << c;
+      }
+      mask &= m2;
+    }
+    int c[kProbeCap];
+    u32x4 sl[kProbeCap];
+#pragma unroll
+    for (int t = 0; t < kProbeCap; t++) {  // unconditional loads: kProbeCap probes in flight
+      c[t] = mask ? __builtin_ctz(mask) : -1;
+      mask &= mask - 1;
+      sl[t] = slots4[hash_key(nn_key_of(kbase, c[t] < 0 ? 13 : c[t])) & map.mask];
+    }
+    uint2 rr[kProbeCap];
+    uint32_t my_entries = 0;
+#pragma unroll
+    for (int t = 0; t < kProbeCap; t++) {
+      rr[t] = make_uint2(0u, 0u);
+      if (c[t] >= 0) {
+        rr[t] = resolve(nn_key_of(kbase, c[t]), sl[t]);
+        if (rr[t].y > 32) { scan_long_run(rr[t]); rr[t].y = 0; }
+      }
+      my_entries += table_entries_of(rr[t]);
+    }
+    uint32_t R;
+    uint32_t pos = wave_excl(my_entries, R);
+#pragma unroll
+    for (int t = 0; t < kProbeCap; t++) {
+      write_entries(pos, rr[t]);
+      pos += table_entries_of(rr[t]);
+    }
+    if (R) consume(R);
+    else wave_sync_lds();
+  }
+
+  // ---- per-point epilogue (owner lanes) ----
+  Acc a;
+  acc_zero(a);
+  if (owner_lane && i < n) {
+    const unsigned long long bk = best[lane];
+    const bool found = bk != ~0ull;
+    f32x4 pt = (f32x4)(0.f);
+    float d2 = __builtin_inff();
+    if (found) {
+      pt = pts4[(uint32_t)(bk & 0xFFFFFFFFu)];
+      d2 = __uint_as_float((uint32_t)(bk >> 32));
+    }
+    bool ok = found;
+    if (FUSED || apply_thr) {
+      const float n2 = (px * px + py * py) + pz * pz;
+      ok = ok && (d2 < thr2 + k.ang2 * n2);
+    }
+    pair_q[i] = make_float4(pt.x, pt.y, pt.z, d2);
+    pair_gidx[i] = ok ? __float_as_uint(pt.w) : kNoMatch;
+    if (FUSED && ok) acc_pt2pt(a, T, x, y, z, pt.x, pt.y, pt.z, k.kernel, kparam, k.w_pt2pt);
+  }
+  if (FUSED) {
+#pragma unroll
+    for (int j = 0; j < kAccN; j++) {
+      const double s = wave_sum(a.v[j]);
+      if (lane == 0) lds[wave][j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kAccN)
+      partials[threadIdx.x * pstride + bid] =
+          ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
   }
 }
 
@@ -564,7 +428,8 @@ __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restri
 #pragma unroll
   for (int i = 0; i < 12; i++) T[i] = st->T[i];
   const double kparam = use_fixed ? kparam_fixed : k.kparam[st->iter];
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t bid = blockIdx.x;
+  const uint32_t i = bid * kBlock + threadIdx.x;
   Acc a;
   acc_zero(a);
   if (i < n && pair_gidx[i] != kNoMatch) {
@@ -579,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restri
   }
   __syncthreads();
   if (threadIdx.x < kAccN)
-    partials[threadIdx.x * pstride + blockIdx.x] =
+    partials[threadIdx.x * pstride + bid] =
         ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
 }
 
@@ -1187,7 +1052,7 @@ struct AlignJob {
   MatchK mk{};
   SolveK sk{};
   uint32_t nb = 0, nbm = 0, enqueued = 0, chunk = 0, prof_n = 0;
-  int variant = 4, vthreads = 512;
+  int variant = 0;
   bool finished = false, trivial = false;
 
   mh_status start(const mh_map* m, const mh_scan* sc, const mh_icp_params* prm, const double* T0, const mh_prior* prior,
@@ -1244,31 +1109,14 @@ struct AlignJob {
     sk.trace = trace ? ctx->trace.as<mh_icp_iter>() : nullptr;
     sk.gn_trace = nullptr;
     nb = nblk(scan->n);
-    {  // development switch: MH_MATCH = "1" (one lane per point) | "4x256" | "4x512" (default) | "4x1024"
-      // | "q4" | "q8" (default) | "q16": LPQ lanes co-operating on one point, persistent blocks
+    {  // MH_MATCH = "p" (default: one lane per point, exact branch-and-bound) | "x" (exhaustive 27-voxel scan, the
+       // literal reference algorithm; kept for A/B runs) | "r" (experimental: one 16-lane row per voxel run, LDS run table)
       const char* e = getenv("MH_MATCH");
-      variant = 0; vthreads = 512;  // default: "p" = one lane per point, exact branch-and-bound pruning
-      if (e && e[0] == '1') variant = 1;
-      if (e && e[0] == '4') variant = 4;
-      if (e && !strcmp(e, "4x256")) vthreads = 256;
-      if (e && !strcmp(e, "4x1024")) vthreads = 1024;
-      if (e && !strcmp(e, "q4")) variant = 104;
-      if (e && !strcmp(e, "q8")) variant = 8;
-      if (e && !strcmp(e, "q16")) variant = 16;
-      if (e && !strcmp(e, "c4")) variant = 204;
-      if (e && !strcmp(e, "c8")) variant = 208;
-      if (e && !strcmp(e, "c16")) variant = 216;
+      variant = 0;
+      if (e && e[0] == 'x') variant = 1;
+      if (e && e[0] == 'r') variant = 2;
     }
-    if (variant == 1 || variant == 0) nbm = nb;
-    else if (variant == 4) nbm = (uint32_t)((4 * scan->n + vthreads - 1) / vthreads);
-    else {
-      const uint32_t lpq = variant >= 200 ? (uint32_t)(variant - 200) : (variant == 104 ? 4u : (uint32_t)variant);
-      const uint32_t qpb = kBlock / lpq;
-      const uint32_t nchunks = (uint32_t)((scan->n + qpb - 1) / qpb);
-      uint32_t maxgrid = 1024;
-      if (const char* g = getenv("MH_MATCH_GRID")) maxgrid = (uint32_t)atoi(g);
-      nbm = nchunks < maxgrid ? nchunks : maxgrid;
-    }
+    nbm = variant == 2 ? (uint32_t)((scan->n + 4 * kQPW - 1) / (4 * kQPW)) : nb;
     MH_TRY(ctx->partials.reserve((size_t)kGenN * (nbm > nb ? nbm : nb) * sizeof(double)));
     chunk = p->poll_every ? p->poll_every : 10;
     enqueued = 0;
@@ -1300,39 +1148,15 @@ struct AlignJob {
     double* part = ctx->partials.as<double>();
     for (uint32_t j = 0; j < m; j++) {
       if (p->profile) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n], s));
-      if (variant == 208)
-        hipLaunchKernelGGL(k_matchc<8>, dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, mk, scan->x, scan->y, scan->z, n, mv,
-                           ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      else if (variant == 204)
-        hipLaunchKernelGGL(k_matchc<4>, dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, mk, scan->x, scan->y, scan->z, n, mv,
-                           ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      else if (variant == 216)
-        hipLaunchKernelGGL(k_matchc<16>, dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, mk, scan->x, scan->y, scan->z, n, mv,
-                           ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      else if (variant == 8)
-        hipLaunchKernelGGL(k_matchq<8>, dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, mk, scan->x, scan->y, scan->z, n, mv,
-                           ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      else if (variant == 104)
-        hipLaunchKernelGGL(k_matchq<4>, dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, mk, scan->x, scan->y, scan->z, n, mv,
-                           ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      else if (variant == 16)
-        hipLaunchKernelGGL(k_matchq<16>, dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, mk, scan->x, scan->y, scan->z, n, mv,
-                           ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      else if (variant == 0)
+      if (variant == 2)
+        hipLaunchKernelGGL(k_matchr<true>, dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, mk, scan->x, scan->y,
+                           scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
+      else if (variant == 1)
+        hipLaunchKernelGGL((k_match<true, false>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, mk, scan->x,
+                           scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
+      else
         hipLaunchKernelGGL((k_match<true, true>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, mk, scan->x,
                            scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      else if (variant == 1)
-        hipLaunchKernelGGL((k_match<true, false>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, mk, scan->x, scan->y,
-                           scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      else if (vthreads == 256)
-        hipLaunchKernelGGL(k_match4<256>, dim3(nbm), dim3(256), 0, s, ctx->d_state, mk, scan->x, scan->y, scan->z, n, mv,
-                           ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      else if (vthreads == 512)
-        hipLaunchKernelGGL(k_match4<512>, dim3(nbm), dim3(512), 0, s, ctx->d_state, mk, scan->x, scan->y, scan->z, n, mv,
-                           ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      else
-        hipLaunchKernelGGL(k_match4<1024>, dim3(nbm), dim3(1024), 0, s, ctx->d_state, mk, scan->x, scan->y, scan->z, n, mv,
-                           ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
       if (p->profile) {
         MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));
         prof_n++;
@@ -1486,8 +1310,8 @@ mh_status mh_nn_search(const mh_map* map, const mh_scan* scan, const double T[12
   const double ang = threshold_angular_deg * 3.14159265358979323846 / 180.0;
   mk.ang2 = (float)(ang * ang);
   hipLaunchKernelGGL((k_match<false, true>), dim3(nblk(scan->n)), dim3(kBlock), 0, ctx->stream, ctx->d_state, Ta,
-                     (float)(threshold * threshold), 1u, mk, scan->x, scan->y, scan->z, (uint32_t)scan->n, map->view(),
-                     ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (double*)nullptr, 0u);
+                       (float)(threshold * threshold), 1u, mk, scan->x, scan->y, scan->z, (uint32_t)scan->n, map->view(),
+                       ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (double*)nullptr, 0u);
   MH_HIP(hipGetLastError());
   mh_pairs_out none{};
   uint64_t np = 0;
@@ -1512,9 +1336,9 @@ mh_status mh_nn_search_dense(const mh_map* map, const mh_scan* scan, const doubl
   for (int i = 0; i < 12; i++) Ta.m[i] = T[i];
   MatchK mk{};
   hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL((k_match<false, true>), dim3(nblk(n)), dim3(kBlock), 0, s, ctx->d_state, Ta, 0.f, 0u, mk, scan->x, scan->y,
-                     scan->z, (uint32_t)n, map->view(), ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
-                     (double*)nullptr, 0u);
+  hipLaunchKernelGGL((k_match<false, true>), dim3(nblk(n)), dim3(kBlock), 0, s, ctx->d_state, Ta, 0.f, 0u, mk, scan->x,
+                       scan->y, scan->z, (uint32_t)n, map->view(), ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+                       (double*)nullptr, 0u);
   uint32_t* o_gi = global_idx;
   float *o_x = gx, *o_y = gy, *o_z = gz, *o_d2 = d2;
   const size_t n4 = ((n + 63) / 64) * 64;

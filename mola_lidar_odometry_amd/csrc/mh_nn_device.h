@@ -9,6 +9,15 @@ namespace mh {
 
 constexpr uint32_t kNoMatch = 0xFFFFFFFFu;
 
+// XCD-aware block order.  The dispatcher places workgroup b on XCD b % 8 (observed, MI355X guide; used for speed
+// only) and every XCD has its own 4 MiB L2.  Consecutive scan points are spatial neighbours, so handing XCD x the
+// CONTIGUOUS logical block range [start_x, start_x + count_x) keeps each L2's share of the map (16 MiB of records +
+// 4 MiB of hash slots on C2, i.e. more than one L2) to the ~1/8 its points actually touch.  Bijective for any grid size.
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
+  const uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u, j = b >> 3;
+  return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + j;
+}
+
 // native clang vectors: a plain dwordx4 load into registers (HIP's uint4/float4 are union structs whose
 // copies become memcpy's that keep arrays of them in scratch memory)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -180,20 +189,19 @@ __device__ __forceinline__ void nn_consider(const f32x4& c, uint32_t idx, float 
   }
 }
 
-// all records of one voxel, four predicated loads in flight
+// all records of one voxel, eight loads in flight (offsets clamped into the run instead of predicated: a load
+// inside an `if` makes hipcc wait for it at the end of the branch, which would serialise the round trips)
 __device__ __forceinline__ void nn_scan_voxel(const f32x4* __restrict__ pts, uint32_t first, uint32_t cnt, float qx,
                                               float qy, float qz, NNBest& b) {
-  for (uint32_t j = 0; j < cnt; j += 4) {
-    const bool v1 = j + 1 < cnt, v2 = j + 2 < cnt, v3 = j + 3 < cnt;
+  for (uint32_t j = 0; j < cnt; j += 8) {
     const f32x4* __restrict__ p = pts + (first + j);
-    f32x4 c0 = p[0], c1 = c0, c2 = c0, c3 = c0;
-    if (v1) c1 = p[1];
-    if (v2) c2 = p[2];
-    if (v3) c3 = p[3];
-    nn_consider(c0, first + j, qx, qy, qz, b);
-    if (v1) nn_consider(c1, first + j + 1, qx, qy, qz, b);
-    if (v2) nn_consider(c2, first + j + 2, qx, qy, qz, b);
-    if (v3) nn_consider(c3, first + j + 3, qx, qy, qz, b);
+    const uint32_t rem = cnt - j;  // >= 1
+    f32x4 c[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) c[u] = p[(uint32_t)u < rem ? u : 0];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if ((uint32_t)u < rem) nn_consider(c[u], first + j + u, qx, qy, qz, b);
   }
 }
 
@@ -255,6 +263,7 @@ __device__ __forceinline__ NNResult nn_search_pruned(const MapView& m, float qx,
   }
   // 2. the neighbours that can still hold a candidate with d2 <= best: bit `code` of `mask`
   uint32_t mask = 0;
+
 #pragma unroll
   for (int c = 0; c < 27; c++) {
     if (c == 13) continue;
@@ -277,10 +286,8 @@ __device__ __forceinline__ NNResult nn_search_pruned(const MapView& m, float qx,
       if (mm) { c3 = __builtin_ctz(mm); mm &= mm - 1; }
       const unsigned long long k0 = nn_key_of(kbase, c0), k1 = nn_key_of(kbase, c1 < 0 ? 0 : c1),
                                k2 = nn_key_of(kbase, c2 < 0 ? 0 : c2), k3 = nn_key_of(kbase, c3 < 0 ? 0 : c3);
-      u32x4 s0 = slots4[hash_key(k0) & m.mask], s1 = s0, s2 = s0, s3 = s0;
-      if (c1 >= 0) s1 = slots4[hash_key(k1) & m.mask];
-      if (c2 >= 0) s2 = slots4[hash_key(k2) & m.mask];
-      if (c3 >= 0) s3 = slots4[hash_key(k3) & m.mask];
+      const u32x4 s0 = slots4[hash_key(k0) & m.mask], s1 = slots4[hash_key(k1) & m.mask],
+                  s2 = slots4[hash_key(k2) & m.mask], s3 = slots4[hash_key(k3) & m.mask];  // unconditional: 4 in flight
       if (!(nn_lower_bound(c0, gx, gy, gz) * 0.9999f > b.d2)) nn_visit(m, slots4, pts4, k0, s0, qx, qy, qz, b);
       if (c1 >= 0 && !(nn_lower_bound(c1, gx, gy, gz) * 0.9999f > b.d2)) nn_visit(m, slots4, pts4, k1, s1, qx, qy, qz, b);
       if (c2 >= 0 && !(nn_lower_bound(c2, gx, gy, gz) * 0.9999f > b.d2)) nn_visit(m, slots4, pts4, k2, s2, qx, qy, qz, b);
@@ -293,117 +300,6 @@ __device__ __forceinline__ NNResult nn_search_pruned(const MapView& m, float qx,
     r.found = true;
   }
   return r;
-}
-
-// Quad-split variant: four adjacent lanes share one query and split its nine (x,y) columns in
-// reference order -- part 0: columns 0-2 (x-1), part 1: 3-4, part 2: 5-6, part 3: 7-8 -- so the
-// dependent-load chain per lane is ~4x shorter and four times as many waves are in flight.  The caller
-// merges the four partial results with quad_combine(), which keeps the FIRST minimum in column order,
-// i.e. exactly what the sequential scan would have kept.
-__device__ __forceinline__ void nn_search_cols(const MapView& m, float qx, float qy, float qz, int part, float& best_d2,
-                                               f32x4& best_pt) {
-  best_d2 = __builtin_inff();
-  best_pt = (f32x4)(0.f);
-  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return;
-  const float lim = 1.0e6f;
-  if (!(fabsf(qx * m.inv_vs) < lim && fabsf(qy * m.inv_vs) < lim && fabsf(qz * m.inv_vs) < lim)) return;
-  const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
-  const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
-  const int cb = part == 0 ? 0 : 2 * part + 1;  // first column of this part: 0,3,5,7
-  const int nc = part == 0 ? 3 : 2;
-  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
-  u32x4 s[9];
-  unsigned long long keys[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const int col = cb + k;
-    const int ix = col >= 6 ? 2 : (col >= 3 ? 1 : 0);
-    const int iy = col - 3 * ix;
-    keys[k] = kbase + ((unsigned long long)ix << 42) + ((unsigned long long)iy << 21);
-#pragma unroll
-    for (int iz = 0; iz < 3; iz++) {
-      u32x4 v = (u32x4)(0xFFFFFFFFu);  // reads as an empty slot
-      if (k < nc) v = slots4[hash_key(keys[k] + iz) & m.mask];
-      s[k * 3 + iz] = v;
-    }
-  }
-  uint32_t first3[3], cnt3[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    uint32_t first = 0, cnt = 0;
-#pragma unroll
-    for (int iz = 0; iz < 3; iz++) {
-      const unsigned long long key = keys[k] + iz;
-      u32x4 sl = s[k * 3 + iz];
-      unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
-      if (sk != key && sk != kEmptyKey) {
-        uint32_t h = hash_key(key) & m.mask;
-        do {
-          h = (h + 1) & m.mask;
-          sl = slots4[h];
-          sk = ((unsigned long long)sl.y << 32) | sl.x;
-        } while (sk != key && sk != kEmptyKey);
-      }
-      if (sk == key) {
-        if (cnt == 0) first = sl.z;
-        cnt += sl.w;
-      }
-    }
-    first3[k] = first;
-    cnt3[k] = cnt;
-  }
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const uint32_t cnt = cnt3[k];
-    const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(m.pts) + first3[k];
-    for (uint32_t j = 0; j < cnt; j += 4) {
-      const uint32_t last = cnt - 1;
-      const f32x4 c0 = p[j];
-      const f32x4 c1 = p[min(j + 1, last)];
-      const f32x4 c2 = p[min(j + 2, last)];
-      const f32x4 c3 = p[min(j + 3, last)];
-      {
-        const float dx = c0.x - qx, dy = c0.y - qy, dz = c0.z - qz;
-        const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order
-        if (d2 < best_d2) { best_d2 = d2; best_pt = c0; }
-      }
-      {
-        const float dx = c1.x - qx, dy = c1.y - qy, dz = c1.z - qz;
-        const float d2 = (dx * dx + dy * dy) + dz * dz;
-        if (d2 < best_d2) { best_d2 = d2; best_pt = c1; }
-      }
-      {
-        const float dx = c2.x - qx, dy = c2.y - qy, dz = c2.z - qz;
-        const float d2 = (dx * dx + dy * dy) + dz * dz;
-        if (d2 < best_d2) { best_d2 = d2; best_pt = c2; }
-      }
-      {
-        const float dx = c3.x - qx, dy = c3.y - qy, dz = c3.z - qz;
-        const float d2 = (dx * dx + dy * dy) + dz * dz;
-        if (d2 < best_d2) { best_d2 = d2; best_pt = c3; }
-      }
-    }
-  }
-}
-
-// merge the partial nearest neighbours of the four lanes of a quad; every lane ends with the result
-__device__ __forceinline__ void quad_combine(int part, float& d2, f32x4& pt) {
-#pragma unroll
-  for (int bit = 1; bit <= 2; bit <<= 1) {
-    const float od2 = __shfl_xor(d2, bit);
-    f32x4 opt;
-    opt.x = __shfl_xor(pt.x, bit);
-    opt.y = __shfl_xor(pt.y, bit);
-    opt.z = __shfl_xor(pt.z, bit);
-    opt.w = __shfl_xor(pt.w, bit);
-    // "lower" = earlier in the reference scan order; the later one only wins with a strictly smaller d2
-    const bool me_lower = (part & bit) == 0;
-    const bool take_other = me_lower ? (od2 < d2) : !(d2 < od2);
-    if (take_other) {
-      d2 = od2;
-      pt = opt;
-    }
-  }
 }
 
 // ---- robust kernels (mp2p_icp::create_robust_kernel [U], lidar3d-default.yaml:188-190) ---------
@@ -459,10 +355,29 @@ __device__ __forceinline__ void acc_pt2pt(Acc& a, const double* __restrict__ T, 
   a.v[17] += 1.0;
 }
 
+// Sum over the 64 lanes of a wave, result valid in every lane... of interest only in lane 0.
+// DPP row shifts (VALU, no LDS traffic) reduce each 16-lane row to its lane 0, then the four row heads are read
+// with v_readlane and added in a fixed order.  (The first version used 6 x __shfl_xor = 12 ds_bpermute per value;
+// with 18 fp64 moments per wave that was ~200 dependent LDS round trips at the tail of every match/accum launch.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long b = __double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const unsigned long long b = __double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+  v += dpp_f64<0x101>(v);  // row_shl:1  (lane i += lane i+1 of its row; out-of-row reads 0)
+  v += dpp_f64<0x102>(v);  // row_shl:2
+  v += dpp_f64<0x104>(v);  // row_shl:4
+  v += dpp_f64<0x108>(v);  // row_shl:8  -> lane 0 of each row holds the row sum
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 // Block-wide reduction of NV doubles per thread for 256-thread blocks; the result is written by the
