@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=8, help="scans in flight per GPU (one per HIP stream)")
+    ap.add_argument("--streams", type=int, default=16, help="scans in flight per GPU (one per HIP stream)")
     ap.add_argument("--workload", default="c2", choices=["c2", "creal", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (bounded sample)")
@@ -80,7 +80,7 @@ def main():
         guesses.append(synth.pose_from_ypr(g))
     prof = not args.no_profile
     params = capi.ICPParams(max_iterations=w.n_iters, disable_stall_test=True, threshold=w.threshold,
-                            kernel_param=w.kernel_param, poll_every=w.n_iters, profile=prof)
+                            kernel_param=w.kernel_param, poll_every=w.n_iters, profile=2 if prof else 0)
     maps = [gmap] * S
 
     def step():
@@ -136,14 +136,17 @@ def main():
             # pick the thread count that is fastest on THIS box (more threads than usable cores collapses
             # OpenMP throughput); the count actually used is what "cores" reports
             cores, best_t = 1, None
-            cal = oracle_c.ICPParams(max_iterations=2, disable_stall_test=True, threshold=w.threshold[:2],
-                                     kernel_param=w.kernel_param[:2], compute_covariance=False)
-            for nt in (1, 4, 8, 16, 32, 64, 128):
+            cal = oracle_c.ICPParams(max_iterations=3, disable_stall_test=True, threshold=w.threshold[:3],
+                                     kernel_param=w.kernel_param[:3], compute_covariance=False)
+            for nt in (1, 4, 8, 16, 24, 32, 48, 64, 96, 128):
                 if nt > oracle_c.max_threads():
                     break
-                tc = time.perf_counter()
-                oracle_c.icp_align(om, w.scan_xyz, guesses[0], cal, n_threads=nt)
-                tcal = time.perf_counter() - tc
+                tcal = None
+                for _ in range(2):  # best of two: the first call at a new width pays for thread creation
+                    tc = time.perf_counter()
+                    oracle_c.icp_align(om, w.scan_xyz, guesses[0], cal, n_threads=nt)
+                    dt_cal = time.perf_counter() - tc
+                    tcal = dt_cal if tcal is None else min(tcal, dt_cal)
                 if best_t is None or tcal < best_t:
                     cores, best_t = nt, tcal
             n_done, t_cpu, o = 0, 0.0, None
@@ -173,9 +176,9 @@ def main():
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                     "avg_kernel_ms": avg_ms, "launches": match_launches, "p_bar": p_bar,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "note": "event-timed on the kernel's own stream with the other streams' kernels running "
-                            "concurrently; the working set is L2/Infinity-Cache resident, so algorithmic GB/s may "
-                            "exceed HBM traffic"}
+                    "note": "HIP events around every k_match launch of stream 0 inside the timed region, with the other "
+                            "streams' kernels running concurrently (they replay a captured hipGraph); the working set "
+                            "is cache resident, so HBM traffic is far below the algorithmic bytes"}
             import glob
             pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
             if pmc:  # HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (profiles/collect.sh)

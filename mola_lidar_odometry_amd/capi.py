@@ -450,7 +450,7 @@ class ICPParams:
         cp.cov_findif_xyz = self.cov_findif_xyz
         cp.cov_findif_ang = self.cov_findif_ang
         cp.poll_every = self.poll_every
-        cp.profile = int(self.profile)
+        cp.profile = int(self.profile)  # 0 | 1 (all jobs) | 2 (job 0 of a batch only)
         return cp, (thr, kp)
 
 

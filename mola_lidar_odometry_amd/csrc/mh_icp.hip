@@ -28,6 +28,9 @@
 using namespace mh;
 
 constexpr uint32_t kBlock = 256;
+#ifndef MH_MATCH_WAVES
+#define MH_MATCH_WAVES 1  // min waves per SIMD asked of the register allocator for k_match (tuning knob)
+#endif
 constexpr uint32_t kMaxGnTrace = 16;
 
 struct IcpDeviceState {
@@ -40,12 +43,18 @@ struct IcpDeviceState {
   double covD[72];  // (T(x+h_j) - T(x-h_j)) / (2 h_j), j = 0..5, 3x4 each
 };
 
+// Per-alignment parameters live in DEVICE memory (uploaded once per align from a pinned host mirror) and the kernels
+// receive pointers to them: the kernel arguments of a whole chunk of iterations are then identical from one alignment
+// to the next, so the chunk can be captured once into a hipGraph and replayed with one host call instead of ~80 launches.
 struct MatchK {
   const double* thr;     // [max_iterations] device
   const double* kparam;  // [max_iterations] device
   float ang2;
   uint32_t kernel;
   double w_pt2pt;
+  double kparam_fixed;   // solver-granular path: fixed robust-kernel parameter
+  uint32_t use_fixed;
+  uint32_t pad;
 };
 
 struct SolveK {
@@ -60,6 +69,12 @@ struct SolveK {
   const double* kparam;
   mh_icp_iter* trace;
   mh_gn_step* gn_trace;
+  double cov_hx, cov_ha;  // finite-difference steps of the covariance
+};
+
+struct IcpDeviceParams {
+  MatchK mk;
+  SolveK sk;
 };
 
 struct PoseArg {
@@ -79,13 +94,14 @@ __device__ __forceinline__ void wave_sync_lds() {
 // k_match: correspondence search (+ first Gauss-Newton accumulation when FUSED)
 // ================================================================================================
 template <bool FUSED, bool PRUNE>
-__global__ __launch_bounds__(kBlock) void k_match(const IcpDeviceState* __restrict__ st, PoseArg Targ, float thr2_arg,
-                                                  uint32_t apply_thr, MatchK k, const float* __restrict__ lx,
+__global__ __launch_bounds__(kBlock, MH_MATCH_WAVES) void k_match(const IcpDeviceState* __restrict__ st, PoseArg Targ, float thr2_arg,
+                                                  uint32_t apply_thr, const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                   MapView map, float4* __restrict__ pair_q,
                                                   uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
                                                   uint32_t pstride) {
   __shared__ double lds[kBlock / 64][kAccN];
+  const MatchK k = *kp;  // wave-uniform scalar loads
   double T[12];
   float thr2;
   double kparam = 0.0;
@@ -178,7 +194,7 @@ __device__ __forceinline__ unsigned long long row_min_u64(unsigned long long key
 
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_matchr(const IcpDeviceState* __restrict__ st, PoseArg Targ, float thr2_arg,
-                                                   uint32_t apply_thr, MatchK k, const float* __restrict__ lx,
+                                                   uint32_t apply_thr, const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                    const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                    MapView map, float4* __restrict__ pair_q,
                                                    uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
@@ -188,6 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_matchr(const IcpDeviceState* __restr
   __shared__ unsigned long long s_best[NW][kQPW];
   __shared__ uint2 s_tab[NW][kRunTab];
   __shared__ double lds[NW][kAccN];
+  const MatchK k = *kp;  // wave-uniform scalar loads
   double T[12];
   float thr2;
   double kparam = 0.0;
@@ -415,8 +432,8 @@ __global__ __launch_bounds__(kBlock) void k_matchr(const IcpDeviceState* __restr
 // ================================================================================================
 // k_accum: point-to-point accumulation on stored pairings (inner GN steps, solver-granular path)
 // ================================================================================================
-__global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first, MatchK k,
-                                                  double kparam_fixed, uint32_t use_fixed, const float* __restrict__ lx,
+__global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first,
+                                                  const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                   const float4* __restrict__ pair_q,
                                                   const uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
@@ -427,7 +444,8 @@ __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restri
   double T[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) T[i] = st->T[i];
-  const double kparam = use_fixed ? kparam_fixed : k.kparam[st->iter];
+  const MatchK k = *kp;
+  const double kparam = k.use_fixed ? k.kparam_fixed : k.kparam[st->iter];
   const uint32_t bid = blockIdx.x;
   const uint32_t i = bid * kBlock + threadIdx.x;
   Acc a;
@@ -539,7 +557,7 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ part, uin
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restrict__ st, SolveK k,
+__global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
                                                          const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                                          const double* __restrict__ partB, uint32_t nB,
                                                          uint32_t strideB) {
@@ -547,6 +565,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restr
   __shared__ double totA[kAccN], totB[kGenN];
   __shared__ double sh_log[13][6];
   if (st->done) return;
+  const SolveK& k = *kp;  // read field by field (uniform loads); the 36-double prior is only touched when present
   const int lane = threadIdx.x;
   if (nA)
     reduce_rows(partA, nA, strideA, kAccN, totA, red);
@@ -722,7 +741,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restr
 // ================================================================================================
 constexpr int kCovN = 22;  // 21 upper-triangle + count
 
-__global__ void k_cov_prepare(IcpDeviceState* __restrict__ st, double hx, double ha, uint32_t force) {
+__global__ void k_cov_prepare(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp, uint32_t force) {
   if (!force && (!st->done || st->cov_done)) return;
   const int j = threadIdx.x;
   if (j >= 6) return;
@@ -730,7 +749,7 @@ __global__ void k_cov_prepare(IcpDeviceState* __restrict__ st, double hx, double
   for (int i = 0; i < 12; i++) Tc.m[i] = st->T[i];
   double v[6];
   pose_to_ypr(Tc, v);
-  const double h = j < 3 ? hx : ha;
+  const double h = j < 3 ? kp->cov_hx : kp->cov_ha;
   double vp[6], vm[6];
   for (int i = 0; i < 6; i++) { vp[i] = v[i]; vm[i] = v[i]; }
   vp[j] += h;
@@ -954,7 +973,17 @@ mh_status ensure_state(mh_ctx* ctx) {
   if (!ctx->d_state) {
     MH_HIP(hipMalloc((void**)&ctx->d_state, sizeof(IcpDeviceState)));
     MH_HIP(hipHostMalloc((void**)&ctx->h_state, sizeof(IcpDeviceState), hipHostMallocDefault));
+    MH_HIP(hipMalloc((void**)&ctx->d_params, sizeof(IcpDeviceParams)));
+    MH_HIP(hipHostMalloc((void**)&ctx->h_params, sizeof(IcpDeviceParams), hipHostMallocDefault));
   }
+  return MH_OK;
+}
+
+// parameters -> pinned mirror -> device block (the caller has synchronised the previous use of the mirror)
+mh_status upload_params(mh_ctx* ctx, const MatchK& mk, const SolveK& sk) {
+  ctx->h_params->mk = mk;
+  ctx->h_params->sk = sk;
+  MH_HIP(hipMemcpyAsync(ctx->d_params, ctx->h_params, sizeof(IcpDeviceParams), hipMemcpyHostToDevice, ctx->stream));
   return MH_OK;
 }
 
@@ -1054,10 +1083,12 @@ struct AlignJob {
   uint32_t nb = 0, nbm = 0, enqueued = 0, chunk = 0, prof_n = 0;
   int variant = 0;
   bool finished = false, trivial = false;
+  bool prof = false;  // time this job's match kernels with events (then it cannot use the graph path)
 
   mh_status start(const mh_map* m, const mh_scan* sc, const mh_icp_params* prm, const double* T0, const mh_prior* prior,
-                  mh_icp_result* r, mh_icp_iter* tr) {
+                  mh_icp_result* r, mh_icp_iter* tr, size_t batch_index = 0) {
     map = m; scan = sc; ctx = sc->ctx; p = prm; res = r; trace = tr;
+    prof = prm->profile == 1 || (prm->profile == 2 && batch_index == 0);
     memset(res, 0, sizeof(*res));
     for (int i = 0; i < 12; i++) res->T[i] = T0[i];
     for (int i = 0; i < 6; i++) res->cov[i * 7] = 1e6;
@@ -1108,6 +1139,9 @@ struct AlignJob {
     sk.kparam = mk.kparam;
     sk.trace = trace ? ctx->trace.as<mh_icp_iter>() : nullptr;
     sk.gn_trace = nullptr;
+    sk.cov_hx = p->cov_findif_xyz;
+    sk.cov_ha = p->cov_findif_ang;
+    MH_TRY(upload_params(ctx, mk, sk));
     nb = nblk(scan->n);
     {  // MH_MATCH = "p" (default: one lane per point, exact branch-and-bound) | "x" (exhaustive 27-voxel scan, the
        // literal reference algorithm; kept for A/B runs) | "r" (experimental: one 16-lane row per voxel run, LDS run table)
@@ -1121,7 +1155,7 @@ struct AlignJob {
     chunk = p->poll_every ? p->poll_every : 10;
     enqueued = 0;
     prof_n = 0;
-    if (p->profile) {
+    if (prof) {
       const uint32_t need = 2 * p->max_iterations;
       if (ctx->prof_cap < need) {
         hipEvent_t* ne = new (std::nothrow) hipEvent_t[need];
@@ -1146,40 +1180,89 @@ struct AlignJob {
     const uint32_t m = (p->max_iterations - enqueued) < chunk ? (p->max_iterations - enqueued) : chunk;
     PoseArg dummy{};
     double* part = ctx->partials.as<double>();
-    for (uint32_t j = 0; j < m; j++) {
-      if (p->profile) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n], s));
-      if (variant == 2)
-        hipLaunchKernelGGL(k_matchr<true>, dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, mk, scan->x, scan->y,
-                           scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      else if (variant == 1)
-        hipLaunchKernelGGL((k_match<true, false>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, mk, scan->x,
-                           scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      else
-        hipLaunchKernelGGL((k_match<true, true>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, mk, scan->x,
-                           scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-      if (p->profile) {
-        MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));
-        prof_n++;
+    const MatchK* dmk = &ctx->d_params->mk;
+    const SolveK* dsk = &ctx->d_params->sk;
+    // everything a chunk launches, in stream order; used directly (profiling / MH_NO_GRAPH) or under stream capture
+    auto enqueue_kernels = [&]() -> mh_status {
+      for (uint32_t j = 0; j < m; j++) {
+        if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n], s));
+        if (variant == 2)
+          hipLaunchKernelGGL(k_matchr<true>, dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x, scan->y,
+                             scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
+        else if (variant == 1)
+          hipLaunchKernelGGL((k_match<true, false>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x,
+                             scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
+        else
+          hipLaunchKernelGGL((k_match<true, true>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x,
+                             scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
+        if (prof) {
+          MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));
+          prof_n++;
+        }
+        hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nbm, nbm,
+                           (const double*)nullptr, 0u, 0u);
+        for (uint32_t in = 1; in < p->gn.max_inner_iterations; in++) {
+          hipLaunchKernelGGL(k_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
+                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nb);
+          hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nb, nb,
+                             (const double*)nullptr, 0u, 0u);
+        }
       }
-      hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, sk, part, nbm, nbm, (const double*)nullptr, 0u, 0u);
-      for (uint32_t in = 1; in < p->gn.max_inner_iterations; in++) {
-        hipLaunchKernelGGL(k_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, mk, 0.0, 0u, scan->x, scan->y, scan->z,
-                           n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nb);
-        hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, sk, part, nb, nb, (const double*)nullptr, 0u,
-                           0u);
+      if (p->compute_covariance) {  // no-ops unless the loop has terminated
+        hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, dsk, 0u);
+        hipLaunchKernelGGL(k_cov_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, scan->x, scan->y, scan->z, n,
+                           ctx->pair_gidx.as<uint32_t>(), part, nb);
+        hipLaunchKernelGGL(k_cov_finalize, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, 0u, part, nb, nb,
+                           (const double*)nullptr, 0u, 0u);
       }
+      MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
+      return MH_OK;
+    };
+    static const bool no_graph = getenv("MH_NO_GRAPH") != nullptr;
+    if (prof || no_graph) {
+      MH_TRY(enqueue_kernels());
+      MH_HIP(hipGetLastError());
+    } else {
+      // The launch sequence only depends on sizes and device pointers (the per-alignment values sit in device
+      // memory), so it is captured once and replayed: one host call per chunk instead of ~4 per iteration.
+      unsigned long long key[24] = {0};
+      uint32_t fb;
+      memcpy(&fb, &mv.inv_vs, 4);
+      const unsigned long long kv[] = {n, nb, nbm, (unsigned long long)variant, m, p->gn.max_inner_iterations,
+                                       p->compute_covariance, (unsigned long long)mv.slots, (unsigned long long)mv.pts, mv.mask,
+                                       fb, mv.trunc, (unsigned long long)scan->x, (unsigned long long)scan->y,
+                                       (unsigned long long)scan->z, (unsigned long long)ctx->pair_q.p,
+                                       (unsigned long long)ctx->pair_gidx.p, (unsigned long long)part,
+                                       (unsigned long long)ctx->d_state, (unsigned long long)ctx->d_params,
+                                       (unsigned long long)ctx->h_state, 1ull};
+      static_assert(sizeof(kv) <= sizeof(key), "graph key too small");
+      memcpy(key, kv, sizeof(kv));
+      if (!ctx->graph_exec || memcmp(key, ctx->graph_key, sizeof(key)) != 0) {
+        if (ctx->graph_exec) {
+          (void)hipGraphExecDestroy(ctx->graph_exec);
+          ctx->graph_exec = nullptr;
+        }
+        hipGraph_t g = nullptr;
+        MH_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const mh_status cs = enqueue_kernels();
+        const hipError_t ce = hipStreamEndCapture(s, &g);
+        if (cs != MH_OK) {
+          if (g) (void)hipGraphDestroy(g);
+          return cs;
+        }
+        if (ce != hipSuccess) return fail(MH_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+        const hipError_t ie = hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ie != hipSuccess) {
+          ctx->graph_exec = nullptr;
+          return fail(MH_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+        }
+        memcpy(ctx->graph_key, key, sizeof(key));
+      }
+      MH_HIP(hipGraphLaunch(ctx->graph_exec, s));
     }
     enqueued += m;
-    if (p->compute_covariance) {  // no-ops unless the loop has terminated
-      hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, p->cov_findif_xyz, p->cov_findif_ang, 0u);
-      hipLaunchKernelGGL(k_cov_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, scan->x, scan->y, scan->z, n,
-                         ctx->pair_gidx.as<uint32_t>(), part, nb);
-      hipLaunchKernelGGL(k_cov_finalize, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, 0u, part, nb, nb, (const double*)nullptr,
-                         0u, 0u);
-    }
-    MH_HIP(hipGetLastError());
-    MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
-    if (p->profile) MH_HIP(hipEventRecord(ctx->ev_t1, s));
+    if (prof) MH_HIP(hipEventRecord(ctx->ev_t1, s));
     MH_HIP(hipEventRecord(ctx->ev_poll, s));
     return MH_OK;
   }
@@ -1210,7 +1293,7 @@ struct AlignJob {
                                  ? h->n_iterations : cnt;
       if (valid) MH_HIP(hipMemcpy(trace, ctx->trace.p, sizeof(mh_icp_iter) * valid, hipMemcpyDeviceToHost));
     }
-    if (p->profile) {
+    if (prof) {
       float ms = 0.f;
       double sum = 0.0;
       // launches enqueued after termination are early-exit no-ops; time only the live ones
@@ -1274,7 +1357,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
     for (size_t j = 0; j < i; j++)
       MH_REQUIRE(scans[j]->ctx != scans[i]->ctx, "each job of a batch needs its own context");
     MH_TRY(jobs[i].start(maps[i], scans[i], params, T_guesses + 12 * i, priors ? priors[i] : nullptr, &results[i],
-                         nullptr));
+                         nullptr, i));
   }
   for (;;) {
     bool any = false;
@@ -1307,10 +1390,12 @@ mh_status mh_nn_search(const mh_map* map, const mh_scan* scan, const double T[12
   PoseArg Ta;
   for (int i = 0; i < 12; i++) Ta.m[i] = T[i];
   MatchK mk{};
+  SolveK sk0{};
   const double ang = threshold_angular_deg * 3.14159265358979323846 / 180.0;
   mk.ang2 = (float)(ang * ang);
+  MH_TRY(upload_params(ctx, mk, sk0));
   hipLaunchKernelGGL((k_match<false, true>), dim3(nblk(scan->n)), dim3(kBlock), 0, ctx->stream, ctx->d_state, Ta,
-                       (float)(threshold * threshold), 1u, mk, scan->x, scan->y, scan->z, (uint32_t)scan->n, map->view(),
+                       (float)(threshold * threshold), 1u, &ctx->d_params->mk, scan->x, scan->y, scan->z, (uint32_t)scan->n, map->view(),
                        ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (double*)nullptr, 0u);
   MH_HIP(hipGetLastError());
   mh_pairs_out none{};
@@ -1335,8 +1420,11 @@ mh_status mh_nn_search_dense(const mh_map* map, const mh_scan* scan, const doubl
   PoseArg Ta;
   for (int i = 0; i < 12; i++) Ta.m[i] = T[i];
   MatchK mk{};
+  SolveK sk0{};
   hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL((k_match<false, true>), dim3(nblk(n)), dim3(kBlock), 0, s, ctx->d_state, Ta, 0.f, 0u, mk, scan->x,
+  MH_TRY(upload_params(ctx, mk, sk0));
+  hipLaunchKernelGGL((k_match<false, true>), dim3(nblk(n)), dim3(kBlock), 0, s, ctx->d_state, Ta, 0.f, 0u,
+                     &ctx->d_params->mk, scan->x,
                        scan->y, scan->z, (uint32_t)n, map->view(), ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
                        (double*)nullptr, 0u);
   uint32_t* o_gi = global_idx;
@@ -1428,18 +1516,22 @@ mh_status mh_gn_solve(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt2p
   sk.max_cost = p->max_cost;
   fill_prior(sk, prior);
   sk.gn_trace = (mh_gn_step*)ctx->trace.p;
+  mk.use_fixed = 1;
+  mk.kparam_fixed = p->robust_kernel_param;
+  MH_TRY(upload_params(ctx, mk, sk));
   MH_HIP(hipMemsetAsync(ctx->trace.p, 0, sizeof(mh_gn_step) * kMaxGnTrace, s));
   const float* P = ctx->build_b.as<float>();
   for (uint32_t in = 0; in < p->max_inner_iterations; in++) {
     if (np)
-      hipLaunchKernelGGL(k_accum, dim3(nbp), dim3(kBlock), 0, s, ctx->d_state, in == 0 ? 1u : 0u, mk,
-                         p->robust_kernel_param, 1u, L, L + sp, L + 2 * sp, (uint32_t)np, ctx->pair_q.as<float4>(),
+      hipLaunchKernelGGL(k_accum, dim3(nbp), dim3(kBlock), 0, s, ctx->d_state, in == 0 ? 1u : 0u, &ctx->d_params->mk,
+                         L, L + sp, L + 2 * sp, (uint32_t)np, ctx->pair_q.as<float4>(),
                          ctx->pair_gidx.as<uint32_t>(), ctx->partials.as<double>(), nbp);
     if (nl)
       hipLaunchKernelGGL(k_accum_pl, dim3(nbl), dim3(kBlock), 0, s, ctx->d_state, p->robust_kernel,
                          p->robust_kernel_param, p->weight_pt2pl, P, P + 3 * sl, P + 6 * sl, (uint32_t)nl, (uint32_t)sl,
                          ctx->partials_b.as<double>(), nbl);
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, sk, ctx->partials.as<double>(), nbp, nbp,
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, &ctx->d_params->sk,
+                       ctx->partials.as<double>(), nbp, nbp,
                        ctx->partials_b.as<double>(), nbl, nbl);
   }
   MH_HIP(hipGetLastError());
@@ -1481,7 +1573,14 @@ mh_status mh_covariance(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt
   init_state(ctx->h_state, T);
   MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpDeviceState), hipMemcpyHostToDevice, s));
   if (np) MH_HIP(hipMemsetAsync(ctx->pair_gidx.p, 0, np * sizeof(uint32_t), s));  // all valid
-  hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, findif_xyz, findif_ang, 1u);
+  {
+    MatchK mk0{};
+    SolveK sk0{};
+    sk0.cov_hx = findif_xyz;
+    sk0.cov_ha = findif_ang;
+    MH_TRY(upload_params(ctx, mk0, sk0));
+  }
+  hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, &ctx->d_params->sk, 1u);
   const float* L = ctx->build_a.as<float>();
   const float* P = ctx->build_b.as<float>();
   if (np)

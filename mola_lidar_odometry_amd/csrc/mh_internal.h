@@ -96,7 +96,8 @@ __host__ __device__ inline bool key_in_range(int k) { return k > -kKeyBias + 1 &
 }  // namespace mh
 
 // ---- opaque handle bodies ---------------------------------------------------------------------
-struct IcpDeviceState;  // mh_icp.hip
+struct IcpDeviceState;   // mh_icp.hip
+struct IcpDeviceParams;  // mh_icp.hip
 
 struct mh_ctx {
   int device = 0;
@@ -115,6 +116,10 @@ struct mh_ctx {
   mh::DevBuf build_a, build_b, build_c, build_d, build_e;  // map build scratch
   IcpDeviceState* d_state = nullptr;
   IcpDeviceState* h_state = nullptr;  // pinned mirror
+  IcpDeviceParams* d_params = nullptr;  // per-alignment parameters (kernels take pointers into this block)
+  IcpDeviceParams* h_params = nullptr;  // pinned mirror
+  hipGraphExec_t graph_exec = nullptr;  // captured chunk of ICP iterations (replayed while graph_key matches)
+  unsigned long long graph_key[24] = {0};
   hipEvent_t ev_poll = nullptr;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   // profiling events for the match kernel (pairs), created lazily

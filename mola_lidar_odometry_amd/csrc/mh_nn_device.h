@@ -189,18 +189,19 @@ __device__ __forceinline__ void nn_consider(const f32x4& c, uint32_t idx, float 
   }
 }
 
-// all records of one voxel, eight loads in flight (offsets clamped into the run instead of predicated: a load
-// inside an `if` makes hipcc wait for it at the end of the branch, which would serialise the round trips)
+// all records of one voxel, four loads in flight (offsets clamped into the run instead of predicated: a load inside
+// an `if` makes hipcc wait for it at the end of the branch, which would serialise the round trips; eight in flight
+// measured no faster and costs a wave of occupancy per SIMD)
 __device__ __forceinline__ void nn_scan_voxel(const f32x4* __restrict__ pts, uint32_t first, uint32_t cnt, float qx,
                                               float qy, float qz, NNBest& b) {
-  for (uint32_t j = 0; j < cnt; j += 8) {
+  for (uint32_t j = 0; j < cnt; j += 4) {
     const f32x4* __restrict__ p = pts + (first + j);
     const uint32_t rem = cnt - j;  // >= 1
-    f32x4 c[8];
+    f32x4 c[4];
 #pragma unroll
-    for (int u = 0; u < 8; u++) c[u] = p[(uint32_t)u < rem ? u : 0];
+    for (int u = 0; u < 4; u++) c[u] = p[(uint32_t)u < rem ? u : 0];
 #pragma unroll
-    for (int u = 0; u < 8; u++)
+    for (int u = 0; u < 4; u++)
       if ((uint32_t)u < rem) nn_consider(c[u], first + j + u, qx, qy, qz, b);
   }
 }

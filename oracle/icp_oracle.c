@@ -403,7 +403,7 @@ size_t orc_match_points(const orc_map* m, const float* lx, const float* ly, cons
   uint64_t nc = 0, nv = 0;
   (void)n_threads;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : 1) reduction(+ : nc, nv)
+#pragma omp parallel for schedule(dynamic, 512) num_threads(n_threads > 0 ? n_threads : 1) reduction(+ : nc, nv)
 #endif
   for (long i = 0; i < (long)n; i++) {
     float px, py, pz, q[3], dd;
@@ -681,18 +681,35 @@ void orc_covariance(const orc_pairs_pt2pt* pp, const orc_pairs_pt2pl* pl, const 
     memcpy(x, x0, sizeof(x)); x[j] -= hh[j]; orc_pose_from_ypr(x, Tm[j]);
   }
   double AtA[36] = {0};
-  for (size_t i = 0; i < np; i++) {
-    const double l[3] = {pp->lx[i], pp->ly[i], pp->lz[i]};
-    double A[3][6];
-    for (int j = 0; j < 6; j++)
-      for (int r = 0; r < 3; r++) {
-        const double fp = R_(Tp[j], r, 0) * l[0] + R_(Tp[j], r, 1) * l[1] + R_(Tp[j], r, 2) * l[2] + t_(Tp[j], r);
-        const double fm = R_(Tm[j], r, 0) * l[0] + R_(Tm[j], r, 1) * l[1] + R_(Tm[j], r, 2) * l[2] + t_(Tm[j], r);
-        A[r][j] = (fp - fm) / (2.0 * hh[j]); /* the constant -q cancels */
+  {
+    /* point-to-point block rows, thread-split with an ordered join (same scheme as the GN accumulation) */
+    int nt = orc_max_threads();
+    if (nt > 32) nt = 32;
+    if ((size_t)nt > np) nt = np ? (int)np : 1;
+    double* parts = (double*)calloc((size_t)nt * 36, sizeof(double));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+#endif
+    for (int t = 0; t < nt; t++) {
+      double* P = parts + (size_t)t * 36;
+      const size_t i0 = np * (size_t)t / (size_t)nt, i1 = np * (size_t)(t + 1) / (size_t)nt;
+      for (size_t i = i0; i < i1; i++) {
+        const double l[3] = {pp->lx[i], pp->ly[i], pp->lz[i]};
+        double A[3][6];
+        for (int j = 0; j < 6; j++)
+          for (int r = 0; r < 3; r++) {
+            const double fp = R_(Tp[j], r, 0) * l[0] + R_(Tp[j], r, 1) * l[1] + R_(Tp[j], r, 2) * l[2] + t_(Tp[j], r);
+            const double fm = R_(Tm[j], r, 0) * l[0] + R_(Tm[j], r, 1) * l[1] + R_(Tm[j], r, 2) * l[2] + t_(Tm[j], r);
+            A[r][j] = (fp - fm) / (2.0 * hh[j]); /* the constant -q cancels */
+          }
+        for (int r = 0; r < 3; r++)
+          for (int a = 0; a < 6; a++)
+            for (int b = 0; b < 6; b++) P[a * 6 + b] += A[r][a] * A[r][b];
       }
-    for (int r = 0; r < 3; r++)
-      for (int a = 0; a < 6; a++)
-        for (int b = 0; b < 6; b++) AtA[a * 6 + b] += A[r][a] * A[r][b];
+    }
+    for (int t = 0; t < nt; t++)
+      for (int q = 0; q < 36; q++) AtA[q] += parts[(size_t)t * 36 + q];
+    free(parts);
   }
   for (size_t i = 0; i < nl; i++) {
     const double l[3] = {pl->lx[i], pl->ly[i], pl->lz[i]};
