@@ -166,6 +166,9 @@ typedef struct {
   uint32_t n, cap;
   float* xyz;    /* n x 3 interleaved, insertion order */
   uint32_t* src; /* source index of each stored point */
+  /* NDT statistics (mola::NDT role), recomputed lazily after insertions */
+  float ndt_c[3], ndt_n[3];
+  uint8_t ndt_plane, ndt_dirty;
 } voxel_t;
 
 struct orc_map {
@@ -265,6 +268,8 @@ static voxel_t* map_find_or_create(orc_map* m, int32_t kx, int32_t ky, int32_t k
   voxel_t* v = &m->vox[m->n_vox];
   v->k[0] = kx; v->k[1] = ky; v->k[2] = kz;
   v->n = 0;
+  v->ndt_plane = 0;
+  v->ndt_dirty = 1;
   v->cap = m->p.max_points_per_voxel ? m->p.max_points_per_voxel : 8;
   v->xyz = (float*)malloc((size_t)v->cap * 3 * sizeof(float));
   v->src = (uint32_t*)malloc((size_t)v->cap * sizeof(uint32_t));
@@ -282,6 +287,17 @@ void orc_map_insert(orc_map* m, const float* x, const float* y, const float* z, 
     if (!isfinite(px) || !isfinite(py) || !isfinite(pz)) continue;
     voxel_t* v = map_find_or_create(m, coord2idx(m, px), coord2idx(m, py), coord2idx(m, pz));
     if (m->p.max_points_per_voxel && v->n >= m->p.max_points_per_voxel) continue;
+    if (m->p.min_distance_between_points > 0.f) {
+      /* mola::NDT / HashedVoxelPointCloud insertOpts.min_distance_between_points (lidar3d-ndt.yaml:244) */
+      const float md2 = m->p.min_distance_between_points * m->p.min_distance_between_points;
+      int too_close = 0;
+      for (uint32_t j = 0; j < v->n && !too_close; j++) {
+        const float dx = v->xyz[3 * j] - px, dy = v->xyz[3 * j + 1] - py, dz = v->xyz[3 * j + 2] - pz;
+        too_close = ((dx * dx + dy * dy) + dz * dz) < md2;
+      }
+      if (too_close) continue;
+    }
+    v->ndt_dirty = 1;
     if (v->n == v->cap) {
       v->cap *= 2;
       v->xyz = (float*)realloc(v->xyz, (size_t)v->cap * 3 * sizeof(float));
@@ -343,6 +359,112 @@ void orc_map_dump(const orc_map* m, float* x, float* y, float* z, uint32_t* src_
       if (z) z[o] = v->xyz[3 * j + 2];
       if (src_idx) src_idx[o] = v->src[j];
     }
+  }
+  free(order);
+}
+
+/* ---- NDT voxel statistics (mola::NDT role; SURVEY 8a row a13, App.B U10) ------------------ */
+/* Cyclic Jacobi on a symmetric 3x3 (fp64), fixed sweep count; eigenvalues ascending in w[], eigenvectors in the
+ * columns of V.  Written as a plain operation sequence so that the device code can follow it step by step. */
+static void jacobi3(double a[3][3], double w[3], double V[3][3]) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 12; sweep++) {
+    for (int pq = 0; pq < 3; pq++) {
+      const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2, r = 3 - p - q;
+      const double apq = a[p][q];
+      if (apq == 0.0) continue;
+      const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+      const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+      const double app = a[p][p] - t * apq, aqq = a[q][q] + t * apq;
+      const double arp = c * a[r][p] - sn * a[r][q], arq = sn * a[r][p] + c * a[r][q];
+      a[p][p] = app; a[q][q] = aqq; a[p][q] = a[q][p] = 0.0;
+      a[r][p] = a[p][r] = arp; a[r][q] = a[q][r] = arq;
+      for (int i = 0; i < 3; i++) {
+        const double vip = c * V[i][p] - sn * V[i][q], viq = sn * V[i][p] + c * V[i][q];
+        V[i][p] = vip; V[i][q] = viq;
+      }
+    }
+  }
+  int idx[3] = {0, 1, 2};
+  for (int i = 0; i < 3; i++) w[i] = a[i][i];
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2 - i; j++)
+      if (w[idx[j + 1]] < w[idx[j]]) { int t = idx[j]; idx[j] = idx[j + 1]; idx[j + 1] = t; }
+  double ws[3], Vs[3][3];
+  for (int k = 0; k < 3; k++) {
+    ws[k] = w[idx[k]];
+    for (int i = 0; i < 3; i++) Vs[i][k] = V[i][idx[k]];
+  }
+  for (int k = 0; k < 3; k++) {
+    w[k] = ws[k];
+    for (int i = 0; i < 3; i++) V[i][k] = Vs[i][k];
+  }
+}
+
+static void voxel_update_ndt(const orc_map* m, voxel_t* v) {
+  v->ndt_dirty = 0;
+  v->ndt_plane = 0;
+  v->ndt_c[0] = v->ndt_c[1] = v->ndt_c[2] = 0.f;
+  v->ndt_n[0] = v->ndt_n[1] = v->ndt_n[2] = 0.f;
+  const uint32_t minp = m->p.ndt_min_points ? m->p.ndt_min_points : 4;
+  if (!(m->p.ndt_max_eigen_ratio > 0.f) || v->n < minp) return;
+  double mu[3] = {0, 0, 0};
+  for (uint32_t j = 0; j < v->n; j++)
+    for (int a = 0; a < 3; a++) mu[a] += (double)v->xyz[3 * j + a];
+  for (int a = 0; a < 3; a++) mu[a] /= (double)v->n;
+  double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (uint32_t j = 0; j < v->n; j++) {
+    const double d[3] = {(double)v->xyz[3 * j] - mu[0], (double)v->xyz[3 * j + 1] - mu[1], (double)v->xyz[3 * j + 2] - mu[2]};
+    for (int a = 0; a < 3; a++)
+      for (int b = a; b < 3; b++) C[a][b] += d[a] * d[b];
+  }
+  for (int a = 0; a < 3; a++)
+    for (int b = a; b < 3; b++) {
+      C[a][b] /= (double)(v->n - 1);
+      C[b][a] = C[a][b];
+    }
+  double w[3], V[3][3];
+  jacobi3(C, w, V);
+  for (int a = 0; a < 3; a++) v->ndt_c[a] = (float)mu[a];
+  if (!(w[2] > 0.0) || !(w[0] / w[2] < (double)m->p.ndt_max_eigen_ratio)) return;
+  double nrm[3] = {V[0][0], V[1][0], V[2][0]};
+  const double len = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+  int big = 0;
+  for (int a = 1; a < 3; a++)
+    if (fabs(nrm[a]) > fabs(nrm[big])) big = a;
+  const double sgn = (nrm[big] < 0.0 ? -1.0 : 1.0) / len;
+  for (int a = 0; a < 3; a++) v->ndt_n[a] = (float)(nrm[a] * sgn);
+  v->ndt_plane = 1;
+}
+
+static inline const voxel_t* voxel_ndt(const orc_map* m, const voxel_t* v) {
+  if (v->ndt_dirty) {
+#ifdef _OPENMP
+#pragma omp critical(orc_ndt)
+#endif
+    if (v->ndt_dirty) voxel_update_ndt(m, (voxel_t*)v);
+  }
+  return v;
+}
+
+void orc_map_dump_ndt(const orc_map* m, float* cx, float* cy, float* cz, float* nx, float* ny, float* nz, uint32_t* is_plane) {
+  uint32_t* order = (uint32_t*)malloc((m->n_vox + 1) * sizeof(uint32_t));
+  size_t nv = 0;
+  for (size_t i = 0; i < m->n_vox; i++)
+    if (m->vox[i].n > 0) order[nv++] = (uint32_t)i;
+  g_sort_map = m;
+  qsort(order, nv, sizeof(uint32_t), cmp_vox);
+  for (size_t i = 0; i < nv; i++) {
+    const voxel_t* v = voxel_ndt(m, &m->vox[order[i]]);
+    if (cx) cx[i] = v->ndt_c[0];
+    if (cy) cy[i] = v->ndt_c[1];
+    if (cz) cz[i] = v->ndt_c[2];
+    if (nx) nx[i] = v->ndt_n[0];
+    if (ny) ny[i] = v->ndt_n[1];
+    if (nz) nz[i] = v->ndt_n[2];
+    if (is_plane) is_plane[i] = v->ndt_plane;
   }
   free(order);
 }
@@ -409,6 +531,7 @@ size_t orc_match_points(const orc_map* m, const float* lx, const float* ly, cons
     float px, py, pz, q[3], dd;
     uint32_t gi = 0;
     transform_pt(T, lx[i], ly[i], lz[i], &px, &py, &pz);
+    if (!isfinite(px) || !isfinite(py) || !isfinite(pz)) { ok[i] = 0; continue; } /* a non-finite point pairs with nothing */
     const int found = orc_map_nn_single(m, px, py, pz, q, &dd, &gi, &nc, &nv);
     const float norm2 = (px * px + py * py) + pz * pz;
     const float lim = thr2 + ang2 * norm2;
@@ -429,6 +552,56 @@ size_t orc_match_points(const orc_map* m, const float* lx, const float* ly, cons
     stats->n_candidates = nc;
     stats->n_voxels_hit = nv;
   }
+  return np;
+}
+
+/* Matcher_Point2Plane on the NDT map (semantics: icp_oracle.h) */
+size_t orc_match_pt2pl(const orc_map* m, const float* lx, const float* ly, const float* lz, size_t n, const double T[12],
+                       double distance_threshold, uint32_t* local_idx, float* cx, float* cy, float* cz, float* nx,
+                       float* ny, float* nz, int n_threads) {
+  const float thr = (float)distance_threshold;
+  uint8_t* ok = (uint8_t*)malloc(n ? n : 1);
+  /* make sure every voxel's statistics are current before going parallel */
+  for (size_t i = 0; i < m->n_vox; i++) voxel_ndt(m, &m->vox[i]);
+  (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 512) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+  for (long i = 0; i < (long)n; i++) {
+    float px, py, pz;
+    transform_pt(T, lx[i], ly[i], lz[i], &px, &py, &pz);
+    ok[i] = 0;
+    if (!isfinite(px) || !isfinite(py) || !isfinite(pz)) continue;
+    const int32_t vx = coord2idx(m, px), vy = coord2idx(m, py), vz = coord2idx(m, pz);
+    float best = INFINITY;
+    const voxel_t* bv = NULL;
+    for (int32_t ix = vx - 1; ix <= vx + 1; ix++)
+      for (int32_t iy = vy - 1; iy <= vy + 1; iy++)
+        for (int32_t iz = vz - 1; iz <= vz + 1; iz++) {
+          const voxel_t* v = map_find(m, ix, iy, iz);
+          if (!v || !v->ndt_plane) continue;
+          const float dx = v->ndt_c[0] - px, dy = v->ndt_c[1] - py, dz = v->ndt_c[2] - pz;
+          const float d2 = (dx * dx + dy * dy) + dz * dz;
+          if (d2 < best) { best = d2; bv = v; }
+        }
+    if (!bv) continue;
+    const float dx = px - bv->ndt_c[0], dy = py - bv->ndt_c[1], dz = pz - bv->ndt_c[2];
+    const float e = (bv->ndt_n[0] * dx + bv->ndt_n[1] * dy) + bv->ndt_n[2] * dz;
+    if (fabsf(e) < thr) {
+      ok[i] = 1;
+      cx[i] = bv->ndt_c[0]; cy[i] = bv->ndt_c[1]; cz[i] = bv->ndt_c[2];
+      nx[i] = bv->ndt_n[0]; ny[i] = bv->ndt_n[1]; nz[i] = bv->ndt_n[2];
+    }
+  }
+  size_t np = 0;
+  for (size_t i = 0; i < n; i++)
+    if (ok[i]) {
+      local_idx[np] = (uint32_t)i;
+      cx[np] = cx[i]; cy[np] = cy[i]; cz[np] = cz[i];
+      nx[np] = nx[i]; ny[np] = ny[i]; nz[np] = nz[i];
+      np++;
+    }
+  free(ok);
   return np;
 }
 
@@ -750,31 +923,39 @@ int orc_icp_align(const orc_map* m, const float* lx, const float* ly, const floa
   const size_t na = n ? n : 1;
   uint32_t* li = (uint32_t*)malloc(na * sizeof(uint32_t));
   uint32_t* gi = (uint32_t*)malloc(na * sizeof(uint32_t));
-  float* gx = (float*)malloc(na * sizeof(float));
-  float* gy = (float*)malloc(na * sizeof(float));
-  float* gz = (float*)malloc(na * sizeof(float));
-  float* d2 = (float*)malloc(na * sizeof(float));
-  float* plx = (float*)malloc(na * sizeof(float));
-  float* ply = (float*)malloc(na * sizeof(float));
-  float* plz = (float*)malloc(na * sizeof(float));
-  size_t npairs = 0;
+  float* buf = (float*)malloc(na * sizeof(float) * 16);
+  float *gx = buf, *gy = buf + na, *gz = buf + 2 * na, *d2 = buf + 3 * na, *plx = buf + 4 * na, *ply = buf + 5 * na,
+        *plz = buf + 6 * na;
+  /* point-to-plane pairings (Matcher_Point2Plane, only when p->pt2pl_threshold is given) */
+  float *qcx = buf + 7 * na, *qcy = buf + 8 * na, *qcz = buf + 9 * na, *qnx = buf + 10 * na, *qny = buf + 11 * na,
+        *qnz = buf + 12 * na, *qlx = buf + 13 * na, *qly = buf + 14 * na, *qlz = buf + 15 * na;
+  uint32_t* qli = (uint32_t*)malloc(na * sizeof(uint32_t));
+  size_t npairs = 0, nplanes = 0;
   uint64_t potential = 0;
   res->termination_reason = ORC_TERM_UNDEFINED;
 
   uint32_t it;
   for (it = 0; it < p->max_iterations; it++) {
     /* ICP_ITERATION = it -> threshold / kernel param formulas (yaml:190,198) pre-evaluated */
+    potential = 0;
+    nplanes = 0;
+    if (p->pt2pl_threshold) { /* matchers run in YAML order: Point2Plane first (lidar3d-ndt.yaml:195-210) */
+      nplanes = orc_match_pt2pl(m, lx, ly, lz, n, T, p->pt2pl_threshold[it], qli, qcx, qcy, qcz, qnx, qny, qnz, n_threads);
+      potential += n;
+      for (size_t k = 0; k < nplanes; k++) { qlx[k] = lx[qli[k]]; qly[k] = ly[qli[k]]; qlz[k] = lz[qli[k]]; }
+    }
     orc_match_stats st;
     npairs = orc_match_points(m, lx, ly, lz, n, T, p->threshold[it], p->threshold_angular_deg, li, gi, gx, gy, gz, d2,
                               &st, n_threads);
-    potential = st.potential_pairings;
+    potential += st.potential_pairings;
     res->n_candidates_total += st.n_candidates;
-    if (npairs == 0) { res->termination_reason = ORC_TERM_NO_PAIRINGS; break; }
+    if (npairs + nplanes == 0) { res->termination_reason = ORC_TERM_NO_PAIRINGS; break; }
     for (size_t k = 0; k < npairs; k++) { plx[k] = lx[li[k]]; ply[k] = ly[li[k]]; plz[k] = lz[li[k]]; }
     orc_pairs_pt2pt pp = {plx, ply, plz, gx, gy, gz, npairs};
+    orc_pairs_pt2pl pl = {qlx, qly, qlz, qcx, qcy, qcz, qnx, qny, qnz, nplanes};
     orc_gn_params gp = p->gn;
     gp.robust_kernel_param = p->kernel_param[it];
-    const int ok = orc_gn_solve(&pp, NULL, &gp, prior, T, NULL, n_threads);
+    const int ok = orc_gn_solve(&pp, nplanes ? &pl : NULL, &gp, prior, T, NULL, n_threads);
     if (ok < 0) { res->termination_reason = ORC_TERM_SOLVER_ERROR; break; }
     /* stall test on log(T_prev^-1 (+) T_new) (yaml:174-175) */
     double Pinv[12], D[12], d[6];
@@ -785,7 +966,7 @@ int orc_icp_align(const orc_map* m, const float* lx, const float* ly, const floa
     const double drot = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
     if (trace) {
       memcpy(trace[it].T, T, sizeof(T));
-      trace[it].n_pairs = (uint32_t)npairs;
+      trace[it].n_pairs = (uint32_t)(npairs + nplanes);
       trace[it].threshold = p->threshold[it];
       trace[it].kernel_param = p->kernel_param[it];
       trace[it].delta_trans = dtr;
@@ -811,12 +992,14 @@ int orc_icp_align(const orc_map* m, const float* lx, const float* ly, const floa
   if (it >= p->max_iterations) res->termination_reason = ORC_TERM_MAX_ITERATIONS;
 
   memcpy(res->T, T, sizeof(T));
-  res->n_final_pairs = (uint32_t)npairs;
+  res->n_final_pairs = (uint32_t)(npairs + nplanes);
+  res->n_final_pairs_pt2pl = (uint32_t)nplanes;
   res->potential_pairings = potential;
-  res->quality = (npairs && potential) ? (double)npairs / (double)potential : 0.0; /* PairedRatio */
+  res->quality = ((npairs + nplanes) && potential) ? (double)(npairs + nplanes) / (double)potential : 0.0; /* PairedRatio */
   if (p->compute_covariance) {
     orc_pairs_pt2pt pp = {plx, ply, plz, gx, gy, gz, npairs};
-    orc_covariance(&pp, NULL, T, p->cov_findif_xyz, p->cov_findif_ang, res->cov, NULL);
+    orc_pairs_pt2pl pl = {qlx, qly, qlz, qcx, qcy, qcz, qnx, qny, qnz, nplanes};
+    orc_covariance(&pp, nplanes ? &pl : NULL, T, p->cov_findif_xyz, p->cov_findif_ang, res->cov, NULL);
   }
   if (final_pairs) {
     for (size_t k = 0; k < npairs; k++) {
@@ -828,7 +1011,7 @@ int orc_icp_align(const orc_map* m, const float* lx, const float* ly, const floa
       if (final_pairs->d2) final_pairs->d2[k] = d2[k];
     }
   }
-  free(li); free(gi); free(gx); free(gy); free(gz); free(d2); free(plx); free(ply); free(plz);
+  free(li); free(gi); free(buf); free(qli);
   return 0;
 }
 

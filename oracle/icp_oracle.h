@@ -66,6 +66,10 @@ typedef struct {
   float voxel_size;              /* creationOpts.voxel_size            (yaml:233) */
   uint32_t max_points_per_voxel; /* insertOpts.max_points_per_voxel    (yaml:235); 0 = no cap */
   uint32_t index_mode;           /* ORC_INDEX_FLOOR (SURVEY App.A) | ORC_INDEX_TRUNC */
+  /* mola::NDT role (lidar3d-ndt.yaml:236-254): */
+  float min_distance_between_points; /* insertOpts (ndt yaml:244): drop a point closer than this to a stored point of its voxel; 0 = off */
+  float ndt_max_eigen_ratio;         /* max_eigen_ratio_for_planes (ndt yaml:248); 0 = no NDT statistics */
+  uint32_t ndt_min_points;           /* voxels with fewer points have no NDT (4) */
 } orc_map_params;
 
 orc_map* orc_map_create(const orc_map_params* p);
@@ -103,6 +107,21 @@ size_t orc_match_points(const orc_map* m, const float* lx, const float* ly, cons
                         const double T[12], double threshold, double threshold_angular_deg,
                         uint32_t* local_idx, uint32_t* global_idx, float* gx, float* gy, float* gz,
                         float* d2, orc_match_stats* stats, int n_threads);
+
+/* ---- matcher: mp2p_icp::Matcher_Point2Plane on a mola::NDT map (lidar3d-ndt.yaml:195-200; SURVEY 8a row a13,
+ * App.B U10 -- the upstream semantics are unverified, this is the documented default): per voxel with
+ * >= ndt_min_points points: mean, covariance (1/(n-1)), eigen-decomposition; the voxel is a plane iff
+ * lambda_min/lambda_max < ndt_max_eigen_ratio, normal = eigenvector of lambda_min (sign: largest component > 0).
+ * For a transformed local point p' the planar voxel of the 3x3x3 block with the nearest centroid (fp32 d^2, first
+ * minimum in scan order) is taken and the pairing {centroid, normal, local point} is emitted iff
+ * |n.(p'-c)| < distanceThreshold.  Pairs in ascending local index; arrays sized n. */
+size_t orc_match_pt2pl(const orc_map* m, const float* lx, const float* ly, const float* lz, size_t n, const double T[12],
+                       double distance_threshold, uint32_t* local_idx, float* cx, float* cy, float* cz, float* nx,
+                       float* ny, float* nz, int n_threads);
+/* NDT statistics of the occupied voxels in ascending key order (same order as orc_map_dump): centroid, normal,
+ * is_plane flag; arrays of orc_map_num_voxels() entries. */
+void orc_map_dump_ndt(const orc_map* m, float* cx, float* cy, float* cz, float* nx, float* ny, float* nz,
+                      uint32_t* is_plane);
 
 /* ---- solver: mp2p_icp::Solver_GaussNewton / optimal_tf_gauss_newton (yaml:184-190) ------ */
 typedef struct {
@@ -156,6 +175,8 @@ typedef struct {
   /* matcher */
   const double* threshold;     /* [max_iterations] value of the yaml:198 formula per ICP_ITERATION */
   double threshold_angular_deg;/* yaml:200 */
+  const double* pt2pl_threshold; /* NULL = no Matcher_Point2Plane; else [max_iterations] distanceThreshold (ndt yaml:197),
+                                    that matcher runs BEFORE the point matcher and both pairing sets go to one solve */
   /* solver */
   const double* kernel_param;  /* [max_iterations] value of the yaml:190 formula */
   orc_gn_params gn;            /* robust_kernel_param ignored (taken from kernel_param[k]) */
@@ -182,9 +203,10 @@ typedef struct {
   double quality;
   uint32_t n_iterations;
   uint32_t termination_reason;
-  uint32_t n_final_pairs;
+  uint32_t n_final_pairs;      /* point-to-point + point-to-plane */
   uint64_t potential_pairings;
   uint64_t n_candidates_total; /* sum over iterations, for P-bar */
+  uint32_t n_final_pairs_pt2pl;
 } orc_icp_result;
 
 /* final pairings (optional): arrays sized n_local */

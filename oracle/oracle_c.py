@@ -31,7 +31,9 @@ def build(force: bool = False) -> str:
 
 
 class _MapParams(C.Structure):
-    _fields_ = [("voxel_size", C.c_float), ("max_points_per_voxel", C.c_uint32), ("index_mode", C.c_uint32)]
+    _fields_ = [("voxel_size", C.c_float), ("max_points_per_voxel", C.c_uint32), ("index_mode", C.c_uint32),
+                ("min_distance_between_points", C.c_float), ("ndt_max_eigen_ratio", C.c_float),
+                ("ndt_min_points", C.c_uint32)]
 
 
 class _MatchStats(C.Structure):
@@ -70,7 +72,7 @@ class _GNStep(C.Structure):
 class _ICPParams(C.Structure):
     _fields_ = [("max_iterations", C.c_uint32), ("min_abs_step_trans", C.c_double), ("min_abs_step_rot", C.c_double),
                 ("disable_stall_test", C.c_uint32), ("threshold", _DP), ("threshold_angular_deg", C.c_double),
-                ("kernel_param", _DP), ("gn", _GNParams), ("hook_enabled", C.c_uint32),
+                ("pt2pl_threshold", _DP), ("kernel_param", _DP), ("gn", _GNParams), ("hook_enabled", C.c_uint32),
                 ("hook_min_trans", C.c_double), ("hook_min_rot", C.c_double), ("hook_checkpoint", C.c_double * 12),
                 ("compute_covariance", C.c_uint32), ("cov_findif_xyz", C.c_double), ("cov_findif_ang", C.c_double)]
 
@@ -83,7 +85,8 @@ class _ICPIter(C.Structure):
 class _ICPResult(C.Structure):
     _fields_ = [("T", C.c_double * 12), ("cov", C.c_double * 36), ("quality", C.c_double),
                 ("n_iterations", C.c_uint32), ("termination_reason", C.c_uint32), ("n_final_pairs", C.c_uint32),
-                ("potential_pairings", C.c_uint64), ("n_candidates_total", C.c_uint64)]
+                ("potential_pairings", C.c_uint64), ("n_candidates_total", C.c_uint64),
+                ("n_final_pairs_pt2pl", C.c_uint32)]
 
 
 class _PairsOut(C.Structure):
@@ -114,6 +117,10 @@ def lib():
         L.orc_match_points.restype = C.c_size_t
         L.orc_match_points.argtypes = [C.c_void_p, _FP, _FP, _FP, C.c_size_t, _DP, C.c_double, C.c_double,
                                        _UP, _UP, _FP, _FP, _FP, _FP, C.POINTER(_MatchStats), C.c_int]
+        L.orc_match_pt2pl.restype = C.c_size_t
+        L.orc_match_pt2pl.argtypes = [C.c_void_p, _FP, _FP, _FP, C.c_size_t, _DP, C.c_double, _UP, _FP, _FP, _FP, _FP, _FP,
+                                      _FP, C.c_int]
+        L.orc_map_dump_ndt.argtypes = [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _UP]
         L.orc_gn_solve.restype = C.c_int
         L.orc_gn_solve.argtypes = [C.POINTER(_PairsPt2Pt), C.POINTER(_PairsPt2Pl), C.POINTER(_GNParams),
                                    C.POINTER(_Prior), _DP, C.POINTER(_GNStep), C.c_int]
@@ -180,8 +187,10 @@ def pose_compose(a, b):
 
 # ---- map --------------------------------------------------------------------------------
 class Map:
-    def __init__(self, voxel_size=1.0, max_points_per_voxel=20, index_mode=INDEX_FLOOR):
-        p = _MapParams(voxel_size, max_points_per_voxel, index_mode)
+    def __init__(self, voxel_size=1.0, max_points_per_voxel=20, index_mode=INDEX_FLOOR, min_distance_between_points=0.0,
+                 ndt_max_eigen_ratio=0.0, ndt_min_points=4):
+        p = _MapParams(voxel_size, max_points_per_voxel, index_mode, min_distance_between_points, ndt_max_eigen_ratio,
+                       ndt_min_points)
         self._h = lib().orc_map_create(C.byref(p))
         self.voxel_size = voxel_size
 
@@ -219,6 +228,13 @@ class Map:
                            _up(first), _up(count))
         return dict(xyz=np.stack([x, y, z], 1), src_idx=src, vox_keys=keys, vox_first=first, vox_count=count)
 
+    def dump_ndt(self):
+        v = self.num_voxels
+        a = [np.zeros(max(v, 1), np.float32) for _ in range(6)]
+        pl = np.zeros(max(v, 1), np.uint32)
+        lib().orc_map_dump_ndt(self._h, *[_fp(x) for x in a], _up(pl))
+        return dict(centroid=np.stack(a[:3], 1)[:v], normal=np.stack(a[3:], 1)[:v], is_plane=pl[:v])
+
     def nn_single(self, q):
         pt = np.zeros(3, np.float32)
         d2 = C.c_float()
@@ -242,6 +258,18 @@ def match_points(m: Map, local_xyz, T, threshold, threshold_angular_deg=0.0, n_t
     return dict(local_idx=li[:k].copy(), global_idx=gi[:k].copy(), global_xyz=np.stack([gx[:k], gy[:k], gz[:k]], 1),
                 d2=d2[:k].copy(), potential_pairings=int(st.potential_pairings), n_candidates=int(st.n_candidates),
                 n_voxels_hit=int(st.n_voxels_hit))
+
+
+def match_pt2pl(m: Map, local_xyz, T, distance_threshold, n_threads=1):
+    l = np.asarray(local_xyz, dtype=np.float32)
+    n = len(l)
+    lx, ly, lz = _f32(l[:, 0]), _f32(l[:, 1]), _f32(l[:, 2])
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(12)
+    li = np.zeros(max(n, 1), np.uint32)
+    a = [np.zeros(max(n, 1), np.float32) for _ in range(6)]
+    k = lib().orc_match_pt2pl(m._h, _fp(lx), _fp(ly), _fp(lz), n, _dp(T), float(distance_threshold), _up(li),
+                              *[_fp(x) for x in a], n_threads)
+    return dict(local_idx=li[:k].copy(), centroid=np.stack(a[:3], 1)[:k].copy(), normal=np.stack(a[3:], 1)[:k].copy())
 
 
 @dataclass
@@ -318,6 +346,7 @@ class ICPParams:
     disable_stall_test: bool = False
     threshold: object = None  # array [max_iterations]
     threshold_angular_deg: float = 0.0
+    pt2pl_threshold: object = None  # None = no Matcher_Point2Plane, else array [max_iterations]
     kernel_param: object = None  # array [max_iterations]
     gn: GNParams = field(default_factory=GNParams)
     hook_enabled: bool = False
@@ -343,6 +372,10 @@ def icp_align(m: Map, local_xyz, T_guess, p: ICPParams, prior=None, n_threads=1,
     cp.threshold = _dp(thr)
     cp.threshold_angular_deg = p.threshold_angular_deg
     cp.kernel_param = _dp(kp)
+    plt = None
+    if p.pt2pl_threshold is not None:
+        plt = np.ascontiguousarray(np.broadcast_to(np.asarray(p.pt2pl_threshold, np.float64), (p.max_iterations,)))
+        cp.pt2pl_threshold = _dp(plt)
     cp.gn = p.gn.c()
     cp.hook_enabled = int(p.hook_enabled)
     cp.hook_min_trans = p.hook_min_trans
@@ -369,12 +402,12 @@ def icp_align(m: Map, local_xyz, T_guess, p: ICPParams, prior=None, n_threads=1,
     out = dict(T=np.array(res.T), cov=np.array(res.cov).reshape(6, 6), quality=res.quality,
                n_iterations=int(res.n_iterations), termination_reason=int(res.termination_reason),
                n_final_pairs=int(res.n_final_pairs), potential_pairings=int(res.potential_pairings),
-               n_candidates_total=int(res.n_candidates_total),
+               n_candidates_total=int(res.n_candidates_total), n_final_pairs_pt2pl=int(res.n_final_pairs_pt2pl),
                trace=[dict(T=np.array(trace[i].T), n_pairs=int(trace[i].n_pairs), threshold=trace[i].threshold,
                            kernel_param=trace[i].kernel_param, delta_trans=trace[i].delta_trans,
                            delta_rot=trace[i].delta_rot) for i in range(n_tr)])
     if want_pairs:
-        k = out["n_final_pairs"]
+        k = out["n_final_pairs"] - out["n_final_pairs_pt2pl"]
         out["pairs"] = dict(local_idx=li[:k].copy(), global_idx=gi[:k].copy(),
                             global_xyz=np.stack([gx[:k], gy[:k], gz[:k]], 1), d2=d2[:k].copy())
     return out
