@@ -109,7 +109,10 @@ typedef struct {
   float voxel_size;              /* [m] > 0 */
   uint32_t max_points_per_voxel; /* 0 = unlimited */
   uint32_t index_mode;           /* MH_INDEX_* */
-  uint32_t reserved;
+  /* mola::NDT [U] role (lidar3d-ndt.yaml:236-254); all 0 = plain HashedVoxelPointCloud */
+  float min_distance_between_points; /* insertOpts: drop a point closer than this to a stored point of its voxel */
+  float ndt_max_eigen_ratio;         /* insertOpts.max_eigen_ratio_for_planes; > 0 enables per-voxel NDT statistics */
+  uint32_t ndt_min_points;           /* voxels with fewer stored points carry no NDT (0 -> 4) */
 } mh_map_params;
 
 typedef struct {
@@ -120,6 +123,7 @@ typedef struct {
   float bbox_min[3], bbox_max[3];
   float voxel_size;
   uint32_t max_points_per_voxel;
+  uint64_t n_planes;   /* voxels whose NDT is a plane (0 when NDT statistics are off) */
 } mh_map_info;
 
 MH_API mh_status mh_map_create(mh_ctx* ctx, const mh_map_params* params, mh_map** out);
@@ -134,6 +138,10 @@ MH_API mh_status mh_map_get_info(const mh_map* map, mh_map_info* info);
  * (kx,ky,kz), in-voxel insertion order.  xyz/src_idx hold n_points entries, vox_* hold n_voxels. */
 MH_API mh_status mh_map_download(const mh_map* map, float* x, float* y, float* z, uint32_t* src_idx,
                                  int32_t* vox_keys_xyz, uint32_t* vox_first, uint32_t* vox_count);
+/* NDT statistics per occupied voxel, same voxel order as mh_map_download (HOST arrays of n_voxels entries, any may be
+ * NULL): centroid, unit normal (largest component positive) and the plane flag.  Zeros when NDT is off. */
+MH_API mh_status mh_map_download_ndt(const mh_map* map, float* cx, float* cy, float* cz, float* nx, float* ny, float* nz,
+                                     uint32_t* is_plane);
 
 /* ------------------------------------------------------------------------------------------------
  * Scan: the local point layer handed to align() ("decimated_for_icp", lidar3d-default.yaml:204),
@@ -175,6 +183,20 @@ MH_API mh_status mh_nn_search(const mh_map* map, const mh_scan* scan, const doub
  * the 27-voxel block (no threshold applied).  Arrays hold scan-size entries; any may be NULL. */
 MH_API mh_status mh_nn_search_dense(const mh_map* map, const mh_scan* scan, const double T[12], uint32_t* global_idx,
                                     float* gx, float* gy, float* gz, float* d2, int32_t mem);
+
+/* Replaces mp2p_icp::Matcher_Point2Plane::implMatchOneLayer [U] on a mola::NDT [U] map (lidar3d-ndt.yaml:195-200,
+ * 236-254).  The upstream semantics are unverified (SURVEY App.B U10); implemented default: among
+ * the planar voxels of the 3x3x3 block around voxel(p') the one with the nearest centroid is taken (fp32 d^2, first
+ * minimum in scan order) and the pairing {centroid, normal, local point} is emitted iff |n.(p'-c)| < distance_threshold.
+ * Needs a map built with ndt_max_eigen_ratio > 0.  Output = Pairings::paired_pt2pl [U] as SoA, ascending local index. */
+typedef struct {
+  uint32_t* local_idx;
+  float *cx, *cy, *cz; /* plane centroid */
+  float *nx, *ny, *nz; /* plane unit normal */
+} mh_pairs_pl_out;
+
+MH_API mh_status mh_nn_search_pt2pl(const mh_map* map, const mh_scan* scan, const double T[12], double distance_threshold,
+                                    const mh_pairs_pl_out* out, int32_t mem, mh_match_info* info);
 
 /* ------------------------------------------------------------------------------------------------
  * Solver-granular path.  Replaces mp2p_icp::Solver_GaussNewton::impl_optimal_pose /
@@ -248,6 +270,9 @@ typedef struct {
   const double* threshold;
   const double* kernel_param;
   double threshold_angular_deg; /* yaml:200 */
+  /* NULL, or max_iterations values of Matcher_Point2Plane.distanceThreshold (lidar3d-ndt.yaml:197): that matcher
+   * then runs before the point matcher in every iteration and both pairing sets go to one solve (ndt yaml:195-210). */
+  const double* pt2pl_threshold;
   mh_gn_params gn;              /* robust_kernel_param ignored (kernel_param[k] is used) */
   /* Device-side equivalent of the in-tree iteration hook (LidarOdometry.cpp:923-952): request a stop
    * when the pose has moved more than hook_min_trans [m] or hook_min_rot [rad] from hook_checkpoint. */
@@ -285,6 +310,7 @@ typedef struct {
   uint32_t n_match_launches;
   double match_kernel_ms;      /* sum of the match kernel durations */
   double total_ms;             /* stream time of the whole align */
+  uint32_t n_final_pairs_pt2pl; /* how many of n_final_pairs are point-to-plane */
 } mh_icp_result;
 
 /* `trace` (nullable, HOST, max_iterations entries) receives one record per executed iteration;
@@ -292,6 +318,10 @@ typedef struct {
 MH_API mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_icp_params* params,
                               const double T_guess[12], const mh_prior* prior, mh_icp_result* result,
                               mh_icp_iter* trace, const mh_pairs_out* final_pairs, int32_t pairs_mem);
+
+/* Results::finalPairings.paired_pt2pl [U] of the LAST mh_icp_align run on `scan`'s context (arrays in `mem`, scan-size
+ * entries, any may be NULL). */
+MH_API mh_status mh_icp_get_pt2pl_pairs(const mh_scan* scan, const mh_pairs_pl_out* out, int32_t mem, uint64_t* n_pairs);
 
 /* Many independent alignments, one per context/stream, interleaved from one host thread so that the
  * kernels of different scans overlap on the device (one-scan-per-stream sharding).  Job i uses

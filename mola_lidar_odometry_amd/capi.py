@@ -38,17 +38,22 @@ class MolahipError(RuntimeError):
 
 class MapParams(C.Structure):
     _fields_ = [("voxel_size", C.c_float), ("max_points_per_voxel", C.c_uint32), ("index_mode", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("min_distance_between_points", C.c_float), ("ndt_max_eigen_ratio", C.c_float),
+                ("ndt_min_points", C.c_uint32)]
 
 
 class MapInfo(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("n_offered", C.c_uint64), ("n_voxels", C.c_uint64),
                 ("table_size", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
-                ("voxel_size", C.c_float), ("max_points_per_voxel", C.c_uint32)]
+                ("voxel_size", C.c_float), ("max_points_per_voxel", C.c_uint32), ("n_planes", C.c_uint64)]
 
 
 class PairsOut(C.Structure):
     _fields_ = [("local_idx", _UP), ("global_idx", _UP), ("gx", _FP), ("gy", _FP), ("gz", _FP), ("d2", _FP)]
+
+
+class PairsPlOut(C.Structure):
+    _fields_ = [("local_idx", _UP), ("cx", _FP), ("cy", _FP), ("cz", _FP), ("nx", _FP), ("ny", _FP), ("nz", _FP)]
 
 
 class MatchInfo(C.Structure):
@@ -82,7 +87,7 @@ class GNStep(C.Structure):
 class ICPParamsC(C.Structure):
     _fields_ = [("max_iterations", C.c_uint32), ("min_abs_step_trans", C.c_double), ("min_abs_step_rot", C.c_double),
                 ("disable_stall_test", C.c_uint32), ("threshold", _DP), ("kernel_param", _DP),
-                ("threshold_angular_deg", C.c_double), ("gn", GNParamsC), ("hook_enabled", C.c_uint32),
+                ("threshold_angular_deg", C.c_double), ("pt2pl_threshold", _DP), ("gn", GNParamsC), ("hook_enabled", C.c_uint32),
                 ("hook_min_trans", C.c_double), ("hook_min_rot", C.c_double), ("hook_checkpoint", C.c_double * 12),
                 ("compute_covariance", C.c_uint32), ("cov_findif_xyz", C.c_double), ("cov_findif_ang", C.c_double),
                 ("poll_every", C.c_uint32), ("profile", C.c_uint32)]
@@ -97,7 +102,7 @@ class ICPResult(C.Structure):
     _fields_ = [("T", C.c_double * 12), ("cov", C.c_double * 36), ("quality", C.c_double),
                 ("n_iterations", C.c_uint32), ("termination_reason", C.c_uint32), ("n_final_pairs", C.c_uint32),
                 ("potential_pairings", C.c_uint64), ("n_match_launches", C.c_uint32),
-                ("match_kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("match_kernel_ms", C.c_double), ("total_ms", C.c_double), ("n_final_pairs_pt2pl", C.c_uint32)]
 
 
 # every entry point include/molahip.h declares, with its ctypes signature
@@ -115,6 +120,7 @@ _SIGNATURES = {
     "mh_map_build": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
     "mh_map_get_info": (C.c_int32, [C.c_void_p, C.POINTER(MapInfo)]),
     "mh_map_download": (C.c_int32, [C.c_void_p, _FP, _FP, _FP, _UP, C.POINTER(C.c_int32), _UP, _UP]),
+    "mh_map_download_ndt": (C.c_int32, [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _UP]),
     "mh_scan_create": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32,
                                    C.POINTER(C.c_void_p)]),
     "mh_scan_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
@@ -124,6 +130,9 @@ _SIGNATURES = {
                                  C.POINTER(MatchInfo)]),
     "mh_nn_search_dense": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int32]),
+    "mh_nn_search_pt2pl": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_double, C.POINTER(PairsPlOut), C.c_int32,
+                                       C.POINTER(MatchInfo)]),
+    "mh_icp_get_pt2pl_pairs": (C.c_int32, [C.c_void_p, C.POINTER(PairsPlOut), C.c_int32, C.POINTER(C.c_uint64)]),
     "mh_gn_solve": (C.c_int32, [C.c_void_p, C.POINTER(PairsPt2Pt), C.POINTER(PairsPt2Pl), C.c_int32,
                                 C.POINTER(GNParamsC), C.POINTER(Prior), _DP, C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int32), C.POINTER(GNStep)]),
@@ -227,10 +236,12 @@ class Context:
 class Map:
     """Device-resident voxel-hashed local map (stands in for mola::HashedVoxelPointCloud)."""
 
-    def __init__(self, ctx: Context, voxel_size=1.0, max_points_per_voxel=20, index_mode=INDEX_FLOOR):
+    def __init__(self, ctx: Context, voxel_size=1.0, max_points_per_voxel=20, index_mode=INDEX_FLOOR,
+                 min_distance_between_points=0.0, ndt_max_eigen_ratio=0.0, ndt_min_points=4):
         self.ctx = ctx
         self._h = C.c_void_p()
-        p = MapParams(voxel_size, max_points_per_voxel, index_mode, 0)
+        p = MapParams(voxel_size, max_points_per_voxel, index_mode, min_distance_between_points, ndt_max_eigen_ratio,
+                      ndt_min_points)
         _chk(lib().mh_map_create(ctx._h, C.byref(p), C.byref(self._h)))
         ctx._children.add(self)
 
@@ -260,6 +271,13 @@ class Map:
                                    first.ctypes.data_as(_UP), count.ctypes.data_as(_UP)))
         return dict(xyz=np.stack([x[:n], y[:n], z[:n]], 1), src_idx=src[:n], vox_keys=keys[:v], vox_first=first[:v],
                     vox_count=count[:v])
+
+    def download_ndt(self):
+        v = int(self.info().n_voxels)
+        a = [np.zeros(max(v, 1), np.float32) for _ in range(6)]
+        pl = np.zeros(max(v, 1), np.uint32)
+        _chk(lib().mh_map_download_ndt(self._h, *[x.ctypes.data_as(_FP) for x in a], pl.ctypes.data_as(_UP)))
+        return dict(centroid=np.stack(a[:3], 1)[:v], normal=np.stack(a[3:], 1)[:v], is_plane=pl[:v])
 
     def close(self):
         if self._h:
@@ -334,6 +352,32 @@ def nn_search(m: Map, s: Scan, T, threshold, threshold_angular_deg=0.0):
     k = int(info.n_pairs)
     return dict(local_idx=li[:k].copy(), global_idx=gi[:k].copy(), global_xyz=np.stack([gx[:k], gy[:k], gz[:k]], 1),
                 d2=d2[:k].copy(), potential_pairings=int(info.potential_pairings))
+
+
+def _pl_arrays(n):
+    li = np.zeros(n, np.uint32)
+    a = [np.zeros(n, np.float32) for _ in range(6)]
+    return li, a, PairsPlOut(li.ctypes.data_as(_UP), *[x.ctypes.data_as(_FP) for x in a])
+
+
+def nn_search_pt2pl(m: Map, s: Scan, T, distance_threshold):
+    """Matcher_Point2Plane on an NDT map (mh_nn_search_pt2pl)."""
+    li, a, out = _pl_arrays(max(s.n, 1))
+    info = MatchInfo()
+    T = _T12(T)
+    _chk(lib().mh_nn_search_pt2pl(m._h, s._h, T.ctypes.data_as(_DP), float(distance_threshold), C.byref(out), MEM_HOST,
+                                  C.byref(info)))
+    k = int(info.n_pairs)
+    return dict(local_idx=li[:k].copy(), centroid=np.stack(a[:3], 1)[:k].copy(), normal=np.stack(a[3:], 1)[:k].copy(),
+                potential_pairings=int(info.potential_pairings))
+
+
+def icp_get_pt2pl_pairs(s: Scan):
+    li, a, out = _pl_arrays(max(s.n, 1))
+    k = C.c_uint64(0)
+    _chk(lib().mh_icp_get_pt2pl_pairs(s._h, C.byref(out), MEM_HOST, C.byref(k)))
+    k = int(k.value)
+    return dict(local_idx=li[:k].copy(), centroid=np.stack(a[:3], 1)[:k].copy(), normal=np.stack(a[3:], 1)[:k].copy())
 
 
 def nn_search_dense(m: Map, s: Scan, T):
@@ -418,6 +462,7 @@ class ICPParams:
     threshold: object = None
     kernel_param: object = None
     threshold_angular_deg: float = 0.0
+    pt2pl_threshold: object = None  # None, or per-iteration Matcher_Point2Plane.distanceThreshold (needs an NDT map)
     gn: GNParams = field(default_factory=GNParams)
     hook_enabled: bool = False
     hook_min_trans: float = 0.15
@@ -440,6 +485,10 @@ class ICPParams:
         cp.threshold = thr.ctypes.data_as(_DP)
         cp.kernel_param = kp.ctypes.data_as(_DP)
         cp.threshold_angular_deg = self.threshold_angular_deg
+        plt = None
+        if self.pt2pl_threshold is not None:
+            plt = np.ascontiguousarray(np.broadcast_to(np.asarray(self.pt2pl_threshold, np.float64), (self.max_iterations,)))
+            cp.pt2pl_threshold = plt.ctypes.data_as(_DP)
         cp.gn = self.gn.c()
         cp.hook_enabled = int(self.hook_enabled)
         cp.hook_min_trans = self.hook_min_trans
@@ -451,14 +500,15 @@ class ICPParams:
         cp.cov_findif_ang = self.cov_findif_ang
         cp.poll_every = self.poll_every
         cp.profile = int(self.profile)  # 0 | 1 (all jobs) | 2 (job 0 of a batch only)
-        return cp, (thr, kp)
+        return cp, (thr, kp, plt)
 
 
 def _result_dict(res: ICPResult):
     return dict(T=np.array(res.T), cov=np.array(res.cov).reshape(6, 6), quality=res.quality,
                 n_iterations=int(res.n_iterations), termination_reason=int(res.termination_reason),
                 n_final_pairs=int(res.n_final_pairs), potential_pairings=int(res.potential_pairings),
-                n_match_launches=int(res.n_match_launches), match_kernel_ms=res.match_kernel_ms, total_ms=res.total_ms)
+                n_match_launches=int(res.n_match_launches), match_kernel_ms=res.match_kernel_ms, total_ms=res.total_ms,
+                n_final_pairs_pt2pl=int(res.n_final_pairs_pt2pl))
 
 
 def icp_align(m: Map, s: Scan, T_guess, p: ICPParams, prior=None, want_trace=True, want_pairs=False):
@@ -486,7 +536,7 @@ def icp_align(m: Map, s: Scan, T_guess, p: ICPParams, prior=None, want_trace=Tru
                              kernel_param=trace[i].kernel_param, delta_trans=trace[i].delta_trans,
                              delta_rot=trace[i].delta_rot) for i in range(n_tr)]
     if want_pairs:
-        k = out["n_final_pairs"]
+        k = out["n_final_pairs"] - out["n_final_pairs_pt2pl"]
         out["pairs"] = dict(local_idx=li[:k].copy(), global_idx=gi[:k].copy(),
                             global_xyz=np.stack([gx[:k], gy[:k], gz[:k]], 1), d2=d2[:k].copy())
     return out

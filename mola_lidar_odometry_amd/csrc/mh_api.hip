@@ -120,6 +120,8 @@ mh_status mh_ctx_destroy(mh_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->pair_q.release();
   ctx->pair_gidx.release();
+  ctx->pl_c.release();
+  ctx->pl_n.release();
   ctx->partials.release();
   ctx->partials_b.release();
   ctx->sched.release();

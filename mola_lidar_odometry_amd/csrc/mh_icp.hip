@@ -38,7 +38,7 @@ struct IcpDeviceState {
   double T_prev[12];
   uint32_t iter, inner, done, term_reason;
   uint32_t n_pairs, n_iterations, solver_ok, n_solves;
-  uint32_t cov_done, pad0, pad1, pad2;
+  uint32_t cov_done, n_pairs_pl, pad1, pad2;
   double cov[36];
   double covD[72];  // (T(x+h_j) - T(x-h_j)) / (2 h_j), j = 0..5, 3x4 each
 };
@@ -55,6 +55,8 @@ struct MatchK {
   double kparam_fixed;   // solver-granular path: fixed robust-kernel parameter
   uint32_t use_fixed;
   uint32_t pad;
+  const double* pl_thr;  // [max_iterations] device: Matcher_Point2Plane.distanceThreshold per iteration (or null)
+  double w_pt2pl;
 };
 
 struct SolveK {
@@ -525,6 +527,170 @@ __global__ __launch_bounds__(kBlock) void k_accum_pl(const IcpDeviceState* __res
 // k_solve: one wave.  Ordered reduction of the block partials, prior factor, LDL^T solve, SE(3)
 // retraction, inner/outer loop bookkeeping (optimal_tf_gauss_newton + the tail of ICP::align's loop).
 // ================================================================================================
+// ================================================================================================
+// Matcher_Point2Plane on an NDT map (lidar3d-ndt.yaml:195-200): nearest planar voxel of the 27-block
+// by centroid distance, accepted iff |n.(p'-c)| < threshold.  One lane per scan point; the 27 slot probes go out in
+// three batches of nine unconditional loads, the nine centroid records of a batch likewise.
+// ================================================================================================
+__device__ __forceinline__ void acc_pt2pl_rows(double* v, const double* __restrict__ T, float lxf, float lyf, float lzf,
+                                               const float4& c, const float4& nrm, uint32_t kernel, double kparam,
+                                               double wpair) {
+  const double lx = lxf, ly = lyf, lz = lzf;
+  const double gx = T[0] * lx + T[1] * ly + T[2] * lz + T[3] - (double)c.x;
+  const double gy = T[4] * lx + T[5] * ly + T[6] * lz + T[7] - (double)c.y;
+  const double gz = T[8] * lx + T[9] * ly + T[10] * lz + T[11] - (double)c.z;
+  const double nx = nrm.x, ny = nrm.y, nz = nrm.z;
+  const double e = nx * gx + ny * gy + nz * gz;
+  const double w = wpair * robust_weight(kernel, kparam, e * e);
+  double J[6];
+  J[0] = T[0] * nx + T[4] * ny + T[8] * nz;  // m = R^T n
+  J[1] = T[1] * nx + T[5] * ny + T[9] * nz;
+  J[2] = T[2] * nx + T[6] * ny + T[10] * nz;
+  J[3] = ly * J[2] - lz * J[1];
+  J[4] = lz * J[0] - lx * J[2];
+  J[5] = lx * J[1] - ly * J[0];
+  int q = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = a; b < 6; b++) v[q++] = w * J[a] * J[b];
+#pragma unroll
+  for (int a = 0; a < 6; a++) v[21 + a] = w * J[a] * e;
+  v[27] = w * e * e;
+  v[28] = 1.0;
+}
+
+template <int NV>
+__device__ __forceinline__ void block_reduce_rows(const double* v, double (*lds)[NV], double* __restrict__ partials,
+                                                  uint32_t pstride, uint32_t bid) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const double s = wave_sum(v[j]);
+    if (lane == 0) lds[wave][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV)
+    partials[threadIdx.x * pstride + bid] = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_match_pl(const IcpDeviceState* __restrict__ st, PoseArg Targ, float thr_arg,
+                                                     const MatchK* __restrict__ kp, const float* __restrict__ lx,
+                                                     const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                     MapView map, float4* __restrict__ pl_c, float4* __restrict__ pl_n,
+                                                     double* __restrict__ partials, uint32_t pstride) {
+  __shared__ double lds[kBlock / 64][kGenN];
+  const MatchK k = *kp;
+  double T[12];
+  float thr;
+  double kparam = 0.0;
+  if (FUSED) {
+    if (st->done) return;
+    const uint32_t it = st->iter;
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = st->T[i];
+    thr = (float)k.pl_thr[it];
+    kparam = k.kparam[it];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = Targ.m[i];
+    thr = thr_arg;
+  }
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  double v[kGenN];
+#pragma unroll
+  for (int j = 0; j < kGenN; j++) v[j] = 0.0;
+  if (i < n) {
+    const float x = lx[i], y = ly[i], z = lz[i];
+    float px, py, pz;
+    transform_point(T, x, y, z, px, py, pz);
+    const float lim = 1.0e6f;
+    const bool valid = isfinite(px) && isfinite(py) && isfinite(pz) && fabsf(px * map.inv_vs) < lim &&
+                       fabsf(py * map.inv_vs) < lim && fabsf(pz * map.inv_vs) < lim;
+    float best = __builtin_inff();
+    uint32_t best_first = 0;
+    f32x4 bc = (f32x4)(0.f);
+    if (valid) {
+      const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(map.slots);
+      const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(map.pts);
+      const unsigned long long kbase = pack_key(voxel_of(px, map.inv_vs, map.trunc) - 1, voxel_of(py, map.inv_vs, map.trunc) - 1,
+                                                voxel_of(pz, map.inv_vs, map.trunc) - 1);
+#pragma unroll 1
+      for (int ix = 0; ix < 3; ix++) {  // x outer: scan order is preserved for the first-minimum rule
+        u32x4 sl[9];
+        uint32_t first[9];
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+          const unsigned long long key = kbase + ((unsigned long long)ix << 42) + ((unsigned long long)(c / 3) << 21) + (unsigned long long)(c % 3);
+          sl[c] = slots4[hash_key(key) & map.mask];
+        }
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+          const unsigned long long key = kbase + ((unsigned long long)ix << 42) + ((unsigned long long)(c / 3) << 21) + (unsigned long long)(c % 3);
+          unsigned long long sk = ((unsigned long long)sl[c].y << 32) | sl[c].x;
+          if (sk != key && sk != kEmptyKey) {
+            uint32_t h = hash_key(key) & map.mask;
+            do {
+              h = (h + 1) & map.mask;
+              sl[c] = slots4[h];
+              sk = ((unsigned long long)sl[c].y << 32) | sl[c].x;
+            } while (sk != key && sk != kEmptyKey);
+          }
+          first[c] = (sk == key) ? sl[c].z : 0u;  // 0 = absent (a present voxel has first >= 2)
+        }
+        f32x4 cen[9];
+#pragma unroll
+        for (int c = 0; c < 9; c++) cen[c] = pts4[first[c] >= 2u ? first[c] - 2u : 0u];  // unconditional, clamped
+#pragma unroll
+        for (int c = 0; c < 9; c++)
+          if (first[c] >= 2u && cen[c].w != 0.f) {
+            const float dx = cen[c].x - px, dy = cen[c].y - py, dz = cen[c].z - pz;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < best) { best = d2; best_first = first[c]; bc = cen[c]; }
+          }
+      }
+    }
+    bool ok = false;
+    f32x4 bn = (f32x4)(0.f);
+    if (best_first >= 2u) {
+      bn = reinterpret_cast<const f32x4*>(map.pts)[best_first - 1u];
+      const float dx = px - bc.x, dy = py - bc.y, dz = pz - bc.z;
+      const float e = (bn.x * dx + bn.y * dy) + bn.z * dz;
+      ok = fabsf(e) < thr;
+    }
+    const float4 c4 = make_float4(bc.x, bc.y, bc.z, ok ? 1.f : 0.f), n4 = make_float4(bn.x, bn.y, bn.z, 0.f);
+    pl_c[i] = c4;
+    pl_n[i] = n4;
+    if (FUSED && ok) acc_pt2pl_rows(v, T, x, y, z, c4, n4, k.kernel, kparam, k.w_pt2pl);
+  }
+  if (FUSED) block_reduce_rows<kGenN>(v, lds, partials, pstride, blockIdx.x);
+}
+
+// inner Gauss-Newton steps >= 1 on the stored point-to-plane pairings
+__global__ __launch_bounds__(kBlock) void k_accum_plbuf(const IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
+                                                        const float* __restrict__ lx, const float* __restrict__ ly,
+                                                        const float* __restrict__ lz, uint32_t n,
+                                                        const float4* __restrict__ pl_c, const float4* __restrict__ pl_n,
+                                                        double* __restrict__ partials, uint32_t pstride) {
+  __shared__ double lds[kBlock / 64][kGenN];
+  if (st->done || st->inner == 0) return;
+  const MatchK k = *kp;
+  double T[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) T[i] = st->T[i];
+  const double kparam = k.kparam[st->iter];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  double v[kGenN];
+#pragma unroll
+  for (int j = 0; j < kGenN; j++) v[j] = 0.0;
+  if (i < n) {
+    const float4 c = pl_c[i];
+    if (c.w != 0.f) acc_pt2pl_rows(v, T, lx[i], ly[i], lz[i], c, pl_n[i], k.kernel, kparam, k.w_pt2pl);
+  }
+  block_reduce_rows<kGenN>(v, lds, partials, pstride, blockIdx.x);
+}
+
 constexpr int kSolveThreads = 512;  // 2 waves per SIMD -> 256 VGPRs for the serial 6x6 code of thread 0
 
 // Ordered sum of `nvals` rows of a [nvals][stride] array of per-block partials over n blocks, by the
@@ -606,6 +772,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restr
   const uint32_t n_pairs = (uint32_t)(a[17] + gen[28] + 0.5);
   if (inner == 0) {
     st->n_pairs = n_pairs;
+    st->n_pairs_pl = (uint32_t)(gen[28] + 0.5);
     if (n_pairs == 0) {  // ICP::align: "if (pairings.empty()) NoPairings; break"
       st->term_reason = MH_TERM_NO_PAIRINGS;
       st->n_iterations = it;
@@ -842,6 +1009,43 @@ __global__ __launch_bounds__(kBlock) void k_cov_accum_pl(const IcpDeviceState* _
         ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
 }
 
+// covariance rows of the stored point-to-plane pairings (fused path)
+__global__ __launch_bounds__(kBlock) void k_cov_accum_plbuf(const IcpDeviceState* __restrict__ st,
+                                                            const float* __restrict__ lx, const float* __restrict__ ly,
+                                                            const float* __restrict__ lz, uint32_t n,
+                                                            const float4* __restrict__ pl_c, const float4* __restrict__ pl_n,
+                                                            double* __restrict__ partials, uint32_t pstride) {
+  __shared__ double sD[72];
+  __shared__ double lds[kBlock / 64][kCovN];
+  if (!st->done || st->cov_done) return;
+  if (threadIdx.x < 72) sD[threadIdx.x] = st->covD[threadIdx.x];
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  double v[kCovN];
+#pragma unroll
+  for (int j = 0; j < kCovN; j++) v[j] = 0.0;
+  if (i < n && pl_c[i].w != 0.f) {
+    const double x = lx[i], y = ly[i], z = lz[i];
+    const float4 nn = pl_n[i];
+    double A[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      double r[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+        r[q] = sD[j * 12 + q * 4] * x + sD[j * 12 + q * 4 + 1] * y + sD[j * 12 + q * 4 + 2] * z + sD[j * 12 + q * 4 + 3];
+      A[j] = (double)nn.x * r[0] + (double)nn.y * r[1] + (double)nn.z * r[2];
+    }
+    int q = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = a; b < 6; b++) v[q++] = A[a] * A[b];
+    v[21] = 1.0;
+  }
+  block_reduce_rows<kCovN>(v, lds, partials, pstride, blockIdx.x);
+}
+
 __global__ __launch_bounds__(kSolveThreads) void k_cov_finalize(IcpDeviceState* __restrict__ st, uint32_t force,
                                                                 const double* __restrict__ partA, uint32_t nA,
                                                                 uint32_t strideA, const double* __restrict__ partB,
@@ -939,6 +1143,37 @@ __global__ __launch_bounds__(kBlock) void k_compact(const uint32_t* __restrict__
   if (o_d2) o_d2[pos] = q.w;
 }
 
+// point-to-plane pairings: flags + compaction in ascending local index
+__global__ void k_pl_flags(const float4* __restrict__ pl_c, uint32_t n, uint32_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = pl_c[i].w != 0.f ? i : kNoMatch;
+}
+__global__ __launch_bounds__(kBlock) void k_compact_pl(const uint32_t* __restrict__ flags, const float4* __restrict__ pl_c,
+                                                       const float4* __restrict__ pl_n, uint32_t n,
+                                                       const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ o_li,
+                                                       float* __restrict__ o_cx, float* __restrict__ o_cy,
+                                                       float* __restrict__ o_cz, float* __restrict__ o_nx,
+                                                       float* __restrict__ o_ny, float* __restrict__ o_nz) {
+  __shared__ uint32_t wc[kBlock / 64];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const bool v = i < n && flags[i] != kNoMatch;
+  const unsigned long long m = __ballot(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wc[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (!v) return;
+  uint32_t pos = block_offsets[blockIdx.x] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; w++) pos += wc[w];
+  const float4 c = pl_c[i], nn = pl_n[i];
+  if (o_li) o_li[pos] = i;
+  if (o_cx) o_cx[pos] = c.x;
+  if (o_cy) o_cy[pos] = c.y;
+  if (o_cz) o_cz[pos] = c.z;
+  if (o_nx) o_nx[pos] = nn.x;
+  if (o_ny) o_ny[pos] = nn.y;
+  if (o_nz) o_nz[pos] = nn.z;
+}
+
 // dense outputs of the un-compacted search
 __global__ void k_unpack_dense(const uint32_t* __restrict__ gidx, const float4* __restrict__ pq, uint32_t n,
                                uint32_t* __restrict__ o_gi, float* __restrict__ o_x, float* __restrict__ o_y,
@@ -993,6 +1228,14 @@ mh_status ensure_pair_buffers(mh_ctx* ctx, size_t n) {
   MH_TRY(ctx->pair_gidx.reserve(nn * sizeof(uint32_t)));
   const size_t nb = nblk(nn);
   MH_TRY(ctx->partials.reserve((size_t)kGenN * nb * sizeof(double)));
+  return MH_OK;
+}
+
+mh_status ensure_pl_buffers(mh_ctx* ctx, size_t n) {
+  const size_t nn = n ? n : 1;
+  MH_TRY(ctx->pl_c.reserve(nn * sizeof(float4)));
+  MH_TRY(ctx->pl_n.reserve(nn * sizeof(float4)));
+  MH_TRY(ctx->partials_b.reserve((size_t)kGenN * nblk(nn) * sizeof(double)));
   return MH_OK;
 }
 
@@ -1084,15 +1327,17 @@ struct AlignJob {
   int variant = 0;
   bool finished = false, trivial = false;
   bool prof = false;  // time this job's match kernels with events (then it cannot use the graph path)
+  bool pl = false;    // Matcher_Point2Plane runs before the point matcher (lidar3d-ndt.yaml:195-210)
 
   mh_status start(const mh_map* m, const mh_scan* sc, const mh_icp_params* prm, const double* T0, const mh_prior* prior,
                   mh_icp_result* r, mh_icp_iter* tr, size_t batch_index = 0) {
     map = m; scan = sc; ctx = sc->ctx; p = prm; res = r; trace = tr;
     prof = prm->profile == 1 || (prm->profile == 2 && batch_index == 0);
+    pl = prm->pt2pl_threshold != nullptr;
     memset(res, 0, sizeof(*res));
     for (int i = 0; i < 12; i++) res->T[i] = T0[i];
     for (int i = 0; i < 6; i++) res->cov[i * 7] = 1e6;
-    res->potential_pairings = scan->n;
+    res->potential_pairings = scan->n * (pl ? 2u : 1u);  // every matcher adds its layer size (App.B U6)
     if (p->max_iterations == 0 || scan->n == 0) {
       // ICP::align with nothing to iterate on: no pairings, quality 0, cov = diag(1e6)
       res->termination_reason = p->max_iterations == 0 ? MH_TERM_MAX_ITERATIONS : MH_TERM_NO_PAIRINGS;
@@ -1104,9 +1349,17 @@ struct AlignJob {
     MH_TRY(ensure_pair_buffers(ctx, scan->n));
     hipStream_t s = ctx->stream;
     const size_t mi = p->max_iterations;
-    MH_TRY(ctx->sched.reserve(2 * mi * sizeof(double)));
+    if (pl) {
+      if (!map->view().ndt)
+        return fail(MH_ERR_INVALID_ARGUMENT, "pt2pl_threshold given but the map carries no NDT statistics "
+                                             "(build it with ndt_max_eigen_ratio > 0)");
+      MH_TRY(ensure_pl_buffers(ctx, scan->n));
+    }
+    MH_TRY(ctx->sched.reserve(3 * mi * sizeof(double)));
     MH_HIP(hipMemcpyAsync(ctx->sched.p, p->threshold, mi * sizeof(double), hipMemcpyHostToDevice, s));
     MH_HIP(hipMemcpyAsync(ctx->sched.as<double>() + mi, p->kernel_param, mi * sizeof(double), hipMemcpyHostToDevice, s));
+    if (pl)
+      MH_HIP(hipMemcpyAsync(ctx->sched.as<double>() + 2 * mi, p->pt2pl_threshold, mi * sizeof(double), hipMemcpyHostToDevice, s));
     if (trace) MH_TRY(ctx->trace.reserve(mi * sizeof(mh_icp_iter)));
     init_state(ctx->h_state, T0);
     MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpDeviceState), hipMemcpyHostToDevice, s));
@@ -1117,6 +1370,8 @@ struct AlignJob {
     mk.ang2 = (float)(ang * ang);
     mk.kernel = p->gn.robust_kernel;
     mk.w_pt2pt = p->gn.weight_pt2pt;
+    mk.w_pt2pl = p->gn.weight_pt2pl;
+    mk.pl_thr = pl ? ctx->sched.as<double>() + 2 * mi : nullptr;
     memset(&sk, 0, sizeof(sk));
     sk.max_iterations = p->max_iterations;
     sk.disable_stall = p->disable_stall_test;
@@ -1149,6 +1404,7 @@ struct AlignJob {
       variant = 0;
       if (e && e[0] == 'x') variant = 1;
       if (e && e[0] == 'r') variant = 2;
+      if (map->view().ndt) variant = 0;  // NDT records are interleaved with the points: no contiguous z-runs
     }
     nbm = variant == 2 ? (uint32_t)((scan->n + 4 * kQPW - 1) / (4 * kQPW)) : nb;
     MH_TRY(ctx->partials.reserve((size_t)kGenN * (nbm > nb ? nbm : nb) * sizeof(double)));
@@ -1184,7 +1440,12 @@ struct AlignJob {
     const SolveK* dsk = &ctx->d_params->sk;
     // everything a chunk launches, in stream order; used directly (profiling / MH_NO_GRAPH) or under stream capture
     auto enqueue_kernels = [&]() -> mh_status {
+      double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
+      const uint32_t nB = pl ? nb : 0u;
       for (uint32_t j = 0; j < m; j++) {
+        if (pl)
+          hipLaunchKernelGGL(k_match_pl<true>, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, dmk, scan->x, scan->y,
+                             scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
         if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n], s));
         if (variant == 2)
           hipLaunchKernelGGL(k_matchr<true>, dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x, scan->y,
@@ -1200,20 +1461,26 @@ struct AlignJob {
           prof_n++;
         }
         hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nbm, nbm,
-                           (const double*)nullptr, 0u, 0u);
+                           (const double*)partb, nB, nB);
         for (uint32_t in = 1; in < p->gn.max_inner_iterations; in++) {
           hipLaunchKernelGGL(k_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nb);
+          if (pl)
+            hipLaunchKernelGGL(k_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dmk, scan->x, scan->y, scan->z, n,
+                               ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
           hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nb, nb,
-                             (const double*)nullptr, 0u, 0u);
+                             (const double*)partb, nB, nB);
         }
       }
       if (p->compute_covariance) {  // no-ops unless the loop has terminated
         hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, dsk, 0u);
         hipLaunchKernelGGL(k_cov_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, scan->x, scan->y, scan->z, n,
                            ctx->pair_gidx.as<uint32_t>(), part, nb);
+        if (pl)
+          hipLaunchKernelGGL(k_cov_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, scan->x, scan->y, scan->z, n,
+                             ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
         hipLaunchKernelGGL(k_cov_finalize, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, 0u, part, nb, nb,
-                           (const double*)nullptr, 0u, 0u);
+                           (const double*)partb, nB, nB);
       }
       MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
       return MH_OK;
@@ -1234,7 +1501,9 @@ struct AlignJob {
                                        (unsigned long long)scan->z, (unsigned long long)ctx->pair_q.p,
                                        (unsigned long long)ctx->pair_gidx.p, (unsigned long long)part,
                                        (unsigned long long)ctx->d_state, (unsigned long long)ctx->d_params,
-                                       (unsigned long long)ctx->h_state, 1ull};
+                                       (unsigned long long)ctx->h_state, pl ? 2ull : 1ull,
+                                       (unsigned long long)(pl ? ctx->pl_c.p : nullptr),
+                                       (unsigned long long)(pl ? ctx->partials_b.p : nullptr)};
       static_assert(sizeof(kv) <= sizeof(key), "graph key too small");
       memcpy(key, kv, sizeof(kv));
       if (!ctx->graph_exec || memcmp(key, ctx->graph_key, sizeof(key)) != 0) {
@@ -1282,8 +1551,9 @@ struct AlignJob {
     res->n_iterations = h->n_iterations;
     res->termination_reason = h->term_reason;
     res->n_final_pairs = h->n_pairs;
-    res->potential_pairings = scan->n;
-    res->quality = (h->n_pairs && scan->n) ? (double)h->n_pairs / (double)scan->n : 0.0;  // PairedRatio
+    res->n_final_pairs_pt2pl = pl ? h->n_pairs_pl : 0u;
+    res->potential_pairings = scan->n * (pl ? 2u : 1u);
+    res->quality = (h->n_pairs && scan->n) ? (double)h->n_pairs / (double)res->potential_pairings : 0.0;  // PairedRatio
     if (h->term_reason == MH_TERM_NO_PAIRINGS)
       for (int i = 0; i < 36; i++) res->cov[i] = (i % 7 == 0) ? 1e6 : 0.0;
     if (trace) {
@@ -1339,10 +1609,10 @@ mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_icp_para
     MH_TRY(job.enqueue_chunk());
     MH_TRY(job.poll());
   }
-  if (final_pairs && !job.trivial && result->n_final_pairs) {
+  if (final_pairs && !job.trivial && result->n_final_pairs > result->n_final_pairs_pt2pl) {
     uint64_t np = 0;
     MH_TRY(compact_pairs(scan->ctx, scan->n, final_pairs, pairs_mem, &np));
-    if (np != result->n_final_pairs) return fail(MH_ERR_INTERNAL, "pair compaction count mismatch");
+    if (np != result->n_final_pairs - result->n_final_pairs_pt2pl) return fail(MH_ERR_INTERNAL, "pair compaction count mismatch");
   }
   return MH_OK;
 }
@@ -1451,6 +1721,83 @@ mh_status mh_nn_search_dense(const mh_map* map, const mh_scan* scan, const doubl
     if (d2) MH_HIP(hipMemcpy(d2, o_d2, n * 4, hipMemcpyDeviceToHost));
   }
   return MH_OK;
+}
+
+// compaction of the context's point-to-plane pairing buffers into caller arrays
+static mh_status compact_pl_pairs(mh_ctx* ctx, size_t n, const mh_pairs_pl_out* out, int32_t mem, uint64_t* n_pairs_out) {
+  hipStream_t s = ctx->stream;
+  const uint32_t nb = nblk(n);
+  const size_t n4 = ((n + 63) / 64) * 64;
+  // layout: flags[n4] | counts[nb] | offsets[nb] | total[1] | (host staging) li,cx,cy,cz,nx,ny,nz [n4 each]
+  const size_t hdr = ((n4 + (size_t)2 * nb + 1) * 4 + 255) / 256 * 256;
+  MH_TRY(ctx->compact.reserve(hdr + 7 * n4 * 4));
+  uint32_t* flags = ctx->compact.as<uint32_t>();
+  uint32_t* counts = flags + n4;
+  uint32_t* offsets = counts + nb;
+  uint32_t* total = offsets + nb;
+  char* stage = ctx->compact.as<char>() + hdr;
+  void* o[7] = {out->local_idx, out->cx, out->cy, out->cz, out->nx, out->ny, out->nz};
+  void* d[7];
+  for (int a = 0; a < 7; a++) d[a] = (mem == MH_MEM_DEVICE) ? o[a] : (o[a] ? (void*)(stage + (size_t)a * n4 * 4) : nullptr);
+  uint32_t h_total = 0;
+  if (n) {
+    hipLaunchKernelGGL(k_pl_flags, dim3(nb), dim3(kBlock), 0, s, ctx->pl_c.as<float4>(), (uint32_t)n, flags);
+    hipLaunchKernelGGL(k_count_valid, dim3(nb), dim3(kBlock), 0, s, flags, (uint32_t)n, counts);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, counts, nb, offsets, total);
+    hipLaunchKernelGGL(k_compact_pl, dim3(nb), dim3(kBlock), 0, s, flags, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(),
+                       (uint32_t)n, offsets, (uint32_t*)d[0], (float*)d[1], (float*)d[2], (float*)d[3], (float*)d[4],
+                       (float*)d[5], (float*)d[6]);
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipMemcpyAsync(&h_total, total, 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+  }
+  if (mem == MH_MEM_HOST && h_total)
+    for (int a = 0; a < 7; a++)
+      if (o[a]) MH_HIP(hipMemcpy(o[a], d[a], (size_t)h_total * 4, hipMemcpyDeviceToHost));
+  if (n_pairs_out) *n_pairs_out = h_total;
+  return MH_OK;
+}
+
+mh_status mh_nn_search_pt2pl(const mh_map* map, const mh_scan* scan, const double T[12], double distance_threshold,
+                             const mh_pairs_pl_out* out, int32_t mem, mh_match_info* info) {
+  MH_REQUIRE(map && scan && T, "null argument");
+  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
+  MH_REQUIRE(map->ctx->device == scan->ctx->device, "map and scan live on different devices");
+  MH_REQUIRE(pose_ok(T), "non-finite pose");
+  MH_REQUIRE(map->view().ndt, "the map carries no NDT statistics (build it with ndt_max_eigen_ratio > 0)");
+  mh_ctx* ctx = scan->ctx;
+  MH_TRY(set_device(ctx));
+  if (info) {
+    info->n_pairs = 0;
+    info->potential_pairings = scan->n;
+  }
+  if (scan->n == 0) return MH_OK;
+  MH_TRY(ensure_state(ctx));
+  MH_TRY(ensure_pl_buffers(ctx, scan->n));
+  PoseArg Ta;
+  for (int i = 0; i < 12; i++) Ta.m[i] = T[i];
+  MatchK mk{};
+  SolveK sk0{};
+  MH_TRY(upload_params(ctx, mk, sk0));
+  hipLaunchKernelGGL(k_match_pl<false>, dim3(nblk(scan->n)), dim3(kBlock), 0, ctx->stream, ctx->d_state, Ta,
+                     (float)distance_threshold, &ctx->d_params->mk, scan->x, scan->y, scan->z, (uint32_t)scan->n, map->view(),
+                     ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), (double*)nullptr, 0u);
+  MH_HIP(hipGetLastError());
+  mh_pairs_pl_out none{};
+  uint64_t np = 0;
+  MH_TRY(compact_pl_pairs(ctx, scan->n, out ? out : &none, mem, &np));
+  if (info) info->n_pairs = np;
+  return MH_OK;
+}
+
+mh_status mh_icp_get_pt2pl_pairs(const mh_scan* scan, const mh_pairs_pl_out* out, int32_t mem, uint64_t* n_pairs) {
+  MH_REQUIRE(scan && out, "null argument");
+  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
+  mh_ctx* ctx = scan->ctx;
+  MH_TRY(set_device(ctx));
+  if (n_pairs) *n_pairs = 0;
+  if (scan->n == 0 || !ctx->pl_c.p || ctx->pl_c.bytes < scan->n * sizeof(float4)) return MH_OK;  // no pt2pl matcher has run
+  return compact_pl_pairs(ctx, scan->n, out, mem, n_pairs);
 }
 
 // ---- solver-granular entry points ---------------------------------------------------------------

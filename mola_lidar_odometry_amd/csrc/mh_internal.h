@@ -77,6 +77,7 @@ struct MapView {
   uint32_t mask;      // table_size - 1
   float inv_vs;
   uint32_t trunc;     // index_mode == MH_INDEX_TRUNC
+  uint32_t ndt;       // 1: every voxel's points are preceded by two records {centroid, plane flag} {normal, 0}
 };
 
 __host__ __device__ inline unsigned long long pack_key(int kx, int ky, int kz) {
@@ -106,6 +107,7 @@ struct mh_ctx {
   // scratch (grow-only), all on `device`
   mh::DevBuf pair_q;      // float4 per scan point: NN point xyz + d2
   mh::DevBuf pair_gidx;   // uint32 per scan point: source index or 0xFFFFFFFF
+  mh::DevBuf pl_c, pl_n;  // float4 per scan point: point-to-plane pairing {centroid, valid flag} {normal, 0}
   mh::DevBuf partials;    // per-block reduction partials (double)
   mh::DevBuf partials_b;  // generic (pt2pl) partials
   mh::DevBuf sched;       // threshold / kernel-param arrays (double)
@@ -136,7 +138,7 @@ struct mh_map {
   mh::DevBuf vox_keys;   // uint64[n_voxels], ascending
   mh::DevBuf vox_first;  // uint32[n_voxels]
   mh::DevBuf vox_count;  // uint32[n_voxels]
-  uint64_t n_points = 0, n_offered = 0, n_voxels = 0, table_size = 0;
+  uint64_t n_points = 0, n_offered = 0, n_voxels = 0, table_size = 0, n_records = 0, n_planes = 0;
   float bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
   mh::MapView view() const {
     mh::MapView v;
@@ -145,6 +147,7 @@ struct mh_map {
     v.mask = (uint32_t)(table_size ? table_size - 1 : 0);
     v.inv_vs = inv_vs;
     v.trunc = params.index_mode == MH_INDEX_TRUNC;
+    v.ndt = params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
     return v;
   }
 };

@@ -76,6 +76,114 @@ __global__ void k_keep(const unsigned long long* __restrict__ ks, const uint32_t
   keep[i] = k;
 }
 
+// insertPoint with min_distance_between_points > 0 is order dependent inside a voxel (a point is dropped when it is
+// closer than that to an ALREADY STORED point of its voxel, lidar3d-ndt.yaml:244): one thread walks each voxel run.
+__global__ void k_keep_seq(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                           const unsigned long long* __restrict__ ks, const uint32_t* __restrict__ idx_s,
+                           const uint32_t* __restrict__ head, uint32_t n, uint32_t cap, float min_dist,
+                           uint32_t* __restrict__ keep) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = ks[i];
+  if (k == kEmptyKey) { keep[i] = 0; return; }
+  if (!head[i]) return;  // the head thread of the run decides for the whole voxel
+  const float md2 = min_dist * min_dist;
+  uint32_t kept = 0;
+  for (uint32_t j = i; j < n && ks[j] == k; j++) {
+    uint32_t ok = (cap == 0 || kept < cap) ? 1u : 0u;
+    if (ok) {
+      const uint32_t sj = idx_s[j];
+      const float px = x[sj], py = y[sj], pz = z[sj];
+      for (uint32_t q = i; q < j && ok; q++)
+        if (keep[q]) {
+          const uint32_t sq = idx_s[q];
+          const float dx = x[sq] - px, dy = y[sq] - py, dz = z[sq] - pz;
+          if (((dx * dx + dy * dy) + dz * dz) < md2) ok = 0;
+        }
+    }
+    keep[j] = ok;
+    kept += ok;
+  }
+}
+
+__global__ void k_add_ndt_slots(const uint32_t* __restrict__ head, uint32_t n, uint32_t* __restrict__ keep_plus) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && head[i]) keep_plus[i] += 2u;  // two NDT records in front of the voxel's points
+}
+
+// mola::NDT [U] voxel statistics (SURVEY 8a row a13, App.B U10): mean, covariance 1/(n-1), cyclic Jacobi (fp64, the
+// same operation sequence as the CPU restatement), plane iff lambda_min/lambda_max < ratio, normal = eigenvector of
+// lambda_min with its largest component positive.  Records: pts[first-2] = {centroid, plane flag}, pts[first-1] = {normal, 0}.
+__global__ void k_ndt_stats(float4* __restrict__ pts, const uint32_t* __restrict__ vox_first,
+                            const uint32_t* __restrict__ vox_count, uint32_t n_vox, float max_ratio, uint32_t min_pts,
+                            uint32_t* __restrict__ n_planes) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n_vox) return;
+  const uint32_t first = vox_first[v], cnt = vox_count[v];
+  float4 rc = make_float4(0.f, 0.f, 0.f, 0.f), rn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cnt >= min_pts) {
+    double mu[3] = {0.0, 0.0, 0.0};
+    for (uint32_t j = 0; j < cnt; j++) {
+      const float4 p = pts[first + j];
+      mu[0] += (double)p.x; mu[1] += (double)p.y; mu[2] += (double)p.z;
+    }
+    mu[0] /= (double)cnt; mu[1] /= (double)cnt; mu[2] /= (double)cnt;
+    double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+    for (uint32_t j = 0; j < cnt; j++) {
+      const float4 p = pts[first + j];
+      const double d0 = (double)p.x - mu[0], d1 = (double)p.y - mu[1], d2 = (double)p.z - mu[2];
+      c00 += d0 * d0; c01 += d0 * d1; c02 += d0 * d2; c11 += d1 * d1; c12 += d1 * d2; c22 += d2 * d2;
+    }
+    const double inv = (double)(cnt - 1);
+    double a[3][3] = {{c00 / inv, c01 / inv, c02 / inv}, {c01 / inv, c11 / inv, c12 / inv}, {c02 / inv, c12 / inv, c22 / inv}};
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 12; sweep++) {
+#pragma unroll
+      for (int pq = 0; pq < 3; pq++) {
+        const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2, r = 3 - p - q;
+        const double apq = a[p][q];
+        if (apq != 0.0) {
+          const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+          const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+          const double app = a[p][p] - t * apq, aqq = a[q][q] + t * apq;
+          const double arp = c * a[r][p] - sn * a[r][q], arq = sn * a[r][p] + c * a[r][q];
+          a[p][p] = app; a[q][q] = aqq; a[p][q] = 0.0; a[q][p] = 0.0;
+          a[r][p] = arp; a[p][r] = arp; a[r][q] = arq; a[q][r] = arq;
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            const double vip = c * V[i][p] - sn * V[i][q], viq = sn * V[i][p] + c * V[i][q];
+            V[i][p] = vip; V[i][q] = viq;
+          }
+        }
+      }
+    }
+    // smallest / largest eigenvalue and the eigenvector of the smallest (stable selection: first minimum)
+    const double w0 = a[0][0], w1 = a[1][1], w2 = a[2][2];
+    int imin = 0;
+    double wmin = w0, wmax = w0;
+    if (w1 < wmin) { wmin = w1; imin = 1; }
+    if (w2 < wmin) { wmin = w2; imin = 2; }
+    if (w1 > wmax) wmax = w1;
+    if (w2 > wmax) wmax = w2;
+    rc = make_float4((float)mu[0], (float)mu[1], (float)mu[2], 0.f);
+    if (wmax > 0.0 && (wmin / wmax) < (double)max_ratio) {
+      double nv[3] = {imin == 0 ? V[0][0] : (imin == 1 ? V[0][1] : V[0][2]), imin == 0 ? V[1][0] : (imin == 1 ? V[1][1] : V[1][2]),
+                      imin == 0 ? V[2][0] : (imin == 1 ? V[2][1] : V[2][2])};
+      const double len = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+      int big = 0;
+      if (fabs(nv[1]) > fabs(nv[big])) big = 1;
+      if (fabs(nv[2]) > fabs(nv[big])) big = 2;
+      const double sgn = ((big == 0 ? nv[0] : (big == 1 ? nv[1] : nv[2])) < 0.0 ? -1.0 : 1.0) / len;
+      rn = make_float4((float)(nv[0] * sgn), (float)(nv[1] * sgn), (float)(nv[2] * sgn), 0.f);
+      rc.w = 1.f;
+      atomicAdd(n_planes, 1u);
+    }
+  }
+  pts[first - 2] = rc;
+  pts[first - 1] = rn;
+}
+
 __device__ __forceinline__ uint32_t f2ord(float f) {
   const uint32_t u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -94,23 +202,25 @@ __global__ void k_scatter(const float* __restrict__ x, const float* __restrict__
                           const uint32_t* __restrict__ outpos, uint32_t n, uint32_t cap,
                           const uint32_t* __restrict__ counters, uint32_t n_vox, float4* __restrict__ pts,
                           unsigned long long* __restrict__ vox_keys, uint32_t* __restrict__ vox_first,
-                          uint32_t* __restrict__ vox_count, uint32_t* __restrict__ bbox /*6 ordered uints*/) {
+                          uint32_t* __restrict__ vox_count, uint32_t* __restrict__ bbox /*6 ordered uints*/,
+                          uint32_t ndt) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   float px = 0, py = 0, pz = 0;
   bool kept = false;
-  if (i < n && keep[i]) {
+  if (i < n && (keep[i] & 1u)) {  // bit 0 = point kept (head elements of NDT maps carry +2 for their two records)
     kept = true;
     const uint32_t src = idx_s[i];
     px = x[src]; py = y[src]; pz = z[src];
-    pts[outpos[i]] = make_float4(px, py, pz, __uint_as_float(src));
+    const uint32_t pos = outpos[i] + ((ndt && head[i]) ? 2u : 0u);
+    pts[pos] = make_float4(px, py, pz, __uint_as_float(src));
     if (head[i]) {
+      // stored points of this voxel = records between this head and the next one, minus the two NDT records
       const uint32_t v = vid1[i] - 1;
-      const uint32_t n_valid = counters[1];
-      const uint32_t end = (v + 1 < n_vox) ? vstart[v + 1] : n_valid;
-      const uint32_t cnt = end - i;
+      const uint32_t total_records = outpos[n - 1] + keep[n - 1];
+      const uint32_t next = (v + 1 < n_vox) ? outpos[vstart[v + 1]] : total_records;
       vox_keys[v] = ks[i];
-      vox_first[v] = outpos[i];
-      vox_count[v] = (cap == 0 || cnt < cap) ? cnt : cap;
+      vox_first[v] = pos;
+      vox_count[v] = next - outpos[i] - (ndt ? 2u : 0u);
     }
   }
   // bounding box of the stored points: wave min/max, then one atomic per wave
@@ -157,6 +267,7 @@ mh_status mh_map_create(mh_ctx* ctx, const mh_map_params* params, mh_map** out) 
   *out = nullptr;
   MH_REQUIRE(params->voxel_size > 0.f && isfinite(params->voxel_size), "voxel_size must be > 0");
   MH_REQUIRE(params->index_mode == MH_INDEX_FLOOR || params->index_mode == MH_INDEX_TRUNC, "bad index_mode");
+  MH_REQUIRE(params->min_distance_between_points >= 0.f && params->ndt_max_eigen_ratio >= 0.f, "negative NDT parameter");
   mh_map* m = new (std::nothrow) mh_map();
   if (!m) return fail(MH_ERR_OUT_OF_MEMORY, "host allocation failed");
   m->ctx = ctx;
@@ -195,7 +306,7 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
   hipStream_t s = ctx->stream;
   MH_HIP(hipStreamSynchronize(s));  // a rebuild invalidates everything queued against the old content
 
-  uint32_t n_vox = 0, n_pts = 0;
+  uint32_t n_vox = 0, n_pts = 0, n_rec = 0;
   uint32_t h_counters[12] = {0};
   if (n > 0) {
     const float *dx = x, *dy = y, *dz = z;
@@ -248,8 +359,14 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
     tb = ctx->sort_tmp.bytes;
     MH_HIP(rocprim::inclusive_scan(ctx->sort_tmp.p, tb, head, vid1, N, rocprim::plus<uint32_t>(), s));
     hipLaunchKernelGGL(k_vstart, dim3(nblk(n, B)), dim3(B), 0, s, head, vid1, N, vstart);
-    hipLaunchKernelGGL(k_keep, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, vid1, vstart, N, m->params.max_points_per_voxel,
-                       keep);
+    const uint32_t ndt = m->params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
+    if (m->params.min_distance_between_points > 0.f)
+      hipLaunchKernelGGL(k_keep_seq, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, keys_s, idx_s, head, N,
+                         m->params.max_points_per_voxel, m->params.min_distance_between_points, keep);
+    else
+      hipLaunchKernelGGL(k_keep, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, vid1, vstart, N, m->params.max_points_per_voxel,
+                         keep);
+    if (ndt) hipLaunchKernelGGL(k_add_ndt_slots, dim3(nblk(n, B)), dim3(B), 0, s, head, N, keep);
     tb = ctx->sort_tmp.bytes;
     MH_HIP(rocprim::exclusive_scan(ctx->sort_tmp.p, tb, keep, outpos, 0u, N, rocprim::plus<uint32_t>(), s));
     // sizes back to the host
@@ -263,9 +380,10 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
       return fail(MH_ERR_OUT_OF_RANGE, "a point's voxel index exceeds the +-2^20 range of the packed key "
                                        "(|coord|/voxel_size must be < 1e6)");
     n_vox = h_last[0];
-    n_pts = h_last[1] + h_last[2];
+    n_rec = h_last[1] + h_last[2];
+    n_pts = n_rec - (ndt ? 2u * n_vox : 0u);
 
-    MH_TRY(m->pts.reserve((size_t)(n_pts ? n_pts : 1) * sizeof(float4)));
+    MH_TRY(m->pts.reserve((size_t)(n_rec ? n_rec : 1) * sizeof(float4)));
     MH_TRY(m->vox_keys.reserve((size_t)(n_vox ? n_vox : 1) * sizeof(unsigned long long)));
     MH_TRY(m->vox_first.reserve((size_t)(n_vox ? n_vox : 1) * sizeof(uint32_t)));
     MH_TRY(m->vox_count.reserve((size_t)(n_vox ? n_vox : 1) * sizeof(uint32_t)));
@@ -273,7 +391,11 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
       hipLaunchKernelGGL(k_scatter, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, keys_s, idx_s, head, vid1, vstart, keep,
                          outpos, N, m->params.max_points_per_voxel, counters, n_vox, m->pts.as<float4>(),
                          m->vox_keys.as<unsigned long long>(), m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(),
-                         counters + 2);
+                         counters + 2, ndt);
+      if (ndt)
+        hipLaunchKernelGGL(k_ndt_stats, dim3(nblk(n_vox, 128)), dim3(128), 0, s, m->pts.as<float4>(),
+                           m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(), n_vox, m->params.ndt_max_eigen_ratio,
+                           m->params.ndt_min_points ? m->params.ndt_min_points : 4u, counters + 8);
       MH_HIP(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, s));
     }
   }
@@ -289,6 +411,8 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
   MH_HIP(hipGetLastError());
   MH_HIP(hipStreamSynchronize(s));
   m->n_points = n_pts;
+  m->n_records = n_rec;
+  m->n_planes = n_pts ? h_counters[8] : 0;
   m->n_voxels = n_vox;
   m->n_offered = n;
   m->table_size = tsize;
@@ -311,6 +435,7 @@ mh_status mh_map_get_info(const mh_map* m, mh_map_info* info) {
   }
   info->voxel_size = m->params.voxel_size;
   info->max_points_per_voxel = m->params.max_points_per_voxel;
+  info->n_planes = m->n_planes;
   return MH_OK;
 }
 
@@ -320,30 +445,67 @@ mh_status mh_map_download(const mh_map* m, float* x, float* y, float* z, uint32_
   mh_ctx* ctx = m->ctx;
   MH_TRY(set_device(ctx));
   MH_HIP(hipStreamSynchronize(ctx->stream));
-  if (m->n_points && (x || y || z || src_idx)) {
-    std::vector<float4> h(m->n_points);
-    MH_HIP(hipMemcpy(h.data(), m->pts.p, m->n_points * sizeof(float4), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < m->n_points; i++) {
-      if (x) x[i] = h[i].x;
-      if (y) y[i] = h[i].y;
-      if (z) z[i] = h[i].z;
-      if (src_idx) memcpy(&src_idx[i], &h[i].w, 4);
+  if (!m->n_voxels) return MH_OK;
+  std::vector<uint32_t> hf(m->n_voxels), hc(m->n_voxels);
+  MH_HIP(hipMemcpy(hf.data(), m->vox_first.p, m->n_voxels * 4, hipMemcpyDeviceToHost));
+  MH_HIP(hipMemcpy(hc.data(), m->vox_count.p, m->n_voxels * 4, hipMemcpyDeviceToHost));
+  if (x || y || z || src_idx) {
+    std::vector<float4> h(m->n_records);
+    MH_HIP(hipMemcpy(h.data(), m->pts.p, m->n_records * sizeof(float4), hipMemcpyDeviceToHost));
+    size_t o = 0;
+    for (size_t v = 0; v < m->n_voxels; v++)  // NDT maps interleave two statistics records per voxel: skip them
+      for (uint32_t j = 0; j < hc[v]; j++, o++) {
+        const float4& p = h[hf[v] + j];
+        if (x) x[o] = p.x;
+        if (y) y[o] = p.y;
+        if (z) z[o] = p.z;
+        if (src_idx) memcpy(&src_idx[o], &p.w, 4);
+      }
+  }
+  if (vox_keys_xyz) {
+    std::vector<unsigned long long> k(m->n_voxels);
+    MH_HIP(hipMemcpy(k.data(), m->vox_keys.p, m->n_voxels * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t v = 0; v < m->n_voxels; v++) {
+      int kx, ky, kz;
+      unpack_key(k[v], kx, ky, kz);
+      vox_keys_xyz[3 * v] = kx;
+      vox_keys_xyz[3 * v + 1] = ky;
+      vox_keys_xyz[3 * v + 2] = kz;
     }
   }
-  if (m->n_voxels) {
-    if (vox_keys_xyz) {
-      std::vector<unsigned long long> k(m->n_voxels);
-      MH_HIP(hipMemcpy(k.data(), m->vox_keys.p, m->n_voxels * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-      for (size_t v = 0; v < m->n_voxels; v++) {
-        int kx, ky, kz;
-        unpack_key(k[v], kx, ky, kz);
-        vox_keys_xyz[3 * v] = kx;
-        vox_keys_xyz[3 * v + 1] = ky;
-        vox_keys_xyz[3 * v + 2] = kz;
-      }
-    }
-    if (vox_first) MH_HIP(hipMemcpy(vox_first, m->vox_first.p, m->n_voxels * 4, hipMemcpyDeviceToHost));
-    if (vox_count) MH_HIP(hipMemcpy(vox_count, m->vox_count.p, m->n_voxels * 4, hipMemcpyDeviceToHost));
+  size_t o = 0;
+  for (size_t v = 0; v < m->n_voxels; v++) {  // offsets in the point-only numbering of the arrays above
+    if (vox_first) vox_first[v] = (uint32_t)o;
+    if (vox_count) vox_count[v] = hc[v];
+    o += hc[v];
+  }
+  return MH_OK;
+}
+
+mh_status mh_map_download_ndt(const mh_map* m, float* cx, float* cy, float* cz, float* nx, float* ny, float* nz,
+                              uint32_t* is_plane) {
+  MH_REQUIRE(m, "null map");
+  mh_ctx* ctx = m->ctx;
+  MH_TRY(set_device(ctx));
+  MH_HIP(hipStreamSynchronize(ctx->stream));
+  if (!m->n_voxels) return MH_OK;
+  const bool ndt = m->params.ndt_max_eigen_ratio > 0.f;
+  std::vector<uint32_t> hf(m->n_voxels);
+  std::vector<float4> h;
+  if (ndt) {
+    MH_HIP(hipMemcpy(hf.data(), m->vox_first.p, m->n_voxels * 4, hipMemcpyDeviceToHost));
+    h.resize(m->n_records);
+    MH_HIP(hipMemcpy(h.data(), m->pts.p, m->n_records * sizeof(float4), hipMemcpyDeviceToHost));
+  }
+  for (size_t v = 0; v < m->n_voxels; v++) {
+    const float4 c = ndt ? h[hf[v] - 2] : make_float4(0, 0, 0, 0), nn = ndt ? h[hf[v] - 1] : make_float4(0, 0, 0, 0);
+    if (cx) cx[v] = c.x;
+    if (cy) cy[v] = c.y;
+    if (cz) cz[v] = c.z;
+    if (nx) nx[v] = nn.x;
+    if (ny) ny[v] = nn.y;
+    if (nz) nz[v] = nn.z;
+    if (is_plane) is_plane[v] = c.w != 0.f ? 1u : 0u;
   }
   return MH_OK;
 }

@@ -86,6 +86,77 @@ def test_map_build_from_device_pointers(ctx, oracle):
     assert_maps_equal(g.download(), oracle.Map(1.0, 20).insert(pts).dump())
 
 
+def _ndt_cloud(seed=0):
+    rng = np.random.default_rng(seed)
+    ground = np.stack([rng.uniform(-10, 10, 20000), rng.uniform(-10, 10, 20000), rng.normal(0.3, 0.01, 20000)], 1)
+    wall = np.stack([rng.uniform(-10, 10, 12000), rng.normal(5.4, 0.01, 12000), rng.uniform(0.5, 4, 12000)], 1)
+    blob = rng.normal([3.5, -3.5, 1.5], 0.25, (4000, 3))
+    return np.concatenate([ground, wall, blob]).astype(np.float32)
+
+
+@pytest.mark.parametrize("cap,md", [(0, 0.2), (20, 0.05), (0, 0.0), (7, 0.1)])
+def test_ndt_map_build_parity(ctx, oracle, cap, md):
+    """mola::NDT role (lidar3d-ndt.yaml:236-254): min-distance insertion filter + per-voxel statistics."""
+    pts = _ndt_cloud(cap + int(md * 100))
+    g = capi.Map(ctx, 1.0, cap, 0, md, 0.05, 4).build(pts)
+    o = oracle.Map(1.0, cap, 0, md, 0.05, 4).insert(pts)
+    assert (g.info().n_points, g.info().n_voxels) == (o.num_points, o.num_voxels)
+    assert_maps_equal(g.download(), o.dump())  # which points survive the filter: bit-exact
+    gn, on = g.download_ndt(), o.dump_ndt()
+    np.testing.assert_array_equal(gn["is_plane"], on["is_plane"])
+    assert g.info().n_planes == int(on["is_plane"].sum()) > 100
+    np.testing.assert_array_equal(gn["centroid"], on["centroid"])
+    np.testing.assert_allclose(gn["normal"], on["normal"], atol=1e-6)
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.1, 0.02])
+def test_point2plane_matcher_parity(ctx, oracle, thr):
+    """Matcher_Point2Plane on the NDT map (lidar3d-ndt.yaml:195-200): same pairings, centroids and normals."""
+    pts = _ndt_cloud(7)
+    g = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts)
+    o = oracle.Map(1.0, 0, 0, 0.1, 0.05, 4).insert(pts)
+    rng = np.random.default_rng(8)
+    q = np.concatenate([pts[rng.permutation(len(pts))[:4000]] + rng.normal(0, 0.05, (4000, 3)).astype(np.float32),
+                        rng.uniform(-12, 12, (1000, 3)).astype(np.float32)]).astype(np.float32)
+    q[5] = [np.nan, 0, 0]
+    gs = capi.Scan(ctx, q)
+    for T in (I12, oracle.se3_exp([0.06, -0.04, 0.03, 0.004, -0.002, 0.005])):
+        a = capi.nn_search_pt2pl(g, gs, T, thr)
+        b = oracle.match_pt2pl(o, q, T, thr)
+        np.testing.assert_array_equal(a["local_idx"], b["local_idx"])
+        np.testing.assert_array_equal(a["centroid"], b["centroid"])
+        np.testing.assert_allclose(a["normal"], b["normal"], atol=1e-6)
+        assert a["potential_pairings"] == len(q)
+    assert len(a["local_idx"]) > 0
+    with pytest.raises(capi.MolahipError):  # a plain map has no planes to offer
+        capi.nn_search_pt2pl(capi.Map(ctx, 1.0, 20).build(pts), gs, I12, thr)
+
+
+@pytest.mark.parametrize("inner", [1, 2])
+def test_align_ndt_pipeline_matches_oracle(ctx, oracle, inner):
+    """The lidar3d-ndt.yaml ICP block: Matcher_Point2Plane + Matcher_Points_DistanceThreshold feeding one
+    Gauss-Newton solve per iteration (yaml:184-210), stall thresholds 5e-4 (yaml:173-174)."""
+    pts = _ndt_cloud(11)
+    g = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts)
+    o = oracle.Map(1.0, 0, 0, 0.1, 0.05, 4).insert(pts)
+    rng = np.random.default_rng(12)
+    scan = pts[rng.permutation(len(pts))[:5000]]
+    guess = oracle.se3_exp([0.12, -0.09, 0.06, 0.006, -0.004, 0.01])
+    thr, kp = synth.threshold_schedule(0.5, 60)
+    kw = dict(max_iterations=60, min_abs_step_trans=5e-4, min_abs_step_rot=5e-4, threshold=thr, kernel_param=kp,
+              pt2pl_threshold=0.5)
+    a = capi.icp_align(g, capi.Scan(ctx, scan), guess, capi.ICPParams(gn=capi.GNParams(max_inner_iterations=inner), **kw),
+                       want_pairs=True)
+    b = oracle.icp_align(o, scan, guess, oracle.ICPParams(gn=oracle.GNParams(max_inner_iterations=inner), **kw),
+                         want_pairs=True)
+    assert_align_equal(a, b)
+    assert a["n_final_pairs_pt2pl"] == b["n_final_pairs_pt2pl"] > 1000
+    assert a["potential_pairings"] == 2 * len(scan)
+    np.testing.assert_array_equal(a["pairs"]["global_idx"], b["pairs"]["global_idx"])
+    np.testing.assert_allclose(a["cov"], b["cov"], rtol=2e-5, atol=1e-6 * np.abs(b["cov"]).max())
+    assert np.abs(a["T"] - I12).max() < 5e-3  # and it actually registers the scan
+
+
 # ---------------------------------------------------------------------------- NN / matcher
 def test_nn_dense_bit_exact(ctx, oracle, small):
     w, gm, om, gs = small
