@@ -153,6 +153,8 @@ class HashedVoxelPointCloud : public Layer {
  public:
   HashedVoxelPointCloud(float voxel_size, uint32_t max_points_per_voxel,
                         std::shared_ptr<DeviceContext> ctx = DeviceContext::Default());
+  // full parameter set (also what the NDT subclass uses)
+  HashedVoxelPointCloud(const mh_map_params& p, std::shared_ptr<DeviceContext> ctx);
   ~HashedVoxelPointCloud() override;
   void setPoints(const float* x, const float* y, const float* z, size_t n);  // clear + insertPoint for each
   void insertPoints(const float* x, const float* y, const float* z, size_t n);  // keeps a host copy, rebuilds
@@ -165,6 +167,14 @@ class HashedVoxelPointCloud : public Layer {
   std::shared_ptr<DeviceContext> ctx_;
   mh_map* map_ = nullptr;
   std::vector<float> hx_, hy_, hz_;
+};
+// mola::NDT stand-in (lidar3d-ndt.yaml:236-254): the same device map plus per-voxel mean / covariance / eigen
+// statistics, i.e. additionally NearestPlaneCapable for Matcher_Point2Plane
+class NDT : public HashedVoxelPointCloud {
+ public:
+  NDT(float voxel_size, uint32_t max_points_per_voxel, float min_distance_between_points, float max_eigen_ratio_for_planes,
+      std::shared_ptr<DeviceContext> ctx = DeviceContext::Default());
+  size_t planeCount() const;
 };
 struct metric_map_t {
   std::map<std::string, std::shared_ptr<Layer>> layers;
@@ -237,6 +247,21 @@ class Matcher_Points_DistanceThreshold : public Matcher {
     double weight = 1.0;
   };
   std::vector<LayerMatch> pointLayerMatches;
+  void initialize(const Config& params) override;
+
+ protected:
+  void impl_match(const metric_map_t& pcGlobal, const metric_map_t& pcLocal, const CPose3D& localPose,
+                  const MatchContext& mc, Pairings& out) const override;
+};
+
+// mp2p_icp::Matcher_Point2Plane [U] (lidar3d-ndt.yaml:195-200) against an NDT global layer.  The KNN/PCA knobs of the
+// upstream class (knn, planeEigenThreshold, minimumPlanePoints, searchRadius: used with non-NDT maps, rgbd.yaml:143-150)
+// are accepted and ignored.
+class Matcher_Point2Plane : public Matcher {
+ public:
+  double distanceThreshold = 0.5;
+  bool allowMatchAlreadyMatchedGlobalPoints = true;
+  std::vector<Matcher_Points_DistanceThreshold::LayerMatch> pointLayerMatches;
   void initialize(const Config& params) override;
 
  protected:

@@ -111,8 +111,34 @@ std::shared_ptr<DeviceContext> DeviceContext::Default() {
 
 HashedVoxelPointCloud::HashedVoxelPointCloud(float voxel_size, uint32_t max_points_per_voxel, std::shared_ptr<DeviceContext> ctx)
     : ctx_(std::move(ctx)) {
-  mh_map_params p{voxel_size, max_points_per_voxel, MH_INDEX_FLOOR, 0};
+  mh_map_params p{};
+  p.voxel_size = voxel_size;
+  p.max_points_per_voxel = max_points_per_voxel;
+  p.index_mode = MH_INDEX_FLOOR;
   check(mh_map_create(ctx_->get(), &p, &map_), "mh_map_create");
+}
+HashedVoxelPointCloud::HashedVoxelPointCloud(const mh_map_params& p, std::shared_ptr<DeviceContext> ctx) : ctx_(std::move(ctx)) {
+  check(mh_map_create(ctx_->get(), &p, &map_), "mh_map_create");
+}
+
+static mh_map_params ndt_params(float vs, uint32_t cap, float min_dist, float ratio) {
+  mh_map_params p{};
+  p.voxel_size = vs;
+  p.max_points_per_voxel = cap;
+  p.index_mode = MH_INDEX_FLOOR;
+  p.min_distance_between_points = min_dist;
+  p.ndt_max_eigen_ratio = ratio;
+  p.ndt_min_points = 4;
+  return p;
+}
+NDT::NDT(float voxel_size, uint32_t max_points_per_voxel, float min_distance_between_points, float max_eigen_ratio_for_planes,
+         std::shared_ptr<DeviceContext> ctx)
+    : HashedVoxelPointCloud(ndt_params(voxel_size, max_points_per_voxel, min_distance_between_points, max_eigen_ratio_for_planes),
+                            std::move(ctx)) {}
+size_t NDT::planeCount() const {
+  mh_map_info i;
+  check(mh_map_get_info(handle(), &i), "mh_map_get_info");
+  return i.n_planes;
 }
 HashedVoxelPointCloud::~HashedVoxelPointCloud() { mh_map_destroy(map_); }
 
@@ -234,6 +260,62 @@ void Matcher_Points_DistanceThreshold::impl_match(const metric_map_t& pcGlobal, 
   }
 }
 
+void Matcher_Point2Plane::initialize(const Config& c) {
+  parameterFromConfig(c, "distanceThreshold", &distanceThreshold, true);
+  if (c.has("allowMatchAlreadyMatchedGlobalPoints"))
+    allowMatchAlreadyMatchedGlobalPoints = to_bool(c["allowMatchAlreadyMatchedGlobalPoints"].asString());
+  if (c.has("runFromIteration")) runFromIteration = to_u32(c["runFromIteration"].asString());
+  if (c.has("runUpToIteration")) runUpToIteration = to_u32(c["runUpToIteration"].asString());
+  pointLayerMatches.clear();
+  if (c.has("pointLayerMatches")) {
+    const Config& s = c["pointLayerMatches"];
+    for (size_t i = 0; i < s.size(); i++) {
+      Matcher_Points_DistanceThreshold::LayerMatch lm;
+      lm.global = s.at(i)["global"].asString();
+      lm.local = s.at(i)["local"].asString();
+      lm.weight = strtod(s.at(i).getOr("weight", "1.0").c_str(), nullptr);
+      pointLayerMatches.push_back(lm);
+    }
+  }
+}
+
+static void append_pl_pairs(const PointCloud& loc, const std::vector<uint32_t>& li, const std::vector<float>* a, size_t k,
+                            Pairings& out) {
+  for (size_t i = 0; i < k; i++) {
+    out.pl_lx.push_back(loc.x[li[i]]);
+    out.pl_ly.push_back(loc.y[li[i]]);
+    out.pl_lz.push_back(loc.z[li[i]]);
+    out.pl_cx.push_back(a[0][i]);
+    out.pl_cy.push_back(a[1][i]);
+    out.pl_cz.push_back(a[2][i]);
+    out.pl_nx.push_back(a[3][i]);
+    out.pl_ny.push_back(a[4][i]);
+    out.pl_nz.push_back(a[5][i]);
+  }
+}
+
+void Matcher_Point2Plane::impl_match(const metric_map_t& pcGlobal, const metric_map_t& pcLocal, const CPose3D& localPose,
+                                     const MatchContext&, Pairings& out) const {
+  for (const auto& lm : pointLayerMatches) {
+    const PointCloud& loc = local_layer(pcLocal, lm.local);
+    const HashedVoxelPointCloud& glob = global_layer(pcGlobal, lm.global);
+    const size_t n = loc.size();
+    out.potential_pairings += n;
+    if (!n) continue;
+    mh_scan* scan = nullptr;
+    check(mh_scan_create(glob.context()->get(), loc.x.data(), loc.y.data(), loc.z.data(), n, MH_MEM_HOST, &scan), "mh_scan_create");
+    std::vector<uint32_t> li(n);
+    std::vector<float> a[6];
+    for (auto& v : a) v.resize(n);
+    mh_pairs_pl_out po{li.data(), a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), a[5].data()};
+    mh_match_info info{};
+    const mh_status st = mh_nn_search_pt2pl(glob.handle(), scan, localPose.T, distanceThreshold, &po, MH_MEM_HOST, &info);
+    mh_scan_destroy(scan);
+    check(st, "mh_nn_search_pt2pl");
+    append_pl_pairs(loc, li, a, info.n_pairs, out);
+  }
+}
+
 // ================================================================== solver
 static RobustKernel parse_kernel(std::string s) {
   const size_t p = s.rfind("::");
@@ -293,6 +375,8 @@ bool Solver_GaussNewton::optimal_pose(const Pairings& p, OptimalTF_Result& out, 
 Matcher::Ptr create_matcher(const std::string& cn) {
   if (cn == "mp2p_icp::Matcher_Points_DistanceThreshold" || cn == "mp2p_icp_hip::Matcher_Points_DistanceThreshold")
     return std::make_shared<Matcher_Points_DistanceThreshold>();
+  if (cn == "mp2p_icp::Matcher_Point2Plane" || cn == "mp2p_icp_hip::Matcher_Point2Plane")
+    return std::make_shared<Matcher_Point2Plane>();
   throw std::runtime_error("matcher class '" + cn + "' is not available in mp2p_icp_hip");
 }
 Solver::Ptr create_solver(const std::string& cn) {
@@ -351,14 +435,24 @@ void ICP::realize_iteration(uint32_t k) {
   for (auto& s : solvers_) s->realizeWith(vars);
 }
 
+// the two pipeline shapes the device loop implements: [Points_DistanceThreshold] (lidar3d-default.yaml:195-204) and
+// [Point2Plane, Points_DistanceThreshold] on the same layers (lidar3d-ndt.yaml:195-210), with one Solver_GaussNewton
 bool ICP::can_fuse() const {
   if (force_generic_ || iteration_hook_) return false;
-  if (matchers_.size() != 1 || solvers_.size() != 1) return false;
-  auto m = std::dynamic_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_[0]);
+  if (matchers_.empty() || matchers_.size() > 2 || solvers_.size() != 1) return false;
+  auto m = std::dynamic_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_.back());
   auto s = std::dynamic_pointer_cast<Solver_GaussNewton>(solvers_[0]);
   if (!m || !s) return false;
-  return m->enabled && m->runFromIteration == 0 && m->runUpToIteration == 0 && m->pairingsPerPoint == 1 &&
-         m->pointLayerMatches.size() == 1 && m->pointLayerMatches[0].weight == 1.0;
+  if (!(m->enabled && m->runFromIteration == 0 && m->runUpToIteration == 0 && m->pairingsPerPoint == 1 &&
+        m->pointLayerMatches.size() == 1 && m->pointLayerMatches[0].weight == 1.0))
+    return false;
+  if (matchers_.size() == 2) {
+    auto pl = std::dynamic_pointer_cast<Matcher_Point2Plane>(matchers_[0]);
+    if (!pl || !pl->enabled || pl->runFromIteration || pl->runUpToIteration || pl->pointLayerMatches.size() != 1) return false;
+    const auto &a = pl->pointLayerMatches[0], &b = m->pointLayerMatches[0];
+    if (a.global != b.global || a.local != b.local || a.weight != 1.0) return false;
+  }
+  return true;
 }
 
 void ICP::align(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const TPose3D& guess, const Parameters& p,
@@ -366,7 +460,7 @@ void ICP::align(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const
   result = Results();
   const CPose3D g(guess);
   if (can_fuse()) {
-    auto m = std::static_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_[0]);
+    auto m = std::static_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_.back());
     last_fused_ = true;
     align_fused(local_layer(pcLocal, m->pointLayerMatches[0].local), global_layer(pcGlobal, m->pointLayerMatches[0].global), g, p,
                 result, prior);
@@ -378,15 +472,17 @@ void ICP::align(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const
 
 void ICP::align_fused(const PointCloud& local, const HashedVoxelPointCloud& global, const CPose3D& guess, const Parameters& p,
                       Results& result, const std::optional<CPose3DPDFGaussianInf>& prior) {
-  auto m = std::static_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_[0]);
+  auto m = std::static_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_.back());
   auto s = std::static_pointer_cast<Solver_GaussNewton>(solvers_[0]);
+  auto mpl = matchers_.size() == 2 ? std::static_pointer_cast<Matcher_Point2Plane>(matchers_[0]) : nullptr;
   // the thresholds are functions of ICP_ITERATION only once the caller's variables are fixed for this call
   // (LidarOdometry.cpp:1571-1635 publishes them before align): evaluate them for every iteration up front
-  std::vector<double> thr(p.maxIterations), kp(p.maxIterations);
+  std::vector<double> thr(p.maxIterations), kp(p.maxIterations), plthr(p.maxIterations);
   for (uint32_t k = 0; k < p.maxIterations; k++) {
     realize_iteration(k);
     thr[k] = m->threshold;
     kp[k] = s->robustKernelParam;
+    if (mpl) plthr[k] = mpl->distanceThreshold;
   }
   if (p.maxIterations) realize_iteration(0);
   mh_icp_params ip{};
@@ -396,6 +492,7 @@ void ICP::align_fused(const PointCloud& local, const HashedVoxelPointCloud& glob
   ip.threshold = thr.data();
   ip.kernel_param = kp.data();
   ip.threshold_angular_deg = m->thresholdAngularDeg;
+  ip.pt2pl_threshold = mpl ? plthr.data() : nullptr;
   ip.gn = gn_params_of(*s);
   ip.hook_enabled = dev_hook_ ? 1u : 0u;
   ip.hook_min_trans = dev_hook_trans_;
@@ -424,7 +521,16 @@ void ICP::align_fused(const PointCloud& local, const HashedVoxelPointCloud& glob
   result.terminationReason = (IterTermReason)r.termination_reason;
   Pairings& fp = result.finalPairings;
   fp.potential_pairings = r.potential_pairings;
-  for (uint32_t k = 0; k < r.n_final_pairs; k++) {
+  if (r.n_final_pairs_pt2pl) {
+    std::vector<uint32_t> qli(n);
+    std::vector<float> a[6];
+    for (auto& v : a) v.resize(n);
+    mh_pairs_pl_out qo{qli.data(), a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), a[5].data()};
+    uint64_t nq = 0;
+    check(mh_icp_get_pt2pl_pairs(scan_, &qo, MH_MEM_HOST, &nq), "mh_icp_get_pt2pl_pairs");
+    append_pl_pairs(local, qli, a, nq, fp);
+  }
+  for (uint32_t k = 0; k < r.n_final_pairs - r.n_final_pairs_pt2pl; k++) {
     fp.localIdx.push_back(li[k]);
     fp.globalIdx.push_back(gi[k]);
     fp.lx.push_back(local.x[li[k]]);

@@ -61,6 +61,9 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
         auto c = make_cloud(xyz); h.insertPoints(c->x.data(), c->y.data(), c->z.data(), c->size()); })
       .def("size", &HashedVoxelPointCloud::size)
       .def("voxelCount", &HashedVoxelPointCloud::voxelCount);
+  py::class_<NDT, HashedVoxelPointCloud, std::shared_ptr<NDT>>(m, "NDT")
+      .def(py::init([](float vs, uint32_t cap, float min_dist, float ratio) { return std::make_shared<NDT>(vs, cap, min_dist, ratio); }))
+      .def("planeCount", &NDT::planeCount);
   py::class_<metric_map_t>(m, "metric_map_t")
       .def(py::init<>())
       .def("set_layer", [](metric_map_t& mm, const std::string& n, std::shared_ptr<Layer> l) { mm.layers[n] = std::move(l); });
@@ -82,6 +85,7 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
       .def("pose", [](const Results& r) { return std::vector<double>(r.optimal_tf.mean.T, r.optimal_tf.mean.T + 12); })
       .def("cov", [](const Results& r) { return std::vector<double>(r.optimal_tf.cov, r.optimal_tf.cov + 36); })
       .def("n_pairs", [](const Results& r) { return r.finalPairings.size(); })
+      .def("n_pairs_pt2pl", [](const Results& r) { return r.finalPairings.pl_lx.size(); })
       .def("pair_global_idx", [](const Results& r) { return r.finalPairings.globalIdx; })
       .def("pair_local_idx", [](const Results& r) { return r.finalPairings.localIdx; });
   py::class_<ICP, std::shared_ptr<ICP>>(m, "ICP")

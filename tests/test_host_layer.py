@@ -13,6 +13,8 @@ from mola_lidar_odometry_amd import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_YAML = "/root/reference/pipelines/lidar3d-default.yaml"
 OUR_YAML = os.path.join(ROOT, "pipelines", "lidar3d-default-hip.yaml")
+REF_NDT_YAML = "/root/reference/pipelines/lidar3d-ndt.yaml"
+OUR_NDT_YAML = os.path.join(ROOT, "pipelines", "lidar3d-ndt-hip.yaml")
 
 
 @pytest.fixture(scope="module")
@@ -71,6 +73,21 @@ def test_pipeline_from_yaml_builds_by_class_name(hl, path):
         assert hl.evaluate_expression(s["robustKernelParam"].asString(), v) == pytest.approx(kp[k])
     assert m["pointLayerMatches"].at(0)["global"].asString() == "localmap"
     assert m["pointLayerMatches"].at(0)["local"].asString() == "decimated_for_icp"
+
+
+@pytest.mark.parametrize("path", [OUR_NDT_YAML, REF_NDT_YAML])
+def test_ndt_pipeline_from_yaml(hl, path):
+    """lidar3d-ndt.yaml:162-215: Matcher_Point2Plane + Matcher_Points_DistanceThreshold, one GN step, 5e-4 stall steps."""
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present on this box")
+    cfg = hl.Config.FromYamlFile(path)["icp_settings_with_vel"]
+    icp, params = hl.icp_pipeline_from_yaml(cfg)
+    assert params.maxIterations == 300 and params.minAbsStep_trans == 5e-4 and params.minAbsStep_rot == 5e-4
+    assert cfg["matchers"].size() == 2
+    assert cfg["matchers"].at(0)["class"].asString().endswith("Matcher_Point2Plane")
+    assert hl.evaluate_expression(cfg["matchers"].at(0)["params"]["distanceThreshold"].asString(),
+                                  {"ADAPTIVE_THRESHOLD_SIGMA": 0.7}) == pytest.approx(0.7)
+    assert cfg["solvers"].at(0)["params"]["maxIterations"].asString() == "1"
 
 
 def test_unknown_class_is_an_error(hl):
@@ -184,3 +201,43 @@ def test_failures_surface_as_exceptions(hl, small_workload):
     icp.attachToParameterSource(src)
     with pytest.raises(RuntimeError):  # layer missing
         icp.align(empty, g, hl.TPose3D(*w.guess_ypr), params)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("generic", [False, True])
+def test_ndt_pipeline_align_matches_oracle(hl, oracle, generic):
+    """lidar3d-ndt.yaml driven through the plugin API against an mp2p_icp_hip::NDT map (config 5 of BASELINE.json)."""
+    rng = np.random.default_rng(21)
+    ground = np.stack([rng.uniform(-10, 10, 20000), rng.uniform(-10, 10, 20000), rng.normal(0.3, 0.01, 20000)], 1)
+    wall = np.stack([rng.uniform(-10, 10, 12000), rng.normal(5.4, 0.01, 12000), rng.uniform(0.5, 4, 12000)], 1)
+    blob = rng.normal([3.5, -3.5, 1.5], 0.25, (4000, 3))
+    pts = np.concatenate([ground, wall, blob]).astype(np.float32)
+    scan = pts[rng.permutation(len(pts))[:4000]]
+    cfg = hl.Config.FromYamlFile(OUR_NDT_YAML)["icp_settings_with_vel"]
+    icp, params = hl.icp_pipeline_from_yaml(cfg)
+    src = hl.ParameterSource()
+    sigma = 0.5
+    src.updateVariable("ADAPTIVE_THRESHOLD_SIGMA", sigma)
+    icp.attachToParameterSource(src)
+    icp.forceGenericPath(generic)
+    params.maxIterations = 60
+    g = hl.metric_map_t()
+    ndt = hl.NDT(1.0, 0, 0.2, 0.05)
+    ndt.setPoints(pts)
+    assert ndt.planeCount() > 100
+    g.set_layer("localmap", ndt)
+    l = hl.metric_map_t()
+    l.set_layer("decimated_for_icp", hl.PointCloud(scan))
+    guess_ypr = [0.10, -0.08, 0.05, 0.008, -0.004, 0.005]
+    res = icp.align(l, g, hl.TPose3D(*guess_ypr), params)
+    assert icp.lastAlignUsedFusedPath() == (not generic)
+    om = oracle.Map(1.0, 0, 0, 0.2, 0.05, 4).insert(pts)
+    thr, kp = synth.threshold_schedule(sigma, 60)
+    o = oracle.icp_align(om, scan, oracle.pose_from_ypr(guess_ypr), oracle.ICPParams(
+        max_iterations=60, min_abs_step_trans=5e-4, min_abs_step_rot=5e-4, threshold=thr, kernel_param=kp,
+        pt2pl_threshold=1.0 * sigma, gn=oracle.GNParams(max_inner_iterations=1)))
+    assert res.nIterations == o["n_iterations"]
+    assert res.terminationReason.name == oracle.TERM_NAMES[o["termination_reason"]]
+    np.testing.assert_allclose(res.pose(), o["T"], atol=1e-7)
+    assert res.n_pairs() == o["n_final_pairs"] and res.n_pairs_pt2pl() == o["n_final_pairs_pt2pl"] > 500
+    assert res.quality == o["quality"]
