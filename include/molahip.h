@@ -134,6 +134,15 @@ MH_API mh_status mh_map_destroy(mh_map* map);
  * index" reported by the NN search is the point's index in these arrays. */
 MH_API mh_status mh_map_build(mh_map* map, const float* x, const float* y, const float* z, size_t n, int32_t mem);
 MH_API mh_status mh_map_get_info(const mh_map* map, mh_map_info* info);
+/* Incremental key-frame update, device resident.  Replaces FilterMerge ->
+ * HashedVoxelPointCloud::insertPointCloud [U] (lidar3d-default.yaml:362-368, LidarOdometry.cpp:1161-1206) for the
+ * layer `scan` (vehicle frame, input_layer_in_local_coordinates: true): every point is composed with the robot
+ * pose T (row-major 3x4, fp64, result rounded to float) and offered to insertPoint in order, after everything the
+ * map already stores; then, if remove_voxels_farther_than > 0 (insertOpts, yaml:238), every voxel whose index
+ * distance max(|dkx|,|dky|,|dkz|) to the voxel of T's translation exceeds ceil(remove_voxels_farther_than/voxel_size)
+ * is erased [U].  The source index of a new point is (points ever offered to this map) + its index in `scan`.
+ * Nothing travels to the host except four counters. */
+MH_API mh_status mh_map_insert(mh_map* map, const mh_scan* scan, const double T[12], float remove_voxels_farther_than);
 /* Copy the stored content to HOST arrays (any may be NULL): points voxel by voxel, voxels in ascending
  * (kx,ky,kz), in-voxel insertion order.  xyz/src_idx hold n_points entries, vox_* hold n_voxels. */
 MH_API mh_status mh_map_download(const mh_map* map, float* x, float* y, float* z, uint32_t* src_idx,
@@ -153,6 +162,44 @@ MH_API mh_status mh_scan_create(mh_ctx* ctx, const float* x, const float* y, con
 MH_API mh_status mh_scan_update(mh_scan* scan, const float* x, const float* y, const float* z, size_t n, int32_t mem);
 MH_API mh_status mh_scan_destroy(mh_scan* scan);
 MH_API mh_status mh_scan_size(const mh_scan* scan, uint64_t* n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Scan pre-processing on the device: the observation filter chain that produces the
+ * layers `decimated_for_map` / `decimated_for_icp` from the raw sensor cloud.  Replaces, for the
+ * configuration of lidar3d-default.yaml:270-350, mp2p_icp_filters::{FilterAdjustTimestamps,
+ * FilterDecimateVoxels(FirstPoint), FilterByRange, FilterBoundingBox, FilterDeskew} [U].
+ * ---------------------------------------------------------------------------------------------- */
+enum { MH_TS_NONE = 0, MH_TS_MIDDLE_IS_ZERO = 1, MH_TS_EARLIEST_IS_ZERO = 2 }; /* TimestampAdjustMethod (yaml:275) */
+enum { MH_BBOX_OFF = 0, MH_BBOX_KEEP_OUTSIDE = 1, MH_BBOX_KEEP_INSIDE = 2 };
+
+typedef struct {
+  float decim_map_resolution;    /* FilterDecimateVoxels #1 voxel_filter_resolution (yaml:289); 0 = stage skipped */
+  float decim_icp_resolution;    /* FilterDecimateVoxels #2 (yaml:316); 0 = stage skipped */
+  uint32_t min_points_to_filter; /* minimum_input_points_to_filter (yaml:290,317): smaller inputs pass undecimated */
+  int32_t index_mode;            /* MH_INDEX_FLOOR | MH_INDEX_TRUNC of the decimation grid */
+  float range_min, range_max;    /* FilterByRange (yaml:301-302), inclusive; range_max <= 0 = stage skipped */
+  float range_center[3];
+  int32_t bbox_mode;             /* FilterBoundingBox (yaml:305-310): MH_BBOX_* ; the pipeline keeps the OUTSIDE */
+  float bbox_min[3], bbox_max[3];
+  int32_t timestamp_method;      /* FilterAdjustTimestamps (yaml:270-276): MH_TS_* ; ignored without time stamps */
+  float time_offset;
+} mh_preprocess_params;
+
+/* Attach per-point time stamps [s] (relative to the scan's reference time) to a scan of the same size. */
+MH_API mh_status mh_scan_set_timestamps(mh_scan* scan, const float* t, size_t n, int32_t mem);
+/* raw -> decimate(map res) -> by-range -> bounding box -> out_map -> decimate(icp res) -> out_icp (may be NULL).
+ * Survivors keep the raw order (upstream's FirstPoint decimation emits them in the iteration order of its hash
+ * container, which is implementation-defined: same set, deterministic order here).  The outputs carry adjusted
+ * time stamps (when `raw` has them) and each point's index in `raw`; they are the *_skewed layers. */
+MH_API mh_status mh_scan_preprocess(const mh_scan* raw, const mh_preprocess_params* params, mh_scan* out_map,
+                                    mh_scan* out_icp);
+/* FilterDeskew (yaml:328-350): p' = Exp_SO3(w*t_i)*p + v*t_i with twist = (vx,vy,vz,wx,wy,wz) in the vehicle frame,
+ * fp64, rounded to float [U].  twist == NULL or a scan without time stamps copies the points (skip_deskew /
+ * silently_ignore_no_timestamps).  `out` must differ from `in`; it is what align() and mh_map_insert() consume, and
+ * `in` stays valid for the re-de-skew inside the ICP loop (LidarOdometry.cpp:992-999) with no host round trip. */
+MH_API mh_status mh_scan_deskew(const mh_scan* in, const double twist[6], mh_scan* out);
+/* Copy a scan to HOST arrays (any may be NULL; t / src_idx are zero-filled when the scan has none). */
+MH_API mh_status mh_scan_download(const mh_scan* scan, float* x, float* y, float* z, float* t, uint32_t* src_idx);
 
 /* ------------------------------------------------------------------------------------------------
  * Matcher-granular path.  Replaces mp2p_icp::Matcher_Points_DistanceThreshold::implMatchOneLayer [U]

@@ -105,6 +105,18 @@ class ICPResult(C.Structure):
                 ("match_kernel_ms", C.c_double), ("total_ms", C.c_double), ("n_final_pairs_pt2pl", C.c_uint32)]
 
 
+class PreprocessParams(C.Structure):
+    _fields_ = [("decim_map_resolution", C.c_float), ("decim_icp_resolution", C.c_float),
+                ("min_points_to_filter", C.c_uint32), ("index_mode", C.c_int32), ("range_min", C.c_float),
+                ("range_max", C.c_float), ("range_center", C.c_float * 3), ("bbox_mode", C.c_int32),
+                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("timestamp_method", C.c_int32),
+                ("time_offset", C.c_float)]
+
+
+TS_NONE, TS_MIDDLE_IS_ZERO, TS_EARLIEST_IS_ZERO = 0, 1, 2
+BBOX_OFF, BBOX_KEEP_OUTSIDE, BBOX_KEEP_INSIDE = 0, 1, 2
+
+
 # every entry point include/molahip.h declares, with its ctypes signature
 _SIGNATURES = {
     "mh_version": (C.c_int32, [_UP, _UP, _UP]),
@@ -126,6 +138,11 @@ _SIGNATURES = {
     "mh_scan_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
     "mh_scan_destroy": (C.c_int32, [C.c_void_p]),
     "mh_scan_size": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mh_map_insert": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_float]),
+    "mh_scan_set_timestamps": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
+    "mh_scan_preprocess": (C.c_int32, [C.c_void_p, C.POINTER(PreprocessParams), C.c_void_p, C.c_void_p]),
+    "mh_scan_deskew": (C.c_int32, [C.c_void_p, _DP, C.c_void_p]),
+    "mh_scan_download": (C.c_int32, [C.c_void_p, _FP, _FP, _FP, _FP, _UP]),
     "mh_nn_search": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_double, C.c_double, C.POINTER(PairsOut), C.c_int32,
                                  C.POINTER(MatchInfo)]),
     "mh_nn_search_dense": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -254,6 +271,12 @@ class Map:
         _chk(lib().mh_map_build(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(z_ptr), n, MEM_DEVICE))
         return self
 
+    def insert(self, scan: "Scan", T, remove_voxels_farther_than=0.0):
+        """Key-frame update on the device: FilterMerge + insertPointCloud + far-voxel removal (mh_map_insert)."""
+        T = _T12(T)
+        _chk(lib().mh_map_insert(self._h, scan._h, T.ctypes.data_as(_DP), float(remove_voxels_farther_than)))
+        return self
+
     def info(self) -> MapInfo:
         i = MapInfo()
         _chk(lib().mh_map_get_info(self._h, C.byref(i)))
@@ -301,12 +324,36 @@ class Scan:
             px, py, pz = device_ptrs
             _chk(lib().mh_scan_create(ctx._h, C.c_void_p(px), C.c_void_p(py), C.c_void_p(pz), n, MEM_DEVICE,
                                       C.byref(self._h)))
-            self.n = n
         else:
-            x, y, z = _soa(xyz)
+            x, y, z = _soa(xyz if xyz is not None else np.zeros((0, 3), np.float32))
             _chk(lib().mh_scan_create(ctx._h, _vp(x), _vp(y), _vp(z), len(x), MEM_HOST, C.byref(self._h)))
-            self.n = len(x)
         ctx._children.add(self)
+
+    @property
+    def n(self) -> int:
+        return len(self)
+
+    def set_timestamps(self, t):
+        t = _f32(t)
+        _chk(lib().mh_scan_set_timestamps(self._h, _vp(t), len(t), MEM_HOST))
+        return self
+
+    def preprocess(self, params: "PreprocessParams", out_map: "Scan", out_icp: "Scan | None" = None):
+        """1st-pass observation filters on the device (mh_scan_preprocess): self = raw scan."""
+        _chk(lib().mh_scan_preprocess(self._h, C.byref(params), out_map._h, out_icp._h if out_icp is not None else None))
+        return out_map, out_icp
+
+    def deskew(self, twist, out: "Scan"):
+        tw = None if twist is None else np.ascontiguousarray(twist, dtype=np.float64)
+        _chk(lib().mh_scan_deskew(self._h, tw.ctypes.data_as(_DP) if tw is not None else None, out._h))
+        return out
+
+    def download(self):
+        n = len(self)
+        x, y, z, t = (np.zeros(max(n, 1), np.float32) for _ in range(4))
+        src = np.zeros(max(n, 1), np.uint32)
+        _chk(lib().mh_scan_download(self._h, *[a.ctypes.data_as(_FP) for a in (x, y, z, t)], src.ctypes.data_as(_UP)))
+        return dict(xyz=np.stack([x[:n], y[:n], z[:n]], 1), t=t[:n], src_idx=src[:n])
 
     @classmethod
     def from_torch(cls, ctx: Context, x, y, z):
@@ -320,7 +367,6 @@ class Scan:
     def update(self, xyz):
         x, y, z = _soa(xyz)
         _chk(lib().mh_scan_update(self._h, _vp(x), _vp(y), _vp(z), len(x), MEM_HOST))
-        self.n = len(x)
 
     def __len__(self):
         n = C.c_uint64()
@@ -560,3 +606,14 @@ def icp_align_batch(maps, scans, T_guesses, p: ICPParams, priors=None):
                 pr_arr[i] = C.pointer(keep_pr[-1])
     _chk(lib().mh_icp_align_batch(n, mh, sh, C.byref(cp), T.ctypes.data_as(_DP), pr_arr, res))
     return [_result_dict(r) for r in res]
+
+
+def preprocess_params(decim_map_resolution, decim_icp_resolution, min_points_to_filter=2000, index_mode=INDEX_FLOOR,
+                      range_min=0.0, range_max=0.0, range_center=(0.0, 0.0, 0.0), bbox_mode=BBOX_OFF,
+                      bbox_min=(0.0, 0.0, 0.0), bbox_max=(0.0, 0.0, 0.0), timestamp_method=TS_NONE,
+                      time_offset=0.0) -> PreprocessParams:
+    return PreprocessParams(float(decim_map_resolution), float(decim_icp_resolution), int(min_points_to_filter),
+                            int(index_mode), float(range_min), float(range_max),
+                            (C.c_float * 3)(*map(float, range_center)), int(bbox_mode),
+                            (C.c_float * 3)(*map(float, bbox_min)), (C.c_float * 3)(*map(float, bbox_max)),
+                            int(timestamp_method), float(time_offset))

@@ -38,6 +38,24 @@ mh_status stage_in(mh_ctx* ctx, DevBuf& buf, size_t offset_bytes, const void* sr
   return MH_OK;
 }
 
+mh_status scan_alloc(mh_scan* s, size_t n, bool with_t, bool with_src) {
+  mh_ctx* ctx = s->ctx;
+  const size_t stride = ((n * sizeof(float) + 255) / 256) * 256;
+  if (s->xyz.bytes < 3 * stride || (s->aux.bytes < 2 * stride && (with_t || with_src))) {
+    MH_HIP(hipStreamSynchronize(ctx->stream));  // nobody may still read the old buffers
+    MH_TRY(s->xyz.reserve(3 * stride ? 3 * stride : 256));
+    if (with_t || with_src) MH_TRY(s->aux.reserve(2 * stride ? 2 * stride : 256));
+  }
+  char* base = s->xyz.as<char>();
+  s->x = (const float*)base;
+  s->y = (const float*)(base + stride);
+  s->z = (const float*)(base + 2 * stride);
+  s->t = with_t ? (const float*)s->aux.as<char>() : nullptr;
+  s->src = with_src ? (const uint32_t*)(s->aux.as<char>() + stride) : nullptr;
+  s->n = n;
+  return MH_OK;
+}
+
 }  // namespace mh
 
 using namespace mh;
@@ -186,6 +204,8 @@ static mh_status scan_set(mh_scan* s, const float* x, const float* y, const floa
   s->x = (const float*)base;
   s->y = (const float*)(base + stride);
   s->z = (const float*)(base + 2 * stride);
+  s->t = nullptr;  // new points: whatever channels the old ones carried are gone
+  s->src = nullptr;
   s->n = n;
   return MH_OK;
 }
@@ -200,6 +220,7 @@ mh_status mh_scan_create(mh_ctx* ctx, const float* x, const float* y, const floa
   mh_status st = scan_set(s, x, y, z, n, mem);
   if (st != MH_OK) {
     s->xyz.release();
+    s->aux.release();
     delete s;
     return st;
   }
@@ -217,6 +238,7 @@ mh_status mh_scan_destroy(mh_scan* scan) {
   (void)hipSetDevice(scan->ctx->device);
   (void)hipStreamSynchronize(scan->ctx->stream);
   scan->xyz.release();
+  scan->aux.release();
   delete scan;
   return MH_OK;
 }

@@ -139,6 +139,7 @@ struct mh_map {
   mh::DevBuf vox_first;  // uint32[n_voxels]
   mh::DevBuf vox_count;  // uint32[n_voxels]
   uint64_t n_points = 0, n_offered = 0, n_voxels = 0, table_size = 0, n_records = 0, n_planes = 0;
+  mh::DevBuf merge;  // mh_map_insert staging: x | y | z | src of (stored + new) points
   float bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
   mh::MapView view() const {
     mh::MapView v;
@@ -155,7 +156,10 @@ struct mh_map {
 struct mh_scan {
   mh_ctx* ctx = nullptr;
   mh::DevBuf xyz;  // own storage: x[n] | y[n] | z[n] (SoA, 256-byte aligned sections)
+  mh::DevBuf aux;  // optional channels: t[n] | src[n]
   const float *x = nullptr, *y = nullptr, *z = nullptr;  // device pointers actually used
+  const float* t = nullptr;       // per-point time stamps [s] or null
+  const uint32_t* src = nullptr;  // index of each point in the raw scan it was filtered from, or null
   size_t n = 0;
 };
 
@@ -163,4 +167,9 @@ namespace mh {
 mh_status set_device(const mh_ctx* ctx);
 // copy `n` elements of a caller array living in `mem` into device scratch (returns device ptr)
 mh_status stage_in(mh_ctx* ctx, DevBuf& buf, size_t offset_bytes, const void* src, size_t bytes, int32_t mem);
+// (re)size a scan's own storage for n points (+ optional t / src channels) and point x,y,z,t,src at it
+mh_status scan_alloc(mh_scan* s, size_t n, bool with_t, bool with_src);
+// map (re)build from device arrays; src_ids null = identity.  evict: 0 or {cx,cy,cz,dist_in_grid} voxel test.
+mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc, size_t n,
+                           const int* evict);
 }  // namespace mh

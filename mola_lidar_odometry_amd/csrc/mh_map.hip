@@ -28,8 +28,8 @@ __device__ __forceinline__ int voxel_index(float c, float inv_vs, uint32_t trunc
 }
 
 __global__ void k_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
-                       float inv_vs, uint32_t trunc, unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx,
-                       uint32_t* __restrict__ flags) {
+                       float inv_vs, uint32_t trunc, int4 evict /* {cx,cy,cz,dist_in_grid}; w < 0 = off */,
+                       unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t* __restrict__ flags) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float px = x[i], py = y[i], pz = z[i];
@@ -37,7 +37,10 @@ __global__ void k_keys(const float* __restrict__ x, const float* __restrict__ y,
   if (isfinite(px) && isfinite(py) && isfinite(pz)) {
     const float sx = px * inv_vs, sy = py * inv_vs, sz = pz * inv_vs;
     if (fabsf(sx) < 1.0e6f && fabsf(sy) < 1.0e6f && fabsf(sz) < 1.0e6f) {
-      k = pack_key(voxel_index(px, inv_vs, trunc), voxel_index(py, inv_vs, trunc), voxel_index(pz, inv_vs, trunc));
+      const int kx = voxel_index(px, inv_vs, trunc), ky = voxel_index(py, inv_vs, trunc), kz = voxel_index(pz, inv_vs, trunc);
+      // remove_voxels_farther_than (yaml:238): erasing a voxel after the insertion == never storing its points
+      const bool far = evict.w >= 0 && max(max(abs(kx - evict.x), abs(ky - evict.y)), abs(kz - evict.z)) > evict.w;
+      if (!far) k = pack_key(kx, ky, kz);
     } else {
       atomicOr(&flags[0], 1u);  // voxel index does not fit 21 bits
     }
@@ -203,7 +206,7 @@ __global__ void k_scatter(const float* __restrict__ x, const float* __restrict__
                           const uint32_t* __restrict__ counters, uint32_t n_vox, float4* __restrict__ pts,
                           unsigned long long* __restrict__ vox_keys, uint32_t* __restrict__ vox_first,
                           uint32_t* __restrict__ vox_count, uint32_t* __restrict__ bbox /*6 ordered uints*/,
-                          uint32_t ndt) {
+                          uint32_t ndt, const uint32_t* __restrict__ src_ids /*null: identity*/) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   float px = 0, py = 0, pz = 0;
   bool kept = false;
@@ -212,7 +215,7 @@ __global__ void k_scatter(const float* __restrict__ x, const float* __restrict__
     const uint32_t src = idx_s[i];
     px = x[src]; py = y[src]; pz = z[src];
     const uint32_t pos = outpos[i] + ((ndt && head[i]) ? 2u : 0u);
-    pts[pos] = make_float4(px, py, pz, __uint_as_float(src));
+    pts[pos] = make_float4(px, py, pz, __uint_as_float(src_ids ? src_ids[src] : src));
     if (head[i]) {
       // stored points of this voxel = records between this head and the next one, minus the two NDT records
       const uint32_t v = vid1[i] - 1;
@@ -256,6 +259,39 @@ __global__ void k_table_insert(const unsigned long long* __restrict__ vox_keys, 
   }
 }
 
+// mh_map_insert: the stored points, voxel by voxel (ascending key, in-voxel insertion order), back into SoA arrays
+__global__ void k_gather_stored(const float4* __restrict__ pts, const uint32_t* __restrict__ vox_first,
+                                const uint32_t* __restrict__ vox_count, uint32_t n_vox, uint32_t ndt,
+                                float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
+                                uint32_t* __restrict__ osrc) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n_vox) return;
+  const uint32_t first = vox_first[v], cnt = vox_count[v];
+  const uint32_t o = ndt ? first - 2u * (v + 1u) : first;  // position in the point-only numbering
+  for (uint32_t j = 0; j < cnt; j++) {
+    const float4 p = pts[first + j];
+    ox[o + j] = p.x;
+    oy[o + j] = p.y;
+    oz[o + j] = p.z;
+    osrc[o + j] = __float_as_uint(p.w);
+  }
+}
+
+struct Pose12 { double m[12]; };
+
+// FilterMerge with input_layer_in_local_coordinates: p_map = (float)(R*p + t) (CPose3D::composePoint [U])
+__global__ void k_compose_new(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                              uint32_t n, Pose12 T, uint32_t src0, float* __restrict__ ox, float* __restrict__ oy,
+                              float* __restrict__ oz, uint32_t* __restrict__ osrc) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double px = x[i], py = y[i], pz = z[i];
+  ox[i] = (float)(((T.m[0] * px + T.m[1] * py) + T.m[2] * pz) + T.m[3]);
+  oy[i] = (float)(((T.m[4] * px + T.m[5] * py) + T.m[6] * pz) + T.m[7]);
+  oz[i] = (float)(((T.m[8] * px + T.m[9] * py) + T.m[10] * pz) + T.m[11]);
+  osrc[i] = src0 + i;
+}
+
 inline uint32_t nblk(size_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
 
 }  // namespace
@@ -292,6 +328,7 @@ mh_status mh_map_destroy(mh_map* m) {
   m->vox_keys.release();
   m->vox_first.release();
   m->vox_count.release();
+  m->merge.release();
   delete m;
   return MH_OK;
 }
@@ -305,21 +342,75 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
   MH_TRY(set_device(ctx));
   hipStream_t s = ctx->stream;
   MH_HIP(hipStreamSynchronize(s));  // a rebuild invalidates everything queued against the old content
+  const float *dx = x, *dy = y, *dz = z;
+  if (n > 0 && mem == MH_MEM_HOST) {
+    const size_t stride = ((n * sizeof(float) + 255) / 256) * 256;
+    MH_TRY(ctx->staging.reserve(3 * stride));
+    MH_TRY(stage_in(ctx, ctx->staging, 0, x, n * sizeof(float), mem));
+    MH_TRY(stage_in(ctx, ctx->staging, stride, y, n * sizeof(float), mem));
+    MH_TRY(stage_in(ctx, ctx->staging, 2 * stride, z, n * sizeof(float), mem));
+    dx = (const float*)ctx->staging.as<char>();
+    dy = (const float*)(ctx->staging.as<char>() + stride);
+    dz = (const float*)(ctx->staging.as<char>() + 2 * stride);
+  }
+  MH_TRY(map_build_device(m, dx, dy, dz, nullptr, n, nullptr));
+  m->n_offered = n;
+  return MH_OK;
+}
 
+mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], float remove_voxels_farther_than) {
+  MH_REQUIRE(m && scan && T, "null argument");
+  MH_REQUIRE(m->ctx == scan->ctx, "map and scan belong to different contexts");
+  MH_REQUIRE(remove_voxels_farther_than >= 0.f, "negative remove_voxels_farther_than");
+  for (int i = 0; i < 12; i++) MH_REQUIRE(isfinite(T[i]), "non-finite pose");
+  mh_ctx* ctx = m->ctx;
+  MH_TRY(set_device(ctx));
+  hipStream_t s = ctx->stream;
+  const size_t n_old = m->n_points, n_new = scan->n, total = n_old + n_new;
+  MH_REQUIRE(total < 0x7FFFFFF0ull && m->n_offered + n_new < 0xFFFFFFF0ull, "too many points");
+  const size_t stride = ((total * sizeof(float) + 255) / 256) * 256;
+  MH_TRY(m->merge.reserve(4 * stride ? 4 * stride : 256));
+  char* base = m->merge.as<char>();
+  float *mx = (float*)base, *my = (float*)(base + stride), *mz = (float*)(base + 2 * stride);
+  uint32_t* msrc = (uint32_t*)(base + 3 * stride);
+  const uint32_t ndt = m->params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
+  if (m->n_voxels)
+    hipLaunchKernelGGL(k_gather_stored, dim3(nblk(m->n_voxels, 128)), dim3(128), 0, s, m->pts.as<float4>(),
+                       m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(), (uint32_t)m->n_voxels, ndt, mx, my, mz,
+                       msrc);
+  if (n_new) {
+    Pose12 P;
+    for (int i = 0; i < 12; i++) P.m[i] = T[i];
+    hipLaunchKernelGGL(k_compose_new, dim3(nblk(n_new, 256)), dim3(256), 0, s, scan->x, scan->y, scan->z, (uint32_t)n_new,
+                       P, (uint32_t)m->n_offered, mx + n_old, my + n_old, mz + n_old, msrc + n_old);
+  }
+  MH_HIP(hipGetLastError());
+  int evict[4] = {0, 0, 0, -1};
+  if (remove_voxels_farther_than > 0.f) {
+    const bool trunc = m->params.index_mode == MH_INDEX_TRUNC;
+    for (int a = 0; a < 3; a++) {
+      const float sc = (float)T[4 * a + 3] * m->inv_vs;
+      MH_REQUIRE(fabsf(sc) < 1.0e6f, "insertion pose outside the key range");
+      evict[a] = trunc ? (int)sc : (int)floorf(sc);
+    }
+    evict[3] = (int)ceilf(remove_voxels_farther_than * m->inv_vs);
+  }
+  MH_TRY(map_build_device(m, mx, my, mz, msrc, total, evict));
+  m->n_offered += n_new;
+  return MH_OK;
+}
+
+}  // extern "C"
+
+namespace mh {
+
+mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc, size_t n,
+                           const int* evict) {
+  mh_ctx* ctx = m->ctx;
+  hipStream_t s = ctx->stream;
   uint32_t n_vox = 0, n_pts = 0, n_rec = 0;
   uint32_t h_counters[12] = {0};
   if (n > 0) {
-    const float *dx = x, *dy = y, *dz = z;
-    if (mem == MH_MEM_HOST) {
-      const size_t stride = ((n * sizeof(float) + 255) / 256) * 256;
-      MH_TRY(ctx->staging.reserve(3 * stride));
-      MH_TRY(stage_in(ctx, ctx->staging, 0, x, n * sizeof(float), mem));
-      MH_TRY(stage_in(ctx, ctx->staging, stride, y, n * sizeof(float), mem));
-      MH_TRY(stage_in(ctx, ctx->staging, 2 * stride, z, n * sizeof(float), mem));
-      dx = (const float*)ctx->staging.as<char>();
-      dy = (const float*)(ctx->staging.as<char>() + stride);
-      dz = (const float*)(ctx->staging.as<char>() + 2 * stride);
-    }
     const uint32_t N = (uint32_t)n;
     // scratch carve-up
     MH_TRY(ctx->build_a.reserve(2 * n * sizeof(unsigned long long)));  // keys in | keys sorted
@@ -341,8 +432,9 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
     const uint32_t init_counters[12] = {0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0, 0, 0};
     MH_HIP(hipMemcpyAsync(counters, init_counters, sizeof(init_counters), hipMemcpyHostToDevice, s));
     const uint32_t B = 256;
+    const int4 ev = evict ? make_int4(evict[0], evict[1], evict[2], evict[3]) : make_int4(0, 0, 0, -1);
     hipLaunchKernelGGL(k_keys, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, N, m->inv_vs,
-                       (uint32_t)(m->params.index_mode == MH_INDEX_TRUNC), keys, idx, counters);
+                       (uint32_t)(m->params.index_mode == MH_INDEX_TRUNC), ev, keys, idx, counters);
     size_t tmp = 0;
     MH_HIP(rocprim::radix_sort_pairs(nullptr, tmp, keys, keys_s, idx, idx_s, N, 0, 64, s));
     {
@@ -391,7 +483,7 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
       hipLaunchKernelGGL(k_scatter, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, keys_s, idx_s, head, vid1, vstart, keep,
                          outpos, N, m->params.max_points_per_voxel, counters, n_vox, m->pts.as<float4>(),
                          m->vox_keys.as<unsigned long long>(), m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(),
-                         counters + 2, ndt);
+                         counters + 2, ndt, dsrc);
       if (ndt)
         hipLaunchKernelGGL(k_ndt_stats, dim3(nblk(n_vox, 128)), dim3(128), 0, s, m->pts.as<float4>(),
                            m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(), n_vox, m->params.ndt_max_eigen_ratio,
@@ -414,7 +506,6 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
   m->n_records = n_rec;
   m->n_planes = n_pts ? h_counters[8] : 0;
   m->n_voxels = n_vox;
-  m->n_offered = n;
   m->table_size = tsize;
   for (int a = 0; a < 3; a++) {
     m->bbox_min[a] = n_pts ? ord2f(h_counters[2 + a]) : 0.f;
@@ -422,6 +513,10 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
   }
   return MH_OK;
 }
+
+}  // namespace mh
+
+extern "C" {
 
 mh_status mh_map_get_info(const mh_map* m, mh_map_info* info) {
   MH_REQUIRE(m && info, "null argument");

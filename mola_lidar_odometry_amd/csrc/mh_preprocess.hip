@@ -1,0 +1,342 @@
+// mh_preprocess.hip -- scan pre-processing on the device: the observation filter chain of
+// lidar3d-default.yaml:270-350 that turns the raw sensor cloud into the layers `decimated_for_map` and
+// `decimated_for_icp`, so that the per-scan path is device resident from the raw points on and the re-de-skew
+// inside the ICP loop (LidarOdometry.cpp:992-999) needs no host round trip.
+//
+//   FilterAdjustTimestamps  -> min/max reduction, applied while compacting
+//   FilterDecimateVoxels    -> FirstPoint: hash insert with atomicMin(first index) per voxel, then "am I the first"
+//   FilterByRange / FilterBoundingBox -> per-point predicates fused into the same flag pass
+//   (flags) -> exclusive scan -> order-preserving compaction (survivors keep the raw order)
+//   FilterDeskew            -> p' = Exp_SO3(w t_i) p + v t_i, fp64, rounded to float
+// All of it is HBM-bound byte/index work: coalesced SoA streams, one pass per stage, atomics only on the
+// (L2-resident) decimation table.
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "mh_internal.h"
+#include "mh_nn_device.h"
+
+using namespace mh;
+
+namespace {
+
+struct StageParams {
+  float inv_res;       // 1/voxel_filter_resolution, 0 = no decimation in this stage
+  uint32_t trunc;      // MH_INDEX_TRUNC
+  uint32_t decimate;   // 0 when the input is smaller than minimum_input_points_to_filter
+  uint32_t range_on;
+  float sq_min, sq_max, cx, cy, cz;
+  int32_t bbox_mode;
+  float bmin[3], bmax[3];
+  int32_t ts_method;   // applied to t while compacting (stage 1 only)
+  float ts_offset;
+};
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+  u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  return __uint_as_float(u);
+}
+
+// counters[0] = min(t), counters[1] = max(t) as order-preserving uints
+__global__ void k_pp_tminmax(const float* __restrict__ t, uint32_t n, uint32_t* __restrict__ counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+  if (i < n) mn = mx = f2ord(t[i]);
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+  }
+  if ((threadIdx.x & 63) == 0 && mn != 0xFFFFFFFFu) {
+    atomicMin(&counters[0], mn);
+    atomicMax(&counters[1], mx);
+  }
+}
+
+__device__ __forceinline__ bool pp_key(float px, float py, float pz, float inv, uint32_t trunc, unsigned long long& key,
+                                       uint32_t* __restrict__ counters) {
+  if (!(isfinite(px) && isfinite(py) && isfinite(pz))) return false;
+  const float sx = px * inv, sy = py * inv, sz = pz * inv;
+  if (!(fabsf(sx) < 1.0e6f && fabsf(sy) < 1.0e6f && fabsf(sz) < 1.0e6f)) {
+    atomicOr(&counters[2], 1u);  // voxel index does not fit the 21-bit key fields
+    return false;
+  }
+  key = pack_key(voxel_of(px, inv, trunc), voxel_of(py, inv, trunc), voxel_of(pz, inv, trunc));
+  return true;
+}
+
+// FirstPoint decimation, pass 1: every point claims its voxel's table entry and records the smallest point index
+__global__ void k_pp_insert(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                            uint32_t n, float inv, uint32_t trunc, unsigned long long* __restrict__ keys,
+                            uint32_t* __restrict__ first_idx, uint32_t mask, uint32_t* __restrict__ counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long key;
+  if (!pp_key(x[i], y[i], z[i], inv, trunc, key, counters)) return;
+  uint32_t h = hash_key(key) & mask;
+  for (;;) {
+    const unsigned long long old = atomicCAS(&keys[h], kEmptyKey, key);
+    if (old == kEmptyKey || old == key) break;
+    h = (h + 1) & mask;
+  }
+  atomicMin(&first_idx[h], i);
+}
+
+// pass 2: flag = first point of its voxel (when decimating) && FilterByRange && FilterBoundingBox
+__global__ void k_pp_flag(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                          uint32_t n, StageParams sp, const unsigned long long* __restrict__ keys,
+                          const uint32_t* __restrict__ first_idx, uint32_t mask, uint32_t* __restrict__ counters,
+                          uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[i], py = y[i], pz = z[i];
+  bool keep = isfinite(px) && isfinite(py) && isfinite(pz);
+  if (keep && sp.decimate) {
+    unsigned long long key;
+    keep = pp_key(px, py, pz, sp.inv_res, sp.trunc, key, counters);
+    if (keep) {
+      uint32_t h = hash_key(key) & mask;
+      while (keys[h] != key) h = (h + 1) & mask;  // inserted by pass 1
+      keep = first_idx[h] == i;
+    }
+  }
+  if (keep && sp.range_on) {
+    const float dx = px - sp.cx, dy = py - sp.cy, dz = pz - sp.cz;
+    const float sq = (dx * dx + dy * dy) + dz * dz;
+    keep = sq >= sp.sq_min && sq <= sp.sq_max;
+  }
+  if (keep && sp.bbox_mode) {
+    const bool inside = px >= sp.bmin[0] && px <= sp.bmax[0] && py >= sp.bmin[1] && py <= sp.bmax[1] &&
+                        pz >= sp.bmin[2] && pz <= sp.bmax[2];
+    keep = inside == (sp.bbox_mode == MH_BBOX_KEEP_INSIDE);
+  }
+  flag[i] = keep ? 1u : 0u;
+}
+
+__global__ void k_pp_compact(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                             const float* __restrict__ t, const uint32_t* __restrict__ src, uint32_t n,
+                             const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, int32_t ts_method,
+                             float ts_offset, const uint32_t* __restrict__ counters, float* __restrict__ ox,
+                             float* __restrict__ oy, float* __restrict__ oz, float* __restrict__ ot,
+                             uint32_t* __restrict__ osrc) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  const uint32_t o = pos[i];
+  ox[o] = x[i];
+  oy[o] = y[i];
+  oz[o] = z[i];
+  if (ot) {
+    float tv = t[i];
+    if (ts_method != MH_TS_NONE) {  // FilterAdjustTimestamps over ALL raw points (it runs before the decimation)
+      const float tmin = ord2f(counters[0]), tmax = ord2f(counters[1]);
+      const float dt = ts_method == MH_TS_MIDDLE_IS_ZERO ? 0.5f * (tmin + tmax) : tmin;
+      tv = (tv - dt) + ts_offset;
+    }
+    ot[o] = tv;
+  }
+  osrc[o] = src ? src[i] : i;
+}
+
+struct Twist { double v[6]; };
+
+__global__ void k_pp_deskew(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                            const float* __restrict__ t, uint32_t n, Twist tw, float* __restrict__ ox,
+                            float* __restrict__ oy, float* __restrict__ oz) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double dt = (double)t[i];
+  const double xi[6] = {0.0, 0.0, 0.0, tw.v[3] * dt, tw.v[4] * dt, tw.v[5] * dt};
+  Pose p = se3_exp(xi);  // zero translation part: pure Exp_SO3(w dt)
+  p.t(0) = tw.v[0] * dt;
+  p.t(1) = tw.v[1] * dt;
+  p.t(2) = tw.v[2] * dt;
+  float gx, gy, gz;
+  transform_point(p.m, x[i], y[i], z[i], gx, gy, gz);
+  ox[i] = gx;
+  oy[i] = gy;
+  oz[i] = gz;
+}
+
+inline uint32_t nblk(size_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
+
+// One stage: [decimate] + predicates over `in` -> `out` (compacted, order preserving).  Returns the survivor count.
+mh_status run_stage(mh_ctx* ctx, const mh_scan* in, const StageParams& sp, uint32_t* counters, mh_scan* out,
+                    bool want_t) {
+  hipStream_t s = ctx->stream;
+  const uint32_t N = (uint32_t)in->n;
+  const uint32_t B = 256;
+  if (N == 0) return scan_alloc(out, 0, want_t, true);
+  uint32_t* flag = ctx->build_c.as<uint32_t>();
+  uint32_t* pos = flag + N;
+  unsigned long long* keys = nullptr;
+  uint32_t* first_idx = nullptr;
+  uint32_t mask = 0;
+  if (sp.decimate) {
+    uint64_t tsize = 64;
+    while (tsize < 2ull * N) tsize <<= 1;
+    MH_TRY(ctx->build_a.reserve(tsize * sizeof(unsigned long long)));
+    MH_TRY(ctx->build_b.reserve(tsize * sizeof(uint32_t)));
+    keys = ctx->build_a.as<unsigned long long>();
+    first_idx = ctx->build_b.as<uint32_t>();
+    mask = (uint32_t)(tsize - 1);
+    MH_HIP(hipMemsetAsync(keys, 0xFF, tsize * sizeof(unsigned long long), s));
+    MH_HIP(hipMemsetAsync(first_idx, 0xFF, tsize * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_pp_insert, dim3(nblk(N, B)), dim3(B), 0, s, in->x, in->y, in->z, N, sp.inv_res, sp.trunc, keys,
+                       first_idx, mask, counters);
+  }
+  hipLaunchKernelGGL(k_pp_flag, dim3(nblk(N, B)), dim3(B), 0, s, in->x, in->y, in->z, N, sp, keys, first_idx, mask,
+                     counters, flag);
+  size_t tb = ctx->sort_tmp.bytes;
+  MH_HIP(rocprim::exclusive_scan(ctx->sort_tmp.p, tb, flag, pos, 0u, N, rocprim::plus<uint32_t>(), s));
+  uint32_t h_last[2] = {0, 0}, h_flags = 0;
+  MH_HIP(hipMemcpyAsync(&h_last[0], pos + (N - 1), 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(hipMemcpyAsync(&h_last[1], flag + (N - 1), 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(hipMemcpyAsync(&h_flags, counters + 2, 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(hipStreamSynchronize(s));
+  if (h_flags & 1u)
+    return fail(MH_ERR_OUT_OF_RANGE, "a point's decimation voxel index exceeds the +-2^20 range of the packed key");
+  const uint32_t M = h_last[0] + h_last[1];
+  MH_TRY(scan_alloc(out, M, want_t, true));
+  if (M)
+    hipLaunchKernelGGL(k_pp_compact, dim3(nblk(N, B)), dim3(B), 0, s, in->x, in->y, in->z, want_t ? in->t : nullptr,
+                       in->src, N, flag, pos, sp.ts_method, sp.ts_offset, counters, (float*)out->x, (float*)out->y,
+                       (float*)out->z, want_t ? (float*)out->t : nullptr, (uint32_t*)out->src);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+mh_status mh_scan_set_timestamps(mh_scan* scan, const float* t, size_t n, int32_t mem) {
+  MH_REQUIRE(scan, "null scan");
+  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
+  MH_REQUIRE(n == scan->n, "time stamp count differs from the scan size");
+  MH_REQUIRE(n == 0 || t, "null time stamps");
+  mh_ctx* ctx = scan->ctx;
+  MH_TRY(set_device(ctx));
+  const size_t stride = ((n * sizeof(float) + 255) / 256) * 256;
+  if (scan->aux.bytes < 2 * stride) {
+    MH_HIP(hipStreamSynchronize(ctx->stream));
+    MH_TRY(scan->aux.reserve(2 * stride ? 2 * stride : 256));
+  }
+  if (n) {
+    MH_HIP(hipMemcpyAsync(scan->aux.p, t, n * sizeof(float),
+                          mem == MH_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+    if (mem == MH_MEM_HOST) MH_HIP(hipStreamSynchronize(ctx->stream));  // host array is borrowed for the call only
+  }
+  scan->t = (const float*)scan->aux.p;
+  return MH_OK;
+}
+
+mh_status mh_scan_preprocess(const mh_scan* raw, const mh_preprocess_params* p, mh_scan* out_map, mh_scan* out_icp) {
+  MH_REQUIRE(raw && p && out_map, "null argument");
+  MH_REQUIRE(out_map != raw && out_icp != raw && out_map != out_icp, "outputs must be distinct scans");
+  MH_REQUIRE(out_map->ctx == raw->ctx && (!out_icp || out_icp->ctx == raw->ctx), "scans belong to different contexts");
+  MH_REQUIRE(p->decim_map_resolution >= 0.f && p->decim_icp_resolution >= 0.f, "negative decimation resolution");
+  MH_REQUIRE(p->index_mode == MH_INDEX_FLOOR || p->index_mode == MH_INDEX_TRUNC, "bad index_mode");
+  MH_REQUIRE(p->bbox_mode >= MH_BBOX_OFF && p->bbox_mode <= MH_BBOX_KEEP_INSIDE, "bad bbox_mode");
+  MH_REQUIRE(p->timestamp_method >= MH_TS_NONE && p->timestamp_method <= MH_TS_EARLIEST_IS_ZERO, "bad timestamp_method");
+  MH_REQUIRE(raw->n < 0x7FFFFFF0ull, "scan too large");
+  mh_ctx* ctx = raw->ctx;
+  MH_TRY(set_device(ctx));
+  hipStream_t s = ctx->stream;
+  const size_t n = raw->n;
+  const bool has_t = raw->t != nullptr;
+
+  MH_TRY(ctx->build_c.reserve(2 * (n ? n : 1) * sizeof(uint32_t)));  // flag | pos
+  MH_TRY(ctx->build_e.reserve(64));                                   // counters: tmin, tmax, range flag
+  uint32_t* counters = ctx->build_e.as<uint32_t>();
+  const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+  MH_HIP(hipMemcpyAsync(counters, init, sizeof(init), hipMemcpyHostToDevice, s));
+  if (n) {
+    size_t tmp = 0;
+    MH_HIP(rocprim::exclusive_scan(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>(), s));
+    MH_TRY(ctx->sort_tmp.reserve(tmp));
+  }
+  if (has_t && n && p->timestamp_method != MH_TS_NONE)
+    hipLaunchKernelGGL(k_pp_tminmax, dim3(nblk(n, 256)), dim3(256), 0, s, raw->t, (uint32_t)n, counters);
+
+  StageParams s1{};
+  s1.inv_res = p->decim_map_resolution > 0.f ? 1.0f / p->decim_map_resolution : 0.f;
+  s1.trunc = p->index_mode == MH_INDEX_TRUNC;
+  s1.decimate = (p->decim_map_resolution > 0.f && n >= p->min_points_to_filter) ? 1u : 0u;
+  s1.range_on = p->range_max > 0.f ? 1u : 0u;
+  s1.sq_min = p->range_min * p->range_min;
+  s1.sq_max = p->range_max * p->range_max;
+  s1.cx = p->range_center[0]; s1.cy = p->range_center[1]; s1.cz = p->range_center[2];
+  s1.bbox_mode = p->bbox_mode;
+  for (int a = 0; a < 3; a++) { s1.bmin[a] = p->bbox_min[a]; s1.bmax[a] = p->bbox_max[a]; }
+  s1.ts_method = has_t ? p->timestamp_method : MH_TS_NONE;
+  s1.ts_offset = p->time_offset;
+  MH_TRY(run_stage(ctx, raw, s1, counters, out_map, has_t));
+
+  if (out_icp) {
+    StageParams s2{};
+    s2.inv_res = p->decim_icp_resolution > 0.f ? 1.0f / p->decim_icp_resolution : 0.f;
+    s2.trunc = s1.trunc;
+    s2.decimate = (p->decim_icp_resolution > 0.f && out_map->n >= p->min_points_to_filter) ? 1u : 0u;
+    s2.ts_method = MH_TS_NONE;  // out_map's stamps are adjusted already
+    MH_TRY(run_stage(ctx, out_map, s2, counters, out_icp, has_t));
+  }
+  return MH_OK;
+}
+
+mh_status mh_scan_deskew(const mh_scan* in, const double twist[6], mh_scan* out) {
+  MH_REQUIRE(in && out, "null argument");
+  MH_REQUIRE(in != out, "`out` must differ from `in`");
+  MH_REQUIRE(in->ctx == out->ctx, "scans belong to different contexts");
+  mh_ctx* ctx = in->ctx;
+  MH_TRY(set_device(ctx));
+  hipStream_t s = ctx->stream;
+  const size_t n = in->n;
+  MH_TRY(scan_alloc(out, n, in->t != nullptr, in->src != nullptr));
+  if (!n) return MH_OK;
+  if (in->t) MH_HIP(hipMemcpyAsync((void*)out->t, in->t, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (in->src) MH_HIP(hipMemcpyAsync((void*)out->src, in->src, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  if (twist && in->t) {
+    Twist tw;
+    for (int i = 0; i < 6; i++) {
+      MH_REQUIRE(isfinite(twist[i]), "non-finite twist");
+      tw.v[i] = twist[i];
+    }
+    hipLaunchKernelGGL(k_pp_deskew, dim3(nblk(n, 256)), dim3(256), 0, s, in->x, in->y, in->z, in->t, (uint32_t)n, tw,
+                       (float*)out->x, (float*)out->y, (float*)out->z);
+    MH_HIP(hipGetLastError());
+  } else {  // skip_deskew / silently_ignore_no_timestamps
+    MH_HIP(hipMemcpyAsync((void*)out->x, in->x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    MH_HIP(hipMemcpyAsync((void*)out->y, in->y, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    MH_HIP(hipMemcpyAsync((void*)out->z, in->z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  return MH_OK;
+}
+
+mh_status mh_scan_download(const mh_scan* scan, float* x, float* y, float* z, float* t, uint32_t* src_idx) {
+  MH_REQUIRE(scan, "null scan");
+  mh_ctx* ctx = scan->ctx;
+  MH_TRY(set_device(ctx));
+  hipStream_t s = ctx->stream;
+  const size_t n = scan->n;
+  if (n) {
+    if (x) MH_HIP(hipMemcpyAsync(x, scan->x, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (y) MH_HIP(hipMemcpyAsync(y, scan->y, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (z) MH_HIP(hipMemcpyAsync(z, scan->z, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (t) {
+      if (scan->t) MH_HIP(hipMemcpyAsync(t, scan->t, n * sizeof(float), hipMemcpyDeviceToHost, s));
+      else memset(t, 0, n * sizeof(float));
+    }
+    if (src_idx) {
+      if (scan->src) MH_HIP(hipMemcpyAsync(src_idx, scan->src, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      else memset(src_idx, 0, n * sizeof(uint32_t));
+    }
+  }
+  MH_HIP(hipStreamSynchronize(s));
+  return MH_OK;
+}
+
+}  // extern "C"

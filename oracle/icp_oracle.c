@@ -1015,6 +1015,162 @@ int orc_icp_align(const orc_map* m, const float* lx, const float* ly, const floa
   return 0;
 }
 
+/* ======================================================================================
+ * SURVEY 8(f) rows f1 / f2
+ * ==================================================================================== */
+static void map_recompute_bbox(orc_map* m) {
+  for (int i = 0; i < 3; i++) { m->bb_min[i] = INFINITY; m->bb_max[i] = -INFINITY; }
+  for (size_t id = 0; id < m->n_vox; id++) {
+    const voxel_t* v = &m->vox[id];
+    for (uint32_t j = 0; j < v->n; j++)
+      for (int a = 0; a < 3; a++) {
+        const float c = v->xyz[3 * j + a];
+        if (c < m->bb_min[a]) m->bb_min[a] = c;
+        if (c > m->bb_max[a]) m->bb_max[a] = c;
+      }
+  }
+}
+
+void orc_map_insert_posed(orc_map* m, const float* x, const float* y, const float* z, size_t n, const double T[12],
+                          float remove_voxels_farther_than) {
+  float* g = (float*)malloc((n ? n : 1) * 3 * sizeof(float));
+  for (size_t i = 0; i < n; i++) transform_pt(T, x[i], y[i], z[i], &g[i], &g[n + i], &g[2 * n + i]);
+  orc_map_insert(m, g, g + n, g + 2 * n, n);
+  free(g);
+  if (remove_voxels_farther_than > 0.f) {
+    const int dist_in_grid = (int)ceilf(remove_voxels_farther_than * m->inv_vs);
+    const int32_t c[3] = {coord2idx(m, (float)t_(T, 0)), coord2idx(m, (float)t_(T, 1)), coord2idx(m, (float)t_(T, 2))};
+    int removed = 0;
+    for (size_t id = 0; id < m->n_vox; id++) {
+      voxel_t* v = &m->vox[id];
+      if (!v->n) continue;
+      int d = 0;
+      for (int a = 0; a < 3; a++) {
+        const int da = abs(v->k[a] - c[a]);
+        if (da > d) d = da;
+      }
+      if (d > dist_in_grid) { /* erase(): an emptied voxel behaves like a missing one everywhere */
+        m->n_points -= v->n;
+        v->n = 0;
+        v->ndt_dirty = 1;
+        removed = 1;
+      }
+    }
+    if (removed) map_recompute_bbox(m);
+  }
+}
+
+void orc_adjust_timestamps(float* t, size_t n, int method, float time_offset) {
+  if (!n || method == ORC_TS_NONE) return;
+  float tmin = t[0], tmax = t[0];
+  for (size_t i = 1; i < n; i++) {
+    if (t[i] < tmin) tmin = t[i];
+    if (t[i] > tmax) tmax = t[i];
+  }
+  const float dt = (method == ORC_TS_MIDDLE_IS_ZERO) ? 0.5f * (tmin + tmax) : tmin;
+  for (size_t i = 0; i < n; i++) t[i] = (t[i] - dt) + time_offset;
+}
+
+typedef struct { int32_t k[3]; uint32_t used; } dec_cell;
+
+size_t orc_decimate_first_point(const float* x, const float* y, const float* z, size_t n, float resolution,
+                                uint32_t min_points_to_filter, int index_mode, uint32_t* out_idx) {
+  size_t o = 0;
+  if (resolution <= 0.f || n < min_points_to_filter) {
+    for (size_t i = 0; i < n; i++)
+      if (isfinite(x[i]) && isfinite(y[i]) && isfinite(z[i])) out_idx[o++] = (uint32_t)i;
+    return o;
+  }
+  const float inv = 1.0f / resolution;
+  size_t tsize = 64;
+  while (tsize < 2 * n) tsize <<= 1;
+  dec_cell* tab = (dec_cell*)calloc(tsize, sizeof(dec_cell));
+  for (size_t i = 0; i < n; i++) {
+    if (!isfinite(x[i]) || !isfinite(y[i]) || !isfinite(z[i])) continue;
+    int32_t k[3];
+    const float s[3] = {x[i] * inv, y[i] * inv, z[i] * inv};
+    for (int a = 0; a < 3; a++) k[a] = (index_mode == ORC_INDEX_TRUNC) ? (int32_t)s[a] : (int32_t)floorf(s[a]);
+    size_t h = hash3(k[0], k[1], k[2]) & (tsize - 1);
+    int seen = 0;
+    while (tab[h].used) {
+      if (tab[h].k[0] == k[0] && tab[h].k[1] == k[1] && tab[h].k[2] == k[2]) { seen = 1; break; }
+      h = (h + 1) & (tsize - 1);
+    }
+    if (seen) continue; /* the voxel already holds its first point */
+    tab[h].used = 1;
+    tab[h].k[0] = k[0]; tab[h].k[1] = k[1]; tab[h].k[2] = k[2];
+    out_idx[o++] = (uint32_t)i;
+  }
+  free(tab);
+  return o;
+}
+
+size_t orc_filter_by_range(const float* x, const float* y, const float* z, size_t n, float range_min, float range_max,
+                           const float center[3], uint32_t* out_idx) {
+  const float sq_min = range_min * range_min, sq_max = range_max * range_max;
+  size_t o = 0;
+  for (size_t i = 0; i < n; i++) {
+    const float dx = x[i] - center[0], dy = y[i] - center[1], dz = z[i] - center[2];
+    const float sq = (dx * dx + dy * dy) + dz * dz;
+    if (sq >= sq_min && sq <= sq_max) out_idx[o++] = (uint32_t)i;
+  }
+  return o;
+}
+
+size_t orc_filter_bbox(const float* x, const float* y, const float* z, size_t n, const float bb_min[3],
+                       const float bb_max[3], int keep_inside, uint32_t* out_idx) {
+  size_t o = 0;
+  for (size_t i = 0; i < n; i++) {
+    const int inside = x[i] >= bb_min[0] && x[i] <= bb_max[0] && y[i] >= bb_min[1] && y[i] <= bb_max[1] &&
+                       z[i] >= bb_min[2] && z[i] <= bb_max[2];
+    if ((inside != 0) == (keep_inside != 0)) out_idx[o++] = (uint32_t)i;
+  }
+  return o;
+}
+
+void orc_deskew(const float* x, const float* y, const float* z, const float* t, size_t n, const double twist[6],
+                float* ox, float* oy, float* oz) {
+  for (size_t i = 0; i < n; i++) {
+    const double dt = (double)t[i];
+    const double xi[6] = {0.0, 0.0, 0.0, twist[3] * dt, twist[4] * dt, twist[5] * dt};
+    double T[12];
+    orc_se3_exp(xi, T); /* zero translation part: pure Exp_SO3(w dt) */
+    T[3] = twist[0] * dt; T[7] = twist[1] * dt; T[11] = twist[2] * dt;
+    transform_pt(T, x[i], y[i], z[i], &ox[i], &oy[i], &oz[i]);
+  }
+}
+
+void orc_preprocess(const float* x, const float* y, const float* z, size_t n, const orc_preprocess_params* p,
+                    uint32_t* idx_map, size_t* n_map, uint32_t* idx_icp, size_t* n_icp) {
+  /* every stage materialises its layer like the filter classes do, carrying the raw index along */
+  float* bx = (float*)malloc((n ? n : 1) * 3 * sizeof(float));
+  float *by = bx + n, *bz = bx + 2 * n;
+  uint32_t* cur = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+  uint32_t* sel = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+  size_t m = n;
+  for (size_t i = 0; i < n; i++) { cur[i] = (uint32_t)i; bx[i] = x[i]; by[i] = y[i]; bz[i] = z[i]; }
+#define ORC_APPLY(count_expr)                                                        \
+  do {                                                                               \
+    const size_t k_ = (count_expr);                                                  \
+    for (size_t i = 0; i < k_; i++) {                                                \
+      const uint32_t s_ = sel[i];                                                    \
+      cur[i] = cur[s_]; bx[i] = bx[s_]; by[i] = by[s_]; bz[i] = bz[s_];              \
+    }                                                                                \
+    m = k_;                                                                          \
+  } while (0)
+  /* (selection lists are ascending, so the in-place gather never overwrites an unread entry) */
+  ORC_APPLY(orc_decimate_first_point(bx, by, bz, m, p->decim_map_resolution, p->min_points_to_filter, p->index_mode, sel));
+  if (p->range_max > 0.f) ORC_APPLY(orc_filter_by_range(bx, by, bz, m, p->range_min, p->range_max, p->range_center, sel));
+  if (p->bbox_mode) ORC_APPLY(orc_filter_bbox(bx, by, bz, m, p->bbox_min, p->bbox_max, p->bbox_mode == 2, sel));
+  for (size_t i = 0; i < m; i++) idx_map[i] = cur[i];
+  *n_map = m;
+  ORC_APPLY(orc_decimate_first_point(bx, by, bz, m, p->decim_icp_resolution, p->min_points_to_filter, p->index_mode, sel));
+  for (size_t i = 0; i < m; i++) idx_icp[i] = cur[i];
+  *n_icp = m;
+#undef ORC_APPLY
+  free(bx); free(cur); free(sel);
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -221,6 +221,62 @@ int orc_icp_align(const orc_map* m, const float* lx, const float* ly, const floa
                   orc_icp_result* res, orc_icp_iter* trace /*nullable [max_iterations]*/,
                   orc_pairs_out* final_pairs /*nullable*/, int n_threads);
 
+/* ======================================================================================
+ * scan pre-processing and the incrementally updated local map.
+ * The filter classes live in mp2p_icp_filters / mola_metric_maps [U] (not vendored): restated
+ * from their published behaviour, anchored on the YAML that instantiates them.
+ * ==================================================================================== */
+
+/* HashedVoxelPointCloud::insertPointCloud via FilterMerge (lidar3d-default.yaml:362-368,
+ * input_layer_in_local_coordinates: true): every point is composed with the robot pose
+ * (CPose3D::composePoint, fp64, rounded to float) and offered to insertPoint in order; then,
+ * when remove_voxels_farther_than > 0 (yaml:238), every voxel whose index distance
+ * max(|dkx|,|dky|,|dkz|) to the voxel of the insertion pose exceeds
+ * ceil(remove_voxels_farther_than / voxel_size) is erased [U]. */
+void orc_map_insert_posed(orc_map* m, const float* x, const float* y, const float* z, size_t n, const double T[12],
+                          float remove_voxels_farther_than);
+
+/* FilterAdjustTimestamps (yaml:270-276): method 1 = MiddleIsZero (t -= (tmin+tmax)/2),
+ * 2 = EarliestIsZero (t -= tmin); then + time_offset.  float arithmetic [U].  In place. */
+enum { ORC_TS_NONE = 0, ORC_TS_MIDDLE_IS_ZERO = 1, ORC_TS_EARLIEST_IS_ZERO = 2 };
+void orc_adjust_timestamps(float* t, size_t n, int method, float time_offset);
+
+/* FilterDecimateVoxels, DecimateMethod::FirstPoint (yaml:285-292, 312-319): the first point (input order)
+ * that falls into each voxel of size `resolution` survives; an input smaller than min_points_to_filter is passed
+ * through.  out_idx receives the surviving input indices in ASCENDING order (upstream emits them in the iteration
+ * order of its hash container, which is implementation-defined; the set is the same).  Non-finite points are
+ * dropped.  Returns the number of survivors. */
+size_t orc_decimate_first_point(const float* x, const float* y, const float* z, size_t n, float resolution,
+                                uint32_t min_points_to_filter, int index_mode, uint32_t* out_idx);
+
+/* FilterByRange (yaml:297-302): keep range_min^2 <= |p-center|^2 <= range_max^2, float arithmetic.
+ * FilterBoundingBox (yaml:305-310): inside = min <= p <= max on every axis; keep_inside selects which side is
+ * emitted (the default pipeline keeps the OUTSIDE, `outside_pointcloud_layer`).  Index lists, ascending. */
+size_t orc_filter_by_range(const float* x, const float* y, const float* z, size_t n, float range_min, float range_max,
+                           const float center[3], uint32_t* out_idx);
+size_t orc_filter_bbox(const float* x, const float* y, const float* z, size_t n, const float bb_min[3],
+                       const float bb_max[3], int keep_inside, uint32_t* out_idx);
+
+/* FilterDeskew (yaml:328-350): with the constant twist (vx,vy,vz,wx,wy,wz) of the vehicle frame, every point is
+ * moved by the pose reached after its own time stamp: p' = Exp_SO3(w*t_i) * p + v*t_i  (fp64, rounded to float) [U]. */
+void orc_deskew(const float* x, const float* y, const float* z, const float* t, size_t n, const double twist[6],
+                float* ox, float* oy, float* oz);
+
+/* The 1st-pass chain of lidar3d-default.yaml:278-319 on one raw scan:
+ * decimate(res_map) -> by-range -> bounding box -> [map layer] -> decimate(res_icp) -> [icp layer].
+ * idx_map / idx_icp (each sized n) receive indices into the RAW scan, ascending. */
+typedef struct {
+  float decim_map_resolution, decim_icp_resolution; /* 0 = stage skipped */
+  uint32_t min_points_to_filter;
+  int32_t index_mode;
+  float range_min, range_max; /* range_max <= 0: FilterByRange skipped */
+  float range_center[3];
+  int32_t bbox_mode; /* 0 skipped, 1 keep outside, 2 keep inside */
+  float bbox_min[3], bbox_max[3];
+} orc_preprocess_params;
+void orc_preprocess(const float* x, const float* y, const float* z, size_t n, const orc_preprocess_params* p,
+                    uint32_t* idx_map, size_t* n_map, uint32_t* idx_icp, size_t* n_icp);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -36,6 +36,13 @@ class _MapParams(C.Structure):
                 ("ndt_min_points", C.c_uint32)]
 
 
+class _PreprocessParams(C.Structure):
+    _fields_ = [("decim_map_resolution", C.c_float), ("decim_icp_resolution", C.c_float),
+                ("min_points_to_filter", C.c_uint32), ("index_mode", C.c_int32), ("range_min", C.c_float),
+                ("range_max", C.c_float), ("range_center", C.c_float * 3), ("bbox_mode", C.c_int32),
+                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3)]
+
+
 class _MatchStats(C.Structure):
     _fields_ = [("potential_pairings", C.c_uint64), ("n_candidates", C.c_uint64), ("n_voxels_hit", C.c_uint64)]
 
@@ -131,6 +138,17 @@ def lib():
                                     C.POINTER(_Prior), C.POINTER(_ICPResult), C.POINTER(_ICPIter),
                                     C.POINTER(_PairsOut), C.c_int]
         L.orc_max_threads.restype = C.c_int
+        L.orc_map_insert_posed.argtypes = [C.c_void_p, _FP, _FP, _FP, C.c_size_t, _DP, C.c_float]
+        L.orc_adjust_timestamps.argtypes = [_FP, C.c_size_t, C.c_int, C.c_float]
+        L.orc_decimate_first_point.restype = C.c_size_t
+        L.orc_decimate_first_point.argtypes = [_FP, _FP, _FP, C.c_size_t, C.c_float, C.c_uint32, C.c_int, _UP]
+        L.orc_filter_by_range.restype = C.c_size_t
+        L.orc_filter_by_range.argtypes = [_FP, _FP, _FP, C.c_size_t, C.c_float, C.c_float, _FP, _UP]
+        L.orc_filter_bbox.restype = C.c_size_t
+        L.orc_filter_bbox.argtypes = [_FP, _FP, _FP, C.c_size_t, _FP, _FP, C.c_int, _UP]
+        L.orc_deskew.argtypes = [_FP, _FP, _FP, _FP, C.c_size_t, _DP, _FP, _FP, _FP]
+        L.orc_preprocess.argtypes = [_FP, _FP, _FP, C.c_size_t, C.POINTER(_PreprocessParams), _UP,
+                                     C.POINTER(C.c_size_t), _UP, C.POINTER(C.c_size_t)]
         for name in ("orc_pose_from_ypr", "orc_pose_to_ypr", "orc_se3_exp", "orc_se3_log", "orc_pose_inverse"):
             getattr(L, name).argtypes = [_DP, _DP]
         L.orc_so3_log.argtypes = [_DP, _DP]
@@ -203,6 +221,14 @@ class Map:
         xyz = np.asarray(xyz, dtype=np.float32)
         x, y, z = _f32(xyz[:, 0]), _f32(xyz[:, 1]), _f32(xyz[:, 2])
         lib().orc_map_insert(self._h, _fp(x), _fp(y), _fp(z), len(x))
+        return self
+
+    def insert_posed(self, xyz, T, remove_voxels_farther_than=0.0):
+        """FilterMerge + insertPointCloud + far-voxel removal (orc_map_insert_posed)."""
+        xyz = np.asarray(xyz, dtype=np.float32)
+        x, y, z = _f32(xyz[:, 0]), _f32(xyz[:, 1]), _f32(xyz[:, 2])
+        T = np.ascontiguousarray(np.asarray(T, np.float64).reshape(-1)[:12])
+        lib().orc_map_insert_posed(self._h, _fp(x), _fp(y), _fp(z), len(x), _dp(T), float(remove_voxels_farther_than))
         return self
 
     @property
@@ -411,3 +437,65 @@ def icp_align(m: Map, local_xyz, T_guess, p: ICPParams, prior=None, n_threads=1,
         out["pairs"] = dict(local_idx=li[:k].copy(), global_idx=gi[:k].copy(),
                             global_xyz=np.stack([gx[:k], gy[:k], gz[:k]], 1), d2=d2[:k].copy())
     return out
+
+
+# ---- scan pre-processing ------------------------------------------------------------------
+TS_NONE, TS_MIDDLE_IS_ZERO, TS_EARLIEST_IS_ZERO = 0, 1, 2
+
+
+def _xyz_cols(xyz):
+    xyz = np.asarray(xyz, dtype=np.float32)
+    return _f32(xyz[:, 0]), _f32(xyz[:, 1]), _f32(xyz[:, 2])
+
+
+def adjust_timestamps(t, method=TS_MIDDLE_IS_ZERO, time_offset=0.0):
+    t = _f32(np.array(t, dtype=np.float32, copy=True))
+    lib().orc_adjust_timestamps(_fp(t), len(t), int(method), float(time_offset))
+    return t
+
+
+def decimate_first_point(xyz, resolution, min_points_to_filter=0, index_mode=INDEX_FLOOR):
+    x, y, z = _xyz_cols(xyz)
+    out = np.zeros(max(len(x), 1), np.uint32)
+    k = lib().orc_decimate_first_point(_fp(x), _fp(y), _fp(z), len(x), float(resolution), int(min_points_to_filter),
+                                       int(index_mode), _up(out))
+    return out[:k].copy()
+
+
+def filter_by_range(xyz, range_min, range_max, center=(0.0, 0.0, 0.0)):
+    x, y, z = _xyz_cols(xyz)
+    out = np.zeros(max(len(x), 1), np.uint32)
+    c = _f32(np.asarray(center, np.float32))
+    k = lib().orc_filter_by_range(_fp(x), _fp(y), _fp(z), len(x), float(range_min), float(range_max), _fp(c), _up(out))
+    return out[:k].copy()
+
+
+def filter_bbox(xyz, bb_min, bb_max, keep_inside=False):
+    x, y, z = _xyz_cols(xyz)
+    out = np.zeros(max(len(x), 1), np.uint32)
+    mn, mx = _f32(np.asarray(bb_min, np.float32)), _f32(np.asarray(bb_max, np.float32))
+    k = lib().orc_filter_bbox(_fp(x), _fp(y), _fp(z), len(x), _fp(mn), _fp(mx), int(bool(keep_inside)), _up(out))
+    return out[:k].copy()
+
+
+def deskew(xyz, t, twist):
+    x, y, z = _xyz_cols(xyz)
+    t = _f32(t)
+    tw = np.ascontiguousarray(twist, dtype=np.float64)
+    ox, oy, oz = (np.zeros(len(x), np.float32) for _ in range(3))
+    lib().orc_deskew(_fp(x), _fp(y), _fp(z), _fp(t), len(x), _dp(tw), _fp(ox), _fp(oy), _fp(oz))
+    return np.stack([ox, oy, oz], 1)
+
+
+def preprocess(xyz, decim_map_resolution, decim_icp_resolution, min_points_to_filter=2000, index_mode=INDEX_FLOOR,
+               range_min=0.0, range_max=0.0, range_center=(0.0, 0.0, 0.0), bbox_mode=0, bbox_min=(0, 0, 0),
+               bbox_max=(0, 0, 0)):
+    """1st-pass filter chain of lidar3d-default.yaml:278-319 -> (idx_map, idx_icp), indices into the raw scan."""
+    x, y, z = _xyz_cols(xyz)
+    p = _PreprocessParams(float(decim_map_resolution), float(decim_icp_resolution), int(min_points_to_filter),
+                          int(index_mode), float(range_min), float(range_max), (C.c_float * 3)(*map(float, range_center)),
+                          int(bbox_mode), (C.c_float * 3)(*map(float, bbox_min)), (C.c_float * 3)(*map(float, bbox_max)))
+    im, ii = np.zeros(max(len(x), 1), np.uint32), np.zeros(max(len(x), 1), np.uint32)
+    nm, ni = C.c_size_t(0), C.c_size_t(0)
+    lib().orc_preprocess(_fp(x), _fp(y), _fp(z), len(x), C.byref(p), _up(im), C.byref(nm), _up(ii), C.byref(ni))
+    return im[:nm.value].copy(), ii[:ni.value].copy()

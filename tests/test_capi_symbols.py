@@ -57,10 +57,14 @@ int main(void){
     sizeof(mh_gn_step), sizeof(mh_icp_params), sizeof(mh_icp_result));
   printf("%zu %zu %zu %zu\n", sizeof(mh_icp_iter), offsetof(mh_icp_params, gn), offsetof(mh_icp_params, hook_checkpoint),
     offsetof(mh_icp_result, match_kernel_ms));
+  printf("%zu %zu %zu\n", sizeof(mh_preprocess_params), offsetof(mh_preprocess_params, bbox_mode),
+    offsetof(mh_preprocess_params, time_offset));
   return 0; }''')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
-    a, b = subprocess.check_output([str(exe)], text=True).strip().splitlines()
+    a, b, c = subprocess.check_output([str(exe)], text=True).strip().splitlines()
+    assert [int(v) for v in c.split()] == [C.sizeof(capi.PreprocessParams), capi.PreprocessParams.bbox_mode.offset,
+                                           capi.PreprocessParams.time_offset.offset]
     sizes = [int(v) for v in a.split()]
     mirrors = [capi.MapParams, capi.MapInfo, capi.PairsOut, capi.MatchInfo, capi.PairsPt2Pt, capi.PairsPt2Pl, capi.Prior,
                capi.GNParamsC, capi.GNStep, capi.ICPParamsC, capi.ICPResult]

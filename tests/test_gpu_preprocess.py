@@ -1,0 +1,165 @@
+"""-m gpu: device-side scan pre-processing and the device-resident incremental local map (row f2),
+through the C ABI, against the CPU oracle.  Index sets, voxel contents and source indices are bit-exact; de-skewed
+coordinates are floating point (fp64 sin/cos differ by an ulp between libm and the device) and are held to 1 float ulp."""
+import numpy as np
+import pytest
+
+from mola_lidar_odometry_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _raw(seed, small_workload, with_nan=True):
+    rng = np.random.default_rng(seed)
+    xyz = small_workload.scan_xyz.copy()
+    if with_nan:
+        xyz[11] = [np.nan, 1, 1]
+        xyz[500] = [1, -np.inf, 1]
+    t = (1.7e4 + np.sort(rng.uniform(0.0, 0.1, len(xyz)))).astype(np.float32)
+    return xyz, t
+
+
+PP = dict(decim_map_resolution=0.35, decim_icp_resolution=1.1, min_points_to_filter=300, range_min=2.0, range_max=70.0,
+          bbox_mode=1, bbox_min=(-8.0, -8.0, -1.8), bbox_max=(8.0, 8.0, 4.0))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_preprocess_bit_exact(ctx, oracle, small_workload, mode):
+    xyz, t = _raw(1, small_workload)
+    raw = capi.Scan(ctx, xyz).set_timestamps(t)
+    om, oi = capi.Scan(ctx), capi.Scan(ctx)
+    raw.preprocess(capi.preprocess_params(index_mode=mode, timestamp_method=capi.TS_MIDDLE_IS_ZERO, time_offset=0.01, **PP),
+                   om, oi)
+    im, ii = oracle.preprocess(xyz, index_mode=mode, **PP)
+    ta = oracle.adjust_timestamps(t, oracle.TS_MIDDLE_IS_ZERO, 0.01)
+    assert 0 < len(ii) < len(im) < len(xyz)
+    for scan, idx in ((om, im), (oi, ii)):
+        d = scan.download()
+        assert scan.n == len(idx)
+        np.testing.assert_array_equal(d["src_idx"], idx)
+        np.testing.assert_array_equal(d["xyz"], xyz[idx])
+        np.testing.assert_array_equal(d["t"], ta[idx])
+
+
+def test_preprocess_edge_cases(ctx, oracle, small_workload):
+    xyz, t = _raw(2, small_workload, with_nan=False)
+    # smaller than minimum_input_points_to_filter: no decimation, predicates still apply; no time stamps attached
+    few = xyz[:250]
+    raw = capi.Scan(ctx, few)
+    om, oi = capi.Scan(ctx), capi.Scan(ctx)
+    raw.preprocess(capi.preprocess_params(**PP), om, oi)
+    im, ii = oracle.preprocess(few, **PP)
+    np.testing.assert_array_equal(om.download()["src_idx"], im)
+    np.testing.assert_array_equal(oi.download()["src_idx"], ii)
+    np.testing.assert_array_equal(om.download()["t"], np.zeros(len(im), np.float32))
+    # all stages off: pass-through; EarliestIsZero
+    raw = capi.Scan(ctx, xyz).set_timestamps(t)
+    raw.preprocess(capi.preprocess_params(0.0, 0.0, timestamp_method=capi.TS_EARLIEST_IS_ZERO), om, None)
+    d = om.download()
+    np.testing.assert_array_equal(d["xyz"], xyz)
+    np.testing.assert_array_equal(d["t"], oracle.adjust_timestamps(t, oracle.TS_EARLIEST_IS_ZERO))
+    # empty input
+    raw = capi.Scan(ctx)
+    raw.preprocess(capi.preprocess_params(**PP), om, oi)
+    assert om.n == 0 and oi.n == 0
+    # everything filtered out
+    raw = capi.Scan(ctx, xyz)
+    raw.preprocess(capi.preprocess_params(0.3, 1.0, range_min=1e4, range_max=2e4), om, oi)
+    assert om.n == 0 and oi.n == 0
+    with pytest.raises(capi.MolahipError):
+        raw.preprocess(capi.preprocess_params(**PP), om, om)
+    with pytest.raises(capi.MolahipError):
+        capi.Scan(ctx, xyz).set_timestamps(t[:10])
+
+
+def test_deskew(ctx, oracle, small_workload):
+    xyz, t = _raw(3, small_workload, with_nan=False)
+    raw = capi.Scan(ctx, xyz).set_timestamps(t)
+    sk, out = capi.Scan(ctx), capi.Scan(ctx)
+    raw.preprocess(capi.preprocess_params(0.35, 0.0, timestamp_method=capi.TS_MIDDLE_IS_ZERO), sk, None)
+    d0 = sk.download()
+    tw = np.array([14.0, -0.3, 0.05, 0.01, -0.02, 0.7])
+    ref = oracle.deskew(d0["xyz"], d0["t"], tw)
+    sk.deskew(tw, out)
+    d = out.download()
+    np.testing.assert_array_equal(d["src_idx"], d0["src_idx"])
+    np.testing.assert_array_equal(d["t"], d0["t"])
+    ulp = np.spacing(np.abs(ref).astype(np.float32))
+    assert np.all(np.abs(d["xyz"] - ref) <= ulp)
+    assert np.mean(d["xyz"] == ref) > 0.999
+    assert np.abs(d["xyz"] - d0["xyz"]).max() > 0.5  # the twist really moved points
+    # the skewed layer is untouched and can be de-skewed again with another twist (LidarOdometry.cpp:992-999)
+    sk.deskew(0.5 * tw, out)
+    assert np.all(np.abs(out.download()["xyz"] - oracle.deskew(d0["xyz"], d0["t"], 0.5 * tw)) <= ulp)
+    np.testing.assert_array_equal(sk.download()["xyz"], d0["xyz"])
+    # skip_deskew / no time stamps: copy
+    sk.deskew(None, out)
+    np.testing.assert_array_equal(out.download()["xyz"], d0["xyz"])
+    nots = capi.Scan(ctx, xyz)
+    nots.deskew(tw, out)
+    np.testing.assert_array_equal(out.download()["xyz"], xyz)
+
+
+def _assert_maps_equal(g, o):
+    for k in ("vox_keys", "vox_first", "vox_count", "src_idx", "xyz"):
+        np.testing.assert_array_equal(g[k], o[k], err_msg=k)
+
+
+@pytest.mark.parametrize("vs,cap,far", [(1.0, 20, 0.0), (1.0, 20, 45.0), (0.5, 4, 30.0)])
+def test_map_insert_keyframes_bit_exact(ctx, oracle, vs, cap, far):
+    """A drive of key-frames: every update (posed insertion after the stored content, cap, far-voxel removal)
+    leaves exactly the voxel contents and source indices of the per-point CPU insertion."""
+    scene = synth.make_scene(777, 80.0, 12)
+    g, o = capi.Map(ctx, vs, cap), oracle.Map(vs, cap)
+    offered = 0
+    for k in range(6):
+        pose = [-40.0 + 14.0 * k, 0.6 * np.sin(k), synth.SENSOR_H, 0.05 * k, 0.002 * k, -0.001 * k]
+        xyz = synth.make_scan(scene, pose, rings=32, azimuths=400, seed=100 + k)
+        T = synth.pose_from_ypr(pose)
+        g.insert(capi.Scan(ctx, xyz), T, far)
+        o.insert_posed(xyz, T, far)
+        offered += len(xyz)
+        i = g.info()
+        assert (i.n_points, i.n_voxels, i.n_offered) == (o.num_points, o.num_voxels, offered)
+        _assert_maps_equal(g.download(), o.dump())
+        mn, mx = o.bbox()
+        np.testing.assert_array_equal(np.array(i.bbox_min), mn)
+        np.testing.assert_array_equal(np.array(i.bbox_max), mx)
+    if far:
+        assert o.num_points < oracle.Map(vs, cap).insert_posed(xyz, T).num_points * 6
+    # the updated map answers NN queries like the oracle's
+    q = capi.Scan(ctx, xyz)
+    got = capi.nn_search(g, q, T, 1.5)
+    ref = oracle.match_points(o, xyz, T, 1.5)
+    np.testing.assert_array_equal(got["local_idx"], ref["local_idx"])
+    np.testing.assert_array_equal(got["global_idx"], ref["global_idx"])
+    np.testing.assert_array_equal(got["d2"], ref["d2"])
+
+
+def test_map_insert_ndt_and_empty(ctx, oracle):
+    scene = synth.make_scene(778, 60.0, 8)
+    kw = dict(min_distance_between_points=0.1, ndt_max_eigen_ratio=0.03, ndt_min_points=4)
+    g, o = capi.Map(ctx, 2.0, 12, 0, 0.1, 0.03, 4), oracle.Map(2.0, 12, 0, **kw)
+    g.insert(capi.Scan(ctx), np.eye(4)[:3], 10.0)  # empty key-frame into an empty map
+    assert g.info().n_points == 0
+    for k in range(3):
+        pose = [-10.0 + 9.0 * k, 0.3 * k, synth.SENSOR_H, 0.1 * k, 0.0, 0.0]
+        xyz = synth.make_scan(scene, pose, rings=32, azimuths=300, seed=200 + k)
+        T = synth.pose_from_ypr(pose)
+        g.insert(capi.Scan(ctx, xyz), T, 35.0)
+        o.insert_posed(xyz, T, 35.0)
+        _assert_maps_equal(g.download(), o.dump())
+        gn, on = g.download_ndt(), o.dump_ndt()
+        np.testing.assert_array_equal(gn["is_plane"], on["is_plane"])
+        np.testing.assert_allclose(gn["centroid"], on["centroid"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(gn["normal"], on["normal"], rtol=0, atol=1e-5)
+    assert g.info().n_planes > 10
+    g.insert(capi.Scan(ctx), T, 35.0)  # empty key-frame: nothing changes
+    _assert_maps_equal(g.download(), o.dump())
