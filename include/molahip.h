@@ -198,6 +198,9 @@ MH_API mh_status mh_scan_preprocess(const mh_scan* raw, const mh_preprocess_para
  * silently_ignore_no_timestamps).  `out` must differ from `in`; it is what align() and mh_map_insert() consume, and
  * `in` stays valid for the re-de-skew inside the ICP loop (LidarOdometry.cpp:992-999) with no host round trip. */
 MH_API mh_status mh_scan_deskew(const mh_scan* in, const double twist[6], mh_scan* out);
+/* Axis-aligned bounding box of the finite points (CPointsMap::boundingBox [U], used by the sensor-range estimate at
+ * LidarOdometry.cpp:1503-1508, 1517-1534).  n_finite (nullable) = number of finite points; zeros for an empty scan. */
+MH_API mh_status mh_scan_bbox(const mh_scan* scan, float bb_min[3], float bb_max[3], uint64_t* n_finite);
 /* Copy a scan to HOST arrays (any may be NULL; t / src_idx are zero-filled when the scan has none). */
 MH_API mh_status mh_scan_download(const mh_scan* scan, float* x, float* y, float* z, float* t, uint32_t* src_idx);
 

@@ -143,6 +143,7 @@ _SIGNATURES = {
     "mh_scan_preprocess": (C.c_int32, [C.c_void_p, C.POINTER(PreprocessParams), C.c_void_p, C.c_void_p]),
     "mh_scan_deskew": (C.c_int32, [C.c_void_p, _DP, C.c_void_p]),
     "mh_scan_download": (C.c_int32, [C.c_void_p, _FP, _FP, _FP, _FP, _UP]),
+    "mh_scan_bbox": (C.c_int32, [C.c_void_p, _FP, _FP, C.POINTER(C.c_uint64)]),
     "mh_nn_search": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_double, C.c_double, C.POINTER(PairsOut), C.c_int32,
                                  C.POINTER(MatchInfo)]),
     "mh_nn_search_dense": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -347,6 +348,12 @@ class Scan:
         tw = None if twist is None else np.ascontiguousarray(twist, dtype=np.float64)
         _chk(lib().mh_scan_deskew(self._h, tw.ctypes.data_as(_DP) if tw is not None else None, out._h))
         return out
+
+    def bbox(self):
+        mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        k = C.c_uint64()
+        _chk(lib().mh_scan_bbox(self._h, mn.ctypes.data_as(_FP), mx.ctypes.data_as(_FP), C.byref(k)))
+        return mn, mx, int(k.value)
 
     def download(self):
         n = len(self)

@@ -141,6 +141,38 @@ __global__ void k_pp_compact(const float* __restrict__ x, const float* __restric
   osrc[o] = src ? src[i] : i;
 }
 
+// counters[0..2] = min, [3..5] = max (ordered uints), [6] = finite count
+__global__ void k_pp_bbox(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                          uint32_t n, uint32_t* __restrict__ counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  float p[3] = {0.f, 0.f, 0.f};
+  if (i < n) {
+    p[0] = x[i]; p[1] = y[i]; p[2] = z[i];
+    ok = isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]);
+  }
+  uint32_t mn[3], mx[3];
+  for (int a = 0; a < 3; a++) {
+    mn[a] = ok ? f2ord(p[a]) : 0xFFFFFFFFu;
+    mx[a] = ok ? f2ord(p[a]) : 0u;
+  }
+  uint32_t cnt = ok ? 1u : 0u;
+  for (int off = 32; off > 0; off >>= 1) {
+    for (int a = 0; a < 3; a++) {
+      mn[a] = min(mn[a], (uint32_t)__shfl_xor((int)mn[a], off));
+      mx[a] = max(mx[a], (uint32_t)__shfl_xor((int)mx[a], off));
+    }
+    cnt += (uint32_t)__shfl_xor((int)cnt, off);
+  }
+  if ((threadIdx.x & 63) == 0 && cnt) {
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&counters[a], mn[a]);
+      atomicMax(&counters[3 + a], mx[a]);
+    }
+    atomicAdd(&counters[6], cnt);
+  }
+}
+
 struct Twist { double v[6]; };
 
 __global__ void k_pp_deskew(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
@@ -313,6 +345,30 @@ mh_status mh_scan_deskew(const mh_scan* in, const double twist[6], mh_scan* out)
     MH_HIP(hipMemcpyAsync((void*)out->y, in->y, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     MH_HIP(hipMemcpyAsync((void*)out->z, in->z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
+  return MH_OK;
+}
+
+mh_status mh_scan_bbox(const mh_scan* scan, float bb_min[3], float bb_max[3], uint64_t* n_finite) {
+  MH_REQUIRE(scan && bb_min && bb_max, "null argument");
+  mh_ctx* ctx = scan->ctx;
+  MH_TRY(set_device(ctx));
+  hipStream_t s = ctx->stream;
+  uint32_t h[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+  if (scan->n) {
+    MH_TRY(ctx->build_e.reserve(64));
+    uint32_t* counters = ctx->build_e.as<uint32_t>();
+    MH_HIP(hipMemcpyAsync(counters, h, sizeof(h), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pp_bbox, dim3(nblk(scan->n, 256)), dim3(256), 0, s, scan->x, scan->y, scan->z, (uint32_t)scan->n,
+                       counters);
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+  }
+  for (int a = 0; a < 3; a++) {
+    bb_min[a] = h[6] ? [](uint32_t u) { u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &u, 4); return f; }(h[a]) : 0.f;
+    bb_max[a] = h[6] ? [](uint32_t u) { u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &u, 4); return f; }(h[3 + a]) : 0.f;
+  }
+  if (n_finite) *n_finite = h[6];
   return MH_OK;
 }
 

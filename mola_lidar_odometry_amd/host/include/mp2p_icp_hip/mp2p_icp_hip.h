@@ -49,6 +49,9 @@ struct CPose3D {
   CPose3D operator-(const CPose3D& b) const;  // inverse composition: b^-1 (+) a
   double translationNorm() const;
   double rotationAngle() const;  // |SO(3) log|
+  void so3Log(double w[3]) const;  // mrpt::poses::Lie::SO<3>::log of the rotation part
+  // (Exp_SO3(w), t): the pose a constant twist reaches after one unit of time in FilterDeskew's model
+  static CPose3D FromRotVecAndTranslation(const double w[3], const double t[3]);
 };
 struct CPose3DPDFGaussian {
   CPose3D mean;
@@ -148,6 +151,25 @@ struct PointCloud : Layer {
   size_t size() const { return x.size(); }
   void insertPoint(float px, float py, float pz) { x.push_back(px); y.push_back(py); z.push_back(pz); }
 };
+// a point layer that lives on the device (mh_scan): what the device-side filters produce and align() consumes
+// without any host copy
+class DeviceContext;
+class DevicePointCloud : public Layer {
+ public:
+  explicit DevicePointCloud(std::shared_ptr<DeviceContext> ctx);
+  ~DevicePointCloud() override;
+  DevicePointCloud(const DevicePointCloud&) = delete;
+  size_t size() const;
+  mh_scan* handle() const { return scan_; }
+  void setPoints(const float* x, const float* y, const float* z, size_t n);
+  void setTimestamps(const float* t, size_t n);
+  void boundingBox(float mn[3], float mx[3]) const;
+  void download(std::vector<float>& x, std::vector<float>& y, std::vector<float>& z) const;
+
+ private:
+  std::shared_ptr<DeviceContext> ctx_;
+  mh_scan* scan_ = nullptr;
+};
 // mola::HashedVoxelPointCloud stand-in, device resident (NearestNeighborsCapable role only)
 class HashedVoxelPointCloud : public Layer {
  public:
@@ -158,6 +180,9 @@ class HashedVoxelPointCloud : public Layer {
   ~HashedVoxelPointCloud() override;
   void setPoints(const float* x, const float* y, const float* z, size_t n);  // clear + insertPoint for each
   void insertPoints(const float* x, const float* y, const float* z, size_t n);  // keeps a host copy, rebuilds
+  // FilterMerge + insertPointCloud + far-voxel removal, all on the device (mh_map_insert; lidar3d-default.yaml:362-368)
+  void insertPointCloud(const DevicePointCloud& pc, const CPose3D& robot_pose, float remove_voxels_farther_than);
+  void clear();
   size_t size() const;
   size_t voxelCount() const;
   mh_map* handle() const { return map_; }
@@ -166,7 +191,6 @@ class HashedVoxelPointCloud : public Layer {
  private:
   std::shared_ptr<DeviceContext> ctx_;
   mh_map* map_ = nullptr;
-  std::vector<float> hx_, hy_, hz_;
 };
 // mola::NDT stand-in (lidar3d-ndt.yaml:236-254): the same device map plus per-voxel mean / covariance / eigen
 // statistics, i.e. additionally NearestPlaneCapable for Matcher_Point2Plane
@@ -327,12 +351,15 @@ class ICP {
   void initialize_matchers(const Config& seq);
   void initialize_solvers(const Config& seq);
   bool lastAlignUsedFusedPath() const { return last_fused_; }
+  // false: Results::finalPairings stays empty in the fused path (the odometry driver never reads it)
+  void setKeepFinalPairings(bool v) { keep_pairings_ = v; }
   void forceGenericPath(bool v) { force_generic_ = v; }
 
  private:
   bool can_fuse() const;
-  void align_fused(const PointCloud& local, const HashedVoxelPointCloud& global, const CPose3D& guess, const Parameters& p,
-                   Results& result, const std::optional<CPose3DPDFGaussianInf>& prior);
+  void align_fused(const PointCloud* local, const DevicePointCloud* dev_local, const HashedVoxelPointCloud& global,
+                   const CPose3D& guess, const Parameters& p, Results& result,
+                   const std::optional<CPose3DPDFGaussianInf>& prior);
   void align_generic(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const CPose3D& guess, const Parameters& p,
                      Results& result, const std::optional<CPose3DPDFGaussianInf>& prior);
   void realize_iteration(uint32_t k);
@@ -348,7 +375,7 @@ class ICP {
   ParameterSource* source_ = nullptr;
   ParameterSource own_source_;
   mh_scan* scan_ = nullptr;
-  bool last_fused_ = false, force_generic_ = false;
+  bool last_fused_ = false, force_generic_ = false, keep_pairings_ = true;
 };
 
 // class factory by name (mrpt::rtti::classFactory stand-in): "mp2p_icp::X" and "mp2p_icp_hip::X" both resolve

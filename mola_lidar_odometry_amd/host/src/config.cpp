@@ -270,8 +270,34 @@ Config parse_flow_map(const std::string& t) {  // {a: b, c: "d"}
   return c;
 }
 
+Config parse_scalar_or_flow(const std::string& t);
+
+Config parse_flow_seq(const std::string& t) {  // [a, 'b', max(1, c)]: commas inside quotes / brackets do not split
+  Config c;
+  c.kind = Config::Kind::Seq;
+  const std::string body = trim(t.substr(1, t.size() - 2));
+  size_t i = 0;
+  while (i < body.size()) {
+    size_t j = i;
+    bool sq = false, dq = false;
+    int depth = 0;
+    while (j < body.size() && (sq || dq || depth > 0 || body[j] != ',')) {
+      if (body[j] == '\'' && !dq) sq = !sq;
+      if (body[j] == '"' && !sq) dq = !dq;
+      if (!sq && !dq && (body[j] == '(' || body[j] == '{' || body[j] == '[')) depth++;
+      if (!sq && !dq && (body[j] == ')' || body[j] == '}' || body[j] == ']')) depth--;
+      j++;
+    }
+    const std::string item = trim(body.substr(i, j - i));
+    if (!item.empty()) c.seq.push_back(parse_scalar_or_flow(item));
+    i = j + 1;
+  }
+  return c;
+}
+
 Config parse_scalar_or_flow(const std::string& t) {
   if (t.size() >= 2 && t.front() == '{' && t.back() == '}') return parse_flow_map(t);
+  if (t.size() >= 2 && t.front() == '[' && t.back() == ']') return parse_flow_seq(t);
   Config c;
   c.kind = Config::Kind::Scalar;
   c.scalar = substitute_env(unquote(t));

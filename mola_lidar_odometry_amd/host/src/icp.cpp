@@ -60,6 +60,54 @@ double CPose3D::rotationAngle() const {
   return atan2(0.5 * s2, cth);
 }
 
+void CPose3D::so3Log(double w[3]) const {
+  const double vx = T[9] - T[6], vy = T[2] - T[8], vz = T[4] - T[1];
+  const double s2 = std::sqrt(vx * vx + vy * vy + vz * vz);  // 2 sin(th)
+  const double th = rotationAngle();
+  if (th < 1e-7) {
+    const double k = 0.5 * (1.0 + th * th / 6.0);
+    w[0] = k * vx; w[1] = k * vy; w[2] = k * vz;
+    return;
+  }
+  if (M_PI - th > 1e-6) {
+    const double k = th / s2;
+    w[0] = k * vx; w[1] = k * vy; w[2] = k * vz;
+    return;
+  }
+  // th ~ pi: R + I ~ 2 n n^T
+  const double d[3] = {T[0], T[5], T[10]};
+  const int k = (d[0] >= d[1] && d[0] >= d[2]) ? 0 : (d[1] >= d[2] ? 1 : 2);
+  double n[3];
+  const double nk = std::sqrt(std::max(0.0, 0.5 * (d[k] + 1.0)));
+  for (int j = 0; j < 3; j++) n[j] = (j == k) ? nk : 0.25 * (T[k * 4 + j] + T[j * 4 + k]) / nk;
+  const double dot = n[0] * vx + n[1] * vy + n[2] * vz;
+  const double nn = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  const double sc = (dot < 0.0 ? -th : th) / nn;
+  for (int j = 0; j < 3; j++) w[j] = sc * n[j];
+}
+
+CPose3D CPose3D::FromRotVecAndTranslation(const double w[3], const double t[3]) {
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+  double a, b;  // sin(th)/th, (1-cos th)/th^2
+  if (th < 1e-2) {
+    a = 1.0 - th2 / 6.0 * (1.0 - th2 / 20.0 * (1.0 - th2 / 42.0));
+    b = 0.5 - th2 / 24.0 * (1.0 - th2 / 30.0 * (1.0 - th2 / 56.0));
+  } else {
+    const double sh = std::sin(0.5 * th);
+    a = std::sin(th) / th;
+    b = 2.0 * sh * sh / th2;
+  }
+  const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  const double xx = w[0] * w[0], yy = w[1] * w[1], zz = w[2] * w[2], xy = w[0] * w[1], xz = w[0] * w[2], yz = w[1] * w[2];
+  const double W2[9] = {-(yy + zz), xy, xz, xy, -(xx + zz), yz, xz, yz, -(xx + yy)};
+  CPose3D p;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) p.T[i * 4 + j] = ((i == j) ? 1.0 : 0.0) + a * W[i * 3 + j] + b * W2[i * 3 + j];
+    p.T[i * 4 + 3] = t[i];
+  }
+  return p;
+}
+
 // |v| and |w| of log_SE3(d) = [V^-1 t; w]  
 static void se3_log_norms(const CPose3D& d, double& nt, double& nr) {
   const double* T = d.T;
@@ -143,19 +191,45 @@ size_t NDT::planeCount() const {
 HashedVoxelPointCloud::~HashedVoxelPointCloud() { mh_map_destroy(map_); }
 
 void HashedVoxelPointCloud::setPoints(const float* x, const float* y, const float* z, size_t n) {
-  hx_.assign(x, x + n);
-  hy_.assign(y, y + n);
-  hz_.assign(z, z + n);
-  check(mh_map_build(map_, hx_.data(), hy_.data(), hz_.data(), n, MH_MEM_HOST), "mh_map_build");
+  check(mh_map_build(map_, x, y, z, n, MH_MEM_HOST), "mh_map_build");
 }
 
 void HashedVoxelPointCloud::insertPoints(const float* x, const float* y, const float* z, size_t n) {
-  // insertPoint semantics need every earlier point (per-voxel cap in insertion order); until the device map
-  // grows an incremental insert the host keeps the offered points and rebuilds.
-  hx_.insert(hx_.end(), x, x + n);
-  hy_.insert(hy_.end(), y, y + n);
-  hz_.insert(hz_.end(), z, z + n);
-  check(mh_map_build(map_, hx_.data(), hy_.data(), hz_.data(), hx_.size(), MH_MEM_HOST), "mh_map_build");
+  // insertPoint for each point after everything already stored: the device-resident incremental update
+  DevicePointCloud pc(ctx_);
+  pc.setPoints(x, y, z, n);
+  insertPointCloud(pc, CPose3D(), 0.f);
+}
+
+void HashedVoxelPointCloud::insertPointCloud(const DevicePointCloud& pc, const CPose3D& robot_pose,
+                                             float remove_voxels_farther_than) {
+  check(mh_map_insert(map_, pc.handle(), robot_pose.T, remove_voxels_farther_than), "mh_map_insert");
+}
+
+void HashedVoxelPointCloud::clear() { check(mh_map_build(map_, nullptr, nullptr, nullptr, 0, MH_MEM_HOST), "mh_map_build"); }
+
+DevicePointCloud::DevicePointCloud(std::shared_ptr<DeviceContext> ctx) : ctx_(std::move(ctx)) {
+  check(mh_scan_create(ctx_->get(), nullptr, nullptr, nullptr, 0, MH_MEM_HOST, &scan_), "mh_scan_create");
+}
+DevicePointCloud::~DevicePointCloud() { mh_scan_destroy(scan_); }
+size_t DevicePointCloud::size() const {
+  uint64_t n = 0;
+  check(mh_scan_size(scan_, &n), "mh_scan_size");
+  return n;
+}
+void DevicePointCloud::setPoints(const float* x, const float* y, const float* z, size_t n) {
+  check(mh_scan_update(scan_, x, y, z, n, MH_MEM_HOST), "mh_scan_update");
+}
+void DevicePointCloud::setTimestamps(const float* t, size_t n) {
+  check(mh_scan_set_timestamps(scan_, t, n, MH_MEM_HOST), "mh_scan_set_timestamps");
+}
+void DevicePointCloud::boundingBox(float mn[3], float mx[3]) const {
+  check(mh_scan_bbox(scan_, mn, mx, nullptr), "mh_scan_bbox");
+}
+void DevicePointCloud::download(std::vector<float>& x, std::vector<float>& y, std::vector<float>& z) const {
+  const size_t n = size();
+  x.resize(n); y.resize(n); z.resize(n);
+  check(mh_scan_download(scan_, x.data(), y.data(), z.data(), nullptr, nullptr), "mh_scan_download");
 }
 
 size_t HashedVoxelPointCloud::size() const {
@@ -462,16 +536,20 @@ void ICP::align(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const
   if (can_fuse()) {
     auto m = std::static_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_.back());
     last_fused_ = true;
-    align_fused(local_layer(pcLocal, m->pointLayerMatches[0].local), global_layer(pcGlobal, m->pointLayerMatches[0].global), g, p,
-                result, prior);
+    const std::string& lname = m->pointLayerMatches[0].local;
+    auto it = pcLocal.layers.find(lname);
+    auto dev = it != pcLocal.layers.end() ? std::dynamic_pointer_cast<DevicePointCloud>(it->second) : nullptr;
+    align_fused(dev ? nullptr : &local_layer(pcLocal, lname), dev.get(), global_layer(pcGlobal, m->pointLayerMatches[0].global),
+                g, p, result, prior);
   } else {
     last_fused_ = false;
     align_generic(pcLocal, pcGlobal, g, p, result, prior);
   }
 }
 
-void ICP::align_fused(const PointCloud& local, const HashedVoxelPointCloud& global, const CPose3D& guess, const Parameters& p,
-                      Results& result, const std::optional<CPose3DPDFGaussianInf>& prior) {
+void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_local, const HashedVoxelPointCloud& global,
+                      const CPose3D& guess, const Parameters& p, Results& result,
+                      const std::optional<CPose3DPDFGaussianInf>& prior) {
   auto m = std::static_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_.back());
   auto s = std::static_pointer_cast<Solver_GaussNewton>(solvers_[0]);
   auto mpl = matchers_.size() == 2 ? std::static_pointer_cast<Matcher_Point2Plane>(matchers_[0]) : nullptr;
@@ -501,19 +579,29 @@ void ICP::align_fused(const PointCloud& local, const HashedVoxelPointCloud& glob
   ip.compute_covariance = 1;
   ip.cov_findif_xyz = 1e-7;
   ip.cov_findif_ang = 1e-7;
-  if (!scan_)
-    check(mh_scan_create(global.context()->get(), local.x.data(), local.y.data(), local.z.data(), local.size(), MH_MEM_HOST, &scan_),
-          "mh_scan_create");
-  else
-    check(mh_scan_update(scan_, local.x.data(), local.y.data(), local.z.data(), local.size(), MH_MEM_HOST), "mh_scan_update");
+  mh_scan* scan = nullptr;
+  PointCloud downloaded;  // only when a device layer's final pairings are requested
+  if (dev_local) {
+    scan = dev_local->handle();  // already resident: no upload
+  } else {
+    const PointCloud& hl = *host_local;
+    if (!scan_)
+      check(mh_scan_create(global.context()->get(), hl.x.data(), hl.y.data(), hl.z.data(), hl.size(), MH_MEM_HOST, &scan_),
+            "mh_scan_create");
+    else
+      check(mh_scan_update(scan_, hl.x.data(), hl.y.data(), hl.z.data(), hl.size(), MH_MEM_HOST), "mh_scan_update");
+    scan = scan_;
+  }
   mh_prior pr;
   if (prior) fill_prior(prior, pr);
   mh_icp_result r{};
-  const size_t n = local.size();
-  std::vector<uint32_t> li(n), gi(n);
-  std::vector<float> gx(n), gy(n), gz(n), d2(n);
+  const size_t n = dev_local ? dev_local->size() : host_local->size();
+  const bool want_pairs = keep_pairings_;
+  std::vector<uint32_t> li(want_pairs ? n : 0), gi(li.size());
+  std::vector<float> gx(li.size()), gy(li.size()), gz(li.size()), d2(li.size());
   mh_pairs_out po{li.data(), gi.data(), gx.data(), gy.data(), gz.data(), d2.data()};
-  check(mh_icp_align(global.handle(), scan_, &ip, guess.T, prior ? &pr : nullptr, &r, nullptr, &po, MH_MEM_HOST), "mh_icp_align");
+  check(mh_icp_align(global.handle(), scan, &ip, guess.T, prior ? &pr : nullptr, &r, nullptr, want_pairs ? &po : nullptr,
+                     MH_MEM_HOST), "mh_icp_align");
   memcpy(result.optimal_tf.mean.T, r.T, sizeof(r.T));
   memcpy(result.optimal_tf.cov, r.cov, sizeof(r.cov));
   result.quality = r.quality;
@@ -521,13 +609,16 @@ void ICP::align_fused(const PointCloud& local, const HashedVoxelPointCloud& glob
   result.terminationReason = (IterTermReason)r.termination_reason;
   Pairings& fp = result.finalPairings;
   fp.potential_pairings = r.potential_pairings;
+  if (!want_pairs) return;
+  if (dev_local) dev_local->download(downloaded.x, downloaded.y, downloaded.z);
+  const PointCloud& local = dev_local ? downloaded : *host_local;
   if (r.n_final_pairs_pt2pl) {
     std::vector<uint32_t> qli(n);
     std::vector<float> a[6];
     for (auto& v : a) v.resize(n);
     mh_pairs_pl_out qo{qli.data(), a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), a[5].data()};
     uint64_t nq = 0;
-    check(mh_icp_get_pt2pl_pairs(scan_, &qo, MH_MEM_HOST, &nq), "mh_icp_get_pt2pl_pairs");
+    check(mh_icp_get_pt2pl_pairs(scan, &qo, MH_MEM_HOST, &nq), "mh_icp_get_pt2pl_pairs");
     append_pl_pairs(local, qli, a, nq, fp);
   }
   for (uint32_t k = 0; k < r.n_final_pairs - r.n_final_pairs_pt2pl; k++) {

@@ -1,0 +1,634 @@
+// lidar_odometry.cpp -- see mola_lidar_odometry_hip/LidarOdometry.h.  Control logic only: the arithmetic on points
+// is behind include/molahip.h.  Citations are module/src/LidarOdometry.cpp unless another file is named.
+#include "mola_lidar_odometry_hip/LidarOdometry.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+namespace mola_hip {
+
+using namespace mp2p_icp_hip;
+
+namespace {
+
+double to_double(const std::string& s) { return strtod(s.c_str(), nullptr); }
+bool to_bool(const std::string& s) { return s == "true" || s == "True" || s == "1" || s == "yes"; }
+constexpr double kDeg2Rad = M_PI / 180.0;
+
+// "$f{expr}" (evaluated once, at object creation) or a plain number / expression
+double eval_now(std::string s, const std::map<std::string, double>& vars) {
+  if (s.size() > 4 && s.compare(0, 3, "$f{") == 0 && s.back() == '}') s = s.substr(3, s.size() - 4);
+  return evaluate_expression(s, vars);
+}
+
+std::string class_of(const Config& entry) { return entry["class_name"].asString(); }
+bool ends_with(const std::string& s, const std::string& suffix) {
+  return s.size() >= suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0;
+}
+
+}  // namespace
+
+// ================================================================== motion model
+void NavStateFuse::initialize(const Config& c) {
+  if (c.has("max_time_to_use_velocity_model"))
+    max_time_to_use_velocity_model = to_double(c["max_time_to_use_velocity_model"].asString());
+  reset();
+}
+void NavStateFuse::reset() {
+  last_pose_.reset();
+  twist_.reset();
+  last_t_ = 0;
+}
+void NavStateFuse::fuse_pose(double t, const CPose3D& pose) {
+  if (last_pose_) {
+    const double dt = t - last_t_;
+    if (dt > 0) {
+      const CPose3D incr = pose - *last_pose_;  // increment in the frame of the previous pose
+      double w[3];
+      incr.so3Log(w);
+      Twist tw;
+      tw.vx = incr.T[3] / dt; tw.vy = incr.T[7] / dt; tw.vz = incr.T[11] / dt;
+      tw.wx = w[0] / dt; tw.wy = w[1] / dt; tw.wz = w[2] / dt;
+      twist_ = tw;
+    }
+  }
+  last_pose_ = pose;
+  last_t_ = t;
+}
+std::optional<NavStateFuse::NavState> NavStateFuse::estimated_navstate(double t) const {
+  if (!last_pose_ || !twist_) return std::nullopt;
+  const double dt = t - last_t_;
+  if (dt < 0 || dt > max_time_to_use_velocity_model) return std::nullopt;
+  const double w[3] = {twist_->wx * dt, twist_->wy * dt, twist_->wz * dt};
+  const double v[3] = {twist_->vx * dt, twist_->vy * dt, twist_->vz * dt};
+  NavState ns;
+  ns.pose.mean = *last_pose_ + CPose3D::FromRotVecAndTranslation(w, v);
+  ns.twist = *twist_;
+  return ns;  // cov_inv stays zero: no prior term
+}
+
+// ================================================================== key-frame list
+std::pair<bool, CPose3D> SearchablePoseList::check(const CPose3D& p) const {
+  if (poses_.empty()) return {true, CPose3D()};
+  size_t best = 0;
+  double best_d2 = INFINITY;
+  for (size_t i = 0; i < poses_.size(); i++) {
+    const double dx = poses_[i].T[3] - p.T[3], dy = poses_[i].T[7] - p.T[7], dz = poses_[i].T[11] - p.T[11];
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    if (d2 < best_d2) {
+      best_d2 = d2;
+      best = i;
+    }
+  }
+  return {false, p - poses_[best]};
+}
+void SearchablePoseList::removeAllFartherThan(const CPose3D& p, double max_dist) {
+  std::vector<CPose3D> kept;
+  for (const auto& q : poses_) {
+    const double dx = q.T[3] - p.T[3], dy = q.T[7] - p.T[7], dz = q.T[11] - p.T[11];
+    if (std::sqrt(dx * dx + dy * dy + dz * dz) <= max_dist) kept.push_back(q);
+  }
+  poses_.swap(kept);
+}
+
+// ================================================================== parameters
+void LidarOdometry::Params::load_from(const Config& c) {
+  auto num = [&](const Config& n, const char* k, double& v) { if (n.has(k)) v = to_double(n[k].asString()); };
+  auto flag = [&](const Config& n, const char* k, bool& v) { if (n.has(k)) v = to_bool(n[k].asString()); };
+  num(c, "min_time_between_scans", min_time_between_scans);
+  num(c, "max_sensor_range_filter_coefficient", max_sensor_range_filter_coefficient);
+  num(c, "absolute_minimum_sensor_range", absolute_minimum_sensor_range);
+  flag(c, "optimize_twist", optimize_twist);
+  num(c, "optimize_twist_rerun_min_trans", optimize_twist_rerun_min_trans);
+  num(c, "optimize_twist_rerun_min_rot_deg", optimize_twist_rerun_min_rot_deg);
+  if (c.has("optimize_twist_max_corrections"))
+    optimize_twist_max_corrections = (size_t)to_double(c["optimize_twist_max_corrections"].asString());
+  num(c, "min_icp_goodness", min_icp_goodness);
+  if (c.has("local_map_updates")) {
+    const Config& l = c["local_map_updates"];
+    flag(l, "enabled", local_map_updates_enabled);
+    // DECLARE_PARAMETER_IN_REQ: formulas over wx,wy,wz and ESTIMATED_SENSOR_MAX_RANGE (yaml:44-46)
+    parameterFromConfig(l, "min_translation_between_keyframes", &min_translation_between_keyframes, true);
+    parameterFromConfig(l, "min_rotation_between_keyframes", &min_rotation_between_keyframes, true);
+    parameterFromConfig(l, "max_distance_to_keep_keyframes", &max_distance_to_keep_keyframes, false);
+    if (l.has("check_for_removal_every_n")) check_for_removal_every_n = (uint32_t)to_double(l["check_for_removal_every_n"].asString());
+  }
+  if (c.has("adaptive_threshold")) {
+    const Config& a = c["adaptive_threshold"];
+    flag(a, "enabled", adaptive_threshold_enabled);
+    num(a, "initial_sigma", initial_sigma);
+    num(a, "min_motion", min_motion);
+    num(a, "maximum_sigma", maximum_sigma);
+    num(a, "kp", kp);
+    num(a, "alpha", alpha);
+  }
+  if (c.has("observation_validity_checks")) {
+    const Config& v = c["observation_validity_checks"];
+    flag(v, "enabled", validity_check_enabled);
+    if (v.has("minimum_point_count")) validity_minimum_point_count = (uint32_t)to_double(v["minimum_point_count"].asString());
+  }
+}
+
+// The observation filter chain the device implements, recognised from the pipeline file:
+//   1st pass  Decimate(raw -> A) -> [ByRange(A -> B)] -> [BoundingBox(B -> C)] -> Decimate(C -> D)      (yaml:278-319)
+//   2nd pass  [DeleteLayer] -> Deskew(C -> for_map) -> Deskew(D -> for_icp)                               (yaml:322-350)
+//   merge     FilterMerge(for_map -> local map layer)                                                     (yaml:362-368)
+struct LidarOdometry::FilterPlan : public Parameterizable {
+  double decim_map_res = 0, decim_icp_res = 0, range_min = 0, range_max = 0;
+  double bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
+  double time_offset = 0;
+  uint32_t min_points_to_filter = 0;
+  int32_t bbox_mode = MH_BBOX_OFF, timestamp_method = MH_TS_NONE;
+  bool skip_deskew = false;
+  std::string layer_for_map, layer_for_icp, map_layer;
+
+  static void unsupported(const std::string& what) {
+    throw std::runtime_error("LidarOdometry (HIP): unsupported observation filter chain: " + what +
+                             ". Implemented on the device: FilterAdjustTimestamps; FilterDecimateVoxels(FirstPoint) -> "
+                             "[FilterByRange] -> [FilterBoundingBox] -> FilterDecimateVoxels(FirstPoint); FilterDeskew x2; "
+                             "FilterMerge (the chain of pipelines/lidar3d-default.yaml)");
+  }
+  void decimate(const Config& p, double* res) {
+    if (p.has("decimate_method") && !ends_with(p["decimate_method"].asString(), "FirstPoint"))
+      unsupported("decimate_method " + p["decimate_method"].asString());
+    parameterFromConfig(p, "voxel_filter_resolution", res, true);
+    const uint32_t mp = p.has("minimum_input_points_to_filter") ? (uint32_t)to_double(p["minimum_input_points_to_filter"].asString()) : 0;
+    if (res == &decim_map_res) min_points_to_filter = mp;
+    else if (mp != min_points_to_filter) unsupported("different minimum_input_points_to_filter in the two decimations");
+  }
+  void load(const Config& cfg) {
+    if (cfg.has("observations_filter_adjust_timestamps")) {
+      const Config& s = cfg["observations_filter_adjust_timestamps"];
+      for (size_t i = 0; i < s.size(); i++) {
+        if (!ends_with(class_of(s.at(i)), "FilterAdjustTimestamps")) unsupported(class_of(s.at(i)));
+        const Config& p = s.at(i)["params"];
+        const std::string m = p.getOr("method", "TimestampAdjustMethod::MiddleIsZero");
+        timestamp_method = ends_with(m, "MiddleIsZero") ? MH_TS_MIDDLE_IS_ZERO : ends_with(m, "EarliestIsZero") ? MH_TS_EARLIEST_IS_ZERO : -1;
+        if (timestamp_method < 0) unsupported("timestamp method " + m);
+        if (p.has("time_offset")) parameterFromConfig(p, "time_offset", &time_offset, false);
+      }
+    }
+    // ---- 1st pass
+    const Config& f1 = cfg["observations_filter_1st_pass"];
+    std::string cur = "raw";
+    size_t i = 0;
+    auto params_of = [&](size_t k) -> const Config& { return f1.at(k)["params"]; };
+    if (i >= f1.size() || !ends_with(class_of(f1.at(i)), "FilterDecimateVoxels")) unsupported("1st pass must start with FilterDecimateVoxels");
+    if (params_of(i)["input_pointcloud_layer"].asString() != cur) unsupported("first decimation must read layer 'raw'");
+    decimate(params_of(i), &decim_map_res);
+    cur = params_of(i)["output_pointcloud_layer"].asString();
+    i++;
+    if (i < f1.size() && ends_with(class_of(f1.at(i)), "FilterByRange")) {
+      const Config& p = params_of(i);
+      if (p["input_pointcloud_layer"].asString() != cur || !p.has("output_layer_between")) unsupported("FilterByRange wiring");
+      parameterFromConfig(p, "range_min", &range_min, true);
+      parameterFromConfig(p, "range_max", &range_max, true);
+      cur = p["output_layer_between"].asString();
+      i++;
+    }
+    if (i < f1.size() && ends_with(class_of(f1.at(i)), "FilterBoundingBox")) {
+      const Config& p = params_of(i);
+      if (p["input_pointcloud_layer"].asString() != cur) unsupported("FilterBoundingBox wiring");
+      if (p.has("outside_pointcloud_layer")) { bbox_mode = MH_BBOX_KEEP_OUTSIDE; cur = p["outside_pointcloud_layer"].asString(); }
+      else if (p.has("inside_pointcloud_layer")) { bbox_mode = MH_BBOX_KEEP_INSIDE; cur = p["inside_pointcloud_layer"].asString(); }
+      else unsupported("FilterBoundingBox without an output layer");
+      for (int a = 0; a < 3; a++) {
+        declareParameter("bounding_box_min", p["bounding_box_min"].at(a).asString(), &bbox_min[a]);
+        declareParameter("bounding_box_max", p["bounding_box_max"].at(a).asString(), &bbox_max[a]);
+      }
+      i++;
+    }
+    const std::string skewed_map = cur;
+    if (i >= f1.size() || !ends_with(class_of(f1.at(i)), "FilterDecimateVoxels")) unsupported("1st pass must end with FilterDecimateVoxels");
+    if (params_of(i)["input_pointcloud_layer"].asString() != cur) unsupported("second decimation wiring");
+    decimate(params_of(i), &decim_icp_res);
+    const std::string skewed_icp = params_of(i)["output_pointcloud_layer"].asString();
+    if (++i != f1.size()) unsupported("extra filters after the second decimation: " + class_of(f1.at(i)));
+    // ---- 2nd pass
+    const Config& f2 = cfg["observations_filter_2nd_pass"];
+    for (size_t k = 0; k < f2.size(); k++) {
+      const std::string cn = class_of(f2.at(k));
+      if (ends_with(cn, "FilterDeleteLayer")) continue;
+      if (!ends_with(cn, "FilterDeskew")) unsupported(cn);
+      const Config& p = f2.at(k)["params"];
+      const std::string in = p["input_pointcloud_layer"].asString(), out = p["output_pointcloud_layer"].asString();
+      if (in == skewed_map) layer_for_map = out;
+      else if (in == skewed_icp) layer_for_icp = out;
+      else unsupported("FilterDeskew reads unknown layer " + in);
+      if (p.has("skip_deskew")) skip_deskew = to_bool(p["skip_deskew"].asString());
+    }
+    if (layer_for_map.empty() || layer_for_icp.empty()) unsupported("both skewed layers need a FilterDeskew");
+    // ---- merge
+    const Config& mg = cfg["insert_observation_into_local_map"];
+    if (mg.size() != 1 || !ends_with(class_of(mg.at(0)), "FilterMerge")) unsupported("insert_observation_into_local_map must be one FilterMerge");
+    const Config& mp = mg.at(0)["params"];
+    if (mp["input_pointcloud_layer"].asString() != layer_for_map) unsupported("FilterMerge must read the de-skewed map layer");
+    if (mp.has("input_layer_in_local_coordinates") && !to_bool(mp["input_layer_in_local_coordinates"].asString()))
+      unsupported("FilterMerge with input_layer_in_local_coordinates: false");
+    map_layer = mp["target_layer"].asString();
+  }
+};
+
+// ================================================================== driver
+LidarOdometry::LidarOdometry(std::shared_ptr<DeviceContext> ctx) : ctx_(std::move(ctx)) {}
+LidarOdometry::~LidarOdometry() = default;
+
+void LidarOdometry::initialize(const Config& cfg) {
+  if (plan_) throw std::runtime_error("LidarOdometry::initialize() called twice; create a new object instead");
+  params_.load_from(cfg["params"]);
+  params_.attachToParameterSource(source_);
+  if (cfg.has("navstate_fuse_params")) navstate_.initialize(cfg["navstate_fuse_params"]);
+  plan_ = std::make_unique<FilterPlan>();
+  plan_->load(cfg);
+  plan_->attachToParameterSource(source_);
+
+  // ICP pipelines (:340-358)
+  auto t0 = icp_pipeline_from_yaml(cfg["icp_settings_with_vel"], ctx_);
+  icp_[0] = std::get<0>(t0);
+  icp_params_[0] = std::get<1>(t0);
+  if (cfg.has("icp_settings_without_vel")) {
+    auto t1 = icp_pipeline_from_yaml(cfg["icp_settings_without_vel"], ctx_);
+    icp_[1] = std::get<0>(t1);
+    icp_params_[1] = std::get<1>(t1);
+  } else {
+    icp_[1] = icp_[0];
+    icp_params_[1] = icp_params_[0];
+  }
+  for (auto& icp : icp_) {
+    icp->attachToParameterSource(source_);
+    icp->setKeepFinalPairings(false);
+  }
+  // local map definition (yaml:213-242), instantiated at the first key-frame when its $f{} formulas can be evaluated
+  const Config& gen = cfg["localmap_generator"];
+  if (gen.size() < 1) throw std::runtime_error("localmap_generator is empty");
+  map_def_ = gen.at(0)["params"]["metric_map_definition"];
+
+  reset();  // device objects are created at the first scan: a pipeline can be loaded and checked without a GPU
+}
+
+void LidarOdometry::ensure_device() {
+  if (raw_) return;
+  if (!ctx_) ctx_ = DeviceContext::Default();
+  raw_ = std::make_shared<DevicePointCloud>(ctx_);
+  map_skewed_ = std::make_shared<DevicePointCloud>(ctx_);
+  icp_skewed_ = std::make_shared<DevicePointCloud>(ctx_);
+  for_map_ = std::make_shared<DevicePointCloud>(ctx_);
+  for_icp_ = std::make_shared<DevicePointCloud>(ctx_);
+}
+
+void LidarOdometry::reset() {
+  navstate_.reset();
+  local_map_.reset();
+  last_lidar_pose_ = CPose3D();
+  last_icp_was_good_ = true;
+  last_icp_quality_ = 0;
+  last_obs_tim_.reset();
+  last_icp_timestamp_.reset();
+  first_ever_timestamp_.reset();
+  last_obs_timestamp_.reset();
+  last_motion_model_output_.reset();
+  adapt_thres_sigma_ = 0;
+  estimated_sensor_max_range_.reset();
+  instantaneous_sensor_max_range_.reset();
+  distance_checker_local_map_.clear();
+  localmap_check_removal_counter_ = 0;
+  trajectory_.clear();
+  records_.clear();
+}
+
+void LidarOdometry::updatePipelineTwistVariables(const Twist& tw) {  // :1571-1579
+  source_.updateVariable("vx", tw.vx); source_.updateVariable("vy", tw.vy); source_.updateVariable("vz", tw.vz);
+  source_.updateVariable("wx", tw.wx); source_.updateVariable("wy", tw.wy); source_.updateVariable("wz", tw.wz);
+}
+
+void LidarOdometry::updatePipelineDynamicVariables() {  // :1581-1635
+  updatePipelineTwistVariables(last_motion_model_output_ ? last_motion_model_output_->twist : Twist());
+  const TPose3D p = last_lidar_pose_.asTPose();
+  source_.updateVariable("robot_x", p.x); source_.updateVariable("robot_y", p.y); source_.updateVariable("robot_z", p.z);
+  source_.updateVariable("robot_yaw", p.yaw); source_.updateVariable("robot_pitch", p.pitch); source_.updateVariable("robot_roll", p.roll);
+  source_.updateVariable("ADAPTIVE_THRESHOLD_SIGMA", adapt_thres_sigma_ != 0 ? adapt_thres_sigma_ : params_.initial_sigma);
+  source_.updateVariable("ICP_ITERATION", 0);
+  const auto& vars = source_.getVariableValues();
+  for (const char* v : {"icp_iterations", "SENSOR_TIME_OFFSET", "twistCorrectionCount"})
+    if (!vars.count(v)) source_.updateVariable(v, 0);
+  if (estimated_sensor_max_range_) source_.updateVariable("ESTIMATED_SENSOR_MAX_RANGE", *estimated_sensor_max_range_);
+  source_.updateVariable("INSTANTANEOUS_SENSOR_MAX_RANGE", instantaneous_sensor_max_range_ ? *instantaneous_sensor_max_range_ : 20.0);
+  if (last_obs_timestamp_ && first_ever_timestamp_)
+    source_.updateVariable("current_relative_timestamp", *last_obs_timestamp_ - *first_ever_timestamp_);
+  source_.realize();
+}
+
+// bounding-box "radius" used by the sensor range estimate (:1503-1508, 1523-1527): float norms, like TPoint3Df::norm()
+static double bbox_radius(const float mn[3], const float mx[3]) {
+  const float a = std::sqrt((mx[0] * mx[0] + mx[1] * mx[1]) + mx[2] * mx[2]);
+  const float b = std::sqrt((mn[0] * mn[0] + mn[1] * mn[1]) + mn[2] * mn[2]);
+  return (double)std::max(a, b);
+}
+
+void LidarOdometry::run_first_pass() {
+  const FilterPlan& f = *plan_;
+  mh_preprocess_params pp{};
+  pp.decim_map_resolution = (float)f.decim_map_res;
+  pp.decim_icp_resolution = (float)f.decim_icp_res;
+  pp.min_points_to_filter = f.min_points_to_filter;
+  pp.index_mode = MH_INDEX_FLOOR;
+  pp.range_min = (float)f.range_min;
+  pp.range_max = (float)f.range_max;
+  pp.bbox_mode = f.bbox_mode;
+  for (int a = 0; a < 3; a++) {
+    pp.bbox_min[a] = (float)f.bbox_min[a];
+    pp.bbox_max[a] = (float)f.bbox_max[a];
+  }
+  pp.timestamp_method = f.timestamp_method;
+  pp.time_offset = (float)f.time_offset;
+  check(mh_scan_preprocess(raw_->handle(), &pp, map_skewed_->handle(), icp_skewed_->handle()), "mh_scan_preprocess");
+}
+
+void LidarOdometry::run_second_pass() {
+  const auto& v = source_.getVariableValues();
+  const double tw[6] = {v.at("vx"), v.at("vy"), v.at("vz"), v.at("wx"), v.at("wy"), v.at("wz")};
+  const double* twp = plan_->skip_deskew ? nullptr : tw;
+  check(mh_scan_deskew(map_skewed_->handle(), twp, for_map_->handle()), "mh_scan_deskew");
+  check(mh_scan_deskew(icp_skewed_->handle(), twp, for_icp_->handle()), "mh_scan_deskew");
+}
+
+void LidarOdometry::doUpdateAdaptiveThreshold(const CPose3D& err) {  // :1449-1485 (KISS-ICP's scheme)
+  if (!estimated_sensor_max_range_) return;
+  const double max_range = *estimated_sensor_max_range_;
+  const double theta = err.rotationAngle();
+  const double model_error = err.translationNorm() + 2.0 * max_range * std::sin(theta / 2.0);
+  double rot_error = 0;
+  if (last_motion_model_output_) {
+    const Twist& tw = last_motion_model_output_->twist;
+    rot_error = 0.1 * std::sqrt(tw.wx * tw.wx + tw.wy * tw.wy + tw.wz * tw.wz) * max_range;
+  }
+  const double KP = params_.kp;
+  if (!(KP > 1.0)) throw std::runtime_error("adaptive_threshold.kp must be > 1");
+  const double gain = std::min(KP, std::max(0.1, KP * (1.0 - last_icp_quality_)));
+  const double new_sigma = (model_error + rot_error) * gain;
+  if (adapt_thres_sigma_ == 0) adapt_thres_sigma_ = params_.initial_sigma;
+  adapt_thres_sigma_ = params_.alpha * adapt_thres_sigma_ + (1.0 - params_.alpha) * new_sigma;
+  adapt_thres_sigma_ = std::min(params_.maximum_sigma, std::max(params_.min_motion, adapt_thres_sigma_));
+}
+
+void LidarOdometry::create_local_map() {  // :1165-1171 with yaml:228-242
+  const auto& vars = source_.getVariableValues();
+  const std::string cls = map_def_["class"].asString();
+  const Config& co = map_def_["creationOpts"];
+  const Config& io = map_def_["insertOpts"];
+  mh_map_params mp{};
+  map_voxel_size_ = eval_now(co["voxel_size"].asString(), vars);
+  mp.voxel_size = (float)map_voxel_size_;
+  mp.max_points_per_voxel = io.has("max_points_per_voxel") ? (uint32_t)eval_now(io["max_points_per_voxel"].asString(), vars) : 0;
+  mp.index_mode = MH_INDEX_FLOOR;
+  mp.min_distance_between_points = io.has("min_distance_between_points") ? (float)eval_now(io["min_distance_between_points"].asString(), vars) : 0.f;
+  remove_voxels_farther_than_ = io.has("remove_voxels_farther_than") ? (float)eval_now(io["remove_voxels_farther_than"].asString(), vars) : 0.f;
+  if (ends_with(cls, "NDT")) {
+    mp.ndt_max_eigen_ratio = io.has("max_eigen_ratio_for_planes") ? (float)eval_now(io["max_eigen_ratio_for_planes"].asString(), vars) : 0.05f;
+    mp.ndt_min_points = 4;
+  } else if (!ends_with(cls, "HashedVoxelPointCloud")) {
+    throw std::runtime_error("local map class '" + cls + "' has no device implementation (HashedVoxelPointCloud, NDT)");
+  }
+  local_map_ = std::make_shared<HashedVoxelPointCloud>(mp, ctx_);
+}
+
+const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, const float* x, const float* y, const float* z,
+                                                        const float* t, size_t n) {
+  if (!plan_) throw std::runtime_error("LidarOdometry::onLidar called before initialize()");
+  records_.emplace_back();
+  ScanRecord& rec = records_.back();
+  rec.timestamp = this_obs_tim;
+  rec.n_raw = n;
+  rec.pose = last_lidar_pose_;
+
+  // drop scans too close in time (:644-657)
+  if (last_obs_tim_ && (this_obs_tim - *last_obs_tim_) < params_.min_time_between_scans) {
+    rec.dropped = true;
+    return rec;
+  }
+  ensure_device();
+  raw_->setPoints(x, y, z, n);
+  if (t) raw_->setTimestamps(t, n);
+
+  // first call: sensor range from the raw cloud (:660, 1487-1513)
+  if (!estimated_sensor_max_range_ && n) {
+    float mn[3], mx[3];
+    raw_->boundingBox(mn, mx);
+    estimated_sensor_max_range_ = std::max(bbox_radius(mn, mx), params_.absolute_minimum_sensor_range);
+  }
+  updatePipelineDynamicVariables();  // :692
+  rec.twist = last_motion_model_output_ ? last_motion_model_output_->twist : Twist();
+
+  run_first_pass();   // :734
+  run_second_pass();  // :739
+  rec.decim_map_resolution = plan_->decim_map_res;
+  rec.decim_icp_resolution = plan_->decim_icp_res;
+  rec.n_for_map = for_map_->size();
+  rec.n_for_icp = for_icp_->size();
+
+  // sensor range low-pass from the first point layer of the observation, 'decimated_for_icp' (:744, 1515-1545)
+  if (estimated_sensor_max_range_) {
+    float mn[3], mx[3];
+    for_icp_->boundingBox(mn, mx);
+    const double radius = std::max(bbox_radius(mn, mx), params_.absolute_minimum_sensor_range);
+    instantaneous_sensor_max_range_ = radius;
+    const double a = params_.max_sensor_range_filter_coefficient;
+    estimated_sensor_max_range_ = *estimated_sensor_max_range_ * a + radius * (1.0 - a);
+  }
+  rec.estimated_sensor_max_range = estimated_sensor_max_range_.value_or(0);
+  rec.instantaneous_sensor_max_range = instantaneous_sensor_max_range_.value_or(0);
+
+  if (params_.validity_check_enabled && !(n > params_.validity_minimum_point_count)) {  // :749-757, 1548-1568
+    rec.dropped = true;
+    return rec;
+  }
+  last_obs_tim_ = this_obs_tim;
+  last_obs_timestamp_ = this_obs_tim;
+  if (!first_ever_timestamp_) first_ever_timestamp_ = this_obs_tim;
+  if (n == 0) {  // :769-775
+    rec.dropped = true;
+    return rec;
+  }
+
+  bool updateLocalMap = false;
+  last_motion_model_output_ = navstate_.estimated_navstate(this_obs_tim);  // :810-811
+  const bool hasMotionModel = last_motion_model_output_.has_value();
+  rec.had_motion_model = hasMotionModel;
+
+  const bool map_empty = !local_map_ || local_map_->size() == 0;
+  if (map_empty) {
+    // first point cloud: no ICP, it becomes the map (:817-838)
+    rec.first_scan = true;
+    updateLocalMap = true;
+    trajectory_.emplace_back(this_obs_tim, last_lidar_pose_);
+    navstate_.fuse_pose(this_obs_tim, CPose3D());
+  } else {
+    // ---- ICP (:840-1024)
+    TPose3D init_guess = hasMotionModel ? last_motion_model_output_->pose.mean.asTPose() : last_lidar_pose_.asTPose();
+    std::optional<CPose3DPDFGaussianInf> prior;
+    if (hasMotionModel) {
+      bool any = false;
+      for (double v : last_motion_model_output_->pose.cov_inv) any = any || v != 0.0;
+      if (any) prior = last_motion_model_output_->pose;
+    }
+    const int kind = hasMotionModel ? 0 : 1;
+    const CPose3D last_keyframe_pose = last_lidar_pose_;
+    double time_since_last_keyframe = 0;
+    if (last_icp_timestamp_) time_since_last_keyframe = this_obs_tim - *last_icp_timestamp_;
+    last_icp_timestamp_ = this_obs_tim;
+
+    TPose3D current_solution = init_guess;
+    rec.init_guess = CPose3D(init_guess);
+    ICP& icp = *icp_[kind];
+    mp2p_icp_hip::Parameters icp_params = icp_params_[kind];
+    size_t remaining = icp_params.maxIterations;
+    mp2p_icp_hip::Results res;
+    mp2p_icp_hip::metric_map_t obs, glob;
+    obs.layers[plan_->layer_for_icp] = for_icp_;
+    obs.layers[plan_->layer_for_map] = for_map_;
+    glob.layers[plan_->map_layer] = local_map_;
+    do {
+      icp_params.maxIterations = (uint32_t)remaining;
+      // the in-tree hook (:919-952) only compares the running solution with its check point: evaluated on the device.
+      // NOTE the reference increments optimize_twist_max_corrections instead of its counter (:941), so the number of
+      // corrections is bounded by the shared iteration budget only; kept.
+      if (params_.optimize_twist)
+        icp.setDeviceHook(params_.optimize_twist_rerun_min_trans, params_.optimize_twist_rerun_min_rot_deg * kDeg2Rad,
+                          CPose3D(current_solution));
+      else
+        icp.clearHooks();
+      icp.align(obs, glob, current_solution, icp_params, res, prior);  // :961-962
+      rec.align_calls++;
+      remaining -= std::min(remaining, res.nIterations);
+      rec.icp_iterations += (uint32_t)res.nIterations;
+      if (res.terminationReason == IterTermReason::HookRequest) {
+        current_solution = res.optimal_tf.mean.asTPose();  // what the hook stored (:949)
+        rec.twist_corrections++;
+        if (time_since_last_keyframe > 0) {
+          // re-estimate the twist from the running solution and de-skew again (:973-1004), all on the device
+          const CPose3D incr = res.optimal_tf.mean - last_keyframe_pose;
+          double w[3];
+          incr.so3Log(w);
+          const double At = time_since_last_keyframe;
+          Twist tw;
+          tw.vx = incr.T[3] / At; tw.vy = incr.T[7] / At; tw.vz = incr.T[11] / At;
+          tw.wx = w[0] / At; tw.wy = w[1] / At; tw.wz = w[2] / At;
+          updatePipelineTwistVariables(tw);
+          source_.realize();
+          run_second_pass();
+          rec.twist = tw;
+        }
+      }
+    } while (res.terminationReason == IterTermReason::HookRequest);
+    icp.clearHooks();
+    rec.icp_run = true;
+    rec.termination = (int)res.terminationReason;
+    rec.goodness = res.quality;
+
+    // ---- gate, motion model, trajectory (:1026-1045)
+    const bool icpIsGood = res.quality >= params_.min_icp_goodness;
+    last_icp_was_good_ = icpIsGood;
+    last_icp_quality_ = res.quality;
+    rec.icp_good = icpIsGood;
+    if (icpIsGood) {
+      last_lidar_pose_ = res.optimal_tf.mean;
+      navstate_.fuse_pose(this_obs_tim, res.optimal_tf.mean);
+      trajectory_.emplace_back(this_obs_tim, last_lidar_pose_);
+    } else {
+      navstate_.reset();
+    }
+    source_.updateVariable("icp_iterations", (double)res.nIterations);
+    source_.updateVariable("twistCorrectionCount", 0);  // always 0 in the reference (App. C.2)
+
+    // ---- adaptive threshold, also after a rejected ICP (:1052-1064)
+    if (params_.adaptive_threshold_enabled) doUpdateAdaptiveThreshold(res.optimal_tf.mean - CPose3D(init_guess));
+
+    // ---- key-frame decision (:1066-1118)
+    const auto [isFirstPoseInChecker, distanceToClosest] = distance_checker_local_map_.check(last_lidar_pose_);
+    const double dist_eucl_since_last = distanceToClosest.translationNorm();
+    const double rot_since_last = distanceToClosest.rotationAngle();
+    updateLocalMap = icpIsGood && params_.local_map_updates_enabled && hasMotionModel &&
+                     (isFirstPoseInChecker || dist_eucl_since_last > params_.min_translation_between_keyframes ||
+                      rot_since_last > params_.min_rotation_between_keyframes * kDeg2Rad);
+    if (updateLocalMap) {
+      distance_checker_local_map_.insert(last_lidar_pose_);
+      if (params_.max_distance_to_keep_keyframes > 0 &&
+          (localmap_check_removal_counter_++ >= params_.check_for_removal_every_n)) {
+        localmap_check_removal_counter_ = 0;
+        distance_checker_local_map_.removeAllFartherThan(last_lidar_pose_, params_.max_distance_to_keep_keyframes);
+      }
+    }
+  }
+
+  // a bad ICP right after the start: begin again from an empty map (:1146-1156)
+  if (!last_icp_was_good_ && trajectory_.size() == 1) {
+    if (local_map_) local_map_->clear();
+    trajectory_.clear();
+    updateLocalMap = false;
+    last_icp_was_good_ = true;
+    rec.restarted = true;
+  }
+
+  // ---- local map update (:1158-1206): FilterMerge of the de-skewed map layer at the current pose, on the device
+  if (updateLocalMap) {
+    if (!local_map_) create_local_map();
+    updatePipelineDynamicVariables();  // robot_x..robot_roll (:1194)
+    local_map_->insertPointCloud(*for_map_, last_lidar_pose_, remove_voxels_farther_than_);
+    rec.map_updated = true;
+  }
+  rec.pose = last_lidar_pose_;
+  rec.sigma = adapt_thres_sigma_;
+  rec.map_voxel_size = map_voxel_size_;
+  if (local_map_) {
+    rec.n_map_points = local_map_->size();
+    rec.n_map_voxels = local_map_->voxelCount();
+  }
+  return rec;
+}
+
+std::map<std::string, std::string> LidarOdometry::describePipeline() const {
+  std::map<std::string, std::string> d;
+  if (!plan_) return d;
+  d["layer_for_map"] = plan_->layer_for_map;
+  d["layer_for_icp"] = plan_->layer_for_icp;
+  d["map_layer"] = plan_->map_layer;
+  d["map_class"] = map_def_["class"].asString();
+  d["bbox_mode"] = std::to_string(plan_->bbox_mode);
+  d["timestamp_method"] = std::to_string(plan_->timestamp_method);
+  d["min_points_to_filter"] = std::to_string(plan_->min_points_to_filter);
+  d["skip_deskew"] = plan_->skip_deskew ? "true" : "false";
+  for (const auto& p : plan_->declaredParameters()) d["formula:" + p.name + (d.count("formula:" + p.name) ? "#" + std::to_string(d.size()) : "")] = p.expr;
+  for (const auto& p : params_.declaredParameters()) d["formula:" + p.name] = p.expr;
+  return d;
+}
+
+void LidarOdometry::saveTrajectoryTUM(const std::string& path) const {
+  FILE* f = fopen(path.c_str(), "w");
+  if (!f) throw std::runtime_error("cannot write " + path);
+  for (const auto& [t, p] : trajectory_) {
+    // rotation matrix -> unit quaternion (w >= 0)
+    const double* T = p.T;
+    const double tr = T[0] + T[5] + T[10];
+    double qw, qx, qy, qz;
+    if (tr > 0) {
+      const double s = std::sqrt(tr + 1.0) * 2;
+      qw = 0.25 * s; qx = (T[9] - T[6]) / s; qy = (T[2] - T[8]) / s; qz = (T[4] - T[1]) / s;
+    } else if (T[0] > T[5] && T[0] > T[10]) {
+      const double s = std::sqrt(1.0 + T[0] - T[5] - T[10]) * 2;
+      qw = (T[9] - T[6]) / s; qx = 0.25 * s; qy = (T[1] + T[4]) / s; qz = (T[2] + T[8]) / s;
+    } else if (T[5] > T[10]) {
+      const double s = std::sqrt(1.0 + T[5] - T[0] - T[10]) * 2;
+      qw = (T[2] - T[8]) / s; qx = (T[1] + T[4]) / s; qy = 0.25 * s; qz = (T[6] + T[9]) / s;
+    } else {
+      const double s = std::sqrt(1.0 + T[10] - T[0] - T[5]) * 2;
+      qw = (T[4] - T[1]) / s; qx = (T[2] + T[8]) / s; qy = (T[6] + T[9]) / s; qz = 0.25 * s;
+    }
+    if (qw < 0) { qw = -qw; qx = -qx; qy = -qy; qz = -qz; }
+    fprintf(f, "%.9f %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n", t, T[3], T[7], T[11], qx, qy, qz, qw);
+  }
+  fclose(f);
+}
+
+}  // namespace mola_hip

@@ -5,6 +5,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include "mola_lidar_odometry_hip/LidarOdometry.h"
 #include "mp2p_icp_hip/mp2p_icp_hip.h"
 
 namespace py = pybind11;
@@ -102,5 +103,51 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
           ICP::IterationHook_Output o;
           o.request_stop = f(in.currentIteration, std::vector<double>(in.currentSolution->optimalPose.T, in.currentSolution->optimalPose.T + 12));
           return o; }); });
+  // ---- stand-alone odometry driver
+  using mola_hip::LidarOdometry;
+  auto rec2dict = [](const LidarOdometry::ScanRecord& r) {
+    py::dict d;
+    d["timestamp"] = r.timestamp; d["dropped"] = r.dropped; d["first_scan"] = r.first_scan; d["icp_run"] = r.icp_run;
+    d["icp_good"] = r.icp_good; d["had_motion_model"] = r.had_motion_model; d["map_updated"] = r.map_updated;
+    d["restarted"] = r.restarted;
+    d["pose"] = std::vector<double>(r.pose.T, r.pose.T + 12);
+    d["init_guess"] = std::vector<double>(r.init_guess.T, r.init_guess.T + 12);
+    d["goodness"] = r.goodness; d["sigma"] = r.sigma; d["estimated_sensor_max_range"] = r.estimated_sensor_max_range;
+    d["instantaneous_sensor_max_range"] = r.instantaneous_sensor_max_range;
+    d["icp_iterations"] = r.icp_iterations; d["twist_corrections"] = r.twist_corrections; d["align_calls"] = r.align_calls;
+    d["termination"] = r.termination; d["n_raw"] = r.n_raw; d["n_for_map"] = r.n_for_map; d["n_for_icp"] = r.n_for_icp;
+    d["n_map_points"] = r.n_map_points; d["n_map_voxels"] = r.n_map_voxels;
+    d["twist"] = std::vector<double>{r.twist.vx, r.twist.vy, r.twist.vz, r.twist.wx, r.twist.wy, r.twist.wz};
+    d["decim_map_resolution"] = r.decim_map_resolution; d["decim_icp_resolution"] = r.decim_icp_resolution;
+    d["map_voxel_size"] = r.map_voxel_size;
+    return d;
+  };
+  py::class_<LidarOdometry>(m, "LidarOdometry")
+      .def(py::init([]() { return std::make_unique<LidarOdometry>(); }))
+      .def("initialize", &LidarOdometry::initialize)
+      .def("reset", &LidarOdometry::reset)
+      .def("onLidar", [rec2dict](LidarOdometry& lo, double stamp, py::array_t<float, py::array::c_style | py::array::forcecast> xyz,
+                                 std::optional<py::array_t<float, py::array::c_style | py::array::forcecast>> t) {
+        auto r = xyz.unchecked<2>();
+        if (r.shape(1) != 3) throw std::runtime_error("xyz must be [n,3]");
+        const size_t n = (size_t)r.shape(0);
+        std::vector<float> x(n), y(n), z(n);
+        for (size_t i = 0; i < n; i++) { x[i] = r(i, 0); y[i] = r(i, 1); z[i] = r(i, 2); }
+        const float* tp = nullptr;
+        if (t) {
+          if ((size_t)t->size() != n) throw std::runtime_error("t must have n entries");
+          tp = t->data();
+        }
+        return rec2dict(lo.onLidar(stamp, x.data(), y.data(), z.data(), tp, n)); },
+           py::arg("timestamp"), py::arg("xyz"), py::arg("t") = std::nullopt)
+      .def("records", [rec2dict](const LidarOdometry& lo) { py::list l; for (auto& r : lo.records()) l.append(rec2dict(r)); return l; })
+      .def("trajectory", [](const LidarOdometry& lo) {
+        py::list l;
+        for (auto& [t, p] : lo.estimatedTrajectory()) l.append(py::make_tuple(t, std::vector<double>(p.T, p.T + 12)));
+        return l; })
+      .def("saveTrajectoryTUM", &LidarOdometry::saveTrajectoryTUM)
+      .def("dynamicVariables", &LidarOdometry::dynamicVariables)
+      .def("describePipeline", &LidarOdometry::describePipeline)
+      .def("localMapSize", [](const LidarOdometry& lo) { return lo.localMap() ? lo.localMap()->size() : 0; });
   m.def("icp_pipeline_from_yaml", [](const Config& c) { auto t = icp_pipeline_from_yaml(c); return py::make_tuple(std::get<0>(t), std::get<1>(t)); });
 }

@@ -172,6 +172,98 @@ def make_scan(scene: Scene, pose_ypr, rings: int = 64, azimuths: int = 1875, see
     return np.ascontiguousarray(d_local[hit] * rngs[:, None], dtype=np.float32)
 
 
+def _so3_exp(w: np.ndarray) -> np.ndarray:
+    """Rodrigues for a batch of rotation vectors [N,3] -> [N,3,3]."""
+    th = np.linalg.norm(w, axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a = np.where(th < 1e-8, 1.0 - th * th / 6.0, np.sin(th) / th)
+        b = np.where(th < 1e-8, 0.5 - th * th / 24.0, (1.0 - np.cos(th)) / (th * th))
+    W = np.zeros((len(w), 3, 3))
+    W[:, 0, 1], W[:, 0, 2], W[:, 1, 0], W[:, 1, 2], W[:, 2, 0], W[:, 2, 1] = -w[:, 2], w[:, 1], w[:, 2], -w[:, 0], -w[:, 1], w[:, 0]
+    return np.eye(3)[None] + a[:, None, None] * W + b[:, None, None] * (W @ W)
+
+
+def _raycast(scene: Scene, o: np.ndarray, d: np.ndarray) -> np.ndarray:
+    """Distance along each ray (origins o[N,3], unit directions d[N,3]) to the first scene surface (inf = none)."""
+    tmin = np.full(len(d), np.inf)
+    h, ex = scene.half_extent, scene.end_wall_x
+
+    def plane(axis, value, bounds):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (value - o[:, axis]) / d[:, axis]
+        p = o + t[:, None] * d
+        ok = (t > 1e-6) & np.isfinite(t)
+        for ax, lo, hi in bounds:
+            ok &= (p[:, ax] >= lo) & (p[:, ax] <= hi)
+        np.minimum(tmin, np.where(ok, t, np.inf), out=tmin)
+
+    plane(2, 0.0, [(0, -h, h), (1, -h, h)])
+    for s in (-1.0, 1.0):
+        plane(1, s * FACADE_Y, [(0, -h, h), (2, 0.0, FACADE_H)])
+        plane(0, s * ex, [(1, -FACADE_Y, FACADE_Y), (2, 0.0, FACADE_H)])
+    for b in scene.boxes:  # slab test
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t0 = (b[None, :3] - o) / d
+            t1 = (b[None, 3:] - o) / d
+        tn = np.nanmax(np.minimum(t0, t1), axis=1)
+        tf = np.nanmin(np.maximum(t0, t1), axis=1)
+        ok = (tf >= tn) & (tn > 1e-6)
+        np.minimum(tmin, np.where(ok, tn, np.inf), out=tmin)
+    return tmin
+
+
+def make_sweep(scene: Scene, T_ref, twist, sweep_time: float = 0.1, rings: int = 32, azimuths: int = 600,
+               seed: int = 1, max_range: float = 120.0, range_noise: float = 0.02):
+    """One sweep of a spinning LiDAR that moves with a constant twist (vx,vy,vz,wx,wy,wz, vehicle frame) while it
+    scans: azimuth column j fires at t_j = (j/azimuths - 0.5)*sweep_time relative to the scan's reference time, from
+    the pose T_ref (+) (Exp_SO3(w t_j), v t_j) -- the motion model FilterDeskew undoes (lidar3d-default.yaml:328-350).
+    Returns (xyz [N,3] fp32 in the sensor frame AT FIRING TIME, i.e. skewed; t [N] fp32), ring-major order."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    T = np.asarray(T_ref, dtype=np.float64).reshape(3, 4)
+    tw = np.asarray(twist, dtype=np.float64)
+    el = np.deg2rad(np.linspace(2.0, -24.8, rings))
+    az = np.linspace(-np.pi, np.pi, azimuths, endpoint=False)
+    tcol = (np.arange(azimuths) / azimuths - 0.5) * sweep_time
+    E, A = np.meshgrid(el, az, indexing="ij")
+    tt = np.broadcast_to(tcol[None, :], E.shape).reshape(-1)
+    d_local = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
+    Rt = _so3_exp(tw[None, 3:] * tt[:, None])                      # rotation of the sensor at firing time, in T_ref
+    pt = tw[None, :3] * tt[:, None]
+    R = T[None, :, :3] @ Rt
+    o = (T[:, :3] @ pt.T).T + T[:, 3]
+    d = np.einsum("nij,nj->ni", R, d_local)
+    tmin = _raycast(scene, o, d)
+    hit = tmin < max_range
+    rngs = tmin[hit] + rng.normal(0.0, range_noise, int(hit.sum()))
+    return (np.ascontiguousarray(d_local[hit] * rngs[:, None], dtype=np.float32),
+            np.ascontiguousarray(tt[hit], dtype=np.float32))
+
+
+def make_drive(n_scans: int = 12, dt: float = 0.1, speed: float = 8.0, yaw_rate: float = 0.12, rings: int = 32,
+               azimuths: int = 600, seed: int = 4242, half_extent: float = 120.0, n_boxes: int = 160,
+               ramp_scans: int = 6):
+    """A synthetic drive along the street canyon: ground-truth poses (12 doubles each), per-scan twists and skewed
+    sweeps with per-point time stamps.  The vehicle pulls away from rest over `ramp_scans` scans and then moves with
+    a slowly varying twist; the pose at scan k+1 is the pose at scan k composed with (Exp_SO3(w dt), v dt), so a
+    constant-velocity model is exact up to the variation.  The canyon is cluttered (n_boxes) because two facades and
+    a ground plane alone do not constrain the motion along the street."""
+    scene = make_scene(seed, half_extent, n_boxes)
+    T = pose_from_ypr([-60.0, 0.5, SENSOR_H, 0.0, 0.0, 0.0]).reshape(3, 4)
+    poses, twists, scans, stamps = [], [], [], []
+    for k in range(n_scans):
+        gain = min(1.0, k / float(ramp_scans)) if ramp_scans > 0 else 1.0
+        tw = np.array([gain * speed * (1.0 + 0.05 * np.sin(0.7 * k)), 0.02 * np.cos(0.5 * k), 0.0, 0.0, 0.0,
+                       gain * yaw_rate * np.sin(0.9 * k)])
+        xyz, t = make_sweep(scene, T.reshape(12), tw, dt, rings, azimuths, seed + 10 * k)
+        poses.append(T.reshape(12).copy())
+        twists.append(tw)
+        scans.append((xyz, t))
+        stamps.append(1000.0 + k * dt)
+        Rn = _so3_exp((tw[3:] * dt)[None])[0]
+        T = np.concatenate([T[:, :3] @ Rn, (T[:, :3] @ (tw[:3] * dt) + T[:, 3])[:, None]], axis=1)
+    return dict(scene=scene, poses=np.asarray(poses), twists=np.asarray(twists), scans=scans, stamps=np.asarray(stamps))
+
+
 def threshold_schedule(sigma: float, n_iters: int):
     """Matcher threshold and robust-kernel parameter as functions of ICP_ITERATION
     (lidar3d-default.yaml:198 and :190)."""

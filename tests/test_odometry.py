@@ -1,0 +1,191 @@
+"""Stand-alone odometry driver.
+
+CPU: the pipeline files are recognised by the C++ driver (no GPU needed to load them), the trajectory I/O / metrics
+are right, and the CPU oracle driver tracks a synthetic drive.  GPU (-m gpu): the C++ driver on libmolahip reproduces
+the oracle driver scan by scan -- same decisions (key-frames, hook re-runs, iteration counts, layer sizes, map
+sizes) and the same poses far inside the 1e-4 m / 1e-4 rad bar."""
+import os
+
+import numpy as np
+import pytest
+
+from mola_lidar_odometry_amd import synth, trajectory
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PIPE = os.path.join(ROOT, "pipelines", "lidar3d-default-hip.yaml")
+PIPE_NDT = os.path.join(ROOT, "pipelines", "lidar3d-ndt-hip.yaml")
+REF_PIPES = "/root/reference/pipelines"
+
+
+@pytest.fixture(scope="module")
+def host():
+    from mola_lidar_odometry_amd import _mp2p_icp_hip as H
+    return H
+
+
+@pytest.fixture(scope="module")
+def drive():
+    return synth.make_drive(14)
+
+
+def _gt_rel(drive):
+    G = np.stack([trajectory.to44(p) for p in drive["poses"]])
+    return np.linalg.inv(G[0])[None] @ G
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+@pytest.mark.parametrize("path", [PIPE, PIPE_NDT, REF_PIPES + "/lidar3d-default.yaml", REF_PIPES + "/lidar3d-ndt.yaml"])
+def test_driver_recognises_pipeline(host, path):
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present on this box")
+    lo = host.LidarOdometry()
+    lo.initialize(host.Config.FromYamlFile(path))
+    d = lo.describePipeline()
+    assert d["layer_for_icp"] == "decimated_for_icp" and d["layer_for_map"] == "decimated_for_map"
+    assert d["map_layer"] == "localmap" and d["min_points_to_filter"] == "2000"
+    assert int(d["bbox_mode"]) == 1 and int(d["timestamp_method"]) == 1 and d["skip_deskew"] == "false"
+    assert d["map_class"] == ("mola::NDT" if "ndt" in os.path.basename(path) else "mola::HashedVoxelPointCloud")
+    assert d["formula:range_max"] == "1.2*ESTIMATED_SENSOR_MAX_RANGE"
+    assert "ESTIMATED_SENSOR_MAX_RANGE" in d["formula:min_translation_between_keyframes"]
+    with pytest.raises(RuntimeError):
+        lo.initialize(host.Config.FromYamlFile(path))  # one object, one pipeline
+
+
+def test_repo_pipelines_carry_the_reference_values(host):
+    """The driver sections of pipelines/*-hip.yaml must say what the reference pipelines say (checked with PyYAML,
+    independently of the C++ reader)."""
+    if not os.path.exists(REF_PIPES):
+        pytest.skip("reference tree not present on this box")
+    from oracle import odometry_oracle as oo
+    for mine, ref in ((PIPE, "lidar3d-default.yaml"), (PIPE_NDT, "lidar3d-ndt.yaml")):
+        a, b = oo.load_pipeline(mine), oo.load_pipeline(os.path.join(REF_PIPES, ref))
+        for key in ("observations_filter_adjust_timestamps", "observations_filter_1st_pass", "insert_observation_into_local_map"):
+            assert a[key] == b[key], key
+        deskew = [e for e in b["observations_filter_2nd_pass"] if e["class_name"].endswith("FilterDeskew")]
+        assert a["observations_filter_2nd_pass"] == deskew
+        for k, v in a["params"].items():
+            if isinstance(v, dict):
+                for kk, vv in v.items():
+                    assert b["params"][k][kk] == vv, (k, kk)
+            else:
+                assert b["params"][k] == v, k
+        assert a["navstate_fuse_params"]["max_time_to_use_velocity_model"] == b["navstate_fuse_params"]["max_time_to_use_velocity_model"]
+        ma = a["localmap_generator"][0]["params"]["metric_map_definition"]
+        mb = b["localmap_generator"][0]["params"]["metric_map_definition"]
+        assert ma["class"] == mb["class"] and ma["creationOpts"] == mb["creationOpts"] and ma["insertOpts"] == mb["insertOpts"]
+
+
+def test_unsupported_chain_is_rejected(host, tmp_path):
+    txt = open(PIPE).read().replace("DecimateMethod::FirstPoint", "DecimateMethod::ClosestToAverage")
+    p = tmp_path / "bad.yaml"
+    p.write_text(txt)
+    with pytest.raises(RuntimeError, match="unsupported observation filter chain"):
+        host.LidarOdometry().initialize(host.Config.FromYamlFile(str(p)))
+
+
+def test_tum_roundtrip_and_metrics(tmp_path):
+    rng = np.random.default_rng(0)
+    n = 400
+    poses = np.tile(np.eye(4), (n, 1, 1))
+    for i in range(1, n):
+        d = trajectory.to44(synth.pose_from_ypr([2.5, 0.01 * rng.normal(), 0.0, 0.004 * rng.normal() + 0.002, 0.0, 0.0]))
+        poses[i] = poses[i - 1] @ d
+    stamps = 10.0 + 0.1 * np.arange(n)
+    f = tmp_path / "t.tum"
+    trajectory.write_tum(str(f), stamps, poses)
+    s2, p2 = trajectory.read_tum(str(f))
+    np.testing.assert_allclose(s2, stamps, atol=1e-9)
+    np.testing.assert_allclose(p2, poses, atol=2e-8)
+    assert trajectory.ate_rmse(p2, poses) < 1e-7
+    te, re, k = trajectory.kitti_relative_errors(poses, poses)
+    assert k > 0 and te < 1e-9 and re < 1e-6
+    # a 1 % scale error along the path shows up as ~1 % translation error
+    est = poses.copy()
+    est[:, :3, 3] *= 1.01
+    te, re, _ = trajectory.kitti_relative_errors(est, poses)
+    assert 0.9 < te < 1.1 and re < 1e-6
+    # rigidly displaced copy: zero after SE(3) alignment, not before
+    M = trajectory.to44(synth.pose_from_ypr([5, -3, 1, 0.4, 0.1, -0.2]))
+    moved = M[None] @ poses
+    assert trajectory.ate_rmse(moved, poses, "se3") < 1e-6 < trajectory.ate_rmse(moved, poses, "none")
+    ia, ib = trajectory.associate(stamps[::2] + 0.001, stamps)
+    np.testing.assert_array_equal(ib, np.arange(0, n, 2))
+    # the reference's own GT fragment parses (23 poses, starts at identity)
+    ref = "/root/reference/test/rslidar_fragment_gt.tum"
+    if os.path.exists(ref):
+        s, p = trajectory.read_tum(ref)
+        assert len(s) == len(p) > 10 and np.allclose(p[0], np.eye(4), atol=1e-6)
+
+
+def test_oracle_driver_tracks_synthetic_drive(drive):
+    from oracle import odometry_oracle as oo
+    o = oo.OdometryOracle(PIPE, n_threads=8)
+    for (xyz, t), st in zip(drive["scans"], drive["stamps"]):
+        r = o.on_lidar(st, xyz, t)
+    recs = o.records
+    assert recs[0]["first_scan"] and not recs[0]["icp_run"] and recs[0]["map_updated"]
+    assert recs[1]["icp_run"] and not recs[1]["had_motion_model"] and not recs[1]["map_updated"]  # App. C.6
+    assert all(r["icp_good"] and r["had_motion_model"] for r in recs[2:])
+    assert sum(r["twist_corrections"] for r in recs) >= 1  # the hook loop is exercised
+    est = np.stack([trajectory.to44(p) for _, p in o.trajectory])
+    assert trajectory.ate_rmse(est, _gt_rel(drive), "none") < 0.2
+    sig = [r["sigma"] for r in recs[1:]]
+    assert all(0.1 <= s <= 3.0 for s in sig) and sig[-1] < sig[0]  # adaptive threshold shrinks while tracking well
+    # dropped scan: closer in time than min_time_between_scans
+    r = o.on_lidar(drive["stamps"][-1] + 1e-4, *drive["scans"][-1])
+    assert r["dropped"]
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_driver_matches_oracle_driver(host, drive, tmp_path):
+    from oracle import odometry_oracle as oo
+    o = oo.OdometryOracle(PIPE, n_threads=8)
+    lo = host.LidarOdometry()
+    lo.initialize(host.Config.FromYamlFile(PIPE))
+    worst_t = worst_r = 0.0
+    for k, ((xyz, t), st) in enumerate(zip(drive["scans"], drive["stamps"])):
+        a = lo.onLidar(st, xyz, t)
+        b = o.on_lidar(st, xyz, t)
+        for key in ("dropped", "first_scan", "icp_run", "icp_good", "had_motion_model", "map_updated", "restarted",
+                    "icp_iterations", "twist_corrections", "align_calls", "termination", "n_raw", "n_for_map",
+                    "n_for_icp", "n_map_points", "n_map_voxels"):
+            assert a[key] == b[key], (k, key, a[key], b[key])
+        for key in ("goodness", "sigma", "estimated_sensor_max_range", "instantaneous_sensor_max_range",
+                    "decim_map_resolution", "decim_icp_resolution"):
+            assert abs(a[key] - b[key]) <= 1e-9 * max(1.0, abs(b[key])), (k, key, a[key], b[key])
+        np.testing.assert_allclose(a["twist"], b["twist"], rtol=0, atol=1e-6)
+        Ta, Tb = np.array(a["pose"]).reshape(3, 4), b["pose"].reshape(3, 4)
+        worst_t = max(worst_t, float(np.linalg.norm(Ta[:, 3] - Tb[:, 3])))
+        worst_r = max(worst_r, float(np.linalg.norm(Ta[:, :3] - Tb[:, :3])))
+    assert worst_t < 1e-6 and worst_r < 1e-6, (worst_t, worst_r)  # bar: 1e-4 m / 1e-4 rad
+    # trajectory out, TUM file, accuracy against the ground truth of the synthetic drive
+    f = tmp_path / "est.tum"
+    lo.saveTrajectoryTUM(str(f))
+    stamps, est = trajectory.read_tum(str(f))
+    np.testing.assert_allclose(stamps, drive["stamps"], atol=1e-6)
+    assert trajectory.ate_rmse(est, _gt_rel(drive), "none") < 0.2
+    dropped = lo.onLidar(drive["stamps"][-1] + 1e-4, *drive["scans"][-1])
+    assert dropped["dropped"]
+
+
+@pytest.mark.gpu
+def test_hip_driver_ndt_pipeline_and_restart(host, drive):
+    lo = host.LidarOdometry()
+    lo.initialize(host.Config.FromYamlFile(PIPE_NDT))
+    for (xyz, t), st in zip(drive["scans"][:8], drive["stamps"][:8]):
+        r = lo.onLidar(st, xyz, t)
+    recs = lo.records()
+    assert all(r["icp_good"] for r in recs[1:]) and recs[-1]["n_map_points"] > 1000
+    est = np.stack([trajectory.to44(p) for _, p in lo.trajectory()])
+    assert trajectory.ate_rmse(est, _gt_rel(drive)[:8], "none") < 0.3
+    # a hopeless second scan (unrelated cloud): ICP rejected right after the start => map dropped, start over (:1146-1156)
+    lo2 = host.LidarOdometry()
+    lo2.initialize(host.Config.FromYamlFile(PIPE))
+    lo2.onLidar(1.0, *drive["scans"][0])
+    rng = np.random.default_rng(5)
+    junk = (rng.normal(0, 1, (20000, 3)) * [30, 30, 30] + [0, 0, 500]).astype(np.float32)
+    r = lo2.onLidar(1.1, junk, None)
+    assert r["icp_run"] and not r["icp_good"] and r["restarted"] and len(lo2.trajectory()) == 0
+    r = lo2.onLidar(1.2, *drive["scans"][1])
+    assert r["first_scan"] and r["map_updated"]
