@@ -28,6 +28,10 @@
 using namespace mh;
 
 constexpr uint32_t kBlock = 256;
+#ifndef MH_QUAD_WAVES
+#define MH_QUAD_WAVES 4  // waves per SIMD the register allocator may assume for the quad kernels: with the default target
+                         // it recycles the same registers for the scan loads and so serialises their round trips
+#endif
 #ifndef MH_MATCH_WAVES
 #define MH_MATCH_WAVES 1  // min waves per SIMD asked of the register allocator for k_match (tuning knob)
 #endif
@@ -38,7 +42,8 @@ struct IcpDeviceState {
   double T_prev[12];
   uint32_t iter, inner, done, term_reason;
   uint32_t n_pairs, n_iterations, solver_ok, n_solves;
-  uint32_t cov_done, n_pairs_pl, pad1, pad2;
+  uint32_t cov_done, n_pairs_pl;
+  float cur_thr2, cur_ang2;  // matcher threshold^2 of iteration `iter` and the angular term: k_match4 reads nothing but this block
   double cov[36];
   double covD[72];  // (T(x+h_j) - T(x-h_j)) / (2 h_j), j = 0..5, 3x4 each
 };
@@ -95,7 +100,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 // ================================================================================================
 // k_match: correspondence search (+ first Gauss-Newton accumulation when FUSED)
 // ================================================================================================
-template <bool FUSED, bool PRUNE>
+template <bool FUSED, int MODE /* 0: literal 27-voxel scan | 1: exact branch-and-bound */>
 __global__ __launch_bounds__(kBlock, MH_MATCH_WAVES) void k_match(const IcpDeviceState* __restrict__ st, PoseArg Targ, float thr2_arg,
                                                   uint32_t apply_thr, const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(kBlock, MH_MATCH_WAVES) void k_match(const IcpDevic
     const float x = lx[i], y = ly[i], z = lz[i];
     float px, py, pz;
     transform_point(T, x, y, z, px, py, pz);
-    const NNResult r = PRUNE ? nn_search_pruned(map, px, py, pz) : nn_single_search(map, px, py, pz);
+    const NNResult r = MODE == 1 ? nn_search_pruned(map, px, py, pz) : nn_single_search(map, px, py, pz);
     bool ok = r.found;
     if (FUSED || apply_thr) {
       const float n2 = (px * px + py * py) + pz * pz;
@@ -146,288 +151,65 @@ __global__ __launch_bounds__(kBlock, MH_MATCH_WAVES) void k_match(const IcpDevic
       if (lane == 0) lds[wave][j] = s;
     }
     __syncthreads();
-    if (threadIdx.x < kAccN)
-      partials[threadIdx.x * pstride + bid] =
-          ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+    if (threadIdx.x < kAccN) {
+      double sum = lds[0][threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < (int)(kBlock / 64); w++) sum += lds[w][threadIdx.x];  // fixed order: bitwise reproducible
+      partials[threadIdx.x * pstride + bid] = sum;
+    }
   }
 }
 
-// ================================================================================================
-// k_matchr: "one 16-lane row per voxel run" version of the exact branch-and-bound search.
-//
-// Lessons of the instrumented k_matchw (s_memtime per phase, C2): a dependent round trip costs ~2k cycles here, so a
-// wave's time is (#round trips) x 2k + work; the item list cost 11k cycles to produce and the same-address LDS atomics
-// of consecutive items another ~10k.  This version keeps the pooling idea but drops the item list:
-//   * a wave owns QPW = 32 scan points (lanes 0..31 take the per-point decisions); twice as many, lighter waves also
-//     shorten the tail that the slowest wave imposes on a one-scan launch;
-//   * surviving voxel runs (split to <= 16 records) go to a per-wave run table {first, count | owner << 16} in LDS;
-//   * consumption is run-major: each 16-lane row takes one run, lane t loads record first+t (one coalesced 256-byte
-//     access per row), eight rows-steps (32 runs) are in flight before the first is looked at;
-//   * the row minimum of (d2 bits << 32 | record index) is taken with DPP row shifts (VALU only, no LDS traffic) and
-//     lane 0 of the row issues ONE ds_min_u64 for the run -- at most 4 atomics per step, to different owners.
-// Exactness is unchanged: integer order of the key == lexicographic (d2, scan position) == the reference's first strict
-// minimum; a voxel is skipped only if its conservative lower bound exceeds the best d2 already found.
-// ================================================================================================
-constexpr int kQPW = 32;       // scan points per wave
-constexpr int kRowLanes = 16;  // lanes co-operating on one run
-constexpr int kProbeCap = 12;  // neighbour probes per point per pass
-constexpr int kRunTab = kQPW * kProbeCap * 2;  // run-table entries per wave (a run of <= 32 records is <= 2 entries)
 
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
+#ifdef MH_DEBUG_WAVETRACE
+static unsigned long long* g_wtrace = nullptr;  // debug build only: [2 * n_waves] begin/end wall_clock64 of the last launch
+extern "C" __attribute__((visibility("default"))) int mh_debug_wavetrace(unsigned long long* host_out, size_t n_waves) {
+  if (!g_wtrace) { if (hipMalloc(&g_wtrace, 16u << 20) != hipSuccess) return 1; (void)hipMemset(g_wtrace, 0, 16u << 20); return 0; }
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(host_out, g_wtrace, n_waves * 16, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
 }
-// min over the 16 lanes of a row, result valid in lane 0 of the row (row_shl:k = lane i reads lane i+k of its row)
-__device__ __forceinline__ unsigned long long row_min_u64(unsigned long long key) {
-#define MH_ROW_STEP(CTRL)                                                     \
-  {                                                                           \
-    const uint32_t lo = dpp_u32<CTRL>(0xFFFFFFFFu, (uint32_t)key);            \
-    const uint32_t hi = dpp_u32<CTRL>(0xFFFFFFFFu, (uint32_t)(key >> 32));    \
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;         \
-    key = o < key ? o : key;                                                  \
-  }
-  MH_ROW_STEP(0x101)
-  MH_ROW_STEP(0x102)
-  MH_ROW_STEP(0x104)
-  MH_ROW_STEP(0x108)
-#undef MH_ROW_STEP
-  return key;
-}
-
-template <bool FUSED>
-__global__ __launch_bounds__(kBlock) void k_matchr(const IcpDeviceState* __restrict__ st, PoseArg Targ, float thr2_arg,
-                                                   uint32_t apply_thr, const MatchK* __restrict__ kp, const float* __restrict__ lx,
-                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
-                                                   MapView map, float4* __restrict__ pair_q,
-                                                   uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
-                                                   uint32_t pstride) {
-  constexpr int NW = kBlock / 64;
-  __shared__ float4 s_qpos[NW][kQPW];
-  __shared__ unsigned long long s_best[NW][kQPW];
-  __shared__ uint2 s_tab[NW][kRunTab];
-  __shared__ double lds[NW][kAccN];
-  const MatchK k = *kp;  // wave-uniform scalar loads
+#endif
+// ================================================================================================
+// k_match4: correspondence search with a DPP quad per scan point (nn_search_quad).  Device-state driven like the
+// fused k_match, but it only stores the pairings: the first Gauss-Newton accumulation is the k_accum launch that
+// follows (64 points per wave there, 16 here).
+// ================================================================================================
+__global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDeviceState* __restrict__ st,
+                                                   const float* __restrict__ lx, const float* __restrict__ ly,
+                                                   const float* __restrict__ lz, uint32_t n, MapView map,
+                                                   float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx
+#ifdef MH_DEBUG_WAVETRACE
+                                                   , unsigned long long* __restrict__ wtrace
+#endif
+) {
+#ifdef MH_DEBUG_WAVETRACE
+  struct WT { unsigned long long* p; unsigned long long t0; uint32_t w;
+              __device__ ~WT() { if ((threadIdx.x & 63) == 0 && p) { p[2 * w] = t0; p[2 * w + 1] = wall_clock64(); } } }
+      wt{wtrace, (unsigned long long)wall_clock64(), (blockIdx.x * kBlock + threadIdx.x) >> 6};
+#endif
+  // everything needed per iteration sits in the state block (k_solve publishes the next threshold there): one batch of
+  // scalar loads instead of the chain state -> parameter block -> threshold table, and the point is fetched alongside
+  // (handing each XCD a contiguous range of the scan -- xcd_block() -- measured 10 % slower: L2 misses are not what
+  //  this kernel waits for, and a contiguous range concentrates the crowded parts of the scene on one XCD)
+  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = gl >> 2, sub = gl & 3u;
+  const uint32_t ic = i < n ? i : n - 1;
+  const float x = lx[ic], y = ly[ic], z = lz[ic];
+  const uint32_t done = st->done;
   double T[12];
-  float thr2;
-  double kparam = 0.0;
-  if (FUSED) {
-    if (st->done) return;  // wave-uniform
-    const uint32_t it = st->iter;
 #pragma unroll
-    for (int i = 0; i < 12; i++) T[i] = st->T[i];
-    const double thr = k.thr[it];
-    thr2 = (float)(thr * thr);
-    kparam = k.kparam[it];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 12; i++) T[i] = Targ.m[i];
-    thr2 = thr2_arg;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool owner_lane = lane < kQPW;
-  const uint32_t bid = blockIdx.x;
-  const uint32_t i = (bid * NW + wave) * kQPW + lane;  // scan point of an owner lane
-  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(map.slots);
-  const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(map.pts);
-  float4* qpos = s_qpos[wave];
-  unsigned long long* best = s_best[wave];
-  uint2* tab = s_tab[wave];
-
-  float x = 0.f, y = 0.f, z = 0.f, px = 0.f, py = 0.f, pz = 0.f;
-  bool valid = false;
-  if (owner_lane && i < n) {
-    x = lx[i]; y = ly[i]; z = lz[i];
-    transform_point(T, x, y, z, px, py, pz);
-    const float lim = 1.0e6f;
-    valid = isfinite(px) && isfinite(py) && isfinite(pz) && fabsf(px * map.inv_vs) < lim && fabsf(py * map.inv_vs) < lim &&
-            fabsf(pz * map.inv_vs) < lim;
-  }
-  if (owner_lane) {
-    qpos[lane] = make_float4(px, py, pz, 0.f);
-    best[lane] = ~0ull;
-  }
-  unsigned long long kbase = 0;
-  Gaps gx, gy, gz;
-  gx.s[0] = gx.s[1] = gx.s[2] = gy.s[0] = gy.s[1] = gy.s[2] = gz.s[0] = gz.s[1] = gz.s[2] = 0.f;
-  if (valid) {
-    const int cx = voxel_of(px, map.inv_vs, map.trunc), cy = voxel_of(py, map.inv_vs, map.trunc), cz = voxel_of(pz, map.inv_vs, map.trunc);
-    kbase = pack_key(cx - 1, cy - 1, cz - 1);
-    const float vs = 1.0f / map.inv_vs;
-    gx = axis_gaps(px, cx, vs, map.trunc);
-    gy = axis_gaps(py, cy, vs, map.trunc);
-    gz = axis_gaps(pz, cz, vs, map.trunc);
-  }
-
-  // resolve a probed slot to {first, count} (count 0 = voxel absent); rare linear probing past collisions
-  auto resolve = [&](unsigned long long key, u32x4 sl) -> uint2 {
-    unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
-    if (sk != key && sk != kEmptyKey) {
-      uint32_t h = hash_key(key) & map.mask;
-      do {
-        h = (h + 1) & map.mask;
-        sl = slots4[h];
-        sk = ((unsigned long long)sl.y << 32) | sl.x;
-      } while (sk != key && sk != kEmptyKey);
-    }
-    return sk == key ? make_uint2(sl.z, sl.w) : make_uint2(0u, 0u);
-  };
-  // a run longer than 32 records (only possible with max_points_per_voxel > 32 or 0) is scanned by its owner alone
-  auto scan_long_run = [&](uint2 r) {
-    NNBest b;
-    b.d2 = __builtin_inff();
-    b.idx = 0xFFFFFFFFu;
-    nn_scan_voxel(pts4, r.x, r.y, px, py, pz, b);
-    if (b.idx != 0xFFFFFFFFu) atomicMin(&best[lane], ((unsigned long long)__float_as_uint(b.d2) << 32) | b.idx);
-  };
-  // wave-wide exclusive prefix sum of a per-lane count
-  auto wave_excl = [&](uint32_t v, uint32_t& total) -> uint32_t {
-    uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
-      if (lane >= off) incl += t;
-    }
-    total = (uint32_t)__shfl((int)incl, 63);
-    return incl - v;
-  };
-  // consume `R` run-table entries: one 16-lane row per entry, 8 row-steps (32 entries) of loads in flight
-  const int row = lane >> 4, tl = lane & (kRowLanes - 1);
-  auto consume = [&](uint32_t R) {
-    wave_sync_lds();
-    for (uint32_t base = 0; base < R; base += 32) {
-      uint2 e[8];
-      f32x4 rec[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const uint32_t r = base + u * 4 + row;
-        e[u] = tab[r < R ? r : R - 1];
-        if (r >= R) e[u].y = 0;  // count 0: the row idles this step (the load below still goes to a valid record)
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const uint32_t cnt = e[u].y & 0xFFFFu;
-        const uint32_t t = (uint32_t)tl < cnt ? (uint32_t)tl : (cnt ? cnt - 1 : 0u);
-        rec[u] = pts4[e[u].x + t];  // unconditional, clamped (see k_matchw)
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const uint32_t cnt = e[u].y & 0xFFFFu, owner = e[u].y >> 16;
-        unsigned long long key = ~0ull;
-        if ((uint32_t)tl < cnt) {
-          const float4 q = qpos[owner];
-          const float dx = rec[u].x - q.x, dy = rec[u].y - q.y, dz = rec[u].z - q.z;
-          const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order
-          // NaN / inf never win ("d2 < best" is false for them in the reference)
-          if (d2 < __builtin_inff()) key = ((unsigned long long)__float_as_uint(d2) << 32) | (e[u].x + (uint32_t)tl);
-        }
-        key = row_min_u64(key);
-        if (tl == 0 && key != ~0ull) atomicMin(&best[owner], key);
-      }
-    }
-    wave_sync_lds();
-  };
-  // append this lane's run (if any) to the table, split into <= 16-record entries
-  auto table_entries_of = [&](uint2 r) -> uint32_t { return r.y == 0 || r.y > 32 ? 0u : (r.y + 15u) >> 4; };
-  auto write_entries = [&](uint32_t pos, uint2 r) {
-    if (r.y == 0 || r.y > 32) return;
-    const uint32_t tag = (uint32_t)lane << 16;
-    tab[pos] = make_uint2(r.x, (r.y < 16 ? r.y : 16u) | tag);
-    if (r.y > 16) tab[pos + 1] = make_uint2(r.x + 16, (r.y - 16) | tag);
-  };
-
-  // ---- 1. every point's own voxel (code 13) ----
-  {
-    uint2 r = make_uint2(0u, 0u);
-    if (valid) {
-      const unsigned long long key = nn_key_of(kbase, 13);
-      r = resolve(key, slots4[hash_key(key) & map.mask]);
-      if (r.y > 32) { scan_long_run(r); r.y = 0; }
-    }
-    uint32_t R;
-    const uint32_t pos = wave_excl(table_entries_of(r), R);
-    write_entries(pos, r);
-    if (R) consume(R);
-    else wave_sync_lds();
-  }
-  // ---- 2. neighbours that can still hold a candidate with d2 <= best; all their probes go out together ----
-  uint32_t mask = valid ? (0x07FFFFFFu & ~(1u << 13)) : 0u;
-  while (__ballot(mask != 0)) {
-    float bestd2 = __builtin_inff();
-    if (owner_lane) {
-      bestd2 = __uint_as_float((uint32_t)(best[lane] >> 32));
-      if (!(bestd2 == bestd2)) bestd2 = __builtin_inff();  // 0xFFFFFFFF (nothing found yet) reads as NaN
-    }
-    {
-      uint32_t m2 = 0;
-#pragma unroll
-      for (int c = 0; c < 27; c++) {
-        if (c == 13) continue;
-        const float lb = (gx.s[c / 9] + gy.s[(c / 3) % 3]) + gz.s[c % 3];
-        if (!(lb * 0.9999f > bestd2)) m2 |= 1u << c;
-      }
-      mask &= m2;
-    }
-    int c[kProbeCap];
-    u32x4 sl[kProbeCap];
-#pragma unroll
-    for (int t = 0; t < kProbeCap; t++) {  // unconditional loads: kProbeCap probes in flight
-      c[t] = mask ? __builtin_ctz(mask) : -1;
-      mask &= mask - 1;
-      sl[t] = slots4[hash_key(nn_key_of(kbase, c[t] < 0 ? 13 : c[t])) & map.mask];
-    }
-    uint2 rr[kProbeCap];
-    uint32_t my_entries = 0;
-#pragma unroll
-    for (int t = 0; t < kProbeCap; t++) {
-      rr[t] = make_uint2(0u, 0u);
-      if (c[t] >= 0) {
-        rr[t] = resolve(nn_key_of(kbase, c[t]), sl[t]);
-        if (rr[t].y > 32) { scan_long_run(rr[t]); rr[t].y = 0; }
-      }
-      my_entries += table_entries_of(rr[t]);
-    }
-    uint32_t R;
-    uint32_t pos = wave_excl(my_entries, R);
-#pragma unroll
-    for (int t = 0; t < kProbeCap; t++) {
-      write_entries(pos, rr[t]);
-      pos += table_entries_of(rr[t]);
-    }
-    if (R) consume(R);
-    else wave_sync_lds();
-  }
-
-  // ---- per-point epilogue (owner lanes) ----
-  Acc a;
-  acc_zero(a);
-  if (owner_lane && i < n) {
-    const unsigned long long bk = best[lane];
-    const bool found = bk != ~0ull;
-    f32x4 pt = (f32x4)(0.f);
-    float d2 = __builtin_inff();
-    if (found) {
-      pt = pts4[(uint32_t)(bk & 0xFFFFFFFFu)];
-      d2 = __uint_as_float((uint32_t)(bk >> 32));
-    }
-    bool ok = found;
-    if (FUSED || apply_thr) {
-      const float n2 = (px * px + py * py) + pz * pz;
-      ok = ok && (d2 < thr2 + k.ang2 * n2);
-    }
-    pair_q[i] = make_float4(pt.x, pt.y, pt.z, d2);
-    pair_gidx[i] = ok ? __float_as_uint(pt.w) : kNoMatch;
-    if (FUSED && ok) acc_pt2pt(a, T, x, y, z, pt.x, pt.y, pt.z, k.kernel, kparam, k.w_pt2pt);
-  }
-  if (FUSED) {
-#pragma unroll
-    for (int j = 0; j < kAccN; j++) {
-      const double s = wave_sum(a.v[j]);
-      if (lane == 0) lds[wave][j] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < kAccN)
-      partials[threadIdx.x * pstride + bid] =
-          ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+  for (int k = 0; k < 12; k++) T[k] = st->T[k];
+  const float thr2 = st->cur_thr2, ang2 = st->cur_ang2;
+  if (done) return;  // wave-uniform
+  if (i >= n) return;  // whole quads
+  float px, py, pz;
+  transform_point(T, x, y, z, px, py, pz);
+  const NNResult r = nn_search_quad(map, sub, px, py, pz);
+  if (sub == 0) {
+    const float n2 = (px * px + py * py) + pz * pz;
+    const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
+    pair_q[i] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
+    pair_gidx[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
   }
 }
 
@@ -896,6 +678,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restr
   }
   for (int i = 0; i < 12; i++) st->T_prev[i] = Tc.m[i];
   st->iter = it + 1;
+  if (it + 1 < k.max_iterations) {
+    const double thr = k.thr[it + 1];
+    st->cur_thr2 = (float)(thr * thr);
+  }
   if (it + 1 >= k.max_iterations) {
     st->term_reason = MH_TERM_MAX_ITERATIONS;
     st->n_iterations = it + 1;
@@ -1362,9 +1148,11 @@ struct AlignJob {
       MH_HIP(hipMemcpyAsync(ctx->sched.as<double>() + 2 * mi, p->pt2pl_threshold, mi * sizeof(double), hipMemcpyHostToDevice, s));
     if (trace) MH_TRY(ctx->trace.reserve(mi * sizeof(mh_icp_iter)));
     init_state(ctx->h_state, T0);
+    const double ang = p->threshold_angular_deg * 3.14159265358979323846 / 180.0;
+    ctx->h_state->cur_thr2 = (float)(p->threshold[0] * p->threshold[0]);
+    ctx->h_state->cur_ang2 = (float)(ang * ang);
     MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpDeviceState), hipMemcpyHostToDevice, s));
 
-    const double ang = p->threshold_angular_deg * 3.14159265358979323846 / 180.0;
     mk.thr = ctx->sched.as<double>();
     mk.kparam = ctx->sched.as<double>() + mi;
     mk.ang2 = (float)(ang * ang);
@@ -1398,15 +1186,17 @@ struct AlignJob {
     sk.cov_ha = p->cov_findif_ang;
     MH_TRY(upload_params(ctx, mk, sk));
     nb = nblk(scan->n);
-    {  // MH_MATCH = "p" (default: one lane per point, exact branch-and-bound) | "x" (exhaustive 27-voxel scan, the
-       // literal reference algorithm; kept for A/B runs) | "r" (experimental: one 16-lane row per voxel run, LDS run table)
+    {  // MH_MATCH selects the correspondence kernel of the fused loop (all exact, bit-identical pairings):
+       //   "q" (default)  a DPP quad per scan point, merged candidate scans          -> k_match4 + k_accum
+       //   "p"            one lane per point, branch-and-bound, fused accumulation   -> k_match<true, 1>
+       //   "x"            one lane per point, the literal 27-voxel scan of the reference (A/B baseline)
       const char* e = getenv("MH_MATCH");
-      variant = 0;
+      variant = 4;
+      if (e && e[0] == 'p') variant = 0;
       if (e && e[0] == 'x') variant = 1;
-      if (e && e[0] == 'r') variant = 2;
-      if (map->view().ndt) variant = 0;  // NDT records are interleaved with the points: no contiguous z-runs
+      if (variant == 1 && map->view().ndt) variant = 0;  // "x" walks contiguous z-runs; NDT maps interleave statistics records
     }
-    nbm = variant == 2 ? (uint32_t)((scan->n + 4 * kQPW - 1) / (4 * kQPW)) : nb;
+    nbm = nb;
     MH_TRY(ctx->partials.reserve((size_t)kGenN * (nbm > nb ? nbm : nb) * sizeof(double)));
     chunk = p->poll_every ? p->poll_every : 10;
     enqueued = 0;
@@ -1447,14 +1237,20 @@ struct AlignJob {
           hipLaunchKernelGGL(k_match_pl<true>, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, dmk, scan->x, scan->y,
                              scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
         if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n], s));
-        if (variant == 2)
-          hipLaunchKernelGGL(k_matchr<true>, dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x, scan->y,
-                             scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
-        else if (variant == 1)
-          hipLaunchKernelGGL((k_match<true, false>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x,
+        if (variant == 4) {
+          hipLaunchKernelGGL(k_match4, dim3((uint32_t)((4ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
+                             scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>()
+#ifdef MH_DEBUG_WAVETRACE
+                             , g_wtrace
+#endif
+          );
+          hipLaunchKernelGGL(k_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nb);
+        } else if (variant == 1)
+          hipLaunchKernelGGL((k_match<true, 0>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x,
                              scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
         else
-          hipLaunchKernelGGL((k_match<true, true>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x,
+          hipLaunchKernelGGL((k_match<true, 1>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x,
                              scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
         if (prof) {
           MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));
@@ -1664,7 +1460,7 @@ mh_status mh_nn_search(const mh_map* map, const mh_scan* scan, const double T[12
   const double ang = threshold_angular_deg * 3.14159265358979323846 / 180.0;
   mk.ang2 = (float)(ang * ang);
   MH_TRY(upload_params(ctx, mk, sk0));
-  hipLaunchKernelGGL((k_match<false, true>), dim3(nblk(scan->n)), dim3(kBlock), 0, ctx->stream, ctx->d_state, Ta,
+  hipLaunchKernelGGL((k_match<false, 1>), dim3(nblk(scan->n)), dim3(kBlock), 0, ctx->stream, ctx->d_state, Ta,
                        (float)(threshold * threshold), 1u, &ctx->d_params->mk, scan->x, scan->y, scan->z, (uint32_t)scan->n, map->view(),
                        ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (double*)nullptr, 0u);
   MH_HIP(hipGetLastError());
@@ -1693,7 +1489,7 @@ mh_status mh_nn_search_dense(const mh_map* map, const mh_scan* scan, const doubl
   SolveK sk0{};
   hipStream_t s = ctx->stream;
   MH_TRY(upload_params(ctx, mk, sk0));
-  hipLaunchKernelGGL((k_match<false, true>), dim3(nblk(n)), dim3(kBlock), 0, s, ctx->d_state, Ta, 0.f, 0u,
+  hipLaunchKernelGGL((k_match<false, 1>), dim3(nblk(n)), dim3(kBlock), 0, s, ctx->d_state, Ta, 0.f, 0u,
                      &ctx->d_params->mk, scan->x,
                        scan->y, scan->z, (uint32_t)n, map->view(), ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
                        (double*)nullptr, 0u);

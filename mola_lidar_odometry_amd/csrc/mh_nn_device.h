@@ -303,6 +303,207 @@ __device__ __forceinline__ NNResult nn_search_pruned(const MapView& m, float qx,
   return r;
 }
 
+
+// {first, count} of voxel `key` given the slot its hash points at; count 0 when absent or not wanted
+__device__ __forceinline__ void nn_resolve(const MapView& m, const u32x4* __restrict__ slots4, unsigned long long key, u32x4 sl,
+                                           bool want, uint32_t& first, uint32_t& cnt) {
+  first = 0;
+  cnt = 0;
+  if (!want) return;
+  unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
+  if (sk != key && sk != kEmptyKey) {  // rare: linear probing past a collision
+    uint32_t h = hash_key(key) & m.mask;
+    do {
+      h = (h + 1) & m.mask;
+      sl = slots4[h];
+      sk = ((unsigned long long)sl.y << 32) | sl.x;
+    } while (sk != key && sk != kEmptyKey);
+  }
+  if (sk == key) {
+    first = sl.z;
+    cnt = sl.w;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Four lanes per scan point (a DPP quad): the same exact branch-and-bound search, with the point's work spread over
+// its quad.  Lane `sub` of the quad issues the probe of the batch's voxel #sub (one load instead of four) and reads
+// every fourth candidate of the merged record ranges; the quad agrees on the best (d2, record) with two quad_perm
+// steps after every scan, so its four lanes always take the same branches.  Per lane that is a quarter of the load
+// instructions and a quarter of the scan round trips; a quad's loads hit four consecutive 16-byte records, which the
+// vector L1 serves ~3.6x faster than four scattered ones (tools/gather_bench.hip: 888 vs 246 M loads/ms).
+//
+// What the measurements behind this design say (C2, MI355X; per-wave wall_clock64 traces, PMC passes, A/B runs):
+//   * a launch lasts as long as its slowest wave; a wave costs ~7.5 us + ~0.45 us per dependent round trip of its
+//     slowest lane (every round trip of a 64-lane wave contains an L1 miss, so it always pays L2/Infinity-Cache latency);
+//   * with one lane per point (nn_search_pruned) the slowest lanes chain up to ~90 round trips (57 us per launch);
+//     merging the scans of a probe batch and splitting a point over a quad brings that to ~26 (28 us incl. k_accum);
+//   * what did NOT help: 8-wide scans or twice as many loads in flight for crowded batches (registers -> occupancy),
+//     probing all 26 neighbours up front (more loads and VALU than the saved round trips are worth on C2), forcing
+//     the loads of a round to be issued unconditionally, an XCD-contiguous block order, other workgroup sizes.
+// -------------------------------------------------------------------------------------------------
+#ifndef MH_QUAD_W
+#define MH_QUAD_W 5  // candidates per lane and round trip: 4 x 5 = 20 = one full voxel (max_points_per_voxel: 20)
+#endif
+constexpr int kQuadW = MH_QUAD_W;
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int L>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return quad_u32<L * 0x55>(v); }  // quad_perm:[L,L,L,L]
+
+// (d2 bits << 32 | record index): for the non-negative d2 here the unsigned order of this key IS the lexicographic
+// (d2, scan position) order the reference's first-strict-minimum rule induces; one 64-bit compare per candidate.
+typedef unsigned long long nnkey_t;
+constexpr nnkey_t kNNKeyNone = 0x7F800000FFFFFFFFull;  // (+inf, no record)
+__device__ __forceinline__ float nnkey_d2(nnkey_t k) { return __uint_as_float((uint32_t)(k >> 32)); }
+__device__ __forceinline__ uint32_t nnkey_idx(nnkey_t k) { return (uint32_t)k; }
+
+__device__ __forceinline__ nnkey_t quad_min_key(nnkey_t k) {
+#define MH_QUAD_STEP(CTRL)                                                                   \
+  {                                                                                          \
+    const nnkey_t o = ((nnkey_t)quad_u32<CTRL>((uint32_t)(k >> 32)) << 32) | quad_u32<CTRL>((uint32_t)k); \
+    k = o < k ? o : k;                                                                       \
+  }
+  MH_QUAD_STEP(0xB1)  // quad_perm:[1,0,3,2]
+  MH_QUAD_STEP(0x4E)  // quad_perm:[2,3,0,1]
+#undef MH_QUAD_STEP
+  return k;
+}
+
+// One round trip: W records per lane of the merged ranges.
+template <int NV, int W>
+__device__ __forceinline__ nnkey_t nn_scan_round_quad(const f32x4* __restrict__ pts4, const uint32_t (&start)[NV],
+                                                      const uint32_t (&pre)[NV + 1], uint32_t t0, uint32_t sub, float qx,
+                                                      float qy, float qz, nnkey_t best) {
+  const uint32_t total = pre[NV];
+  f32x4 c[W];
+  uint32_t ri[W];
+  bool valid[W];
+#pragma unroll
+  for (int u = 0; u < W; u++) {
+    const uint32_t tu = t0 + 4u * (uint32_t)u + sub;
+    valid[u] = tu < total;
+    const uint32_t t = valid[u] ? tu : total - 1;  // clamped into the ranges: no load sits behind a data-dependent branch in the source
+    uint32_t off = start[0];                        // start[v] = first[v] - pre[v]: record = t + start[voxel of t]
+#pragma unroll
+    for (int v = 1; v < NV; v++) off = t >= pre[v] ? start[v] : off;
+    ri[u] = t + off;
+    c[u] = pts4[ri[u]];
+  }
+#pragma unroll
+  for (int u = 0; u < W; u++) {
+    const float dx = c[u].x - qx, dy = c[u].y - qy, dz = c[u].z - qz;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order (bit-exact with the oracle)
+    // (measured: hipcc turns this select into a branch and sinks the load of a lane past the end under it; forcing
+    // straight-line code with every load issued -- masks, sched_barrier, inline-asm loads -- was 30-40 % SLOWER on C2:
+    // the clamped duplicate loads cost more in the texture-address path than the extra waits do)
+    const nnkey_t k = valid[u] ? (((nnkey_t)__float_as_uint(d2) << 32) | ri[u]) : kNNKeyNone;
+    best = k < best ? k : best;
+  }
+  return best;
+}
+
+template <int NV>
+__device__ __forceinline__ nnkey_t nn_scan_merged_quad(const f32x4* __restrict__ pts4, const uint32_t (&first)[NV],
+                                                       const uint32_t (&cnt)[NV], uint32_t sub, float qx, float qy, float qz,
+                                                       nnkey_t best) {
+  uint32_t pre[NV + 1], start[NV];
+  pre[0] = 0;
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    pre[v + 1] = pre[v] + cnt[v];
+    start[v] = first[v] - pre[v];
+  }
+  const uint32_t total = pre[NV];  // the same in the four lanes
+  for (uint32_t t0 = 0; t0 < total; t0 += 4 * kQuadW) best = nn_scan_round_quad<NV, kQuadW>(pts4, start, pre, t0, sub, qx, qy, qz, best);
+  return quad_min_key(best);
+}
+
+// the neighbour codes lane `sub` of a quad is responsible for when the bound is evaluated: sub, sub+4, ... (< 27, != 13)
+struct QuadBounds {
+  float lb[7];  // conservative lower bounds of codes sub + 4j (inf for code 13 / >= 27)
+};
+__device__ __forceinline__ QuadBounds quad_bounds(const Gaps& gx, const Gaps& gy, const Gaps& gz, uint32_t sub) {
+  QuadBounds q;
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    const int code = (int)sub + 4 * j;
+    q.lb[j] = (code == 13 || code >= 27) ? __builtin_inff() : nn_lower_bound(code, gx, gy, gz) * 0.9999f;
+  }
+  return q;
+}
+// bit `code` set iff the voxel can still hold the winner; each lane tests its 7 codes, the quad ORs them together
+__device__ __forceinline__ uint32_t quad_bound_mask(const QuadBounds& q, uint32_t sub, float best) {
+  uint32_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < 7; j++) mine |= (!(q.lb[j] > best)) ? (1u << (4 * j)) : 0u;
+  mine <<= sub;
+  mine |= quad_u32<0xB1>(mine);
+  mine |= quad_u32<0x4E>(mine);
+  return mine & 0x07FFFFFFu & ~(1u << 13);
+}
+
+// every lane of the quad passes the same q and gets the same result
+__device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t sub, float qx, float qy, float qz) {
+  NNResult r;
+  r.d2 = __builtin_inff();
+  r.found = false;
+  r.pt = (f32x4)(0.f);
+  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return r;
+  const float lim = 1.0e6f;
+  if (!(fabsf(qx * m.inv_vs) < lim && fabsf(qy * m.inv_vs) < lim && fabsf(qz * m.inv_vs) < lim)) return r;
+  const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
+  const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
+  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
+  const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
+  const float vs = 1.0f / m.inv_vs;
+  const Gaps gx = axis_gaps(qx, cx, vs, m.trunc), gy = axis_gaps(qy, cy, vs, m.trunc), gz = axis_gaps(qz, cz, vs, m.trunc);
+  nnkey_t best = kNNKeyNone;
+  {  // the query's own voxel (code 13): the four lanes read the same slot
+    const unsigned long long key = nn_key_of(kbase, 13);
+    uint32_t f1[1], c1[1];
+    nn_resolve(m, slots4, key, slots4[hash_key(key) & m.mask], true, f1[0], c1[0]);
+    best = nn_scan_merged_quad<1>(pts4, f1, c1, sub, qx, qy, qz, best);
+  }
+  const uint32_t kFaces = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 14) | (1u << 16) | (1u << 22);
+  const uint32_t kCorners = (1u << 0) | (1u << 2) | (1u << 6) | (1u << 8) | (1u << 18) | (1u << 20) | (1u << 24) | (1u << 26);
+  const uint32_t kEdges = 0x07FFFFFFu & ~(kFaces | kCorners | (1u << 13));
+  uint32_t todo = 0x07FFFFFFu & ~(1u << 13);
+  const QuadBounds qb = quad_bounds(gx, gy, gz, sub);
+#pragma unroll 1
+  for (int cls = 0; cls < 3; cls++) {
+    const uint32_t cbits = cls == 0 ? kFaces : (cls == 1 ? kEdges : kCorners);
+    for (;;) {
+      uint32_t mm = todo & cbits & quad_bound_mask(qb, sub, nnkey_d2(best));
+      if (!mm) break;
+      int c_mine = -1;
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int cv = mm ? __builtin_ctz(mm) : -1;
+        mm &= mm - 1;
+        if (cv >= 0) todo &= ~(1u << cv);
+        c_mine = (uint32_t)v == sub ? cv : c_mine;
+      }
+      const unsigned long long key = nn_key_of(kbase, c_mine < 0 ? 0 : c_mine);
+      const u32x4 sl = slots4[hash_key(key) & m.mask];  // one probe per lane, four per point in flight
+      uint32_t f_mine, n_mine;
+      nn_resolve(m, slots4, key, sl, c_mine >= 0, f_mine, n_mine);
+      const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
+      const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
+      best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best);
+    }
+  }
+  if (nnkey_idx(best) != 0xFFFFFFFFu) {
+    r.pt = pts4[nnkey_idx(best)];
+    r.d2 = nnkey_d2(best);
+    r.found = true;
+  }
+  return r;
+}
+
 // ---- robust kernels (mp2p_icp::create_robust_kernel [U], lidar3d-default.yaml:188-190) ---------
 __device__ __forceinline__ double robust_weight(uint32_t kernel, double c, double e2) {
   switch (kernel) {

@@ -1,0 +1,154 @@
+"""Run the stand-alone odometry driver over sequences and time it (BASELINE.json configs[2]/[3]).
+
+    python -m mola_lidar_odometry_amd.run_odometry --synthetic 200                       # synthetic drive, 200 scans
+    python -m mola_lidar_odometry_amd.run_odometry --kitti-root /data/kitti --seqs 00 04  # KITTI velodyne folders
+    python -m torch.distributed.run --nproc-per-node 8 ... run_odometry.py --kitti-root ... --seqs 00 ... 10
+
+What eval/cli_kitti.sh:23-50 (relative to /root/reference) does with mola-lidar-odometry-cli + GNU parallel: one whole
+sequence per worker (here one process per GPU, sequences assigned longest-first), a TUM trajectory per sequence,
+then the KITTI / ATE metrics when ground truth (poses/XX.txt) is present.  Prints one JSON line per sequence and a
+summary line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import time
+
+import numpy as np
+
+from . import dist as mdist
+from . import synth, trajectory
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _kitti_scans(seq_dir):
+    files = sorted(glob.glob(os.path.join(seq_dir, "velodyne", "*.bin")))
+    times = os.path.join(seq_dir, "times.txt")
+    stamps = np.loadtxt(times) if os.path.exists(times) else 0.1 * np.arange(len(files))
+    for f, st in zip(files, stamps):
+        xyz, _ = trajectory.read_kitti_bin(f)
+        yield float(st), xyz, None  # KITTI odometry scans are motion compensated and carry no time stamps
+
+
+def _kitti_gt(root, seq, Tr=None):
+    f = os.path.join(root, "poses", seq + ".txt")
+    if not os.path.exists(f):
+        return None
+    a = np.loadtxt(f).reshape(-1, 3, 4)
+    T = np.tile(np.eye(4), (len(a), 1, 1))
+    T[:, :3] = a
+    if Tr is not None:  # camera-frame ground truth -> velodyne frame
+        T = np.linalg.inv(Tr)[None] @ T @ Tr[None]
+    return T
+
+
+def _kitti_calib_Tr(seq_dir):
+    f = os.path.join(seq_dir, "calib.txt")
+    if not os.path.exists(f):
+        return None
+    for line in open(f):
+        if line.startswith("Tr:"):
+            return np.vstack([np.asarray(line.split()[1:], np.float64).reshape(3, 4), [0, 0, 0, 1]])
+    return None
+
+
+def run_sequence(pipeline, scans, out_tum=None, device=None):
+    """scans: iterable of (stamp, xyz[N,3] fp32, t[N] fp32 | None).  Returns (records, trajectory, seconds)."""
+    from . import _mp2p_icp_hip as H
+    from . import capi
+    capi.lib()  # torch's HIP runtime first (one runtime per process), then libmolahip
+    lo = H.LidarOdometry()
+    lo.initialize(H.Config.FromYamlFile(pipeline))
+    t0 = time.perf_counter()
+    n = 0
+    for st, xyz, t in scans:
+        lo.onLidar(st, xyz, t)
+        n += 1
+    dt = time.perf_counter() - t0
+    if out_tum:
+        lo.saveTrajectoryTUM(out_tum)
+    return lo.records(), lo.trajectory(), dt
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--pipeline", default=os.path.join(ROOT, "pipelines", "lidar3d-default-hip.yaml"))
+    ap.add_argument("--synthetic", type=int, default=0, help="number of scans of the synthetic drive")
+    ap.add_argument("--rings", type=int, default=64)
+    ap.add_argument("--azimuths", type=int, default=1875, help="64 x 1875 = the 120k-point sweep of BASELINE.json C2")
+    ap.add_argument("--kitti-root", default=None, help="KITTI odometry root (sequences/XX/velodyne, poses/XX.txt)")
+    ap.add_argument("--seqs", nargs="*", default=[])
+    ap.add_argument("--out-dir", default="gpurun_out/odometry")
+    a = ap.parse_args(argv)
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        import torch
+        import torch.distributed as td
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        td.init_process_group("nccl")
+    os.makedirs(a.out_dir, exist_ok=True)
+
+    jobs = []  # (name, length, factory)
+    if a.synthetic:
+        jobs.append(("synthetic", a.synthetic, None))
+    for s in a.seqs:
+        d = os.path.join(a.kitti_root, "sequences", s)
+        jobs.append((s, len(glob.glob(os.path.join(d, "velodyne", "*.bin"))), d))
+    mine = mdist.lpt_assign([j[1] for j in jobs], world)[rank]
+
+    total_scans, total_time = 0, 0.0
+    for j in mine:
+        name, length, src = jobs[j]
+        if src is None:
+            drive = synth.make_drive(length, rings=a.rings, azimuths=a.azimuths)
+            scans = [(st, xyz, t) for (xyz, t), st in zip(drive["scans"], drive["stamps"])]
+            G = np.stack([trajectory.to44(p) for p in drive["poses"]])
+            gt = np.linalg.inv(G[0])[None] @ G
+            gt_stamps = drive["stamps"]
+        else:
+            scans = _kitti_scans(src)
+            gt = _kitti_gt(a.kitti_root, name, _kitti_calib_Tr(src))
+            gt_stamps = None
+        out = os.path.join(a.out_dir, "%s.tum" % name)
+        recs, traj, secs = run_sequence(a.pipeline, scans, out)
+        line = dict(sequence=name, scans=len(recs), seconds=secs, scans_per_s=len(recs) / secs if secs else 0.0,
+                    good=int(sum(r["icp_good"] for r in recs)), keyframes=int(sum(r["map_updated"] for r in recs)),
+                    icp_iterations=int(sum(r["icp_iterations"] for r in recs)),
+                    mean_points_for_icp=float(np.mean([r["n_for_icp"] for r in recs])) if recs else 0.0,
+                    map_points=int(recs[-1]["n_map_points"]) if recs else 0, tum=out, rank=rank)
+        if gt is not None and len(traj):
+            est_stamps = np.array([t for t, _ in traj])
+            est = np.stack([trajectory.to44(p) for _, p in traj])
+            if gt_stamps is None:
+                gt_stamps = np.array([r["timestamp"] for r in recs])[: len(gt)]
+            ia, ib = trajectory.associate(est_stamps, np.asarray(gt_stamps))
+            if len(ia) > 1:
+                g = np.linalg.inv(gt[ib[0]])[None] @ gt[ib]
+                e = np.linalg.inv(est[ia[0]])[None] @ est[ia]
+                line["ate_rmse_m"] = trajectory.ate_rmse(e, g, "none")
+                te, re, k = trajectory.kitti_relative_errors(e, g)
+                if k:
+                    line["kitti_t_err_percent"], line["kitti_r_err_deg_per_m"] = te, re
+        print(json.dumps(line), flush=True)
+        total_scans += len(recs)
+        total_time += secs
+    wall = mdist.max_over_ranks(total_time, device="cuda" if world > 1 else None)
+    if world > 1:
+        import torch
+        import torch.distributed as td
+        tot = torch.tensor([total_scans], dtype=torch.int64, device="cuda")
+        td.all_reduce(tot)
+        total_scans = int(tot.item())
+        td.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(dict(summary=True, n_gpus=world, scans=total_scans, seconds=wall,
+                              scans_per_s=total_scans / wall if wall else 0.0)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,8 @@ OUT=/root/repo/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o ${TAG}_bench -- python /root/repo/bench.py > $OUT/${TAG}_bench_stdout.log 2>&1
+# 3. the whole per-scan path (device filters, ICP, key-frame map updates) of the stand-alone driver on a synthetic drive
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/odom -o ${TAG}_odom -- env PYTHONPATH=/root/repo python -m mola_lidar_odometry_amd.run_odometry --synthetic 40 --out-dir /root/repo/gpurun_out/odometry > $OUT/${TAG}_odom_stdout.log 2>&1
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVES" \
@@ -42,4 +44,8 @@ rows=list(csv.DictReader(open(glob.glob(out+'/bench/*kernel_stats.csv')[0])))
 for r in rows[:8]:
     print(r['Name'][:70].ljust(70), r['Calls'].rjust(6), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(9),'us', r['Percentage'])
 print(open(out+'/'+tag+'_bench_stdout.log').read().strip().splitlines()[-1][:1500])
+print('--- odometry driver, 40 synthetic scans of 120k points')
+for r in list(csv.DictReader(open(glob.glob(out+'/odom/*kernel_stats.csv')[0])))[:14]:
+    print(r['Name'][:70].ljust(70), r['Calls'].rjust(6), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(9),'us', r['Percentage'])
+print(open(out+'/'+tag+'_odom_stdout.log').read().strip()[-1200:])
 PY

@@ -189,3 +189,14 @@ def test_hip_driver_ndt_pipeline_and_restart(host, drive):
     assert r["icp_run"] and not r["icp_good"] and r["restarted"] and len(lo2.trajectory()) == 0
     r = lo2.onLidar(1.2, *drive["scans"][1])
     assert r["first_scan"] and r["map_updated"]
+
+
+@pytest.mark.gpu
+def test_sequence_runner_reports_metrics(tmp_path, capsys):
+    import json
+    from mola_lidar_odometry_amd import run_odometry
+    run_odometry.main(["--synthetic", "8", "--rings", "32", "--azimuths", "600", "--out-dir", str(tmp_path)])
+    lines = [json.loads(l) for l in capsys.readouterr().out.strip().splitlines()]
+    seq, summary = lines[0], lines[-1]
+    assert seq["scans"] == 8 and seq["good"] == 7 and seq["ate_rmse_m"] < 0.2 and os.path.exists(seq["tum"])
+    assert summary["summary"] and summary["scans"] == 8 and summary["scans_per_s"] > 1.0

@@ -27,7 +27,11 @@ __global__ void gather(const u32x4* __restrict__ tab, unsigned mask, unsigned n,
       unsigned idx;
       if (MODE==0) idx = hash32(i*K+k)&mask;
       else if (MODE==2) idx = (hash32((i>>6)*K+k)&mask&~63u) + (i&7)*8 + ((i>>3)&7);
-      else idx = ((hash32((i>>3)*K+k)&mask)&~7u) + (i&7);
+      else if (MODE==3) idx = ((hash32((i>>3)*K+k)&mask)&~7u) + (i&7);
+      else if (MODE==4) idx = ((hash32((i>>2)*K+k)&mask)&~3u) + (i&3);      // quads read 4 consecutive records (64 B)
+      else if (MODE==5) idx = ((hash32((i>>4)*K+k)&mask)&~15u) + (i&15);    // 16 lanes read 16 consecutive records (256 B)
+      else if (MODE==6) idx = ((hash32((i>>6)*K+k)&mask)&~63u) + (i&63);    // the wave reads 64 consecutive records (1 KiB)
+      else idx = hash32((i>>6)*K+k)&mask;                                   // the whole wave reads ONE record (broadcast)
       v[k]=tab[idx];
     }
     #pragma unroll
@@ -70,5 +74,13 @@ int main(){
   run<0,27>(tab,TAB-1,n*8,out,"27 indep random, 4MiB, 8x lanes");
   run<1,27>(tab,TAB-1,n*8,out,"27 dependent, 4MiB, 8x lanes");
   run<3,27>(tab,TAB-1,n*8,out,"27 indep 8-lane contig, 8x lanes");
+  run<4,27>(tab,TAB-1,n*8,out,"27 indep quad contig, 8x lanes");
+  run<5,27>(tab,TAB-1,n*8,out,"27 indep 16-lane contig, 8x lanes");
+  run<6,27>(tab,TAB-1,n*8,out,"27 indep wave contig, 8x lanes");
+  run<7,27>(tab,TAB-1,n*8,out,"27 indep wave broadcast, 8x lanes");
+  run<2,27>(tab,TAB-1,n*8,out,"27 indep wave-coherent, 8x lanes");
+  run<0,27>(tab2,TAB2-1,n*8,out,"27 indep random 16MiB, 8x lanes");
+  run<4,27>(tab2,TAB2-1,n*8,out,"27 quad contig 16MiB, 8x lanes");
+  run<5,27>(tab2,TAB2-1,n*8,out,"27 16-lane contig 16MiB, 8x");
   return 0;
 }
