@@ -1244,6 +1244,7 @@ struct AlignJob {
                              , g_wtrace
 #endif
           );
+          if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
           hipLaunchKernelGGL(k_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nb);
         } else if (variant == 1)
@@ -1253,7 +1254,7 @@ struct AlignJob {
           hipLaunchKernelGGL((k_match<true, 1>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x,
                              scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
         if (prof) {
-          MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));
+          if (variant != 4) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));
           prof_n++;
         }
         hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nbm, nbm,

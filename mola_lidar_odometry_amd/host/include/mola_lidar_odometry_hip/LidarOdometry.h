@@ -138,6 +138,8 @@ class LidarOdometry {
   std::map<std::string, double> dynamicVariables() const { return source_.getVariableValues(); }
   // what initialize() recognised in the pipeline file (for tests / logs)
   std::map<std::string, std::string> describePipeline() const;
+  // accumulated host wall time [s] per stage of onLidar (the role of the reference's profiler_ sections "onLidar.*")
+  const std::map<std::string, double>& profile() const { return profile_; }
 
  private:
   struct FilterPlan;  // the recognised observation filter chain, as data for mh_scan_preprocess / mh_scan_deskew
@@ -176,6 +178,7 @@ class LidarOdometry {
   uint32_t localmap_check_removal_counter_ = 0;
   std::vector<std::pair<double, CPose3D>> trajectory_;
   std::vector<ScanRecord> records_;
+  std::map<std::string, double> profile_;
 };
 
 }  // namespace mola_hip

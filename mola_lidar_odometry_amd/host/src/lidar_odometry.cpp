@@ -2,6 +2,7 @@
 // is behind include/molahip.h.  Citations are module/src/LidarOdometry.cpp unless another file is named.
 #include "mola_lidar_odometry_hip/LidarOdometry.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -22,6 +23,14 @@ double eval_now(std::string s, const std::map<std::string, double>& vars) {
   if (s.size() > 4 && s.compare(0, 3, "$f{") == 0 && s.back() == '}') s = s.substr(3, s.size() - 4);
   return evaluate_expression(s, vars);
 }
+
+struct StageTimer {  // adds the wall time of its scope to a profile entry
+  std::map<std::string, double>& prof;
+  const char* name;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  StageTimer(std::map<std::string, double>& p, const char* n) : prof(p), name(n) {}
+  ~StageTimer() { prof[name] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 std::string class_of(const Config& entry) { return entry["class_name"].asString(); }
 bool ends_with(const std::string& s, const std::string& suffix) {
@@ -408,9 +417,13 @@ const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, con
     rec.dropped = true;
     return rec;
   }
+  StageTimer t_all(profile_, "onLidar");
   ensure_device();
-  raw_->setPoints(x, y, z, n);
-  if (t) raw_->setTimestamps(t, n);
+  {
+    StageTimer tt(profile_, "onLidar.0.upload_raw");
+    raw_->setPoints(x, y, z, n);
+    if (t) raw_->setTimestamps(t, n);
+  }
 
   // first call: sensor range from the raw cloud (:660, 1487-1513)
   if (!estimated_sensor_max_range_ && n) {
@@ -421,8 +434,14 @@ const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, con
   updatePipelineDynamicVariables();  // :692
   rec.twist = last_motion_model_output_ ? last_motion_model_output_->twist : Twist();
 
-  run_first_pass();   // :734
-  run_second_pass();  // :739
+  {
+    StageTimer tt(profile_, "onLidar.1.filter_1st");
+    run_first_pass();  // :734
+  }
+  {
+    StageTimer tt(profile_, "onLidar.1.filter_2nd");
+    run_second_pass();  // :739
+  }
   rec.decim_map_resolution = plan_->decim_map_res;
   rec.decim_icp_resolution = plan_->decim_icp_res;
   rec.n_for_map = for_map_->size();
@@ -430,6 +449,7 @@ const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, con
 
   // sensor range low-pass from the first point layer of the observation, 'decimated_for_icp' (:744, 1515-1545)
   if (estimated_sensor_max_range_) {
+    StageTimer tt(profile_, "onLidar.2.sensor_range");
     float mn[3], mx[3];
     for_icp_->boundingBox(mn, mx);
     const double radius = std::max(bbox_radius(mn, mx), params_.absolute_minimum_sensor_range);
@@ -489,6 +509,7 @@ const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, con
     obs.layers[plan_->layer_for_icp] = for_icp_;
     obs.layers[plan_->layer_for_map] = for_map_;
     glob.layers[plan_->map_layer] = local_map_;
+    StageTimer t_icp(profile_, "onLidar.3.run_icp");
     do {
       icp_params.maxIterations = (uint32_t)remaining;
       // the in-tree hook (:919-952) only compares the running solution with its check point: evaluated on the device.
@@ -573,6 +594,7 @@ const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, con
 
   // ---- local map update (:1158-1206): FilterMerge of the de-skewed map layer at the current pose, on the device
   if (updateLocalMap) {
+    StageTimer tt(profile_, "onLidar.4.update_local_map");
     if (!local_map_) create_local_map();
     updatePipelineDynamicVariables();  // robot_x..robot_roll (:1194)
     local_map_->insertPointCloud(*for_map_, last_lidar_pose_, remove_voxels_farther_than_);

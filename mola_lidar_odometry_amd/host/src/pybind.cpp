@@ -148,6 +148,7 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
       .def("saveTrajectoryTUM", &LidarOdometry::saveTrajectoryTUM)
       .def("dynamicVariables", &LidarOdometry::dynamicVariables)
       .def("describePipeline", &LidarOdometry::describePipeline)
+      .def("profile", [](const LidarOdometry& lo) { return lo.profile(); })
       .def("localMapSize", [](const LidarOdometry& lo) { return lo.localMap() ? lo.localMap()->size() : 0; });
   m.def("icp_pipeline_from_yaml", [](const Config& c) { auto t = icp_pipeline_from_yaml(c); return py::make_tuple(std::get<0>(t), std::get<1>(t)); });
 }

@@ -71,6 +71,7 @@ def run_sequence(pipeline, scans, out_tum=None, device=None):
     dt = time.perf_counter() - t0
     if out_tum:
         lo.saveTrajectoryTUM(out_tum)
+    run_sequence.last_profile = {k: round(1e3 * v / max(n, 1), 4) for k, v in lo.profile().items()}  # ms per scan
     return lo.records(), lo.trajectory(), dt
 
 
@@ -120,7 +121,8 @@ def main(argv=None):
                     good=int(sum(r["icp_good"] for r in recs)), keyframes=int(sum(r["map_updated"] for r in recs)),
                     icp_iterations=int(sum(r["icp_iterations"] for r in recs)),
                     mean_points_for_icp=float(np.mean([r["n_for_icp"] for r in recs])) if recs else 0.0,
-                    map_points=int(recs[-1]["n_map_points"]) if recs else 0, tum=out, rank=rank)
+                    map_points=int(recs[-1]["n_map_points"]) if recs else 0, tum=out, rank=rank,
+                    host_ms_per_scan=getattr(run_sequence, "last_profile", {}))
         if gt is not None and len(traj):
             est_stamps = np.array([t for t, _ in traj])
             est = np.stack([trajectory.to44(p) for _, p in traj])
