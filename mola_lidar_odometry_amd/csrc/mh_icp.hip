@@ -505,14 +505,25 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ part, uin
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
-                                                         const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
-                                                         const double* __restrict__ partB, uint32_t nB,
-                                                         uint32_t strideB) {
-  __shared__ double red[kGenN][64];
-  __shared__ double totA[kAccN], totB[kGenN];
-  __shared__ double sh_log[13][6];
-  if (st->done) return;
+struct SolveShared {
+  double red[kGenN][64];
+  double totA[kAccN], totB[kGenN];
+  double sh_log[13][6];
+};
+
+// One Gauss-Newton step + the tail of the ICP iteration, executed by ONE workgroup of kSolveThreads lanes.  Every lane
+// must call it; only lane 0 runs the serial part.  (A cooperative single-launch version of the whole loop for the
+// 1-8 k-point layers of the real pipeline -- match | grid barrier | solve | grid barrier | accumulate ... -- was
+// built on top of this and measured: 1.91 vs 1.98 ms of ICP per scan, i.e. the launch boundaries are not what a
+// small alignment waits for; it was removed again.)
+__device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
+                                           const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
+                                           const double* __restrict__ partB, uint32_t nB, uint32_t strideB,
+                                           SolveShared& sh) {
+  double (*red)[64] = sh.red;
+  double* totA = sh.totA;
+  double* totB = sh.totB;
+  double (*sh_log)[6] = sh.sh_log;
   const SolveK& k = *kp;  // read field by field (uniform loads); the 36-double prior is only touched when present
   const int lane = threadIdx.x;
   if (nA)
@@ -687,6 +698,15 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restr
     st->n_iterations = it + 1;
     st->done = 1;
   }
+}
+
+__global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
+                                                         const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
+                                                         const double* __restrict__ partB, uint32_t nB,
+                                                         uint32_t strideB) {
+  __shared__ SolveShared sh;
+  if (st->done) return;
+  solve_body(st, kp, partA, nA, strideA, partB, nB, strideB, sh);
 }
 
 // ================================================================================================

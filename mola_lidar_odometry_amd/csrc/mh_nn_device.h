@@ -473,28 +473,27 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
   const uint32_t kEdges = 0x07FFFFFFu & ~(kFaces | kCorners | (1u << 13));
   uint32_t todo = 0x07FFFFFFu & ~(1u << 13);
   const QuadBounds qb = quad_bounds(gx, gy, gz, sub);
-#pragma unroll 1
-  for (int cls = 0; cls < 3; cls++) {
-    const uint32_t cbits = cls == 0 ? kFaces : (cls == 1 ? kEdges : kCorners);
-    for (;;) {
-      uint32_t mm = todo & cbits & quad_bound_mask(qb, sub, nnkey_d2(best));
-      if (!mm) break;
-      int c_mine = -1;
+  for (;;) {
+    // voxels that can still hold the winner (one evaluation per batch); nearest class first: faces, edges, corners
+    const uint32_t live = todo & quad_bound_mask(qb, sub, nnkey_d2(best));
+    if (!live) break;
+    const uint32_t lf = live & kFaces, le = live & kEdges;
+    uint32_t mm = lf ? lf : (le ? le : live);
+    int c_mine = -1;
 #pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const int cv = mm ? __builtin_ctz(mm) : -1;
-        mm &= mm - 1;
-        if (cv >= 0) todo &= ~(1u << cv);
-        c_mine = (uint32_t)v == sub ? cv : c_mine;
-      }
-      const unsigned long long key = nn_key_of(kbase, c_mine < 0 ? 0 : c_mine);
-      const u32x4 sl = slots4[hash_key(key) & m.mask];  // one probe per lane, four per point in flight
-      uint32_t f_mine, n_mine;
-      nn_resolve(m, slots4, key, sl, c_mine >= 0, f_mine, n_mine);
-      const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
-      const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
-      best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best);
+    for (int v = 0; v < 4; v++) {
+      const int cv = mm ? __builtin_ctz(mm) : -1;
+      mm &= mm - 1;
+      if (cv >= 0) todo &= ~(1u << cv);
+      c_mine = (uint32_t)v == sub ? cv : c_mine;
     }
+    const unsigned long long key = nn_key_of(kbase, c_mine < 0 ? 0 : c_mine);
+    const u32x4 sl = slots4[hash_key(key) & m.mask];  // one probe per lane, four per point in flight
+    uint32_t f_mine, n_mine;
+    nn_resolve(m, slots4, key, sl, c_mine >= 0, f_mine, n_mine);
+    const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
+    const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
+    best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best);
   }
   if (nnkey_idx(best) != 0xFFFFFFFFu) {
     r.pt = pts4[nnkey_idx(best)];

@@ -11,6 +11,7 @@
 namespace mp2p_icp_hip {
 
 // ================================================================== expressions
+struct ExprCompiler;
 namespace {
 struct ExprParser {
   const std::string& s;
@@ -143,12 +144,210 @@ double evaluate_expression(const std::string& expr, const std::map<std::string, 
   return p.parse();
 }
 
+// ---- the same grammar, emitting a stack program instead of a value
+struct ExprCompiler {
+  const std::string& s;
+  CompiledExpression& out;
+  size_t i = 0;
+  enum { CONST = 0, VAR, ADD, SUB, MUL, DIV, NEG, POW, CALL };
+  enum Fn { F_MAX = 0, F_MIN, F_ABS, F_SQRT, F_EXP, F_LOG, F_SIN, F_COS, F_TAN, F_POW, F_CLAMP };
+  void ws() { while (i < s.size() && isspace((unsigned char)s[i])) i++; }
+  [[noreturn]] void fail(const std::string& what) const {
+    throw std::runtime_error("expression '" + s + "': " + what + " at position " + std::to_string(i));
+  }
+  void emit(int code, int arg = 0, int nargs = 0, double v = 0) { out.prog_.push_back({code, arg, nargs, v}); }
+  void compile() {
+    expr();
+    ws();
+    if (i != s.size()) fail("unexpected trailing characters");
+  }
+  void expr() {
+    term();
+    for (;;) {
+      ws();
+      if (i < s.size() && (s[i] == '+' || s[i] == '-')) {
+        const char op = s[i++];
+        term();
+        emit(op == '+' ? ADD : SUB);
+      } else
+        return;
+    }
+  }
+  void term() {
+    unary();
+    for (;;) {
+      ws();
+      if (i < s.size() && (s[i] == '*' || s[i] == '/')) {
+        const char op = s[i++];
+        unary();
+        emit(op == '*' ? MUL : DIV);
+      } else
+        return;
+    }
+  }
+  void unary() {
+    ws();
+    if (i < s.size() && (s[i] == '-' || s[i] == '+')) {
+      const char op = s[i++];
+      unary();
+      if (op == '-') emit(NEG);
+      return;
+    }
+    power();
+  }
+  void power() {
+    primary();
+    ws();
+    if (i < s.size() && s[i] == '^') {
+      i++;
+      unary();
+      emit(POW);
+    }
+  }
+  void primary() {
+    ws();
+    if (i >= s.size()) fail("unexpected end");
+    if (s[i] == '(') {
+      i++;
+      expr();
+      ws();
+      if (i >= s.size() || s[i] != ')') fail("missing ')'");
+      i++;
+      return;
+    }
+    if (isdigit((unsigned char)s[i]) || s[i] == '.') {
+      char* end = nullptr;
+      const double v = strtod(s.c_str() + i, &end);
+      i = end - s.c_str();
+      emit(CONST, 0, 0, v);
+      return;
+    }
+    if (isalpha((unsigned char)s[i]) || s[i] == '_') {
+      size_t j = i;
+      while (j < s.size() && (isalnum((unsigned char)s[j]) || s[j] == '_')) j++;
+      const std::string id = s.substr(i, j - i);
+      i = j;
+      ws();
+      if (i < s.size() && s[i] == '(') {
+        i++;
+        int n = 0;
+        ws();
+        if (i < s.size() && s[i] == ')')
+          i++;
+        else
+          for (;;) {
+            expr();
+            n++;
+            ws();
+            if (i < s.size() && s[i] == ',') { i++; continue; }
+            if (i < s.size() && s[i] == ')') { i++; break; }
+            fail("missing ')' in call to " + id);
+          }
+        static const char* names[] = {"max", "min", "abs", "sqrt", "exp", "log", "sin", "cos", "tan", "pow", "clamp"};
+        static const int arity[] = {-1, -1, 1, 1, 1, 1, 1, 1, 1, 2, 3};
+        for (int f = 0; f < 11; f++)
+          if (id == names[f]) {
+            if ((arity[f] >= 0 && n != arity[f]) || (arity[f] < 0 && n < 1))
+              throw std::runtime_error("expression '" + s + "': " + id + "() called with " + std::to_string(n) + " argument(s)");
+            emit(CALL, f, n);
+            return;
+          }
+        throw std::runtime_error("expression '" + s + "': unknown function '" + id + "'");
+      }
+      if (id == "pi" || id == "M_PI") { emit(CONST, 0, 0, 3.14159265358979323846); return; }
+      if (id == "true") { emit(CONST, 0, 0, 1.0); return; }
+      if (id == "false") { emit(CONST, 0, 0, 0.0); return; }
+      int idx = -1;
+      for (size_t k = 0; k < out.vars_.size(); k++)
+        if (out.vars_[k] == id) idx = (int)k;
+      if (idx < 0) {
+        idx = (int)out.vars_.size();
+        out.vars_.push_back(id);
+      }
+      emit(VAR, idx);
+      return;
+    }
+    fail("unexpected character");
+  }
+};
+
+CompiledExpression::CompiledExpression(const std::string& text) : text_(text) {
+  ExprCompiler c{text_, *this};
+  c.compile();
+}
+
+double CompiledExpression::evaluate(const std::vector<const double*>& values) const {
+  double st[32];
+  int sp = 0;
+  for (const Op& o : prog_) {
+    switch (o.code) {
+      case ExprCompiler::CONST: st[sp++] = o.value; break;
+      case ExprCompiler::VAR: st[sp++] = *values[o.arg]; break;
+      case ExprCompiler::ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
+      case ExprCompiler::SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
+      case ExprCompiler::MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
+      case ExprCompiler::DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
+      case ExprCompiler::NEG: st[sp - 1] = -st[sp - 1]; break;
+      case ExprCompiler::POW: sp--; st[sp - 1] = std::pow(st[sp - 1], st[sp]); break;
+      default: {
+        double* a = &st[sp - o.nargs];
+        double v = a[0];
+        switch (o.arg) {
+          case ExprCompiler::F_MAX: for (int k = 1; k < o.nargs; k++) v = std::max(v, a[k]); break;
+          case ExprCompiler::F_MIN: for (int k = 1; k < o.nargs; k++) v = std::min(v, a[k]); break;
+          case ExprCompiler::F_ABS: v = std::fabs(a[0]); break;
+          case ExprCompiler::F_SQRT: v = std::sqrt(a[0]); break;
+          case ExprCompiler::F_EXP: v = std::exp(a[0]); break;
+          case ExprCompiler::F_LOG: v = std::log(a[0]); break;
+          case ExprCompiler::F_SIN: v = std::sin(a[0]); break;
+          case ExprCompiler::F_COS: v = std::cos(a[0]); break;
+          case ExprCompiler::F_TAN: v = std::tan(a[0]); break;
+          case ExprCompiler::F_POW: v = std::pow(a[0], a[1]); break;
+          case ExprCompiler::F_CLAMP: v = std::min(std::max(a[0], a[1]), a[2]); break;
+        }
+        sp -= o.nargs;
+        st[sp++] = v;
+      }
+    }
+    if (sp >= 31) throw std::runtime_error("expression '" + text_ + "': too deeply nested");
+  }
+  return st[0];
+}
+
+double CompiledExpression::evaluate(const std::map<std::string, double>& vars) const {
+  std::vector<const double*> vals(vars_.size());
+  for (size_t k = 0; k < vars_.size(); k++) {
+    auto it = vars.find(vars_[k]);
+    if (it == vars.end()) throw std::runtime_error("expression '" + text_ + "': unknown variable '" + vars_[k] + "'");
+    vals[k] = &it->second;
+  }
+  return evaluate(vals);
+}
+
 void ParameterSource::realize() {
   for (auto* p : attached_) p->realizeWith(vars_);
 }
 
 void Parameterizable::realizeWith(const std::map<std::string, double>& vars) {
-  for (auto& d : declared_) *d.target = evaluate_expression(d.expr, vars);
+  for (auto& d : declared_) *d.target = d.compiled->evaluate(vars);
+}
+
+Parameterizable::Binding Parameterizable::bind(const std::map<std::string, double>& vars) const {
+  Binding b;
+  for (const auto& d : declared_) {
+    std::vector<const double*> vals;
+    for (const auto& name : d.compiled->variables()) {
+      auto it = vars.find(name);
+      if (it == vars.end()) throw std::runtime_error("expression '" + d.expr + "': unknown variable '" + name + "'");
+      vals.push_back(&it->second);
+    }
+    b.items.emplace_back(&d, std::move(vals));
+  }
+  return b;
+}
+
+void Parameterizable::Binding::realize() const {
+  for (const auto& it : items) *it.first->target = it.first->compiled->evaluate(it.second);
 }
 
 static bool looks_numeric(const std::string& s) {

@@ -556,11 +556,23 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
   // the thresholds are functions of ICP_ITERATION only once the caller's variables are fixed for this call
   // (LidarOdometry.cpp:1571-1635 publishes them before align): evaluate them for every iteration up front
   std::vector<double> thr(p.maxIterations), kp(p.maxIterations), plthr(p.maxIterations);
-  for (uint32_t k = 0; k < p.maxIterations; k++) {
-    realize_iteration(k);
-    thr[k] = m->threshold;
-    kp[k] = s->robustKernelParam;
-    if (mpl) plthr[k] = mpl->distanceThreshold;
+  {
+    // formulas compiled once and bound to one copy of the variables; only ICP_ITERATION is swept (in place)
+    std::map<std::string, double> vars = source_ ? source_->getVariableValues() : own_source_.getVariableValues();
+    double& it_var = vars["ICP_ITERATION"];
+    const auto bm = m->bind(vars);
+    const auto bs = s->bind(vars);
+    Parameterizable::Binding bp;
+    if (mpl) bp = mpl->bind(vars);
+    for (uint32_t k = 0; k < p.maxIterations; k++) {
+      it_var = (double)k;
+      bm.realize();
+      bs.realize();
+      bp.realize();
+      thr[k] = m->threshold;
+      kp[k] = s->robustKernelParam;
+      if (mpl) plthr[k] = mpl->distanceThreshold;
+    }
   }
   if (p.maxIterations) realize_iteration(0);
   mh_icp_params ip{};

@@ -46,6 +46,7 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
       .def("size", &Config::size)
       .def("asString", &Config::asString);
   m.def("evaluate_expression", &evaluate_expression);
+  m.def("evaluate_compiled", [](const std::string& e, const std::map<std::string, double>& v) { return CompiledExpression(e).evaluate(v); });
   py::class_<ParameterSource>(m, "ParameterSource")
       .def(py::init<>())
       .def("updateVariable", &ParameterSource::updateVariable)

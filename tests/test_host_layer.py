@@ -241,3 +241,19 @@ def test_ndt_pipeline_align_matches_oracle(hl, oracle, generic):
     np.testing.assert_allclose(res.pose(), o["T"], atol=1e-7)
     assert res.n_pairs() == o["n_final_pairs"] and res.n_pairs_pt2pl() == o["n_final_pairs_pt2pl"] > 500
     assert res.quality == o["quality"]
+
+
+def test_compiled_formulas_equal_the_interpreter():
+    """ICP::align sweeps ICP_ITERATION over compiled formulas; they must give what the text interpreter gives."""
+    from mola_lidar_odometry_amd import _mp2p_icp_hip as H
+    v = {"ADAPTIVE_THRESHOLD_SIGMA": 1.37, "ICP_ITERATION": 7.0, "ESTIMATED_SENSOR_MAX_RANGE": 83.2, "wx": 0.01, "wy": -0.2,
+         "wz": 0.4, "INSTANTANEOUS_SENSOR_MAX_RANGE": 71.0}
+    exprs = ["2.0*max(ADAPTIVE_THRESHOLD_SIGMA, 2.0*ADAPTIVE_THRESHOLD_SIGMA-(2.0*ADAPTIVE_THRESHOLD_SIGMA-0.5*ADAPTIVE_THRESHOLD_SIGMA)*ICP_ITERATION/30)",
+             "(0.1e-2 + sqrt(wx^2+wy^2+wz^2)*0.1)*ESTIMATED_SENSOR_MAX_RANGE", "(15 + sqrt(wx^2+wy^2+wz^2)*500 )",
+             "max(0.20, 0.55*1e-2*ESTIMATED_SENSOR_MAX_RANGE)", "-0.20*INSTANTANEOUS_SENSOR_MAX_RANGE", "-(1+2)*-3^2",
+             "clamp(ICP_ITERATION/2, 1, 3) + min(4, 5, wx) - abs(wy) + pow(2, 3) + pi", "1.0*ADAPTIVE_THRESHOLD_SIGMA"]
+    for e in exprs:
+        assert H.evaluate_compiled(e, v) == H.evaluate_expression(e, v), e
+    for bad in ("max()", "foo(1)", "1 +", "nope + 1"):
+        with pytest.raises(RuntimeError):
+            H.evaluate_compiled(bad, v)
