@@ -234,11 +234,22 @@ __global__ void k_scatter(const float* __restrict__ x, const float* __restrict__
       mn[a] = min(mn[a], (uint32_t)__shfl_xor((int)mn[a], off));
       mx[a] = max(mx[a], (uint32_t)__shfl_xor((int)mx[a], off));
     }
-  if ((threadIdx.x & 63) == 0 && mx[0] != 0u)
+  // one set of atomics per workgroup (one per wave serialised ~4 k waves on six addresses: most of this kernel's time)
+  __shared__ uint32_t sh[4][6];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
     for (int a = 0; a < 3; a++) {
-      atomicMin(&bbox[a], mn[a]);
-      atomicMax(&bbox[3 + a], mx[a]);
+      sh[w][a] = mn[a];
+      sh[w][3 + a] = mx[a];
     }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    uint32_t v = sh[0][a];
+    for (int q = 1; q < 4; q++) v = a < 3 ? min(v, sh[q][a]) : max(v, sh[q][a]);
+    if (a < 3) { if (v != 0xFFFFFFFFu) atomicMin(&bbox[a], v); }
+    else if (v != 0u) atomicMax(&bbox[a], v);
+  }
 }
 
 __global__ void k_table_insert(const unsigned long long* __restrict__ vox_keys, const uint32_t* __restrict__ vox_first,
