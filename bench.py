@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=16, help="scans in flight per GPU (one per HIP stream)")
+    ap.add_argument("--streams", type=int, default=32, help="scans in flight per GPU (one per HIP stream)")
     ap.add_argument("--workload", default="c2", choices=["c2", "creal", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (bounded sample)")

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <string>
 
@@ -78,6 +79,9 @@ struct MapView {
   float inv_vs;
   uint32_t trunc;     // index_mode == MH_INDEX_TRUNC
   uint32_t ndt;       // 1: every voxel's points are preceded by two records {centroid, plane flag} {normal, 0}
+#ifdef MH_DEBUG_WAVETRACE
+  uint32_t dbg_stop;  // debug build: leave the quad search after phase N (tools/wavetrace_probe.py)
+#endif
 };
 
 __host__ __device__ inline unsigned long long pack_key(int kx, int ky, int kz) {
@@ -149,6 +153,9 @@ struct mh_map {
     v.inv_vs = inv_vs;
     v.trunc = params.index_mode == MH_INDEX_TRUNC;
     v.ndt = params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
+#ifdef MH_DEBUG_WAVETRACE
+    v.dbg_stop = getenv("MH_DBG_STOP") ? (uint32_t)atoi(getenv("MH_DBG_STOP")) : 0u;
+#endif
     return v;
   }
 };

@@ -461,18 +461,48 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
   const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
   const float vs = 1.0f / m.inv_vs;
   const Gaps gx = axis_gaps(qx, cx, vs, m.trunc), gy = axis_gaps(qy, cy, vs, m.trunc), gz = axis_gaps(qz, cz, vs, m.trunc);
+  const QuadBounds qb = quad_bounds(gx, gy, gz, sub);
   nnkey_t best = kNNKeyNone;
+#ifdef MH_DEBUG_WAVETRACE
+  if (m.dbg_stop == 1) return r;  // prologue only
+#endif
+  // Speculative probes, issued together with the own-voxel probe (same round trip): the three faces on the near side
+  // of each axis and the edge between the two nearest of them -- almost always the only neighbours that survive the
+  // bound once the own voxel has been scanned.  Lane s of the quad probes the s-th of them.
+  const int sx = gx.s[0] <= gx.s[2] ? 0 : 2, sy = gy.s[0] <= gy.s[2] ? 0 : 2, sz = gz.s[0] <= gz.s[2] ? 0 : 2;
+  const float nx = gx.s[sx], ny = gy.s[sy], nz = gz.s[sz];
+  const int c_fx = sx * 9 + 3 + 1, c_fy = 9 + sy * 3 + 1, c_fz = 9 + 3 + sz;
+  const int c_e = (nz >= nx && nz >= ny) ? sx * 9 + sy * 3 + 1 : (ny >= nx ? sx * 9 + 3 + sz : 9 + sy * 3 + sz);
+  const int c_spec = sub == 0 ? c_fx : (sub == 1 ? c_fy : (sub == 2 ? c_fz : c_e));
+  const uint32_t spec_bits = (1u << c_fx) | (1u << c_fy) | (1u << c_fz) | (1u << c_e);
+  const unsigned long long key_s = nn_key_of(kbase, c_spec);
   {  // the query's own voxel (code 13): the four lanes read the same slot
     const unsigned long long key = nn_key_of(kbase, 13);
+    const u32x4 sl_c = slots4[hash_key(key) & m.mask];
+    const u32x4 sl_s = slots4[hash_key(key_s) & m.mask];
     uint32_t f1[1], c1[1];
-    nn_resolve(m, slots4, key, slots4[hash_key(key) & m.mask], true, f1[0], c1[0]);
+    nn_resolve(m, slots4, key, sl_c, true, f1[0], c1[0]);
+#ifdef MH_DEBUG_WAVETRACE
+    if (m.dbg_stop == 2) { r.d2 = (float)(f1[0] + c1[0] + sl_s.z); return r; }  // + own-voxel probe
+#endif
     best = nn_scan_merged_quad<1>(pts4, f1, c1, sub, qx, qy, qz, best);
+#ifdef MH_DEBUG_WAVETRACE
+    if (m.dbg_stop == 3) { r.d2 = nnkey_d2(best) + (float)sl_s.z; return r; }  // + own-voxel scan
+#endif
+    // the speculated neighbours that did survive: one merged scan, no further probe round trip
+    const uint32_t live0 = quad_bound_mask(qb, sub, nnkey_d2(best));
+    uint32_t f_s, n_s;
+    nn_resolve(m, slots4, key_s, sl_s, ((live0 >> c_spec) & 1u) != 0, f_s, n_s);
+    // (the edge lane may repeat a face code when two gaps tie at zero: count it once)
+    if (sub == 3 && (c_e == c_fx || c_e == c_fy || c_e == c_fz)) n_s = 0;
+    const uint32_t first[4] = {quad_bcast<0>(f_s), quad_bcast<1>(f_s), quad_bcast<2>(f_s), quad_bcast<3>(f_s)};
+    const uint32_t cnt[4] = {quad_bcast<0>(n_s), quad_bcast<1>(n_s), quad_bcast<2>(n_s), quad_bcast<3>(n_s)};
+    best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best);
   }
   const uint32_t kFaces = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 14) | (1u << 16) | (1u << 22);
   const uint32_t kCorners = (1u << 0) | (1u << 2) | (1u << 6) | (1u << 8) | (1u << 18) | (1u << 20) | (1u << 24) | (1u << 26);
   const uint32_t kEdges = 0x07FFFFFFu & ~(kFaces | kCorners | (1u << 13));
-  uint32_t todo = 0x07FFFFFFu & ~(1u << 13);
-  const QuadBounds qb = quad_bounds(gx, gy, gz, sub);
+  uint32_t todo = 0x07FFFFFFu & ~(1u << 13) & ~spec_bits;
   for (;;) {
     // voxels that can still hold the winner (one evaluation per batch); nearest class first: faces, edges, corners
     const uint32_t live = todo & quad_bound_mask(qb, sub, nnkey_d2(best));
@@ -495,6 +525,9 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
     const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
     best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best);
   }
+#ifdef MH_DEBUG_WAVETRACE
+  if (m.dbg_stop == 4) { r.d2 = nnkey_d2(best); return r; }  // + neighbours, without the final record fetch
+#endif
   if (nnkey_idx(best) != 0xFFFFFFFFu) {
     r.pt = pts4[nnkey_idx(best)];
     r.d2 = nnkey_d2(best);

@@ -27,6 +27,6 @@ np.savez(os.path.join(ROOT, "gpurun_out", "wavetrace_%s.npz" % os.environ["MH_MA
 t = out["rep2"].astype(np.int64)
 t0 = t[:, 0].min()
 dur = (t[:, 1] - t[:, 0]) / 100.0  # wall_clock64 is 100 MHz -> us
-print("waves", len(t), "kernel span us", (t[:, 1].max() - t0) / 100.0)
+print("variant", os.environ["MH_MATCH"], "stop", os.environ.get("MH_DBG_STOP", "0"), "waves", len(t), "kernel span us", (t[:, 1].max() - t0) / 100.0)
 print("start offset us: pct", np.percentile((t[:, 0] - t0) / 100.0, [0, 50, 90, 99, 100]))
 print("duration us: pct", np.percentile(dur, [0, 10, 50, 90, 99, 100]), "mean", dur.mean())
