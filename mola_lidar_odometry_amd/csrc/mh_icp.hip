@@ -1167,6 +1167,7 @@ struct AlignJob {
     if (pl)
       MH_HIP(hipMemcpyAsync(ctx->sched.as<double>() + 2 * mi, p->pt2pl_threshold, mi * sizeof(double), hipMemcpyHostToDevice, s));
     if (trace) MH_TRY(ctx->trace.reserve(mi * sizeof(mh_icp_iter)));
+    ctx->align_serial++;
     init_state(ctx->h_state, T0);
     const double ang = p->threshold_angular_deg * 3.14159265358979323846 / 180.0;
     ctx->h_state->cur_thr2 = (float)(p->threshold[0] * p->threshold[0]);
@@ -1323,7 +1324,23 @@ struct AlignJob {
                                        (unsigned long long)(pl ? ctx->partials_b.p : nullptr)};
       static_assert(sizeof(kv) <= sizeof(key), "graph key too small");
       memcpy(key, kv, sizeof(kv));
-      if (!ctx->graph_exec || memcmp(key, ctx->graph_key, sizeof(key)) != 0) {
+      const bool cached = ctx->graph_exec && memcmp(key, ctx->graph_key, sizeof(key)) == 0;
+      const bool seen_before = memcmp(key, ctx->graph_candidate, sizeof(key)) == 0 && ctx->graph_candidate_align != ctx->align_serial;
+      if (!cached && !seen_before) {
+        // a shape not seen in an earlier alignment: launch directly and remember it; it is captured when a later
+        // alignment brings it again.  (The real pipeline's ICP layer changes size with every scan: capturing and
+        // instantiating a graph per alignment cost 0.4 ms each.)
+        if (memcmp(key, ctx->graph_candidate, sizeof(key)) != 0) {
+          memcpy(ctx->graph_candidate, key, sizeof(key));
+          ctx->graph_candidate_align = ctx->align_serial;
+        }
+        MH_TRY(enqueue_kernels());
+        MH_HIP(hipGetLastError());
+        enqueued += m;
+        MH_HIP(hipEventRecord(ctx->ev_poll, s));
+        return MH_OK;
+      }
+      if (!cached) {
         if (ctx->graph_exec) {
           (void)hipGraphExecDestroy(ctx->graph_exec);
           ctx->graph_exec = nullptr;

@@ -126,6 +126,8 @@ struct mh_ctx {
   IcpDeviceParams* h_params = nullptr;  // pinned mirror
   hipGraphExec_t graph_exec = nullptr;  // captured chunk of ICP iterations (replayed while graph_key matches)
   unsigned long long graph_key[24] = {0};
+  unsigned long long graph_candidate[24] = {0};  // key of the last direct-launched chunk: captured when a LATER alignment repeats it
+  unsigned long long graph_candidate_align = 0, align_serial = 0;
   hipEvent_t ev_poll = nullptr;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   // profiling events for the match kernel (pairs), created lazily
