@@ -23,6 +23,7 @@
 #include <stdexcept>
 #include <unordered_map>
 
+#include "hashed_voxel_pointcloud_hip.h"
 #include "molahip.h"
 
 namespace mp2p_icp
@@ -159,6 +160,9 @@ class ICP_HIP : public ICP
    private:
     mh_map* mirror_of(const mrpt::maps::CMetricMap& g)
     {
+        // a device-owned local map (hashed_voxel_pointcloud_hip.h): nothing to mirror, the handle is the map.
+        // (Its context must be the one this ICP runs on: both use device 0's default stream here.)
+        if (const auto* dm = dynamic_cast<const mola::HashedVoxelPointCloudHIP*>(&g)) return dm->deviceHandle();
         const auto* pm = dynamic_cast<const mrpt::maps::CPointsMap*>(&g);  // HashedVoxelPointCloud exposes its points through
         ASSERT_(pm);                                                        // a visitor [U]; adapt here once verified
         auto& mir = mirrors_[&g];

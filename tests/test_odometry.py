@@ -171,10 +171,20 @@ def test_hip_driver_matches_oracle_driver(host, drive, tmp_path):
 
 @pytest.mark.gpu
 def test_hip_driver_ndt_pipeline_and_restart(host, drive):
+    """lidar3d-ndt: NDT local map (min-distance insertion, plane statistics), point-to-plane + point-to-point ICP --
+    again scan by scan against the oracle driver."""
+    from oracle import odometry_oracle as oo
+    o = oo.OdometryOracle(PIPE_NDT, n_threads=8)
     lo = host.LidarOdometry()
     lo.initialize(host.Config.FromYamlFile(PIPE_NDT))
-    for (xyz, t), st in zip(drive["scans"][:8], drive["stamps"][:8]):
-        r = lo.onLidar(st, xyz, t)
+    for k, ((xyz, t), st) in enumerate(zip(drive["scans"][:8], drive["stamps"][:8])):
+        a = lo.onLidar(st, xyz, t)
+        b = o.on_lidar(st, xyz, t)
+        for key in ("icp_run", "icp_good", "map_updated", "icp_iterations", "twist_corrections", "termination",
+                    "n_for_map", "n_for_icp", "n_map_points", "n_map_voxels"):
+            assert a[key] == b[key], (k, key, a[key], b[key])
+        assert abs(a["goodness"] - b["goodness"]) < 1e-12 and abs(a["sigma"] - b["sigma"]) < 1e-9
+        np.testing.assert_allclose(np.array(a["pose"]), b["pose"], rtol=0, atol=1e-6)
     recs = lo.records()
     assert all(r["icp_good"] for r in recs[1:]) and recs[-1]["n_map_points"] > 1000
     est = np.stack([trajectory.to44(p) for _, p in lo.trajectory()])
