@@ -216,6 +216,9 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDevic
 // ================================================================================================
 // k_accum: point-to-point accumulation on stored pairings (inner GN steps, solver-granular path)
 // ================================================================================================
+constexpr uint32_t kAccPPT = 4;  // scan points per lane of k_accum
+inline uint32_t nblk_acc(size_t n) { return (uint32_t)((n + (size_t)kBlock * kAccPPT - 1) / ((size_t)kBlock * kAccPPT)); }
+
 __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first,
                                                   const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
@@ -230,14 +233,25 @@ __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restri
   for (int i = 0; i < 12; i++) T[i] = st->T[i];
   const MatchK k = *kp;
   const double kparam = k.use_fixed ? k.kparam_fixed : k.kparam[st->iter];
+  // kAccPPT points per lane: the 18 wave reductions below are most of this kernel's instructions, so they are
+  // amortised over four times as many points (the device is VALU-bound once several alignments run concurrently)
   const uint32_t bid = blockIdx.x;
-  const uint32_t i = bid * kBlock + threadIdx.x;
+  uint32_t gi[kAccPPT];
+  float4 q[kAccPPT];
+  float px[kAccPPT], py[kAccPPT], pz[kAccPPT];
+#pragma unroll
+  for (int u = 0; u < kAccPPT; u++) {  // all loads first (clamped index), then the arithmetic
+    const uint32_t i = (bid * kAccPPT + (uint32_t)u) * kBlock + threadIdx.x;
+    const uint32_t ic = i < n ? i : n - 1;
+    gi[u] = i < n ? pair_gidx[ic] : kNoMatch;
+    q[u] = pair_q[ic];
+    px[u] = lx[ic]; py[u] = ly[ic]; pz[u] = lz[ic];
+  }
   Acc a;
   acc_zero(a);
-  if (i < n && pair_gidx[i] != kNoMatch) {
-    const float4 q = pair_q[i];
-    acc_pt2pt(a, T, lx[i], ly[i], lz[i], q.x, q.y, q.z, k.kernel, kparam, k.w_pt2pt);
-  }
+#pragma unroll
+  for (int u = 0; u < kAccPPT; u++)
+    if (gi[u] != kNoMatch) acc_pt2pt(a, T, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int j = 0; j < kAccN; j++) {
@@ -1129,7 +1143,7 @@ struct AlignJob {
   mh_icp_iter* trace = nullptr;
   MatchK mk{};
   SolveK sk{};
-  uint32_t nb = 0, nbm = 0, enqueued = 0, chunk = 0, prof_n = 0;
+  uint32_t nb = 0, nbm = 0, nba = 0, enqueued = 0, chunk = 0, prof_n = 0;
   int variant = 0;
   bool finished = false, trivial = false;
   bool prof = false;  // time this job's match kernels with events (then it cannot use the graph path)
@@ -1217,7 +1231,8 @@ struct AlignJob {
       if (e && e[0] == 'x') variant = 1;
       if (variant == 1 && map->view().ndt) variant = 0;  // "x" walks contiguous z-runs; NDT maps interleave statistics records
     }
-    nbm = nb;
+    nba = nblk_acc(scan->n);
+    nbm = variant == 4 ? nba : nb;  // who writes the partials of the first Gauss-Newton step
     MH_TRY(ctx->partials.reserve((size_t)kGenN * (nbm > nb ? nbm : nb) * sizeof(double)));
     chunk = p->poll_every ? p->poll_every : 10;
     enqueued = 0;
@@ -1266,8 +1281,8 @@ struct AlignJob {
 #endif
           );
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
-          hipLaunchKernelGGL(k_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
-                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nb);
+          hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
         } else if (variant == 1)
           hipLaunchKernelGGL((k_match<true, 0>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x,
                              scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
@@ -1281,12 +1296,12 @@ struct AlignJob {
         hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nbm, nbm,
                            (const double*)partb, nB, nB);
         for (uint32_t in = 1; in < p->gn.max_inner_iterations; in++) {
-          hipLaunchKernelGGL(k_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
-                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nb);
+          hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
+                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
           if (pl)
             hipLaunchKernelGGL(k_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dmk, scan->x, scan->y, scan->z, n,
                                ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
-          hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nb, nb,
+          hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nba, nba,
                              (const double*)partb, nB, nB);
         }
       }
@@ -1704,15 +1719,15 @@ mh_status mh_gn_solve(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt2p
   const float* P = ctx->build_b.as<float>();
   for (uint32_t in = 0; in < p->max_inner_iterations; in++) {
     if (np)
-      hipLaunchKernelGGL(k_accum, dim3(nbp), dim3(kBlock), 0, s, ctx->d_state, in == 0 ? 1u : 0u, &ctx->d_params->mk,
+      hipLaunchKernelGGL(k_accum, dim3(nblk_acc(np)), dim3(kBlock), 0, s, ctx->d_state, in == 0 ? 1u : 0u, &ctx->d_params->mk,
                          L, L + sp, L + 2 * sp, (uint32_t)np, ctx->pair_q.as<float4>(),
-                         ctx->pair_gidx.as<uint32_t>(), ctx->partials.as<double>(), nbp);
+                         ctx->pair_gidx.as<uint32_t>(), ctx->partials.as<double>(), nblk_acc(np));
     if (nl)
       hipLaunchKernelGGL(k_accum_pl, dim3(nbl), dim3(kBlock), 0, s, ctx->d_state, p->robust_kernel,
                          p->robust_kernel_param, p->weight_pt2pl, P, P + 3 * sl, P + 6 * sl, (uint32_t)nl, (uint32_t)sl,
                          ctx->partials_b.as<double>(), nbl);
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, &ctx->d_params->sk,
-                       ctx->partials.as<double>(), nbp, nbp,
+                       ctx->partials.as<double>(), np ? nblk_acc(np) : 0u, np ? nblk_acc(np) : 0u,
                        ctx->partials_b.as<double>(), nbl, nbl);
   }
   MH_HIP(hipGetLastError());
