@@ -107,6 +107,14 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     dt = mdist.max_over_ranks(dt, device="cuda" if distributed else None)  # MAX over ranks
+    # outside the timed region: the same kernel with nothing else on the device (what a rocprofv3 kernel trace,
+    # which serialises the streams, reports per launch)
+    iso_ms, iso_launches = 0.0, 0
+    if prof and rank == 0:
+        for _ in range(3):
+            for r in capi.icp_align_batch(maps[:1], scans[:1], guesses[:1], params):
+                iso_ms += r["match_kernel_ms"]
+                iso_launches += r["n_match_launches"]
     # the trivial result gather: poses of the last step from every rank, RCCL all_gather
     gathered = mdist.gather_poses(np.stack([r["T"] for r in last]), device="cuda" if distributed else None)
     all_poses = np.stack(gathered)
@@ -174,14 +182,17 @@ def main():
                 os.environ.get("MH_MATCH", "q")[:1], "k_match4 (quad per point)")
             roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                    "avg_kernel_ms": avg_ms, "launches": match_launches, "p_bar": p_bar,
+                    "avg_kernel_ms": avg_ms, "launches": match_launches,
+                    "avg_kernel_ms_alone": (iso_ms / iso_launches) if iso_launches else None, "p_bar": p_bar,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "note": "HIP events around the match kernel of every iteration of stream 0 inside the timed region, with the other "
                             "streams' kernels running concurrently (they replay a captured hipGraph). The working set "
                             "(16 MB of records + the hash table) is cache resident: measured HBM traffic (`traffic`, bytes "
                             "per launch) is ~30x below the algorithmic bytes, so `achieved` is a rate of ALGORITHMIC bytes "
                             "and can exceed the HBM peak; what the kernel waits for is the chain of dependent L1-miss "
-                            "round trips of its slowest wave (DESIGN.md section 3)"}
+                            "round trips of its slowest wave (DESIGN.md section 3). avg_kernel_ms_alone = the same kernel "
+                            "with a single stream, after the timed region: the figure a (stream-serialising) rocprofv3 "
+                            "kernel trace reports"}
             import glob
             pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
             if pmc:  # HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (profiles/collect.sh)
