@@ -10,12 +10,14 @@
 //   mp2p_icp::covariance                                    <- LidarOdometry.cpp:1009
 //
 // Kernel sequence per ICP iteration (everything stays in HBM/L2; the host never sees pairings):
-//   k_match<fused>   one lane per scan point: transform, 27-voxel NN, threshold test, store pairing,
-//                    robust weight + 18 fp64 moment sums, block reduction -> partials
-//   k_solve          one wave: ordered sum of partials, prior factor, LDL^T, T <- T(+)exp(delta),
-//                    inner/outer loop bookkeeping, stall + hook tests, termination flag
-//   k_accum          (inner GN steps >= 1) re-evaluate the SAME pairings at the new pose -> partials
-//   k_solve
+//   k_match4         a DPP quad per scan point: transform, exact branch-and-bound NN over the 27-voxel block,
+//                    threshold test, store pairing            (MH_MATCH=p|x: k_match<fused>, one lane per point,
+//                    with the first accumulation fused in)
+//   k_accum          robust weight + 18 fp64 moment sums of the stored pairings at the current pose -> partials
+//   k_solve          one workgroup: ordered sum of partials, prior factor, LDL^T, T <- T(+)exp(delta),
+//                    inner/outer loop bookkeeping, stall + hook tests, termination flag, next threshold
+//   k_accum, k_solve (inner Gauss-Newton steps >= 1 on the SAME pairings)
+// A chunk of iterations is one hipGraph launch; every kernel begins with `if (st->done) return`.
 // No fp atomics anywhere: reductions are fixed-shape trees, so results are bitwise reproducible.
 #include <stdlib.h>
 #include <string.h>
@@ -189,8 +191,6 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDevic
 #endif
   // everything needed per iteration sits in the state block (k_solve publishes the next threshold there): one batch of
   // scalar loads instead of the chain state -> parameter block -> threshold table, and the point is fetched alongside
-  // (handing each XCD a contiguous range of the scan -- xcd_block() -- measured 10 % slower: L2 misses are not what
-  //  this kernel waits for, and a contiguous range concentrates the crowded parts of the scene on one XCD)
   const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
   const uint32_t i = gl >> 2, sub = gl & 3u;
   const uint32_t ic = i < n ? i : n - 1;
