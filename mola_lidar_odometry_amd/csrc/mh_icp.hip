@@ -529,7 +529,10 @@ struct SolveShared {
 // must call it; only lane 0 runs the serial part.  (A cooperative single-launch version of the whole loop for the
 // 1-8 k-point layers of the real pipeline -- match | grid barrier | solve | grid barrier | accumulate ... -- was
 // built on top of this and measured: 1.91 vs 1.98 ms of ICP per scan, i.e. the launch boundaries are not what a
-// small alignment waits for; it was removed again.)
+// small alignment waits for; it was removed again.  So was a "last workgroup of k_accum runs the solve" fusion
+// (ticket counter + __threadfence): correct, but the device-scope release/acquire fences write back and invalidate the
+// XCDs' L2s on every launch -- the map falls out of cache and C2 drops from 2285 to 960 scans/s.  Kernel boundaries
+// are the cheap way to order producers and consumers on this part.)
 __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
                                            const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                            const double* __restrict__ partB, uint32_t nB, uint32_t strideB,
