@@ -97,6 +97,9 @@ MH_API mh_status mh_ctx_create(int32_t device, void* hip_stream, mh_ctx** out);
 MH_API mh_status mh_ctx_destroy(mh_ctx* ctx);
 MH_API mh_status mh_ctx_synchronize(mh_ctx* ctx);
 MH_API mh_status mh_ctx_stream(mh_ctx* ctx, void** hip_stream_out);
+/* Free / total device memory [bytes] of the context's GPU after draining its stream (capacity planning for batches of
+ * maps and scans; also how the tests check that destroyed handles give their memory back). */
+MH_API mh_status mh_ctx_memory_info(mh_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * Local map: the NN-search target.  Replaces mola::HashedVoxelPointCloud [U] as configured at

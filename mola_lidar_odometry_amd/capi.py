@@ -127,6 +127,7 @@ _SIGNATURES = {
     "mh_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "mh_ctx_synchronize": (C.c_int32, [C.c_void_p]),
     "mh_ctx_stream": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mh_ctx_memory_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mh_map_create": (C.c_int32, [C.c_void_p, C.POINTER(MapParams), C.POINTER(C.c_void_p)]),
     "mh_map_destroy": (C.c_int32, [C.c_void_p]),
     "mh_map_build": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
@@ -230,6 +231,12 @@ class Context:
 
     def synchronize(self):
         _chk(lib().mh_ctx_synchronize(self._h))
+
+    def memory_info(self):
+        """(free, total) bytes of device memory."""
+        f, t = C.c_uint64(), C.c_uint64()
+        _chk(lib().mh_ctx_memory_info(self._h, C.byref(f), C.byref(t)))
+        return int(f.value), int(t.value)
 
     @property
     def stream(self) -> int:

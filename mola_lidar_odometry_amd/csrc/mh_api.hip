@@ -174,6 +174,17 @@ mh_status mh_ctx_synchronize(mh_ctx* ctx) {
   return MH_OK;
 }
 
+mh_status mh_ctx_memory_info(mh_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes) {
+  MH_REQUIRE(ctx && free_bytes && total_bytes, "null argument");
+  MH_TRY(set_device(ctx));
+  MH_HIP(hipStreamSynchronize(ctx->stream));
+  size_t f = 0, t = 0;
+  MH_HIP(hipMemGetInfo(&f, &t));
+  *free_bytes = f;
+  *total_bytes = t;
+  return MH_OK;
+}
+
 mh_status mh_ctx_stream(mh_ctx* ctx, void** hip_stream_out) {
   MH_REQUIRE(ctx && hip_stream_out, "null argument");
   *hip_stream_out = (void*)ctx->stream;

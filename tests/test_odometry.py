@@ -256,3 +256,31 @@ def test_sequence_runner_on_a_kitti_tree(tmp_path, drive, capsys):
     # vehicle moves 0.8 m per sweep, so this is a plumbing check (frames, files, metrics), not an accuracy figure
     assert seq["sequence"] == "00" and seq["scans"] == len(drive["scans"]) and seq["good"] >= seq["scans"] - 2
     assert os.path.exists(seq["tum"]) and seq["ate_rmse_m"] < 1.5
+
+
+@pytest.mark.gpu
+def test_driver_objects_release_their_device_memory(host, drive):
+    """Five drivers one after the other (each with its own maps, layers and scratch): device memory in use after the
+    last one equals what it was after the first (handles are freed, scratch buffers do not accumulate)."""
+    import gc
+    from mola_lidar_odometry_amd import capi
+    probe = capi.Context(0)
+
+    def free_bytes():
+        return probe.memory_info()[0]
+
+    def one_run():
+        lo = host.LidarOdometry()
+        lo.initialize(host.Config.FromYamlFile(PIPE))
+        for (xyz, t), st in zip(drive["scans"][:6], drive["stamps"][:6]):
+            lo.onLidar(st, xyz, t)
+        poses = [p for _, p in lo.trajectory()]
+        del lo
+        gc.collect()
+        return poses, free_bytes()
+
+    first_poses, free_after_first = one_run()
+    for _ in range(4):
+        poses, free_now = one_run()
+        assert poses == first_poses  # and bitwise the same trajectory every time
+    assert free_after_first - free_now < 8 << 20, (free_after_first, free_now)
