@@ -70,3 +70,76 @@ def test_hip_path_reproduces_golden(small_workload):
            lambda: capi.icp_align(gm, gs, w.T_guess, capi.ICPParams(max_iterations=300, threshold=thr, kernel_param=kp)),
            capi.TERM_NAMES)
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------ rows f1-f3
+FRONT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "frontend.json")))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _crc(a):
+    import zlib
+    return int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+@pytest.fixture(scope="module")
+def front_drive():
+    d = synth.make_drive(FRONT["drive"]["n_scans"])
+    xyz, t = d["scans"][5]
+    assert (len(xyz), _crc(xyz), _crc(t)) == (FRONT["drive"]["scan5_points"], FRONT["drive"]["scan5_crc"], FRONT["drive"]["scan5_t_crc"])
+    return d
+
+
+def _check_frontend(pre, deskew, map_dump, recs):
+    g = FRONT["preprocess"]
+    im, ii = pre
+    assert (len(im), len(ii), _crc(im), _crc(ii)) == (g["n_map"], g["n_icp"], g["idx_map_crc"], g["idx_icp_crc"])
+    assert [int(v) for v in ii[:8]] == g["idx_icp_head"] and [int(v) for v in ii[-8:]] == g["idx_icp_tail"]
+    if deskew is not None:  # (floating point: the device may differ from libm by one float ulp on a few coordinates)
+        np.testing.assert_allclose(deskew[:3], FRONT["deskew"]["first3"], rtol=0, atol=4e-6)
+    gm = FRONT["map_insert"]
+    assert (len(map_dump["xyz"]), len(map_dump["vox_keys"])) == (gm["n_points"], gm["n_voxels"])
+    assert (_crc(map_dump["xyz"]), _crc(map_dump["src_idx"]), _crc(map_dump["vox_keys"]), _crc(map_dump["vox_count"])) == (
+        gm["xyz_crc"], gm["src_crc"], gm["keys_crc"], gm["count_crc"])
+    go = FRONT["odometry"]
+    for key in ("icp_iterations", "twist_corrections", "map_updated", "n_for_icp", "n_map_points"):
+        assert [type(go[key][0])(r[key]) for r in recs] == go[key], key
+    np.testing.assert_allclose([np.asarray(r["pose"]) for r in recs], go["poses"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose([r["sigma"] for r in recs], go["sigma"], rtol=0, atol=1e-8)
+
+
+def test_c_oracle_reproduces_frontend_golden(oracle, front_drive):
+    from oracle import odometry_oracle as oo
+    d = front_drive
+    xyz, t = d["scans"][5]
+    pre = oracle.preprocess(xyz, **FRONT["preprocess"]["params"])
+    ta = oracle.adjust_timestamps(t, oracle.TS_MIDDLE_IS_ZERO, 0.0)
+    dsk = oracle.deskew(xyz[pre[1]], ta[pre[1]], FRONT["deskew"]["twist"])
+    assert _crc(dsk) == FRONT["deskew"]["xyz_crc_of_icp_layer"]
+    m = oracle.Map(1.0, 20)
+    for k in FRONT["map_insert"]["keyframes"]:
+        m.insert_posed(d["scans"][k][0][::3], d["poses"][k], FRONT["map_insert"]["remove_voxels_farther_than"])
+    o = oo.OdometryOracle(os.path.join(ROOT, FRONT["odometry"]["pipeline"]), n_threads=8)
+    recs = [o.on_lidar(st, s[0], s[1]) for s, st in zip(d["scans"], d["stamps"])]
+    _check_frontend(pre, dsk, m.dump(), recs)
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_frontend_golden(front_drive):
+    from mola_lidar_odometry_amd import _mp2p_icp_hip as H
+    from mola_lidar_odometry_amd import capi
+    d = front_drive
+    ctx = capi.Context(0)
+    xyz, t = d["scans"][5]
+    raw = capi.Scan(ctx, xyz).set_timestamps(t)
+    om, oi, out = capi.Scan(ctx), capi.Scan(ctx), capi.Scan(ctx)
+    raw.preprocess(capi.preprocess_params(timestamp_method=capi.TS_MIDDLE_IS_ZERO, **FRONT["preprocess"]["params"]), om, oi)
+    oi.deskew(FRONT["deskew"]["twist"], out)
+    m = capi.Map(ctx, 1.0, 20)
+    for k in FRONT["map_insert"]["keyframes"]:
+        m.insert(capi.Scan(ctx, d["scans"][k][0][::3]), d["poses"][k], FRONT["map_insert"]["remove_voxels_farther_than"])
+    lo = H.LidarOdometry()
+    lo.initialize(H.Config.FromYamlFile(os.path.join(ROOT, FRONT["odometry"]["pipeline"])))
+    recs = [lo.onLidar(st, s[0], s[1]) for s, st in zip(d["scans"], d["stamps"])]
+    _check_frontend((om.download()["src_idx"], oi.download()["src_idx"]), out.download()["xyz"], m.download(), recs)
+    ctx.close()
