@@ -213,6 +213,35 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDevic
   }
 }
 
+// k_match16: the same step with a DPP row (16 lanes) per scan point (nn_search_row16): for small layers, where the
+// launch is pure latency; chosen automatically below kRowMaxPoints points.
+constexpr uint32_t kRowMaxPoints = 16384;
+__global__ __launch_bounds__(kBlock) void k_match16(const IcpDeviceState* __restrict__ st, const float* __restrict__ lx,
+                                                    const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                    MapView map, float4* __restrict__ pair_q,
+                                                    uint32_t* __restrict__ pair_gidx) {
+  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = gl >> 4, r16 = gl & 15u;
+  const uint32_t ic = i < n ? i : n - 1;
+  const float x = lx[ic], y = ly[ic], z = lz[ic];
+  const uint32_t done = st->done;
+  double T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = st->T[k];
+  const float thr2 = st->cur_thr2, ang2 = st->cur_ang2;
+  if (done) return;    // wave-uniform
+  if (i >= n) return;  // whole rows
+  float px, py, pz;
+  transform_point(T, x, y, z, px, py, pz);
+  const NNResult r = nn_search_row16(map, r16, px, py, pz);
+  if (r16 == 0) {
+    const float n2 = (px * px + py * py) + pz * pz;
+    const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
+    pair_q[i] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
+    pair_gidx[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+  }
+}
+
 // ================================================================================================
 // k_accum: point-to-point accumulation on stored pairings (inner GN steps, solver-granular path)
 // ================================================================================================
@@ -1228,14 +1257,17 @@ struct AlignJob {
        //   "q" (default)  a DPP quad per scan point, merged candidate scans          -> k_match4 + k_accum
        //   "p"            one lane per point, branch-and-bound, fused accumulation   -> k_match<true, 1>
        //   "x"            one lane per point, the literal 27-voxel scan of the reference (A/B baseline)
+      //   "s"            a DPP row (16 lanes) per point: what "q" becomes automatically for small layers    -> k_match16 + k_accum
       const char* e = getenv("MH_MATCH");
-      variant = 4;
+      variant = scan->n <= kRowMaxPoints ? 5 : 4;
+      if (e && e[0] == 'q') variant = 4;
+      if (e && e[0] == 's') variant = 5;
       if (e && e[0] == 'p') variant = 0;
       if (e && e[0] == 'x') variant = 1;
       if (variant == 1 && map->view().ndt) variant = 0;  // "x" walks contiguous z-runs; NDT maps interleave statistics records
     }
     nba = nblk_acc(scan->n);
-    nbm = variant == 4 ? nba : nb;  // who writes the partials of the first Gauss-Newton step
+    nbm = variant >= 4 ? nba : nb;  // who writes the partials of the first Gauss-Newton step
     MH_TRY(ctx->partials.reserve((size_t)kGenN * (nbm > nb ? nbm : nb) * sizeof(double)));
     chunk = p->poll_every ? p->poll_every : 10;
     enqueued = 0;
@@ -1276,7 +1308,13 @@ struct AlignJob {
           hipLaunchKernelGGL(k_match_pl<true>, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, dmk, scan->x, scan->y,
                              scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
         if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n], s));
-        if (variant == 4) {
+        if (variant == 5) {
+          hipLaunchKernelGGL(k_match16, dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
+                             scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>());
+          if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
+          hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
+        } else if (variant == 4) {
           hipLaunchKernelGGL(k_match4, dim3((uint32_t)((4ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
                              scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>()
 #ifdef MH_DEBUG_WAVETRACE
@@ -1293,7 +1331,7 @@ struct AlignJob {
           hipLaunchKernelGGL((k_match<true, 1>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x,
                              scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
         if (prof) {
-          if (variant != 4) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));
+          if (variant < 4) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));
           prof_n++;
         }
         hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nbm, nbm,

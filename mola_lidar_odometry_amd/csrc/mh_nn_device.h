@@ -532,6 +532,146 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
   return r;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Sixteen lanes (a DPP row) per scan point: the search for SMALL layers (the real pipeline's decimated_for_icp,
+// 1-8 k points).  There the device is nearly empty and a launch costs what its slowest lane's chain of dependent
+// round trips costs, so the row spends bandwidth to shorten the chain:
+//   round 1   all 27 slots of the block at once (lane r probes codes r and r + 16)
+//   round 2   the own voxel's records, two per lane
+//   round 3+  the neighbours that survive the bound, four voxels per round trip (their slots are already known),
+//             merged record ranges as in the quad kernel; typically one round
+// and the usual exact (d2, record index) key, reduced over the row with DPP row shifts.  Same result, bit for bit.
+// -------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ uint32_t row_dpp_keep(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t row_bcast_u32(uint32_t v, uint32_t src_lane_in_row) {
+  const uint32_t lane = (uint32_t)__lane_id();
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & ~15u) + src_lane_in_row) << 2), (int)v);
+}
+// min over the 16 lanes of a row, valid in every lane of the row afterwards
+__device__ __forceinline__ nnkey_t row_min_key(nnkey_t k) {
+#define MH_ROW_STEP(CTRL)                                                                                         \
+  {                                                                                                               \
+    const nnkey_t o = ((nnkey_t)row_dpp_keep<CTRL>(0xFFFFFFFFu, (uint32_t)(k >> 32)) << 32) |                     \
+                      row_dpp_keep<CTRL>(0xFFFFFFFFu, (uint32_t)k);                                               \
+    k = o < k ? o : k;                                                                                            \
+  }
+  MH_ROW_STEP(0x101)  // row_shl:1 (lane i reads lane i+1 of its row; out-of-row lanes keep `old` = all ones)
+  MH_ROW_STEP(0x102)
+  MH_ROW_STEP(0x104)
+  MH_ROW_STEP(0x108)  // lane 0 of the row holds the minimum
+#undef MH_ROW_STEP
+  return ((nnkey_t)row_bcast_u32((uint32_t)(k >> 32), 0) << 32) | row_bcast_u32((uint32_t)k, 0);
+}
+
+constexpr int kRowW = 2;  // records per lane and round trip: 16 x 2 = 32 >= one full voxel (cap 20)
+
+template <int NV>
+__device__ __forceinline__ nnkey_t nn_scan_merged_row(const f32x4* __restrict__ pts4, const uint32_t (&first)[NV],
+                                                      const uint32_t (&cnt)[NV], uint32_t r16, float qx, float qy, float qz,
+                                                      nnkey_t best) {
+  uint32_t pre[NV + 1], start[NV];
+  pre[0] = 0;
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    pre[v + 1] = pre[v] + cnt[v];
+    start[v] = first[v] - pre[v];
+  }
+  const uint32_t total = pre[NV];  // the same in the sixteen lanes
+  for (uint32_t t0 = 0; t0 < total; t0 += 16 * kRowW) {
+    f32x4 c[kRowW];
+    uint32_t ri[kRowW];
+    bool valid[kRowW];
+#pragma unroll
+    for (int u = 0; u < kRowW; u++) {
+      const uint32_t tu = t0 + 16u * (uint32_t)u + r16;
+      valid[u] = tu < total;
+      const uint32_t t = valid[u] ? tu : total - 1;
+      uint32_t off = start[0];
+#pragma unroll
+      for (int v = 1; v < NV; v++) off = t >= pre[v] ? start[v] : off;
+      ri[u] = t + off;
+      c[u] = pts4[ri[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < kRowW; u++) {
+      const float dx = c[u].x - qx, dy = c[u].y - qy, dz = c[u].z - qz;
+      const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order (bit-exact with the oracle)
+      const nnkey_t k = valid[u] ? (((nnkey_t)__float_as_uint(d2) << 32) | ri[u]) : kNNKeyNone;
+      best = k < best ? k : best;
+    }
+  }
+  return row_min_key(best);
+}
+
+// every lane of the row passes the same q and gets the same result
+__device__ __forceinline__ NNResult nn_search_row16(const MapView& m, uint32_t r16, float qx, float qy, float qz) {
+  NNResult r;
+  r.d2 = __builtin_inff();
+  r.found = false;
+  r.pt = (f32x4)(0.f);
+  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return r;
+  const float lim = 1.0e6f;
+  if (!(fabsf(qx * m.inv_vs) < lim && fabsf(qy * m.inv_vs) < lim && fabsf(qz * m.inv_vs) < lim)) return r;
+  const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
+  const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
+  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
+  const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
+  const float vs = 1.0f / m.inv_vs;
+  const Gaps gx = axis_gaps(qx, cx, vs, m.trunc), gy = axis_gaps(qy, cy, vs, m.trunc), gz = axis_gaps(qz, cz, vs, m.trunc);
+  // round 1: lane r owns codes r ("a") and r + 16 ("b", only r <= 10)
+  const int ca = (int)r16, cb = (int)r16 + 16;
+  const bool has_b = cb < 27;
+  const unsigned long long ka = nn_key_of(kbase, ca), kb = nn_key_of(kbase, has_b ? cb : ca);
+  const u32x4 sa = slots4[hash_key(ka) & m.mask];
+  const u32x4 sb = slots4[hash_key(kb) & m.mask];
+  uint32_t fa, na, fb, nb;
+  nn_resolve(m, slots4, ka, sa, true, fa, na);
+  nn_resolve(m, slots4, kb, sb, has_b, fb, nb);
+  const float lba = ca == 13 ? __builtin_inff() : nn_lower_bound(ca, gx, gy, gz) * 0.9999f;  // own voxel: handled first
+  const float lbb = has_b ? nn_lower_bound(cb, gx, gy, gz) * 0.9999f : __builtin_inff();
+  nnkey_t best = kNNKeyNone;
+  {  // round 2: the own voxel (code 13, slot "a" of lane 13)
+    const uint32_t f1[1] = {row_bcast_u32(fa, 13)}, c1[1] = {row_bcast_u32(na, 13)};
+    best = nn_scan_merged_row<1>(pts4, f1, c1, r16, qx, qy, qz, best);
+  }
+  // rounds 3+: surviving non-empty neighbours, four at a time, lowest code first (any order gives the same minimum)
+  bool todo_a = ca != 13 && na > 0, todo_b = has_b && nb > 0;
+  const uint32_t row_shift = (uint32_t)__lane_id() & 48u;
+  for (;;) {
+    const float bd = nnkey_d2(best);
+    const bool pa = todo_a && !(lba > bd), pb = todo_b && !(lbb > bd);
+    const uint32_t ma = (uint32_t)(__ballot(pa) >> row_shift) & 0xFFFFu, mb = (uint32_t)(__ballot(pb) >> row_shift) & 0xFFFFu;
+    uint32_t mm = ma | (mb << 16);  // bit = code
+    if (!mm) break;
+    uint32_t first[4], cnt[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int code = mm ? __builtin_ctz(mm) : -1;
+      mm &= mm - 1;
+      const uint32_t owner = (uint32_t)(code < 0 ? 0 : code) & 15u;
+      const bool is_b = code >= 16;
+      const uint32_t f = row_bcast_u32(is_b ? fb : fa, owner), n = row_bcast_u32(is_b ? nb : na, owner);
+      // NB: the value is selected BEFORE the permute in every lane, so the owner lane contributes the right slot
+      first[v] = f;
+      cnt[v] = code < 0 ? 0u : n;
+      if (code >= 0) {
+        if (code == ca) todo_a = false;
+        if (code == cb) todo_b = false;
+      }
+    }
+    best = nn_scan_merged_row<4>(pts4, first, cnt, r16, qx, qy, qz, best);
+  }
+  if (nnkey_idx(best) != 0xFFFFFFFFu) {
+    r.pt = pts4[nnkey_idx(best)];
+    r.d2 = nnkey_d2(best);
+    r.found = true;
+  }
+  return r;
+}
+
 // ---- robust kernels (mp2p_icp::create_robust_kernel [U], lidar3d-default.yaml:188-190) ---------
 __device__ __forceinline__ double robust_weight(uint32_t kernel, double c, double e2) {
   switch (kernel) {

@@ -1,7 +1,8 @@
 #!/bin/bash
 # scratch: A/B runs on the GPU box
 cd /root/repo
-MH_MATCH=q timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -1
-for S in 1 32; do python bench.py --no-cpu-baseline --streams $S --steps 10 | python -c "
-import sys, json
-d=json.loads(sys.stdin.read()); print('S=$S: %.0f scans/s  k_match %.1f us' % (d['value'], 1e3*d['roofline']['avg_kernel_ms']))"; done
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+MH_MATCH=s timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -2
+MH_MATCH=q timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_odometry.py -m gpu -x -q 2>&1 | tail -2
+python -m mola_lidar_odometry_amd.run_odometry --synthetic 200 2>&1 | head -1 | cut -c1-120,330-640
+MH_MATCH=q python -m mola_lidar_odometry_amd.run_odometry --synthetic 200 2>&1 | head -1 | cut -c1-120,330-640
