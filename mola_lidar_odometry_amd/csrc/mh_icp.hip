@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDevic
 
 // k_match16: the same step with a DPP row (16 lanes) per scan point (nn_search_row16): for small layers, where the
 // launch is pure latency; chosen automatically below kRowMaxPoints points.
-constexpr uint32_t kRowMaxPoints = 16384;
+constexpr uint32_t kRowMaxPoints = 32768;  // measured cross-over with the quad kernel: ~40 k points (C2 map)
 __global__ __launch_bounds__(kBlock) void k_match16(const IcpDeviceState* __restrict__ st, const float* __restrict__ lx,
                                                     const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                     MapView map, float4* __restrict__ pair_q,
@@ -753,6 +753,67 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restr
   __shared__ SolveShared sh;
   if (st->done) return;
   solve_body(st, kp, partA, nA, strideA, partB, nB, strideB, sh);
+}
+
+// ================================================================================================
+// k_accum_solve1: accumulation AND Gauss-Newton step of a small layer in ONE workgroup (no inter-workgroup hand-over,
+// hence no device-scope fence): for the <= kOneGroupMaxPoints points of the real pipeline's ICP layer an iteration
+// becomes match | accumulate+solve | accumulate+solve -- three launches instead of five.
+// ================================================================================================
+constexpr uint32_t kOneGroupMaxPoints = 2048;  // measured: 1 k points -8 %, 2 k -4 %, 4 k +7 % per alignment vs k_accum + k_solve
+constexpr int kOneGroupBatch = 4;  // points per lane and round of loads
+
+__global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* __restrict__ st, uint32_t first,
+                                                                const MatchK* __restrict__ kp, const SolveK* __restrict__ sk,
+                                                                const float* __restrict__ lx, const float* __restrict__ ly,
+                                                                const float* __restrict__ lz, uint32_t n,
+                                                                const float4* __restrict__ pair_q,
+                                                                const uint32_t* __restrict__ pair_gidx, double* partials) {
+  __shared__ SolveShared sh;
+  __shared__ double lds[kSolveThreads / 64][kAccN];
+  if (st->done) return;
+  if (!first && st->inner == 0) return;  // the previous solve already closed this ICP iteration
+  {
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = st->T[i];
+    const MatchK k = *kp;
+    const double kparam = k.use_fixed ? k.kparam_fixed : k.kparam[st->iter];
+    Acc a;
+    acc_zero(a);
+    for (uint32_t base = 0; base < n; base += kSolveThreads * kOneGroupBatch) {
+      uint32_t gi[kOneGroupBatch];
+      float4 q[kOneGroupBatch];
+      float px[kOneGroupBatch], py[kOneGroupBatch], pz[kOneGroupBatch];
+#pragma unroll
+      for (int u = 0; u < kOneGroupBatch; u++) {  // all loads first (clamped index), then the arithmetic
+        const uint32_t i = base + (uint32_t)u * kSolveThreads + threadIdx.x;
+        const uint32_t ic = i < n ? i : n - 1;
+        gi[u] = i < n ? pair_gidx[ic] : kNoMatch;
+        q[u] = pair_q[ic];
+        px[u] = lx[ic]; py[u] = ly[ic]; pz[u] = lz[ic];
+      }
+#pragma unroll
+      for (int u = 0; u < kOneGroupBatch; u++)
+        if (gi[u] != kNoMatch) acc_pt2pt(a, T, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < kAccN; j++) {
+      const double s = wave_sum(a.v[j]);
+      if (lane == 0) lds[wave][j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kAccN) {
+      double sum = lds[0][threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < (int)(kSolveThreads / 64); w++) sum += lds[w][threadIdx.x];  // fixed order
+      partials[threadIdx.x] = sum;  // one "workgroup partial" per row: the solve below reads it back (same CU)
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  solve_body(st, sk, partials, 1u, 1u, nullptr, 0u, 0u, sh);
 }
 
 // ================================================================================================
@@ -1300,6 +1361,8 @@ struct AlignJob {
     const MatchK* dmk = &ctx->d_params->mk;
     const SolveK* dsk = &ctx->d_params->sk;
     // everything a chunk launches, in stream order; used directly (profiling / MH_NO_GRAPH) or under stream capture
+    static const bool no_one_group = getenv("MH_NO_ONE_GROUP") != nullptr;
+    const bool one_group = variant == 5 && !pl && n <= kOneGroupMaxPoints && !no_one_group;  // accumulate + solve in one workgroup
     auto enqueue_kernels = [&]() -> mh_status {
       double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
       const uint32_t nB = pl ? nb : 0u;
@@ -1312,6 +1375,13 @@ struct AlignJob {
           hipLaunchKernelGGL(k_match16, dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
                              scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>());
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
+          if (one_group) {
+            if (prof) prof_n++;
+            for (uint32_t in = 0; in < p->gn.max_inner_iterations; in++)
+              hipLaunchKernelGGL(k_accum_solve1, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, in == 0 ? 1u : 0u, dmk, dsk,
+                                 scan->x, scan->y, scan->z, n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part);
+            continue;
+          }
           hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
         } else if (variant == 4) {
