@@ -1361,7 +1361,7 @@ struct AlignJob {
     const MatchK* dmk = &ctx->d_params->mk;
     const SolveK* dsk = &ctx->d_params->sk;
     // everything a chunk launches, in stream order; used directly (profiling / MH_NO_GRAPH) or under stream capture
-    static const bool no_one_group = getenv("MH_NO_ONE_GROUP") != nullptr;
+    const bool no_one_group = getenv("MH_NO_ONE_GROUP") != nullptr;  // (read per chunk: tests toggle it)
     const bool one_group = variant == 5 && !pl && n <= kOneGroupMaxPoints && !no_one_group;  // accumulate + solve in one workgroup
     auto enqueue_kernels = [&]() -> mh_status {
       double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
@@ -1429,7 +1429,7 @@ struct AlignJob {
       MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
       return MH_OK;
     };
-    static const bool no_graph = getenv("MH_NO_GRAPH") != nullptr;
+    const bool no_graph = getenv("MH_NO_GRAPH") != nullptr;
     if (prof || no_graph) {
       MH_TRY(enqueue_kernels());
       MH_HIP(hipGetLastError());

@@ -501,3 +501,27 @@ def test_profile_fields(ctx, small):
     w, gm, om, gs = small
     r = capi.icp_align(gm, gs, w.T_guess, _params(capi, w, disable_stall_test=True, profile=True), want_trace=False)
     assert r["n_match_launches"] == w.n_iters and r["match_kernel_ms"] > 0 and r["total_ms"] >= r["match_kernel_ms"]
+
+
+@pytest.mark.parametrize("env", [{"MH_MATCH": "s"}, {"MH_MATCH": "s", "MH_NO_ONE_GROUP": "1"}, {"MH_MATCH": "q"},
+                                 {"MH_MATCH": "p"}, {"MH_MATCH": "x"}, {"MH_MATCH": "q", "MH_NO_GRAPH": "1"}])
+@pytest.mark.parametrize("n_scan", [2000, 5000])
+def test_every_kernel_variant_matches_the_oracle(ctx, oracle, env, n_scan, monkeypatch):
+    """The default path picks its kernels by layer size (row / quad search, one-workgroup or multi-launch solve);
+    here every combination is forced on the same inputs: identical pairings and termination, poses within 1e-9."""
+    scene = synth.make_scene(4321, 80.0, 25)
+    mp = synth.make_map(scene, 60000, 4321)
+    pose = [1.5, -0.8, synth.SENSOR_H, 0.05, 0.004, -0.003]
+    scan = synth.make_scan(scene, pose, rings=32, azimuths=400, seed=99)[:n_scan]
+    guess = synth.pose_from_ypr(np.array(pose) + [0.3, 0.1, 0.02, 0.01, 0.002, 0.002])
+    thr, kp = synth.threshold_schedule(2.0, 300)
+    kw = dict(max_iterations=300, threshold=thr, kernel_param=kp)
+    o = oracle.icp_align(oracle.Map(1.0, 20).insert(mp), scan, guess, oracle.ICPParams(**kw), want_pairs=True)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = capi.icp_align(capi.Map(ctx, 1.0, 20).build(mp), capi.Scan(ctx, scan), guess, capi.ICPParams(**kw), want_pairs=True)
+    assert g["n_iterations"] == o["n_iterations"] and g["termination_reason"] == o["termination_reason"]
+    assert [t["n_pairs"] for t in g["trace"]] == [t["n_pairs"] for t in o["trace"]]
+    np.testing.assert_array_equal(g["pairs"]["global_idx"], o["pairs"]["global_idx"])
+    np.testing.assert_array_equal(g["pairs"]["d2"], o["pairs"]["d2"])
+    np.testing.assert_allclose(g["T"], o["T"], rtol=0, atol=1e-9)
