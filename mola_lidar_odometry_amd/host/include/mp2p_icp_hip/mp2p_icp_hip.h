@@ -253,7 +253,12 @@ struct Parameters {  // mp2p_icp::Parameters (lidar3d-default.yaml:172-182)
   uint32_t maxIterations = 40;
   double minAbsStep_trans = 5e-4;
   double minAbsStep_rot = 1e-4;
-  bool generateDebugFiles = false;  // accepted, not honoured (no .icplog writer here): documented in INTEGRATION.md
+  // MP2P_ICP_GENERATE_DEBUG_FILES (lidar3d-default.yaml:177-182): every align() writes its per-iteration trace.  The
+  // upstream .icplog is an MRPT-serialised LogRecord and cannot be produced without MRPT; the file written here is
+  // JSON with the same content an icp-log-viewer session starts from: initial guess, per-iteration pose / pairings /
+  // thresholds, termination, final pose, quality.
+  bool generateDebugFiles = false;
+  std::string debugFileNameFormat = "icp-logs/icp-run-$UNIQUE_ID.icplog.json";  // $UNIQUE_ID = counter
   void load_from(const Config& c);
 };
 struct Results {

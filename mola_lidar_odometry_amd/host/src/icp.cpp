@@ -1,6 +1,11 @@
 // icp.cpp -- mp2p_icp_hip: the reference's plugin classes re-stated as thin drivers of the C ABI.
 // No arithmetic of the hot path happens here; see include/molahip.h for what each call replaces.
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 
@@ -252,6 +257,12 @@ void Parameters::load_from(const Config& c) {
   if (c.has("minAbsStep_trans")) minAbsStep_trans = strtod(c["minAbsStep_trans"].asString().c_str(), nullptr);
   if (c.has("minAbsStep_rot")) minAbsStep_rot = strtod(c["minAbsStep_rot"].asString().c_str(), nullptr);
   if (c.has("generateDebugFiles")) generateDebugFiles = to_bool(c["generateDebugFiles"].asString());
+  if (c.has("debugFileNameFormat")) {
+    debugFileNameFormat = c["debugFileNameFormat"].asString();
+    const std::string ext = ".icplog";  // the JSON trace must not masquerade as an MRPT-serialised .icplog
+    if (debugFileNameFormat.size() >= ext.size() && debugFileNameFormat.compare(debugFileNameFormat.size() - ext.size(), ext.size(), ext) == 0)
+      debugFileNameFormat += ".json";
+  }
 }
 
 // ================================================================== matcher
@@ -547,6 +558,47 @@ void ICP::align(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const
   }
 }
 
+// the per-align trace file of Parameters::generateDebugFiles (see the header)
+static void write_debug_file(const Parameters& p, const CPose3D& guess, const mh_icp_result& r, const std::vector<mh_icp_iter>& trace,
+                             size_t n_local) {
+  static std::atomic<uint64_t> counter{0};
+  std::string path = p.debugFileNameFormat;
+  const std::string id = std::to_string(counter++);
+  for (size_t pos; (pos = path.find("$UNIQUE_ID")) != std::string::npos;) path.replace(pos, 10, id);
+  for (const char* var : {"$LOCAL_ID", "$LOCAL_LABEL", "$GLOBAL_ID", "$GLOBAL_LABEL"})
+    for (size_t pos; (pos = path.find(var)) != std::string::npos;) path.erase(pos, strlen(var));
+  const size_t slash = path.find_last_of('/');
+  if (slash != std::string::npos) {
+    std::string dir;
+    for (size_t i = 0; i <= slash; i++) {  // mkdir -p
+      dir += path[i];
+      if (path[i] == '/') (void)mkdir(dir.c_str(), 0755);
+    }
+  }
+  FILE* f = fopen(path.c_str(), "w");
+  if (!f) throw std::runtime_error("generateDebugFiles: cannot write " + path);
+  auto pose = [&](const double* T) {
+    fprintf(f, "[");
+    for (int i = 0; i < 12; i++) fprintf(f, "%s%.17g", i ? ", " : "", T[i]);
+    fprintf(f, "]");
+  };
+  fprintf(f, "{\n \"format\": \"molahip-icplog-json-1\", \"n_local_points\": %zu, \"max_iterations\": %u,\n \"initial_guess\": ", n_local, p.maxIterations);
+  pose(guess.T);
+  fprintf(f, ",\n \"iterations\": [\n");
+  const uint32_t cnt = std::min<uint32_t>(p.maxIterations, r.n_iterations + 1);
+  for (uint32_t k = 0; k < cnt; k++) {
+    fprintf(f, "  {\"iteration\": %u, \"n_pairs\": %u, \"threshold\": %.17g, \"kernel_param\": %.17g, \"delta_trans\": %.17g, \"delta_rot\": %.17g, \"pose\": ",
+            k, trace[k].n_pairs, trace[k].threshold, trace[k].kernel_param, trace[k].delta_trans, trace[k].delta_rot);
+    pose(trace[k].T);
+    fprintf(f, "}%s\n", k + 1 < cnt ? "," : "");
+  }
+  fprintf(f, " ],\n \"n_iterations\": %u, \"termination\": \"%s\", \"quality\": %.17g, \"n_final_pairs\": %u,\n \"final_pose\": ",
+          r.n_iterations, enum2str((IterTermReason)r.termination_reason), r.quality, r.n_final_pairs);
+  pose(r.T);
+  fprintf(f, "\n}\n");
+  fclose(f);
+}
+
 void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_local, const HashedVoxelPointCloud& global,
                       const CPose3D& guess, const Parameters& p, Results& result,
                       const std::optional<CPose3DPDFGaussianInf>& prior) {
@@ -612,8 +664,10 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
   std::vector<uint32_t> li(want_pairs ? n : 0), gi(li.size());
   std::vector<float> gx(li.size()), gy(li.size()), gz(li.size()), d2(li.size());
   mh_pairs_out po{li.data(), gi.data(), gx.data(), gy.data(), gz.data(), d2.data()};
-  check(mh_icp_align(global.handle(), scan, &ip, guess.T, prior ? &pr : nullptr, &r, nullptr, want_pairs ? &po : nullptr,
-                     MH_MEM_HOST), "mh_icp_align");
+  std::vector<mh_icp_iter> trace(p.generateDebugFiles ? p.maxIterations : 0);
+  check(mh_icp_align(global.handle(), scan, &ip, guess.T, prior ? &pr : nullptr, &r, trace.empty() ? nullptr : trace.data(),
+                     want_pairs ? &po : nullptr, MH_MEM_HOST), "mh_icp_align");
+  if (p.generateDebugFiles) write_debug_file(p, guess, r, trace, n);
   memcpy(result.optimal_tf.mean.T, r.T, sizeof(r.T));
   memcpy(result.optimal_tf.cov, r.cov, sizeof(r.cov));
   result.quality = r.quality;

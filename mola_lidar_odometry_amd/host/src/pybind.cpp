@@ -73,7 +73,9 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
       .def(py::init<>())
       .def_readwrite("maxIterations", &Parameters::maxIterations)
       .def_readwrite("minAbsStep_trans", &Parameters::minAbsStep_trans)
-      .def_readwrite("minAbsStep_rot", &Parameters::minAbsStep_rot);
+      .def_readwrite("minAbsStep_rot", &Parameters::minAbsStep_rot)
+      .def_readwrite("generateDebugFiles", &Parameters::generateDebugFiles)
+      .def_readwrite("debugFileNameFormat", &Parameters::debugFileNameFormat);
   py::enum_<IterTermReason>(m, "IterTermReason")
       .value("Undefined", IterTermReason::Undefined).value("NoPairings", IterTermReason::NoPairings)
       .value("SolverError", IterTermReason::SolverError).value("MaxIterations", IterTermReason::MaxIterations)

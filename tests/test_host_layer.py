@@ -257,3 +257,35 @@ def test_compiled_formulas_equal_the_interpreter():
     for bad in ("max()", "foo(1)", "1 +", "nope + 1"):
         with pytest.raises(RuntimeError):
             H.evaluate_compiled(bad, v)
+
+
+@pytest.mark.gpu
+def test_generate_debug_files_writes_the_iteration_trace(hl, oracle, small_workload, tmp_path):
+    """MP2P_ICP_GENERATE_DEBUG_FILES (lidar3d-default.yaml:177-182): one trace file per align(); its content is the
+    oracle's per-iteration trajectory."""
+    import json
+    w = small_workload
+    icp, params = hl.icp_pipeline_from_yaml(hl.Config.FromYamlFile(OUR_YAML)["icp_settings_with_vel"])
+    src = hl.ParameterSource()
+    src.updateVariable("ADAPTIVE_THRESHOLD_SIGMA", w.sigma)
+    src.updateVariable("ICP_ITERATION", 0)
+    icp.attachToParameterSource(src)
+    src.realize()
+    params.generateDebugFiles = True
+    params.debugFileNameFormat = str(tmp_path / "logs" / "icp-run-$UNIQUE_ID-local_$LOCAL_ID$LOCAL_LABEL.icplog.json")
+    l, g, _ = _maps(hl, w)
+    res = icp.align(l, g, hl.TPose3D(*w.guess_ypr), params)
+    files = sorted(os.listdir(tmp_path / "logs"))
+    assert len(files) == 1 and files[0].endswith(".icplog.json") and "$" not in files[0]
+    log = json.load(open(tmp_path / "logs" / files[0]))
+    thr, kp = synth.threshold_schedule(w.sigma, 300)
+    o = oracle.icp_align(oracle.Map(w.voxel_size, w.cap).insert(w.map_xyz), w.scan_xyz, w.T_guess,
+                         oracle.ICPParams(max_iterations=300, threshold=thr, kernel_param=kp))
+    assert log["format"] == "molahip-icplog-json-1" and log["n_iterations"] == o["n_iterations"] == res.nIterations
+    assert log["termination"] == oracle.TERM_NAMES[o["termination_reason"]] and log["n_local_points"] == len(w.scan_xyz)
+    assert [it["n_pairs"] for it in log["iterations"]] == [t["n_pairs"] for t in o["trace"]]
+    np.testing.assert_allclose([it["pose"] for it in log["iterations"]], [t["T"] for t in o["trace"]], atol=1e-9)
+    np.testing.assert_allclose([it["threshold"] for it in log["iterations"]], thr[:len(log["iterations"])])
+    np.testing.assert_allclose(log["final_pose"], o["T"], atol=1e-9)
+    icp.align(l, g, hl.TPose3D(*w.guess_ypr), params)
+    assert len(os.listdir(tmp_path / "logs")) == 2
