@@ -87,11 +87,14 @@ def main(argv=None):
     a = ap.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    backend = os.environ.get("MH_DIST_BACKEND", "nccl")  # "gloo" in the CPU tests of the sharding logic
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch
         import torch.distributed as td
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        td.init_process_group("nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        td.init_process_group(backend)
     os.makedirs(a.out_dir, exist_ok=True)
 
     jobs = []  # (name, length, factory)
@@ -139,11 +142,11 @@ def main(argv=None):
         print(json.dumps(line), flush=True)
         total_scans += len(recs)
         total_time += secs
-    wall = mdist.max_over_ranks(total_time, device="cuda" if world > 1 else None)
+    wall = mdist.max_over_ranks(total_time, device=red_dev if world > 1 else None)
     if world > 1:
         import torch
         import torch.distributed as td
-        tot = torch.tensor([total_scans], dtype=torch.int64, device="cuda")
+        tot = torch.tensor([total_scans], dtype=torch.int64, device=red_dev)
         td.all_reduce(tot)
         total_scans = int(tot.item())
         td.destroy_process_group()

@@ -79,3 +79,60 @@ def test_gather_of_poses_world2_gloo():
     assert t0 == t1 == 2.0  # max over ranks (the bench's timing rule)
     assert sorted(mine0 + mine1) == list(range(11)) and not set(mine0) & set(mine1)
     assert e0 == e1 == [2, 0]
+
+
+def _runner_worker(rank, world, port, root, out_dir, q):
+    """run_odometry.main under a world-size-2 gloo group with the GPU part (run_sequence) replaced by a stub."""
+    import io
+    import json
+    from contextlib import redirect_stdout
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MH_DIST_BACKEND="gloo")
+    from mola_lidar_odometry_amd import run_odometry
+
+    def fake_run_sequence(pipeline, scans, out_tum=None, device=None):
+        scans = list(scans)
+        recs = [dict(timestamp=st, icp_good=True, map_updated=True, icp_iterations=3, n_for_icp=10, n_map_points=5) for st, _, _ in scans]
+        traj = [(st, np.eye(4)[:3].reshape(12).tolist()) for st, _, _ in scans]
+        open(out_tum, "w").write("".join("%f 0 0 0 0 0 0 1\n" % st for st, _, _ in scans))
+        return recs, traj, 0.001 * len(scans) * (rank + 1)
+
+    run_odometry.run_sequence = fake_run_sequence
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        run_odometry.main(["--kitti-root", root, "--seqs", "00", "01", "02", "--out-dir", out_dir])
+    q.put((rank, [json.loads(l) for l in buf.getvalue().strip().splitlines()]))
+
+
+def test_sequence_runner_shards_whole_sequences_world2_gloo(tmp_path):
+    """eval/cli_kitti.sh runs one sequence per worker; here: LPT assignment of whole sequences to ranks, one TUM per
+    sequence, the summary on rank 0 counts every scan once and takes the slowest rank's time."""
+    import torch.multiprocessing as mp
+    root = tmp_path / "kitti"
+    lengths = {"00": 5, "01": 2, "02": 4}
+    for seq, n in lengths.items():
+        d = root / "sequences" / seq / "velodyne"
+        d.mkdir(parents=True)
+        for k in range(n):
+            np.zeros((7, 4), np.float32).tofile(d / ("%06d.bin" % k))
+        np.savetxt(root / "sequences" / seq / "times.txt", 0.1 * np.arange(n))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_runner_worker, args=(r, 2, port, str(root), str(tmp_path / "out"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seqs = {r: sorted(l["sequence"] for l in lines if "sequence" in l) for r, lines in res.items()}
+    assert seqs == {0: ["00"], 1: ["01", "02"]}  # longest first: rank 0 gets 00 (5), rank 1 gets 02 (4) + 01 (2)
+    summary = [l for l in res[0] if l.get("summary")]
+    assert len(summary) == 1 and not any(l.get("summary") for l in res[1])
+    assert summary[0]["scans"] == 11 and summary[0]["n_gpus"] == 2 and abs(summary[0]["seconds"] - 0.012) < 1e-9
+    for seq, n in lengths.items():
+        assert len(open(tmp_path / "out" / (seq + ".tum")).read().splitlines()) == n
