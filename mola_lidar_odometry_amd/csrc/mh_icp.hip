@@ -46,6 +46,7 @@ struct IcpDeviceState {
   uint32_t n_pairs, n_iterations, solver_ok, n_solves;
   uint32_t cov_done, n_pairs_pl;
   float cur_thr2, cur_ang2;  // matcher threshold^2 of iteration `iter` and the angular term: k_match4 reads nothing but this block
+  double cur_kparam;         // robust-kernel parameter of iteration `iter` (no dependent table look-up in k_accum*)
   double cov[36];
   double covD[72];  // (T(x+h_j) - T(x-h_j)) / (2 h_j), j = 0..5, 3x4 each
 };
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restri
 #pragma unroll
   for (int i = 0; i < 12; i++) T[i] = st->T[i];
   const MatchK k = *kp;
-  const double kparam = k.use_fixed ? k.kparam_fixed : k.kparam[st->iter];
+  const double kparam = st->cur_kparam;
   // kAccPPT points per lane: the 18 wave reductions below are most of this kernel's instructions, so they are
   // amortised over four times as many points (the device is VALU-bound once several alignments run concurrently)
   const uint32_t bid = blockIdx.x;
@@ -738,6 +739,7 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, cons
   if (it + 1 < k.max_iterations) {
     const double thr = k.thr[it + 1];
     st->cur_thr2 = (float)(thr * thr);
+    st->cur_kparam = k.kparam[it + 1];
   }
   if (it + 1 >= k.max_iterations) {
     st->term_reason = MH_TERM_MAX_ITERATIONS;
@@ -778,7 +780,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* 
 #pragma unroll
     for (int i = 0; i < 12; i++) T[i] = st->T[i];
     const MatchK k = *kp;
-    const double kparam = k.use_fixed ? k.kparam_fixed : k.kparam[st->iter];
+    const double kparam = st->cur_kparam;
     Acc a;
     acc_zero(a);
     for (uint32_t base = 0; base < n; base += kSolveThreads * kOneGroupBatch) {
@@ -1279,6 +1281,7 @@ struct AlignJob {
     const double ang = p->threshold_angular_deg * 3.14159265358979323846 / 180.0;
     ctx->h_state->cur_thr2 = (float)(p->threshold[0] * p->threshold[0]);
     ctx->h_state->cur_ang2 = (float)(ang * ang);
+    ctx->h_state->cur_kparam = p->kernel_param[0];
     MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpDeviceState), hipMemcpyHostToDevice, s));
 
     mk.thr = ctx->sched.as<double>();
@@ -1810,6 +1813,7 @@ mh_status mh_gn_solve(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt2p
     hipLaunchKernelGGL(k_pack_pairs, dim3(nbp), dim3(kBlock), 0, s, L + 3 * sp, (uint32_t)np, (uint32_t)sp,
                        ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>());
   init_state(ctx->h_state, T_io);
+  ctx->h_state->cur_kparam = p->robust_kernel_param;  // solver-granular path: fixed robust-kernel parameter
   MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpDeviceState), hipMemcpyHostToDevice, s));
   MatchK mk{};
   mk.kernel = p->robust_kernel;
