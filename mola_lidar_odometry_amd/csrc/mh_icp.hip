@@ -493,14 +493,93 @@ __global__ __launch_bounds__(kBlock) void k_match_pl(const IcpDeviceState* __res
   if (FUSED) block_reduce_rows<kGenN>(v, lds, partials, pstride, blockIdx.x);
 }
 
-// inner Gauss-Newton steps >= 1 on the stored point-to-plane pairings
-__global__ __launch_bounds__(kBlock) void k_accum_plbuf(const IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
+// k_match_pl16: Matcher_Point2Plane with a DPP row (16 lanes) per point, for small layers.  k_match_pl walks the 27
+// voxels in three dependent groups of probes + centroid loads (57 us per launch on a 1 k-point layer); here lane r
+// probes codes r and r + 16, reads the two statistics records of its voxels, and the row takes the minimum of
+// (d2 to the centroid, code) -- code order IS the reference's scan order -- in two round trips.  Pairings only; the
+// point-to-plane rows are accumulated by k_accum_plbuf.
+__global__ __launch_bounds__(kBlock) void k_match_pl16(const IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
+                                                       const float* __restrict__ lx, const float* __restrict__ ly,
+                                                       const float* __restrict__ lz, uint32_t n, MapView map,
+                                                       float4* __restrict__ pl_c, float4* __restrict__ pl_n) {
+  if (st->done) return;
+  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = gl >> 4, r16 = gl & 15u;
+  if (i >= n) return;  // whole rows
+  double T[12];
+#pragma unroll
+  for (int q = 0; q < 12; q++) T[q] = st->T[q];
+  const float thr = (float)kp->pl_thr[st->iter];
+  float px, py, pz;
+  transform_point(T, lx[i], ly[i], lz[i], px, py, pz);
+  const float lim = 1.0e6f;
+  const bool valid = isfinite(px) && isfinite(py) && isfinite(pz) && fabsf(px * map.inv_vs) < lim &&
+                     fabsf(py * map.inv_vs) < lim && fabsf(pz * map.inv_vs) < lim;
+  nnkey_t best = kNNKeyNone;  // (d2 bits << 32 | code): first strict minimum in scan order
+  f32x4 ca = (f32x4)(0.f), na = (f32x4)(0.f), cb = (f32x4)(0.f), nb = (f32x4)(0.f);
+  if (valid) {  // row-uniform
+    const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(map.slots);
+    const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(map.pts);
+    const unsigned long long kbase = pack_key(voxel_of(px, map.inv_vs, map.trunc) - 1, voxel_of(py, map.inv_vs, map.trunc) - 1,
+                                              voxel_of(pz, map.inv_vs, map.trunc) - 1);
+    const int code_a = (int)r16, code_b = (int)r16 + 16;
+    const bool has_b = code_b < 27;
+    const unsigned long long ka = nn_key_of(kbase, code_a), kb = nn_key_of(kbase, has_b ? code_b : code_a);
+    const u32x4 sa = slots4[hash_key(ka) & map.mask];
+    const u32x4 sb = slots4[hash_key(kb) & map.mask];
+    uint32_t fa, cnt_a, fb, cnt_b;
+    nn_resolve(map, slots4, ka, sa, true, fa, cnt_a);
+    nn_resolve(map, slots4, kb, sb, has_b, fb, cnt_b);
+    const bool pa = cnt_a > 0 || fa >= 2u, pb = has_b && (cnt_b > 0 || fb >= 2u);  // a present voxel has first >= 2
+    // both statistics records of both voxels in one round trip (clamped, not predicated)
+    ca = pts4[pa ? fa - 2u : 0u];
+    na = pts4[pa ? fa - 1u : 0u];
+    cb = pts4[pb ? fb - 2u : 0u];
+    nb = pts4[pb ? fb - 1u : 0u];
+    if (pa && ca.w != 0.f) {
+      const float dx = ca.x - px, dy = ca.y - py, dz = ca.z - pz;
+      const nnkey_t kk = ((nnkey_t)__float_as_uint((dx * dx + dy * dy) + dz * dz) << 32) | (uint32_t)code_a;
+      best = kk < best ? kk : best;
+    }
+    if (pb && cb.w != 0.f) {
+      const float dx = cb.x - px, dy = cb.y - py, dz = cb.z - pz;
+      const nnkey_t kk = ((nnkey_t)__float_as_uint((dx * dx + dy * dy) + dz * dz) << 32) | (uint32_t)code_b;
+      best = kk < best ? kk : best;
+    }
+  }
+  best = row_min_key(best);
+  const uint32_t wcode = nnkey_idx(best);
+  f32x4 bc = (f32x4)(0.f), bn = (f32x4)(0.f);
+  bool ok = false;
+  if (wcode != 0xFFFFFFFFu) {  // row-uniform: the owner lane hands its records to the row
+    const bool from_b = wcode >= 16u;
+    const uint32_t owner = wcode & 15u;
+    const f32x4 mc = from_b ? cb : ca, mn = from_b ? nb : na;
+    bc.x = __uint_as_float(row_bcast_u32(__float_as_uint(mc.x), owner));
+    bc.y = __uint_as_float(row_bcast_u32(__float_as_uint(mc.y), owner));
+    bc.z = __uint_as_float(row_bcast_u32(__float_as_uint(mc.z), owner));
+    bn.x = __uint_as_float(row_bcast_u32(__float_as_uint(mn.x), owner));
+    bn.y = __uint_as_float(row_bcast_u32(__float_as_uint(mn.y), owner));
+    bn.z = __uint_as_float(row_bcast_u32(__float_as_uint(mn.z), owner));
+    const float dx = px - bc.x, dy = py - bc.y, dz = pz - bc.z;
+    const float e = (bn.x * dx + bn.y * dy) + bn.z * dz;
+    ok = fabsf(e) < thr;
+  }
+  if (r16 == 0) {
+    pl_c[i] = make_float4(bc.x, bc.y, bc.z, ok ? 1.f : 0.f);
+    pl_n[i] = make_float4(bn.x, bn.y, bn.z, 0.f);
+  }
+}
+
+// Gauss-Newton rows of the stored point-to-plane pairings (`first`: also when the iteration has just begun)
+__global__ __launch_bounds__(kBlock) void k_accum_plbuf(const IcpDeviceState* __restrict__ st, uint32_t first,
+                                                        const MatchK* __restrict__ kp,
                                                         const float* __restrict__ lx, const float* __restrict__ ly,
                                                         const float* __restrict__ lz, uint32_t n,
                                                         const float4* __restrict__ pl_c, const float4* __restrict__ pl_n,
                                                         double* __restrict__ partials, uint32_t pstride) {
   __shared__ double lds[kBlock / 64][kGenN];
-  if (st->done || st->inner == 0) return;
+  if (st->done || (!first && st->inner == 0)) return;
   const MatchK k = *kp;
   double T[12];
 #pragma unroll
@@ -1370,7 +1449,12 @@ struct AlignJob {
       double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
       const uint32_t nB = pl ? nb : 0u;
       for (uint32_t j = 0; j < m; j++) {
-        if (pl)
+        if (pl && variant == 5) {  // small layer: row kernel for the pairings, then their Gauss-Newton rows
+          hipLaunchKernelGGL(k_match_pl16, dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state, dmk,
+                             scan->x, scan->y, scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>());
+          hipLaunchKernelGGL(k_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+                             ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
+        } else if (pl)
           hipLaunchKernelGGL(k_match_pl<true>, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, dmk, scan->x, scan->y,
                              scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
         if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n], s));
@@ -1413,7 +1497,7 @@ struct AlignJob {
           hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
           if (pl)
-            hipLaunchKernelGGL(k_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dmk, scan->x, scan->y, scan->z, n,
+            hipLaunchKernelGGL(k_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
                                ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
           hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nba, nba,
                              (const double*)partb, nB, nB);

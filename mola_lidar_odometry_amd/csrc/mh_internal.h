@@ -179,6 +179,7 @@ mh_status stage_in(mh_ctx* ctx, DevBuf& buf, size_t offset_bytes, const void* sr
 // (re)size a scan's own storage for n points (+ optional t / src channels) and point x,y,z,t,src at it
 mh_status scan_alloc(mh_scan* s, size_t n, bool with_t, bool with_src);
 // map (re)build from device arrays; src_ids null = identity.  evict: 0 or {cx,cy,cz,dist_in_grid} voxel test.
+// n_stored: the first n_stored inputs are points the map already stores (accepted by the insertion rules before).
 mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc, size_t n,
-                           const int* evict);
+                           const int* evict, size_t n_stored);
 }  // namespace mh

@@ -84,6 +84,7 @@ __global__ void k_keep(const unsigned long long* __restrict__ ks, const uint32_t
 __global__ void k_keep_seq(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                            const unsigned long long* __restrict__ ks, const uint32_t* __restrict__ idx_s,
                            const uint32_t* __restrict__ head, uint32_t n, uint32_t cap, float min_dist,
+                           uint32_t n_stored /* inputs [0, n_stored) are the map's stored points: accepted already */,
                            uint32_t* __restrict__ keep) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -94,8 +95,9 @@ __global__ void k_keep_seq(const float* __restrict__ x, const float* __restrict_
   uint32_t kept = 0;
   for (uint32_t j = i; j < n && ks[j] == k; j++) {
     uint32_t ok = (cap == 0 || kept < cap) ? 1u : 0u;
-    if (ok) {
-      const uint32_t sj = idx_s[j];
+    const uint32_t sj0 = idx_s[j];
+    if (ok && sj0 >= n_stored) {  // (stored points passed this test when they were inserted; they sort first in the run)
+      const uint32_t sj = sj0;
       const float px = x[sj], py = y[sj], pz = z[sj];
       for (uint32_t q = i; q < j && ok; q++)
         if (keep[q]) {
@@ -364,7 +366,7 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
     dy = (const float*)(ctx->staging.as<char>() + stride);
     dz = (const float*)(ctx->staging.as<char>() + 2 * stride);
   }
-  MH_TRY(map_build_device(m, dx, dy, dz, nullptr, n, nullptr));
+  MH_TRY(map_build_device(m, dx, dy, dz, nullptr, n, nullptr, 0));
   m->n_offered = n;
   return MH_OK;
 }
@@ -406,7 +408,7 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
     }
     evict[3] = (int)ceilf(remove_voxels_farther_than * m->inv_vs);
   }
-  MH_TRY(map_build_device(m, mx, my, mz, msrc, total, evict));
+  MH_TRY(map_build_device(m, mx, my, mz, msrc, total, evict, n_old));
   m->n_offered += n_new;
   return MH_OK;
 }
@@ -416,7 +418,7 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
 namespace mh {
 
 mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc, size_t n,
-                           const int* evict) {
+                           const int* evict, size_t n_stored) {
   mh_ctx* ctx = m->ctx;
   hipStream_t s = ctx->stream;
   uint32_t n_vox = 0, n_pts = 0, n_rec = 0;
@@ -465,7 +467,7 @@ mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const fl
     const uint32_t ndt = m->params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
     if (m->params.min_distance_between_points > 0.f)
       hipLaunchKernelGGL(k_keep_seq, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, keys_s, idx_s, head, N,
-                         m->params.max_points_per_voxel, m->params.min_distance_between_points, keep);
+                         m->params.max_points_per_voxel, m->params.min_distance_between_points, (uint32_t)n_stored, keep);
     else
       hipLaunchKernelGGL(k_keep, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, vid1, vstart, N, m->params.max_points_per_voxel,
                          keep);
