@@ -1198,13 +1198,28 @@ namespace {
 
 inline uint32_t nblk(size_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
+// One device block [state | parameters] with a pinned mirror of the same layout: an alignment starts with ONE upload.
+constexpr size_t kParamsOffset = (sizeof(IcpDeviceState) + 255) / 256 * 256;
+
 mh_status ensure_state(mh_ctx* ctx) {
   if (!ctx->d_state) {
-    MH_HIP(hipMalloc((void**)&ctx->d_state, sizeof(IcpDeviceState)));
-    MH_HIP(hipHostMalloc((void**)&ctx->h_state, sizeof(IcpDeviceState), hipHostMallocDefault));
-    MH_HIP(hipMalloc((void**)&ctx->d_params, sizeof(IcpDeviceParams)));
-    MH_HIP(hipHostMalloc((void**)&ctx->h_params, sizeof(IcpDeviceParams), hipHostMallocDefault));
+    char *d = nullptr, *h = nullptr;
+    MH_HIP(hipMalloc((void**)&d, kParamsOffset + sizeof(IcpDeviceParams)));
+    MH_HIP(hipHostMalloc((void**)&h, kParamsOffset + sizeof(IcpDeviceParams), hipHostMallocDefault));
+    ctx->d_state = (IcpDeviceState*)d;
+    ctx->h_state = (IcpDeviceState*)h;
+    ctx->d_params = (IcpDeviceParams*)(d + kParamsOffset);
+    ctx->h_params = (IcpDeviceParams*)(h + kParamsOffset);
   }
+  return MH_OK;
+}
+
+// state + parameters in one copy (start of mh_icp_align)
+mh_status upload_state_and_params(mh_ctx* ctx, const MatchK& mk, const SolveK& sk) {
+  ctx->h_params->mk = mk;
+  ctx->h_params->sk = sk;
+  MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, kParamsOffset + sizeof(IcpDeviceParams), hipMemcpyHostToDevice,
+                        ctx->stream));
   return MH_OK;
 }
 
@@ -1350,18 +1365,27 @@ struct AlignJob {
       MH_TRY(ensure_pl_buffers(ctx, scan->n));
     }
     MH_TRY(ctx->sched.reserve(3 * mi * sizeof(double)));
-    MH_HIP(hipMemcpyAsync(ctx->sched.p, p->threshold, mi * sizeof(double), hipMemcpyHostToDevice, s));
-    MH_HIP(hipMemcpyAsync(ctx->sched.as<double>() + mi, p->kernel_param, mi * sizeof(double), hipMemcpyHostToDevice, s));
-    if (pl)
-      MH_HIP(hipMemcpyAsync(ctx->sched.as<double>() + 2 * mi, p->pt2pl_threshold, mi * sizeof(double), hipMemcpyHostToDevice, s));
+    {  // threshold | kernel_param | pt2pl_threshold schedules: packed in a pinned staging block, one upload
+      const size_t nsched = (pl ? 3 : 2) * mi;
+      if (ctx->h_sched_cap < nsched) {
+        if (ctx->h_sched) (void)hipHostFree(ctx->h_sched);
+        ctx->h_sched = nullptr;
+        ctx->h_sched_cap = 0;
+        MH_HIP(hipHostMalloc((void**)&ctx->h_sched, 3 * mi * sizeof(double), hipHostMallocDefault));
+        ctx->h_sched_cap = 3 * mi;
+      }
+      memcpy(ctx->h_sched, p->threshold, mi * sizeof(double));
+      memcpy(ctx->h_sched + mi, p->kernel_param, mi * sizeof(double));
+      if (pl) memcpy(ctx->h_sched + 2 * mi, p->pt2pl_threshold, mi * sizeof(double));
+      MH_HIP(hipMemcpyAsync(ctx->sched.p, ctx->h_sched, nsched * sizeof(double), hipMemcpyHostToDevice, s));
+    }
     if (trace) MH_TRY(ctx->trace.reserve(mi * sizeof(mh_icp_iter)));
     ctx->align_serial++;
     init_state(ctx->h_state, T0);
     const double ang = p->threshold_angular_deg * 3.14159265358979323846 / 180.0;
     ctx->h_state->cur_thr2 = (float)(p->threshold[0] * p->threshold[0]);
     ctx->h_state->cur_ang2 = (float)(ang * ang);
-    ctx->h_state->cur_kparam = p->kernel_param[0];
-    MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpDeviceState), hipMemcpyHostToDevice, s));
+    ctx->h_state->cur_kparam = p->kernel_param[0];  // uploaded together with the parameters below
 
     mk.thr = ctx->sched.as<double>();
     mk.kparam = ctx->sched.as<double>() + mi;
@@ -1394,7 +1418,7 @@ struct AlignJob {
     sk.gn_trace = nullptr;
     sk.cov_hx = p->cov_findif_xyz;
     sk.cov_ha = p->cov_findif_ang;
-    MH_TRY(upload_params(ctx, mk, sk));
+    MH_TRY(upload_state_and_params(ctx, mk, sk));
     nb = nblk(scan->n);
     {  // MH_MATCH selects the correspondence kernel of the fused loop (all exact, bit-identical pairings):
        //   "q" (default)  a DPP quad per scan point, merged candidate scans          -> k_match4 + k_accum

@@ -115,13 +115,15 @@ struct mh_ctx {
   mh::DevBuf partials;    // per-block reduction partials (double)
   mh::DevBuf partials_b;  // generic (pt2pl) partials
   mh::DevBuf sched;       // threshold / kernel-param arrays (double)
+  double* h_sched = nullptr;  // pinned staging for them
+  size_t h_sched_cap = 0;
   mh::DevBuf trace;       // mh_icp_iter[max_iterations]
   mh::DevBuf compact;     // compaction scratch (block counts / offsets) and staged outputs
   mh::DevBuf staging;     // generic staging for host<->device array transfers
   mh::DevBuf sort_tmp;    // rocprim temporary storage
   mh::DevBuf build_a, build_b, build_c, build_d, build_e;  // map build scratch
   IcpDeviceState* d_state = nullptr;
-  IcpDeviceState* h_state = nullptr;  // pinned mirror
+  IcpDeviceState* h_state = nullptr;  // pinned mirror; d_state/h_state own one block [state | params]
   IcpDeviceParams* d_params = nullptr;  // per-alignment parameters (kernels take pointers into this block)
   IcpDeviceParams* h_params = nullptr;  // pinned mirror
   hipGraphExec_t graph_exec = nullptr;  // captured chunk of ICP iterations (replayed while graph_key matches)

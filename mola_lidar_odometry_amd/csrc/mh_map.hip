@@ -417,6 +417,13 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
 
 namespace mh {
 
+// voxel and record totals (last elements of the two scans) next to the other counters
+__global__ void k_sizes(const uint32_t* __restrict__ vid1, const uint32_t* __restrict__ outpos,
+                        const uint32_t* __restrict__ keep, uint32_t n, uint32_t* __restrict__ out) {
+  out[0] = vid1[n - 1];
+  out[1] = outpos[n - 1] + keep[n - 1];
+}
+
 mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc, size_t n,
                            const int* evict, size_t n_stored) {
   mh_ctx* ctx = m->ctx;
@@ -475,17 +482,14 @@ mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const fl
     tb = ctx->sort_tmp.bytes;
     MH_HIP(rocprim::exclusive_scan(ctx->sort_tmp.p, tb, keep, outpos, 0u, N, rocprim::plus<uint32_t>(), s));
     // sizes back to the host
-    uint32_t h_last[3] = {0, 0, 0};
-    MH_HIP(hipMemcpyAsync(&h_last[0], vid1 + (n - 1), 4, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipMemcpyAsync(&h_last[1], outpos + (n - 1), 4, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipMemcpyAsync(&h_last[2], keep + (n - 1), 4, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipMemcpyAsync(h_counters, counters, 8, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_sizes, dim3(1), dim3(1), 0, s, vid1, outpos, keep, N, counters + 9);
+    MH_HIP(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, s));  // one read-back
     MH_HIP(hipStreamSynchronize(s));
     if (h_counters[0] & 1u)
       return fail(MH_ERR_OUT_OF_RANGE, "a point's voxel index exceeds the +-2^20 range of the packed key "
                                        "(|coord|/voxel_size must be < 1e6)");
-    n_vox = h_last[0];
-    n_rec = h_last[1] + h_last[2];
+    n_vox = h_counters[9];
+    n_rec = h_counters[10];
     n_pts = n_rec - (ndt ? 2u * n_vox : 0u);
 
     MH_TRY(m->pts.reserve((size_t)(n_rec ? n_rec : 1) * sizeof(float4)));

@@ -101,11 +101,11 @@ __global__ void k_pp_insert(const float* __restrict__ x, const float* __restrict
 __global__ void k_pp_flag(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                           uint32_t n, StageParams sp, const unsigned long long* __restrict__ keys,
                           const uint32_t* __restrict__ first_idx, uint32_t mask, uint32_t* __restrict__ counters,
-                          uint32_t* __restrict__ flag) {
+                          uint32_t* __restrict__ flag, uint32_t count_slot) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float px = x[i], py = y[i], pz = z[i];
-  bool keep = isfinite(px) && isfinite(py) && isfinite(pz);
+  const bool valid = i < n;
+  const float px = valid ? x[i] : 0.f, py = valid ? y[i] : 0.f, pz = valid ? z[i] : 0.f;
+  bool keep = valid && isfinite(px) && isfinite(py) && isfinite(pz);
   if (keep && sp.decimate) {
     unsigned long long key;
     keep = pp_key(px, py, pz, sp.inv_res, sp.trunc, key, counters);
@@ -125,7 +125,9 @@ __global__ void k_pp_flag(const float* __restrict__ x, const float* __restrict__
                         pz >= sp.bmin[2] && pz <= sp.bmax[2];
     keep = inside == (sp.bbox_mode == MH_BBOX_KEEP_INSIDE);
   }
-  flag[i] = keep ? 1u : 0u;
+  if (valid) flag[i] = keep ? 1u : 0u;
+  const unsigned long long kept = __ballot(keep);  // survivor count: one atomic per wavefront
+  if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&counters[count_slot], (uint32_t)__popcll(kept));
 }
 
 __global__ void k_pp_compact(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
@@ -200,11 +202,15 @@ __global__ __launch_bounds__(256) void k_pp_bbox(const float* __restrict__ x, co
 struct Twist { double v[6]; };
 
 __global__ void k_pp_deskew(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                            const float* __restrict__ t, uint32_t n, Twist tw, float* __restrict__ ox,
-                            float* __restrict__ oy, float* __restrict__ oz) {
+                            const float* __restrict__ t, const uint32_t* __restrict__ src, uint32_t n, Twist tw,
+                            float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
+                            float* __restrict__ ot, uint32_t* __restrict__ osrc) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double dt = (double)t[i];
+  const float tf = t[i];
+  ot[i] = tf;
+  if (src) osrc[i] = src[i];
+  const double dt = (double)tf;
   const double xi[6] = {0.0, 0.0, 0.0, tw.v[3] * dt, tw.v[4] * dt, tw.v[5] * dt};
   Pose p = se3_exp(xi);  // zero translation part: pure Exp_SO3(w dt)
   p.t(0) = tw.v[0] * dt;
@@ -220,8 +226,8 @@ __global__ void k_pp_deskew(const float* __restrict__ x, const float* __restrict
 inline uint32_t nblk(size_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
 
 // One stage: [decimate] + predicates over `in` -> `out` (compacted, order preserving).  Returns the survivor count.
-mh_status run_stage(mh_ctx* ctx, const mh_scan* in, const StageParams& sp, uint32_t* counters, mh_scan* out,
-                    bool want_t) {
+mh_status run_stage(mh_ctx* ctx, const mh_scan* in, const StageParams& sp, uint32_t* counters, uint32_t count_slot,
+                    mh_scan* out, bool want_t) {
   hipStream_t s = ctx->stream;
   const uint32_t N = (uint32_t)in->n;
   const uint32_t B = 256;
@@ -245,17 +251,15 @@ mh_status run_stage(mh_ctx* ctx, const mh_scan* in, const StageParams& sp, uint3
                        first_idx, mask, counters);
   }
   hipLaunchKernelGGL(k_pp_flag, dim3(nblk(N, B)), dim3(B), 0, s, in->x, in->y, in->z, N, sp, keys, first_idx, mask,
-                     counters, flag);
+                     counters, flag, count_slot);
   size_t tb = ctx->sort_tmp.bytes;
   MH_HIP(rocprim::exclusive_scan(ctx->sort_tmp.p, tb, flag, pos, 0u, N, rocprim::plus<uint32_t>(), s));
-  uint32_t h_last[2] = {0, 0}, h_flags = 0;
-  MH_HIP(hipMemcpyAsync(&h_last[0], pos + (N - 1), 4, hipMemcpyDeviceToHost, s));
-  MH_HIP(hipMemcpyAsync(&h_last[1], flag + (N - 1), 4, hipMemcpyDeviceToHost, s));
-  MH_HIP(hipMemcpyAsync(&h_flags, counters + 2, 4, hipMemcpyDeviceToHost, s));
+  uint32_t h[3] = {0, 0, 0};  // range flag, stage-1 count, stage-2 count: one read-back per stage
+  MH_HIP(hipMemcpyAsync(h, counters + 2, sizeof(h), hipMemcpyDeviceToHost, s));
   MH_HIP(hipStreamSynchronize(s));
-  if (h_flags & 1u)
+  if (h[0] & 1u)
     return fail(MH_ERR_OUT_OF_RANGE, "a point's decimation voxel index exceeds the +-2^20 range of the packed key");
-  const uint32_t M = h_last[0] + h_last[1];
+  const uint32_t M = h[count_slot - 2];
   MH_TRY(scan_alloc(out, M, want_t, true));
   if (M)
     hipLaunchKernelGGL(k_pp_compact, dim3(nblk(N, B)), dim3(B), 0, s, in->x, in->y, in->z, want_t ? in->t : nullptr,
@@ -306,9 +310,9 @@ mh_status mh_scan_preprocess(const mh_scan* raw, const mh_preprocess_params* p, 
   const bool has_t = raw->t != nullptr;
 
   MH_TRY(ctx->build_c.reserve(2 * (n ? n : 1) * sizeof(uint32_t)));  // flag | pos
-  MH_TRY(ctx->build_e.reserve(64));                                   // counters: tmin, tmax, range flag
+  MH_TRY(ctx->build_e.reserve(64));  // counters: tmin, tmax, range flag, survivors of stage 1, of stage 2
   uint32_t* counters = ctx->build_e.as<uint32_t>();
-  const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+  const uint32_t init[5] = {0xFFFFFFFFu, 0u, 0u, 0u, 0u};
   MH_HIP(hipMemcpyAsync(counters, init, sizeof(init), hipMemcpyHostToDevice, s));
   if (n) {
     size_t tmp = 0;
@@ -330,7 +334,7 @@ mh_status mh_scan_preprocess(const mh_scan* raw, const mh_preprocess_params* p, 
   for (int a = 0; a < 3; a++) { s1.bmin[a] = p->bbox_min[a]; s1.bmax[a] = p->bbox_max[a]; }
   s1.ts_method = has_t ? p->timestamp_method : MH_TS_NONE;
   s1.ts_offset = p->time_offset;
-  MH_TRY(run_stage(ctx, raw, s1, counters, out_map, has_t));
+  MH_TRY(run_stage(ctx, raw, s1, counters, 3, out_map, has_t));
 
   if (out_icp) {
     StageParams s2{};
@@ -338,7 +342,7 @@ mh_status mh_scan_preprocess(const mh_scan* raw, const mh_preprocess_params* p, 
     s2.trunc = s1.trunc;
     s2.decimate = (p->decim_icp_resolution > 0.f && out_map->n >= p->min_points_to_filter) ? 1u : 0u;
     s2.ts_method = MH_TS_NONE;  // out_map's stamps are adjusted already
-    MH_TRY(run_stage(ctx, out_map, s2, counters, out_icp, has_t));
+    MH_TRY(run_stage(ctx, out_map, s2, counters, 4, out_icp, has_t));
   }
   return MH_OK;
 }
@@ -353,18 +357,18 @@ mh_status mh_scan_deskew(const mh_scan* in, const double twist[6], mh_scan* out)
   const size_t n = in->n;
   MH_TRY(scan_alloc(out, n, in->t != nullptr, in->src != nullptr));
   if (!n) return MH_OK;
-  if (in->t) MH_HIP(hipMemcpyAsync((void*)out->t, in->t, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-  if (in->src) MH_HIP(hipMemcpyAsync((void*)out->src, in->src, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
   if (twist && in->t) {
     Twist tw;
     for (int i = 0; i < 6; i++) {
       MH_REQUIRE(isfinite(twist[i]), "non-finite twist");
       tw.v[i] = twist[i];
     }
-    hipLaunchKernelGGL(k_pp_deskew, dim3(nblk(n, 256)), dim3(256), 0, s, in->x, in->y, in->z, in->t, (uint32_t)n, tw,
-                       (float*)out->x, (float*)out->y, (float*)out->z);
+    hipLaunchKernelGGL(k_pp_deskew, dim3(nblk(n, 256)), dim3(256), 0, s, in->x, in->y, in->z, in->t, in->src,
+                       (uint32_t)n, tw, (float*)out->x, (float*)out->y, (float*)out->z, (float*)out->t, (uint32_t*)out->src);
     MH_HIP(hipGetLastError());
   } else {  // skip_deskew / silently_ignore_no_timestamps
+    if (in->t) MH_HIP(hipMemcpyAsync((void*)out->t, in->t, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (in->src) MH_HIP(hipMemcpyAsync((void*)out->src, in->src, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     MH_HIP(hipMemcpyAsync((void*)out->x, in->x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     MH_HIP(hipMemcpyAsync((void*)out->y, in->y, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     MH_HIP(hipMemcpyAsync((void*)out->z, in->z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
