@@ -165,6 +165,17 @@ __global__ __launch_bounds__(kBlock, MH_MATCH_WAVES) void k_match(const IcpDevic
 
 
 #ifdef MH_DEBUG_WAVETRACE
+// debug build only: wall_clock64 (100 MHz) at numbered points of the one-workgroup kernels, last launch wins
+__device__ unsigned long long g_phase[16];
+#define MH_PHASE(i) do { if (threadIdx.x == 0) g_phase[i] = wall_clock64(); } while (0)
+extern "C" __attribute__((visibility("default"))) int mh_debug_phases(unsigned long long* host_out) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase), sizeof(g_phase)) == hipSuccess ? 0 : 2;
+}
+#else
+#define MH_PHASE(i) do { } while (0)
+#endif
+#ifdef MH_DEBUG_WAVETRACE
 static unsigned long long* g_wtrace = nullptr;  // debug build only: [2 * n_waves] begin/end wall_clock64 of the last launch
 extern "C" __attribute__((visibility("default"))) int mh_debug_wavetrace(unsigned long long* host_out, size_t n_waves) {
   if (!g_wtrace) { if (hipMalloc(&g_wtrace, 16u << 20) != hipSuccess) return 1; (void)hipMemset(g_wtrace, 0, 16u << 20); return 0; }
@@ -645,7 +656,7 @@ struct SolveShared {
 __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
                                            const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                            const double* __restrict__ partB, uint32_t nB, uint32_t strideB,
-                                           SolveShared& sh) {
+                                           SolveShared& sh, bool totA_ready = false) {
   double (*red)[64] = sh.red;
   double* totA = sh.totA;
   double* totB = sh.totB;
@@ -658,7 +669,7 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, cons
     reduce_rows(partB, nB, strideB, kGenN, totB, red);
   double a[kAccN], gen[kGenN];
 #pragma unroll
-  for (int i = 0; i < kAccN; i++) a[i] = nA ? totA[i] : 0.0;
+  for (int i = 0; i < kAccN; i++) a[i] = (nA || totA_ready) ? totA[i] : 0.0;
 #pragma unroll
   for (int i = 0; i < kGenN; i++) gen[i] = nB ? totB[i] : 0.0;
   Pose Tc;
@@ -685,9 +696,15 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, cons
     __syncthreads();
   }
   if (lane != 0) return;
+  MH_PHASE(4);
 
   const uint32_t inner = st->inner;
   const uint32_t it = st->iter;
+  double thr_next = 0.0, kparam_next = 0.0;  // fetched now, needed at the very end: two dependent loads off the tail
+  if (it + 1 < k.max_iterations) {
+    thr_next = k.thr[it + 1];
+    kparam_next = k.kparam[it + 1];
+  }
   const uint32_t n_pairs = (uint32_t)(a[17] + gen[28] + 0.5);
   if (inner == 0) {
     st->n_pairs = n_pairs;
@@ -747,6 +764,7 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, cons
     for (int i = 0; i < 12; i++) gt->T_after[i] = Tc.m[i];
   }
   bool inner_done = false;
+  MH_PHASE(5);
   if (sqrt(cost) <= k.max_cost) {
     inner_done = true;  // "target error" early exit, no solve (App.B U8)
   } else {
@@ -760,8 +778,10 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, cons
     }
     double dn = 0.0;
     for (int i = 0; i < 6; i++) { delta[i] = -x[i]; dn += x[i] * x[i]; }
+    MH_PHASE(6);
     Tc = compose(Tc, se3_exp(delta));  // T <- T (+) exp(delta)
     for (int i = 0; i < 12; i++) st->T[i] = Tc.m[i];
+    MH_PHASE(7);
     st->n_solves += 1;
     if (gt) {
       for (int i = 0; i < 6; i++) gt->delta[i] = delta[i];
@@ -776,10 +796,12 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, cons
   }
   // ---- end of ICP iteration `it` (tail of the loop body of ICP::align) ----
   st->inner = 0;
+  MH_PHASE(8);
   Pose Tp;
   for (int i = 0; i < 12; i++) Tp.m[i] = st->T_prev[i];
   double d[6];
   se3_log(compose(inverse(Tp), Tc), d);
+  MH_PHASE(9);
   const double dtr = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   const double drot = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
   if (k.trace) {
@@ -816,15 +838,15 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, cons
   for (int i = 0; i < 12; i++) st->T_prev[i] = Tc.m[i];
   st->iter = it + 1;
   if (it + 1 < k.max_iterations) {
-    const double thr = k.thr[it + 1];
-    st->cur_thr2 = (float)(thr * thr);
-    st->cur_kparam = k.kparam[it + 1];
+    st->cur_thr2 = (float)(thr_next * thr_next);
+    st->cur_kparam = kparam_next;
   }
   if (it + 1 >= k.max_iterations) {
     st->term_reason = MH_TERM_MAX_ITERATIONS;
     st->n_iterations = it + 1;
     st->done = 1;
   }
+  MH_PHASE(10);
 }
 
 __global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
@@ -842,59 +864,92 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restr
 // becomes match | accumulate+solve | accumulate+solve -- three launches instead of five.
 // ================================================================================================
 constexpr uint32_t kOneGroupMaxPoints = 2048;  // measured: 1 k points -8 %, 2 k -4 %, 4 k +7 % per alignment vs k_accum + k_solve
-constexpr int kOneGroupBatch = 4;  // points per lane and round of loads
+constexpr int kOneGroupBatch = 4;        // points per lane and round of loads
+constexpr int kOneGroupAccThreads = 256;  // lanes that accumulate (one wave per SIMD: the same VALU time as 512, half the reduction)
+constexpr int kOneGroupChunk = 17;        // lanes summed by one thread of the first reduction stage (odd: conflict-free LDS reads)
+constexpr int kOneGroupGroups = (kOneGroupAccThreads + kOneGroupChunk - 1) / kOneGroupChunk;  // 16
 
+// Phase times of the first version (wall_clock64 stamps, 900 points): loads+accumulate 1.8 us, 18 wave_sum 2.3 us
+// (8 waves x 414 DPP/readlane/add instructions: issue bound), partials through global memory + reduce_rows 0.9 us,
+// LDLT 2.5 us, exp 0.5 us, log + tail 1.9 us.  Hence: the per-lane sums go through LDS transposed (each lane writes its
+// 18 values, 288 threads add 17 lanes each, 18 threads add the 16 group sums: fixed order, ~60 instructions per wave)
+// and land in the solve's shared totals directly; the point loads are issued before the state is even looked at.
 __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* __restrict__ st, uint32_t first,
                                                                 const MatchK* __restrict__ kp, const SolveK* __restrict__ sk,
                                                                 const float* __restrict__ lx, const float* __restrict__ ly,
                                                                 const float* __restrict__ lz, uint32_t n,
                                                                 const float4* __restrict__ pair_q,
-                                                                const uint32_t* __restrict__ pair_gidx, double* partials) {
+                                                                const uint32_t* __restrict__ pair_gidx) {
   __shared__ SolveShared sh;
-  __shared__ double lds[kSolveThreads / 64][kAccN];
-  if (st->done) return;
-  if (!first && st->inner == 0) return;  // the previous solve already closed this ICP iteration
-  {
-    double T[12];
+  __shared__ double tr[kAccN][kOneGroupAccThreads + 1];
+  __shared__ double p1[kAccN][kOneGroupGroups];
+  MH_PHASE(0);
+  const bool acc_lane = threadIdx.x < kOneGroupAccThreads;
+  uint32_t gi[kOneGroupBatch];
+  float4 q[kOneGroupBatch];
+  float px[kOneGroupBatch], py[kOneGroupBatch], pz[kOneGroupBatch];
+  if (acc_lane) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) T[i] = st->T[i];
-    const MatchK k = *kp;
-    const double kparam = st->cur_kparam;
+    for (int u = 0; u < kOneGroupBatch; u++) {  // first round of loads: nothing here depends on the state block
+      const uint32_t i = (uint32_t)u * kOneGroupAccThreads + threadIdx.x;
+      const uint32_t ic = i < n ? i : n - 1;
+      gi[u] = i < n ? pair_gidx[ic] : kNoMatch;
+      q[u] = pair_q[ic];
+      px[u] = lx[ic]; py[u] = ly[ic]; pz[u] = lz[ic];
+    }
+  }
+  // ... and neither do the pose and the parameters wait for the done flag: everything is in flight at once
+  double T[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) T[i] = st->T[i];
+  const MatchK k = *kp;
+  const double kparam = st->cur_kparam;
+  const uint32_t done = st->done, inner0 = st->inner;
+  if (done) return;
+  if (!first && inner0 == 0) return;  // the previous solve already closed this ICP iteration
+  if (acc_lane) {
     Acc a;
     acc_zero(a);
-    for (uint32_t base = 0; base < n; base += kSolveThreads * kOneGroupBatch) {
-      uint32_t gi[kOneGroupBatch];
-      float4 q[kOneGroupBatch];
-      float px[kOneGroupBatch], py[kOneGroupBatch], pz[kOneGroupBatch];
+    for (uint32_t base = 0;;) {
 #pragma unroll
-      for (int u = 0; u < kOneGroupBatch; u++) {  // all loads first (clamped index), then the arithmetic
-        const uint32_t i = base + (uint32_t)u * kSolveThreads + threadIdx.x;
+      for (int u = 0; u < kOneGroupBatch; u++)
+        if (gi[u] != kNoMatch) acc_pt2pt(a, T, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
+      base += kOneGroupAccThreads * kOneGroupBatch;
+      if (base >= n) break;
+#pragma unroll
+      for (int u = 0; u < kOneGroupBatch; u++) {
+        const uint32_t i = base + (uint32_t)u * kOneGroupAccThreads + threadIdx.x;
         const uint32_t ic = i < n ? i : n - 1;
         gi[u] = i < n ? pair_gidx[ic] : kNoMatch;
         q[u] = pair_q[ic];
         px[u] = lx[ic]; py[u] = ly[ic]; pz[u] = lz[ic];
       }
-#pragma unroll
-      for (int u = 0; u < kOneGroupBatch; u++)
-        if (gi[u] != kNoMatch) acc_pt2pt(a, T, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    MH_PHASE(1);
 #pragma unroll
-    for (int j = 0; j < kAccN; j++) {
-      const double s = wave_sum(a.v[j]);
-      if (lane == 0) lds[wave][j] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < kAccN) {
-      double sum = lds[0][threadIdx.x];
-#pragma unroll
-      for (int w = 1; w < (int)(kSolveThreads / 64); w++) sum += lds[w][threadIdx.x];  // fixed order
-      partials[threadIdx.x] = sum;  // one "workgroup partial" per row: the solve below reads it back (same CU)
-    }
-    __threadfence_block();
-    __syncthreads();
+    for (int j = 0; j < kAccN; j++) tr[j][threadIdx.x] = a.v[j];
   }
-  solve_body(st, sk, partials, 1u, 1u, nullptr, 0u, 0u, sh);
+  __syncthreads();
+  if (threadIdx.x < kAccN * kOneGroupGroups) {  // stage 1: row j, lanes [17 g, 17 g + 17)
+    const int j = threadIdx.x / kOneGroupGroups, g = threadIdx.x % kOneGroupGroups;
+    const int l0 = g * kOneGroupChunk;
+    double sum = tr[j][l0];
+#pragma unroll
+    for (int i = 1; i < kOneGroupChunk; i++)
+      if (l0 + i < kOneGroupAccThreads) sum += tr[j][l0 + i];
+    p1[j][g] = sum;
+  }
+  __syncthreads();
+  MH_PHASE(2);
+  if (threadIdx.x < kAccN) {  // stage 2: the group sums in order
+    double sum = p1[threadIdx.x][0];
+#pragma unroll
+    for (int g = 1; g < kOneGroupGroups; g++) sum += p1[threadIdx.x][g];
+    sh.totA[threadIdx.x] = sum;
+  }
+  __syncthreads();
+  MH_PHASE(3);
+  solve_body(st, sk, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true);
 }
 
 // ================================================================================================
@@ -1490,7 +1545,7 @@ struct AlignJob {
             if (prof) prof_n++;
             for (uint32_t in = 0; in < p->gn.max_inner_iterations; in++)
               hipLaunchKernelGGL(k_accum_solve1, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, in == 0 ? 1u : 0u, dmk, dsk,
-                                 scan->x, scan->y, scan->z, n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part);
+                                 scan->x, scan->y, scan->z, n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>());
             continue;
           }
           hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,

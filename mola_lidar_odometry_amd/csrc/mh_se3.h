@@ -162,8 +162,9 @@ MH_HD int sym6(int i, int j) {
 
 // x = H^-1 b by LDL^T with diagonal pivoting (what Eigen's ldlt() does for the reference's
 // optimal_tf_gauss_newton); zero pivots give a zero component.  Returns false on non-finite results.
-// Written with compile-time indices only (the pivot swaps are predicated selects) so that on the
-// device the whole 6x6 stays in registers -- a runtime-indexed array would live in scratch memory.
+// Written with compile-time indices only so that on the device the whole 6x6 stays in registers -- a runtime-indexed
+// array would live in scratch memory.  The pivot swaps are branches around compile-time-indexed swaps (one thread runs
+// this: as predicated selects the 15 candidate swaps cost ~800 instructions, a third of the solve's time).
 MH_HD void cswap(bool c, double& a, double& b) {
   const double ta = c ? b : a, tb = c ? a : b;
   a = ta;
@@ -171,7 +172,7 @@ MH_HD void cswap(bool c, double& a, double& b) {
 }
 
 MH_HD bool ldlt_solve6(const double Hfull[36], const double b[6], double x[6]) {
-  double A[6][6], y[6];
+  double A[6][6], y[6], invd[6];
   int piv[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) {
@@ -193,17 +194,19 @@ MH_HD bool ldlt_solve6(const double Hfull[36], const double b[6], double x[6]) {
     piv[k] = p;
 #pragma unroll
     for (int i = k + 1; i < 6; i++) {
-      const bool sw = (p == i);
+      if (p == i) {
 #pragma unroll
-      for (int j = 0; j < 6; j++) cswap(sw, A[k][j], A[i][j]);
+        for (int j = 0; j < 6; j++) cswap(true, A[k][j], A[i][j]);
 #pragma unroll
-      for (int j = 0; j < 6; j++) cswap(sw, A[j][k], A[j][i]);
-      cswap(sw, y[k], y[i]);
+        for (int j = 0; j < 6; j++) cswap(true, A[j][k], A[j][i]);
+        cswap(true, y[k], y[i]);
+      }
     }
     const double d = A[k][k];
     ok = ok && isfinite(d);
     const bool nz = fabs(d) > tiny;
     const double inv = nz ? 1.0 / d : 0.0;
+    invd[k] = inv;
 #pragma unroll
     for (int i = k + 1; i < 6; i++) A[i][k] = nz ? A[i][k] * inv : 0.0;
 #pragma unroll
@@ -220,10 +223,7 @@ MH_HD bool ldlt_solve6(const double Hfull[36], const double b[6], double x[6]) {
 #pragma unroll
     for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    const double d = A[i][i];
-    y[i] = (fabs(d) > tiny) ? y[i] / d : 0.0;
-  }
+  for (int i = 0; i < 6; i++) y[i] *= invd[i];  // (0 where the pivot vanished)
 #pragma unroll
   for (int i = 5; i >= 0; i--)
 #pragma unroll
@@ -232,7 +232,8 @@ MH_HD bool ldlt_solve6(const double Hfull[36], const double b[6], double x[6]) {
 #pragma unroll
   for (int k = 5; k >= 0; k--)
 #pragma unroll
-    for (int i = k + 1; i < 6; i++) cswap(piv[k] == i, y[k], y[i]);
+    for (int i = k + 1; i < 6; i++)
+      if (piv[k] == i) cswap(true, y[k], y[i]);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     x[i] = y[i];
