@@ -163,6 +163,14 @@ MH_API mh_status mh_scan_create(mh_ctx* ctx, const float* x, const float* y, con
                                 mh_scan** out);
 /* Replace the points (e.g. after the caller re-ran its de-skew, LidarOdometry.cpp:992-999). */
 MH_API mh_status mh_scan_update(mh_scan* scan, const float* x, const float* y, const float* z, size_t n, int32_t mem);
+/* Replace the points from an interleaved buffer, the form raw sensor data arrives in: point i has float32 x/y/z at
+ * data + i*point_step + off_{x,y,z} and, with off_t >= 0, a float32 time stamp [s] at off_t (a KITTI velodyne .bin is
+ * point_step 16 / offsets 0,4,8; a sensor_msgs/PointCloud2 payload gives its own).  This is the step the reference's
+ * observations_generator (mp2p_icp_filters::Generator, lidar3d-default.yaml:250-262) performs on the CPU when it turns
+ * the raw observation into the SoA 'raw' layer; here: ONE copy of the bytes and a de-interleave kernel.  point_step and
+ * the offsets are multiples of 4.  With off_t < 0 the scan carries no time stamps afterwards. */
+MH_API mh_status mh_scan_update_aos(mh_scan* scan, const void* data, size_t n, size_t point_step, size_t off_x,
+                                    size_t off_y, size_t off_z, int64_t off_t, int32_t mem);
 MH_API mh_status mh_scan_destroy(mh_scan* scan);
 MH_API mh_status mh_scan_size(const mh_scan* scan, uint64_t* n);
 

@@ -137,6 +137,8 @@ _SIGNATURES = {
     "mh_scan_create": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32,
                                    C.POINTER(C.c_void_p)]),
     "mh_scan_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
+    "mh_scan_update_aos": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                       C.c_int64, C.c_int32]),
     "mh_scan_destroy": (C.c_int32, [C.c_void_p]),
     "mh_scan_size": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mh_map_insert": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_float]),
@@ -381,6 +383,12 @@ class Scan:
     def update(self, xyz):
         x, y, z = _soa(xyz)
         _chk(lib().mh_scan_update(self._h, _vp(x), _vp(y), _vp(z), len(x), MEM_HOST))
+
+    def update_interleaved(self, records, off_x=0, off_y=4, off_z=8, off_t=-1):
+        """records: C-contiguous float32 [n,k] rows (KITTI .bin: k=4) -- one copy, de-interleaved on the device."""
+        a = np.ascontiguousarray(records, dtype=np.float32)
+        assert a.ndim == 2
+        _chk(lib().mh_scan_update_aos(self._h, _vp(a), a.shape[0], a.shape[1] * 4, off_x, off_y, off_z, off_t, MEM_HOST))
 
     def __len__(self):
         n = C.c_uint64()

@@ -223,6 +223,19 @@ __global__ void k_pp_deskew(const float* __restrict__ x, const float* __restrict
   oz[i] = gz;
 }
 
+// interleaved records (step/offsets in 4-byte words) -> SoA
+__global__ void k_pp_deinterleave(const uint32_t* __restrict__ data, uint32_t n, uint32_t step, uint32_t ox, uint32_t oy,
+                                  uint32_t oz, int32_t ot, float* __restrict__ x, float* __restrict__ y,
+                                  float* __restrict__ z, float* __restrict__ t) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* rec = data + (size_t)i * step;
+  x[i] = __uint_as_float(rec[ox]);
+  y[i] = __uint_as_float(rec[oy]);
+  z[i] = __uint_as_float(rec[oz]);
+  if (ot >= 0) t[i] = __uint_as_float(rec[ot]);
+}
+
 inline uint32_t nblk(size_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
 
 // One stage: [decimate] + predicates over `in` -> `out` (compacted, order preserving).  Returns the survivor count.
@@ -291,6 +304,48 @@ mh_status mh_scan_set_timestamps(mh_scan* scan, const float* t, size_t n, int32_
     if (mem == MH_MEM_HOST) MH_HIP(hipStreamSynchronize(ctx->stream));  // host array is borrowed for the call only
   }
   scan->t = (const float*)scan->aux.p;
+  return MH_OK;
+}
+
+mh_status mh_scan_update_aos(mh_scan* scan, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y,
+                             size_t off_z, int64_t off_t, int32_t mem) {
+  MH_REQUIRE(scan, "null scan");
+  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
+  MH_REQUIRE(n == 0 || data, "null data");
+  MH_REQUIRE(n < 0x7FFFFFFFull, "scan too large");
+  MH_REQUIRE(point_step >= 12 && point_step % 4 == 0 && point_step <= (1u << 16), "point_step must be a multiple of 4 in [12, 65536]");
+  MH_REQUIRE(off_x % 4 == 0 && off_y % 4 == 0 && off_z % 4 == 0 && off_x + 4 <= point_step && off_y + 4 <= point_step &&
+                 off_z + 4 <= point_step, "coordinate offsets must be multiples of 4 inside the record");
+  MH_REQUIRE(off_t < 0 || (off_t % 4 == 0 && (size_t)off_t + 4 <= point_step), "time stamp offset must be a multiple of 4 inside the record");
+  mh_ctx* ctx = scan->ctx;
+  MH_TRY(set_device(ctx));
+  hipStream_t s = ctx->stream;
+  const size_t stride = ((n * sizeof(float) + 255) / 256) * 256;
+  const size_t raw_bytes = n * point_step;
+  if (scan->xyz.bytes < 3 * stride || (off_t >= 0 && scan->aux.bytes < 2 * stride) || ctx->build_a.bytes < raw_bytes) {
+    MH_HIP(hipStreamSynchronize(s));  // nobody may still read the old buffers
+    MH_TRY(scan->xyz.reserve(3 * stride ? 3 * stride : 256));
+    if (off_t >= 0) MH_TRY(scan->aux.reserve(2 * stride ? 2 * stride : 256));
+    MH_TRY(ctx->build_a.reserve(raw_bytes ? raw_bytes : 256));
+  }
+  char* base = scan->xyz.as<char>();
+  scan->x = (const float*)base;
+  scan->y = (const float*)(base + stride);
+  scan->z = (const float*)(base + 2 * stride);
+  scan->t = off_t >= 0 ? (const float*)scan->aux.p : nullptr;
+  scan->src = nullptr;
+  scan->n = n;
+  if (!n) return MH_OK;
+  const uint32_t* recs = (const uint32_t*)data;
+  if (mem == MH_MEM_HOST) {  // the only copy of the call: the raw bytes as they are
+    MH_HIP(hipMemcpyAsync(ctx->build_a.p, data, raw_bytes, hipMemcpyHostToDevice, s));
+    recs = ctx->build_a.as<uint32_t>();
+  }
+  hipLaunchKernelGGL(k_pp_deinterleave, dim3(nblk(n, 256)), dim3(256), 0, s, recs, (uint32_t)n, (uint32_t)(point_step / 4),
+                     (uint32_t)(off_x / 4), (uint32_t)(off_y / 4), (uint32_t)(off_z / 4), off_t >= 0 ? (int32_t)(off_t / 4) : -1,
+                     (float*)scan->x, (float*)scan->y, (float*)scan->z, (float*)scan->t);
+  MH_HIP(hipGetLastError());
+  MH_HIP(hipStreamSynchronize(s));  // `data` is borrowed for the call only
   return MH_OK;
 }
 

@@ -128,6 +128,12 @@ class LidarOdometry {
   // One LiDAR observation: points in the vehicle frame, optional per-point time stamps [s] relative to `timestamp`.
   // Returns the record of this scan (also appended to records()).
   const ScanRecord& onLidar(double timestamp, const float* x, const float* y, const float* z, const float* t, size_t n);
+  // The same for raw interleaved records as sensors and data sets deliver them (KITTI velodyne .bin: point_step 16,
+  // offsets 0/4/8; PointCloud2: its own): the bytes go to the device as they are and are split into channels there
+  // (the job of observations_generator, lidar3d-default.yaml:250-262).  Time stamps: float32 field at off_t (>= 0), or
+  // the separate array `t` (may be nullptr).
+  const ScanRecord& onLidarInterleaved(double timestamp, const void* data, size_t n, size_t point_step, size_t off_x,
+                                       size_t off_y, size_t off_z, long long off_t = -1, const float* t = nullptr);
 
   const std::vector<ScanRecord>& records() const { return records_; }
   const std::vector<std::pair<double, CPose3D>>& estimatedTrajectory() const { return trajectory_; }
@@ -143,6 +149,8 @@ class LidarOdometry {
 
  private:
   struct FilterPlan;  // the recognised observation filter chain, as data for mh_scan_preprocess / mh_scan_deskew
+  struct RawInput;  // where the points of the current observation come from
+  const ScanRecord& process(double timestamp, const RawInput& in);
   void updatePipelineDynamicVariables();
   void updatePipelineTwistVariables(const Twist& tw);
   void run_first_pass();

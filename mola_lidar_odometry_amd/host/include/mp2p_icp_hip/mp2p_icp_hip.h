@@ -193,6 +193,9 @@ class DevicePointCloud : public Layer {
   size_t size() const;
   mh_scan* handle() const { return scan_; }
   void setPoints(const float* x, const float* y, const float* z, size_t n);
+  // interleaved records (KITTI .bin, PointCloud2 payload): float32 x/y/z [and time stamp when off_t >= 0] at byte offsets
+  void setPointsInterleaved(const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
+                            long long off_t = -1);
   void setTimestamps(const float* t, size_t n);
   void boundingBox(float mn[3], float mx[3]) const;
   void download(std::vector<float>& x, std::vector<float>& y, std::vector<float>& z) const;

@@ -225,6 +225,10 @@ size_t DevicePointCloud::size() const {
 void DevicePointCloud::setPoints(const float* x, const float* y, const float* z, size_t n) {
   check(mh_scan_update(scan_, x, y, z, n, MH_MEM_HOST), "mh_scan_update");
 }
+void DevicePointCloud::setPointsInterleaved(const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y,
+                                            size_t off_z, long long off_t) {
+  check(mh_scan_update_aos(scan_, data, n, point_step, off_x, off_y, off_z, (int64_t)off_t, MH_MEM_HOST), "mh_scan_update_aos");
+}
 void DevicePointCloud::setTimestamps(const float* t, size_t n) {
   check(mh_scan_set_timestamps(scan_, t, n, MH_MEM_HOST), "mh_scan_set_timestamps");
 }

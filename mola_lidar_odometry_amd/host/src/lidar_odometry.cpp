@@ -403,8 +403,34 @@ void LidarOdometry::create_local_map() {  // :1165-1171 with yaml:228-242
   local_map_ = std::make_shared<HashedVoxelPointCloud>(mp, ctx_);
 }
 
+struct LidarOdometry::RawInput {
+  size_t n = 0;
+  const float *x = nullptr, *y = nullptr, *z = nullptr, *t = nullptr;  // channel arrays, or ...
+  const void* data = nullptr;                                           // ... interleaved records
+  size_t point_step = 0, off_x = 0, off_y = 0, off_z = 0;
+  long long off_t = -1;
+};
+
 const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, const float* x, const float* y, const float* z,
                                                         const float* t, size_t n) {
+  RawInput in;
+  in.n = n; in.x = x; in.y = y; in.z = z; in.t = t;
+  return process(this_obs_tim, in);
+}
+
+const LidarOdometry::ScanRecord& LidarOdometry::onLidarInterleaved(double this_obs_tim, const void* data, size_t n,
+                                                                   size_t point_step, size_t off_x, size_t off_y,
+                                                                   size_t off_z, long long off_t, const float* t) {
+  RawInput in;
+  in.n = n; in.data = data; in.point_step = point_step; in.off_x = off_x; in.off_y = off_y; in.off_z = off_z;
+  in.off_t = off_t; in.t = t;
+  return process(this_obs_tim, in);
+}
+
+const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, const RawInput& in) {
+  const size_t n = in.n;
+  const bool has_t = in.t != nullptr || (in.data && in.off_t >= 0);
+  (void)has_t;
   if (!plan_) throw std::runtime_error("LidarOdometry::onLidar called before initialize()");
   records_.emplace_back();
   ScanRecord& rec = records_.back();
@@ -421,8 +447,9 @@ const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, con
   ensure_device();
   {
     StageTimer tt(profile_, "onLidar.0.upload_raw");
-    raw_->setPoints(x, y, z, n);
-    if (t) raw_->setTimestamps(t, n);
+    if (in.data) raw_->setPointsInterleaved(in.data, n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t);
+    else raw_->setPoints(in.x, in.y, in.z, n);
+    if (in.t) raw_->setTimestamps(in.t, n);
   }
 
   // first call: sensor range from the raw cloud (:660, 1487-1513)
@@ -431,7 +458,10 @@ const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, con
     raw_->boundingBox(mn, mx);
     estimated_sensor_max_range_ = std::max(bbox_radius(mn, mx), params_.absolute_minimum_sensor_range);
   }
-  updatePipelineDynamicVariables();  // :692
+  {
+    StageTimer tt(profile_, "onLidar.0.dynamic_variables");
+    updatePipelineDynamicVariables();  // :692
+  }
   rec.twist = last_motion_model_output_ ? last_motion_model_output_->twist : Twist();
 
   {
@@ -473,7 +503,10 @@ const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, con
   }
 
   bool updateLocalMap = false;
-  last_motion_model_output_ = navstate_.estimated_navstate(this_obs_tim);  // :810-811
+  {
+    StageTimer tt(profile_, "onLidar.2.navstate");
+    last_motion_model_output_ = navstate_.estimated_navstate(this_obs_tim);  // :810-811
+  }
   const bool hasMotionModel = last_motion_model_output_.has_value();
   rec.had_motion_model = hasMotionModel;
 
@@ -502,6 +535,7 @@ const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, con
     TPose3D current_solution = init_guess;
     rec.init_guess = CPose3D(init_guess);
     ICP& icp = *icp_[kind];
+    StageTimer t_icp_all(profile_, "onLidar.3.icp_with_setup");
     mp2p_icp_hip::Parameters icp_params = icp_params_[kind];
     size_t remaining = icp_params.maxIterations;
     mp2p_icp_hip::Results res;
@@ -509,7 +543,8 @@ const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, con
     obs.layers[plan_->layer_for_icp] = for_icp_;
     obs.layers[plan_->layer_for_map] = for_map_;
     glob.layers[plan_->map_layer] = local_map_;
-    StageTimer t_icp(profile_, "onLidar.3.run_icp");
+    std::optional<StageTimer> t_icp;
+    t_icp.emplace(profile_, "onLidar.3.run_icp");
     do {
       icp_params.maxIterations = (uint32_t)remaining;
       // the in-tree hook (:919-952) only compares the running solution with its check point: evaluated on the device.
@@ -543,12 +578,14 @@ const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, con
         }
       }
     } while (res.terminationReason == IterTermReason::HookRequest);
+    t_icp.reset();
     icp.clearHooks();
     rec.icp_run = true;
     rec.termination = (int)res.terminationReason;
     rec.goodness = res.quality;
 
     // ---- gate, motion model, trajectory (:1026-1045)
+    StageTimer t_post(profile_, "onLidar.3.post_icp");
     const bool icpIsGood = res.quality >= params_.min_icp_goodness;
     last_icp_was_good_ = icpIsGood;
     last_icp_quality_ = res.quality;

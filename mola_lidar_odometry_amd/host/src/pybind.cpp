@@ -131,17 +131,16 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
       .def("reset", &LidarOdometry::reset)
       .def("onLidar", [rec2dict](LidarOdometry& lo, double stamp, py::array_t<float, py::array::c_style | py::array::forcecast> xyz,
                                  std::optional<py::array_t<float, py::array::c_style | py::array::forcecast>> t) {
-        auto r = xyz.unchecked<2>();
-        if (r.shape(1) != 3) throw std::runtime_error("xyz must be [n,3]");
-        const size_t n = (size_t)r.shape(0);
-        std::vector<float> x(n), y(n), z(n);
-        for (size_t i = 0; i < n; i++) { x[i] = r(i, 0); y[i] = r(i, 1); z[i] = r(i, 2); }
+        // [n,3] points or [n,>=3] records whose first three fields are x,y,z (a KITTI .bin is [n,4]): the rows go to
+        // the device as they are and are split into channels there
+        if (xyz.ndim() != 2 || xyz.shape(1) < 3) throw std::runtime_error("xyz must be [n,3] (or [n,k>=3] records starting with x,y,z)");
+        const size_t n = (size_t)xyz.shape(0);
         const float* tp = nullptr;
         if (t) {
           if ((size_t)t->size() != n) throw std::runtime_error("t must have n entries");
           tp = t->data();
         }
-        return rec2dict(lo.onLidar(stamp, x.data(), y.data(), z.data(), tp, n)); },
+        return rec2dict(lo.onLidarInterleaved(stamp, xyz.data(), n, (size_t)xyz.shape(1) * sizeof(float), 0, 4, 8, -1, tp)); },
            py::arg("timestamp"), py::arg("xyz"), py::arg("t") = std::nullopt)
       .def("records", [rec2dict](const LidarOdometry& lo) { py::list l; for (auto& r : lo.records()) l.append(rec2dict(r)); return l; })
       .def("trajectory", [](const LidarOdometry& lo) {

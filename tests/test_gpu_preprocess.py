@@ -163,3 +163,36 @@ def test_map_insert_ndt_and_empty(ctx, oracle):
     assert g.info().n_planes > 10
     g.insert(capi.Scan(ctx), T, 35.0)  # empty key-frame: nothing changes
     _assert_maps_equal(g.download(), o.dump())
+
+
+def test_interleaved_upload_equals_channel_upload(ctx, small_workload):
+    """mh_scan_update_aos: KITTI-style [n,4] rows, a PointCloud2-style record with the fields in odd places and a time
+    stamp field, an empty buffer, and the argument checks."""
+    xyz, t = _raw(3, small_workload)
+    n = len(xyz)
+    ref = capi.Scan(ctx, xyz).download()
+    kitti = np.concatenate([xyz, np.full((n, 1), 0.5, np.float32)], 1)
+    s = capi.Scan(ctx)
+    s.update_interleaved(kitti)
+    got = s.download()
+    assert got["xyz"].tobytes() == ref["xyz"].tobytes() and len(s) == n
+    # record: [intensity, z, t, x, ring, y]  (24 bytes)
+    rec = np.zeros((n, 6), np.float32)
+    rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3], rec[:, 4], rec[:, 5] = 7.0, xyz[:, 2], t, xyz[:, 0], 3.0, xyz[:, 1]
+    s.update_interleaved(rec, off_x=12, off_y=20, off_z=4, off_t=8)
+    got = s.download()
+    assert got["xyz"].tobytes() == ref["xyz"].tobytes() and got["t"].tobytes() == t.tobytes()
+    # ... and it feeds the filters like any other scan
+    a, b = capi.Scan(ctx), capi.Scan(ctx)
+    s.preprocess(capi.preprocess_params(timestamp_method=capi.TS_MIDDLE_IS_ZERO, **PP), a, None)
+    capi.Scan(ctx, xyz).set_timestamps(t).preprocess(capi.preprocess_params(timestamp_method=capi.TS_MIDDLE_IS_ZERO, **PP), b, None)
+    da, db = a.download(), b.download()
+    assert da["xyz"].tobytes() == db["xyz"].tobytes() and da["t"].tobytes() == db["t"].tobytes()
+    s.update_interleaved(kitti)  # no time stamp field: the channel is gone again
+    assert not s.download()["t"].any()
+    s.update_interleaved(np.zeros((0, 4), np.float32))
+    assert len(s) == 0
+    with pytest.raises(capi.MolahipError):
+        s.update_interleaved(kitti, off_x=2)
+    with pytest.raises(capi.MolahipError):
+        s.update_interleaved(kitti, off_t=16)

@@ -167,6 +167,13 @@ def test_hip_driver_matches_oracle_driver(host, drive, tmp_path):
     assert trajectory.ate_rmse(est, _gt_rel(drive), "none") < 0.2
     dropped = lo.onLidar(drive["stamps"][-1] + 1e-4, *drive["scans"][-1])
     assert dropped["dropped"]
+    # [n,4] records (x,y,z,intensity as in a KITTI .bin) take the same path as [n,3] points
+    lo2 = host.LidarOdometry()
+    lo2.initialize(host.Config.FromYamlFile(PIPE))
+    for (xyz, t), st in list(zip(drive["scans"], drive["stamps"]))[:4]:
+        lo2.onLidar(st, np.concatenate([xyz, np.ones((len(xyz), 1), np.float32)], 1), t)
+    for ra, rb in zip(lo2.records(), lo.records()[:4]):
+        assert ra["pose"] == rb["pose"] and ra["n_for_icp"] == rb["n_for_icp"]
 
 
 @pytest.mark.gpu
@@ -237,7 +244,7 @@ def test_kitti_tree_reader_roundtrip(tmp_path, drive):
     seq = os.path.join(str(tmp_path), "sequences", "00")
     scans = list(run_odometry._kitti_scans(seq))
     assert len(scans) == len(drive["scans"])
-    np.testing.assert_array_equal(scans[3][1], drive["scans"][3][0])
+    np.testing.assert_array_equal(scans[3][1][:, :3], drive["scans"][3][0])  # rows are x,y,z,intensity
     assert abs(scans[3][0] - 0.3) < 1e-6 and scans[3][2] is None
     gt = run_odometry._kitti_gt(str(tmp_path), "00", run_odometry._kitti_calib_Tr(seq))
     np.testing.assert_allclose(gt, _gt_rel(drive), atol=1e-6)  # camera-frame poses come back in the velodyne frame

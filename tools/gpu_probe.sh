@@ -1,9 +1,8 @@
 #!/bin/bash
 cd /root/repo
-cp mola_lidar_odometry_amd/libmolahip.so /tmp/prod.so
-python tools/phase_probe.py
-cp /tmp/prod.so mola_lidar_odometry_amd/libmolahip.so
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-for p in default default ndt; do
-python -m mola_lidar_odometry_amd.run_odometry --synthetic 200 --pipeline pipelines/lidar3d-$p-hip.yaml 2>&1 | head -1 | cut -c1-120,330-700
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for p in default ndt; do
+python -m mola_lidar_odometry_amd.run_odometry --synthetic 200 --pipeline pipelines/lidar3d-$p-hip.yaml 2>&1 | head -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print(d['scans_per_s'], d['steady_scans_per_s'], d['startup_s_first_3_scans']); print(d['host_ms_per_scan'])"
 done
