@@ -344,7 +344,8 @@ typedef struct {
   uint32_t compute_covariance;
   double cov_findif_xyz;        /* 1e-7 */
   double cov_findif_ang;        /* 1e-7 */
-  uint32_t poll_every;          /* ICP iterations enqueued between host polls of the done flag; 0 = default */
+  uint32_t poll_every;          /* ICP iterations enqueued between host polls of the done flag; 0 = automatic: the
+                                   first chunk as long as the context's previous alignment ran, then short ones */
   uint32_t profile;             /* 1: time every match kernel with HIP events on the context stream (such a job is
                                    enqueued kernel by kernel instead of replaying the captured graph); 2: in
                                    mh_icp_align_batch, do that for job 0 only */

@@ -1388,6 +1388,7 @@ struct AlignJob {
   MatchK mk{};
   SolveK sk{};
   uint32_t nb = 0, nbm = 0, nba = 0, enqueued = 0, chunk = 0, prof_n = 0;
+  bool auto_chunk = false;
   int variant = 0;
   bool finished = false, trivial = false;
   bool prof = false;  // time this job's match kernels with events (then it cannot use the graph path)
@@ -1491,7 +1492,11 @@ struct AlignJob {
     nba = nblk_acc(scan->n);
     nbm = variant >= 4 ? nba : nb;  // who writes the partials of the first Gauss-Newton step
     MH_TRY(ctx->partials.reserve((size_t)kGenN * (nbm > nb ? nbm : nb) * sizeof(double)));
-    chunk = p->poll_every ? p->poll_every : 10;
+    // poll_every == 0: the first chunk is sized by what the previous alignment of this context needed (consecutive scans
+    // of a sequence converge in about as many iterations: one host round trip instead of three), later chunks are short
+    auto_chunk = p->poll_every == 0;
+    chunk = p->poll_every ? p->poll_every
+                          : (ctx->predicted_iterations ? (ctx->predicted_iterations + 2 > 64 ? 64u : ctx->predicted_iterations + 2) : 10u);
     enqueued = 0;
     prof_n = 0;
     if (prof) {
@@ -1668,9 +1673,13 @@ struct AlignJob {
     MH_TRY(set_device(ctx));
     MH_HIP(hipEventSynchronize(ctx->ev_poll));
     const IcpDeviceState* h = ctx->h_state;
-    if (!h->done && enqueued < p->max_iterations) return MH_OK;
+    if (!h->done && enqueued < p->max_iterations) {
+      if (auto_chunk) chunk = 6;
+      return MH_OK;
+    }
     if (!h->done) return fail(MH_ERR_INTERNAL, "device ICP loop did not terminate after max_iterations");
     finished = true;
+    if (auto_chunk) ctx->predicted_iterations = h->n_iterations + (h->term_reason == MH_TERM_MAX_ITERATIONS ? 0u : 1u);
     for (int i = 0; i < 12; i++) res->T[i] = h->T[i];
     if (p->compute_covariance)
       for (int i = 0; i < 36; i++) res->cov[i] = h->cov[i];

@@ -115,6 +115,7 @@ struct mh_ctx {
   mh::DevBuf partials;    // per-block reduction partials (double)
   mh::DevBuf partials_b;  // generic (pt2pl) partials
   mh::DevBuf sched;       // threshold / kernel-param arrays (double)
+  uint32_t predicted_iterations = 0;  // launches the last auto-chunked alignment needed (sizes the next first chunk)
   double* h_sched = nullptr;  // pinned staging for them
   size_t h_sched_cap = 0;
   mh::DevBuf trace;       // mh_icp_iter[max_iterations]
