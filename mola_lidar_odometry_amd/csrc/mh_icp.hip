@@ -260,13 +260,18 @@ __global__ __launch_bounds__(kBlock) void k_match16(const IcpDeviceState* __rest
 constexpr uint32_t kAccPPT = 4;  // scan points per lane of k_accum
 inline uint32_t nblk_acc(size_t n) { return (uint32_t)((n + (size_t)kBlock * kAccPPT - 1) / ((size_t)kBlock * kAccPPT)); }
 
+constexpr int kAccChunk = 19;                                     // lanes added by one thread of the first reduction stage
+constexpr int kAccGroups = (kBlock + kAccChunk - 1) / kAccChunk;  // 14
+
 __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first,
                                                   const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                   const float4* __restrict__ pair_q,
                                                   const uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
                                                   uint32_t pstride) {
-  __shared__ double lds[kBlock / 64][kAccN];
+  __shared__ double tr[kAccN][kBlock + 1];
+  __shared__ double p1[kAccN][kAccGroups];
+  static_assert(kAccN * kAccGroups <= (int)kBlock, "first reduction stage needs one thread per (row, group)");
   if (st->done) return;
   if (!first && st->inner == 0) return;  // the previous solve already closed this ICP iteration
   double T[12];
@@ -274,8 +279,8 @@ __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restri
   for (int i = 0; i < 12; i++) T[i] = st->T[i];
   const MatchK k = *kp;
   const double kparam = st->cur_kparam;
-  // kAccPPT points per lane: the 18 wave reductions below are most of this kernel's instructions, so they are
-  // amortised over four times as many points (the device is VALU-bound once several alignments run concurrently)
+  // kAccPPT points per lane: the reduction below is a fixed cost per lane, amortised over four points
+  // (the device is VALU-bound once several alignments run concurrently)
   const uint32_t bid = blockIdx.x;
   uint32_t gi[kAccPPT];
   float4 q[kAccPPT];
@@ -293,16 +298,28 @@ __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restri
 #pragma unroll
   for (int u = 0; u < kAccPPT; u++)
     if (gi[u] != kNoMatch) acc_pt2pt(a, T, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // Workgroup sum of the 18 rows through LDS, transposed: every lane stores its values, (row, group) threads add 19
+  // lanes each, 18 threads add the 14 group sums -- ~60 instructions per wave where 18 DPP wave reductions took ~410
+  // (the larger share of this kernel); fixed order, bitwise reproducible.
 #pragma unroll
-  for (int j = 0; j < kAccN; j++) {
-    const double s = wave_sum(a.v[j]);
-    if (lane == 0) lds[wave][j] = s;
+  for (int j = 0; j < kAccN; j++) tr[j][threadIdx.x] = a.v[j];
+  __syncthreads();
+  if (threadIdx.x < kAccN * kAccGroups) {
+    const int j = threadIdx.x / kAccGroups, g = threadIdx.x % kAccGroups;
+    const int l0 = g * kAccChunk;
+    double sum = tr[j][l0];
+#pragma unroll
+    for (int i = 1; i < kAccChunk; i++)
+      if (l0 + i < (int)kBlock) sum += tr[j][l0 + i];
+    p1[j][g] = sum;
   }
   __syncthreads();
-  if (threadIdx.x < kAccN)
-    partials[threadIdx.x * pstride + bid] =
-        ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+  if (threadIdx.x < kAccN) {
+    double sum = p1[threadIdx.x][0];
+#pragma unroll
+    for (int g = 1; g < kAccGroups; g++) sum += p1[threadIdx.x][g];
+    partials[threadIdx.x * pstride + bid] = sum;
+  }
 }
 
 // point-to-plane rows (Matcher_Point2Plane pairings, lidar3d-ndt.yaml:195-200): e = n.(R l + t - c),
