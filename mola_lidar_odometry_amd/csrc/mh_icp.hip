@@ -100,6 +100,44 @@ __device__ __forceinline__ void wave_sync_lds() {
 }
 
 
+// Workgroup sum of NV doubles per lane through LDS, transposed: every lane stores its values, one thread per (row, group)
+// adds `chunk` lanes (odd: conflict-free reads), NV threads add the group sums and write partials[row * pstride + bid].
+// ~(NV + chunk) instructions per wave where NV DPP wave reductions (wave_sum) take ~23 NV; fixed order -> bitwise
+// reproducible.  (k_accum: 18 rows, 19-lane chunks, 14 groups;  point-to-plane rows: 29 / 33 / 8.)
+template <int NV>
+struct BlockSum {
+  static constexpr int kG0 = (int)kBlock / NV;
+  static constexpr int kChunk = (((int)kBlock + kG0 - 1) / kG0) | 1;
+  static constexpr int kGroups = ((int)kBlock + kChunk - 1) / kChunk;
+  static_assert(NV * kGroups <= (int)kBlock, "one thread per (row, group)");
+  double tr[NV][kBlock + 1];
+  double p1[NV][kGroups];
+};
+
+template <int NV>
+__device__ __forceinline__ void block_sum_rows(const double* v, BlockSum<NV>& sh, double* __restrict__ partials,
+                                               uint32_t pstride, uint32_t bid) {
+#pragma unroll
+  for (int j = 0; j < NV; j++) sh.tr[j][threadIdx.x] = v[j];
+  __syncthreads();
+  if (threadIdx.x < NV * BlockSum<NV>::kGroups) {
+    const int j = threadIdx.x / BlockSum<NV>::kGroups, g = threadIdx.x % BlockSum<NV>::kGroups;
+    const int l0 = g * BlockSum<NV>::kChunk;
+    double sum = sh.tr[j][l0];
+#pragma unroll
+    for (int i = 1; i < BlockSum<NV>::kChunk; i++)
+      if (l0 + i < (int)kBlock) sum += sh.tr[j][l0 + i];
+    sh.p1[j][g] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double sum = sh.p1[threadIdx.x][0];
+#pragma unroll
+    for (int g = 1; g < BlockSum<NV>::kGroups; g++) sum += sh.p1[threadIdx.x][g];
+    partials[threadIdx.x * pstride + bid] = sum;
+  }
+}
+
 // ================================================================================================
 // k_match: correspondence search (+ first Gauss-Newton accumulation when FUSED)
 // ================================================================================================
@@ -110,7 +148,7 @@ __global__ __launch_bounds__(kBlock, MH_MATCH_WAVES) void k_match(const IcpDevic
                                                   MapView map, float4* __restrict__ pair_q,
                                                   uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
                                                   uint32_t pstride) {
-  __shared__ double lds[kBlock / 64][kAccN];
+  __shared__ BlockSum<kAccN> lds;
   const MatchK k = *kp;  // wave-uniform scalar loads
   double T[12];
   float thr2;
@@ -146,21 +184,7 @@ __global__ __launch_bounds__(kBlock, MH_MATCH_WAVES) void k_match(const IcpDevic
     pair_gidx[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
     if (FUSED && ok) acc_pt2pt(a, T, x, y, z, r.pt.x, r.pt.y, r.pt.z, k.kernel, kparam, k.w_pt2pt);
   }
-  if (FUSED) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int j = 0; j < kAccN; j++) {
-      const double s = wave_sum(a.v[j]);
-      if (lane == 0) lds[wave][j] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < kAccN) {
-      double sum = lds[0][threadIdx.x];
-#pragma unroll
-      for (int w = 1; w < (int)(kBlock / 64); w++) sum += lds[w][threadIdx.x];  // fixed order: bitwise reproducible
-      partials[threadIdx.x * pstride + bid] = sum;
-    }
-  }
+  if (FUSED) block_sum_rows<kAccN>(a.v, lds, partials, pstride, bid);
 }
 
 
@@ -260,18 +284,13 @@ __global__ __launch_bounds__(kBlock) void k_match16(const IcpDeviceState* __rest
 constexpr uint32_t kAccPPT = 4;  // scan points per lane of k_accum
 inline uint32_t nblk_acc(size_t n) { return (uint32_t)((n + (size_t)kBlock * kAccPPT - 1) / ((size_t)kBlock * kAccPPT)); }
 
-constexpr int kAccChunk = 19;                                     // lanes added by one thread of the first reduction stage
-constexpr int kAccGroups = (kBlock + kAccChunk - 1) / kAccChunk;  // 14
-
 __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first,
                                                   const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                   const float4* __restrict__ pair_q,
                                                   const uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
                                                   uint32_t pstride) {
-  __shared__ double tr[kAccN][kBlock + 1];
-  __shared__ double p1[kAccN][kAccGroups];
-  static_assert(kAccN * kAccGroups <= (int)kBlock, "first reduction stage needs one thread per (row, group)");
+  __shared__ BlockSum<kAccN> bs;
   if (st->done) return;
   if (!first && st->inner == 0) return;  // the previous solve already closed this ICP iteration
   double T[12];
@@ -298,28 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restri
 #pragma unroll
   for (int u = 0; u < kAccPPT; u++)
     if (gi[u] != kNoMatch) acc_pt2pt(a, T, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
-  // Workgroup sum of the 18 rows through LDS, transposed: every lane stores its values, (row, group) threads add 19
-  // lanes each, 18 threads add the 14 group sums -- ~60 instructions per wave where 18 DPP wave reductions took ~410
-  // (the larger share of this kernel); fixed order, bitwise reproducible.
-#pragma unroll
-  for (int j = 0; j < kAccN; j++) tr[j][threadIdx.x] = a.v[j];
-  __syncthreads();
-  if (threadIdx.x < kAccN * kAccGroups) {
-    const int j = threadIdx.x / kAccGroups, g = threadIdx.x % kAccGroups;
-    const int l0 = g * kAccChunk;
-    double sum = tr[j][l0];
-#pragma unroll
-    for (int i = 1; i < kAccChunk; i++)
-      if (l0 + i < (int)kBlock) sum += tr[j][l0 + i];
-    p1[j][g] = sum;
-  }
-  __syncthreads();
-  if (threadIdx.x < kAccN) {
-    double sum = p1[threadIdx.x][0];
-#pragma unroll
-    for (int g = 1; g < kAccGroups; g++) sum += p1[threadIdx.x][g];
-    partials[threadIdx.x * pstride + bid] = sum;
-  }
+  block_sum_rows<kAccN>(a.v, bs, partials, pstride, bid);
 }
 
 // point-to-plane rows (Matcher_Point2Plane pairings, lidar3d-ndt.yaml:195-200): e = n.(R l + t - c),
@@ -330,7 +328,7 @@ __global__ __launch_bounds__(kBlock) void k_accum_pl(const IcpDeviceState* __res
                                                      const float* __restrict__ c3, const float* __restrict__ n3,
                                                      uint32_t n, uint32_t stride, double* __restrict__ partials,
                                                      uint32_t pstride) {
-  __shared__ double lds[kBlock / 64][kGenN];
+  __shared__ BlockSum<kGenN> lds;
   if (st->done) return;
   double T[12];
 #pragma unroll
@@ -365,16 +363,7 @@ __global__ __launch_bounds__(kBlock) void k_accum_pl(const IcpDeviceState* __res
     v[27] = w * e * e;
     v[28] = 1.0;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int j = 0; j < kGenN; j++) {
-    const double s = wave_sum(v[j]);
-    if (lane == 0) lds[wave][j] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < kGenN)
-    partials[threadIdx.x * pstride + blockIdx.x] =
-        ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+  block_sum_rows<kGenN>(v, lds, partials, pstride, blockIdx.x);
 }
 
 // ================================================================================================
@@ -414,27 +403,13 @@ __device__ __forceinline__ void acc_pt2pl_rows(double* v, const double* __restri
   v[28] = 1.0;
 }
 
-template <int NV>
-__device__ __forceinline__ void block_reduce_rows(const double* v, double (*lds)[NV], double* __restrict__ partials,
-                                                  uint32_t pstride, uint32_t bid) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int j = 0; j < NV; j++) {
-    const double s = wave_sum(v[j]);
-    if (lane == 0) lds[wave][j] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < NV)
-    partials[threadIdx.x * pstride + bid] = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
-}
-
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_match_pl(const IcpDeviceState* __restrict__ st, PoseArg Targ, float thr_arg,
                                                      const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                      const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                      MapView map, float4* __restrict__ pl_c, float4* __restrict__ pl_n,
                                                      double* __restrict__ partials, uint32_t pstride) {
-  __shared__ double lds[kBlock / 64][kGenN];
+  __shared__ BlockSum<kGenN> lds;
   const MatchK k = *kp;
   double T[12];
   float thr;
@@ -518,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void k_match_pl(const IcpDeviceState* __res
     pl_n[i] = n4;
     if (FUSED && ok) acc_pt2pl_rows(v, T, x, y, z, c4, n4, k.kernel, kparam, k.w_pt2pl);
   }
-  if (FUSED) block_reduce_rows<kGenN>(v, lds, partials, pstride, blockIdx.x);
+  if (FUSED) block_sum_rows<kGenN>(v, lds, partials, pstride, blockIdx.x);
 }
 
 // k_match_pl16: Matcher_Point2Plane with a DPP row (16 lanes) per point, for small layers.  k_match_pl walks the 27
@@ -606,7 +581,7 @@ __global__ __launch_bounds__(kBlock) void k_accum_plbuf(const IcpDeviceState* __
                                                         const float* __restrict__ lz, uint32_t n,
                                                         const float4* __restrict__ pl_c, const float4* __restrict__ pl_n,
                                                         double* __restrict__ partials, uint32_t pstride) {
-  __shared__ double lds[kBlock / 64][kGenN];
+  __shared__ BlockSum<kGenN> lds;
   if (st->done || (!first && st->inner == 0)) return;
   const MatchK k = *kp;
   double T[12];
@@ -621,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void k_accum_plbuf(const IcpDeviceState* __
     const float4 c = pl_c[i];
     if (c.w != 0.f) acc_pt2pl_rows(v, T, lx[i], ly[i], lz[i], c, pl_n[i], k.kernel, kparam, k.w_pt2pl);
   }
-  block_reduce_rows<kGenN>(v, lds, partials, pstride, blockIdx.x);
+  block_sum_rows<kGenN>(v, lds, partials, pstride, blockIdx.x);
 }
 
 constexpr int kSolveThreads = 512;  // 2 waves per SIMD -> 256 VGPRs for the serial 6x6 code of thread 0
@@ -997,7 +972,7 @@ __global__ __launch_bounds__(kBlock) void k_cov_accum(const IcpDeviceState* __re
                                                       const uint32_t* __restrict__ pair_gidx,
                                                       double* __restrict__ partials, uint32_t pstride) {
   __shared__ double sD[72];
-  __shared__ double lds[kBlock / 64][kCovN];
+  __shared__ BlockSum<kCovN> lds;
   if (!force && (!st->done || st->cov_done)) return;
   if (threadIdx.x < 72) sD[threadIdx.x] = st->covD[threadIdx.x];
   __syncthreads();
@@ -1020,16 +995,7 @@ __global__ __launch_bounds__(kBlock) void k_cov_accum(const IcpDeviceState* __re
       for (int b = a; b < 6; b++) v[q++] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b];
     v[21] = 1.0;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int j = 0; j < kCovN; j++) {
-    const double s = wave_sum(v[j]);
-    if (lane == 0) lds[wave][j] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < kCovN)
-    partials[threadIdx.x * pstride + blockIdx.x] =
-        ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+  block_sum_rows<kCovN>(v, lds, partials, pstride, blockIdx.x);
 }
 
 __global__ __launch_bounds__(kBlock) void k_cov_accum_pl(const IcpDeviceState* __restrict__ st,
@@ -1037,7 +1003,7 @@ __global__ __launch_bounds__(kBlock) void k_cov_accum_pl(const IcpDeviceState* _
                                                          uint32_t n, uint32_t stride, double* __restrict__ partials,
                                                          uint32_t pstride) {
   __shared__ double sD[72];
-  __shared__ double lds[kBlock / 64][kCovN];
+  __shared__ BlockSum<kCovN> lds;
   if (threadIdx.x < 72) sD[threadIdx.x] = st->covD[threadIdx.x];
   __syncthreads();
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -1063,16 +1029,7 @@ __global__ __launch_bounds__(kBlock) void k_cov_accum_pl(const IcpDeviceState* _
       for (int b = a; b < 6; b++) v[q++] = A[a] * A[b];
     v[21] = 1.0;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int j = 0; j < kCovN; j++) {
-    const double s = wave_sum(v[j]);
-    if (lane == 0) lds[wave][j] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < kCovN)
-    partials[threadIdx.x * pstride + blockIdx.x] =
-        ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+  block_sum_rows<kCovN>(v, lds, partials, pstride, blockIdx.x);
 }
 
 // covariance rows of the stored point-to-plane pairings (fused path)
@@ -1082,7 +1039,7 @@ __global__ __launch_bounds__(kBlock) void k_cov_accum_plbuf(const IcpDeviceState
                                                             const float4* __restrict__ pl_c, const float4* __restrict__ pl_n,
                                                             double* __restrict__ partials, uint32_t pstride) {
   __shared__ double sD[72];
-  __shared__ double lds[kBlock / 64][kCovN];
+  __shared__ BlockSum<kCovN> lds;
   if (!st->done || st->cov_done) return;
   if (threadIdx.x < 72) sD[threadIdx.x] = st->covD[threadIdx.x];
   __syncthreads();
@@ -1109,7 +1066,7 @@ __global__ __launch_bounds__(kBlock) void k_cov_accum_plbuf(const IcpDeviceState
       for (int b = a; b < 6; b++) v[q++] = A[a] * A[b];
     v[21] = 1.0;
   }
-  block_reduce_rows<kCovN>(v, lds, partials, pstride, blockIdx.x);
+  block_sum_rows<kCovN>(v, lds, partials, pstride, blockIdx.x);
 }
 
 __global__ __launch_bounds__(kSolveThreads) void k_cov_finalize(IcpDeviceState* __restrict__ st, uint32_t force,
