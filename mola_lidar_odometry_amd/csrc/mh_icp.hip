@@ -648,7 +648,7 @@ struct SolveShared {
 __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
                                            const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                            const double* __restrict__ partB, uint32_t nB, uint32_t strideB,
-                                           SolveShared& sh, bool totA_ready = false) {
+                                           SolveShared& sh, bool totA_ready = false, bool totB_ready = false) {
   double (*red)[64] = sh.red;
   double* totA = sh.totA;
   double* totB = sh.totB;
@@ -663,7 +663,7 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, cons
 #pragma unroll
   for (int i = 0; i < kAccN; i++) a[i] = (nA || totA_ready) ? totA[i] : 0.0;
 #pragma unroll
-  for (int i = 0; i < kGenN; i++) gen[i] = nB ? totB[i] : 0.0;
+  for (int i = 0; i < kGenN; i++) gen[i] = (nB || totB_ready) ? totB[i] : 0.0;
   Pose Tc;
 #pragma unroll
   for (int i = 0; i < 12; i++) Tc.m[i] = st->T[i];
@@ -866,19 +866,53 @@ constexpr int kOneGroupGroups = (kOneGroupAccThreads + kOneGroupChunk - 1) / kOn
 // LDLT 2.5 us, exp 0.5 us, log + tail 1.9 us.  Hence: the per-lane sums go through LDS transposed (each lane writes its
 // 18 values, 288 threads add 17 lanes each, 18 threads add the 16 group sums: fixed order, ~60 instructions per wave)
 // and land in the solve's shared totals directly; the point loads are issued before the state is even looked at.
+// sum of NR (<= kAccN) values per accumulating lane -> out[0..NR), through the transposed buffer (reusable afterwards)
+template <int NR>
+__device__ __forceinline__ void one_group_sum(const double* vals, bool acc_lane, double (*tr)[kOneGroupAccThreads + 1],
+                                              double (*p1)[kOneGroupGroups], double* out) {
+  static_assert(NR <= kAccN, "rows per pass");
+  if (acc_lane) {
+#pragma unroll
+    for (int j = 0; j < NR; j++) tr[j][threadIdx.x] = vals[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < NR * kOneGroupGroups) {  // stage 1: row j, lanes [17 g, 17 g + 17)
+    const int j = threadIdx.x / kOneGroupGroups, g = threadIdx.x % kOneGroupGroups;
+    const int l0 = g * kOneGroupChunk;
+    double sum = tr[j][l0];
+#pragma unroll
+    for (int i = 1; i < kOneGroupChunk; i++)
+      if (l0 + i < kOneGroupAccThreads) sum += tr[j][l0 + i];
+    p1[j][g] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x < NR) {  // stage 2: the group sums in order
+    double sum = p1[threadIdx.x][0];
+#pragma unroll
+    for (int g = 1; g < kOneGroupGroups; g++) sum += p1[threadIdx.x][g];
+    out[threadIdx.x] = sum;
+  }
+  __syncthreads();
+}
+
+// PL: the layer also carries Matcher_Point2Plane pairings (pl_c.w != 0: centroid + normal of the paired voxel, written by
+// k_match_pl16) whose 29 generic rows are accumulated alongside and summed in two more passes of the same buffer.
+template <bool PL>
 __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* __restrict__ st, uint32_t first,
                                                                 const MatchK* __restrict__ kp, const SolveK* __restrict__ sk,
                                                                 const float* __restrict__ lx, const float* __restrict__ ly,
                                                                 const float* __restrict__ lz, uint32_t n,
                                                                 const float4* __restrict__ pair_q,
-                                                                const uint32_t* __restrict__ pair_gidx) {
+                                                                const uint32_t* __restrict__ pair_gidx,
+                                                                const float4* __restrict__ pl_c,
+                                                                const float4* __restrict__ pl_n) {
   __shared__ SolveShared sh;
   __shared__ double tr[kAccN][kOneGroupAccThreads + 1];
   __shared__ double p1[kAccN][kOneGroupGroups];
   MH_PHASE(0);
   const bool acc_lane = threadIdx.x < kOneGroupAccThreads;
   uint32_t gi[kOneGroupBatch];
-  float4 q[kOneGroupBatch];
+  float4 q[kOneGroupBatch], pc[kOneGroupBatch], pn[kOneGroupBatch];
   float px[kOneGroupBatch], py[kOneGroupBatch], pz[kOneGroupBatch];
   if (acc_lane) {
 #pragma unroll
@@ -888,6 +922,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* 
       gi[u] = i < n ? pair_gidx[ic] : kNoMatch;
       q[u] = pair_q[ic];
       px[u] = lx[ic]; py[u] = ly[ic]; pz[u] = lz[ic];
+      if (PL) {
+        pc[u] = pl_c[ic];
+        pn[u] = pl_n[ic];
+        if (i >= n) pc[u].w = 0.f;
+      }
     }
   }
   // ... and neither do the pose and the parameters wait for the done flag: everything is in flight at once
@@ -899,13 +938,23 @@ __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* 
   const uint32_t done = st->done, inner0 = st->inner;
   if (done) return;
   if (!first && inner0 == 0) return;  // the previous solve already closed this ICP iteration
+  Acc a;
+  acc_zero(a);
+  double v[PL ? kGenN : 1];
+#pragma unroll
+  for (int j = 0; j < (PL ? kGenN : 1); j++) v[j] = 0.0;
   if (acc_lane) {
-    Acc a;
-    acc_zero(a);
     for (uint32_t base = 0;;) {
 #pragma unroll
-      for (int u = 0; u < kOneGroupBatch; u++)
+      for (int u = 0; u < kOneGroupBatch; u++) {
         if (gi[u] != kNoMatch) acc_pt2pt(a, T, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
+        if (PL && pc[u].w != 0.f) {
+          double r[kGenN];
+          acc_pt2pl_rows(r, T, px[u], py[u], pz[u], pc[u], pn[u], k.kernel, kparam, k.w_pt2pl);
+#pragma unroll
+          for (int j = 0; j < kGenN; j++) v[PL ? j : 0] += r[j];
+        }
+      }
       base += kOneGroupAccThreads * kOneGroupBatch;
       if (base >= n) break;
 #pragma unroll
@@ -915,33 +964,22 @@ __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* 
         gi[u] = i < n ? pair_gidx[ic] : kNoMatch;
         q[u] = pair_q[ic];
         px[u] = lx[ic]; py[u] = ly[ic]; pz[u] = lz[ic];
+        if (PL) {
+          pc[u] = pl_c[ic];
+          pn[u] = pl_n[ic];
+          if (i >= n) pc[u].w = 0.f;
+        }
       }
     }
     MH_PHASE(1);
-#pragma unroll
-    for (int j = 0; j < kAccN; j++) tr[j][threadIdx.x] = a.v[j];
   }
-  __syncthreads();
-  if (threadIdx.x < kAccN * kOneGroupGroups) {  // stage 1: row j, lanes [17 g, 17 g + 17)
-    const int j = threadIdx.x / kOneGroupGroups, g = threadIdx.x % kOneGroupGroups;
-    const int l0 = g * kOneGroupChunk;
-    double sum = tr[j][l0];
-#pragma unroll
-    for (int i = 1; i < kOneGroupChunk; i++)
-      if (l0 + i < kOneGroupAccThreads) sum += tr[j][l0 + i];
-    p1[j][g] = sum;
+  one_group_sum<kAccN>(a.v, acc_lane, tr, p1, sh.totA);
+  if (PL) {
+    one_group_sum<kAccN>(v, acc_lane, tr, p1, sh.totB);
+    one_group_sum<kGenN - kAccN>(v + (PL ? kAccN : 0), acc_lane, tr, p1, sh.totB + kAccN);
   }
-  __syncthreads();
-  MH_PHASE(2);
-  if (threadIdx.x < kAccN) {  // stage 2: the group sums in order
-    double sum = p1[threadIdx.x][0];
-#pragma unroll
-    for (int g = 1; g < kOneGroupGroups; g++) sum += p1[threadIdx.x][g];
-    sh.totA[threadIdx.x] = sum;
-  }
-  __syncthreads();
   MH_PHASE(3);
-  solve_body(st, sk, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true);
+  solve_body(st, sk, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true, PL);
 }
 
 // ================================================================================================
@@ -1502,7 +1540,7 @@ struct AlignJob {
     const SolveK* dsk = &ctx->d_params->sk;
     // everything a chunk launches, in stream order; used directly (profiling / MH_NO_GRAPH) or under stream capture
     const bool no_one_group = getenv("MH_NO_ONE_GROUP") != nullptr;  // (read per chunk: tests toggle it)
-    const bool one_group = variant == 5 && !pl && n <= kOneGroupMaxPoints && !no_one_group;  // accumulate + solve in one workgroup
+    const bool one_group = variant == 5 && n <= kOneGroupMaxPoints && !no_one_group;  // accumulate + solve in one workgroup
     auto enqueue_kernels = [&]() -> mh_status {
       double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
       const uint32_t nB = pl ? nb : 0u;
@@ -1510,8 +1548,9 @@ struct AlignJob {
         if (pl && variant == 5) {  // small layer: row kernel for the pairings, then their Gauss-Newton rows
           hipLaunchKernelGGL(k_match_pl16, dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state, dmk,
                              scan->x, scan->y, scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>());
-          hipLaunchKernelGGL(k_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
-                             ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
+          if (!one_group)
+            hipLaunchKernelGGL(k_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+                               ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
         } else if (pl)
           hipLaunchKernelGGL(k_match_pl<true>, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, dmk, scan->x, scan->y,
                              scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
@@ -1522,9 +1561,16 @@ struct AlignJob {
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
           if (one_group) {
             if (prof) prof_n++;
-            for (uint32_t in = 0; in < p->gn.max_inner_iterations; in++)
-              hipLaunchKernelGGL(k_accum_solve1, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, in == 0 ? 1u : 0u, dmk, dsk,
-                                 scan->x, scan->y, scan->z, n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>());
+            for (uint32_t in = 0; in < p->gn.max_inner_iterations; in++) {
+              if (pl)
+                hipLaunchKernelGGL(k_accum_solve1<true>, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, in == 0 ? 1u : 0u, dmk,
+                                   dsk, scan->x, scan->y, scan->z, n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+                                   ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>());
+              else
+                hipLaunchKernelGGL(k_accum_solve1<false>, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, in == 0 ? 1u : 0u, dmk,
+                                   dsk, scan->x, scan->y, scan->z, n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+                                   (const float4*)nullptr, (const float4*)nullptr);
+            }
             continue;
           }
           hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
