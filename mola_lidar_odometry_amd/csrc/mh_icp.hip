@@ -249,35 +249,10 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDevic
   }
 }
 
-// k_match16: the same step with a DPP row (16 lanes) per scan point (nn_search_row16): for small layers, where the
-// launch is pure latency; chosen automatically below kRowMaxPoints points.
+// k_match16 (below, after the point-to-plane row search it can carry along): the same step with a DPP row (16 lanes)
+// per scan point (nn_search_row16): for small layers, where the launch is pure latency; chosen automatically below
+// kRowMaxPoints points.
 constexpr uint32_t kRowMaxPoints = 32768;  // measured cross-over with the quad kernel: ~40 k points (C2 map)
-__global__ __launch_bounds__(kBlock) void k_match16(const IcpDeviceState* __restrict__ st, const float* __restrict__ lx,
-                                                    const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
-                                                    MapView map, float4* __restrict__ pair_q,
-                                                    uint32_t* __restrict__ pair_gidx) {
-  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
-  const uint32_t i = gl >> 4, r16 = gl & 15u;
-  const uint32_t ic = i < n ? i : n - 1;
-  const float x = lx[ic], y = ly[ic], z = lz[ic];
-  const uint32_t done = st->done;
-  double T[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) T[k] = st->T[k];
-  const float thr2 = st->cur_thr2, ang2 = st->cur_ang2;
-  if (done) return;    // wave-uniform
-  if (i >= n) return;  // whole rows
-  float px, py, pz;
-  transform_point(T, x, y, z, px, py, pz);
-  const NNResult r = nn_search_row16(map, r16, px, py, pz);
-  if (r16 == 0) {
-    const float n2 = (px * px + py * py) + pz * pz;
-    const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
-    pair_q[i] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
-    pair_gidx[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
-  }
-}
-
 // ================================================================================================
 // k_accum: point-to-point accumulation on stored pairings (inner GN steps, solver-granular path)
 // ================================================================================================
@@ -496,25 +471,10 @@ __global__ __launch_bounds__(kBlock) void k_match_pl(const IcpDeviceState* __res
   if (FUSED) block_sum_rows<kGenN>(v, lds, partials, pstride, blockIdx.x);
 }
 
-// k_match_pl16: Matcher_Point2Plane with a DPP row (16 lanes) per point, for small layers.  k_match_pl walks the 27
-// voxels in three dependent groups of probes + centroid loads (57 us per launch on a 1 k-point layer); here lane r
-// probes codes r and r + 16, reads the two statistics records of its voxels, and the row takes the minimum of
-// (d2 to the centroid, code) -- code order IS the reference's scan order -- in two round trips.  Pairings only; the
-// point-to-plane rows are accumulated by k_accum_plbuf.
-__global__ __launch_bounds__(kBlock) void k_match_pl16(const IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
-                                                       const float* __restrict__ lx, const float* __restrict__ ly,
-                                                       const float* __restrict__ lz, uint32_t n, MapView map,
-                                                       float4* __restrict__ pl_c, float4* __restrict__ pl_n) {
-  if (st->done) return;
-  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
-  const uint32_t i = gl >> 4, r16 = gl & 15u;
-  if (i >= n) return;  // whole rows
-  double T[12];
-#pragma unroll
-  for (int q = 0; q < 12; q++) T[q] = st->T[q];
-  const float thr = (float)kp->pl_thr[st->iter];
-  float px, py, pz;
-  transform_point(T, lx[i], ly[i], lz[i], px, py, pz);
+// the row's search for one transformed point: nearest planar voxel of the 27-block by centroid distance (first in code
+// order among equals), accepted iff |n.(p'-c)| < thr; every lane of the row returns the same centroid / normal / verdict
+__device__ __forceinline__ bool pl_row_search(const MapView& map, uint32_t r16, float px, float py, float pz, float thr,
+                                              f32x4& bc, f32x4& bn) {
   const float lim = 1.0e6f;
   const bool valid = isfinite(px) && isfinite(py) && isfinite(pz) && fabsf(px * map.inv_vs) < lim &&
                      fabsf(py * map.inv_vs) < lim && fabsf(pz * map.inv_vs) < lim;
@@ -552,7 +512,8 @@ __global__ __launch_bounds__(kBlock) void k_match_pl16(const IcpDeviceState* __r
   }
   best = row_min_key(best);
   const uint32_t wcode = nnkey_idx(best);
-  f32x4 bc = (f32x4)(0.f), bn = (f32x4)(0.f);
+  bc = (f32x4)(0.f);
+  bn = (f32x4)(0.f);
   bool ok = false;
   if (wcode != 0xFFFFFFFFu) {  // row-uniform: the owner lane hands its records to the row
     const bool from_b = wcode >= 16u;
@@ -568,9 +529,74 @@ __global__ __launch_bounds__(kBlock) void k_match_pl16(const IcpDeviceState* __r
     const float e = (bn.x * dx + bn.y * dy) + bn.z * dz;
     ok = fabsf(e) < thr;
   }
+  return ok;
+}
+
+// k_match_pl16: Matcher_Point2Plane with a DPP row (16 lanes) per point, for small layers.  k_match_pl walks the 27
+// voxels in three dependent groups of probes + centroid loads (57 us per launch on a 1 k-point layer); here lane r
+// probes codes r and r + 16, reads the two statistics records of its voxels, and the row takes the minimum of
+// (d2 to the centroid, code) -- code order IS the reference's scan order -- in two round trips.  Pairings only; the
+// point-to-plane rows are accumulated by k_accum_plbuf.
+__global__ __launch_bounds__(kBlock) void k_match_pl16(const IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
+                                                       const float* __restrict__ lx, const float* __restrict__ ly,
+                                                       const float* __restrict__ lz, uint32_t n, MapView map,
+                                                       float4* __restrict__ pl_c, float4* __restrict__ pl_n) {
+  if (st->done) return;
+  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = gl >> 4, r16 = gl & 15u;
+  if (i >= n) return;  // whole rows
+  double T[12];
+#pragma unroll
+  for (int q = 0; q < 12; q++) T[q] = st->T[q];
+  const float thr = (float)kp->pl_thr[st->iter];
+  float px, py, pz;
+  transform_point(T, lx[i], ly[i], lz[i], px, py, pz);
+  f32x4 bc, bn;
+  const bool ok = pl_row_search(map, r16, px, py, pz, thr, bc, bn);
   if (r16 == 0) {
     pl_c[i] = make_float4(bc.x, bc.y, bc.z, ok ? 1.f : 0.f);
     pl_n[i] = make_float4(bn.x, bn.y, bn.z, 0.f);
+  }
+}
+
+// k_match16: a DPP row (16 lanes) per scan point for layers up to kRowMaxPoints (see nn_search_row16).
+// PL: the same launch also runs Matcher_Point2Plane for the point (pl_row_search, pairings into pl_c / pl_n): the NDT
+// pipeline's two matchers in one kernel instead of two.
+template <bool PL>
+__global__ __launch_bounds__(kBlock) void k_match16(const IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
+                                                    const float* __restrict__ lx, const float* __restrict__ ly,
+                                                    const float* __restrict__ lz, uint32_t n, MapView map,
+                                                    float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
+                                                    float4* __restrict__ pl_c, float4* __restrict__ pl_n) {
+  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = gl >> 4, r16 = gl & 15u;
+  const uint32_t ic = i < n ? i : n - 1;
+  const float x = lx[ic], y = ly[ic], z = lz[ic];
+  const uint32_t done = st->done;
+  double T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = st->T[k];
+  const float thr2 = st->cur_thr2, ang2 = st->cur_ang2;
+  float pl_thr = 0.f;
+  if (PL) pl_thr = (float)kp->pl_thr[st->iter];
+  if (done) return;    // wave-uniform
+  if (i >= n) return;  // whole rows
+  float px, py, pz;
+  transform_point(T, x, y, z, px, py, pz);
+  const NNResult r = nn_search_row16(map, r16, px, py, pz);
+  if (r16 == 0) {
+    const float n2 = (px * px + py * py) + pz * pz;
+    const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
+    pair_q[i] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
+    pair_gidx[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+  }
+  if (PL) {
+    f32x4 bc, bn;
+    const bool ok = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
+    if (r16 == 0) {
+      pl_c[i] = make_float4(bc.x, bc.y, bc.z, ok ? 1.f : 0.f);
+      pl_n[i] = make_float4(bn.x, bn.y, bn.z, 0.f);
+    }
   }
 }
 
@@ -1545,7 +1571,9 @@ struct AlignJob {
       double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
       const uint32_t nB = pl ? nb : 0u;
       for (uint32_t j = 0; j < m; j++) {
-        if (pl && variant == 5) {  // small layer: row kernel for the pairings, then their Gauss-Newton rows
+        const bool both16 = pl && variant == 5 && one_group;  // both matchers in one launch (k_match16<true>)
+        if (both16) {
+        } else if (pl && variant == 5) {  // small layer: row kernel for the pairings, then their Gauss-Newton rows
           hipLaunchKernelGGL(k_match_pl16, dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state, dmk,
                              scan->x, scan->y, scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>());
           if (!one_group)
@@ -1556,8 +1584,14 @@ struct AlignJob {
                              scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
         if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n], s));
         if (variant == 5) {
-          hipLaunchKernelGGL(k_match16, dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
-                             scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>());
+          if (both16)
+            hipLaunchKernelGGL(k_match16<true>, dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
+                               dmk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+                               ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>());
+          else
+            hipLaunchKernelGGL(k_match16<false>, dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
+                               dmk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+                               (float4*)nullptr, (float4*)nullptr);
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
           if (one_group) {
             if (prof) prof_n++;
