@@ -8,18 +8,20 @@ rng = np.random.default_rng(0)
 w = synth.workload_c2()
 ctx = capi.Context(0)
 m = capi.Map(ctx, w.voxel_size, w.cap).build(w.map_xyz[:100000])
+order = [int(a) for a in os.environ.get("FIT_ITERS", "1,2,5,10,20,40").split(",")]
 for npts in (900, 4000):
     s = capi.Scan(ctx, w.scan_xyz[rng.choice(len(w.scan_xyz), npts, replace=False)])
-    xs, ys = [], []
-    for iters in (1, 2, 5, 10, 20, 40):
+    for iters in order:
         thr = np.full(iters, w.threshold[0]); kp = np.full(iters, w.kernel_param[0])
         for poll in (0, iters):
             p = capi.ICPParams(max_iterations=iters, threshold=thr, kernel_param=kp, disable_stall_test=True, poll_every=poll)
             for _ in range(3):
                 capi.icp_align(m, s, w.T_guess, p)
-            t0 = time.perf_counter()
-            R = 30
-            for _ in range(R):
+            ts = []
+            for _ in range(30):
+                t0 = time.perf_counter()
                 capi.icp_align(m, s, w.T_guess, p)
-            dt = (time.perf_counter() - t0) / R * 1e6
-            print("n", npts, "iters", iters, "poll", poll, "us per align %.1f" % dt, "per iter %.1f" % (dt / iters), "graph" if not os.environ.get("MH_NO_GRAPH") else "direct")
+                ts.append((time.perf_counter() - t0) * 1e6)
+            ts = np.array(ts)
+            print("n", npts, "iters", iters, "poll", poll, "us per align: median %.1f mean %.1f max %.1f" % (np.median(ts), ts.mean(), ts.max()),
+                  "per iter %.1f" % (np.median(ts) / iters))
