@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restri
   acc_zero(a);
 #pragma unroll
   for (int u = 0; u < kAccPPT; u++)
-    if (gi[u] != kNoMatch) acc_pt2pt(a, T, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
+    acc_pt2pt_masked(a, T, gi[u] != kNoMatch, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
   block_sum_rows<kAccN>(a.v, bs, partials, pstride, bid);
 }
 
@@ -973,7 +973,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* 
     for (uint32_t base = 0;;) {
 #pragma unroll
       for (int u = 0; u < kOneGroupBatch; u++) {
-        if (gi[u] != kNoMatch) acc_pt2pt(a, T, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
+        acc_pt2pt_masked(a, T, gi[u] != kNoMatch, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
         if (PL && pc[u].w != 0.f) {
           double r[kGenN];
           acc_pt2pl_rows(r, T, px[u], py[u], pz[u], pc[u], pn[u], k.kernel, kparam, k.w_pt2pl);

@@ -702,6 +702,9 @@ __device__ __forceinline__ void acc_zero(Acc& a) {
 
 __device__ __forceinline__ void acc_pt2pt(Acc& a, const double* __restrict__ T, float lxf, float lyf, float lzf, float qxf,
                                           float qyf, float qzf, uint32_t kernel, double kparam, double wpair) {
+  // fp64 moments held to a relative tolerance, not bit-compared: let the multiply-adds fuse here (126 -> ~75
+  // instructions per point); everything that decides WHICH points pair stays un-fused (file header)
+#pragma clang fp contract(fast)
   const double lx = lxf, ly = lyf, lz = lzf;
   const double ex = T[0] * lx + T[1] * ly + T[2] * lz + T[3] - (double)qxf;
   const double ey = T[4] * lx + T[5] * ly + T[6] * lz + T[7] - (double)qyf;
@@ -723,6 +726,17 @@ __device__ __forceinline__ void acc_pt2pt(Acc& a, const double* __restrict__ T, 
   a.v[15] += w * (lx * ry - ly * rx);
   a.v[16] += w * e2;
   a.v[17] += 1.0;
+}
+
+// The same without a branch: an unpaired (or non-finite) point is accumulated with weight 0 on sanitised inputs, which
+// leaves every sum unchanged.  Straight-line code lets the compiler interleave the dependent fp64 chains of the
+// several points a lane handles (under `if (paired)` each point's chain ran on its own).
+__device__ __forceinline__ void acc_pt2pt_masked(Acc& a, const double* __restrict__ T, bool paired, float lxf, float lyf,
+                                                 float lzf, float qxf, float qyf, float qzf, uint32_t kernel, double kparam,
+                                                 double wpair) {
+  acc_pt2pt(a, T, paired ? lxf : 0.f, paired ? lyf : 0.f, paired ? lzf : 0.f, paired ? qxf : 0.f, paired ? qyf : 0.f,
+            paired ? qzf : 0.f, kernel, kparam, paired ? wpair : 0.0);
+  a.v[17] -= paired ? 0.0 : 1.0;  // acc_pt2pt counted it
 }
 
 // Sum over the 64 lanes of a wave, result valid in every lane... of interest only in lane 0.

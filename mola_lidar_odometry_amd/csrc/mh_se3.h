@@ -172,6 +172,7 @@ MH_HD void cswap(bool c, double& a, double& b) {
 }
 
 MH_HD bool ldlt_solve6(const double Hfull[36], const double b[6], double x[6]) {
+#pragma clang fp contract(fast)  // one thread's dependent fp64 chain: fused multiply-adds halve it
   double A[6][6], y[6], invd[6];
   int piv[6];
 #pragma unroll

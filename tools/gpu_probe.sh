@@ -1,3 +1,5 @@
 #!/bin/bash
 cd /root/repo
-FIT_ITERS=5,10,5,1,5 python tools/align_fit.py 2>&1 | head -12
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+MH_NO_GRAPH=1 python tools/og_sweep.py
+python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-330
