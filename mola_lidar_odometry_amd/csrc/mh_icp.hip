@@ -252,6 +252,7 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDevic
 // k_match16 (below, after the point-to-plane row search it can carry along): the same step with a DPP row (16 lanes)
 // per scan point (nn_search_row16): for small layers, where the launch is pure latency; chosen automatically below
 // kRowMaxPoints points.
+constexpr uint32_t kFused16MaxPoints = 12288;  // up to here the row kernel also accumulates the first Gauss-Newton step
 constexpr uint32_t kRowMaxPoints = 32768;  // measured cross-over with the quad kernel: ~40 k points (C2 map)
 // ================================================================================================
 // k_accum: point-to-point accumulation on stored pairings (inner GN steps, solver-granular path)
@@ -562,12 +563,17 @@ __global__ __launch_bounds__(kBlock) void k_match_pl16(const IcpDeviceState* __r
 // k_match16: a DPP row (16 lanes) per scan point for layers up to kRowMaxPoints (see nn_search_row16).
 // PL: the same launch also runs Matcher_Point2Plane for the point (pl_row_search, pairings into pl_c / pl_n): the NDT
 // pipeline's two matchers in one kernel instead of two.
-template <bool PL>
+// FUSED: the row leaders also accumulate the first Gauss-Newton step of their pairing and the workgroup writes one
+// partial per row of sums (16 points per workgroup): layers of 2-32 k points -- what lidar3d-default.yaml really feeds --
+// run match | solve | accumulate | solve, four launches per iteration instead of five.
+template <bool PL, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_match16(const IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
                                                     const float* __restrict__ lx, const float* __restrict__ ly,
                                                     const float* __restrict__ lz, uint32_t n, MapView map,
                                                     float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
-                                                    float4* __restrict__ pl_c, float4* __restrict__ pl_n) {
+                                                    float4* __restrict__ pl_c, float4* __restrict__ pl_n,
+                                                    double* __restrict__ partials, uint32_t pstride) {
+  __shared__ double rows[FUSED ? kAccN : 1][kBlock / 16 + 1];
   const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
   const uint32_t i = gl >> 4, r16 = gl & 15u;
   const uint32_t ic = i < n ? i : n - 1;
@@ -579,23 +585,48 @@ __global__ __launch_bounds__(kBlock) void k_match16(const IcpDeviceState* __rest
   const float thr2 = st->cur_thr2, ang2 = st->cur_ang2;
   float pl_thr = 0.f;
   if (PL) pl_thr = (float)kp->pl_thr[st->iter];
-  if (done) return;    // wave-uniform
-  if (i >= n) return;  // whole rows
-  float px, py, pz;
-  transform_point(T, x, y, z, px, py, pz);
-  const NNResult r = nn_search_row16(map, r16, px, py, pz);
-  if (r16 == 0) {
+  uint32_t kernel = 0;
+  double kparam = 0.0, wpair = 0.0;
+  if (FUSED) {
+    kernel = kp->kernel;
+    wpair = kp->w_pt2pt;
+    kparam = st->cur_kparam;
+  }
+  if (done) return;              // grid-uniform
+  if (!FUSED && i >= n) return;  // whole rows (FUSED: they stay for the barrier)
+  Acc a;
+  acc_zero(a);
+  if (i < n) {  // row-uniform
+    float px, py, pz;
+    transform_point(T, x, y, z, px, py, pz);
+    const NNResult r = nn_search_row16(map, r16, px, py, pz);
     const float n2 = (px * px + py * py) + pz * pz;
     const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
-    pair_q[i] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
-    pair_gidx[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
-  }
-  if (PL) {
-    f32x4 bc, bn;
-    const bool ok = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
     if (r16 == 0) {
-      pl_c[i] = make_float4(bc.x, bc.y, bc.z, ok ? 1.f : 0.f);
-      pl_n[i] = make_float4(bn.x, bn.y, bn.z, 0.f);
+      pair_q[i] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
+      pair_gidx[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+    }
+    if (FUSED && r16 == 0) acc_pt2pt_masked(a, T, ok, x, y, z, r.pt.x, r.pt.y, r.pt.z, kernel, kparam, wpair);
+    if (PL) {
+      f32x4 bc, bn;
+      const bool okp = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
+      if (r16 == 0) {
+        pl_c[i] = make_float4(bc.x, bc.y, bc.z, okp ? 1.f : 0.f);
+        pl_n[i] = make_float4(bn.x, bn.y, bn.z, 0.f);
+      }
+    }
+  }
+  if (FUSED) {  // 16 row leaders per workgroup -> one partial per sum, fixed order
+    if (r16 == 0) {
+#pragma unroll
+      for (int j = 0; j < kAccN; j++) rows[j][threadIdx.x >> 4] = a.v[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < kAccN) {
+      double sum = rows[threadIdx.x][0];
+#pragma unroll
+      for (int q = 1; q < (int)(kBlock / 16); q++) sum += rows[threadIdx.x][q];
+      partials[threadIdx.x * pstride + blockIdx.x] = sum;
     }
   }
 }
@@ -1427,6 +1458,7 @@ struct AlignJob {
   SolveK sk{};
   uint32_t nb = 0, nbm = 0, nba = 0, enqueued = 0, chunk = 0, prof_n = 0;
   bool auto_chunk = false;
+  bool fused16 = false;  // row kernel accumulates the first Gauss-Newton step itself (layers above the one-workgroup size)
   int variant = 0;
   bool finished = false, trivial = false;
   bool prof = false;  // time this job's match kernels with events (then it cannot use the graph path)
@@ -1528,7 +1560,11 @@ struct AlignJob {
       if (variant == 1 && map->view().ndt) variant = 0;  // "x" walks contiguous z-runs; NDT maps interleave statistics records
     }
     nba = nblk_acc(scan->n);
-    nbm = variant >= 4 ? nba : nb;  // who writes the partials of the first Gauss-Newton step
+    // (measured per iteration, fused vs k_accum: 31.0 vs 33.8 us at 4 k points, 33.2 vs 35.0 at 8 k, equal at 16 k,
+    //  45.9 vs 41.8 at 32 k -- one partial row per 16 points makes the solve's reduction the longer pole there)
+    fused16 = variant == 5 && !pl && scan->n <= kFused16MaxPoints && getenv("MH_NO_FUSE16") == nullptr;
+    // who writes the partials of the first Gauss-Newton step: the row kernel (16 points per workgroup), k_accum, or k_match
+    nbm = fused16 ? (uint32_t)((16ull * scan->n + kBlock - 1) / kBlock) : (variant >= 4 ? nba : nb);
     MH_TRY(ctx->partials.reserve((size_t)kGenN * (nbm > nb ? nbm : nb) * sizeof(double)));
     // poll_every == 0: the first chunk is sized by what the previous alignment of this context needed (consecutive scans
     // of a sequence converge in about as many iterations: one host round trip instead of three), later chunks are short
@@ -1584,14 +1620,18 @@ struct AlignJob {
                              scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
         if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n], s));
         if (variant == 5) {
-          if (both16)
-            hipLaunchKernelGGL(k_match16<true>, dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
+          if (fused16 && !one_group)
+            hipLaunchKernelGGL((k_match16<false, true>), dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, dmk, scan->x, scan->y,
+                               scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (float4*)nullptr,
+                               (float4*)nullptr, part, nbm);
+          else if (both16)
+            hipLaunchKernelGGL((k_match16<true, false>), dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
                                dmk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
-                               ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>());
+                               ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), (double*)nullptr, 0u);
           else
-            hipLaunchKernelGGL(k_match16<false>, dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
+            hipLaunchKernelGGL((k_match16<false, false>), dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
                                dmk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
-                               (float4*)nullptr, (float4*)nullptr);
+                               (float4*)nullptr, (float4*)nullptr, (double*)nullptr, 0u);
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
           if (one_group) {
             if (prof) prof_n++;
@@ -1607,8 +1647,9 @@ struct AlignJob {
             }
             continue;
           }
-          hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
-                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
+          if (!fused16)
+            hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+                               ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
         } else if (variant == 4) {
           hipLaunchKernelGGL(k_match4, dim3((uint32_t)((4ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
                              scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>()

@@ -503,7 +503,8 @@ def test_profile_fields(ctx, small):
     assert r["n_match_launches"] == w.n_iters and r["match_kernel_ms"] > 0 and r["total_ms"] >= r["match_kernel_ms"]
 
 
-@pytest.mark.parametrize("env", [{"MH_MATCH": "s"}, {"MH_MATCH": "s", "MH_NO_ONE_GROUP": "1"}, {"MH_MATCH": "q"},
+@pytest.mark.parametrize("env", [{"MH_MATCH": "s"}, {"MH_MATCH": "s", "MH_NO_ONE_GROUP": "1"},
+                                 {"MH_MATCH": "s", "MH_NO_ONE_GROUP": "1", "MH_NO_FUSE16": "1"}, {"MH_MATCH": "q"},
                                  {"MH_MATCH": "p"}, {"MH_MATCH": "x"}, {"MH_MATCH": "q", "MH_NO_GRAPH": "1"}])
 @pytest.mark.parametrize("n_scan", [2000, 5000])
 def test_every_kernel_variant_matches_the_oracle(ctx, oracle, env, n_scan, monkeypatch):

@@ -2,4 +2,3 @@
 cd /root/repo
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 MH_NO_GRAPH=1 python tools/og_sweep.py
-python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-330
