@@ -472,8 +472,12 @@ __global__ __launch_bounds__(kBlock) void k_match_pl(const IcpDeviceState* __res
   if (FUSED) block_sum_rows<kGenN>(v, lds, partials, pstride, blockIdx.x);
 }
 
-// the row's search for one transformed point: nearest planar voxel of the 27-block by centroid distance (first in code
-// order among equals), accepted iff |n.(p'-c)| < thr; every lane of the row returns the same centroid / normal / verdict
+// Matcher_Point2Plane with a DPP row (16 lanes) per point, for small layers.  k_match_pl walks the 27 voxels in three
+// dependent groups of probes + centroid loads (57 us per launch on a 1 k-point layer); here lane r probes codes r and
+// r + 16, reads the two statistics records of its voxels, and the row takes the minimum of (d2 to the centroid, code) --
+// code order IS the reference's scan order -- in two round trips: nearest planar voxel of the 27-block by centroid
+// distance (first in code order among equals), accepted iff |n.(p'-c)| < thr; every lane of the row returns the same
+// centroid / normal / verdict.  Runs inside k_match16<true>.
 __device__ __forceinline__ bool pl_row_search(const MapView& map, uint32_t r16, float px, float py, float pz, float thr,
                                               f32x4& bc, f32x4& bn) {
   const float lim = 1.0e6f;
@@ -531,33 +535,6 @@ __device__ __forceinline__ bool pl_row_search(const MapView& map, uint32_t r16, 
     ok = fabsf(e) < thr;
   }
   return ok;
-}
-
-// k_match_pl16: Matcher_Point2Plane with a DPP row (16 lanes) per point, for small layers.  k_match_pl walks the 27
-// voxels in three dependent groups of probes + centroid loads (57 us per launch on a 1 k-point layer); here lane r
-// probes codes r and r + 16, reads the two statistics records of its voxels, and the row takes the minimum of
-// (d2 to the centroid, code) -- code order IS the reference's scan order -- in two round trips.  Pairings only; the
-// point-to-plane rows are accumulated by k_accum_plbuf.
-__global__ __launch_bounds__(kBlock) void k_match_pl16(const IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
-                                                       const float* __restrict__ lx, const float* __restrict__ ly,
-                                                       const float* __restrict__ lz, uint32_t n, MapView map,
-                                                       float4* __restrict__ pl_c, float4* __restrict__ pl_n) {
-  if (st->done) return;
-  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
-  const uint32_t i = gl >> 4, r16 = gl & 15u;
-  if (i >= n) return;  // whole rows
-  double T[12];
-#pragma unroll
-  for (int q = 0; q < 12; q++) T[q] = st->T[q];
-  const float thr = (float)kp->pl_thr[st->iter];
-  float px, py, pz;
-  transform_point(T, lx[i], ly[i], lz[i], px, py, pz);
-  f32x4 bc, bn;
-  const bool ok = pl_row_search(map, r16, px, py, pz, thr, bc, bn);
-  if (r16 == 0) {
-    pl_c[i] = make_float4(bc.x, bc.y, bc.z, ok ? 1.f : 0.f);
-    pl_n[i] = make_float4(bn.x, bn.y, bn.z, 0.f);
-  }
 }
 
 // k_match16: a DPP row (16 lanes) per scan point for layers up to kRowMaxPoints (see nn_search_row16).
@@ -953,7 +930,7 @@ __device__ __forceinline__ void one_group_sum(const double* vals, bool acc_lane,
 }
 
 // PL: the layer also carries Matcher_Point2Plane pairings (pl_c.w != 0: centroid + normal of the paired voxel, written by
-// k_match_pl16) whose 29 generic rows are accumulated alongside and summed in two more passes of the same buffer.
+// k_match16<true>) whose 29 generic rows are accumulated alongside and summed in two more passes of the same buffer.
 template <bool PL>
 __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* __restrict__ st, uint32_t first,
                                                                 const MatchK* __restrict__ kp, const SolveK* __restrict__ sk,
@@ -1607,15 +1584,8 @@ struct AlignJob {
       double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
       const uint32_t nB = pl ? nb : 0u;
       for (uint32_t j = 0; j < m; j++) {
-        const bool both16 = pl && variant == 5 && one_group;  // both matchers in one launch (k_match16<true>)
-        if (both16) {
-        } else if (pl && variant == 5) {  // small layer: row kernel for the pairings, then their Gauss-Newton rows
-          hipLaunchKernelGGL(k_match_pl16, dim3((uint32_t)((16ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state, dmk,
-                             scan->x, scan->y, scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>());
-          if (!one_group)
-            hipLaunchKernelGGL(k_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
-                               ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
-        } else if (pl)
+        const bool both16 = pl && variant == 5;  // small layer: both matchers in one launch (k_match16<true>)
+        if (pl && !both16)
           hipLaunchKernelGGL(k_match_pl<true>, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, dmk, scan->x, scan->y,
                              scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
         if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n], s));
@@ -1633,6 +1603,9 @@ struct AlignJob {
                                dmk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
                                (float4*)nullptr, (float4*)nullptr, (double*)nullptr, 0u);
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
+          if (both16 && !one_group)  // Gauss-Newton rows of the point-to-plane pairings just written
+            hipLaunchKernelGGL(k_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+                               ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
           if (one_group) {
             if (prof) prof_n++;
             for (uint32_t in = 0; in < p->gn.max_inner_iterations; in++) {
