@@ -115,27 +115,34 @@ struct BlockSum {
 };
 
 template <int NV>
-__device__ __forceinline__ void block_sum_rows(const double* v, BlockSum<NV>& sh, double* __restrict__ partials,
-                                               uint32_t pstride, uint32_t bid) {
+__device__ __forceinline__ void block_sum_rows_raw(const double* v, double (*tr)[kBlock + 1], double* p1,
+                                                   double* __restrict__ partials, uint32_t pstride, uint32_t bid) {
+  constexpr int G = BlockSum<NV>::kGroups, C = BlockSum<NV>::kChunk;
 #pragma unroll
-  for (int j = 0; j < NV; j++) sh.tr[j][threadIdx.x] = v[j];
+  for (int j = 0; j < NV; j++) tr[j][threadIdx.x] = v[j];
   __syncthreads();
-  if (threadIdx.x < NV * BlockSum<NV>::kGroups) {
-    const int j = threadIdx.x / BlockSum<NV>::kGroups, g = threadIdx.x % BlockSum<NV>::kGroups;
-    const int l0 = g * BlockSum<NV>::kChunk;
-    double sum = sh.tr[j][l0];
+  if (threadIdx.x < NV * G) {
+    const int j = threadIdx.x / G, g = threadIdx.x % G;
+    const int l0 = g * C;
+    double sum = tr[j][l0];
 #pragma unroll
-    for (int i = 1; i < BlockSum<NV>::kChunk; i++)
-      if (l0 + i < (int)kBlock) sum += sh.tr[j][l0 + i];
-    sh.p1[j][g] = sum;
+    for (int i = 1; i < C; i++)
+      if (l0 + i < (int)kBlock) sum += tr[j][l0 + i];
+    p1[j * G + g] = sum;
   }
   __syncthreads();
   if (threadIdx.x < NV) {
-    double sum = sh.p1[threadIdx.x][0];
+    double sum = p1[threadIdx.x * G];
 #pragma unroll
-    for (int g = 1; g < BlockSum<NV>::kGroups; g++) sum += sh.p1[threadIdx.x][g];
+    for (int g = 1; g < G; g++) sum += p1[threadIdx.x * G + g];
     partials[threadIdx.x * pstride + bid] = sum;
   }
+}
+
+template <int NV>
+__device__ __forceinline__ void block_sum_rows(const double* v, BlockSum<NV>& sh, double* __restrict__ partials,
+                                               uint32_t pstride, uint32_t bid) {
+  block_sum_rows_raw<NV>(v, sh.tr, &sh.p1[0][0], partials, pstride, bid);
 }
 
 // ================================================================================================
@@ -608,29 +615,59 @@ __global__ __launch_bounds__(kBlock) void k_match16(const IcpDeviceState* __rest
   }
 }
 
-// Gauss-Newton rows of the stored point-to-plane pairings (`first`: also when the iteration has just begun)
-__global__ __launch_bounds__(kBlock) void k_accum_plbuf(const IcpDeviceState* __restrict__ st, uint32_t first,
-                                                        const MatchK* __restrict__ kp,
-                                                        const float* __restrict__ lx, const float* __restrict__ ly,
-                                                        const float* __restrict__ lz, uint32_t n,
-                                                        const float4* __restrict__ pl_c, const float4* __restrict__ pl_n,
-                                                        double* __restrict__ partials, uint32_t pstride) {
-  __shared__ BlockSum<kGenN> lds;
+// Point-to-point moments AND the Gauss-Newton rows of the stored point-to-plane pairings in one launch (NDT maps,
+// layers above the one-workgroup size; `first`: also when the iteration has just begun): four points per lane, both
+// kinds of rows, the two workgroup sums share one transposed buffer.  partials / partials_b both get gridDim.x columns.
+__global__ __launch_bounds__(kBlock) void k_accum_both(const IcpDeviceState* __restrict__ st, uint32_t first,
+                                                       const MatchK* __restrict__ kp, const float* __restrict__ lx,
+                                                       const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                       const float4* __restrict__ pair_q,
+                                                       const uint32_t* __restrict__ pair_gidx,
+                                                       const float4* __restrict__ pl_c, const float4* __restrict__ pl_n,
+                                                       double* __restrict__ partials, double* __restrict__ partials_b,
+                                                       uint32_t pstride) {
+  __shared__ double tr[kGenN][kBlock + 1];
+  __shared__ double p1[(kAccN * BlockSum<kAccN>::kGroups > kGenN * BlockSum<kGenN>::kGroups) ? kAccN * BlockSum<kAccN>::kGroups
+                                                                                               : kGenN * BlockSum<kGenN>::kGroups];
   if (st->done || (!first && st->inner == 0)) return;
-  const MatchK k = *kp;
   double T[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) T[i] = st->T[i];
-  const double kparam = k.kparam[st->iter];
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const MatchK k = *kp;
+  const double kparam = st->cur_kparam;
+  const uint32_t bid = blockIdx.x;
+  uint32_t gi[kAccPPT];
+  float4 q[kAccPPT], pc[kAccPPT], pn[kAccPPT];
+  float px[kAccPPT], py[kAccPPT], pz[kAccPPT];
+#pragma unroll
+  for (int u = 0; u < kAccPPT; u++) {  // all loads first (clamped index), then the arithmetic
+    const uint32_t i = (bid * kAccPPT + (uint32_t)u) * kBlock + threadIdx.x;
+    const uint32_t ic = i < n ? i : n - 1;
+    gi[u] = i < n ? pair_gidx[ic] : kNoMatch;
+    q[u] = pair_q[ic];
+    px[u] = lx[ic]; py[u] = ly[ic]; pz[u] = lz[ic];
+    pc[u] = pl_c[ic];
+    pn[u] = pl_n[ic];
+    if (i >= n) pc[u].w = 0.f;
+  }
+  Acc a;
+  acc_zero(a);
   double v[kGenN];
 #pragma unroll
   for (int j = 0; j < kGenN; j++) v[j] = 0.0;
-  if (i < n) {
-    const float4 c = pl_c[i];
-    if (c.w != 0.f) acc_pt2pl_rows(v, T, lx[i], ly[i], lz[i], c, pl_n[i], k.kernel, kparam, k.w_pt2pl);
+#pragma unroll
+  for (int u = 0; u < kAccPPT; u++) {
+    acc_pt2pt_masked(a, T, gi[u] != kNoMatch, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
+    if (pc[u].w != 0.f) {
+      double r[kGenN];
+      acc_pt2pl_rows(r, T, px[u], py[u], pz[u], pc[u], pn[u], k.kernel, kparam, k.w_pt2pl);
+#pragma unroll
+      for (int j = 0; j < kGenN; j++) v[j] += r[j];
+    }
   }
-  block_sum_rows<kGenN>(v, lds, partials, pstride, blockIdx.x);
+  block_sum_rows_raw<kAccN>(a.v, tr, p1, partials, pstride, bid);
+  __syncthreads();  // the buffer is reused
+  block_sum_rows_raw<kGenN>(v, tr, p1, partials_b, pstride, bid);
 }
 
 constexpr int kSolveThreads = 512;  // 2 waves per SIMD -> 256 VGPRs for the serial 6x6 code of thread 0
@@ -1582,7 +1619,9 @@ struct AlignJob {
     const bool one_group = variant == 5 && n <= kOneGroupMaxPoints && !no_one_group;  // accumulate + solve in one workgroup
     auto enqueue_kernels = [&]() -> mh_status {
       double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
-      const uint32_t nB = pl ? nb : 0u;
+      const bool rows16 = pl && variant == 5;                  // NDT layer handled by the row kernel
+      const uint32_t nB = pl ? (rows16 ? nba : nb) : 0u;       // columns of the point-to-plane partials of the FIRST step
+      const uint32_t nBi = pl ? nba : 0u;                      // ... of the inner steps (k_accum_both)
       for (uint32_t j = 0; j < m; j++) {
         const bool both16 = pl && variant == 5;  // small layer: both matchers in one launch (k_match16<true>)
         if (pl && !both16)
@@ -1603,9 +1642,6 @@ struct AlignJob {
                                dmk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
                                (float4*)nullptr, (float4*)nullptr, (double*)nullptr, 0u);
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
-          if (both16 && !one_group)  // Gauss-Newton rows of the point-to-plane pairings just written
-            hipLaunchKernelGGL(k_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
-                               ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
           if (one_group) {
             if (prof) prof_n++;
             for (uint32_t in = 0; in < p->gn.max_inner_iterations; in++) {
@@ -1620,7 +1656,11 @@ struct AlignJob {
             }
             continue;
           }
-          if (!fused16)
+          if (both16)  // both kinds of Gauss-Newton rows of the pairings just written
+            hipLaunchKernelGGL(k_accum_both, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+                               ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), ctx->pl_c.as<float4>(),
+                               ctx->pl_n.as<float4>(), part, partb, nba);
+          else if (!fused16)
             hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                                ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
         } else if (variant == 4) {
@@ -1646,13 +1686,15 @@ struct AlignJob {
         hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nbm, nbm,
                            (const double*)partb, nB, nB);
         for (uint32_t in = 1; in < p->gn.max_inner_iterations; in++) {
-          hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
-                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
           if (pl)
-            hipLaunchKernelGGL(k_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
-                               ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
+            hipLaunchKernelGGL(k_accum_both, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
+                               ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), ctx->pl_c.as<float4>(),
+                               ctx->pl_n.as<float4>(), part, partb, nba);
+          else
+            hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
+                               ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
           hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nba, nba,
-                             (const double*)partb, nB, nB);
+                             (const double*)partb, nBi, nBi);
         }
       }
       if (p->compute_covariance) {  // no-ops unless the loop has terminated
@@ -1663,7 +1705,7 @@ struct AlignJob {
           hipLaunchKernelGGL(k_cov_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, scan->x, scan->y, scan->z, n,
                              ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
         hipLaunchKernelGGL(k_cov_finalize, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, 0u, part, nb, nb,
-                           (const double*)partb, nB, nB);
+                           (const double*)partb, pl ? nb : 0u, pl ? nb : 0u);  // (the covariance kernels write nb columns)
       }
       MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
       return MH_OK;
