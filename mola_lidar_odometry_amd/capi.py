@@ -386,6 +386,13 @@ class Scan:
 
     def update_interleaved(self, records, off_x=0, off_y=4, off_z=8, off_t=-1):
         """records: C-contiguous float32 [n,k] rows (KITTI .bin: k=4) -- one copy, de-interleaved on the device."""
+        if hasattr(records, "data_ptr"):  # a contiguous float32 torch tensor on the context's device: read in place
+            import torch  # plumbing only
+            assert records.is_cuda and records.dtype == torch.float32 and records.is_contiguous() and records.dim() == 2
+            torch.cuda.current_stream(records.device).synchronize()
+            _chk(lib().mh_scan_update_aos(self._h, C.c_void_p(records.data_ptr()), records.shape[0], records.shape[1] * 4,
+                                          off_x, off_y, off_z, off_t, MEM_DEVICE))
+            return
         a = np.ascontiguousarray(records, dtype=np.float32)
         assert a.ndim == 2
         _chk(lib().mh_scan_update_aos(self._h, _vp(a), a.shape[0], a.shape[1] * 4, off_x, off_y, off_z, off_t, MEM_HOST))

@@ -132,12 +132,13 @@ def test_point2plane_matcher_parity(ctx, oracle, thr):
         capi.nn_search_pt2pl(capi.Map(ctx, 1.0, 20).build(pts), gs, I12, thr)
 
 
-@pytest.mark.parametrize("inner,match,n_scan", [(1, None, 5000), (2, None, 5000), (2, "p", 5000), (2, None, 1500)])
+@pytest.mark.parametrize("inner,match,n_scan", [(1, None, 5000), (2, None, 5000), (2, "p", 5000), (2, "q", 5000),
+                                                (2, None, 1500)])
 def test_align_ndt_pipeline_matches_oracle(ctx, oracle, inner, match, n_scan, monkeypatch):
     """The lidar3d-ndt.yaml ICP block: Matcher_Point2Plane + Matcher_Points_DistanceThreshold feeding one
     Gauss-Newton solve per iteration (yaml:184-210), stall thresholds 5e-4 (yaml:173-174).  Kernel paths: both
     matchers in the row kernel + separate accumulations (5000 points), everything in one workgroup (1500), and the
-    one-lane-per-point matchers of large layers (MH_MATCH=p)."""
+    matchers of large layers (MH_MATCH=p: one lane per point for both; q: quad kernel for the points)."""
     if match:
         monkeypatch.setenv("MH_MATCH", match)
     pts = _ndt_cloud(11)

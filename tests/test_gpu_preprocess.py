@@ -188,6 +188,10 @@ def test_interleaved_upload_equals_channel_upload(ctx, small_workload):
     capi.Scan(ctx, xyz).set_timestamps(t).preprocess(capi.preprocess_params(timestamp_method=capi.TS_MIDDLE_IS_ZERO, **PP), b, None)
     da, db = a.download(), b.download()
     assert da["xyz"].tobytes() == db["xyz"].tobytes() and da["t"].tobytes() == db["t"].tobytes()
+    import torch  # device-resident records (MH_MEM_DEVICE): read in place
+    s.update_interleaved(torch.from_numpy(rec).cuda(), off_x=12, off_y=20, off_z=4, off_t=8)
+    got = s.download()
+    assert got["xyz"].tobytes() == ref["xyz"].tobytes() and got["t"].tobytes() == t.tobytes()
     s.update_interleaved(kitti)  # no time stamp field: the channel is gone again
     assert not s.download()["t"].any()
     s.update_interleaved(np.zeros((0, 4), np.float32))
