@@ -196,8 +196,19 @@ def main():
             import glob
             pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
             if pmc:  # HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (profiles/collect.sh)
-                roof["traffic"] = json.load(open(pmc[-1])).get("k_match_fused_hbm_bytes_per_launch")
+                summary = json.load(open(pmc[-1]))
+                roof["traffic"] = summary.get("k_match_fused_hbm_bytes_per_launch")
                 roof["traffic_source"] = os.path.basename(pmc[-1])
+                # second view, since HBM is not what this kernel waits for: VALU issue.  SQ_INSTS_VALU wave-instructions per
+                # launch / (1024 SIMDs x 2.4 GHz / 4 cycles per 64-lane instruction) = the time the launch needs if
+                # nothing but VALU issue limited it; its share of the measured single-stream launch time
+                mk = [k for k in summary.get("counters", {}) if k.startswith("k_match4")]
+                valu = summary["counters"][mk[0]].get("SQ_INSTS_VALU", {}).get("mean") if mk else None
+                if valu and roof["avg_kernel_ms_alone"]:
+                    floor_ms = valu / (1024 * 2.4e9 / 4.0) * 1e3
+                    roof["valu"] = {"wave_instructions_per_launch": valu, "issue_floor_ms": floor_ms,
+                                    "frac_of_launch_alone": floor_ms / roof["avg_kernel_ms_alone"],
+                                    "frac_of_launch_concurrent": floor_ms / avg_ms}
         out["roofline"] = roof
         out["cpu_baseline"] = cpu
         out["gathered_poses"] = int(all_poses.shape[0] * all_poses.shape[1])
