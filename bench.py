@@ -202,7 +202,7 @@ def main():
                 # second view, since HBM is not what this kernel waits for: VALU issue.  SQ_INSTS_VALU wave-instructions per
                 # launch / (1024 SIMDs x 2.4 GHz / 4 cycles per 64-lane instruction) = the time the launch needs if
                 # nothing but VALU issue limited it; its share of the measured single-stream launch time
-                mk = [k for k in summary.get("counters", {}) if k.startswith("k_match4")]
+                mk = [k for k in summary.get("counters", {}) if k.startswith("k_match4")] if kname.startswith("k_match4") else []
                 valu = summary["counters"][mk[0]].get("SQ_INSTS_VALU", {}).get("mean") if mk else None
                 if valu and roof["avg_kernel_ms_alone"]:
                     floor_ms = valu / (1024 * 2.4e9 / 4.0) * 1e3
