@@ -130,18 +130,26 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
       .def("initialize", &LidarOdometry::initialize)
       .def("reset", &LidarOdometry::reset)
       .def("onLidar", [rec2dict](LidarOdometry& lo, double stamp, py::array_t<float, py::array::c_style | py::array::forcecast> xyz,
-                                 std::optional<py::array_t<float, py::array::c_style | py::array::forcecast>> t) {
-        // [n,3] points or [n,>=3] records whose first three fields are x,y,z (a KITTI .bin is [n,4]): the rows go to
-        // the device as they are and are split into channels there
-        if (xyz.ndim() != 2 || xyz.shape(1) < 3) throw std::runtime_error("xyz must be [n,3] (or [n,k>=3] records starting with x,y,z)");
-        const size_t n = (size_t)xyz.shape(0);
+                                 std::optional<py::array_t<float, py::array::c_style | py::array::forcecast>> t,
+                                 std::array<int, 3> xyz_fields, int t_field) {
+        // [n,3] points or [n,k] float32 records (a KITTI .bin is [n,4]; a PointCloud2 payload of float fields likewise):
+        // the rows go to the device as they are and are split into channels there.  xyz_fields / t_field = column
+        // indices of the coordinates / of a per-point time stamp (-1: none, or the separate array `t`)
+        if (xyz.ndim() != 2 || xyz.shape(1) < 3) throw std::runtime_error("xyz must be [n,3] (or [n,k>=3] records)");
+        const size_t n = (size_t)xyz.shape(0), k = (size_t)xyz.shape(1);
+        for (int f : xyz_fields)
+          if (f < 0 || (size_t)f >= k) throw std::runtime_error("xyz_fields out of range");
+        if (t_field >= (int)k) throw std::runtime_error("t_field out of range");
         const float* tp = nullptr;
         if (t) {
           if ((size_t)t->size() != n) throw std::runtime_error("t must have n entries");
           tp = t->data();
         }
-        return rec2dict(lo.onLidarInterleaved(stamp, xyz.data(), n, (size_t)xyz.shape(1) * sizeof(float), 0, 4, 8, -1, tp)); },
-           py::arg("timestamp"), py::arg("xyz"), py::arg("t") = std::nullopt)
+        return rec2dict(lo.onLidarInterleaved(stamp, xyz.data(), n, k * sizeof(float), 4u * (size_t)xyz_fields[0],
+                                              4u * (size_t)xyz_fields[1], 4u * (size_t)xyz_fields[2],
+                                              t_field >= 0 ? 4ll * t_field : -1ll, tp)); },
+           py::arg("timestamp"), py::arg("xyz"), py::arg("t") = std::nullopt,
+           py::arg("xyz_fields") = std::array<int, 3>{0, 1, 2}, py::arg("t_field") = -1)
       .def("records", [rec2dict](const LidarOdometry& lo) { py::list l; for (auto& r : lo.records()) l.append(rec2dict(r)); return l; })
       .def("trajectory", [](const LidarOdometry& lo) {
         py::list l;

@@ -174,6 +174,14 @@ def test_hip_driver_matches_oracle_driver(host, drive, tmp_path):
         lo2.onLidar(st, np.concatenate([xyz, np.ones((len(xyz), 1), np.float32)], 1), t)
     for ra, rb in zip(lo2.records(), lo.records()[:4]):
         assert ra["pose"] == rb["pose"] and ra["n_for_icp"] == rb["n_for_icp"]
+    # ... and so do records that carry the fields elsewhere, time stamp included: [intensity, y, t, x, z]
+    lo3 = host.LidarOdometry()
+    lo3.initialize(host.Config.FromYamlFile(PIPE))
+    for (xyz, t), st in list(zip(drive["scans"], drive["stamps"]))[:4]:
+        rec = np.stack([np.ones(len(xyz), np.float32), xyz[:, 1], t, xyz[:, 0], xyz[:, 2]], 1)
+        lo3.onLidar(st, rec, xyz_fields=(3, 1, 4), t_field=2)
+    for ra, rb in zip(lo3.records(), lo.records()[:4]):
+        assert ra["pose"] == rb["pose"] and ra["n_for_icp"] == rb["n_for_icp"]
 
 
 @pytest.mark.gpu
