@@ -339,7 +339,8 @@ __device__ __forceinline__ void nn_resolve(const MapView& m, const u32x4* __rest
 //     the loads of a round to be issued unconditionally, an XCD-contiguous block order, other workgroup sizes.
 // -------------------------------------------------------------------------------------------------
 #ifndef MH_QUAD_W
-#define MH_QUAD_W 5  // candidates per lane and round trip: 4 x 5 = 20 = one full voxel (max_points_per_voxel: 20)
+#define MH_QUAD_W 3  // candidates per lane and round trip: 4 x 3 = 12.  (5 = one full voxel of 20 per round trip costs 14
+                     // more VGPRs: 6 instead of 8 waves per SIMD, see MH_QUAD_WAVES in mh_icp.hip)
 #endif
 constexpr int kQuadW = MH_QUAD_W;
 
