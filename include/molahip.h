@@ -207,7 +207,9 @@ MH_API mh_status mh_scan_preprocess(const mh_scan* raw, const mh_preprocess_para
 /* FilterDeskew (yaml:328-350): p' = Exp_SO3(w*t_i)*p + v*t_i with twist = (vx,vy,vz,wx,wy,wz) in the vehicle frame,
  * fp64, rounded to float [U].  twist == NULL or a scan without time stamps copies the points (skip_deskew /
  * silently_ignore_no_timestamps).  `out` must differ from `in`; it is what align() and mh_map_insert() consume, and
- * `in` stays valid for the re-de-skew inside the ICP loop (LidarOdometry.cpp:992-999) with no host round trip. */
+ * `in` stays valid for the re-de-skew inside the ICP loop (LidarOdometry.cpp:992-999) with no host round trip.
+ * `in` may belong to another context of the same device (a layer prepared on a second stream whose work the caller
+ * has synchronised); the kernel is ordered on `out`'s stream. */
 MH_API mh_status mh_scan_deskew(const mh_scan* in, const double twist[6], mh_scan* out);
 /* Axis-aligned bounding box of the finite points (CPointsMap::boundingBox [U], used by the sensor-range estimate at
  * LidarOdometry.cpp:1503-1508, 1517-1534).  n_finite (nullable) = number of finite points; zeros for an empty scan. */

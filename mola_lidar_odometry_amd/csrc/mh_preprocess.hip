@@ -405,8 +405,10 @@ mh_status mh_scan_preprocess(const mh_scan* raw, const mh_preprocess_params* p, 
 mh_status mh_scan_deskew(const mh_scan* in, const double twist[6], mh_scan* out) {
   MH_REQUIRE(in && out, "null argument");
   MH_REQUIRE(in != out, "`out` must differ from `in`");
-  MH_REQUIRE(in->ctx == out->ctx, "scans belong to different contexts");
-  mh_ctx* ctx = in->ctx;
+  MH_REQUIRE(in->ctx->device == out->ctx->device, "scans live on different devices");
+  // `in` may belong to another context of the same device (a layer prepared on a second stream, complete by now):
+  // the work is ordered on `out`'s stream
+  mh_ctx* ctx = out->ctx;
   MH_TRY(set_device(ctx));
   hipStream_t s = ctx->stream;
   const size_t n = in->n;

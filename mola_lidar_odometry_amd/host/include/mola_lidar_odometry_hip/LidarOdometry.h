@@ -135,6 +135,16 @@ class LidarOdometry {
   const ScanRecord& onLidarInterleaved(double timestamp, const void* data, size_t n, size_t point_step, size_t off_x,
                                        size_t off_y, size_t off_z, long long off_t = -1, const float* t = nullptr);
 
+  // Off-line replay (data sets, eval/cli_kitti.sh): announce the NEXT observation before calling onLidar* for the
+  // current one.  Its upload and first filter pass then run on a second stream of the same device, in a worker thread,
+  // while the current scan is in its ICP loop; the next onLidar* call (same buffer, same layout) picks the result up.
+  // The buffers must stay valid until that call.  Results are identical to the sequential flow: the first pass only
+  // depends on the sensor-range estimate, which is final before ICP starts; if any filter parameter turns out
+  // different when the scan is really due, the prepared layers are dropped and the pass runs again.
+  void prefetchInterleaved(const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
+                           long long off_t = -1, const float* t = nullptr);
+  void prefetch(const float* x, const float* y, const float* z, const float* t, size_t n);
+
   const std::vector<ScanRecord>& records() const { return records_; }
   const std::vector<std::pair<double, CPose3D>>& estimatedTrajectory() const { return trajectory_; }
   // TUM format "t x y z qx qy qz qw" (estimated_trajectory.output_file, yaml:79-81; eval/cli_kitti.sh:41-50)
@@ -150,7 +160,10 @@ class LidarOdometry {
  private:
   struct FilterPlan;  // the recognised observation filter chain, as data for mh_scan_preprocess / mh_scan_deskew
   struct RawInput;  // where the points of the current observation come from
+  struct Prefetch;  // the announced next observation and its worker
   const ScanRecord& process(double timestamp, const RawInput& in);
+  void launch_prefetch();
+  void cancel_prefetch();
   void updatePipelineDynamicVariables();
   void updatePipelineTwistVariables(const Twist& tw);
   void run_first_pass();
@@ -170,6 +183,12 @@ class LidarOdometry {
 
   // observation layers (device)
   std::shared_ptr<DevicePointCloud> raw_, map_skewed_, icp_skewed_, for_map_, for_icp_;
+  // prefetch: a second context (stream + scratch) used by the worker thread only, with two sets of raw / skewed layers
+  // filled alternately (the current scan may still re-de-skew from its set while the next one is being prepared)
+  std::shared_ptr<DeviceContext> ctx_b_;
+  std::shared_ptr<DevicePointCloud> raw_b_[2], map_skewed_b_[2], icp_skewed_b_[2];
+  std::shared_ptr<DevicePointCloud> cur_raw_, cur_map_skewed_, cur_icp_skewed_;  // the set the current scan reads
+  std::unique_ptr<Prefetch> pf_;
   std::shared_ptr<HashedVoxelPointCloud> local_map_;
   float remove_voxels_farther_than_ = 0.f;
   double map_voxel_size_ = 0;

@@ -161,10 +161,13 @@ class DeviceContext {  // one HIP device + stream (mh_ctx)
   ~DeviceContext();
   DeviceContext(const DeviceContext&) = delete;
   mh_ctx* get() const { return ctx_; }
+  int device() const { return device_; }
+  void synchronize() const;
   static std::shared_ptr<DeviceContext> Default();  // process-wide context on device 0
 
  private:
   mh_ctx* ctx_ = nullptr;
+  int device_ = 0;
 };
 
 [[noreturn]] void throw_status(mh_status s, const char* where);

@@ -147,7 +147,8 @@ void throw_status(mh_status s, const char* where) {
 }
 
 // ================================================================== device handles
-DeviceContext::DeviceContext(int device) { check(mh_ctx_create(device, nullptr, &ctx_), "mh_ctx_create"); }
+DeviceContext::DeviceContext(int device) : device_(device) { check(mh_ctx_create(device, nullptr, &ctx_), "mh_ctx_create"); }
+void DeviceContext::synchronize() const { check(mh_ctx_synchronize(ctx_), "mh_ctx_synchronize"); }
 DeviceContext::~DeviceContext() { mh_ctx_destroy(ctx_); }
 
 std::shared_ptr<DeviceContext> DeviceContext::Default() {

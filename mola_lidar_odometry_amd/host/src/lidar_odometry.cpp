@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <stdexcept>
 
 namespace mola_hip {
@@ -241,8 +242,29 @@ struct LidarOdometry::FilterPlan : public Parameterizable {
 };
 
 // ================================================================== driver
-LidarOdometry::LidarOdometry(std::shared_ptr<DeviceContext> ctx) : ctx_(std::move(ctx)) {}
-LidarOdometry::~LidarOdometry() = default;
+struct LidarOdometry::RawInput {
+  size_t n = 0;
+  const float *x = nullptr, *y = nullptr, *z = nullptr, *t = nullptr;  // channel arrays, or ...
+  const void* data = nullptr;                                           // ... interleaved records
+  size_t point_step = 0, off_x = 0, off_y = 0, off_z = 0;
+  long long off_t = -1;
+  bool same(const RawInput& o) const {
+    return n == o.n && x == o.x && y == o.y && z == o.z && t == o.t && data == o.data && point_step == o.point_step &&
+           off_x == o.off_x && off_y == o.off_y && off_z == o.off_z && off_t == o.off_t;
+  }
+};
+
+struct LidarOdometry::Prefetch {
+  RawInput req;  // announced, waiting for the current scan to reach its launch point
+  RawInput in;   // handed to the worker
+  bool requested = false, launched = false;
+  int slot = 0;               // which of the two prefetch sets the worker fills / filled
+  mh_preprocess_params pp{};  // the filter parameters the worker used
+  std::future<void> done;
+};
+
+LidarOdometry::LidarOdometry(std::shared_ptr<DeviceContext> ctx) : ctx_(std::move(ctx)), pf_(new Prefetch) {}
+LidarOdometry::~LidarOdometry() { cancel_prefetch(); }
 
 void LidarOdometry::initialize(const Config& cfg) {
   if (plan_) throw std::runtime_error("LidarOdometry::initialize() called twice; create a new object instead");
@@ -288,6 +310,7 @@ void LidarOdometry::ensure_device() {
 }
 
 void LidarOdometry::reset() {
+  cancel_prefetch();
   navstate_.reset();
   local_map_.reset();
   last_lidar_pose_ = CPose3D();
@@ -336,31 +359,102 @@ static double bbox_radius(const float mn[3], const float mx[3]) {
   return (double)std::max(a, b);
 }
 
+static mh_preprocess_params make_pp(double decim_map_res, double decim_icp_res, uint32_t min_points_to_filter, double range_min,
+                                    double range_max, int32_t bbox_mode, const double bbox_min[3], const double bbox_max[3],
+                                    int32_t timestamp_method, double time_offset) {
+  mh_preprocess_params pp;
+  memset(&pp, 0, sizeof(pp));  // (compared bytewise with the parameters a prefetch used)
+  pp.decim_map_resolution = (float)decim_map_res;
+  pp.decim_icp_resolution = (float)decim_icp_res;
+  pp.min_points_to_filter = min_points_to_filter;
+  pp.index_mode = MH_INDEX_FLOOR;
+  pp.range_min = (float)range_min;
+  pp.range_max = (float)range_max;
+  pp.bbox_mode = bbox_mode;
+  for (int a = 0; a < 3; a++) {
+    pp.bbox_min[a] = (float)bbox_min[a];
+    pp.bbox_max[a] = (float)bbox_max[a];
+  }
+  pp.timestamp_method = timestamp_method;
+  pp.time_offset = (float)time_offset;
+  return pp;
+}
+
 void LidarOdometry::run_first_pass() {
   const FilterPlan& f = *plan_;
-  mh_preprocess_params pp{};
-  pp.decim_map_resolution = (float)f.decim_map_res;
-  pp.decim_icp_resolution = (float)f.decim_icp_res;
-  pp.min_points_to_filter = f.min_points_to_filter;
-  pp.index_mode = MH_INDEX_FLOOR;
-  pp.range_min = (float)f.range_min;
-  pp.range_max = (float)f.range_max;
-  pp.bbox_mode = f.bbox_mode;
-  for (int a = 0; a < 3; a++) {
-    pp.bbox_min[a] = (float)f.bbox_min[a];
-    pp.bbox_max[a] = (float)f.bbox_max[a];
-  }
-  pp.timestamp_method = f.timestamp_method;
-  pp.time_offset = (float)f.time_offset;
+  const mh_preprocess_params pp = make_pp(f.decim_map_res, f.decim_icp_res, f.min_points_to_filter, f.range_min, f.range_max,
+                                          f.bbox_mode, f.bbox_min, f.bbox_max, f.timestamp_method, f.time_offset);
   check(mh_scan_preprocess(raw_->handle(), &pp, map_skewed_->handle(), icp_skewed_->handle()), "mh_scan_preprocess");
+}
+
+// ---- the announced next observation: upload + first pass on a second stream while this scan is in its ICP loop
+void LidarOdometry::prefetch(const float* x, const float* y, const float* z, const float* t, size_t n) {
+  pf_->req = RawInput();  // (a prepared scan that is still waiting to be picked up stays untouched)
+  pf_->req.n = n; pf_->req.x = x; pf_->req.y = y; pf_->req.z = z; pf_->req.t = t;
+  pf_->requested = n > 0;
+}
+
+void LidarOdometry::prefetchInterleaved(const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y,
+                                        size_t off_z, long long off_t, const float* t) {
+  pf_->req = RawInput();
+  pf_->req.n = n; pf_->req.data = data; pf_->req.point_step = point_step; pf_->req.off_x = off_x; pf_->req.off_y = off_y;
+  pf_->req.off_z = off_z; pf_->req.off_t = off_t; pf_->req.t = t;
+  pf_->requested = n > 0;
+}
+
+void LidarOdometry::cancel_prefetch() {
+  if (pf_->launched && pf_->done.valid()) {
+    try { pf_->done.get(); } catch (...) {}
+  }
+  pf_->launched = pf_->requested = false;
+}
+
+void LidarOdometry::launch_prefetch() {
+  if (!pf_->requested || !plan_ || !estimated_sensor_max_range_) return;
+  if (pf_->launched) {  // prepared but never picked up: drop it
+    try { pf_->done.get(); } catch (...) {}
+    pf_->launched = false;
+  }
+  pf_->in = pf_->req;
+  if (!ctx_b_) {
+    ctx_b_ = std::make_shared<DeviceContext>(ctx_->device());
+    for (int i = 0; i < 2; i++) {
+      raw_b_[i] = std::make_shared<DevicePointCloud>(ctx_b_);
+      map_skewed_b_[i] = std::make_shared<DevicePointCloud>(ctx_b_);
+      icp_skewed_b_[i] = std::make_shared<DevicePointCloud>(ctx_b_);
+    }
+  }
+  pf_->slot ^= 1;  // not the set the current scan may still be reading
+  // the filter parameters as the next onLidar will publish them (:692): only the sensor range differs from now
+  std::map<std::string, double> vars = source_.getVariableValues();
+  vars["ESTIMATED_SENSOR_MAX_RANGE"] = *estimated_sensor_max_range_;
+  vars["INSTANTANEOUS_SENSOR_MAX_RANGE"] = instantaneous_sensor_max_range_ ? *instantaneous_sensor_max_range_ : 20.0;
+  plan_->realizeWith(vars);
+  const FilterPlan& f = *plan_;
+  pf_->pp = make_pp(f.decim_map_res, f.decim_icp_res, f.min_points_to_filter, f.range_min, f.range_max, f.bbox_mode,
+                    f.bbox_min, f.bbox_max, f.timestamp_method, f.time_offset);
+  plan_->realizeWith(source_.getVariableValues());  // and back: this scan goes on with what it started with
+  const RawInput in = pf_->in;
+  const mh_preprocess_params pp = pf_->pp;
+  auto raw = raw_b_[pf_->slot], ms = map_skewed_b_[pf_->slot], is = icp_skewed_b_[pf_->slot];
+  auto ctx = ctx_b_;
+  pf_->done = std::async(std::launch::async, [in, pp, raw, ms, is, ctx]() {
+    if (in.data) raw->setPointsInterleaved(in.data, in.n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t);
+    else raw->setPoints(in.x, in.y, in.z, in.n);
+    if (in.t) raw->setTimestamps(in.t, in.n);
+    check(mh_scan_preprocess(raw->handle(), &pp, ms->handle(), is->handle()), "mh_scan_preprocess (prefetch)");
+    ctx->synchronize();
+  });
+  pf_->launched = true;
+  pf_->requested = false;
 }
 
 void LidarOdometry::run_second_pass() {
   const auto& v = source_.getVariableValues();
   const double tw[6] = {v.at("vx"), v.at("vy"), v.at("vz"), v.at("wx"), v.at("wy"), v.at("wz")};
   const double* twp = plan_->skip_deskew ? nullptr : tw;
-  check(mh_scan_deskew(map_skewed_->handle(), twp, for_map_->handle()), "mh_scan_deskew");
-  check(mh_scan_deskew(icp_skewed_->handle(), twp, for_icp_->handle()), "mh_scan_deskew");
+  check(mh_scan_deskew(cur_map_skewed_->handle(), twp, for_map_->handle()), "mh_scan_deskew");
+  check(mh_scan_deskew(cur_icp_skewed_->handle(), twp, for_icp_->handle()), "mh_scan_deskew");
 }
 
 void LidarOdometry::doUpdateAdaptiveThreshold(const CPose3D& err) {  // :1449-1485 (KISS-ICP's scheme)
@@ -403,14 +497,6 @@ void LidarOdometry::create_local_map() {  // :1165-1171 with yaml:228-242
   local_map_ = std::make_shared<HashedVoxelPointCloud>(mp, ctx_);
 }
 
-struct LidarOdometry::RawInput {
-  size_t n = 0;
-  const float *x = nullptr, *y = nullptr, *z = nullptr, *t = nullptr;  // channel arrays, or ...
-  const void* data = nullptr;                                           // ... interleaved records
-  size_t point_step = 0, off_x = 0, off_y = 0, off_z = 0;
-  long long off_t = -1;
-};
-
 const LidarOdometry::ScanRecord& LidarOdometry::onLidar(double this_obs_tim, const float* x, const float* y, const float* z,
                                                         const float* t, size_t n) {
   RawInput in;
@@ -445,7 +531,19 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
   }
   StageTimer t_all(profile_, "onLidar");
   ensure_device();
-  {
+  cur_raw_ = raw_;
+  cur_map_skewed_ = map_skewed_;
+  cur_icp_skewed_ = icp_skewed_;
+  bool prepared = false;  // upload + first pass already done by the prefetch worker?
+  if (pf_->launched) {
+    StageTimer tt(profile_, "onLidar.0.prefetch_wait");
+    bool ok = true;
+    try { pf_->done.get(); } catch (...) { ok = false; }  // (a failed prefetch is simply redone below, and reports there)
+    pf_->launched = false;
+    if (ok && pf_->in.same(in)) prepared = true;
+  }
+  if (pf_->requested && pf_->req.same(in)) pf_->requested = false;  // due before it could be launched
+  if (!prepared) {
     StageTimer tt(profile_, "onLidar.0.upload_raw");
     if (in.data) raw_->setPointsInterleaved(in.data, n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t);
     else raw_->setPoints(in.x, in.y, in.z, n);
@@ -455,7 +553,7 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
   // first call: sensor range from the raw cloud (:660, 1487-1513)
   if (!estimated_sensor_max_range_ && n) {
     float mn[3], mx[3];
-    raw_->boundingBox(mn, mx);
+    cur_raw_->boundingBox(mn, mx);
     estimated_sensor_max_range_ = std::max(bbox_radius(mn, mx), params_.absolute_minimum_sensor_range);
   }
   {
@@ -464,7 +562,25 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
   }
   rec.twist = last_motion_model_output_ ? last_motion_model_output_->twist : Twist();
 
-  {
+  if (prepared) {  // valid only if the parameters published just now are the ones the worker used
+    const FilterPlan& f = *plan_;
+    const mh_preprocess_params now = make_pp(f.decim_map_res, f.decim_icp_res, f.min_points_to_filter, f.range_min, f.range_max,
+                                             f.bbox_mode, f.bbox_min, f.bbox_max, f.timestamp_method, f.time_offset);
+    if (memcmp(&now, &pf_->pp, sizeof(now)) == 0) {
+      cur_raw_ = raw_b_[pf_->slot];
+      cur_map_skewed_ = map_skewed_b_[pf_->slot];
+      cur_icp_skewed_ = icp_skewed_b_[pf_->slot];
+      profile_["prefetch_hits"] += 1.0;
+    } else {
+      prepared = false;
+      profile_["prefetch_misses"] += 1.0;
+      StageTimer tt(profile_, "onLidar.0.upload_raw");
+      if (in.data) raw_->setPointsInterleaved(in.data, n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t);
+      else raw_->setPoints(in.x, in.y, in.z, n);
+      if (in.t) raw_->setTimestamps(in.t, n);
+    }
+  }
+  if (!prepared) {
     StageTimer tt(profile_, "onLidar.1.filter_1st");
     run_first_pass();  // :734
   }
@@ -487,6 +603,7 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
     const double a = params_.max_sensor_range_filter_coefficient;
     estimated_sensor_max_range_ = *estimated_sensor_max_range_ * a + radius * (1.0 - a);
   }
+  launch_prefetch();  // the announced next scan: its first pass only needs the range estimate, which is final now
   rec.estimated_sensor_max_range = estimated_sensor_max_range_.value_or(0);
   rec.instantaneous_sensor_max_range = instantaneous_sensor_max_range_.value_or(0);
 

@@ -125,7 +125,7 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
     d["map_voxel_size"] = r.map_voxel_size;
     return d;
   };
-  py::class_<LidarOdometry>(m, "LidarOdometry")
+  py::class_<LidarOdometry>(m, "LidarOdometry", py::dynamic_attr())
       .def(py::init([]() { return std::make_unique<LidarOdometry>(); }))
       .def("initialize", &LidarOdometry::initialize)
       .def("reset", &LidarOdometry::reset)
@@ -150,6 +150,27 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
                                               t_field >= 0 ? 4ll * t_field : -1ll, tp)); },
            py::arg("timestamp"), py::arg("xyz"), py::arg("t") = std::nullopt,
            py::arg("xyz_fields") = std::array<int, 3>{0, 1, 2}, py::arg("t_field") = -1)
+      .def("prefetch", [](py::object self, py::array_t<float, py::array::c_style | py::array::forcecast> xyz,
+                          std::optional<py::array_t<float, py::array::c_style | py::array::forcecast>> t,
+                          std::array<int, 3> xyz_fields, int t_field) {
+        // announce the NEXT scan (same arguments as the onLidar call that will follow): upload + first filter pass run
+        // on a second stream while the current scan is registered.  The arrays are kept alive on the object.
+        LidarOdometry& lo = self.cast<LidarOdometry&>();
+        if (xyz.ndim() != 2 || xyz.shape(1) < 3) throw std::runtime_error("xyz must be [n,3] (or [n,k>=3] records)");
+        const size_t n = (size_t)xyz.shape(0), k = (size_t)xyz.shape(1);
+        for (int f : xyz_fields)
+          if (f < 0 || (size_t)f >= k) throw std::runtime_error("xyz_fields out of range");
+        if (t_field >= (int)k) throw std::runtime_error("t_field out of range");
+        const float* tp = nullptr;
+        if (t) {
+          if ((size_t)t->size() != n) throw std::runtime_error("t must have n entries");
+          tp = t->data();
+        }
+        lo.prefetchInterleaved(xyz.data(), n, k * sizeof(float), 4u * (size_t)xyz_fields[0], 4u * (size_t)xyz_fields[1],
+                               4u * (size_t)xyz_fields[2], t_field >= 0 ? 4ll * t_field : -1ll, tp);
+        self.attr("_prefetch_keepalive") = py::make_tuple(xyz, t ? py::object(*t) : py::none()); },
+           py::arg("xyz"), py::arg("t") = std::nullopt, py::arg("xyz_fields") = std::array<int, 3>{0, 1, 2},
+           py::arg("t_field") = -1)
       .def("records", [rec2dict](const LidarOdometry& lo) { py::list l; for (auto& r : lo.records()) l.append(rec2dict(r)); return l; })
       .def("trajectory", [](const LidarOdometry& lo) {
         py::list l;

@@ -56,8 +56,9 @@ def _kitti_calib_Tr(seq_dir):
     return None
 
 
-def run_sequence(pipeline, scans, out_tum=None, device=None):
-    """scans: iterable of (stamp, xyz[N,3] fp32, t[N] fp32 | None).  Returns (records, trajectory, seconds)."""
+def run_sequence(pipeline, scans, out_tum=None, device=None, prefetch=True):
+    """scans: iterable of (stamp, xyz[N,3] fp32, t[N] fp32 | None).  Returns (records, trajectory, seconds).
+    prefetch: announce scan k+1 before registering scan k (its upload + first filter pass overlap with scan k's ICP)."""
     from . import _mp2p_icp_hip as H
     from . import capi
     capi.lib()  # torch's HIP runtime first (one runtime per process), then libmolahip
@@ -66,11 +67,23 @@ def run_sequence(pipeline, scans, out_tum=None, device=None):
     t0 = time.perf_counter()
     n = 0
     per_scan = []
-    for st, xyz, t in scans:
+    def as_f32(item):  # the very arrays handed to prefetch must be the ones handed to onLidar (matched by address)
+        st, xyz, t = item
+        return (st, np.ascontiguousarray(xyz, dtype=np.float32), None if t is None else np.ascontiguousarray(t, dtype=np.float32))
+
+    it = iter(scans)
+    cur = next(it, None)
+    cur = as_f32(cur) if cur is not None else None
+    while cur is not None:
+        nxt = next(it, None)
+        nxt = as_f32(nxt) if nxt is not None else None
         t1 = time.perf_counter()
-        lo.onLidar(st, xyz, t)
+        if prefetch and nxt is not None:
+            lo.prefetch(nxt[1], nxt[2])
+        lo.onLidar(cur[0], cur[1], cur[2])
         per_scan.append(time.perf_counter() - t1)
         n += 1
+        cur = nxt
     dt = time.perf_counter() - t0
     # the first scans pay for the device context, the code objects and the first map: quote the steady state apart
     run_sequence.last_steady = (len(per_scan) - 3) / sum(per_scan[3:]) if len(per_scan) > 3 and sum(per_scan[3:]) > 0 else 0.0
@@ -89,6 +102,7 @@ def main(argv=None):
     ap.add_argument("--azimuths", type=int, default=1875, help="64 x 1875 = the 120k-point sweep of BASELINE.json C2")
     ap.add_argument("--kitti-root", default=None, help="KITTI odometry root (sequences/XX/velodyne, poses/XX.txt)")
     ap.add_argument("--seqs", nargs="*", default=[])
+    ap.add_argument("--no-prefetch", action="store_true", help="strictly sequential scans (what a live sensor feed gives)")
     ap.add_argument("--out-dir", default="gpurun_out/odometry")
     a = ap.parse_args(argv)
 
@@ -125,7 +139,7 @@ def main(argv=None):
             gt = _kitti_gt(a.kitti_root, name, _kitti_calib_Tr(src))
             gt_stamps = None
         out = os.path.join(a.out_dir, "%s.tum" % name)
-        recs, traj, secs = run_sequence(a.pipeline, scans, out)
+        recs, traj, secs = run_sequence(a.pipeline, scans, out, prefetch=not a.no_prefetch)
         line = dict(sequence=name, scans=len(recs), seconds=secs, scans_per_s=len(recs) / secs if secs else 0.0,
                     good=int(sum(r["icp_good"] for r in recs)), keyframes=int(sum(r["map_updated"] for r in recs)),
                     icp_iterations=int(sum(r["icp_iterations"] for r in recs)),

@@ -90,7 +90,7 @@ def _runner_worker(rank, world, port, root, out_dir, q):
                       LOCAL_RANK=str(rank), MH_DIST_BACKEND="gloo")
     from mola_lidar_odometry_amd import run_odometry
 
-    def fake_run_sequence(pipeline, scans, out_tum=None, device=None):
+    def fake_run_sequence(pipeline, scans, out_tum=None, device=None, prefetch=True):
         scans = list(scans)
         recs = [dict(timestamp=st, icp_good=True, map_updated=True, icp_iterations=3, n_for_icp=10, n_map_points=5) for st, _, _ in scans]
         traj = [(st, np.eye(4)[:3].reshape(12).tolist()) for st, _, _ in scans]

@@ -185,6 +185,37 @@ def test_hip_driver_matches_oracle_driver(host, drive, tmp_path):
 
 
 @pytest.mark.gpu
+def test_prefetch_overlap_gives_identical_records(host, drive):
+    """Announcing scan k+1 before registering scan k (upload + first filter pass on a second stream, worker thread) must
+    not change a single record; every announced scan but the first is picked up from the prepared layers."""
+    def run(prefetch):
+        lo = host.LidarOdometry()
+        lo.initialize(host.Config.FromYamlFile(PIPE))
+        items = [(st, np.ascontiguousarray(xyz, np.float32), np.ascontiguousarray(t, np.float32))
+                 for (xyz, t), st in zip(drive["scans"], drive["stamps"])]
+        for k, (st, xyz, t) in enumerate(items):
+            if prefetch and k + 1 < len(items):
+                lo.prefetch(items[k + 1][1], items[k + 1][2])
+            lo.onLidar(st, xyz, t)
+        return lo.records(), lo.profile()
+    ra, pa = run(False)
+    rb, pb = run(True)
+    assert len(ra) == len(rb)
+    for a, b in zip(ra, rb):
+        assert a == b
+    assert pb.get("prefetch_hits", 0) >= len(ra) - 2 and pb.get("prefetch_misses", 0) == 0
+    assert "prefetch_hits" not in pa
+    # a prefetch that is never picked up (different scan registered next) is harmless
+    lo = host.LidarOdometry()
+    lo.initialize(host.Config.FromYamlFile(PIPE))
+    (x0, t0), (x1, t1) = drive["scans"][0], drive["scans"][1]
+    lo.onLidar(drive["stamps"][0], x0, t0)
+    lo.prefetch(np.ascontiguousarray(x0), np.ascontiguousarray(t0))
+    r = lo.onLidar(drive["stamps"][1], x1, t1)
+    assert r["pose"] == ra[1]["pose"]
+
+
+@pytest.mark.gpu
 def test_hip_driver_ndt_pipeline_and_restart(host, drive):
     """lidar3d-ndt: NDT local map (min-distance insertion, plane statistics), point-to-plane + point-to-point ICP --
     again scan by scan against the oracle driver."""
