@@ -126,7 +126,12 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
     return d;
   };
   py::class_<LidarOdometry>(m, "LidarOdometry", py::dynamic_attr())
-      .def(py::init([]() { return std::make_unique<LidarOdometry>(); }))
+      .def(py::init([](int device, bool own_context) {
+             // default: the process-wide context on device 0; device >= 0 / own_context: a context (stream + scratch) of
+             // its own on that device -- one per GPU rank, and required when several drivers run in threads of one process
+             if (device < 0 && !own_context) return std::make_unique<LidarOdometry>();
+             return std::make_unique<LidarOdometry>(std::make_shared<DeviceContext>(device < 0 ? 0 : device)); }),
+           py::arg("device") = -1, py::arg("own_context") = false)
       .def("initialize", &LidarOdometry::initialize)
       .def("reset", &LidarOdometry::reset)
       .def("onLidar", [rec2dict](LidarOdometry& lo, double stamp, py::array_t<float, py::array::c_style | py::array::forcecast> xyz,
@@ -145,9 +150,14 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
           if ((size_t)t->size() != n) throw std::runtime_error("t must have n entries");
           tp = t->data();
         }
-        return rec2dict(lo.onLidarInterleaved(stamp, xyz.data(), n, k * sizeof(float), 4u * (size_t)xyz_fields[0],
-                                              4u * (size_t)xyz_fields[1], 4u * (size_t)xyz_fields[2],
-                                              t_field >= 0 ? 4ll * t_field : -1ll, tp)); },
+        const LidarOdometry::ScanRecord* rec = nullptr;
+        {
+          py::gil_scoped_release nogil;  // the numpy buffers are only read through their pointers: other drivers' threads may run
+          rec = &lo.onLidarInterleaved(stamp, xyz.data(), n, k * sizeof(float), 4u * (size_t)xyz_fields[0],
+                                       4u * (size_t)xyz_fields[1], 4u * (size_t)xyz_fields[2],
+                                       t_field >= 0 ? 4ll * t_field : -1ll, tp);
+        }
+        return rec2dict(*rec); },
            py::arg("timestamp"), py::arg("xyz"), py::arg("t") = std::nullopt,
            py::arg("xyz_fields") = std::array<int, 3>{0, 1, 2}, py::arg("t_field") = -1)
       .def("prefetch", [](py::object self, py::array_t<float, py::array::c_style | py::array::forcecast> xyz,

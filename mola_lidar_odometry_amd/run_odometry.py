@@ -3,6 +3,7 @@
     python -m mola_lidar_odometry_amd.run_odometry --synthetic 200                       # synthetic drive, 200 scans
     python -m mola_lidar_odometry_amd.run_odometry --kitti-root /data/kitti --seqs 00 04  # KITTI velodyne folders
     python -m torch.distributed.run --nproc-per-node 8 ... run_odometry.py --kitti-root ... --seqs 00 ... 10
+    (more ranks than GPUs is allowed and pays off: the ranks share the devices round robin, each sequence in its own process)
 
 What eval/cli_kitti.sh:23-50 (relative to /root/reference) does with mola-lidar-odometry-cli + GNU parallel: one whole
 sequence per worker (here one process per GPU, sequences assigned longest-first), a TUM trajectory per sequence,
@@ -62,7 +63,9 @@ def run_sequence(pipeline, scans, out_tum=None, device=None, prefetch=True):
     from . import _mp2p_icp_hip as H
     from . import capi
     capi.lib()  # torch's HIP runtime first (one runtime per process), then libmolahip
-    lo = H.LidarOdometry()
+    if device is None:
+        device = int(os.environ.get("MH_DEVICE", os.environ.get("LOCAL_RANK", 0)))
+    lo = H.LidarOdometry(device=device, own_context=True)
     lo.initialize(H.Config.FromYamlFile(pipeline))
     t0 = time.perf_counter()
     n = 0
@@ -86,12 +89,14 @@ def run_sequence(pipeline, scans, out_tum=None, device=None, prefetch=True):
         cur = nxt
     dt = time.perf_counter() - t0
     # the first scans pay for the device context, the code objects and the first map: quote the steady state apart
-    run_sequence.last_steady = (len(per_scan) - 3) / sum(per_scan[3:]) if len(per_scan) > 3 and sum(per_scan[3:]) > 0 else 0.0
-    run_sequence.last_startup = sum(per_scan[:3])
     if out_tum:
         lo.saveTrajectoryTUM(out_tum)
-    run_sequence.last_profile = {k: round(1e3 * v / max(n, 1), 4) for k, v in lo.profile().items()}  # ms per scan
-    return lo.records(), lo.trajectory(), dt
+    recs = lo.records()
+    if recs:  # per-run figures travel with the records (several runs may be in flight in threads of this process)
+        recs[-1]["_steady_scans_per_s"] = (len(per_scan) - 3) / sum(per_scan[3:]) if len(per_scan) > 3 and sum(per_scan[3:]) > 0 else 0.0
+        recs[-1]["_startup_s"] = sum(per_scan[:3])
+        recs[-1]["_host_ms_per_scan"] = {k: round(1e3 * v / max(n, 1), 4) for k, v in lo.profile().items()}
+    return recs, lo.trajectory(), dt
 
 
 def main(argv=None):
@@ -102,34 +107,44 @@ def main(argv=None):
     ap.add_argument("--azimuths", type=int, default=1875, help="64 x 1875 = the 120k-point sweep of BASELINE.json C2")
     ap.add_argument("--kitti-root", default=None, help="KITTI odometry root (sequences/XX/velodyne, poses/XX.txt)")
     ap.add_argument("--seqs", nargs="*", default=[])
+    ap.add_argument("--copies", type=int, default=1, help="run the synthetic drive this many times (as separate sequences)")
     ap.add_argument("--no-prefetch", action="store_true", help="strictly sequential scans (what a live sensor feed gives)")
     ap.add_argument("--out-dir", default="gpurun_out/odometry")
     a = ap.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     backend = os.environ.get("MH_DIST_BACKEND", "nccl")  # "gloo" in the CPU tests of the sharding logic
-    red_dev = "cuda" if backend == "nccl" else "cpu"
+    n_gpus = world
     if world > 1:
         import torch
         import torch.distributed as td
-        if backend == "nccl":
+        ndev = torch.cuda.device_count() if backend == "nccl" else 0
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if backend == "nccl" and ndev and local_world > ndev:
+            # more ranks than GPUs (several sequences per GPU, each in its own process): ranks share devices round
+            # robin; RCCL wants one rank per device, and the only collective is a count and a max -> gloo
+            backend = "gloo"
+            n_gpus = ndev * (world // local_world)
+            os.environ["MH_DEVICE"] = str(int(os.environ.get("LOCAL_RANK", 0)) % ndev)
+        elif backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
         td.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     os.makedirs(a.out_dir, exist_ok=True)
 
     jobs = []  # (name, length, factory)
-    if a.synthetic:
-        jobs.append(("synthetic", a.synthetic, None))
+    drive_cache = {}
+    for c in range(a.copies if a.synthetic else 0):
+        jobs.append(("synthetic" if a.copies == 1 else "synthetic%d" % c, a.synthetic, None))
     for s in a.seqs:
         d = os.path.join(a.kitti_root, "sequences", s)
         jobs.append((s, len(glob.glob(os.path.join(d, "velodyne", "*.bin"))), d))
     mine = mdist.lpt_assign([j[1] for j in jobs], world)[rank]
 
-    total_scans, total_time = 0, 0.0
-    for j in mine:
+    def do_job(j):
         name, length, src = jobs[j]
         if src is None:
-            drive = synth.make_drive(length, rings=a.rings, azimuths=a.azimuths)
+            drive = drive_cache["drive"]
             scans = [(st, xyz, t) for (xyz, t), st in zip(drive["scans"], drive["stamps"])]
             G = np.stack([trajectory.to44(p) for p in drive["poses"]])
             gt = np.linalg.inv(G[0])[None] @ G
@@ -145,9 +160,9 @@ def main(argv=None):
                     icp_iterations=int(sum(r["icp_iterations"] for r in recs)),
                     mean_points_for_icp=float(np.mean([r["n_for_icp"] for r in recs])) if recs else 0.0,
                     map_points=int(recs[-1]["n_map_points"]) if recs else 0, tum=out, rank=rank,
-                    steady_scans_per_s=getattr(run_sequence, "last_steady", 0.0),
-                    startup_s_first_3_scans=getattr(run_sequence, "last_startup", 0.0),
-                    host_ms_per_scan=getattr(run_sequence, "last_profile", {}))
+                    steady_scans_per_s=recs[-1].get("_steady_scans_per_s", 0.0) if recs else 0.0,
+                    startup_s_first_3_scans=recs[-1].get("_startup_s", 0.0) if recs else 0.0,
+                    host_ms_per_scan=recs[-1].get("_host_ms_per_scan", {}) if recs else {})
         if gt is not None and len(traj):
             est_stamps = np.array([t for t, _ in traj])
             est = np.stack([trajectory.to44(p) for _, p in traj])
@@ -162,8 +177,16 @@ def main(argv=None):
                 if k:
                     line["kitti_t_err_percent"], line["kitti_r_err_deg_per_m"] = te, re
         print(json.dumps(line), flush=True)
-        total_scans += len(recs)
-        total_time += secs
+        return len(recs), secs
+
+    if any(jobs[j][2] is None for j in mine):  # one synthetic drive, shared by its copies
+        drive_cache["drive"] = synth.make_drive(a.synthetic, rings=a.rings, azimuths=a.azimuths)
+    # (Sequences side by side on one GPU pay off only as separate PROCESSES -- launch more ranks than GPUs, see below:
+    #  4 ranks on one MI355X register 1617 scans/s together against 737 for one; threads of one process sharing the HIP
+    #  runtime measured slower than one after the other, 483 vs 722 scans/s.)
+    done = [do_job(j) for j in mine]
+    total_time = sum(d[1] for d in done)  # the time spent registering scans
+    total_scans = sum(d[0] for d in done)
     wall = mdist.max_over_ranks(total_time, device=red_dev if world > 1 else None)
     if world > 1:
         import torch
@@ -173,7 +196,7 @@ def main(argv=None):
         total_scans = int(tot.item())
         td.destroy_process_group()
     if rank == 0:
-        print(json.dumps(dict(summary=True, n_gpus=world, scans=total_scans, seconds=wall,
+        print(json.dumps(dict(summary=True, n_gpus=n_gpus, ranks=world, scans=total_scans, seconds=wall,
                               scans_per_s=total_scans / wall if wall else 0.0)), flush=True)
 
 

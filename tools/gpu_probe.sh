@@ -1,11 +1,7 @@
 #!/bin/bash
 # scratch: A/B runs on the GPU box
 cd /root/repo
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-for a in "" "--no-prefetch"; do
-for p in default ndt; do
-timeout 300 python -m mola_lidar_odometry_amd.run_odometry --synthetic 200 --pipeline pipelines/lidar3d-$p-hip.yaml $a 2>&1 | head -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print('$p $a', round(d['scans_per_s'],1), 'steady', round(d['steady_scans_per_s'],1), 'ate', round(d['ate_rmse_m'],4)); print({k:v for k,v in d['host_ms_per_scan'].items() if v>0.02})"
+for np in 2 4; do
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $np --master-addr 127.0.0.1 --master-port 29511 -m mola_lidar_odometry_amd.run_odometry --synthetic 200 --copies $np 2>&1 | grep summary | cut -c1-200
 done
-done
+timeout 400 python -m mola_lidar_odometry_amd.run_odometry --synthetic 200 --copies 2 2>&1 | grep summary | cut -c1-200
