@@ -213,6 +213,18 @@ def test_prefetch_overlap_gives_identical_records(host, drive):
     lo.prefetch(np.ascontiguousarray(x0), np.ascontiguousarray(t0))
     r = lo.onLidar(drive["stamps"][1], x1, t1)
     assert r["pose"] == ra[1]["pose"]
+    # a scan the filters reject (voxel index out of the key range) fails when it is registered, prefetched or not,
+    # and the driver carries on with the next good scan
+    bad = np.ascontiguousarray(drive["scans"][2][0]).copy()
+    bad[5] = [3.0e9, 0.0, 0.0]
+    tb = np.ascontiguousarray(drive["scans"][2][1])
+    lo.prefetch(bad, tb)
+    (x2, t2) = drive["scans"][2]
+    lo.onLidar(drive["stamps"][2], x2, t2)  # launches the worker for `bad`
+    with pytest.raises(RuntimeError):
+        lo.onLidar(drive["stamps"][3], bad, tb)
+    (x4, t4) = drive["scans"][4]
+    assert lo.onLidar(drive["stamps"][4], x4, t4)["icp_run"]
 
 
 @pytest.mark.gpu
