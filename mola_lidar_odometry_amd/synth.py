@@ -264,6 +264,15 @@ def make_drive(n_scans: int = 12, dt: float = 0.1, speed: float = 8.0, yaw_rate:
     return dict(scene=scene, poses=np.asarray(poses), twists=np.asarray(twists), scans=scans, stamps=np.asarray(stamps))
 
 
+def ndt_cloud(seed=0):
+    """Ground plane + wall + blob with 1 cm noise: planar and non-planar voxels for the NDT map / point-to-plane tests."""
+    rng = np.random.default_rng(seed)
+    ground = np.stack([rng.uniform(-10, 10, 20000), rng.uniform(-10, 10, 20000), rng.normal(0.3, 0.01, 20000)], 1)
+    wall = np.stack([rng.uniform(-10, 10, 12000), rng.normal(5.4, 0.01, 12000), rng.uniform(0.5, 4, 12000)], 1)
+    blob = rng.normal([3.5, -3.5, 1.5], 0.25, (4000, 3))
+    return np.concatenate([ground, wall, blob]).astype(np.float32)
+
+
 def threshold_schedule(sigma: float, n_iters: int):
     """Matcher threshold and robust-kernel parameter as functions of ICP_ITERATION
     (lidar3d-default.yaml:198 and :190)."""

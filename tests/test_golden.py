@@ -143,3 +143,61 @@ def test_hip_path_reproduces_frontend_golden(front_drive):
     recs = [lo.onLidar(st, s[0], s[1]) for s, st in zip(d["scans"], d["stamps"])]
     _check_frontend((om.download()["src_idx"], oi.download()["src_idx"]), out.download()["xyz"], m.download(), recs)
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------ NDT / point-to-plane
+NDT = json.load(open(os.path.join(ROOT, "tests", "golden", "ndt.json")))
+
+
+def _ndt_inputs():
+    pts = synth.ndt_cloud(NDT["cloud"]["seed"])
+    assert (len(pts), _crc(pts)) == (NDT["cloud"]["n"], NDT["cloud"]["crc"])
+    rng = np.random.default_rng(12)
+    scan = pts[rng.permutation(len(pts))[:NDT["align"]["n_scan"]]]
+    thr, kp = synth.threshold_schedule(0.5, 60)
+    kw = dict(max_iterations=60, min_abs_step_trans=5e-4, min_abs_step_rot=5e-4, threshold=thr, kernel_param=kp,
+              pt2pl_threshold=0.5)
+    return pts, scan, np.asarray(NDT["align"]["guess"]), kw
+
+
+def _check_ndt(info, ndt_dump, al, term_name, recs):
+    g = NDT["map"]
+    assert (info[0], info[1], int(ndt_dump["is_plane"].sum())) == (g["n_points"], g["n_voxels"], g["n_planes"])
+    assert (_crc(ndt_dump["is_plane"].astype(np.uint32)), _crc(ndt_dump["centroid"])) == (g["plane_crc"], g["centroid_crc"])
+    a = NDT["align"]
+    assert (int(al["n_iterations"]), term_name, int(al["n_final_pairs"]), int(al["n_final_pairs_pt2pl"])) == (
+        a["n_iterations"], a["termination"], a["n_final_pairs"], a["n_final_pairs_pt2pl"])
+    np.testing.assert_allclose(np.asarray(al["T"]).reshape(-1), a["T_final"], rtol=0, atol=1e-9)
+    d = NDT["drive"]
+    for key in ("icp_iterations", "n_for_icp", "n_map_points", "map_updated"):
+        assert [type(d[key][0])(r[key]) for r in recs] == d[key], key
+    np.testing.assert_allclose([np.asarray(r["pose"]).reshape(-1) for r in recs], d["poses"], rtol=0, atol=1e-6)
+
+
+def test_c_oracle_reproduces_ndt_golden(oracle):
+    from oracle import odometry_oracle as oo
+    pts, scan, guess, kw = _ndt_inputs()
+    m = oracle.Map(1.0, 0, 0, 0.1, 0.05, 4).insert(pts)
+    al = oracle.icp_align(m, scan, guess, oracle.ICPParams(gn=oracle.GNParams(max_inner_iterations=2), **kw))
+    d = synth.make_drive(NDT["drive"]["n_scans"])
+    o = oo.OdometryOracle(os.path.join(ROOT, NDT["drive"]["pipeline"]), n_threads=8)
+    recs = [o.on_lidar(st, s[0], s[1]) for s, st in zip(d["scans"], d["stamps"])]
+    _check_ndt((m.num_points, m.num_voxels), m.dump_ndt(), al, oracle.TERM_NAMES[al["termination_reason"]], recs)
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_ndt_golden():
+    from mola_lidar_odometry_amd import _mp2p_icp_hip as H
+    from mola_lidar_odometry_amd import capi
+    from oracle import oracle_c
+    pts, scan, guess, kw = _ndt_inputs()
+    ctx = capi.Context(0)
+    m = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts)
+    al = capi.icp_align(m, capi.Scan(ctx, scan), guess, capi.ICPParams(gn=capi.GNParams(max_inner_iterations=2), **kw))
+    d = synth.make_drive(NDT["drive"]["n_scans"])
+    lo = H.LidarOdometry()
+    lo.initialize(H.Config.FromYamlFile(os.path.join(ROOT, NDT["drive"]["pipeline"])))
+    recs = [lo.onLidar(st, s[0], s[1]) for s, st in zip(d["scans"], d["stamps"])]
+    info = m.info()
+    _check_ndt((int(info.n_points), int(info.n_voxels)), m.download_ndt(), al, oracle_c.TERM_NAMES[al["termination_reason"]], recs)
+    ctx.close()

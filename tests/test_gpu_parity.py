@@ -86,12 +86,7 @@ def test_map_build_from_device_pointers(ctx, oracle):
     assert_maps_equal(g.download(), oracle.Map(1.0, 20).insert(pts).dump())
 
 
-def _ndt_cloud(seed=0):
-    rng = np.random.default_rng(seed)
-    ground = np.stack([rng.uniform(-10, 10, 20000), rng.uniform(-10, 10, 20000), rng.normal(0.3, 0.01, 20000)], 1)
-    wall = np.stack([rng.uniform(-10, 10, 12000), rng.normal(5.4, 0.01, 12000), rng.uniform(0.5, 4, 12000)], 1)
-    blob = rng.normal([3.5, -3.5, 1.5], 0.25, (4000, 3))
-    return np.concatenate([ground, wall, blob]).astype(np.float32)
+_ndt_cloud = synth.ndt_cloud
 
 
 @pytest.mark.parametrize("cap,md", [(0, 0.2), (20, 0.05), (0, 0.0), (7, 0.1)])
