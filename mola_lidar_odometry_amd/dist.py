@@ -74,3 +74,14 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def plan_ranks_on_devices(world: int, local_world: int, n_devices: int, local_rank: int):
+    """How the ranks of one node use its GPUs -> (device index of this rank, number of distinct GPUs in the job,
+    oversubscribed?).  One rank per GPU is the normal case; with more local ranks than GPUs (several sequences per GPU,
+    each in its own process -- they overlap well) the ranks share the devices round robin, and
+    the caller must not use RCCL (one rank per device) for its reductions."""
+    if n_devices <= 0 or local_world <= n_devices:
+        return local_rank, world, False
+    nodes = max(1, world // max(local_world, 1))
+    return local_rank % n_devices, n_devices * nodes, True

@@ -120,14 +120,14 @@ def main(argv=None):
         import torch.distributed as td
         ndev = torch.cuda.device_count() if backend == "nccl" else 0
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        if backend == "nccl" and ndev and local_world > ndev:
-            # more ranks than GPUs (several sequences per GPU, each in its own process): ranks share devices round
-            # robin; RCCL wants one rank per device, and the only collective is a count and a max -> gloo
+        dev, n_gpus, shared = mdist.plan_ranks_on_devices(world, local_world, ndev, int(os.environ.get("LOCAL_RANK", 0)))
+        if backend == "nccl" and shared:
+            # more ranks than GPUs (several sequences per GPU, each in its own process): the only collective is a count
+            # and a max, and RCCL wants one rank per device -> gloo
             backend = "gloo"
-            n_gpus = ndev * (world // local_world)
-            os.environ["MH_DEVICE"] = str(int(os.environ.get("LOCAL_RANK", 0)) % ndev)
+            os.environ["MH_DEVICE"] = str(dev)
         elif backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+            torch.cuda.set_device(dev)
         td.init_process_group(backend)
     red_dev = "cuda" if backend == "nccl" else "cpu"
     os.makedirs(a.out_dir, exist_ok=True)

@@ -136,3 +136,15 @@ def test_sequence_runner_shards_whole_sequences_world2_gloo(tmp_path):
     assert summary[0]["scans"] == 11 and summary[0]["n_gpus"] == 2 and abs(summary[0]["seconds"] - 0.012) < 1e-9
     for seq, n in lengths.items():
         assert len(open(tmp_path / "out" / (seq + ".tum")).read().splitlines()) == n
+
+
+def test_ranks_sharing_devices_plan():
+    """run_odometry accepts more ranks than GPUs: device of each rank, GPUs in the job, and whether RCCL is out."""
+    from mola_lidar_odometry_amd import dist as mdist
+    assert mdist.plan_ranks_on_devices(8, 8, 8, 5) == (5, 8, False)           # one rank per GPU
+    assert [mdist.plan_ranks_on_devices(4, 4, 1, r)[0] for r in range(4)] == [0, 0, 0, 0]
+    assert mdist.plan_ranks_on_devices(4, 4, 1, 3) == (0, 1, True)            # four sequences on one GPU
+    assert [mdist.plan_ranks_on_devices(16, 16, 8, r)[0] for r in (0, 7, 8, 15)] == [0, 7, 0, 7]
+    assert mdist.plan_ranks_on_devices(16, 16, 8, 9) == (1, 8, True)
+    assert mdist.plan_ranks_on_devices(32, 16, 8, 9) == (1, 16, True)         # two nodes
+    assert mdist.plan_ranks_on_devices(2, 2, 0, 1) == (1, 2, False)           # CPU tests of the sharding logic (gloo)
