@@ -17,7 +17,14 @@
 //   k_solve          one workgroup: ordered sum of partials, prior factor, LDL^T, T <- T(+)exp(delta),
 //                    inner/outer loop bookkeeping, stall + hook tests, termination flag, next threshold
 //   k_accum, k_solve (inner Gauss-Newton steps >= 1 on the SAME pairings)
-// A chunk of iterations is one hipGraph launch; every kernel begins with `if (st->done) return`.
+// Smaller layers take shorter chains (chosen by size in AlignJob::start / enqueue_chunk):
+//   <= 32 k points   k_match16: a DPP row (16 lanes) per point; up to 12 k points it also accumulates the first step
+//                    (k_match16<.,true> | k_solve | k_accum | k_solve)
+//   <= 2 k points    k_match16 | k_accum_solve1 | k_accum_solve1: accumulation and solve in one workgroup
+//   NDT maps         Matcher_Point2Plane rides in the row kernel (k_match16<true,.>), its Gauss-Newton rows are summed by
+//                    k_accum_both / k_accum_solve1<true>; above 32 k points k_match_pl (one lane per point)
+// A chunk of iterations is one hipGraph launch when its shape repeats (direct launches otherwise); every kernel begins
+// with `if (st->done) return`.
 // No fp atomics anywhere: reductions are fixed-shape trees, so results are bitwise reproducible.
 #include <stdlib.h>
 #include <string.h>
