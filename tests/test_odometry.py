@@ -342,3 +342,37 @@ def test_driver_objects_release_their_device_memory(host, drive):
         poses, free_now = one_run()
         assert poses == first_poses  # and bitwise the same trajectory every time
     assert free_after_first - free_now < 8 << 20, (free_after_first, free_now)
+
+
+def test_native_cli_is_built_and_explains_itself():
+    """build() also produces molahip-lo-cli (the role of mola-lidar-odometry-cli in eval/cli_kitti.sh); without a GPU
+    it can only print its usage."""
+    import subprocess
+    exe = os.path.join(ROOT, "mola_lidar_odometry_amd", "molahip-lo-cli")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "--seq-dir" in r.stderr
+
+
+@pytest.mark.gpu
+def test_native_cli_matches_the_python_runner(tmp_path, drive, capsys):
+    """One KITTI-style sequence through the C++ command-line driver (next-scan prefetch on) and through the Python
+    runner: the two TUM files are the same text."""
+    import json
+    import subprocess
+    from mola_lidar_odometry_amd import run_odometry
+    _write_kitti_tree(str(tmp_path / "kitti"), drive)
+    seq_dir = str(tmp_path / "kitti" / "sequences" / "00")
+    exe = os.path.join(ROOT, "mola_lidar_odometry_amd", "molahip-lo-cli")
+    out_cli = str(tmp_path / "cli.tum")
+    r = subprocess.run([exe, "--pipeline", PIPE, "--seq-dir", seq_dir, "--out", out_cli], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["scans"] == len(drive["scans"]) and line["good"] >= line["scans"] - 2 and line["scans_per_s"] > 0
+    run_odometry.main(["--kitti-root", str(tmp_path / "kitti"), "--seqs", "00", "--out-dir", str(tmp_path / "out")])
+    seq = json.loads(capsys.readouterr().out.strip().splitlines()[0])
+    assert open(out_cli).read() == open(seq["tum"]).read()
+    seq_np = str(tmp_path / "np.tum")
+    r2 = subprocess.run([exe, "--pipeline", PIPE, "--seq-dir", seq_dir, "--out", seq_np, "--no-prefetch"], capture_output=True,
+                        text=True, timeout=300)
+    assert r2.returncode == 0 and open(seq_np).read() == open(out_cli).read()
