@@ -386,12 +386,16 @@ def test_align_inner_iterations(ctx, oracle, small, inner):
     assert_align_equal(g, o)
 
 
-@pytest.mark.parametrize("poll", [1, 3, 7, 64])
+@pytest.mark.parametrize("poll", [0, 1, 3, 7, 64])
 def test_align_stall_termination_any_poll_interval(ctx, oracle, small, poll):
     """yaml defaults: maxIterations 300, stall thresholds 1e-4 / 5e-5 (lidar3d-default.yaml:173-175).  The
-    termination iteration must equal the oracle's exactly whatever the host polling interval."""
+    termination iteration must equal the oracle's exactly whatever the host polling interval (0 = automatic: the first
+    chunk sized by the context's previous alignment -- run twice so that both the cold and the predicted sizes occur)."""
     w, gm, om, gs = small
     g = capi.icp_align(gm, gs, w.T_guess, _params(capi, w, 300, poll_every=poll))
+    if poll == 0:
+        g2 = capi.icp_align(gm, gs, w.T_guess, _params(capi, w, 300, poll_every=poll))
+        assert g2["n_iterations"] == g["n_iterations"] and np.array_equal(g2["T"], g["T"])
     o = oracle.icp_align(om, w.scan_xyz, w.T_guess, _params(oracle, w, 300))
     assert_align_equal(g, o)
     assert capi.TERM_NAMES[g["termination_reason"]] in ("Stalled", "MaxIterations")
