@@ -77,6 +77,7 @@ struct MapView {
   const float4* pts;  // {x,y,z, bit-cast source index}, voxel-contiguous
   uint32_t mask;      // table_size - 1
   float inv_vs;
+  float vs;           // 1.0f / inv_vs, divided once on the host (the kernels only need it for the pruning bounds)
   uint32_t trunc;     // index_mode == MH_INDEX_TRUNC
   uint32_t ndt;       // 1: every voxel's points are preceded by two records {centroid, plane flag} {normal, 0}
 #ifdef MH_DEBUG_WAVETRACE
@@ -156,6 +157,7 @@ struct mh_map {
     v.pts = pts.as<float4>();
     v.mask = (uint32_t)(table_size ? table_size - 1 : 0);
     v.inv_vs = inv_vs;
+    v.vs = 1.0f / inv_vs;
     v.trunc = params.index_mode == MH_INDEX_TRUNC;
     v.ndt = params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
 #ifdef MH_DEBUG_WAVETRACE

@@ -248,7 +248,7 @@ __device__ __forceinline__ NNResult nn_search_pruned(const MapView& m, float qx,
   const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
   const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
   const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
-  const float vs = 1.0f / m.inv_vs;  // only used for bounds, which carry their own safety margin
+  const float vs = m.vs;  // only used for bounds, which carry their own safety margin
   const Gaps gx = axis_gaps(qx, cx, vs, m.trunc), gy = axis_gaps(qy, cy, vs, m.trunc), gz = axis_gaps(qz, cz, vs, m.trunc);
   NNBest b;
   b.d2 = __builtin_inff();
@@ -456,7 +456,7 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
   const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
   const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
   const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
-  const float vs = 1.0f / m.inv_vs;
+  const float vs = m.vs;
   const Gaps gx = axis_gaps(qx, cx, vs, m.trunc), gy = axis_gaps(qy, cy, vs, m.trunc), gz = axis_gaps(qz, cz, vs, m.trunc);
   const QuadBounds qb = quad_bounds(gx, gy, gz, sub);
   nnkey_t best = kNNKeyNone;
@@ -620,7 +620,7 @@ __device__ __forceinline__ NNResult nn_search_row16(const MapView& m, uint32_t r
   const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
   const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
   const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
-  const float vs = 1.0f / m.inv_vs;
+  const float vs = m.vs;
   const Gaps gx = axis_gaps(qx, cx, vs, m.trunc), gy = axis_gaps(qy, cy, vs, m.trunc), gz = axis_gaps(qz, cz, vs, m.trunc);
   // round 1: lane r owns codes r ("a") and r + 16 ("b", only r <= 10)
   const int ca = (int)r16, cb = (int)r16 + 16;
