@@ -57,9 +57,8 @@ __device__ __forceinline__ NNResult nn_single_search(const MapView& m, float qx,
   r.d2 = __builtin_inff();
   r.found = false;
   r.pt = (f32x4)(0.f);
-  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return r;
-  const float lim = 1.0e6f;
-  if (!(fabsf(qx * m.inv_vs) < lim && fabsf(qy * m.inv_vs) < lim && fabsf(qz * m.inv_vs) < lim)) return r;
+  const float lim = 1.0e6f;  // one test, no short-circuit branches: NaN and inf fail it as well
+  if (!((int)(fabsf(qx * m.inv_vs) < lim) & (int)(fabsf(qy * m.inv_vs) < lim) & (int)(fabsf(qz * m.inv_vs) < lim))) return r;
   const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
   const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
   const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);  // one dwordx4 per slot
@@ -241,9 +240,8 @@ __device__ __forceinline__ NNResult nn_search_pruned(const MapView& m, float qx,
   r.d2 = __builtin_inff();
   r.found = false;
   r.pt = (f32x4)(0.f);
-  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return r;
-  const float lim = 1.0e6f;
-  if (!(fabsf(qx * m.inv_vs) < lim && fabsf(qy * m.inv_vs) < lim && fabsf(qz * m.inv_vs) < lim)) return r;
+  const float lim = 1.0e6f;  // one test, no short-circuit branches: NaN and inf fail it as well
+  if (!((int)(fabsf(qx * m.inv_vs) < lim) & (int)(fabsf(qy * m.inv_vs) < lim) & (int)(fabsf(qz * m.inv_vs) < lim))) return r;
   const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
   const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
   const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
@@ -449,9 +447,8 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
   r.d2 = __builtin_inff();
   r.found = false;
   r.pt = (f32x4)(0.f);
-  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return r;
-  const float lim = 1.0e6f;
-  if (!(fabsf(qx * m.inv_vs) < lim && fabsf(qy * m.inv_vs) < lim && fabsf(qz * m.inv_vs) < lim)) return r;
+  const float lim = 1.0e6f;  // one test, no short-circuit branches: NaN and inf fail it as well
+  if (!((int)(fabsf(qx * m.inv_vs) < lim) & (int)(fabsf(qy * m.inv_vs) < lim) & (int)(fabsf(qz * m.inv_vs) < lim))) return r;
   const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
   const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
   const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
@@ -613,9 +610,8 @@ __device__ __forceinline__ NNResult nn_search_row16(const MapView& m, uint32_t r
   r.d2 = __builtin_inff();
   r.found = false;
   r.pt = (f32x4)(0.f);
-  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return r;
-  const float lim = 1.0e6f;
-  if (!(fabsf(qx * m.inv_vs) < lim && fabsf(qy * m.inv_vs) < lim && fabsf(qz * m.inv_vs) < lim)) return r;
+  const float lim = 1.0e6f;  // one test, no short-circuit branches: NaN and inf fail it as well
+  if (!((int)(fabsf(qx * m.inv_vs) < lim) & (int)(fabsf(qy * m.inv_vs) < lim) & (int)(fabsf(qz * m.inv_vs) < lim))) return r;
   const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
   const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
   const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
