@@ -155,7 +155,10 @@ mh_status mh_ctx_destroy(mh_ctx* ctx) {
   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   if (ctx->h_state) (void)hipHostFree(ctx->h_state);
-  if (ctx->h_sched) (void)hipHostFree(ctx->h_sched);  // d_params / h_params point into the state blocks
+  if (ctx->h_sched) (void)hipHostFree(ctx->h_sched);
+  if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
+  ctx->batch_desc.release();
+  ctx->batch_states.release();  // d_params / h_params point into the state blocks
   if (ctx->ev_poll) (void)hipEventDestroy(ctx->ev_poll);
   if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
   if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);

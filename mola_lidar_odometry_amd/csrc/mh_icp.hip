@@ -100,6 +100,21 @@ struct PoseArg {
   double m[12];
 };
 
+// mh_icp_align_batch, lock-step mode: one descriptor per alignment; the *_b kernels take blockIdx.y as the job index.
+// One launch over all jobs keeps the device full across their tails: per 120 k-point scan the match step costs 9.7 us
+// in a launch of sixteen scans' worth of points, 21.8 us alone (tools/batch_hypothesis.py).
+struct BatchJob {
+  IcpDeviceState* st;
+  const MatchK* mk;
+  const SolveK* sk;
+  const float *lx, *ly, *lz;
+  uint32_t n, nb, nba, pad;
+  MapView map;
+  float4* pair_q;
+  uint32_t* pair_gidx;
+  double* part;
+};
+
 // LDS hand-off between lanes of ONE wave: LDS operations of a wave execute in order, so only the compiler has to be
 // kept from moving the accesses across this point.
 __device__ __forceinline__ void wave_sync_lds() {
@@ -228,7 +243,7 @@ extern "C" __attribute__((visibility("default"))) int mh_debug_wavetrace(unsigne
 // fused k_match, but it only stores the pairings: the first Gauss-Newton accumulation is the k_accum launch that
 // follows (64 points per wave there, 16 here).
 // ================================================================================================
-__global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDeviceState* __restrict__ st,
+__device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__ st,
                                                    const float* __restrict__ lx, const float* __restrict__ ly,
                                                    const float* __restrict__ lz, uint32_t n, MapView map,
                                                    float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx
@@ -276,7 +291,7 @@ constexpr uint32_t kRowMaxPoints = 32768;  // measured cross-over with the quad 
 constexpr uint32_t kAccPPT = 4;  // scan points per lane of k_accum
 inline uint32_t nblk_acc(size_t n) { return (uint32_t)((n + (size_t)kBlock * kAccPPT - 1) / ((size_t)kBlock * kAccPPT)); }
 
-__global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first,
+__device__ __forceinline__ void k_accum_body(const IcpDeviceState* __restrict__ st, uint32_t first,
                                                   const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                   const float4* __restrict__ pair_q,
@@ -921,7 +936,7 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, cons
   MH_PHASE(10);
 }
 
-__global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
+__device__ __forceinline__ void k_solve_body(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
                                                          const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                                          const double* __restrict__ partB, uint32_t nB,
                                                          uint32_t strideB) {
@@ -1067,7 +1082,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* 
 // ================================================================================================
 constexpr int kCovN = 22;  // 21 upper-triangle + count
 
-__global__ void k_cov_prepare(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp, uint32_t force) {
+__device__ __forceinline__ void k_cov_prepare_body(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp, uint32_t force) {
   if (!force && (!st->done || st->cov_done)) return;
   const int j = threadIdx.x;
   if (j >= 6) return;
@@ -1084,7 +1099,7 @@ __global__ void k_cov_prepare(IcpDeviceState* __restrict__ st, const SolveK* __r
   for (int i = 0; i < 12; i++) st->covD[j * 12 + i] = (P.m[i] - M.m[i]) / (2.0 * h);
 }
 
-__global__ __launch_bounds__(kBlock) void k_cov_accum(const IcpDeviceState* __restrict__ st, uint32_t force,
+__device__ __forceinline__ void k_cov_accum_body(const IcpDeviceState* __restrict__ st, uint32_t force,
                                                       const float* __restrict__ lx, const float* __restrict__ ly,
                                                       const float* __restrict__ lz, uint32_t n,
                                                       const uint32_t* __restrict__ pair_gidx,
@@ -1187,7 +1202,7 @@ __global__ __launch_bounds__(kBlock) void k_cov_accum_plbuf(const IcpDeviceState
   block_sum_rows<kCovN>(v, lds, partials, pstride, blockIdx.x);
 }
 
-__global__ __launch_bounds__(kSolveThreads) void k_cov_finalize(IcpDeviceState* __restrict__ st, uint32_t force,
+__device__ __forceinline__ void k_cov_finalize_body(IcpDeviceState* __restrict__ st, uint32_t force,
                                                                 const double* __restrict__ partA, uint32_t nA,
                                                                 uint32_t strideA, const double* __restrict__ partB,
                                                                 uint32_t nB, uint32_t strideB) {
@@ -1219,6 +1234,88 @@ __global__ __launch_bounds__(kSolveThreads) void k_cov_finalize(IcpDeviceState* 
 // ================================================================================================
 // Pairing compaction: per-block count -> scan of block counts -> ballot/prefix scatter.
 // Output order = ascending local index (what a serial matcher emits).
+// ---- kernel entry points of the bodies above: one alignment per launch, or one job per blockIdx.y -------------------
+__global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDeviceState* __restrict__ st,
+                                                   const float* __restrict__ lx, const float* __restrict__ ly,
+                                                   const float* __restrict__ lz, uint32_t n, MapView map,
+                                                   float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx
+#ifdef MH_DEBUG_WAVETRACE
+                                                   , unsigned long long* __restrict__ wtrace
+#endif
+) {
+  k_match4_body(st, lx, ly, lz, n, map, pair_q, pair_gidx
+#ifdef MH_DEBUG_WAVETRACE
+                , wtrace
+#endif
+  );
+}
+__global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  k_match4_body(j.st, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx
+#ifdef MH_DEBUG_WAVETRACE
+                , nullptr
+#endif
+  );
+}
+__global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first,
+                                                  const MatchK* __restrict__ kp, const float* __restrict__ lx,
+                                                  const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                  const float4* __restrict__ pair_q,
+                                                  const uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
+                                                  uint32_t pstride) {
+  k_accum_body(st, first, kp, lx, ly, lz, n, pair_q, pair_gidx, partials, pstride);
+}
+__global__ __launch_bounds__(kBlock) void k_accum_b(const BatchJob* __restrict__ jobs, uint32_t first) {
+  const BatchJob& j = jobs[blockIdx.y];
+  if (blockIdx.x >= j.nba) return;
+  k_accum_body(j.st, first, j.mk, j.lx, j.ly, j.lz, j.n, j.pair_q, j.pair_gidx, j.part, j.nba);
+}
+__global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
+                                                         const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
+                                                         const double* __restrict__ partB, uint32_t nB,
+                                                         uint32_t strideB) {
+  k_solve_body(st, kp, partA, nA, strideA, partB, nB, strideB);
+}
+__global__ __launch_bounds__(kSolveThreads) void k_solve_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  k_solve_body(j.st, j.sk, j.part, j.nba, j.nba, nullptr, 0u, 0u);
+}
+__global__ void k_cov_prepare(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp, uint32_t force) {
+  k_cov_prepare_body(st, kp, force);
+}
+__global__ void k_cov_prepare_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  k_cov_prepare_body(j.st, j.sk, 0u);
+}
+__global__ __launch_bounds__(kBlock) void k_cov_accum(const IcpDeviceState* __restrict__ st, uint32_t force,
+                                                      const float* __restrict__ lx, const float* __restrict__ ly,
+                                                      const float* __restrict__ lz, uint32_t n,
+                                                      const uint32_t* __restrict__ pair_gidx,
+                                                      double* __restrict__ partials, uint32_t pstride) {
+  k_cov_accum_body(st, force, lx, ly, lz, n, pair_gidx, partials, pstride);
+}
+__global__ __launch_bounds__(kBlock) void k_cov_accum_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  if (blockIdx.x >= j.nb) return;
+  k_cov_accum_body(j.st, 0u, j.lx, j.ly, j.lz, j.n, j.pair_gidx, j.part, j.nb);
+}
+__global__ __launch_bounds__(kSolveThreads) void k_cov_finalize(IcpDeviceState* __restrict__ st, uint32_t force,
+                                                                const double* __restrict__ partA, uint32_t nA,
+                                                                uint32_t strideA, const double* __restrict__ partB,
+                                                                uint32_t nB, uint32_t strideB) {
+  k_cov_finalize_body(st, force, partA, nA, strideA, partB, nB, strideB);
+}
+__global__ __launch_bounds__(kSolveThreads) void k_cov_finalize_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  k_cov_finalize_body(j.st, 0u, j.part, j.nb, j.nb, nullptr, 0u, 0u);
+}
+// all jobs' state blocks into one contiguous buffer: one read-back per chunk instead of one per job
+__global__ void k_gather_states(const BatchJob* __restrict__ jobs, IcpDeviceState* __restrict__ out) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(jobs[blockIdx.x].st);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(out + blockIdx.x);
+  for (uint32_t i = threadIdx.x; i < sizeof(IcpDeviceState) / 4; i += blockDim.x) dst[i] = src[i];
+}
+
 // ================================================================================================
 __global__ __launch_bounds__(kBlock) void k_count_valid(const uint32_t* __restrict__ gidx, uint32_t n,
                                                         uint32_t* __restrict__ block_counts) {
@@ -1787,10 +1884,10 @@ struct AlignJob {
   }
 
   // waits for the last enqueued chunk; sets finished when the device loop has terminated
-  mh_status poll() {
+  mh_status poll(bool already_synced = false) {  // (lock-step batches copy the state into h_state themselves)
     if (finished) return MH_OK;
     MH_TRY(set_device(ctx));
-    MH_HIP(hipEventSynchronize(ctx->ev_poll));
+    if (!already_synced) MH_HIP(hipEventSynchronize(ctx->ev_poll));
     const IcpDeviceState* h = ctx->h_state;
     if (!h->done && enqueued < p->max_iterations) {
       if (auto_chunk) chunk = 6;
@@ -1882,6 +1979,114 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       MH_REQUIRE(scans[j]->ctx != scans[i]->ctx, "each job of a batch needs its own context");
     MH_TRY(jobs[i].start(maps[i], scans[i], params, T_guesses + 12 * i, priors ? priors[i] : nullptr, &results[i],
                          nullptr, i));
+  }
+  // Lock-step mode: every kernel of an iteration is ONE launch over all jobs (blockIdx.y = job).  The jobs' tails fill
+  // each other's idle lanes, which concurrent streams do not achieve (HIP maps them onto four hardware queues whose
+  // kernels mostly run one after the other).  Taken for the large-layer chain (quad matcher, point-to-point).
+  std::vector<AlignJob*> act;
+  for (auto& j : jobs)
+    if (!j.finished) act.push_back(&j);
+  bool lockstep = act.size() >= 2 && getenv("MH_NO_LOCKSTEP") == nullptr;
+  for (AlignJob* j : act) lockstep = lockstep && j->variant == 4 && !j->pl && !j->trace && j->ctx->device == act[0]->ctx->device;
+  if (lockstep) {
+    const uint32_t A = (uint32_t)act.size();
+    mh_ctx* lead = act[0]->ctx;
+    MH_TRY(set_device(lead));
+    hipStream_t s = lead->stream;
+    const bool want_prof = act[0]->prof;
+    for (AlignJob* j : act) j->prof = false;
+    MH_TRY(lead->batch_desc.reserve(A * sizeof(BatchJob)));
+    MH_TRY(lead->batch_states.reserve(A * sizeof(IcpDeviceState)));
+    if (lead->h_batch_cap < A * sizeof(IcpDeviceState) + A * sizeof(BatchJob)) {
+      if (lead->h_batch) (void)hipHostFree(lead->h_batch);
+      lead->h_batch = nullptr;
+      lead->h_batch_cap = 0;
+      MH_HIP(hipHostMalloc(&lead->h_batch, A * sizeof(IcpDeviceState) + A * sizeof(BatchJob), hipHostMallocDefault));
+      lead->h_batch_cap = A * sizeof(IcpDeviceState) + A * sizeof(BatchJob);
+    }
+    IcpDeviceState* h_states = reinterpret_cast<IcpDeviceState*>(lead->h_batch);
+    BatchJob* h_desc = reinterpret_cast<BatchJob*>(reinterpret_cast<char*>(lead->h_batch) + A * sizeof(IcpDeviceState));
+    uint32_t gx_match = 1, gx_acc = 1, gx_cov = 1;
+    for (uint32_t a = 0; a < A; a++) {
+      AlignJob& j = *act[a];
+      BatchJob& d = h_desc[a];
+      memset(&d, 0, sizeof(d));
+      d.st = j.ctx->d_state;
+      d.mk = &j.ctx->d_params->mk;
+      d.sk = &j.ctx->d_params->sk;
+      d.lx = j.scan->x; d.ly = j.scan->y; d.lz = j.scan->z;
+      d.n = (uint32_t)j.scan->n;
+      d.nb = j.nb;
+      d.nba = j.nba;
+      d.map = j.map->view();
+      d.pair_q = j.ctx->pair_q.as<float4>();
+      d.pair_gidx = j.ctx->pair_gidx.as<uint32_t>();
+      d.part = j.ctx->partials.as<double>();
+      const uint32_t bm = (uint32_t)((4ull * d.n + kBlock - 1) / kBlock);
+      gx_match = bm > gx_match ? bm : gx_match;
+      gx_acc = d.nba > gx_acc ? d.nba : gx_acc;
+      gx_cov = d.nb > gx_cov ? d.nb : gx_cov;
+      if (a) {  // the other jobs' start() uploads went out on their own streams
+        MH_HIP(hipEventRecord(j.ctx->ev_poll, j.ctx->stream));
+        MH_HIP(hipStreamWaitEvent(s, j.ctx->ev_poll, 0));
+      }
+    }
+    MH_HIP(hipMemcpyAsync(lead->batch_desc.p, h_desc, A * sizeof(BatchJob), hipMemcpyHostToDevice, s));
+    const BatchJob* dj = lead->batch_desc.as<BatchJob>();
+    const uint32_t chunk = params->poll_every ? params->poll_every : 10;
+    uint32_t enq = 0, prof_n = 0;
+    bool all_done = false;
+    while (!all_done) {
+      const uint32_t m = (params->max_iterations - enq) < chunk ? (params->max_iterations - enq) : chunk;
+      for (uint32_t it = 0; it < m; it++) {
+        if (want_prof) MH_HIP(hipEventRecord(lead->prof_ev[2 * prof_n], s));
+        hipLaunchKernelGGL(k_match4_b, dim3(gx_match, A), dim3(kBlock), 0, s, dj);
+        if (want_prof) {
+          MH_HIP(hipEventRecord(lead->prof_ev[2 * prof_n + 1], s));
+          prof_n++;
+        }
+        hipLaunchKernelGGL(k_accum_b, dim3(gx_acc, A), dim3(kBlock), 0, s, dj, 1u);
+        hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, dj);
+        for (uint32_t in = 1; in < params->gn.max_inner_iterations; in++) {
+          hipLaunchKernelGGL(k_accum_b, dim3(gx_acc, A), dim3(kBlock), 0, s, dj, 0u);
+          hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, dj);
+        }
+      }
+      if (params->compute_covariance) {  // no-ops for jobs whose loop has not terminated
+        hipLaunchKernelGGL(k_cov_prepare_b, dim3(1, A), dim3(64), 0, s, dj);
+        hipLaunchKernelGGL(k_cov_accum_b, dim3(gx_cov, A), dim3(kBlock), 0, s, dj);
+        hipLaunchKernelGGL(k_cov_finalize_b, dim3(1, A), dim3(kSolveThreads), 0, s, dj);
+      }
+      hipLaunchKernelGGL(k_gather_states, dim3(A), dim3(256), 0, s, dj, lead->batch_states.as<IcpDeviceState>());
+      MH_HIP(hipGetLastError());
+      MH_HIP(hipMemcpyAsync(h_states, lead->batch_states.p, A * sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
+      MH_HIP(hipStreamSynchronize(s));
+      enq += m;
+      all_done = true;
+      for (uint32_t a = 0; a < A; a++) {
+        AlignJob& j = *act[a];
+        if (j.finished) continue;
+        memcpy(j.ctx->h_state, &h_states[a], sizeof(IcpDeviceState));
+        j.enqueued = enq;
+        MH_TRY(j.poll(true));
+        all_done = all_done && j.finished;
+      }
+    }
+    if (want_prof) {  // the match step of job 0 = its share of the batched launches
+      float ms = 0.f;
+      double sum = 0.0;
+      const mh_icp_result* r0 = act[0]->res;
+      uint32_t live = r0->n_iterations + ((r0->termination_reason == MH_TERM_MAX_ITERATIONS) ? 0u : 1u);
+      if (live > prof_n) live = prof_n;
+      for (uint32_t i = 0; i < live; i++) {
+        MH_HIP(hipEventElapsedTime(&ms, lead->prof_ev[2 * i], lead->prof_ev[2 * i + 1]));
+        sum += ms;
+      }
+      act[0]->res->n_match_launches = live;
+      act[0]->res->match_kernel_ms = sum / (double)A;
+      act[0]->res->total_ms = 0.0;
+    }
+    return MH_OK;
   }
   for (;;) {
     bool any = false;

@@ -116,6 +116,9 @@ struct mh_ctx {
   mh::DevBuf partials;    // per-block reduction partials (double)
   mh::DevBuf partials_b;  // generic (pt2pl) partials
   mh::DevBuf sched;       // threshold / kernel-param arrays (double)
+  mh::DevBuf batch_desc, batch_states;  // lock-step batches led by this context: job descriptors, gathered states
+  void* h_batch = nullptr;              // pinned mirror of both
+  size_t h_batch_cap = 0;
   uint32_t predicted_iterations = 0;  // launches the last auto-chunked alignment needed (sizes the next first chunk)
   double* h_sched = nullptr;  // pinned staging for them
   size_t h_sched_cap = 0;

@@ -93,3 +93,37 @@ def test_aligning_map_points_to_their_map_is_a_fixed_point(ctx, gmap, c2):
     np.testing.assert_array_equal(r["T"], np.eye(4)[:3].reshape(12))       # zero residuals: the solve returns delta = 0
     assert r["n_final_pairs"] == len(sub) and r["quality"] == 1.0
     assert capi.TERM_NAMES[r["termination_reason"]] == "Stalled" and r["n_iterations"] == 0
+
+
+def test_lockstep_batch_equals_single_alignments(gmap, c2, monkeypatch):
+    """mh_icp_align_batch runs large-layer jobs in lock step (one launch per kernel over all jobs, blockIdx.y = job):
+    ragged scan sizes, different guesses, a prior on one job, a stall-terminated run where the jobs finish at different
+    iterations -- every result is bitwise the single alignment's, and so is the per-stream fallback's."""
+    sizes = [len(c2.scan_xyz), 50000, 77777]
+    ctxs = [capi.Context(0) for _ in sizes]
+    scans = [capi.Scan(c, c2.scan_xyz[:n]) for c, n in zip(ctxs, sizes)]
+    rng = np.random.default_rng(5)
+    guesses = []
+    for _ in sizes:
+        g = c2.guess_ypr.copy()
+        g[:3] += rng.normal(0, 0.05, 3)
+        guesses.append(synth.pose_from_ypr(g))
+    prior = (c2.T_guess, np.diag([4.0, 4.0, 4.0, 100.0, 100.0, 100.0]))
+    thr, kp = synth.threshold_schedule(c2.sigma, 60)
+    for kw, priors in ((dict(max_iterations=6, disable_stall_test=True, threshold=c2.threshold[:6], kernel_param=c2.kernel_param[:6],
+                             poll_every=6), None),
+                       (dict(max_iterations=60, threshold=thr, kernel_param=kp, poll_every=4), [None, prior, None])):
+        p = capi.ICPParams(**kw)
+        singles = [capi.icp_align(gmap, s, g, p, prior=(priors[i] if priors else None), want_trace=False)
+                   for i, (s, g) in enumerate(zip(scans, guesses))]
+        batch = capi.icp_align_batch([gmap] * 3, scans, guesses, p, priors=priors)
+        monkeypatch.setenv("MH_NO_LOCKSTEP", "1")
+        streams = capi.icp_align_batch([gmap] * 3, scans, guesses, p, priors=priors)
+        monkeypatch.delenv("MH_NO_LOCKSTEP")
+        for a, b, c in zip(singles, batch, streams):
+            for r in (b, c):
+                assert (r["n_iterations"], r["termination_reason"], r["n_final_pairs"]) == (
+                    a["n_iterations"], a["termination_reason"], a["n_final_pairs"])
+                assert np.array_equal(r["T"], a["T"]) and np.array_equal(r["cov"], a["cov"]) and r["quality"] == a["quality"]
+    for c in ctxs:
+        c.close()
