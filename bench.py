@@ -185,8 +185,8 @@ def main():
                     "avg_kernel_ms": avg_ms, "launches": match_launches,
                     "avg_kernel_ms_alone": (iso_ms / iso_launches) if iso_launches else None, "p_bar": p_bar,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "note": "HIP events around the match kernel of every iteration of stream 0 inside the timed region, with the other "
-                            "streams' kernels running concurrently (they replay a captured hipGraph). The working set "
+                    "note": "avg_kernel_ms = the match step PER SCAN inside the timed region: HIP events around every lock-step match "
+                            "launch (one launch over all scans of the step, blockIdx.y = scan) divided by the scans in it. The working set "
                             "(16 MB of records + the hash table) is cache resident: measured HBM traffic (`traffic`, bytes "
                             "per launch) is ~30x below the algorithmic bytes, so `achieved` is a rate of ALGORITHMIC bytes "
                             "and can exceed the HBM peak; what the kernel waits for is the chain of dependent L1-miss "
@@ -200,12 +200,13 @@ def main():
                 roof["traffic"] = summary.get("k_match_fused_hbm_bytes_per_launch")
                 roof["traffic_source"] = os.path.basename(pmc[-1])
                 # second view, since HBM is not what this kernel waits for: VALU issue.  SQ_INSTS_VALU wave-instructions per
-                # launch / (1024 SIMDs x 2.4 GHz / 4 cycles per 64-lane instruction) = the time the launch needs if
-                # nothing but VALU issue limited it; its share of the measured single-stream launch time
+                # scan / (1024 SIMD-32s x 2.4 GHz / 2 cycles per wave64 instruction, MI355X_MICROARCH.md) = the time the
+                # match step of one scan needs if nothing but VALU issue limited it; its share of the measured time per
+                # scan, alone and inside the lock-step batch
                 mk = [k for k in summary.get("counters", {}) if k.startswith("k_match4")] if kname.startswith("k_match4") else []
                 valu = summary["counters"][mk[0]].get("SQ_INSTS_VALU", {}).get("mean") if mk else None
                 if valu and roof["avg_kernel_ms_alone"]:
-                    floor_ms = valu / (1024 * 2.4e9 / 4.0) * 1e3
+                    floor_ms = valu / (1024 * 2.4e9 / 2.0) * 1e3
                     roof["valu"] = {"wave_instructions_per_launch": valu, "issue_floor_ms": floor_ms,
                                     "frac_of_launch_alone": floor_ms / roof["avg_kernel_ms_alone"],
                                     "frac_of_launch_concurrent": floor_ms / avg_ms}
