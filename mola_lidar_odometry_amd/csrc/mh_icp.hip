@@ -1989,101 +1989,146 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
   bool lockstep = act.size() >= 2 && getenv("MH_NO_LOCKSTEP") == nullptr;
   for (AlignJob* j : act) lockstep = lockstep && j->variant == 4 && !j->pl && !j->trace && j->ctx->device == act[0]->ctx->device;
   if (lockstep) {
-    const uint32_t A = (uint32_t)act.size();
-    mh_ctx* lead = act[0]->ctx;
-    MH_TRY(set_device(lead));
-    hipStream_t s = lead->stream;
+    // MH_LOCKSTEP_GROUPS splits the jobs into groups that advance independently, each on its leader's stream, so that one
+    // group's match launch runs while the other is in its short accumulate / solve launches.  Measured on C2 with 32
+    // jobs: 1 group 3580-3610 scans/s, 2 groups 3680-3770, 4 groups 3090 -- overlapping match launches slow each other
+    // down (9.9 -> 16-17 us per scan), so the gain is small; the default stays at one group, whose kernel times are
+    // also the ones a (stream-serialising) profiler reports.
     const bool want_prof = act[0]->prof;
     for (AlignJob* j : act) j->prof = false;
-    MH_TRY(lead->batch_desc.reserve(A * sizeof(BatchJob)));
-    MH_TRY(lead->batch_states.reserve(A * sizeof(IcpDeviceState)));
-    if (lead->h_batch_cap < A * sizeof(IcpDeviceState) + A * sizeof(BatchJob)) {
-      if (lead->h_batch) (void)hipHostFree(lead->h_batch);
-      lead->h_batch = nullptr;
-      lead->h_batch_cap = 0;
-      MH_HIP(hipHostMalloc(&lead->h_batch, A * sizeof(IcpDeviceState) + A * sizeof(BatchJob), hipHostMallocDefault));
-      lead->h_batch_cap = A * sizeof(IcpDeviceState) + A * sizeof(BatchJob);
-    }
-    IcpDeviceState* h_states = reinterpret_cast<IcpDeviceState*>(lead->h_batch);
-    BatchJob* h_desc = reinterpret_cast<BatchJob*>(reinterpret_cast<char*>(lead->h_batch) + A * sizeof(IcpDeviceState));
-    uint32_t gx_match = 1, gx_acc = 1, gx_cov = 1;
-    for (uint32_t a = 0; a < A; a++) {
-      AlignJob& j = *act[a];
-      BatchJob& d = h_desc[a];
-      memset(&d, 0, sizeof(d));
-      d.st = j.ctx->d_state;
-      d.mk = &j.ctx->d_params->mk;
-      d.sk = &j.ctx->d_params->sk;
-      d.lx = j.scan->x; d.ly = j.scan->y; d.lz = j.scan->z;
-      d.n = (uint32_t)j.scan->n;
-      d.nb = j.nb;
-      d.nba = j.nba;
-      d.map = j.map->view();
-      d.pair_q = j.ctx->pair_q.as<float4>();
-      d.pair_gidx = j.ctx->pair_gidx.as<uint32_t>();
-      d.part = j.ctx->partials.as<double>();
-      const uint32_t bm = (uint32_t)((4ull * d.n + kBlock - 1) / kBlock);
-      gx_match = bm > gx_match ? bm : gx_match;
-      gx_acc = d.nba > gx_acc ? d.nba : gx_acc;
-      gx_cov = d.nb > gx_cov ? d.nb : gx_cov;
-      if (a) {  // the other jobs' start() uploads went out on their own streams
-        MH_HIP(hipEventRecord(j.ctx->ev_poll, j.ctx->stream));
-        MH_HIP(hipStreamWaitEvent(s, j.ctx->ev_poll, 0));
+    uint32_t n_groups = 1;
+    if (const char* e = getenv("MH_LOCKSTEP_GROUPS")) n_groups = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : n_groups;
+    if (n_groups > act.size() / 2) n_groups = (uint32_t)(act.size() / 2) ? (uint32_t)(act.size() / 2) : 1u;
+    struct Group {
+      std::vector<AlignJob*> jobs;
+      mh_ctx* lead = nullptr;
+      IcpDeviceState* h_states = nullptr;
+      const BatchJob* dj = nullptr;
+      uint32_t gx_match = 1, gx_acc = 1, gx_cov = 1, enq = 0, prof_n = 0;
+      bool done = false;
+    };
+    std::vector<Group> groups(n_groups);
+    for (size_t a = 0; a < act.size(); a++) groups[a * n_groups / act.size()].jobs.push_back(act[a]);
+    MH_TRY(set_device(act[0]->ctx));
+    for (Group& g : groups) {
+      const uint32_t A = (uint32_t)g.jobs.size();
+      mh_ctx* lead = g.lead = g.jobs[0]->ctx;
+      hipStream_t s = lead->stream;
+      MH_TRY(lead->batch_desc.reserve(A * sizeof(BatchJob)));
+      MH_TRY(lead->batch_states.reserve(A * sizeof(IcpDeviceState)));
+      if (lead->h_batch_cap < A * sizeof(IcpDeviceState) + A * sizeof(BatchJob)) {
+        if (lead->h_batch) (void)hipHostFree(lead->h_batch);
+        lead->h_batch = nullptr;
+        lead->h_batch_cap = 0;
+        MH_HIP(hipHostMalloc(&lead->h_batch, A * sizeof(IcpDeviceState) + A * sizeof(BatchJob), hipHostMallocDefault));
+        lead->h_batch_cap = A * sizeof(IcpDeviceState) + A * sizeof(BatchJob);
       }
-    }
-    MH_HIP(hipMemcpyAsync(lead->batch_desc.p, h_desc, A * sizeof(BatchJob), hipMemcpyHostToDevice, s));
-    const BatchJob* dj = lead->batch_desc.as<BatchJob>();
-    const uint32_t chunk = params->poll_every ? params->poll_every : 10;
-    uint32_t enq = 0, prof_n = 0;
-    bool all_done = false;
-    while (!all_done) {
-      const uint32_t m = (params->max_iterations - enq) < chunk ? (params->max_iterations - enq) : chunk;
-      for (uint32_t it = 0; it < m; it++) {
-        if (want_prof) MH_HIP(hipEventRecord(lead->prof_ev[2 * prof_n], s));
-        hipLaunchKernelGGL(k_match4_b, dim3(gx_match, A), dim3(kBlock), 0, s, dj);
-        if (want_prof) {
-          MH_HIP(hipEventRecord(lead->prof_ev[2 * prof_n + 1], s));
-          prof_n++;
-        }
-        hipLaunchKernelGGL(k_accum_b, dim3(gx_acc, A), dim3(kBlock), 0, s, dj, 1u);
-        hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, dj);
-        for (uint32_t in = 1; in < params->gn.max_inner_iterations; in++) {
-          hipLaunchKernelGGL(k_accum_b, dim3(gx_acc, A), dim3(kBlock), 0, s, dj, 0u);
-          hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, dj);
-        }
-      }
-      if (params->compute_covariance) {  // no-ops for jobs whose loop has not terminated
-        hipLaunchKernelGGL(k_cov_prepare_b, dim3(1, A), dim3(64), 0, s, dj);
-        hipLaunchKernelGGL(k_cov_accum_b, dim3(gx_cov, A), dim3(kBlock), 0, s, dj);
-        hipLaunchKernelGGL(k_cov_finalize_b, dim3(1, A), dim3(kSolveThreads), 0, s, dj);
-      }
-      hipLaunchKernelGGL(k_gather_states, dim3(A), dim3(256), 0, s, dj, lead->batch_states.as<IcpDeviceState>());
-      MH_HIP(hipGetLastError());
-      MH_HIP(hipMemcpyAsync(h_states, lead->batch_states.p, A * sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
-      MH_HIP(hipStreamSynchronize(s));
-      enq += m;
-      all_done = true;
+      g.h_states = reinterpret_cast<IcpDeviceState*>(lead->h_batch);
+      BatchJob* h_desc = reinterpret_cast<BatchJob*>(reinterpret_cast<char*>(lead->h_batch) + A * sizeof(IcpDeviceState));
       for (uint32_t a = 0; a < A; a++) {
-        AlignJob& j = *act[a];
-        if (j.finished) continue;
-        memcpy(j.ctx->h_state, &h_states[a], sizeof(IcpDeviceState));
-        j.enqueued = enq;
-        MH_TRY(j.poll(true));
-        all_done = all_done && j.finished;
+        AlignJob& j = *g.jobs[a];
+        BatchJob& d = h_desc[a];
+        memset(&d, 0, sizeof(d));
+        d.st = j.ctx->d_state;
+        d.mk = &j.ctx->d_params->mk;
+        d.sk = &j.ctx->d_params->sk;
+        d.lx = j.scan->x; d.ly = j.scan->y; d.lz = j.scan->z;
+        d.n = (uint32_t)j.scan->n;
+        d.nb = j.nb;
+        d.nba = j.nba;
+        d.map = j.map->view();
+        d.pair_q = j.ctx->pair_q.as<float4>();
+        d.pair_gidx = j.ctx->pair_gidx.as<uint32_t>();
+        d.part = j.ctx->partials.as<double>();
+        const uint32_t bm = (uint32_t)((4ull * d.n + kBlock - 1) / kBlock);
+        g.gx_match = bm > g.gx_match ? bm : g.gx_match;
+        g.gx_acc = d.nba > g.gx_acc ? d.nba : g.gx_acc;
+        g.gx_cov = d.nb > g.gx_cov ? d.nb : g.gx_cov;
+        if (a) {  // the other jobs' start() uploads went out on their own streams
+          MH_HIP(hipEventRecord(j.ctx->ev_poll, j.ctx->stream));
+          MH_HIP(hipStreamWaitEvent(s, j.ctx->ev_poll, 0));
+        }
+      }
+      MH_HIP(hipMemcpyAsync(lead->batch_desc.p, h_desc, A * sizeof(BatchJob), hipMemcpyHostToDevice, s));
+      g.dj = lead->batch_desc.as<BatchJob>();
+    }
+    const uint32_t chunk = params->poll_every ? params->poll_every : 10;
+    for (;;) {
+      bool any = false;
+      uint32_t m_of[64] = {0};
+      // enqueue one chunk per unfinished group, iteration by iteration across the groups so that their launches interleave
+      uint32_t m_max = 0;
+      for (size_t gi = 0; gi < groups.size() && gi < 64; gi++) {
+        Group& g = groups[gi];
+        if (g.done) continue;
+        any = true;
+        m_of[gi] = (params->max_iterations - g.enq) < chunk ? (params->max_iterations - g.enq) : chunk;
+        m_max = m_of[gi] > m_max ? m_of[gi] : m_max;
+      }
+      if (!any) break;
+      for (uint32_t it = 0; it < m_max; it++)
+        for (size_t gi = 0; gi < groups.size() && gi < 64; gi++) {
+          Group& g = groups[gi];
+          if (g.done || it >= m_of[gi]) continue;
+          hipStream_t s = g.lead->stream;
+          const uint32_t A = (uint32_t)g.jobs.size();
+          const bool pr = want_prof && gi == 0;
+          if (pr) MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n], s));
+          hipLaunchKernelGGL(k_match4_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj);
+          if (pr) {
+            MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n + 1], s));
+            g.prof_n++;
+          }
+          hipLaunchKernelGGL(k_accum_b, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 1u);
+          hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj);
+          for (uint32_t in = 1; in < params->gn.max_inner_iterations; in++) {
+            hipLaunchKernelGGL(k_accum_b, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 0u);
+            hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj);
+          }
+        }
+      for (size_t gi = 0; gi < groups.size() && gi < 64; gi++) {
+        Group& g = groups[gi];
+        if (g.done) continue;
+        hipStream_t s = g.lead->stream;
+        const uint32_t A = (uint32_t)g.jobs.size();
+        if (params->compute_covariance) {  // no-ops for jobs whose loop has not terminated
+          hipLaunchKernelGGL(k_cov_prepare_b, dim3(1, A), dim3(64), 0, s, g.dj);
+          hipLaunchKernelGGL(k_cov_accum_b, dim3(g.gx_cov, A), dim3(kBlock), 0, s, g.dj);
+          hipLaunchKernelGGL(k_cov_finalize_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj);
+        }
+        hipLaunchKernelGGL(k_gather_states, dim3(A), dim3(256), 0, s, g.dj, g.lead->batch_states.as<IcpDeviceState>());
+        MH_HIP(hipGetLastError());
+        MH_HIP(hipMemcpyAsync(g.h_states, g.lead->batch_states.p, A * sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
+      }
+      for (size_t gi = 0; gi < groups.size() && gi < 64; gi++) {
+        Group& g = groups[gi];
+        if (g.done) continue;
+        MH_HIP(hipStreamSynchronize(g.lead->stream));
+        g.enq += m_of[gi];
+        g.done = true;
+        for (size_t a = 0; a < g.jobs.size(); a++) {
+          AlignJob& j = *g.jobs[a];
+          if (j.finished) continue;
+          memcpy(j.ctx->h_state, &g.h_states[a], sizeof(IcpDeviceState));
+          j.enqueued = g.enq;
+          MH_TRY(j.poll(true));
+          g.done = g.done && j.finished;
+        }
       }
     }
-    if (want_prof) {  // the match step of job 0 = its share of the batched launches
+    if (want_prof) {  // the match step of job 0 = its share of its group's lock-step launches
+      Group& g = groups[0];
       float ms = 0.f;
       double sum = 0.0;
       const mh_icp_result* r0 = act[0]->res;
       uint32_t live = r0->n_iterations + ((r0->termination_reason == MH_TERM_MAX_ITERATIONS) ? 0u : 1u);
-      if (live > prof_n) live = prof_n;
+      if (live > g.prof_n) live = g.prof_n;
       for (uint32_t i = 0; i < live; i++) {
-        MH_HIP(hipEventElapsedTime(&ms, lead->prof_ev[2 * i], lead->prof_ev[2 * i + 1]));
+        MH_HIP(hipEventElapsedTime(&ms, g.lead->prof_ev[2 * i], g.lead->prof_ev[2 * i + 1]));
         sum += ms;
       }
       act[0]->res->n_match_launches = live;
-      act[0]->res->match_kernel_ms = sum / (double)A;
+      act[0]->res->match_kernel_ms = sum / (double)g.jobs.size();
       act[0]->res->total_ms = 0.0;
     }
     return MH_OK;

@@ -99,7 +99,7 @@ def test_lockstep_batch_equals_single_alignments(gmap, c2, monkeypatch):
     """mh_icp_align_batch runs large-layer jobs in lock step (one launch per kernel over all jobs, blockIdx.y = job):
     ragged scan sizes, different guesses, a prior on one job, a stall-terminated run where the jobs finish at different
     iterations -- every result is bitwise the single alignment's, and so is the per-stream fallback's."""
-    sizes = [len(c2.scan_xyz), 50000, 77777]
+    sizes = [len(c2.scan_xyz), 50000, 77777, 40001]
     ctxs = [capi.Context(0) for _ in sizes]
     scans = [capi.Scan(c, c2.scan_xyz[:n]) for c, n in zip(ctxs, sizes)]
     rng = np.random.default_rng(5)
@@ -112,16 +112,19 @@ def test_lockstep_batch_equals_single_alignments(gmap, c2, monkeypatch):
     thr, kp = synth.threshold_schedule(c2.sigma, 60)
     for kw, priors in ((dict(max_iterations=6, disable_stall_test=True, threshold=c2.threshold[:6], kernel_param=c2.kernel_param[:6],
                              poll_every=6), None),
-                       (dict(max_iterations=60, threshold=thr, kernel_param=kp, poll_every=4), [None, prior, None])):
+                       (dict(max_iterations=60, threshold=thr, kernel_param=kp, poll_every=4), [None, prior, None, None])):
         p = capi.ICPParams(**kw)
         singles = [capi.icp_align(gmap, s, g, p, prior=(priors[i] if priors else None), want_trace=False)
                    for i, (s, g) in enumerate(zip(scans, guesses))]
-        batch = capi.icp_align_batch([gmap] * 3, scans, guesses, p, priors=priors)
+        batch = capi.icp_align_batch([gmap] * len(scans), scans, guesses, p, priors=priors)
         monkeypatch.setenv("MH_NO_LOCKSTEP", "1")
-        streams = capi.icp_align_batch([gmap] * 3, scans, guesses, p, priors=priors)
+        streams = capi.icp_align_batch([gmap] * len(scans), scans, guesses, p, priors=priors)
         monkeypatch.delenv("MH_NO_LOCKSTEP")
-        for a, b, c in zip(singles, batch, streams):
-            for r in (b, c):
+        monkeypatch.setenv("MH_LOCKSTEP_GROUPS", "2")  # (two groups of two jobs)
+        grouped = capi.icp_align_batch([gmap] * len(scans), scans, guesses, p, priors=priors)
+        monkeypatch.delenv("MH_LOCKSTEP_GROUPS")
+        for a, b, c, d in zip(singles, batch, streams, grouped):
+            for r in (b, c, d):
                 assert (r["n_iterations"], r["termination_reason"], r["n_final_pairs"]) == (
                     a["n_iterations"], a["termination_reason"], a["n_final_pairs"])
                 assert np.array_equal(r["T"], a["T"]) and np.array_equal(r["cov"], a["cov"]) and r["quality"] == a["quality"]
