@@ -108,7 +108,7 @@ struct BatchJob {
   const MatchK* mk;
   const SolveK* sk;
   const float *lx, *ly, *lz;
-  uint32_t n, nb, nba, pad;
+  uint32_t n, nb, nba, nbm;  // nbm: columns of the partials the FIRST solve of an iteration reads (who wrote them)
   MapView map;
   float4* pair_q;
   uint32_t* pair_gidx;
@@ -575,7 +575,7 @@ __device__ __forceinline__ bool pl_row_search(const MapView& map, uint32_t r16, 
 // partial per row of sums (16 points per workgroup): layers of 2-32 k points -- what lidar3d-default.yaml really feeds --
 // run match | solve | accumulate | solve, four launches per iteration instead of five.
 template <bool PL, bool FUSED>
-__global__ __launch_bounds__(kBlock) void k_match16(const IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
+__device__ __forceinline__ void k_match16_body(const IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
                                                     const float* __restrict__ lx, const float* __restrict__ ly,
                                                     const float* __restrict__ lz, uint32_t n, MapView map,
                                                     float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
@@ -1276,9 +1276,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restr
                                                          uint32_t strideB) {
   k_solve_body(st, kp, partA, nA, strideA, partB, nB, strideB);
 }
-__global__ __launch_bounds__(kSolveThreads) void k_solve_b(const BatchJob* __restrict__ jobs) {
+__global__ __launch_bounds__(kSolveThreads) void k_solve_b(const BatchJob* __restrict__ jobs, uint32_t first) {
   const BatchJob& j = jobs[blockIdx.y];
-  k_solve_body(j.st, j.sk, j.part, j.nba, j.nba, nullptr, 0u, 0u);
+  const uint32_t cols = first ? j.nbm : j.nba;  // the first step's partials come from the matcher-side producer
+  k_solve_body(j.st, j.sk, j.part, cols, cols, nullptr, 0u, 0u);
 }
 __global__ void k_cov_prepare(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp, uint32_t force) {
   k_cov_prepare_body(st, kp, force);
@@ -1308,6 +1309,21 @@ __global__ __launch_bounds__(kSolveThreads) void k_cov_finalize(IcpDeviceState* 
 __global__ __launch_bounds__(kSolveThreads) void k_cov_finalize_b(const BatchJob* __restrict__ jobs) {
   const BatchJob& j = jobs[blockIdx.y];
   k_cov_finalize_body(j.st, 0u, j.part, j.nb, j.nb, nullptr, 0u, 0u);
+}
+template <bool PL, bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_match16(const IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
+                                                    const float* __restrict__ lx, const float* __restrict__ ly,
+                                                    const float* __restrict__ lz, uint32_t n, MapView map,
+                                                    float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
+                                                    float4* __restrict__ pl_c, float4* __restrict__ pl_n,
+                                                    double* __restrict__ partials, uint32_t pstride) {
+  k_match16_body<PL, FUSED>(st, kp, lx, ly, lz, n, map, pair_q, pair_gidx, pl_c, pl_n, partials, pstride);
+}
+// row kernel with the fused first accumulation, one job per blockIdx.y (layers of 2-12 k points in lock step)
+__global__ __launch_bounds__(kBlock) void k_match16f_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  if (blockIdx.x >= j.nbm) return;
+  k_match16_body<false, true>(j.st, j.mk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, nullptr, nullptr, j.part, j.nbm);
 }
 // all jobs' state blocks into one contiguous buffer: one read-back per chunk instead of one per job
 __global__ void k_gather_states(const BatchJob* __restrict__ jobs, IcpDeviceState* __restrict__ out) {
@@ -1987,7 +2003,12 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
   for (auto& j : jobs)
     if (!j.finished) act.push_back(&j);
   bool lockstep = act.size() >= 2 && getenv("MH_NO_LOCKSTEP") == nullptr;
-  for (AlignJob* j : act) lockstep = lockstep && j->variant == 4 && !j->pl && !j->trace && j->ctx->device == act[0]->ctx->device;
+  const bool row_chain = !act.empty() && act[0]->variant == 5;  // row kernel with the fused first accumulation
+  const bool no_one_group_env = getenv("MH_NO_ONE_GROUP") != nullptr;
+  for (AlignJob* j : act) {
+    const bool quad = j->variant == 4, row = j->variant == 5 && j->fused16 && (j->scan->n > kOneGroupMaxPoints || no_one_group_env);
+    lockstep = lockstep && (row_chain ? row : quad) && !j->pl && !j->trace && j->ctx->device == act[0]->ctx->device;
+  }
   if (lockstep) {
     // MH_LOCKSTEP_GROUPS splits the jobs into groups that advance independently, each on its leader's stream, so that one
     // group's match launch runs while the other is in its short accumulate / solve launches.  Measured on C2 with 32
@@ -2036,11 +2057,12 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         d.n = (uint32_t)j.scan->n;
         d.nb = j.nb;
         d.nba = j.nba;
+        d.nbm = j.nbm;
         d.map = j.map->view();
         d.pair_q = j.ctx->pair_q.as<float4>();
         d.pair_gidx = j.ctx->pair_gidx.as<uint32_t>();
         d.part = j.ctx->partials.as<double>();
-        const uint32_t bm = (uint32_t)((4ull * d.n + kBlock - 1) / kBlock);
+        const uint32_t bm = row_chain ? d.nbm : (uint32_t)((4ull * d.n + kBlock - 1) / kBlock);
         g.gx_match = bm > g.gx_match ? bm : g.gx_match;
         g.gx_acc = d.nba > g.gx_acc ? d.nba : g.gx_acc;
         g.gx_cov = d.nb > g.gx_cov ? d.nb : g.gx_cov;
@@ -2074,16 +2096,19 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
           const uint32_t A = (uint32_t)g.jobs.size();
           const bool pr = want_prof && gi == 0;
           if (pr) MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n], s));
-          hipLaunchKernelGGL(k_match4_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj);
+          if (row_chain)
+            hipLaunchKernelGGL(k_match16f_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj);
+          else
+            hipLaunchKernelGGL(k_match4_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj);
           if (pr) {
             MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n + 1], s));
             g.prof_n++;
           }
-          hipLaunchKernelGGL(k_accum_b, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 1u);
-          hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj);
+          if (!row_chain) hipLaunchKernelGGL(k_accum_b, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 1u);
+          hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, 1u);
           for (uint32_t in = 1; in < params->gn.max_inner_iterations; in++) {
             hipLaunchKernelGGL(k_accum_b, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 0u);
-            hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj);
+            hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, 0u);
           }
         }
       for (size_t gi = 0; gi < groups.size() && gi < 64; gi++) {

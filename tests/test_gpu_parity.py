@@ -482,6 +482,39 @@ def test_align_batch_equals_single(ctx, oracle, small):
         np.testing.assert_array_equal(b["cov"], s["cov"])
 
 
+def test_lockstep_batch_of_row_kernel_layers(ctx, monkeypatch):
+    """Layers of a few thousand points (what lidar3d-default.yaml feeds align()) in one mh_icp_align_batch: the row
+    kernel with the fused first accumulation runs in lock step (one launch over all jobs); bitwise equal to single
+    alignments and to the per-stream fallback, ragged sizes, jobs stalling at different iterations."""
+    scene = synth.make_scene(4321, 80.0, 25)
+    mp = synth.make_map(scene, 60000, 4321)
+    gm = capi.Map(ctx, 1.0, 20).build(mp)
+    pose = [1.5, -0.8, synth.SENSOR_H, 0.05, 0.004, -0.003]
+    full = synth.make_scan(scene, pose, rings=32, azimuths=400, seed=99)
+    thr, kp = synth.threshold_schedule(2.0, 300)
+    p = capi.ICPParams(max_iterations=300, threshold=thr, kernel_param=kp, poll_every=5)
+    rng = np.random.default_rng(8)
+    sizes = [3000, 5000, 9000, 2500]
+    ctxs = [capi.Context(0) for _ in sizes]
+    scans, guesses, singles = [], [], []
+    for c, n in zip(ctxs, sizes):
+        sub = full[rng.permutation(len(full))[:n]]
+        g = synth.pose_from_ypr(np.array(pose) + [0.3, 0.1, 0.02, 0.01, 0.002, 0.002] + rng.normal(0, 0.02, 6) * [1, 1, 0, 0, 0, 0])
+        scans.append(capi.Scan(c, sub)); guesses.append(g)
+        singles.append(capi.icp_align(gm, capi.Scan(ctx, sub), g, p, want_trace=False))
+    batch = capi.icp_align_batch([gm] * len(sizes), scans, guesses, p)
+    monkeypatch.setenv("MH_NO_LOCKSTEP", "1")
+    streams = capi.icp_align_batch([gm] * len(sizes), scans, guesses, p)
+    monkeypatch.delenv("MH_NO_LOCKSTEP")
+    assert len({s["n_iterations"] for s in singles}) > 1
+    for a, b, c in zip(singles, batch, streams):
+        for r in (b, c):
+            assert (r["n_iterations"], r["termination_reason"], r["n_final_pairs"]) == (a["n_iterations"], a["termination_reason"], a["n_final_pairs"])
+            assert np.array_equal(r["T"], a["T"]) and np.array_equal(r["cov"], a["cov"])
+    for c in ctxs:
+        c.close()
+
+
 def test_align_is_bitwise_reproducible(ctx, small):
     w, gm, om, gs = small
     p = _params(capi, w, disable_stall_test=True)
