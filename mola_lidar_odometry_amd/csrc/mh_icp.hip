@@ -1325,6 +1325,12 @@ __global__ __launch_bounds__(kBlock) void k_match16f_b(const BatchJob* __restric
   if (blockIdx.x >= j.nbm) return;
   k_match16_body<false, true>(j.st, j.mk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, nullptr, nullptr, j.part, j.nbm);
 }
+// start of a lock-step batch: the staged [state | params] blocks of all jobs -> where each job keeps its block
+__global__ void k_scatter_blocks(const BatchJob* __restrict__ jobs, const uint32_t* __restrict__ stage, uint32_t dwords) {
+  uint32_t* dst = reinterpret_cast<uint32_t*>(jobs[blockIdx.x].st);
+  const uint32_t* src = stage + (size_t)blockIdx.x * dwords;
+  for (uint32_t i = threadIdx.x; i < dwords; i += blockDim.x) dst[i] = src[i];
+}
 // all jobs' state blocks into one contiguous buffer: one read-back per chunk instead of one per job
 __global__ void k_gather_states(const BatchJob* __restrict__ jobs, IcpDeviceState* __restrict__ out) {
   const uint32_t* src = reinterpret_cast<const uint32_t*>(jobs[blockIdx.x].st);
@@ -1595,6 +1601,8 @@ struct AlignJob {
   uint32_t nb = 0, nbm = 0, nba = 0, enqueued = 0, chunk = 0, prof_n = 0;
   bool auto_chunk = false;
   bool fused16 = false;  // row kernel accumulates the first Gauss-Newton step itself (layers above the one-workgroup size)
+  bool defer_upload = false;   // batches: the pinned mirrors are filled, the copies are issued by the batch (staged) or flush()
+  size_t nsched_pending = 0;
   int variant = 0;
   bool finished = false, trivial = false;
   bool prof = false;  // time this job's match kernels with events (then it cannot use the graph path)
@@ -1639,7 +1647,8 @@ struct AlignJob {
       memcpy(ctx->h_sched, p->threshold, mi * sizeof(double));
       memcpy(ctx->h_sched + mi, p->kernel_param, mi * sizeof(double));
       if (pl) memcpy(ctx->h_sched + 2 * mi, p->pt2pl_threshold, mi * sizeof(double));
-      MH_HIP(hipMemcpyAsync(ctx->sched.p, ctx->h_sched, nsched * sizeof(double), hipMemcpyHostToDevice, s));
+      nsched_pending = nsched;
+      if (!defer_upload) MH_HIP(hipMemcpyAsync(ctx->sched.p, ctx->h_sched, nsched * sizeof(double), hipMemcpyHostToDevice, s));
     }
     if (trace) MH_TRY(ctx->trace.reserve(mi * sizeof(mh_icp_iter)));
     ctx->align_serial++;
@@ -1680,7 +1689,12 @@ struct AlignJob {
     sk.gn_trace = nullptr;
     sk.cov_hx = p->cov_findif_xyz;
     sk.cov_ha = p->cov_findif_ang;
-    MH_TRY(upload_state_and_params(ctx, mk, sk));
+    if (defer_upload) {
+      ctx->h_params->mk = mk;
+      ctx->h_params->sk = sk;
+    } else {
+      MH_TRY(upload_state_and_params(ctx, mk, sk));
+    }
     nb = nblk(scan->n);
     {  // MH_MATCH selects the correspondence kernel of the fused loop (all exact, bit-identical pairings):
        //   "q" (default)  a DPP quad per scan point, merged candidate scans          -> k_match4 + k_accum
@@ -1722,6 +1736,17 @@ struct AlignJob {
       }
       MH_HIP(hipEventRecord(ctx->ev_t0, s));
     }
+    return MH_OK;
+  }
+
+  // issues the copies a deferred start() left out, on this job's own stream
+  mh_status flush_deferred() {
+    if (!defer_upload || finished) return MH_OK;
+    MH_TRY(set_device(ctx));
+    MH_HIP(hipMemcpyAsync(ctx->sched.p, ctx->h_sched, nsched_pending * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, kParamsOffset + sizeof(IcpDeviceParams), hipMemcpyHostToDevice,
+                          ctx->stream));
+    defer_upload = false;
     return MH_OK;
   }
 
@@ -1993,6 +2018,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
     MH_TRY(check_align_args(maps[i], scans[i], params, T_guesses + 12 * i, &results[i]));
     for (size_t j = 0; j < i; j++)
       MH_REQUIRE(scans[j]->ctx != scans[i]->ctx, "each job of a batch needs its own context");
+    jobs[i].defer_upload = n_jobs >= 2;  // a lock-step batch uploads all jobs' blocks in one staged copy
     MH_TRY(jobs[i].start(maps[i], scans[i], params, T_guesses + 12 * i, priors ? priors[i] : nullptr, &results[i],
                          nullptr, i));
   }
@@ -2035,17 +2061,25 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       const uint32_t A = (uint32_t)g.jobs.size();
       mh_ctx* lead = g.lead = g.jobs[0]->ctx;
       hipStream_t s = lead->stream;
-      MH_TRY(lead->batch_desc.reserve(A * sizeof(BatchJob)));
+      constexpr size_t kBlockBytes = kParamsOffset + sizeof(IcpDeviceParams);  // one job's [state | params] block
+      static_assert(kBlockBytes % 4 == 0 && sizeof(BatchJob) % 8 == 0, "staging layout");
+      const size_t need = A * sizeof(IcpDeviceState) + A * sizeof(BatchJob) + A * kBlockBytes;
+      MH_TRY(lead->batch_desc.reserve(A * sizeof(BatchJob) + A * kBlockBytes));  // descriptors | staged blocks
       MH_TRY(lead->batch_states.reserve(A * sizeof(IcpDeviceState)));
-      if (lead->h_batch_cap < A * sizeof(IcpDeviceState) + A * sizeof(BatchJob)) {
+      if (lead->h_batch_cap < need) {
         if (lead->h_batch) (void)hipHostFree(lead->h_batch);
         lead->h_batch = nullptr;
         lead->h_batch_cap = 0;
-        MH_HIP(hipHostMalloc(&lead->h_batch, A * sizeof(IcpDeviceState) + A * sizeof(BatchJob), hipHostMallocDefault));
-        lead->h_batch_cap = A * sizeof(IcpDeviceState) + A * sizeof(BatchJob);
+        MH_HIP(hipHostMalloc(&lead->h_batch, need, hipHostMallocDefault));
+        lead->h_batch_cap = need;
       }
       g.h_states = reinterpret_cast<IcpDeviceState*>(lead->h_batch);
       BatchJob* h_desc = reinterpret_cast<BatchJob*>(reinterpret_cast<char*>(lead->h_batch) + A * sizeof(IcpDeviceState));
+      char* h_stage = reinterpret_cast<char*>(h_desc) + A * sizeof(BatchJob);
+      // the schedules are the same for every job of the batch (shared params): one copy, into the leader's buffer
+      AlignJob& j0 = *g.jobs[0];
+      MH_HIP(hipMemcpyAsync(lead->sched.p, lead->h_sched, j0.nsched_pending * sizeof(double), hipMemcpyHostToDevice, s));
+      const size_t mi = params->max_iterations;
       for (uint32_t a = 0; a < A; a++) {
         AlignJob& j = *g.jobs[a];
         BatchJob& d = h_desc[a];
@@ -2066,13 +2100,18 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         g.gx_match = bm > g.gx_match ? bm : g.gx_match;
         g.gx_acc = d.nba > g.gx_acc ? d.nba : g.gx_acc;
         g.gx_cov = d.nb > g.gx_cov ? d.nb : g.gx_cov;
-        if (a) {  // the other jobs' start() uploads went out on their own streams
-          MH_HIP(hipEventRecord(j.ctx->ev_poll, j.ctx->stream));
-          MH_HIP(hipStreamWaitEvent(s, j.ctx->ev_poll, 0));
-        }
+        // this job's [state | params] mirror, its schedule pointers redirected to the leader's copy, into the staging area
+        j.ctx->h_params->mk.thr = j.ctx->h_params->sk.thr = lead->sched.as<double>();
+        j.ctx->h_params->mk.kparam = j.ctx->h_params->sk.kparam = lead->sched.as<double>() + mi;
+        memcpy(h_stage + a * kBlockBytes, j.ctx->h_state, kBlockBytes);
+        j.defer_upload = false;
       }
-      MH_HIP(hipMemcpyAsync(lead->batch_desc.p, h_desc, A * sizeof(BatchJob), hipMemcpyHostToDevice, s));
+      // descriptors and staged blocks in ONE copy, then a scatter kernel writes every job's block where it lives
+      MH_HIP(hipMemcpyAsync(lead->batch_desc.p, h_desc, A * sizeof(BatchJob) + A * kBlockBytes, hipMemcpyHostToDevice, s));
       g.dj = lead->batch_desc.as<BatchJob>();
+      hipLaunchKernelGGL(k_scatter_blocks, dim3(A), dim3(256), 0, s, g.dj,
+                         reinterpret_cast<const uint32_t*>(lead->batch_desc.as<char>() + A * sizeof(BatchJob)),
+                         (uint32_t)(kBlockBytes / 4));
     }
     const uint32_t chunk = params->poll_every ? params->poll_every : 10;
     for (;;) {
@@ -2158,6 +2197,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
     }
     return MH_OK;
   }
+  for (auto& j : jobs) MH_TRY(j.flush_deferred());
   for (;;) {
     bool any = false;
     for (auto& j : jobs)
