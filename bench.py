@@ -3,13 +3,14 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input: S independent scans of the
 C2 workload (BASELINE.json configs[1]: ~120k-pt scan vs 1M-pt local map, 20 ICP iterations, fp32
-points / fp64 accumulators), one scan per HIP stream (mh_icp_align_batch), everything already
-resident in HBM when the timed region starts.  With --gpus N (launched by torch.distributed.run) each
+points / fp64 accumulators), one context per scan, aligned together by mh_icp_align_batch in lock step (every
+kernel of an iteration is one launch over all S scans), everything already resident in HBM when the timed
+region starts.  With --gpus N (launched by torch.distributed.run) each
 rank runs the same per-GPU batch on its own GPU (weak scaling, no data-path collective); the only
 collective is the gather of the resulting poses (RCCL all_gather of 12 doubles per scan).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline":     algorithmic bytes of the match kernel / its HIP-event duration vs 8 TB/s HBM
+  "roofline":     algorithmic bytes of the match step of one scan / its HIP-event time per scan vs 8 TB/s HBM
   "cpu_baseline": the CPU oracle (a port of the reference algorithm, not the reference binary)
                   timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -39,7 +40,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=32, help="scans in flight per GPU (one per HIP stream)")
+    ap.add_argument("--streams", type=int, default=32, help="scans per step and GPU (one context each; mh_icp_align_batch aligns them in lock step)")
     ap.add_argument("--workload", default="c2", choices=["c2", "creal", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (bounded sample)")
