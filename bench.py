@@ -1,22 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- scans/sec of the ICP registration hot path on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of synthetic input: S independent scans of the
-C2 workload (BASELINE.json configs[1]: ~120k-pt scan vs 1M-pt local map, 20 ICP iterations, fp32
-points / fp64 accumulators), one context per scan, aligned together by mh_icp_align_batch in lock step (every
-kernel of an iteration is one launch over all S scans), everything already resident in HBM when the timed
-region starts.  With --gpus N (launched by torch.distributed.run) each
-rank runs the same per-GPU batch on its own GPU (weak scaling, no data-path collective); the only
-collective is the gather of the resulting poses (RCCL all_gather of 12 doubles per scan).
+A "step" is one pass of the hot path over one batch of synthetic input: S independent scans of the C2 workload
+(BASELINE.json configs[1]: ~120k-pt scan vs 1M-pt local map, 20 ICP iterations, fp32 points / fp64 accumulators), each
+against ITS OWN map (S independent draws of the generator: S sequences have S local maps, eval/cli_kitti.sh:23-36), one
+context per scan, aligned together by mh_icp_align_batch in lock step.  As SURVEY.md 8(d) / BASELINE.md section 3 define
+the metric, the timed region contains, per scan: the H->D copy of the scan (page-locked host memory, asynchronous, queued
+one step ahead on the contexts of the other buffer set so that it overlaps the current step's kernels), the alignment,
+and the D->H copy of the result -- pose, covariance, quality, counters AND Results::finalPairings (compacted on the
+device, downloaded on a copy stream that overlaps the next step).  The maps are built before the timed region (a local
+map changes only at key-frames).  `shared_map` repeats the measurement with every job on ONE map and one scan (the
+best case for the caches, round 1's configuration) as a labelled second number.
+
+--gpus N: without WORLD_SIZE in the environment the script starts N ranks itself (torch.distributed.run on 127.0.0.1);
+each rank runs the same per-GPU batch on its own GPU (weak scaling, no data-path collective), the only collective is
+the gather of the resulting poses (RCCL all_gather of 12 doubles per scan).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline":     algorithmic bytes of the match step of one scan / its HIP-event time per scan vs 8 TB/s HBM
-  "cpu_baseline": the CPU oracle (a port of the reference algorithm, not the reference binary)
-                  timed on this box's host cores on a bounded sample of the same workload.
+  "roofline":     the match kernel (k_match4_b, one launch over all S scans): compulsory bytes per launch / its
+                  HIP-event duration vs the 8 TB/s HBM peak (frac <= 1 by construction), the PMC-measured HBM traffic of
+                  that kernel (profiles/), and the L2 / VALU-issue views that say what the kernel really waits for;
+  "cpu_baseline": the CPU oracle (a port of the reference algorithm, not the reference binary) timed on this box's
+                  host cores on a bounded sample of the same workload.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,12 +39,72 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBPS = 34500.0  # ibid.: aggregate L2 bandwidth
+VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2.0  # 1024 SIMDs, one wave64 VALU instruction per two cycles at 2.4 GHz
 
 
 def algorithmic_bytes_per_query(p_bar: float) -> float:
-    """12 (local xyz) + 27 x 16 (hash-slot probes) + 12 x P-bar (candidate points
-    distance-tested) + 8 (pairing write-back)."""
+    """SURVEY.md 8(d), the REFERENCE algorithm's bytes per query point and iteration: 12 (local xyz) + 27 x 16
+    (hash-slot probes) + 12 x P-bar (candidate points distance-tested) + 8 (pairing write-back)."""
     return 12.0 + 27.0 * 16.0 + 12.0 * p_bar + 8.0
+
+
+def _gen(args):
+    name, variant = args
+    from mola_lidar_odometry_amd import synth
+    return synth.workload_by_name(name, variant)
+
+
+def generate_workloads(name, variants):
+    """S independent draws of the generator, in worker processes (numpy only; started before HIP is initialised)."""
+    import multiprocessing as mp
+    n_proc = max(1, min(len(variants), (os.cpu_count() or 2) // 2, 16))
+    if n_proc == 1:
+        return [_gen((name, v)) for v in variants]
+    with mp.get_context("fork").Pool(n_proc) as pool:
+        return pool.map(_gen, [(name, v) for v in variants])
+
+
+def compulsory_bytes(w, stats):
+    """Bytes that have to move at least once per match launch and scan, whatever the search strategy: the scan (12 B per
+    point), the pairing written back (16 B nearest point + d2, 4 B index), and each map record / hash slot inside the
+    union of the scan's 27-voxel neighbourhoods once (16 B each)."""
+    n = len(w.scan_xyz)
+    return 12.0 * n + 20.0 * n + 16.0 * stats["records_in_union"] + 16.0 * stats["voxels_in_union"]
+
+
+def neighbourhood_union(w):
+    """Occupied map voxels / stored points inside the union of the 27-voxel blocks around the scan points at the initial
+    guess (numpy; bench bookkeeping for the compulsory-traffic figure, not the product path)."""
+    T = w.T_guess.reshape(3, 4)
+    p = (w.scan_xyz.astype(np.float64) @ T[:, :3].T + T[:, 3]).astype(np.float32)
+    inv = np.float32(1.0) / np.float32(w.voxel_size)
+
+    def keys(xyz):
+        k = np.floor(xyz * inv).astype(np.int64) + (1 << 20)
+        return (k[:, 0] << 42) | (k[:, 1] << 21) | k[:, 2]
+
+    qk = np.unique(keys(p))
+    nb = []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                nb.append(qk + (dx << 42) + (dy << 21) + dz)
+    nb = np.unique(np.concatenate(nb))
+    mk, mc = np.unique(keys(w.map_xyz), return_counts=True)
+    hit = np.isin(mk, nb)
+    return {"query_voxels": int(len(qk)), "voxels_in_union": int(hit.sum()), "records_in_union": int(mc[hit].sum())}
+
+
+def relaunch_under_torchrun(n):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -42,20 +114,47 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=32, help="scans per step and GPU (one context each; mh_icp_align_batch aligns them in lock step)")
     ap.add_argument("--workload", default="c2", choices=["c2", "creal", "small"])
+    ap.add_argument("--maps", default="distinct", choices=["distinct", "shared"],
+                    help="distinct (default): every job has its own map and scan; shared: one map and scan for all jobs")
+    ap.add_argument("--no-io", action="store_true", help="leave the scan upload and the pairings download out of the timed region (resident inputs)")
+    ap.add_argument("--no-shared-run", action="store_true", help="skip the second, shared-map measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (bounded sample)")
     ap.add_argument("--no-profile", action="store_true", help="do not time the match kernel with HIP events")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, gather their ranks over gloo and print n_gpus (no GPU needed: tests the self-launch)")
     args = ap.parse_args()
 
-    import torch  # plumbing: process group, barrier, device selection
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU")
+    distributed = world > 1
+    if args.launch_check:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        got = [None] * world
+        dist.all_gather_object(got, (rank, local_rank))
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks": got}), flush=True)
+        dist.destroy_process_group()
+        return
+    S = args.streams
+    n_var = 1 if args.maps == "shared" else S
+    # inputs first (worker processes, before the HIP runtime exists in this one); ranks draw different variants
+    ws = generate_workloads(args.workload, [rank * S + j for j in range(n_var)])
+    w = ws[0]
+
+    import torch  # plumbing: pinned host memory, process group, barrier, device selection
     import torch.distributed as dist
     from mola_lidar_odometry_amd import capi, synth
     from mola_lidar_odometry_amd import dist as mdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
     if not torch.cuda.is_available() or capi.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -63,62 +162,117 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    w = {"c2": synth.workload_c2, "creal": synth.workload_creal, "small": synth.workload_small}[args.workload]()
-    S = args.streams
     n_scan, n_map = len(w.scan_xyz), len(w.map_xyz)
-
-    # ---- device-resident inputs (outside the timed region) --------------------------------------
-    ctx0 = capi.Context(local_rank)
-    gmap = capi.Map(ctx0, w.voxel_size, w.cap).build(w.map_xyz)
-    ctxs = [capi.Context(local_rank) for _ in range(S)]
-    tx = [torch.from_numpy(np.ascontiguousarray(w.scan_xyz[:, i])).cuda() for i in range(3)]
-    scans = [capi.Scan.from_torch(c, *tx) for c in ctxs]
-    rng = np.random.default_rng(1000 + rank)
-    guesses = []
-    for _ in range(S):  # C2 replicated: same scan, guesses jittered by 1 cm so the jobs are not byte-identical
-        g = w.guess_ypr.copy()
-        g[:3] += rng.normal(0, 0.01, 3)
-        guesses.append(synth.pose_from_ypr(g))
     prof = not args.no_profile
     params = capi.ICPParams(max_iterations=w.n_iters, disable_stall_test=True, threshold=w.threshold,
                             kernel_param=w.kernel_param, poll_every=w.n_iters, profile=2 if prof else 0)
-    maps = [gmap] * S
 
-    def step():
-        return capi.icp_align_batch(maps, scans, guesses, params)
+    class Setup:
+        """Device-side state of one measurement: S jobs, two buffer sets (A/B) of contexts + scans, pinned host mirrors."""
 
-    def sync_all():
-        for c in ctxs:
-            c.synchronize()
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
+        def __init__(self, wl, io):
+            self.wl, self.io = wl, io
+            self.map_ctx = capi.Context(local_rank)
+            self.maps = [capi.Map(self.map_ctx, x.voxel_size, x.cap).build(x.map_xyz) for x in wl]
+            if len(self.maps) == 1:
+                self.maps = self.maps * S
+            self.job_w = [wl[j % len(wl)] for j in range(S)]
+            rng = np.random.default_rng(1000 + rank)
+            self.guesses = []
+            for x in self.job_w:  # guesses jittered by 1 cm so that jobs sharing a scan are not byte-identical
+                g = x.guess_ypr.copy()
+                g[:3] += rng.normal(0, 0.01, 3)
+                self.guesses.append(synth.pose_from_ypr(g))
+            self.pinned = []  # page-locked host copy of every job's scan (what a driver would hand over)
+            for x in self.job_w:  # interleaved xyz records, the form a sensor driver delivers: one copy per scan
+                t = torch.from_numpy(np.ascontiguousarray(x.scan_xyz, dtype=np.float32)).pin_memory()
+                self.pinned.append(t)
+            self.ctxs = [[capi.Context(local_rank) for _ in range(S)] for _ in range(2 if io else 1)]
+            self.scans = [[capi.Scan(c, x.scan_xyz) for c, x in zip(cs, self.job_w)] for cs in self.ctxs]
+            self.sizes = [len(x.scan_xyz) for x in self.job_w]
+            nbytes = sum(capi.pairs_block_bytes(n) for n in self.sizes)
+            self.blocks = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)] if io else None
+            self.k = 0
 
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    match_ms, match_launches = 0.0, 0
-    last = None
-    for _ in range(args.steps):
-        last = step()
-        for r in last:
-            match_ms += r["match_kernel_ms"]
-            match_launches += r["n_match_launches"]
-    sync_all()
-    dt = time.perf_counter() - t0
-    dt = mdist.max_over_ranks(dt, device="cuda" if distributed else None)  # MAX over ranks
-    # outside the timed region: the same kernel with nothing else on the device (what a rocprofv3 kernel trace,
-    # which serialises the streams, reports per launch)
+        def upload(self, which):
+            for sc, t, n in zip(self.scans[which], self.pinned, self.sizes):
+                sc.update_interleaved_pinned(t.data_ptr(), n, 12)
+
+        def step(self):
+            if not self.io:
+                return capi.icp_align_batch(self.maps, self.scans[0], self.guesses, params)
+            cur = self.k & 1
+            self.upload(1 - cur)  # next step's scans: asynchronous, on the other set's streams
+            r = capi.icp_align_batch(self.maps, self.scans[cur], self.guesses, params,
+                                     pairs_block=self.blocks[cur].data_ptr(), pairs_mem=capi.MEM_HOST_PINNED)
+            self.k += 1
+            return r
+
+        def sync(self):
+            for cs in self.ctxs:
+                for c in cs:
+                    c.synchronize()
+            torch.cuda.synchronize()
+            if distributed:
+                dist.barrier()
+
+        def run(self, steps, warmup):
+            if self.io:
+                self.upload(self.k & 1)
+            for _ in range(warmup):
+                self.step()
+            self.sync()
+            t0 = time.perf_counter()
+            ms, launches, last = 0.0, 0, None
+            for _ in range(steps):
+                last = self.step()
+                ms += last[0]["match_kernel_ms"]
+                launches += last[0]["n_match_launches"]
+            self.sync()
+            dt = time.perf_counter() - t0
+            dt = mdist.max_over_ranks(dt, device="cuda" if distributed else None)  # MAX over ranks
+            return dt, ms, launches, last
+
+        def last_pairs(self, results):
+            cur = (self.k - 1) & 1
+            return capi.unpack_pairs_block(self.blocks[cur].numpy(), self.sizes, results)
+
+        def close(self):
+            self.sync()
+            for cs in self.ctxs:
+                for c in cs:
+                    c.close()
+            self.map_ctx.close()
+
+    io = not args.no_io
+    main_run = Setup(ws, io)
+    dt, match_ms, match_launches, last = main_run.run(args.steps, args.warmup)
+    # outside the timed region: the same kernel with nothing else on the device (S = 1), what rocprofv3 --stats of a
+    # one-stream run reports per launch
     iso_ms, iso_launches = 0.0, 0
     if prof and rank == 0:
         for _ in range(3):
-            for r in capi.icp_align_batch(maps[:1], scans[:1], guesses[:1], params):
+            for r in capi.icp_align_batch(main_run.maps[:1], main_run.scans[0][:1], main_run.guesses[:1], params):
                 iso_ms += r["match_kernel_ms"]
                 iso_launches += r["n_match_launches"]
     # the trivial result gather (SURVEY 8e): poses of the last step from every rank, RCCL all_gather
     gathered = mdist.gather_poses(np.stack([r["T"] for r in last]), device="cuda" if distributed else None)
     all_poses = np.stack(gathered)
+    pairs_last = main_run.last_pairs(last) if io else None
+    if pairs_last is not None:
+        pairs_last = [dict(local_idx=p["local_idx"].copy(), global_idx=p["global_idx"].copy(), d2=p["d2"].copy()) for p in pairs_last]
+    guesses = main_run.guesses
+    main_run.close()
+
+    shared = None
+    if args.maps == "distinct" and not args.no_shared_run and S > 1:
+        sh = Setup(ws[:1], io)
+        sdt, sms, sl, _ = sh.run(max(2, args.steps // 2), 1)
+        shared = {"value": world * max(2, args.steps // 2) * S / sdt, "unit": "scans/sec",
+                  "match_kernel_ms_per_scan": (sms / sl) if sl else None,
+                  "note": "every job on ONE map and ONE scan (guesses jittered): the working set of all jobs is 20 MB, the "
+                          "best case for L1/L2/Infinity Cache; round 1's configuration"}
+        sh.close()
 
     scans_total = world * args.steps * S
     value = scans_total / dt
@@ -128,10 +282,17 @@ def main():
         "value": value, "unit": "scans/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 points / f64 accumulators", "data": "synthetic",
-        "config": {"workload": f"{w.name}: {n_scan}-pt scan vs {n_map}-pt voxel-hashed map (voxel {w.voxel_size} m, "
+        "config": {"workload": f"{ws[0].name}: {n_scan}-pt scan vs {n_map}-pt voxel-hashed map (voxel {w.voxel_size} m, "
                                f"cap {w.cap}), {w.n_iters} ICP iterations x 2 GN steps, GM kernel, sigma={w.sigma} "
                                "schedule of lidar3d-default.yaml:190,198",
-                   "scans_per_step_per_gpu": S, "streams_per_gpu": S, "parallelism": f"{world}x independent GPUs"},
+                   "scans_per_step_per_gpu": S, "maps": args.maps,
+                   "distinct_maps_per_gpu": len(ws), "map_bytes_per_gpu": int(len(ws) * (n_map * 16 + 4 * 2 ** 20)),
+                   "timed_region": ("scan H2D (pinned, async, one step ahead) + align + result D2H incl. finalPairings"
+                                    if io else "align only, inputs resident (--no-io)"),
+                   "parallelism": f"{world}x independent GPUs"},
+        "shared_map": shared,
+        "real_data": {"KITTI_BASE_DIR": os.environ.get("KITTI_BASE_DIR"), "MULRAN_BASE_DIR": os.environ.get("MULRAN_BASE_DIR"),
+                      "available": bool(os.environ.get("KITTI_BASE_DIR") and os.path.isdir(os.environ.get("KITTI_BASE_DIR", "")))},
     }
     if rank == 0:
         # ---- CPU baseline: the oracle (a port), bounded sample, N=1 only ------------------------
@@ -139,9 +300,9 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle_c
-            om = oracle_c.Map(w.voxel_size, w.cap).insert(w.map_xyz)
             op = oracle_c.ICPParams(max_iterations=w.n_iters, disable_stall_test=True, threshold=w.threshold,
                                     kernel_param=w.kernel_param, compute_covariance=True)
+            om = oracle_c.Map(w.voxel_size, w.cap).insert(w.map_xyz)
             # pick the thread count that is fastest on THIS box (more threads than usable cores collapses
             # OpenMP throughput); the count actually used is what "cores" reports
             cores, best_t = min(8, oracle_c.max_threads()), None
@@ -164,53 +325,73 @@ def main():
                 n_done += 1
             p_bar = o["n_candidates_total"] / (w.n_iters * n_scan)
             cpu = {"value": n_done / t_cpu, "unit": "scans/sec", "cores": cores, "kind": "port",
-                   "sample": f"{n_done} full alignment(s) of the same workload ({w.n_iters} iterations each) "
+                   "sample": f"{n_done} full alignment(s) of job 0's workload ({w.n_iters} iterations each) "
                              f"with the C oracle (OpenMP, {cores} threads) in {t_cpu:.1f} s"}
-            # parity of the timed product path against the oracle on the same input
-            d = np.abs(last[0]["T"] - o["T"])
-            out["parity_vs_cpu"] = {"max_abs_pose_diff": float(d.max()), "tolerance": 1e-4,
-                                    "n_pairs_equal": bool(last[0]["n_final_pairs"] == o["n_final_pairs"])}
-        if p_bar is None:
-            stats = os.path.join(ROOT, "tests", "golden", "workload_stats.json")
-            if os.path.exists(stats):
-                p_bar = json.load(open(stats)).get(w.name, {}).get("p_bar")
+            # parity of the timed product path against the oracle: EVERY job of the last timed step
+            worst, pairs_equal, idx_equal = 0.0, True, True
+            for j in range(S):
+                x = ws[j % len(ws)]
+                omj = om if j % len(ws) == 0 else oracle_c.Map(x.voxel_size, x.cap).insert(x.map_xyz)
+                oj = oracle_c.icp_align(omj, x.scan_xyz, guesses[j], op, n_threads=cores, want_pairs=pairs_last is not None)
+                worst = max(worst, float(np.abs(last[j]["T"] - oj["T"]).max()))
+                pairs_equal = pairs_equal and last[j]["n_final_pairs"] == oj["n_final_pairs"]
+                if pairs_last is not None:
+                    pj = oj["pairs"]
+                    idx_equal = idx_equal and np.array_equal(pairs_last[j]["local_idx"], pj["local_idx"]) and \
+                        np.array_equal(pairs_last[j]["global_idx"], pj["global_idx"]) and np.array_equal(pairs_last[j]["d2"], pj["d2"])
+            out["parity_vs_cpu"] = {"jobs_checked": S, "max_abs_pose_diff": worst, "tolerance": 1e-4,
+                                    "n_pairs_equal": bool(pairs_equal),
+                                    "downloaded_final_pairings_bit_equal": bool(idx_equal) if pairs_last is not None else None}
+        stats_file = os.path.join(ROOT, "tests", "golden", "workload_stats.json")
+        if p_bar is None and os.path.exists(stats_file):
+            p_bar = json.load(open(stats_file)).get(w.name.split("#")[0], {}).get("p_bar")
         roof = None
-        if prof and match_launches and p_bar:
-            bytes_per_launch = n_scan * algorithmic_bytes_per_query(p_bar)
-            avg_ms = match_ms / match_launches
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            kname = {"p": "k_match<fused,branch-and-bound>", "x": "k_match<fused,27-voxel>"}.get(
-                os.environ.get("MH_MATCH", "q")[:1], "k_match4 (quad per point)")
-            roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                    "avg_kernel_ms": avg_ms, "launches": match_launches,
-                    "avg_kernel_ms_alone": (iso_ms / iso_launches) if iso_launches else None, "p_bar": p_bar,
-                    "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "note": "avg_kernel_ms = the match step PER SCAN inside the timed region: HIP events around every lock-step match "
-                            "launch (one launch over all scans of the step, blockIdx.y = scan) divided by the scans in it. The working set "
-                            "(16 MB of records + the hash table) is cache resident: measured HBM traffic (`traffic`, bytes "
-                            "per launch) is ~30x below the algorithmic bytes, so `achieved` is a rate of ALGORITHMIC bytes "
-                            "and can exceed the HBM peak; what the kernel waits for is the chain of dependent L1-miss "
-                            "round trips of its slowest wave (DESIGN.md section 3). avg_kernel_ms_alone = the same kernel "
-                            "with a single stream, after the timed region: the figure a (stream-serialising) rocprofv3 "
-                            "kernel trace reports"}
-            import glob
+        if prof and match_launches:
+            union = neighbourhood_union(w)
+            per_scan = compulsory_bytes(w, union)
+            avg_ms = match_ms / match_launches          # per scan: launch duration / scans in the launch
+            launch_ms = avg_ms * S
+            achieved = per_scan * S / (launch_ms * 1e-3) / 1e9
+            kname = {"p": "k_match<fused,branch-and-bound>", "x": "k_match<fused,27-voxel>", "t": "k_match_tile_b"}.get(
+                os.environ.get("MH_MATCH", "q")[:1], "k_match4_b (quad per point, one launch over all scans of the step)")
+            roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                    "avg_launch_ms": launch_ms, "scans_per_launch": S, "launches": match_launches,
+                    "avg_kernel_ms_per_scan": avg_ms,
+                    "avg_kernel_ms_alone": (iso_ms / iso_launches) if iso_launches else None,
+                    "compulsory_bytes_per_launch": per_scan * S, "compulsory": union,
+                    "note": "achieved = COMPULSORY bytes per launch (scan read + pairing write + every map record / hash slot "
+                            "inside the union of the scan's 27-voxel blocks once) / HIP-event duration of the launch, so frac "
+                            "<= 1 is the share of the HBM peak this launch would need if nothing was cached; `traffic` = "
+                            "PMC-measured HBM bytes per launch of the same kernel (profiles/).  The kernel is NOT HBM-bound: "
+                            "see `views` (VALU issue and dependent cache round trips bound it)."}
+            views = {}
+            if p_bar:
+                ref_bytes = n_scan * algorithmic_bytes_per_query(p_bar)
+                views["reference_algorithm_bytes"] = {
+                    "p_bar": p_bar, "bytes_per_scan_launch": ref_bytes, "rate_GBps": ref_bytes / (avg_ms * 1e-3) / 1e9,
+                    "note": "SURVEY 8(d) bytes of the REFERENCE's exhaustive 27-voxel scan per second of this kernel; the "
+                            "branch-and-bound search does not move them, so this is a speed-up statement, not a roofline"}
             pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-            if pmc:  # HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (profiles/collect.sh)
+            if pmc:
                 summary = json.load(open(pmc[-1]))
-                roof["traffic"] = summary.get("k_match_fused_hbm_bytes_per_launch")
                 roof["traffic_source"] = os.path.basename(pmc[-1])
-                # second view, since HBM is not what this kernel waits for: VALU issue.  SQ_INSTS_VALU wave-instructions per
-                # scan / (1024 SIMD-32s x 2.4 GHz / 2 cycles per wave64 instruction, MI355X_MICROARCH.md) = the time the
-                # match step of one scan needs if nothing but VALU issue limited it; its share of the measured time per
-                # scan, alone and inside the lock-step batch
-                mk = [k for k in summary.get("counters", {}) if k.startswith("k_match4")] if kname.startswith("k_match4") else []
-                valu = summary["counters"][mk[0]].get("SQ_INSTS_VALU", {}).get("mean") if mk else None
-                if valu and roof["avg_kernel_ms_alone"]:
-                    floor_ms = valu / (1024 * 2.4e9 / 2.0) * 1e3
-                    roof["valu"] = {"wave_instructions_per_launch": valu, "issue_floor_ms": floor_ms,
-                                    "frac_of_launch_alone": floor_ms / roof["avg_kernel_ms_alone"],
-                                    "frac_of_launch_concurrent": floor_ms / avg_ms}
+                tr = summary.get("timed_kernel", {})
+                if tr.get("hbm_bytes_per_launch") is not None:
+                    roof["traffic"] = tr["hbm_bytes_per_launch"]
+                    views["hbm_measured"] = {"bytes_per_launch": tr["hbm_bytes_per_launch"], "scans_per_launch": tr.get("scans_per_launch"),
+                                             "frac_of_peak": tr["hbm_bytes_per_launch"] / (tr.get("avg_launch_ms", launch_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                                             if tr.get("avg_launch_ms") else None}
+                if tr.get("l2_request_bytes_per_launch") is not None and tr.get("avg_launch_ms"):
+                    views["l2"] = {"request_bytes_per_launch": tr["l2_request_bytes_per_launch"],
+                                   "frac_of_peak": tr["l2_request_bytes_per_launch"] / (tr["avg_launch_ms"] * 1e-3) / 1e9 / L2_PEAK_GBPS}
+                if tr.get("valu_wave_instructions_per_launch") is not None and tr.get("avg_launch_ms"):
+                    floor_ms = tr["valu_wave_instructions_per_launch"] / VALU_WAVE_INSTR_PER_S * 1e3
+                    views["valu"] = {"wave_instructions_per_launch": tr["valu_wave_instructions_per_launch"],
+                                     "issue_floor_ms": floor_ms, "frac_of_launch": floor_ms / tr["avg_launch_ms"]}
+                if tr.get("wait_frac") is not None:
+                    views["wave_wait_frac"] = tr["wait_frac"]
+            roof["views"] = views
         out["roofline"] = roof
         out["cpu_baseline"] = cpu
         out["gathered_poses"] = int(all_poses.shape[0] * all_poses.shape[1])

@@ -14,8 +14,12 @@
  *  - Tangent vectors / 6x6 matrices use [v(3); w(3)] ordering (LidarOdometry.cpp:977-984); the
  *    covariance is in (x,y,z,yaw,pitch,roll) like mrpt::poses::CPose3DPDFGaussian.
  *  - Point clouds are SoA float arrays (mrpt CPointsMap::getPointsBufferRef_{x,y,z} [U]).
- *  - `mem` arguments say where the caller's arrays live: MH_MEM_HOST (borrowed for the call, copied)
- *    or MH_MEM_DEVICE (HIP device pointers on the context's device, read in place).
+ *  - `mem` arguments say where the caller's arrays live: MH_MEM_HOST (borrowed for the call, copied),
+ *    MH_MEM_DEVICE (HIP device pointers on the context's device, read in place) or, where an entry point says
+ *    so, MH_MEM_HOST_PINNED: page-locked host memory (hipHostMalloc / torch pin_memory) that the caller keeps
+ *    valid and unmodified until the context's stream has passed the copy (mh_ctx_synchronize, or the return of
+ *    the next blocking call that uses the scan) -- the copy is then asynchronous on the context's stream and
+ *    the call returns at once, so uploads of the next scans overlap the alignment of the current ones.
  *  - Every function returns mh_status (0 = OK), never throws, never aborts; a message for the last
  *    failure on the calling thread is available from mh_last_error_string().
  *  - One context = one HIP device + one stream.  Contexts are independent and may be driven from
@@ -52,7 +56,7 @@ enum {
   MH_ERR_INTERNAL = 7
 };
 
-enum { MH_MEM_HOST = 0, MH_MEM_DEVICE = 1 };
+enum { MH_MEM_HOST = 0, MH_MEM_DEVICE = 1, MH_MEM_HOST_PINNED = 2 };
 
 /* coordinate -> voxel index rule (FLOOR is the default) */
 enum { MH_INDEX_FLOOR = 0, MH_INDEX_TRUNC = 1 };
@@ -161,14 +165,16 @@ MH_API mh_status mh_map_download_ndt(const mh_map* map, float* cx, float* cy, fl
  * ---------------------------------------------------------------------------------------------- */
 MH_API mh_status mh_scan_create(mh_ctx* ctx, const float* x, const float* y, const float* z, size_t n, int32_t mem,
                                 mh_scan** out);
-/* Replace the points (e.g. after the caller re-ran its de-skew, LidarOdometry.cpp:992-999). */
+/* Replace the points (e.g. after the caller re-ran its de-skew, LidarOdometry.cpp:992-999).  `mem` may be
+ * MH_MEM_HOST_PINNED (asynchronous upload, see Conventions). */
 MH_API mh_status mh_scan_update(mh_scan* scan, const float* x, const float* y, const float* z, size_t n, int32_t mem);
 /* Replace the points from an interleaved buffer, the form raw sensor data arrives in: point i has float32 x/y/z at
  * data + i*point_step + off_{x,y,z} and, with off_t >= 0, a float32 time stamp [s] at off_t (a KITTI velodyne .bin is
  * point_step 16 / offsets 0,4,8; a sensor_msgs/PointCloud2 payload gives its own).  This is the step the reference's
  * observations_generator (mp2p_icp_filters::Generator, lidar3d-default.yaml:250-262) performs on the CPU when it turns
  * the raw observation into the SoA 'raw' layer; here: ONE copy of the bytes and a de-interleave kernel.  point_step and
- * the offsets are multiples of 4.  With off_t < 0 the scan carries no time stamps afterwards. */
+ * the offsets are multiples of 4.  With off_t < 0 the scan carries no time stamps afterwards.  `mem` may be
+ * MH_MEM_HOST_PINNED (asynchronous upload, see Conventions). */
 MH_API mh_status mh_scan_update_aos(mh_scan* scan, const void* data, size_t n, size_t point_step, size_t off_x,
                                     size_t off_y, size_t off_z, int64_t off_t, int32_t mem);
 MH_API mh_status mh_scan_destroy(mh_scan* scan);
@@ -390,12 +396,23 @@ MH_API mh_status mh_icp_get_pt2pl_pairs(const mh_scan* scan, const mh_pairs_pl_o
 /* Many independent alignments from one host thread, one context per job.  Job i uses maps[i], scans[i] (distinct
  * contexts), guesses + 12*i, priors[i] (array or entries may be NULL), and writes results[i]; every result is bitwise
  * what mh_icp_align gives for that job alone.  Layers above 2048 points on plain maps run in LOCK STEP: each kernel of
- * an iteration is one launch over all jobs (the jobs' tails fill each other's idle lanes: 3800 instead of 2500 scans/s
- * on the 120 k-point workload, 12.5 k instead of 4.8 k on 6 k-point layers); the other chains are interleaved, one
- * stream per job.  With profile = 2, job 0's match_kernel_ms is its share of the lock-step match launches. */
+ * an iteration is one launch over all jobs (the jobs' tails fill each other's idle lanes); the other chains are
+ * interleaved, one stream per job.  With profile = 2, job 0's match_kernel_ms is its share of the lock-step match
+ * launches.  Work still queued on the jobs' own streams (asynchronous uploads, de-skew, filters) is ordered before the
+ * batch, whichever stream the batch runs on.
+ *
+ * `pairs_block` (nullable): Results::finalPairings of every job.  Job i's part starts at byte offset
+ * sum_{j<i} mh_pairs_block_bytes(scan size of job j) and holds six arrays of S = mh_pairs_block_bytes(n)/24 entries
+ * each -- local_idx | global_idx (uint32) | gx | gy | gz | d2 (float) -- of which the first
+ * results[i].n_final_pairs - results[i].n_final_pairs_pt2pl are valid, ascending local index.  `pairs_mem`:
+ * MH_MEM_DEVICE, MH_MEM_HOST, or MH_MEM_HOST_PINNED: the download is then queued on a copy stream of the first job's
+ * context and the call returns without waiting for it (it overlaps the next batch); mh_ctx_synchronize(scans[0]'s
+ * context) waits for it, and so does the next batch before it overwrites the device-side staging. */
+MH_API size_t mh_pairs_block_bytes(size_t n_scan_points);
 MH_API mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_scan* const* scans,
                                     const mh_icp_params* params, const double* T_guesses,
-                                    const mh_prior* const* priors, mh_icp_result* results);
+                                    const mh_prior* const* priors, mh_icp_result* results, void* pairs_block,
+                                    int32_t pairs_mem);
 
 #ifdef __cplusplus
 }

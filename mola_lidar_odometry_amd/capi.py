@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmolahip.so")
 
 MH_OK = 0
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 INDEX_FLOOR, INDEX_TRUNC = 0, 1
 KERNEL_NONE, KERNEL_GM_C4, KERNEL_GM_KISS, KERNEL_GM_BARRON, KERNEL_CAUCHY, KERNEL_GM_C2 = range(6)
 TERM_NAMES = ["Undefined", "NoPairings", "SolverError", "MaxIterations", "Stalled",
@@ -162,7 +162,8 @@ _SIGNATURES = {
     "mh_icp_align": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(ICPParamsC), _DP, C.POINTER(Prior),
                                  C.POINTER(ICPResult), C.POINTER(ICPIter), C.POINTER(PairsOut), C.c_int32]),
     "mh_icp_align_batch": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(ICPParamsC),
-                                       _DP, C.POINTER(C.POINTER(Prior)), C.POINTER(ICPResult)]),
+                                       _DP, C.POINTER(C.POINTER(Prior)), C.POINTER(ICPResult), C.c_void_p, C.c_int32]),
+    "mh_pairs_block_bytes": (C.c_size_t, [C.c_size_t]),
 }
 
 _lib = None
@@ -383,6 +384,16 @@ class Scan:
     def update(self, xyz):
         x, y, z = _soa(xyz)
         _chk(lib().mh_scan_update(self._h, _vp(x), _vp(y), _vp(z), len(x), MEM_HOST))
+
+    def update_pinned(self, x_ptr: int, y_ptr: int, z_ptr: int, n: int):
+        """Asynchronous upload from page-locked host arrays (MH_MEM_HOST_PINNED): returns at once; the caller keeps the
+        arrays alive and unchanged until the context's stream has passed the copies."""
+        _chk(lib().mh_scan_update(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(z_ptr), n, MEM_HOST_PINNED))
+
+    def update_interleaved_pinned(self, ptr: int, n: int, point_step: int, off_x=0, off_y=4, off_z=8, off_t=-1):
+        """Asynchronous upload of n interleaved records from page-locked host memory (MH_MEM_HOST_PINNED): ONE copy of the
+        raw bytes + the de-interleave kernel, queued on the context's stream; returns at once."""
+        _chk(lib().mh_scan_update_aos(self._h, C.c_void_p(ptr), n, point_step, off_x, off_y, off_z, off_t, MEM_HOST_PINNED))
 
     def update_interleaved(self, records, off_x=0, off_y=4, off_z=8, off_t=-1):
         """records: C-contiguous float32 [n,k] rows (KITTI .bin: k=4) -- one copy, de-interleaved on the device."""
@@ -617,8 +628,29 @@ def icp_align(m: Map, s: Scan, T_guess, p: ICPParams, prior=None, want_trace=Tru
     return out
 
 
-def icp_align_batch(maps, scans, T_guesses, p: ICPParams, priors=None):
-    """One alignment per (map, scan) pair; every scan must live in its own Context (its own stream)."""
+def pairs_block_bytes(n_scan_points: int) -> int:
+    return int(lib().mh_pairs_block_bytes(int(n_scan_points)))
+
+
+def unpack_pairs_block(block: np.ndarray, scan_sizes, results):
+    """Views of every job's final pairings inside a pairs block (uint8 array as filled by icp_align_batch)."""
+    out, off = [], 0
+    for n, r in zip(scan_sizes, results):
+        nbytes = pairs_block_bytes(n)
+        S = nbytes // 24
+        k = r["n_final_pairs"] - r["n_final_pairs_pt2pl"]
+        u = block[off:off + nbytes].view(np.uint32).reshape(6, S)
+        f = block[off:off + nbytes].view(np.float32).reshape(6, S)
+        out.append(dict(local_idx=u[0, :k], global_idx=u[1, :k], global_xyz=np.stack([f[2, :k], f[3, :k], f[4, :k]], 1),
+                        d2=f[5, :k]))
+        off += nbytes
+    return out
+
+
+def icp_align_batch(maps, scans, T_guesses, p: ICPParams, priors=None, pairs_block=None, pairs_mem=MEM_HOST):
+    """One alignment per (map, scan) pair; every scan must live in its own Context (its own stream).
+    pairs_block: None, a writable uint8 numpy array (host; pairs_mem MEM_HOST, or MEM_HOST_PINNED when its memory is
+    page-locked -- the download then completes asynchronously, see molahip.h) or a raw pointer (int) with pairs_mem."""
     n = len(scans)
     T = np.ascontiguousarray(np.stack([_T12(t) for t in T_guesses]).reshape(n * 12))
     cp, keep = p.c(T[:12])
@@ -633,7 +665,10 @@ def icp_align_batch(maps, scans, T_guesses, p: ICPParams, priors=None):
             if pr is not None:
                 keep_pr.append(_mk_prior(pr))
                 pr_arr[i] = C.pointer(keep_pr[-1])
-    _chk(lib().mh_icp_align_batch(n, mh, sh, C.byref(cp), T.ctypes.data_as(_DP), pr_arr, res))
+    pb = None
+    if pairs_block is not None:
+        pb = C.c_void_p(pairs_block if isinstance(pairs_block, int) else pairs_block.ctypes.data)
+    _chk(lib().mh_icp_align_batch(n, mh, sh, C.byref(cp), T.ctypes.data_as(_DP), pr_arr, res, pb, pairs_mem))
     return [_result_dict(r) for r in res]
 
 

@@ -124,6 +124,7 @@ mh_status mh_ctx_create(int32_t device, void* hip_stream, mh_ctx** out) {
   hipError_t e1 = hipEventCreateWithFlags(&ctx->ev_poll, hipEventDisableTiming);
   hipError_t e2 = hipEventCreate(&ctx->ev_t0);
   hipError_t e3 = hipEventCreate(&ctx->ev_t1);
+  if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
     mh_ctx_destroy(ctx);
     return fail(MH_ERR_HIP, "hipEventCreate failed");
@@ -136,6 +137,14 @@ mh_status mh_ctx_destroy(mh_ctx* ctx) {
   if (!ctx) return MH_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->copy_stream) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+  }
+  if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
+  if (ctx->ev_pairs_ready) (void)hipEventDestroy(ctx->ev_pairs_ready);
+  if (ctx->ev_pairs_copied) (void)hipEventDestroy(ctx->ev_pairs_copied);
+  ctx->pairs_stage.release();
   ctx->pair_q.release();
   ctx->pair_gidx.release();
   ctx->pl_c.release();
@@ -173,6 +182,10 @@ mh_status mh_ctx_synchronize(mh_ctx* ctx) {
   MH_REQUIRE(ctx, "null context");
   MH_TRY(set_device(ctx));
   MH_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->copy_stream) {  // a batch led by this context may still be downloading its final pairings
+    MH_HIP(hipStreamSynchronize(ctx->copy_stream));
+    ctx->pairs_copy_pending = false;
+  }
   return MH_OK;
 }
 
@@ -196,7 +209,7 @@ mh_status mh_ctx_stream(mh_ctx* ctx, void** hip_stream_out) {
 // ---- scan -----------------------------------------------------------------------------------
 static mh_status scan_set(mh_scan* s, const float* x, const float* y, const float* z, size_t n, int32_t mem) {
   mh_ctx* ctx = s->ctx;
-  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
+  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE || mem == MH_MEM_HOST_PINNED, "bad mem space");
   MH_REQUIRE(n == 0 || (x && y && z), "null point arrays");
   MH_REQUIRE(n < 0x7FFFFFFFull, "scan too large");
   MH_TRY(set_device(ctx));
@@ -207,12 +220,13 @@ static mh_status scan_set(mh_scan* s, const float* x, const float* y, const floa
     MH_TRY(s->xyz.reserve(3 * stride ? 3 * stride : 256));
   }
   char* base = s->xyz.as<char>();
-  const hipMemcpyKind kind = mem == MH_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  const hipMemcpyKind kind = mem == MH_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   if (n) {
     MH_HIP(hipMemcpyAsync(base, x, n * sizeof(float), kind, ctx->stream));
     MH_HIP(hipMemcpyAsync(base + stride, y, n * sizeof(float), kind, ctx->stream));
     MH_HIP(hipMemcpyAsync(base + 2 * stride, z, n * sizeof(float), kind, ctx->stream));
     if (mem == MH_MEM_HOST) MH_HIP(hipStreamSynchronize(ctx->stream));  // host arrays are borrowed only for the call
+    // (MH_MEM_HOST_PINNED: the caller keeps them valid until the stream has passed the copies; no wait here)
   }
   s->x = (const float*)base;
   s->y = (const float*)(base + stride);

@@ -113,6 +113,10 @@ struct BatchJob {
   float4* pair_q;
   uint32_t* pair_gidx;
   double* part;
+  // final pairings of the batch (mh_icp_align_batch's pairs_block), or null
+  uint32_t* cp_counts;   // [nb] pairs per 256-point block | [nb] exclusive offsets
+  uint32_t* cp_out;      // six arrays of cp_stride entries: local_idx | global_idx | gx | gy | gz | d2
+  uint32_t cp_stride, cp_pad;
 };
 
 // LDS hand-off between lanes of ONE wave: LDS operations of a wave execute in order, so only the compiler has to be
@@ -1339,8 +1343,8 @@ __global__ void k_gather_states(const BatchJob* __restrict__ jobs, IcpDeviceStat
 }
 
 // ================================================================================================
-__global__ __launch_bounds__(kBlock) void k_count_valid(const uint32_t* __restrict__ gidx, uint32_t n,
-                                                        uint32_t* __restrict__ block_counts) {
+__device__ __forceinline__ void k_count_valid_body(const uint32_t* __restrict__ gidx, uint32_t n,
+                                                   uint32_t* __restrict__ block_counts) {
   __shared__ uint32_t wc[kBlock / 64];
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const bool v = i < n && gidx[i] != kNoMatch;
@@ -1349,9 +1353,13 @@ __global__ __launch_bounds__(kBlock) void k_count_valid(const uint32_t* __restri
   __syncthreads();
   if (threadIdx.x == 0) block_counts[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
+__global__ __launch_bounds__(kBlock) void k_count_valid(const uint32_t* __restrict__ gidx, uint32_t n,
+                                                        uint32_t* __restrict__ block_counts) {
+  k_count_valid_body(gidx, n, block_counts);
+}
 
-__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict__ counts, uint32_t nb,
-                                                      uint32_t* __restrict__ offsets, uint32_t* __restrict__ total) {
+__device__ __forceinline__ void k_scan_blocks_body(const uint32_t* __restrict__ counts, uint32_t nb,
+                                                   uint32_t* __restrict__ offsets, uint32_t* __restrict__ total) {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry;
   if (threadIdx.x == 0) carry = 0;
@@ -1375,14 +1383,18 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict
     if (threadIdx.x == 1023) carry += wpre + incl;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *total = carry;
+  if (threadIdx.x == 0 && total) *total = carry;
+}
+__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict__ counts, uint32_t nb,
+                                                      uint32_t* __restrict__ offsets, uint32_t* __restrict__ total) {
+  k_scan_blocks_body(counts, nb, offsets, total);
 }
 
-__global__ __launch_bounds__(kBlock) void k_compact(const uint32_t* __restrict__ gidx, const float4* __restrict__ pq,
-                                                    uint32_t n, const uint32_t* __restrict__ block_offsets,
-                                                    uint32_t* __restrict__ o_li, uint32_t* __restrict__ o_gi,
-                                                    float* __restrict__ o_x, float* __restrict__ o_y,
-                                                    float* __restrict__ o_z, float* __restrict__ o_d2) {
+__device__ __forceinline__ void k_compact_body(const uint32_t* __restrict__ gidx, const float4* __restrict__ pq,
+                                               uint32_t n, const uint32_t* __restrict__ block_offsets,
+                                               uint32_t* __restrict__ o_li, uint32_t* __restrict__ o_gi,
+                                               float* __restrict__ o_x, float* __restrict__ o_y,
+                                               float* __restrict__ o_z, float* __restrict__ o_d2) {
   __shared__ uint32_t wc[kBlock / 64];
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const uint32_t gi = i < n ? gidx[i] : kNoMatch;
@@ -1401,6 +1413,32 @@ __global__ __launch_bounds__(kBlock) void k_compact(const uint32_t* __restrict__
   if (o_y) o_y[pos] = q.y;
   if (o_z) o_z[pos] = q.z;
   if (o_d2) o_d2[pos] = q.w;
+}
+__global__ __launch_bounds__(kBlock) void k_compact(const uint32_t* __restrict__ gidx, const float4* __restrict__ pq,
+                                                    uint32_t n, const uint32_t* __restrict__ block_offsets,
+                                                    uint32_t* __restrict__ o_li, uint32_t* __restrict__ o_gi,
+                                                    float* __restrict__ o_x, float* __restrict__ o_y,
+                                                    float* __restrict__ o_z, float* __restrict__ o_d2) {
+  k_compact_body(gidx, pq, n, block_offsets, o_li, o_gi, o_x, o_y, o_z, o_d2);
+}
+// the same three steps for every job of a batch (blockIdx.y = job), once the job's loop has terminated: the final
+// pairings of job j land in its part of the batch's pairs block, ascending local index
+__global__ __launch_bounds__(kBlock) void k_count_valid_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  if (blockIdx.x >= j.nb || !j.cp_out || !j.st->done) return;
+  k_count_valid_body(j.pair_gidx, j.n, j.cp_counts);
+}
+__global__ __launch_bounds__(1024) void k_scan_blocks_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  if (!j.cp_out || !j.st->done) return;
+  k_scan_blocks_body(j.cp_counts, j.nb, j.cp_counts + j.nb, nullptr);
+}
+__global__ __launch_bounds__(kBlock) void k_compact_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  if (blockIdx.x >= j.nb || !j.cp_out || !j.st->done) return;
+  const uint32_t S = j.cp_stride;
+  k_compact_body(j.pair_gidx, j.pair_q, j.n, j.cp_counts + j.nb, j.cp_out, j.cp_out + S, (float*)(j.cp_out + 2 * S),
+                 (float*)(j.cp_out + 3 * S), (float*)(j.cp_out + 4 * S), (float*)(j.cp_out + 5 * S));
 }
 
 // point-to-plane pairings: flags + compaction in ascending local index
@@ -1873,8 +1911,10 @@ struct AlignJob {
                                        (unsigned long long)scan->z, (unsigned long long)ctx->pair_q.p,
                                        (unsigned long long)ctx->pair_gidx.p, (unsigned long long)part,
                                        (unsigned long long)ctx->d_state, (unsigned long long)ctx->d_params,
-                                       (unsigned long long)ctx->h_state, pl ? 2ull : 1ull,
-                                       (unsigned long long)(pl ? ctx->pl_c.p : nullptr),
+                                       (unsigned long long)ctx->h_state,
+                                       (pl ? 2ull : 1ull) | (one_group ? 4ull : 0ull) | (fused16 ? 8ull : 0ull),
+                                       (unsigned long long)(pl ? ctx->pl_c.p : nullptr) ^
+                                           ((unsigned long long)(pl ? ctx->pl_n.p : nullptr) << 1),
                                        (unsigned long long)(pl ? ctx->partials_b.p : nullptr)};
       static_assert(sizeof(kv) <= sizeof(key), "graph key too small");
       memcpy(key, kv, sizeof(kv));
@@ -2009,25 +2049,149 @@ mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_icp_para
   return MH_OK;
 }
 
+size_t mh_pairs_block_bytes(size_t n_scan_points) {
+  const size_t S = ((n_scan_points ? n_scan_points : 1) + 63) / 64 * 64;
+  return 6 * S * sizeof(uint32_t);
+}
+
+namespace {
+// descriptor of one job for the *_b kernels (device pointers only; the pairing-block fields are filled by the caller)
+void fill_batch_desc(const AlignJob& j, BatchJob& d) {
+  memset(&d, 0, sizeof(d));
+  d.st = j.ctx->d_state;
+  d.mk = &j.ctx->d_params->mk;
+  d.sk = &j.ctx->d_params->sk;
+  d.lx = j.scan->x; d.ly = j.scan->y; d.lz = j.scan->z;
+  d.n = (uint32_t)j.scan->n;
+  d.nb = j.nb;
+  d.nba = j.nba;
+  d.nbm = j.nbm;
+  d.map = j.map->view();
+  d.pair_q = j.ctx->pair_q.as<float4>();
+  d.pair_gidx = j.ctx->pair_gidx.as<uint32_t>();
+  d.part = j.ctx->partials.as<double>();
+}
+
+// Work still queued on a job's own stream (asynchronous uploads, filters, de-skew, an earlier alignment) must be
+// complete before `lead`'s stream reads that job's scan / state: an event per job, waited for by the leader's stream.
+mh_status order_after_job_streams(mh_ctx* lead, const std::vector<AlignJob*>& jobs) {
+  for (AlignJob* j : jobs) {
+    if (j->ctx == lead || j->ctx->stream == lead->stream) continue;
+    if (hipStreamQuery(j->ctx->stream) == hipSuccess) continue;  // nothing pending there
+    MH_HIP(hipEventRecord(j->ctx->ev_ready, j->ctx->stream));
+    MH_HIP(hipStreamWaitEvent(lead->stream, j->ctx->ev_ready, 0));
+  }
+  (void)hipGetLastError();  // hipStreamQuery's hipErrorNotReady is not an error
+  return MH_OK;
+}
+
+// Where the batch's final pairings go: device-side layout of the pairs block (header of per-block counts / offsets for
+// the compaction + the block itself unless the caller's block already is device memory).
+struct PairsPlan {
+  bool want = false;
+  int32_t mem = MH_MEM_HOST;
+  char* host_block = nullptr;    // caller's block (host kinds)
+  char* dev_block = nullptr;     // where the kernels write
+  uint32_t* dev_hdr = nullptr;
+  size_t total_bytes = 0;
+  std::vector<size_t> off;       // byte offset of job i in the block
+  std::vector<size_t> hdr_off;   // entry offset of job i's counts in the header
+};
+
+mh_status plan_pairs(mh_ctx* lead, const std::vector<AlignJob>& jobs, void* pairs_block, int32_t pairs_mem, PairsPlan& pp) {
+  pp.want = pairs_block != nullptr;
+  if (!pp.want) return MH_OK;
+  pp.mem = pairs_mem;
+  pp.off.resize(jobs.size());
+  pp.hdr_off.resize(jobs.size());
+  size_t bytes = 0, hdr = 0;
+  for (size_t i = 0; i < jobs.size(); i++) {
+    pp.off[i] = bytes;
+    pp.hdr_off[i] = hdr;
+    bytes += mh_pairs_block_bytes(jobs[i].scan->n);
+    hdr += 2 * (size_t)nblk(jobs[i].scan->n ? jobs[i].scan->n : 1);
+  }
+  pp.total_bytes = bytes;
+  const size_t hdr_bytes = (hdr * 4 + 255) / 256 * 256;
+  const size_t need = hdr_bytes + (pairs_mem == MH_MEM_DEVICE ? 0 : bytes);
+  if (lead->pairs_stage.bytes < need && lead->pairs_copy_pending) {  // the previous download still reads the old buffer
+    MH_HIP(hipStreamSynchronize(lead->copy_stream));
+    lead->pairs_copy_pending = false;
+  }
+  MH_TRY(lead->pairs_stage.reserve(need));
+  pp.dev_hdr = lead->pairs_stage.as<uint32_t>();
+  pp.dev_block = pairs_mem == MH_MEM_DEVICE ? (char*)pairs_block : lead->pairs_stage.as<char>() + hdr_bytes;
+  pp.host_block = pairs_mem == MH_MEM_DEVICE ? nullptr : (char*)pairs_block;
+  if (pairs_mem == MH_MEM_HOST_PINNED && !lead->copy_stream) {
+    MH_HIP(hipStreamCreateWithFlags(&lead->copy_stream, hipStreamNonBlocking));
+    MH_HIP(hipEventCreateWithFlags(&lead->ev_pairs_ready, hipEventDisableTiming));
+    MH_HIP(hipEventCreateWithFlags(&lead->ev_pairs_copied, hipEventDisableTiming));
+  }
+  return MH_OK;
+}
+
+void set_pairs_fields(const PairsPlan& pp, size_t job_index, BatchJob& d) {
+  if (!pp.want) return;
+  d.cp_counts = pp.dev_hdr + pp.hdr_off[job_index];
+  d.cp_out = reinterpret_cast<uint32_t*>(pp.dev_block + pp.off[job_index]);
+  d.cp_stride = (uint32_t)(mh_pairs_block_bytes(d.n) / 24);
+}
+
+// compaction of every finished job's pairings into the block (descriptors `dj` already on the device) + the download
+mh_status finish_pairs(mh_ctx* lead, const PairsPlan& pp, const BatchJob* dj, uint32_t A, uint32_t gx_cov) {
+  if (!pp.want || A == 0) return MH_OK;
+  hipStream_t s = lead->stream;
+  if (lead->pairs_copy_pending) MH_HIP(hipStreamWaitEvent(s, lead->ev_pairs_copied, 0));  // staging still being read
+  hipLaunchKernelGGL(k_count_valid_b, dim3(gx_cov, A), dim3(kBlock), 0, s, dj);
+  hipLaunchKernelGGL(k_scan_blocks_b, dim3(1, A), dim3(1024), 0, s, dj);
+  hipLaunchKernelGGL(k_compact_b, dim3(gx_cov, A), dim3(kBlock), 0, s, dj);
+  MH_HIP(hipGetLastError());
+  if (pp.mem == MH_MEM_HOST) {
+    MH_HIP(hipMemcpyAsync(pp.host_block, pp.dev_block, pp.total_bytes, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+  } else if (pp.mem == MH_MEM_HOST_PINNED) {
+    // on the copy stream: the call returns, the next batch's kernels run while this block travels
+    MH_HIP(hipEventRecord(lead->ev_pairs_ready, s));
+    MH_HIP(hipStreamWaitEvent(lead->copy_stream, lead->ev_pairs_ready, 0));
+    MH_HIP(hipMemcpyAsync(pp.host_block, pp.dev_block, pp.total_bytes, hipMemcpyDeviceToHost, lead->copy_stream));
+    MH_HIP(hipEventRecord(lead->ev_pairs_copied, lead->copy_stream));
+    lead->pairs_copy_pending = true;
+  }
+  return MH_OK;
+}
+}  // namespace
+
 mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_scan* const* scans,
                              const mh_icp_params* params, const double* T_guesses, const mh_prior* const* priors,
-                             mh_icp_result* results) {
+                             mh_icp_result* results, void* pairs_block, int32_t pairs_mem) {
   MH_REQUIRE(n_jobs == 0 || (maps && scans && params && T_guesses && results), "null argument");
+  MH_REQUIRE(!pairs_block || pairs_mem == MH_MEM_HOST || pairs_mem == MH_MEM_DEVICE || pairs_mem == MH_MEM_HOST_PINNED,
+             "bad mem space");
+  if (n_jobs == 0) return MH_OK;
   std::vector<AlignJob> jobs(n_jobs);
   for (size_t i = 0; i < n_jobs; i++) {
     MH_TRY(check_align_args(maps[i], scans[i], params, T_guesses + 12 * i, &results[i]));
     for (size_t j = 0; j < i; j++)
       MH_REQUIRE(scans[j]->ctx != scans[i]->ctx, "each job of a batch needs its own context");
+    MH_REQUIRE(!pairs_block || scans[i]->ctx->device == scans[0]->ctx->device, "a pairs block needs all jobs on one device");
     jobs[i].defer_upload = n_jobs >= 2;  // a lock-step batch uploads all jobs' blocks in one staged copy
     MH_TRY(jobs[i].start(maps[i], scans[i], params, T_guesses + 12 * i, priors ? priors[i] : nullptr, &results[i],
                          nullptr, i));
   }
+  mh_ctx* lead0 = scans[0]->ctx;
+  PairsPlan pp;
+  MH_TRY(set_device(lead0));
+  MH_TRY(plan_pairs(lead0, jobs, pairs_block, pairs_mem, pp));
   // Lock-step mode: every kernel of an iteration is ONE launch over all jobs (blockIdx.y = job).  The jobs' tails fill
   // each other's idle lanes, which concurrent streams do not achieve (HIP maps them onto four hardware queues whose
   // kernels mostly run one after the other).  Taken for the large-layer chain (quad matcher, point-to-point).
   std::vector<AlignJob*> act;
-  for (auto& j : jobs)
-    if (!j.finished) act.push_back(&j);
+  std::vector<size_t> act_index;
+  for (size_t i = 0; i < n_jobs; i++)
+    if (!jobs[i].finished) {
+      act.push_back(&jobs[i]);
+      act_index.push_back(i);
+    }
   bool lockstep = act.size() >= 2 && getenv("MH_NO_LOCKSTEP") == nullptr;
   const bool row_chain = !act.empty() && act[0]->variant == 5;  // row kernel with the fused first accumulation
   const bool no_one_group_env = getenv("MH_NO_ONE_GROUP") != nullptr;
@@ -2046,8 +2210,11 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
     uint32_t n_groups = 1;
     if (const char* e = getenv("MH_LOCKSTEP_GROUPS")) n_groups = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : n_groups;
     if (n_groups > act.size() / 2) n_groups = (uint32_t)(act.size() / 2) ? (uint32_t)(act.size() / 2) : 1u;
+    if (n_groups > 64) n_groups = 64;
+    if (pp.want) n_groups = 1;  // the pairs block is compacted by one launch over all jobs
     struct Group {
       std::vector<AlignJob*> jobs;
+      std::vector<size_t> index;
       mh_ctx* lead = nullptr;
       IcpDeviceState* h_states = nullptr;
       const BatchJob* dj = nullptr;
@@ -2055,12 +2222,16 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       bool done = false;
     };
     std::vector<Group> groups(n_groups);
-    for (size_t a = 0; a < act.size(); a++) groups[a * n_groups / act.size()].jobs.push_back(act[a]);
+    for (size_t a = 0; a < act.size(); a++) {
+      groups[a * n_groups / act.size()].jobs.push_back(act[a]);
+      groups[a * n_groups / act.size()].index.push_back(act_index[a]);
+    }
     MH_TRY(set_device(act[0]->ctx));
     for (Group& g : groups) {
       const uint32_t A = (uint32_t)g.jobs.size();
       mh_ctx* lead = g.lead = g.jobs[0]->ctx;
       hipStream_t s = lead->stream;
+      MH_TRY(order_after_job_streams(lead, g.jobs));
       constexpr size_t kBlockBytes = kParamsOffset + sizeof(IcpDeviceParams);  // one job's [state | params] block
       static_assert(kBlockBytes % 4 == 0 && sizeof(BatchJob) % 8 == 0, "staging layout");
       const size_t need = A * sizeof(IcpDeviceState) + A * sizeof(BatchJob) + A * kBlockBytes;
@@ -2083,19 +2254,8 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       for (uint32_t a = 0; a < A; a++) {
         AlignJob& j = *g.jobs[a];
         BatchJob& d = h_desc[a];
-        memset(&d, 0, sizeof(d));
-        d.st = j.ctx->d_state;
-        d.mk = &j.ctx->d_params->mk;
-        d.sk = &j.ctx->d_params->sk;
-        d.lx = j.scan->x; d.ly = j.scan->y; d.lz = j.scan->z;
-        d.n = (uint32_t)j.scan->n;
-        d.nb = j.nb;
-        d.nba = j.nba;
-        d.nbm = j.nbm;
-        d.map = j.map->view();
-        d.pair_q = j.ctx->pair_q.as<float4>();
-        d.pair_gidx = j.ctx->pair_gidx.as<uint32_t>();
-        d.part = j.ctx->partials.as<double>();
+        fill_batch_desc(j, d);
+        set_pairs_fields(pp, g.index[a], d);
         const uint32_t bm = row_chain ? d.nbm : (uint32_t)((4ull * d.n + kBlock - 1) / kBlock);
         g.gx_match = bm > g.gx_match ? bm : g.gx_match;
         g.gx_acc = d.nba > g.gx_acc ? d.nba : g.gx_acc;
@@ -2119,7 +2279,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       uint32_t m_of[64] = {0};
       // enqueue one chunk per unfinished group, iteration by iteration across the groups so that their launches interleave
       uint32_t m_max = 0;
-      for (size_t gi = 0; gi < groups.size() && gi < 64; gi++) {
+      for (size_t gi = 0; gi < groups.size(); gi++) {
         Group& g = groups[gi];
         if (g.done) continue;
         any = true;
@@ -2128,7 +2288,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       }
       if (!any) break;
       for (uint32_t it = 0; it < m_max; it++)
-        for (size_t gi = 0; gi < groups.size() && gi < 64; gi++) {
+        for (size_t gi = 0; gi < groups.size(); gi++) {
           Group& g = groups[gi];
           if (g.done || it >= m_of[gi]) continue;
           hipStream_t s = g.lead->stream;
@@ -2150,7 +2310,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
             hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, 0u);
           }
         }
-      for (size_t gi = 0; gi < groups.size() && gi < 64; gi++) {
+      for (size_t gi = 0; gi < groups.size(); gi++) {
         Group& g = groups[gi];
         if (g.done) continue;
         hipStream_t s = g.lead->stream;
@@ -2164,7 +2324,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         MH_HIP(hipGetLastError());
         MH_HIP(hipMemcpyAsync(g.h_states, g.lead->batch_states.p, A * sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
       }
-      for (size_t gi = 0; gi < groups.size() && gi < 64; gi++) {
+      for (size_t gi = 0; gi < groups.size(); gi++) {
         Group& g = groups[gi];
         if (g.done) continue;
         MH_HIP(hipStreamSynchronize(g.lead->stream));
@@ -2195,6 +2355,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       act[0]->res->match_kernel_ms = sum / (double)g.jobs.size();
       act[0]->res->total_ms = 0.0;
     }
+    if (pp.want) MH_TRY(finish_pairs(groups[0].lead, pp, groups[0].dj, (uint32_t)groups[0].jobs.size(), groups[0].gx_cov));
     return MH_OK;
   }
   for (auto& j : jobs) MH_TRY(j.flush_deferred());
@@ -2207,6 +2368,30 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       }
     if (!any) break;
     for (auto& j : jobs) MH_TRY(j.poll());
+  }
+  if (pp.want && !act.empty()) {
+    // every job has terminated and its stream is drained: one compaction launch over all of them on the first job's stream
+    mh_ctx* lead = lead0;
+    MH_TRY(set_device(lead));
+    const uint32_t A = (uint32_t)act.size();
+    MH_TRY(lead->batch_desc.reserve(A * sizeof(BatchJob)));
+    if (lead->h_batch_cap < A * sizeof(BatchJob)) {
+      if (lead->h_batch) (void)hipHostFree(lead->h_batch);
+      lead->h_batch = nullptr;
+      lead->h_batch_cap = 0;
+      MH_HIP(hipHostMalloc(&lead->h_batch, A * sizeof(BatchJob), hipHostMallocDefault));
+      lead->h_batch_cap = A * sizeof(BatchJob);
+    }
+    BatchJob* h_desc = reinterpret_cast<BatchJob*>(lead->h_batch);
+    uint32_t gx_cov = 1;
+    for (uint32_t a = 0; a < A; a++) {
+      fill_batch_desc(*act[a], h_desc[a]);
+      set_pairs_fields(pp, act_index[a], h_desc[a]);
+      gx_cov = h_desc[a].nb > gx_cov ? h_desc[a].nb : gx_cov;
+    }
+    MH_HIP(hipMemcpyAsync(lead->batch_desc.p, h_desc, A * sizeof(BatchJob), hipMemcpyHostToDevice, lead->stream));
+    MH_TRY(finish_pairs(lead, pp, lead->batch_desc.as<BatchJob>(), A, gx_cov));
+    if (pp.mem != MH_MEM_HOST) MH_HIP(hipStreamSynchronize(lead->stream));  // h_batch is reused by the next batch
   }
   return MH_OK;
 }

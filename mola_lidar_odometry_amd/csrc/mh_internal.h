@@ -136,7 +136,13 @@ struct mh_ctx {
   unsigned long long graph_candidate[24] = {0};  // key of the last direct-launched chunk: captured when a LATER alignment repeats it
   unsigned long long graph_candidate_align = 0, align_serial = 0;
   hipEvent_t ev_poll = nullptr;
+  hipEvent_t ev_ready = nullptr;  // "everything queued on this context's stream so far": what a batch leader waits for
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+  // batches led by this context: second stream for the download of the final pairings (overlaps the next batch)
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_pairs_ready = nullptr, ev_pairs_copied = nullptr;
+  bool pairs_copy_pending = false;
+  mh::DevBuf pairs_stage;  // compacted pairings of all jobs of a batch
   // profiling events for the match kernel (pairs), created lazily
   hipEvent_t* prof_ev = nullptr;
   uint32_t prof_cap = 0;

@@ -310,7 +310,7 @@ mh_status mh_scan_set_timestamps(mh_scan* scan, const float* t, size_t n, int32_
 mh_status mh_scan_update_aos(mh_scan* scan, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y,
                              size_t off_z, int64_t off_t, int32_t mem) {
   MH_REQUIRE(scan, "null scan");
-  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
+  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE || mem == MH_MEM_HOST_PINNED, "bad mem space");
   MH_REQUIRE(n == 0 || data, "null data");
   MH_REQUIRE(n < 0x7FFFFFFFull, "scan too large");
   MH_REQUIRE(point_step >= 12 && point_step % 4 == 0 && point_step <= (1u << 16), "point_step must be a multiple of 4 in [12, 65536]");
@@ -337,7 +337,7 @@ mh_status mh_scan_update_aos(mh_scan* scan, const void* data, size_t n, size_t p
   scan->n = n;
   if (!n) return MH_OK;
   const uint32_t* recs = (const uint32_t*)data;
-  if (mem == MH_MEM_HOST) {  // the only copy of the call: the raw bytes as they are
+  if (mem != MH_MEM_DEVICE) {  // the only copy of the call: the raw bytes as they are
     MH_HIP(hipMemcpyAsync(ctx->build_a.p, data, raw_bytes, hipMemcpyHostToDevice, s));
     recs = ctx->build_a.as<uint32_t>();
   }
@@ -345,7 +345,7 @@ mh_status mh_scan_update_aos(mh_scan* scan, const void* data, size_t n, size_t p
                      (uint32_t)(off_x / 4), (uint32_t)(off_y / 4), (uint32_t)(off_z / 4), off_t >= 0 ? (int32_t)(off_t / 4) : -1,
                      (float*)scan->x, (float*)scan->y, (float*)scan->z, (float*)scan->t);
   MH_HIP(hipGetLastError());
-  MH_HIP(hipStreamSynchronize(s));  // `data` is borrowed for the call only
+  if (mem != MH_MEM_HOST_PINNED) MH_HIP(hipStreamSynchronize(s));  // `data` is borrowed for the call only
   return MH_OK;
 }
 

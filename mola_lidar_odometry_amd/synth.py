@@ -303,27 +303,40 @@ POSE_GT = np.array([2.5, -1.2, SENSOR_H, np.deg2rad(8.0), np.deg2rad(0.5), np.de
 
 
 def make_workload(name: str, n_map: int, rings: int, azimuths: int, half_extent: float, n_boxes: int,
-                  n_iters: int = 20, sigma: float = 2.0, voxel_size: float = 1.0, cap: int = 20) -> Workload:
-    scene = make_scene(12345, half_extent, n_boxes)
-    m = make_map(scene, n_map, 12345, voxel_size, cap)
-    s = make_scan(scene, POSE_GT, rings, azimuths, 54321)
-    guess = POSE_GT + GUESS_PERTURBATION
+                  n_iters: int = 20, sigma: float = 2.0, voxel_size: float = 1.0, cap: int = 20,
+                  variant: int = 0) -> Workload:
+    """variant 0 is the canonical workload (the golden fixtures and workload_stats.json refer to it); variant j > 0 is
+    an independent draw of the same generator -- another scene (boxes), another map sample, another sensor pose and
+    scan noise -- so that a batch of S scans works on S different maps, as S sequences would (eval/cli_kitti.sh:23-36)."""
+    scene = make_scene(12345 + 1009 * variant, half_extent, n_boxes)
+    m = make_map(scene, n_map, 12345 + 1009 * variant, voxel_size, cap)
+    pose_gt = POSE_GT.copy()
+    if variant:
+        rng = np.random.Generator(np.random.PCG64(777 + variant))
+        pose_gt[:2] += rng.uniform(-1.5, 1.5, 2) * np.array([4.0, 1.0])
+        pose_gt[3] += rng.uniform(-0.3, 0.3)
+    s = make_scan(scene, pose_gt, rings, azimuths, 54321 + 31 * variant)
+    guess = pose_gt + GUESS_PERTURBATION
     thr, kp = threshold_schedule(sigma, n_iters)
-    return Workload(name, m, s, POSE_GT.copy(), guess, pose_from_ypr(POSE_GT), pose_from_ypr(guess), voxel_size, cap,
-                    n_iters, thr, kp, sigma)
+    return Workload(name if not variant else f"{name}#{variant}", m, s, pose_gt, guess, pose_from_ypr(pose_gt),
+                    pose_from_ypr(guess), voxel_size, cap, n_iters, thr, kp, sigma)
 
 
-def workload_c2() -> Workload:
+def workload_c2(variant: int = 0) -> Workload:
     """BASELINE.json configs[1]: ~120k-pt scan vs 1M-pt map, 20 iterations."""
-    return make_workload("C2_120k_vs_1M", 1_000_000, 64, 1875, 120.0, 40)
+    return make_workload("C2_120k_vs_1M", 1_000_000, 64, 1875, 120.0, 40, variant=variant)
 
 
-def workload_small() -> Workload:
+def workload_small(variant: int = 0) -> Workload:
     """Reduced copy of C2 (2k-pt scan vs 20k-pt map): the committed golden fixture's generator."""
-    return make_workload("small_2k_vs_20k", 20_000, 16, 125, 25.0, 6)
+    return make_workload("small_2k_vs_20k", 20_000, 16, 125, 25.0, 6, variant=variant)
 
 
-def workload_creal() -> Workload:
+def workload_creal(variant: int = 0) -> Workload:
     """What lidar3d-default.yaml actually feeds align(): a few-thousand-point decimated scan
     (yaml:285-319) against the same 1M-pt map."""
-    return make_workload("Creal_6k_vs_1M", 1_000_000, 32, 192, 120.0, 40)
+    return make_workload("Creal_6k_vs_1M", 1_000_000, 32, 192, 120.0, 40, variant=variant)
+
+
+def workload_by_name(name: str, variant: int = 0) -> Workload:
+    return {"c2": workload_c2, "creal": workload_creal, "small": workload_small}[name](variant)

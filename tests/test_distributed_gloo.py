@@ -148,3 +148,19 @@ def test_ranks_sharing_devices_plan():
     assert mdist.plan_ranks_on_devices(16, 16, 8, 9) == (1, 8, True)
     assert mdist.plan_ranks_on_devices(32, 16, 8, 9) == (1, 16, True)         # two nodes
     assert mdist.plan_ranks_on_devices(2, 2, 0, 1) == (1, 2, False)           # CPU tests of the sharding logic (gloo)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without WORLD_SIZE starts N ranks itself (torch.distributed.run on 127.0.0.1) and the
+    line it prints carries n_gpus == N (--launch-check: rendezvous and gather only, over gloo, no GPU)."""
+    import json
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    got = json.loads(line)
+    assert got["n_gpus"] == 2 and sorted(r[0] for r in got["ranks"]) == [0, 1]

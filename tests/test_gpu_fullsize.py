@@ -114,9 +114,13 @@ def test_lockstep_batch_equals_single_alignments(gmap, c2, monkeypatch):
                              poll_every=6), None),
                        (dict(max_iterations=60, threshold=thr, kernel_param=kp, poll_every=4), [None, prior, None, None])):
         p = capi.ICPParams(**kw)
-        singles = [capi.icp_align(gmap, s, g, p, prior=(priors[i] if priors else None), want_trace=False)
+        singles = [capi.icp_align(gmap, s, g, p, prior=(priors[i] if priors else None), want_trace=False, want_pairs=True)
                    for i, (s, g) in enumerate(zip(scans, guesses))]
-        batch = capi.icp_align_batch([gmap] * len(scans), scans, guesses, p, priors=priors)
+        block = np.zeros(sum(capi.pairs_block_bytes(n) for n in sizes), np.uint8)  # Results::finalPairings of all jobs
+        batch = capi.icp_align_batch([gmap] * len(scans), scans, guesses, p, priors=priors, pairs_block=block)
+        for a, pr in zip(singles, capi.unpack_pairs_block(block, sizes, batch)):
+            for k in ("local_idx", "global_idx", "global_xyz", "d2"):
+                assert np.array_equal(pr[k], a["pairs"][k])
         monkeypatch.setenv("MH_NO_LOCKSTEP", "1")
         streams = capi.icp_align_batch([gmap] * len(scans), scans, guesses, p, priors=priors)
         monkeypatch.delenv("MH_NO_LOCKSTEP")

@@ -515,6 +515,61 @@ def test_lockstep_batch_of_row_kernel_layers(ctx, monkeypatch):
         c.close()
 
 
+def test_batch_pairs_block_pinned_uploads_and_distinct_maps(ctx, monkeypatch):
+    """What bench.py's timed region does, at test size: every job has its OWN map (independent draws of the generator),
+    the scans arrive through asynchronous uploads from page-locked host memory queued right before the batch (the batch
+    has to order itself after them, whichever stream it runs on), and Results::finalPairings of every job come back in
+    one pairs block -- pageable host, page-locked host (asynchronous download, complete after mh_ctx_synchronize of the
+    first job's context) and device memory.  Lock-step chain (row kernel, ragged sizes) and the per-stream fallback:
+    poses bitwise those of single alignments, pairings bit-equal to mh_icp_align's final_pairs."""
+    import torch
+    ws = [synth.make_workload("t", 60000, 32, 400, 80.0, 25, variant=v) for v in range(3)]
+    maps = [capi.Map(ctx, 1.0, 20).build(w.map_xyz) for w in ws]
+    sizes = [3000, 5000, 2600]
+    thr, kp = synth.threshold_schedule(2.0, 40)
+    p = capi.ICPParams(max_iterations=40, threshold=thr, kernel_param=kp, poll_every=5)
+    rng = np.random.default_rng(3)
+    subs = [w.scan_xyz[rng.permutation(len(w.scan_xyz))[:n]] for w, n in zip(ws, sizes)]
+    guesses = [w.T_guess for w in ws]
+    singles = [capi.icp_align(m, capi.Scan(ctx, sub), g, p, want_trace=False, want_pairs=True)
+               for m, sub, g in zip(maps, subs, guesses)]
+    assert all(s["n_final_pairs"] > 500 for s in singles)
+    ctxs = [capi.Context(0) for _ in sizes]
+    scans = [capi.Scan(c, np.zeros((n, 3), np.float32)) for c, n in zip(ctxs, sizes)]
+    pinned = [torch.from_numpy(np.ascontiguousarray(sub.T)).pin_memory() for sub in subs]
+    nbytes = sum(capi.pairs_block_bytes(n) for n in sizes)
+    for env in (None, "MH_NO_LOCKSTEP"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        for mem in (capi.MEM_HOST, capi.MEM_HOST_PINNED, capi.MEM_DEVICE):
+            for sc, t, n in zip(scans, pinned, sizes):  # asynchronous uploads, still in flight when the batch starts
+                sc.update(np.zeros((n, 3), np.float32))
+                sc.update_pinned(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n)
+            if mem == capi.MEM_DEVICE:
+                dev = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                res = capi.icp_align_batch(maps, scans, guesses, p, pairs_block=dev.data_ptr(), pairs_mem=mem)
+                ctxs[0].synchronize()
+                block = dev.cpu().numpy()
+            else:
+                host = torch.zeros(nbytes, dtype=torch.uint8)
+                if mem == capi.MEM_HOST_PINNED:
+                    host = host.pin_memory()
+                res = capi.icp_align_batch(maps, scans, guesses, p, pairs_block=host.data_ptr(), pairs_mem=mem)
+                ctxs[0].synchronize()  # (the pinned download completes here)
+                block = host.numpy()
+            for a, r, pr in zip(singles, res, capi.unpack_pairs_block(block, sizes, res)):
+                assert (r["n_iterations"], r["termination_reason"], r["n_final_pairs"]) == (
+                    a["n_iterations"], a["termination_reason"], a["n_final_pairs"])
+                assert np.array_equal(r["T"], a["T"]) and np.array_equal(r["cov"], a["cov"])
+                for k in ("local_idx", "global_idx", "global_xyz", "d2"):
+                    assert np.array_equal(pr[k], a["pairs"][k]), (env, mem, k)
+        if env:
+            monkeypatch.delenv(env)
+    for c in ctxs:
+        c.close()
+
+
 def test_align_is_bitwise_reproducible(ctx, small):
     w, gm, om, gs = small
     p = _params(capi, w, disable_stall_test=True)

@@ -1,6 +1,10 @@
 #!/bin/bash
-# scratch: A/B runs on the GPU box (edit freely; the default re-checks the GPU suite, the smoke test and the bench)
-cd /root/repo
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 600 python bench.py 2>&1 | tail -1 | cut -c1-300
+# development probe (rewritten per experiment; run on the GPU box through gpurun)
+REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
+cd $REPO
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu -k "batch or lockstep" > gpurun_out/pytest_batch.log 2>&1
+tail -5 gpurun_out/pytest_batch.log
+timeout 600 python bench.py > gpurun_out/bench_default.log 2>&1; tail -c 6000 gpurun_out/bench_default.log
+timeout 300 python bench.py --no-io --no-cpu-baseline --no-shared-run > gpurun_out/bench_noio.log 2>&1; tail -c 1500 gpurun_out/bench_noio.log
+timeout 300 python bench.py --maps shared --no-cpu-baseline > gpurun_out/bench_shared.log 2>&1; tail -c 1500 gpurun_out/bench_shared.log
