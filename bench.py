@@ -116,7 +116,14 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "creal", "small"])
     ap.add_argument("--maps", default="distinct", choices=["distinct", "shared"],
                     help="distinct (default): every job has its own map and scan; shared: one map and scan for all jobs")
-    ap.add_argument("--no-io", action="store_true", help="leave the scan upload and the pairings download out of the timed region (resident inputs)")
+    ap.add_argument("--io", default="both", choices=["both", "upload", "pairs", "none"],
+                    help="what travels inside the timed region: the scans H2D and the final pairings D2H (default, the metric's "
+                         "definition), one of them, or nothing (resident inputs: an upper bound, not the metric)")
+    ap.add_argument("--no-io", action="store_true", help="same as --io none")
+    ap.add_argument("--upload-delay-ms", type=float, default=1.0, help="the upload thread starts this long after the step's batch call")
+    ap.add_argument("--shared-stream", type=int, default=1, help="1: the contexts of a buffer set share one stream; 0: a stream per context")
+    ap.add_argument("--upload-thread", type=int, default=1, help="1: the next step's uploads are queued by a second host thread while "
+                    "the current step's batch call blocks; 0: by the main thread before the call")
     ap.add_argument("--no-shared-run", action="store_true", help="skip the second, shared-map measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (bounded sample)")
@@ -171,7 +178,9 @@ def main():
         """Device-side state of one measurement: S jobs, two buffer sets (A/B) of contexts + scans, pinned host mirrors."""
 
         def __init__(self, wl, io):
-            self.wl, self.io = wl, io
+            self.wl, self.io = wl, io != "none"
+            self.up, self.dl = io in ("both", "upload"), io in ("both", "pairs")
+            self.worker = None
             self.map_ctx = capi.Context(local_rank)
             self.maps = [capi.Map(self.map_ctx, x.voxel_size, x.cap).build(x.map_xyz) for x in wl]
             if len(self.maps) == 1:
@@ -187,14 +196,23 @@ def main():
             for x in self.job_w:  # interleaved xyz records, the form a sensor driver delivers: one copy per scan
                 t = torch.from_numpy(np.ascontiguousarray(x.scan_xyz, dtype=np.float32)).pin_memory()
                 self.pinned.append(t)
-            self.ctxs = [[capi.Context(local_rank) for _ in range(S)] for _ in range(2 if io else 1)]
+            # one context per job and buffer set; the contexts of a set share ONE stream (the lock-step batch runs on its
+            # first job's stream anyway): the uploads of the other set are then a second stream, not 32 -- HIP maps streams
+            # onto a handful of hardware queues, and a copy + de-interleave pair waiting at the head of a queue it shares
+            # with the batch's stream stalls the batch's kernels behind it (measured: +2 ms per step with 64 streams)
+            n_sets = 2 if self.up else 1
+            self.streams = [torch.cuda.Stream(device=local_rank) for _ in range(n_sets)] if args.shared_stream else None
+            self.ctxs = [[capi.Context(local_rank, stream=self.streams[k].cuda_stream if self.streams else None) for _ in range(S)]
+                         for k in range(n_sets)]
             self.scans = [[capi.Scan(c, x.scan_xyz) for c, x in zip(cs, self.job_w)] for cs in self.ctxs]
             self.sizes = [len(x.scan_xyz) for x in self.job_w]
             nbytes = sum(capi.pairs_block_bytes(n) for n in self.sizes)
-            self.blocks = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)] if io else None
+            self.blocks = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)] if self.dl else None
             self.k = 0
 
-        def upload(self, which):
+        def upload(self, which, delay=0.0):
+            if delay:  # (second host thread) let the main thread queue its step first: both contend for the HIP runtime's locks
+                time.sleep(delay)
             for sc, t, n in zip(self.scans[which], self.pinned, self.sizes):
                 sc.update_interleaved_pinned(t.data_ptr(), n, 12)
 
@@ -202,9 +220,22 @@ def main():
             if not self.io:
                 return capi.icp_align_batch(self.maps, self.scans[0], self.guesses, params)
             cur = self.k & 1
-            self.upload(1 - cur)  # next step's scans: asynchronous, on the other set's streams
-            r = capi.icp_align_batch(self.maps, self.scans[cur], self.guesses, params,
-                                     pairs_block=self.blocks[cur].data_ptr(), pairs_mem=capi.MEM_HOST_PINNED)
+            sset = cur if self.up else 0
+            if self.up:  # next step's scans: asynchronous copies on the OTHER buffer set's streams
+                if args.upload_thread:  # queued by a second host thread while this one blocks in the batch call below
+                    import threading
+                    self.worker = threading.Thread(target=self.upload, args=(1 - cur, args.upload_delay_ms * 1e-3))
+                    self.worker.start()
+                else:
+                    self.upload(1 - cur)
+            if self.dl:
+                r = capi.icp_align_batch(self.maps, self.scans[sset], self.guesses, params,
+                                         pairs_block=self.blocks[cur].data_ptr(), pairs_mem=capi.MEM_HOST_PINNED)
+            else:
+                r = capi.icp_align_batch(self.maps, self.scans[sset], self.guesses, params)
+            if self.worker is not None:
+                self.worker.join()
+                self.worker = None
             self.k += 1
             return r
 
@@ -217,7 +248,7 @@ def main():
                 dist.barrier()
 
         def run(self, steps, warmup):
-            if self.io:
+            if self.up:
                 self.upload(self.k & 1)
             for _ in range(warmup):
                 self.step()
@@ -244,7 +275,7 @@ def main():
                     c.close()
             self.map_ctx.close()
 
-    io = not args.no_io
+    io = "none" if args.no_io else args.io
     main_run = Setup(ws, io)
     dt, match_ms, match_launches, last = main_run.run(args.steps, args.warmup)
     # outside the timed region: the same kernel with nothing else on the device (S = 1), what rocprofv3 --stats of a
@@ -258,7 +289,7 @@ def main():
     # the trivial result gather: poses of the last step from every rank, RCCL all_gather
     gathered = mdist.gather_poses(np.stack([r["T"] for r in last]), device="cuda" if distributed else None)
     all_poses = np.stack(gathered)
-    pairs_last = main_run.last_pairs(last) if io else None
+    pairs_last = main_run.last_pairs(last) if main_run.dl else None
     if pairs_last is not None:
         pairs_last = [dict(local_idx=p["local_idx"].copy(), global_idx=p["global_idx"].copy(), d2=p["d2"].copy()) for p in pairs_last]
     guesses = main_run.guesses
@@ -287,8 +318,10 @@ def main():
                                "schedule of lidar3d-default.yaml:190,198",
                    "scans_per_step_per_gpu": S, "maps": args.maps,
                    "distinct_maps_per_gpu": len(ws), "map_bytes_per_gpu": int(len(ws) * (n_map * 16 + 4 * 2 ** 20)),
-                   "timed_region": ("scan H2D (pinned, async, one step ahead) + align + result D2H incl. finalPairings"
-                                    if io else "align only, inputs resident (--no-io)"),
+                   "timed_region": {"both": "scan H2D (pinned, async, one step ahead) + align + result D2H incl. finalPairings",
+                                    "upload": "scan H2D (pinned, async, one step ahead) + align + result D2H without finalPairings",
+                                    "pairs": "align (scans resident) + result D2H incl. finalPairings",
+                                    "none": "align only, inputs resident (--io none)"}[io],
                    "parallelism": f"{world}x independent GPUs"},
         "shared_map": shared,
         "real_data": {"KITTI_BASE_DIR": os.environ.get("KITTI_BASE_DIR"), "MULRAN_BASE_DIR": os.environ.get("MULRAN_BASE_DIR"),

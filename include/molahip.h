@@ -177,6 +177,11 @@ MH_API mh_status mh_scan_update(mh_scan* scan, const float* x, const float* y, c
  * MH_MEM_HOST_PINNED (asynchronous upload, see Conventions). */
 MH_API mh_status mh_scan_update_aos(mh_scan* scan, const void* data, size_t n, size_t point_step, size_t off_x,
                                     size_t off_y, size_t off_z, int64_t off_t, int32_t mem);
+/* Optional: queue the construction of the scan's search order for the tile matcher (large layers: the points sorted by
+ * 2x2x2-voxel block of the local frame and cut into tiles) right behind an upload, for the voxel size of the
+ * map it will be aligned against, so that it overlaps whatever else the device is doing.  Asynchronous on the context's
+ * stream.  mh_icp_align / mh_icp_align_batch build it themselves when it is missing or stale. */
+MH_API mh_status mh_scan_prepare(const mh_scan* scan, float voxel_size);
 MH_API mh_status mh_scan_destroy(mh_scan* scan);
 MH_API mh_status mh_scan_size(const mh_scan* scan, uint64_t* n);
 

@@ -139,6 +139,7 @@ _SIGNATURES = {
     "mh_scan_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
     "mh_scan_update_aos": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
                                        C.c_int64, C.c_int32]),
+    "mh_scan_prepare": (C.c_int32, [C.c_void_p, C.c_float]),
     "mh_scan_destroy": (C.c_int32, [C.c_void_p]),
     "mh_scan_size": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mh_map_insert": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_float]),
@@ -384,6 +385,11 @@ class Scan:
     def update(self, xyz):
         x, y, z = _soa(xyz)
         _chk(lib().mh_scan_update(self._h, _vp(x), _vp(y), _vp(z), len(x), MEM_HOST))
+
+    def prepare(self, voxel_size: float):
+        """Queue the build of the tile matcher's search order behind whatever was uploaded last (asynchronous)."""
+        _chk(lib().mh_scan_prepare(self._h, float(voxel_size)))
+        return self
 
     def update_pinned(self, x_ptr: int, y_ptr: int, z_ptr: int, n: int):
         """Asynchronous upload from page-locked host arrays (MH_MEM_HOST_PINNED): returns at once; the caller keeps the

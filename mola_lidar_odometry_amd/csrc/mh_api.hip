@@ -53,6 +53,7 @@ mh_status scan_alloc(mh_scan* s, size_t n, bool with_t, bool with_src) {
   s->t = with_t ? (const float*)s->aux.as<char>() : nullptr;
   s->src = with_src ? (const uint32_t*)(s->aux.as<char>() + stride) : nullptr;
   s->n = n;
+  scan_drop_tiles(s);
   return MH_OK;
 }
 
@@ -234,6 +235,7 @@ static mh_status scan_set(mh_scan* s, const float* x, const float* y, const floa
   s->t = nullptr;  // new points: whatever channels the old ones carried are gone
   s->src = nullptr;
   s->n = n;
+  scan_drop_tiles(s);
   return MH_OK;
 }
 
@@ -248,6 +250,7 @@ mh_status mh_scan_create(mh_ctx* ctx, const float* x, const float* y, const floa
   if (st != MH_OK) {
     s->xyz.release();
     s->aux.release();
+    scan_free_tiles(s);
     delete s;
     return st;
   }
@@ -266,6 +269,7 @@ mh_status mh_scan_destroy(mh_scan* scan) {
   (void)hipStreamSynchronize(scan->ctx->stream);
   scan->xyz.release();
   scan->aux.release();
+  scan_free_tiles(scan);
   delete scan;
   return MH_OK;
 }

@@ -114,6 +114,10 @@ struct BatchJob {
   uint32_t* pair_gidx;
   double* part;
   // final pairings of the batch (mh_icp_align_batch's pairs_block), or null
+  // tile matcher: the scan in search order (mh_tile.hip)
+  const float *sx, *sy, *sz;
+  const uint32_t *perm, *tile_start;
+  uint32_t n_tiles, tile_pad;
   uint32_t* cp_counts;   // [nb] pairs per 256-point block | [nb] exclusive offsets
   uint32_t* cp_out;      // six arrays of cp_stride entries: local_idx | global_idx | gx | gy | gz | d2
   uint32_t cp_stride, cp_pad;
@@ -282,6 +286,57 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
     pair_q[i] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
     pair_gidx[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
   }
+}
+
+// ================================================================================================
+// k_match_tile: correspondence search of a large layer with the map records staged in LDS, one workgroup per tile of the
+// spatially sorted scan (nn_search_tile, mh_tile.hip).  Pairings are written at the points' ORIGINAL indices, so
+// everything downstream (k_accum, covariance, compaction of the final pairings) is what it is for the other matchers.
+// ================================================================================================
+__device__ __forceinline__ void k_match_tile_body(const IcpDeviceState* __restrict__ st, const float* __restrict__ sx,
+                                                  const float* __restrict__ sy, const float* __restrict__ sz,
+                                                  const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tile_start,
+                                                  uint32_t n_tiles, MapView map, float4* __restrict__ pair_q,
+                                                  uint32_t* __restrict__ pair_gidx
+#ifdef MH_DEBUG_WAVETRACE
+                                                  , unsigned long long* __restrict__ wtrace
+#endif
+) {
+  __shared__ TileShared sh;
+  const uint32_t t = blockIdx.x;
+  if (t >= n_tiles) return;
+#ifdef MH_DEBUG_WAVETRACE
+  unsigned long long* dbg = wtrace ? wtrace + 8ull * t : nullptr;  // [start, bbox, probe, copy, search, end, nvox, records]
+  if (threadIdx.x == 0 && dbg) dbg[0] = wall_clock64();
+#endif
+  const uint32_t s0 = tile_start[t], s1 = tile_start[t + 1];
+  const uint32_t i = s0 + threadIdx.x;
+  const bool active = i < s1;
+  const uint32_t ic = active ? i : s0;
+  const float x = sx[ic], y = sy[ic], z = sz[ic];
+  const uint32_t orig = perm[ic];
+  const uint32_t done = st->done;
+  double T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = st->T[k];
+  const float thr2 = st->cur_thr2, ang2 = st->cur_ang2;
+  if (done) return;  // grid-uniform
+  float px, py, pz;
+  transform_point(T, x, y, z, px, py, pz);
+  const NNResult r = nn_search_tile(map, sh, active, px, py, pz
+#ifdef MH_DEBUG_WAVETRACE
+                                    , dbg
+#endif
+  );
+  if (active) {
+    const float n2 = (px * px + py * py) + pz * pz;
+    const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
+    pair_q[orig] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
+    pair_gidx[orig] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+  }
+#ifdef MH_DEBUG_WAVETRACE
+  if (threadIdx.x == 0 && dbg) dbg[5] = wall_clock64();
+#endif
 }
 
 // k_match16 (below, after the point-to-plane row search it can carry along): the same step with a DPP row (16 lanes)
@@ -1261,6 +1316,30 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4_b(const BatchJ
 #endif
   );
 }
+__global__ __launch_bounds__(kTileThreads) void k_match_tile(const IcpDeviceState* __restrict__ st, const float* __restrict__ sx,
+                                                             const float* __restrict__ sy, const float* __restrict__ sz,
+                                                             const uint32_t* __restrict__ perm,
+                                                             const uint32_t* __restrict__ tile_start, uint32_t n_tiles,
+                                                             MapView map, float4* __restrict__ pair_q,
+                                                             uint32_t* __restrict__ pair_gidx
+#ifdef MH_DEBUG_WAVETRACE
+                                                             , unsigned long long* __restrict__ wtrace
+#endif
+) {
+  k_match_tile_body(st, sx, sy, sz, perm, tile_start, n_tiles, map, pair_q, pair_gidx
+#ifdef MH_DEBUG_WAVETRACE
+                    , wtrace
+#endif
+  );
+}
+__global__ __launch_bounds__(kTileThreads) void k_match_tile_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  k_match_tile_body(j.st, j.sx, j.sy, j.sz, j.perm, j.tile_start, j.n_tiles, j.map, j.pair_q, j.pair_gidx
+#ifdef MH_DEBUG_WAVETRACE
+                    , nullptr
+#endif
+  );
+}
 __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first,
                                                   const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
@@ -1739,14 +1818,17 @@ struct AlignJob {
        //   "p"            one lane per point, branch-and-bound, fused accumulation   -> k_match<true, 1>
        //   "x"            one lane per point, the literal 27-voxel scan of the reference (A/B baseline)
       //   "s"            a DPP row (16 lanes) per point: what "q" becomes automatically for small layers    -> k_match16 + k_accum
+      //   "t"            a workgroup per tile of the spatially sorted scan, map records staged in LDS      -> k_match_tile + k_accum
       const char* e = getenv("MH_MATCH");
       variant = scan->n <= kRowMaxPoints ? 5 : 4;
+      if (e && e[0] == 't') variant = 6;
       if (e && e[0] == 'q') variant = 4;
       if (e && e[0] == 's') variant = 5;
       if (e && e[0] == 'p') variant = 0;
       if (e && e[0] == 'x') variant = 1;
       if (variant == 1 && map->view().ndt) variant = 0;  // "x" walks contiguous z-runs; NDT maps interleave statistics records
     }
+    if (variant == 6) MH_TRY(scan_build_tiles(scan, map->inv_vs));  // asynchronous; a no-op when the scan is already in search order
     nba = nblk_acc(scan->n);
     // (measured per iteration, fused vs k_accum: 31.0 vs 33.8 us at 4 k points, 33.2 vs 35.0 at 8 k, equal at 16 k,
     //  45.9 vs 41.8 at 32 k -- one partial row per 16 points makes the solve's reduction the longer pole there)
@@ -1794,6 +1876,7 @@ struct AlignJob {
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t)scan->n;
     const MapView mv = map->view();
+    if (variant == 6) MH_TRY(scan_tiles_ready(scan));  // the launch grid needs the tile count
     const uint32_t m = (p->max_iterations - enqueued) < chunk ? (p->max_iterations - enqueued) : chunk;
     PoseArg dummy{};
     double* part = ctx->partials.as<double>();
@@ -1848,6 +1931,17 @@ struct AlignJob {
           else if (!fused16)
             hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                                ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
+        } else if (variant == 6) {
+          hipLaunchKernelGGL(k_match_tile, dim3(scan->n_tiles), dim3(kTileThreads), 0, s, ctx->d_state, scan->sx, scan->sy, scan->sz,
+                             scan->perm, scan->tile_start, scan->n_tiles, mv, ctx->pair_q.as<float4>(),
+                             ctx->pair_gidx.as<uint32_t>()
+#ifdef MH_DEBUG_WAVETRACE
+                             , g_wtrace
+#endif
+          );
+          if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
+          hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
         } else if (variant == 4) {
           hipLaunchKernelGGL(k_match4, dim3((uint32_t)((4ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
                              scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>()
@@ -1915,7 +2009,8 @@ struct AlignJob {
                                        (pl ? 2ull : 1ull) | (one_group ? 4ull : 0ull) | (fused16 ? 8ull : 0ull),
                                        (unsigned long long)(pl ? ctx->pl_c.p : nullptr) ^
                                            ((unsigned long long)(pl ? ctx->pl_n.p : nullptr) << 1),
-                                       (unsigned long long)(pl ? ctx->partials_b.p : nullptr)};
+                                       (unsigned long long)(pl ? ctx->partials_b.p : nullptr) ^
+                                           (variant == 6 ? ((unsigned long long)scan->sx ^ ((unsigned long long)scan->n_tiles << 48)) : 0ull)};
       static_assert(sizeof(kv) <= sizeof(key), "graph key too small");
       memcpy(key, kv, sizeof(kv));
       const bool cached = ctx->graph_exec && memcmp(key, ctx->graph_key, sizeof(key)) == 0;
@@ -2070,6 +2165,12 @@ void fill_batch_desc(const AlignJob& j, BatchJob& d) {
   d.pair_q = j.ctx->pair_q.as<float4>();
   d.pair_gidx = j.ctx->pair_gidx.as<uint32_t>();
   d.part = j.ctx->partials.as<double>();
+  if (j.variant == 6) {
+    d.sx = j.scan->sx; d.sy = j.scan->sy; d.sz = j.scan->sz;
+    d.perm = j.scan->perm;
+    d.tile_start = j.scan->tile_start;
+    d.n_tiles = j.scan->n_tiles;
+  }
 }
 
 // Work still queued on a job's own stream (asynchronous uploads, filters, de-skew, an earlier alignment) must be
@@ -2194,11 +2295,15 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
     }
   bool lockstep = act.size() >= 2 && getenv("MH_NO_LOCKSTEP") == nullptr;
   const bool row_chain = !act.empty() && act[0]->variant == 5;  // row kernel with the fused first accumulation
+  const bool tile_chain = !act.empty() && act[0]->variant == 6;
   const bool no_one_group_env = getenv("MH_NO_ONE_GROUP") != nullptr;
   for (AlignJob* j : act) {
     const bool quad = j->variant == 4, row = j->variant == 5 && j->fused16 && (j->scan->n > kOneGroupMaxPoints || no_one_group_env);
-    lockstep = lockstep && (row_chain ? row : quad) && !j->pl && !j->trace && j->ctx->device == act[0]->ctx->device;
+    lockstep = lockstep && (row_chain ? row : (tile_chain ? j->variant == 6 : quad)) && !j->pl && !j->trace &&
+               j->ctx->device == act[0]->ctx->device;
   }
+  if (lockstep && tile_chain)
+    for (AlignJob* j : act) MH_TRY(scan_tiles_ready(j->scan));  // tile counts (the builds were queued by start())
   if (lockstep) {
     // MH_LOCKSTEP_GROUPS splits the jobs into groups that advance independently, each on its leader's stream, so that one
     // group's match launch runs while the other is in its short accumulate / solve launches.  Measured on C2 with 32
@@ -2256,7 +2361,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         BatchJob& d = h_desc[a];
         fill_batch_desc(j, d);
         set_pairs_fields(pp, g.index[a], d);
-        const uint32_t bm = row_chain ? d.nbm : (uint32_t)((4ull * d.n + kBlock - 1) / kBlock);
+        const uint32_t bm = row_chain ? d.nbm : (tile_chain ? d.n_tiles : (uint32_t)((4ull * d.n + kBlock - 1) / kBlock));
         g.gx_match = bm > g.gx_match ? bm : g.gx_match;
         g.gx_acc = d.nba > g.gx_acc ? d.nba : g.gx_acc;
         g.gx_cov = d.nb > g.gx_cov ? d.nb : g.gx_cov;
@@ -2297,6 +2402,8 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
           if (pr) MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n], s));
           if (row_chain)
             hipLaunchKernelGGL(k_match16f_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj);
+          else if (tile_chain)
+            hipLaunchKernelGGL(k_match_tile_b, dim3(g.gx_match, A), dim3(kTileThreads), 0, s, g.dj);
           else
             hipLaunchKernelGGL(k_match4_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj);
           if (pr) {
@@ -2396,6 +2503,35 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
   return MH_OK;
 }
 
+namespace {
+// MH_MATCH=t: the matcher-granular entry points run the tile matcher too (the parity tests drive every search kernel
+// through mh_nn_search / mh_nn_search_dense); thr2 = +inf: no threshold
+mh_status launch_tile_search(const mh_map* map, const mh_scan* scan, const double T[12], float thr2, float ang2) {
+  mh_ctx* ctx = scan->ctx;
+  MH_TRY(scan_build_tiles(scan, map->inv_vs));
+  MH_TRY(scan_tiles_ready(scan));
+  MH_HIP(hipStreamSynchronize(ctx->stream));  // the pinned state mirror may still be travelling
+  init_state(ctx->h_state, T);
+  ctx->h_state->cur_thr2 = thr2;
+  ctx->h_state->cur_ang2 = ang2;
+  MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpDeviceState), hipMemcpyHostToDevice, ctx->stream));
+  if (scan->n_tiles)
+    hipLaunchKernelGGL(k_match_tile, dim3(scan->n_tiles), dim3(kTileThreads), 0, ctx->stream, ctx->d_state, scan->sx, scan->sy,
+                       scan->sz, scan->perm, scan->tile_start, scan->n_tiles, map->view(), ctx->pair_q.as<float4>(),
+                       ctx->pair_gidx.as<uint32_t>()
+#ifdef MH_DEBUG_WAVETRACE
+                       , (unsigned long long*)nullptr
+#endif
+    );
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+inline bool tile_search_forced() {
+  const char* e = getenv("MH_MATCH");
+  return e && e[0] == 't';
+}
+}  // namespace
+
 mh_status mh_nn_search(const mh_map* map, const mh_scan* scan, const double T[12], double threshold,
                        double threshold_angular_deg, const mh_pairs_out* out, int32_t mem, mh_match_info* info) {
   MH_REQUIRE(map && scan && T, "null argument");
@@ -2418,7 +2554,10 @@ mh_status mh_nn_search(const mh_map* map, const mh_scan* scan, const double T[12
   const double ang = threshold_angular_deg * 3.14159265358979323846 / 180.0;
   mk.ang2 = (float)(ang * ang);
   MH_TRY(upload_params(ctx, mk, sk0));
-  hipLaunchKernelGGL((k_match<false, 1>), dim3(nblk(scan->n)), dim3(kBlock), 0, ctx->stream, ctx->d_state, Ta,
+  if (tile_search_forced())
+    MH_TRY(launch_tile_search(map, scan, T, (float)(threshold * threshold), mk.ang2));
+  else
+    hipLaunchKernelGGL((k_match<false, 1>), dim3(nblk(scan->n)), dim3(kBlock), 0, ctx->stream, ctx->d_state, Ta,
                        (float)(threshold * threshold), 1u, &ctx->d_params->mk, scan->x, scan->y, scan->z, (uint32_t)scan->n, map->view(),
                        ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (double*)nullptr, 0u);
   MH_HIP(hipGetLastError());
@@ -2447,8 +2586,11 @@ mh_status mh_nn_search_dense(const mh_map* map, const mh_scan* scan, const doubl
   SolveK sk0{};
   hipStream_t s = ctx->stream;
   MH_TRY(upload_params(ctx, mk, sk0));
-  hipLaunchKernelGGL((k_match<false, 1>), dim3(nblk(n)), dim3(kBlock), 0, s, ctx->d_state, Ta, 0.f, 0u,
-                     &ctx->d_params->mk, scan->x,
+  if (tile_search_forced())
+    MH_TRY(launch_tile_search(map, scan, T, __builtin_inff(), 0.f));
+  else
+    hipLaunchKernelGGL((k_match<false, 1>), dim3(nblk(n)), dim3(kBlock), 0, s, ctx->d_state, Ta, 0.f, 0u,
+                       &ctx->d_params->mk, scan->x,
                        scan->y, scan->z, (uint32_t)n, map->view(), ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
                        (double*)nullptr, 0u);
   uint32_t* o_gi = global_idx;

@@ -184,6 +184,19 @@ struct mh_scan {
   const float* t = nullptr;       // per-point time stamps [s] or null
   const uint32_t* src = nullptr;  // index of each point in the raw scan it was filtered from, or null
   size_t n = 0;
+  // Search order of the tile matcher (mh_tile.hip), a cache that belongs to the point content: the points sorted by
+  // (2x2x2-voxel block of the LOCAL frame, quarter-voxel Morton code inside it) and cut into tiles of <= 256 consecutive
+  // points that never cross a block.  A rigid transform keeps a tile's points together, so the map records one tile needs
+  // fit one workgroup's LDS whatever the pose.  Built lazily (scan_build_tiles), dropped whenever the points change.
+  mutable mh::DevBuf tiles;  // sx | sy | sz | perm | tile_start[n + 1]
+  mutable const float *sx = nullptr, *sy = nullptr, *sz = nullptr;
+  mutable const uint32_t* perm = nullptr;        // sorted position -> index in x/y/z
+  mutable const uint32_t* tile_start = nullptr;  // [n_tiles + 1]
+  mutable uint32_t n_tiles = 0;
+  mutable float tile_inv_vs = 0.f;
+  mutable bool tiles_valid = false, tiles_pending = false;  // pending: n_tiles still travelling to h_ntiles
+  mutable uint32_t* h_ntiles = nullptr;  // pinned
+  mutable hipEvent_t ev_tiles = nullptr;
 };
 
 namespace mh {
@@ -194,6 +207,12 @@ mh_status stage_in(mh_ctx* ctx, DevBuf& buf, size_t offset_bytes, const void* sr
 mh_status scan_alloc(mh_scan* s, size_t n, bool with_t, bool with_src);
 // map (re)build from device arrays; src_ids null = identity.  evict: 0 or {cx,cy,cz,dist_in_grid} voxel test.
 // n_stored: the first n_stored inputs are points the map already stores (accepted by the insertion rules before).
+// sorted copy + tile table of a scan for voxel size 1/inv_vs (no-op when valid); asynchronous on the scan's stream,
+// scan_tiles_ready() waits for the tile count
+mh_status scan_build_tiles(const mh_scan* s, float inv_vs);
+mh_status scan_tiles_ready(const mh_scan* s);
+void scan_drop_tiles(mh_scan* s);  // host-side bookkeeping only (the points changed)
+void scan_free_tiles(mh_scan* s);
 mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc, size_t n,
                            const int* evict, size_t n_stored);
 }  // namespace mh

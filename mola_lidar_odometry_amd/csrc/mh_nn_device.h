@@ -669,6 +669,225 @@ __device__ __forceinline__ NNResult nn_search_row16(const MapView& m, uint32_t r
   return r;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Tile search: one WORKGROUP per tile of <= 256 spatially sorted scan points (mh_tile.hip), one lane per point.
+//   1. the workgroup takes the box of voxels around its transformed points (their bounding box + 1 voxel each way;
+//      the points of a tile come from one 2x2x2-voxel block of the local frame, so the box has <= ~150 voxels);
+//   2. thread v probes box voxel v (ONE round trip for the whole box), an exclusive scan of the counts in box order
+//      assigns every voxel its place in LDS;
+//   3. the records of the occupied voxels are copied to LDS, a DPP row (16 lanes) per voxel: ONE more round trip,
+//      coalesced;  C2: 3.8 records loaded per scan point, where the per-point searches read ~35 candidates + ~8 slots;
+//   4. every lane scans its 27 voxels in LDS: own voxel, then faces, edges, corners, a voxel being skipped by the whole
+//      wave when no lane's bound admits it (the 64 points of a wave are neighbours, they want the same voxels).
+// Box order (x outer, y, z inner) is ascending packed-key order, i.e. ascending record index, so the position in LDS
+// orders candidates exactly as the record index does: the key (d2 bits << 32 | LDS position) has the reference's
+// tie-break order.  Same candidates (27 voxels), same fp32 arithmetic, same strict minimum: bit-identical pairings.
+// A tile whose box or record count does not fit (never on C2) falls back to nn_search_pruned, lane by lane.
+// -------------------------------------------------------------------------------------------------
+constexpr int kTileMaxVox = 256;    // box voxels (one probe per thread)
+constexpr int kTileMaxRec = 1152;   // records in LDS (18 KiB); C2: median 280, maximum 1076
+constexpr int kTileThreads = 256;
+
+struct TileShared {
+  f32x4 rec[kTileMaxRec];
+  uint32_t vt[kTileMaxVox];       // LDS position of the voxel's first record | count << 16
+  uint32_t vfirst[kTileMaxVox];   // record index of the voxel's first record in the map
+  uint32_t occ[kTileMaxVox];      // occupied voxels, compacted
+  int red[6][4];                  // per-wave bounding box
+  uint32_t wtot[4], wocc[4];
+};
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_keep_i32(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, 0xF, false);  // lanes without a source keep `old`
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+  const int big = 0x7FFFFFFF;
+  v = min(v, dpp_keep_i32<0x101>(big, v));  // row_shl:1
+  v = min(v, dpp_keep_i32<0x102>(big, v));
+  v = min(v, dpp_keep_i32<0x104>(big, v));
+  v = min(v, dpp_keep_i32<0x108>(big, v));  // lane 0 of each row holds the row's minimum
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }  // (callers stay away from INT_MIN)
+
+// inclusive prefix sum over the 64 lanes of a wave (DPP row shifts inside the 16-lane rows, three readlanes across)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);  // row_shr:1 (lane i reads lane i-1 of its row, else 0)
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+  const int t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31), t2 = __builtin_amdgcn_readlane(x, 47);
+  const uint32_t row = ((uint32_t)__lane_id()) >> 4;
+  x += (row >= 1 ? t0 : 0) + (row >= 2 ? t1 : 0) + (row >= 3 ? t2 : 0);
+  return (uint32_t)x;
+}
+
+// all records of one voxel's run in LDS, every lane its own run (cnt may be 0), four reads in flight per lane
+__device__ __forceinline__ void tile_scan_run(const TileShared& sh, uint32_t off, uint32_t cnt, float qx, float qy, float qz,
+                                              nnkey_t& best) {
+  for (uint32_t j = 0; __ballot(j < cnt) != 0ull; j += 4u) {
+    f32x4 c[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      ok[u] = j + (uint32_t)u < cnt;
+      c[u] = sh.rec[ok[u] ? off + j + (uint32_t)u : 0u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const float dx = c[u].x - qx, dy = c[u].y - qy, dz = c[u].z - qz;
+      const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order (bit-exact with the oracle)
+      const nnkey_t k = ok[u] ? (((nnkey_t)__float_as_uint(d2) << 32) | (off + j + (uint32_t)u)) : kNNKeyNone;
+      best = k < best ? k : best;
+    }
+  }
+}
+
+// The whole workgroup calls this (it contains barriers).  `active`: the lane holds a point of the tile.  Returns the
+// nearest map point of the lane's query (every lane its own).
+#ifdef MH_DEBUG_WAVETRACE
+#define MH_TILE_DBG_ARG , unsigned long long* __restrict__ dbg
+#define MH_TSTAMP(i) do { if (threadIdx.x == 0 && dbg) dbg[i] = wall_clock64(); } while (0)
+#define MH_TVALUE(i, v) do { if (threadIdx.x == 0 && dbg) dbg[i] = (unsigned long long)(v); } while (0)
+#else
+#define MH_TILE_DBG_ARG
+#define MH_TSTAMP(i) do { } while (0)
+#define MH_TVALUE(i, v) do { } while (0)
+#endif
+__device__ __forceinline__ NNResult nn_search_tile(const MapView& m, TileShared& sh, bool active, float qx, float qy, float qz MH_TILE_DBG_ARG) {
+  NNResult r;
+  r.d2 = __builtin_inff();
+  r.found = false;
+  r.pt = (f32x4)(0.f);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const float lim = 1.0e6f;  // one test, no short-circuit branches: NaN and inf fail it as well
+  const bool valid = active && ((int)(fabsf(qx * m.inv_vs) < lim) & (int)(fabsf(qy * m.inv_vs) < lim) & (int)(fabsf(qz * m.inv_vs) < lim));
+  const int cx = valid ? voxel_of(qx, m.inv_vs, m.trunc) : 0, cy = valid ? voxel_of(qy, m.inv_vs, m.trunc) : 0,
+            cz = valid ? voxel_of(qz, m.inv_vs, m.trunc) : 0;
+  {  // bounding box of the tile's voxels
+    const int big = 0x40000000;
+    const int lo_x = wave_min_i32(valid ? cx : big), lo_y = wave_min_i32(valid ? cy : big), lo_z = wave_min_i32(valid ? cz : big);
+    const int hi_x = wave_max_i32(valid ? cx : -big), hi_y = wave_max_i32(valid ? cy : -big), hi_z = wave_max_i32(valid ? cz : -big);
+    if (lane == 0) {
+      sh.red[0][wave] = lo_x; sh.red[1][wave] = lo_y; sh.red[2][wave] = lo_z;
+      sh.red[3][wave] = hi_x; sh.red[4][wave] = hi_y; sh.red[5][wave] = hi_z;
+    }
+  }
+  __syncthreads();
+  int lo[3], hi[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    lo[a] = min(min(sh.red[a][0], sh.red[a][1]), min(sh.red[a][2], sh.red[a][3]));
+    hi[a] = max(max(sh.red[a + 3][0], sh.red[a + 3][1]), max(sh.red[a + 3][2], sh.red[a + 3][3]));
+  }
+  MH_TSTAMP(1);
+  if (hi[0] < lo[0]) return r;  // no valid point in the tile (workgroup-uniform)
+  const int ox = lo[0] - 1, oy = lo[1] - 1, oz = lo[2] - 1;
+  const long long ex = (long long)hi[0] - lo[0] + 3, ey = (long long)hi[1] - lo[1] + 3, ez = (long long)hi[2] - lo[2] + 3;
+  const long long nvox_l = ex * ey * ez;
+  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
+  const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
+  bool fits = nvox_l <= (long long)kTileMaxVox;
+  const int dy = (int)ey, dz = (int)ez, dydz = dy * dz;
+  const uint32_t nvox = fits ? (uint32_t)nvox_l : 0u;
+  uint32_t first = 0, cnt = 0;
+  if (fits && tid < nvox) {  // thread v <-> box voxel v = (ix * dy + iy) * dz + iz
+    const uint32_t t = (uint32_t)(((float)tid + 0.5f) * (1.0f / (float)dz));  // exact for these ranges (margin 1/(2 dz))
+    const uint32_t iz = tid - t * (uint32_t)dz;
+    const uint32_t ix = (uint32_t)(((float)t + 0.5f) * (1.0f / (float)dy));
+    const uint32_t iy = t - ix * (uint32_t)dy;
+    const unsigned long long key = pack_key(ox + (int)ix, oy + (int)iy, oz + (int)iz);
+    nn_resolve(m, slots4, key, slots4[hash_key(key) & m.mask], true, first, cnt);
+  }
+  const uint32_t incl = wave_scan_incl(cnt);
+  const unsigned long long occ_mask = __ballot(cnt > 0u);
+  if (lane == 63) sh.wtot[wave] = incl;
+  if (lane == 0) sh.wocc[wave] = (uint32_t)__popcll(occ_mask);
+  __syncthreads();
+  uint32_t base = 0, obase = 0, total = 0, n_occ = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 4; w++) {
+    base += w < wave ? sh.wtot[w] : 0u;
+    obase += w < wave ? sh.wocc[w] : 0u;
+    total += sh.wtot[w];
+    n_occ += sh.wocc[w];
+  }
+  fits = fits && total <= (uint32_t)kTileMaxRec;
+  MH_TSTAMP(2);
+  MH_TVALUE(6, nvox_l);
+  MH_TVALUE(7, total | ((unsigned long long)n_occ << 32));
+  if (!fits) {  // workgroup-uniform: the lane-by-lane search through the caches
+    return valid ? nn_search_pruned(m, qx, qy, qz) : r;
+  }
+  if (tid < nvox) {
+    const uint32_t off = base + incl - cnt;
+    sh.vt[tid] = off | (cnt << 16);
+    sh.vfirst[tid] = first;
+    if (cnt > 0u) sh.occ[obase + (uint32_t)__popcll(occ_mask & ((1ull << lane) - 1ull))] = tid;
+  }
+  __syncthreads();
+  {  // records -> LDS, sixteen lanes per occupied voxel
+    const uint32_t r16 = tid & 15u;
+    for (uint32_t k = tid >> 4; k < n_occ; k += kTileThreads / 16) {
+      const uint32_t v = sh.occ[k];
+      const uint32_t oc = sh.vt[v], gf = sh.vfirst[v];
+      const uint32_t off = oc & 0xFFFFu, c = oc >> 16;
+      for (uint32_t j = r16; j < c; j += 16u) sh.rec[off + j] = pts4[gf + j];
+    }
+  }
+  __syncthreads();
+  MH_TSTAMP(3);
+  const Gaps gx = axis_gaps(qx, cx, m.vs, m.trunc), gy = axis_gaps(qy, cy, m.vs, m.trunc), gz = axis_gaps(qz, cz, m.vs, m.trunc);
+  const int b0 = ((cx - ox) * dy + (cy - oy)) * dz + (cz - oz);
+  nnkey_t best = kNNKeyNone;
+  {  // the query's own voxel
+    const uint32_t oc = valid ? sh.vt[b0] : 0u;
+    tile_scan_run(sh, oc & 0xFFFFu, oc >> 16, qx, qy, qz, best);
+  }
+  // the neighbours that can still hold a candidate with d2 <= best: bit `code` of `mask` (code = ix * 9 + iy * 3 + iz)
+  uint32_t mask = 0;
+  if (valid) {
+#pragma unroll
+    for (int c = 0; c < 27; c++) {
+      if (c == 13) continue;
+      const float lb = (gx.s[c / 9] + gy.s[(c / 3) % 3]) + gz.s[c % 3];
+      if (!(lb * 0.9999f > nnkey_d2(best))) mask |= 1u << c;
+    }
+  }
+  // every lane walks ITS OWN live voxels (faces, then edges, then corners: nearer voxels tighten the bound for the
+  // farther ones); the wave stays in the loop as long as one lane has a voxel left
+  const uint32_t kFaces = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 14) | (1u << 16) | (1u << 22);
+  const uint32_t kCorners = (1u << 0) | (1u << 2) | (1u << 6) | (1u << 8) | (1u << 18) | (1u << 20) | (1u << 24) | (1u << 26);
+  const uint32_t kEdges = 0x07FFFFFFu & ~(kFaces | kCorners | (1u << 13));
+#pragma unroll 1
+  for (int cls = 0; cls < 3; cls++) {
+    uint32_t mm = mask & (cls == 0 ? kFaces : (cls == 1 ? kEdges : kCorners));
+    while (__ballot(mm != 0u) != 0ull) {
+      uint32_t off = 0, cnt = 0;
+      while (mm != 0u && cnt == 0u) {  // next live voxel of this lane that holds records and still passes the bound
+        const int c = __builtin_ctz(mm);
+        mm &= mm - 1u;
+        if (nn_lower_bound(c, gx, gy, gz) * 0.9999f > nnkey_d2(best)) continue;
+        const int ix = (c * 57) >> 9, rr = c - 9 * ix, iy = (rr * 11) >> 5, iz = rr - 3 * iy;
+        const uint32_t oc = sh.vt[b0 + (ix - 1) * dydz + (iy - 1) * dz + (iz - 1)];
+        off = oc & 0xFFFFu;
+        cnt = oc >> 16;
+      }
+      tile_scan_run(sh, off, cnt, qx, qy, qz, best);
+    }
+  }
+  MH_TSTAMP(4);
+  if (valid && nnkey_idx(best) != 0xFFFFFFFFu) {
+    r.pt = sh.rec[nnkey_idx(best)];
+    r.d2 = nnkey_d2(best);
+    r.found = true;
+  }
+  return r;
+}
+
 // ---- robust kernels (mp2p_icp::create_robust_kernel [U], lidar3d-default.yaml:188-190) ---------
 __device__ __forceinline__ double robust_weight(uint32_t kernel, double c, double e2) {
   switch (kernel) {

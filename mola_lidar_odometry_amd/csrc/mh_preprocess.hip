@@ -335,6 +335,7 @@ mh_status mh_scan_update_aos(mh_scan* scan, const void* data, size_t n, size_t p
   scan->t = off_t >= 0 ? (const float*)scan->aux.p : nullptr;
   scan->src = nullptr;
   scan->n = n;
+  scan_drop_tiles(scan);
   if (!n) return MH_OK;
   const uint32_t* recs = (const uint32_t*)data;
   if (mem != MH_MEM_DEVICE) {  // the only copy of the call: the raw bytes as they are

@@ -53,7 +53,9 @@ def test_every_map_point_finds_itself(ctx, gmap, c2):
     assert np.all(hit <= np.arange(len(hit)))
 
 
-def test_full_size_alignment_matches_oracle(ctx, gmap, c2, oracle):
+@pytest.mark.parametrize("match", ["q", "t"])
+def test_full_size_alignment_matches_oracle(ctx, gmap, c2, oracle, match, monkeypatch):
+    monkeypatch.setenv("MH_MATCH", match)  # quad search through the caches / tiles staged in LDS
     om = oracle.Map(c2.voxel_size, c2.cap).insert(c2.map_xyz)
     kw = dict(max_iterations=c2.n_iters, disable_stall_test=True, threshold=c2.threshold, kernel_param=c2.kernel_param)
     scan = capi.Scan(ctx, c2.scan_xyz)
@@ -95,10 +97,12 @@ def test_aligning_map_points_to_their_map_is_a_fixed_point(ctx, gmap, c2):
     assert capi.TERM_NAMES[r["termination_reason"]] == "Stalled" and r["n_iterations"] == 0
 
 
-def test_lockstep_batch_equals_single_alignments(gmap, c2, monkeypatch):
+@pytest.mark.parametrize("match", ["q", "t"])
+def test_lockstep_batch_equals_single_alignments(gmap, c2, match, monkeypatch):
     """mh_icp_align_batch runs large-layer jobs in lock step (one launch per kernel over all jobs, blockIdx.y = job):
     ragged scan sizes, different guesses, a prior on one job, a stall-terminated run where the jobs finish at different
     iterations -- every result is bitwise the single alignment's, and so is the per-stream fallback's."""
+    monkeypatch.setenv("MH_MATCH", match)
     sizes = [len(c2.scan_xyz), 50000, 77777, 40001]
     ctxs = [capi.Context(0) for _ in sizes]
     scans = [capi.Scan(c, c2.scan_xyz[:n]) for c, n in zip(ctxs, sizes)]

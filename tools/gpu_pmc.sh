@@ -1,14 +1,18 @@
 #!/bin/bash
 # development probe: PMC counters for the match kernel (separate passes, no tracing flags besides kernel-trace)
-mkdir -p /root/repo/gpurun_out/pmc
+REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
+OUT=$REPO/gpurun_out/pmc
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*LDS[A-Z_0-9]*" | sort -u | tr '\n' ' ' > $OUT/lds_counters.txt
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVES" \
-         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE"; do
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /root/repo/gpurun_out/pmc/p$i -o p -- python /root/repo/bench.py --steps 2 --warmup 1 --streams ${PMC_STREAMS:-1} --no-cpu-baseline --no-profile > /root/repo/gpurun_out/pmc/p$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -o p -- python $REPO/bench.py --steps 2 --warmup 1 --streams ${PMC_STREAMS:-1} --no-cpu-baseline --no-profile --no-shared-run --no-io > $OUT/p$i.log 2>&1
 done
-cd /root/repo
+cd $REPO
+cat $OUT/lds_counters.txt; echo
 python - <<'PY'
 import csv, glob, collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
@@ -26,3 +30,4 @@ for k in acc:
     for c,v in sorted(acc[k].items()):
         print('   %-36s n=%4d avg=%.4g'%(c,len(v),sum(v)/len(v)))
 PY
+tail -3 $OUT/p2.log
