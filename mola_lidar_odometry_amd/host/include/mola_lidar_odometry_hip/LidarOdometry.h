@@ -40,24 +40,37 @@ struct Twist {
 };
 
 // Role of mola::NavStateFuse [U] (mola_navstate_fuse, not vendored; LidarOdometry.cpp:338, 810-811, 838, 1035-1038)
-// restated as a plain constant-velocity model: the twist is the increment between the last two fused poses over their
-// time difference; the extrapolation composes the last pose with (Exp_SO3(w dt), v dt).  The upstream module is a
-// sliding-window factor graph whose marginal also yields a prior information matrix; this restatement yields none
-// (cov_inv = 0 => LidarOdometry.cpp:859 skips the prior term).
+// restated as a constant-velocity model: the twist is the increment between the last two fused poses over their time
+// difference (or `initial_twist`, yaml:137 / MOLA_INITIAL_VX of eval/cli_kitti.sh:25, while only one pose is known and
+// that twist is not zero); the extrapolation composes the last pose with (Exp_SO3(w dt), v dt).  The upstream module is
+// a sliding-window factor graph whose marginal also yields the prior information matrix that LidarOdometry.cpp:859-861
+// hands to align(); here the prior is the simple propagation upstream used before the factor graph [U]: covariance
+// of the last fused pose (the previous ICP result) + (sigma_random_walk_acceleration_{linear,angular} * dt)^2 on the
+// diagonal (yaml:132-133), inverted.  It is switched by `motion_model_prior` (this implementation's own key; env
+// MOLA_HIP_MOTION_MODEL_PRIOR in the -hip pipelines) and OFF by default: its strength relative to upstream's marginal
+// is unverified, and a prior of the wrong strength pulls the solution towards the constant-velocity prediction (the
+// synthetic drive that pulls away from rest at 13 m/s^2 ends 0.31 m off with it, 0.15 m without).  Poses older than
+// max_time_to_use_velocity_model, or not newer than the last one, do not produce a twist.
 class NavStateFuse {
  public:
   struct NavState {
-    CPose3DPDFGaussianInf pose;
+    CPose3DPDFGaussianInf pose;  // cov_inv in the solver's tangent order [v; w]
     Twist twist;
   };
   double max_time_to_use_velocity_model = 2.0;  // [s] (yaml:130)
+  double sigma_random_walk_acceleration_linear = 1.0;    // [m/s^2] (yaml:132)
+  double sigma_random_walk_acceleration_angular = 10.0;  // [rad/s^2] (yaml:133)
+  bool motion_model_prior = false;
+  std::optional<Twist> initial_twist;
   void initialize(const Config& c);
   void reset();
-  void fuse_pose(double t, const CPose3D& pose);
+  // cov: 6x6 row-major covariance of `pose` in (x,y,z,yaw,pitch,roll) (Results::optimal_tf.cov), or null = exact
+  void fuse_pose(double t, const CPose3D& pose, const double* cov = nullptr);
   std::optional<NavState> estimated_navstate(double t) const;
 
  private:
   std::optional<CPose3D> last_pose_;
+  double last_cov_[36] = {0};
   double last_t_ = 0;
   std::optional<Twist> twist_;
 };

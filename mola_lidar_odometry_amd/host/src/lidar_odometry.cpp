@@ -42,19 +42,37 @@ bool ends_with(const std::string& s, const std::string& suffix) {
 
 // ================================================================== motion model
 void NavStateFuse::initialize(const Config& c) {
-  if (c.has("max_time_to_use_velocity_model"))
-    max_time_to_use_velocity_model = to_double(c["max_time_to_use_velocity_model"].asString());
+  auto num = [&](const char* k, double& v) { if (c.has(k)) v = to_double(c[k].asString()); };
+  num("max_time_to_use_velocity_model", max_time_to_use_velocity_model);
+  num("sigma_random_walk_acceleration_linear", sigma_random_walk_acceleration_linear);
+  num("sigma_random_walk_acceleration_angular", sigma_random_walk_acceleration_angular);
+  if (c.has("motion_model_prior")) motion_model_prior = to_bool(c["motion_model_prior"].asString());
+  initial_twist.reset();
+  if (c.has("initial_twist") && c["initial_twist"].size() == 6) {
+    double v[6];
+    bool any = false;
+    for (size_t i = 0; i < 6; i++) {
+      v[i] = to_double(c["initial_twist"].at(i).asString());
+      any = any || v[i] != 0.0;
+    }
+    if (any) {
+      Twist tw;
+      tw.vx = v[0]; tw.vy = v[1]; tw.vz = v[2]; tw.wx = v[3]; tw.wy = v[4]; tw.wz = v[5];
+      initial_twist = tw;
+    }
+  }
   reset();
 }
 void NavStateFuse::reset() {
   last_pose_.reset();
   twist_.reset();
   last_t_ = 0;
+  for (double& v : last_cov_) v = 0;
 }
-void NavStateFuse::fuse_pose(double t, const CPose3D& pose) {
+void NavStateFuse::fuse_pose(double t, const CPose3D& pose, const double* cov) {
   if (last_pose_) {
     const double dt = t - last_t_;
-    if (dt > 0) {
+    if (dt > 0 && dt <= max_time_to_use_velocity_model) {
       const CPose3D incr = pose - *last_pose_;  // increment in the frame of the previous pose
       double w[3];
       incr.so3Log(w);
@@ -62,11 +80,51 @@ void NavStateFuse::fuse_pose(double t, const CPose3D& pose) {
       tw.vx = incr.T[3] / dt; tw.vy = incr.T[7] / dt; tw.vz = incr.T[11] / dt;
       tw.wx = w[0] / dt; tw.wy = w[1] / dt; tw.wz = w[2] / dt;
       twist_ = tw;
+    } else {
+      twist_.reset();  // a gap or a stamp that does not advance: no velocity from this pair
     }
+  } else if (initial_twist) {
+    twist_ = initial_twist;
   }
   last_pose_ = pose;
+  for (int i = 0; i < 36; i++) last_cov_[i] = cov ? cov[i] : ((i % 7 == 0) ? 1e-12 : 0.0);  // (:834-836: "cannot be zero")
   last_t_ = t;
 }
+
+namespace {
+// inverse of a symmetric positive-definite 6x6 (Cholesky); false when it is not
+bool spd_inverse6(const double* A, double* Ainv) {
+  double L[36] = {0};
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = A[i * 6 + j];
+      for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+      if (i == j) {
+        if (!(s > 0.0) || !std::isfinite(s)) return false;
+        L[i * 6 + i] = std::sqrt(s);
+      } else {
+        L[i * 6 + j] = s / L[j * 6 + j];
+      }
+    }
+  double Li[36] = {0};  // inverse of the lower-triangular factor
+  for (int c = 0; c < 6; c++) {
+    Li[c * 6 + c] = 1.0 / L[c * 6 + c];
+    for (int r = c + 1; r < 6; r++) {
+      double s = 0;
+      for (int k = c; k < r; k++) s -= L[r * 6 + k] * Li[k * 6 + c];
+      Li[r * 6 + c] = s / L[r * 6 + r];
+    }
+  }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      double s = 0;
+      for (int k = 0; k < 6; k++) s += Li[k * 6 + i] * Li[k * 6 + j];
+      Ainv[i * 6 + j] = s;
+    }
+  return true;
+}
+}  // namespace
+
 std::optional<NavStateFuse::NavState> NavStateFuse::estimated_navstate(double t) const {
   if (!last_pose_ || !twist_) return std::nullopt;
   const double dt = t - last_t_;
@@ -76,7 +134,21 @@ std::optional<NavStateFuse::NavState> NavStateFuse::estimated_navstate(double t)
   NavState ns;
   ns.pose.mean = *last_pose_ + CPose3D::FromRotVecAndTranslation(w, v);
   ns.twist = *twist_;
-  return ns;  // cov_inv stays zero: no prior term
+  if (motion_model_prior) {
+    // covariance of the last pose, grown by the random-walk acceleration over dt, in the solver's tangent order:
+    // (x,y,z,yaw,pitch,roll) -> [v; w] with w = (roll, pitch, yaw) to first order
+    static const int perm[6] = {0, 1, 2, 5, 4, 3};
+    double C[36];
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) C[i * 6 + j] = last_cov_[perm[i] * 6 + perm[j]];
+    const double sl = sigma_random_walk_acceleration_linear * dt, sa = sigma_random_walk_acceleration_angular * dt;
+    for (int i = 0; i < 3; i++) C[i * 7] += sl * sl;
+    for (int i = 3; i < 6; i++) C[i * 7] += sa * sa;
+    double Ci[36];
+    if (spd_inverse6(C, Ci))
+      for (int i = 0; i < 36; i++) ns.pose.cov_inv[i] = Ci[i];
+  }
+  return ns;
 }
 
 // ================================================================== key-frame list
@@ -709,7 +781,7 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
     rec.icp_good = icpIsGood;
     if (icpIsGood) {
       last_lidar_pose_ = res.optimal_tf.mean;
-      navstate_.fuse_pose(this_obs_tim, res.optimal_tf.mean);
+      navstate_.fuse_pose(this_obs_tim, res.optimal_tf.mean, res.optimal_tf.cov);
       trajectory_.emplace_back(this_obs_tim, last_lidar_pose_);
     } else {
       navstate_.reset();

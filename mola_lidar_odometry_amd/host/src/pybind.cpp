@@ -160,11 +160,24 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
         return rec2dict(*rec); },
            py::arg("timestamp"), py::arg("xyz"), py::arg("t") = std::nullopt,
            py::arg("xyz_fields") = std::array<int, 3>{0, 1, 2}, py::arg("t_field") = -1)
-      .def("prefetch", [](py::object self, py::array_t<float, py::array::c_style | py::array::forcecast> xyz,
-                          std::optional<py::array_t<float, py::array::c_style | py::array::forcecast>> t,
+      .def("prefetch", [](py::object self, py::array xyz_any, std::optional<py::array> t_any,
                           std::array<int, 3> xyz_fields, int t_field) {
         // announce the NEXT scan (same arguments as the onLidar call that will follow): upload + first filter pass run
-        // on a second stream while the current scan is registered.  The arrays are kept alive on the object.
+        // on a second stream while the current scan is registered.  The worker thread reads the caller's buffers, so
+        // no hidden temporary may stand in for them: float32, C-contiguous arrays only (anything else is rejected
+        // instead of converted), kept alive on the object -- the announced scan AND the one whose worker may still be
+        // running (it is joined by the onLidar call that picks it up, which comes before the next prefetch but one).
+        auto strict = [](const py::array& a, const char* what) {
+          if (!py::dtype::of<float>().is(a.dtype()) || !(a.flags() & py::array::c_style))
+            throw std::runtime_error(std::string(what) + " must be a C-contiguous float32 array (prefetch reads it from a worker thread)");
+        };
+        strict(xyz_any, "xyz");
+        if (t_any) strict(*t_any, "t");
+        auto xyz = py::array_t<float, py::array::c_style>::ensure(xyz_any);
+        std::optional<py::array_t<float, py::array::c_style>> t;
+        if (t_any) t = py::array_t<float, py::array::c_style>::ensure(*t_any);
+        if (!xyz || (t_any && !*t)) throw std::runtime_error("prefetch: unusable array");
+        if (xyz.data() != xyz_any.data() || (t && t->data() != t_any->data())) throw std::runtime_error("prefetch: array was copied");
         LidarOdometry& lo = self.cast<LidarOdometry&>();
         if (xyz.ndim() != 2 || xyz.shape(1) < 3) throw std::runtime_error("xyz must be [n,3] (or [n,k>=3] records)");
         const size_t n = (size_t)xyz.shape(0), k = (size_t)xyz.shape(1);
@@ -178,6 +191,7 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
         }
         lo.prefetchInterleaved(xyz.data(), n, k * sizeof(float), 4u * (size_t)xyz_fields[0], 4u * (size_t)xyz_fields[1],
                                4u * (size_t)xyz_fields[2], t_field >= 0 ? 4ll * t_field : -1ll, tp);
+        if (py::hasattr(self, "_prefetch_keepalive")) self.attr("_prefetch_inflight") = self.attr("_prefetch_keepalive");
         self.attr("_prefetch_keepalive") = py::make_tuple(xyz, t ? py::object(*t) : py::none()); },
            py::arg("xyz"), py::arg("t") = std::nullopt, py::arg("xyz_fields") = std::array<int, 3>{0, 1, 2},
            py::arg("t_field") = -1)

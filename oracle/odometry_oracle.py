@@ -84,7 +84,15 @@ class OdometryOracle:
         self.cfg = c
         self.p = c["params"]
         self.n_threads = n_threads
-        self.max_time_vel = float(c.get("navstate_fuse_params", {}).get("max_time_to_use_velocity_model", 2.0))
+        nav = c.get("navstate_fuse_params", {}) or {}
+        self.max_time_vel = float(nav.get("max_time_to_use_velocity_model", 2.0))
+        # the motion model's covariance as a prior of align() (LidarOdometry.cpp:859-861): covariance of the last fused
+        # pose + (sigma_random_walk_acceleration * dt)^2, inverted [U]; `motion_model_prior: false` = no prior term
+        self.sigma_lin = float(nav.get("sigma_random_walk_acceleration_linear", 1.0))
+        self.sigma_ang = float(nav.get("sigma_random_walk_acceleration_angular", 10.0))
+        self.motion_model_prior = _b(nav.get("motion_model_prior", False))
+        it = [float(v) for v in (nav.get("initial_twist") or [])]
+        self.initial_twist = np.array(it) if len(it) == 6 and any(v != 0.0 for v in it) else None
         f1 = c["observations_filter_1st_pass"]
         names = [e["class_name"].split("::")[-1] for e in f1]
         assert names == ["FilterDecimateVoxels", "FilterByRange", "FilterBoundingBox", "FilterDecimateVoxels"], names
@@ -104,6 +112,7 @@ class OdometryOracle:
         self.last_pose = np.eye(4)[:3].reshape(12).copy()
         self.nav_last = None       # (t, pose)
         self.nav_twist = None
+        self.nav_cov = np.zeros((6, 6))
         self.last_mm = None        # (pose, twist)
         self.last_obs_tim = None
         self.last_icp_timestamp = None
@@ -123,24 +132,45 @@ class OdometryOracle:
     # ---- motion model
     def _nav_reset(self):
         self.nav_last, self.nav_twist = None, None
+        self.nav_cov = np.zeros((6, 6))
 
-    def _nav_fuse(self, t, pose):
+    def _nav_fuse(self, t, pose, cov=None):
         if self.nav_last is not None:
             dt = t - self.nav_last[0]
-            if dt > 0:
+            if 0 < dt <= self.max_time_vel:
                 inc = _inv_compose(pose, self.nav_last[1]).reshape(3, 4)
                 w = oc.so3_log(inc.reshape(12))
                 self.nav_twist = np.concatenate([inc[:, 3] / dt, w / dt])
+            else:
+                self.nav_twist = None
+        elif self.initial_twist is not None:
+            self.nav_twist = self.initial_twist.copy()
         self.nav_last = (t, np.array(pose, np.float64))
+        self.nav_cov = np.array(cov, np.float64).reshape(6, 6) if cov is not None else np.eye(6) * 1e-12
 
     def _nav_estimate(self, t):
+        """-> (pose, twist, prior information in the solver's tangent order [v; w], or None)"""
         if self.nav_last is None or self.nav_twist is None:
             return None
         dt = t - self.nav_last[0]
         if dt < 0 or dt > self.max_time_vel:
             return None
         tw = self.nav_twist
-        return _compose(self.nav_last[1], _rotvec_pose(tw[3:] * dt, tw[:3] * dt)), tw.copy()
+        info = None
+        if self.motion_model_prior:
+            perm = [0, 1, 2, 5, 4, 3]  # (x,y,z,yaw,pitch,roll) -> [v; w], w = (roll, pitch, yaw) to first order
+            Cm = self.nav_cov[np.ix_(perm, perm)].copy()
+            Cm[np.arange(3), np.arange(3)] += (self.sigma_lin * dt) ** 2
+            Cm[np.arange(3, 6), np.arange(3, 6)] += (self.sigma_ang * dt) ** 2
+            try:
+                L = np.linalg.cholesky(Cm)
+                Li = np.linalg.inv(L)
+                info = Li.T @ Li
+                if not np.all(np.isfinite(info)):
+                    info = None
+            except np.linalg.LinAlgError:
+                info = None
+        return _compose(self.nav_last[1], _rotvec_pose(tw[3:] * dt, tw[:3] * dt)), tw.copy(), info
 
     # ---- dynamic variables (LidarOdometry.cpp:1571-1635)
     def _update_vars(self):
@@ -252,7 +282,8 @@ class OdometryOracle:
                                  hook_enabled=opt_twist, hook_min_trans=float(P["optimize_twist_rerun_min_trans"]),
                                  hook_min_rot=math.radians(float(P["optimize_twist_rerun_min_rot_deg"])),
                                  hook_checkpoint=T0)
-                res = oc.icp_align(self.map, self.for_icp, T0, q, n_threads=self.n_threads)
+                prior = (self.last_mm[0], self.last_mm[2]) if (has_mm and self.last_mm[2] is not None) else None
+                res = oc.icp_align(self.map, self.for_icp, T0, q, prior=prior, n_threads=self.n_threads)
                 rec["align_calls"] += 1
                 remaining -= min(remaining, res["n_iterations"])
                 rec["icp_iterations"] += res["n_iterations"]
@@ -276,7 +307,7 @@ class OdometryOracle:
             rec["icp_good"] = good
             if good:
                 self.last_pose = res["T"].copy()
-                self._nav_fuse(stamp, res["T"])
+                self._nav_fuse(stamp, res["T"], res["cov"])
                 self.trajectory.append((stamp, self.last_pose.copy()))
             else:
                 self._nav_reset()

@@ -184,6 +184,46 @@ def test_hip_driver_matches_oracle_driver(host, drive, tmp_path):
         assert ra["pose"] == rb["pose"] and ra["n_for_icp"] == rb["n_for_icp"]
 
 
+def test_oracle_driver_motion_model_prior_and_initial_twist(drive, monkeypatch):
+    """navstate_fuse_params of the -hip pipelines: `motion_model_prior` hands the motion model's covariance (last ICP
+    covariance + (sigma_random_walk_acceleration * dt)^2, inverted) to align() as LidarOdometry.cpp:859-861 does;
+    MOLA_INITIAL_VX (eval/cli_kitti.sh:25) gives a motion model from the second scan on."""
+    from oracle import odometry_oracle as oo
+    monkeypatch.setenv("MOLA_HIP_MOTION_MODEL_PRIOR", "true")
+    monkeypatch.setenv("MOLA_INITIAL_VX", "1.5")
+    o = oo.OdometryOracle(PIPE, n_threads=8)
+    assert o.motion_model_prior and o.initial_twist is not None and o.initial_twist[0] == 1.5
+    for (xyz, t), st in list(zip(drive["scans"], drive["stamps"]))[:6]:
+        o.on_lidar(st, xyz, t)
+    assert o.records[1]["had_motion_model"]          # from the initial twist
+    est, info = o._nav_estimate(drive["stamps"][6])[0], o._nav_estimate(drive["stamps"][6])[2]
+    assert info is not None and np.allclose(info, info.T) and np.all(np.linalg.eigvalsh(info) > 0)
+    # dt = 0.1 s: position information ~ 1 / (0.1 m)^2, orientation ~ 1 / (1 rad)^2 (sigmas 1.0 m/s^2, 10 rad/s^2)
+    assert 50 < info[0, 0] <= 100.0 + 1e-6 and 0.5 < info[5, 5] <= 1.0 + 1e-9
+
+
+@pytest.mark.gpu
+def test_hip_driver_matches_oracle_driver_with_motion_model_prior(host, drive, monkeypatch):
+    """The same scan-by-scan comparison with the prior term switched on (and an initial twist): the driver now exercises
+    the prior path of mh_icp_align on every scan; records identical to the oracle driver's, poses within 1e-6."""
+    from oracle import odometry_oracle as oo
+    monkeypatch.setenv("MOLA_HIP_MOTION_MODEL_PRIOR", "true")
+    monkeypatch.setenv("MOLA_INITIAL_VX", "1.5")
+    o = oo.OdometryOracle(PIPE, n_threads=8)
+    lo = host.LidarOdometry()
+    lo.initialize(host.Config.FromYamlFile(PIPE))
+    worst = 0.0
+    for k, ((xyz, t), st) in enumerate(zip(drive["scans"], drive["stamps"])):
+        a = lo.onLidar(st, xyz, t)
+        b = o.on_lidar(st, xyz, t)
+        for key in ("icp_run", "icp_good", "had_motion_model", "map_updated", "icp_iterations", "twist_corrections",
+                    "align_calls", "termination", "n_for_icp", "n_map_points"):
+            assert a[key] == b[key], (k, key, a[key], b[key])
+        worst = max(worst, float(np.abs(np.array(a["pose"]) - b["pose"]).max()))
+    assert worst < 1e-6, worst
+    assert lo.records()[1]["had_motion_model"]
+
+
 @pytest.mark.gpu
 def test_prefetch_overlap_gives_identical_records(host, drive):
     """Announcing scan k+1 before registering scan k (upload + first filter pass on a second stream, worker thread) must
@@ -225,6 +265,11 @@ def test_prefetch_overlap_gives_identical_records(host, drive):
         lo.onLidar(drive["stamps"][3], bad, tb)
     (x4, t4) = drive["scans"][4]
     assert lo.onLidar(drive["stamps"][4], x4, t4)["icp_run"]
+    # the worker reads the caller's memory: arrays that would need a hidden converted copy are rejected, not converted
+    with pytest.raises(RuntimeError):
+        lo.prefetch(x4.astype(np.float64), t4)
+    with pytest.raises(RuntimeError):
+        lo.prefetch(np.asfortranarray(x4), t4)
 
 
 @pytest.mark.gpu
