@@ -1,0 +1,163 @@
+"""BASELINE.json configs 1, 3 and 5 on REAL data: the KITTI-00 fragment the reference's own test replays
+(test/test_lidar_odometry_rawlog.cpp:39-120 against test/kitti_00_fragment_gt.tum), the full KITTI sequence 00 replay of
+eval/cli_kitti.sh:23-36 (MOLA_INITIAL_VX=18.0), and the NDT pipeline on MulRan (eval/cli_mulran.sh:23-51).
+
+The reference bundles no point clouds (its tests fetch them from the external package mola_test_datasets) and
+neither container has a network, so these tests PROBE for the data (the environment variables the reference's CLI reads,
+apps/mola-lidar-odometry-cli.cpp:194,255, plus the usual mount points) and skip, saying where they looked, when it is
+absent.  What IS bundled by the reference, and committed here as data under tests/golden/, is the ground truth of the
+two fragments: the CPU tests below pin the numbers the GPU tests compare against.
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mola_lidar_odometry_amd import trajectory
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+CLI = os.path.join(ROOT, "mola_lidar_odometry_amd", "molahip-lo-cli")
+PIPE = os.path.join(ROOT, "pipelines", "lidar3d-default-hip.yaml")
+PIPE_NDT = os.path.join(ROOT, "pipelines", "lidar3d-ndt-hip.yaml")
+TOL = 0.1  # test/test_lidar_odometry_rawlog.cpp:101-103: |log(gt^-1 * pose)| < 0.1 per pose
+
+
+def _candidates(env, names):
+    out = []
+    if os.environ.get(env):
+        out.append(os.environ[env])
+    for base in ("/data", "/datasets", "/mnt/data", "/mnt/datasets", "/workspace/data", os.path.expanduser("~/data"),
+                 os.path.expanduser("~/datasets"), "/root/data"):
+        for n in names:
+            out.append(os.path.join(base, n))
+    return out
+
+
+def kitti_sequence_dir(seq="00"):
+    """-> (dir with velodyne/*.bin, or None; the base directories that were probed, each as <base>/[dataset/]sequences/<seq>)"""
+    probed = []
+    for base in dict.fromkeys(_candidates("KITTI_BASE_DIR", ("kitti", "KITTI", "kitti_odometry", "kitti/odometry"))):
+        probed.append(base)
+        for sub in (os.path.join("sequences", seq), os.path.join("dataset", "sequences", seq)):
+            d = os.path.join(base, sub)
+            if os.path.isdir(os.path.join(d, "velodyne")):
+                return d, probed
+    return None, probed
+
+
+def mulran_sequence_dir():
+    probed = []
+    for base in dict.fromkeys(_candidates("MULRAN_BASE_DIR", ("mulran", "MulRan", "MULRAN"))):
+        probed.append(base)
+        if os.path.isdir(base):
+            for seq in sorted(os.listdir(base)):
+                d = os.path.join(base, seq, "Ouster")
+                if os.path.isdir(d):
+                    return d, probed
+    return None, probed
+
+
+def se3_log_norm(T):
+    """|log(T)| of a 4x4 rigid transform, [v; w] stacked (mrpt::poses::Lie::SE<3>::log(...).norm())."""
+    R, t = T[:3, :3], T[:3, 3]
+    c = np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)
+    th = np.arccos(c)
+    if th < 1e-9:
+        w = np.zeros(3)
+        V_inv = np.eye(3)
+    else:
+        W = (R - R.T) * (th / (2.0 * np.sin(th)))
+        w = np.array([W[2, 1], W[0, 2], W[1, 0]])
+        A, B = np.sin(th) / th, (1.0 - np.cos(th)) / th ** 2
+        V_inv = np.eye(3) - 0.5 * W + (1.0 / th ** 2) * (1.0 - A / (2.0 * B)) * (W @ W)
+    return float(np.linalg.norm(np.concatenate([V_inv @ t, w])))
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the bundled data
+def test_bundled_ground_truth_fragments():
+    """The only real-data artefacts the reference ships: 3 poses of KITTI-00 and 23 of the RoboSense fragment.  KITTI-00
+    starts by moving 0.691 m then 0.747 m forward (the plausibility envelope of configs 1/3)."""
+    st, T = trajectory.read_tum(os.path.join(GOLD, "kitti_00_fragment_gt.tum"))
+    assert len(st) == 3 and np.allclose(T[0], np.eye(4))
+    step1 = np.linalg.norm(T[1][:3, 3] - T[0][:3, 3])
+    step2 = np.linalg.norm(T[2][:3, 3] - T[1][:3, 3])
+    assert abs(step1 - 0.691) < 2e-3 and abs(step2 - 0.747) < 2e-3
+    assert T[2][0, 3] > 1.4 and abs(T[2][1, 3]) < 0.05          # along +x of the vehicle
+    st2, T2 = trajectory.read_tum(os.path.join(GOLD, "rslidar_fragment_gt.tum"))
+    assert len(st2) == 23 and np.all(np.diff(st2) > 0.09) and np.all(np.diff(st2) < 0.11)  # a 10 Hz sweep
+    assert se3_log_norm(np.eye(4)) == 0.0
+    assert abs(se3_log_norm(np.linalg.inv(T[1]) @ T[2]) - 0.7468) < 2e-3
+
+
+def test_probe_reports_where_it_looked(monkeypatch, tmp_path):
+    monkeypatch.setenv("KITTI_BASE_DIR", str(tmp_path))
+    d, probed = kitti_sequence_dir("00")
+    assert d is None and str(tmp_path) in probed
+    (tmp_path / "sequences" / "00" / "velodyne").mkdir(parents=True)
+    d, _ = kitti_sequence_dir("00")
+    assert d == str(tmp_path / "sequences" / "00")
+
+
+# ------------------------------------------------------------------------------------------------ GPU: configs 1, 3, 5
+def _run_cli(pipeline, seq_dir, out, max_scans=None, env=None):
+    cmd = [CLI, "--pipeline", pipeline, "--seq-dir", seq_dir, "--out", out]
+    if max_scans is not None:
+        cmd += ["--max-scans", str(max_scans)]
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=3600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_config1_kitti00_fragment_against_the_reference_ground_truth(tmp_path):
+    """Config 1: frames 0-2 of KITTI sequence 00 through lidar3d-default(-hip).yaml, each pose within the reference's own
+    tolerance of test/kitti_00_fragment_gt.tum (test/test_lidar_odometry_rawlog.cpp:91,101-103)."""
+    seq, probed = kitti_sequence_dir("00")
+    if seq is None:
+        pytest.skip("KITTI odometry sequence 00 not found (no dataset in this image, no network); KITTI_BASE_DIR=%r; probed "
+                    "<base>/[dataset/]sequences/00 for base in: %s" % (os.environ.get("KITTI_BASE_DIR"), ", ".join(probed)))
+    out = str(tmp_path / "frag.tum")
+    rep = _run_cli(PIPE, seq, out, max_scans=3)
+    assert rep["scans"] == 3
+    _, est = trajectory.read_tum(out)
+    _, gt = trajectory.read_tum(os.path.join(GOLD, "kitti_00_fragment_gt.tum"))
+    assert len(est) == 3
+    for a, b in zip(est, gt):
+        assert se3_log_norm(np.linalg.inv(b) @ a) < TOL
+
+
+@pytest.mark.gpu
+def test_config3_full_kitti00_replay(tmp_path):
+    """Config 3: the whole sequence as eval/cli_kitti.sh:23-36 runs it (MOLA_INITIAL_VX=18.0); reports scans/s and, when
+    the benchmark's poses/00.txt is there, ATE and the KITTI relative errors."""
+    seq, probed = kitti_sequence_dir("00")
+    if seq is None:
+        pytest.skip("KITTI odometry sequence 00 not found (no dataset in this image, no network); KITTI_BASE_DIR=%r; probed "
+                    "<base>/[dataset/]sequences/00 for base in: %s" % (os.environ.get("KITTI_BASE_DIR"), ", ".join(probed)))
+    out = str(tmp_path / "00.tum")
+    rep = _run_cli(PIPE, seq, out, env={"MOLA_INITIAL_VX": "18.0"})
+    assert rep["scans"] >= 4000 and rep["good"] > 0.99 * rep["scans"]
+    print("config 3:", json.dumps(rep))
+    gt_file = os.path.join(os.path.dirname(os.path.dirname(seq)), "poses", "00.txt")
+    if os.path.exists(gt_file):
+        from mola_lidar_odometry_amd import run_odometry
+        gt = run_odometry._kitti_gt(os.path.dirname(os.path.dirname(seq)), "00", run_odometry._kitti_calib_Tr(seq))
+        _, est = trajectory.read_tum(out)
+        n = min(len(est), len(gt))
+        ate = trajectory.ate_rmse(est[:n], gt[:n], "umeyama")
+        print("config 3: ATE rmse [m]", ate, "KITTI t/r errors", trajectory.kitti_relative_errors(est[:n], gt[:n]))
+        assert ate < 10.0  # published LiDAR odometry on seq 00 is at the metre level over 3.7 km
+
+
+@pytest.mark.gpu
+def test_config5_ndt_pipeline_on_mulran(tmp_path):
+    """Config 5: lidar3d-ndt(-hip).yaml on a MulRan sequence (eval/cli_mulran.sh:23-51)."""
+    seq, probed = mulran_sequence_dir()
+    if seq is None:
+        pytest.skip("MulRan not found (no dataset in this image, no network); probed: " + ", ".join(probed))
+    pytest.skip("MulRan found at %s but its Ouster .bin reader (ring/time fields) is not part of the hot-path scope" % seq)
