@@ -19,12 +19,15 @@
 #include <mrpt/maps/CPointsMap.h>
 #include <mrpt/rtti/CObject.h>
 
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <stdexcept>
 #include <unordered_map>
 
 #include "hashed_voxel_pointcloud_hip.h"
 #include "molahip.h"
+#include "molahip_host/hook_replay.h"  // the opaque iteration hook on the fused loop (compiled + tested via host/src/icp.cpp)
 
 namespace mp2p_icp
 {
@@ -46,14 +49,49 @@ inline void pose_to_T12(const mrpt::poses::CPose3D& p, double T[12])
 }
 
 /** Device mirror of one host map layer.  The plugin does not own the host map (no change notification), so the
- *  mirror is rebuilt when (point count, bounding box) change -- SURVEY.md 7.3 "map mirror coherence".  The proper
- *  fix is a device-owned CMetricMap class. */
+ *  mirror is rebuilt when its CONTENT changes: point count, bounding box and a fingerprint of the coordinates (every
+ *  point when there are few, a strided sample of 4096 otherwise: a key-frame insertion that replaces points without
+ *  changing their number or their box still moves the fingerprint) -- SURVEY.md 7.3 "map mirror coherence".  The
+ *  proper fix is the device-owned CMetricMap class next to this file (hashed_voxel_pointcloud_hip.h, row f2). */
 struct MapMirror
 {
     mh_map* map   = nullptr;
     size_t  nPts  = 0;
     mrpt::math::TBoundingBoxf bbox;
+    uint64_t fingerprint = 0;
+    float voxel_size = 0;
+    uint32_t max_points_per_voxel = 0;
 };
+
+inline uint64_t fingerprint_of(const mrpt::maps::CPointsMap& pm)
+{
+    const auto& x = pm.getPointsBufferRef_x();
+    const auto& y = pm.getPointsBufferRef_y();
+    const auto& z = pm.getPointsBufferRef_z();
+    const size_t n = x.size(), step = n > 4096 ? n / 4096 : 1;
+    uint64_t h = 1469598103934665603ull;  // FNV-1a over the raw coordinate bits
+    auto mix = [&h](float v) { uint32_t b; memcpy(&b, &v, 4); h = (h ^ b) * 1099511628211ull; };
+    for (size_t i = 0; i < n; i += step) { mix(x[i]); mix(y[i]); mix(z[i]); }
+    if (n) { mix(x[n - 1]); mix(y[n - 1]); mix(z[n - 1]); }
+    return h;
+}
+
+/** creationOpts.voxel_size / insertOpts.max_points_per_voxel of the host map (lidar3d-default.yaml:233,235; the yaml
+ *  evaluates voxel_size to 0.5-1.0 m).  [U]: mola::HashedVoxelPointCloud keeps the voxel size private behind
+ *  setVoxelProperties() and exposes insertionOptions; adapt the two accessors below to the installed header.  The
+ *  environment overrides exist for the day the accessors are wrong. */
+inline void voxel_params_of(const mrpt::maps::CMetricMap& g, float& voxel_size, uint32_t& max_points_per_voxel)
+{
+    voxel_size = 1.0f;
+    max_points_per_voxel = 20;
+    if (const auto* hv = dynamic_cast<const mola::HashedVoxelPointCloud*>(&g))
+    {
+        voxel_size           = hv->voxel_size();                            // [U]
+        max_points_per_voxel = hv->insertionOptions.max_points_per_voxel;   // [U]
+    }
+    if (const char* e = getenv("MOLAHIP_VOXEL_SIZE")) voxel_size = static_cast<float>(atof(e));
+    if (const char* e = getenv("MOLAHIP_MAX_POINTS_PER_VOXEL")) max_points_per_voxel = static_cast<uint32_t>(atoi(e));
+}
 }  // namespace
 
 /** Drop-in for mp2p_icp::ICP: same align() signature as the call at LidarOdometry.cpp:961-962. */
@@ -74,7 +112,9 @@ class ICP_HIP : public ICP
         const Parameters& p, Results& result, const std::optional<mrpt::poses::CPose3DPDFGaussianInf>& prior = std::nullopt,
         const mrpt::optional_ref<LogRecord>& outputDebugInfo = std::nullopt) override  // [U]
     {
-        // Fused path only for the pipeline shape of lidar3d-default.yaml:162-209; anything else -> upstream CPU code
+        // Fused path only for the pipeline shape of lidar3d-default.yaml:162-209; anything else -> upstream CPU code.
+        // generateDebugFiles too: the upstream loop then fills the LogRecord and applies
+        // Parameters::functor_before_logging_local (set at LidarOdometry.cpp:360-364) itself before it writes the .icplog.
         auto* m = matchers().size() == 1 ? dynamic_cast<Matcher_Points_DistanceThreshold*>(matchers()[0].get()) : nullptr;
         auto* s = solvers().size() == 1 ? dynamic_cast<Solver_GaussNewton*>(solvers()[0].get()) : nullptr;
         if (!m || !s || m->pairingsPerPoint != 1 || m->weight_pt2pt_layers.size() != 1 /*[U]*/ || p.generateDebugFiles)
@@ -116,10 +156,7 @@ class ICP_HIP : public ICP
         ip.gn.weight_pt2pt = ip.gn.weight_pt2pl = 1.0;
         ip.compute_covariance    = 1;
         ip.cov_findif_xyz = ip.cov_findif_ang = 1e-7;
-        // An arbitrary user hook needs the pose every iteration: poll after each iteration and replay the hook on the
-        // per-iteration trace; stop at the first request_stop (costs one host round trip per iteration).
-        std::vector<mh_icp_iter> trace(p.maxIterations);
-        ip.poll_every = iteration_hook_ ? 1 : 0;
+        ip.poll_every = 0;
 
         double T0[12];
         pose_to_T12(mrpt::poses::CPose3D(initialGuessLocalWrtGlobal), T0);
@@ -133,7 +170,34 @@ class ICP_HIP : public ICP
         std::vector<uint32_t> li(lx.size()), gi(lx.size());
         std::vector<float> gx(lx.size()), gy(lx.size()), gz(lx.size()), d2(lx.size());
         mh_pairs_out po{li.data(), gi.data(), gx.data(), gy.data(), gz.data(), d2.data()};
-        mh_check(mh_icp_align(dmap, scan_, &ip, T0, prior ? &pr : nullptr, &r, trace.data(), &po, MH_MEM_HOST), "mh_icp_align");
+        auto run = [&](uint32_t budget, mh_icp_iter* trace) {
+            mh_icp_params q = ip;
+            q.max_iterations = budget;
+            mh_icp_result rr{};
+            mh_check(mh_icp_align(dmap, scan_, &q, T0, prior ? &pr : nullptr, &rr, trace, &po, MH_MEM_HOST), "mh_icp_align");
+            return rr;
+        };
+        if (iteration_hook_)  // [U] ICP::iteration_hook_: what setIterationHook() stored (LidarOdometry.cpp:923)
+        {
+            // The hook LidarOdometry installs (LidarOdometry.cpp:923-952) is opaque here: replay it on the traced poses
+            // and reproduce a requested stop with a second run of that budget (molahip_host/hook_replay.h).  Without
+            // this the twist re-estimation loop of :958-1007 would silently never trigger.
+            auto hook = [&](uint32_t k, const double* T) {
+                mrpt::math::CMatrixDouble44 Mk = mrpt::math::CMatrixDouble44::Identity();
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) Mk(i, j) = T[i * 4 + j];
+                OptimalTF_Result cur;                                 // [U]
+                cur.optimalPose = mrpt::poses::CPose3D(Mk);
+                IterationHook_Input in;                               // [U] fields as used at LidarOdometry.cpp:932-936
+                in.currentIteration = k;
+                in.currentSolution  = &cur;
+                in.pcGlobal = &pcGlobal;
+                in.pcLocal  = &pcLocal;
+                return iteration_hook_(in).request_stop;              // [U] IterationHook_Output::request_stop (:949)
+            };
+            r = molahip_host::align_with_replayed_hook(p.maxIterations, run, hook);
+        }
+        else
+            r = run(p.maxIterations, nullptr);
 
         // results back into the upstream structures (Results::finalPairings is read by LidarOdometry and the log writer)
         mrpt::math::CMatrixDouble44 M = mrpt::math::CMatrixDouble44::Identity();
@@ -166,18 +230,33 @@ class ICP_HIP : public ICP
         const auto* pm = dynamic_cast<const mrpt::maps::CPointsMap*>(&g);  // HashedVoxelPointCloud exposes its points through
         ASSERT_(pm);                                                        // a visitor [U]; adapt here once verified
         auto& mir = mirrors_[&g];
+        float vs; uint32_t cap;
+        voxel_params_of(g, vs, cap);  // what the map object says, not constants (yaml:233 evaluates to 0.5-1.0 m)
+        if (mir.map && (mir.voxel_size != vs || mir.max_points_per_voxel != cap))
+        {
+            mh_map_destroy(mir.map);
+            mir = MapMirror();
+        }
         if (!mir.map)
         {
-            mh_map_params mp{1.0f /* creationOpts.voxel_size [U] */, 20 /* insertOpts.max_points_per_voxel [U] */, MH_INDEX_FLOOR, 0};
+            mh_map_params mp{};
+            mp.voxel_size = vs;
+            mp.max_points_per_voxel = cap;
+            mp.index_mode = MH_INDEX_FLOOR;
             mh_check(mh_map_create(ctx_, &mp, &mir.map), "mh_map_create");
+            mir.voxel_size = vs;
+            mir.max_points_per_voxel = cap;
+            mir.nPts = ~size_t(0);  // force the first build
         }
         const auto bb = g.boundingBox();
-        if (mir.nPts != pm->size() || !(bb == mir.bbox))
+        const uint64_t fp = fingerprint_of(*pm);
+        if (mir.nPts != pm->size() || !(bb == mir.bbox) || fp != mir.fingerprint)
         {
             mh_check(mh_map_build(mir.map, pm->getPointsBufferRef_x().data(), pm->getPointsBufferRef_y().data(),
                                   pm->getPointsBufferRef_z().data(), pm->size(), MH_MEM_HOST), "mh_map_build");
             mir.nPts = pm->size();
             mir.bbox = bb;
+            mir.fingerprint = fp;
         }
         return mir.map;
     }

@@ -381,8 +381,12 @@ class ICP {
   void align(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const TPose3D& initialGuessLocalWrtGlobal,
              const Parameters& p, Results& result, const std::optional<CPose3DPDFGaussianInf>& prior = std::nullopt);
 
-  // arbitrary host callback: forces the matcher/solver-granular loop (one host round trip per iteration)
+  // arbitrary host callback: forces the matcher/solver-granular loop (one host round trip per iteration) ...
   void setIterationHook(const iteration_hook_t& hook) { iteration_hook_ = hook; }
+  // ... unless replay is on: the fused device loop runs with a per-iteration trace, the hook is replayed on the traced
+  // poses and a requested stop is reproduced by a second run with that budget (molahip_host/hook_replay.h: what the
+  // mp2p_icp adapter does, because it only ever sees an opaque std::function)
+  void setHookReplay(bool v) { hook_replay_ = v; }
   // the in-tree hook (LidarOdometry.cpp:923-952) as data: evaluated on the device inside the fused loop
   void setDeviceHook(double min_trans, double min_rot_rad, const CPose3D& checkpoint);
   void clearHooks();
@@ -417,7 +421,7 @@ class ICP {
   ParameterSource* source_ = nullptr;
   ParameterSource own_source_;
   mh_scan* scan_ = nullptr;
-  bool last_fused_ = false, force_generic_ = false, keep_pairings_ = true;
+  bool last_fused_ = false, force_generic_ = false, keep_pairings_ = true, hook_replay_ = false;
 };
 
 // class factory by name (mrpt::rtti::classFactory stand-in): "mp2p_icp::X" and "mp2p_icp_hip::X" both resolve

@@ -10,6 +10,7 @@
 #include <mutex>
 
 #include "mp2p_icp_hip/mp2p_icp_hip.h"
+#include "molahip_host/hook_replay.h"
 
 namespace mp2p_icp_hip {
 
@@ -528,7 +529,7 @@ void ICP::realize_iteration(uint32_t k) {
 // the two pipeline shapes the device loop implements: [Points_DistanceThreshold] (lidar3d-default.yaml:195-204) and
 // [Point2Plane, Points_DistanceThreshold] on the same layers (lidar3d-ndt.yaml:195-210), with one Solver_GaussNewton
 bool ICP::can_fuse() const {
-  if (force_generic_ || iteration_hook_) return false;
+  if (force_generic_ || (iteration_hook_ && !hook_replay_)) return false;
   if (matchers_.empty() || matchers_.size() > 2 || solvers_.size() != 1) return false;
   auto m = std::dynamic_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_.back());
   auto s = std::dynamic_pointer_cast<Solver_GaussNewton>(solvers_[0]);
@@ -670,8 +671,31 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
   std::vector<float> gx(li.size()), gy(li.size()), gz(li.size()), d2(li.size());
   mh_pairs_out po{li.data(), gi.data(), gx.data(), gy.data(), gz.data(), d2.data()};
   std::vector<mh_icp_iter> trace(p.generateDebugFiles ? p.maxIterations : 0);
-  check(mh_icp_align(global.handle(), scan, &ip, guess.T, prior ? &pr : nullptr, &r, trace.empty() ? nullptr : trace.data(),
-                     want_pairs ? &po : nullptr, MH_MEM_HOST), "mh_icp_align");
+  if (iteration_hook_) {
+    // an opaque host hook on the fused loop: replay it on the traced poses (molahip_host/hook_replay.h)
+    ip.hook_enabled = 0;
+    auto run = [&](uint32_t budget, mh_icp_iter* tr) {
+      mh_icp_params q = ip;
+      q.max_iterations = budget;
+      mh_icp_result rr{};
+      check(mh_icp_align(global.handle(), scan, &q, guess.T, prior ? &pr : nullptr, &rr, tr, want_pairs ? &po : nullptr,
+                         MH_MEM_HOST), "mh_icp_align");
+      if (tr && !trace.empty()) std::copy(tr, tr + budget, trace.begin());
+      return rr;
+    };
+    auto hook = [&](uint32_t k, const double* T) {
+      OptimalTF_Result cur;
+      memcpy(cur.optimalPose.T, T, sizeof(cur.optimalPose.T));
+      IterationHook_Input in;
+      in.currentIteration = k;
+      in.currentSolution = &cur;
+      return iteration_hook_(in).request_stop;
+    };
+    r = molahip_host::align_with_replayed_hook(p.maxIterations, run, hook);
+  } else {
+    check(mh_icp_align(global.handle(), scan, &ip, guess.T, prior ? &pr : nullptr, &r, trace.empty() ? nullptr : trace.data(),
+                       want_pairs ? &po : nullptr, MH_MEM_HOST), "mh_icp_align");
+  }
   if (p.generateDebugFiles) write_debug_file(p, guess, r, trace, n);
   memcpy(result.optimal_tf.mean.T, r.T, sizeof(r.T));
   memcpy(result.optimal_tf.cov, r.cov, sizeof(r.cov));

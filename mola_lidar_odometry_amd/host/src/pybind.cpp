@@ -100,6 +100,7 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
       .def("setDeviceHook", &ICP::setDeviceHook)
       .def("clearHooks", &ICP::clearHooks)
       .def("forceGenericPath", &ICP::forceGenericPath)
+      .def("setHookReplay", &ICP::setHookReplay)
       .def("lastAlignUsedFusedPath", &ICP::lastAlignUsedFusedPath)
       .def("setIterationHook", [](ICP& icp, std::function<bool(uint32_t, std::vector<double>)> f) {
         icp.setIterationHook([f](const ICP::IterationHook_Input& in) {

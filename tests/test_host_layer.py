@@ -156,7 +156,7 @@ def test_twist_hook_protocol_device_and_host_hooks_agree(hl, oracle, small_workl
     l, g, _ = _maps(hl, w)
     guess = hl.TPose3D(*w.guess_ypr)
     results = []
-    for mode in ("device", "host"):
+    for mode in ("device", "host", "replay"):
         icp, params = hl.icp_pipeline_from_yaml(cfg)
         src = hl.ParameterSource()
         src.updateVariable("ADAPTIVE_THRESHOLD_SIGMA", w.sigma)
@@ -172,11 +172,18 @@ def test_twist_hook_protocol_device_and_host_hooks_agree(hl, oracle, small_workl
                 ang = np.arccos(np.clip((np.trace(t[:, :3]) - 1) / 2, -1, 1))
                 return bool(np.linalg.norm(t[:, 3]) > 0.15 or ang > np.deg2rad(0.75))
             icp.setIterationHook(hook)
+            # "replay": the opaque hook on the FUSED loop (molahip_host/hook_replay.h, the mp2p_icp adapter's way):
+            # trace, replay, re-run with the budget at which the hook asked to stop
+            icp.setHookReplay(mode == "replay")
         results.append(icp.align(l, g, guess, params))
-    a, b = results
-    assert a.terminationReason.name == b.terminationReason.name == "HookRequest"
-    assert a.nIterations == b.nIterations
+        assert icp.lastAlignUsedFusedPath() == (mode != "host")
+    a, b, c = results
+    assert a.terminationReason.name == b.terminationReason.name == c.terminationReason.name == "HookRequest"
+    assert a.nIterations == b.nIterations == c.nIterations
     np.testing.assert_allclose(a.pose(), b.pose(), atol=1e-9)
+    np.testing.assert_array_equal(a.pose(), c.pose())  # the same device loop, stopped by budget instead of by the device hook
+    assert a.quality == c.quality and a.n_pairs() == c.n_pairs()
+    np.testing.assert_array_equal(np.asarray(a.cov()), np.asarray(c.cov()))
     thr, kp = synth.threshold_schedule(w.sigma, 40)
     om = oracle.Map(w.voxel_size, w.cap).insert(w.map_xyz)
     o = oracle.icp_align(om, w.scan_xyz, w.T_guess, oracle.ICPParams(
