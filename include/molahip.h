@@ -399,9 +399,12 @@ MH_API mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_i
 MH_API mh_status mh_icp_get_pt2pl_pairs(const mh_scan* scan, const mh_pairs_pl_out* out, int32_t mem, uint64_t* n_pairs);
 
 /* Many independent alignments from one host thread, one context per job.  Job i uses maps[i], scans[i] (distinct
- * contexts), guesses + 12*i, priors[i] (array or entries may be NULL), and writes results[i]; every result is bitwise
- * what mh_icp_align gives for that job alone.  Layers above 2048 points on plain maps run in LOCK STEP: each kernel of
- * an iteration is one launch over all jobs (the jobs' tails fill each other's idle lanes); the other chains are
+ * contexts), params[i] when params_per_job != 0 (else the one *params: N sequences have N adaptive thresholds, iteration
+ * budgets and hook check points), guesses + 12*i, priors[i] (array or entries may be NULL), and writes results[i]; every
+ * result is bitwise what mh_icp_align gives for that job alone.  Jobs that run the same kernel chain advance in LOCK
+ * STEP: each kernel of an iteration is one launch over all of them (the jobs' tails fill each other's idle lanes) --
+ * large layers (quad / tile matcher), 2-12 k-point layers (row matcher with the fused accumulation), layers up to 2 k
+ * points (row matcher + one-workgroup accumulate-and-solve, also with Matcher_Point2Plane on NDT maps); the rest is
  * interleaved, one stream per job.  With profile = 2, job 0's match_kernel_ms is its share of the lock-step match
  * launches.  Work still queued on the jobs' own streams (asynchronous uploads, de-skew, filters) is ordered before the
  * batch, whichever stream the batch runs on.
@@ -415,7 +418,7 @@ MH_API mh_status mh_icp_get_pt2pl_pairs(const mh_scan* scan, const mh_pairs_pl_o
  * context) waits for it, and so does the next batch before it overwrites the device-side staging. */
 MH_API size_t mh_pairs_block_bytes(size_t n_scan_points);
 MH_API mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_scan* const* scans,
-                                    const mh_icp_params* params, const double* T_guesses,
+                                    const mh_icp_params* params, int32_t params_per_job, const double* T_guesses,
                                     const mh_prior* const* priors, mh_icp_result* results, void* pairs_block,
                                     int32_t pairs_mem);
 

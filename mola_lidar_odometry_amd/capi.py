@@ -163,7 +163,8 @@ _SIGNATURES = {
     "mh_icp_align": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(ICPParamsC), _DP, C.POINTER(Prior),
                                  C.POINTER(ICPResult), C.POINTER(ICPIter), C.POINTER(PairsOut), C.c_int32]),
     "mh_icp_align_batch": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(ICPParamsC),
-                                       _DP, C.POINTER(C.POINTER(Prior)), C.POINTER(ICPResult), C.c_void_p, C.c_int32]),
+                                       C.c_int32, _DP, C.POINTER(C.POINTER(Prior)), C.POINTER(ICPResult), C.c_void_p,
+                                       C.c_int32]),
     "mh_pairs_block_bytes": (C.c_size_t, [C.c_size_t]),
 }
 
@@ -659,7 +660,15 @@ def icp_align_batch(maps, scans, T_guesses, p: ICPParams, priors=None, pairs_blo
     page-locked -- the download then completes asynchronously, see molahip.h) or a raw pointer (int) with pairs_mem."""
     n = len(scans)
     T = np.ascontiguousarray(np.stack([_T12(t) for t in T_guesses]).reshape(n * 12))
-    cp, keep = p.c(T[:12])
+    if isinstance(p, (list, tuple)):  # one ICPParams per job (its own schedules, budget, hook check point)
+        assert len(p) == n
+        made = [q.c(T[12 * i:12 * i + 12]) for i, q in enumerate(p)]
+        cp_arr = (ICPParamsC * n)(*[m[0] for m in made])
+        keep = [m[1] for m in made]
+        cp_ref, per_job = cp_arr, 1
+    else:
+        cp, keep = p.c(T[:12])
+        cp_ref, per_job = C.byref(cp), 0
     mh = (C.c_void_p * n)(*[m._h for m in maps])
     sh = (C.c_void_p * n)(*[s._h for s in scans])
     res = (ICPResult * n)()
@@ -674,7 +683,7 @@ def icp_align_batch(maps, scans, T_guesses, p: ICPParams, priors=None, pairs_blo
     pb = None
     if pairs_block is not None:
         pb = C.c_void_p(pairs_block if isinstance(pairs_block, int) else pairs_block.ctypes.data)
-    _chk(lib().mh_icp_align_batch(n, mh, sh, C.byref(cp), T.ctypes.data_as(_DP), pr_arr, res, pb, pairs_mem))
+    _chk(lib().mh_icp_align_batch(n, mh, sh, cp_ref, per_job, T.ctypes.data_as(_DP), pr_arr, res, pb, pairs_mem))
     return [_result_dict(r) for r in res]
 
 

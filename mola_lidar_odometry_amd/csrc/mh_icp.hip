@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -114,6 +115,10 @@ struct BatchJob {
   uint32_t* pair_gidx;
   double* part;
   // final pairings of the batch (mh_icp_align_batch's pairs_block), or null
+  double* partb;                 // point-to-plane partials (NDT chains) or null
+  float4 *pl_c, *pl_n;           // point-to-plane pairings or null
+  uint32_t* sched_dst;           // where this job keeps its threshold schedules (staged start-up copy) ...
+  uint32_t sched_dwords, stage_off;  // ... their size, and where this job's [state | params | schedules] start in the staging block
   // tile matcher: the scan in search order (mh_tile.hip)
   const float *sx, *sy, *sz;
   const uint32_t *perm, *tile_start;
@@ -1052,14 +1057,14 @@ __device__ __forceinline__ void one_group_sum(const double* vals, bool acc_lane,
 // PL: the layer also carries Matcher_Point2Plane pairings (pl_c.w != 0: centroid + normal of the paired voxel, written by
 // k_match16<true>) whose 29 generic rows are accumulated alongside and summed in two more passes of the same buffer.
 template <bool PL>
-__global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* __restrict__ st, uint32_t first,
-                                                                const MatchK* __restrict__ kp, const SolveK* __restrict__ sk,
-                                                                const float* __restrict__ lx, const float* __restrict__ ly,
-                                                                const float* __restrict__ lz, uint32_t n,
-                                                                const float4* __restrict__ pair_q,
-                                                                const uint32_t* __restrict__ pair_gidx,
-                                                                const float4* __restrict__ pl_c,
-                                                                const float4* __restrict__ pl_n) {
+__device__ __forceinline__ void k_accum_solve1_body(IcpDeviceState* __restrict__ st, uint32_t first,
+                                                    const MatchK* __restrict__ kp, const SolveK* __restrict__ sk,
+                                                    const float* __restrict__ lx, const float* __restrict__ ly,
+                                                    const float* __restrict__ lz, uint32_t n,
+                                                    const float4* __restrict__ pair_q,
+                                                    const uint32_t* __restrict__ pair_gidx,
+                                                    const float4* __restrict__ pl_c,
+                                                    const float4* __restrict__ pl_n) {
   __shared__ SolveShared sh;
   __shared__ double tr[kAccN][kOneGroupAccThreads + 1];
   __shared__ double p1[kAccN][kOneGroupGroups];
@@ -1134,6 +1139,23 @@ __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* 
   }
   MH_PHASE(3);
   solve_body(st, sk, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true, PL);
+}
+template <bool PL>
+__global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* __restrict__ st, uint32_t first,
+                                                                const MatchK* __restrict__ kp, const SolveK* __restrict__ sk,
+                                                                const float* __restrict__ lx, const float* __restrict__ ly,
+                                                                const float* __restrict__ lz, uint32_t n,
+                                                                const float4* __restrict__ pair_q,
+                                                                const uint32_t* __restrict__ pair_gidx,
+                                                                const float4* __restrict__ pl_c,
+                                                                const float4* __restrict__ pl_n) {
+  k_accum_solve1_body<PL>(st, first, kp, sk, lx, ly, lz, n, pair_q, pair_gidx, pl_c, pl_n);
+}
+// the one-workgroup chain in lock step: one workgroup per job (blockIdx.y)
+template <bool PL>
+__global__ __launch_bounds__(kSolveThreads) void k_accum_solve1_b(const BatchJob* __restrict__ jobs, uint32_t first) {
+  const BatchJob& j = jobs[blockIdx.y];
+  k_accum_solve1_body<PL>(j.st, first, j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.pair_q, j.pair_gidx, j.pl_c, j.pl_n);
 }
 
 // ================================================================================================
@@ -1225,11 +1247,11 @@ __global__ __launch_bounds__(kBlock) void k_cov_accum_pl(const IcpDeviceState* _
 }
 
 // covariance rows of the stored point-to-plane pairings (fused path)
-__global__ __launch_bounds__(kBlock) void k_cov_accum_plbuf(const IcpDeviceState* __restrict__ st,
-                                                            const float* __restrict__ lx, const float* __restrict__ ly,
-                                                            const float* __restrict__ lz, uint32_t n,
-                                                            const float4* __restrict__ pl_c, const float4* __restrict__ pl_n,
-                                                            double* __restrict__ partials, uint32_t pstride) {
+__device__ __forceinline__ void k_cov_accum_plbuf_body(const IcpDeviceState* __restrict__ st,
+                                                       const float* __restrict__ lx, const float* __restrict__ ly,
+                                                       const float* __restrict__ lz, uint32_t n,
+                                                       const float4* __restrict__ pl_c, const float4* __restrict__ pl_n,
+                                                       double* __restrict__ partials, uint32_t pstride) {
   __shared__ double sD[72];
   __shared__ BlockSum<kCovN> lds;
   if (!st->done || st->cov_done) return;
@@ -1259,6 +1281,13 @@ __global__ __launch_bounds__(kBlock) void k_cov_accum_plbuf(const IcpDeviceState
     v[21] = 1.0;
   }
   block_sum_rows<kCovN>(v, lds, partials, pstride, blockIdx.x);
+}
+__global__ __launch_bounds__(kBlock) void k_cov_accum_plbuf(const IcpDeviceState* __restrict__ st,
+                                                            const float* __restrict__ lx, const float* __restrict__ ly,
+                                                            const float* __restrict__ lz, uint32_t n,
+                                                            const float4* __restrict__ pl_c, const float4* __restrict__ pl_n,
+                                                            double* __restrict__ partials, uint32_t pstride) {
+  k_cov_accum_plbuf_body(st, lx, ly, lz, n, pl_c, pl_n, partials, pstride);
 }
 
 __device__ __forceinline__ void k_cov_finalize_body(IcpDeviceState* __restrict__ st, uint32_t force,
@@ -1391,7 +1420,12 @@ __global__ __launch_bounds__(kSolveThreads) void k_cov_finalize(IcpDeviceState* 
 }
 __global__ __launch_bounds__(kSolveThreads) void k_cov_finalize_b(const BatchJob* __restrict__ jobs) {
   const BatchJob& j = jobs[blockIdx.y];
-  k_cov_finalize_body(j.st, 0u, j.part, j.nb, j.nb, nullptr, 0u, 0u);
+  k_cov_finalize_body(j.st, 0u, j.part, j.nb, j.nb, j.partb, j.partb ? j.nb : 0u, j.partb ? j.nb : 0u);
+}
+__global__ __launch_bounds__(kBlock) void k_cov_accum_plbuf_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  if (blockIdx.x >= j.nb || !j.partb) return;
+  k_cov_accum_plbuf_body(j.st, j.lx, j.ly, j.lz, j.n, j.pl_c, j.pl_n, j.partb, j.nb);
 }
 template <bool PL, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_match16(const IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
@@ -1408,11 +1442,21 @@ __global__ __launch_bounds__(kBlock) void k_match16f_b(const BatchJob* __restric
   if (blockIdx.x >= j.nbm) return;
   k_match16_body<false, true>(j.st, j.mk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, nullptr, nullptr, j.part, j.nbm);
 }
-// start of a lock-step batch: the staged [state | params] blocks of all jobs -> where each job keeps its block
+// row kernel without the fused accumulation, one job per blockIdx.y: the small-layer chains in lock step (PL: the NDT
+// pipeline's two matchers in the one launch)
+template <bool PL>
+__global__ __launch_bounds__(kBlock) void k_match16_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  if (blockIdx.x >= (uint32_t)((16ull * j.n + kBlock - 1) / kBlock)) return;
+  k_match16_body<PL, false>(j.st, j.mk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, j.pl_c, j.pl_n, nullptr, 0u);
+}
+// start of a lock-step batch: the staged [state | params | schedules] of all jobs -> where each job keeps them
 __global__ void k_scatter_blocks(const BatchJob* __restrict__ jobs, const uint32_t* __restrict__ stage, uint32_t dwords) {
-  uint32_t* dst = reinterpret_cast<uint32_t*>(jobs[blockIdx.x].st);
-  const uint32_t* src = stage + (size_t)blockIdx.x * dwords;
+  const BatchJob& j = jobs[blockIdx.x];
+  uint32_t* dst = reinterpret_cast<uint32_t*>(j.st);
+  const uint32_t* src = stage + j.stage_off;
   for (uint32_t i = threadIdx.x; i < dwords; i += blockDim.x) dst[i] = src[i];
+  for (uint32_t i = threadIdx.x; i < j.sched_dwords; i += blockDim.x) j.sched_dst[i] = src[dwords + i];
 }
 // all jobs' state blocks into one contiguous buffer: one read-back per chunk instead of one per job
 __global__ void k_gather_states(const BatchJob* __restrict__ jobs, IcpDeviceState* __restrict__ out) {
@@ -2165,6 +2209,13 @@ void fill_batch_desc(const AlignJob& j, BatchJob& d) {
   d.pair_q = j.ctx->pair_q.as<float4>();
   d.pair_gidx = j.ctx->pair_gidx.as<uint32_t>();
   d.part = j.ctx->partials.as<double>();
+  if (j.pl) {
+    d.partb = j.ctx->partials_b.as<double>();
+    d.pl_c = j.ctx->pl_c.as<float4>();
+    d.pl_n = j.ctx->pl_n.as<float4>();
+  }
+  d.sched_dst = j.ctx->sched.as<uint32_t>();
+  d.sched_dwords = (uint32_t)(2 * j.nsched_pending);
   if (j.variant == 6) {
     d.sx = j.scan->sx; d.sy = j.scan->sy; d.sz = j.scan->sz;
     d.perm = j.scan->perm;
@@ -2263,84 +2314,130 @@ mh_status finish_pairs(mh_ctx* lead, const PairsPlan& pp, const BatchJob* dj, ui
 }  // namespace
 
 mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_scan* const* scans,
-                             const mh_icp_params* params, const double* T_guesses, const mh_prior* const* priors,
-                             mh_icp_result* results, void* pairs_block, int32_t pairs_mem) {
+                             const mh_icp_params* params, int32_t params_per_job, const double* T_guesses,
+                             const mh_prior* const* priors, mh_icp_result* results, void* pairs_block, int32_t pairs_mem) {
   MH_REQUIRE(n_jobs == 0 || (maps && scans && params && T_guesses && results), "null argument");
   MH_REQUIRE(!pairs_block || pairs_mem == MH_MEM_HOST || pairs_mem == MH_MEM_DEVICE || pairs_mem == MH_MEM_HOST_PINNED,
              "bad mem space");
   if (n_jobs == 0) return MH_OK;
+  auto P = [&](size_t i) { return params_per_job ? &params[i] : params; };
   std::vector<AlignJob> jobs(n_jobs);
   for (size_t i = 0; i < n_jobs; i++) {
-    MH_TRY(check_align_args(maps[i], scans[i], params, T_guesses + 12 * i, &results[i]));
+    MH_TRY(check_align_args(maps[i], scans[i], P(i), T_guesses + 12 * i, &results[i]));
     for (size_t j = 0; j < i; j++)
       MH_REQUIRE(scans[j]->ctx != scans[i]->ctx, "each job of a batch needs its own context");
     MH_REQUIRE(!pairs_block || scans[i]->ctx->device == scans[0]->ctx->device, "a pairs block needs all jobs on one device");
-    jobs[i].defer_upload = n_jobs >= 2;  // a lock-step batch uploads all jobs' blocks in one staged copy
-    MH_TRY(jobs[i].start(maps[i], scans[i], params, T_guesses + 12 * i, priors ? priors[i] : nullptr, &results[i],
+    jobs[i].defer_upload = n_jobs >= 2;  // a lock-step group uploads its jobs' blocks in one staged copy
+    MH_TRY(jobs[i].start(maps[i], scans[i], P(i), T_guesses + 12 * i, priors ? priors[i] : nullptr, &results[i],
                          nullptr, i));
   }
   mh_ctx* lead0 = scans[0]->ctx;
   PairsPlan pp;
   MH_TRY(set_device(lead0));
   MH_TRY(plan_pairs(lead0, jobs, pairs_block, pairs_mem, pp));
-  // Lock-step mode: every kernel of an iteration is ONE launch over all jobs (blockIdx.y = job).  The jobs' tails fill
-  // each other's idle lanes, which concurrent streams do not achieve (HIP maps them onto four hardware queues whose
-  // kernels mostly run one after the other).  Taken for the large-layer chain (quad matcher, point-to-point).
-  std::vector<AlignJob*> act;
-  std::vector<size_t> act_index;
-  for (size_t i = 0; i < n_jobs; i++)
-    if (!jobs[i].finished) {
-      act.push_back(&jobs[i]);
-      act_index.push_back(i);
-    }
-  bool lockstep = act.size() >= 2 && getenv("MH_NO_LOCKSTEP") == nullptr;
-  const bool row_chain = !act.empty() && act[0]->variant == 5;  // row kernel with the fused first accumulation
-  const bool tile_chain = !act.empty() && act[0]->variant == 6;
+  // Lock-step mode: every kernel of an iteration is ONE launch over all jobs of a group (blockIdx.y = job).  The jobs'
+  // tails fill each other's idle lanes, which concurrent streams do not achieve (HIP maps them onto four hardware queues
+  // whose kernels mostly run one after the other).  A group = the jobs that run the same kernel chain:
+  //   quad / tile matcher + k_accum + k_solve (large layers), row matcher with the fused first accumulation (2-12 k
+  //   points), row matcher + one-workgroup accumulate-and-solve (<= 2 k points: what lidar3d-default.yaml feeds), and the
+  //   same with Matcher_Point2Plane riding along (lidar3d-ndt.yaml);
+  // each job keeps its own parameters (iteration budget, schedules, hook check point, prior), state block, termination
+  // flag and iteration count.  Jobs whose chain has no lock-step form (or that are alone in their group) take the
+  // per-stream path below.
+  enum Kind { K_NONE = 0, K_QUAD, K_TILE, K_ROWF, K_ONE, K_ONE_PL };
+  const bool no_lockstep = getenv("MH_NO_LOCKSTEP") != nullptr;
   const bool no_one_group_env = getenv("MH_NO_ONE_GROUP") != nullptr;
-  for (AlignJob* j : act) {
-    const bool quad = j->variant == 4, row = j->variant == 5 && j->fused16 && (j->scan->n > kOneGroupMaxPoints || no_one_group_env);
-    lockstep = lockstep && (row_chain ? row : (tile_chain ? j->variant == 6 : quad)) && !j->pl && !j->trace &&
-               j->ctx->device == act[0]->ctx->device;
-  }
-  if (lockstep && tile_chain)
-    for (AlignJob* j : act) MH_TRY(scan_tiles_ready(j->scan));  // tile counts (the builds were queued by start())
-  if (lockstep) {
-    // MH_LOCKSTEP_GROUPS splits the jobs into groups that advance independently, each on its leader's stream, so that one
-    // group's match launch runs while the other is in its short accumulate / solve launches.  Measured on C2 with 32
-    // jobs: 1 group 3580-3610 scans/s, 2 groups 3680-3770, 4 groups 3090 -- overlapping match launches slow each other
-    // down (9.9 -> 16-17 us per scan), so the gain is small; the default stays at one group, whose kernel times are
-    // also the ones a (stream-serialising) profiler reports.
-    const bool want_prof = act[0]->prof;
-    for (AlignJob* j : act) j->prof = false;
-    uint32_t n_groups = 1;
-    if (const char* e = getenv("MH_LOCKSTEP_GROUPS")) n_groups = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : n_groups;
-    if (n_groups > act.size() / 2) n_groups = (uint32_t)(act.size() / 2) ? (uint32_t)(act.size() / 2) : 1u;
-    if (n_groups > 64) n_groups = 64;
-    if (pp.want) n_groups = 1;  // the pairs block is compacted by one launch over all jobs
-    struct Group {
-      std::vector<AlignJob*> jobs;
-      std::vector<size_t> index;
-      mh_ctx* lead = nullptr;
-      IcpDeviceState* h_states = nullptr;
-      const BatchJob* dj = nullptr;
-      uint32_t gx_match = 1, gx_acc = 1, gx_cov = 1, enq = 0, prof_n = 0;
-      bool done = false;
-    };
-    std::vector<Group> groups(n_groups);
-    for (size_t a = 0; a < act.size(); a++) {
-      groups[a * n_groups / act.size()].jobs.push_back(act[a]);
-      groups[a * n_groups / act.size()].index.push_back(act_index[a]);
+  auto kind_of = [&](const AlignJob& j) -> int {
+    if (j.finished || no_lockstep || j.trace || j.prof) return K_NONE;
+    const bool one_group = j.variant == 5 && j.scan->n <= kOneGroupMaxPoints && !no_one_group_env;
+    if (j.variant == 4 && !j.pl) return K_QUAD;
+    if (j.variant == 6 && !j.pl) return K_TILE;
+    if (j.variant == 5 && one_group) return j.pl ? K_ONE_PL : K_ONE;
+    if (j.variant == 5 && j.fused16 && !j.pl) return K_ROWF;
+    return K_NONE;
+  };
+  struct Group {
+    int kind = K_NONE;
+    std::vector<AlignJob*> jobs;
+    std::vector<size_t> index;
+    mh_ctx* lead = nullptr;
+    IcpDeviceState* h_states = nullptr;
+    const BatchJob* dj = nullptr;
+    uint32_t gx_match = 1, gx_acc = 1, gx_cov = 1, enq = 0, prof_n = 0, max_iterations = 0, inner = 1, chunk = 10;
+    bool cov = false, done = false;
+  };
+  std::vector<Group> groups;
+  const bool want_prof = !jobs.empty() && jobs[0].prof && !no_lockstep;  // profile == 2: the share of job 0's group
+  if (want_prof) jobs[0].prof = false;
+  for (size_t i = 0; i < n_jobs; i++) {
+    const int k = kind_of(jobs[i]);
+    if (k == K_NONE) continue;
+    const mh_icp_params* q = jobs[i].p;
+    Group* g = nullptr;
+    for (Group& c : groups)  // same chain, same device, same loop shape
+      if (c.kind == k && c.lead->device == jobs[i].ctx->device && c.inner == q->gn.max_inner_iterations &&
+          c.cov == (q->compute_covariance != 0))
+        g = &c;
+    if (!g) {
+      groups.emplace_back();
+      g = &groups.back();
+      g->kind = k;
+      g->lead = jobs[i].ctx;
+      g->inner = q->gn.max_inner_iterations;
+      g->cov = q->compute_covariance != 0;
+      g->chunk = q->poll_every ? q->poll_every : 10;
     }
-    MH_TRY(set_device(act[0]->ctx));
+    g->jobs.push_back(&jobs[i]);
+    g->index.push_back(i);
+    g->max_iterations = q->max_iterations > g->max_iterations ? q->max_iterations : g->max_iterations;
+  }
+  {  // a job alone in its group gains nothing from lock step; MH_LOCKSTEP_GROUPS splits the groups further (measured: two
+     // groups of the C2 batch overlap one's match launch with the other's short launches for +3 %; default off)
+    uint32_t split = 1;
+    if (const char* e = getenv("MH_LOCKSTEP_GROUPS")) split = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 1u;
+    std::vector<Group> kept;
+    for (Group& g : groups) {
+      if (g.jobs.size() < 2) continue;
+      uint32_t parts = split;
+      if (parts > g.jobs.size() / 2) parts = (uint32_t)(g.jobs.size() / 2);
+      if (parts < 1 || pp.want) parts = 1;  // (the pairs block is compacted by one launch over one group's jobs)
+      for (uint32_t part = 0; part < parts; part++) {
+        Group h = g;
+        h.jobs.clear();
+        h.index.clear();
+        for (size_t a = 0; a < g.jobs.size(); a++)
+          if (a * parts / g.jobs.size() == part) {
+            h.jobs.push_back(g.jobs[a]);
+            h.index.push_back(g.index[a]);
+          }
+        h.lead = h.jobs[0]->ctx;
+        kept.push_back(h);
+      }
+    }
+    groups.swap(kept);
+    if (groups.size() > 64) groups.resize(64);  // (their jobs fall through to the per-stream path)
+  }
+  std::vector<char> in_group(n_jobs, 0);
+  for (Group& g : groups)
+    for (size_t i : g.index) in_group[i] = 1;
+  if (want_prof && !in_group[0]) jobs[0].prof = true;  // job 0 goes the per-stream way: its own events
+  bool pairs_by_group = pp.want && groups.size() == 1 && groups[0].jobs.size() == (size_t)std::count_if(jobs.begin(), jobs.end(), [](const AlignJob& j) { return !j.finished; });
+
+  if (!groups.empty()) {
+    constexpr size_t kBlockBytes = kParamsOffset + sizeof(IcpDeviceParams);  // one job's [state | params] block
+    static_assert(kBlockBytes % 4 == 0 && sizeof(BatchJob) % 8 == 0, "staging layout");
     for (Group& g : groups) {
       const uint32_t A = (uint32_t)g.jobs.size();
-      mh_ctx* lead = g.lead = g.jobs[0]->ctx;
+      mh_ctx* lead = g.lead;
+      MH_TRY(set_device(lead));
       hipStream_t s = lead->stream;
+      if (g.kind == K_TILE)
+        for (AlignJob* j : g.jobs) MH_TRY(scan_tiles_ready(j->scan));  // tile counts (the builds were queued by start())
       MH_TRY(order_after_job_streams(lead, g.jobs));
-      constexpr size_t kBlockBytes = kParamsOffset + sizeof(IcpDeviceParams);  // one job's [state | params] block
-      static_assert(kBlockBytes % 4 == 0 && sizeof(BatchJob) % 8 == 0, "staging layout");
-      const size_t need = A * sizeof(IcpDeviceState) + A * sizeof(BatchJob) + A * kBlockBytes;
-      MH_TRY(lead->batch_desc.reserve(A * sizeof(BatchJob) + A * kBlockBytes));  // descriptors | staged blocks
+      size_t stage_bytes = 0;
+      for (AlignJob* j : g.jobs) stage_bytes += kBlockBytes + j->nsched_pending * sizeof(double);
+      const size_t need = A * sizeof(IcpDeviceState) + A * sizeof(BatchJob) + stage_bytes;
+      MH_TRY(lead->batch_desc.reserve(A * sizeof(BatchJob) + stage_bytes));  // descriptors | staged blocks
       MH_TRY(lead->batch_states.reserve(A * sizeof(IcpDeviceState)));
       if (lead->h_batch_cap < need) {
         if (lead->h_batch) (void)hipHostFree(lead->h_batch);
@@ -2352,33 +2449,33 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       g.h_states = reinterpret_cast<IcpDeviceState*>(lead->h_batch);
       BatchJob* h_desc = reinterpret_cast<BatchJob*>(reinterpret_cast<char*>(lead->h_batch) + A * sizeof(IcpDeviceState));
       char* h_stage = reinterpret_cast<char*>(h_desc) + A * sizeof(BatchJob);
-      // the schedules are the same for every job of the batch (shared params): one copy, into the leader's buffer
-      AlignJob& j0 = *g.jobs[0];
-      MH_HIP(hipMemcpyAsync(lead->sched.p, lead->h_sched, j0.nsched_pending * sizeof(double), hipMemcpyHostToDevice, s));
-      const size_t mi = params->max_iterations;
+      size_t off = 0;
       for (uint32_t a = 0; a < A; a++) {
         AlignJob& j = *g.jobs[a];
         BatchJob& d = h_desc[a];
         fill_batch_desc(j, d);
-        set_pairs_fields(pp, g.index[a], d);
-        const uint32_t bm = row_chain ? d.nbm : (tile_chain ? d.n_tiles : (uint32_t)((4ull * d.n + kBlock - 1) / kBlock));
+        if (pairs_by_group) set_pairs_fields(pp, g.index[a], d);
+        d.stage_off = (uint32_t)(off / 4);
+        uint32_t bm = (uint32_t)((4ull * d.n + kBlock - 1) / kBlock);  // quad
+        if (g.kind == K_ROWF) bm = d.nbm;
+        if (g.kind == K_TILE) bm = d.n_tiles;
+        if (g.kind == K_ONE || g.kind == K_ONE_PL) bm = (uint32_t)((16ull * d.n + kBlock - 1) / kBlock);
         g.gx_match = bm > g.gx_match ? bm : g.gx_match;
         g.gx_acc = d.nba > g.gx_acc ? d.nba : g.gx_acc;
         g.gx_cov = d.nb > g.gx_cov ? d.nb : g.gx_cov;
-        // this job's [state | params] mirror, its schedule pointers redirected to the leader's copy, into the staging area
-        j.ctx->h_params->mk.thr = j.ctx->h_params->sk.thr = lead->sched.as<double>();
-        j.ctx->h_params->mk.kparam = j.ctx->h_params->sk.kparam = lead->sched.as<double>() + mi;
-        memcpy(h_stage + a * kBlockBytes, j.ctx->h_state, kBlockBytes);
+        // this job's [state | params] mirror and its schedules into the staging area
+        memcpy(h_stage + off, j.ctx->h_state, kBlockBytes);
+        memcpy(h_stage + off + kBlockBytes, j.ctx->h_sched, j.nsched_pending * sizeof(double));
+        off += kBlockBytes + j.nsched_pending * sizeof(double);
         j.defer_upload = false;
       }
       // descriptors and staged blocks in ONE copy, then a scatter kernel writes every job's block where it lives
-      MH_HIP(hipMemcpyAsync(lead->batch_desc.p, h_desc, A * sizeof(BatchJob) + A * kBlockBytes, hipMemcpyHostToDevice, s));
+      MH_HIP(hipMemcpyAsync(lead->batch_desc.p, h_desc, A * sizeof(BatchJob) + stage_bytes, hipMemcpyHostToDevice, s));
       g.dj = lead->batch_desc.as<BatchJob>();
       hipLaunchKernelGGL(k_scatter_blocks, dim3(A), dim3(256), 0, s, g.dj,
                          reinterpret_cast<const uint32_t*>(lead->batch_desc.as<char>() + A * sizeof(BatchJob)),
                          (uint32_t)(kBlockBytes / 4));
     }
-    const uint32_t chunk = params->poll_every ? params->poll_every : 10;
     for (;;) {
       bool any = false;
       uint32_t m_of[64] = {0};
@@ -2388,7 +2485,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         Group& g = groups[gi];
         if (g.done) continue;
         any = true;
-        m_of[gi] = (params->max_iterations - g.enq) < chunk ? (params->max_iterations - g.enq) : chunk;
+        m_of[gi] = (g.max_iterations - g.enq) < g.chunk ? (g.max_iterations - g.enq) : g.chunk;
         m_max = m_of[gi] > m_max ? m_of[gi] : m_max;
       }
       if (!any) break;
@@ -2398,21 +2495,31 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
           if (g.done || it >= m_of[gi]) continue;
           hipStream_t s = g.lead->stream;
           const uint32_t A = (uint32_t)g.jobs.size();
-          const bool pr = want_prof && gi == 0;
+          const bool pr = want_prof && gi == 0 && g.jobs[0] == &jobs[0];
           if (pr) MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n], s));
-          if (row_chain)
-            hipLaunchKernelGGL(k_match16f_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj);
-          else if (tile_chain)
-            hipLaunchKernelGGL(k_match_tile_b, dim3(g.gx_match, A), dim3(kTileThreads), 0, s, g.dj);
-          else
-            hipLaunchKernelGGL(k_match4_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj);
+          switch (g.kind) {
+            case K_ROWF: hipLaunchKernelGGL(k_match16f_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
+            case K_TILE: hipLaunchKernelGGL(k_match_tile_b, dim3(g.gx_match, A), dim3(kTileThreads), 0, s, g.dj); break;
+            case K_ONE: hipLaunchKernelGGL(k_match16_b<false>, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
+            case K_ONE_PL: hipLaunchKernelGGL(k_match16_b<true>, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
+            default: hipLaunchKernelGGL(k_match4_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
+          }
           if (pr) {
             MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n + 1], s));
             g.prof_n++;
           }
-          if (!row_chain) hipLaunchKernelGGL(k_accum_b, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 1u);
+          if (g.kind == K_ONE || g.kind == K_ONE_PL) {
+            for (uint32_t in = 0; in < g.inner; in++) {
+              if (g.kind == K_ONE_PL)
+                hipLaunchKernelGGL(k_accum_solve1_b<true>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, in == 0 ? 1u : 0u);
+              else
+                hipLaunchKernelGGL(k_accum_solve1_b<false>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, in == 0 ? 1u : 0u);
+            }
+            continue;
+          }
+          if (g.kind != K_ROWF) hipLaunchKernelGGL(k_accum_b, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 1u);
           hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, 1u);
-          for (uint32_t in = 1; in < params->gn.max_inner_iterations; in++) {
+          for (uint32_t in = 1; in < g.inner; in++) {
             hipLaunchKernelGGL(k_accum_b, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 0u);
             hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, 0u);
           }
@@ -2422,9 +2529,10 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         if (g.done) continue;
         hipStream_t s = g.lead->stream;
         const uint32_t A = (uint32_t)g.jobs.size();
-        if (params->compute_covariance) {  // no-ops for jobs whose loop has not terminated
+        if (g.cov) {  // no-ops for jobs whose loop has not terminated
           hipLaunchKernelGGL(k_cov_prepare_b, dim3(1, A), dim3(64), 0, s, g.dj);
           hipLaunchKernelGGL(k_cov_accum_b, dim3(g.gx_cov, A), dim3(kBlock), 0, s, g.dj);
+          if (g.kind == K_ONE_PL) hipLaunchKernelGGL(k_cov_accum_plbuf_b, dim3(g.gx_cov, A), dim3(kBlock), 0, s, g.dj);
           hipLaunchKernelGGL(k_cov_finalize_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj);
         }
         hipLaunchKernelGGL(k_gather_states, dim3(A), dim3(256), 0, s, g.dj, g.lead->batch_states.as<IcpDeviceState>());
@@ -2441,43 +2549,52 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
           AlignJob& j = *g.jobs[a];
           if (j.finished) continue;
           memcpy(j.ctx->h_state, &g.h_states[a], sizeof(IcpDeviceState));
-          j.enqueued = g.enq;
+          j.enqueued = g.enq < j.p->max_iterations ? g.enq : j.p->max_iterations;
           MH_TRY(j.poll(true));
           g.done = g.done && j.finished;
         }
       }
     }
-    if (want_prof) {  // the match step of job 0 = its share of its group's lock-step launches
+    if (want_prof && groups[0].jobs[0] == &jobs[0]) {  // the match step of job 0 = its share of its group's lock-step launches
       Group& g = groups[0];
       float ms = 0.f;
       double sum = 0.0;
-      const mh_icp_result* r0 = act[0]->res;
+      const mh_icp_result* r0 = jobs[0].res;
       uint32_t live = r0->n_iterations + ((r0->termination_reason == MH_TERM_MAX_ITERATIONS) ? 0u : 1u);
       if (live > g.prof_n) live = g.prof_n;
       for (uint32_t i = 0; i < live; i++) {
         MH_HIP(hipEventElapsedTime(&ms, g.lead->prof_ev[2 * i], g.lead->prof_ev[2 * i + 1]));
         sum += ms;
       }
-      act[0]->res->n_match_launches = live;
-      act[0]->res->match_kernel_ms = sum / (double)g.jobs.size();
-      act[0]->res->total_ms = 0.0;
+      jobs[0].res->n_match_launches = live;
+      jobs[0].res->match_kernel_ms = sum / (double)g.jobs.size();
+      jobs[0].res->total_ms = 0.0;
     }
-    if (pp.want) MH_TRY(finish_pairs(groups[0].lead, pp, groups[0].dj, (uint32_t)groups[0].jobs.size(), groups[0].gx_cov));
-    return MH_OK;
+    if (pairs_by_group) {
+      MH_TRY(finish_pairs(groups[0].lead, pp, groups[0].dj, (uint32_t)groups[0].jobs.size(), groups[0].gx_cov));
+      return MH_OK;
+    }
   }
-  for (auto& j : jobs) MH_TRY(j.flush_deferred());
+  // everything that is not in a lock-step group: one stream per job, chunks enqueued round robin
+  for (size_t i = 0; i < n_jobs; i++)
+    if (!in_group[i]) MH_TRY(jobs[i].flush_deferred());
   for (;;) {
     bool any = false;
-    for (auto& j : jobs)
-      if (!j.finished) {
-        MH_TRY(j.enqueue_chunk());
+    for (size_t i = 0; i < n_jobs; i++)
+      if (!in_group[i] && !jobs[i].finished) {
+        MH_TRY(jobs[i].enqueue_chunk());
         any = true;
       }
     if (!any) break;
-    for (auto& j : jobs) MH_TRY(j.poll());
+    for (size_t i = 0; i < n_jobs; i++)
+      if (!in_group[i]) MH_TRY(jobs[i].poll());
   }
-  if (pp.want && !act.empty()) {
+  if (pp.want) {
     // every job has terminated and its stream is drained: one compaction launch over all of them on the first job's stream
+    std::vector<size_t> act;
+    for (size_t i = 0; i < n_jobs; i++)
+      if (!jobs[i].trivial) act.push_back(i);
+    if (act.empty()) return MH_OK;
     mh_ctx* lead = lead0;
     MH_TRY(set_device(lead));
     const uint32_t A = (uint32_t)act.size();
@@ -2492,8 +2609,8 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
     BatchJob* h_desc = reinterpret_cast<BatchJob*>(lead->h_batch);
     uint32_t gx_cov = 1;
     for (uint32_t a = 0; a < A; a++) {
-      fill_batch_desc(*act[a], h_desc[a]);
-      set_pairs_fields(pp, act_index[a], h_desc[a]);
+      fill_batch_desc(jobs[act[a]], h_desc[a]);
+      set_pairs_fields(pp, act[a], h_desc[a]);
       gx_cov = h_desc[a].nb > gx_cov ? h_desc[a].nb : gx_cov;
     }
     MH_HIP(hipMemcpyAsync(lead->batch_desc.p, h_desc, A * sizeof(BatchJob), hipMemcpyHostToDevice, lead->stream));

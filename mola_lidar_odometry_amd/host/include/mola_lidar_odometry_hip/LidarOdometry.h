@@ -154,6 +154,9 @@ class LidarOdometry {
   // The buffers must stay valid until that call.  Results are identical to the sequential flow: the first pass only
   // depends on the sensor-range estimate, which is final before ICP starts; if any filter parameter turns out
   // different when the scan is really due, the prepared layers are dropped and the pass runs again.
+  // several sequences in one process: the ICP of this instance joins the others' in one lock-step batch per round
+  // (mp2p_icp_hip::AlignBatcher); call after initialize(), drive every instance from its own host thread
+  void setAlignBatcher(std::shared_ptr<mp2p_icp_hip::AlignBatcher> b);
   void prefetchInterleaved(const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
                            long long off_t = -1, const float* t = nullptr);
   void prefetch(const float* x, const float* y, const float* z, const float* t, size_t n);

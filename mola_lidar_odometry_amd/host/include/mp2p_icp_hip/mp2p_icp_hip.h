@@ -22,7 +22,9 @@
 // Nothing here computes on the CPU: every numeric step is a call into libmolahip.
 #pragma once
 #include <cstdint>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <map>
 #include <memory>
 #include <optional>
@@ -359,6 +361,44 @@ class QualityEvaluator_PairedRatio {
   }
 };
 
+// ---------------------------------------------------------------- several sequences on one GPU, one process
+// N sequences = N LidarOdometry instances = N independent align() streams (eval/cli_kitti.sh:23-36 runs them as N
+// processes).  One alignment of a decimated scan is a chain of short dependent kernels that leaves the device mostly
+// idle, so the instances' alignments are merged: every instance runs on its own host thread, and where it would call
+// mh_icp_align it hands its request to the batcher and blocks; when ALL active participants are waiting, the last one
+// to arrive runs ONE mh_icp_align_batch over the requests (per-job parameters: every sequence has its own adaptive
+// threshold, iteration budget, hook check point; jobs with the same kernel chain advance in lock step) and wakes the
+// others.  Results are bitwise those of separate alignments, so every sequence's records are those of a solo run.
+class AlignBatcher {
+ public:
+  explicit AlignBatcher(size_t participants);
+  // blocks until the batch this request joined has run; returns its status (the message in `error` when not MH_OK)
+  mh_status align(const mh_map* map, const mh_scan* scan, const mh_icp_params* params, const double T_guess[12],
+                  const mh_prior* prior, mh_icp_result* result, std::string* error);
+  void leave();  // this participant will not align any more (end of its sequence, or it failed)
+  size_t batches() const { return n_batches_; }
+  size_t jobs() const { return n_jobs_; }
+
+ private:
+  struct Request {
+    const mh_map* map = nullptr;
+    const mh_scan* scan = nullptr;
+    const mh_icp_params* params = nullptr;
+    const double* T = nullptr;
+    const mh_prior* prior = nullptr;
+    mh_icp_result* result = nullptr;
+    mh_status status = MH_OK;
+    std::string error;
+    bool done = false;
+  };
+  void run_batch_locked();
+  std::mutex mtx_;
+  std::condition_variable cv_;
+  std::vector<Request*> waiting_;
+  size_t active_;
+  size_t n_batches_ = 0, n_jobs_ = 0;
+};
+
 // ---------------------------------------------------------------- ICP
 class ICP {
  public:
@@ -387,6 +427,8 @@ class ICP {
   // poses and a requested stop is reproduced by a second run with that budget (molahip_host/hook_replay.h: what the
   // mp2p_icp adapter does, because it only ever sees an opaque std::function)
   void setHookReplay(bool v) { hook_replay_ = v; }
+  // fused alignments (without trace / final pairings / host hook) go through the batcher instead of mh_icp_align
+  void setAlignBatcher(std::shared_ptr<AlignBatcher> b) { batcher_ = std::move(b); }
   // the in-tree hook (LidarOdometry.cpp:923-952) as data: evaluated on the device inside the fused loop
   void setDeviceHook(double min_trans, double min_rot_rad, const CPose3D& checkpoint);
   void clearHooks();
@@ -422,6 +464,7 @@ class ICP {
   ParameterSource own_source_;
   mh_scan* scan_ = nullptr;
   bool last_fused_ = false, force_generic_ = false, keep_pairings_ = true, hook_replay_ = false;
+  std::shared_ptr<AlignBatcher> batcher_;
 };
 
 // class factory by name (mrpt::rtti::classFactory stand-in): "mp2p_icp::X" and "mp2p_icp_hip::X" both resolve

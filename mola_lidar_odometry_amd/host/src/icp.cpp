@@ -546,6 +546,68 @@ bool ICP::can_fuse() const {
   return true;
 }
 
+// ---------------------------------------------------------------- AlignBatcher
+AlignBatcher::AlignBatcher(size_t participants) : active_(participants) {}
+
+void AlignBatcher::run_batch_locked() {
+  // every active participant is blocked in align(): one batch over their requests (the caller holds the mutex; the
+  // others only wait on the condition variable, so the device work is issued by this thread alone)
+  std::vector<Request*> batch;
+  batch.swap(waiting_);
+  const size_t n = batch.size();
+  std::vector<const mh_map*> maps(n);
+  std::vector<const mh_scan*> scans(n);
+  std::vector<mh_icp_params> params(n);
+  std::vector<double> T(12 * n);
+  std::vector<const mh_prior*> priors(n);
+  std::vector<mh_icp_result> results(n);
+  bool any_prior = false;
+  for (size_t i = 0; i < n; i++) {
+    maps[i] = batch[i]->map;
+    scans[i] = batch[i]->scan;
+    params[i] = *batch[i]->params;
+    memcpy(&T[12 * i], batch[i]->T, 12 * sizeof(double));
+    priors[i] = batch[i]->prior;
+    any_prior = any_prior || batch[i]->prior;
+  }
+  mh_status st = MH_OK;
+  std::string err;
+  if (n == 1) {
+    st = mh_icp_align(maps[0], scans[0], &params[0], &T[0], priors[0], &results[0], nullptr, nullptr, MH_MEM_HOST);
+  } else {
+    st = mh_icp_align_batch(n, maps.data(), scans.data(), params.data(), 1, T.data(), any_prior ? priors.data() : nullptr,
+                            results.data(), nullptr, MH_MEM_HOST);
+  }
+  if (st != MH_OK) err = mh_last_error_string();  // (thread-local in the library: read it on the thread that made the call)
+  n_batches_++;
+  n_jobs_ += n;
+  for (size_t i = 0; i < n; i++) {
+    *batch[i]->result = results[i];
+    batch[i]->status = st;
+    batch[i]->error = err;
+    batch[i]->done = true;
+  }
+  cv_.notify_all();
+}
+
+mh_status AlignBatcher::align(const mh_map* map, const mh_scan* scan, const mh_icp_params* params, const double T_guess[12],
+                              const mh_prior* prior, mh_icp_result* result, std::string* error) {
+  Request rq;
+  rq.map = map; rq.scan = scan; rq.params = params; rq.T = T_guess; rq.prior = prior; rq.result = result;
+  std::unique_lock<std::mutex> lk(mtx_);
+  waiting_.push_back(&rq);
+  if (waiting_.size() >= active_) run_batch_locked();
+  else cv_.wait(lk, [&] { return rq.done; });
+  if (error) *error = rq.error;
+  return rq.status;
+}
+
+void AlignBatcher::leave() {
+  std::unique_lock<std::mutex> lk(mtx_);
+  if (active_ > 0) active_--;
+  if (!waiting_.empty() && waiting_.size() >= active_) run_batch_locked();  // the others were only waiting for this one
+}
+
 void ICP::align(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const TPose3D& guess, const Parameters& p,
                 Results& result, const std::optional<CPose3DPDFGaussianInf>& prior) {
   result = Results();
@@ -692,6 +754,11 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
       return iteration_hook_(in).request_stop;
     };
     r = molahip_host::align_with_replayed_hook(p.maxIterations, run, hook);
+  } else if (batcher_ && trace.empty() && !want_pairs) {
+    // several sequences in one process: this alignment joins the others' (AlignBatcher)
+    std::string err;
+    const mh_status st = batcher_->align(global.handle(), scan, &ip, guess.T, prior ? &pr : nullptr, &r, &err);
+    if (st != MH_OK) throw std::runtime_error(std::string("mh_icp_align_batch: ") + mh_status_string(st) + ": " + err);
   } else {
     check(mh_icp_align(global.handle(), scan, &ip, guess.T, prior ? &pr : nullptr, &r, trace.empty() ? nullptr : trace.data(),
                        want_pairs ? &po : nullptr, MH_MEM_HOST), "mh_icp_align");

@@ -459,6 +459,11 @@ void LidarOdometry::run_first_pass() {
   check(mh_scan_preprocess(raw_->handle(), &pp, map_skewed_->handle(), icp_skewed_->handle()), "mh_scan_preprocess");
 }
 
+void LidarOdometry::setAlignBatcher(std::shared_ptr<mp2p_icp_hip::AlignBatcher> b) {
+  for (auto& i : icp_)
+    if (i) i->setAlignBatcher(b);
+}
+
 // ---- the announced next observation: upload + first pass on a second stream while this scan is in its ICP loop
 void LidarOdometry::prefetch(const float* x, const float* y, const float* z, const float* t, size_t n) {
   pf_->req = RawInput();  // (a prepared scan that is still waiting to be picked up stays untouched)

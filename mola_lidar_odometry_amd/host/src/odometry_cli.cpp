@@ -7,6 +7,8 @@
 //
 //   molahip-lo-cli --pipeline pipelines/lidar3d-default-hip.yaml --seq-dir /data/kitti/sequences/00 --out 00.tum
 //                  [--device 0] [--no-prefetch] [--max-scans N]
+// Several --seq-dir run together on the one GPU (what eval/cli_kitti.sh:23 does with GNU parallel -j3, as processes):
+// a host thread per sequence, their alignments merged into lock-step batches (mp2p_icp_hip::AlignBatcher).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -14,7 +16,9 @@
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <dirent.h>
@@ -53,38 +57,18 @@ std::vector<float> read_bin(const std::string& path) {
   return v;
 }
 
-}  // namespace
+struct SequenceReport {
+  std::string seq_dir, out;
+  size_t scans = 0, good = 0, keyframes = 0, iterations = 0;
+  double seconds = 0;
+  std::string error;
+};
 
-int main(int argc, char** argv) {
-  std::string pipeline, seq_dir, out = "trajectory.tum";
-  int device = 0;
-  long max_scans = -1;
-  bool prefetch = true;
-  for (int i = 1; i < argc; i++) {
-    const std::string a = argv[i];
-    auto val = [&](const char* name) -> std::string {
-      if (i + 1 >= argc) throw std::runtime_error(std::string("missing value for ") + name);
-      return argv[++i];
-    };
-    try {
-      if (a == "--pipeline") pipeline = val("--pipeline");
-      else if (a == "--seq-dir") seq_dir = val("--seq-dir");
-      else if (a == "--out") out = val("--out");
-      else if (a == "--device") device = atoi(val("--device").c_str());
-      else if (a == "--max-scans") max_scans = atol(val("--max-scans").c_str());
-      else if (a == "--no-prefetch") prefetch = false;
-      else throw std::runtime_error("unknown argument " + a);
-    } catch (const std::exception& e) {
-      fprintf(stderr, "%s\nusage: molahip-lo-cli --pipeline FILE.yaml --seq-dir DIR --out FILE.tum [--device N] "
-                      "[--no-prefetch] [--max-scans N]\n", e.what());
-      return 2;
-    }
-  }
-  if (pipeline.empty() || seq_dir.empty()) {
-    fprintf(stderr, "usage: molahip-lo-cli --pipeline FILE.yaml --seq-dir DIR --out FILE.tum [--device N] [--no-prefetch] "
-                    "[--max-scans N]\n");
-    return 2;
-  }
+// one sequence, start to end; with a batcher its alignments join those of the other sequences of the process
+void run_sequence(const std::string& pipeline, const std::string& seq_dir, const std::string& out, int device, long max_scans,
+                  bool prefetch, std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher, SequenceReport& rep) {
+  rep.seq_dir = seq_dir;
+  rep.out = out;
   try {
     std::vector<std::string> files = list_bins(seq_dir + "/velodyne");
     if (max_scans >= 0 && (size_t)max_scans < files.size()) files.resize((size_t)max_scans);
@@ -98,34 +82,98 @@ int main(int argc, char** argv) {
 
     mola_hip::LidarOdometry lo(std::make_shared<mp2p_icp_hip::DeviceContext>(device));
     lo.initialize(mp2p_icp_hip::Config::FromYamlFile(pipeline));
+    if (batcher) lo.setAlignBatcher(batcher);
 
     std::vector<float> cur, nxt;  // both stay alive while the driver may still read them
     if (!files.empty()) cur = read_bin(files[0]);
-    size_t good = 0, keyframes = 0, iterations = 0;
-    double seconds = 0;
     for (size_t k = 0; k < files.size(); k++) {
       const bool has_next = k + 1 < files.size();
       if (has_next) nxt = read_bin(files[k + 1]);  // (file reading is not part of the registration time)
       const auto t0 = std::chrono::steady_clock::now();
       if (has_next && prefetch) lo.prefetchInterleaved(nxt.data(), nxt.size() / 4, 16, 0, 4, 8);
       const auto& rec = lo.onLidarInterleaved(stamps[k], cur.data(), cur.size() / 4, 16, 0, 4, 8);
-      seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      good += rec.icp_good ? 1 : 0;
-      keyframes += rec.map_updated ? 1 : 0;
-      iterations += rec.icp_iterations;
+      rep.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      rep.good += rec.icp_good ? 1 : 0;
+      rep.keyframes += rec.map_updated ? 1 : 0;
+      rep.iterations += rec.icp_iterations;
+      rep.scans++;
       if (has_next) {
         // the announced buffer must keep its address until it has been registered: swap contents, not storage roles
         cur.swap(nxt);
       }
     }
     lo.saveTrajectoryTUM(out);
+  } catch (const std::exception& e) {
+    rep.error = e.what();
+  }
+  if (batcher) batcher->leave();  // the others must not wait for this sequence any more (also after a failure)
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::string pipeline, out = "trajectory.tum";
+  std::vector<std::string> seq_dirs;
+  int device = 0;
+  long max_scans = -1;
+  bool prefetch = true;
+  const char* usage = "usage: molahip-lo-cli --pipeline FILE.yaml --seq-dir DIR [--seq-dir DIR ...] --out FILE.tum [--device N] "
+                      "[--no-prefetch] [--max-scans N]\n"
+                      "  several --seq-dir: the sequences run together on the one GPU, one host thread each, their alignments\n"
+                      "  merged into lock-step batches; trajectories go to FILE_<k>.tum\n";
+  for (int i = 1; i < argc; i++) {
+    const std::string a = argv[i];
+    auto val = [&](const char* name) -> std::string {
+      if (i + 1 >= argc) throw std::runtime_error(std::string("missing value for ") + name);
+      return argv[++i];
+    };
+    try {
+      if (a == "--pipeline") pipeline = val("--pipeline");
+      else if (a == "--seq-dir") seq_dirs.push_back(val("--seq-dir"));
+      else if (a == "--out") out = val("--out");
+      else if (a == "--device") device = atoi(val("--device").c_str());
+      else if (a == "--max-scans") max_scans = atol(val("--max-scans").c_str());
+      else if (a == "--no-prefetch") prefetch = false;
+      else throw std::runtime_error("unknown argument " + a);
+    } catch (const std::exception& e) {
+      fprintf(stderr, "%s\n%s", e.what(), usage);
+      return 2;
+    }
+  }
+  if (pipeline.empty() || seq_dirs.empty()) {
+    fprintf(stderr, "%s", usage);
+    return 2;
+  }
+  const size_t N = seq_dirs.size();
+  std::vector<SequenceReport> reps(N);
+  const auto t0 = std::chrono::steady_clock::now();
+  if (N == 1) {
+    run_sequence(pipeline, seq_dirs[0], out, device, max_scans, prefetch, nullptr, reps[0]);
+  } else {
+    auto batcher = std::make_shared<mp2p_icp_hip::AlignBatcher>(N);
+    std::vector<std::thread> th;
+    const std::string stem = out.size() > 4 && out.compare(out.size() - 4, 4, ".tum") == 0 ? out.substr(0, out.size() - 4) : out;
+    for (size_t k = 0; k < N; k++)
+      th.emplace_back(run_sequence, pipeline, seq_dirs[k], stem + "_" + std::to_string(k) + ".tum", device, max_scans, prefetch,
+                      batcher, std::ref(reps[k]));
+    for (auto& t : th) t.join();
+  }
+  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  int rc = 0;
+  size_t total = 0;
+  for (const auto& r : reps) {
+    if (!r.error.empty()) {
+      fprintf(stderr, "molahip-lo-cli: %s: %s\n", r.seq_dir.c_str(), r.error.c_str());
+      rc = 1;
+    }
+    total += r.scans;
     printf("{\"sequence_dir\": \"%s\", \"scans\": %zu, \"good\": %zu, \"keyframes\": %zu, \"icp_iterations\": %zu, "
            "\"seconds\": %.6f, \"scans_per_s\": %.3f, \"tum\": \"%s\"}\n",
-           seq_dir.c_str(), files.size(), good, keyframes, iterations, seconds, seconds > 0 ? files.size() / seconds : 0.0,
-           out.c_str());
-  } catch (const std::exception& e) {
-    fprintf(stderr, "molahip-lo-cli: %s\n", e.what());
-    return 1;
+           r.seq_dir.c_str(), r.scans, r.good, r.keyframes, r.iterations, r.seconds, r.seconds > 0 ? r.scans / r.seconds : 0.0,
+           r.out.c_str());
   }
-  return 0;
+  if (N > 1)
+    printf("{\"sequences\": %zu, \"scans\": %zu, \"wall_seconds\": %.6f, \"scans_per_s\": %.3f}\n", N, total, wall,
+           wall > 0 ? total / wall : 0.0);
+  return rc;
 }

@@ -161,6 +161,7 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
         return rec2dict(*rec); },
            py::arg("timestamp"), py::arg("xyz"), py::arg("t") = std::nullopt,
            py::arg("xyz_fields") = std::array<int, 3>{0, 1, 2}, py::arg("t_field") = -1)
+      .def("setAlignBatcher", &LidarOdometry::setAlignBatcher)
       .def("prefetch", [](py::object self, py::array xyz_any, std::optional<py::array> t_any,
                           std::array<int, 3> xyz_fields, int t_field) {
         // announce the NEXT scan (same arguments as the onLidar call that will follow): upload + first filter pass run
@@ -206,5 +207,10 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
       .def("describePipeline", &LidarOdometry::describePipeline)
       .def("profile", [](const LidarOdometry& lo) { return lo.profile(); })
       .def("localMapSize", [](const LidarOdometry& lo) { return lo.localMap() ? lo.localMap()->size() : 0; });
+  py::class_<AlignBatcher, std::shared_ptr<AlignBatcher>>(m, "AlignBatcher")
+      .def(py::init<size_t>(), py::arg("participants"))
+      .def("leave", &AlignBatcher::leave, py::call_guard<py::gil_scoped_release>())
+      .def("batches", &AlignBatcher::batches)
+      .def("jobs", &AlignBatcher::jobs);
   m.def("icp_pipeline_from_yaml", [](const Config& c) { auto t = icp_pipeline_from_yaml(c); return py::make_tuple(std::get<0>(t), std::get<1>(t)); });
 }

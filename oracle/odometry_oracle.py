@@ -78,6 +78,11 @@ def _bbox_radius(xyz):
     return float(max(a, b))
 
 
+# Solver_GaussNewton.robustKernel (lidar3d-default.yaml:188); the forms beyond GemanMcClure are SURVEY App. B U1's candidates
+_KERNELS = {"None": oc.KERNEL_NONE, "GemanMcClure": oc.KERNEL_GM_C4, "GemanMcClure_KISS": oc.KERNEL_GM_KISS,
+            "GemanMcClure_Barron": oc.KERNEL_GM_BARRON, "Cauchy": oc.KERNEL_CAUCHY, "GemanMcClure_C2": oc.KERNEL_GM_C2}
+
+
 class OdometryOracle:
     def __init__(self, pipeline_yaml_path, n_threads=8):
         c = load_pipeline(pipeline_yaml_path)
@@ -278,7 +283,7 @@ class OdometryOracle:
                                  min_abs_step_rot=float(ip["minAbsStep_rot"]), threshold=thr, kernel_param=kp,
                                  pt2pl_threshold=pl, threshold_angular_deg=0.0,
                                  gn=oc.GNParams(max_inner_iterations=int(self.solver["maxIterations"]),
-                                                robust_kernel=oc.KERNEL_GM_C4),
+                                                robust_kernel=_KERNELS[str(self.solver.get("robustKernel", "GemanMcClure")).split("::")[-1]]),
                                  hook_enabled=opt_twist, hook_min_trans=float(P["optimize_twist_rerun_min_trans"]),
                                  hook_min_rot=math.radians(float(P["optimize_twist_rerun_min_rot_deg"])),
                                  hook_checkpoint=T0)

@@ -517,6 +517,56 @@ def test_lockstep_batch_of_row_kernel_layers(ctx, monkeypatch):
         c.close()
 
 
+def test_lockstep_small_chains_with_per_job_parameters(ctx, monkeypatch):
+    """What N sequences on one GPU hand to one mh_icp_align_batch: layers of ~1-3 k points, every job with ITS OWN
+    parameters (adaptive-threshold schedule, remaining iteration budget, hook check point, prior) and its own map.  Jobs
+    with the same kernel chain advance in lock step -- the one-workgroup chain (<= 2 k points), the row kernel with the
+    fused accumulation (above), and the one-workgroup chain with Matcher_Point2Plane on NDT maps -- several groups in one
+    call; every result bitwise the single alignment's, as is the per-stream fallback's."""
+    ws = [synth.make_workload("t", 60000, 32, 400, 80.0, 25, variant=v) for v in range(2)]
+    maps = [capi.Map(ctx, 1.0, 20).build(w.map_xyz) for w in ws]
+    ndt = [capi.Map(ctx, 1.0, 0, min_distance_between_points=0.05, ndt_max_eigen_ratio=0.05).build(w.map_xyz) for w in ws]
+    rng = np.random.default_rng(11)
+    sizes = [900, 1500, 2048, 3000, 1200, 5000, 700]
+    jobs = []
+    for k, n in enumerate(sizes):
+        w = ws[k % 2]
+        sub = w.scan_xyz[rng.permutation(len(w.scan_xyz))[:n]]
+        sigma = [2.0, 1.2, 0.6, 2.0, 0.9, 1.5, 2.5][k]
+        iters = [300, 120, 40, 300, 7, 300, 60][k]
+        thr, kp = synth.threshold_schedule(sigma, iters)
+        kw = dict(max_iterations=iters, threshold=thr, kernel_param=kp, poll_every=[0, 3, 5, 0, 2, 4, 0][k])
+        if k == 1:
+            kw.update(hook_enabled=True, hook_min_trans=0.15, hook_min_rot=float(np.deg2rad(0.75)), hook_checkpoint=w.T_guess)
+        prior = (w.T_guess, np.diag([4.0, 4.0, 4.0, 100.0, 100.0, 100.0])) if k == 2 else None
+        jobs.append((k % 2, sub, w.T_guess, capi.ICPParams(**kw), prior))
+    ctxs = [capi.Context(0) for _ in jobs]
+    scans = [capi.Scan(c, j[1]) for c, j in zip(ctxs, jobs)]
+    for label, mset, pl in (("plain", maps, None), ("ndt", ndt, 0.4)):
+        ps = []
+        for j in jobs:
+            q = j[3]
+            if pl is not None:
+                q = capi.ICPParams(**{**q.__dict__, "pt2pl_threshold": pl})
+            ps.append(q)
+        ms = [mset[j[0]] for j in jobs]
+        singles = [capi.icp_align(m, capi.Scan(ctx, j[1]), j[2], q, prior=j[4], want_trace=False) for m, j, q in zip(ms, jobs, ps)]
+        assert len({s["n_iterations"] for s in singles}) > 2 and any(capi.TERM_NAMES[s["termination_reason"]] == "HookRequest" for s in singles)
+        batch = capi.icp_align_batch(ms, scans, [j[2] for j in jobs], ps, priors=[j[4] for j in jobs])
+        monkeypatch.setenv("MH_NO_LOCKSTEP", "1")
+        streams = capi.icp_align_batch(ms, scans, [j[2] for j in jobs], ps, priors=[j[4] for j in jobs])
+        monkeypatch.delenv("MH_NO_LOCKSTEP")
+        for a, b, c in zip(singles, batch, streams):
+            for r in (b, c):
+                assert (r["n_iterations"], r["termination_reason"], r["n_final_pairs"], r["n_final_pairs_pt2pl"]) == (
+                    a["n_iterations"], a["termination_reason"], a["n_final_pairs"], a["n_final_pairs_pt2pl"]), label
+                assert np.array_equal(r["T"], a["T"]) and np.array_equal(r["cov"], a["cov"]) and r["quality"] == a["quality"], label
+        if pl is not None:
+            assert all(s["n_final_pairs_pt2pl"] > 0 for s in singles)
+    for c in ctxs:
+        c.close()
+
+
 def test_batch_pairs_block_pinned_uploads_and_distinct_maps(ctx, monkeypatch):
     """What bench.py's timed region does, at test size: every job has its OWN map (independent draws of the generator),
     the scans arrive through asynchronous uploads from page-locked host memory queued right before the batch (the batch

@@ -400,6 +400,75 @@ def test_native_cli_is_built_and_explains_itself():
 
 
 @pytest.mark.gpu
+def test_sequences_in_one_process_share_lockstep_batches(host, tmp_path):
+    """Several sequences on ONE GPU from ONE process (what eval/cli_kitti.sh:23 does with processes): every LidarOdometry
+    runs on its own host thread and its alignments join the others' in one mh_icp_align_batch per round
+    (mp2p_icp_hip::AlignBatcher; per-job parameters, lock-step kernels).  Every sequence's records are those of its solo
+    run -- different drives of different lengths, so the batch shrinks as sequences end -- and so are the TUM files the
+    native command line writes for several --seq-dir."""
+    import json
+    import subprocess
+    import threading
+    drives = [synth.make_drive(n, seed=s, speed=v) for n, s, v in ((12, 4242, 8.0), (9, 777, 5.0), (14, 99, 10.0))]
+    solo = []
+    for d in drives:
+        lo = host.LidarOdometry()
+        lo.initialize(host.Config.FromYamlFile(PIPE))
+        for (xyz, t), st in zip(d["scans"], d["stamps"]):
+            lo.onLidar(st, xyz, t)
+        solo.append(lo.records())
+    batcher = host.AlignBatcher(len(drives))
+    los, errors = [], []
+    for _ in drives:
+        lo = host.LidarOdometry()
+        lo.initialize(host.Config.FromYamlFile(PIPE))
+        lo.setAlignBatcher(batcher)
+        los.append(lo)
+
+    def work(lo, d):
+        try:
+            for (xyz, t), st in zip(d["scans"], d["stamps"]):
+                lo.onLidar(st, xyz, t)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+        finally:
+            batcher.leave()
+
+    th = [threading.Thread(target=work, args=(lo, d)) for lo, d in zip(los, drives)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert batcher.jobs() >= sum(len(d["scans"]) - 1 for d in drives) and batcher.batches() < batcher.jobs()
+    for lo, ref in zip(los, solo):
+        got = lo.records()
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            for key in ("pose", "icp_iterations", "twist_corrections", "align_calls", "termination", "goodness", "sigma",
+                        "n_for_icp", "n_map_points", "map_updated", "icp_good"):
+                assert a[key] == b[key], key
+    # the same through the native command line: three --seq-dir in one process against three solo runs
+    exe = os.path.join(ROOT, "mola_lidar_odometry_amd", "molahip-lo-cli")
+    dirs = []
+    for k, d in enumerate(drives):
+        _write_kitti_tree(str(tmp_path / ("k%d" % k)), d)
+        dirs.append(str(tmp_path / ("k%d" % k) / "sequences" / "00"))
+    args = [exe, "--pipeline", PIPE, "--out", str(tmp_path / "multi.tum")]
+    for d in dirs:
+        args += ["--seq-dir", d]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    summary = json.loads(r.stdout.strip().splitlines()[-1])
+    assert summary["sequences"] == 3 and summary["scans"] == sum(len(d["scans"]) for d in drives)
+    for k, d in enumerate(dirs):
+        one = str(tmp_path / ("solo%d.tum" % k))
+        r1 = subprocess.run([exe, "--pipeline", PIPE, "--seq-dir", d, "--out", one], capture_output=True, text=True, timeout=300)
+        assert r1.returncode == 0, r1.stderr
+        assert open(one).read() == open(str(tmp_path / ("multi_%d.tum" % k))).read()
+
+
+@pytest.mark.gpu
 def test_native_cli_matches_the_python_runner(tmp_path, drive, capsys):
     """One KITTI-style sequence through the C++ command-line driver (next-scan prefetch on) and through the Python
     runner: the two TUM files are the same text."""
