@@ -61,8 +61,14 @@ def generate_workloads(name, variants):
     n_proc = max(1, min(len(variants), (os.cpu_count() or 2) // 2, 16))
     if n_proc == 1:
         return [_gen((name, v)) for v in variants]
-    with mp.get_context("fork").Pool(n_proc) as pool:
+    pool = mp.get_context("fork").Pool(n_proc)
+    try:
         return pool.map(_gen, [(name, v) for v in variants])
+    finally:
+        # close + join, not terminate: under `rocprofv3 --pmc` a SIGTERMed worker enters the profiler's signal handler and
+        # never returns (a whole collection run was lost to that)
+        pool.close()
+        pool.join()
 
 
 def compulsory_bytes(w, stats):

@@ -462,7 +462,8 @@ class ICP {
   CPose3D dev_hook_chk_;
   ParameterSource* source_ = nullptr;
   ParameterSource own_source_;
-  mh_scan* scan_ = nullptr;
+  mh_scan* scan_ = nullptr;                 // staging layer for host point clouds handed to the fused path ...
+  std::shared_ptr<DeviceContext> scan_ctx_;  // ... and the (map's) context it lives in, kept alive until ~ICP has destroyed it
   bool last_fused_ = false, force_generic_ = false, keep_pairings_ = true, hook_replay_ = false;
   std::shared_ptr<AlignBatcher> batcher_;
 };

@@ -717,10 +717,15 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
     scan = dev_local->handle();  // already resident: no upload
   } else {
     const PointCloud& hl = *host_local;
-    if (!scan_)
-      check(mh_scan_create(global.context()->get(), hl.x.data(), hl.y.data(), hl.z.data(), hl.size(), MH_MEM_HOST, &scan_),
+    if (scan_ && scan_ctx_ != global.context()) {  // the staging layer lives in the map's context: follow the map
+      mh_scan_destroy(scan_);
+      scan_ = nullptr;
+    }
+    if (!scan_) {
+      scan_ctx_ = global.context();  // (kept alive: the layer must not outlive its context)
+      check(mh_scan_create(scan_ctx_->get(), hl.x.data(), hl.y.data(), hl.z.data(), hl.size(), MH_MEM_HOST, &scan_),
             "mh_scan_create");
-    else
+    } else
       check(mh_scan_update(scan_, hl.x.data(), hl.y.data(), hl.z.data(), hl.size(), MH_MEM_HOST), "mh_scan_update");
     scan = scan_;
   }

@@ -460,6 +460,11 @@ void LidarOdometry::run_first_pass() {
 }
 
 void LidarOdometry::setAlignBatcher(std::shared_ptr<mp2p_icp_hip::AlignBatcher> b) {
+  // the instances of a batch run on their own host threads: each needs a context (stream + scratch) of its own, the
+  // process-wide default one would be shared between threads (molahip.h: one context, one thread at a time)
+  if (b && (!ctx_ || ctx_ == DeviceContext::Default()))
+    throw std::runtime_error("LidarOdometry::setAlignBatcher: this instance uses the process-wide default context; construct "
+                             "it with a DeviceContext of its own");
   for (auto& i : icp_)
     if (i) i->setAlignBatcher(b);
 }

@@ -4,6 +4,8 @@
 #   2. PMC passes of the SAME configuration as the timed region (S = 32 scans per lock-step launch, a map per scan), each
 #      in its own run with --kernel-trace only: FETCH_SIZE, WRITE_SIZE, L2 hit/miss, SQ busy/wait/VALU, TCP requests
 #   3. the odometry driver on a synthetic drive (kernel stats of the whole per-scan path)
+# Every profiler run has its own timeout and queues the uploads from the main thread (--upload-thread 0: a second host thread
+# under rocprofv3's dispatch interception stalled a whole collection run).
 # Usage: profiles/collect.sh <tag> [extra bench args]     (then copy gpurun_out/prof/<tag>_* into profiles/)
 TAG=${1:-r02}
 shift
@@ -12,16 +14,16 @@ REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o ${TAG}_bench -- python $REPO/bench.py $EXTRA > $OUT/${TAG}_bench_stdout.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o ${TAG}_bench -- python $REPO/bench.py --upload-thread 0 $EXTRA > $OUT/${TAG}_bench_stdout.log 2>&1
 if [ -z "$SKIP_ODOM" ]; then
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/odom -o ${TAG}_odom -- env PYTHONPATH=$REPO python -m mola_lidar_odometry_amd.run_odometry --synthetic 40 --out-dir $REPO/gpurun_out/odometry > $OUT/${TAG}_odom_stdout.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/odom -o ${TAG}_odom -- env PYTHONPATH=$REPO python -m mola_lidar_odometry_amd.run_odometry --synthetic 40 --out-dir $REPO/gpurun_out/odometry > $OUT/${TAG}_odom_stdout.log 2>&1
 fi
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVES" \
          "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc$i -o ${TAG}_pmc$i -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-shared-run $EXTRA > $OUT/${TAG}_pmc$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc$i -o ${TAG}_pmc$i -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-shared-run --upload-thread 0 $EXTRA > $OUT/${TAG}_pmc$i.log 2>&1
 done
 cd $REPO
 python - <<PY

@@ -10,6 +10,20 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout(seconds): per-test limit (pytest-timeout when installed; a hung device call must "
+                            "not eat the whole GPU session)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # every GPU test gets a limit of its own (a hung device call or a stuck thread fails ONE test instead of eating the
+    # whole GPU session); explicit @pytest.mark.timeout marks win
+    try:
+        import pytest_timeout  # noqa: F401
+    except ImportError:
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(600))
 
 
 @pytest.fixture(scope="session")

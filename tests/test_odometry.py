@@ -400,6 +400,7 @@ def test_native_cli_is_built_and_explains_itself():
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(600)
 def test_sequences_in_one_process_share_lockstep_batches(host, tmp_path):
     """Several sequences on ONE GPU from ONE process (what eval/cli_kitti.sh:23 does with processes): every LidarOdometry
     runs on its own host thread and its alignments join the others' in one mh_icp_align_batch per round
@@ -419,8 +420,12 @@ def test_sequences_in_one_process_share_lockstep_batches(host, tmp_path):
         solo.append(lo.records())
     batcher = host.AlignBatcher(len(drives))
     los, errors = [], []
+    shared = host.LidarOdometry()
+    shared.initialize(host.Config.FromYamlFile(PIPE))
+    with pytest.raises(RuntimeError):  # threads must not share the process-wide default context
+        shared.setAlignBatcher(batcher)
     for _ in drives:
-        lo = host.LidarOdometry()
+        lo = host.LidarOdometry(own_context=True)
         lo.initialize(host.Config.FromYamlFile(PIPE))
         lo.setAlignBatcher(batcher)
         los.append(lo)
@@ -438,7 +443,8 @@ def test_sequences_in_one_process_share_lockstep_batches(host, tmp_path):
     for t in th:
         t.start()
     for t in th:
-        t.join(timeout=300)
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in th), "a sequence thread is stuck"
     assert not errors, errors
     assert batcher.jobs() >= sum(len(d["scans"]) - 1 for d in drives) and batcher.batches() < batcher.jobs()
     for lo, ref in zip(los, solo):

@@ -3,7 +3,5 @@
 REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
 cd $REPO
 mkdir -p gpurun_out
-for d in 0 1 2 4; do
-timeout 600 python bench.py --no-cpu-baseline --no-shared-run --io both --upload-delay-ms $d > gpurun_out/bench_d$d.log 2>&1; python tools/bench_brief.py gpurun_out/bench_d$d.log
-done
-timeout 600 python bench.py --no-cpu-baseline --no-shared-run --io none > gpurun_out/bench_io_none.log 2>&1; python tools/bench_brief.py gpurun_out/bench_io_none.log
+timeout 1200 python tools/multi_seq_bench.py 200 1,2,4,8,16 > gpurun_out/multi_seq.log 2>&1; tail -7 gpurun_out/multi_seq.log | cut -c1-400
+PYTHONPATH=$REPO timeout 600 python -m mola_lidar_odometry_amd.run_odometry --synthetic 200 --out-dir gpurun_out/odometry > gpurun_out/odom200.log 2>&1; tail -3 gpurun_out/odom200.log | cut -c1-1500
