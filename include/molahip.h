@@ -358,7 +358,11 @@ typedef struct {
   double cov_findif_xyz;        /* 1e-7 */
   double cov_findif_ang;        /* 1e-7 */
   uint32_t poll_every;          /* ICP iterations enqueued between host polls of the done flag; 0 = automatic: the
-                                   first chunk as long as the context's previous alignment ran, then short ones */
+                                   first chunk as long as the context's previous alignment of the same kind ran (a fresh
+                                   call and a re-entry after a hook request are predicted separately, see
+                                   expected_iterations), then short ones */
+  uint32_t expected_iterations; /* with poll_every = 0: the caller's own estimate of how many iterations this call will
+                                   run (e.g. what its previous call of the same kind ran), 0 = let the library predict */
   uint32_t profile;             /* 1: time every match kernel with HIP events on the context stream (such a job is
                                    enqueued kernel by kernel instead of replaying the captured graph); 2: in
                                    mh_icp_align_batch, do that for job 0 only (lock step: its share of the launches) */
@@ -386,6 +390,9 @@ typedef struct {
   double match_kernel_ms;      /* sum of the match kernel durations */
   double total_ms;             /* stream time of the whole align */
   uint32_t n_final_pairs_pt2pl; /* how many of n_final_pairs are point-to-plane */
+  /* host-side bookkeeping of the device loop (what a latency budget wants to know): */
+  uint32_t n_host_polls;          /* times the host waited for the device loop (1 = the first chunk was long enough) */
+  uint32_t n_enqueued_iterations; /* iterations worth of kernels enqueued; those beyond the executed ones were early-exit launches */
 } mh_icp_result;
 
 /* `trace` (nullable, HOST, max_iterations entries) receives one record per executed iteration;

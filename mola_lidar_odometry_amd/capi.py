@@ -90,7 +90,7 @@ class ICPParamsC(C.Structure):
                 ("threshold_angular_deg", C.c_double), ("pt2pl_threshold", _DP), ("gn", GNParamsC), ("hook_enabled", C.c_uint32),
                 ("hook_min_trans", C.c_double), ("hook_min_rot", C.c_double), ("hook_checkpoint", C.c_double * 12),
                 ("compute_covariance", C.c_uint32), ("cov_findif_xyz", C.c_double), ("cov_findif_ang", C.c_double),
-                ("poll_every", C.c_uint32), ("profile", C.c_uint32)]
+                ("poll_every", C.c_uint32), ("expected_iterations", C.c_uint32), ("profile", C.c_uint32)]
 
 
 class ICPIter(C.Structure):
@@ -102,7 +102,8 @@ class ICPResult(C.Structure):
     _fields_ = [("T", C.c_double * 12), ("cov", C.c_double * 36), ("quality", C.c_double),
                 ("n_iterations", C.c_uint32), ("termination_reason", C.c_uint32), ("n_final_pairs", C.c_uint32),
                 ("potential_pairings", C.c_uint64), ("n_match_launches", C.c_uint32),
-                ("match_kernel_ms", C.c_double), ("total_ms", C.c_double), ("n_final_pairs_pt2pl", C.c_uint32)]
+                ("match_kernel_ms", C.c_double), ("total_ms", C.c_double), ("n_final_pairs_pt2pl", C.c_uint32),
+                ("n_host_polls", C.c_uint32), ("n_enqueued_iterations", C.c_uint32)]
 
 
 class PreprocessParams(C.Structure):
@@ -565,6 +566,7 @@ class ICPParams:
     cov_findif_xyz: float = 1e-7
     cov_findif_ang: float = 1e-7
     poll_every: int = 0
+    expected_iterations: int = 0
     profile: bool = False
 
     def c(self, T_guess):
@@ -592,6 +594,7 @@ class ICPParams:
         cp.cov_findif_xyz = self.cov_findif_xyz
         cp.cov_findif_ang = self.cov_findif_ang
         cp.poll_every = self.poll_every
+        cp.expected_iterations = self.expected_iterations
         cp.profile = int(self.profile)  # 0 | 1 (all jobs) | 2 (job 0 of a batch only)
         return cp, (thr, kp, plt)
 
@@ -601,7 +604,8 @@ def _result_dict(res: ICPResult):
                 n_iterations=int(res.n_iterations), termination_reason=int(res.termination_reason),
                 n_final_pairs=int(res.n_final_pairs), potential_pairings=int(res.potential_pairings),
                 n_match_launches=int(res.n_match_launches), match_kernel_ms=res.match_kernel_ms, total_ms=res.total_ms,
-                n_final_pairs_pt2pl=int(res.n_final_pairs_pt2pl))
+                n_final_pairs_pt2pl=int(res.n_final_pairs_pt2pl), n_host_polls=int(res.n_host_polls),
+                n_enqueued_iterations=int(res.n_enqueued_iterations))
 
 
 def icp_align(m: Map, s: Scan, T_guess, p: ICPParams, prior=None, want_trace=True, want_pairs=False):

@@ -1759,7 +1759,7 @@ struct AlignJob {
   mh_icp_iter* trace = nullptr;
   MatchK mk{};
   SolveK sk{};
-  uint32_t nb = 0, nbm = 0, nba = 0, enqueued = 0, chunk = 0, prof_n = 0;
+  uint32_t nb = 0, nbm = 0, nba = 0, enqueued = 0, chunk = 0, prof_n = 0, polls = 0, kind = 0;
   bool auto_chunk = false;
   bool fused16 = false;  // row kernel accumulates the first Gauss-Newton step itself (layers above the one-workgroup size)
   bool defer_upload = false;   // batches: the pinned mirrors are filled, the copies are issued by the batch (staged) or flush()
@@ -1883,8 +1883,17 @@ struct AlignJob {
     // poll_every == 0: the first chunk is sized by what the previous alignment of this context needed (consecutive scans
     // of a sequence converge in about as many iterations: one host round trip instead of three), later chunks are short
     auto_chunk = p->poll_every == 0;
-    chunk = p->poll_every ? p->poll_every
-                          : (ctx->predicted_iterations ? (ctx->predicted_iterations + 2 > 64 ? 64u : ctx->predicted_iterations + 2) : 10u);
+    // Every early-exit launch enqueued beyond the end of the loop costs ~1.5 us of stream time and every extra host poll
+    // ~25 us, so the first chunk should be as long as the loop will run: the caller's estimate when it has one (the
+    // odometry driver's calls alternate between short ones that the hook stops and long ones that converge, and it knows
+    // which kind it is making), else what this context's previous alignment needed.
+    kind = 0;
+    {
+      const uint32_t expect = p->expected_iterations ? p->expected_iterations : ctx->predicted_iterations[kind];
+      static const uint32_t margin = getenv("MH_CHUNK_MARGIN") ? (uint32_t)atoi(getenv("MH_CHUNK_MARGIN")) : 2u;
+      chunk = p->poll_every ? p->poll_every : (expect ? (expect + margin > 64 ? 64u : expect + margin) : 10u);
+    }
+    polls = 0;
     enqueued = 0;
     prof_n = 0;
     if (prof) {
@@ -2106,16 +2115,22 @@ struct AlignJob {
   // waits for the last enqueued chunk; sets finished when the device loop has terminated
   mh_status poll(bool already_synced = false) {  // (lock-step batches copy the state into h_state themselves)
     if (finished) return MH_OK;
+    polls++;
     MH_TRY(set_device(ctx));
     if (!already_synced) MH_HIP(hipEventSynchronize(ctx->ev_poll));
     const IcpDeviceState* h = ctx->h_state;
     if (!h->done && enqueued < p->max_iterations) {
-      if (auto_chunk) chunk = 6;
+      if (auto_chunk) {
+        static const uint32_t next = getenv("MH_CHUNK_NEXT") ? (uint32_t)atoi(getenv("MH_CHUNK_NEXT")) : 6u;
+        chunk = next ? next : 6u;
+      }
       return MH_OK;
     }
     if (!h->done) return fail(MH_ERR_INTERNAL, "device ICP loop did not terminate after max_iterations");
     finished = true;
-    if (auto_chunk) ctx->predicted_iterations = h->n_iterations + (h->term_reason == MH_TERM_MAX_ITERATIONS ? 0u : 1u);
+    if (auto_chunk) ctx->predicted_iterations[kind] = h->n_iterations + (h->term_reason == MH_TERM_MAX_ITERATIONS ? 0u : 1u);
+    res->n_host_polls = polls;
+    res->n_enqueued_iterations = enqueued;
     for (int i = 0; i < 12; i++) res->T[i] = h->T[i];
     if (p->compute_covariance)
       for (int i = 0; i < 36; i++) res->cov[i] = h->cov[i];

@@ -119,7 +119,8 @@ struct mh_ctx {
   mh::DevBuf batch_desc, batch_states;  // lock-step batches led by this context: job descriptors, gathered states
   void* h_batch = nullptr;              // pinned mirror of both
   size_t h_batch_cap = 0;
-  uint32_t predicted_iterations = 0;  // launches the last auto-chunked alignment needed (sizes the next first chunk)
+  // iterations the last auto-chunked alignment needed (sizes the next first chunk when the caller gives no estimate)
+  uint32_t predicted_iterations[2] = {0, 0};
   double* h_sched = nullptr;  // pinned staging for them
   size_t h_sched_cap = 0;
   mh::DevBuf trace;       // mh_icp_iter[max_iterations]

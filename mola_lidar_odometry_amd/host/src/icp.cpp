@@ -711,6 +711,9 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
   ip.compute_covariance = 1;
   ip.cov_findif_xyz = 1e-7;
   ip.cov_findif_ang = 1e-7;
+  if (p.maxIterations > full_budget_) full_budget_ = p.maxIterations;
+  const int call_kind = p.maxIterations < full_budget_ ? 1 : 0;
+  ip.expected_iterations = last_iterations_[call_kind];
   mh_scan* scan = nullptr;
   PointCloud downloaded;  // only when a device layer's final pairings are requested
   if (dev_local) {
@@ -769,6 +772,9 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
                        want_pairs ? &po : nullptr, MH_MEM_HOST), "mh_icp_align");
   }
   if (p.generateDebugFiles) write_debug_file(p, guess, r, trace, n);
+  last_iterations_[call_kind] = r.n_iterations + (r.termination_reason == MH_TERM_MAX_ITERATIONS ? 0u : 1u);
+  last_polls_ = r.n_host_polls;
+  last_enqueued_ = r.n_enqueued_iterations;
   memcpy(result.optimal_tf.mean.T, r.T, sizeof(r.T));
   memcpy(result.optimal_tf.cov, r.cov, sizeof(r.cov));
   result.quality = r.quality;

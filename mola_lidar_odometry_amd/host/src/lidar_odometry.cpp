@@ -756,6 +756,10 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
         icp.clearHooks();
       icp.align(obs, glob, current_solution, icp_params, res, prior);  // :961-962
       rec.align_calls++;
+      profile_["icp.host_polls"] += icp.lastAlignHostPolls();
+      profile_["icp.enqueued_iterations"] += icp.lastAlignEnqueuedIterations();
+      profile_["icp.executed_iterations"] += (double)res.nIterations;
+      profile_["icp.align_calls"] += 1.0;
       remaining -= std::min(remaining, res.nIterations);
       rec.icp_iterations += (uint32_t)res.nIterations;
       if (res.terminationReason == IterTermReason::HookRequest) {

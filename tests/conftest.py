@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # one HIP runtime per process: when torch is there it has to be loaded before libmolahip / the pybind module,
+    import torch  # noqa: F401  whatever order the test files run in (capi.lib() does the same for ctypes users)
+except Exception:  # noqa: BLE001
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -3,5 +3,8 @@
 REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
 cd $REPO
 mkdir -p gpurun_out
-timeout 1200 python tools/multi_seq_bench.py 200 1,2,4,8,16 > gpurun_out/multi_seq.log 2>&1; tail -7 gpurun_out/multi_seq.log | cut -c1-400
-PYTHONPATH=$REPO timeout 600 python -m mola_lidar_odometry_amd.run_odometry --synthetic 200 --out-dir gpurun_out/odometry > gpurun_out/odom200.log 2>&1; tail -3 gpurun_out/odom200.log | cut -c1-1500
+timeout 1700 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; tail -4 gpurun_out/pytest_gpu.log | cut -c1-300
+timeout 600 python bench.py > gpurun_out/bench_default.log 2>&1; python tools/bench_brief.py gpurun_out/bench_default.log
+timeout 600 python bench.py --io none --no-cpu-baseline --no-shared-run > gpurun_out/bench_io_none.log 2>&1; python tools/bench_brief.py gpurun_out/bench_io_none.log
+timeout 600 python bench.py --workload creal --no-cpu-baseline --no-shared-run > gpurun_out/bench_creal.log 2>&1; python tools/bench_brief.py gpurun_out/bench_creal.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
