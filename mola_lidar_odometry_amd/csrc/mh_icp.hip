@@ -259,7 +259,9 @@ extern "C" __attribute__((visibility("default"))) int mh_debug_wavetrace(unsigne
 __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__ st,
                                                    const float* __restrict__ lx, const float* __restrict__ ly,
                                                    const float* __restrict__ lz, uint32_t n, MapView map,
-                                                   float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx
+                                                   float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
+                                                   const uint32_t* __restrict__ perm  // null, or lx/ly/lz are the scan in
+                                                                                      // search order: point i is perm[i]
 #ifdef MH_DEBUG_WAVETRACE
                                                    , unsigned long long* __restrict__ wtrace
 #endif
@@ -275,6 +277,7 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
   const uint32_t i = gl >> 2, sub = gl & 3u;
   const uint32_t ic = i < n ? i : n - 1;
   const float x = lx[ic], y = ly[ic], z = lz[ic];
+  const uint32_t o = perm ? perm[ic] : i;
   const uint32_t done = st->done;
   double T[12];
 #pragma unroll
@@ -288,8 +291,8 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
   if (sub == 0) {
     const float n2 = (px * px + py * py) + pz * pz;
     const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
-    pair_q[i] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
-    pair_gidx[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+    pair_q[o] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
+    pair_gidx[o] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
   }
 }
 
@@ -1326,12 +1329,13 @@ __device__ __forceinline__ void k_cov_finalize_body(IcpDeviceState* __restrict__
 __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDeviceState* __restrict__ st,
                                                    const float* __restrict__ lx, const float* __restrict__ ly,
                                                    const float* __restrict__ lz, uint32_t n, MapView map,
-                                                   float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx
+                                                   float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
+                                                   const uint32_t* __restrict__ perm
 #ifdef MH_DEBUG_WAVETRACE
                                                    , unsigned long long* __restrict__ wtrace
 #endif
 ) {
-  k_match4_body(st, lx, ly, lz, n, map, pair_q, pair_gidx
+  k_match4_body(st, lx, ly, lz, n, map, pair_q, pair_gidx, perm
 #ifdef MH_DEBUG_WAVETRACE
                 , wtrace
 #endif
@@ -1339,7 +1343,17 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDevic
 }
 __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4_b(const BatchJob* __restrict__ jobs) {
   const BatchJob& j = jobs[blockIdx.y];
-  k_match4_body(j.st, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx
+  k_match4_body(j.st, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, nullptr
+#ifdef MH_DEBUG_WAVETRACE
+                , nullptr
+#endif
+  );
+}
+// the quad matcher over the scan in search order (mh_tile.hip): neighbouring quads need the same voxels and tend to take the
+// same number of rounds
+__global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4o_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  k_match4_body(j.st, j.sx, j.sy, j.sz, j.n, j.map, j.pair_q, j.pair_gidx, j.perm
 #ifdef MH_DEBUG_WAVETRACE
                 , nullptr
 #endif
@@ -1369,6 +1383,149 @@ __global__ __launch_bounds__(kTileThreads) void k_match_tile_b(const BatchJob* _
 #endif
   );
 }
+// k_match_wave: tiles of <= 64 spatially sorted points.  Two launches per iteration over the same tile table:
+//   DENSE   one wave (a 64-thread workgroup) per tile with >= kWaveMinPoints points: wave-uniform candidates
+//           (nn_search_wave: scalar loads; LDS: the box's records staged in LDS instead when they fit);
+//   sparse  the other tiles by quads (nn_search_quad), sixteen points per wave, four waves per tile.
+// Each tile is handled by exactly one of the two; the other launch's workgroup leaves at once.  Two kernels instead of
+// one so that each gets the registers of its own path only.
+template <bool DENSE, bool LDS>
+__device__ __forceinline__ void k_match_wave_body(const IcpDeviceState* __restrict__ st, const float* __restrict__ sx,
+                                                  const float* __restrict__ sy, const float* __restrict__ sz,
+                                                  const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tile_start,
+                                                  uint32_t n_tiles, MapView map, float4* __restrict__ pair_q,
+                                                  uint32_t* __restrict__ pair_gidx
+#ifdef MH_DEBUG_WAVETRACE
+                                                  , unsigned long long* __restrict__ wtrace
+#endif
+) {
+  WaveShared* wsh = nullptr;
+  if constexpr (LDS && DENSE) {
+    __shared__ WaveShared wsh_store;
+    wsh = &wsh_store;
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t t = blockIdx.x;
+  if (t >= n_tiles) return;
+  // everything wave-uniform comes in through the scalar path (constant address space, uniform addresses): the pose lives
+  // in SGPRs, not in 24 VGPRs per lane
+  typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
+  typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
+  const cu32_ptr cts = (cu32_ptr)uniform_const_ptr(tile_start);
+  const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
+  const uint32_t s0 = cts[t], s1 = cts[t + 1];
+  const uint32_t cnt = s1 - s0;
+  if ((cnt >= kWaveMinPoints) != DENSE) return;  // the other launch's tile
+  const uint32_t done = cst->done;
+  double T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = cst->T[k];
+  const float thr2 = cst->cur_thr2, ang2 = cst->cur_ang2;
+  if (done) return;  // grid-uniform
+  if (DENSE) {
+    const uint32_t i = s0 + lane;
+    const bool active = i < s1;
+    const uint32_t ic = active ? i : s0;
+    const float x = sx[ic], y = sy[ic], z = sz[ic];
+    const uint32_t orig = perm[ic];
+    float px, py, pz;
+    transform_point(T, x, y, z, px, py, pz);
+#ifdef MH_DEBUG_WAVETRACE
+    unsigned long long* dbg = wtrace ? wtrace + 8ull * t : nullptr;  // [start, end, points, voxels, probed, copied, pass 1, records]
+    if (lane == 0 && dbg) { dbg[0] = wall_clock64(); dbg[2] = cnt; }
+#endif
+    const NNResult r = nn_search_wave<LDS>(map, wsh, active, px, py, pz
+#ifdef MH_DEBUG_WAVETRACE
+                                           , dbg
+#endif
+    );
+#ifdef MH_DEBUG_WAVETRACE
+    if (lane == 0 && dbg) dbg[1] = wall_clock64();
+#endif
+    if (active) {
+      const float n2 = (px * px + py * py) + pz * pz;
+      const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
+      pair_q[orig] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
+      pair_gidx[orig] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+    }
+    return;
+  }
+  const uint32_t sub = lane & 3u;
+  {
+    const uint32_t base = 16u * wave;  // sixteen points per wave, a quad each
+    if (base >= cnt) return;
+    const uint32_t q = base + (lane >> 2);
+    const bool active = q < cnt;
+    const uint32_t ic = s0 + (active ? q : 0u);
+    const float x = sx[ic], y = sy[ic], z = sz[ic];
+    const uint32_t orig = perm[ic];
+    float px, py, pz;
+    transform_point(T, x, y, z, px, py, pz);
+#ifdef MH_DEBUG_WAVETRACE
+    unsigned long long* dbg = (wtrace && wave == 0) ? wtrace + 8ull * t : nullptr;
+    if (lane == 0 && dbg) { dbg[0] = wall_clock64(); dbg[2] = cnt; dbg[3] = 0; }
+#endif
+    const NNResult r = nn_search_quad(map, sub, px, py, pz);
+    if (active && sub == 0u) {
+      const float n2 = (px * px + py * py) + pz * pz;
+      const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
+      pair_q[orig] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
+      pair_gidx[orig] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+    }
+#ifdef MH_DEBUG_WAVETRACE
+    if (lane == 0 && dbg) dbg[1] = wall_clock64();
+#endif
+  }
+}
+#ifdef MH_DEBUG_WAVETRACE
+#define MH_WT_PARAM , unsigned long long* __restrict__ wtrace
+#define MH_WT_ARG , wtrace
+#define MH_WT_NULL , nullptr
+#define MH_WT_G , g_wtrace
+#else
+#define MH_WT_PARAM
+#define MH_WT_ARG
+#define MH_WT_NULL
+#endif
+template <bool LDS>
+__global__ __launch_bounds__(64, 8) void k_match_wave_dense(const IcpDeviceState* __restrict__ st, const float* __restrict__ sx,
+                                                            const float* __restrict__ sy, const float* __restrict__ sz,
+                                                            const uint32_t* __restrict__ perm,
+                                                            const uint32_t* __restrict__ tile_start, uint32_t n_tiles, MapView map,
+                                                            float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx MH_WT_PARAM) {
+  k_match_wave_body<true, LDS>(st, sx, sy, sz, perm, tile_start, n_tiles, map, pair_q, pair_gidx MH_WT_ARG);
+}
+__global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_wave_sparse(const IcpDeviceState* __restrict__ st,
+                                                                            const float* __restrict__ sx, const float* __restrict__ sy,
+                                                                            const float* __restrict__ sz, const uint32_t* __restrict__ perm,
+                                                                            const uint32_t* __restrict__ tile_start, uint32_t n_tiles,
+                                                                            MapView map, float4* __restrict__ pair_q,
+                                                                            uint32_t* __restrict__ pair_gidx MH_WT_PARAM) {
+  k_match_wave_body<false, false>(st, sx, sy, sz, perm, tile_start, n_tiles, map, pair_q, pair_gidx MH_WT_ARG);
+}
+template <bool LDS>
+__global__ __launch_bounds__(64, 8) void k_match_wave_dense_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  k_match_wave_body<true, LDS>(j.st, j.sx, j.sy, j.sz, j.perm, j.tile_start, j.n_tiles, j.map, j.pair_q, j.pair_gidx MH_WT_NULL);
+}
+__global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_wave_sparse_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  k_match_wave_body<false, false>(j.st, j.sx, j.sy, j.sz, j.perm, j.tile_start, j.n_tiles, j.map, j.pair_q, j.pair_gidx MH_WT_NULL);
+}
+// both launches of the wave matcher on stream s (LDS staging of the dense tiles: MH_WAVE_LDS=1)
+static inline bool wave_lds_env() { static const bool v = getenv("MH_WAVE_LDS") != nullptr; return v; }
+#define MH_LAUNCH_WAVE(S, ST, SC, MV, PQ, PG, WT)                                                                          \
+  do {                                                                                                                     \
+    if (wave_lds_env())                                                                                                    \
+      hipLaunchKernelGGL(k_match_wave_dense<true>, dim3((SC)->n_tiles), dim3(64), 0, S, ST, (SC)->sx, (SC)->sy, (SC)->sz,   \
+                         (SC)->perm, (SC)->tile_start, (SC)->n_tiles, MV, PQ, PG WT);                                      \
+    else                                                                                                                   \
+      hipLaunchKernelGGL(k_match_wave_dense<false>, dim3((SC)->n_tiles), dim3(64), 0, S, ST, (SC)->sx, (SC)->sy, (SC)->sz,  \
+                         (SC)->perm, (SC)->tile_start, (SC)->n_tiles, MV, PQ, PG WT);                                      \
+    hipLaunchKernelGGL(k_match_wave_sparse, dim3((SC)->n_tiles), dim3(kBlock), 0, S, ST, (SC)->sx, (SC)->sy, (SC)->sz,      \
+                       (SC)->perm, (SC)->tile_start, (SC)->n_tiles, MV, PQ, PG WT);                                        \
+  } while (0)
 __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first,
                                                   const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
@@ -1865,14 +2022,18 @@ struct AlignJob {
       //   "t"            a workgroup per tile of the spatially sorted scan, map records staged in LDS      -> k_match_tile + k_accum
       const char* e = getenv("MH_MATCH");
       variant = scan->n <= kRowMaxPoints ? 5 : 4;
+      //   "w"            a wave per tile of 64 sorted points, wave-uniform candidates through the scalar path       -> k_match_wave + k_accum
       if (e && e[0] == 't') variant = 6;
+      if (e && e[0] == 'w') variant = 7;
+      //   "o"            "q" over the scan in search order (the sort of "t"/"w", no tiles)                                    -> k_match4 + k_accum
+      if (e && e[0] == 'o') variant = 8;
       if (e && e[0] == 'q') variant = 4;
       if (e && e[0] == 's') variant = 5;
       if (e && e[0] == 'p') variant = 0;
       if (e && e[0] == 'x') variant = 1;
       if (variant == 1 && map->view().ndt) variant = 0;  // "x" walks contiguous z-runs; NDT maps interleave statistics records
     }
-    if (variant == 6) MH_TRY(scan_build_tiles(scan, map->inv_vs));  // asynchronous; a no-op when the scan is already in search order
+    if (variant >= 6) MH_TRY(scan_build_tiles(scan, map->inv_vs, variant == 7 ? 64u : 256u));  // asynchronous; a no-op when the scan is already in search order
     nba = nblk_acc(scan->n);
     // (measured per iteration, fused vs k_accum: 31.0 vs 33.8 us at 4 k points, 33.2 vs 35.0 at 8 k, equal at 16 k,
     //  45.9 vs 41.8 at 32 k -- one partial row per 16 points makes the solve's reduction the longer pole there)
@@ -1929,7 +2090,7 @@ struct AlignJob {
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t)scan->n;
     const MapView mv = map->view();
-    if (variant == 6) MH_TRY(scan_tiles_ready(scan));  // the launch grid needs the tile count
+    if (variant == 6 || variant == 7) MH_TRY(scan_tiles_ready(scan));  // the launch grid needs the tile count
     const uint32_t m = (p->max_iterations - enqueued) < chunk ? (p->max_iterations - enqueued) : chunk;
     PoseArg dummy{};
     double* part = ctx->partials.as<double>();
@@ -1984,6 +2145,15 @@ struct AlignJob {
           else if (!fused16)
             hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                                ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
+        } else if (variant == 7) {
+#ifdef MH_DEBUG_WAVETRACE
+          MH_LAUNCH_WAVE(s, ctx->d_state, scan, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), MH_WT_G);
+#else
+          MH_LAUNCH_WAVE(s, ctx->d_state, scan, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), );
+#endif
+          if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
+          hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
         } else if (variant == 6) {
           hipLaunchKernelGGL(k_match_tile, dim3(scan->n_tiles), dim3(kTileThreads), 0, s, ctx->d_state, scan->sx, scan->sy, scan->sz,
                              scan->perm, scan->tile_start, scan->n_tiles, mv, ctx->pair_q.as<float4>(),
@@ -1995,9 +2165,11 @@ struct AlignJob {
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
           hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
-        } else if (variant == 4) {
+        } else if (variant == 4 || variant == 8) {
+          const bool ord = variant == 8;  // the scan in search order
           hipLaunchKernelGGL(k_match4, dim3((uint32_t)((4ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
-                             scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>()
+                             ord ? scan->sx : scan->x, ord ? scan->sy : scan->y, ord ? scan->sz : scan->z, n, mv,
+                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), ord ? scan->perm : (const uint32_t*)nullptr
 #ifdef MH_DEBUG_WAVETRACE
                              , g_wtrace
 #endif
@@ -2063,7 +2235,7 @@ struct AlignJob {
                                        (unsigned long long)(pl ? ctx->pl_c.p : nullptr) ^
                                            ((unsigned long long)(pl ? ctx->pl_n.p : nullptr) << 1),
                                        (unsigned long long)(pl ? ctx->partials_b.p : nullptr) ^
-                                           (variant == 6 ? ((unsigned long long)scan->sx ^ ((unsigned long long)scan->n_tiles << 48)) : 0ull)};
+                                           (variant >= 6 ? ((unsigned long long)scan->sx ^ ((unsigned long long)scan->n_tiles << 48)) : 0ull)};
       static_assert(sizeof(kv) <= sizeof(key), "graph key too small");
       memcpy(key, kv, sizeof(kv));
       const bool cached = ctx->graph_exec && memcmp(key, ctx->graph_key, sizeof(key)) == 0;
@@ -2231,7 +2403,7 @@ void fill_batch_desc(const AlignJob& j, BatchJob& d) {
   }
   d.sched_dst = j.ctx->sched.as<uint32_t>();
   d.sched_dwords = (uint32_t)(2 * j.nsched_pending);
-  if (j.variant == 6) {
+  if (j.variant >= 6) {
     d.sx = j.scan->sx; d.sy = j.scan->sy; d.sz = j.scan->sz;
     d.perm = j.scan->perm;
     d.tile_start = j.scan->tile_start;
@@ -2359,7 +2531,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
   // each job keeps its own parameters (iteration budget, schedules, hook check point, prior), state block, termination
   // flag and iteration count.  Jobs whose chain has no lock-step form (or that are alone in their group) take the
   // per-stream path below.
-  enum Kind { K_NONE = 0, K_QUAD, K_TILE, K_ROWF, K_ONE, K_ONE_PL };
+  enum Kind { K_NONE = 0, K_QUAD, K_TILE, K_WAVE, K_ORD, K_ROWF, K_ONE, K_ONE_PL };
   const bool no_lockstep = getenv("MH_NO_LOCKSTEP") != nullptr;
   const bool no_one_group_env = getenv("MH_NO_ONE_GROUP") != nullptr;
   auto kind_of = [&](const AlignJob& j) -> int {
@@ -2367,6 +2539,8 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
     const bool one_group = j.variant == 5 && j.scan->n <= kOneGroupMaxPoints && !no_one_group_env;
     if (j.variant == 4 && !j.pl) return K_QUAD;
     if (j.variant == 6 && !j.pl) return K_TILE;
+    if (j.variant == 7 && !j.pl) return K_WAVE;
+    if (j.variant == 8 && !j.pl) return K_ORD;
     if (j.variant == 5 && one_group) return j.pl ? K_ONE_PL : K_ONE;
     if (j.variant == 5 && j.fused16 && !j.pl) return K_ROWF;
     return K_NONE;
@@ -2446,7 +2620,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       mh_ctx* lead = g.lead;
       MH_TRY(set_device(lead));
       hipStream_t s = lead->stream;
-      if (g.kind == K_TILE)
+      if (g.kind == K_TILE || g.kind == K_WAVE)
         for (AlignJob* j : g.jobs) MH_TRY(scan_tiles_ready(j->scan));  // tile counts (the builds were queued by start())
       MH_TRY(order_after_job_streams(lead, g.jobs));
       size_t stage_bytes = 0;
@@ -2474,6 +2648,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         uint32_t bm = (uint32_t)((4ull * d.n + kBlock - 1) / kBlock);  // quad
         if (g.kind == K_ROWF) bm = d.nbm;
         if (g.kind == K_TILE) bm = d.n_tiles;
+        if (g.kind == K_WAVE) bm = d.n_tiles;
         if (g.kind == K_ONE || g.kind == K_ONE_PL) bm = (uint32_t)((16ull * d.n + kBlock - 1) / kBlock);
         g.gx_match = bm > g.gx_match ? bm : g.gx_match;
         g.gx_acc = d.nba > g.gx_acc ? d.nba : g.gx_acc;
@@ -2515,6 +2690,12 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
           switch (g.kind) {
             case K_ROWF: hipLaunchKernelGGL(k_match16f_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
             case K_TILE: hipLaunchKernelGGL(k_match_tile_b, dim3(g.gx_match, A), dim3(kTileThreads), 0, s, g.dj); break;
+            case K_WAVE:
+              if (wave_lds_env()) hipLaunchKernelGGL(k_match_wave_dense_b<true>, dim3(g.gx_match, A), dim3(64), 0, s, g.dj);
+              else hipLaunchKernelGGL(k_match_wave_dense_b<false>, dim3(g.gx_match, A), dim3(64), 0, s, g.dj);
+              hipLaunchKernelGGL(k_match_wave_sparse_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj);
+              break;
+            case K_ORD: hipLaunchKernelGGL(k_match4o_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
             case K_ONE: hipLaunchKernelGGL(k_match16_b<false>, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
             case K_ONE_PL: hipLaunchKernelGGL(k_match16_b<true>, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
             default: hipLaunchKernelGGL(k_match4_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
@@ -2640,14 +2821,17 @@ namespace {
 // through mh_nn_search / mh_nn_search_dense); thr2 = +inf: no threshold
 mh_status launch_tile_search(const mh_map* map, const mh_scan* scan, const double T[12], float thr2, float ang2) {
   mh_ctx* ctx = scan->ctx;
-  MH_TRY(scan_build_tiles(scan, map->inv_vs));
+  const bool wave = tile_points_for_env() == 64u;
+  MH_TRY(scan_build_tiles(scan, map->inv_vs, wave ? 64u : 256u));
   MH_TRY(scan_tiles_ready(scan));
   MH_HIP(hipStreamSynchronize(ctx->stream));  // the pinned state mirror may still be travelling
   init_state(ctx->h_state, T);
   ctx->h_state->cur_thr2 = thr2;
   ctx->h_state->cur_ang2 = ang2;
   MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpDeviceState), hipMemcpyHostToDevice, ctx->stream));
-  if (scan->n_tiles)
+  if (scan->n_tiles && wave)
+    MH_LAUNCH_WAVE(ctx->stream, ctx->d_state, scan, map->view(), ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), MH_WT_NULL);
+  else if (scan->n_tiles)
     hipLaunchKernelGGL(k_match_tile, dim3(scan->n_tiles), dim3(kTileThreads), 0, ctx->stream, ctx->d_state, scan->sx, scan->sy,
                        scan->sz, scan->perm, scan->tile_start, scan->n_tiles, map->view(), ctx->pair_q.as<float4>(),
                        ctx->pair_gidx.as<uint32_t>()
@@ -2660,7 +2844,7 @@ mh_status launch_tile_search(const mh_map* map, const mh_scan* scan, const doubl
 }
 inline bool tile_search_forced() {
   const char* e = getenv("MH_MATCH");
-  return e && e[0] == 't';
+  return e && (e[0] == 't' || e[0] == 'w');
 }
 }  // namespace
 

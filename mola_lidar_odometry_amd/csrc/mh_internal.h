@@ -195,6 +195,7 @@ struct mh_scan {
   mutable const uint32_t* tile_start = nullptr;  // [n_tiles + 1]
   mutable uint32_t n_tiles = 0;
   mutable float tile_inv_vs = 0.f;
+  mutable uint32_t tile_points = 0;
   mutable bool tiles_valid = false, tiles_pending = false;  // pending: n_tiles still travelling to h_ntiles
   mutable uint32_t* h_ntiles = nullptr;  // pinned
   mutable hipEvent_t ev_tiles = nullptr;
@@ -210,7 +211,8 @@ mh_status scan_alloc(mh_scan* s, size_t n, bool with_t, bool with_src);
 // n_stored: the first n_stored inputs are points the map already stores (accepted by the insertion rules before).
 // sorted copy + tile table of a scan for voxel size 1/inv_vs (no-op when valid); asynchronous on the scan's stream,
 // scan_tiles_ready() waits for the tile count
-mh_status scan_build_tiles(const mh_scan* s, float inv_vs);
+mh_status scan_build_tiles(const mh_scan* s, float inv_vs, uint32_t tile_points);
+uint32_t tile_points_for_env();
 mh_status scan_tiles_ready(const mh_scan* s);
 void scan_drop_tiles(mh_scan* s);  // host-side bookkeeping only (the points changed)
 void scan_free_tiles(mh_scan* s);

@@ -6,7 +6,7 @@
 // fall into 2.5 k voxels).  So the points are sorted once per scan -- in the LOCAL frame, because a rigid transform keeps
 // neighbours together whatever the pose of the iteration is -- by
 //     (2x2x2-voxel block, quarter-voxel Morton code inside the block)
-// and cut into tiles of at most kTilePoints consecutive points that never cross a block boundary.  One workgroup of
+// and cut into tiles of at most `tile_points` (256: k_match_tile, 64: k_match_wave) consecutive points that never cross a block boundary.  One workgroup of
 // k_match_tile (mh_icp.hip) then loads the union of its tile's neighbourhoods into LDS once per iteration (the box around
 // the transformed points, at most a few hundred records) and every point searches LDS.
 //
@@ -19,7 +19,6 @@
 
 namespace mh {
 
-constexpr uint32_t kTilePoints = 256;
 constexpr unsigned long long kTileKeyInvalid = (1ull << 39) - 1;  // non-finite / far-away points sort last
 
 __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 3 bits -> every third bit
@@ -44,12 +43,12 @@ __global__ __launch_bounds__(256) void k_tile_keys(const float* __restrict__ x, 
   idx[i] = i;
 }
 
-// sorted copy of the coordinates + "a tile starts here" flags: a new block, or every kTilePoints-th sorted position
+// sorted copy of the coordinates + "a tile starts here" flags: a new block, or every tile_points-th sorted position
 __global__ __launch_bounds__(256) void k_tile_heads(const unsigned long long* __restrict__ keys_s,
                                                     const uint32_t* __restrict__ perm, const float* __restrict__ x,
                                                     const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
                                                     float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz,
-                                                    uint8_t* __restrict__ head) {
+                                                    uint8_t* __restrict__ head, uint32_t tile_points) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const uint32_t p = perm[i];
@@ -57,7 +56,7 @@ __global__ __launch_bounds__(256) void k_tile_heads(const unsigned long long* __
   sy[i] = y[p];
   sz[i] = z[p];
   const unsigned long long b = keys_s[i] >> 9;
-  head[i] = (i == 0 || (i % kTilePoints) == 0 || (keys_s[i - 1] >> 9) != b) ? 1 : 0;
+  head[i] = (i == 0 || (i % tile_points) == 0 || (keys_s[i - 1] >> 9) != b) ? 1 : 0;
 }
 
 __global__ void k_tile_finish(uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ count, uint32_t n,
@@ -65,6 +64,11 @@ __global__ void k_tile_finish(uint32_t* __restrict__ tile_start, const uint32_t*
   const uint32_t c = *count;
   tile_start[c] = n;  // end of the last tile
   *h_count = c;       // pinned host memory
+}
+
+uint32_t tile_points_for_env() {  // MH_MATCH=w (wave matcher): tiles of one wave; t: tiles of one workgroup
+  const char* e = getenv("MH_MATCH");
+  return (e && e[0] == 'w') ? 64u : 256u;
 }
 
 void scan_drop_tiles(mh_scan* s) {
@@ -82,8 +86,8 @@ void scan_free_tiles(mh_scan* s) {
   s->ev_tiles = nullptr;
 }
 
-mh_status scan_build_tiles(const mh_scan* s, float inv_vs) {
-  if (s->tiles_valid && s->tile_inv_vs == inv_vs) return MH_OK;
+mh_status scan_build_tiles(const mh_scan* s, float inv_vs, uint32_t tile_points) {
+  if (s->tiles_valid && s->tile_inv_vs == inv_vs && s->tile_points == tile_points) return MH_OK;
   mh_ctx* ctx = s->ctx;
   MH_TRY(set_device(ctx));
   hipStream_t st = ctx->stream;
@@ -105,6 +109,7 @@ mh_status scan_build_tiles(const mh_scan* s, float inv_vs) {
   uint32_t* tile_start = (uint32_t*)(base + 4 * stride);
   s->sx = sx; s->sy = sy; s->sz = sz; s->perm = perm; s->tile_start = tile_start;
   s->tile_inv_vs = inv_vs;
+  s->tile_points = tile_points;
   s->tiles_valid = true;
   if (n == 0) {
     s->n_tiles = 0;
@@ -129,7 +134,7 @@ mh_status scan_build_tiles(const mh_scan* s, float inv_vs) {
   hipLaunchKernelGGL(k_tile_keys, dim3(nb), dim3(256), 0, st, s->x, s->y, s->z, N, inv_vs * 4.0f, keys, idx);
   size_t tb = ctx->sort_tmp.bytes;
   MH_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tb, keys, keys_s, idx, perm, N, 0, 39, st));
-  hipLaunchKernelGGL(k_tile_heads, dim3(nb), dim3(256), 0, st, keys_s, perm, s->x, s->y, s->z, N, sx, sy, sz, head);
+  hipLaunchKernelGGL(k_tile_heads, dim3(nb), dim3(256), 0, st, keys_s, perm, s->x, s->y, s->z, N, sx, sy, sz, head, tile_points);
   tb = ctx->sort_tmp.bytes;
   MH_HIP(rocprim::select(ctx->sort_tmp.p, tb, rocprim::counting_iterator<uint32_t>(0), head, tile_start, count, N, st));
   hipLaunchKernelGGL(k_tile_finish, dim3(1), dim3(1), 0, st, tile_start, count, N, s->h_ntiles);
@@ -158,6 +163,6 @@ extern "C" {
 mh_status mh_scan_prepare(const mh_scan* scan, float voxel_size) {
   MH_REQUIRE(scan, "null scan");
   MH_REQUIRE(voxel_size > 0.f, "voxel_size must be > 0");
-  return mh::scan_build_tiles(scan, 1.0f / voxel_size);
+  return mh::scan_build_tiles(scan, 1.0f / voxel_size, mh::tile_points_for_env());
 }
 }

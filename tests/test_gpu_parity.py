@@ -222,13 +222,13 @@ def test_nn_voxel_boundary_and_negative_coords(ctx, oracle):
 
 @pytest.mark.parametrize("vs,cap,mode,offset", [(1.0, 20, 0, 0.0), (0.3, 5, 0, 0.0), (2.5, 0, 0, 0.0), (1.0, 20, 1, 0.0),
                                                 (1.0, 20, 0, 50000.0), (0.7, 8, 0, -12345.0), (0.3, 20, 1, 3.0)])
-@pytest.mark.parametrize("match", ["p", "t"])
+@pytest.mark.parametrize("match", ["p", "t", "w"])
 def test_nn_pruning_is_exact_on_adversarial_clouds(ctx, oracle, vs, cap, mode, offset, match, monkeypatch):
     """The production search prunes voxels with a conservative distance bound; its output must stay
     bit-identical to the exhaustive 27-voxel scan of the oracle.  Adversarial inputs: lattice-aligned map
     points and queries (exact distance ties in different voxels), queries exactly on voxel boundaries,
     coordinates where fp32 spacing is coarse, voxel sizes whose reciprocal is inexact, trunc indexing."""
-    monkeypatch.setenv("MH_MATCH", match)  # p: one lane per point through the caches; t: tiles staged in LDS
+    monkeypatch.setenv("MH_MATCH", match)  # p: one lane per point through the caches; t: tiles staged in LDS; w: wave-uniform candidates
     rng = np.random.default_rng(int(vs * 10) + cap + mode)
     g = np.arange(-6, 6, 0.25, dtype=np.float32)
     lattice = np.stack(np.meshgrid(g, g, g[:24], indexing="ij"), -1).reshape(-1, 3)
@@ -650,7 +650,9 @@ def test_profile_fields(ctx, small):
 @pytest.mark.parametrize("env", [{"MH_MATCH": "s"}, {"MH_MATCH": "s", "MH_NO_ONE_GROUP": "1"},
                                  {"MH_MATCH": "s", "MH_NO_ONE_GROUP": "1", "MH_NO_FUSE16": "1"}, {"MH_MATCH": "q"},
                                  {"MH_MATCH": "p"}, {"MH_MATCH": "x"}, {"MH_MATCH": "q", "MH_NO_GRAPH": "1"},
-                                 {"MH_MATCH": "t"}, {"MH_MATCH": "t", "MH_NO_GRAPH": "1"}])
+                                 {"MH_MATCH": "t"}, {"MH_MATCH": "t", "MH_NO_GRAPH": "1"}, {"MH_MATCH": "w"},
+                                 {"MH_MATCH": "w", "MH_NO_GRAPH": "1"}, {"MH_MATCH": "w", "MH_WAVE_LDS": "1"},
+                                 {"MH_MATCH": "o"}])
 @pytest.mark.parametrize("n_scan", [2000, 5000])
 def test_every_kernel_variant_matches_the_oracle(ctx, oracle, env, n_scan, monkeypatch):
     """The default path picks its kernels by layer size (row / quad search, one-workgroup or multi-launch solve);

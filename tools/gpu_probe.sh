@@ -3,8 +3,8 @@
 REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
 cd $REPO
 mkdir -p gpurun_out
-timeout 1700 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; tail -4 gpurun_out/pytest_gpu.log | cut -c1-300
-timeout 600 python bench.py > gpurun_out/bench_default.log 2>&1; python tools/bench_brief.py gpurun_out/bench_default.log
-timeout 600 python bench.py --io none --no-cpu-baseline --no-shared-run > gpurun_out/bench_io_none.log 2>&1; python tools/bench_brief.py gpurun_out/bench_io_none.log
-timeout 600 python bench.py --workload creal --no-cpu-baseline --no-shared-run > gpurun_out/bench_creal.log 2>&1; python tools/bench_brief.py gpurun_out/bench_creal.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+for m in o q; do
+MH_MATCH=$m timeout 600 python bench.py --no-cpu-baseline --no-shared-run --io none > gpurun_out/bench_$m.log 2>&1; python tools/bench_brief.py gpurun_out/bench_$m.log
+MH_MATCH=$m timeout 600 python bench.py --no-cpu-baseline --no-shared-run --streams 1 --io none > gpurun_out/bench_${m}_s1.log 2>&1; python tools/bench_brief.py gpurun_out/bench_${m}_s1.log
+done
+grep -o '"parity[^}]*}' gpurun_out/bench_o.log | head -3
