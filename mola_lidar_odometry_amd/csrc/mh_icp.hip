@@ -172,7 +172,7 @@ __device__ __forceinline__ void block_sum_rows_raw(const double* v, double (*tr)
     double sum = p1[threadIdx.x * G];
 #pragma unroll
     for (int g = 1; g < G; g++) sum += p1[threadIdx.x * G + g];
-    partials[threadIdx.x * pstride + bid] = sum;
+    ((double MH_AS_GLOBAL*)partials)[threadIdx.x * pstride + bid] = sum;  // (global space spelled out: mh_nn_device.h)
   }
 }
 
@@ -276,13 +276,16 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
   const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
   const uint32_t i = gl >> 2, sub = gl & 3u;
   const uint32_t ic = i < n ? i : n - 1;
-  const float x = lx[ic], y = ly[ic], z = lz[ic];
-  const uint32_t o = perm ? perm[ic] : i;
-  const uint32_t done = st->done;
+  const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
+  const uint32_t o = perm ? G(perm)[ic] : i;
+  // the state block through the scalar path (uniform address, not written during this kernel): the pose in SGPRs
+  typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
+  const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
+  const uint32_t done = cst->done;
   double T[12];
 #pragma unroll
-  for (int k = 0; k < 12; k++) T[k] = st->T[k];
-  const float thr2 = st->cur_thr2, ang2 = st->cur_ang2;
+  for (int k = 0; k < 12; k++) T[k] = cst->T[k];
+  const float thr2 = cst->cur_thr2, ang2 = cst->cur_ang2;
   if (done) return;  // wave-uniform
   if (i >= n) return;  // whole quads
   float px, py, pz;
@@ -291,8 +294,8 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
   if (sub == 0) {
     const float n2 = (px * px + py * py) + pz * pz;
     const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
-    pair_q[o] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
-    pair_gidx[o] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+    G(reinterpret_cast<f32x4*>(pair_q))[o] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
+    G(pair_gidx)[o] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
   }
 }
 
@@ -365,26 +368,33 @@ __device__ __forceinline__ void k_accum_body(const IcpDeviceState* __restrict__ 
                                                   const uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
                                                   uint32_t pstride) {
   __shared__ BlockSum<kAccN> bs;
-  if (st->done) return;
-  if (!first && st->inner == 0) return;  // the previous solve already closed this ICP iteration
+  // state and parameters through the scalar path (uniform addresses, not written during this kernel); the arrays through
+  // global-space pointers (mh_nn_device.h, G())
+  typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
+  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
+  const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
+  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
+  if (cst->done) return;
+  if (!first && cst->inner == 0) return;  // the previous solve already closed this ICP iteration
   double T[12];
 #pragma unroll
-  for (int i = 0; i < 12; i++) T[i] = st->T[i];
-  const MatchK k = *kp;
-  const double kparam = st->cur_kparam;
+  for (int i = 0; i < 12; i++) T[i] = cst->T[i];
+  struct { uint32_t kernel; double w_pt2pt; } k = {ck->kernel, ck->w_pt2pt};
+  const double kparam = cst->cur_kparam;
   // kAccPPT points per lane: the reduction below is a fixed cost per lane, amortised over four points
   // (the device is VALU-bound once several alignments run concurrently)
   const uint32_t bid = blockIdx.x;
   uint32_t gi[kAccPPT];
-  float4 q[kAccPPT];
+  f32x4 q[kAccPPT];
   float px[kAccPPT], py[kAccPPT], pz[kAccPPT];
+  const auto gq = G(reinterpret_cast<const f32x4*>(pair_q));
 #pragma unroll
   for (int u = 0; u < kAccPPT; u++) {  // all loads first (clamped index), then the arithmetic
     const uint32_t i = (bid * kAccPPT + (uint32_t)u) * kBlock + threadIdx.x;
     const uint32_t ic = i < n ? i : n - 1;
-    gi[u] = i < n ? pair_gidx[ic] : kNoMatch;
-    q[u] = pair_q[ic];
-    px[u] = lx[ic]; py[u] = ly[ic]; pz[u] = lz[ic];
+    gi[u] = i < n ? G(pair_gidx)[ic] : kNoMatch;
+    q[u] = gq[ic];
+    px[u] = G(lx)[ic]; py[u] = G(ly)[ic]; pz[u] = G(lz)[ic];
   }
   Acc a;
   acc_zero(a);
@@ -515,8 +525,8 @@ __global__ __launch_bounds__(kBlock) void k_match_pl(const IcpDeviceState* __res
     uint32_t best_first = 0;
     f32x4 bc = (f32x4)(0.f);
     if (valid) {
-      const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(map.slots);
-      const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(map.pts);
+      const gslots_ptr slots4 = (gslots_ptr)map.slots;
+      const gpts_ptr pts4 = (gpts_ptr)map.pts;
       const unsigned long long kbase = pack_key(voxel_of(px, map.inv_vs, map.trunc) - 1, voxel_of(py, map.inv_vs, map.trunc) - 1,
                                                 voxel_of(pz, map.inv_vs, map.trunc) - 1);
 #pragma unroll 1
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void k_match_pl(const IcpDeviceState* __res
     bool ok = false;
     f32x4 bn = (f32x4)(0.f);
     if (best_first >= 2u) {
-      bn = reinterpret_cast<const f32x4*>(map.pts)[best_first - 1u];
+      bn = ((gpts_ptr)map.pts)[best_first - 1u];
       const float dx = px - bc.x, dy = py - bc.y, dz = pz - bc.z;
       const float e = (bn.x * dx + bn.y * dy) + bn.z * dz;
       ok = fabsf(e) < thr;
@@ -584,8 +594,8 @@ __device__ __forceinline__ bool pl_row_search(const MapView& map, uint32_t r16, 
   nnkey_t best = kNNKeyNone;  // (d2 bits << 32 | code): first strict minimum in scan order
   f32x4 ca = (f32x4)(0.f), na = (f32x4)(0.f), cb = (f32x4)(0.f), nb = (f32x4)(0.f);
   if (valid) {  // row-uniform
-    const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(map.slots);
-    const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(map.pts);
+    const gslots_ptr slots4 = (gslots_ptr)map.slots;
+    const gpts_ptr pts4 = (gpts_ptr)map.pts;
     const unsigned long long kbase = pack_key(voxel_of(px, map.inv_vs, map.trunc) - 1, voxel_of(py, map.inv_vs, map.trunc) - 1,
                                               voxel_of(pz, map.inv_vs, map.trunc) - 1);
     const int code_a = (int)r16, code_b = (int)r16 + 16;
@@ -652,20 +662,26 @@ __device__ __forceinline__ void k_match16_body(const IcpDeviceState* __restrict_
   const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
   const uint32_t i = gl >> 4, r16 = gl & 15u;
   const uint32_t ic = i < n ? i : n - 1;
-  const float x = lx[ic], y = ly[ic], z = lz[ic];
-  const uint32_t done = st->done;
+  const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
+  // state and parameters through the scalar path (uniform addresses, not written during this kernel: mh_nn_device.h)
+  typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
+  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
+  typedef const double __attribute__((address_space(4))) * cf64_ptr;
+  const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
+  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
+  const uint32_t done = cst->done;
   double T[12];
 #pragma unroll
-  for (int k = 0; k < 12; k++) T[k] = st->T[k];
-  const float thr2 = st->cur_thr2, ang2 = st->cur_ang2;
+  for (int k = 0; k < 12; k++) T[k] = cst->T[k];
+  const float thr2 = cst->cur_thr2, ang2 = cst->cur_ang2;
   float pl_thr = 0.f;
-  if (PL) pl_thr = (float)kp->pl_thr[st->iter];
+  if (PL) pl_thr = (float)((cf64_ptr)uniform_const_ptr(ck->pl_thr))[cst->iter];
   uint32_t kernel = 0;
   double kparam = 0.0, wpair = 0.0;
   if (FUSED) {
-    kernel = kp->kernel;
-    wpair = kp->w_pt2pt;
-    kparam = st->cur_kparam;
+    kernel = ck->kernel;
+    wpair = ck->w_pt2pt;
+    kparam = cst->cur_kparam;
   }
   if (done) return;              // grid-uniform
   if (!FUSED && i >= n) return;  // whole rows (FUSED: they stay for the barrier)
@@ -678,16 +694,16 @@ __device__ __forceinline__ void k_match16_body(const IcpDeviceState* __restrict_
     const float n2 = (px * px + py * py) + pz * pz;
     const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
     if (r16 == 0) {
-      pair_q[i] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
-      pair_gidx[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+      G(reinterpret_cast<f32x4*>(pair_q))[i] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
+      G(pair_gidx)[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
     }
     if (FUSED && r16 == 0) acc_pt2pt_masked(a, T, ok, x, y, z, r.pt.x, r.pt.y, r.pt.z, kernel, kparam, wpair);
     if (PL) {
       f32x4 bc, bn;
       const bool okp = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
       if (r16 == 0) {
-        pl_c[i] = make_float4(bc.x, bc.y, bc.z, okp ? 1.f : 0.f);
-        pl_n[i] = make_float4(bn.x, bn.y, bn.z, 0.f);
+        G(reinterpret_cast<f32x4*>(pl_c))[i] = (f32x4){bc.x, bc.y, bc.z, okp ? 1.f : 0.f};
+        G(reinterpret_cast<f32x4*>(pl_n))[i] = (f32x4){bn.x, bn.y, bn.z, 0.f};
       }
     }
   }
@@ -701,7 +717,7 @@ __device__ __forceinline__ void k_match16_body(const IcpDeviceState* __restrict_
       double sum = rows[threadIdx.x][0];
 #pragma unroll
       for (int q = 1; q < (int)(kBlock / 16); q++) sum += rows[threadIdx.x][q];
-      partials[threadIdx.x * pstride + blockIdx.x] = sum;
+      G(partials)[threadIdx.x * pstride + blockIdx.x] = sum;
     }
   }
 }
@@ -773,7 +789,7 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ part, uin
   if (G > 64) G = 64;
   const int v = t / G, g = t % G;
   if (v < nvals) {
-    const double* __restrict__ src = part + (size_t)v * stride;
+    const double MH_AS_GLOBAL* src = (const double MH_AS_GLOBAL*)part + (size_t)v * stride;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
     uint32_t b = g;
     for (; b + 7u * G < n; b += 8u * G) {  // 8 independent loads in flight per lane
@@ -807,7 +823,7 @@ struct SolveShared {
 // (ticket counter + __threadfence): correct, but the device-scope release/acquire fences write back and invalidate the
 // XCDs' L2s on every launch -- the map falls out of cache and C2 drops from 2285 to 960 scans/s.  Kernel boundaries
 // are the cheap way to order producers and consumers on this part.)
-__device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
+__device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, const SolveK* __restrict__ kp_,
                                            const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                            const double* __restrict__ partB, uint32_t nB, uint32_t strideB,
                                            SolveShared& sh, bool totA_ready = false, bool totB_ready = false) {
@@ -815,7 +831,10 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st, cons
   double* totA = sh.totA;
   double* totB = sh.totB;
   double (*sh_log)[6] = sh.sh_log;
-  const SolveK& k = *kp;  // read field by field (uniform loads); the 36-double prior is only touched when present
+  // the parameter block through the scalar path (uniform address, read-only), field by field: the 36-double prior is only
+  // touched when present; the state block through a global-space pointer (mh_nn_device.h, G())
+  const SolveK __attribute__((address_space(4)))& k = *(const SolveK __attribute__((address_space(4)))*)uniform_const_ptr(kp_);
+  IcpDeviceState MH_AS_GLOBAL* const st = G(st_);
   const int lane = threadIdx.x;
   if (nA)
     reduce_rows(partA, nA, strideA, kAccN, totA, red);
@@ -1074,19 +1093,27 @@ __device__ __forceinline__ void k_accum_solve1_body(IcpDeviceState* __restrict__
   MH_PHASE(0);
   const bool acc_lane = threadIdx.x < kOneGroupAccThreads;
   uint32_t gi[kOneGroupBatch];
-  float4 q[kOneGroupBatch], pc[kOneGroupBatch], pn[kOneGroupBatch];
+  f32x4 q[kOneGroupBatch], pc[kOneGroupBatch], pn[kOneGroupBatch];
   float px[kOneGroupBatch], py[kOneGroupBatch], pz[kOneGroupBatch];
+  // arrays through global-space pointers, parameters through the scalar path (mh_nn_device.h, G())
+  const auto g_q = G(reinterpret_cast<const f32x4*>(pair_q)), g_pc = G(reinterpret_cast<const f32x4*>(pl_c)),
+             g_pn = G(reinterpret_cast<const f32x4*>(pl_n));
+  const auto g_gi = G(pair_gidx);
+  const auto g_x = G(lx), g_y = G(ly), g_z = G(lz);
+  IcpDeviceState MH_AS_GLOBAL* const gst = G(st);
+  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
+  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
   if (acc_lane) {
 #pragma unroll
     for (int u = 0; u < kOneGroupBatch; u++) {  // first round of loads: nothing here depends on the state block
       const uint32_t i = (uint32_t)u * kOneGroupAccThreads + threadIdx.x;
       const uint32_t ic = i < n ? i : n - 1;
-      gi[u] = i < n ? pair_gidx[ic] : kNoMatch;
-      q[u] = pair_q[ic];
-      px[u] = lx[ic]; py[u] = ly[ic]; pz[u] = lz[ic];
+      gi[u] = i < n ? g_gi[ic] : kNoMatch;
+      q[u] = g_q[ic];
+      px[u] = g_x[ic]; py[u] = g_y[ic]; pz[u] = g_z[ic];
       if (PL) {
-        pc[u] = pl_c[ic];
-        pn[u] = pl_n[ic];
+        pc[u] = g_pc[ic];
+        pn[u] = g_pn[ic];
         if (i >= n) pc[u].w = 0.f;
       }
     }
@@ -1094,10 +1121,10 @@ __device__ __forceinline__ void k_accum_solve1_body(IcpDeviceState* __restrict__
   // ... and neither do the pose and the parameters wait for the done flag: everything is in flight at once
   double T[12];
 #pragma unroll
-  for (int i = 0; i < 12; i++) T[i] = st->T[i];
-  const MatchK k = *kp;
-  const double kparam = st->cur_kparam;
-  const uint32_t done = st->done, inner0 = st->inner;
+  for (int i = 0; i < 12; i++) T[i] = gst->T[i];
+  struct { uint32_t kernel; double w_pt2pt, w_pt2pl; } k = {ck->kernel, ck->w_pt2pt, ck->w_pt2pl};
+  const double kparam = gst->cur_kparam;
+  const uint32_t done = gst->done, inner0 = gst->inner;
   if (done) return;
   if (!first && inner0 == 0) return;  // the previous solve already closed this ICP iteration
   Acc a;
@@ -1112,7 +1139,8 @@ __device__ __forceinline__ void k_accum_solve1_body(IcpDeviceState* __restrict__
         acc_pt2pt_masked(a, T, gi[u] != kNoMatch, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
         if (PL && pc[u].w != 0.f) {
           double r[kGenN];
-          acc_pt2pl_rows(r, T, px[u], py[u], pz[u], pc[u], pn[u], k.kernel, kparam, k.w_pt2pl);
+          acc_pt2pl_rows(r, T, px[u], py[u], pz[u], make_float4(pc[u].x, pc[u].y, pc[u].z, pc[u].w),
+                         make_float4(pn[u].x, pn[u].y, pn[u].z, pn[u].w), k.kernel, kparam, k.w_pt2pl);
 #pragma unroll
           for (int j = 0; j < kGenN; j++) v[PL ? j : 0] += r[j];
         }
@@ -1123,12 +1151,12 @@ __device__ __forceinline__ void k_accum_solve1_body(IcpDeviceState* __restrict__
       for (int u = 0; u < kOneGroupBatch; u++) {
         const uint32_t i = base + (uint32_t)u * kOneGroupAccThreads + threadIdx.x;
         const uint32_t ic = i < n ? i : n - 1;
-        gi[u] = i < n ? pair_gidx[ic] : kNoMatch;
-        q[u] = pair_q[ic];
-        px[u] = lx[ic]; py[u] = ly[ic]; pz[u] = lz[ic];
+        gi[u] = i < n ? g_gi[ic] : kNoMatch;
+        q[u] = g_q[ic];
+        px[u] = g_x[ic]; py[u] = g_y[ic]; pz[u] = g_z[ic];
         if (PL) {
-          pc[u] = pl_c[ic];
-          pn[u] = pl_n[ic];
+          pc[u] = g_pc[ic];
+          pn[u] = g_pn[ic];
           if (i >= n) pc[u].w = 0.f;
         }
       }

@@ -18,6 +18,15 @@ constexpr uint32_t kNoMatch = 0xFFFFFFFFu;
 // copies become memcpy's that keep arrays of them in scratch memory)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Global-address-space pointers, spelled out: a pointer that reaches a kernel through a descriptor in memory (BatchJob, the
+// lock-step launches) is GENERIC to the compiler and every access through it becomes a flat_load (both memory counters,
+// the aperture check, no scalar path); only pointers that are kernel arguments themselves get the global space inferred.
+// G(p) casts (a no-op for the latter); the table and record pointers of a MapView have types of their own.
+#define MH_AS_GLOBAL __attribute__((address_space(1)))
+typedef const u32x4 MH_AS_GLOBAL* gslots_ptr;
+typedef const f32x4 MH_AS_GLOBAL* gpts_ptr;
+template <class T>
+__device__ __forceinline__ T MH_AS_GLOBAL* G(T* p) { return (T MH_AS_GLOBAL*)p; }
 
 // p' = (float)(R*l + t): double pose x float point, rounded once to float
 // (Matcher_Points_Base::transform_local_to_global [U] -> CPose3D::composePoint; SURVEY App.B U4)
@@ -61,7 +70,7 @@ __device__ __forceinline__ NNResult nn_single_search(const MapView& m, float qx,
   if (!((int)(fabsf(qx * m.inv_vs) < lim) & (int)(fabsf(qy * m.inv_vs) < lim) & (int)(fabsf(qz * m.inv_vs) < lim))) return r;
   const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
   const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
-  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);  // one dwordx4 per slot
+  const gslots_ptr slots4 = (gslots_ptr)m.slots;  // one dwordx4 per slot
   u32x4 s[27];
 #pragma unroll
   for (int c = 0; c < 27; c++) {
@@ -102,7 +111,7 @@ __device__ __forceinline__ NNResult nn_single_search(const MapView& m, float qx,
 #pragma unroll
   for (int col = 0; col < 9; col++) {
     const uint32_t first = first9[col], cnt = cnt9[col];
-    const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(m.pts) + first;
+    const gpts_ptr p = (gpts_ptr)m.pts + first;
     for (uint32_t j = 0; j < cnt; j += 4) {
       const uint32_t last = cnt - 1;
       const f32x4 c0 = p[j];
@@ -187,10 +196,10 @@ __device__ __forceinline__ void nn_consider(const f32x4& c, uint32_t idx, float 
 // all records of one voxel, four loads in flight (offsets clamped into the run instead of predicated: a load inside
 // an `if` makes hipcc wait for it at the end of the branch, which would serialise the round trips; eight in flight
 // measured no faster and costs a wave of occupancy per SIMD)
-__device__ __forceinline__ void nn_scan_voxel(const f32x4* __restrict__ pts, uint32_t first, uint32_t cnt, float qx,
+__device__ __forceinline__ void nn_scan_voxel(gpts_ptr pts, uint32_t first, uint32_t cnt, float qx,
                                               float qy, float qz, NNBest& b) {
   for (uint32_t j = 0; j < cnt; j += 4) {
-    const f32x4* __restrict__ p = pts + (first + j);
+    const gpts_ptr p = pts + (first + j);
     const uint32_t rem = cnt - j;  // >= 1
     f32x4 c[4];
 #pragma unroll
@@ -221,7 +230,7 @@ __device__ __forceinline__ unsigned long long nn_key_of(unsigned long long kbase
   return kbase + ((unsigned long long)ix << 42) + ((unsigned long long)iy << 21) + (unsigned long long)iz;
 }
 
-__device__ __forceinline__ void nn_visit(const MapView& m, const u32x4* __restrict__ slots4, const f32x4* __restrict__ pts4,
+__device__ __forceinline__ void nn_visit(const MapView& m, gslots_ptr slots4, gpts_ptr pts4,
                                          unsigned long long key, u32x4 sl, float qx, float qy, float qz, NNBest& b) {
   unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
   if (sk != key && sk != kEmptyKey) {  // rare: linear probing past a collision
@@ -244,8 +253,8 @@ __device__ __forceinline__ NNResult nn_search_pruned(const MapView& m, float qx,
   if (!((int)(fabsf(qx * m.inv_vs) < lim) & (int)(fabsf(qy * m.inv_vs) < lim) & (int)(fabsf(qz * m.inv_vs) < lim))) return r;
   const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
   const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
-  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
-  const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
+  const gslots_ptr slots4 = (gslots_ptr)m.slots;
+  const gpts_ptr pts4 = (gpts_ptr)m.pts;
   const float vs = m.vs;  // only used for bounds, which carry their own safety margin
   const Gaps gx = axis_gaps(qx, cx, vs, m.trunc), gy = axis_gaps(qy, cy, vs, m.trunc), gz = axis_gaps(qz, cz, vs, m.trunc);
   NNBest b;
@@ -299,7 +308,7 @@ __device__ __forceinline__ NNResult nn_search_pruned(const MapView& m, float qx,
 
 
 // {first, count} of voxel `key` given the slot its hash points at; count 0 when absent or not wanted
-__device__ __forceinline__ void nn_resolve(const MapView& m, const u32x4* __restrict__ slots4, unsigned long long key, u32x4 sl,
+__device__ __forceinline__ void nn_resolve(const MapView& m, gslots_ptr slots4, unsigned long long key, u32x4 sl,
                                            bool want, uint32_t& first, uint32_t& cnt) {
   first = 0;
   cnt = 0;
@@ -370,7 +379,7 @@ __device__ __forceinline__ nnkey_t quad_min_key(nnkey_t k) {
 
 // One round trip: W records per lane of the merged ranges.
 template <int NV, int W>
-__device__ __forceinline__ nnkey_t nn_scan_round_quad(const f32x4* __restrict__ pts4, const uint32_t (&start)[NV],
+__device__ __forceinline__ nnkey_t nn_scan_round_quad(gpts_ptr pts4, const uint32_t (&start)[NV],
                                                       const uint32_t (&pre)[NV + 1], uint32_t t0, uint32_t sub, float qx,
                                                       float qy, float qz, nnkey_t best) {
   const uint32_t total = pre[NV];
@@ -402,7 +411,7 @@ __device__ __forceinline__ nnkey_t nn_scan_round_quad(const f32x4* __restrict__ 
 }
 
 template <int NV>
-__device__ __forceinline__ nnkey_t nn_scan_merged_quad(const f32x4* __restrict__ pts4, const uint32_t (&first)[NV],
+__device__ __forceinline__ nnkey_t nn_scan_merged_quad(gpts_ptr pts4, const uint32_t (&first)[NV],
                                                        const uint32_t (&cnt)[NV], uint32_t sub, float qx, float qy, float qz,
                                                        nnkey_t best) {
   uint32_t pre[NV + 1], start[NV];
@@ -451,8 +460,8 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
   if (!((int)(fabsf(qx * m.inv_vs) < lim) & (int)(fabsf(qy * m.inv_vs) < lim) & (int)(fabsf(qz * m.inv_vs) < lim))) return r;
   const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
   const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
-  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
-  const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
+  const gslots_ptr slots4 = (gslots_ptr)m.slots;
+  const gpts_ptr pts4 = (gpts_ptr)m.pts;
   const float vs = m.vs;
   const Gaps gx = axis_gaps(qx, cx, vs, m.trunc), gy = axis_gaps(qy, cy, vs, m.trunc), gz = axis_gaps(qz, cz, vs, m.trunc);
   const QuadBounds qb = quad_bounds(gx, gy, gz, sub);
@@ -567,7 +576,7 @@ __device__ __forceinline__ nnkey_t row_min_key(nnkey_t k) {
 constexpr int kRowW = 2;  // records per lane and round trip: 16 x 2 = 32 >= one full voxel (cap 20)
 
 template <int NV>
-__device__ __forceinline__ nnkey_t nn_scan_merged_row(const f32x4* __restrict__ pts4, const uint32_t (&first)[NV],
+__device__ __forceinline__ nnkey_t nn_scan_merged_row(gpts_ptr pts4, const uint32_t (&first)[NV],
                                                       const uint32_t (&cnt)[NV], uint32_t r16, float qx, float qy, float qz,
                                                       nnkey_t best) {
   uint32_t pre[NV + 1], start[NV];
@@ -614,8 +623,8 @@ __device__ __forceinline__ NNResult nn_search_row16(const MapView& m, uint32_t r
   if (!((int)(fabsf(qx * m.inv_vs) < lim) & (int)(fabsf(qy * m.inv_vs) < lim) & (int)(fabsf(qz * m.inv_vs) < lim))) return r;
   const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
   const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
-  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
-  const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
+  const gslots_ptr slots4 = (gslots_ptr)m.slots;
+  const gpts_ptr pts4 = (gpts_ptr)m.pts;
   const float vs = m.vs;
   const Gaps gx = axis_gaps(qx, cx, vs, m.trunc), gy = axis_gaps(qy, cy, vs, m.trunc), gz = axis_gaps(qz, cz, vs, m.trunc);
   // round 1: lane r owns codes r ("a") and r + 16 ("b", only r <= 10)
@@ -790,8 +799,8 @@ __device__ __forceinline__ NNResult nn_search_tile(const MapView& m, TileShared&
   const int ox = lo[0] - 1, oy = lo[1] - 1, oz = lo[2] - 1;
   const long long ex = (long long)hi[0] - lo[0] + 3, ey = (long long)hi[1] - lo[1] + 3, ez = (long long)hi[2] - lo[2] + 3;
   const long long nvox_l = ex * ey * ez;
-  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
-  const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
+  const gslots_ptr slots4 = (gslots_ptr)m.slots;
+  const gpts_ptr pts4 = (gpts_ptr)m.pts;
   bool fits = nvox_l <= (long long)kTileMaxVox;
   const int dy = (int)ey, dz = (int)ez, dydz = dy * dz;
   const uint32_t nvox = fits ? (uint32_t)nvox_l : 0u;
@@ -1056,8 +1065,8 @@ __device__ __forceinline__ NNResult nn_search_wave(const MapView& m, WaveShared*
   const int lo_x = wave_min_i32(valid ? cx : big), lo_y = wave_min_i32(valid ? cy : big), lo_z = wave_min_i32(valid ? cz : big);
   const int hi_x = wave_max_i32(valid ? cx : -big), hi_y = wave_max_i32(valid ? cy : -big), hi_z = wave_max_i32(valid ? cz : -big);
   if (hi_x < lo_x) return r;  // no valid point in the tile (wave-uniform)
-  const u32x4* __restrict__ slots4 = reinterpret_cast<const u32x4*>(m.slots);
-  const f32x4* __restrict__ pts4 = reinterpret_cast<const f32x4*>(m.pts);
+  const gslots_ptr slots4 = (gslots_ptr)m.slots;
+  const gpts_ptr pts4 = (gpts_ptr)m.pts;
   const int ox = lo_x - 1, oy = lo_y - 1, oz = lo_z - 1;
   const long long ex = (long long)hi_x - lo_x + 3, ey = (long long)hi_y - lo_y + 3, ez = (long long)hi_z - lo_z + 3;
   const long long nvox_l = ex * ey * ez;
