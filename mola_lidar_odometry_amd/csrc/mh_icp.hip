@@ -277,11 +277,17 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
   const uint32_t i = gl >> 2, sub = gl & 3u;
   const uint32_t ic = i < n ? i : n - 1;
   const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
-  const uint32_t o = perm ? G(perm)[ic] : i;
+  const uint32_t o = perm ? G(perm)[ic] : ic;  // (clamped: lanes past the end of a short job of a batch read, and never write)
   // the state block through the scalar path (uniform address, not written during this kernel): the pose in SGPRs
   typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
   const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
   const uint32_t done = cst->done;
+  // From the second ICP iteration on, pair_q[o] still holds the record this point was paired with under the previous
+  // pose: its distance under the new pose bounds the search (nn_search_quad).  Iteration 0 of every alignment starts
+  // without one (the buffer may hold another scan's pairings).
+  const bool have_prev = cst->iter > 0 && !map.no_prev_bound;
+  f32x4 prev = (f32x4){0.f, 0.f, 0.f, __builtin_inff()};
+  if (have_prev) prev = G(reinterpret_cast<const f32x4*>(pair_q))[o];  // grid-uniform branch
   double T[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) T[k] = cst->T[k];
@@ -290,7 +296,12 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
   if (i >= n) return;  // whole quads
   float px, py, pz;
   transform_point(T, x, y, z, px, py, pz);
-  const NNResult r = nn_search_quad(map, sub, px, py, pz);
+  float bound0 = __builtin_inff();
+  if (prev.w < __builtin_inff()) {  // a record was found last time (whatever the threshold said)
+    const float dx = prev.x - px, dy = prev.y - py, dz = prev.z - pz;
+    bound0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic of nn_scan_round_quad
+  }
+  const NNResult r = nn_search_quad(map, sub, px, py, pz, bound0);
   if (sub == 0) {
     const float n2 = (px * px + py * py) + pz * pz;
     const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);

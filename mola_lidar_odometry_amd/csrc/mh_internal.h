@@ -80,6 +80,7 @@ struct MapView {
   float vs;           // 1.0f / inv_vs, divided once on the host (the kernels only need it for the pruning bounds)
   uint32_t trunc;     // index_mode == MH_INDEX_TRUNC
   uint32_t ndt;       // 1: every voxel's points are preceded by two records {centroid, plane flag} {normal, 0}
+  uint32_t no_prev_bound;  // A/B switch (MH_NO_PREV_BOUND=1): the quad matcher ignores the previous iteration's pairing
 #ifdef MH_DEBUG_WAVETRACE
   uint32_t dbg_stop;  // debug build: leave the quad search after phase N (tools/wavetrace_probe.py)
 #endif
@@ -170,6 +171,8 @@ struct mh_map {
     v.vs = 1.0f / inv_vs;
     v.trunc = params.index_mode == MH_INDEX_TRUNC;
     v.ndt = params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
+    static const bool no_prev = getenv("MH_NO_PREV_BOUND") != nullptr;
+    v.no_prev_bound = no_prev ? 1u : 0u;
 #ifdef MH_DEBUG_WAVETRACE
     v.dbg_stop = getenv("MH_DBG_STOP") ? (uint32_t)atoi(getenv("MH_DBG_STOP")) : 0u;
 #endif

@@ -216,9 +216,10 @@ __device__ __forceinline__ float nn_lower_bound(int code, const Gaps& gx, const 
   const int r = code - 9 * ix;
   const int iy = (r * 11) >> 5;     // r / 3 for r < 9
   const int iz = r - 3 * iy;
-  const float sx = ix == 0 ? gx.s[0] : (ix == 1 ? 0.f : gx.s[2]);
-  const float sy = iy == 0 ? gy.s[0] : (iy == 1 ? 0.f : gy.s[2]);
-  const float sz = iz == 0 ? gz.s[0] : (iz == 1 ? 0.f : gz.s[2]);
+  // (one-level selects and a max of two non-negative values: hipcc turns the nested form into exec-mask branches)
+  const float sx = fmaxf(ix == 0 ? gx.s[0] : 0.f, ix == 2 ? gx.s[2] : 0.f);
+  const float sy = fmaxf(iy == 0 ? gy.s[0] : 0.f, iy == 2 ? gy.s[2] : 0.f);
+  const float sz = fmaxf(iz == 0 ? gz.s[0] : 0.f, iz == 2 ? gz.s[2] : 0.f);
   return (sx + sy) + sz;
 }
 
@@ -426,32 +427,46 @@ __device__ __forceinline__ nnkey_t nn_scan_merged_quad(gpts_ptr pts4, const uint
   return quad_min_key(best);
 }
 
-// the neighbour codes lane `sub` of a quad is responsible for when the bound is evaluated: sub, sub+4, ... (< 27, != 13)
+// The neighbour codes lane `sub` of a quad is responsible for when the bound is evaluated: the nine codes with iz == sub
+// (code = ix*9 + iy*3 + iz; lane 3 has none).  Per lane that is one select for the z gap and 4 + 9 additions in the order of
+// nn_lower_bound -- (sx + sy) + sz -- instead of seven decompositions of a lane-dependent code (140 vector instructions
+// of the 900 a wave spends on its sixteen points went into those).
 struct QuadBounds {
-  float lb[7];  // conservative lower bounds of codes sub + 4j (inf for code 13 / >= 27)
+  float lb[9];  // conservative lower bounds of codes (ix*3 + iy)*3 + sub, index ix*3 + iy (lane 3: +inf)
 };
 __device__ __forceinline__ QuadBounds quad_bounds(const Gaps& gx, const Gaps& gy, const Gaps& gz, uint32_t sub) {
   QuadBounds q;
+  const float zs = sub == 0 ? gz.s[0] : (sub == 1 ? 0.f : (sub == 2 ? gz.s[2] : __builtin_inff()));
 #pragma unroll
-  for (int j = 0; j < 7; j++) {
-    const int code = (int)sub + 4 * j;
-    q.lb[j] = (code == 13 || code >= 27) ? __builtin_inff() : nn_lower_bound(code, gx, gy, gz) * 0.9999f;
-  }
+  for (int ix = 0; ix < 3; ix++)
+#pragma unroll
+    for (int iy = 0; iy < 3; iy++) {
+      const float sx = ix == 1 ? 0.f : gx.s[ix], sy = iy == 1 ? 0.f : gy.s[iy];
+      q.lb[ix * 3 + iy] = ((sx + sy) + zs) * 0.9999f;
+    }
   return q;
 }
-// bit `code` set iff the voxel can still hold the winner; each lane tests its 7 codes, the quad ORs them together
+// bit `code` set iff the voxel can still hold the winner; each lane tests its nine codes, the quad ORs them together
 __device__ __forceinline__ uint32_t quad_bound_mask(const QuadBounds& q, uint32_t sub, float best) {
   uint32_t mine = 0;
 #pragma unroll
-  for (int j = 0; j < 7; j++) mine |= (!(q.lb[j] > best)) ? (1u << (4 * j)) : 0u;
-  mine <<= sub;
+  for (int j = 0; j < 9; j++) mine |= (!(q.lb[j] > best)) ? (1u << (3 * j)) : 0u;
+  mine = sub < 3u ? mine << sub : 0u;
   mine |= quad_u32<0xB1>(mine);
   mine |= quad_u32<0x4E>(mine);
   return mine & 0x07FFFFFFu & ~(1u << 13);
 }
 
-// every lane of the quad passes the same q and gets the same result
-__device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t sub, float qx, float qy, float qz) {
+// every lane of the quad passes the same q and gets the same result.
+// bound0: an upper bound of the answer's d2 that is KNOWN to be attained by a map record (the distance, in the candidate
+// arithmetic, from q to the record this point was paired with in the previous ICP iteration), or +inf.  With a bound the
+// search skips the own-voxel-first protocol: every voxel whose lower bound does not exceed it -- the own voxel and, for a
+// converging alignment, one neighbour or none -- is probed in ONE round trip and scanned in one more.  The result is the
+// same: the answer's voxel has a lower bound <= the answer's d2 <= bound0, so it is scanned, and ties resolve by the
+// usual (d2, record) key.  Should bound0 not be attained inside the 27-voxel block (the point moved more than a voxel
+// away from its old partner), nothing beats the initial key and the search runs again without a bound.
+__device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t sub, float qx, float qy, float qz,
+                                                   float bound0 = __builtin_inff()) {
   NNResult r;
   r.d2 = __builtin_inff();
   r.found = false;
@@ -469,17 +484,25 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
 #ifdef MH_DEBUG_WAVETRACE
   if (m.dbg_stop == 1) return r;  // prologue only
 #endif
-  // Speculative probes, issued together with the own-voxel probe (same round trip): the three faces on the near side
-  // of each axis and the edge between the two nearest of them -- almost always the only neighbours that survive the
-  // bound once the own voxel has been scanned.  Lane s of the quad probes the s-th of them.
-  const int sx = gx.s[0] <= gx.s[2] ? 0 : 2, sy = gy.s[0] <= gy.s[2] ? 0 : 2, sz = gz.s[0] <= gz.s[2] ? 0 : 2;
-  const float nx = gx.s[sx], ny = gy.s[sy], nz = gz.s[sz];
-  const int c_fx = sx * 9 + 3 + 1, c_fy = 9 + sy * 3 + 1, c_fz = 9 + 3 + sz;
-  const int c_e = (nz >= nx && nz >= ny) ? sx * 9 + sy * 3 + 1 : (ny >= nx ? sx * 9 + 3 + sz : 9 + sy * 3 + sz);
-  const int c_spec = sub == 0 ? c_fx : (sub == 1 ? c_fy : (sub == 2 ? c_fz : c_e));
-  const uint32_t spec_bits = (1u << c_fx) | (1u << c_fy) | (1u << c_fz) | (1u << c_e);
-  const unsigned long long key_s = nn_key_of(kbase, c_spec);
-  {  // the query's own voxel (code 13): the four lanes read the same slot
+  const uint32_t kFaces = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 14) | (1u << 16) | (1u << 22);
+  const uint32_t kCorners = (1u << 0) | (1u << 2) | (1u << 6) | (1u << 8) | (1u << 18) | (1u << 20) | (1u << 24) | (1u << 26);
+  const uint32_t kEdges = 0x07FFFFFFu & ~(kFaces | kCorners | (1u << 13));
+  const bool bounded = bound0 < __builtin_inff();  // the same in the four lanes
+  uint32_t todo = 0x07FFFFFFu;
+  if (bounded) {
+    best = ((nnkey_t)__float_as_uint(bound0) << 32) | 0xFFFFFFFFull;
+  } else {
+    // Speculative probes, issued together with the own-voxel probe (same round trip): the three faces on the near side
+    // of each axis and the edge between the two nearest of them -- almost always the only neighbours that survive the
+    // bound once the own voxel has been scanned.  Lane s of the quad probes the s-th of them.
+    const int sx = gx.s[0] <= gx.s[2] ? 0 : 2, sy = gy.s[0] <= gy.s[2] ? 0 : 2, sz = gz.s[0] <= gz.s[2] ? 0 : 2;
+    const float nx = gx.s[sx], ny = gy.s[sy], nz = gz.s[sz];
+    const int c_fx = sx * 9 + 3 + 1, c_fy = 9 + sy * 3 + 1, c_fz = 9 + 3 + sz;
+    const int c_e = (nz >= nx && nz >= ny) ? sx * 9 + sy * 3 + 1 : (ny >= nx ? sx * 9 + 3 + sz : 9 + sy * 3 + sz);
+    const int c_spec = sub == 0 ? c_fx : (sub == 1 ? c_fy : (sub == 2 ? c_fz : c_e));
+    const uint32_t spec_bits = (1u << c_fx) | (1u << c_fy) | (1u << c_fz) | (1u << c_e);
+    const unsigned long long key_s = nn_key_of(kbase, c_spec);
+    // the query's own voxel (code 13): the four lanes read the same slot
     const unsigned long long key = nn_key_of(kbase, 13);
     const u32x4 sl_c = slots4[hash_key(key) & m.mask];
     const u32x4 sl_s = slots4[hash_key(key_s) & m.mask];
@@ -501,32 +524,43 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
     const uint32_t first[4] = {quad_bcast<0>(f_s), quad_bcast<1>(f_s), quad_bcast<2>(f_s), quad_bcast<3>(f_s)};
     const uint32_t cnt[4] = {quad_bcast<0>(n_s), quad_bcast<1>(n_s), quad_bcast<2>(n_s), quad_bcast<3>(n_s)};
     best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best);
+    todo &= ~(1u << 13) & ~spec_bits;
   }
-  const uint32_t kFaces = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 14) | (1u << 16) | (1u << 22);
-  const uint32_t kCorners = (1u << 0) | (1u << 2) | (1u << 6) | (1u << 8) | (1u << 18) | (1u << 20) | (1u << 24) | (1u << 26);
-  const uint32_t kEdges = 0x07FFFFFFu & ~(kFaces | kCorners | (1u << 13));
-  uint32_t todo = 0x07FFFFFFu & ~(1u << 13) & ~spec_bits;
-  for (;;) {
-    // voxels that can still hold the winner (one evaluation per batch); nearest class first: faces, edges, corners
-    const uint32_t live = todo & quad_bound_mask(qb, sub, nnkey_d2(best));
-    if (!live) break;
-    const uint32_t lf = live & kFaces, le = live & kEdges;
-    uint32_t mm = lf ? lf : (le ? le : live);
-    int c_mine = -1;
+  for (int pass = 0; pass < 2; pass++) {
+    for (;;) {
+      // voxels that can still hold the winner (one evaluation per batch), the own voxel always among them while it is to do
+      const uint32_t live = todo & (quad_bound_mask(qb, sub, nnkey_d2(best)) | (1u << 13));
+      if (!live) break;
+      // four of them, nearest class first: own voxel and faces, edges, corners.  Without a bound a batch stays inside one
+      // class (the scan of the faces usually prunes the edges); with one it is filled up across classes (the bound is
+      // tight already, a second round trip costs more than the candidates it could save)
+      uint32_t rem = live;
+      const uint32_t ln = live & (kFaces | (1u << 13)), le = live & kEdges;
+      if (!bounded || pass) rem = ln ? ln : (le ? le : live);
+      int c_mine = -1;
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
-      const int cv = mm ? __builtin_ctz(mm) : -1;
-      mm &= mm - 1;
-      if (cv >= 0) todo &= ~(1u << cv);
-      c_mine = (uint32_t)v == sub ? cv : c_mine;
+      for (int v = 0; v < 4; v++) {
+        const uint32_t n1 = rem & (kFaces | (1u << 13)), n2 = rem & kEdges;
+        const uint32_t cls = n1 ? n1 : (n2 ? n2 : rem);
+        const int cv = cls ? __builtin_ctz(cls) : -1;
+        if (cv >= 0) {
+          rem &= ~(1u << cv);
+          todo &= ~(1u << cv);
+        }
+        c_mine = (uint32_t)v == sub ? cv : c_mine;
+      }
+      const unsigned long long key = nn_key_of(kbase, c_mine < 0 ? 0 : c_mine);
+      const u32x4 sl = slots4[hash_key(key) & m.mask];  // one probe per lane, four per point in flight
+      uint32_t f_mine, n_mine;
+      nn_resolve(m, slots4, key, sl, c_mine >= 0, f_mine, n_mine);
+      const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
+      const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
+      best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best);
     }
-    const unsigned long long key = nn_key_of(kbase, c_mine < 0 ? 0 : c_mine);
-    const u32x4 sl = slots4[hash_key(key) & m.mask];  // one probe per lane, four per point in flight
-    uint32_t f_mine, n_mine;
-    nn_resolve(m, slots4, key, sl, c_mine >= 0, f_mine, n_mine);
-    const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
-    const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
-    best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best);
+    if (!bounded || nnkey_idx(best) != 0xFFFFFFFFu) break;
+    // the bound was not attained inside the block: once more, without it
+    best = kNNKeyNone;
+    todo = 0x07FFFFFFu;
   }
 #ifdef MH_DEBUG_WAVETRACE
   if (m.dbg_stop == 4) { r.d2 = nnkey_d2(best); return r; }  // + neighbours, without the final record fetch
