@@ -39,10 +39,8 @@ using namespace mh;
 
 constexpr uint32_t kBlock = 256;
 #ifndef MH_QUAD_WAVES
-#define MH_QUAD_WAVES 8  // waves per SIMD the register allocator has to make room for in the quad kernel: 64 VGPRs.  With
-                         // MH_QUAD_W = 3 records in flight per lane that fits without scratch (W = 4 / 5 spill 6 / 15
-                         // registers and measured 7-13 % slower; W = 5 at its natural 78 VGPRs = 6 waves was the
-                         // default before: C2 2407-2455 scans/s, this 2515)
+#define MH_QUAD_WAVES 8  // waves per SIMD the register allocator has to make room for in the quad kernel: 64 VGPRs, which
+                         // MH_QUAD_W = 4 records in flight per lane fit without scratch (mh_nn_device.h has the sweep)
 #endif
 #ifndef MH_MATCH_WAVES
 #define MH_MATCH_WAVES 1  // min waves per SIMD asked of the register allocator for k_match (tuning knob)

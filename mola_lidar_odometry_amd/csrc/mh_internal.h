@@ -171,8 +171,7 @@ struct mh_map {
     v.vs = 1.0f / inv_vs;
     v.trunc = params.index_mode == MH_INDEX_TRUNC;
     v.ndt = params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
-    static const bool no_prev = getenv("MH_NO_PREV_BOUND") != nullptr;
-    v.no_prev_bound = no_prev ? 1u : 0u;
+    v.no_prev_bound = getenv("MH_NO_PREV_BOUND") != nullptr ? 1u : 0u;
 #ifdef MH_DEBUG_WAVETRACE
     v.dbg_stop = getenv("MH_DBG_STOP") ? (uint32_t)atoi(getenv("MH_DBG_STOP")) : 0u;
 #endif

@@ -347,8 +347,10 @@ __device__ __forceinline__ void nn_resolve(const MapView& m, gslots_ptr slots4, 
 //     the loads of a round to be issued unconditionally, an XCD-contiguous block order, other workgroup sizes.
 // -------------------------------------------------------------------------------------------------
 #ifndef MH_QUAD_W
-#define MH_QUAD_W 3  // candidates per lane and round trip: 4 x 3 = 12.  (5 = one full voxel of 20 per round trip costs 14
-                     // more VGPRs: 6 instead of 8 waves per SIMD, see MH_QUAD_WAVES in mh_icp.hip)
+#define MH_QUAD_W 4  // candidates per lane and round trip: 4 x 4 = 16.  Round 2 (search bounded by the previous pairing, 58
+                     // VGPRs at W = 3): W = 4 still fits 64 VGPRs / 8 waves per SIMD without scratch and measured 8.16 us
+                     // per scan in lock step against 8.45 (W = 3), 8.60 (W = 5 at 70 VGPRs / 7 waves), 9.4 (W = 5 with
+                     // scratch, W = 6): see MH_QUAD_WAVES in mh_icp.hip
 #endif
 constexpr int kQuadW = MH_QUAD_W;
 
@@ -527,27 +529,36 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
     todo &= ~(1u << 13) & ~spec_bits;
   }
   for (int pass = 0; pass < 2; pass++) {
-    for (;;) {
-      // voxels that can still hold the winner (one evaluation per batch), the own voxel always among them while it is to do
-      const uint32_t live = todo & (quad_bound_mask(qb, sub, nnkey_d2(best)) | (1u << 13));
-      if (!live) break;
-      // four of them, nearest class first: own voxel and faces, edges, corners.  Without a bound a batch stays inside one
-      // class (the scan of the faces usually prunes the edges); with one it is filled up across classes (the bound is
-      // tight already, a second round trip costs more than the candidates it could save)
-      uint32_t rem = live;
-      const uint32_t ln = live & (kFaces | (1u << 13)), le = live & kEdges;
-      if (!bounded || pass) rem = ln ? ln : (le ? le : live);
+    // voxels that can still hold the winner, the own voxel always among them while it is to do.  The bound only ever
+    // tightens, so the set only shrinks: it is re-evaluated after a batch only if something of it is left.
+    uint32_t cand = todo & (quad_bound_mask(qb, sub, nnkey_d2(best)) | (1u << 13));
+    while (cand) {
       int c_mine = -1;
+      if (bounded && pass == 0) {
+        // with a bound: lane 0 takes the own voxel, the others the three lowest codes of the rest (the order matters
+        // little when the bound is tight already: nearly always this is the only batch)
+        const uint32_t own = cand & (1u << 13);
+        uint32_t rem = cand & ~(1u << 13);
+        const uint32_t b1 = rem & (0u - rem);
+        rem ^= b1;
+        const uint32_t b2 = rem & (0u - rem);
+        rem ^= b2;
+        const uint32_t b3 = rem & (0u - rem);
+        const uint32_t bm = sub == 0 ? own : (sub == 1 ? b1 : (sub == 2 ? b2 : b3));
+        c_mine = bm ? __builtin_ctz(bm) : -1;
+        cand &= ~(own | b1 | b2 | b3);
+      } else {
+        // without one: four of them from the nearest class that has any -- own voxel and faces, then edges, then
+        // corners (the scan of the faces usually prunes the edges)
+        const uint32_t ln = cand & (kFaces | (1u << 13)), le = cand & kEdges;
+        uint32_t rem = ln ? ln : (le ? le : cand);
 #pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const uint32_t n1 = rem & (kFaces | (1u << 13)), n2 = rem & kEdges;
-        const uint32_t cls = n1 ? n1 : (n2 ? n2 : rem);
-        const int cv = cls ? __builtin_ctz(cls) : -1;
-        if (cv >= 0) {
-          rem &= ~(1u << cv);
-          todo &= ~(1u << cv);
+        for (int v = 0; v < 4; v++) {
+          const int cv = rem ? __builtin_ctz(rem) : -1;
+          rem &= rem - 1;
+          if (cv >= 0) cand &= ~(1u << cv);
+          c_mine = (uint32_t)v == sub ? cv : c_mine;
         }
-        c_mine = (uint32_t)v == sub ? cv : c_mine;
       }
       const unsigned long long key = nn_key_of(kbase, c_mine < 0 ? 0 : c_mine);
       const u32x4 sl = slots4[hash_key(key) & m.mask];  // one probe per lane, four per point in flight
@@ -556,6 +567,7 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
       const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
       const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
       best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best);
+      if (cand) cand &= quad_bound_mask(qb, sub, nnkey_d2(best)) | (1u << 13);
     }
     if (!bounded || nnkey_idx(best) != 0xFFFFFFFFu) break;
     // the bound was not attained inside the block: once more, without it

@@ -673,3 +673,31 @@ def test_every_kernel_variant_matches_the_oracle(ctx, oracle, env, n_scan, monke
     np.testing.assert_array_equal(g["pairs"]["global_idx"], o["pairs"]["global_idx"])
     np.testing.assert_array_equal(g["pairs"]["d2"], o["pairs"]["d2"])
     np.testing.assert_allclose(g["T"], o["T"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("vs,shift", [(0.25, 0.9), (0.4, 0.6), (1.0, 0.3)])
+def test_previous_pairing_bound_and_its_fallback(ctx, oracle, vs, shift, monkeypatch):
+    """From the second iteration on the quad matcher bounds its search by the distance to the record a point was paired with
+    before (nn_search_quad, bound0).  Small voxels and a guess that is several voxels off: between iterations points
+    move by more than a voxel, the old partner leaves the 27-voxel block, the bound is not attained inside it and the
+    search has to run again without one -- per-iteration pair counts, final pairings and d2 stay the oracle's, bit for bit,
+    with the bound and without (MH_NO_PREV_BOUND)."""
+    scene = synth.make_scene(777, 60.0, 20)
+    mp = synth.make_map(scene, 150000, 777)
+    pose = [0.7, -0.4, synth.SENSOR_H, 0.03, 0.002, -0.002]
+    scan = synth.make_scan(scene, pose, rings=48, azimuths=500, seed=5)[:20000]
+    guess = synth.pose_from_ypr(np.array(pose) + [shift, -0.5 * shift, 0.05, 0.02, 0.003, 0.002])
+    thr, kp = synth.threshold_schedule(2.0, 40)
+    kw = dict(max_iterations=40, threshold=thr, kernel_param=kp)
+    o = oracle.icp_align(oracle.Map(vs, 20).insert(mp), scan, guess, oracle.ICPParams(**kw), want_pairs=True)
+    monkeypatch.setenv("MH_MATCH", "q")
+    gm, gs = capi.Map(ctx, vs, 20).build(mp), capi.Scan(ctx, scan)
+    for no_bound in (False, True):
+        if no_bound:
+            monkeypatch.setenv("MH_NO_PREV_BOUND", "1")
+        g = capi.icp_align(gm, gs, guess, capi.ICPParams(**kw), want_pairs=True)
+        assert g["n_iterations"] == o["n_iterations"] and g["termination_reason"] == o["termination_reason"]
+        assert [t["n_pairs"] for t in g["trace"]] == [t["n_pairs"] for t in o["trace"]]
+        for k in ("local_idx", "global_idx", "d2", "global_xyz"):
+            np.testing.assert_array_equal(g["pairs"][k], o["pairs"][k])
+        np.testing.assert_allclose(g["T"], o["T"], rtol=0, atol=1e-9)
