@@ -42,6 +42,9 @@ constexpr uint32_t kBlock = 256;
 #define MH_QUAD_WAVES 8  // waves per SIMD the register allocator has to make room for in the quad kernel: 64 VGPRs, which
                          // MH_QUAD_W = 4 records in flight per lane fit without scratch (mh_nn_device.h has the sweep)
 #endif
+#ifndef MH_ACCUM_WAVES
+#define MH_ACCUM_WAVES 1  // min waves per SIMD asked of the register allocator for k_accum (tuning knob)
+#endif
 #ifndef MH_MATCH_WAVES
 #define MH_MATCH_WAVES 1  // min waves per SIMD asked of the register allocator for k_match (tuning knob)
 #endif
@@ -178,6 +181,49 @@ template <int NV>
 __device__ __forceinline__ void block_sum_rows(const double* v, BlockSum<NV>& sh, double* __restrict__ partials,
                                                uint32_t pstride, uint32_t bid) {
   block_sum_rows_raw<NV>(v, sh.tr, &sh.p1[0][0], partials, pstride, bid);
+}
+
+// The same with the four lanes of every DPP quad added first (two quad_perm steps per value, VALU only): a quarter of the
+// LDS (k_accum: 9.6 KiB per workgroup instead of 37.6, which had capped it at four waves per SIMD) and a quarter of the
+// transposed reads.  Fixed order as well.
+template <int NV>
+struct BlockSumQ {
+  static constexpr int kL = (int)kBlock / 4;
+  static constexpr int kG0 = kL / NV;
+  static constexpr int kChunk = ((kL + kG0 - 1) / kG0) | 1;
+  static constexpr int kGroups = (kL + kChunk - 1) / kChunk;
+  static_assert(kG0 >= 1 && NV * kGroups <= (int)kBlock, "one thread per (row, group)");
+  double tr[NV][kL + 1];
+  double p1[NV][kGroups];
+};
+template <int NV>
+__device__ __forceinline__ void block_sum_rows_quad(const double* v, BlockSumQ<NV>& sh, double* __restrict__ partials,
+                                                    uint32_t pstride, uint32_t bid) {
+  constexpr int G = BlockSumQ<NV>::kGroups, C = BlockSumQ<NV>::kChunk, L = BlockSumQ<NV>::kL;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    double q = v[j];
+    q += dpp_f64<0xB1>(q);  // quad_perm:[1,0,3,2]
+    q += dpp_f64<0x4E>(q);  // quad_perm:[2,3,0,1]
+    if ((threadIdx.x & 3u) == 0u) sh.tr[j][threadIdx.x >> 2] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV * G) {
+    const int j = threadIdx.x / G, g = threadIdx.x % G;
+    const int l0 = g * C;
+    double sum = sh.tr[j][l0];
+#pragma unroll
+    for (int i = 1; i < C; i++)
+      if (l0 + i < L) sum += sh.tr[j][l0 + i];
+    sh.p1[j][g] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double sum = sh.p1[threadIdx.x][0];
+#pragma unroll
+    for (int g = 1; g < G; g++) sum += sh.p1[threadIdx.x][g];
+    ((double MH_AS_GLOBAL*)partials)[threadIdx.x * pstride + bid] = sum;
+  }
 }
 
 // ================================================================================================
@@ -376,7 +422,7 @@ __device__ __forceinline__ void k_accum_body(const IcpDeviceState* __restrict__ 
                                                   const float4* __restrict__ pair_q,
                                                   const uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
                                                   uint32_t pstride) {
-  __shared__ BlockSum<kAccN> bs;
+  __shared__ BlockSumQ<kAccN> bs;
   // state and parameters through the scalar path (uniform addresses, not written during this kernel); the arrays through
   // global-space pointers (mh_nn_device.h, G())
   typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
@@ -410,7 +456,7 @@ __device__ __forceinline__ void k_accum_body(const IcpDeviceState* __restrict__ 
 #pragma unroll
   for (int u = 0; u < kAccPPT; u++)
     acc_pt2pt_masked(a, T, gi[u] != kNoMatch, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
-  block_sum_rows<kAccN>(a.v, bs, partials, pstride, bid);
+  block_sum_rows_quad<kAccN>(a.v, bs, partials, pstride, bid);
 }
 
 // point-to-plane rows (Matcher_Point2Plane pairings, lidar3d-ndt.yaml:195-200): e = n.(R l + t - c),
@@ -1563,7 +1609,7 @@ static inline bool wave_lds_env() { static const bool v = getenv("MH_WAVE_LDS") 
     hipLaunchKernelGGL(k_match_wave_sparse, dim3((SC)->n_tiles), dim3(kBlock), 0, S, ST, (SC)->sx, (SC)->sy, (SC)->sz,      \
                        (SC)->perm, (SC)->tile_start, (SC)->n_tiles, MV, PQ, PG WT);                                        \
   } while (0)
-__global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first,
+__global__ __launch_bounds__(kBlock, MH_ACCUM_WAVES) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first,
                                                   const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                   const float4* __restrict__ pair_q,
@@ -1571,7 +1617,7 @@ __global__ __launch_bounds__(kBlock) void k_accum(const IcpDeviceState* __restri
                                                   uint32_t pstride) {
   k_accum_body(st, first, kp, lx, ly, lz, n, pair_q, pair_gidx, partials, pstride);
 }
-__global__ __launch_bounds__(kBlock) void k_accum_b(const BatchJob* __restrict__ jobs, uint32_t first) {
+__global__ __launch_bounds__(kBlock, MH_ACCUM_WAVES) void k_accum_b(const BatchJob* __restrict__ jobs, uint32_t first) {
   const BatchJob& j = jobs[blockIdx.y];
   if (blockIdx.x >= j.nba) return;
   k_accum_body(j.st, first, j.mk, j.lx, j.ly, j.lz, j.n, j.pair_q, j.pair_gidx, j.part, j.nba);
