@@ -725,6 +725,10 @@ __device__ __forceinline__ void k_match16_body(const IcpDeviceState* __restrict_
   const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
   const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
   const uint32_t done = cst->done;
+  // the record paired with this point under the previous pose bounds the search (k_match4_body has the story)
+  const bool have_prev = cst->iter > 0 && !map.no_prev_bound;
+  f32x4 prev = (f32x4){0.f, 0.f, 0.f, __builtin_inff()};
+  if (have_prev) prev = G(reinterpret_cast<const f32x4*>(pair_q))[ic];  // grid-uniform branch
   double T[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) T[k] = cst->T[k];
@@ -745,7 +749,12 @@ __device__ __forceinline__ void k_match16_body(const IcpDeviceState* __restrict_
   if (i < n) {  // row-uniform
     float px, py, pz;
     transform_point(T, x, y, z, px, py, pz);
-    const NNResult r = nn_search_row16(map, r16, px, py, pz);
+    float bound0 = __builtin_inff();
+    if (prev.w < __builtin_inff()) {
+      const float dx = prev.x - px, dy = prev.y - py, dz = prev.z - pz;
+      bound0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic of the scans
+    }
+    const NNResult r = nn_search_row16(map, r16, px, py, pz, bound0);
     const float n2 = (px * px + py * py) + pz * pz;
     const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
     if (r16 == 0) {

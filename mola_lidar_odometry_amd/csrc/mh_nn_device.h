@@ -660,7 +660,10 @@ __device__ __forceinline__ nnkey_t nn_scan_merged_row(gpts_ptr pts4, const uint3
 }
 
 // every lane of the row passes the same q and gets the same result
-__device__ __forceinline__ NNResult nn_search_row16(const MapView& m, uint32_t r16, float qx, float qy, float qz) {
+// bound0: as for nn_search_quad -- the distance to the record paired with this point in the previous iteration (or +inf):
+// the own voxel then joins the first batch of neighbours instead of having a round trip of its own.
+__device__ __forceinline__ NNResult nn_search_row16(const MapView& m, uint32_t r16, float qx, float qy, float qz,
+                                                    float bound0 = __builtin_inff()) {
   NNResult r;
   r.d2 = __builtin_inff();
   r.found = false;
@@ -682,39 +685,45 @@ __device__ __forceinline__ NNResult nn_search_row16(const MapView& m, uint32_t r
   uint32_t fa, na, fb, nb;
   nn_resolve(m, slots4, ka, sa, true, fa, na);
   nn_resolve(m, slots4, kb, sb, has_b, fb, nb);
-  const float lba = ca == 13 ? __builtin_inff() : nn_lower_bound(ca, gx, gy, gz) * 0.9999f;  // own voxel: handled first
+  const bool bounded = bound0 < __builtin_inff();  // the same in the sixteen lanes
+  const float lb13 = ca == 13 ? 0.f : nn_lower_bound(ca, gx, gy, gz) * 0.9999f;
   const float lbb = has_b ? nn_lower_bound(cb, gx, gy, gz) * 0.9999f : __builtin_inff();
-  nnkey_t best = kNNKeyNone;
-  {  // round 2: the own voxel (code 13, slot "a" of lane 13)
-    const uint32_t f1[1] = {row_bcast_u32(fa, 13)}, c1[1] = {row_bcast_u32(na, 13)};
-    best = nn_scan_merged_row<1>(pts4, f1, c1, r16, qx, qy, qz, best);
-  }
-  // rounds 3+: surviving non-empty neighbours, four at a time, lowest code first (any order gives the same minimum)
-  bool todo_a = ca != 13 && na > 0, todo_b = has_b && nb > 0;
+  nnkey_t best = bounded ? (((nnkey_t)__float_as_uint(bound0) << 32) | 0xFFFFFFFFull) : kNNKeyNone;
   const uint32_t row_shift = (uint32_t)__lane_id() & 48u;
-  for (;;) {
-    const float bd = nnkey_d2(best);
-    const bool pa = todo_a && !(lba > bd), pb = todo_b && !(lbb > bd);
-    const uint32_t ma = (uint32_t)(__ballot(pa) >> row_shift) & 0xFFFFu, mb = (uint32_t)(__ballot(pb) >> row_shift) & 0xFFFFu;
-    uint32_t mm = ma | (mb << 16);  // bit = code
-    if (!mm) break;
-    uint32_t first[4], cnt[4];
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-      const int code = mm ? __builtin_ctz(mm) : -1;
-      mm &= mm - 1;
-      const uint32_t owner = (uint32_t)(code < 0 ? 0 : code) & 15u;
-      const bool is_b = code >= 16;
-      const uint32_t f = row_bcast_u32(is_b ? fb : fa, owner), n = row_bcast_u32(is_b ? nb : na, owner);
-      // NB: the value is selected BEFORE the permute in every lane, so the owner lane contributes the right slot
-      first[v] = f;
-      cnt[v] = code < 0 ? 0u : n;
-      if (code >= 0) {
-        if (code == ca) todo_a = false;
-        if (code == cb) todo_b = false;
-      }
+  for (int pass = 0; pass < 2; pass++) {
+    const bool own_first = !bounded || pass == 1;
+    if (own_first) {  // round 2: the own voxel (code 13, slot "a" of lane 13)
+      const uint32_t f1[1] = {row_bcast_u32(fa, 13)}, c1[1] = {row_bcast_u32(na, 13)};
+      best = nn_scan_merged_row<1>(pts4, f1, c1, r16, qx, qy, qz, best);
     }
-    best = nn_scan_merged_row<4>(pts4, first, cnt, r16, qx, qy, qz, best);
+    // rounds 3+: surviving non-empty neighbours, four at a time, lowest code first (any order gives the same minimum)
+    bool todo_a = (ca != 13 || !own_first) && na > 0, todo_b = has_b && nb > 0;
+    for (;;) {
+      const float bd = nnkey_d2(best);
+      const bool pa = todo_a && !(lb13 > bd), pb = todo_b && !(lbb > bd);
+      const uint32_t ma = (uint32_t)(__ballot(pa) >> row_shift) & 0xFFFFu, mb = (uint32_t)(__ballot(pb) >> row_shift) & 0xFFFFu;
+      uint32_t mm = ma | (mb << 16);  // bit = code
+      if (!mm) break;
+      uint32_t first[4], cnt[4];
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int code = mm ? __builtin_ctz(mm) : -1;
+        mm &= mm - 1;
+        const uint32_t owner = (uint32_t)(code < 0 ? 0 : code) & 15u;
+        const bool is_b = code >= 16;
+        const uint32_t f = row_bcast_u32(is_b ? fb : fa, owner), n = row_bcast_u32(is_b ? nb : na, owner);
+        // NB: the value is selected BEFORE the permute in every lane, so the owner lane contributes the right slot
+        first[v] = f;
+        cnt[v] = code < 0 ? 0u : n;
+        if (code >= 0) {
+          if (code == ca) todo_a = false;
+          if (code == cb) todo_b = false;
+        }
+      }
+      best = nn_scan_merged_row<4>(pts4, first, cnt, r16, qx, qy, qz, best);
+    }
+    if (!bounded || nnkey_idx(best) != 0xFFFFFFFFu) break;
+    best = kNNKeyNone;  // the bound was not attained inside the block: once more, without it
   }
   if (nnkey_idx(best) != 0xFFFFFFFFu) {
     r.pt = pts4[nnkey_idx(best)];
