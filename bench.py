@@ -73,10 +73,13 @@ def generate_workloads(name, variants):
 
 def compulsory_bytes(w, stats):
     """Bytes that have to move at least once per match launch and scan, whatever the search strategy: the scan (12 B per
-    point), the pairing written back (16 B nearest point + d2, 4 B index), and each map record / hash slot inside the
-    union of the scan's 27-voxel neighbourhoods once (16 B each)."""
+    point), the pairing written back (16 B nearest point + d2, 4 B index), each map record / hash slot inside the union of
+    the scan's 27-voxel neighbourhoods once (16 B each) and -- in every iteration but an alignment's first -- the previous
+    pairing that bounds the search (16 B per point; averaged over the workload's iterations)."""
     n = len(w.scan_xyz)
-    return 12.0 * n + 20.0 * n + 16.0 * stats["records_in_union"] + 16.0 * stats["voxels_in_union"]
+    prev = 0.0 if os.environ.get("MH_NO_PREV_BOUND") or os.environ.get("MH_MATCH", "q")[:1] in "pxtw" else \
+        16.0 * n * (w.n_iters - 1) / max(1, w.n_iters)
+    return 12.0 * n + 20.0 * n + prev + 16.0 * stats["records_in_union"] + 16.0 * stats["voxels_in_union"]
 
 
 def neighbourhood_union(w):
@@ -391,7 +394,8 @@ def main():
             avg_ms = match_ms / match_launches          # per scan: launch duration / scans in the launch
             launch_ms = avg_ms * S
             achieved = per_scan * S / (launch_ms * 1e-3) / 1e9
-            kname = {"p": "k_match<fused,branch-and-bound>", "x": "k_match<fused,27-voxel>", "t": "k_match_tile_b"}.get(
+            kname = {"p": "k_match<fused,branch-and-bound>", "x": "k_match<fused,27-voxel>", "t": "k_match_tile_b",
+                     "w": "k_match_wave_dense_b + k_match_wave_sparse_b", "o": "k_match4o_b"}.get(
                 os.environ.get("MH_MATCH", "q")[:1], "k_match4_b (quad per point, one launch over all scans of the step)")
             roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
@@ -399,8 +403,8 @@ def main():
                     "avg_kernel_ms_per_scan": avg_ms,
                     "avg_kernel_ms_alone": (iso_ms / iso_launches) if iso_launches else None,
                     "compulsory_bytes_per_launch": per_scan * S, "compulsory": union,
-                    "note": "achieved = COMPULSORY bytes per launch (scan read + pairing write + every map record / hash slot "
-                            "inside the union of the scan's 27-voxel blocks once) / HIP-event duration of the launch, so frac "
+                    "note": "achieved = COMPULSORY bytes per launch (scan read + previous pairing read + pairing write + every map "
+                            "record / hash slot inside the union of the scan's 27-voxel blocks once) / HIP-event duration of the launch, so frac "
                             "<= 1 is the share of the HBM peak this launch would need if nothing was cached; `traffic` = "
                             "PMC-measured HBM bytes per launch of the same kernel (profiles/).  The kernel is NOT HBM-bound: "
                             "see `views` (VALU issue and dependent cache round trips bound it)."}
