@@ -52,7 +52,9 @@ def main():
                   "icp_iterations": sum(p["icp_iterations"] for p in per),
                   "note": "wall clock incl. start-up for n > 1; registration time only (file reading excluded) for n = 1"}
         print("sequences in one process: %d -> %.0f scans/s whole run, %.0f steady state (registration time, first 5 scans left out)" % (n, rate, steady), flush=True)
-    same = all(open("/tmp/molahip_multi/out_%d_0.tum" % n).read() == open("/tmp/molahip_multi/out_1.tum").read() for n in counts if n > 1 and n in out)
+    same = None  # (needs the solo run of THIS invocation)
+    if 1 in out:
+        same = all(open("/tmp/molahip_multi/out_%d_0.tum" % n).read() == open("/tmp/molahip_multi/out_1.tum").read() for n in counts if n > 1 and n in out)
     print(json.dumps({"multi_sequence_one_process": out, "trajectories_identical_to_solo_run": same}))
 
 
