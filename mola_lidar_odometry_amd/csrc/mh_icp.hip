@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, con
     inner_done = true;  // "target error" early exit, no solve (App.B U8)
   } else {
     double x[6], delta[6];
-    if (!ldlt_solve6(H, g, x)) {
+    if (!ldlt_solve6_spd(H, g, x) && !ldlt_solve6(H, g, x)) {  // (pivoted only for what the SPD fast path declines)
       st->solver_ok = 0;
       st->term_reason = MH_TERM_SOLVER_ERROR;
       st->n_iterations = it;

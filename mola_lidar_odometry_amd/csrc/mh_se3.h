@@ -243,6 +243,60 @@ MH_HD bool ldlt_solve6(const double Hfull[36], const double b[6], double x[6]) {
   return ok;
 }
 
+// The same solve without the pivot search, for the matrices the Gauss-Newton step actually sees: H = J^T W J (+ prior
+// information) is symmetric positive definite, and LDL^T of an SPD matrix is stable in any order -- pivoting only decides
+// what happens to (near-)singular ones.  Straight-line code, a third of the pivoted routine's dependent fp64 chain (one
+// lane runs it between two launches of every ICP iteration).  Returns false -- the caller then takes ldlt_solve6 -- as
+// soon as a pivot is not safely positive relative to the largest diagonal entry (rank-deficient geometry, a plane-only
+// scene) or anything is not finite; the two routines agree to rounding (a few 1e-16 of |x| times H's condition) on
+// what this one accepts.
+MH_HD bool ldlt_solve6_spd(const double Hfull[36], const double b[6], double x[6]) {
+#pragma clang fp contract(fast)
+  double A[6][6], y[6], invd[6];
+  double dmax = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) A[i][j] = Hfull[i * 6 + j];
+    y[i] = b[i];
+    dmax = fmax(dmax, fabs(Hfull[i * 6 + i]));
+  }
+  const double floor_d = 1e-10 * dmax;
+  bool ok = dmax > 0.0 && isfinite(dmax);
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double d = A[k][k];
+    ok = ok && (d > floor_d);  // (false for NaN as well)
+    const double inv = 1.0 / d;
+    invd[k] = inv;
+    double l[6];
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) l[i] = A[i][k] * inv;
+#pragma unroll
+    for (int i = k + 1; i < 6; i++)
+#pragma unroll
+      for (int j = k + 1; j <= i; j++) A[i][j] -= l[i] * A[j][k];  // A[j][k] still holds l_jk * d
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) A[i][k] = l[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] *= invd[i];
+#pragma unroll
+  for (int i = 5; i >= 0; i--)
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) y[i] -= A[j][i] * y[j];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    x[i] = y[i];
+    ok = ok && isfinite(y[i]);
+  }
+  return ok;
+}
+
 // inverse of an SPD 6x6 via Cholesky (mrpt inverse_LLt in mp2p_icp::covariance); false if not SPD
 MH_HD bool chol_inverse6(const double A[36], double Ainv[36]) {
   double L[36];

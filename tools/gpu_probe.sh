@@ -2,9 +2,9 @@
 REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
 cd $REPO
 mkdir -p gpurun_out
-timeout 900 python bench.py > gpurun_out/bench_default.log 2>&1; python tools/bench_brief.py gpurun_out/bench_default.log
-timeout 900 python bench.py --no-cpu-baseline --no-shared-run --io none > gpurun_out/bench_res.log 2>&1; python tools/bench_brief.py gpurun_out/bench_res.log
-timeout 900 python bench.py --no-cpu-baseline --no-shared-run --workload creal > gpurun_out/bench_creal_io.log 2>&1; python tools/bench_brief.py gpurun_out/bench_creal_io.log
-timeout 900 python bench.py --no-cpu-baseline --no-shared-run --io none --streams 1 > gpurun_out/bench_s1.log 2>&1; python tools/bench_brief.py gpurun_out/bench_s1.log
-timeout 1200 python tools/multi_seq_bench.py 200 1,2,4,8,16 2>&1 | tail -7 > gpurun_out/multi_seq.log; cat gpurun_out/multi_seq.log
-timeout 1200 python tools/multi_seq_bench.py 120 4,8 pipelines/lidar3d-ndt-hip.yaml 2>&1 | tail -3 > gpurun_out/multi_seq_ndt.log; cat gpurun_out/multi_seq_ndt.log
+timeout 1800 python -m pytest tests -x -q -m gpu --timeout 300 > gpurun_out/pytest_probe.log 2>&1
+tail -3 gpurun_out/pytest_probe.log | cut -c1-400
+timeout 900 python tools/multi_seq_bench.py 150 1,4 2>&1 | tail -3 | head -2
+cd /tmp; export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/st2 -o st -- env PYTHONPATH=$REPO python -m mola_lidar_odometry_amd.run_odometry --synthetic 40 --out-dir $REPO/gpurun_out/odometry > /dev/null 2>&1
+head -4 $REPO/gpurun_out/st2/*kernel_stats.csv | cut -c1-150
