@@ -2318,7 +2318,7 @@ struct AlignJob {
       memcpy(&fb, &mv.inv_vs, 4);
       const unsigned long long kv[] = {n, nb, nbm, (unsigned long long)variant, m, p->gn.max_inner_iterations,
                                        p->compute_covariance, (unsigned long long)mv.slots, (unsigned long long)mv.pts, mv.mask,
-                                       fb, mv.trunc | (mv.ndt << 1), (unsigned long long)scan->x, (unsigned long long)scan->y,
+                                       fb, mv.trunc | (mv.ndt << 1) | (mv.no_prev_bound << 2), (unsigned long long)scan->x, (unsigned long long)scan->y,
                                        (unsigned long long)scan->z, (unsigned long long)ctx->pair_q.p,
                                        (unsigned long long)ctx->pair_gidx.p, (unsigned long long)part,
                                        (unsigned long long)ctx->d_state, (unsigned long long)ctx->d_params,
