@@ -17,6 +17,7 @@
 #include <fstream>
 #include <stdexcept>
 #include <memory>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -65,6 +66,7 @@ struct SequenceReport {
   double seconds = 0, steady_seconds = 0;  // steady: without the first kWarmScans scans (context, code objects, first map)
   size_t steady_scans = 0;
   std::string error;
+  std::map<std::string, double> profile;  // LidarOdometry::profile(): host seconds per stage, whole run
 };
 
 // one sequence, start to end; with a batcher its alignments join those of the other sequences of the process
@@ -111,6 +113,7 @@ void run_sequence(const std::string& pipeline, const std::string& seq_dir, const
       }
     }
     lo.saveTrajectoryTUM(out);
+    rep.profile = lo.profile();
   } catch (const std::exception& e) {
     rep.error = e.what();
   }
@@ -124,9 +127,9 @@ int main(int argc, char** argv) {
   std::vector<std::string> seq_dirs;
   int device = 0;
   long max_scans = -1;
-  bool prefetch = true;
+  bool prefetch = true, print_profile = false;
   const char* usage = "usage: molahip-lo-cli --pipeline FILE.yaml --seq-dir DIR [--seq-dir DIR ...] --out FILE.tum [--device N] "
-                      "[--no-prefetch] [--max-scans N]\n"
+                      "[--no-prefetch] [--max-scans N] [--profile]\n"
                       "  several --seq-dir: the sequences run together on the one GPU, one host thread each, their alignments\n"
                       "  merged into lock-step batches; trajectories go to FILE_<k>.tum\n";
   for (int i = 1; i < argc; i++) {
@@ -142,6 +145,7 @@ int main(int argc, char** argv) {
       else if (a == "--device") device = atoi(val("--device").c_str());
       else if (a == "--max-scans") max_scans = atol(val("--max-scans").c_str());
       else if (a == "--no-prefetch") prefetch = false;
+      else if (a == "--profile") print_profile = true;
       else throw std::runtime_error("unknown argument " + a);
     } catch (const std::exception& e) {
       fprintf(stderr, "%s\n%s", e.what(), usage);
@@ -179,6 +183,15 @@ int main(int argc, char** argv) {
            "\"seconds\": %.6f, \"scans_per_s\": %.3f, \"steady_scans_per_s\": %.3f, \"tum\": \"%s\"}\n",
            r.seq_dir.c_str(), r.scans, r.good, r.keyframes, r.iterations, r.seconds, r.seconds > 0 ? r.scans / r.seconds : 0.0,
            r.steady_seconds > 0 ? r.steady_scans / r.steady_seconds : 0.0, r.out.c_str());
+    if (print_profile && r.scans) {  // host milliseconds per scan and stage (LidarOdometry::profile())
+      printf("{\"profile_ms_per_scan\": {");
+      bool first = true;
+      for (const auto& kv : r.profile) {
+        printf("%s\"%s\": %.4f", first ? "" : ", ", kv.first.c_str(), 1e3 * kv.second / (double)r.scans);
+        first = false;
+      }
+      printf("}}\n");
+    }
   }
   if (N > 1) {
     // the sequences advance together (one batch per round), so the slowest thread's registration time is the job's

@@ -1,11 +1,17 @@
 #!/bin/bash
 REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
 cd $REPO
-mkdir -p gpurun_out
-cp mola_lidar_odometry_amd/libmolahip.so /tmp/cur.so
-for v in 3_8_3 4_7_4 4_7_3; do
-cp tools/_ab/lib_$v.so mola_lidar_odometry_amd/libmolahip.so
-MH_MATCH=q timeout 600 python bench.py --no-cpu-baseline --no-shared-run --io none > gpurun_out/bench_$v.log 2>&1; echo -n "$v halves "; python tools/bench_brief.py gpurun_out/bench_$v.log
-MH_NO_HALVES=1 MH_MATCH=q timeout 600 python bench.py --no-cpu-baseline --no-shared-run --io none > gpurun_out/bench_$v.log 2>&1; echo -n "$v nohalves "; python tools/bench_brief.py gpurun_out/bench_$v.log
+python tools/multi_seq_bench.py 60 1 > /dev/null 2>&1   # writes the tree
+D=/tmp/molahip_multi/sequences/00
+for n in 1 8; do
+args=""
+for i in $(seq $n); do args="$args --seq-dir $D"; done
+./mola_lidar_odometry_amd/molahip-lo-cli --pipeline pipelines/lidar3d-default-hip.yaml --out /tmp/o.tum --profile $args 2>&1 | grep -E "profile_ms|sequences" | head -3 | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l)
+    if 'profile_ms_per_scan' in d:
+        print({k.replace('onLidar.',''):round(v,3) for k,v in d['profile_ms_per_scan'].items() if v>0.004 and not k.startswith('icp.') and not k.startswith('prefetch')})
+    else: print(d)
+"
 done
-cp /tmp/cur.so mola_lidar_odometry_amd/libmolahip.so
