@@ -686,7 +686,7 @@ __device__ __forceinline__ NNResult nn_search_row16(const MapView& m, uint32_t r
   nn_resolve(m, slots4, ka, sa, true, fa, na);
   nn_resolve(m, slots4, kb, sb, has_b, fb, nb);
   const bool bounded = bound0 < __builtin_inff();  // the same in the sixteen lanes
-  const float lb13 = ca == 13 ? 0.f : nn_lower_bound(ca, gx, gy, gz) * 0.9999f;
+  const float lba = ca == 13 ? 0.f : nn_lower_bound(ca, gx, gy, gz) * 0.9999f;  // (the own voxel is always live)
   const float lbb = has_b ? nn_lower_bound(cb, gx, gy, gz) * 0.9999f : __builtin_inff();
   nnkey_t best = bounded ? (((nnkey_t)__float_as_uint(bound0) << 32) | 0xFFFFFFFFull) : kNNKeyNone;
   const uint32_t row_shift = (uint32_t)__lane_id() & 48u;
@@ -700,7 +700,7 @@ __device__ __forceinline__ NNResult nn_search_row16(const MapView& m, uint32_t r
     bool todo_a = (ca != 13 || !own_first) && na > 0, todo_b = has_b && nb > 0;
     for (;;) {
       const float bd = nnkey_d2(best);
-      const bool pa = todo_a && !(lb13 > bd), pb = todo_b && !(lbb > bd);
+      const bool pa = todo_a && !(lba > bd), pb = todo_b && !(lbb > bd);
       const uint32_t ma = (uint32_t)(__ballot(pa) >> row_shift) & 0xFFFFu, mb = (uint32_t)(__ballot(pb) >> row_shift) & 0xFFFFu;
       uint32_t mm = ma | (mb << 16);  // bit = code
       if (!mm) break;

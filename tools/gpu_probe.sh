@@ -1,17 +1,12 @@
 #!/bin/bash
 REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
 cd $REPO
-python tools/multi_seq_bench.py 60 1 > /dev/null 2>&1   # writes the tree
-D=/tmp/molahip_multi/sequences/00
-for n in 1 8; do
-args=""
-for i in $(seq $n); do args="$args --seq-dir $D"; done
-./mola_lidar_odometry_amd/molahip-lo-cli --pipeline pipelines/lidar3d-default-hip.yaml --out /tmp/o.tum --profile $args 2>&1 | grep -E "profile_ms|sequences" | head -3 | python -c "
-import sys,json
-for l in sys.stdin:
-    d=json.loads(l)
-    if 'profile_ms_per_scan' in d:
-        print({k.replace('onLidar.',''):round(v,3) for k,v in d['profile_ms_per_scan'].items() if v>0.004 and not k.startswith('icp.') and not k.startswith('prefetch')})
-    else: print(d)
-"
+mkdir -p gpurun_out
+cp mola_lidar_odometry_amd/libmolahip.so /tmp/cur.so
+for v in r1 r2 r4 r1 r2 r4; do
+cp tools/_ab/lib_$v.so mola_lidar_odometry_amd/libmolahip.so
+MH_MATCH=q timeout 600 python bench.py --no-cpu-baseline --no-shared-run --io none > gpurun_out/bench_$v.log 2>&1; echo -n "$v "; python tools/bench_brief.py gpurun_out/bench_$v.log
 done
+cp /tmp/cur.so mola_lidar_odometry_amd/libmolahip.so
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu --timeout 300 > gpurun_out/pytest_probe.log 2>&1
+tail -2 gpurun_out/pytest_probe.log | cut -c1-300
