@@ -49,6 +49,18 @@ __global__ void k_keys(const float* __restrict__ x, const float* __restrict__ y,
   idx[i] = i;
 }
 
+// merge path of mh_map_insert: remove_voxels_farther_than applied to the SORTED keys (k_keys left them alone so that the
+// stored points stay in order); the runs of empty keys this leaves inside the sequence are skipped by everything below
+__global__ void k_evict_sorted(unsigned long long* __restrict__ ks, uint32_t n, int4 evict) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = ks[i];
+  if (k == kEmptyKey) return;
+  int kx, ky, kz;
+  unpack_key(k, kx, ky, kz);
+  if (max(max(abs(kx - evict.x), abs(ky - evict.y)), abs(kz - evict.z)) > evict.w) ks[i] = kEmptyKey;
+}
+
 // head[i] = 1 where a new voxel run starts; counters[1] = number of valid (finite) points
 __global__ void k_heads(const unsigned long long* __restrict__ ks, uint32_t n, uint32_t* __restrict__ head,
                         uint32_t* __restrict__ counters) {
@@ -433,8 +445,12 @@ mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const fl
   if (n > 0) {
     const uint32_t N = (uint32_t)n;
     // scratch carve-up
-    MH_TRY(ctx->build_a.reserve(2 * n * sizeof(unsigned long long)));  // keys in | keys sorted
-    MH_TRY(ctx->build_b.reserve(2 * n * sizeof(uint32_t)));            // idx in | idx sorted
+    // mh_map_insert hands over [stored points, voxel by voxel in key order | new points]: only the new ones need sorting,
+    // one merge puts them in place (stored first among equal keys = insertion order).  MH_MAP_FULL_SORT=1: sort everything.
+    const size_t n_new = n - n_stored;
+    const bool merge_path = n_stored > 0 && getenv("MH_MAP_FULL_SORT") == nullptr;
+    MH_TRY(ctx->build_a.reserve((2 * n + n_new) * sizeof(unsigned long long)));  // keys in | keys sorted | new keys sorted
+    MH_TRY(ctx->build_b.reserve((2 * n + n_new) * sizeof(uint32_t)));            // idx in | idx sorted | new idx sorted
     MH_TRY(ctx->build_c.reserve(2 * n * sizeof(uint32_t)));            // head | vid1
     MH_TRY(ctx->build_d.reserve(2 * n * sizeof(uint32_t)));            // keep | outpos
     MH_TRY(ctx->build_e.reserve(n * sizeof(uint32_t) + 64));           // vstart | counters(12)
@@ -453,10 +469,21 @@ mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const fl
     MH_HIP(hipMemcpyAsync(counters, init_counters, sizeof(init_counters), hipMemcpyHostToDevice, s));
     const uint32_t B = 256;
     const int4 ev = evict ? make_int4(evict[0], evict[1], evict[2], evict[3]) : make_int4(0, 0, 0, -1);
+    const int4 ev_keys = merge_path ? make_int4(0, 0, 0, -1) : ev;  // (merge path: eviction after the merge, k_evict_sorted)
     hipLaunchKernelGGL(k_keys, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, N, m->inv_vs,
-                       (uint32_t)(m->params.index_mode == MH_INDEX_TRUNC), ev, keys, idx, counters);
+                       (uint32_t)(m->params.index_mode == MH_INDEX_TRUNC), ev_keys, keys, idx, counters);
+    unsigned long long* keys_new = keys + 2 * n;
+    uint32_t* idx_new = idx + 2 * n;
     size_t tmp = 0;
-    MH_HIP(rocprim::radix_sort_pairs(nullptr, tmp, keys, keys_s, idx, idx_s, N, 0, 64, s));
+    if (merge_path) {
+      size_t t2 = 0;
+      if (n_new) MH_HIP(rocprim::radix_sort_pairs(nullptr, tmp, keys + n_stored, keys_new, idx + n_stored, idx_new, n_new, 0, 64, s));
+      MH_HIP(rocprim::merge(nullptr, t2, keys, keys_new, keys_s, idx, idx_new, idx_s, n_stored, n_new,
+                            rocprim::less<unsigned long long>(), s));
+      if (t2 > tmp) tmp = t2;
+    } else {
+      MH_HIP(rocprim::radix_sort_pairs(nullptr, tmp, keys, keys_s, idx, idx_s, N, 0, 64, s));
+    }
     {
       size_t t2 = 0;
       MH_HIP(rocprim::inclusive_scan(nullptr, t2, head, vid1, N, rocprim::plus<uint32_t>(), s));
@@ -466,7 +493,15 @@ mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const fl
     }
     MH_TRY(ctx->sort_tmp.reserve(tmp));
     size_t tb = ctx->sort_tmp.bytes;
-    MH_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tb, keys, keys_s, idx, idx_s, N, 0, 64, s));
+    if (merge_path) {
+      if (n_new) MH_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tb, keys + n_stored, keys_new, idx + n_stored, idx_new, n_new, 0, 64, s));
+      tb = ctx->sort_tmp.bytes;
+      MH_HIP(rocprim::merge(ctx->sort_tmp.p, tb, keys, keys_new, keys_s, idx, idx_new, idx_s, n_stored, n_new,
+                            rocprim::less<unsigned long long>(), s));
+      if (ev.w >= 0) hipLaunchKernelGGL(k_evict_sorted, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, N, ev);
+    } else {
+      MH_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tb, keys, keys_s, idx, idx_s, N, 0, 64, s));
+    }
     hipLaunchKernelGGL(k_heads, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, N, head, counters);
     tb = ctx->sort_tmp.bytes;
     MH_HIP(rocprim::inclusive_scan(ctx->sort_tmp.p, tb, head, vid1, N, rocprim::plus<uint32_t>(), s));
