@@ -189,7 +189,7 @@ def main():
         def __init__(self, wl, io):
             self.wl, self.io = wl, io != "none"
             self.up, self.dl = io in ("both", "upload"), io in ("both", "pairs")
-            self.worker = None
+            self.thread, self.worker_error, self.calls, self.last_call = None, None, {}, None
             self.map_ctx = capi.Context(local_rank)
             self.maps = [capi.Map(self.map_ctx, x.voxel_size, x.cap).build(x.map_xyz) for x in wl]
             if len(self.maps) == 1:
@@ -225,28 +225,58 @@ def main():
             for sc, t, n in zip(self.scans[which], self.pinned, self.sizes):
                 sc.update_interleaved_pinned(t.data_ptr(), n, 12)
 
+        def _worker_main(self):  # the upload thread: one per Setup, fed through a queue (no thread start/join per step)
+            while True:
+                item = self.todo.get()
+                if item is None:
+                    return
+                try:
+                    self.upload(item, args.upload_delay_ms * 1e-3)
+                except BaseException as e:  # noqa: BLE001  (handed to the main thread)
+                    self.worker_error = e
+                self.done.put(item)
+
+        def call_for(self, sset, cur):
+            """The marshalled arguments of this buffer set's batch (capi.BatchCall): built once, reused every step -- the
+            per-step host work is the C call."""
+            key = (sset, cur if self.dl else -1)
+            if key not in self.calls:
+                if self.dl:
+                    self.calls[key] = capi.BatchCall(self.maps, self.scans[sset], self.guesses, params,
+                                                     pairs_block=self.blocks[cur].data_ptr(), pairs_mem=capi.MEM_HOST_PINNED)
+                else:
+                    self.calls[key] = capi.BatchCall(self.maps, self.scans[sset], self.guesses, params)
+            return self.calls[key]
+
         def step(self):
+            """One batch; returns (match_kernel_ms, n_match_launches) of job 0 (lock step: its share of the launches)."""
             if not self.io:
-                return capi.icp_align_batch(self.maps, self.scans[0], self.guesses, params)
+                self.last_call = self.call_for(0, 0)
+                r = self.last_call.run()
+                return r[0].match_kernel_ms, int(r[0].n_match_launches)
             cur = self.k & 1
             sset = cur if self.up else 0
+            pending = False
             if self.up:  # next step's scans: asynchronous copies on the OTHER buffer set's streams
                 if args.upload_thread:  # queued by a second host thread while this one blocks in the batch call below
-                    import threading
-                    self.worker = threading.Thread(target=self.upload, args=(1 - cur, args.upload_delay_ms * 1e-3))
-                    self.worker.start()
+                    if self.thread is None:
+                        import queue
+                        import threading
+                        self.todo, self.done = queue.SimpleQueue(), queue.SimpleQueue()
+                        self.thread = threading.Thread(target=self._worker_main, daemon=True)
+                        self.thread.start()
+                    self.todo.put(1 - cur)
+                    pending = True
                 else:
                     self.upload(1 - cur)
-            if self.dl:
-                r = capi.icp_align_batch(self.maps, self.scans[sset], self.guesses, params,
-                                         pairs_block=self.blocks[cur].data_ptr(), pairs_mem=capi.MEM_HOST_PINNED)
-            else:
-                r = capi.icp_align_batch(self.maps, self.scans[sset], self.guesses, params)
-            if self.worker is not None:
-                self.worker.join()
-                self.worker = None
+            self.last_call = self.call_for(sset, cur)
+            r = self.last_call.run()
+            if pending:
+                self.done.get()
+                if self.worker_error is not None:
+                    raise self.worker_error
             self.k += 1
-            return r
+            return r[0].match_kernel_ms, int(r[0].n_match_launches)
 
         def sync(self):
             for cs in self.ctxs:
@@ -263,15 +293,15 @@ def main():
                 self.step()
             self.sync()
             t0 = time.perf_counter()
-            ms, launches, last = 0.0, 0, None
+            ms, launches = 0.0, 0
             for _ in range(steps):
-                last = self.step()
-                ms += last[0]["match_kernel_ms"]
-                launches += last[0]["n_match_launches"]
+                m, l = self.step()
+                ms += m
+                launches += l
             self.sync()
             dt = time.perf_counter() - t0
             dt = mdist.max_over_ranks(dt, device="cuda" if distributed else None)  # MAX over ranks
-            return dt, ms, launches, last
+            return dt, ms, launches, self.last_call.results()
 
         def last_pairs(self, results):
             cur = (self.k - 1) & 1
@@ -279,6 +309,11 @@ def main():
 
         def close(self):
             self.sync()
+            if self.thread is not None:
+                self.todo.put(None)
+                self.thread.join(timeout=10)
+                self.thread = None
+            self.calls.clear()
             for cs in self.ctxs:
                 for c in cs:
                     c.close()

@@ -658,37 +658,58 @@ def unpack_pairs_block(block: np.ndarray, scan_sizes, results):
     return out
 
 
+class BatchCall:
+    """The arguments of one mh_icp_align_batch call, marshalled once: a caller that repeats a batch (a replay, bench.py)
+    keeps its argument arrays instead of rebuilding them per call -- per call that is the C function and nothing else.
+    run() returns the raw result structs (ICPResult array, overwritten by the next run()); results() the usual dicts."""
+
+    def __init__(self, maps, scans, T_guesses, p, priors=None, pairs_block=None, pairs_mem=MEM_HOST):
+        n = self.n = len(scans)
+        self._T = np.ascontiguousarray(np.stack([_T12(t) for t in T_guesses]).reshape(n * 12))
+        if isinstance(p, (list, tuple)):  # one ICPParams per job (its own schedules, budget, hook check point)
+            assert len(p) == n
+            made = [q.c(self._T[12 * i:12 * i + 12]) for i, q in enumerate(p)]
+            self._cp = (ICPParamsC * n)(*[m[0] for m in made])
+            self._keep = [m[1] for m in made]
+            self._cp_ref, self._per_job = self._cp, 1
+        else:
+            self._cp, self._keep = p.c(self._T[:12])
+            self._cp_ref, self._per_job = C.byref(self._cp), 0
+        self._maps, self._scans = list(maps), list(scans)  # (keep the handles' owners alive)
+        self._mh = (C.c_void_p * n)(*[m._h for m in maps])
+        self._sh = (C.c_void_p * n)(*[s._h for s in scans])
+        self.res = (ICPResult * n)()
+        self._pr_arr = None
+        self._keep_pr = []
+        if priors is not None:
+            self._pr_arr = (C.POINTER(Prior) * n)()
+            for i, pr in enumerate(priors):
+                if pr is not None:
+                    self._keep_pr.append(_mk_prior(pr))
+                    self._pr_arr[i] = C.pointer(self._keep_pr[-1])
+        self._block = pairs_block  # (a numpy array stays referenced)
+        self._pb = None
+        if pairs_block is not None:
+            self._pb = C.c_void_p(pairs_block if isinstance(pairs_block, int) else pairs_block.ctypes.data)
+        self._mem = pairs_mem
+        self._fn = lib().mh_icp_align_batch
+        self._Tp = self._T.ctypes.data_as(_DP)
+
+    def run(self):
+        _chk(self._fn(self.n, self._mh, self._sh, self._cp_ref, self._per_job, self._Tp, self._pr_arr, self.res, self._pb, self._mem))
+        return self.res
+
+    def results(self):
+        return [_result_dict(r) for r in self.res]
+
+
 def icp_align_batch(maps, scans, T_guesses, p: ICPParams, priors=None, pairs_block=None, pairs_mem=MEM_HOST):
     """One alignment per (map, scan) pair; every scan must live in its own Context (its own stream).
     pairs_block: None, a writable uint8 numpy array (host; pairs_mem MEM_HOST, or MEM_HOST_PINNED when its memory is
     page-locked -- the download then completes asynchronously, see molahip.h) or a raw pointer (int) with pairs_mem."""
-    n = len(scans)
-    T = np.ascontiguousarray(np.stack([_T12(t) for t in T_guesses]).reshape(n * 12))
-    if isinstance(p, (list, tuple)):  # one ICPParams per job (its own schedules, budget, hook check point)
-        assert len(p) == n
-        made = [q.c(T[12 * i:12 * i + 12]) for i, q in enumerate(p)]
-        cp_arr = (ICPParamsC * n)(*[m[0] for m in made])
-        keep = [m[1] for m in made]
-        cp_ref, per_job = cp_arr, 1
-    else:
-        cp, keep = p.c(T[:12])
-        cp_ref, per_job = C.byref(cp), 0
-    mh = (C.c_void_p * n)(*[m._h for m in maps])
-    sh = (C.c_void_p * n)(*[s._h for s in scans])
-    res = (ICPResult * n)()
-    pr_arr = None
-    keep_pr = []
-    if priors is not None:
-        pr_arr = (C.POINTER(Prior) * n)()
-        for i, pr in enumerate(priors):
-            if pr is not None:
-                keep_pr.append(_mk_prior(pr))
-                pr_arr[i] = C.pointer(keep_pr[-1])
-    pb = None
-    if pairs_block is not None:
-        pb = C.c_void_p(pairs_block if isinstance(pairs_block, int) else pairs_block.ctypes.data)
-    _chk(lib().mh_icp_align_batch(n, mh, sh, cp_ref, per_job, T.ctypes.data_as(_DP), pr_arr, res, pb, pairs_mem))
-    return [_result_dict(r) for r in res]
+    call = BatchCall(maps, scans, T_guesses, p, priors, pairs_block, pairs_mem)
+    call.run()
+    return call.results()
 
 
 def preprocess_params(decim_map_resolution, decim_icp_resolution, min_points_to_filter=2000, index_mode=INDEX_FLOOR,

@@ -1,12 +1,10 @@
 #!/bin/bash
-# development probe (rewritten per experiment; run on the GPU box through gpurun)
 REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
 cd $REPO
 mkdir -p gpurun_out
-timeout 1800 python -m pytest tests -x -q -m gpu --timeout 300 > gpurun_out/pytest_probe.log 2>&1
-tail -3 gpurun_out/pytest_probe.log | cut -c1-400
-for e in "" "MH_MAP_FULL_SORT=1"; do
-echo "== $e"
-env $e timeout 600 python tools/odom_profile.py 150 2>&1 | grep -E "steady|update_local_map|run_icp"
-env $e timeout 900 python tools/multi_seq_bench.py 120 1,8 2>&1 | grep "sequences in one"
+for io in none both none both; do
+timeout 600 python bench.py --no-cpu-baseline --no-shared-run --io $io > gpurun_out/bench_io_$io.log 2>&1; echo -n "$io "; python tools/bench_brief.py gpurun_out/bench_io_$io.log | cut -c1-330
 done
+timeout 900 python bench.py > gpurun_out/bench_default.log 2>&1; python tools/bench_brief.py gpurun_out/bench_default.log
+tail -3 gpurun_out/bench_default.log | cut -c1-300
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu --timeout 300 -k "batch" 2>&1 | tail -2
