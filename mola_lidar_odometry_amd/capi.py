@@ -318,7 +318,8 @@ class Map:
 
     def close(self):
         if self._h:
-            lib().mh_map_destroy(self._h)
+            if self.ctx._h:  # (see Scan.close)
+                lib().mh_map_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -423,7 +424,10 @@ class Scan:
 
     def close(self):
         if self._h:
-            lib().mh_scan_destroy(self._h)
+            # (garbage collection of a reference cycle may finalise the context first -- its weak set of children is
+            # cleared before any finaliser runs: a scan whose context is gone must not touch it any more)
+            if self.ctx._h:
+                lib().mh_scan_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

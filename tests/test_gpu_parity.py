@@ -482,6 +482,15 @@ def test_align_batch_equals_single(ctx, oracle, small):
         assert b["n_iterations"] == s["n_iterations"] and b["termination_reason"] == s["termination_reason"]
         np.testing.assert_array_equal(b["T"], s["T"])  # bitwise: deterministic reductions
         np.testing.assert_array_equal(b["cov"], s["cov"])
+    # the prepared form (arguments marshalled once, what bench.py repeats every step): the same results, run after run
+    call = capi.BatchCall([gm] * 4, scans, guesses, p)
+    for _ in range(3):
+        raw = call.run()
+        assert len(raw) == 4
+        for b, s in zip(call.results(), singles):
+            assert b["n_iterations"] == s["n_iterations"] and b["termination_reason"] == s["termination_reason"]
+            np.testing.assert_array_equal(b["T"], s["T"])
+            np.testing.assert_array_equal(b["cov"], s["cov"])
 
 
 def test_lockstep_batch_of_row_kernel_layers(ctx, monkeypatch):
