@@ -247,8 +247,8 @@ MH_HD bool ldlt_solve6(const double Hfull[36], const double b[6], double x[6]) {
 // information) is symmetric positive definite, and LDL^T of an SPD matrix is stable in any order -- pivoting only decides
 // what happens to (near-)singular ones.  Straight-line code, a third of the pivoted routine's dependent fp64 chain (one
 // lane runs it between two launches of every ICP iteration).  Returns false -- the caller then takes ldlt_solve6 -- as
-// soon as a pivot is not safely positive relative to the largest diagonal entry (rank-deficient geometry, a plane-only
-// scene) or anything is not finite; the two routines agree to rounding (a few 1e-16 of |x| times H's condition) on
+// soon as a pivot is not safely positive relative to the largest diagonal entry (rank-deficient or weakly constrained
+// geometry: a plane-only scene, a featureless corridor) or anything is not finite; the two routines agree to rounding (a few 1e-16 of |x| times H's condition) on
 // what this one accepts.
 MH_HD bool ldlt_solve6_spd(const double Hfull[36], const double b[6], double x[6]) {
 #pragma clang fp contract(fast)
@@ -261,7 +261,7 @@ MH_HD bool ldlt_solve6_spd(const double Hfull[36], const double b[6], double x[6
     y[i] = b[i];
     dmax = fmax(dmax, fabs(Hfull[i * 6 + i]));
   }
-  const double floor_d = 1e-10 * dmax;
+  const double floor_d = 1e-7 * dmax;  // (condition <= ~1e7: the two routines then agree to ~1e-9 relative even on the weakest direction)
   bool ok = dmax > 0.0 && isfinite(dmax);
 #pragma unroll
   for (int k = 0; k < 6; k++) {
