@@ -1086,12 +1086,18 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, con
   MH_PHASE(10);
 }
 
+// first = 0: a solve of an inner Gauss-Newton step >= 1.  When the previous solve closed the ICP iteration early (step below
+// min_delta, or the cost below max_cost: Solver_GaussNewton leaves its loop), the k_accum in front of this launch has
+// skipped as well (same test) and the partials are stale: nothing to do.  (Found by tools/fuzz_batch.py: a converged
+// alignment with the stall test off kept stepping on stale sums -- harmlessly small steps with k_accum's layout, garbage
+// with the fused matchers' wider one.)
 __device__ __forceinline__ void k_solve_body(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
                                                          const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                                          const double* __restrict__ partB, uint32_t nB,
-                                                         uint32_t strideB) {
+                                                         uint32_t strideB, uint32_t first) {
   __shared__ SolveShared sh;
   if (st->done) return;
+  if (!first && st->inner == 0) return;  // (uniform: every lane reads the same word)
   solve_body(st, kp, partA, nA, strideA, partB, nB, strideB, sh);
 }
 
@@ -1634,13 +1640,13 @@ __global__ __launch_bounds__(kBlock, MH_ACCUM_WAVES) void k_accum_b(const BatchJ
 __global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
                                                          const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                                          const double* __restrict__ partB, uint32_t nB,
-                                                         uint32_t strideB) {
-  k_solve_body(st, kp, partA, nA, strideA, partB, nB, strideB);
+                                                         uint32_t strideB, uint32_t first) {
+  k_solve_body(st, kp, partA, nA, strideA, partB, nB, strideB, first);
 }
 __global__ __launch_bounds__(kSolveThreads) void k_solve_b(const BatchJob* __restrict__ jobs, uint32_t first) {
   const BatchJob& j = jobs[blockIdx.y];
   const uint32_t cols = first ? j.nbm : j.nba;  // the first step's partials come from the matcher-side producer
-  k_solve_body(j.st, j.sk, j.part, cols, cols, nullptr, 0u, 0u);
+  k_solve_body(j.st, j.sk, j.part, cols, cols, nullptr, 0u, 0u, first);
 }
 __global__ void k_cov_prepare(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp, uint32_t force) {
   k_cov_prepare_body(st, kp, force);
@@ -2280,7 +2286,7 @@ struct AlignJob {
           prof_n++;
         }
         hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nbm, nbm,
-                           (const double*)partb, nB, nB);
+                           (const double*)partb, nB, nB, 1u);
         for (uint32_t in = 1; in < p->gn.max_inner_iterations; in++) {
           if (pl)
             hipLaunchKernelGGL(k_accum_both, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
@@ -2290,7 +2296,7 @@ struct AlignJob {
             hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
                                ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
           hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nba, nba,
-                             (const double*)partb, nBi, nBi);
+                             (const double*)partb, nBi, nBi, 0u);
         }
       }
       if (p->compute_covariance) {  // no-ops unless the loop has terminated
@@ -2462,7 +2468,9 @@ mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_icp_para
   if (final_pairs && !job.trivial && result->n_final_pairs > result->n_final_pairs_pt2pl) {
     uint64_t np = 0;
     MH_TRY(compact_pairs(scan->ctx, scan->n, final_pairs, pairs_mem, &np));
-    if (np != result->n_final_pairs - result->n_final_pairs_pt2pl) return fail(MH_ERR_INTERNAL, "pair compaction count mismatch");
+    if (np != result->n_final_pairs - result->n_final_pairs_pt2pl)
+      return fail(MH_ERR_INTERNAL, "pair compaction count mismatch: %llu pairings in the buffers, %u in the last accumulation",
+                  (unsigned long long)np, result->n_final_pairs - result->n_final_pairs_pt2pl);
   }
   return MH_OK;
 }
@@ -3184,7 +3192,7 @@ mh_status mh_gn_solve(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt2p
                          ctx->partials_b.as<double>(), nbl);
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, &ctx->d_params->sk,
                        ctx->partials.as<double>(), np ? nblk_acc(np) : 0u, np ? nblk_acc(np) : 0u,
-                       ctx->partials_b.as<double>(), nbl, nbl);
+                       ctx->partials_b.as<double>(), nbl, nbl, in == 0 ? 1u : 0u);
   }
   MH_HIP(hipGetLastError());
   MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));

@@ -710,3 +710,34 @@ def test_previous_pairing_bound_and_its_fallback(ctx, oracle, vs, shift, monkeyp
         for k in ("local_idx", "global_idx", "d2", "global_xyz"):
             np.testing.assert_array_equal(g["pairs"][k], o["pairs"][k])
         np.testing.assert_allclose(g["T"], o["T"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("n_scan,env", [(900, {}), (3000, {}), (3000, {"MH_NO_FUSE16": "1"}), (3000, {"MH_MATCH": "p"}),
+                                        (9000, {}), (20000, {})])
+def test_converged_alignment_with_early_inner_exit(ctx, oracle, n_scan, env, monkeypatch):
+    """Stall test off and far more iterations than the alignment needs: once the Gauss-Newton step falls below min_delta
+    the solver leaves its inner loop after the FIRST step of every ICP iteration.  The launches of the skipped inner step
+    must then do nothing -- k_accum did, the k_solve behind it kept solving on stale partial sums (the fused matchers'
+    wider layout read as k_accum's: a converged alignment jumped by metres; found by tools/fuzz_batch.py).  Every kernel
+    chain (one workgroup, fused row kernel, row + k_accum, one lane per point, quad) against the oracle, iteration by
+    iteration."""
+    scene = synth.make_scene(4242, 70.0, 20)
+    mp = synth.make_map(scene, 120000, 4242)
+    pose = [1.0, -0.5, synth.SENSOR_H, 0.04, 0.003, -0.002]
+    scan = synth.make_scan(scene, pose, rings=64, azimuths=1000, seed=9)
+    scan = scan[np.random.default_rng(3).permutation(len(scan))[:n_scan]]
+    guess = synth.pose_from_ypr(np.array(pose) + [-0.07, 0.28, 0.01, 0.004, -0.003, 0.002])
+    thr, kp = synth.threshold_schedule(2.0, 60)
+    kw = dict(max_iterations=60, threshold=thr, kernel_param=kp, disable_stall_test=True)
+    o = oracle.icp_align(oracle.Map(1.0, 20).insert(mp), scan, guess, oracle.ICPParams(**kw), want_pairs=True)
+    assert min(t["delta_trans"] for t in o["trace"]) < 1e-7  # (the regime this test is about)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = capi.icp_align(capi.Map(ctx, 1.0, 20).build(mp), capi.Scan(ctx, scan), guess, capi.ICPParams(**kw), want_pairs=True)
+    assert g["n_iterations"] == o["n_iterations"] == 60 and g["termination_reason"] == o["termination_reason"]
+    assert [t["n_pairs"] for t in g["trace"]] == [t["n_pairs"] for t in o["trace"]]
+    for a, b in zip(g["trace"], o["trace"]):
+        np.testing.assert_allclose(a["T"], b["T"], rtol=0, atol=1e-9)
+    for k in ("local_idx", "global_idx", "d2", "global_xyz"):
+        np.testing.assert_array_equal(g["pairs"][k], o["pairs"][k])
+    np.testing.assert_allclose(g["T"], o["T"], rtol=0, atol=1e-9)

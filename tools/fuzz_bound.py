@@ -34,6 +34,10 @@ for case in range(n_cases):
     iters = int(rng.choice([15, 40]))
     thr, kp = synth.threshold_schedule(2.0, iters)
     kw = dict(max_iterations=iters, threshold=thr, kernel_param=kp)
+    if rng.integers(0, 3) == 0:  # converge all the way: the inner Gauss-Newton loop then ends early (step < min_delta)
+        iters = 60
+        thr, kp = synth.threshold_schedule(2.0, iters)
+        kw = dict(max_iterations=iters, threshold=thr, kernel_param=kp, disable_stall_test=True)
     o = oracle_c.icp_align(oracle_c.Map(vs, cap, mode).insert(mp), scan, guess, oracle_c.ICPParams(**kw), want_pairs=True)
     os.environ["MH_MATCH"] = match
     g = capi.icp_align(capi.Map(ctx, vs, cap, mode).build(mp), capi.Scan(ctx, scan), guess, capi.ICPParams(**kw), want_pairs=True)
