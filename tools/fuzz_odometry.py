@@ -1,0 +1,71 @@
+"""development aid: random synthetic drives (speed, yaw rate, sweep size, scene, pull-away ramp; default and NDT pipelines;
+motion-model prior on / off) through the C++ driver and through the Python oracle driver, scan by scan: the decisions
+(ICP run / good, key-frames, restarts, iteration counts, hook re-runs, layer and map sizes) identical, poses within 1e-6.
+Now and then a scan is replaced by an unrelated cloud: the alignment is rejected and the driver starts over.  For alignments
+BOTH sides reject, iteration counts are not compared: with a handful of pairings the normal equations are singular and how
+long either side keeps iterating is decided by rounding noise (seen: 22-point layer, 2 pairings, 0 / 3 / 14 / 72 iterations
+depending on the kernel chain) -- the decisions and everything that follows still have to agree."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mola_lidar_odometry_amd import capi, synth  # noqa: E402
+
+capi.lib()
+from mola_lidar_odometry_amd import _mp2p_icp_hip as host  # noqa: E402
+from oracle import odometry_oracle as oo  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 21)
+PIPES = [os.path.join(ROOT, "pipelines", "lidar3d-default-hip.yaml"), os.path.join(ROOT, "pipelines", "lidar3d-ndt-hip.yaml")]
+bad = 0
+for case in range(n_cases):
+    pipe = PIPES[int(rng.integers(0, 3) == 0)]
+    os.environ["MOLA_HIP_MOTION_MODEL_PRIOR"] = "true" if rng.integers(0, 3) == 0 else "false"
+    n_scans = int(rng.integers(8, 16))
+    kw = dict(dt=0.1, speed=float(rng.uniform(2.0, 15.0)), yaw_rate=float(rng.uniform(-0.3, 0.3)), rings=int(rng.choice([16, 32])),
+              azimuths=int(rng.choice([300, 600])), ramp_scans=int(rng.integers(0, 7)))
+    drive = synth.make_drive(n_scans, **kw)
+    o = oo.OdometryOracle(pipe, n_threads=8)
+    lo = host.LidarOdometry(own_context=True)
+    lo.initialize(host.Config.FromYamlFile(pipe))
+    ok, note = True, ""
+    for k, ((xyz, t), st) in enumerate(zip(drive["scans"], drive["stamps"])):
+        junk = rng.integers(0, 25) == 0
+        if junk:  # an unrelated cloud: the ICP result is rejected, the driver starts over
+            xyz = (rng.normal(0, 1, (len(xyz), 3)) * [30, 30, 30] + [0, 0, 500]).astype(np.float32)
+        a = lo.onLidar(st, xyz, t)
+        b = o.on_lidar(st, xyz, t)
+        keys = ("dropped", "first_scan", "icp_run", "icp_good", "had_motion_model", "map_updated", "restarted",
+                "icp_iterations", "twist_corrections", "align_calls", "termination", "n_raw", "n_for_map",
+                "n_for_icp", "n_map_points", "n_map_voxels")
+        hopeless = a["icp_run"] and b["icp_run"] and not a["icp_good"] and not b["icp_good"]
+        if hopeless:  # a rejected alignment (a handful of pairings, singular normal equations): how long each side iterated
+            keys = tuple(q for q in keys if q not in ("icp_iterations", "twist_corrections", "align_calls", "termination"))  # on rounding noise is not compared
+        for key in keys:
+            if a[key] != b[key]:
+                ok, note = False, "scan %d%s %s: %r vs %r | hip %s | oracle %s" % (
+                    k, " (junk)" if junk else "", key, a[key], b[key],
+                    {q: a[q] for q in ("icp_good", "icp_iterations", "twist_corrections", "align_calls", "termination", "goodness", "n_for_icp")},
+                    {q: b[q] for q in ("icp_good", "icp_iterations", "twist_corrections", "align_calls", "termination", "goodness", "n_for_icp")})
+                break
+        if not ok:
+            break
+        if hopeless:
+            continue
+        if abs(a["goodness"] - b["goodness"]) > 1e-9 or abs(a["sigma"] - b["sigma"]) > 1e-9 * max(1.0, abs(b["sigma"])):
+            ok, note = False, "scan %d goodness / sigma" % k
+            break
+        d = float(np.abs(np.array(a["pose"]) - b["pose"]).max())
+        if d > 1e-6:
+            ok, note = False, "scan %d pose differs by %.3e" % (k, d)
+            break
+    bad += 0 if ok else 1
+    print("case %2d %s prior=%s scans=%d speed=%.1f yaw=%.2f rings=%d az=%d ramp=%d -> %s %s" % (
+        case, os.path.basename(pipe)[8:-9], os.environ["MOLA_HIP_MOTION_MODEL_PRIOR"], n_scans, kw["speed"], kw["yaw_rate"], kw["rings"],
+        kw["azimuths"], kw["ramp_scans"], "ok" if ok else "MISMATCH", note), flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
