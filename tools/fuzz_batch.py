@@ -1,5 +1,5 @@
 """development aid: random batches (2-10 jobs; layers of 300-60 k points = every lock-step kernel chain and the per-stream
-fallback; per-job budgets, schedules, priors, stall test, final pairings) through mh_icp_align_batch against the same
+fallback; point maps and an NDT map; per-job budgets, schedules, solver settings, priors, hooks, stall test, final pairings) through mh_icp_align_batch against the same
 jobs run one by one: results bitwise equal."""
 import os
 import sys
@@ -15,7 +15,9 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
 ctx0 = capi.Context(0)
 scene = synth.make_scene(4242, 70.0, 20)
 maps = [capi.Map(ctx0, 1.0, 20).build(synth.make_map(scene, 120000, 4242)),
-        capi.Map(ctx0, 0.5, 8).build(synth.make_map(scene, 60000, 4243))]
+        capi.Map(ctx0, 0.5, 8).build(synth.make_map(scene, 60000, 4243)),
+        capi.Map(ctx0, 2.0, 12, 0, 0.1, 0.05, 4).build(synth.make_map(scene, 120000, 4244))]  # an NDT map: Matcher_Point2Plane rides along
+NDT = 2
 pose = [1.0, -0.5, synth.SENSOR_H, 0.04, 0.003, -0.002]
 cloud = synth.make_scan(scene, pose, rings=64, azimuths=1000, seed=9)
 bad = 0
@@ -26,15 +28,22 @@ for case in range(n_cases):
     if rng.integers(0, 3) == 0:  # a uniform batch: one lock-step group
         sizes = [sizes[0]] * n_jobs
     scans = [capi.Scan(c, cloud[rng.permutation(len(cloud))[:n]]) for c, n in zip(ctxs, sizes)]
-    jm = [maps[int(rng.integers(0, 2))] for _ in range(n_jobs)]
+    jm = [maps[int(rng.choice([0, 0, 1, NDT]))] for _ in range(n_jobs)]
     guesses, ps, priors = [], [], []
     for j in range(n_jobs):
         g = np.array(pose) + np.concatenate([rng.normal(0, 0.15, 3) * [1, 1, 0.1], rng.normal(0, 0.01, 3)])
         guesses.append(synth.pose_from_ypr(g))
         iters = int(rng.choice([3, 8, 25, 60]))
         thr, kp = synth.threshold_schedule(float(rng.choice([1.0, 2.0])), iters)
+        extra = {}
+        if jm[j] is maps[NDT]:
+            extra["pt2pl_threshold"] = float(rng.choice([0.4, 0.8]))
+        if rng.integers(0, 4) == 0:
+            extra.update(hook_enabled=True, hook_min_trans=float(rng.choice([0.05, 0.2])), hook_min_rot=float(np.deg2rad(0.75)))
+        gn = capi.GNParams(max_inner_iterations=int(rng.choice([1, 2, 2, 4])), robust_kernel=int(rng.integers(0, 6)),
+                           min_delta=float(rng.choice([0.0, 1e-7, 1e-4])), max_cost=float(rng.choice([0.0, 0.0, 1e-3])))
         ps.append(capi.ICPParams(max_iterations=iters, threshold=thr, kernel_param=kp, disable_stall_test=bool(rng.integers(0, 2)),
-                                 poll_every=int(rng.choice([0, 4, iters]))))
+                                 poll_every=int(rng.choice([0, 4, iters])), gn=gn, **extra))
         priors.append((guesses[-1], np.diag([4.0, 4.0, 4.0, 100.0, 100.0, 100.0])) if rng.integers(0, 4) == 0 else None)
     singles = []
     for j, (m, s, g, p, pr) in enumerate(zip(jm, scans, guesses, ps, priors)):
