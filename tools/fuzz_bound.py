@@ -20,9 +20,9 @@ for case in range(n_cases):
     vs = float(rng.choice([0.2, 0.35, 0.5, 1.0, 1.7]))
     cap = int(rng.choice([0, 3, 8, 20, 40]))
     mode = int(rng.choice([0, 0, 1]))
-    n_scan = int(rng.choice([1500, 4000, 9000, 20000]))
+    n_scan = int(rng.choice([1500, 4000, 9000, 20000, 24000]))
     shift = float(rng.uniform(0.05, 1.2))
-    match = str(rng.choice(["q", "s", "q", "s", "o"]))
+    match = str(rng.choice(["q", "s", "q", "s", "o", "t", "w", "p"]))
     seed = int(rng.integers(1, 10000))
     scene = synth.make_scene(seed, 60.0, 20)
     mp = synth.make_map(scene, int(rng.choice([40000, 150000])), seed)
