@@ -61,6 +61,11 @@ enum { MH_MEM_HOST = 0, MH_MEM_DEVICE = 1, MH_MEM_HOST_PINNED = 2 };
 /* coordinate -> voxel index rule (FLOOR is the default) */
 enum { MH_INDEX_FLOOR = 0, MH_INDEX_TRUNC = 1 };
 
+/* Voxel-index distance used by remove_voxels_farther_than (lidar3d-default.yaml:237-238; the comment there says "L1",
+ * upstream's code is unverified [U]): max(|dk|) (default), |dkx|+|dky|+|dkz|, or sqrt(dkx^2+dky^2+dkz^2), each
+ * compared with ceil(remove_voxels_farther_than / voxel_size).  A run-time switch until the reference decides it. */
+enum { MH_FAR_CHEBYSHEV = 0, MH_FAR_L1 = 1, MH_FAR_L2 = 2 };
+
 /* mp2p_icp::RobustKernel [U] as selected at lidar3d-default.yaml:188.  The exact upstream form of
  * GemanMcClure is unverified (SURVEY App.B U1), hence the variants. */
 enum {
@@ -120,6 +125,7 @@ typedef struct {
   float min_distance_between_points; /* insertOpts: drop a point closer than this to a stored point of its voxel */
   float ndt_max_eigen_ratio;         /* insertOpts.max_eigen_ratio_for_planes; > 0 enables per-voxel NDT statistics */
   uint32_t ndt_min_points;           /* voxels with fewer stored points carry no NDT (0 -> 4) */
+  uint32_t far_voxel_metric;         /* MH_FAR_* : how mh_map_insert measures "farther than" (see there) */
 } mh_map_params;
 
 typedef struct {
@@ -146,8 +152,8 @@ MH_API mh_status mh_map_get_info(const mh_map* map, mh_map_info* info);
  * layer `scan` (vehicle frame, input_layer_in_local_coordinates: true): every point is composed with the robot
  * pose T (row-major 3x4, fp64, result rounded to float) and offered to insertPoint in order, after everything the
  * map already stores; then, if remove_voxels_farther_than > 0 (insertOpts, yaml:238), every voxel whose index
- * distance max(|dkx|,|dky|,|dkz|) to the voxel of T's translation exceeds ceil(remove_voxels_farther_than/voxel_size)
- * is erased [U].  The source index of a new point is (points ever offered to this map) + its index in `scan`.
+ * distance (mh_map_params::far_voxel_metric; default max(|dkx|,|dky|,|dkz|)) to the voxel of T's translation exceeds
+ * ceil(remove_voxels_farther_than/voxel_size) is erased [U].  The source index of a new point is (points ever offered to this map) + its index in `scan`.
  * Nothing travels to the host except four counters. */
 MH_API mh_status mh_map_insert(mh_map* map, const mh_scan* scan, const double T[12], float remove_voxels_farther_than);
 /* Copy the stored content to HOST arrays (any may be NULL): points voxel by voxel, voxels in ascending
@@ -269,8 +275,13 @@ typedef struct {
   float *nx, *ny, *nz; /* plane unit normal */
 } mh_pairs_pl_out;
 
+/* What Matcher_Point2Plane.distanceThreshold (lidar3d-ndt.yaml:197) is compared with -- SURVEY App.B U10, a run-time
+ * switch until the reference decides it: the point-to-plane distance |n.(p'-c)| (default) or the distance to the
+ * plane's centroid |p'-c| (fp32 squares, un-fused).  The search for the nearest planar voxel is the same. */
+enum { MH_PT2PL_PLANE_DISTANCE = 0, MH_PT2PL_CENTROID_DISTANCE = 1 };
+
 MH_API mh_status mh_nn_search_pt2pl(const mh_map* map, const mh_scan* scan, const double T[12], double distance_threshold,
-                                    const mh_pairs_pl_out* out, int32_t mem, mh_match_info* info);
+                                    uint32_t mode, const mh_pairs_pl_out* out, int32_t mem, mh_match_info* info);
 
 /* ------------------------------------------------------------------------------------------------
  * Solver-granular path.  Replaces mp2p_icp::Solver_GaussNewton::impl_optimal_pose /
@@ -363,6 +374,7 @@ typedef struct {
                                    expected_iterations), then short ones */
   uint32_t expected_iterations; /* with poll_every = 0: the caller's own estimate of how many iterations this call will
                                    run (e.g. what its previous call of the same kind ran), 0 = let the library predict */
+  uint32_t pt2pl_mode;          /* MH_PT2PL_* : the acceptance test of the point-to-plane matcher (with pt2pl_threshold) */
   uint32_t profile;             /* 1: time every match kernel with HIP events on the context stream (such a job is
                                    enqueued kernel by kernel instead of replaying the captured graph); 2: in
                                    mh_icp_align_batch, do that for job 0 only (lock step: its share of the launches) */

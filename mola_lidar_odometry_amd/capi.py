@@ -20,6 +20,8 @@ LIB_PATH = os.path.join(_HERE, "libmolahip.so")
 MH_OK = 0
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 INDEX_FLOOR, INDEX_TRUNC = 0, 1
+FAR_CHEBYSHEV, FAR_L1, FAR_L2 = 0, 1, 2              # mh_map_params::far_voxel_metric
+PT2PL_PLANE_DISTANCE, PT2PL_CENTROID_DISTANCE = 0, 1  # mh_icp_params::pt2pl_mode
 KERNEL_NONE, KERNEL_GM_C4, KERNEL_GM_KISS, KERNEL_GM_BARRON, KERNEL_CAUCHY, KERNEL_GM_C2 = range(6)
 TERM_NAMES = ["Undefined", "NoPairings", "SolverError", "MaxIterations", "Stalled",
               "QualityCheckpointFailed", "HookRequest"]
@@ -39,7 +41,7 @@ class MolahipError(RuntimeError):
 class MapParams(C.Structure):
     _fields_ = [("voxel_size", C.c_float), ("max_points_per_voxel", C.c_uint32), ("index_mode", C.c_uint32),
                 ("min_distance_between_points", C.c_float), ("ndt_max_eigen_ratio", C.c_float),
-                ("ndt_min_points", C.c_uint32)]
+                ("ndt_min_points", C.c_uint32), ("far_voxel_metric", C.c_uint32)]
 
 
 class MapInfo(C.Structure):
@@ -90,7 +92,8 @@ class ICPParamsC(C.Structure):
                 ("threshold_angular_deg", C.c_double), ("pt2pl_threshold", _DP), ("gn", GNParamsC), ("hook_enabled", C.c_uint32),
                 ("hook_min_trans", C.c_double), ("hook_min_rot", C.c_double), ("hook_checkpoint", C.c_double * 12),
                 ("compute_covariance", C.c_uint32), ("cov_findif_xyz", C.c_double), ("cov_findif_ang", C.c_double),
-                ("poll_every", C.c_uint32), ("expected_iterations", C.c_uint32), ("profile", C.c_uint32)]
+                ("poll_every", C.c_uint32), ("expected_iterations", C.c_uint32), ("pt2pl_mode", C.c_uint32),
+                ("profile", C.c_uint32)]
 
 
 class ICPIter(C.Structure):
@@ -153,7 +156,7 @@ _SIGNATURES = {
                                  C.POINTER(MatchInfo)]),
     "mh_nn_search_dense": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int32]),
-    "mh_nn_search_pt2pl": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_double, C.POINTER(PairsPlOut), C.c_int32,
+    "mh_nn_search_pt2pl": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_double, C.c_uint32, C.POINTER(PairsPlOut), C.c_int32,
                                        C.POINTER(MatchInfo)]),
     "mh_icp_get_pt2pl_pairs": (C.c_int32, [C.c_void_p, C.POINTER(PairsPlOut), C.c_int32, C.POINTER(C.c_uint64)]),
     "mh_gn_solve": (C.c_int32, [C.c_void_p, C.POINTER(PairsPt2Pt), C.POINTER(PairsPt2Pl), C.c_int32,
@@ -268,11 +271,11 @@ class Map:
     """Device-resident voxel-hashed local map (stands in for mola::HashedVoxelPointCloud)."""
 
     def __init__(self, ctx: Context, voxel_size=1.0, max_points_per_voxel=20, index_mode=INDEX_FLOOR,
-                 min_distance_between_points=0.0, ndt_max_eigen_ratio=0.0, ndt_min_points=4):
+                 min_distance_between_points=0.0, ndt_max_eigen_ratio=0.0, ndt_min_points=4, far_voxel_metric=FAR_CHEBYSHEV):
         self.ctx = ctx
         self._h = C.c_void_p()
         p = MapParams(voxel_size, max_points_per_voxel, index_mode, min_distance_between_points, ndt_max_eigen_ratio,
-                      ndt_min_points)
+                      ndt_min_points, far_voxel_metric)
         _chk(lib().mh_map_create(ctx._h, C.byref(p), C.byref(self._h)))
         ctx._children.add(self)
 
@@ -458,13 +461,13 @@ def _pl_arrays(n):
     return li, a, PairsPlOut(li.ctypes.data_as(_UP), *[x.ctypes.data_as(_FP) for x in a])
 
 
-def nn_search_pt2pl(m: Map, s: Scan, T, distance_threshold):
+def nn_search_pt2pl(m: Map, s: Scan, T, distance_threshold, mode=PT2PL_PLANE_DISTANCE):
     """Matcher_Point2Plane on an NDT map (mh_nn_search_pt2pl)."""
     li, a, out = _pl_arrays(max(s.n, 1))
     info = MatchInfo()
     T = _T12(T)
-    _chk(lib().mh_nn_search_pt2pl(m._h, s._h, T.ctypes.data_as(_DP), float(distance_threshold), C.byref(out), MEM_HOST,
-                                  C.byref(info)))
+    _chk(lib().mh_nn_search_pt2pl(m._h, s._h, T.ctypes.data_as(_DP), float(distance_threshold), int(mode), C.byref(out),
+                                  MEM_HOST, C.byref(info)))
     k = int(info.n_pairs)
     return dict(local_idx=li[:k].copy(), centroid=np.stack(a[:3], 1)[:k].copy(), normal=np.stack(a[3:], 1)[:k].copy(),
                 potential_pairings=int(info.potential_pairings))
@@ -561,6 +564,7 @@ class ICPParams:
     kernel_param: object = None
     threshold_angular_deg: float = 0.0
     pt2pl_threshold: object = None  # None, or per-iteration Matcher_Point2Plane.distanceThreshold (needs an NDT map)
+    pt2pl_mode: int = 0             # PT2PL_PLANE_DISTANCE | PT2PL_CENTROID_DISTANCE
     gn: GNParams = field(default_factory=GNParams)
     hook_enabled: bool = False
     hook_min_trans: float = 0.15
@@ -598,6 +602,7 @@ class ICPParams:
         cp.cov_findif_xyz = self.cov_findif_xyz
         cp.cov_findif_ang = self.cov_findif_ang
         cp.poll_every = self.poll_every
+        cp.pt2pl_mode = int(self.pt2pl_mode)
         cp.expected_iterations = self.expected_iterations
         cp.profile = int(self.profile)  # 0 | 1 (all jobs) | 2 (job 0 of a batch only)
         return cp, (thr, kp, plt)

@@ -542,6 +542,13 @@ __device__ __forceinline__ void acc_pt2pl_rows(double* v, const double* __restri
   v[28] = 1.0;
 }
 
+// Matcher_Point2Plane's acceptance test.  thr > 0: point-to-plane distance |n.(p'-c)| < thr (default,
+// MH_PT2PL_PLANE_DISTANCE); thr < 0 encodes MH_PT2PL_CENTROID_DISTANCE: |p'-c|^2 < thr^2, fp32, un-fused like the search.
+__device__ __forceinline__ bool pl_accept(const f32x4& bn, float dx, float dy, float dz, float thr) {
+  if (thr < 0.f) return (dx * dx + dy * dy) + dz * dz < thr * thr;
+  return fabsf((bn.x * dx + bn.y * dy) + bn.z * dz) < thr;
+}
+
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_match_pl(const IcpDeviceState* __restrict__ st, PoseArg Targ, float thr_arg,
                                                      const MatchK* __restrict__ kp, const float* __restrict__ lx,
@@ -624,8 +631,7 @@ __global__ __launch_bounds__(kBlock) void k_match_pl(const IcpDeviceState* __res
     if (best_first >= 2u) {
       bn = ((gpts_ptr)map.pts)[best_first - 1u];
       const float dx = px - bc.x, dy = py - bc.y, dz = pz - bc.z;
-      const float e = (bn.x * dx + bn.y * dy) + bn.z * dz;
-      ok = fabsf(e) < thr;
+      ok = pl_accept(bn, dx, dy, dz, thr);
     }
     const float4 c4 = make_float4(bc.x, bc.y, bc.z, ok ? 1.f : 0.f), n4 = make_float4(bn.x, bn.y, bn.z, 0.f);
     pl_c[i] = c4;
@@ -694,8 +700,7 @@ __device__ __forceinline__ bool pl_row_search(const MapView& map, uint32_t r16, 
     bn.y = __uint_as_float(row_bcast_u32(__float_as_uint(mn.y), owner));
     bn.z = __uint_as_float(row_bcast_u32(__float_as_uint(mn.z), owner));
     const float dx = px - bc.x, dy = py - bc.y, dz = pz - bc.z;
-    const float e = (bn.x * dx + bn.y * dy) + bn.z * dz;
-    ok = fabsf(e) < thr;
+    ok = pl_accept(bn, dx, dy, dz, thr);
   }
   return ok;
 }
@@ -2062,7 +2067,10 @@ struct AlignJob {
       }
       memcpy(ctx->h_sched, p->threshold, mi * sizeof(double));
       memcpy(ctx->h_sched + mi, p->kernel_param, mi * sizeof(double));
-      if (pl) memcpy(ctx->h_sched + 2 * mi, p->pt2pl_threshold, mi * sizeof(double));
+      if (pl) {  // MH_PT2PL_CENTROID_DISTANCE travels as a negative threshold (pl_accept)
+        const double sgn = p->pt2pl_mode == MH_PT2PL_CENTROID_DISTANCE ? -1.0 : 1.0;
+        for (size_t k = 0; k < mi; k++) ctx->h_sched[2 * mi + k] = sgn * fabs(p->pt2pl_threshold[k]);
+      }
       nsched_pending = nsched;
       if (!defer_upload) MH_HIP(hipMemcpyAsync(ctx->sched.p, ctx->h_sched, nsched * sizeof(double), hipMemcpyHostToDevice, s));
     }
@@ -2577,9 +2585,11 @@ void set_pairs_fields(const PairsPlan& pp, size_t job_index, BatchJob& d) {
 }
 
 // compaction of every finished job's pairings into the block (descriptors `dj` already on the device) + the download
-mh_status finish_pairs(mh_ctx* lead, const PairsPlan& pp, const BatchJob* dj, uint32_t A, uint32_t gx_cov) {
+// `lead` owns the staging buffer, the copy stream and its events (plan_pairs: always the FIRST job's context, which is
+// what mh_ctx_synchronize(scans[0]'s context) and the next batch wait on); `s` is the stream the compaction runs on --
+// the lock-step group's, which is another context's when job 0 is trivial (same device: events order them).
+mh_status finish_pairs(mh_ctx* lead, hipStream_t s, const PairsPlan& pp, const BatchJob* dj, uint32_t A, uint32_t gx_cov) {
   if (!pp.want || A == 0) return MH_OK;
-  hipStream_t s = lead->stream;
   if (lead->pairs_copy_pending) MH_HIP(hipStreamWaitEvent(s, lead->ev_pairs_copied, 0));  // staging still being read
   hipLaunchKernelGGL(k_count_valid_b, dim3(gx_cov, A), dim3(kBlock), 0, s, dj);
   hipLaunchKernelGGL(k_scan_blocks_b, dim3(1, A), dim3(1024), 0, s, dj);
@@ -2867,7 +2877,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       jobs[0].res->total_ms = 0.0;
     }
     if (pairs_by_group) {
-      MH_TRY(finish_pairs(groups[0].lead, pp, groups[0].dj, (uint32_t)groups[0].jobs.size(), groups[0].gx_cov));
+      MH_TRY(finish_pairs(lead0, groups[0].lead->stream, pp, groups[0].dj, (uint32_t)groups[0].jobs.size(), groups[0].gx_cov));
       return MH_OK;
     }
   }
@@ -2910,7 +2920,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       gx_cov = h_desc[a].nb > gx_cov ? h_desc[a].nb : gx_cov;
     }
     MH_HIP(hipMemcpyAsync(lead->batch_desc.p, h_desc, A * sizeof(BatchJob), hipMemcpyHostToDevice, lead->stream));
-    MH_TRY(finish_pairs(lead, pp, lead->batch_desc.as<BatchJob>(), A, gx_cov));
+    MH_TRY(finish_pairs(lead, lead->stream, pp, lead->batch_desc.as<BatchJob>(), A, gx_cov));
     if (pp.mem != MH_MEM_HOST) MH_HIP(hipStreamSynchronize(lead->stream));  // h_batch is reused by the next batch
   }
   return MH_OK;
@@ -3071,8 +3081,10 @@ static mh_status compact_pl_pairs(mh_ctx* ctx, size_t n, const mh_pairs_pl_out* 
 }
 
 mh_status mh_nn_search_pt2pl(const mh_map* map, const mh_scan* scan, const double T[12], double distance_threshold,
-                             const mh_pairs_pl_out* out, int32_t mem, mh_match_info* info) {
+                             uint32_t mode, const mh_pairs_pl_out* out, int32_t mem, mh_match_info* info) {
   MH_REQUIRE(map && scan && T, "null argument");
+  MH_REQUIRE(mode == MH_PT2PL_PLANE_DISTANCE || mode == MH_PT2PL_CENTROID_DISTANCE, "bad pt2pl mode");
+  distance_threshold = (mode == MH_PT2PL_CENTROID_DISTANCE ? -1.0 : 1.0) * fabs(distance_threshold);
   MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
   MH_REQUIRE(map->ctx->device == scan->ctx->device, "map and scan live on different devices");
   MH_REQUIRE(pose_ok(T), "non-finite pose");

@@ -27,8 +27,16 @@ __device__ __forceinline__ int voxel_index(float c, float inv_vs, uint32_t trunc
   return trunc ? (int)s : (int)floorf(s);
 }
 
+// remove_voxels_farther_than's voxel-index distance test (mh_map_params::far_voxel_metric, MH_FAR_*)
+__device__ __forceinline__ bool far_voxel(int dx, int dy, int dz, int dist, uint32_t metric) {
+  dx = abs(dx); dy = abs(dy); dz = abs(dz);
+  if (metric == MH_FAR_L1) return (long long)dx + dy + dz > (long long)dist;
+  if (metric == MH_FAR_L2) return (long long)dx * dx + (long long)dy * dy + (long long)dz * dz > (long long)dist * dist;
+  return max(max(dx, dy), dz) > dist;
+}
+
 __global__ void k_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n,
-                       float inv_vs, uint32_t trunc, int4 evict /* {cx,cy,cz,dist_in_grid}; w < 0 = off */,
+                       float inv_vs, uint32_t trunc, int4 evict /* {cx,cy,cz,dist_in_grid}; w < 0 = off */, uint32_t metric,
                        unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t* __restrict__ flags) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -39,7 +47,7 @@ __global__ void k_keys(const float* __restrict__ x, const float* __restrict__ y,
     if (fabsf(sx) < 1.0e6f && fabsf(sy) < 1.0e6f && fabsf(sz) < 1.0e6f) {
       const int kx = voxel_index(px, inv_vs, trunc), ky = voxel_index(py, inv_vs, trunc), kz = voxel_index(pz, inv_vs, trunc);
       // remove_voxels_farther_than (yaml:238): erasing a voxel after the insertion == never storing its points
-      const bool far = evict.w >= 0 && max(max(abs(kx - evict.x), abs(ky - evict.y)), abs(kz - evict.z)) > evict.w;
+      const bool far = evict.w >= 0 && far_voxel(kx - evict.x, ky - evict.y, kz - evict.z, evict.w, metric);
       if (!far) k = pack_key(kx, ky, kz);
     } else {
       atomicOr(&flags[0], 1u);  // voxel index does not fit 21 bits
@@ -51,14 +59,14 @@ __global__ void k_keys(const float* __restrict__ x, const float* __restrict__ y,
 
 // merge path of mh_map_insert: remove_voxels_farther_than applied to the SORTED keys (k_keys left them alone so that the
 // stored points stay in order); the runs of empty keys this leaves inside the sequence are skipped by everything below
-__global__ void k_evict_sorted(unsigned long long* __restrict__ ks, uint32_t n, int4 evict) {
+__global__ void k_evict_sorted(unsigned long long* __restrict__ ks, uint32_t n, int4 evict, uint32_t metric) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned long long k = ks[i];
   if (k == kEmptyKey) return;
   int kx, ky, kz;
   unpack_key(k, kx, ky, kz);
-  if (max(max(abs(kx - evict.x), abs(ky - evict.y)), abs(kz - evict.z)) > evict.w) ks[i] = kEmptyKey;
+  if (far_voxel(kx - evict.x, ky - evict.y, kz - evict.z, evict.w, metric)) ks[i] = kEmptyKey;
 }
 
 // head[i] = 1 where a new voxel run starts; counters[1] = number of valid (finite) points
@@ -328,6 +336,7 @@ mh_status mh_map_create(mh_ctx* ctx, const mh_map_params* params, mh_map** out) 
   *out = nullptr;
   MH_REQUIRE(params->voxel_size > 0.f && isfinite(params->voxel_size), "voxel_size must be > 0");
   MH_REQUIRE(params->index_mode == MH_INDEX_FLOOR || params->index_mode == MH_INDEX_TRUNC, "bad index_mode");
+  MH_REQUIRE(params->far_voxel_metric <= MH_FAR_L2, "bad far_voxel_metric");
   MH_REQUIRE(params->min_distance_between_points >= 0.f && params->ndt_max_eigen_ratio >= 0.f, "negative NDT parameter");
   mh_map* m = new (std::nothrow) mh_map();
   if (!m) return fail(MH_ERR_OUT_OF_MEMORY, "host allocation failed");
@@ -471,7 +480,7 @@ mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const fl
     const int4 ev = evict ? make_int4(evict[0], evict[1], evict[2], evict[3]) : make_int4(0, 0, 0, -1);
     const int4 ev_keys = merge_path ? make_int4(0, 0, 0, -1) : ev;  // (merge path: eviction after the merge, k_evict_sorted)
     hipLaunchKernelGGL(k_keys, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, N, m->inv_vs,
-                       (uint32_t)(m->params.index_mode == MH_INDEX_TRUNC), ev_keys, keys, idx, counters);
+                       (uint32_t)(m->params.index_mode == MH_INDEX_TRUNC), ev_keys, m->params.far_voxel_metric, keys, idx, counters);
     unsigned long long* keys_new = keys + 2 * n;
     uint32_t* idx_new = idx + 2 * n;
     size_t tmp = 0;
@@ -498,7 +507,7 @@ mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const fl
       tb = ctx->sort_tmp.bytes;
       MH_HIP(rocprim::merge(ctx->sort_tmp.p, tb, keys, keys_new, keys_s, idx, idx_new, idx_s, n_stored, n_new,
                             rocprim::less<unsigned long long>(), s));
-      if (ev.w >= 0) hipLaunchKernelGGL(k_evict_sorted, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, N, ev);
+      if (ev.w >= 0) hipLaunchKernelGGL(k_evict_sorted, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, N, ev, m->params.far_voxel_metric);
     } else {
       MH_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tb, keys, keys_s, idx, idx_s, N, 0, 64, s));
     }

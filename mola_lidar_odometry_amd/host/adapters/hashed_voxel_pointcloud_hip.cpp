@@ -1,6 +1,8 @@
 // hashed_voxel_pointcloud_hip.cpp -- see the header.  NOT compiled here; [U] = verify against the installed MRPT / MOLA.
 #include "hashed_voxel_pointcloud_hip.h"
 
+#include "molahip_host/plugin_switches.h"
+
 #include <mrpt/core/initializer.h>
 #include <mrpt/obs/CObservationPointCloud.h>  // [U]
 #include <mrpt/opengl/CPointCloud.h>          // [U]
@@ -34,7 +36,8 @@ void HashedVoxelPointCloudHIP::ensure_device() const
     mh_map_params p{};
     p.voxel_size                  = voxel_size_;                                   // creationOpts.voxel_size (yaml:233)
     p.max_points_per_voxel        = insertionOptions.max_points_per_voxel;        // yaml:235
-    p.index_mode                  = MH_INDEX_FLOOR;
+    p.index_mode                  = molahip_host::plugin_switches().index_mode;       // MOLA_HIP_INDEX_MODE (default floor)
+    p.far_voxel_metric            = molahip_host::plugin_switches().far_voxel_metric; // MOLA_HIP_FAR_VOXEL_METRIC (yaml:237-238)
     p.min_distance_between_points = insertionOptions.min_distance_between_points; // yaml:236
     mh_check(mh_map_create(ctx_, &p, &map_), "mh_map_create");
     mh_check(mh_scan_create(ctx_, nullptr, nullptr, nullptr, 0, MH_MEM_HOST, &staging_), "mh_scan_create");

@@ -11,6 +11,7 @@
 
 #include "mp2p_icp_hip/mp2p_icp_hip.h"
 #include "molahip_host/hook_replay.h"
+#include "molahip_host/plugin_switches.h"
 
 namespace mp2p_icp_hip {
 
@@ -169,7 +170,8 @@ HashedVoxelPointCloud::HashedVoxelPointCloud(float voxel_size, uint32_t max_poin
   mh_map_params p{};
   p.voxel_size = voxel_size;
   p.max_points_per_voxel = max_points_per_voxel;
-  p.index_mode = MH_INDEX_FLOOR;
+  p.index_mode = molahip_host::plugin_switches().index_mode;          // MOLA_HIP_INDEX_MODE (default floor)
+  p.far_voxel_metric = molahip_host::plugin_switches().far_voxel_metric;  // MOLA_HIP_FAR_VOXEL_METRIC (default Chebyshev)
   check(mh_map_create(ctx_->get(), &p, &map_), "mh_map_create");
 }
 HashedVoxelPointCloud::HashedVoxelPointCloud(const mh_map_params& p, std::shared_ptr<DeviceContext> ctx) : ctx_(std::move(ctx)) {
@@ -180,7 +182,8 @@ static mh_map_params ndt_params(float vs, uint32_t cap, float min_dist, float ra
   mh_map_params p{};
   p.voxel_size = vs;
   p.max_points_per_voxel = cap;
-  p.index_mode = MH_INDEX_FLOOR;
+  p.index_mode = molahip_host::plugin_switches().index_mode;
+  p.far_voxel_metric = molahip_host::plugin_switches().far_voxel_metric;
   p.min_distance_between_points = min_dist;
   p.ndt_max_eigen_ratio = ratio;
   p.ndt_min_points = 4;
@@ -400,7 +403,8 @@ void Matcher_Point2Plane::impl_match(const metric_map_t& pcGlobal, const metric_
     for (auto& v : a) v.resize(n);
     mh_pairs_pl_out po{li.data(), a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), a[5].data()};
     mh_match_info info{};
-    const mh_status st = mh_nn_search_pt2pl(glob.handle(), scan, localPose.T, distanceThreshold, &po, MH_MEM_HOST, &info);
+    const mh_status st = mh_nn_search_pt2pl(glob.handle(), scan, localPose.T, distanceThreshold,
+                                            molahip_host::plugin_switches().pt2pl_mode, &po, MH_MEM_HOST, &info);
     mh_scan_destroy(scan);
     check(st, "mh_nn_search_pt2pl");
     append_pl_pairs(loc, li, a, info.n_pairs, out);
@@ -711,6 +715,7 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
   ip.compute_covariance = 1;
   ip.cov_findif_xyz = 1e-7;
   ip.cov_findif_ang = 1e-7;
+  molahip_host::apply_switches(ip, molahip_host::plugin_switches());  // MOLA_HIP_* overrides, if any are set
   if (p.maxIterations > full_budget_) full_budget_ = p.maxIterations;
   const int call_kind = p.maxIterations < full_budget_ ? 1 : 0;
   ip.expected_iterations = last_iterations_[call_kind];

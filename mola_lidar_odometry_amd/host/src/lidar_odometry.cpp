@@ -1,6 +1,7 @@
 // lidar_odometry.cpp -- see mola_lidar_odometry_hip/LidarOdometry.h.  Control logic only: the arithmetic on points
 // is behind include/molahip.h.  Citations are module/src/LidarOdometry.cpp unless another file is named.
 #include "mola_lidar_odometry_hip/LidarOdometry.h"
+#include "molahip_host/plugin_switches.h"
 
 #include <chrono>
 #include <cmath>
@@ -439,7 +440,7 @@ static mh_preprocess_params make_pp(double decim_map_res, double decim_icp_res, 
   pp.decim_map_resolution = (float)decim_map_res;
   pp.decim_icp_resolution = (float)decim_icp_res;
   pp.min_points_to_filter = min_points_to_filter;
-  pp.index_mode = MH_INDEX_FLOOR;
+  pp.index_mode = (int32_t)molahip_host::plugin_switches().index_mode;  // MOLA_HIP_INDEX_MODE (default floor)
   pp.range_min = (float)range_min;
   pp.range_max = (float)range_max;
   pp.bbox_mode = bbox_mode;
@@ -567,7 +568,8 @@ void LidarOdometry::create_local_map() {  // :1165-1171 with yaml:228-242
   map_voxel_size_ = eval_now(co["voxel_size"].asString(), vars);
   mp.voxel_size = (float)map_voxel_size_;
   mp.max_points_per_voxel = io.has("max_points_per_voxel") ? (uint32_t)eval_now(io["max_points_per_voxel"].asString(), vars) : 0;
-  mp.index_mode = MH_INDEX_FLOOR;
+  mp.index_mode = molahip_host::plugin_switches().index_mode;
+  mp.far_voxel_metric = molahip_host::plugin_switches().far_voxel_metric;  // MOLA_HIP_FAR_VOXEL_METRIC
   mp.min_distance_between_points = io.has("min_distance_between_points") ? (float)eval_now(io["min_distance_between_points"].asString(), vars) : 0.f;
   remove_voxels_farther_than_ = io.has("remove_voxels_farther_than") ? (float)eval_now(io["remove_voxels_farther_than"].asString(), vars) : 0.f;
   if (ends_with(cls, "NDT")) {

@@ -7,6 +7,7 @@
 
 #include "mola_lidar_odometry_hip/LidarOdometry.h"
 #include "mp2p_icp_hip/mp2p_icp_hip.h"
+#include "molahip_host/plugin_switches.h"
 
 namespace py = pybind11;
 using namespace mp2p_icp_hip;
@@ -46,6 +47,19 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
       .def("size", &Config::size)
       .def("asString", &Config::asString);
   m.def("evaluate_expression", &evaluate_expression);
+  // MOLA_HIP_* switches (molahip_host/plugin_switches.h, shared with the mp2p_icp adapter): re-read the environment, and
+  // show what was read -- what the adapter would pass to the C ABI for an upstream `RobustKernel::<name>`
+  m.def("reload_plugin_switches", [] { molahip_host::reload_plugin_switches(); });
+  m.def("plugin_switches", [] {
+    const auto& s = molahip_host::plugin_switches();
+    py::dict d;
+    d["gm_form"] = s.gm_form; d["index_mode"] = s.index_mode; d["cov_step_xyz"] = s.cov_step_xyz; d["cov_step_ang"] = s.cov_step_ang;
+    d["min_delta"] = s.min_delta; d["max_cost"] = s.max_cost; d["pt2pl_mode"] = s.pt2pl_mode;
+    d["far_voxel_metric"] = s.far_voxel_metric; d["force_cpu"] = s.force_cpu;
+    return d;
+  });
+  m.def("kernel_from_upstream_name", [](const std::string& n) { return molahip_host::kernel_from_upstream_name(n.c_str(), molahip_host::plugin_switches()); });
+  m.def("term_reason_name", [](uint32_t t) { return std::string(enum2str(molahip_host::term_reason_to<IterTermReason>(t))); });
   m.def("evaluate_compiled", [](const std::string& e, const std::map<std::string, double>& v) { return CompiledExpression(e).evaluate(v); });
   py::class_<ParameterSource>(m, "ParameterSource")
       .def(py::init<>())

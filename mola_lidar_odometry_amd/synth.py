@@ -239,29 +239,62 @@ def make_sweep(scene: Scene, T_ref, twist, sweep_time: float = 0.1, rings: int =
             np.ascontiguousarray(tt[hit], dtype=np.float32))
 
 
-def make_drive(n_scans: int = 12, dt: float = 0.1, speed: float = 8.0, yaw_rate: float = 0.12, rings: int = 32,
-               azimuths: int = 600, seed: int = 4242, half_extent: float = 120.0, n_boxes: int = 160,
+def drive_plan(n_scans: int = 12, dt: float = 0.1, speed: float = 8.0, yaw_rate: float = 0.12, seed: int = 4242,
                ramp_scans: int = 6):
-    """A synthetic drive along the street canyon: ground-truth poses (12 doubles each), per-scan twists and skewed
-    sweeps with per-point time stamps.  The vehicle pulls away from rest over `ramp_scans` scans and then moves with
-    a slowly varying twist; the pose at scan k+1 is the pose at scan k composed with (Exp_SO3(w dt), v dt), so a
-    constant-velocity model is exact up to the variation.  The canyon is cluttered (n_boxes) because two facades and
-    a ground plane alone do not constrain the motion along the street."""
-    scene = make_scene(seed, half_extent, n_boxes)
+    """Poses, twists, stamps and sweep seeds of make_drive (cheap: a recurrence); the sweeps themselves are independent
+    given these, so a caller may cast them in worker processes (drive_sweep)."""
     T = pose_from_ypr([-60.0, 0.5, SENSOR_H, 0.0, 0.0, 0.0]).reshape(3, 4)
-    poses, twists, scans, stamps = [], [], [], []
+    poses, twists, stamps, seeds = [], [], [], []
     for k in range(n_scans):
         gain = min(1.0, k / float(ramp_scans)) if ramp_scans > 0 else 1.0
         tw = np.array([gain * speed * (1.0 + 0.05 * np.sin(0.7 * k)), 0.02 * np.cos(0.5 * k), 0.0, 0.0, 0.0,
                        gain * yaw_rate * np.sin(0.9 * k)])
-        xyz, t = make_sweep(scene, T.reshape(12), tw, dt, rings, azimuths, seed + 10 * k)
         poses.append(T.reshape(12).copy())
         twists.append(tw)
-        scans.append((xyz, t))
         stamps.append(1000.0 + k * dt)
+        seeds.append(seed + 10 * k)
         Rn = _so3_exp((tw[3:] * dt)[None])[0]
         T = np.concatenate([T[:, :3] @ Rn, (T[:, :3] @ (tw[:3] * dt) + T[:, 3])[:, None]], axis=1)
-    return dict(scene=scene, poses=np.asarray(poses), twists=np.asarray(twists), scans=scans, stamps=np.asarray(stamps))
+    return dict(poses=np.asarray(poses), twists=np.asarray(twists), stamps=np.asarray(stamps), seeds=seeds, dt=dt)
+
+
+def drive_sweep(args):
+    """One sweep of a drive_plan: args = (scene seed, half_extent, n_boxes, pose, twist, dt, rings, azimuths, sweep seed)."""
+    scene_seed, half_extent, n_boxes, pose, tw, dt, rings, azimuths, sweep_seed = args
+    return make_sweep(make_scene(scene_seed, half_extent, n_boxes), pose, tw, dt, rings, azimuths, sweep_seed)
+
+
+def make_drive(n_scans: int = 12, dt: float = 0.1, speed: float = 8.0, yaw_rate: float = 0.12, rings: int = 32,
+               azimuths: int = 600, seed: int = 4242, half_extent: float = 120.0, n_boxes: int = 160,
+               ramp_scans: int = 6, pool=None):
+    """A synthetic drive along the street canyon: ground-truth poses (12 doubles each), per-scan twists and skewed
+    sweeps with per-point time stamps.  The vehicle pulls away from rest over `ramp_scans` scans and then moves with
+    a slowly varying twist; the pose at scan k+1 is the pose at scan k composed with (Exp_SO3(w dt), v dt), so a
+    constant-velocity model is exact up to the variation.  The canyon is cluttered (n_boxes) because two facades and
+    a ground plane alone do not constrain the motion along the street.  `pool`: a multiprocessing pool to cast the
+    sweeps in (same result)."""
+    scene = make_scene(seed, half_extent, n_boxes)
+    plan = drive_plan(n_scans, dt, speed, yaw_rate, seed, ramp_scans)
+    if pool is not None:
+        scans = pool.map(drive_sweep, [(seed, half_extent, n_boxes, plan["poses"][k], plan["twists"][k], dt, rings, azimuths,
+                                        plan["seeds"][k]) for k in range(n_scans)])
+    else:
+        scans = [make_sweep(scene, plan["poses"][k], plan["twists"][k], dt, rings, azimuths, plan["seeds"][k])
+                 for k in range(n_scans)]
+    return dict(scene=scene, poses=plan["poses"], twists=plan["twists"], scans=scans, stamps=plan["stamps"])
+
+
+def write_kitti_sequence(root: str, drive, seq: str = "00") -> str:
+    """The drive as a KITTI odometry sequence folder (velodyne/%06d.bin rows of float32 x,y,z,intensity + times.txt), what
+    molahip-lo-cli and eval/cli_kitti.sh's --input-kitti-seq read.  Returns the sequence directory."""
+    import os
+    d = os.path.join(root, "sequences", seq)
+    os.makedirs(os.path.join(d, "velodyne"), exist_ok=True)
+    for k, (xyz, _) in enumerate(drive["scans"]):
+        np.concatenate([xyz, np.zeros((len(xyz), 1), np.float32)], 1).astype(np.float32).tofile(
+            os.path.join(d, "velodyne", "%06d.bin" % k))
+    np.savetxt(os.path.join(d, "times.txt"), drive["stamps"] - drive["stamps"][0], fmt="%.6e")
+    return d
 
 
 def ndt_cloud(seed=0):

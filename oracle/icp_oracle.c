@@ -587,7 +587,10 @@ size_t orc_match_pt2pl(const orc_map* m, const float* lx, const float* ly, const
     if (!bv) continue;
     const float dx = px - bv->ndt_c[0], dy = py - bv->ndt_c[1], dz = pz - bv->ndt_c[2];
     const float e = (bv->ndt_n[0] * dx + bv->ndt_n[1] * dy) + bv->ndt_n[2] * dz;
-    if (fabsf(e) < thr) {
+    /* SURVEY App.B U10: thr > 0 compares the point-to-plane distance; a NEGATIVE distance_threshold selects the other
+     * candidate reading, distance to the plane's centroid: |p'-c|^2 < thr^2 (fp32, un-fused) */
+    const int accept = thr < 0.f ? ((dx * dx + dy * dy) + dz * dz < thr * thr) : (fabsf(e) < thr);
+    if (accept) {
       ok[i] = 1;
       cx[i] = bv->ndt_c[0]; cy[i] = bv->ndt_c[1]; cz[i] = bv->ndt_c[2];
       nx[i] = bv->ndt_n[0]; ny[i] = bv->ndt_n[1]; nz[i] = bv->ndt_n[2];
@@ -1044,12 +1047,13 @@ void orc_map_insert_posed(orc_map* m, const float* x, const float* y, const floa
     for (size_t id = 0; id < m->n_vox; id++) {
       voxel_t* v = &m->vox[id];
       if (!v->n) continue;
-      int d = 0;
-      for (int a = 0; a < 3; a++) {
-        const int da = abs(v->k[a] - c[a]);
-        if (da > d) d = da;
-      }
-      if (d > dist_in_grid) { /* erase(): an emptied voxel behaves like a missing one everywhere */
+      const long long d0 = llabs((long long)v->k[0] - c[0]), d1 = llabs((long long)v->k[1] - c[1]),
+                      d2 = llabs((long long)v->k[2] - c[2]);
+      int far;
+      if (m->p.far_voxel_metric == 1) far = d0 + d1 + d2 > dist_in_grid;                                     /* L1 */
+      else if (m->p.far_voxel_metric == 2) far = d0 * d0 + d1 * d1 + d2 * d2 > (long long)dist_in_grid * dist_in_grid; /* L2 */
+      else far = (d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2)) > dist_in_grid;                       /* Chebyshev */
+      if (far) { /* erase(): an emptied voxel behaves like a missing one everywhere */
         m->n_points -= v->n;
         v->n = 0;
         v->ndt_dirty = 1;

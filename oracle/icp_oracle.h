@@ -70,6 +70,8 @@ typedef struct {
   float min_distance_between_points; /* insertOpts (ndt yaml:244): drop a point closer than this to a stored point of its voxel; 0 = off */
   float ndt_max_eigen_ratio;         /* max_eigen_ratio_for_planes (ndt yaml:248); 0 = no NDT statistics */
   uint32_t ndt_min_points;           /* voxels with fewer points have no NDT (4) */
+  uint32_t far_voxel_metric;         /* remove_voxels_farther_than's voxel-index distance (yaml:237-238; the comment there says
+                                        "L1", upstream's code is unverified): 0 = max|dk| (default), 1 = sum|dk|, 2 = Euclid */
 } orc_map_params;
 
 orc_map* orc_map_create(const orc_map_params* p);

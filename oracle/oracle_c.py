@@ -18,6 +18,8 @@ _LIB_PATH = os.path.join(_HERE, "libicp_oracle.so")
 
 KERNEL_NONE, KERNEL_GM_C4, KERNEL_GM_KISS, KERNEL_GM_BARRON, KERNEL_CAUCHY, KERNEL_GM_C2 = range(6)
 INDEX_FLOOR, INDEX_TRUNC = 0, 1
+FAR_CHEBYSHEV, FAR_L1, FAR_L2 = 0, 1, 2
+PT2PL_PLANE_DISTANCE, PT2PL_CENTROID_DISTANCE = 0, 1  # the oracle takes the second as a NEGATIVE distance threshold
 TERM_NAMES = ["Undefined", "NoPairings", "SolverError", "MaxIterations", "Stalled",
               "QualityCheckpointFailed", "HookRequest"]
 
@@ -33,7 +35,7 @@ def build(force: bool = False) -> str:
 class _MapParams(C.Structure):
     _fields_ = [("voxel_size", C.c_float), ("max_points_per_voxel", C.c_uint32), ("index_mode", C.c_uint32),
                 ("min_distance_between_points", C.c_float), ("ndt_max_eigen_ratio", C.c_float),
-                ("ndt_min_points", C.c_uint32)]
+                ("ndt_min_points", C.c_uint32), ("far_voxel_metric", C.c_uint32)]
 
 
 class _PreprocessParams(C.Structure):
@@ -206,9 +208,9 @@ def pose_compose(a, b):
 # ---- map --------------------------------------------------------------------------------
 class Map:
     def __init__(self, voxel_size=1.0, max_points_per_voxel=20, index_mode=INDEX_FLOOR, min_distance_between_points=0.0,
-                 ndt_max_eigen_ratio=0.0, ndt_min_points=4):
+                 ndt_max_eigen_ratio=0.0, ndt_min_points=4, far_voxel_metric=FAR_CHEBYSHEV):
         p = _MapParams(voxel_size, max_points_per_voxel, index_mode, min_distance_between_points, ndt_max_eigen_ratio,
-                       ndt_min_points)
+                       ndt_min_points, far_voxel_metric)
         self._h = lib().orc_map_create(C.byref(p))
         self.voxel_size = voxel_size
 
@@ -286,7 +288,8 @@ def match_points(m: Map, local_xyz, T, threshold, threshold_angular_deg=0.0, n_t
                 n_voxels_hit=int(st.n_voxels_hit))
 
 
-def match_pt2pl(m: Map, local_xyz, T, distance_threshold, n_threads=1):
+def match_pt2pl(m: Map, local_xyz, T, distance_threshold, n_threads=1, mode=PT2PL_PLANE_DISTANCE):
+    distance_threshold = (-1.0 if mode == PT2PL_CENTROID_DISTANCE else 1.0) * abs(float(distance_threshold))
     l = np.asarray(local_xyz, dtype=np.float32)
     n = len(l)
     lx, ly, lz = _f32(l[:, 0]), _f32(l[:, 1]), _f32(l[:, 2])
@@ -373,6 +376,7 @@ class ICPParams:
     threshold: object = None  # array [max_iterations]
     threshold_angular_deg: float = 0.0
     pt2pl_threshold: object = None  # None = no Matcher_Point2Plane, else array [max_iterations]
+    pt2pl_mode: int = 0             # PT2PL_PLANE_DISTANCE | PT2PL_CENTROID_DISTANCE
     kernel_param: object = None  # array [max_iterations]
     gn: GNParams = field(default_factory=GNParams)
     hook_enabled: bool = False
@@ -401,6 +405,8 @@ def icp_align(m: Map, local_xyz, T_guess, p: ICPParams, prior=None, n_threads=1,
     plt = None
     if p.pt2pl_threshold is not None:
         plt = np.ascontiguousarray(np.broadcast_to(np.asarray(p.pt2pl_threshold, np.float64), (p.max_iterations,)))
+        if p.pt2pl_mode == PT2PL_CENTROID_DISTANCE:
+            plt = -np.abs(plt)
         cp.pt2pl_threshold = _dp(plt)
     cp.gn = p.gn.c()
     cp.hook_enabled = int(p.hook_enabled)

@@ -14,7 +14,7 @@ REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o ${TAG}_bench -- python $REPO/bench.py --upload-thread 0 $EXTRA > $OUT/${TAG}_bench_stdout.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o ${TAG}_bench -- python $REPO/bench.py --upload-thread 0 --no-extras $EXTRA > $OUT/${TAG}_bench_stdout.log 2>&1
 if [ -z "$SKIP_ODOM" ]; then
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/odom -o ${TAG}_odom -- env PYTHONPATH=$REPO python -m mola_lidar_odometry_amd.run_odometry --synthetic 40 --out-dir $REPO/gpurun_out/odometry > $OUT/${TAG}_odom_stdout.log 2>&1
 fi
@@ -23,7 +23,7 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0
          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVES" \
          "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc$i -o ${TAG}_pmc$i -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-shared-run --upload-thread 0 $EXTRA > $OUT/${TAG}_pmc$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc$i -o ${TAG}_pmc$i -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-shared-run --no-extras --upload-thread 0 $EXTRA > $OUT/${TAG}_pmc$i.log 2>&1
 done
 cd $REPO
 python - <<PY

@@ -122,9 +122,38 @@ def test_point2plane_matcher_parity(ctx, oracle, thr):
         np.testing.assert_array_equal(a["centroid"], b["centroid"])
         np.testing.assert_allclose(a["normal"], b["normal"], atol=1e-6)
         assert a["potential_pairings"] == len(q)
+        # SURVEY App. B U10, the switchable other reading: distanceThreshold against the distance to the centroid
+        ac = capi.nn_search_pt2pl(g, gs, T, thr + 0.3, mode=capi.PT2PL_CENTROID_DISTANCE)
+        bc = oracle.match_pt2pl(o, q, T, thr + 0.3, mode=oracle.PT2PL_CENTROID_DISTANCE)
+        np.testing.assert_array_equal(ac["local_idx"], bc["local_idx"])
+        np.testing.assert_array_equal(ac["centroid"], bc["centroid"])
+        assert 0 < len(ac["local_idx"]) != len(a["local_idx"])
     assert len(a["local_idx"]) > 0
     with pytest.raises(capi.MolahipError):  # a plain map has no planes to offer
         capi.nn_search_pt2pl(capi.Map(ctx, 1.0, 20).build(pts), gs, I12, thr)
+
+
+@pytest.mark.parametrize("n_scan,match", [(1500, None), (5000, None), (5000, "p")])
+def test_align_ndt_pipeline_centroid_mode(ctx, oracle, n_scan, match, monkeypatch):
+    """mh_icp_params::pt2pl_mode = MH_PT2PL_CENTROID_DISTANCE through the fused loop (every kernel that runs the plane
+    matcher), against the oracle's negative-threshold reading."""
+    if match:
+        monkeypatch.setenv("MH_MATCH", match)
+    pts = _ndt_cloud(21)
+    g = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts)
+    o = oracle.Map(1.0, 0, 0, 0.1, 0.05, 4).insert(pts)
+    rng = np.random.default_rng(22)
+    scan = pts[rng.permutation(len(pts))[:n_scan]]
+    guess = oracle.se3_exp([0.1, -0.07, 0.05, 0.005, -0.004, 0.008])
+    thr, kp = synth.threshold_schedule(0.5, 40)
+    kw = dict(max_iterations=40, min_abs_step_trans=5e-4, min_abs_step_rot=5e-4, threshold=thr, kernel_param=kp,
+              pt2pl_threshold=0.6, pt2pl_mode=1)
+    a = capi.icp_align(g, capi.Scan(ctx, scan), guess, capi.ICPParams(gn=capi.GNParams(max_inner_iterations=1), **kw), want_pairs=True)
+    b = oracle.icp_align(o, scan, guess, oracle.ICPParams(gn=oracle.GNParams(max_inner_iterations=1), **kw), want_pairs=True)
+    assert_align_equal(a, b)
+    assert a["n_final_pairs_pt2pl"] == b["n_final_pairs_pt2pl"] > 0
+    plane = oracle.icp_align(o, scan, guess, oracle.ICPParams(gn=oracle.GNParams(max_inner_iterations=1), **dict(kw, pt2pl_mode=0)))
+    assert plane["n_final_pairs_pt2pl"] != b["n_final_pairs_pt2pl"]  # the switch does change the pairing set
 
 
 @pytest.mark.parametrize("inner,match,n_scan", [(1, None, 5000), (2, None, 5000), (2, "p", 5000), (2, "q", 5000),
@@ -627,6 +656,52 @@ def test_batch_pairs_block_pinned_uploads_and_distinct_maps(ctx, monkeypatch):
                     assert np.array_equal(pr[k], a["pairs"][k]), (env, mem, k)
         if env:
             monkeypatch.delenv(env)
+    for c in ctxs:
+        c.close()
+
+
+def test_batch_pairs_block_with_a_trivial_first_job(ctx):
+    """job 0 is trivial (an empty scan, then max_iterations = 0 through per-job parameters), so the
+    lock-step group's leader is ANOTHER job's context than the one that owns the pairs staging, the copy stream and its
+    events: the page-locked download must still be queued (used to fail with MH_ERR_HIP after the alignments ran) and
+    complete on mh_ctx_synchronize of the FIRST job's context; a second batch right behind it must wait for it."""
+    import torch
+    ws = [synth.make_workload("t", 60000, 32, 400, 80.0, 25, variant=v) for v in range(3)]
+    maps = [capi.Map(ctx, 1.0, 20).build(w.map_xyz) for w in ws]
+    thr, kp = synth.threshold_schedule(2.0, 30)
+    p = capi.ICPParams(max_iterations=30, threshold=thr, kernel_param=kp, poll_every=5)
+    rng = np.random.default_rng(5)
+    subs = [np.zeros((0, 3), np.float32)] + [w.scan_xyz[rng.permutation(len(w.scan_xyz))[:n]] for w, n in zip(ws[1:], (3000, 4200))]
+    sizes = [len(x) for x in subs]
+    guesses = [w.T_guess for w in ws]
+    singles = [None] + [capi.icp_align(m, capi.Scan(ctx, sub), g, p, want_trace=False, want_pairs=True)
+                        for m, sub, g in zip(maps[1:], subs[1:], guesses[1:])]
+    ctxs = [capi.Context(0) for _ in sizes]
+    scans = [capi.Scan(c, sub) for c, sub in zip(ctxs, subs)]
+    nbytes = sum(capi.pairs_block_bytes(n) for n in sizes)
+    for mem in (capi.MEM_HOST_PINNED, capi.MEM_HOST):
+        for rep in range(2):  # the second batch finds pairs_copy_pending set on the first job's context
+            host = torch.zeros(nbytes, dtype=torch.uint8)
+            if mem == capi.MEM_HOST_PINNED:
+                host = host.pin_memory()
+            res = capi.icp_align_batch(maps, scans, guesses, p, pairs_block=host.data_ptr(), pairs_mem=mem)
+            ctxs[0].synchronize()
+            assert res[0]["n_final_pairs"] == 0 and res[0]["termination_reason"] == 1  # NoPairings
+            for a, r, pr in list(zip(singles, res, capi.unpack_pairs_block(host.numpy(), sizes, res)))[1:]:
+                assert (r["n_iterations"], r["n_final_pairs"]) == (a["n_iterations"], a["n_final_pairs"]) and np.array_equal(r["T"], a["T"])
+                for k in ("local_idx", "global_idx", "global_xyz", "d2"):
+                    assert np.array_equal(pr[k], a["pairs"][k]), (mem, rep, k)
+    # the other way to be trivial: a full-size job 0 with a budget of zero iterations (per-job parameters)
+    scans[0].update(ws[0].scan_xyz[:2000])
+    sizes[0] = 2000
+    p0 = capi.ICPParams(max_iterations=0, threshold=thr[:1], kernel_param=kp[:1])
+    nbytes = sum(capi.pairs_block_bytes(n) for n in sizes)
+    host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+    res = capi.icp_align_batch(maps, scans, guesses, [p0, p, p], pairs_block=host.data_ptr(), pairs_mem=capi.MEM_HOST_PINNED)
+    ctxs[0].synchronize()
+    assert res[0]["n_iterations"] == 0
+    for a, r, pr in list(zip(singles, res, capi.unpack_pairs_block(host.numpy(), sizes, res)))[1:]:
+        assert np.array_equal(r["T"], a["T"]) and np.array_equal(pr["global_idx"], a["pairs"]["global_idx"])
     for c in ctxs:
         c.close()
 

@@ -143,6 +143,27 @@ def test_map_insert_keyframes_bit_exact(ctx, oracle, vs, cap, far):
     np.testing.assert_array_equal(got["d2"], ref["d2"])
 
 
+@pytest.mark.parametrize("metric", [1, 2])
+@pytest.mark.parametrize("full_sort", [False, True])
+def test_map_insert_far_voxel_metric_switch(ctx, oracle, metric, full_sort, monkeypatch):
+    """mh_map_params::far_voxel_metric (L1 / L2 readings of remove_voxels_farther_than, yaml:237-238) on both insertion
+    paths, against the oracle."""
+    if full_sort:
+        monkeypatch.setenv("MH_MAP_FULL_SORT", "1")
+    scene = synth.make_scene(779, 80.0, 12)
+    g, o = capi.Map(ctx, 1.0, 20, far_voxel_metric=metric), oracle.Map(1.0, 20, far_voxel_metric=metric)
+    cheb = oracle.Map(1.0, 20)
+    for k in range(4):
+        pose = [-30.0 + 16.0 * k, 0.5 * np.cos(k), synth.SENSOR_H, 0.04 * k, 0.0, 0.001 * k]
+        xyz = synth.make_scan(scene, pose, rings=32, azimuths=400, seed=300 + k)
+        T = synth.pose_from_ypr(pose)
+        g.insert(capi.Scan(ctx, xyz), T, 40.0)
+        o.insert_posed(xyz, T, 40.0)
+        cheb.insert_posed(xyz, T, 40.0)
+        _assert_maps_equal(g.download(), o.dump())
+    assert o.num_voxels < cheb.num_voxels
+
+
 def test_map_insert_ndt_and_empty(ctx, oracle):
     scene = synth.make_scene(778, 60.0, 8)
     kw = dict(min_distance_between_points=0.1, ndt_max_eigen_ratio=0.03, ndt_min_points=4)

@@ -87,6 +87,25 @@ def test_pt2pl_matcher_known_answer_and_bruteforce(oracle):
                 exp_idx.append(i); exp_c.append(nd["centroid"][bv])
     np.testing.assert_array_equal(r["local_idx"], exp_idx)
     np.testing.assert_array_equal(r["centroid"], np.array(exp_c, np.float32))
+    # SURVEY App. B U10, the other reading: distanceThreshold against the distance to the plane's CENTROID
+    rc = oracle.match_pt2pl(m, q, T, 0.45, mode=oracle.PT2PL_CENTROID_DISTANCE)
+    exp_c_idx = []
+    for i, p in enumerate(g):
+        c = np.floor(p).astype(int)
+        best = np.inf
+        for ix in (-1, 0, 1):
+            for iy in (-1, 0, 1):
+                for iz in (-1, 0, 1):
+                    v = key2v.get((c[0] + ix, c[1] + iy, c[2] + iz))
+                    if v is None or not nd["is_plane"][v]:
+                        continue
+                    dd = nd["centroid"][v] - p
+                    d2 = np.float32(np.float32(dd[0] * dd[0] + dd[1] * dd[1]) + dd[2] * dd[2])
+                    best = min(best, d2)
+        if best < np.float32(0.45) * np.float32(0.45):
+            exp_c_idx.append(i)
+    np.testing.assert_array_equal(rc["local_idx"], exp_c_idx)
+    assert 0 < len(exp_c_idx) < len(r["local_idx"])
     # points 0.3 m above the z=0.3 ground with a 0.1 m threshold pair with nothing from the ground
     hi = np.stack([rng.uniform(-9, 9, 50), rng.uniform(-9, 0, 50), np.full(50, 0.75)], 1).astype(np.float32)
     assert len(oracle.match_pt2pl(m, hi, I12, 0.1)["local_idx"]) == 0

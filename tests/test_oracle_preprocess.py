@@ -119,3 +119,23 @@ def test_incremental_insert_equals_one_shot_and_eviction(oracle):
     # an evicted voxel can be re-populated from empty
     ev.insert_posed(a, I, 0.0)
     assert ev.num_points > keep_p.sum()
+
+
+@pytest.mark.parametrize("metric", [1, 2])
+def test_far_voxel_metric_switch(oracle, metric):
+    """remove_voxels_farther_than with the other readings of "farther" (lidar3d-default.yaml:237 says L1; upstream's code is
+    unverified): brute force over the dumped voxel keys."""
+    rng = np.random.default_rng(17)
+    a = (rng.normal(0, 1, (30000, 3)) * [25, 25, 4]).astype(np.float32)
+    I = np.eye(4)[:3]
+    T2 = I.copy()
+    T2[:, 3] = [6.2, -4.7, 0.3]
+    full = oracle.Map(1.0, 5, far_voxel_metric=metric).insert_posed(a, I).dump()
+    ev = oracle.Map(1.0, 5, far_voxel_metric=metric).insert_posed(a, I).insert_posed(a[:0], T2, 20.0).dump()
+    dk = np.abs(full["vox_keys"].astype(np.int64) - np.floor(np.float32(T2[:, 3])).astype(np.int64))
+    keep = dk.sum(1) <= 20 if metric == 1 else (dk * dk).sum(1) <= 400
+    assert 0 < keep.sum() < len(keep)
+    np.testing.assert_array_equal(ev["vox_keys"], full["vox_keys"][keep])
+    np.testing.assert_array_equal(ev["xyz"], full["xyz"][np.repeat(keep, full["vox_count"])])
+    cheb = oracle.Map(1.0, 5).insert_posed(a, I).insert_posed(a[:0], T2, 20.0)
+    assert cheb.num_voxels > len(ev["vox_keys"])  # the default (Chebyshev) keeps the corners the others drop
