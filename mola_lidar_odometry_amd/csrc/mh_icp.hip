@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "mh_nn_device.h"
@@ -879,7 +880,10 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ part, uin
 }
 
 struct SolveShared {
-  double red[kGenN][64];
+  union {
+    double red[kGenN][64];    // reduce_rows' scratch (partials from global memory)
+    double tr[kAccN][129];    // k_icp_persist: the quad sums, transposed (never in use at the same time)
+  };
   double totA[kAccN], totB[kGenN];
   double sh_log[13][6];
 };
@@ -892,6 +896,8 @@ struct SolveShared {
 // (ticket counter + __threadfence): correct, but the device-scope release/acquire fences write back and invalidate the
 // XCDs' L2s on every launch -- the map falls out of cache and C2 drops from 2285 to 960 scans/s.  Kernel boundaries
 // are the cheap way to order producers and consumers on this part.)
+// LDS_STATE: the state block lives in LDS (k_icp_persist keeps it there for the whole alignment) instead of global memory.
+template <bool LDS_STATE = false>
 __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, const SolveK* __restrict__ kp_,
                                            const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                            const double* __restrict__ partB, uint32_t nB, uint32_t strideB,
@@ -903,7 +909,8 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, con
   // the parameter block through the scalar path (uniform address, read-only), field by field: the 36-double prior is only
   // touched when present; the state block through a global-space pointer (mh_nn_device.h, G())
   const SolveK __attribute__((address_space(4)))& k = *(const SolveK __attribute__((address_space(4)))*)uniform_const_ptr(kp_);
-  IcpDeviceState MH_AS_GLOBAL* const st = G(st_);
+  typedef typename std::conditional<LDS_STATE, IcpDeviceState __attribute__((address_space(3)))*, IcpDeviceState MH_AS_GLOBAL*>::type state_ptr;
+  state_ptr const st = (state_ptr)st_;
   const int lane = threadIdx.x;
   if (nA)
     reduce_rows(partA, nA, strideA, kAccN, totA, red);
@@ -1267,6 +1274,192 @@ __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1_b(const BatchJob
 // ================================================================================================
 // Covariance (mp2p_icp::covariance [U]): A = d residuals / d (x,y,z,yaw,pitch,roll), cov = (A^T A)^-1
 // ================================================================================================
+// ================================================================================================
+// k_icp_persist: the WHOLE alignment of a small layer in ONE workgroup and ONE launch.
+//
+// OPT-IN (MH_PERSIST=1) AND SLOWER THAN THE DEFAULT CHAIN -- kept, parity-tested, as the measured answer to "would one launch
+// per alignment help?" (profiles/r03_persist_kernel.md): the solve side costs what k_accum_solve1 costs (7.8 us per
+// Gauss-Newton step), but ONE compute unit cannot supply the memory-level parallelism of the correspondence search: a lane
+// per point chains ~25 dependent round trips (23 us per 400 points, 57 us per 900, 101 us per 2000) where k_match16 spreads
+// 16 lanes per point over ~60 compute units and needs 10 us.
+//
+// What lidar3d-default.yaml really feeds align() is a layer of a few hundred to a few thousand points; there
+// an iteration was three dependent launches (k_match16 | k_accum_solve1 x2: ~30 us, of which launch boundaries, the
+// re-loading of state / points / pairings at the head of every kernel and the pairing round trip through global memory
+// are about half), plus ~8 early-exit launches per alignment beyond its end and a second host poll whenever the first
+// chunk was too short.  Here a 512-lane workgroup keeps everything it needs between iterations ON THE CU: its points and
+// each point's winning map record in registers (the next iteration's search bound, the Gauss-Newton accumulation's
+// input), the state block in LDS, the 18 moment sums through LDS transposed (fixed order: bitwise reproducible).  One
+// lane per point searches (nn_search_lane); nothing crosses a workgroup, so no device-scope fence is involved (the
+// multi-workgroup cooperative loop that was tried and dropped -- see solve_body -- paid exactly that).  The host sees one
+// launch per alignment, and a batch of N alignments is one launch of N workgroups that finish independently: no lock
+// step, no early-exit launches, no polling chunks.
+// Pairings (pair_q / pair_gidx: the device-side Results::finalPairings, input of the covariance kernels and of the
+// compaction) are written once, at the end, as the last executed match left them -- what the other chains hold there.
+// ================================================================================================
+constexpr uint32_t kPersistMaxPoints = 2048;
+constexpr int kPersistThreads = 512;  // 2 waves per SIMD -> 256 VGPRs per lane (solve_body's serial 6x6 code wants them)
+constexpr int kPersistPPL = (int)(kPersistMaxPoints / kPersistThreads);  // points per lane, at most
+constexpr int kPersistW = 8;          // records per round trip of a lane's scan
+constexpr int kPersistL = kPersistThreads / 4;                       // quad sums that go through LDS
+constexpr int kPersistChunk = ((kPersistL + kPersistL / kAccN - 1) / (kPersistL / kAccN)) | 1;  // 19
+constexpr int kPersistGroups = (kPersistL + kPersistChunk - 1) / kPersistChunk;                 // 7
+static_assert(kAccN * kPersistGroups <= kPersistThreads, "one thread per (row, group)");
+
+static_assert(kPersistL + 1 == 129, "SolveShared::tr");
+struct PersistShared {
+  SolveShared sh;
+  double p1[kAccN][kPersistGroups];
+  IcpDeviceState st;
+  // per point: the map record it is paired with {x, y, z, d2 (inf: none found)} and its source index or kNoMatch --
+  // the next iteration's search bound, the Gauss-Newton accumulation's input, the final pairings
+  f32x4 win[kPersistPPL][kPersistThreads];
+  uint32_t src[kPersistPPL][kPersistThreads];
+};
+static_assert(sizeof(PersistShared) <= 64 * 1024, "LDS per workgroup");
+
+// workgroup sum of the 18 moment rows -> out[0..18): the four lanes of every DPP quad first, then transposed through LDS
+// in a fixed order (block_sum_rows_quad's scheme for 512 lanes, totals into LDS instead of global partials)
+__device__ __forceinline__ void persist_sum(const double* v, PersistShared& S, double* out) {
+  constexpr int G = kPersistGroups, C = kPersistChunk, L = kPersistL;
+#pragma unroll
+  for (int j = 0; j < kAccN; j++) {
+    double q = v[j];
+    q += dpp_f64<0xB1>(q);  // quad_perm:[1,0,3,2]
+    q += dpp_f64<0x4E>(q);  // quad_perm:[2,3,0,1]
+    if ((threadIdx.x & 3u) == 0u) S.sh.tr[j][threadIdx.x >> 2] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccN * G) {
+    const int j = threadIdx.x / G, g = threadIdx.x % G;
+    const int l0 = g * C;
+    double sum = S.sh.tr[j][l0];
+#pragma unroll
+    for (int i = 1; i < C; i++)
+      if (l0 + i < L) sum += S.sh.tr[j][l0 + i];
+    S.p1[j][g] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccN) {
+    double sum = S.p1[threadIdx.x][0];
+#pragma unroll
+    for (int g = 1; g < G; g++) sum += S.p1[threadIdx.x][g];
+    out[threadIdx.x] = sum;
+  }
+  __syncthreads();
+}
+
+// A real call, not an inlined copy: inside the iteration loops the serial 6x6 code's constants and scalar parameters
+// get hoisted into the loop preheader and stay live (107 spilled VGPRs); as a function of its own it allocates like k_solve.
+__device__ __attribute__((noinline)) void persist_solve(IcpDeviceState* st, const SolveK* skp, SolveShared& sh) {
+  solve_body<true>(st, skp, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true, false);
+}
+
+__device__ __forceinline__ void k_icp_persist_body(IcpDeviceState* __restrict__ gst, const MatchK* __restrict__ mkp,
+                                                   const SolveK* __restrict__ skp, const float* __restrict__ lx,
+                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                   const MapView& map, float4* __restrict__ pair_q,
+                                                   uint32_t* __restrict__ pair_gidx) {
+  __shared__ PersistShared S;
+  const uint32_t tid = threadIdx.x;
+  {  // the state block -> LDS (it stays there until the epilogue)
+    const uint32_t MH_AS_GLOBAL* src = G(reinterpret_cast<const uint32_t*>(gst));
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&S.st);
+    for (uint32_t i = tid; i < sizeof(IcpDeviceState) / 4; i += kPersistThreads) dst[i] = src[i];
+  }
+  const uint32_t ppl = (n + kPersistThreads - 1) / kPersistThreads;  // points per lane: uniform, <= kPersistPPL
+  for (uint32_t u = 0; u < ppl; u++) {
+    S.win[u][tid] = (f32x4){0.f, 0.f, 0.f, __builtin_inff()};
+    S.src[u][tid] = kNoMatch;
+  }
+  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
+  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(mkp);
+  const uint32_t kernel = ck->kernel;
+  const double w_pt2pt = ck->w_pt2pt;
+  const auto g_x = G(lx), g_y = G(ly), g_z = G(lz);
+  __syncthreads();
+  if (!S.st.done) {  // (uniform: one LDS word)
+    for (;;) {
+      // ---- match: p' = T (+) l, exact NN over the 27-voxel block bounded by the previous pairing, threshold test
+      MH_PHASE(11);
+      {
+        double T[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[k] = S.st.T[k];
+        const float thr2 = S.st.cur_thr2, ang2 = S.st.cur_ang2;
+#pragma unroll 1
+        for (uint32_t u = 0; u < ppl; u++) {
+          const uint32_t i = tid + u * kPersistThreads;
+          if (i >= n) break;
+          float px, py, pz;
+          transform_point(T, g_x[i], g_y[i], g_z[i], px, py, pz);
+          const f32x4 prev = S.win[u][tid];
+          float bound0 = __builtin_inff();
+          if (prev.w < __builtin_inff() && !map.no_prev_bound) {  // a record was found last time (whatever the threshold said)
+            const float dx = prev.x - px, dy = prev.y - py, dz = prev.z - pz;
+            bound0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic
+          }
+          const NNResult r = nn_search_lane<kPersistW>(map, px, py, pz, bound0);
+          const float n2 = (px * px + py * py) + pz * pz;
+          const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
+          S.win[u][tid] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
+          S.src[u][tid] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+        }
+      }
+      // ---- Gauss-Newton steps on these pairings (Solver_GaussNewton's inner loop), then the tail of the ICP iteration
+      MH_PHASE(12);
+      for (;;) {
+        double T[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[k] = S.st.T[k];
+        const double kparam = S.st.cur_kparam;
+        Acc a;
+        acc_zero(a);
+#pragma unroll 1
+        for (uint32_t u = 0; u < ppl; u++) {
+          const uint32_t i = tid + u * kPersistThreads;
+          const uint32_t ic = i < n ? i : n - 1;
+          const f32x4 q = S.win[u][tid];
+          const bool paired = i < n && S.src[u][tid] != kNoMatch;
+          acc_pt2pt_masked(a, T, paired, g_x[ic], g_y[ic], g_z[ic], q.x, q.y, q.z, kernel, kparam, w_pt2pt);
+        }
+        MH_PHASE(13);
+        persist_sum(a.v, S, S.sh.totA);
+        MH_PHASE(14);
+        persist_solve(&S.st, skp, S.sh);
+        __syncthreads();
+        MH_PHASE(15);
+        if (S.st.done || S.st.inner == 0) break;  // the solver closed this ICP iteration (or the loop)
+      }
+      if (S.st.done) break;
+    }
+  }
+  // ---- epilogue: the pairings of the last match and the state block back to global memory
+  for (uint32_t u = 0; u < ppl; u++) {
+    const uint32_t i = tid + u * kPersistThreads;
+    if (i >= n) break;
+    G(reinterpret_cast<f32x4*>(pair_q))[i] = S.win[u][tid];
+    G(pair_gidx)[i] = S.src[u][tid];
+  }
+  {
+    uint32_t MH_AS_GLOBAL* dst = G(reinterpret_cast<uint32_t*>(gst));
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.st);
+    for (uint32_t i = tid; i < sizeof(IcpDeviceState) / 4; i += kPersistThreads) dst[i] = src[i];
+  }
+}
+__global__ __launch_bounds__(kPersistThreads) void k_icp_persist(IcpDeviceState* __restrict__ st, const MatchK* __restrict__ mk,
+                                                                 const SolveK* __restrict__ sk, const float* __restrict__ lx,
+                                                                 const float* __restrict__ ly, const float* __restrict__ lz,
+                                                                 uint32_t n, MapView map, float4* __restrict__ pair_q,
+                                                                 uint32_t* __restrict__ pair_gidx) {
+  k_icp_persist_body(st, mk, sk, lx, ly, lz, n, map, pair_q, pair_gidx);
+}
+// a batch: one workgroup per alignment (blockIdx.y), each running to its own termination
+__global__ __launch_bounds__(kPersistThreads) void k_icp_persist_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  k_icp_persist_body(j.st, j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx);
+}
+
 constexpr int kCovN = 22;  // 21 upper-triangle + count
 
 __device__ __forceinline__ void k_cov_prepare_body(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp, uint32_t force) {
@@ -2048,6 +2241,7 @@ struct AlignJob {
     MH_TRY(ensure_state(ctx));
     MH_TRY(ensure_pair_buffers(ctx, scan->n));
     hipStream_t s = ctx->stream;
+    MH_TRY(map_ready_on(map, s));  // a key-frame update still running on the map's side stream (mh_map_insert)
     const size_t mi = p->max_iterations;
     if (pl) {
       if (!map->view().ndt)
@@ -2138,6 +2332,10 @@ struct AlignJob {
       if (e && e[0] == 'p') variant = 0;
       if (e && e[0] == 'x') variant = 1;
       if (variant == 1 && map->view().ndt) variant = 0;  // "x" walks contiguous z-runs; NDT maps interleave statistics records
+      //   MH_PERSIST=1   (opt-in, measured slower: profiles/r03_persist_kernel.md) layers up to 2 k points without
+      //                  Matcher_Point2Plane: the whole alignment in one workgroup and one launch -> k_icp_persist
+      if (!e && scan->n <= kPersistMaxPoints && !pl && !prof && getenv("MH_PERSIST") != nullptr)
+        variant = 9;
     }
     if (variant >= 6) MH_TRY(scan_build_tiles(scan, map->inv_vs, variant == 7 ? 64u : 256u));  // asynchronous; a no-op when the scan is already in search order
     nba = nblk_acc(scan->n);
@@ -2159,6 +2357,7 @@ struct AlignJob {
       const uint32_t expect = p->expected_iterations ? p->expected_iterations : ctx->predicted_iterations[kind];
       static const uint32_t margin = getenv("MH_CHUNK_MARGIN") ? (uint32_t)atoi(getenv("MH_CHUNK_MARGIN")) : 2u;
       chunk = p->poll_every ? p->poll_every : (expect ? (expect + margin > 64 ? 64u : expect + margin) : 10u);
+      if (variant == 9) chunk = p->max_iterations;  // one launch runs the loop to its end: nothing to poll in between
     }
     polls = 0;
     enqueued = 0;
@@ -2210,7 +2409,10 @@ struct AlignJob {
       const bool rows16 = pl && variant == 5;                  // NDT layer handled by the row kernel
       const uint32_t nB = pl ? (rows16 ? nba : nb) : 0u;       // columns of the point-to-plane partials of the FIRST step
       const uint32_t nBi = pl ? nba : 0u;                      // ... of the inner steps (k_accum_both)
-      for (uint32_t j = 0; j < m; j++) {
+      if (variant == 9)  // the whole loop: one workgroup, one launch
+        hipLaunchKernelGGL(k_icp_persist, dim3(1), dim3(kPersistThreads), 0, s, ctx->d_state, dmk, dsk, scan->x, scan->y, scan->z,
+                           n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>());
+      for (uint32_t j = 0; j < (variant == 9 ? 0u : m); j++) {
         const bool both16 = pl && variant == 5;  // small layer: both matchers in one launch (k_match16<true>)
         if (pl && !both16)
           hipLaunchKernelGGL(k_match_pl<true>, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, dmk, scan->x, scan->y,
@@ -2523,6 +2725,7 @@ void fill_batch_desc(const AlignJob& j, BatchJob& d) {
 // complete before `lead`'s stream reads that job's scan / state: an event per job, waited for by the leader's stream.
 mh_status order_after_job_streams(mh_ctx* lead, const std::vector<AlignJob*>& jobs) {
   for (AlignJob* j : jobs) {
+    MH_TRY(map_ready_on(j->map, lead->stream));  // a key-frame update of this job's map still running on its side stream
     if (j->ctx == lead || j->ctx->stream == lead->stream) continue;
     if (hipStreamQuery(j->ctx->stream) == hipSuccess) continue;  // nothing pending there
     MH_HIP(hipEventRecord(j->ctx->ev_ready, j->ctx->stream));
@@ -2641,12 +2844,13 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
   // each job keeps its own parameters (iteration budget, schedules, hook check point, prior), state block, termination
   // flag and iteration count.  Jobs whose chain has no lock-step form (or that are alone in their group) take the
   // per-stream path below.
-  enum Kind { K_NONE = 0, K_QUAD, K_TILE, K_WAVE, K_ORD, K_ROWF, K_ONE, K_ONE_PL };
+  enum Kind { K_NONE = 0, K_QUAD, K_TILE, K_WAVE, K_ORD, K_ROWF, K_ONE, K_ONE_PL, K_PERSIST };
   const bool no_lockstep = getenv("MH_NO_LOCKSTEP") != nullptr;
   const bool no_one_group_env = getenv("MH_NO_ONE_GROUP") != nullptr;
   auto kind_of = [&](const AlignJob& j) -> int {
     if (j.finished || no_lockstep || j.trace || j.prof) return K_NONE;
     const bool one_group = j.variant == 5 && j.scan->n <= kOneGroupMaxPoints && !no_one_group_env;
+    if (j.variant == 9) return K_PERSIST;  // one workgroup per job, each to its own end: a "group" is just one launch
     if (j.variant == 4 && !j.pl) return K_QUAD;
     if (j.variant == 6 && !j.pl) return K_TILE;
     if (j.variant == 7 && !j.pl) return K_WAVE;
@@ -2685,6 +2889,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       g->inner = q->gn.max_inner_iterations;
       g->cov = q->compute_covariance != 0;
       g->chunk = q->poll_every ? q->poll_every : 10;
+      if (k == K_PERSIST) g->chunk = 0xFFFFFFFFu;  // no chunks: the launch runs every job's loop to its end
     }
     g->jobs.push_back(&jobs[i]);
     g->index.push_back(i);
@@ -2795,6 +3000,10 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
           if (g.done || it >= m_of[gi]) continue;
           hipStream_t s = g.lead->stream;
           const uint32_t A = (uint32_t)g.jobs.size();
+          if (g.kind == K_PERSIST) {
+            if (it == 0) hipLaunchKernelGGL(k_icp_persist_b, dim3(1, A), dim3(kPersistThreads), 0, s, g.dj);
+            continue;
+          }
           const bool pr = want_prof && gi == 0 && g.jobs[0] == &jobs[0];
           if (pr) MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n], s));
           switch (g.kind) {
@@ -2966,6 +3175,7 @@ mh_status mh_nn_search(const mh_map* map, const mh_scan* scan, const double T[12
   MH_REQUIRE(pose_ok(T), "non-finite pose");
   mh_ctx* ctx = scan->ctx;
   MH_TRY(set_device(ctx));
+  MH_TRY(map_ready_on(map, ctx->stream));
   if (info) {
     info->n_pairs = 0;
     info->potential_pairings = scan->n;  // counted before any test (App.B U6)
@@ -3002,6 +3212,7 @@ mh_status mh_nn_search_dense(const mh_map* map, const mh_scan* scan, const doubl
   MH_REQUIRE(pose_ok(T), "non-finite pose");
   mh_ctx* ctx = scan->ctx;
   MH_TRY(set_device(ctx));
+  MH_TRY(map_ready_on(map, ctx->stream));
   const size_t n = scan->n;
   if (n == 0) return MH_OK;
   MH_TRY(ensure_state(ctx));
@@ -3091,6 +3302,7 @@ mh_status mh_nn_search_pt2pl(const mh_map* map, const mh_scan* scan, const doubl
   MH_REQUIRE(map->view().ndt, "the map carries no NDT statistics (build it with ndt_max_eigen_ratio > 0)");
   mh_ctx* ctx = scan->ctx;
   MH_TRY(set_device(ctx));
+  MH_TRY(map_ready_on(map, ctx->stream));
   if (info) {
     info->n_pairs = 0;
     info->potential_pairings = scan->n;

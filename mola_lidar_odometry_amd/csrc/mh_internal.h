@@ -159,9 +159,23 @@ struct mh_map {
   mh::DevBuf vox_keys;   // uint64[n_voxels], ascending
   mh::DevBuf vox_first;  // uint32[n_voxels]
   mh::DevBuf vox_count;  // uint32[n_voxels]
-  uint64_t n_points = 0, n_offered = 0, n_voxels = 0, table_size = 0, n_records = 0, n_planes = 0;
+  // Counts and bounding box of the stored content.  A (re)build leaves them on the device and copies them into the pinned
+  // block `h_counts` asynchronously; they are read back lazily (mh::map_resolve) by whoever needs them on the host -- the
+  // next insertion, mh_map_get_info, a download -- so that a key-frame update costs no host synchronisation.
+  mutable uint64_t n_points = 0, n_voxels = 0, n_records = 0, n_planes = 0;
+  uint64_t n_offered = 0, table_size = 0;
   mh::DevBuf merge;  // mh_map_insert staging: x | y | z | src of (stored + new) points
-  float bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
+  mutable float bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
+  uint32_t* h_counts = nullptr;          // pinned [16]: what k_sizes / k_scatter / k_ndt_stats left in the device counters
+  hipEvent_t ev_counts = nullptr;        // recorded behind that copy: "the last (re)build is complete"
+  mutable bool counts_pending = false;   // n_points ... bbox above are stale until map_resolve() has seen ev_counts
+  mutable bool build_in_flight = false;  // the last (re)build may still run on `side`: order consumers with map_ready_on()
+  mutable mh_status deferred_error = MH_OK;  // an insertion's out-of-range verdict, reported by the next call that resolves
+  // mh_map_insert's scratch is the map's own; with MH_MAP_SIDE_STREAM=1 the update also runs on a stream of the map's own
+  // (needed only before the NEXT align: it then overlaps the next scan's upload, filters and de-skew on the context's stream)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_main = nullptr, ev_input = nullptr;
+  mh::DevBuf build_a, build_b, build_c, build_d, build_e, sort_tmp;
   mh::MapView view() const {
     mh::MapView v;
     v.slots = slots.as<mh::MapSlot>();
@@ -218,6 +232,13 @@ uint32_t tile_points_for_env();
 mh_status scan_tiles_ready(const mh_scan* s);
 void scan_drop_tiles(mh_scan* s);  // host-side bookkeeping only (the points changed)
 void scan_free_tiles(mh_scan* s);
-mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc, size_t n,
-                           const int* evict, size_t n_stored);
+// Asynchronous on stream `s` (the context's, or the map's side stream); scratch from `m`.  Counts / bbox / the
+// out-of-range verdict are resolved lazily (map_resolve).
+mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc,
+                           size_t n, const int* evict, size_t n_stored);
+// wait (host) for the last (re)build's counters and refresh n_points / n_voxels / n_records / n_planes / bbox; returns the
+// deferred status of that build (MH_ERR_OUT_OF_RANGE) once
+mh_status map_resolve(const mh_map* m);
+// make stream `s` wait for a (re)build that may still be running on the map's side stream (no-op otherwise)
+mh_status map_ready_on(const mh_map* m, hipStream_t s);
 }  // namespace mh

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -140,10 +141,10 @@ __global__ void k_add_ndt_slots(const uint32_t* __restrict__ head, uint32_t n, u
 // same operation sequence as the CPU restatement), plane iff lambda_min/lambda_max < ratio, normal = eigenvector of
 // lambda_min with its largest component positive.  Records: pts[first-2] = {centroid, plane flag}, pts[first-1] = {normal, 0}.
 __global__ void k_ndt_stats(float4* __restrict__ pts, const uint32_t* __restrict__ vox_first,
-                            const uint32_t* __restrict__ vox_count, uint32_t n_vox, float max_ratio, uint32_t min_pts,
-                            uint32_t* __restrict__ n_planes) {
+                            const uint32_t* __restrict__ vox_count, const uint32_t* __restrict__ n_vox_dev, float max_ratio,
+                            uint32_t min_pts, uint32_t* __restrict__ n_planes) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= n_vox) return;
+  if (v >= *n_vox_dev) return;  // (the grid covers the host's upper bound of the voxel count)
   const uint32_t first = vox_first[v], cnt = vox_count[v];
   float4 rc = make_float4(0.f, 0.f, 0.f, 0.f), rn = make_float4(0.f, 0.f, 0.f, 0.f);
   if (cnt >= min_pts) {
@@ -225,7 +226,7 @@ __global__ void k_scatter(const float* __restrict__ x, const float* __restrict__
                           const uint32_t* __restrict__ head, const uint32_t* __restrict__ vid1,
                           const uint32_t* __restrict__ vstart, const uint32_t* __restrict__ keep,
                           const uint32_t* __restrict__ outpos, uint32_t n, uint32_t cap,
-                          const uint32_t* __restrict__ counters, uint32_t n_vox, float4* __restrict__ pts,
+                          const uint32_t* __restrict__ counters /* [9] = number of voxels (k_sizes) */, float4* __restrict__ pts,
                           unsigned long long* __restrict__ vox_keys, uint32_t* __restrict__ vox_first,
                           uint32_t* __restrict__ vox_count, uint32_t* __restrict__ bbox /*6 ordered uints*/,
                           uint32_t ndt, const uint32_t* __restrict__ src_ids /*null: identity*/) {
@@ -241,6 +242,7 @@ __global__ void k_scatter(const float* __restrict__ x, const float* __restrict__
     if (head[i]) {
       // stored points of this voxel = records between this head and the next one, minus the two NDT records
       const uint32_t v = vid1[i] - 1;
+      const uint32_t n_vox = counters[9];
       const uint32_t total_records = outpos[n - 1] + keep[n - 1];
       const uint32_t next = (v + 1 < n_vox) ? outpos[vstart[v + 1]] : total_records;
       vox_keys[v] = ks[i];
@@ -275,10 +277,10 @@ __global__ void k_scatter(const float* __restrict__ x, const float* __restrict__
 }
 
 __global__ void k_table_insert(const unsigned long long* __restrict__ vox_keys, const uint32_t* __restrict__ vox_first,
-                               const uint32_t* __restrict__ vox_count, uint32_t n_vox, MapSlot* __restrict__ slots,
-                               uint32_t mask) {
+                               const uint32_t* __restrict__ vox_count, const uint32_t* __restrict__ n_vox_dev,
+                               MapSlot* __restrict__ slots, uint32_t mask) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= n_vox) return;
+  if (v >= *n_vox_dev) return;  // (the grid covers the host's upper bound of the voxel count)
   const unsigned long long key = vox_keys[v];
   uint32_t h = hash_key(key) & mask;
   for (;;) {
@@ -357,6 +359,15 @@ mh_status mh_map_destroy(mh_map* m) {
   if (!m) return MH_OK;
   (void)hipSetDevice(m->ctx->device);
   (void)hipStreamSynchronize(m->ctx->stream);
+  if (m->side) {
+    (void)hipStreamSynchronize(m->side);
+    (void)hipStreamDestroy(m->side);
+  }
+  if (m->ev_counts) (void)hipEventDestroy(m->ev_counts);
+  if (m->ev_main) (void)hipEventDestroy(m->ev_main);
+  if (m->ev_input) (void)hipEventDestroy(m->ev_input);
+  if (m->h_counts) (void)hipHostFree(m->h_counts);
+  for (mh::DevBuf* b : {&m->build_a, &m->build_b, &m->build_c, &m->build_d, &m->build_e, &m->sort_tmp}) b->release();
   m->slots.release();
   m->pts.release();
   m->vox_keys.release();
@@ -376,6 +387,8 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
   MH_TRY(set_device(ctx));
   hipStream_t s = ctx->stream;
   MH_HIP(hipStreamSynchronize(s));  // a rebuild invalidates everything queued against the old content
+  if (m->side) MH_HIP(hipStreamSynchronize(m->side));
+  (void)map_resolve(m);  // (a pending verdict about the OLD content is moot now)
   const float *dx = x, *dy = y, *dz = z;
   if (n > 0 && mem == MH_MEM_HOST) {
     const size_t stride = ((n * sizeof(float) + 255) / 256) * 256;
@@ -387,9 +400,9 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
     dy = (const float*)(ctx->staging.as<char>() + stride);
     dz = (const float*)(ctx->staging.as<char>() + 2 * stride);
   }
-  MH_TRY(map_build_device(m, dx, dy, dz, nullptr, n, nullptr, 0));
+  MH_TRY(map_build_device(m, s, dx, dy, dz, nullptr, n, nullptr, 0));
   m->n_offered = n;
-  return MH_OK;
+  return map_resolve(m);  // a build reports its own verdict (out-of-range points) and leaves nothing in flight
 }
 
 mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], float remove_voxels_farther_than) {
@@ -399,7 +412,25 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
   for (int i = 0; i < 12; i++) MH_REQUIRE(isfinite(T[i]), "non-finite pose");
   mh_ctx* ctx = m->ctx;
   MH_TRY(set_device(ctx));
+  MH_TRY(map_resolve(m));  // the previous update's counts (long complete by now: an align has run in between) and verdict
+  // The update is asynchronous either way (no host synchronisation: counts and verdict are read back lazily).  With
+  // MH_MAP_SIDE_STREAM=1 it runs on a stream of the map's own, behind everything queued on the context's so far (the layer
+  // it reads, the alignments that still read the old content), and is waited for by the NEXT use of the map only
+  // (map_ready_on) -- measured on the odometry drive: the extra event traffic costs the caller more (0.139 ms per key-frame
+  // against 0.101) than the overlap with the next scan's de-skew returns (967 against 990 scans/s), so the default is the
+  // context's stream.
+  const bool use_side = getenv("MH_MAP_SIDE_STREAM") && atoi(getenv("MH_MAP_SIDE_STREAM")) != 0;  // (per call: tests toggle it)
   hipStream_t s = ctx->stream;
+  if (use_side) {
+    if (!m->side) {
+      MH_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+      MH_HIP(hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming));
+      MH_HIP(hipEventCreateWithFlags(&m->ev_input, hipEventDisableTiming));
+    }
+    MH_HIP(hipEventRecord(m->ev_main, ctx->stream));
+    MH_HIP(hipStreamWaitEvent(m->side, m->ev_main, 0));
+    s = m->side;
+  }
   const size_t n_old = m->n_points, n_new = scan->n, total = n_old + n_new;
   MH_REQUIRE(total < 0x7FFFFFF0ull && m->n_offered + n_new < 0xFFFFFFF0ull, "too many points");
   const size_t stride = ((total * sizeof(float) + 255) / 256) * 256;
@@ -419,6 +450,10 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
                        P, (uint32_t)m->n_offered, mx + n_old, my + n_old, mz + n_old, msrc + n_old);
   }
   MH_HIP(hipGetLastError());
+  if (use_side) {  // the layer has been read: whatever the context's stream does to it next may proceed
+    MH_HIP(hipEventRecord(m->ev_input, s));
+    MH_HIP(hipStreamWaitEvent(ctx->stream, m->ev_input, 0));
+  }
   int evict[4] = {0, 0, 0, -1};
   if (remove_voxels_farther_than > 0.f) {
     const bool trunc = m->params.index_mode == MH_INDEX_TRUNC;
@@ -429,7 +464,7 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
     }
     evict[3] = (int)ceilf(remove_voxels_farther_than * m->inv_vs);
   }
-  MH_TRY(map_build_device(m, mx, my, mz, msrc, total, evict, n_old));
+  MH_TRY(map_build_device(m, s, mx, my, mz, msrc, total, evict, n_old));
   m->n_offered += n_new;
   return MH_OK;
 }
@@ -438,6 +473,12 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
 
 namespace mh {
 
+// counters: [0] range flag  [1] n_valid  [2..7] bbox (ordered uints)  [8] planes  [9] voxels  [10] records
+__global__ void k_init_counters(uint32_t* __restrict__ c) {
+  const uint32_t i = threadIdx.x;
+  if (i < 16) c[i] = (i >= 2 && i <= 4) ? 0xFFFFFFFFu : 0u;
+}
+
 // voxel and record totals (last elements of the two scans) next to the other counters
 __global__ void k_sizes(const uint32_t* __restrict__ vid1, const uint32_t* __restrict__ outpos,
                         const uint32_t* __restrict__ keep, uint32_t n, uint32_t* __restrict__ out) {
@@ -445,12 +486,60 @@ __global__ void k_sizes(const uint32_t* __restrict__ vid1, const uint32_t* __res
   out[1] = outpos[n - 1] + keep[n - 1];
 }
 
-mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc, size_t n,
-                           const int* evict, size_t n_stored) {
-  mh_ctx* ctx = m->ctx;
-  hipStream_t s = ctx->stream;
-  uint32_t n_vox = 0, n_pts = 0, n_rec = 0;
-  uint32_t h_counters[12] = {0};
+mh_status map_resolve(const mh_map* m) {
+  if (m->counts_pending) {
+    MH_HIP(hipEventSynchronize(m->ev_counts));
+    m->counts_pending = false;
+    m->build_in_flight = false;
+    const uint32_t* h = m->h_counts;
+    const bool ndt = m->params.ndt_max_eigen_ratio > 0.f;
+    m->n_voxels = h[9];
+    m->n_records = h[10];
+    m->n_points = h[10] - (ndt ? 2u * h[9] : 0u);
+    m->n_planes = m->n_points ? h[8] : 0;
+    for (int a = 0; a < 3; a++) {
+      m->bbox_min[a] = m->n_points ? ord2f(h[2 + a]) : 0.f;
+      m->bbox_max[a] = m->n_points ? ord2f(h[5 + a]) : 0.f;
+    }
+    if (h[0] & 1u) m->deferred_error = MH_ERR_OUT_OF_RANGE;
+  }
+  if (m->deferred_error != MH_OK) {
+    const mh_status e = m->deferred_error;
+    m->deferred_error = MH_OK;
+    return fail(e, "a point's voxel index exceeds the +-2^20 range of the packed key (|coord|/voxel_size must be < 1e6); "
+                   "the offending points were left out of the map");
+  }
+  return MH_OK;
+}
+
+mh_status map_ready_on(const mh_map* m, hipStream_t s) {
+  if (!m->build_in_flight) return MH_OK;
+  if (hipEventQuery(m->ev_counts) == hipSuccess) {
+    m->build_in_flight = false;
+    return MH_OK;
+  }
+  if (s != m->side) MH_HIP(hipStreamWaitEvent(s, m->ev_counts, 0));
+  return MH_OK;
+}
+
+mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc,
+                           size_t n, const int* evict, size_t n_stored) {
+  if (!m->h_counts) {
+    MH_HIP(hipHostMalloc((void**)&m->h_counts, 16 * sizeof(uint32_t), hipHostMallocDefault));
+    MH_HIP(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
+  }
+  const uint32_t ndt = m->params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
+  // what the host can know without waiting for the device: upper bounds (every offered point kept, every new point a voxel)
+  const size_t n_vox_ub = n_stored ? std::min<size_t>(n, m->n_voxels + (n - n_stored)) : n;
+  const size_t n_rec_ub = n + (ndt ? 2 * n_vox_ub : 0);
+  uint64_t tsize = 64;  // hash table: power of two, load factor <= 0.5
+  while (tsize < 2ull * n_vox_ub) tsize <<= 1;
+  MH_TRY(m->build_e.reserve((n ? n : 1) * sizeof(uint32_t) + 64));  // vstart | counters(16)
+  uint32_t* vstart = m->build_e.as<uint32_t>();
+  uint32_t* counters = vstart + (n ? n : 1);
+  hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(64), 0, s, counters);
+  MH_TRY(m->slots.reserve(tsize * sizeof(MapSlot)));
+  MH_HIP(hipMemsetAsync(m->slots.p, 0xFF, tsize * sizeof(MapSlot), s));
   if (n > 0) {
     const uint32_t N = (uint32_t)n;
     // scratch carve-up
@@ -458,24 +547,19 @@ mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const fl
     // one merge puts them in place (stored first among equal keys = insertion order).  MH_MAP_FULL_SORT=1: sort everything.
     const size_t n_new = n - n_stored;
     const bool merge_path = n_stored > 0 && getenv("MH_MAP_FULL_SORT") == nullptr;
-    MH_TRY(ctx->build_a.reserve((2 * n + n_new) * sizeof(unsigned long long)));  // keys in | keys sorted | new keys sorted
-    MH_TRY(ctx->build_b.reserve((2 * n + n_new) * sizeof(uint32_t)));            // idx in | idx sorted | new idx sorted
-    MH_TRY(ctx->build_c.reserve(2 * n * sizeof(uint32_t)));            // head | vid1
-    MH_TRY(ctx->build_d.reserve(2 * n * sizeof(uint32_t)));            // keep | outpos
-    MH_TRY(ctx->build_e.reserve(n * sizeof(uint32_t) + 64));           // vstart | counters(12)
-    unsigned long long* keys = ctx->build_a.as<unsigned long long>();
+    MH_TRY(m->build_a.reserve((2 * n + n_new) * sizeof(unsigned long long)));  // keys in | keys sorted | new keys sorted
+    MH_TRY(m->build_b.reserve((2 * n + n_new) * sizeof(uint32_t)));            // idx in | idx sorted | new idx sorted
+    MH_TRY(m->build_c.reserve(2 * n * sizeof(uint32_t)));            // head | vid1
+    MH_TRY(m->build_d.reserve(2 * n * sizeof(uint32_t)));            // keep | outpos
+    unsigned long long* keys = m->build_a.as<unsigned long long>();
     unsigned long long* keys_s = keys + n;
-    uint32_t* idx = ctx->build_b.as<uint32_t>();
+    uint32_t* idx = m->build_b.as<uint32_t>();
     uint32_t* idx_s = idx + n;
-    uint32_t* head = ctx->build_c.as<uint32_t>();
+    uint32_t* head = m->build_c.as<uint32_t>();
     uint32_t* vid1 = head + n;
-    uint32_t* keep = ctx->build_d.as<uint32_t>();
+    uint32_t* keep = m->build_d.as<uint32_t>();
     uint32_t* outpos = keep + n;
-    uint32_t* vstart = ctx->build_e.as<uint32_t>();
-    uint32_t* counters = vstart + n;  // [0]=range flag [1]=n_valid [2..7]=bbox ordered
 
-    const uint32_t init_counters[12] = {0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0, 0, 0};
-    MH_HIP(hipMemcpyAsync(counters, init_counters, sizeof(init_counters), hipMemcpyHostToDevice, s));
     const uint32_t B = 256;
     const int4 ev = evict ? make_int4(evict[0], evict[1], evict[2], evict[3]) : make_int4(0, 0, 0, -1);
     const int4 ev_keys = merge_path ? make_int4(0, 0, 0, -1) : ev;  // (merge path: eviction after the merge, k_evict_sorted)
@@ -500,22 +584,21 @@ mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const fl
       MH_HIP(rocprim::exclusive_scan(nullptr, t2, keep, outpos, 0u, N, rocprim::plus<uint32_t>(), s));
       if (t2 > tmp) tmp = t2;
     }
-    MH_TRY(ctx->sort_tmp.reserve(tmp));
-    size_t tb = ctx->sort_tmp.bytes;
+    MH_TRY(m->sort_tmp.reserve(tmp));
+    size_t tb = m->sort_tmp.bytes;
     if (merge_path) {
-      if (n_new) MH_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tb, keys + n_stored, keys_new, idx + n_stored, idx_new, n_new, 0, 64, s));
-      tb = ctx->sort_tmp.bytes;
-      MH_HIP(rocprim::merge(ctx->sort_tmp.p, tb, keys, keys_new, keys_s, idx, idx_new, idx_s, n_stored, n_new,
+      if (n_new) MH_HIP(rocprim::radix_sort_pairs(m->sort_tmp.p, tb, keys + n_stored, keys_new, idx + n_stored, idx_new, n_new, 0, 64, s));
+      tb = m->sort_tmp.bytes;
+      MH_HIP(rocprim::merge(m->sort_tmp.p, tb, keys, keys_new, keys_s, idx, idx_new, idx_s, n_stored, n_new,
                             rocprim::less<unsigned long long>(), s));
       if (ev.w >= 0) hipLaunchKernelGGL(k_evict_sorted, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, N, ev, m->params.far_voxel_metric);
     } else {
-      MH_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tb, keys, keys_s, idx, idx_s, N, 0, 64, s));
+      MH_HIP(rocprim::radix_sort_pairs(m->sort_tmp.p, tb, keys, keys_s, idx, idx_s, N, 0, 64, s));
     }
     hipLaunchKernelGGL(k_heads, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, N, head, counters);
-    tb = ctx->sort_tmp.bytes;
-    MH_HIP(rocprim::inclusive_scan(ctx->sort_tmp.p, tb, head, vid1, N, rocprim::plus<uint32_t>(), s));
+    tb = m->sort_tmp.bytes;
+    MH_HIP(rocprim::inclusive_scan(m->sort_tmp.p, tb, head, vid1, N, rocprim::plus<uint32_t>(), s));
     hipLaunchKernelGGL(k_vstart, dim3(nblk(n, B)), dim3(B), 0, s, head, vid1, N, vstart);
-    const uint32_t ndt = m->params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
     if (m->params.min_distance_between_points > 0.f)
       hipLaunchKernelGGL(k_keep_seq, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, keys_s, idx_s, head, N,
                          m->params.max_points_per_voxel, m->params.min_distance_between_points, (uint32_t)n_stored, keep);
@@ -523,55 +606,36 @@ mh_status map_build_device(mh_map* m, const float* dx, const float* dy, const fl
       hipLaunchKernelGGL(k_keep, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, vid1, vstart, N, m->params.max_points_per_voxel,
                          keep);
     if (ndt) hipLaunchKernelGGL(k_add_ndt_slots, dim3(nblk(n, B)), dim3(B), 0, s, head, N, keep);
-    tb = ctx->sort_tmp.bytes;
-    MH_HIP(rocprim::exclusive_scan(ctx->sort_tmp.p, tb, keep, outpos, 0u, N, rocprim::plus<uint32_t>(), s));
-    // sizes back to the host
-    hipLaunchKernelGGL(k_sizes, dim3(1), dim3(1), 0, s, vid1, outpos, keep, N, counters + 9);
-    MH_HIP(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, s));  // one read-back
-    MH_HIP(hipStreamSynchronize(s));
-    if (h_counters[0] & 1u)
-      return fail(MH_ERR_OUT_OF_RANGE, "a point's voxel index exceeds the +-2^20 range of the packed key "
-                                       "(|coord|/voxel_size must be < 1e6)");
-    n_vox = h_counters[9];
-    n_rec = h_counters[10];
-    n_pts = n_rec - (ndt ? 2u * n_vox : 0u);
+    tb = m->sort_tmp.bytes;
+    MH_HIP(rocprim::exclusive_scan(m->sort_tmp.p, tb, keep, outpos, 0u, N, rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(k_sizes, dim3(1), dim3(1), 0, s, vid1, outpos, keep, N, counters + 9);  // voxels, records: stay on the device
 
-    MH_TRY(m->pts.reserve((size_t)(n_rec ? n_rec : 1) * sizeof(float4)));
-    MH_TRY(m->vox_keys.reserve((size_t)(n_vox ? n_vox : 1) * sizeof(unsigned long long)));
-    MH_TRY(m->vox_first.reserve((size_t)(n_vox ? n_vox : 1) * sizeof(uint32_t)));
-    MH_TRY(m->vox_count.reserve((size_t)(n_vox ? n_vox : 1) * sizeof(uint32_t)));
-    if (n_pts) {
-      hipLaunchKernelGGL(k_scatter, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, keys_s, idx_s, head, vid1, vstart, keep,
-                         outpos, N, m->params.max_points_per_voxel, counters, n_vox, m->pts.as<float4>(),
-                         m->vox_keys.as<unsigned long long>(), m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(),
-                         counters + 2, ndt, dsrc);
-      if (ndt)
-        hipLaunchKernelGGL(k_ndt_stats, dim3(nblk(n_vox, 128)), dim3(128), 0, s, m->pts.as<float4>(),
-                           m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(), n_vox, m->params.ndt_max_eigen_ratio,
-                           m->params.ndt_min_points ? m->params.ndt_min_points : 4u, counters + 8);
-      MH_HIP(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, s));
-    }
-  }
-  // hash table: power of two, load factor <= 0.5
-  uint64_t tsize = 64;
-  while (tsize < 2ull * n_vox) tsize <<= 1;
-  MH_TRY(m->slots.reserve(tsize * sizeof(MapSlot)));
-  MH_HIP(hipMemsetAsync(m->slots.p, 0xFF, tsize * sizeof(MapSlot), s));
-  if (n_vox)
-    hipLaunchKernelGGL(k_table_insert, dim3(nblk(n_vox, 256)), dim3(256), 0, s, m->vox_keys.as<unsigned long long>(),
-                       m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(), n_vox, m->slots.as<MapSlot>(),
+    MH_TRY(m->pts.reserve(n_rec_ub * sizeof(float4)));
+    MH_TRY(m->vox_keys.reserve(n_vox_ub * sizeof(unsigned long long)));
+    MH_TRY(m->vox_first.reserve(n_vox_ub * sizeof(uint32_t)));
+    MH_TRY(m->vox_count.reserve(n_vox_ub * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_scatter, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, keys_s, idx_s, head, vid1, vstart, keep,
+                       outpos, N, m->params.max_points_per_voxel, counters, m->pts.as<float4>(),
+                       m->vox_keys.as<unsigned long long>(), m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(),
+                       counters + 2, ndt, dsrc);
+    if (ndt)
+      hipLaunchKernelGGL(k_ndt_stats, dim3(nblk(n_vox_ub, 128)), dim3(128), 0, s, m->pts.as<float4>(),
+                         m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(), counters + 9, m->params.ndt_max_eigen_ratio,
+                         m->params.ndt_min_points ? m->params.ndt_min_points : 4u, counters + 8);
+    hipLaunchKernelGGL(k_table_insert, dim3(nblk(n_vox_ub, 256)), dim3(256), 0, s, m->vox_keys.as<unsigned long long>(),
+                       m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(), counters + 9, m->slots.as<MapSlot>(),
                        (uint32_t)(tsize - 1));
-  MH_HIP(hipGetLastError());
-  MH_HIP(hipStreamSynchronize(s));
-  m->n_points = n_pts;
-  m->n_records = n_rec;
-  m->n_planes = n_pts ? h_counters[8] : 0;
-  m->n_voxels = n_vox;
-  m->table_size = tsize;
-  for (int a = 0; a < 3; a++) {
-    m->bbox_min[a] = n_pts ? ord2f(h_counters[2 + a]) : 0.f;
-    m->bbox_max[a] = n_pts ? ord2f(h_counters[5 + a]) : 0.f;
   }
+  MH_HIP(hipGetLastError());
+  MH_HIP(hipMemcpyAsync(m->h_counts, counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));  // the one read-back, lazy
+  MH_HIP(hipEventRecord(m->ev_counts, s));
+  m->counts_pending = true;
+  m->build_in_flight = true;
+  m->table_size = tsize;
+  // until map_resolve(): bounds, good enough for whoever only sizes buffers
+  m->n_points = n;
+  m->n_voxels = n_vox_ub;
+  m->n_records = n_rec_ub;
   return MH_OK;
 }
 
@@ -581,6 +645,8 @@ extern "C" {
 
 mh_status mh_map_get_info(const mh_map* m, mh_map_info* info) {
   MH_REQUIRE(m && info, "null argument");
+  MH_TRY(set_device(m->ctx));
+  MH_TRY(map_resolve(m));
   info->n_points = m->n_points;
   info->n_offered = m->n_offered;
   info->n_voxels = m->n_voxels;
@@ -601,6 +667,7 @@ mh_status mh_map_download(const mh_map* m, float* x, float* y, float* z, uint32_
   mh_ctx* ctx = m->ctx;
   MH_TRY(set_device(ctx));
   MH_HIP(hipStreamSynchronize(ctx->stream));
+  MH_TRY(map_resolve(m));  // (waits for an update still running on the side stream)
   if (!m->n_voxels) return MH_OK;
   std::vector<uint32_t> hf(m->n_voxels), hc(m->n_voxels);
   MH_HIP(hipMemcpy(hf.data(), m->vox_first.p, m->n_voxels * 4, hipMemcpyDeviceToHost));
@@ -644,6 +711,7 @@ mh_status mh_map_download_ndt(const mh_map* m, float* cx, float* cy, float* cz, 
   mh_ctx* ctx = m->ctx;
   MH_TRY(set_device(ctx));
   MH_HIP(hipStreamSynchronize(ctx->stream));
+  MH_TRY(map_resolve(m));
   if (!m->n_voxels) return MH_OK;
   const bool ndt = m->params.ndt_max_eigen_ratio > 0.f;
   std::vector<uint32_t> hf(m->n_voxels);

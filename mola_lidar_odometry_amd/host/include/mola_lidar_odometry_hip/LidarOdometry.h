@@ -161,7 +161,9 @@ class LidarOdometry {
                            long long off_t = -1, const float* t = nullptr);
   void prefetch(const float* x, const float* y, const float* z, const float* t, size_t n);
 
-  const std::vector<ScanRecord>& records() const { return records_; }
+  // (n_map_points / n_map_voxels of the records since the last key-frame are read back from the device lazily: here, and
+  // before the next key-frame update -- by then the update has long finished, so the replay itself never waits for it)
+  const std::vector<ScanRecord>& records() const { resolve_map_counts(); return records_; }
   const std::vector<std::pair<double, CPose3D>>& estimatedTrajectory() const { return trajectory_; }
   // TUM format "t x y z qx qy qz qw" (estimated_trajectory.output_file, yaml:79-81; eval/cli_kitti.sh:41-50)
   void saveTrajectoryTUM(const std::string& path) const;
@@ -172,6 +174,7 @@ class LidarOdometry {
   std::map<std::string, std::string> describePipeline() const;
   // accumulated host wall time [s] per stage of onLidar (the role of the reference's profiler_ sections "onLidar.*")
   const std::map<std::string, double>& profile() const { return profile_; }
+  void resetProfile() { profile_.clear(); }  // e.g. after the warm-up scans of a replay: steady-state stage times
 
  private:
   struct FilterPlan;  // the recognised observation filter chain, as data for mh_scan_preprocess / mh_scan_deskew
@@ -187,6 +190,8 @@ class LidarOdometry {
   void doUpdateAdaptiveThreshold(const CPose3D& motionModelError);
   void create_local_map();
   void ensure_device();
+  void resolve_map_counts() const;  // fills n_map_points / n_map_voxels of the records that still wait for them
+  bool map_is_empty();              // local_map_->empty() without a device round trip once the map is known to hold points
 
   std::shared_ptr<DeviceContext> ctx_;
   Params params_;
@@ -220,7 +225,11 @@ class LidarOdometry {
   SearchablePoseList distance_checker_local_map_;
   uint32_t localmap_check_removal_counter_ = 0;
   std::vector<std::pair<double, CPose3D>> trajectory_;
-  std::vector<ScanRecord> records_;
+  mutable std::vector<ScanRecord> records_;
+  mutable bool map_counts_pending_ = false;  // records_[map_counts_from_ ...] wait for the map's counters
+  mutable size_t map_counts_from_ = 0;
+  mutable uint64_t map_points_cached_ = 0, map_voxels_cached_ = 0;
+  bool map_known_nonempty_ = false;
   std::map<std::string, double> profile_;
 };
 

@@ -441,6 +441,7 @@ class ICP {
   bool lastAlignUsedFusedPath() const { return last_fused_; }
   uint32_t lastAlignHostPolls() const { return last_polls_; }              // fused path: host waits for the device loop
   uint32_t lastAlignEnqueuedIterations() const { return last_enqueued_; }  // ... and iterations worth of kernels enqueued
+  double lastAlignSetupSeconds() const { return last_setup_seconds_; }     // host time before the device call (schedules, parameters)
   // false: Results::finalPairings stays empty in the fused path (the odometry driver never reads it)
   void setKeepFinalPairings(bool v) { keep_pairings_ = v; }
   void forceGenericPath(bool v) { force_generic_ = v; }
@@ -471,6 +472,7 @@ class ICP {
   // how long the previous call of each kind ran: [0] calls with the full iteration budget, [1] re-entries after a hook
   // request (LidarOdometry.cpp:956-967 re-enters with what is left of it) -- the first chunk of the device loop is sized by it
   uint32_t full_budget_ = 0, last_iterations_[2] = {0, 0}, last_polls_ = 0, last_enqueued_ = 0;
+  double last_setup_seconds_ = 0;
 };
 
 // class factory by name (mrpt::rtti::classFactory stand-in): "mp2p_icp::X" and "mp2p_icp_hip::X" both resolve

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -679,6 +680,7 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
   auto mpl = matchers_.size() == 2 ? std::static_pointer_cast<Matcher_Point2Plane>(matchers_[0]) : nullptr;
   // the thresholds are functions of ICP_ITERATION only once the caller's variables are fixed for this call
   // (LidarOdometry.cpp:1571-1635 publishes them before align): evaluate them for every iteration up front
+  const auto t_setup0 = std::chrono::steady_clock::now();
   std::vector<double> thr(p.maxIterations), kp(p.maxIterations), plthr(p.maxIterations);
   {
     // formulas compiled once and bound to one copy of the variables; only ICP_ITERATION is swept (in place)
@@ -739,6 +741,7 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
   }
   mh_prior pr;
   if (prior) fill_prior(prior, pr);
+  last_setup_seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count();
   mh_icp_result r{};
   const size_t n = dev_local ? dev_local->size() : host_local->size();
   const bool want_pairs = keep_pairings_;

@@ -382,8 +382,31 @@ void LidarOdometry::ensure_device() {
   for_icp_ = std::make_shared<DevicePointCloud>(ctx_);
 }
 
+void LidarOdometry::resolve_map_counts() const {
+  if (!map_counts_pending_) return;
+  map_points_cached_ = local_map_ ? local_map_->size() : 0;  // (mh_map_get_info: waits for the update if it still runs)
+  map_voxels_cached_ = local_map_ ? local_map_->voxelCount() : 0;
+  for (size_t i = map_counts_from_; i < records_.size(); i++) {
+    if (records_[i].dropped) continue;  // (those returned before the map was looked at)
+    records_[i].n_map_points = map_points_cached_;
+    records_[i].n_map_voxels = map_voxels_cached_;
+  }
+  map_counts_pending_ = false;
+}
+
+bool LidarOdometry::map_is_empty() {
+  if (!local_map_) return true;
+  if (map_known_nonempty_) return false;
+  map_known_nonempty_ = local_map_->size() != 0;
+  return !map_known_nonempty_;
+}
+
 void LidarOdometry::reset() {
   cancel_prefetch();
+  map_counts_pending_ = false;
+  map_counts_from_ = 0;
+  map_points_cached_ = map_voxels_cached_ = 0;
+  map_known_nonempty_ = false;
   navstate_.reset();
   local_map_.reset();
   last_lidar_pose_ = CPose3D();
@@ -711,7 +734,7 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
   const bool hasMotionModel = last_motion_model_output_.has_value();
   rec.had_motion_model = hasMotionModel;
 
-  const bool map_empty = !local_map_ || local_map_->size() == 0;
+  const bool map_empty = map_is_empty();
   if (map_empty) {
     // first point cloud: no ICP, it becomes the map (:817-838)
     rec.first_scan = true;
@@ -762,6 +785,7 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
       profile_["icp.enqueued_iterations"] += icp.lastAlignEnqueuedIterations();
       profile_["icp.executed_iterations"] += (double)res.nIterations;
       profile_["icp.align_calls"] += 1.0;
+      profile_["onLidar.3.icp_host_setup"] += icp.lastAlignSetupSeconds();
       remaining -= std::min(remaining, res.nIterations);
       rec.icp_iterations += (uint32_t)res.nIterations;
       if (res.terminationReason == IterTermReason::HookRequest) {
@@ -827,7 +851,10 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
 
   // a bad ICP right after the start: begin again from an empty map (:1146-1156)
   if (!last_icp_was_good_ && trajectory_.size() == 1) {
+    resolve_map_counts();  // (earlier records keep the counts of the map they saw)
     if (local_map_) local_map_->clear();
+    map_known_nonempty_ = false;
+    map_points_cached_ = map_voxels_cached_ = 0;
     trajectory_.clear();
     updateLocalMap = false;
     last_icp_was_good_ = true;
@@ -839,15 +866,20 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
     StageTimer tt(profile_, "onLidar.4.update_local_map");
     if (!local_map_) create_local_map();
     updatePipelineDynamicVariables();  // robot_x..robot_roll (:1194)
+    resolve_map_counts();  // the previous update's counters (it finished before this scan's alignment started: no wait)
+    // asynchronous: the update runs on the map's own stream and is waited for by the next use of the map only
     local_map_->insertPointCloud(*for_map_, last_lidar_pose_, remove_voxels_farther_than_);
     rec.map_updated = true;
+    if (rec.n_for_map == 0) map_known_nonempty_ = false;  // (nothing offered: ask the device next time)
+    map_counts_pending_ = true;
+    map_counts_from_ = records_.size() - 1;
   }
   rec.pose = last_lidar_pose_;
   rec.sigma = adapt_thres_sigma_;
   rec.map_voxel_size = map_voxel_size_;
-  if (local_map_) {
-    rec.n_map_points = local_map_->size();
-    rec.n_map_voxels = local_map_->voxelCount();
+  if (!map_counts_pending_) {  // (otherwise filled by resolve_map_counts())
+    rec.n_map_points = map_points_cached_;
+    rec.n_map_voxels = map_voxels_cached_;
   }
   return rec;
 }

@@ -165,14 +165,13 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
           if ((size_t)t->size() != n) throw std::runtime_error("t must have n entries");
           tp = t->data();
         }
-        const LidarOdometry::ScanRecord* rec = nullptr;
         {
           py::gil_scoped_release nogil;  // the numpy buffers are only read through their pointers: other drivers' threads may run
-          rec = &lo.onLidarInterleaved(stamp, xyz.data(), n, k * sizeof(float), 4u * (size_t)xyz_fields[0],
+          (void)lo.onLidarInterleaved(stamp, xyz.data(), n, k * sizeof(float), 4u * (size_t)xyz_fields[0],
                                        4u * (size_t)xyz_fields[1], 4u * (size_t)xyz_fields[2],
                                        t_field >= 0 ? 4ll * t_field : -1ll, tp);
         }
-        return rec2dict(*rec); },
+        return rec2dict(lo.records().back()); },  // (records(): the map counters of this record, read back now)
            py::arg("timestamp"), py::arg("xyz"), py::arg("t") = std::nullopt,
            py::arg("xyz_fields") = std::array<int, 3>{0, 1, 2}, py::arg("t_field") = -1)
       .def("setAlignBatcher", &LidarOdometry::setAlignBatcher)

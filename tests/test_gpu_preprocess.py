@@ -112,10 +112,13 @@ def _assert_maps_equal(g, o):
         np.testing.assert_array_equal(g[k], o[k], err_msg=k)
 
 
-@pytest.mark.parametrize("vs,cap,far", [(1.0, 20, 0.0), (1.0, 20, 45.0), (0.5, 4, 30.0)])
-def test_map_insert_keyframes_bit_exact(ctx, oracle, vs, cap, far):
+@pytest.mark.parametrize("vs,cap,far,side", [(1.0, 20, 0.0, 0), (1.0, 20, 45.0, 0), (0.5, 4, 30.0, 0), (1.0, 20, 45.0, 1)])
+def test_map_insert_keyframes_bit_exact(ctx, oracle, vs, cap, far, side, monkeypatch):
     """A drive of key-frames: every update (posed insertion after the stored content, cap, far-voxel removal)
-    leaves exactly the voxel contents and source indices of the per-point CPU insertion."""
+    leaves exactly the voxel contents and source indices of the per-point CPU insertion.  The update is asynchronous
+    (counts read back lazily by info() / download(); side = 1: on the map's own stream, MH_MAP_SIDE_STREAM)."""
+    if side:
+        monkeypatch.setenv("MH_MAP_SIDE_STREAM", "1")
     scene = synth.make_scene(777, 80.0, 12)
     g, o = capi.Map(ctx, vs, cap), oracle.Map(vs, cap)
     offered = 0
