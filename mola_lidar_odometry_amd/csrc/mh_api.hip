@@ -165,6 +165,7 @@ mh_status mh_ctx_destroy(mh_ctx* ctx) {
   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+  if (ctx->h_small) (void)hipHostFree(ctx->h_small);
   if (ctx->h_sched) (void)hipHostFree(ctx->h_sched);
   if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
   ctx->batch_desc.release();

@@ -137,6 +137,7 @@ struct mh_ctx {
   unsigned long long graph_key[24] = {0};
   unsigned long long graph_candidate[24] = {0};  // key of the last direct-launched chunk: captured when a LATER alignment repeats it
   unsigned long long graph_candidate_align = 0, align_serial = 0;
+  uint32_t* h_small = nullptr;  // pinned, device-visible [64]: small results a kernel writes straight to the host (mh_scan_bbox)
   hipEvent_t ev_poll = nullptr;
   hipEvent_t ev_ready = nullptr;  // "everything queued on this context's stream so far": what a batch leader waits for
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;

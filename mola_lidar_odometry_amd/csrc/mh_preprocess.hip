@@ -154,6 +154,48 @@ __global__ void k_pp_compact(const float* __restrict__ x, const float* __restric
   osrc[o] = src ? src[i] : i;
 }
 
+// The same for a layer one workgroup can walk (what the sensor-range estimate reads every scan: the ~1 k-point ICP
+// layer): no counters to initialise, no atomics, and the seven words go straight to page-locked HOST memory -- one
+// launch and one wait instead of an upload, a launch, a download and a wait.
+__global__ __launch_bounds__(1024) void k_pp_bbox_one(const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ z, uint32_t n, uint32_t* __restrict__ host_out) {
+  __shared__ uint32_t sh[16][7];
+  uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u}, cnt = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const float p[3] = {x[i], y[i], z[i]};
+    if (isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2])) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const uint32_t o = f2ord(p[a]);
+        mn[a] = min(mn[a], o);
+        mx[a] = max(mx[a], o);
+      }
+      cnt++;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      mn[a] = min(mn[a], (uint32_t)__shfl_xor((int)mn[a], off));
+      mx[a] = max(mx[a], (uint32_t)__shfl_xor((int)mx[a], off));
+    }
+    cnt += (uint32_t)__shfl_xor((int)cnt, off);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { sh[w][a] = mn[a]; sh[w][3 + a] = mx[a]; }
+    sh[w][6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int a = threadIdx.x;
+    uint32_t v = sh[0][a];
+    for (int q = 1; q < (int)(blockDim.x >> 6); q++) v = a < 3 ? min(v, sh[q][a]) : (a < 6 ? max(v, sh[q][a]) : v + sh[q][a]);
+    host_out[a] = v;
+  }
+}
+
 // counters[0..2] = min, [3..5] = max (ordered uints), [6] = finite count; grid-stride, seven atomics per workgroup
 __global__ __launch_bounds__(256) void k_pp_bbox(const float* __restrict__ x, const float* __restrict__ y,
                                                  const float* __restrict__ z, uint32_t n, uint32_t* __restrict__ counters) {
@@ -440,7 +482,13 @@ mh_status mh_scan_bbox(const mh_scan* scan, float bb_min[3], float bb_max[3], ui
   MH_TRY(set_device(ctx));
   hipStream_t s = ctx->stream;
   uint32_t h[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
-  if (scan->n) {
+  if (scan->n && scan->n <= 65536) {
+    if (!ctx->h_small) MH_HIP(hipHostMalloc((void**)&ctx->h_small, 64 * sizeof(uint32_t), hipHostMallocDefault));
+    hipLaunchKernelGGL(k_pp_bbox_one, dim3(1), dim3(1024), 0, s, scan->x, scan->y, scan->z, (uint32_t)scan->n, ctx->h_small);
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipStreamSynchronize(s));
+    for (int a = 0; a < 7; a++) h[a] = ctx->h_small[a];
+  } else if (scan->n) {
     MH_TRY(ctx->build_e.reserve(64));
     uint32_t* counters = ctx->build_e.as<uint32_t>();
     MH_HIP(hipMemcpyAsync(counters, h, sizeof(h), hipMemcpyHostToDevice, s));

@@ -7,6 +7,9 @@
 //
 //   molahip-lo-cli --pipeline pipelines/lidar3d-default-hip.yaml --seq-dir /data/kitti/sequences/00 --out 00.tum
 //                  [--device 0] [--no-prefetch] [--max-scans N]
+// --seq-dir also takes a MulRan sequence folder (eval/cli_mulran.sh:23-36, `--input-mulran-seq KAIST01` with
+// MULRAN_BASE_DIR, apps/mola-lidar-odometry-cli.cpp:186-208): <dir>/sensor_data/Ouster/<stamp in ns>.bin (or <dir>/Ouster/),
+// float32 x,y,z,intensity rows like KITTI's, the scan's time stamp is its file name.
 // Several --seq-dir run together on the one GPU (what eval/cli_kitti.sh:23 does with GNU parallel -j3, as processes):
 // a host thread per sequence, their alignments merged into lock-step batches (mp2p_icp_hip::AlignBatcher).
 #include <algorithm>
@@ -39,6 +42,18 @@ std::vector<std::string> list_bins(const std::string& dir) {
   closedir(d);
   std::sort(out.begin(), out.end());
   return out;
+}
+
+bool dir_exists(const std::string& d) {
+  DIR* h = opendir(d.c_str());
+  if (h) closedir(h);
+  return h != nullptr;
+}
+// ".../1561000444390857630.bin" -> 1561000444.390857630 [s]
+double stamp_of_name(const std::string& path) {
+  const size_t slash = path.rfind('/');
+  const std::string base = path.substr(slash == std::string::npos ? 0 : slash + 1);
+  return 1e-9 * strtod(base.c_str(), nullptr);
 }
 
 std::vector<float> read_bin(const std::string& path) {
@@ -75,14 +90,23 @@ void run_sequence(const std::string& pipeline, const std::string& seq_dir, const
   rep.seq_dir = seq_dir;
   rep.out = out;
   try {
-    std::vector<std::string> files = list_bins(seq_dir + "/velodyne");
-    if (max_scans >= 0 && (size_t)max_scans < files.size()) files.resize((size_t)max_scans);
+    std::vector<std::string> files;
     std::vector<double> stamps;
-    {
+    const std::string ouster = dir_exists(seq_dir + "/sensor_data/Ouster") ? seq_dir + "/sensor_data/Ouster"
+                               : (dir_exists(seq_dir + "/Ouster") ? seq_dir + "/Ouster" : std::string());
+    if (!dir_exists(seq_dir + "/velodyne") && !ouster.empty()) {
+      // MulRan: one <time stamp in nanoseconds>.bin per sweep (numeric order = lexical order for equal-length names)
+      files = list_bins(ouster);
+      std::sort(files.begin(), files.end(), [](const std::string& a, const std::string& b) { return stamp_of_name(a) < stamp_of_name(b); });
+      const double t0 = files.empty() ? 0.0 : stamp_of_name(files[0]);
+      for (const auto& f : files) stamps.push_back(stamp_of_name(f) - t0);  // relative seconds (TUM output keeps sub-ms digits)
+    } else {
+      files = list_bins(seq_dir + "/velodyne");
       std::ifstream ts(seq_dir + "/times.txt");
       double t;
       while (ts >> t) stamps.push_back(t);
     }
+    if (max_scans >= 0 && (size_t)max_scans < files.size()) files.resize((size_t)max_scans);
     while (stamps.size() < files.size()) stamps.push_back(0.1 * (double)stamps.size());  // 10 Hz when times.txt is absent
 
     mola_hip::LidarOdometry lo(std::make_shared<mp2p_icp_hip::DeviceContext>(device));

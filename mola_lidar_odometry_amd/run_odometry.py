@@ -35,6 +35,42 @@ def _kitti_scans(seq_dir):
         yield float(st), rec, None  # KITTI odometry scans are motion compensated and carry no time stamps
 
 
+def _mulran_scans(seq_dir):
+    """A MulRan sequence folder (eval/cli_mulran.sh:23-36; apps/mola-lidar-odometry-cli.cpp:186-208 `--input-mulran-seq`):
+    <dir>/sensor_data/Ouster/<time stamp in ns>.bin (or <dir>/Ouster/), float32 x,y,z,intensity rows."""
+    d = os.path.join(seq_dir, "sensor_data", "Ouster")
+    if not os.path.isdir(d):
+        d = os.path.join(seq_dir, "Ouster")
+    files = sorted(glob.glob(os.path.join(d, "*.bin")), key=lambda f: int(os.path.splitext(os.path.basename(f))[0]))
+    t0 = int(os.path.splitext(os.path.basename(files[0]))[0]) if files else 0
+    for f in files:
+        rec = np.fromfile(f, dtype=np.float32).reshape(-1, 4)
+        yield 1e-9 * (int(os.path.splitext(os.path.basename(f))[0]) - t0), rec, None
+
+
+def is_mulran_dir(seq_dir):
+    return not os.path.isdir(os.path.join(seq_dir, "velodyne")) and (
+        os.path.isdir(os.path.join(seq_dir, "sensor_data", "Ouster")) or os.path.isdir(os.path.join(seq_dir, "Ouster")))
+
+
+def sequence_scans(seq_dir):
+    """KITTI or MulRan folder -> iterator of (stamp, records [n,4], None)."""
+    return _mulran_scans(seq_dir) if is_mulran_dir(seq_dir) else _kitti_scans(seq_dir)
+
+
+def mulran_gt(seq_dir):
+    """global_pose.csv of a MulRan sequence: rows `stamp_ns, r00, r01, r02, tx, r10, ... tz` -> (stamps [s], poses [n,4,4])
+    or None.  (The vehicle's pose; the Ouster sits 1.7 m ahead and 1.8 m up, turned by ~180 deg: compare after an SE(3)
+    fit -- what `evo_ape -a` does, eval/cli_mulran.sh:50 -- and mind that a lever arm remains.)"""
+    f = os.path.join(seq_dir, "global_pose.csv")
+    if not os.path.exists(f):
+        return None
+    a = np.loadtxt(f, delimiter=",").reshape(-1, 13)
+    T = np.tile(np.eye(4), (len(a), 1, 1))
+    T[:, :3, :] = a[:, 1:].reshape(-1, 3, 4)
+    return 1e-9 * a[:, 0], T
+
+
 def _kitti_gt(root, seq, Tr=None):
     f = os.path.join(root, "poses", seq + ".txt")
     if not os.path.exists(f):
@@ -106,6 +142,8 @@ def main(argv=None):
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--azimuths", type=int, default=1875, help="64 x 1875 = the 120k-point sweep of BASELINE.json C2")
     ap.add_argument("--kitti-root", default=None, help="KITTI odometry root (sequences/XX/velodyne, poses/XX.txt)")
+    ap.add_argument("--mulran-root", default=None, help="MulRan root (<seq>/sensor_data/Ouster/*.bin, <seq>/global_pose.csv): "
+                    "what MULRAN_BASE_DIR is to eval/cli_mulran.sh; --seqs then names KAIST01 DCC02 ...")
     ap.add_argument("--seqs", nargs="*", default=[])
     ap.add_argument("--copies", type=int, default=1, help="run the synthetic drive this many times (as separate sequences)")
     ap.add_argument("--no-prefetch", action="store_true", help="strictly sequential scans (what a live sensor feed gives)")
@@ -137,6 +175,11 @@ def main(argv=None):
     for c in range(a.copies if a.synthetic else 0):
         jobs.append(("synthetic" if a.copies == 1 else "synthetic%d" % c, a.synthetic, None))
     for s in a.seqs:
+        if a.mulran_root:
+            d = os.path.join(a.mulran_root, s)
+            n_files = len(glob.glob(os.path.join(d, "sensor_data", "Ouster", "*.bin"))) or len(glob.glob(os.path.join(d, "Ouster", "*.bin")))
+            jobs.append((s, n_files, d))
+            continue
         d = os.path.join(a.kitti_root, "sequences", s)
         jobs.append((s, len(glob.glob(os.path.join(d, "velodyne", "*.bin"))), d))
     mine = mdist.lpt_assign([j[1] for j in jobs], world)[rank]
@@ -149,6 +192,15 @@ def main(argv=None):
             G = np.stack([trajectory.to44(p) for p in drive["poses"]])
             gt = np.linalg.inv(G[0])[None] @ G
             gt_stamps = drive["stamps"]
+        elif is_mulran_dir(src):
+            scans = _mulran_scans(src)
+            g = mulran_gt(src)
+            gt, gt_stamps = (None, None)
+            if g is not None:  # ground-truth stamps on the scans' relative clock
+                files = sorted(glob.glob(os.path.join(src, "sensor_data", "Ouster", "*.bin")) or glob.glob(os.path.join(src, "Ouster", "*.bin")),
+                               key=lambda f: int(os.path.splitext(os.path.basename(f))[0]))
+                t0 = 1e-9 * int(os.path.splitext(os.path.basename(files[0]))[0]) if files else 0.0
+                gt_stamps, gt = g[0] - t0, g[1]
         else:
             scans = _kitti_scans(src)
             gt = _kitti_gt(a.kitti_root, name, _kitti_calib_Tr(src))

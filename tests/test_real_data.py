@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from mola_lidar_odometry_amd import trajectory
+from mola_lidar_odometry_amd import synth, trajectory
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -54,9 +54,9 @@ def mulran_sequence_dir():
         probed.append(base)
         if os.path.isdir(base):
             for seq in sorted(os.listdir(base)):
-                d = os.path.join(base, seq, "Ouster")
-                if os.path.isdir(d):
-                    return d, probed
+                for sub in (("sensor_data", "Ouster"), ("Ouster",)):
+                    if os.path.isdir(os.path.join(base, seq, *sub)):
+                        return os.path.join(base, seq), probed  # the SEQUENCE folder (what --seq-dir takes)
     return None, probed
 
 
@@ -159,5 +159,68 @@ def test_config5_ndt_pipeline_on_mulran(tmp_path):
     """Config 5: lidar3d-ndt(-hip).yaml on a MulRan sequence (eval/cli_mulran.sh:23-51)."""
     seq, probed = mulran_sequence_dir()
     if seq is None:
-        pytest.skip("MulRan not found (no dataset in this image, no network); probed: " + ", ".join(probed))
-    pytest.skip("MulRan found at %s but its Ouster .bin reader (ring/time fields) is not part of the hot-path scope" % seq)
+        pytest.skip("MulRan not found (no dataset in this image, no network); MULRAN_BASE_DIR=%r; probed <base>/<SEQ>/"
+                    "[sensor_data/]Ouster for base in: %s" % (os.environ.get("MULRAN_BASE_DIR"), ", ".join(probed)))
+    out = str(tmp_path / "mulran.tum")
+    rep = _run_cli(PIPE_NDT, seq, out, max_scans=int(os.environ.get("MULRAN_MAX_SCANS", "2000")))
+    assert rep["scans"] > 10 and rep["good"] > 0.95 * rep["scans"]
+    print("config 5:", json.dumps(rep))
+    from mola_lidar_odometry_amd import run_odometry
+    g = run_odometry.mulran_gt(seq)
+    if g is not None:
+        st, est = trajectory.read_tum(out)
+        files = sorted(os.listdir(os.path.join(seq, "sensor_data", "Ouster") if os.path.isdir(os.path.join(seq, "sensor_data", "Ouster")) else os.path.join(seq, "Ouster")))
+        t0 = 1e-9 * int(os.path.splitext(files[0])[0])
+        ia, ib = trajectory.associate(st, g[0] - t0, max_dt=0.06)
+        if len(ia) > 10:
+            ate = trajectory.ate_rmse(est[ia], g[1][ib], "se3")  # evo_ape -a (eval/cli_mulran.sh:50)
+            print("config 5: ATE rmse [m] after SE(3) fit", ate)
+            assert ate < 25.0
+
+
+def _write_mulran_tree(root, drive, seq="SYNTH01"):
+    """The synthetic drive in MulRan's layout: <seq>/sensor_data/Ouster/<stamp ns>.bin + <seq>/global_pose.csv."""
+    d = os.path.join(root, seq, "sensor_data", "Ouster")
+    os.makedirs(d, exist_ok=True)
+    rows = []
+    for (xyz, _), st, pose in zip(drive["scans"], drive["stamps"], drive["poses"]):
+        ns = int(round(st * 1e9)) + 1561000000000000000
+        np.concatenate([xyz, np.zeros((len(xyz), 1), np.float32)], 1).astype(np.float32).tofile(os.path.join(d, "%d.bin" % ns))
+        rows.append([ns] + list(np.asarray(pose).reshape(12)))
+    np.savetxt(os.path.join(root, seq, "global_pose.csv"), np.asarray(rows), delimiter=",", fmt="%.18g")
+    return os.path.join(root, seq)
+
+
+def test_mulran_layout_is_recognised(tmp_path):
+    """CPU: the probe, the Python reader and the ground-truth loader on a synthetic tree in MulRan's layout."""
+    from mola_lidar_odometry_amd import run_odometry
+    drive = synth.make_drive(3, rings=8, azimuths=90)
+    seq = _write_mulran_tree(str(tmp_path), drive)
+    assert run_odometry.is_mulran_dir(seq) and not run_odometry.is_mulran_dir(str(tmp_path))
+    scans = list(run_odometry.sequence_scans(seq))
+    assert len(scans) == 3 and scans[0][0] == 0.0 and abs(scans[2][0] - 0.2) < 1e-6
+    np.testing.assert_array_equal(scans[1][1][:, :3], drive["scans"][1][0])
+    st, T = run_odometry.mulran_gt(seq)
+    assert T.shape == (3, 4, 4) and np.allclose(T[2][:3].reshape(-1), drive["poses"][2])
+    os.environ["MULRAN_BASE_DIR"] = str(tmp_path)
+    try:
+        d, _ = mulran_sequence_dir()
+        assert d == seq
+    finally:
+        del os.environ["MULRAN_BASE_DIR"]
+
+
+@pytest.mark.gpu
+def test_mulran_folder_through_the_cli_with_the_ndt_pipeline(tmp_path):
+    """GPU: molahip-lo-cli reads a MulRan-layout folder (stamps from the file names) and runs lidar3d-ndt-hip.yaml on it --
+    the plumbing of config 5 on a synthetic drive: same trajectory as the same scans in KITTI layout."""
+    drive = synth.make_drive(12, rings=32, azimuths=600)
+    seq_m = _write_mulran_tree(str(tmp_path / "m"), drive)
+    seq_k = synth.write_kitti_sequence(str(tmp_path / "k"), drive)
+    rep_m = _run_cli(PIPE_NDT, seq_m, str(tmp_path / "m.tum"))
+    rep_k = _run_cli(PIPE_NDT, seq_k, str(tmp_path / "k.tum"))
+    assert rep_m["scans"] == rep_k["scans"] == 12 and rep_m["good"] == rep_k["good"] >= 10
+    sm, Tm = trajectory.read_tum(str(tmp_path / "m.tum"))
+    sk, Tk = trajectory.read_tum(str(tmp_path / "k.tum"))
+    np.testing.assert_allclose(sm, sk, atol=1e-5)
+    np.testing.assert_allclose(Tm, Tk, atol=1e-6)
