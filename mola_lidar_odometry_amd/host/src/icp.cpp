@@ -552,13 +552,21 @@ bool ICP::can_fuse() const {
 }
 
 // ---------------------------------------------------------------- AlignBatcher
-AlignBatcher::AlignBatcher(size_t participants) : active_(participants) {}
+AlignBatcher::AlignBatcher(size_t participants) : active_(participants) {
+  if (const char* e = getenv("MOLA_HIP_BATCH_SPLIT")) split_ = (size_t)std::max(1, atoi(e));
+}
 
-void AlignBatcher::run_batch_locked() {
-  // every active participant is blocked in align(): one batch over their requests (the caller holds the mutex; the
-  // others only wait on the condition variable, so the device work is issued by this thread alone)
-  std::vector<Request*> batch;
-  batch.swap(waiting_);
+// how many waiting requests make a batch: all active participants (split 1), or a share of them -- then two or more
+// batches are in flight at once, each led by the thread that completed it, and nobody waits for the slowest alignment of
+// ALL sequences (iteration counts differ by 5x from scan to scan), only for the slowest of its own batch
+size_t AlignBatcher::threshold_locked() const {
+  if (active_ < 4 || split_ <= 1) return active_;
+  return std::max<size_t>(2, (active_ + split_ - 1) / split_);
+}
+
+void AlignBatcher::run_batch(std::vector<Request*>& batch) {
+  // the device work of this batch is issued by this thread alone; the mutex is NOT held (other participants queue up and
+  // may start the next batch on their own contexts meanwhile: the C ABI is re-entrant across contexts)
   const size_t n = batch.size();
   std::vector<const mh_map*> maps(n);
   std::vector<const mh_scan*> scans(n);
@@ -584,12 +592,24 @@ void AlignBatcher::run_batch_locked() {
                             results.data(), nullptr, MH_MEM_HOST);
   }
   if (st != MH_OK) err = mh_last_error_string();  // (thread-local in the library: read it on the thread that made the call)
+  std::vector<mh_status> sts(n, st);
+  std::vector<std::string> errs(n, err);
+  if (st != MH_OK && n > 1) {
+    // one job's bad argument or allocation failure must not fail the other sequences: once more, one by one, so that
+    // every request gets its own status
+    for (size_t i = 0; i < n; i++) {
+      sts[i] = mh_icp_align(maps[i], scans[i], &params[i], &T[12 * i], priors[i], &results[i], nullptr, nullptr, MH_MEM_HOST);
+      errs[i] = sts[i] != MH_OK ? mh_last_error_string() : "";
+    }
+  }
+  std::lock_guard<std::mutex> lk(mtx_);
   n_batches_++;
   n_jobs_ += n;
+  in_flight_ -= n;
   for (size_t i = 0; i < n; i++) {
     *batch[i]->result = results[i];
-    batch[i]->status = st;
-    batch[i]->error = err;
+    batch[i]->status = sts[i];
+    batch[i]->error = errs[i];
     batch[i]->done = true;
   }
   cv_.notify_all();
@@ -601,8 +621,18 @@ mh_status AlignBatcher::align(const mh_map* map, const mh_scan* scan, const mh_i
   rq.map = map; rq.scan = scan; rq.params = params; rq.T = T_guess; rq.prior = prior; rq.result = result;
   std::unique_lock<std::mutex> lk(mtx_);
   waiting_.push_back(&rq);
-  if (waiting_.size() >= active_) run_batch_locked();
-  else cv_.wait(lk, [&] { return rq.done; });
+  // a batch is due when enough requests wait -- or when everybody who is not waiting is inside a running batch already
+  // (then waiting longer only idles the device)
+  if (waiting_.size() >= threshold_locked() || waiting_.size() + in_flight_ >= active_) {
+    std::vector<Request*> batch;
+    batch.swap(waiting_);
+    in_flight_ += batch.size();
+    lk.unlock();
+    run_batch(batch);
+    lk.lock();
+  } else {
+    cv_.wait(lk, [&] { return rq.done; });
+  }
   if (error) *error = rq.error;
   return rq.status;
 }
@@ -610,7 +640,14 @@ mh_status AlignBatcher::align(const mh_map* map, const mh_scan* scan, const mh_i
 void AlignBatcher::leave() {
   std::unique_lock<std::mutex> lk(mtx_);
   if (active_ > 0) active_--;
-  if (!waiting_.empty() && waiting_.size() >= active_) run_batch_locked();  // the others were only waiting for this one
+  if (!waiting_.empty() && (waiting_.size() >= threshold_locked() || waiting_.size() + in_flight_ >= active_)) {
+    // the others were only waiting for this one
+    std::vector<Request*> batch;
+    batch.swap(waiting_);
+    in_flight_ += batch.size();
+    lk.unlock();
+    run_batch(batch);
+  }
 }
 
 void ICP::align(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const TPose3D& guess, const Parameters& p,
