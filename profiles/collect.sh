@@ -64,19 +64,19 @@ if mk:
     if 'TCC_HIT_sum' in m and 'TCC_MISS_sum' in m: t['l2_hit_rate']=m['TCC_HIT_sum']['mean']/max(1.0,m['TCC_HIT_sum']['mean']+m['TCC_MISS_sum']['mean'])
     if 'TCP_TOTAL_CACHE_ACCESSES_sum' in m and 'TCP_TCC_READ_REQ_sum' in m: t['l1_hit_rate']=1.0-m['TCP_TCC_READ_REQ_sum']['mean']/max(1.0,m['TCP_TOTAL_CACHE_ACCESSES_sum']['mean'])
     # duration of that kernel in the --stats run of the default bench (no counters): what the roofline divides by
-    rows=list(csv.DictReader(open(glob.glob(out+'/bench/*kernel_stats.csv')[0])))
+    rows=list(csv.DictReader(open(glob.glob(out+'/bench/'+tag+'_*kernel_stats.csv')[0])))
     for r in rows:
         if r['Name'].split('(')[0]==k: t['avg_launch_ms']=float(r['AverageNs'])/1e6; t['calls']=int(r['Calls'])
     res['timed_kernel']=t
 json.dump(res, open(out+'/'+tag+'_pmc_summary.json','w'), indent=1)
 print(json.dumps(res.get('timed_kernel'), indent=1))
-rows=list(csv.DictReader(open(glob.glob(out+'/bench/*kernel_stats.csv')[0])))
+rows=list(csv.DictReader(open(glob.glob(out+'/bench/'+tag+'_*kernel_stats.csv')[0])))
 for r in rows[:10]:
     print(r['Name'][:70].ljust(70), r['Calls'].rjust(6), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(9),'us', r['Percentage'])
 print(stdout[-1][:3000] if stdout else 'no bench output')
-if glob.glob(out+'/odom/*kernel_stats.csv'):
+if glob.glob(out+'/odom/'+tag+'_*kernel_stats.csv'):
     print('--- odometry driver, 40 synthetic scans of 120k points')
-    for r in list(csv.DictReader(open(glob.glob(out+'/odom/*kernel_stats.csv')[0])))[:14]:
+    for r in list(csv.DictReader(open(glob.glob(out+'/odom/'+tag+'_*kernel_stats.csv')[0])))[:14]:
         print(r['Name'][:70].ljust(70), r['Calls'].rjust(6), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(9),'us', r['Percentage'])
     print(open(out+'/'+tag+'_odom_stdout.log').read().strip()[-1200:])
 PY

@@ -1,7 +1,7 @@
 """scratch: does one match launch over k scans' worth of points cost less per scan than k launches? (tail filling)"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mola_lidar_odometry_amd import capi, synth
 w = synth.workload_c2()

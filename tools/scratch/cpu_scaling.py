@@ -1,6 +1,6 @@
 """Development probe: OpenMP scaling of the CPU oracle on the box it runs on."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from mola_lidar_odometry_amd import synth
 from oracle import oracle_c as oc

@@ -1,6 +1,6 @@
 #!/bin/bash
 # development probe (edited per experiment; run on the GPU box through gpurun): the GPU suite and one bench line
-REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
+REPO=$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)
 cd $REPO
 mkdir -p gpurun_out
 timeout 1800 python -m pytest tests -x -q -m gpu --timeout 300 > gpurun_out/pytest_probe.log 2>&1

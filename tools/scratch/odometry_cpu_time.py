@@ -1,6 +1,6 @@
 """scratch: wall time of the CPU oracle driver on the synthetic drive the GPU driver is profiled on."""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mola_lidar_odometry_amd import synth
 from oracle import odometry_oracle as oo

@@ -1,6 +1,6 @@
 """scratch: match-kernel time of the row (16 lanes/point) and quad (4 lanes/point) kernels vs layer size."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from mola_lidar_odometry_amd import capi, synth
