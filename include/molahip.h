@@ -110,6 +110,20 @@ MH_API mh_status mh_ctx_stream(mh_ctx* ctx, void** hip_stream_out);
  * maps and scans; also how the tests check that destroyed handles give their memory back). */
 MH_API mh_status mh_ctx_memory_info(mh_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 
+/* Cooperative waiting (no reference counterpart; the reference runs one sequence per PROCESS, eval/cli_kitti.sh:23-36).
+ * With a hook installed on the CALLING THREAD, every point where the library would block that thread on the device --
+ * the poll of an alignment's device loop, the size read-backs of the filters, mh_scan_bbox, mh_ctx_synchronize, ... --
+ * becomes "mark the stream with an event, then call hook(user) until the event has completed".  The hook typically
+ * switches to another fiber of the same thread, which may call into the library on OTHER contexts (a context is still
+ * used by one flow of control at a time): several sequences then share ONE host thread, so their HIP calls never contend
+ * for the runtime's locks, and every wait of one sequence is filled with the others' host work.  NULL removes the hook. */
+typedef void (*mh_wait_hook_fn)(void* user);
+MH_API mh_status mh_set_wait_hook(mh_wait_hook_fn hook, void* user);
+/* Page-locked host memory for MH_MEM_HOST_PINNED uploads (hipHostMalloc / hipHostFree behind the C ABI, for host code
+ * that does not link the HIP runtime itself). */
+MH_API mh_status mh_host_alloc_pinned(size_t bytes, void** out);
+MH_API mh_status mh_host_free_pinned(void* p);
+
 /* ------------------------------------------------------------------------------------------------
  * Local map: the NN-search target.  Replaces mola::HashedVoxelPointCloud [U] as configured at
  * lidar3d-default.yaml:228-242 (creationOpts.voxel_size :233, insertOpts.max_points_per_voxel :235)

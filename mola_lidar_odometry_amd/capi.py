@@ -150,6 +150,9 @@ _SIGNATURES = {
     "mh_scan_set_timestamps": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
     "mh_scan_preprocess": (C.c_int32, [C.c_void_p, C.POINTER(PreprocessParams), C.c_void_p, C.c_void_p]),
     "mh_scan_deskew": (C.c_int32, [C.c_void_p, _DP, C.c_void_p]),
+    "mh_set_wait_hook": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "mh_host_alloc_pinned": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mh_host_free_pinned": (C.c_int32, [C.c_void_p]),
     "mh_scan_download": (C.c_int32, [C.c_void_p, _FP, _FP, _FP, _FP, _UP]),
     "mh_scan_bbox": (C.c_int32, [C.c_void_p, _FP, _FP, C.POINTER(C.c_uint64)]),
     "mh_nn_search": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_double, C.c_double, C.POINTER(PairsOut), C.c_int32,

@@ -25,6 +25,45 @@ mh_status fail(mh_status s, const char* fmt, ...) {
   return s;
 }
 
+static thread_local mh_wait_hook_fn g_wait_hook = nullptr;
+static thread_local void* g_wait_user = nullptr;
+static thread_local hipEvent_t g_wait_ev[16] = {nullptr};  // one marker event per device, per thread
+
+hipError_t wait_event(hipEvent_t e) {
+  if (!g_wait_hook) return hipEventSynchronize(e);
+  for (;;) {
+    const hipError_t q = hipEventQuery(e);
+    if (q != hipErrorNotReady) return q;
+    g_wait_hook(g_wait_user);  // (may run other fibers of this thread, which may call into the library on THEIR contexts)
+  }
+}
+
+hipError_t wait_stream(hipStream_t s) {
+  if (!g_wait_hook) return hipStreamSynchronize(s);
+  if (hipStreamQuery(s) == hipSuccess) return hipSuccess;
+  (void)hipGetLastError();
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 16) return hipStreamSynchronize(s);
+  // the marker is per wait: another fiber of this thread may record the per-device event while this one is suspended,
+  // so each wait gets an event of its own from a small free list
+  static thread_local hipEvent_t pool[16][32];
+  static thread_local int pool_n[16] = {0};
+  hipEvent_t ev;
+  if (pool_n[dev] > 0) ev = pool[dev][--pool_n[dev]];
+  else {
+    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  e = hipEventRecord(ev, s);
+  if (e == hipSuccess) e = wait_event(ev);
+  if (pool_n[dev] < 32) pool[dev][pool_n[dev]++] = ev;
+  else (void)hipEventDestroy(ev);
+  (void)g_wait_ev;
+  return e;
+}
+
 mh_status set_device(const mh_ctx* ctx) {
   MH_HIP(hipSetDevice(ctx->device));
   return MH_OK;
@@ -42,7 +81,7 @@ mh_status scan_alloc(mh_scan* s, size_t n, bool with_t, bool with_src) {
   mh_ctx* ctx = s->ctx;
   const size_t stride = ((n * sizeof(float) + 255) / 256) * 256;
   if (s->xyz.bytes < 3 * stride || (s->aux.bytes < 2 * stride && (with_t || with_src))) {
-    MH_HIP(hipStreamSynchronize(ctx->stream));  // nobody may still read the old buffers
+    MH_HIP(mh::wait_stream(ctx->stream));  // nobody may still read the old buffers
     MH_TRY(s->xyz.reserve(3 * stride ? 3 * stride : 256));
     if (with_t || with_src) MH_TRY(s->aux.reserve(2 * stride ? 2 * stride : 256));
   }
@@ -62,6 +101,25 @@ mh_status scan_alloc(mh_scan* s, size_t n, bool with_t, bool with_src) {
 using namespace mh;
 
 extern "C" {
+
+mh_status mh_set_wait_hook(mh_wait_hook_fn hook, void* user) {
+  mh::g_wait_hook = hook;
+  mh::g_wait_user = user;
+  return MH_OK;
+}
+
+mh_status mh_host_alloc_pinned(size_t bytes, void** out) {
+  MH_REQUIRE(out, "null argument");
+  *out = nullptr;
+  MH_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return MH_OK;
+}
+
+mh_status mh_host_free_pinned(void* p) {
+  if (p) MH_HIP(hipHostFree(p));
+  return MH_OK;
+}
+
 
 mh_status mh_version(uint32_t* major, uint32_t* minor, uint32_t* patch) {
   if (major) *major = MH_VERSION_MAJOR;
@@ -137,9 +195,9 @@ mh_status mh_ctx_create(int32_t device, void* hip_stream, mh_ctx** out) {
 mh_status mh_ctx_destroy(mh_ctx* ctx) {
   if (!ctx) return MH_OK;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream) (void)mh::wait_stream(ctx->stream);
   if (ctx->copy_stream) {
-    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)mh::wait_stream(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->copy_stream);
   }
   if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
@@ -183,9 +241,9 @@ mh_status mh_ctx_destroy(mh_ctx* ctx) {
 mh_status mh_ctx_synchronize(mh_ctx* ctx) {
   MH_REQUIRE(ctx, "null context");
   MH_TRY(set_device(ctx));
-  MH_HIP(hipStreamSynchronize(ctx->stream));
+  MH_HIP(mh::wait_stream(ctx->stream));
   if (ctx->copy_stream) {  // a batch led by this context may still be downloading its final pairings
-    MH_HIP(hipStreamSynchronize(ctx->copy_stream));
+    MH_HIP(mh::wait_stream(ctx->copy_stream));
     ctx->pairs_copy_pending = false;
   }
   return MH_OK;
@@ -194,7 +252,7 @@ mh_status mh_ctx_synchronize(mh_ctx* ctx) {
 mh_status mh_ctx_memory_info(mh_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes) {
   MH_REQUIRE(ctx && free_bytes && total_bytes, "null argument");
   MH_TRY(set_device(ctx));
-  MH_HIP(hipStreamSynchronize(ctx->stream));
+  MH_HIP(mh::wait_stream(ctx->stream));
   size_t f = 0, t = 0;
   MH_HIP(hipMemGetInfo(&f, &t));
   *free_bytes = f;
@@ -218,7 +276,7 @@ static mh_status scan_set(mh_scan* s, const float* x, const float* y, const floa
   // own SoA copy so that the caller's arrays are only borrowed for the call (SURVEY 8b ownership)
   const size_t stride = ((n * sizeof(float) + 255) / 256) * 256;
   if (s->xyz.bytes < 3 * stride) {
-    MH_HIP(hipStreamSynchronize(ctx->stream));  // nobody may still read the old buffer
+    MH_HIP(mh::wait_stream(ctx->stream));  // nobody may still read the old buffer
     MH_TRY(s->xyz.reserve(3 * stride ? 3 * stride : 256));
   }
   char* base = s->xyz.as<char>();
@@ -227,7 +285,7 @@ static mh_status scan_set(mh_scan* s, const float* x, const float* y, const floa
     MH_HIP(hipMemcpyAsync(base, x, n * sizeof(float), kind, ctx->stream));
     MH_HIP(hipMemcpyAsync(base + stride, y, n * sizeof(float), kind, ctx->stream));
     MH_HIP(hipMemcpyAsync(base + 2 * stride, z, n * sizeof(float), kind, ctx->stream));
-    if (mem == MH_MEM_HOST) MH_HIP(hipStreamSynchronize(ctx->stream));  // host arrays are borrowed only for the call
+    if (mem == MH_MEM_HOST) MH_HIP(mh::wait_stream(ctx->stream));  // host arrays are borrowed only for the call
     // (MH_MEM_HOST_PINNED: the caller keeps them valid until the stream has passed the copies; no wait here)
   }
   s->x = (const float*)base;
@@ -267,7 +325,7 @@ mh_status mh_scan_update(mh_scan* scan, const float* x, const float* y, const fl
 mh_status mh_scan_destroy(mh_scan* scan) {
   if (!scan) return MH_OK;
   (void)hipSetDevice(scan->ctx->device);
-  (void)hipStreamSynchronize(scan->ctx->stream);
+  (void)mh::wait_stream(scan->ctx->stream);
   scan->xyz.release();
   scan->aux.release();
   scan_free_tiles(scan);

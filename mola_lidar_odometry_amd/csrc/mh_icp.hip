@@ -2186,7 +2186,7 @@ mh_status compact_pairs(mh_ctx* ctx, size_t n, const mh_pairs_out* out, int32_t 
                        (uint32_t)n, offsets, o_li, o_gi, o_x, o_y, o_z, o_d2);
     MH_HIP(hipGetLastError());
     MH_HIP(hipMemcpyAsync(&h_total, total, 4, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(mh::wait_stream(s));
   }
   if (mem == MH_MEM_HOST && h_total) {
     const size_t b = (size_t)h_total * 4;
@@ -2597,7 +2597,7 @@ struct AlignJob {
     if (finished) return MH_OK;
     polls++;
     MH_TRY(set_device(ctx));
-    if (!already_synced) MH_HIP(hipEventSynchronize(ctx->ev_poll));
+    if (!already_synced) MH_HIP(mh::wait_event(ctx->ev_poll));
     const IcpDeviceState* h = ctx->h_state;
     if (!h->done && enqueued < p->max_iterations) {
       if (auto_chunk) {
@@ -2765,7 +2765,7 @@ mh_status plan_pairs(mh_ctx* lead, const std::vector<AlignJob>& jobs, void* pair
   const size_t hdr_bytes = (hdr * 4 + 255) / 256 * 256;
   const size_t need = hdr_bytes + (pairs_mem == MH_MEM_DEVICE ? 0 : bytes);
   if (lead->pairs_stage.bytes < need && lead->pairs_copy_pending) {  // the previous download still reads the old buffer
-    MH_HIP(hipStreamSynchronize(lead->copy_stream));
+    MH_HIP(mh::wait_stream(lead->copy_stream));
     lead->pairs_copy_pending = false;
   }
   MH_TRY(lead->pairs_stage.reserve(need));
@@ -2800,7 +2800,7 @@ mh_status finish_pairs(mh_ctx* lead, hipStream_t s, const PairsPlan& pp, const B
   MH_HIP(hipGetLastError());
   if (pp.mem == MH_MEM_HOST) {
     MH_HIP(hipMemcpyAsync(pp.host_block, pp.dev_block, pp.total_bytes, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(mh::wait_stream(s));
   } else if (pp.mem == MH_MEM_HOST_PINNED) {
     // on the copy stream: the call returns, the next batch's kernels run while this block travels
     MH_HIP(hipEventRecord(lead->ev_pairs_ready, s));
@@ -3063,7 +3063,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       for (size_t gi = 0; gi < groups.size(); gi++) {
         Group& g = groups[gi];
         if (g.done) continue;
-        MH_HIP(hipStreamSynchronize(g.lead->stream));
+        MH_HIP(mh::wait_stream(g.lead->stream));
         g.enq += m_of[gi];
         g.done = true;
         if (g.auto_chunk && g.kind != K_PERSIST) g.chunk = 8;  // follow-up chunks
@@ -3137,7 +3137,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
     }
     MH_HIP(hipMemcpyAsync(lead->batch_desc.p, h_desc, A * sizeof(BatchJob), hipMemcpyHostToDevice, lead->stream));
     MH_TRY(finish_pairs(lead, lead->stream, pp, lead->batch_desc.as<BatchJob>(), A, gx_cov));
-    if (pp.mem != MH_MEM_HOST) MH_HIP(hipStreamSynchronize(lead->stream));  // h_batch is reused by the next batch
+    if (pp.mem != MH_MEM_HOST) MH_HIP(mh::wait_stream(lead->stream));  // h_batch is reused by the next batch
   }
   return MH_OK;
 }
@@ -3150,7 +3150,7 @@ mh_status launch_tile_search(const mh_map* map, const mh_scan* scan, const doubl
   const bool wave = tile_points_for_env() == 64u;
   MH_TRY(scan_build_tiles(scan, map->inv_vs, wave ? 64u : 256u));
   MH_TRY(scan_tiles_ready(scan));
-  MH_HIP(hipStreamSynchronize(ctx->stream));  // the pinned state mirror may still be travelling
+  MH_HIP(mh::wait_stream(ctx->stream));  // the pinned state mirror may still be travelling
   init_state(ctx->h_state, T);
   ctx->h_state->cur_thr2 = thr2;
   ctx->h_state->cur_ang2 = ang2;
@@ -3252,7 +3252,7 @@ mh_status mh_nn_search_dense(const mh_map* map, const mh_scan* scan, const doubl
   hipLaunchKernelGGL(k_unpack_dense, dim3(nblk(n)), dim3(kBlock), 0, s, ctx->pair_gidx.as<uint32_t>(),
                      ctx->pair_q.as<float4>(), (uint32_t)n, o_gi, o_x, o_y, o_z, o_d2);
   MH_HIP(hipGetLastError());
-  MH_HIP(hipStreamSynchronize(s));
+  MH_HIP(mh::wait_stream(s));
   if (mem == MH_MEM_HOST) {
     if (global_idx) MH_HIP(hipMemcpy(global_idx, o_gi, n * 4, hipMemcpyDeviceToHost));
     if (gx) MH_HIP(hipMemcpy(gx, o_x, n * 4, hipMemcpyDeviceToHost));
@@ -3289,7 +3289,7 @@ static mh_status compact_pl_pairs(mh_ctx* ctx, size_t n, const mh_pairs_pl_out* 
                        (float*)d[5], (float*)d[6]);
     MH_HIP(hipGetLastError());
     MH_HIP(hipMemcpyAsync(&h_total, total, 4, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(mh::wait_stream(s));
   }
   if (mem == MH_MEM_HOST && h_total)
     for (int a = 0; a < 7; a++)
@@ -3373,7 +3373,7 @@ mh_status mh_gn_solve(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt2p
   MH_TRY(set_device(ctx));
   MH_TRY(ensure_state(ctx));
   hipStream_t s = ctx->stream;
-  MH_HIP(hipStreamSynchronize(s));
+  MH_HIP(mh::wait_stream(s));
   // stage pairings: build_a = pt2pt (l xyz | g xyz), build_b = pt2pl (l | c | n)
   size_t sp = 0, sl = 0;
   if (np) {
@@ -3427,7 +3427,7 @@ mh_status mh_gn_solve(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt2p
   }
   MH_HIP(hipGetLastError());
   MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
-  MH_HIP(hipStreamSynchronize(s));
+  MH_HIP(mh::wait_stream(s));
   const IcpDeviceState* h = ctx->h_state;
   for (int i = 0; i < 12; i++) T_io[i] = h->T[i];
   if (n_steps) *n_steps = (int32_t)h->n_solves;
@@ -3448,7 +3448,7 @@ mh_status mh_covariance(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt
   MH_TRY(set_device(ctx));
   MH_TRY(ensure_state(ctx));
   hipStream_t s = ctx->stream;
-  MH_HIP(hipStreamSynchronize(s));
+  MH_HIP(mh::wait_stream(s));
   size_t sp = 0, sl = 0;
   if (np) {
     const float* arrs[3] = {pp->lx, pp->ly, pp->lz};
@@ -3484,7 +3484,7 @@ mh_status mh_covariance(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt
                      ctx->partials_b.as<double>(), nbl, nbl);
   MH_HIP(hipGetLastError());
   MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
-  MH_HIP(hipStreamSynchronize(s));
+  MH_HIP(mh::wait_stream(s));
   for (int i = 0; i < 36; i++) cov[i] = ctx->h_state->cov[i];
   return MH_OK;
 }

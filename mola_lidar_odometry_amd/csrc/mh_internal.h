@@ -219,6 +219,11 @@ struct mh_scan {
 };
 
 namespace mh {
+// Blocking waits of the library.  With a wait hook installed on the calling thread (mh_set_wait_hook) they turn into
+// "record an event, then call the hook until the event has completed": a host layer that multiplexes several sequences
+// on ONE thread (cooperative fibers) gets control back at every point where the library would otherwise block.
+hipError_t wait_stream(hipStream_t s);
+hipError_t wait_event(hipEvent_t e);
 mh_status set_device(const mh_ctx* ctx);
 // copy `n` elements of a caller array living in `mem` into device scratch (returns device ptr)
 mh_status stage_in(mh_ctx* ctx, DevBuf& buf, size_t offset_bytes, const void* src, size_t bytes, int32_t mem);

@@ -358,9 +358,9 @@ mh_status mh_map_create(mh_ctx* ctx, const mh_map_params* params, mh_map** out) 
 mh_status mh_map_destroy(mh_map* m) {
   if (!m) return MH_OK;
   (void)hipSetDevice(m->ctx->device);
-  (void)hipStreamSynchronize(m->ctx->stream);
+  (void)mh::wait_stream(m->ctx->stream);
   if (m->side) {
-    (void)hipStreamSynchronize(m->side);
+    (void)mh::wait_stream(m->side);
     (void)hipStreamDestroy(m->side);
   }
   if (m->ev_counts) (void)hipEventDestroy(m->ev_counts);
@@ -386,8 +386,8 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
   mh_ctx* ctx = m->ctx;
   MH_TRY(set_device(ctx));
   hipStream_t s = ctx->stream;
-  MH_HIP(hipStreamSynchronize(s));  // a rebuild invalidates everything queued against the old content
-  if (m->side) MH_HIP(hipStreamSynchronize(m->side));
+  MH_HIP(mh::wait_stream(s));  // a rebuild invalidates everything queued against the old content
+  if (m->side) MH_HIP(mh::wait_stream(m->side));
   (void)map_resolve(m);  // (a pending verdict about the OLD content is moot now)
   const float *dx = x, *dy = y, *dz = z;
   if (n > 0 && mem == MH_MEM_HOST) {
@@ -488,7 +488,7 @@ __global__ void k_sizes(const uint32_t* __restrict__ vid1, const uint32_t* __res
 
 mh_status map_resolve(const mh_map* m) {
   if (m->counts_pending) {
-    MH_HIP(hipEventSynchronize(m->ev_counts));
+    MH_HIP(mh::wait_event(m->ev_counts));
     m->counts_pending = false;
     m->build_in_flight = false;
     const uint32_t* h = m->h_counts;
@@ -666,7 +666,7 @@ mh_status mh_map_download(const mh_map* m, float* x, float* y, float* z, uint32_
   MH_REQUIRE(m, "null map");
   mh_ctx* ctx = m->ctx;
   MH_TRY(set_device(ctx));
-  MH_HIP(hipStreamSynchronize(ctx->stream));
+  MH_HIP(mh::wait_stream(ctx->stream));
   MH_TRY(map_resolve(m));  // (waits for an update still running on the side stream)
   if (!m->n_voxels) return MH_OK;
   std::vector<uint32_t> hf(m->n_voxels), hc(m->n_voxels);
@@ -710,7 +710,7 @@ mh_status mh_map_download_ndt(const mh_map* m, float* cx, float* cy, float* cz, 
   MH_REQUIRE(m, "null map");
   mh_ctx* ctx = m->ctx;
   MH_TRY(set_device(ctx));
-  MH_HIP(hipStreamSynchronize(ctx->stream));
+  MH_HIP(mh::wait_stream(ctx->stream));
   MH_TRY(map_resolve(m));
   if (!m->n_voxels) return MH_OK;
   const bool ndt = m->params.ndt_max_eigen_ratio > 0.f;

@@ -311,7 +311,7 @@ mh_status run_stage(mh_ctx* ctx, const mh_scan* in, const StageParams& sp, uint3
   MH_HIP(rocprim::exclusive_scan(ctx->sort_tmp.p, tb, flag, pos, 0u, N, rocprim::plus<uint32_t>(), s));
   uint32_t h[3] = {0, 0, 0};  // range flag, stage-1 count, stage-2 count: one read-back per stage
   MH_HIP(hipMemcpyAsync(h, counters + 2, sizeof(h), hipMemcpyDeviceToHost, s));
-  MH_HIP(hipStreamSynchronize(s));
+  MH_HIP(mh::wait_stream(s));
   if (h[0] & 1u)
     return fail(MH_ERR_OUT_OF_RANGE, "a point's decimation voxel index exceeds the +-2^20 range of the packed key");
   const uint32_t M = h[count_slot - 2];
@@ -337,13 +337,13 @@ mh_status mh_scan_set_timestamps(mh_scan* scan, const float* t, size_t n, int32_
   MH_TRY(set_device(ctx));
   const size_t stride = ((n * sizeof(float) + 255) / 256) * 256;
   if (scan->aux.bytes < 2 * stride) {
-    MH_HIP(hipStreamSynchronize(ctx->stream));
+    MH_HIP(mh::wait_stream(ctx->stream));
     MH_TRY(scan->aux.reserve(2 * stride ? 2 * stride : 256));
   }
   if (n) {
     MH_HIP(hipMemcpyAsync(scan->aux.p, t, n * sizeof(float),
                           mem == MH_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
-    if (mem == MH_MEM_HOST) MH_HIP(hipStreamSynchronize(ctx->stream));  // host array is borrowed for the call only
+    if (mem == MH_MEM_HOST) MH_HIP(mh::wait_stream(ctx->stream));  // host array is borrowed for the call only
   }
   scan->t = (const float*)scan->aux.p;
   return MH_OK;
@@ -365,7 +365,7 @@ mh_status mh_scan_update_aos(mh_scan* scan, const void* data, size_t n, size_t p
   const size_t stride = ((n * sizeof(float) + 255) / 256) * 256;
   const size_t raw_bytes = n * point_step;
   if (scan->xyz.bytes < 3 * stride || (off_t >= 0 && scan->aux.bytes < 2 * stride) || ctx->build_a.bytes < raw_bytes) {
-    MH_HIP(hipStreamSynchronize(s));  // nobody may still read the old buffers
+    MH_HIP(mh::wait_stream(s));  // nobody may still read the old buffers
     MH_TRY(scan->xyz.reserve(3 * stride ? 3 * stride : 256));
     if (off_t >= 0) MH_TRY(scan->aux.reserve(2 * stride ? 2 * stride : 256));
     MH_TRY(ctx->build_a.reserve(raw_bytes ? raw_bytes : 256));
@@ -388,7 +388,7 @@ mh_status mh_scan_update_aos(mh_scan* scan, const void* data, size_t n, size_t p
                      (uint32_t)(off_x / 4), (uint32_t)(off_y / 4), (uint32_t)(off_z / 4), off_t >= 0 ? (int32_t)(off_t / 4) : -1,
                      (float*)scan->x, (float*)scan->y, (float*)scan->z, (float*)scan->t);
   MH_HIP(hipGetLastError());
-  if (mem != MH_MEM_HOST_PINNED) MH_HIP(hipStreamSynchronize(s));  // `data` is borrowed for the call only
+  if (mem != MH_MEM_HOST_PINNED) MH_HIP(mh::wait_stream(s));  // `data` is borrowed for the call only
   return MH_OK;
 }
 
@@ -486,7 +486,7 @@ mh_status mh_scan_bbox(const mh_scan* scan, float bb_min[3], float bb_max[3], ui
     if (!ctx->h_small) MH_HIP(hipHostMalloc((void**)&ctx->h_small, 64 * sizeof(uint32_t), hipHostMallocDefault));
     hipLaunchKernelGGL(k_pp_bbox_one, dim3(1), dim3(1024), 0, s, scan->x, scan->y, scan->z, (uint32_t)scan->n, ctx->h_small);
     MH_HIP(hipGetLastError());
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(mh::wait_stream(s));
     for (int a = 0; a < 7; a++) h[a] = ctx->h_small[a];
   } else if (scan->n) {
     MH_TRY(ctx->build_e.reserve(64));
@@ -496,7 +496,7 @@ mh_status mh_scan_bbox(const mh_scan* scan, float bb_min[3], float bb_max[3], ui
                        scan->y, scan->z, (uint32_t)scan->n, counters);
     MH_HIP(hipGetLastError());
     MH_HIP(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(mh::wait_stream(s));
   }
   for (int a = 0; a < 3; a++) {
     bb_min[a] = h[6] ? [](uint32_t u) { u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &u, 4); return f; }(h[a]) : 0.f;
@@ -525,7 +525,7 @@ mh_status mh_scan_download(const mh_scan* scan, float* x, float* y, float* z, fl
       else memset(src_idx, 0, n * sizeof(uint32_t));
     }
   }
-  MH_HIP(hipStreamSynchronize(s));
+  MH_HIP(mh::wait_stream(s));
   return MH_OK;
 }
 

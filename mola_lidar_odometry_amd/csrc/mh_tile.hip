@@ -100,7 +100,7 @@ mh_status scan_build_tiles(const mh_scan* s, float inv_vs, uint32_t tile_points)
   const size_t stride = ((n * sizeof(float) + 255) / 256) * 256;
   const size_t need = 4 * stride + ((n + 2) * sizeof(uint32_t) + 255) / 256 * 256;
   if (s->tiles.bytes < need) {
-    MH_HIP(hipStreamSynchronize(st));  // nobody may still read the old buffer
+    MH_HIP(mh::wait_stream(st));  // nobody may still read the old buffer
     MH_TRY(s->tiles.reserve(need));
   }
   char* base = s->tiles.as<char>();
@@ -148,7 +148,7 @@ mh_status scan_tiles_ready(const mh_scan* s) {
   if (!s->tiles_valid) return fail(MH_ERR_INTERNAL, "scan_tiles_ready without scan_build_tiles");
   if (s->tiles_pending) {
     MH_TRY(set_device(s->ctx));
-    MH_HIP(hipEventSynchronize(s->ev_tiles));
+    MH_HIP(mh::wait_event(s->ev_tiles));
     s->n_tiles = *s->h_ntiles;
     s->tiles_pending = false;
   }

@@ -174,7 +174,10 @@ class LidarOdometry {
   std::map<std::string, std::string> describePipeline() const;
   // accumulated host wall time [s] per stage of onLidar (the role of the reference's profiler_ sections "onLidar.*")
   const std::map<std::string, double>& profile() const { return profile_; }
-  void resetProfile() { profile_.clear(); }  // e.g. after the warm-up scans of a replay: steady-state stage times
+  void resetProfile() { profile_.clear(); }
+  // The interleaved buffers handed to onLidarInterleaved / prefetchInterleaved are page-locked (mh_host_alloc_pinned) and
+  // stay valid and unmodified until the scan AFTER the one they hold has been registered: uploads are then asynchronous.
+  void setInputPinned(bool pinned) { input_pinned_ = pinned; }  // e.g. after the warm-up scans of a replay: steady-state stage times
 
  private:
   struct FilterPlan;  // the recognised observation filter chain, as data for mh_scan_preprocess / mh_scan_deskew
@@ -230,6 +233,7 @@ class LidarOdometry {
   mutable size_t map_counts_from_ = 0;
   mutable uint64_t map_points_cached_ = 0, map_voxels_cached_ = 0;
   bool map_known_nonempty_ = false;
+  bool input_pinned_ = false;
   std::map<std::string, double> profile_;
 };
 

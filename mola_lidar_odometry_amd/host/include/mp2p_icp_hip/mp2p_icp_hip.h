@@ -199,8 +199,10 @@ class DevicePointCloud : public Layer {
   mh_scan* handle() const { return scan_; }
   void setPoints(const float* x, const float* y, const float* z, size_t n);
   // interleaved records (KITTI .bin, PointCloud2 payload): float32 x/y/z [and time stamp when off_t >= 0] at byte offsets
+  // pinned: `data` is page-locked memory (mh_host_alloc_pinned) that stays valid and unmodified until the context's
+  // stream has passed the copy -- the upload is then asynchronous (MH_MEM_HOST_PINNED, include/molahip.h)
   void setPointsInterleaved(const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
-                            long long off_t = -1);
+                            long long off_t = -1, bool pinned = false);
   void setTimestamps(const float* t, size_t n);
   void boundingBox(float mn[3], float mx[3]) const;
   void download(std::vector<float>& x, std::vector<float>& y, std::vector<float>& z) const;

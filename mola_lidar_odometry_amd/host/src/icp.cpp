@@ -11,6 +11,7 @@
 #include <mutex>
 
 #include "mp2p_icp_hip/mp2p_icp_hip.h"
+#include "molahip_host/fibers.h"
 #include "molahip_host/hook_replay.h"
 #include "molahip_host/plugin_switches.h"
 
@@ -232,8 +233,9 @@ void DevicePointCloud::setPoints(const float* x, const float* y, const float* z,
   check(mh_scan_update(scan_, x, y, z, n, MH_MEM_HOST), "mh_scan_update");
 }
 void DevicePointCloud::setPointsInterleaved(const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y,
-                                            size_t off_z, long long off_t) {
-  check(mh_scan_update_aos(scan_, data, n, point_step, off_x, off_y, off_z, (int64_t)off_t, MH_MEM_HOST), "mh_scan_update_aos");
+                                            size_t off_z, long long off_t, bool pinned) {
+  check(mh_scan_update_aos(scan_, data, n, point_step, off_x, off_y, off_z, (int64_t)off_t, pinned ? MH_MEM_HOST_PINNED : MH_MEM_HOST),
+        "mh_scan_update_aos");
 }
 void DevicePointCloud::setTimestamps(const float* t, size_t n) {
   check(mh_scan_set_timestamps(scan_, t, n, MH_MEM_HOST), "mh_scan_set_timestamps");
@@ -629,6 +631,12 @@ mh_status AlignBatcher::align(const mh_map* map, const mh_scan* scan, const mh_i
     in_flight_ += batch.size();
     lk.unlock();
     run_batch(batch);
+    lk.lock();
+  } else if (molahip_host::FiberScheduler::in_fiber()) {
+    // the participants are fibers of ONE thread (molahip_host/fibers.h): blocking on the condition variable would stop
+    // all of them -- let the others run until the fiber that completes the batch has run it
+    lk.unlock();
+    while (!rq.done) molahip_host::FiberScheduler::yield();
     lk.lock();
   } else {
     cv_.wait(lk, [&] { return rq.done; });

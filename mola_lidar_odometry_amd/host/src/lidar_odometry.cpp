@@ -1,6 +1,7 @@
 // lidar_odometry.cpp -- see mola_lidar_odometry_hip/LidarOdometry.h.  Control logic only: the arithmetic on points
 // is behind include/molahip.h.  Citations are module/src/LidarOdometry.cpp unless another file is named.
 #include "mola_lidar_odometry_hip/LidarOdometry.h"
+#include "molahip_host/fibers.h"
 #include "molahip_host/plugin_switches.h"
 
 #include <chrono>
@@ -333,7 +334,19 @@ struct LidarOdometry::Prefetch {
   bool requested = false, launched = false;
   int slot = 0;               // which of the two prefetch sets the worker fills / filled
   mh_preprocess_params pp{};  // the filter parameters the worker used
+  // the worker: a thread (std::async) -- or, when this driver itself runs as a fiber of a FiberScheduler, another fiber
+  // of the same thread (no second thread in the HIP runtime; the worker's waits for the filter counts yield)
   std::future<void> done;
+  molahip_host::FiberScheduler::Handle done_fiber;
+  void join() {
+    if (done_fiber.valid()) {
+      molahip_host::FiberScheduler::Handle h = done_fiber;
+      done_fiber = molahip_host::FiberScheduler::Handle();
+      h.wait();
+    } else if (done.valid()) {
+      done.get();
+    }
+  }
 };
 
 LidarOdometry::LidarOdometry(std::shared_ptr<DeviceContext> ctx) : ctx_(std::move(ctx)), pf_(new Prefetch) {}
@@ -509,8 +522,8 @@ void LidarOdometry::prefetchInterleaved(const void* data, size_t n, size_t point
 }
 
 void LidarOdometry::cancel_prefetch() {
-  if (pf_->launched && pf_->done.valid()) {
-    try { pf_->done.get(); } catch (...) {}
+  if (pf_->launched) {
+    try { pf_->join(); } catch (...) {}
   }
   pf_->launched = pf_->requested = false;
 }
@@ -518,7 +531,7 @@ void LidarOdometry::cancel_prefetch() {
 void LidarOdometry::launch_prefetch() {
   if (!pf_->requested || !plan_ || !estimated_sensor_max_range_) return;
   if (pf_->launched) {  // prepared but never picked up: drop it
-    try { pf_->done.get(); } catch (...) {}
+    try { pf_->join(); } catch (...) {}
     pf_->launched = false;
   }
   pf_->in = pf_->req;
@@ -544,13 +557,16 @@ void LidarOdometry::launch_prefetch() {
   const mh_preprocess_params pp = pf_->pp;
   auto raw = raw_b_[pf_->slot], ms = map_skewed_b_[pf_->slot], is = icp_skewed_b_[pf_->slot];
   auto ctx = ctx_b_;
-  pf_->done = std::async(std::launch::async, [in, pp, raw, ms, is, ctx]() {
-    if (in.data) raw->setPointsInterleaved(in.data, in.n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t);
+  const bool pinned = input_pinned_;
+  auto work = [in, pp, raw, ms, is, ctx, pinned]() {
+    if (in.data) raw->setPointsInterleaved(in.data, in.n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t, pinned);
     else raw->setPoints(in.x, in.y, in.z, in.n);
     if (in.t) raw->setTimestamps(in.t, in.n);
     check(mh_scan_preprocess(raw->handle(), &pp, ms->handle(), is->handle()), "mh_scan_preprocess (prefetch)");
     ctx->synchronize();
-  });
+  };
+  if (molahip_host::FiberScheduler::in_fiber()) pf_->done_fiber = molahip_host::FiberScheduler::current()->spawn(work);
+  else pf_->done = std::async(std::launch::async, work);
   pf_->launched = true;
   pf_->requested = false;
 }
@@ -645,14 +661,14 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
   if (pf_->launched) {
     StageTimer tt(profile_, "onLidar.0.prefetch_wait");
     bool ok = true;
-    try { pf_->done.get(); } catch (...) { ok = false; }  // (a failed prefetch is simply redone below, and reports there)
+    try { pf_->join(); } catch (...) { ok = false; }  // (a failed prefetch is simply redone below, and reports there)
     pf_->launched = false;
     if (ok && pf_->in.same(in)) prepared = true;
   }
   if (pf_->requested && pf_->req.same(in)) pf_->requested = false;  // due before it could be launched
   if (!prepared) {
     StageTimer tt(profile_, "onLidar.0.upload_raw");
-    if (in.data) raw_->setPointsInterleaved(in.data, n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t);
+    if (in.data) raw_->setPointsInterleaved(in.data, n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t, input_pinned_);
     else raw_->setPoints(in.x, in.y, in.z, n);
     if (in.t) raw_->setTimestamps(in.t, n);
   }
@@ -682,7 +698,7 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
       prepared = false;
       profile_["prefetch_misses"] += 1.0;
       StageTimer tt(profile_, "onLidar.0.upload_raw");
-      if (in.data) raw_->setPointsInterleaved(in.data, n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t);
+      if (in.data) raw_->setPointsInterleaved(in.data, n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t, input_pinned_);
       else raw_->setPoints(in.x, in.y, in.z, n);
       if (in.t) raw_->setTimestamps(in.t, n);
     }

@@ -27,7 +27,15 @@
 
 #include <dirent.h>
 
+#include <sys/stat.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+
 #include "mola_lidar_odometry_hip/LidarOdometry.h"
+#include "molahip.h"
+#include "molahip_host/fibers.h"
 
 namespace {
 
@@ -84,6 +92,117 @@ struct SequenceReport {
   std::map<std::string, double> profile;  // LidarOdometry::profile(): host seconds per stage, whole run
 };
 
+// files + stamps of a KITTI or MulRan sequence folder
+void list_sequence(const std::string& seq_dir, long max_scans, std::vector<std::string>& files, std::vector<double>& stamps) {
+  const std::string ouster = dir_exists(seq_dir + "/sensor_data/Ouster") ? seq_dir + "/sensor_data/Ouster"
+                             : (dir_exists(seq_dir + "/Ouster") ? seq_dir + "/Ouster" : std::string());
+  if (!dir_exists(seq_dir + "/velodyne") && !ouster.empty()) {
+    // MulRan: one <time stamp in nanoseconds>.bin per sweep (numeric order = lexical order for equal-length names)
+    files = list_bins(ouster);
+    std::sort(files.begin(), files.end(), [](const std::string& a, const std::string& b) { return stamp_of_name(a) < stamp_of_name(b); });
+    const double t0 = files.empty() ? 0.0 : stamp_of_name(files[0]);
+    for (const auto& f : files) stamps.push_back(stamp_of_name(f) - t0);  // relative seconds (TUM output keeps sub-ms digits)
+  } else {
+    files = list_bins(seq_dir + "/velodyne");
+    std::ifstream ts(seq_dir + "/times.txt");
+    double t;
+    while (ts >> t) stamps.push_back(t);
+  }
+  if (max_scans >= 0 && (size_t)max_scans < files.size()) files.resize((size_t)max_scans);
+  while (stamps.size() < files.size()) stamps.push_back(0.1 * (double)stamps.size());  // 10 Hz when times.txt is absent
+}
+
+// --fibers: every sequence is a fiber of the ONE thread that talks to the HIP runtime (molahip_host/fibers.h).  Its scans
+// are read ahead by a plain reader thread (no HIP calls) into a ring of page-locked buffers, so that the uploads are
+// asynchronous copies; a buffer is handed back once the scan AFTER its own has been registered.
+struct SequenceFeed {
+  static constexpr size_t kDepth = 4;
+  std::vector<std::string> files;
+  void* buf[kDepth] = {nullptr, nullptr, nullptr, nullptr};
+  size_t n_floats[kDepth] = {0, 0, 0, 0};
+  size_t cap_bytes = 0;
+  std::atomic<size_t> read_upto{0}, consumed{0};
+  std::atomic<bool> failed{false}, stop{false};
+  std::string error;
+  std::thread th;
+  void start() {
+    for (const auto& f : files) {
+      struct stat st;
+      if (stat(f.c_str(), &st) == 0 && (size_t)st.st_size > cap_bytes) cap_bytes = (size_t)st.st_size;
+    }
+    for (size_t i = 0; i < kDepth; i++)
+      if (mh_host_alloc_pinned(cap_bytes ? cap_bytes : 16, &buf[i]) != MH_OK) throw std::runtime_error(std::string("pinned buffer: ") + mh_last_error_string());
+    th = std::thread([this] {
+      for (size_t k = 0; k < files.size(); k++) {
+        while (!stop && k >= consumed.load(std::memory_order_acquire) + kDepth) std::this_thread::yield();
+        if (stop) return;
+        FILE* f = fopen(files[k].c_str(), "rb");
+        size_t got = 0;
+        if (f) {
+          got = fread(buf[k % kDepth], 1, cap_bytes, f);
+          fclose(f);
+        }
+        if (!f || got % 16 != 0) {
+          error = files[k] + ": not a sequence of float32 x,y,z,intensity rows";
+          failed = true;
+          read_upto.store(files.size(), std::memory_order_release);
+          return;
+        }
+        n_floats[k % kDepth] = got / 4;
+        read_upto.store(k + 1, std::memory_order_release);
+      }
+    });
+  }
+  ~SequenceFeed() {
+    stop = true;
+    if (th.joinable()) th.join();
+    for (void* b : buf) (void)mh_host_free_pinned(b);
+  }
+};
+
+void run_sequence_fiber(const std::string& pipeline, const std::string& seq_dir, const std::string& out, int device, long max_scans,
+                        std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher, SequenceReport& rep) {
+  rep.seq_dir = seq_dir;
+  rep.out = out;
+  try {
+    SequenceFeed feed;
+    std::vector<double> stamps;
+    list_sequence(seq_dir, max_scans, feed.files, stamps);
+    feed.start();
+    mola_hip::LidarOdometry lo(std::make_shared<mp2p_icp_hip::DeviceContext>(device));
+    lo.initialize(mp2p_icp_hip::Config::FromYamlFile(pipeline));
+    lo.setInputPinned(true);
+    if (batcher) lo.setAlignBatcher(batcher);
+    const size_t n = feed.files.size();
+    for (size_t k = 0; k < n; k++) {
+      const size_t need = std::min(k + 2, n);  // this scan and the next one (announced to the prefetch)
+      while (feed.read_upto.load(std::memory_order_acquire) < need) molahip_host::FiberScheduler::yield();
+      if (feed.failed) throw std::runtime_error(feed.error);
+      const bool has_next = k + 1 < n;
+      const auto t0 = std::chrono::steady_clock::now();
+      if (has_next) lo.prefetchInterleaved(feed.buf[(k + 1) % SequenceFeed::kDepth], feed.n_floats[(k + 1) % SequenceFeed::kDepth] / 4, 16, 0, 4, 8);
+      const auto& rec = lo.onLidarInterleaved(stamps[k], feed.buf[k % SequenceFeed::kDepth], feed.n_floats[k % SequenceFeed::kDepth] / 4, 16, 0, 4, 8);
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      rep.seconds += dt;
+      if (k >= kWarmScans) {
+        rep.steady_seconds += dt;
+        rep.steady_scans++;
+      }
+      if (k + 1 == kWarmScans) lo.resetProfile();
+      rep.good += rec.icp_good ? 1 : 0;
+      rep.keyframes += rec.map_updated ? 1 : 0;
+      rep.iterations += rec.icp_iterations;
+      rep.scans++;
+      feed.consumed.store(k, std::memory_order_release);  // buffers of scans < k may be refilled (k + 1 is in flight)
+    }
+    lo.saveTrajectoryTUM(out);
+    rep.profile = lo.profile();
+  } catch (const std::exception& e) {
+    rep.error = e.what();
+  }
+  if (batcher) batcher->leave();
+}
+
 // one sequence, start to end; with a batcher its alignments join those of the other sequences of the process
 void run_sequence(const std::string& pipeline, const std::string& seq_dir, const std::string& out, int device, long max_scans,
                   bool prefetch, std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher, SequenceReport& rep) {
@@ -92,22 +211,7 @@ void run_sequence(const std::string& pipeline, const std::string& seq_dir, const
   try {
     std::vector<std::string> files;
     std::vector<double> stamps;
-    const std::string ouster = dir_exists(seq_dir + "/sensor_data/Ouster") ? seq_dir + "/sensor_data/Ouster"
-                               : (dir_exists(seq_dir + "/Ouster") ? seq_dir + "/Ouster" : std::string());
-    if (!dir_exists(seq_dir + "/velodyne") && !ouster.empty()) {
-      // MulRan: one <time stamp in nanoseconds>.bin per sweep (numeric order = lexical order for equal-length names)
-      files = list_bins(ouster);
-      std::sort(files.begin(), files.end(), [](const std::string& a, const std::string& b) { return stamp_of_name(a) < stamp_of_name(b); });
-      const double t0 = files.empty() ? 0.0 : stamp_of_name(files[0]);
-      for (const auto& f : files) stamps.push_back(stamp_of_name(f) - t0);  // relative seconds (TUM output keeps sub-ms digits)
-    } else {
-      files = list_bins(seq_dir + "/velodyne");
-      std::ifstream ts(seq_dir + "/times.txt");
-      double t;
-      while (ts >> t) stamps.push_back(t);
-    }
-    if (max_scans >= 0 && (size_t)max_scans < files.size()) files.resize((size_t)max_scans);
-    while (stamps.size() < files.size()) stamps.push_back(0.1 * (double)stamps.size());  // 10 Hz when times.txt is absent
+    list_sequence(seq_dir, max_scans, files, stamps);
 
     mola_hip::LidarOdometry lo(std::make_shared<mp2p_icp_hip::DeviceContext>(device));
     lo.initialize(mp2p_icp_hip::Config::FromYamlFile(pipeline));
@@ -152,9 +256,9 @@ int main(int argc, char** argv) {
   std::vector<std::string> seq_dirs;
   int device = 0;
   long max_scans = -1;
-  bool prefetch = true, print_profile = false;
+  bool prefetch = true, print_profile = false, fibers = false;
   const char* usage = "usage: molahip-lo-cli --pipeline FILE.yaml --seq-dir DIR [--seq-dir DIR ...] --out FILE.tum [--device N] "
-                      "[--no-prefetch] [--max-scans N] [--profile]\n"
+                      "[--no-prefetch] [--max-scans N] [--profile] [--fibers]\n"
                       "  several --seq-dir: the sequences run together on the one GPU, one host thread each, their alignments\n"
                       "  merged into lock-step batches; trajectories go to FILE_<k>.tum\n";
   for (int i = 1; i < argc; i++) {
@@ -171,6 +275,7 @@ int main(int argc, char** argv) {
       else if (a == "--max-scans") max_scans = atol(val("--max-scans").c_str());
       else if (a == "--no-prefetch") prefetch = false;
       else if (a == "--profile") print_profile = true;
+      else if (a == "--fibers") fibers = true;
       else throw std::runtime_error("unknown argument " + a);
     } catch (const std::exception& e) {
       fprintf(stderr, "%s\n%s", e.what(), usage);
@@ -184,7 +289,17 @@ int main(int argc, char** argv) {
   const size_t N = seq_dirs.size();
   std::vector<SequenceReport> reps(N);
   const auto t0 = std::chrono::steady_clock::now();
-  if (N == 1) {
+  if (fibers) {
+    // ONE thread in the HIP runtime: the sequences (and their prefetch workers) are fibers of this thread
+    molahip_host::FiberScheduler sched;
+    auto batcher = N > 1 ? std::make_shared<mp2p_icp_hip::AlignBatcher>(N) : nullptr;
+    const std::string stem = out.size() > 4 && out.compare(out.size() - 4, 4, ".tum") == 0 ? out.substr(0, out.size() - 4) : out;
+    for (size_t k = 0; k < N; k++) {
+      const std::string o = N == 1 ? out : stem + "_" + std::to_string(k) + ".tum";
+      sched.spawn([&, k, o] { run_sequence_fiber(pipeline, seq_dirs[k], o, device, max_scans, batcher, reps[k]); });
+    }
+    sched.run();
+  } else if (N == 1) {
     run_sequence(pipeline, seq_dirs[0], out, device, max_scans, prefetch, nullptr, reps[0]);
   } else {
     auto batcher = std::make_shared<mp2p_icp_hip::AlignBatcher>(N);
