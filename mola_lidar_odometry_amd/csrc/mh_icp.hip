@@ -897,7 +897,9 @@ struct SolveShared {
 // XCDs' L2s on every launch -- the map falls out of cache and C2 drops from 2285 to 960 scans/s.  Kernel boundaries
 // are the cheap way to order producers and consumers on this part.)
 // LDS_STATE: the state block lives in LDS (k_icp_persist keeps it there for the whole alignment) instead of global memory.
-template <bool LDS_STATE = false>
+// WAVE0: only the first wave of the workgroup calls (the totals are ready in LDS, nothing here needs the other waves): the
+// one workgroup barrier below becomes a wave-level hand-over.
+template <bool LDS_STATE = false, bool WAVE0 = false>
 __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, const SolveK* __restrict__ kp_,
                                            const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                            const double* __restrict__ partB, uint32_t nB, uint32_t strideB,
@@ -942,7 +944,8 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, con
 #pragma unroll
       for (int i = 0; i < 6; i++) sh_log[lane][i] = lg[i];
     }
-    __syncthreads();
+    if (WAVE0) wave_sync_lds();
+    else __syncthreads();
   }
   if (lane != 0) return;
   MH_PHASE(4);
@@ -1275,6 +1278,125 @@ __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1_b(const BatchJob
 // Covariance (mp2p_icp::covariance [U]): A = d residuals / d (x,y,z,yaw,pitch,roll), cov = (A^T A)^-1
 // ================================================================================================
 // ================================================================================================
+// k_accum_solveN: ALL inner Gauss-Newton steps of an ICP iteration in one launch (round 3).  An iteration of a small layer
+// was k_match16 | k_accum_solve1 | k_accum_solve1: ~21 us of kernels and three ~3 us gaps between dependent launches.  Round
+// 1 had tried this fusion and dropped it (19.6 us against 2 x 9.3: the fused body spilled); what had gone wrong there is
+// what k_icp_persist ran into as well -- inlined inside a loop, solve_body's fp64 constants and scalar parameters are
+// hoisted into the preheader and stay live -- and has the same cure: the serial solve is CALLED (persist_solve, noinline),
+// and the state block lives in LDS for the launch (solve_body<LDS_STATE>), so the second step neither waits for a launch
+// nor re-reads the state, only the points and pairings (cache hits).  One launch less per extra inner step.
+// MEASURED SLOWER AGAIN, so it is opt-in (MH_FUSED_INNER=1) and parity-tested, not the default: through the odometry driver
+// ICP per scan 0.90 ms against 0.815 with two launches (0.97 while all eight waves made the call: see persist_solve).  The
+// second step's loads cannot be issued before the first step's solve has published the pose, the state takes an extra
+// round trip into LDS before anything starts, and what is saved -- one boundary between two dependent launches inside a
+// captured graph -- is worth ~1 us, not the 3 us the per-iteration arithmetic suggested.
+// ================================================================================================
+struct OneGroupNShared {
+  SolveShared sh;
+  double tr[kAccN][kOneGroupAccThreads + 1];
+  double p1[kAccN][kOneGroupGroups];
+  IcpDeviceState st;
+};
+static_assert(sizeof(OneGroupNShared) <= 64 * 1024, "LDS per workgroup");
+
+__device__ __attribute__((noinline)) void persist_solve(IcpDeviceState* st, const SolveK* skp, SolveShared& sh, bool plB);
+
+template <bool PL>
+__device__ __forceinline__ void k_accum_solveN_body(IcpDeviceState* __restrict__ gst, const MatchK* __restrict__ kp,
+                                                    const SolveK* __restrict__ sk, const float* __restrict__ lx,
+                                                    const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                    const float4* __restrict__ pair_q, const uint32_t* __restrict__ pair_gidx,
+                                                    const float4* __restrict__ pl_c, const float4* __restrict__ pl_n) {
+  __shared__ OneGroupNShared S;
+  const uint32_t tid = threadIdx.x;
+  const bool acc_lane = tid < kOneGroupAccThreads;
+  const auto g_q = G(reinterpret_cast<const f32x4*>(pair_q)), g_pc = G(reinterpret_cast<const f32x4*>(pl_c)),
+             g_pn = G(reinterpret_cast<const f32x4*>(pl_n));
+  const auto g_gi = G(pair_gidx);
+  const auto g_x = G(lx), g_y = G(ly), g_z = G(lz);
+  {  // the state block -> LDS for the whole launch
+    const uint32_t MH_AS_GLOBAL* src = G(reinterpret_cast<const uint32_t*>(gst));
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&S.st);
+    for (uint32_t i = tid; i < sizeof(IcpDeviceState) / 4; i += kSolveThreads) dst[i] = src[i];
+  }
+  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
+  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
+  struct { uint32_t kernel; double w_pt2pt, w_pt2pl; } k = {ck->kernel, ck->w_pt2pt, ck->w_pt2pl};
+  __syncthreads();
+  if (S.st.done) return;  // (uniform; nothing was changed: no write-back)
+  for (;;) {
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = S.st.T[i];
+    const double kparam = S.st.cur_kparam;
+    Acc a;
+    acc_zero(a);
+    double v[PL ? kGenN : 1];
+#pragma unroll
+    for (int j = 0; j < (PL ? kGenN : 1); j++) v[j] = 0.0;
+    if (acc_lane) {
+#pragma unroll 1
+      for (uint32_t base = 0; base < n; base += kOneGroupAccThreads * kOneGroupBatch) {
+        uint32_t gi[kOneGroupBatch];
+        f32x4 q[kOneGroupBatch], pc[kOneGroupBatch], pn[kOneGroupBatch];
+        float px[kOneGroupBatch], py[kOneGroupBatch], pz[kOneGroupBatch];
+#pragma unroll
+        for (int u = 0; u < kOneGroupBatch; u++) {
+          const uint32_t i = base + (uint32_t)u * kOneGroupAccThreads + tid;
+          const uint32_t ic = i < n ? i : n - 1;
+          gi[u] = i < n ? g_gi[ic] : kNoMatch;
+          q[u] = g_q[ic];
+          px[u] = g_x[ic]; py[u] = g_y[ic]; pz[u] = g_z[ic];
+          if (PL) {
+            pc[u] = g_pc[ic];
+            pn[u] = g_pn[ic];
+            if (i >= n) pc[u].w = 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kOneGroupBatch; u++) {
+          acc_pt2pt_masked(a, T, gi[u] != kNoMatch, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
+          if (PL && pc[u].w != 0.f) {
+            double r[kGenN];
+            acc_pt2pl_rows(r, T, px[u], py[u], pz[u], make_float4(pc[u].x, pc[u].y, pc[u].z, pc[u].w),
+                           make_float4(pn[u].x, pn[u].y, pn[u].z, pn[u].w), k.kernel, kparam, k.w_pt2pl);
+#pragma unroll
+            for (int j = 0; j < kGenN; j++) v[PL ? j : 0] += r[j];
+          }
+        }
+      }
+    }
+    one_group_sum<kAccN>(a.v, acc_lane, S.tr, S.p1, S.sh.totA);
+    if (PL) {
+      one_group_sum<kAccN>(v, acc_lane, S.tr, S.p1, S.sh.totB);
+      one_group_sum<kGenN - kAccN>(v + (PL ? kAccN : 0), acc_lane, S.tr, S.p1, S.sh.totB + kAccN);
+    }
+    if (tid < 64) persist_solve(&S.st, sk, S.sh, PL);  // (the sums above ended with a workgroup barrier)
+    __syncthreads();
+    if (S.st.done || S.st.inner == 0) break;  // the solver closed this ICP iteration (or the loop)
+  }
+  {  // the state block back to global memory
+    uint32_t MH_AS_GLOBAL* dst = G(reinterpret_cast<uint32_t*>(gst));
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.st);
+    for (uint32_t i = tid; i < sizeof(IcpDeviceState) / 4; i += kSolveThreads) dst[i] = src[i];
+  }
+}
+template <bool PL>
+__global__ __launch_bounds__(kSolveThreads) void k_accum_solveN(IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
+                                                                const SolveK* __restrict__ sk, const float* __restrict__ lx,
+                                                                const float* __restrict__ ly, const float* __restrict__ lz,
+                                                                uint32_t n, const float4* __restrict__ pair_q,
+                                                                const uint32_t* __restrict__ pair_gidx,
+                                                                const float4* __restrict__ pl_c, const float4* __restrict__ pl_n) {
+  k_accum_solveN_body<PL>(st, kp, sk, lx, ly, lz, n, pair_q, pair_gidx, pl_c, pl_n);
+}
+template <bool PL>
+__global__ __launch_bounds__(kSolveThreads) void k_accum_solveN_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  k_accum_solveN_body<PL>(j.st, j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.pair_q, j.pair_gidx, j.pl_c, j.pl_n);
+}
+
+// ================================================================================================
 // k_icp_persist: the WHOLE alignment of a small layer in ONE workgroup and ONE launch.
 //
 // OPT-IN (MH_PERSIST=1) AND SLOWER THAN THE DEFAULT CHAIN -- kept, parity-tested, as the measured answer to "would one launch
@@ -1351,8 +1473,11 @@ __device__ __forceinline__ void persist_sum(const double* v, PersistShared& S, d
 
 // A real call, not an inlined copy: inside the iteration loops the serial 6x6 code's constants and scalar parameters
 // get hoisted into the loop preheader and stay live (107 spilled VGPRs); as a function of its own it allocates like k_solve.
-__device__ __attribute__((noinline)) void persist_solve(IcpDeviceState* st, const SolveK* skp, SolveShared& sh) {
-  solve_body<true>(st, skp, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true, false);
+// Called by the FIRST WAVE only: a call saves and restores ~130 callee-saved VGPRs through scratch, and eight waves doing
+// that around a function in which seven of them return at once cost 4.5 us per call (measured: the fused inner steps were
+// 6 us per iteration SLOWER than two launches until the other waves stopped calling).
+__device__ __attribute__((noinline)) void persist_solve(IcpDeviceState* st, const SolveK* skp, SolveShared& sh, bool plB) {
+  solve_body<true, true>(st, skp, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true, plB);
 }
 
 __device__ __forceinline__ void k_icp_persist_body(IcpDeviceState* __restrict__ gst, const MatchK* __restrict__ mkp,
@@ -1426,7 +1551,7 @@ __device__ __forceinline__ void k_icp_persist_body(IcpDeviceState* __restrict__ 
         MH_PHASE(13);
         persist_sum(a.v, S, S.sh.totA);
         MH_PHASE(14);
-        persist_solve(&S.st, skp, S.sh);
+        if (tid < 64) persist_solve(&S.st, skp, S.sh, false);
         __syncthreads();
         MH_PHASE(15);
         if (S.st.done || S.st.inner == 0) break;  // the solver closed this ICP iteration (or the loop)
@@ -2404,6 +2529,7 @@ struct AlignJob {
     // everything a chunk launches, in stream order; used directly (profiling / MH_NO_GRAPH) or under stream capture
     const bool no_one_group = getenv("MH_NO_ONE_GROUP") != nullptr;  // (read per chunk: tests toggle it)
     const bool one_group = variant == 5 && n <= kOneGroupMaxPoints && !no_one_group;  // accumulate + solve in one workgroup
+    const bool fused_inner = one_group && getenv("MH_FUSED_INNER") != nullptr;  // ... and all inner steps in one launch (opt-in: slower)
     auto enqueue_kernels = [&]() -> mh_status {
       double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
       const bool rows16 = pl && variant == 5;                  // NDT layer handled by the row kernel
@@ -2434,6 +2560,17 @@ struct AlignJob {
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
           if (one_group) {
             if (prof) prof_n++;
+            if (fused_inner) {  // all inner Gauss-Newton steps in one launch
+              if (pl)
+                hipLaunchKernelGGL(k_accum_solveN<true>, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dmk, dsk, scan->x,
+                                   scan->y, scan->z, n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+                                   ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>());
+              else
+                hipLaunchKernelGGL(k_accum_solveN<false>, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dmk, dsk, scan->x,
+                                   scan->y, scan->z, n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+                                   (const float4*)nullptr, (const float4*)nullptr);
+              continue;
+            }
             for (uint32_t in = 0; in < p->gn.max_inner_iterations; in++) {
               if (pl)
                 hipLaunchKernelGGL(k_accum_solve1<true>, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, in == 0 ? 1u : 0u, dmk,
@@ -2539,7 +2676,7 @@ struct AlignJob {
                                        (unsigned long long)ctx->pair_gidx.p, (unsigned long long)part,
                                        (unsigned long long)ctx->d_state, (unsigned long long)ctx->d_params,
                                        (unsigned long long)ctx->h_state,
-                                       (pl ? 2ull : 1ull) | (one_group ? 4ull : 0ull) | (fused16 ? 8ull : 0ull),
+                                       (pl ? 2ull : 1ull) | (one_group ? 4ull : 0ull) | (fused16 ? 8ull : 0ull) | (fused_inner ? 16ull : 0ull),
                                        (unsigned long long)(pl ? ctx->pl_c.p : nullptr) ^
                                            ((unsigned long long)(pl ? ctx->pl_n.p : nullptr) << 1),
                                        (unsigned long long)(pl ? ctx->partials_b.p : nullptr) ^
@@ -2847,6 +2984,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
   enum Kind { K_NONE = 0, K_QUAD, K_TILE, K_WAVE, K_ORD, K_ROWF, K_ONE, K_ONE_PL, K_PERSIST };
   const bool no_lockstep = getenv("MH_NO_LOCKSTEP") != nullptr;
   const bool no_one_group_env = getenv("MH_NO_ONE_GROUP") != nullptr;
+  const bool fused_inner_env = getenv("MH_FUSED_INNER") != nullptr;
   auto kind_of = [&](const AlignJob& j) -> int {
     if (j.finished || no_lockstep || j.trace || j.prof) return K_NONE;
     const bool one_group = j.variant == 5 && j.scan->n <= kOneGroupMaxPoints && !no_one_group_env;
@@ -3030,6 +3168,11 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
             g.prof_n++;
           }
           if (g.kind == K_ONE || g.kind == K_ONE_PL) {
+            if (fused_inner_env) {
+              if (g.kind == K_ONE_PL) hipLaunchKernelGGL(k_accum_solveN_b<true>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj);
+              else hipLaunchKernelGGL(k_accum_solveN_b<false>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj);
+              continue;
+            }
             for (uint32_t in = 0; in < g.inner; in++) {
               if (g.kind == K_ONE_PL)
                 hipLaunchKernelGGL(k_accum_solve1_b<true>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, in == 0 ? 1u : 0u);

@@ -779,6 +779,45 @@ def test_one_workgroup_kernel_in_batches(ctx, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("inner", [1, 2, 3])
+def test_fused_inner_steps_kernel(ctx, inner, monkeypatch):
+    """k_accum_solveN (opt-in, MH_FUSED_INNER=1: all inner Gauss-Newton steps of an iteration in one launch; measured
+    slower than a launch per step, kept as a tested alternative): plain and NDT layers, single and in a batch, against the
+    default chain -- same iterations, termination and pairings, poses within 1e-12; batch bitwise the singles."""
+    pts = _ndt_cloud(31)
+    rng = np.random.default_rng(32)
+    w = synth.make_workload("t", 60000, 32, 400, 80.0, 25, variant=5)
+    jobs = []  # (device map, scan, guess, params)
+    thr, kp = synth.threshold_schedule(1.0, 40)
+    g_plain = capi.Map(ctx, 1.0, 20).build(w.map_xyz)
+    jobs.append((g_plain, w.scan_xyz[rng.permutation(len(w.scan_xyz))[:900]], w.T_guess,
+                 capi.ICPParams(max_iterations=40, threshold=thr * 2, kernel_param=kp * 2, gn=capi.GNParams(max_inner_iterations=inner))))
+    g_ndt = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts)
+    guess = np.array([1, 0, 0, 0.1, 0, 1, 0, -0.07, 0, 0, 1, 0.05], np.float64)
+    for n in (1500, 700):
+        jobs.append((g_ndt, pts[rng.permutation(len(pts))[:n]], guess,
+                     capi.ICPParams(max_iterations=40, min_abs_step_trans=5e-4, min_abs_step_rot=5e-4, threshold=thr, kernel_param=kp,
+                                    pt2pl_threshold=0.5, gn=capi.GNParams(max_inner_iterations=inner))))
+    ref = [capi.icp_align(m, capi.Scan(ctx, sc), g, p, want_trace=False, want_pairs=True) for m, sc, g, p in jobs]
+    monkeypatch.setenv("MH_FUSED_INNER", "1")
+    got = [capi.icp_align(m, capi.Scan(ctx, sc), g, p, want_trace=False, want_pairs=True) for m, sc, g, p in jobs]
+    for a, b in zip(got, ref):
+        assert (a["n_iterations"], a["termination_reason"], a["n_final_pairs"], a["n_final_pairs_pt2pl"]) == (
+            b["n_iterations"], b["termination_reason"], b["n_final_pairs"], b["n_final_pairs_pt2pl"])
+        np.testing.assert_allclose(a["T"], b["T"], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(a["pairs"]["global_idx"], b["pairs"]["global_idx"])
+    assert got[1]["n_final_pairs_pt2pl"] > 0
+    # two NDT jobs in one batch (the lock-step form of the fused kernel) + the plain pair
+    ctxs = [capi.Context(0) for _ in range(4)]
+    order = [1, 2, 0, 0]
+    scans = [capi.Scan(c, jobs[k][1]) for c, k in zip(ctxs, order)]
+    res = capi.icp_align_batch([jobs[k][0] for k in order], scans, [jobs[k][2] for k in order], [jobs[k][3] for k in order])
+    for r, k in zip(res, order):
+        assert np.array_equal(r["T"], got[k]["T"]) and r["n_iterations"] == got[k]["n_iterations"] and np.array_equal(r["cov"], got[k]["cov"])
+    for c in ctxs:
+        c.close()
+
+
 def test_align_is_bitwise_reproducible(ctx, small):
     w, gm, om, gs = small
     p = _params(capi, w, disable_stall_test=True)
@@ -860,7 +899,7 @@ def test_previous_pairing_bound_and_its_fallback(ctx, oracle, vs, shift, monkeyp
         np.testing.assert_allclose(g["T"], o["T"], rtol=0, atol=1e-9)
 
 
-@pytest.mark.parametrize("n_scan,env", [(900, {}), (3000, {}), (3000, {"MH_NO_FUSE16": "1"}), (3000, {"MH_MATCH": "p"}),
+@pytest.mark.parametrize("n_scan,env", [(900, {}), (900, {"MH_FUSED_INNER": "1"}), (3000, {}), (3000, {"MH_NO_FUSE16": "1"}), (3000, {"MH_MATCH": "p"}),
                                         (9000, {}), (20000, {})])
 def test_converged_alignment_with_early_inner_exit(ctx, oracle, n_scan, env, monkeypatch):
     """Stall test off and far more iterations than the alignment needs: once the Gauss-Newton step falls below min_delta
