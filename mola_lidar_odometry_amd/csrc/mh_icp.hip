@@ -2666,7 +2666,7 @@ struct AlignJob {
     } else {
       // The launch sequence only depends on sizes and device pointers (the per-alignment values sit in device
       // memory), so it is captured once and replayed: one host call per chunk instead of ~4 per iteration.
-      unsigned long long key[24] = {0};
+      unsigned long long key[28] = {0};
       uint32_t fb;
       memcpy(&fb, &mv.inv_vs, 4);
       const unsigned long long kv[] = {n, nb, nbm, (unsigned long long)variant, m, p->gn.max_inner_iterations,
@@ -2677,10 +2677,11 @@ struct AlignJob {
                                        (unsigned long long)ctx->d_state, (unsigned long long)ctx->d_params,
                                        (unsigned long long)ctx->h_state,
                                        (pl ? 2ull : 1ull) | (one_group ? 4ull : 0ull) | (fused16 ? 8ull : 0ull) | (fused_inner ? 16ull : 0ull),
-                                       (unsigned long long)(pl ? ctx->pl_c.p : nullptr) ^
-                                           ((unsigned long long)(pl ? ctx->pl_n.p : nullptr) << 1),
-                                       (unsigned long long)(pl ? ctx->partials_b.p : nullptr) ^
-                                           (variant >= 6 ? ((unsigned long long)scan->sx ^ ((unsigned long long)scan->n_tiles << 48)) : 0ull)};
+                                       (unsigned long long)(pl ? ctx->pl_c.p : nullptr),
+                                       (unsigned long long)(pl ? ctx->pl_n.p : nullptr),
+                                       (unsigned long long)(pl ? ctx->partials_b.p : nullptr),
+                                       variant >= 6 ? (unsigned long long)scan->sx : 0ull,
+                                       variant >= 6 ? (unsigned long long)scan->n_tiles : 0ull};  // (a word each: no XOR folding)
       static_assert(sizeof(kv) <= sizeof(key), "graph key too small");
       memcpy(key, kv, sizeof(kv));
       const bool cached = ctx->graph_exec && memcmp(key, ctx->graph_key, sizeof(key)) == 0;

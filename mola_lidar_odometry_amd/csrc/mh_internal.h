@@ -134,8 +134,8 @@ struct mh_ctx {
   IcpDeviceParams* d_params = nullptr;  // per-alignment parameters (kernels take pointers into this block)
   IcpDeviceParams* h_params = nullptr;  // pinned mirror
   hipGraphExec_t graph_exec = nullptr;  // captured chunk of ICP iterations (replayed while graph_key matches)
-  unsigned long long graph_key[24] = {0};
-  unsigned long long graph_candidate[24] = {0};  // key of the last direct-launched chunk: captured when a LATER alignment repeats it
+  unsigned long long graph_key[28] = {0};
+  unsigned long long graph_candidate[28] = {0};  // key of the last direct-launched chunk: captured when a LATER alignment repeats it
   unsigned long long graph_candidate_align = 0, align_serial = 0;
   uint32_t* h_small = nullptr;  // pinned, device-visible [64]: small results a kernel writes straight to the host (mh_scan_bbox)
   hipEvent_t ev_poll = nullptr;

@@ -78,7 +78,8 @@ __global__ void k_heads(const unsigned long long* __restrict__ ks, uint32_t n, u
   const unsigned long long k = ks[i];
   const bool valid = k != kEmptyKey;
   head[i] = (valid && (i == 0 || ks[i - 1] != k)) ? 1u : 0u;
-  if (valid && (i + 1 == n || ks[i + 1] == kEmptyKey)) counters[1] = i + 1;
+  // (the merge path leaves runs of evicted keys INSIDE the sequence: several valid-to-empty boundaries -> the maximum)
+  if (valid && (i + 1 == n || ks[i + 1] == kEmptyKey)) atomicMax(&counters[1], i + 1);
 }
 
 __global__ void k_vstart(const uint32_t* __restrict__ head, const uint32_t* __restrict__ vid1, uint32_t n,

@@ -108,12 +108,13 @@ mh_status scan_build_tiles(const mh_scan* s, float inv_vs, uint32_t tile_points)
   uint32_t* perm = (uint32_t*)(base + 3 * stride);
   uint32_t* tile_start = (uint32_t*)(base + 4 * stride);
   s->sx = sx; s->sy = sy; s->sz = sz; s->perm = perm; s->tile_start = tile_start;
+  s->tiles_valid = false;  // (set again only after the last enqueue below has succeeded: a failed build must not look valid)
   s->tile_inv_vs = inv_vs;
   s->tile_points = tile_points;
-  s->tiles_valid = true;
   if (n == 0) {
     s->n_tiles = 0;
     s->tiles_pending = false;
+    s->tiles_valid = true;
     return MH_OK;
   }
   // scratch: keys | sorted keys | indices | flags | count, in the context's build buffers
@@ -141,6 +142,7 @@ mh_status scan_build_tiles(const mh_scan* s, float inv_vs, uint32_t tile_points)
   MH_HIP(hipGetLastError());
   MH_HIP(hipEventRecord(s->ev_tiles, st));
   s->tiles_pending = true;
+  s->tiles_valid = true;
   return MH_OK;
 }
 
