@@ -103,6 +103,12 @@ MH_API mh_status mh_device_count(int32_t* n);
 /* `hip_stream`: a hipStream_t to run on (e.g. the caller's torch stream), or NULL to let the context
  * create and own a non-blocking stream. */
 MH_API mh_status mh_ctx_create(int32_t device, void* hip_stream, mh_ctx** out);
+/* The same with a stream of the given priority class (the runtime keeps streams of different classes on different
+ * hardware queues): a caller that prepares the NEXT scan on a second context while the current one is being aligned
+ * (upload, filters: long copies and wide kernels) gives that context MH_PRIORITY_LOW so that its work neither sits in
+ * front of the alignment's short dependent kernels in a shared queue nor competes with them for dispatch. */
+enum { MH_PRIORITY_LOW = -1, MH_PRIORITY_NORMAL = 0, MH_PRIORITY_HIGH = 1 };
+MH_API mh_status mh_ctx_create_with_priority(int32_t device, int32_t priority, mh_ctx** out);
 MH_API mh_status mh_ctx_destroy(mh_ctx* ctx);
 MH_API mh_status mh_ctx_synchronize(mh_ctx* ctx);
 MH_API mh_status mh_ctx_stream(mh_ctx* ctx, void** hip_stream_out);
@@ -235,6 +241,14 @@ MH_API mh_status mh_scan_set_timestamps(mh_scan* scan, const float* t, size_t n,
  * time stamps (when `raw` has them) and each point's index in `raw`; they are the *_skewed layers. */
 MH_API mh_status mh_scan_preprocess(const mh_scan* raw, const mh_preprocess_params* params, mh_scan* out_map,
                                     mh_scan* out_icp);
+/* The same chain for the scans of several sequences at once: every step is ONE launch over all of them, issued on the
+ * stream of the first scan's context (work still queued on the other scans' streams is waited for), and one read-back
+ * brings all counts -- N sequences in one process cost the host one sequence's launches (the callers' threads contend
+ * for the runtime otherwise).  `params` is an array with `params_stride` bytes between entries (0: one set for all);
+ * `out_icps` may be NULL, or hold NULL entries.  Outputs are those of n_jobs separate mh_scan_preprocess calls, bit for
+ * bit.  Each job's three scans belong to one context; the contexts may differ from job to job (same device). */
+MH_API mh_status mh_scan_preprocess_batch(size_t n_jobs, const mh_scan* const* raws, const mh_preprocess_params* params,
+                                          size_t params_stride, mh_scan* const* out_maps, mh_scan* const* out_icps);
 /* FilterDeskew (yaml:328-350): p' = Exp_SO3(w*t_i)*p + v*t_i with twist = (vx,vy,vz,wx,wy,wz) in the vehicle frame,
  * fp64, rounded to float [U].  twist == NULL or a scan without time stamps copies the points (skip_deskew /
  * silently_ignore_no_timestamps).  `out` must differ from `in`; it is what align() and mh_map_insert() consume, and

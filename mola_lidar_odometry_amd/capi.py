@@ -128,6 +128,7 @@ _SIGNATURES = {
     "mh_status_string": (C.c_char_p, [C.c_int32]),
     "mh_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
     "mh_ctx_create": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mh_ctx_create_with_priority": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "mh_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "mh_ctx_synchronize": (C.c_int32, [C.c_void_p]),
     "mh_ctx_stream": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -149,6 +150,8 @@ _SIGNATURES = {
     "mh_map_insert": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_float]),
     "mh_scan_set_timestamps": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
     "mh_scan_preprocess": (C.c_int32, [C.c_void_p, C.POINTER(PreprocessParams), C.c_void_p, C.c_void_p]),
+    "mh_scan_preprocess_batch": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(PreprocessParams), C.c_size_t,
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mh_scan_deskew": (C.c_int32, [C.c_void_p, _DP, C.c_void_p]),
     "mh_set_wait_hook": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "mh_host_alloc_pinned": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -232,12 +235,19 @@ def _T12(T):
     return np.ascontiguousarray(T.reshape(12))
 
 
+PRIORITY_LOW, PRIORITY_NORMAL, PRIORITY_HIGH = -1, 0, 1  # enum MH_PRIORITY_*
+
+
 class Context:
     """One HIP device + one stream (mh_ctx)."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream: int | None = None, priority: int = 0):
+        """priority: PRIORITY_LOW / PRIORITY_NORMAL / PRIORITY_HIGH -- the class of the stream the context creates"""
         self._h = C.c_void_p()
-        _chk(lib().mh_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        if priority != PRIORITY_NORMAL and not stream:
+            _chk(lib().mh_ctx_create_with_priority(device, priority, C.byref(self._h)))
+        else:
+            _chk(lib().mh_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.device = device
         self._children = weakref.WeakSet()  # maps/scans must be destroyed before their context (C-ABI rule)
 
@@ -722,6 +732,17 @@ def icp_align_batch(maps, scans, T_guesses, p: ICPParams, priors=None, pairs_blo
     call = BatchCall(maps, scans, T_guesses, p, priors, pairs_block, pairs_mem)
     call.run()
     return call.results()
+
+
+def preprocess_batch(raws, params, out_maps, out_icps=None):
+    """mh_scan_preprocess_batch: the filter chain of several scans in one set of launches.  `params`: one PreprocessParams
+    for all, or a list with one per scan; `out_icps`: None, or a list whose entries may be None."""
+    n = len(raws)
+    per_job = isinstance(params, (list, tuple))
+    arr = (PreprocessParams * (n if per_job else 1))(*(params if per_job else [params]))
+    hs = lambda scans: (C.c_void_p * n)(*[(sc._h if sc is not None else None) for sc in scans])
+    _chk(lib().mh_scan_preprocess_batch(n, hs(raws), arr, C.sizeof(PreprocessParams) if per_job else 0, hs(out_maps),
+                                        hs(out_icps) if out_icps is not None else None))
 
 
 def preprocess_params(decim_map_resolution, decim_icp_resolution, min_points_to_filter=2000, index_mode=INDEX_FLOOR,

@@ -156,7 +156,16 @@ mh_status mh_device_count(int32_t* n) {
   return MH_OK;
 }
 
-mh_status mh_ctx_create(int32_t device, void* hip_stream, mh_ctx** out) {
+static mh_status ctx_create(int32_t device, void* hip_stream, int32_t priority, mh_ctx** out);
+
+mh_status mh_ctx_create(int32_t device, void* hip_stream, mh_ctx** out) { return ctx_create(device, hip_stream, MH_PRIORITY_NORMAL, out); }
+
+mh_status mh_ctx_create_with_priority(int32_t device, int32_t priority, mh_ctx** out) {
+  MH_REQUIRE(priority >= MH_PRIORITY_LOW && priority <= MH_PRIORITY_HIGH, "bad priority class");
+  return ctx_create(device, nullptr, priority, out);
+}
+
+static mh_status ctx_create(int32_t device, void* hip_stream, int32_t priority, mh_ctx** out) {
   MH_REQUIRE(out, "null output");
   *out = nullptr;
   int c = 0;
@@ -173,7 +182,14 @@ mh_status mh_ctx_create(int32_t device, void* hip_stream, mh_ctx** out) {
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
   } else {
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (priority == MH_PRIORITY_NORMAL) {
+      e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    } else {
+      int least = 0, greatest = 0;  // (numerically: greatest priority <= least priority)
+      e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (e == hipSuccess)
+        e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, priority == MH_PRIORITY_HIGH ? greatest : least);
+    }
     if (e != hipSuccess) {
       delete ctx;
       return fail(MH_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -224,6 +240,7 @@ mh_status mh_ctx_destroy(mh_ctx* ctx) {
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   if (ctx->h_state) (void)hipHostFree(ctx->h_state);
   if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+  if (ctx->h_pp) (void)hipHostFree(ctx->h_pp);
   if (ctx->h_sched) (void)hipHostFree(ctx->h_sched);
   if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
   ctx->batch_desc.release();

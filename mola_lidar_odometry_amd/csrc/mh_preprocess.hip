@@ -280,47 +280,326 @@ __global__ void k_pp_deinterleave(const uint32_t* __restrict__ data, uint32_t n,
 
 inline uint32_t nblk(size_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
 
-// One stage: [decimate] + predicates over `in` -> `out` (compacted, order preserving).  Returns the survivor count.
-mh_status run_stage(mh_ctx* ctx, const mh_scan* in, const StageParams& sp, uint32_t* counters, uint32_t count_slot,
-                    mh_scan* out, bool want_t) {
-  hipStream_t s = ctx->stream;
-  const uint32_t N = (uint32_t)in->n;
-  const uint32_t B = 256;
-  if (N == 0) return scan_alloc(out, 0, want_t, true);
-  uint32_t* flag = ctx->build_c.as<uint32_t>();
-  uint32_t* pos = flag + N;
-  unsigned long long* keys = nullptr;
-  uint32_t* first_idx = nullptr;
-  uint32_t mask = 0;
-  if (sp.decimate) {
-    uint64_t tsize = 64;
-    while (tsize < 2ull * N) tsize <<= 1;
-    MH_TRY(ctx->build_a.reserve(tsize * sizeof(unsigned long long)));
-    MH_TRY(ctx->build_b.reserve(tsize * sizeof(uint32_t)));
-    keys = ctx->build_a.as<unsigned long long>();
-    first_idx = ctx->build_b.as<uint32_t>();
-    mask = (uint32_t)(tsize - 1);
-    MH_HIP(hipMemsetAsync(keys, 0xFF, tsize * sizeof(unsigned long long), s));
-    MH_HIP(hipMemsetAsync(first_idx, 0xFF, tsize * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_pp_insert, dim3(nblk(N, B)), dim3(B), 0, s, in->x, in->y, in->z, N, sp.inv_res, sp.trunc, keys,
-                       first_idx, mask, counters);
+// ---- the filter chain over several scans at once (one launch per step, blockIdx.y = scan) -------------------------
+// Everything the host used to learn between the steps (how many points stage 1 left, whether stage 2 decimates) stays
+// on the device: the outputs are allocated for the raw size, stage 2 runs over that many threads with the live count
+// read from the counters, and ONE read-back at the end of the chain brings the counts of all scans.
+struct PpJob {
+  const float *x, *y, *z, *t;  // raw input
+  const uint32_t* src;
+  uint32_t n;                  // raw count (also the capacity of the outputs)
+  uint32_t off, cap;           // this scan's range in the shared flag / position arrays (cap = n rounded up to 64)
+  StageParams s1, s2;
+  uint32_t min_points;         // stage 2 decimates only when stage 1 left at least this many (minimum_input_points_to_filter)
+  uint32_t want_icp, want_t;
+  unsigned long long *keys1, *keys2;
+  uint32_t *first1, *first2;
+  uint32_t tsize1, tsize2;     // table sizes (powers of two; 0 = the stage never decimates)
+  uint32_t* counters;          // 8 words: tmin, tmax, range flag, survivors of stage 1, of stage 2
+  float *mx, *my, *mz, *mt;    // out_map
+  uint32_t* msrc;
+  float *ix, *iy, *iz, *it;    // out_icp
+  uint32_t* isrc;
+};
+
+__global__ __launch_bounds__(256) void k_pp_init_b(const PpJob* __restrict__ jobs) {
+  const PpJob& j = jobs[blockIdx.y];
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  if (tid < 8) j.counters[tid] = tid == 0 ? 0xFFFFFFFFu : 0u;
+  for (uint32_t i = tid; i < j.tsize1; i += stride) {
+    j.keys1[i] = kEmptyKey;
+    j.first1[i] = 0xFFFFFFFFu;
   }
-  hipLaunchKernelGGL(k_pp_flag, dim3(nblk(N, B)), dim3(B), 0, s, in->x, in->y, in->z, N, sp, keys, first_idx, mask,
-                     counters, flag, count_slot);
-  size_t tb = ctx->sort_tmp.bytes;
-  MH_HIP(rocprim::exclusive_scan(ctx->sort_tmp.p, tb, flag, pos, 0u, N, rocprim::plus<uint32_t>(), s));
-  uint32_t h[3] = {0, 0, 0};  // range flag, stage-1 count, stage-2 count: one read-back per stage
-  MH_HIP(hipMemcpyAsync(h, counters + 2, sizeof(h), hipMemcpyDeviceToHost, s));
-  MH_HIP(mh::wait_stream(s));
-  if (h[0] & 1u)
-    return fail(MH_ERR_OUT_OF_RANGE, "a point's decimation voxel index exceeds the +-2^20 range of the packed key");
-  const uint32_t M = h[count_slot - 2];
-  MH_TRY(scan_alloc(out, M, want_t, true));
-  if (M)
-    hipLaunchKernelGGL(k_pp_compact, dim3(nblk(N, B)), dim3(B), 0, s, in->x, in->y, in->z, want_t ? in->t : nullptr,
-                       in->src, N, flag, pos, sp.ts_method, sp.ts_offset, counters, (float*)out->x, (float*)out->y,
-                       (float*)out->z, want_t ? (float*)out->t : nullptr, (uint32_t*)out->src);
+  for (uint32_t i = tid; i < j.tsize2; i += stride) {
+    j.keys2[i] = kEmptyKey;
+    j.first2[i] = 0xFFFFFFFFu;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pp_tminmax_b(const PpJob* __restrict__ jobs) {
+  const PpJob& j = jobs[blockIdx.y];
+  if (!j.t || j.s1.ts_method == MH_TS_NONE) return;
+  __shared__ uint32_t smn[4], smx[4];
+  uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < j.n; i += gridDim.x * blockDim.x) {
+    const uint32_t o = f2ord(j.t[i]);
+    mn = min(mn, o);
+    mx = max(mx, o);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+  }
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mn = min(min(smn[0], smn[1]), min(smn[2], smn[3]));
+    mx = max(max(smx[0], smx[1]), max(smx[2], smx[3]));
+    if (mn != 0xFFFFFFFFu) {
+      atomicMin(&j.counters[0], mn);
+      atomicMax(&j.counters[1], mx);
+    }
+  }
+}
+
+// what a stage reads: stage 1 the raw scan, stage 2 what stage 1 wrote (its count lives in the counters)
+template <int STAGE>
+__device__ __forceinline__ void pp_stage_view(const PpJob& j, const float*& x, const float*& y, const float*& z, uint32_t& n,
+                                              StageParams& sp, unsigned long long*& keys, uint32_t*& first, uint32_t& mask) {
+  if (STAGE == 1) {
+    x = j.x; y = j.y; z = j.z;
+    n = j.n;
+    sp = j.s1;
+    keys = j.keys1; first = j.first1; mask = j.tsize1 - 1;
+  } else {
+    x = j.mx; y = j.my; z = j.mz;
+    n = j.counters[3];
+    sp = j.s2;
+    if (n < j.min_points) sp.decimate = 0;
+    keys = j.keys2; first = j.first2; mask = j.tsize2 - 1;
+  }
+}
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_pp_insert_b(const PpJob* __restrict__ jobs) {
+  const PpJob& j = jobs[blockIdx.y];
+  if (STAGE == 2 && !j.want_icp) return;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= j.n) return;
+  const float *x, *y, *z;
+  uint32_t n, mask, *first;
+  unsigned long long* keys;
+  StageParams sp;
+  pp_stage_view<STAGE>(j, x, y, z, n, sp, keys, first, mask);
+  if (i >= n || !sp.decimate) return;
+  unsigned long long key;
+  if (!pp_key(x[i], y[i], z[i], sp.inv_res, sp.trunc, key, j.counters)) return;
+  uint32_t h = hash_key(key) & mask;
+  for (;;) {
+    const unsigned long long old = atomicCAS(&keys[h], kEmptyKey, key);
+    if (old == kEmptyKey || old == key) break;
+    h = (h + 1) & mask;
+  }
+  atomicMin(&first[h], i);
+}
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_pp_flag_b(const PpJob* __restrict__ jobs, uint32_t* __restrict__ flag) {
+  const PpJob& j = jobs[blockIdx.y];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x * blockDim.x >= j.cap) return;  // (whole workgroup beyond this scan's range)
+  if (STAGE == 2 && !j.want_icp) {
+    if (i < j.cap) flag[j.off + i] = 0u;
+    return;
+  }
+  const float *x, *y, *z;
+  uint32_t n, mask, *first;
+  unsigned long long* keys;
+  StageParams sp;
+  pp_stage_view<STAGE>(j, x, y, z, n, sp, keys, first, mask);
+  const bool valid = i < n;
+  const float px = valid ? x[i] : 0.f, py = valid ? y[i] : 0.f, pz = valid ? z[i] : 0.f;
+  bool keep = valid && isfinite(px) && isfinite(py) && isfinite(pz);
+  if (keep && sp.decimate) {
+    unsigned long long key;
+    keep = pp_key(px, py, pz, sp.inv_res, sp.trunc, key, j.counters);
+    if (keep) {
+      uint32_t h = hash_key(key) & mask;
+      while (keys[h] != key) h = (h + 1) & mask;  // inserted by k_pp_insert_b
+      keep = first[h] == i;
+    }
+  }
+  if (keep && sp.range_on) {
+    const float dx = px - sp.cx, dy = py - sp.cy, dz = pz - sp.cz;
+    const float sq = (dx * dx + dy * dy) + dz * dz;
+    keep = sq >= sp.sq_min && sq <= sp.sq_max;
+  }
+  if (keep && sp.bbox_mode) {
+    const bool inside = px >= sp.bmin[0] && px <= sp.bmax[0] && py >= sp.bmin[1] && py <= sp.bmax[1] &&
+                        pz >= sp.bmin[2] && pz <= sp.bmax[2];
+    keep = inside == (sp.bbox_mode == MH_BBOX_KEEP_INSIDE);
+  }
+  if (i < j.cap) flag[j.off + i] = keep ? 1u : 0u;  // (zeros up to the end of the range: the scan runs over all of it)
+  const unsigned long long kept = __ballot(keep);  // survivor count: one atomic per wavefront
+  if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&j.counters[2 + STAGE], (uint32_t)__popcll(kept));
+}
+
+// pos = exclusive scan of the flags of ALL scans in a row: a survivor's place in its own output is pos - pos[first of scan]
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_pp_compact_b(const PpJob* __restrict__ jobs, const uint32_t* __restrict__ flag,
+                                                      const uint32_t* __restrict__ pos) {
+  const PpJob& j = jobs[blockIdx.y];
+  if (STAGE == 2 && !j.want_icp) return;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= j.n || !flag[j.off + i]) return;
+  const uint32_t o = pos[j.off + i] - pos[j.off];
+  if (STAGE == 1) {
+    j.mx[o] = j.x[i];
+    j.my[o] = j.y[i];
+    j.mz[o] = j.z[i];
+    if (j.want_t) {
+      float tv = j.t[i];
+      if (j.s1.ts_method != MH_TS_NONE) {  // FilterAdjustTimestamps over ALL raw points (it runs before the decimation)
+        const float tmin = ord2f(j.counters[0]), tmax = ord2f(j.counters[1]);
+        const float dt = j.s1.ts_method == MH_TS_MIDDLE_IS_ZERO ? 0.5f * (tmin + tmax) : tmin;
+        tv = (tv - dt) + j.s1.ts_offset;
+      }
+      j.mt[o] = tv;
+    }
+    j.msrc[o] = j.src ? j.src[i] : i;
+  } else {
+    j.ix[o] = j.mx[i];
+    j.iy[o] = j.my[i];
+    j.iz[o] = j.mz[i];
+    if (j.want_t) j.it[o] = j.mt[i];  // out_map's stamps are adjusted already
+    j.isrc[o] = j.msrc[i];
+  }
+}
+
+StageParams stage1_of(const mh_preprocess_params* p, size_t n, bool has_t) {
+  StageParams s1{};
+  s1.inv_res = p->decim_map_resolution > 0.f ? 1.0f / p->decim_map_resolution : 0.f;
+  s1.trunc = p->index_mode == MH_INDEX_TRUNC;
+  s1.decimate = (p->decim_map_resolution > 0.f && n >= p->min_points_to_filter) ? 1u : 0u;
+  s1.range_on = p->range_max > 0.f ? 1u : 0u;
+  s1.sq_min = p->range_min * p->range_min;
+  s1.sq_max = p->range_max * p->range_max;
+  s1.cx = p->range_center[0]; s1.cy = p->range_center[1]; s1.cz = p->range_center[2];
+  s1.bbox_mode = p->bbox_mode;
+  for (int a = 0; a < 3; a++) { s1.bmin[a] = p->bbox_min[a]; s1.bmax[a] = p->bbox_max[a]; }
+  s1.ts_method = has_t ? p->timestamp_method : MH_TS_NONE;
+  s1.ts_offset = p->time_offset;
+  return s1;
+}
+
+mh_status preprocess_batch(size_t n_jobs, const mh_scan* const* raws, const mh_preprocess_params* params, size_t params_stride,
+                           mh_scan* const* out_maps, mh_scan* const* out_icps) {
+  mh_ctx* lead = raws[0]->ctx;
+  MH_TRY(set_device(lead));
+  hipStream_t s = lead->stream;
+  // pinned staging of the leader: job descriptors up, counters down
+  const size_t stage_bytes = n_jobs * sizeof(PpJob) + n_jobs * 8 * sizeof(uint32_t);
+  if (lead->h_pp_bytes < stage_bytes) {
+    if (lead->h_pp) (void)hipHostFree(lead->h_pp);
+    lead->h_pp = nullptr;
+    lead->h_pp_bytes = 0;
+    MH_HIP(hipHostMalloc((void**)&lead->h_pp, 2 * stage_bytes, hipHostMallocDefault));
+    lead->h_pp_bytes = 2 * stage_bytes;
+  }
+  PpJob* h_jobs = reinterpret_cast<PpJob*>(lead->h_pp);
+  uint32_t* h_counts = reinterpret_cast<uint32_t*>(lead->h_pp + n_jobs * sizeof(PpJob));
+  size_t total = 0, max_n = 0, max_t = 0, table_entries = 0;
+  bool any_icp = false, any_t = false;
+  for (size_t k = 0; k < n_jobs; k++) {
+    total += (raws[k]->n + 63) / 64 * 64;
+    uint64_t tsize = 64;
+    while (tsize < 2ull * raws[k]->n) tsize <<= 1;
+    table_entries += 2 * tsize;  // (both stages; upper bound)
+  }
+  MH_REQUIRE(total < 0x7FFFFFF0ull, "scans too large for one batch");
+  // decimation tables of all scans: keys | first index, in the leader's scratch
+  MH_TRY(lead->build_a.reserve(table_entries * sizeof(unsigned long long)));
+  MH_TRY(lead->build_b.reserve(table_entries * sizeof(uint32_t)));
+  size_t table_off = 0;
+  MH_TRY(lead->build_c.reserve(2 * (total ? total : 1) * sizeof(uint32_t)));              // flag | pos
+  MH_TRY(lead->build_e.reserve(n_jobs * (sizeof(PpJob) + 8 * sizeof(uint32_t)) + 256));   // descriptors | counters
+  PpJob* d_jobs = lead->build_e.as<PpJob>();
+  uint32_t* d_counts = reinterpret_cast<uint32_t*>(lead->build_e.as<char>() + (n_jobs * sizeof(PpJob) + 63) / 64 * 64);
+  uint32_t* flag = lead->build_c.as<uint32_t>();
+  uint32_t* pos = flag + total;
+  size_t off = 0;
+  for (size_t k = 0; k < n_jobs; k++) {
+    const mh_scan* raw = raws[k];
+    const mh_preprocess_params* p = reinterpret_cast<const mh_preprocess_params*>(reinterpret_cast<const char*>(params) + k * params_stride);
+    mh_scan* om = out_maps[k];
+    mh_scan* oi = out_icps ? out_icps[k] : nullptr;
+    mh_ctx* ctx = raw->ctx;
+    const size_t n = raw->n;
+    const bool has_t = raw->t != nullptr;
+    PpJob& j = h_jobs[k];
+    memset(&j, 0, sizeof(j));
+    j.x = raw->x; j.y = raw->y; j.z = raw->z; j.t = raw->t; j.src = raw->src;
+    j.n = (uint32_t)n;
+    j.off = (uint32_t)off;
+    j.cap = (uint32_t)((n + 63) / 64 * 64);
+    off += j.cap;
+    j.s1 = stage1_of(p, n, has_t);
+    j.s2.inv_res = p->decim_icp_resolution > 0.f ? 1.0f / p->decim_icp_resolution : 0.f;
+    j.s2.trunc = j.s1.trunc;
+    j.s2.decimate = p->decim_icp_resolution > 0.f ? 1u : 0u;  // && stage 1 left >= min_points: decided on the device
+    j.s2.ts_method = MH_TS_NONE;
+    j.min_points = p->min_points_to_filter;
+    j.want_icp = oi ? 1u : 0u;
+    j.want_t = has_t ? 1u : 0u;
+    uint64_t tsize = 64;
+    while (tsize < 2ull * n) tsize <<= 1;
+    j.tsize1 = j.s1.decimate ? (uint32_t)tsize : 0u;
+    j.tsize2 = (oi && j.s2.decimate && n >= p->min_points_to_filter) ? (uint32_t)tsize : 0u;
+    if (!j.tsize2) j.s2.decimate = 0;
+    j.keys1 = lead->build_a.as<unsigned long long>() + table_off;
+    j.keys2 = j.keys1 + j.tsize1;
+    j.first1 = lead->build_b.as<uint32_t>() + table_off;
+    j.first2 = j.first1 + j.tsize1;
+    table_off += (size_t)j.tsize1 + j.tsize2;
+    j.counters = d_counts + 8 * k;
+    MH_TRY(scan_alloc(om, n, has_t, true));  // capacity: the raw size; the real counts arrive with the read-back below
+    j.mx = (float*)om->x; j.my = (float*)om->y; j.mz = (float*)om->z; j.mt = (float*)om->t; j.msrc = (uint32_t*)om->src;
+    if (oi) {
+      MH_TRY(scan_alloc(oi, n, has_t, true));
+      j.ix = (float*)oi->x; j.iy = (float*)oi->y; j.iz = (float*)oi->z; j.it = (float*)oi->t; j.isrc = (uint32_t*)oi->src;
+      any_icp = true;
+    }
+    any_t = any_t || (has_t && p->timestamp_method != MH_TS_NONE);
+    max_n = n > max_n ? n : max_n;
+    const size_t ts = j.tsize1 > j.tsize2 ? j.tsize1 : j.tsize2;
+    max_t = ts > max_t ? ts : max_t;
+    // uploads / earlier work still queued on this scan's own stream come first
+    if (ctx != lead && ctx->stream != s && hipStreamQuery(ctx->stream) != hipSuccess) {
+      MH_HIP(hipEventRecord(ctx->ev_ready, ctx->stream));
+      MH_HIP(hipStreamWaitEvent(s, ctx->ev_ready, 0));
+    }
+  }
+  (void)hipGetLastError();  // hipStreamQuery's hipErrorNotReady is not an error
+  if (max_n == 0) {
+    for (size_t k = 0; k < n_jobs; k++) {
+      out_maps[k]->n = 0;
+      if (out_icps && out_icps[k]) out_icps[k]->n = 0;
+    }
+    return MH_OK;
+  }
+  size_t tmp = 0;
+  MH_HIP(rocprim::exclusive_scan(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, total, rocprim::plus<uint32_t>(), s));
+  MH_TRY(lead->sort_tmp.reserve(tmp));
+  MH_HIP(hipMemcpyAsync(d_jobs, h_jobs, n_jobs * sizeof(PpJob), hipMemcpyHostToDevice, s));
+  const uint32_t B = 256;
+  const dim3 grid(nblk(max_n, B), (uint32_t)n_jobs);
+  const uint32_t init_blocks = nblk(max_t ? max_t : 8, B);
+  hipLaunchKernelGGL(k_pp_init_b, dim3(init_blocks < 512u ? init_blocks : 512u, (uint32_t)n_jobs), dim3(B), 0, s, d_jobs);
+  if (any_t) hipLaunchKernelGGL(k_pp_tminmax_b, dim3(grid.x < 128u ? grid.x : 128u, (uint32_t)n_jobs), dim3(B), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_pp_insert_b<1>, grid, dim3(B), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_pp_flag_b<1>, grid, dim3(B), 0, s, d_jobs, flag);
+  size_t tb = lead->sort_tmp.bytes;
+  MH_HIP(rocprim::exclusive_scan(lead->sort_tmp.p, tb, flag, pos, 0u, total, rocprim::plus<uint32_t>(), s));
+  hipLaunchKernelGGL(k_pp_compact_b<1>, grid, dim3(B), 0, s, d_jobs, flag, pos);
+  if (any_icp) {
+    hipLaunchKernelGGL(k_pp_insert_b<2>, grid, dim3(B), 0, s, d_jobs);
+    hipLaunchKernelGGL(k_pp_flag_b<2>, grid, dim3(B), 0, s, d_jobs, flag);
+    tb = lead->sort_tmp.bytes;
+    MH_HIP(rocprim::exclusive_scan(lead->sort_tmp.p, tb, flag, pos, 0u, total, rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(k_pp_compact_b<2>, grid, dim3(B), 0, s, d_jobs, flag, pos);
+  }
   MH_HIP(hipGetLastError());
+  MH_HIP(hipMemcpyAsync(h_counts, d_counts, n_jobs * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  MH_HIP(mh::wait_stream(s));
+  bool out_of_range = false;
+  for (size_t k = 0; k < n_jobs; k++) {
+    const uint32_t* c = h_counts + 8 * k;
+    out_of_range = out_of_range || (c[2] & 1u);
+    out_maps[k]->n = c[3];
+    if (out_icps && out_icps[k]) out_icps[k]->n = c[4];
+  }
+  if (out_of_range)
+    return fail(MH_ERR_OUT_OF_RANGE, "a point's decimation voxel index exceeds the +-2^20 range of the packed key");
   return MH_OK;
 }
 
@@ -392,7 +671,7 @@ mh_status mh_scan_update_aos(mh_scan* scan, const void* data, size_t n, size_t p
   return MH_OK;
 }
 
-mh_status mh_scan_preprocess(const mh_scan* raw, const mh_preprocess_params* p, mh_scan* out_map, mh_scan* out_icp) {
+static mh_status check_preprocess_args(const mh_scan* raw, const mh_preprocess_params* p, const mh_scan* out_map, const mh_scan* out_icp) {
   MH_REQUIRE(raw && p && out_map, "null argument");
   MH_REQUIRE(out_map != raw && out_icp != raw && out_map != out_icp, "outputs must be distinct scans");
   MH_REQUIRE(out_map->ctx == raw->ctx && (!out_icp || out_icp->ctx == raw->ctx), "scans belong to different contexts");
@@ -401,48 +680,30 @@ mh_status mh_scan_preprocess(const mh_scan* raw, const mh_preprocess_params* p, 
   MH_REQUIRE(p->bbox_mode >= MH_BBOX_OFF && p->bbox_mode <= MH_BBOX_KEEP_INSIDE, "bad bbox_mode");
   MH_REQUIRE(p->timestamp_method >= MH_TS_NONE && p->timestamp_method <= MH_TS_EARLIEST_IS_ZERO, "bad timestamp_method");
   MH_REQUIRE(raw->n < 0x7FFFFFF0ull, "scan too large");
-  mh_ctx* ctx = raw->ctx;
-  MH_TRY(set_device(ctx));
-  hipStream_t s = ctx->stream;
-  const size_t n = raw->n;
-  const bool has_t = raw->t != nullptr;
-
-  MH_TRY(ctx->build_c.reserve(2 * (n ? n : 1) * sizeof(uint32_t)));  // flag | pos
-  MH_TRY(ctx->build_e.reserve(64));  // counters: tmin, tmax, range flag, survivors of stage 1, of stage 2
-  uint32_t* counters = ctx->build_e.as<uint32_t>();
-  const uint32_t init[5] = {0xFFFFFFFFu, 0u, 0u, 0u, 0u};
-  MH_HIP(hipMemcpyAsync(counters, init, sizeof(init), hipMemcpyHostToDevice, s));
-  if (n) {
-    size_t tmp = 0;
-    MH_HIP(rocprim::exclusive_scan(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>(), s));
-    MH_TRY(ctx->sort_tmp.reserve(tmp));
-  }
-  if (has_t && n && p->timestamp_method != MH_TS_NONE)
-    hipLaunchKernelGGL(k_pp_tminmax, dim3(nblk(n, 256) < 128u ? nblk(n, 256) : 128u), dim3(256), 0, s, raw->t, (uint32_t)n, counters);
-
-  StageParams s1{};
-  s1.inv_res = p->decim_map_resolution > 0.f ? 1.0f / p->decim_map_resolution : 0.f;
-  s1.trunc = p->index_mode == MH_INDEX_TRUNC;
-  s1.decimate = (p->decim_map_resolution > 0.f && n >= p->min_points_to_filter) ? 1u : 0u;
-  s1.range_on = p->range_max > 0.f ? 1u : 0u;
-  s1.sq_min = p->range_min * p->range_min;
-  s1.sq_max = p->range_max * p->range_max;
-  s1.cx = p->range_center[0]; s1.cy = p->range_center[1]; s1.cz = p->range_center[2];
-  s1.bbox_mode = p->bbox_mode;
-  for (int a = 0; a < 3; a++) { s1.bmin[a] = p->bbox_min[a]; s1.bmax[a] = p->bbox_max[a]; }
-  s1.ts_method = has_t ? p->timestamp_method : MH_TS_NONE;
-  s1.ts_offset = p->time_offset;
-  MH_TRY(run_stage(ctx, raw, s1, counters, 3, out_map, has_t));
-
-  if (out_icp) {
-    StageParams s2{};
-    s2.inv_res = p->decim_icp_resolution > 0.f ? 1.0f / p->decim_icp_resolution : 0.f;
-    s2.trunc = s1.trunc;
-    s2.decimate = (p->decim_icp_resolution > 0.f && out_map->n >= p->min_points_to_filter) ? 1u : 0u;
-    s2.ts_method = MH_TS_NONE;  // out_map's stamps are adjusted already
-    MH_TRY(run_stage(ctx, out_map, s2, counters, 4, out_icp, has_t));
-  }
   return MH_OK;
+}
+
+mh_status mh_scan_preprocess(const mh_scan* raw, const mh_preprocess_params* p, mh_scan* out_map, mh_scan* out_icp) {
+  MH_TRY(check_preprocess_args(raw, p, out_map, out_icp));
+  return preprocess_batch(1, &raw, p, sizeof(mh_preprocess_params), &out_map, out_icp ? &out_icp : nullptr);
+}
+
+mh_status mh_scan_preprocess_batch(size_t n_jobs, const mh_scan* const* raws, const mh_preprocess_params* params,
+                                   size_t params_stride, mh_scan* const* out_maps, mh_scan* const* out_icps) {
+  MH_REQUIRE(n_jobs == 0 || (raws && params && out_maps), "null argument");
+  MH_REQUIRE(params_stride == 0 || params_stride >= sizeof(mh_preprocess_params), "params_stride smaller than the structure");
+  if (!n_jobs) return MH_OK;
+  for (size_t k = 0; k < n_jobs; k++) {
+    const mh_preprocess_params* p = reinterpret_cast<const mh_preprocess_params*>(reinterpret_cast<const char*>(params) + k * params_stride);
+    MH_TRY(check_preprocess_args(raws[k], p, out_maps[k], out_icps ? out_icps[k] : nullptr));
+    MH_REQUIRE(raws[k]->ctx->device == raws[0]->ctx->device, "scans live on different devices");
+    for (size_t q = 0; q < k; q++) {
+      const mh_scan* others[3] = {raws[q], out_maps[q], out_icps ? out_icps[q] : nullptr};
+      for (const mh_scan* o : others)
+        MH_REQUIRE(!o || (o != out_maps[k] && (!out_icps || o != out_icps[k])), "an output scan appears twice in the batch");
+    }
+  }
+  return preprocess_batch(n_jobs, raws, params, params_stride, out_maps, out_icps);
 }
 
 mh_status mh_scan_deskew(const mh_scan* in, const double twist[6], mh_scan* out) {

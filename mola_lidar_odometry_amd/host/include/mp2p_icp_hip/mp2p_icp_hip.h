@@ -25,6 +25,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <optional>
@@ -159,7 +160,8 @@ class Parameterizable {
 // ---------------------------------------------------------------- device handles
 class DeviceContext {  // one HIP device + stream (mh_ctx)
  public:
-  explicit DeviceContext(int device = 0);
+  // priority: MH_PRIORITY_LOW / NORMAL / HIGH (include/molahip.h) -- the class of the context's stream
+  explicit DeviceContext(int device = 0, int priority = 0);
   ~DeviceContext();
   DeviceContext(const DeviceContext&) = delete;
   mh_ctx* get() const { return ctx_; }
@@ -380,6 +382,10 @@ class AlignBatcher {
   void leave();  // this participant will not align any more (end of its sequence, or it failed)
   size_t batches() const { return n_batches_; }
   size_t jobs() const { return n_jobs_; }
+  // where a batch's wall time goes: from the first request of a batch to its start (the sequences' other phases), and the
+  // mh_icp_align_batch call itself; seconds, summed over the batches so far
+  double secondsAssembling() const { return t_assemble_; }
+  double secondsRunning() const { return t_run_; }
 
  private:
   struct Request {
@@ -392,6 +398,7 @@ class AlignBatcher {
     mh_status status = MH_OK;
     std::string error;
     bool done = false;
+    std::chrono::steady_clock::time_point arrived{};
   };
   void run_batch(std::vector<Request*>& batch);  // called WITHOUT the mutex
   size_t threshold_locked() const;
@@ -404,6 +411,7 @@ class AlignBatcher {
                           // default: two or more batches in flight measured SLOWER -- 8 sequences 2590 -> 2160 scans/s -- the
                           // host threads then contend for the HIP runtime, which is what limits this runner in the first place)
   size_t n_batches_ = 0, n_jobs_ = 0;
+  double t_assemble_ = 0.0, t_run_ = 0.0;
 };
 
 // ---------------------------------------------------------------- ICP

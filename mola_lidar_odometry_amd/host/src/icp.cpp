@@ -151,7 +151,10 @@ void throw_status(mh_status s, const char* where) {
 }
 
 // ================================================================== device handles
-DeviceContext::DeviceContext(int device) : device_(device) { check(mh_ctx_create(device, nullptr, &ctx_), "mh_ctx_create"); }
+DeviceContext::DeviceContext(int device, int priority) : device_(device) {
+  if (priority == MH_PRIORITY_NORMAL) check(mh_ctx_create(device, nullptr, &ctx_), "mh_ctx_create");
+  else check(mh_ctx_create_with_priority(device, priority, &ctx_), "mh_ctx_create_with_priority");
+}
 void DeviceContext::synchronize() const { check(mh_ctx_synchronize(ctx_), "mh_ctx_synchronize"); }
 DeviceContext::~DeviceContext() { mh_ctx_destroy(ctx_); }
 
@@ -570,6 +573,7 @@ void AlignBatcher::run_batch(std::vector<Request*>& batch) {
   // the device work of this batch is issued by this thread alone; the mutex is NOT held (other participants queue up and
   // may start the next batch on their own contexts meanwhile: the C ABI is re-entrant across contexts)
   const size_t n = batch.size();
+  const auto t_start = std::chrono::steady_clock::now();
   std::vector<const mh_map*> maps(n);
   std::vector<const mh_scan*> scans(n);
   std::vector<mh_icp_params> params(n);
@@ -607,6 +611,8 @@ void AlignBatcher::run_batch(std::vector<Request*>& batch) {
   std::lock_guard<std::mutex> lk(mtx_);
   n_batches_++;
   n_jobs_ += n;
+  t_run_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  t_assemble_ += std::chrono::duration<double>(t_start - batch[0]->arrived).count();
   in_flight_ -= n;
   for (size_t i = 0; i < n; i++) {
     *batch[i]->result = results[i];
@@ -622,6 +628,7 @@ mh_status AlignBatcher::align(const mh_map* map, const mh_scan* scan, const mh_i
   Request rq;
   rq.map = map; rq.scan = scan; rq.params = params; rq.T = T_guess; rq.prior = prior; rq.result = result;
   std::unique_lock<std::mutex> lk(mtx_);
+  rq.arrived = std::chrono::steady_clock::now();
   waiting_.push_back(&rq);
   // a batch is due when enough requests wait -- or when everybody who is not waiting is inside a running batch already
   // (then waiting longer only idles the device)

@@ -288,11 +288,13 @@ int main(int argc, char** argv) {
   }
   const size_t N = seq_dirs.size();
   std::vector<SequenceReport> reps(N);
+  std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher_keep;
   const auto t0 = std::chrono::steady_clock::now();
   if (fibers) {
     // ONE thread in the HIP runtime: the sequences (and their prefetch workers) are fibers of this thread
     molahip_host::FiberScheduler sched;
     auto batcher = N > 1 ? std::make_shared<mp2p_icp_hip::AlignBatcher>(N) : nullptr;
+    batcher_keep = batcher;
     const std::string stem = out.size() > 4 && out.compare(out.size() - 4, 4, ".tum") == 0 ? out.substr(0, out.size() - 4) : out;
     for (size_t k = 0; k < N; k++) {
       const std::string o = N == 1 ? out : stem + "_" + std::to_string(k) + ".tum";
@@ -303,6 +305,7 @@ int main(int argc, char** argv) {
     run_sequence(pipeline, seq_dirs[0], out, device, max_scans, prefetch, nullptr, reps[0]);
   } else {
     auto batcher = std::make_shared<mp2p_icp_hip::AlignBatcher>(N);
+    batcher_keep = batcher;
     std::vector<std::thread> th;
     const std::string stem = out.size() > 4 && out.compare(out.size() - 4, 4, ".tum") == 0 ? out.substr(0, out.size() - 4) : out;
     for (size_t k = 0; k < N; k++)
@@ -344,8 +347,13 @@ int main(int argc, char** argv) {
       steady += r.steady_scans;
       slowest = r.steady_seconds > slowest ? r.steady_seconds : slowest;
     }
-    printf("{\"sequences\": %zu, \"scans\": %zu, \"wall_seconds\": %.6f, \"scans_per_s\": %.3f, \"steady_scans_per_s\": %.3f}\n", N,
-           total, wall, wall > 0 ? total / wall : 0.0, slowest > 0 ? steady / slowest : 0.0);
+    // the batcher's view of a round (all scans, warm-up included): waiting for the last sequence to arrive / the batch call
+    const double nb = batcher_keep && batcher_keep->batches() ? (double)batcher_keep->batches() : 1.0;
+    printf("{\"sequences\": %zu, \"scans\": %zu, \"wall_seconds\": %.6f, \"scans_per_s\": %.3f, \"steady_scans_per_s\": %.3f, "
+           "\"batches\": %zu, \"jobs_per_batch\": %.2f, \"ms_per_batch_assembling\": %.4f, \"ms_per_batch_running\": %.4f}\n",
+           N, total, wall, wall > 0 ? total / wall : 0.0, slowest > 0 ? steady / slowest : 0.0,
+           batcher_keep ? batcher_keep->batches() : (size_t)0, batcher_keep ? batcher_keep->jobs() / nb : 0.0,
+           batcher_keep ? 1e3 * batcher_keep->secondsAssembling() / nb : 0.0, batcher_keep ? 1e3 * batcher_keep->secondsRunning() / nb : 0.0);
   }
   return rc;
 }

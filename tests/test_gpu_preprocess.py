@@ -79,6 +79,72 @@ def test_preprocess_edge_cases(ctx, oracle, small_workload):
         capi.Scan(ctx, xyz).set_timestamps(t[:10])
 
 
+def test_preprocess_batch_equals_single_calls(ctx, oracle, small_workload):
+    """mh_scan_preprocess_batch over ragged scans in their own contexts, per-scan parameters, one scan below
+    minimum_input_points_to_filter, one empty, one without time stamps, one without an ICP layer: every output bit for bit
+    what a single call gives (and the oracle)."""
+    rng = np.random.default_rng(5)
+    xyz, t = _raw(3, small_workload)
+    sizes = [len(xyz), len(xyz) // 2, 250, 0, len(xyz) // 3, min(777, len(xyz))]
+    ctxs = [capi.Context(0) for _ in sizes]
+    pars, raws, clouds = [], [], []
+    for k, n in enumerate(sizes):
+        sel = np.sort(rng.choice(len(xyz), n, replace=False))
+        c = xyz[sel] + np.float32(0.01 * k)
+        raw = capi.Scan(ctxs[k], c)
+        if k != 4 and n:
+            raw.set_timestamps(t[sel])
+        raws.append(raw)
+        clouds.append(c)
+        pars.append(capi.preprocess_params(decim_map_resolution=0.25 + 0.05 * k, decim_icp_resolution=0.9 + 0.1 * k, min_points_to_filter=300,
+                                           range_min=1.0 + 0.3 * k, range_max=60.0 + k, bbox_mode=1 + (k % 2), bbox_min=(-8.0, -8.0, -1.8),
+                                           bbox_max=(8.0 + k, 8.0, 4.0), index_mode=k % 2,
+                                           timestamp_method=(capi.TS_MIDDLE_IS_ZERO, capi.TS_EARLIEST_IS_ZERO, capi.TS_NONE)[k % 3], time_offset=0.01 * k))
+    oms = [capi.Scan(c) for c in ctxs]
+    ois = [capi.Scan(c) if k != 5 else None for k, c in enumerate(ctxs)]
+    capi.preprocess_batch(raws, pars, oms, ois)
+    for k in range(len(sizes)):
+        sm, si = capi.Scan(ctxs[k]), capi.Scan(ctxs[k])
+        raws[k].preprocess(pars[k], sm, si if ois[k] is not None else None)
+        for got, want in ((oms[k], sm), (ois[k], si)):
+            if got is None:
+                continue
+            assert got.n == want.n
+            a, b = got.download(), want.download()
+            for key in ("xyz", "t", "src_idx"):
+                np.testing.assert_array_equal(a[key], b[key])
+        p = pars[k]
+        im, ii = oracle.preprocess(clouds[k], decim_map_resolution=p.decim_map_resolution, decim_icp_resolution=p.decim_icp_resolution,
+                                   min_points_to_filter=300, range_min=p.range_min, range_max=p.range_max, bbox_mode=p.bbox_mode,
+                                   bbox_min=tuple(p.bbox_min), bbox_max=tuple(p.bbox_max), index_mode=p.index_mode)
+        np.testing.assert_array_equal(oms[k].download()["src_idx"], im)
+        if ois[k] is not None:
+            np.testing.assert_array_equal(ois[k].download()["src_idx"], ii)
+    # one parameter set for all; no ICP layers at all; the same call again (buffers reused)
+    for _ in range(2):
+        capi.preprocess_batch(raws, pars[1], oms, None)
+        for k in range(len(sizes)):
+            sm = capi.Scan(ctxs[k])
+            raws[k].preprocess(pars[1], sm, None)
+            np.testing.assert_array_equal(oms[k].download()["src_idx"], sm.download()["src_idx"])
+    # an output listed twice is refused
+    with pytest.raises(capi.MolahipError):
+        capi.preprocess_batch(raws[:2], pars[0], [oms[0], oms[0]], None)
+    for c in ctxs:
+        c.close()
+
+
+def test_context_priority_classes(small_workload):
+    """mh_ctx_create_with_priority: a stream of the low / high class works like any other; a bad class is refused"""
+    for prio in (capi.PRIORITY_LOW, capi.PRIORITY_HIGH):
+        c = capi.Context(0, priority=prio)
+        s = capi.Scan(c, small_workload.scan_xyz)
+        np.testing.assert_array_equal(s.download()["xyz"], small_workload.scan_xyz)
+        c.close()
+    with pytest.raises(capi.MolahipError):
+        capi.Context(0, priority=7)
+
+
 def test_deskew(ctx, oracle, small_workload):
     xyz, t = _raw(3, small_workload, with_nan=False)
     raw = capi.Scan(ctx, xyz).set_timestamps(t)
