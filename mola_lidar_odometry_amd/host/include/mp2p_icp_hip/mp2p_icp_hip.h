@@ -379,7 +379,18 @@ class AlignBatcher {
   // blocks until the batch this request joined has run; returns its status (the message in `error` when not MH_OK)
   mh_status align(const mh_map* map, const mh_scan* scan, const mh_icp_params* params, const double T_guess[12],
                   const mh_prior* prior, mh_icp_result* result, std::string* error);
+  // the observation filters of the participants' next scans (mh_scan_preprocess) merged the same way: a rendezvous of
+  // its own (a sequence's filter request for scan k+1 and its alignment of scan k are in flight together), one
+  // mh_scan_preprocess_batch by whoever completes the set.  A request that has waited 1 ms (MOLA_HIP_FILTER_SET_WAIT_US) runs with whatever
+  // waits by then: a sequence that skips a scan's filters (no announced next scan, a restart) must not hold the others.
+  mh_status preprocess(const mh_scan* raw, const mh_preprocess_params* params, mh_scan* out_map, mh_scan* out_icp, std::string* error);
+  // this participant has no filter request for the set now being assembled (no next scan announced): the others' set
+  // is complete without it
+  void skipFilterRound();
   void leave();  // this participant will not align any more (end of its sequence, or it failed)
+  size_t filterBatches() const { return n_pp_batches_; }
+  size_t filterJobs() const { return n_pp_jobs_; }
+  size_t filterTimeouts() const { return n_pp_timeouts_; }  // sets run incomplete because a request had waited long enough
   size_t batches() const { return n_batches_; }
   size_t jobs() const { return n_jobs_; }
   // where a batch's wall time goes: from the first request of a batch to its start (the sequences' other phases), and the
@@ -400,6 +411,21 @@ class AlignBatcher {
     bool done = false;
     std::chrono::steady_clock::time_point arrived{};
   };
+  struct FilterRequest {
+    const mh_scan* raw = nullptr;
+    const mh_preprocess_params* params = nullptr;
+    mh_scan* out_map = nullptr;
+    mh_scan* out_icp = nullptr;
+    mh_status status = MH_OK;
+    std::string error;
+    bool done = false, taken = false;
+  };
+  void run_filter_batch(std::vector<FilterRequest*>& batch);  // called WITHOUT the mutex
+  std::vector<FilterRequest*> pp_waiting_;
+  size_t pp_skips_ = 0;
+  bool filter_set_due_locked() const { return pp_waiting_.size() + pp_in_flight_ + pp_skips_ >= active_; }
+  void take_filter_set(std::unique_lock<std::mutex>& lk);
+  size_t pp_in_flight_ = 0, n_pp_batches_ = 0, n_pp_jobs_ = 0, n_pp_timeouts_ = 0;
   void run_batch(std::vector<Request*>& batch);  // called WITHOUT the mutex
   size_t threshold_locked() const;
   std::mutex mtx_;

@@ -652,9 +652,99 @@ mh_status AlignBatcher::align(const mh_map* map, const mh_scan* scan, const mh_i
   return rq.status;
 }
 
+void AlignBatcher::run_filter_batch(std::vector<FilterRequest*>& batch) {
+  const size_t n = batch.size();
+  std::vector<const mh_scan*> raws(n);
+  std::vector<mh_preprocess_params> params(n);
+  std::vector<mh_scan*> maps(n), icps(n);
+  for (size_t i = 0; i < n; i++) {
+    raws[i] = batch[i]->raw;
+    params[i] = *batch[i]->params;
+    maps[i] = batch[i]->out_map;
+    icps[i] = batch[i]->out_icp;
+  }
+  mh_status st = n == 1 ? mh_scan_preprocess(raws[0], &params[0], maps[0], icps[0])
+                        : mh_scan_preprocess_batch(n, raws.data(), params.data(), sizeof(mh_preprocess_params), maps.data(), icps.data());
+  std::vector<mh_status> sts(n, st);
+  std::vector<std::string> errs(n, st != MH_OK ? mh_last_error_string() : "");
+  if (st != MH_OK && n > 1)  // whose scan it was: one by one
+    for (size_t i = 0; i < n; i++) {
+      sts[i] = mh_scan_preprocess(raws[i], &params[i], maps[i], icps[i]);
+      errs[i] = sts[i] != MH_OK ? mh_last_error_string() : "";
+    }
+  std::lock_guard<std::mutex> lk(mtx_);
+  n_pp_batches_++;
+  n_pp_jobs_ += n;
+  pp_in_flight_ -= n;
+  for (size_t i = 0; i < n; i++) {
+    batch[i]->status = sts[i];
+    batch[i]->error = errs[i];
+    batch[i]->done = true;
+  }
+  cv_.notify_all();
+}
+
+void AlignBatcher::take_filter_set(std::unique_lock<std::mutex>& lk) {
+  std::vector<FilterRequest*> batch;
+  batch.swap(pp_waiting_);
+  for (auto* r : batch) r->taken = true;
+  pp_in_flight_ += batch.size();
+  pp_skips_ = 0;
+  lk.unlock();
+  run_filter_batch(batch);
+  lk.lock();
+}
+
+mh_status AlignBatcher::preprocess(const mh_scan* raw, const mh_preprocess_params* params, mh_scan* out_map, mh_scan* out_icp,
+                                   std::string* error) {
+  FilterRequest rq;
+  rq.raw = raw; rq.params = params; rq.out_map = out_map; rq.out_icp = out_icp;
+  std::unique_lock<std::mutex> lk(mtx_);
+  pp_waiting_.push_back(&rq);
+  // how long a request waits for the set to complete.  A sequence that re-aligns the scan it is on (twist correction)
+  // sits out a round, so incomplete sets are part of normal operation: the limit is what such a round costs everybody,
+  // against sets split in two when the requests of a round arrive further apart than this (8 copies of one drive:
+  // 0.15 / 0.3 / 0.6 / 2 ms -> 3550 / 3800 / 4020 / 3970 scans/s, 340 / 186 / 43 / 10 incomplete sets of 150)
+  static const auto limit = std::chrono::microseconds([] {
+    const char* e = getenv("MOLA_HIP_FILTER_SET_WAIT_US");
+    return e ? std::max(0, atoi(e)) : 1000;
+  }());
+  if (filter_set_due_locked()) {
+    take_filter_set(lk);
+  } else if (molahip_host::FiberScheduler::in_fiber()) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!rq.done) {
+      lk.unlock();
+      molahip_host::FiberScheduler::yield();
+      lk.lock();
+      if (!rq.done && !rq.taken && std::chrono::steady_clock::now() - t0 > limit) {
+        n_pp_timeouts_++;
+        take_filter_set(lk);
+      }
+    }
+  } else {
+    while (!rq.done) {
+      if (cv_.wait_for(lk, limit, [&] { return rq.done; })) break;
+      if (!rq.taken) {  // nobody completed the set in time: run what waits (this request included)
+        n_pp_timeouts_++;
+        take_filter_set(lk);
+      }
+    }
+  }
+  if (error) *error = rq.error;
+  return rq.status;
+}
+
+void AlignBatcher::skipFilterRound() {
+  std::unique_lock<std::mutex> lk(mtx_);
+  if (pp_skips_ < active_) pp_skips_++;
+  if (!pp_waiting_.empty() && filter_set_due_locked()) take_filter_set(lk);
+}
+
 void AlignBatcher::leave() {
   std::unique_lock<std::mutex> lk(mtx_);
   if (active_ > 0) active_--;
+  if (!pp_waiting_.empty() && filter_set_due_locked()) take_filter_set(lk);
   if (!waiting_.empty() && (waiting_.size() >= threshold_locked() || waiting_.size() + in_flight_ >= active_)) {
     // the others were only waiting for this one
     std::vector<Request*> batch;

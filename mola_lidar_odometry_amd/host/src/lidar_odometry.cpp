@@ -493,7 +493,13 @@ void LidarOdometry::run_first_pass() {
   const FilterPlan& f = *plan_;
   const mh_preprocess_params pp = make_pp(f.decim_map_res, f.decim_icp_res, f.min_points_to_filter, f.range_min, f.range_max,
                                           f.bbox_mode, f.bbox_min, f.bbox_max, f.timestamp_method, f.time_offset);
-  check(mh_scan_preprocess(raw_->handle(), &pp, map_skewed_->handle(), icp_skewed_->handle()), "mh_scan_preprocess");
+  if (batcher_) {  // several sequences in one process: this scan's filters join the others'
+    std::string err;
+    const mh_status st = batcher_->preprocess(raw_->handle(), &pp, map_skewed_->handle(), icp_skewed_->handle(), &err);
+    if (st != MH_OK) throw std::runtime_error("mh_scan_preprocess (batched): " + err);
+  } else {
+    check(mh_scan_preprocess(raw_->handle(), &pp, map_skewed_->handle(), icp_skewed_->handle()), "mh_scan_preprocess");
+  }
 }
 
 void LidarOdometry::setAlignBatcher(std::shared_ptr<mp2p_icp_hip::AlignBatcher> b) {
@@ -504,6 +510,7 @@ void LidarOdometry::setAlignBatcher(std::shared_ptr<mp2p_icp_hip::AlignBatcher> 
                              "it with a DeviceContext of its own");
   for (auto& i : icp_)
     if (i) i->setAlignBatcher(b);
+  batcher_ = std::move(b);
 }
 
 // ---- the announced next observation: upload + first pass on a second stream while this scan is in its ICP loop
@@ -529,7 +536,10 @@ void LidarOdometry::cancel_prefetch() {
 }
 
 void LidarOdometry::launch_prefetch() {
-  if (!pf_->requested || !plan_ || !estimated_sensor_max_range_) return;
+  if (!pf_->requested || !plan_ || !estimated_sensor_max_range_) {
+    if (batcher_) batcher_->skipFilterRound();  // (the last scan of the sequence, or nothing announced)
+    return;
+  }
   if (pf_->launched) {  // prepared but never picked up: drop it
     try { pf_->join(); } catch (...) {}
     pf_->launched = false;
@@ -562,11 +572,18 @@ void LidarOdometry::launch_prefetch() {
   auto raw = raw_b_[pf_->slot], ms = map_skewed_b_[pf_->slot], is = icp_skewed_b_[pf_->slot];
   auto ctx = ctx_b_;
   const bool pinned = input_pinned_;
-  auto work = [in, pp, raw, ms, is, ctx, pinned]() {
+  auto batcher = batcher_;
+  auto work = [in, pp, raw, ms, is, ctx, pinned, batcher]() {
     if (in.data) raw->setPointsInterleaved(in.data, in.n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t, pinned);
     else raw->setPoints(in.x, in.y, in.z, in.n);
     if (in.t) raw->setTimestamps(in.t, in.n);
-    check(mh_scan_preprocess(raw->handle(), &pp, ms->handle(), is->handle()), "mh_scan_preprocess (prefetch)");
+    if (batcher) {
+      std::string err;
+      const mh_status st = batcher->preprocess(raw->handle(), &pp, ms->handle(), is->handle(), &err);
+      if (st != MH_OK) throw std::runtime_error("mh_scan_preprocess (prefetch, batched): " + err);
+    } else {
+      check(mh_scan_preprocess(raw->handle(), &pp, ms->handle(), is->handle()), "mh_scan_preprocess (prefetch)");
+    }
     ctx->synchronize();
   };
   if (molahip_host::FiberScheduler::in_fiber()) pf_->done_fiber = molahip_host::FiberScheduler::current()->spawn(work);

@@ -350,10 +350,13 @@ int main(int argc, char** argv) {
     // the batcher's view of a round (all scans, warm-up included): waiting for the last sequence to arrive / the batch call
     const double nb = batcher_keep && batcher_keep->batches() ? (double)batcher_keep->batches() : 1.0;
     printf("{\"sequences\": %zu, \"scans\": %zu, \"wall_seconds\": %.6f, \"scans_per_s\": %.3f, \"steady_scans_per_s\": %.3f, "
-           "\"batches\": %zu, \"jobs_per_batch\": %.2f, \"ms_per_batch_assembling\": %.4f, \"ms_per_batch_running\": %.4f}\n",
+           "\"batches\": %zu, \"jobs_per_batch\": %.2f, \"ms_per_batch_assembling\": %.4f, \"ms_per_batch_running\": %.4f, "
+           "\"filter_batches\": %zu, \"filter_jobs\": %zu, \"filter_timeouts\": %zu}\n",
            N, total, wall, wall > 0 ? total / wall : 0.0, slowest > 0 ? steady / slowest : 0.0,
            batcher_keep ? batcher_keep->batches() : (size_t)0, batcher_keep ? batcher_keep->jobs() / nb : 0.0,
-           batcher_keep ? 1e3 * batcher_keep->secondsAssembling() / nb : 0.0, batcher_keep ? 1e3 * batcher_keep->secondsRunning() / nb : 0.0);
+           batcher_keep ? 1e3 * batcher_keep->secondsAssembling() / nb : 0.0, batcher_keep ? 1e3 * batcher_keep->secondsRunning() / nb : 0.0,
+           batcher_keep ? batcher_keep->filterBatches() : (size_t)0, batcher_keep ? batcher_keep->filterJobs() : (size_t)0,
+           batcher_keep ? batcher_keep->filterTimeouts() : (size_t)0);
   }
   return rc;
 }
