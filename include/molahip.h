@@ -256,6 +256,13 @@ MH_API mh_status mh_scan_preprocess_batch(size_t n_jobs, const mh_scan* const* r
  * `in` may belong to another context of the same device (a layer prepared on a second stream whose work the caller
  * has synchronised); the kernel is ordered on `out`'s stream. */
 MH_API mh_status mh_scan_deskew(const mh_scan* in, const double twist[6], mh_scan* out);
+/* Both layers of a scan (`a`: the large one for the map, `b`: the small one for the ICP) de-skewed by ONE launch, which
+ * also leaves the bounding box of the de-skewed `b` -- the input of the sensor-range low-pass that runs next
+ * (LidarOdometry.cpp:744, 1515-1545) -- in host memory: one launch and one wait on the per-scan chain instead of
+ * mh_scan_deskew x 2 + mh_scan_bbox.  Same results bit for bit; falls back to those calls for copies (twist NULL or no
+ * time stamps), empty layers and a `b` above 65536 points. */
+MH_API mh_status mh_scan_deskew_pair(const mh_scan* in_a, const mh_scan* in_b, const double twist[6], mh_scan* out_a,
+                                     mh_scan* out_b, float bb_min[3], float bb_max[3], uint64_t* n_finite);
 /* Axis-aligned bounding box of the finite points (CPointsMap::boundingBox [U], used by the sensor-range estimate at
  * LidarOdometry.cpp:1503-1508, 1517-1534).  n_finite (nullable) = number of finite points; zeros for an empty scan. */
 MH_API mh_status mh_scan_bbox(const mh_scan* scan, float bb_min[3], float bb_max[3], uint64_t* n_finite);

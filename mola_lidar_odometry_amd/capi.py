@@ -153,6 +153,7 @@ _SIGNATURES = {
     "mh_scan_preprocess_batch": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(PreprocessParams), C.c_size_t,
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mh_scan_deskew": (C.c_int32, [C.c_void_p, _DP, C.c_void_p]),
+    "mh_scan_deskew_pair": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_void_p, C.c_void_p, _FP, _FP, C.POINTER(C.c_uint64)]),
     "mh_set_wait_hook": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "mh_host_alloc_pinned": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "mh_host_free_pinned": (C.c_int32, [C.c_void_p]),
@@ -373,6 +374,14 @@ class Scan:
         """1st-pass observation filters on the device (mh_scan_preprocess): self = raw scan."""
         _chk(lib().mh_scan_preprocess(self._h, C.byref(params), out_map._h, out_icp._h if out_icp is not None else None))
         return out_map, out_icp
+
+    def deskew_pair(self, small: "Scan", twist, out: "Scan", out_small: "Scan"):
+        """mh_scan_deskew_pair: self = the large layer; returns (bb_min, bb_max, n_finite) of the de-skewed small layer"""
+        tw = None if twist is None else np.ascontiguousarray(twist, dtype=np.float64)
+        mn, mx, nf = np.zeros(3, np.float32), np.zeros(3, np.float32), C.c_uint64(0)
+        _chk(lib().mh_scan_deskew_pair(self._h, small._h, tw.ctypes.data_as(_DP) if tw is not None else None, out._h, out_small._h,
+                                       mn.ctypes.data_as(_FP), mx.ctypes.data_as(_FP), C.byref(nf)))
+        return mn, mx, nf.value
 
     def deskew(self, twist, out: "Scan"):
         tw = None if twist is None else np.ascontiguousarray(twist, dtype=np.float64)

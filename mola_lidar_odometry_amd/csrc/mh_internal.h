@@ -190,7 +190,7 @@ struct mh_map {
   uint64_t n_offered = 0, table_size = 0;
   mh::DevBuf merge;  // mh_map_insert staging: x | y | z | src of (stored + new) points
   mutable float bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
-  uint32_t* h_counts = nullptr;          // pinned [16]: what k_sizes / k_scatter / k_ndt_stats left in the device counters
+  uint32_t* h_counts = nullptr;          // pinned [16]: what k_scatter / k_ndt_stats left in the device counters
   hipEvent_t ev_counts = nullptr;        // recorded behind that copy: "the last (re)build is complete"
   mutable bool counts_pending = false;   // n_points ... bbox above are stale until map_resolve() has seen ev_counts
   mutable bool build_in_flight = false;  // the last (re)build may still run on `side`: order consumers with map_ready_on()

@@ -227,11 +227,15 @@ __global__ void k_scatter(const float* __restrict__ x, const float* __restrict__
                           const uint32_t* __restrict__ head, const uint32_t* __restrict__ vid1,
                           const uint32_t* __restrict__ vstart, const uint32_t* __restrict__ keep,
                           const uint32_t* __restrict__ outpos, uint32_t n, uint32_t cap,
-                          const uint32_t* __restrict__ counters /* [9] = number of voxels (k_sizes) */, float4* __restrict__ pts,
+                          uint32_t* __restrict__ counters /* [9], [10]: voxel and record totals, written here */, float4* __restrict__ pts,
                           unsigned long long* __restrict__ vox_keys, uint32_t* __restrict__ vox_first,
                           uint32_t* __restrict__ vox_count, uint32_t* __restrict__ bbox /*6 ordered uints*/,
                           uint32_t ndt, const uint32_t* __restrict__ src_ids /*null: identity*/) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {  // voxel and record totals (the last elements of the two scans) next to the other counters: they stay on
+    counters[9] = vid1[n - 1];  // the device for k_ndt_stats / k_table_insert and travel with the one read-back
+    counters[10] = outpos[n - 1] + keep[n - 1];
+  }
   float px = 0, py = 0, pz = 0;
   bool kept = false;
   if (i < n && (keep[i] & 1u)) {  // bit 0 = point kept (head elements of NDT maps carry +2 for their two records)
@@ -243,7 +247,7 @@ __global__ void k_scatter(const float* __restrict__ x, const float* __restrict__
     if (head[i]) {
       // stored points of this voxel = records between this head and the next one, minus the two NDT records
       const uint32_t v = vid1[i] - 1;
-      const uint32_t n_vox = counters[9];
+      const uint32_t n_vox = vid1[n - 1];
       const uint32_t total_records = outpos[n - 1] + keep[n - 1];
       const uint32_t next = (v + 1 < n_vox) ? outpos[vstart[v + 1]] : total_records;
       vox_keys[v] = ks[i];
@@ -475,16 +479,12 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
 namespace mh {
 
 // counters: [0] range flag  [1] n_valid  [2..7] bbox (ordered uints)  [8] planes  [9] voxels  [10] records
-__global__ void k_init_counters(uint32_t* __restrict__ c) {
-  const uint32_t i = threadIdx.x;
-  if (i < 16) c[i] = (i >= 2 && i <= 4) ? 0xFFFFFFFFu : 0u;
-}
-
-// voxel and record totals (last elements of the two scans) next to the other counters
-__global__ void k_sizes(const uint32_t* __restrict__ vid1, const uint32_t* __restrict__ outpos,
-                        const uint32_t* __restrict__ keep, uint32_t n, uint32_t* __restrict__ out) {
-  out[0] = vid1[n - 1];
-  out[1] = outpos[n - 1] + keep[n - 1];
+// ... and the empty slot table of the rebuild, in the same launch
+__global__ __launch_bounds__(256) void k_init_build(uint32_t* __restrict__ c, uint4* __restrict__ slots, uint32_t n_slots) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid < 16) c[tid] = (tid >= 2 && tid <= 4) ? 0xFFFFFFFFu : 0u;
+  const uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  for (uint32_t i = tid; i < n_slots; i += gridDim.x * blockDim.x) slots[i] = e;
 }
 
 mh_status map_resolve(const mh_map* m) {
@@ -538,9 +538,11 @@ mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const floa
   MH_TRY(m->build_e.reserve((n ? n : 1) * sizeof(uint32_t) + 64));  // vstart | counters(16)
   uint32_t* vstart = m->build_e.as<uint32_t>();
   uint32_t* counters = vstart + (n ? n : 1);
-  hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(64), 0, s, counters);
   MH_TRY(m->slots.reserve(tsize * sizeof(MapSlot)));
-  MH_HIP(hipMemsetAsync(m->slots.p, 0xFF, tsize * sizeof(MapSlot), s));
+  {
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((tsize + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_init_build, dim3(blocks), dim3(256), 0, s, counters, reinterpret_cast<uint4*>(m->slots.p), (uint32_t)tsize);
+  }
   if (n > 0) {
     const uint32_t N = (uint32_t)n;
     // scratch carve-up
@@ -609,7 +611,6 @@ mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const floa
     if (ndt) hipLaunchKernelGGL(k_add_ndt_slots, dim3(nblk(n, B)), dim3(B), 0, s, head, N, keep);
     tb = m->sort_tmp.bytes;
     MH_HIP(rocprim::exclusive_scan(m->sort_tmp.p, tb, keep, outpos, 0u, N, rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL(k_sizes, dim3(1), dim3(1), 0, s, vid1, outpos, keep, N, counters + 9);  // voxels, records: stay on the device
 
     MH_TRY(m->pts.reserve(n_rec_ub * sizeof(float4)));
     MH_TRY(m->vox_keys.reserve(n_vox_ub * sizeof(unsigned long long)));

@@ -243,6 +243,16 @@ __global__ __launch_bounds__(256) void k_pp_bbox(const float* __restrict__ x, co
 
 struct Twist { double v[6]; };
 
+__device__ __forceinline__ void deskew_point(const Twist& tw, float x, float y, float z, float tf, float& gx, float& gy, float& gz) {
+  const double dt = (double)tf;
+  const double xi[6] = {0.0, 0.0, 0.0, tw.v[3] * dt, tw.v[4] * dt, tw.v[5] * dt};
+  Pose p = se3_exp(xi);  // zero translation part: pure Exp_SO3(w dt)
+  p.t(0) = tw.v[0] * dt;
+  p.t(1) = tw.v[1] * dt;
+  p.t(2) = tw.v[2] * dt;
+  transform_point(p.m, x, y, z, gx, gy, gz);
+}
+
 __global__ void k_pp_deskew(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                             const float* __restrict__ t, const uint32_t* __restrict__ src, uint32_t n, Twist tw,
                             float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
@@ -252,17 +262,81 @@ __global__ void k_pp_deskew(const float* __restrict__ x, const float* __restrict
   const float tf = t[i];
   ot[i] = tf;
   if (src) osrc[i] = src[i];
-  const double dt = (double)tf;
-  const double xi[6] = {0.0, 0.0, 0.0, tw.v[3] * dt, tw.v[4] * dt, tw.v[5] * dt};
-  Pose p = se3_exp(xi);  // zero translation part: pure Exp_SO3(w dt)
-  p.t(0) = tw.v[0] * dt;
-  p.t(1) = tw.v[1] * dt;
-  p.t(2) = tw.v[2] * dt;
   float gx, gy, gz;
-  transform_point(p.m, x[i], y[i], z[i], gx, gy, gz);
+  deskew_point(tw, x[i], y[i], z[i], tf, gx, gy, gz);
   ox[i] = gx;
   oy[i] = gy;
   oz[i] = gz;
+}
+
+// Both layers of a scan in one launch, and the bounding box of the de-skewed SMALL layer (what the sensor-range estimate
+// reads next, LidarOdometry.cpp:744) straight into page-locked host memory: workgroup 0 walks the small layer and
+// reduces its box, the others take 1024 points of the large layer each.  One launch and one wait instead of three
+// launches and a wait -- on a path where every launch is a dependent step of the per-scan chain.
+struct DeskewLayer {
+  const float *x, *y, *z, *t;
+  const uint32_t* src;
+  float *ox, *oy, *oz, *ot;
+  uint32_t* osrc;
+  uint32_t n;
+};
+
+__global__ __launch_bounds__(1024) void k_pp_deskew_pair(DeskewLayer big, DeskewLayer small, Twist tw, uint32_t* __restrict__ host_out) {
+  if (blockIdx.x > 0) {
+    const uint32_t i = (blockIdx.x - 1) * 1024 + threadIdx.x;
+    if (i >= big.n) return;
+    const float tf = big.t[i];
+    big.ot[i] = tf;
+    if (big.src) big.osrc[i] = big.src[i];
+    float gx, gy, gz;
+    deskew_point(tw, big.x[i], big.y[i], big.z[i], tf, gx, gy, gz);
+    big.ox[i] = gx;
+    big.oy[i] = gy;
+    big.oz[i] = gz;
+    return;
+  }
+  __shared__ uint32_t sh[16][7];
+  uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u}, cnt = 0;
+  for (uint32_t i = threadIdx.x; i < small.n; i += 1024) {
+    const float tf = small.t[i];
+    small.ot[i] = tf;
+    if (small.src) small.osrc[i] = small.src[i];
+    float p[3];
+    deskew_point(tw, small.x[i], small.y[i], small.z[i], tf, p[0], p[1], p[2]);
+    small.ox[i] = p[0];
+    small.oy[i] = p[1];
+    small.oz[i] = p[2];
+    if (isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2])) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const uint32_t o = f2ord(p[a]);
+        mn[a] = min(mn[a], o);
+        mx[a] = max(mx[a], o);
+      }
+      cnt++;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      mn[a] = min(mn[a], (uint32_t)__shfl_xor((int)mn[a], off));
+      mx[a] = max(mx[a], (uint32_t)__shfl_xor((int)mx[a], off));
+    }
+    cnt += (uint32_t)__shfl_xor((int)cnt, off);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { sh[w][a] = mn[a]; sh[w][3 + a] = mx[a]; }
+    sh[w][6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int a = threadIdx.x;
+    uint32_t v = sh[0][a];
+    for (int q = 1; q < 16; q++) v = a < 3 ? min(v, sh[q][a]) : (a < 6 ? max(v, sh[q][a]) : v + sh[q][a]);
+    host_out[a] = v;
+  }
 }
 
 // interleaved records (step/offsets in 4-byte words) -> SoA
@@ -734,6 +808,55 @@ mh_status mh_scan_deskew(const mh_scan* in, const double twist[6], mh_scan* out)
     MH_HIP(hipMemcpyAsync((void*)out->y, in->y, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     MH_HIP(hipMemcpyAsync((void*)out->z, in->z, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
+  return MH_OK;
+}
+
+static void bbox_from_words(const uint32_t h[8], float bb_min[3], float bb_max[3], uint64_t* n_finite) {
+  auto ord = [](uint32_t u) { u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &u, 4); return f; };
+  for (int a = 0; a < 3; a++) {
+    bb_min[a] = h[6] ? ord(h[a]) : 0.f;
+    bb_max[a] = h[6] ? ord(h[3 + a]) : 0.f;
+  }
+  if (n_finite) *n_finite = h[6];
+}
+
+mh_status mh_scan_deskew_pair(const mh_scan* in_a, const mh_scan* in_b, const double twist[6], mh_scan* out_a, mh_scan* out_b,
+                              float bb_min[3], float bb_max[3], uint64_t* n_finite) {
+  MH_REQUIRE(in_a && in_b && out_a && out_b && bb_min && bb_max, "null argument");
+  MH_REQUIRE(in_a != out_a && in_b != out_b && out_a != out_b && in_a != out_b && in_b != out_a, "the four scans must be distinct");
+  MH_REQUIRE(out_a->ctx == out_b->ctx, "the outputs belong to different contexts");
+  mh_ctx* ctx = out_a->ctx;
+  const bool fused = twist && in_a->t && in_b->t && in_a->n && in_b->n && in_b->n <= 65536 && in_a->n < 0x7FFFFF00ull &&
+                     in_a->ctx->device == ctx->device && in_b->ctx->device == ctx->device;
+  if (!fused) {  // copies (skip_deskew / no time stamps), empty or huge layers: the separate calls
+    MH_TRY(mh_scan_deskew(in_a, twist, out_a));
+    MH_TRY(mh_scan_deskew(in_b, twist, out_b));
+    return mh_scan_bbox(out_b, bb_min, bb_max, n_finite);
+  }
+  MH_TRY(set_device(ctx));
+  hipStream_t s = ctx->stream;
+  Twist tw;
+  for (int i = 0; i < 6; i++) {
+    MH_REQUIRE(isfinite(twist[i]), "non-finite twist");
+    tw.v[i] = twist[i];
+  }
+  MH_TRY(scan_alloc(out_a, in_a->n, true, in_a->src != nullptr));
+  MH_TRY(scan_alloc(out_b, in_b->n, true, in_b->src != nullptr));
+  if (!ctx->h_small) MH_HIP(hipHostMalloc((void**)&ctx->h_small, 64 * sizeof(uint32_t), hipHostMallocDefault));
+  auto layer = [](const mh_scan* in, mh_scan* out) {
+    DeskewLayer l;
+    l.x = in->x; l.y = in->y; l.z = in->z; l.t = in->t; l.src = in->src;
+    l.ox = (float*)out->x; l.oy = (float*)out->y; l.oz = (float*)out->z; l.ot = (float*)out->t; l.osrc = (uint32_t*)out->src;
+    l.n = (uint32_t)in->n;
+    return l;
+  };
+  hipLaunchKernelGGL(k_pp_deskew_pair, dim3(1 + nblk(in_a->n, 1024)), dim3(1024), 0, s, layer(in_a, out_a), layer(in_b, out_b), tw,
+                     ctx->h_small);
+  MH_HIP(hipGetLastError());
+  MH_HIP(mh::wait_stream(s));
+  uint32_t h[8];
+  for (int a = 0; a < 7; a++) h[a] = ctx->h_small[a];
+  bbox_from_words(h, bb_min, bb_max, n_finite);
   return MH_OK;
 }
 

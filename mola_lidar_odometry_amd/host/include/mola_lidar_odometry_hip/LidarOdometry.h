@@ -210,6 +210,7 @@ class LidarOdometry {
   // prefetch: a second context (stream + scratch) used by the worker thread only, with two sets of raw / skewed layers
   // filled alternately (the current scan may still re-de-skew from its set while the next one is being prepared)
   std::shared_ptr<DeviceContext> ctx_b_;
+  float icp_bb_min_[3] = {0, 0, 0}, icp_bb_max_[3] = {0, 0, 0};  // bounding box of for_icp_ (run_second_pass)
   std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher_;  // set: filters and alignments join those of the other sequences
   std::shared_ptr<DevicePointCloud> raw_b_[2], map_skewed_b_[2], icp_skewed_b_[2];
   std::shared_ptr<DevicePointCloud> cur_raw_, cur_map_skewed_, cur_icp_skewed_;  // the set the current scan reads

@@ -596,8 +596,9 @@ void LidarOdometry::run_second_pass() {
   const auto& v = source_.getVariableValues();
   const double tw[6] = {v.at("vx"), v.at("vy"), v.at("vz"), v.at("wx"), v.at("wy"), v.at("wz")};
   const double* twp = plan_->skip_deskew ? nullptr : tw;
-  check(mh_scan_deskew(cur_map_skewed_->handle(), twp, for_map_->handle()), "mh_scan_deskew");
-  check(mh_scan_deskew(cur_icp_skewed_->handle(), twp, for_icp_->handle()), "mh_scan_deskew");
+  // both layers and the bounding box of the de-skewed ICP layer (read by the sensor-range estimate right below) at once
+  check(mh_scan_deskew_pair(cur_map_skewed_->handle(), cur_icp_skewed_->handle(), twp, for_map_->handle(), for_icp_->handle(),
+                            icp_bb_min_, icp_bb_max_, nullptr), "mh_scan_deskew_pair");
 }
 
 void LidarOdometry::doUpdateAdaptiveThreshold(const CPose3D& err) {  // :1449-1485 (KISS-ICP's scheme)
@@ -740,9 +741,7 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
   // sensor range low-pass from the first point layer of the observation, 'decimated_for_icp' (:744, 1515-1545)
   if (estimated_sensor_max_range_) {
     StageTimer tt(profile_, "onLidar.2.sensor_range");
-    float mn[3], mx[3];
-    for_icp_->boundingBox(mn, mx);
-    const double radius = std::max(bbox_radius(mn, mx), params_.absolute_minimum_sensor_range);
+    const double radius = std::max(bbox_radius(icp_bb_min_, icp_bb_max_), params_.absolute_minimum_sensor_range);  // (run_second_pass)
     instantaneous_sensor_max_range_ = radius;
     const double a = params_.max_sensor_range_filter_coefficient;
     estimated_sensor_max_range_ = *estimated_sensor_max_range_ * a + radius * (1.0 - a);

@@ -173,6 +173,41 @@ def test_deskew(ctx, oracle, small_workload):
     np.testing.assert_array_equal(out.download()["xyz"], xyz)
 
 
+def test_deskew_pair_equals_separate_calls(ctx, small_workload):
+    """mh_scan_deskew_pair: both layers + the bounding box of the de-skewed small one in one launch == mh_scan_deskew x 2 +
+    mh_scan_bbox, bit for bit; the fallbacks (no twist, no time stamps, an empty layer) as well."""
+    xyz, t = _raw(4, small_workload)
+    raw = capi.Scan(ctx, xyz).set_timestamps(t)
+    big, small = capi.Scan(ctx), capi.Scan(ctx)
+    raw.preprocess(capi.preprocess_params(0.3, 1.2, min_points_to_filter=100, timestamp_method=capi.TS_MIDDLE_IS_ZERO), big, small)
+    assert 0 < small.n < big.n
+    tw = np.array([11.0, 0.4, -0.05, 0.02, -0.01, 0.5])
+    for twist in (tw, None):
+        a, b, a1, b1 = capi.Scan(ctx), capi.Scan(ctx), capi.Scan(ctx), capi.Scan(ctx)
+        mn, mx, nf = big.deskew_pair(small, twist, a, b)
+        big.deskew(twist, a1)
+        small.deskew(twist, b1)
+        for got, want in ((a, a1), (b, b1)):
+            dg, dw = got.download(), want.download()
+            for key in ("xyz", "t", "src_idx"):
+                np.testing.assert_array_equal(dg[key], dw[key])
+        mn1, mx1, nf1 = b1.bbox()
+        np.testing.assert_array_equal(mn, mn1)
+        np.testing.assert_array_equal(mx, mx1)
+        assert nf == nf1 == small.n
+    # a layer without time stamps / an empty small layer: the separate calls behind the same entry point
+    nots_big, nots_small = capi.Scan(ctx, xyz[:5000]), capi.Scan(ctx, xyz[:300])
+    a, b = capi.Scan(ctx), capi.Scan(ctx)
+    mn, mx, nf = nots_big.deskew_pair(nots_small, tw, a, b)
+    np.testing.assert_array_equal(b.download()["xyz"], xyz[:300])
+    assert nf == np.isfinite(xyz[:300]).all(axis=1).sum()
+    empty = capi.Scan(ctx)
+    mn, mx, nf = big.deskew_pair(empty, tw, a, b)
+    assert nf == 0 and b.n == 0 and a.n == big.n
+    with pytest.raises(capi.MolahipError):
+        big.deskew_pair(small, tw, a, a)
+
+
 def _assert_maps_equal(g, o):
     for k in ("vox_keys", "vox_first", "vox_count", "src_idx", "xyz"):
         np.testing.assert_array_equal(g[k], o[k], err_msg=k)
