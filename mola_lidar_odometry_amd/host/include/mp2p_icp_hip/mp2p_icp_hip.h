@@ -486,6 +486,9 @@ class ICP {
   // false: Results::finalPairings stays empty in the fused path (the odometry driver never reads it)
   void setKeepFinalPairings(bool v) { keep_pairings_ = v; }
   void forceGenericPath(bool v) { force_generic_ = v; }
+  // evaluate the per-iteration thresholds of the fused path NOW, on the variables' current values; the next align()
+  // re-uses them if the variables its formulas read still have these values (anything else: evaluated again, as before)
+  void precomputeSchedule(uint32_t n_iterations);
 
  private:
   bool can_fuse() const;
@@ -495,6 +498,12 @@ class ICP {
   void align_generic(const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const CPose3D& guess, const Parameters& p,
                      Results& result, const std::optional<CPose3DPDFGaussianInf>& prior);
   void realize_iteration(uint32_t k);
+  void prepare_schedule(uint32_t n_iterations);
+  struct Schedule {
+    bool valid = false;
+    std::vector<double> key;  // values of the variables the formulas read (ICP_ITERATION = 0)
+    std::vector<double> thr, kp, plthr;
+  } sched_;
 
   std::shared_ptr<DeviceContext> ctx_;
   std::vector<Matcher::Ptr> matchers_;

@@ -814,6 +814,51 @@ static void write_debug_file(const Parameters& p, const CPose3D& guess, const mh
   fclose(f);
 }
 
+// The thresholds are functions of ICP_ITERATION only once the caller's variables are fixed (LidarOdometry.cpp:1571-1635
+// publishes them before align): all iterations evaluated up front.  The result is kept with the VALUES of the variables
+// the formulas read, so that a caller who knows them early (the odometry driver, while the device is busy with the
+// key-frame update of the previous scan) can have the work done before align() needs it: 300 iterations x 2-3 formulas
+// were 40 us of a 1 ms scan with the device idle.
+void ICP::prepare_schedule(uint32_t n_iterations) {
+  auto m = std::static_pointer_cast<Matcher_Points_DistanceThreshold>(matchers_.back());
+  auto s = std::static_pointer_cast<Solver_GaussNewton>(solvers_[0]);
+  auto mpl = matchers_.size() == 2 ? std::static_pointer_cast<Matcher_Point2Plane>(matchers_[0]) : nullptr;
+  // formulas compiled once and bound to one copy of the variables; only ICP_ITERATION is swept (in place)
+  std::map<std::string, double> vars = source_ ? source_->getVariableValues() : own_source_.getVariableValues();
+  double& it_var = vars["ICP_ITERATION"];
+  it_var = 0.0;
+  const auto bm = m->bind(vars);
+  const auto bs = s->bind(vars);
+  Parameterizable::Binding bp;
+  if (mpl) bp = mpl->bind(vars);
+  std::vector<double> key;
+  for (const Parameterizable::Binding* b : {&bm, &bs, (const Parameterizable::Binding*)&bp})
+    for (const auto& item : b->items)
+      for (const double* v : item.second) key.push_back(*v);
+  if (sched_.valid && sched_.key == key && sched_.thr.size() >= n_iterations) return;
+  sched_.valid = false;
+  sched_.key = key;
+  sched_.thr.assign(n_iterations, 0.0);
+  sched_.kp.assign(n_iterations, 0.0);
+  sched_.plthr.assign(n_iterations, 0.0);
+  for (uint32_t k = 0; k < n_iterations; k++) {
+    it_var = (double)k;
+    bm.realize();
+    bs.realize();
+    bp.realize();
+    sched_.thr[k] = m->threshold;
+    sched_.kp[k] = s->robustKernelParam;
+    if (mpl) sched_.plthr[k] = mpl->distanceThreshold;
+  }
+  sched_.valid = true;
+}
+
+void ICP::precomputeSchedule(uint32_t n_iterations) {
+  if (!can_fuse() || !n_iterations) return;
+  prepare_schedule(n_iterations);
+  realize_iteration(0);  // (the members the formulas write are left as align() leaves them)
+}
+
 void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_local, const HashedVoxelPointCloud& global,
                       const CPose3D& guess, const Parameters& p, Results& result,
                       const std::optional<CPose3DPDFGaussianInf>& prior) {
@@ -823,25 +868,8 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
   // the thresholds are functions of ICP_ITERATION only once the caller's variables are fixed for this call
   // (LidarOdometry.cpp:1571-1635 publishes them before align): evaluate them for every iteration up front
   const auto t_setup0 = std::chrono::steady_clock::now();
-  std::vector<double> thr(p.maxIterations), kp(p.maxIterations), plthr(p.maxIterations);
-  {
-    // formulas compiled once and bound to one copy of the variables; only ICP_ITERATION is swept (in place)
-    std::map<std::string, double> vars = source_ ? source_->getVariableValues() : own_source_.getVariableValues();
-    double& it_var = vars["ICP_ITERATION"];
-    const auto bm = m->bind(vars);
-    const auto bs = s->bind(vars);
-    Parameterizable::Binding bp;
-    if (mpl) bp = mpl->bind(vars);
-    for (uint32_t k = 0; k < p.maxIterations; k++) {
-      it_var = (double)k;
-      bm.realize();
-      bs.realize();
-      bp.realize();
-      thr[k] = m->threshold;
-      kp[k] = s->robustKernelParam;
-      if (mpl) plthr[k] = mpl->distanceThreshold;
-    }
-  }
+  prepare_schedule(p.maxIterations);  // (a no-op when precomputeSchedule() ran on the same values of the variables)
+  const std::vector<double>&thr = sched_.thr, &kp = sched_.kp, &plthr = sched_.plthr;
   if (p.maxIterations) realize_iteration(0);
   mh_icp_params ip{};
   ip.max_iterations = p.maxIterations;

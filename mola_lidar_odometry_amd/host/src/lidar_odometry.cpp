@@ -910,6 +910,9 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
     map_counts_pending_ = true;
     map_counts_from_ = records_.size() - 1;
   }
+  // the next alignment's threshold schedules while the device works on the map update (the formulas' variables -- the
+  // adaptive sigma -- are final for this scan; align() checks the values and evaluates again if they differ after all)
+  if (icp_[0] && local_map_) icp_[0]->precomputeSchedule(icp_params_[0].maxIterations);
   rec.pose = last_lidar_pose_;
   rec.sigma = adapt_thres_sigma_;
   rec.map_voxel_size = map_voxel_size_;
