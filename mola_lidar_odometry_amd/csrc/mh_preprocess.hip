@@ -379,14 +379,20 @@ struct PpJob {
 __global__ __launch_bounds__(256) void k_pp_init_b(const PpJob* __restrict__ jobs) {
   const PpJob& j = jobs[blockIdx.y];
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-  if (tid < 8) j.counters[tid] = tid == 0 ? 0xFFFFFFFFu : 0u;
+  // (pointers that arrive through the descriptor are generic to the compiler: G() spells the global space out, or every
+  // access below becomes a flat_ instruction -- the decimation's CAS loop ran at half its speed that way)
+  if (tid < 8) G(j.counters)[tid] = tid == 0 ? 0xFFFFFFFFu : 0u;
+  unsigned long long MH_AS_GLOBAL* k1 = G(j.keys1);
+  unsigned long long MH_AS_GLOBAL* k2 = G(j.keys2);
+  uint32_t MH_AS_GLOBAL* f1 = G(j.first1);
+  uint32_t MH_AS_GLOBAL* f2 = G(j.first2);
   for (uint32_t i = tid; i < j.tsize1; i += stride) {
-    j.keys1[i] = kEmptyKey;
-    j.first1[i] = 0xFFFFFFFFu;
+    k1[i] = kEmptyKey;
+    f1[i] = 0xFFFFFFFFu;
   }
   for (uint32_t i = tid; i < j.tsize2; i += stride) {
-    j.keys2[i] = kEmptyKey;
-    j.first2[i] = 0xFFFFFFFFu;
+    k2[i] = kEmptyKey;
+    f2[i] = 0xFFFFFFFFu;
   }
 }
 
@@ -395,8 +401,9 @@ __global__ __launch_bounds__(256) void k_pp_tminmax_b(const PpJob* __restrict__ 
   if (!j.t || j.s1.ts_method == MH_TS_NONE) return;
   __shared__ uint32_t smn[4], smx[4];
   uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+  const float MH_AS_GLOBAL* gt = G(j.t);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < j.n; i += gridDim.x * blockDim.x) {
-    const uint32_t o = f2ord(j.t[i]);
+    const uint32_t o = f2ord(gt[i]);
     mn = min(mn, o);
     mx = max(mx, o);
   }
@@ -427,7 +434,7 @@ __device__ __forceinline__ void pp_stage_view(const PpJob& j, const float*& x, c
     keys = j.keys1; first = j.first1; mask = j.tsize1 - 1;
   } else {
     x = j.mx; y = j.my; z = j.mz;
-    n = j.counters[3];
+    n = G(j.counters)[3];
     sp = j.s2;
     if (n < j.min_points) sp.decimate = 0;
     keys = j.keys2; first = j.first2; mask = j.tsize2 - 1;
@@ -439,22 +446,33 @@ __global__ __launch_bounds__(256) void k_pp_insert_b(const PpJob* __restrict__ j
   const PpJob& j = jobs[blockIdx.y];
   if (STAGE == 2 && !j.want_icp) return;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= j.n) return;
+  if (blockIdx.x * blockDim.x >= j.n) return;  // (whole workgroup beyond the scan: the lanes below stay together)
   const float *x, *y, *z;
   uint32_t n, mask, *first;
   unsigned long long* keys;
   StageParams sp;
   pp_stage_view<STAGE>(j, x, y, z, n, sp, keys, first, mask);
-  if (i >= n || !sp.decimate) return;
-  unsigned long long key;
-  if (!pp_key(x[i], y[i], z[i], sp.inv_res, sp.trunc, key, j.counters)) return;
+  if (!sp.decimate) return;  // (uniform)
+  unsigned long long key = kEmptyKey;
+  bool live = i < n;
+  if (live) live = pp_key(G(x)[i], G(y)[i], G(z)[i], sp.inv_res, sp.trunc, key, j.counters);
+  if (!live) key = kEmptyKey;
+  // A sensor delivers its points ring by ring, so neighbours in the array are neighbours in space: of a run of lanes
+  // with the same voxel only the first touches the table -- it holds the run's smallest index, which is all the others
+  // could contribute (atomicMin), and the claim of the entry is the same.  Fewer same-address atomics, same table.
+  const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+  const uint32_t plo = (uint32_t)__shfl_up((int)lo, 1), phi = (uint32_t)__shfl_up((int)hi, 1);
+  const bool same_as_previous_lane = (threadIdx.x & 63) != 0 && plo == lo && phi == hi;
+  if (!live || same_as_previous_lane) return;
+  unsigned long long MH_AS_GLOBAL* gkeys = G(keys);
   uint32_t h = hash_key(key) & mask;
   for (;;) {
-    const unsigned long long old = atomicCAS(&keys[h], kEmptyKey, key);
-    if (old == kEmptyKey || old == key) break;
+    unsigned long long old = kEmptyKey;
+    if (__hip_atomic_compare_exchange_strong(&gkeys[h], &old, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || old == key)
+      break;
     h = (h + 1) & mask;
   }
-  atomicMin(&first[h], i);
+  (void)__hip_atomic_fetch_min(&G(first)[h], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int STAGE>
@@ -472,15 +490,16 @@ __global__ __launch_bounds__(256) void k_pp_flag_b(const PpJob* __restrict__ job
   StageParams sp;
   pp_stage_view<STAGE>(j, x, y, z, n, sp, keys, first, mask);
   const bool valid = i < n;
-  const float px = valid ? x[i] : 0.f, py = valid ? y[i] : 0.f, pz = valid ? z[i] : 0.f;
+  const float px = valid ? G(x)[i] : 0.f, py = valid ? G(y)[i] : 0.f, pz = valid ? G(z)[i] : 0.f;
   bool keep = valid && isfinite(px) && isfinite(py) && isfinite(pz);
   if (keep && sp.decimate) {
     unsigned long long key;
     keep = pp_key(px, py, pz, sp.inv_res, sp.trunc, key, j.counters);
     if (keep) {
+      const unsigned long long MH_AS_GLOBAL* gkeys = G(keys);
       uint32_t h = hash_key(key) & mask;
-      while (keys[h] != key) h = (h + 1) & mask;  // inserted by k_pp_insert_b
-      keep = first[h] == i;
+      while (gkeys[h] != key) h = (h + 1) & mask;  // inserted by k_pp_insert_b
+      keep = G(first)[h] == i;
     }
   }
   if (keep && sp.range_on) {
@@ -494,8 +513,8 @@ __global__ __launch_bounds__(256) void k_pp_flag_b(const PpJob* __restrict__ job
     keep = inside == (sp.bbox_mode == MH_BBOX_KEEP_INSIDE);
   }
   if (i < j.cap) flag[j.off + i] = keep ? 1u : 0u;  // (zeros up to the end of the range: the scan runs over all of it)
-  const unsigned long long kept = __ballot(keep);  // survivor count: one atomic per wavefront
-  if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&j.counters[2 + STAGE], (uint32_t)__popcll(kept));
+  // (the survivor count is the scan's total: k_pp_compact_b writes it -- an atomic per wavefront on ONE address was most
+  // of this kernel's time, 2 k of them for a 120 k-point scan)
 }
 
 // pos = exclusive scan of the flags of ALL scans in a row: a survivor's place in its own output is pos - pos[first of scan]
@@ -505,28 +524,30 @@ __global__ __launch_bounds__(256) void k_pp_compact_b(const PpJob* __restrict__ 
   const PpJob& j = jobs[blockIdx.y];
   if (STAGE == 2 && !j.want_icp) return;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && j.cap)  // survivors of this stage = the exclusive scan's total over the scan's range
+    G(j.counters)[2 + STAGE] = pos[j.off + j.cap - 1] + flag[j.off + j.cap - 1] - pos[j.off];
   if (i >= j.n || !flag[j.off + i]) return;
   const uint32_t o = pos[j.off + i] - pos[j.off];
   if (STAGE == 1) {
-    j.mx[o] = j.x[i];
-    j.my[o] = j.y[i];
-    j.mz[o] = j.z[i];
+    G(j.mx)[o] = G(j.x)[i];
+    G(j.my)[o] = G(j.y)[i];
+    G(j.mz)[o] = G(j.z)[i];
     if (j.want_t) {
-      float tv = j.t[i];
+      float tv = G(j.t)[i];
       if (j.s1.ts_method != MH_TS_NONE) {  // FilterAdjustTimestamps over ALL raw points (it runs before the decimation)
-        const float tmin = ord2f(j.counters[0]), tmax = ord2f(j.counters[1]);
+        const float tmin = ord2f(G(j.counters)[0]), tmax = ord2f(G(j.counters)[1]);
         const float dt = j.s1.ts_method == MH_TS_MIDDLE_IS_ZERO ? 0.5f * (tmin + tmax) : tmin;
         tv = (tv - dt) + j.s1.ts_offset;
       }
-      j.mt[o] = tv;
+      G(j.mt)[o] = tv;
     }
-    j.msrc[o] = j.src ? j.src[i] : i;
+    G(j.msrc)[o] = j.src ? G(j.src)[i] : i;
   } else {
-    j.ix[o] = j.mx[i];
-    j.iy[o] = j.my[i];
-    j.iz[o] = j.mz[i];
-    if (j.want_t) j.it[o] = j.mt[i];  // out_map's stamps are adjusted already
-    j.isrc[o] = j.msrc[i];
+    G(j.ix)[o] = G(j.mx)[i];
+    G(j.iy)[o] = G(j.my)[i];
+    G(j.iz)[o] = G(j.mz)[i];
+    if (j.want_t) G(j.it)[o] = G(j.mt)[i];  // out_map's stamps are adjusted already
+    G(j.isrc)[o] = G(j.msrc)[i];
   }
 }
 

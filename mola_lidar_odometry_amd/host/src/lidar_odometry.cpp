@@ -8,7 +8,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
-#include <future>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <stdexcept>
 
 namespace mola_hip {
@@ -334,17 +337,70 @@ struct LidarOdometry::Prefetch {
   bool requested = false, launched = false;
   int slot = 0;               // which of the two prefetch sets the worker fills / filled
   mh_preprocess_params pp{};  // the filter parameters the worker used
-  // the worker: a thread (std::async) -- or, when this driver itself runs as a fiber of a FiberScheduler, another fiber
-  // of the same thread (no second thread in the HIP runtime; the worker's waits for the filter counts yield)
-  std::future<void> done;
+  // the worker: ONE thread that lives as long as the driver and takes a task per scan (a std::async per scan created a
+  // thread per scan: ~20 us of the main thread's time right before its alignment) -- or, when this driver itself runs
+  // as a fiber of a FiberScheduler, another fiber of the same thread (no second thread in the HIP runtime; the worker's
+  // waits for the filter counts yield)
+  struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> task;
+    bool has_task = false, busy = false, stop = false;
+    std::exception_ptr error;
+    void start() {
+      th = std::thread([this] {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+          cv.wait(lk, [this] { return has_task || stop; });
+          if (stop) return;
+          std::function<void()> t = std::move(task);
+          has_task = false;
+          lk.unlock();
+          std::exception_ptr e;
+          try { t(); } catch (...) { e = std::current_exception(); }
+          lk.lock();
+          error = e;
+          busy = false;
+          cv.notify_all();
+        }
+      });
+    }
+    void submit(std::function<void()> t) {
+      if (!th.joinable()) start();
+      std::lock_guard<std::mutex> lk(m);
+      task = std::move(t);
+      has_task = busy = true;
+      error = nullptr;
+      cv.notify_all();
+    }
+    void wait() {  // rethrows what the task threw
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [this] { return !busy; });
+      if (error) {
+        std::exception_ptr e = error;
+        error = nullptr;
+        std::rethrow_exception(e);
+      }
+    }
+    ~Worker() {
+      if (th.joinable()) {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        th.join();
+      }
+    }
+  } worker;
+  bool on_worker = false;
   molahip_host::FiberScheduler::Handle done_fiber;
   void join() {
     if (done_fiber.valid()) {
       molahip_host::FiberScheduler::Handle h = done_fiber;
       done_fiber = molahip_host::FiberScheduler::Handle();
       h.wait();
-    } else if (done.valid()) {
-      done.get();
+    } else if (on_worker) {
+      on_worker = false;
+      worker.wait();
     }
   }
 };
@@ -587,7 +643,10 @@ void LidarOdometry::launch_prefetch() {
     ctx->synchronize();
   };
   if (molahip_host::FiberScheduler::in_fiber()) pf_->done_fiber = molahip_host::FiberScheduler::current()->spawn(work);
-  else pf_->done = std::async(std::launch::async, work);
+  else {
+    pf_->worker.submit(work);
+    pf_->on_worker = true;
+  }
   pf_->launched = true;
   pf_->requested = false;
 }

@@ -1,0 +1,11 @@
+python -m pytest tests/test_gpu_preprocess.py tests/test_odometry.py -m gpu -x -q 2>&1 | tail -2
+python tools/fuzz_preprocess.py 100 31 | tail -1
+R=$GRAFT_REPO_ROOT
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/po -o po -- env PYTHONPATH=$R python -m mola_lidar_odometry_amd.run_odometry --synthetic 40 --out-dir /tmp/odo > /dev/null 2>&1
+python - <<PY
+import csv,glob
+for r in list(csv.DictReader(open(glob.glob("/tmp/po/**/po_kernel_stats.csv",recursive=True)[0]))):
+    if "k_pp" in r["Name"]: print(r["Name"][:60], r["Calls"], round(float(r["AverageNs"])/1e3,1))
+PY
+cd $R; python tools/scratch/ms_probe.py 150 1,8,8 "" 2>&1 | cut -c1-330 | tail -3
