@@ -384,6 +384,20 @@ class AlignBatcher {
   // mh_scan_preprocess_batch by whoever completes the set.  A request that has waited 1 ms (MOLA_HIP_FILTER_SET_WAIT_US) runs with whatever
   // waits by then: a sequence that skips a scan's filters (no announced next scan, a restart) must not hold the others.
   mh_status preprocess(const mh_scan* raw, const mh_preprocess_params* params, mh_scan* out_map, mh_scan* out_icp, std::string* error);
+  // Participation as a scope: leave() when the object goes away, however the sequence ended (an exception between
+  // construction and the first align() must not leave the others waiting for ever).
+  class Membership {
+   public:
+    explicit Membership(std::shared_ptr<AlignBatcher> b) : b_(std::move(b)) {}
+    ~Membership() {
+      if (b_) b_->leave();
+    }
+    Membership(const Membership&) = delete;
+    Membership& operator=(const Membership&) = delete;
+
+   private:
+    std::shared_ptr<AlignBatcher> b_;
+  };
   // this participant has no filter request for the set now being assembled (no next scan announced): the others' set
   // is complete without it
   void skipFilterRound();

@@ -160,19 +160,11 @@ struct SequenceFeed {
   }
 };
 
-// the others must not wait for a sequence that has ended -- however it ended
-struct LeaveOnExit {
-  std::shared_ptr<mp2p_icp_hip::AlignBatcher> b;
-  ~LeaveOnExit() {
-    if (b) b->leave();
-  }
-};
-
 void run_sequence_fiber(const std::string& pipeline, const std::string& seq_dir, const std::string& out, int device, long max_scans,
                         std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher, SequenceReport& rep) {
   rep.seq_dir = seq_dir;
   rep.out = out;
-  LeaveOnExit leave{batcher};
+  mp2p_icp_hip::AlignBatcher::Membership member(batcher);  // leave() however this sequence ends
   try {
     SequenceFeed feed;
     std::vector<double> stamps;
@@ -216,7 +208,7 @@ void run_sequence(const std::string& pipeline, const std::string& seq_dir, const
                   bool prefetch, std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher, SequenceReport& rep) {
   rep.seq_dir = seq_dir;
   rep.out = out;
-  LeaveOnExit leave{batcher};
+  mp2p_icp_hip::AlignBatcher::Membership member(batcher);  // leave() however this sequence ends
   try {
     // (the page-locked read-ahead ring of the fiber mode was tried here as well: with asynchronous uploads the eight
     // copies and the filter batch land on the alignment's first iterations -- 8 sequences 4000 scans/s against 4700, one

@@ -467,6 +467,10 @@ def test_sequences_in_one_process_share_lockstep_batches(host, tmp_path):
     assert r.returncode == 0, r.stderr
     summary = json.loads(r.stdout.strip().splitlines()[-1])
     assert summary["sequences"] == 3 and summary["scans"] == sum(len(d["scans"]) for d in drives)
+    # alignments AND the next scans' filter chains ran as batches over the sequences (mh_icp_align_batch,
+    # mh_scan_preprocess_batch): fewer calls than jobs, every scan's filters accounted for
+    assert summary["batches"] < summary["batches"] * summary["jobs_per_batch"]
+    assert summary["filter_jobs"] >= summary["scans"] - 3 and summary["filter_batches"] < summary["filter_jobs"]
     for k, d in enumerate(dirs):
         one = str(tmp_path / ("solo%d.tum" % k))
         r1 = subprocess.run([exe, "--pipeline", PIPE, "--seq-dir", d, "--out", one], capture_output=True, text=True, timeout=300)
