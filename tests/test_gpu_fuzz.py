@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("tool,cases,seed", [("fuzz_nn.py", 25, 101), ("fuzz_bound.py", 14, 102), ("fuzz_align.py", 14, 103),
                                              ("fuzz_batch.py", 6, 104), ("fuzz_map_insert.py", 12, 105),
                                              ("fuzz_preprocess.py", 25, 106), ("fuzz_odometry.py", 3, 107),
-                                             ("fuzz_hook_replay.py", 20, 108)])
+                                             ("fuzz_hook_replay.py", 20, 108), ("stress_cli_sequences.py", 1, 109)])
 def test_randomized_parity_tool(tool, cases, seed):
     env = dict(os.environ)
     for k in ("MH_MATCH", "MH_NO_PREV_BOUND", "MH_NO_FUSE16", "MH_NO_ONE_GROUP", "MH_NO_LOCKSTEP", "MH_NO_GRAPH"):
