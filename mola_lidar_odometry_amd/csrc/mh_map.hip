@@ -58,28 +58,29 @@ __global__ void k_keys(const float* __restrict__ x, const float* __restrict__ y,
   idx[i] = i;
 }
 
-// merge path of mh_map_insert: remove_voxels_farther_than applied to the SORTED keys (k_keys left them alone so that the
-// stored points stay in order); the runs of empty keys this leaves inside the sequence are skipped by everything below
-__global__ void k_evict_sorted(unsigned long long* __restrict__ ks, uint32_t n, int4 evict, uint32_t metric) {
+// head[i] = 1 where a new voxel run starts; counters[1] = number of valid (finite) points.
+// evict.w >= 0 (merge path of mh_map_insert): remove_voxels_farther_than applied to the SORTED keys on the way (k_keys
+// left them alone so that the stored points stay in order) -- a far voxel's keys become empty, and the runs of empty
+// keys this leaves inside the sequence are skipped by everything below.  A neighbour's key may or may not have been
+// rewritten by its own thread yet: the test is repeated on whatever is read, so both readings agree.
+__global__ void k_heads(unsigned long long* __restrict__ ks, uint32_t n, uint32_t* __restrict__ head,
+                        uint32_t* __restrict__ counters, int4 evict, uint32_t metric) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  auto live = [&](unsigned long long k) {
+    if (k == kEmptyKey) return false;
+    if (evict.w < 0) return true;
+    int kx, ky, kz;
+    unpack_key(k, kx, ky, kz);
+    return !far_voxel(kx - evict.x, ky - evict.y, kz - evict.z, evict.w, metric);
+  };
   const unsigned long long k = ks[i];
-  if (k == kEmptyKey) return;
-  int kx, ky, kz;
-  unpack_key(k, kx, ky, kz);
-  if (far_voxel(kx - evict.x, ky - evict.y, kz - evict.z, evict.w, metric)) ks[i] = kEmptyKey;
-}
-
-// head[i] = 1 where a new voxel run starts; counters[1] = number of valid (finite) points
-__global__ void k_heads(const unsigned long long* __restrict__ ks, uint32_t n, uint32_t* __restrict__ head,
-                        uint32_t* __restrict__ counters) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long k = ks[i];
-  const bool valid = k != kEmptyKey;
+  const bool valid = live(k);
+  if (!valid && k != kEmptyKey) ks[i] = kEmptyKey;
+  // (equal keys share their fate, so comparing with the neighbour's ORIGINAL or rewritten key gives the same head flag)
   head[i] = (valid && (i == 0 || ks[i - 1] != k)) ? 1u : 0u;
-  // (the merge path leaves runs of evicted keys INSIDE the sequence: several valid-to-empty boundaries -> the maximum)
-  if (valid && (i + 1 == n || ks[i + 1] == kEmptyKey)) atomicMax(&counters[1], i + 1);
+  // (runs of evicted keys INSIDE the sequence: several valid-to-empty boundaries -> the maximum)
+  if (valid && (i + 1 == n || !live(ks[i + 1]))) atomicMax(&counters[1], i + 1);
 }
 
 __global__ void k_vstart(const uint32_t* __restrict__ head, const uint32_t* __restrict__ vid1, uint32_t n,
@@ -565,7 +566,7 @@ mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const floa
 
     const uint32_t B = 256;
     const int4 ev = evict ? make_int4(evict[0], evict[1], evict[2], evict[3]) : make_int4(0, 0, 0, -1);
-    const int4 ev_keys = merge_path ? make_int4(0, 0, 0, -1) : ev;  // (merge path: eviction after the merge, k_evict_sorted)
+    const int4 ev_keys = merge_path ? make_int4(0, 0, 0, -1) : ev;  // (merge path: eviction after the merge, inside k_heads)
     hipLaunchKernelGGL(k_keys, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, N, m->inv_vs,
                        (uint32_t)(m->params.index_mode == MH_INDEX_TRUNC), ev_keys, m->params.far_voxel_metric, keys, idx, counters);
     unsigned long long* keys_new = keys + 2 * n;
@@ -594,11 +595,11 @@ mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const floa
       tb = m->sort_tmp.bytes;
       MH_HIP(rocprim::merge(m->sort_tmp.p, tb, keys, keys_new, keys_s, idx, idx_new, idx_s, n_stored, n_new,
                             rocprim::less<unsigned long long>(), s));
-      if (ev.w >= 0) hipLaunchKernelGGL(k_evict_sorted, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, N, ev, m->params.far_voxel_metric);
     } else {
       MH_HIP(rocprim::radix_sort_pairs(m->sort_tmp.p, tb, keys, keys_s, idx, idx_s, N, 0, 64, s));
     }
-    hipLaunchKernelGGL(k_heads, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, N, head, counters);
+    hipLaunchKernelGGL(k_heads, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, N, head, counters,
+                       merge_path ? ev : make_int4(0, 0, 0, -1), m->params.far_voxel_metric);  // (merge path: eviction on the sorted keys)
     tb = m->sort_tmp.bytes;
     MH_HIP(rocprim::inclusive_scan(m->sort_tmp.p, tb, head, vid1, N, rocprim::plus<uint32_t>(), s));
     hipLaunchKernelGGL(k_vstart, dim3(nblk(n, B)), dim3(B), 0, s, head, vid1, N, vstart);
