@@ -109,6 +109,10 @@ MH_API mh_status mh_ctx_create(int32_t device, void* hip_stream, mh_ctx** out);
  * front of the alignment's short dependent kernels in a shared queue nor competes with them for dispatch. */
 enum { MH_PRIORITY_LOW = -1, MH_PRIORITY_NORMAL = 0, MH_PRIORITY_HIGH = 1 };
 MH_API mh_status mh_ctx_create_with_priority(int32_t device, int32_t priority, mh_ctx** out);
+/* A context whose stream may only use the compute units [first_cu, first_cu + n_cus) of the device (hardware CU mask):
+ * for work that runs BESIDE a latency-bound chain of small kernels on another context -- wide filter kernels and copy
+ * kernels otherwise fill every wave slot of the device and each small kernel of the chain waits for slots to drain. */
+MH_API mh_status mh_ctx_create_on_cus(int32_t device, uint32_t first_cu, uint32_t n_cus, mh_ctx** out);
 MH_API mh_status mh_ctx_destroy(mh_ctx* ctx);
 MH_API mh_status mh_ctx_synchronize(mh_ctx* ctx);
 MH_API mh_status mh_ctx_stream(mh_ctx* ctx, void** hip_stream_out);

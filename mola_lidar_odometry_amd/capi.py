@@ -129,6 +129,7 @@ _SIGNATURES = {
     "mh_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
     "mh_ctx_create": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mh_ctx_create_with_priority": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "mh_ctx_create_on_cus": (C.c_int32, [C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "mh_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "mh_ctx_synchronize": (C.c_int32, [C.c_void_p]),
     "mh_ctx_stream": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -242,10 +243,13 @@ PRIORITY_LOW, PRIORITY_NORMAL, PRIORITY_HIGH = -1, 0, 1  # enum MH_PRIORITY_*
 class Context:
     """One HIP device + one stream (mh_ctx)."""
 
-    def __init__(self, device: int = 0, stream: int | None = None, priority: int = 0):
-        """priority: PRIORITY_LOW / PRIORITY_NORMAL / PRIORITY_HIGH -- the class of the stream the context creates"""
+    def __init__(self, device: int = 0, stream: int | None = None, priority: int = 0, cus: tuple | None = None):
+        """priority: PRIORITY_LOW / PRIORITY_NORMAL / PRIORITY_HIGH -- the class of the stream the context creates;
+        cus = (first, count): a stream restricted to that range of compute units (mh_ctx_create_on_cus)"""
         self._h = C.c_void_p()
-        if priority != PRIORITY_NORMAL and not stream:
+        if cus is not None and not stream:
+            _chk(lib().mh_ctx_create_on_cus(device, int(cus[0]), int(cus[1]), C.byref(self._h)))
+        elif priority != PRIORITY_NORMAL and not stream:
             _chk(lib().mh_ctx_create_with_priority(device, priority, C.byref(self._h)))
         else:
             _chk(lib().mh_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))

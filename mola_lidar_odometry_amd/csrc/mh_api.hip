@@ -165,6 +165,31 @@ mh_status mh_ctx_create_with_priority(int32_t device, int32_t priority, mh_ctx**
   return ctx_create(device, nullptr, priority, out);
 }
 
+mh_status mh_ctx_create_on_cus(int32_t device, uint32_t first_cu, uint32_t n_cus, mh_ctx** out) {
+  MH_REQUIRE(out, "null output");
+  *out = nullptr;
+  MH_REQUIRE(n_cus > 0, "empty CU range");
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device available; libmolahip has no CPU fallback");
+  if (device < 0 || device >= c) return fail(MH_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", device, c);
+  MH_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  MH_HIP(hipGetDeviceProperties(&prop, device));
+  const uint32_t total = (uint32_t)prop.multiProcessorCount;
+  MH_REQUIRE(first_cu < total && n_cus <= total - first_cu, "CU range outside the device");
+  uint32_t mask[32] = {0};
+  for (uint32_t cu = first_cu; cu < first_cu + n_cus && cu < 1024; cu++) mask[cu / 32] |= 1u << (cu % 32);
+  hipStream_t s = nullptr;
+  MH_HIP(hipExtStreamCreateWithCUMask(&s, (total + 31) / 32, mask));
+  const mh_status st = ctx_create(device, s, MH_PRIORITY_NORMAL, out);
+  if (st != MH_OK) {
+    (void)hipStreamDestroy(s);
+    return st;
+  }
+  (*out)->own_stream = true;  // (created here: destroyed with the context)
+  return MH_OK;
+}
+
 static mh_status ctx_create(int32_t device, void* hip_stream, int32_t priority, mh_ctx** out) {
   MH_REQUIRE(out, "null output");
   *out = nullptr;

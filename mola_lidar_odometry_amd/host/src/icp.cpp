@@ -156,6 +156,9 @@ DeviceContext::DeviceContext(int device, int priority) : device_(device) {
   else check(mh_ctx_create_with_priority(device, priority, &ctx_), "mh_ctx_create_with_priority");
 }
 void DeviceContext::synchronize() const { check(mh_ctx_synchronize(ctx_), "mh_ctx_synchronize"); }
+DeviceContext::DeviceContext(int device, unsigned first_cu, unsigned n_cus) : device_(device) {
+  check(mh_ctx_create_on_cus(device, first_cu, n_cus, &ctx_), "mh_ctx_create_on_cus");
+}
 DeviceContext::~DeviceContext() { mh_ctx_destroy(ctx_); }
 
 std::shared_ptr<DeviceContext> DeviceContext::Default() {

@@ -606,7 +606,15 @@ void LidarOdometry::launch_prefetch() {
     // class (MOLA_HIP_PREFETCH_PRIORITY=-1) was measured and lost: 8 sequences 2180 scans/s against 2870, one sequence
     // 1.05 ms per scan against 0.99 -- the prepared layers arrive later and the alignment's kernels are not faster for it
     const char* pe = getenv("MOLA_HIP_PREFETCH_PRIORITY");
-    ctx_b_ = std::make_shared<DeviceContext>(ctx_->device(), pe ? atoi(pe) : (int)MH_PRIORITY_NORMAL);
+    // ... and neither is a stream restricted to a quarter or an eighth of the compute units (MOLA_HIP_PREFETCH_CUS=first:count,
+    // mh_ctx_create_on_cus): 8 sequences 4530-4650 scans/s against 4780, the lock-step alignment beside it 1.23-1.26 ms
+    // against 1.19 -- whatever the filters and uploads take from the alignment's kernels, it is not wave slots
+    const char* pc = getenv("MOLA_HIP_PREFETCH_CUS");
+    unsigned first_cu = 0, n_cus = 0;
+    if (pc && sscanf(pc, "%u:%u", &first_cu, &n_cus) == 2 && n_cus > 0)
+      ctx_b_ = std::make_shared<DeviceContext>(ctx_->device(), first_cu, n_cus);
+    else
+      ctx_b_ = std::make_shared<DeviceContext>(ctx_->device(), pe ? atoi(pe) : (int)MH_PRIORITY_NORMAL);
     for (int i = 0; i < 2; i++) {
       raw_b_[i] = std::make_shared<DevicePointCloud>(ctx_b_);
       map_skewed_b_[i] = std::make_shared<DevicePointCloud>(ctx_b_);

@@ -143,6 +143,19 @@ def test_context_priority_classes(small_workload):
         c.close()
     with pytest.raises(capi.MolahipError):
         capi.Context(0, priority=7)
+    # a stream restricted to a range of compute units (mh_ctx_create_on_cus): same results; a range outside the device is refused
+    c = capi.Context(0, cus=(0, 32))
+    s = capi.Scan(c, small_workload.scan_xyz)
+    om = capi.Scan(c)
+    s.preprocess(capi.preprocess_params(0.4, 0.0, min_points_to_filter=10), om, None)
+    ref = capi.Context(0)
+    s2, om2 = capi.Scan(ref, small_workload.scan_xyz), capi.Scan(ref)
+    s2.preprocess(capi.preprocess_params(0.4, 0.0, min_points_to_filter=10), om2, None)
+    np.testing.assert_array_equal(om.download()["src_idx"], om2.download()["src_idx"])
+    c.close()
+    ref.close()
+    with pytest.raises(capi.MolahipError):
+        capi.Context(0, cus=(100000, 8))
 
 
 def test_deskew(ctx, oracle, small_workload):
