@@ -64,6 +64,29 @@ def analyse(trace_dir, n_scans_total):
                 "gaps_below_15us": [len(small), sum(small) / max(1, len(small))],
                 "gaps_15_to_150us": [len(mid_g), sum(mid_g) / max(1, len(mid_g))],
                 "gaps_above_150us (between alignments)": [len(gaps) - len(small) - len(mid_g)]}
+    # what runs beside the alignment's kernels: their duration by the family of the other kernels in flight when they start
+    def family(name):
+        n = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("mh::", "")
+        if n.startswith("__amd_rocclr_copy"): return "copy"
+        if n.startswith("__amd_rocclr_fill"): return "fill"
+        if n.startswith("k_pp_deskew"): return "deskew"
+        if n.startswith("k_pp_"): return "filters"
+        if n.startswith("rocprim"): return "rocprim"
+        if any(n.startswith(p) for p in ("k_match", "k_accum", "k_solve", "k_cov", "k_gather_states", "k_scatter_blocks")): return "icp"
+        return "map_update"
+    others = [(r[0], r[1], family(r[2])) for r in mid if family(r[2]) != "icp"]
+    others.sort()
+    beside = {}
+    import bisect
+    starts = [o[0] for o in others]
+    for r in icp:
+        k = bisect.bisect_right(starts, r[0])
+        fams = sorted({o[2] for o in others[max(0, k - 40):k] if o[1] > r[0]})
+        key = "+".join(fams) if fams else "alone"
+        b = beside.setdefault(key, [0, 0])
+        b[0] += 1
+        b[1] += r[1] - r[0]
+    icp_view["avg_kernel_us_by_what_runs_beside"] = {k: [v[0], round(v[1] / 1e3 / v[0], 2)] for k, v in sorted(beside.items(), key=lambda kv: -kv[1][0])}
     scans_mid = n_scans_total * 0.6
     return {"wall_ms_mid": wall / 1e6, "device_busy_share": busy / wall, "avg_kernels_running_when_busy": area / max(1, busy),
             "queues_busy_share": {q: round(v / wall, 3) for q, v in sorted(queues.items())},
