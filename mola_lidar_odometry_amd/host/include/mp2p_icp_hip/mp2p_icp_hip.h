@@ -378,14 +378,25 @@ class QualityEvaluator_PairedRatio {
 class AlignBatcher {
  public:
   explicit AlignBatcher(size_t participants);
-  // blocks until the batch this request joined has run; returns its status (the message in `error` when not MH_OK)
-  mh_status align(const mh_map* map, const mh_scan* scan, const mh_icp_params* params, const double T_guess[12],
+  // blocks until the batch this request joined has run; returns its status (the message in `error` when not MH_OK).
+  // `owner`: any address that identifies the participant (the same one in every call it makes; nullptr: the scan)
+  mh_status align(const void* owner, const mh_map* map, const mh_scan* scan, const mh_icp_params* params, const double T_guess[12],
                   const mh_prior* prior, mh_icp_result* result, std::string* error);
-  // the observation filters of the participants' next scans (mh_scan_preprocess) merged the same way: a rendezvous of
-  // its own (a sequence's filter request for scan k+1 and its alignment of scan k are in flight together), one
-  // mh_scan_preprocess_batch by whoever completes the set.  A request that has waited 1 ms (MOLA_HIP_FILTER_SET_WAIT_US) runs with whatever
-  // waits by then: a sequence that skips a scan's filters (no announced next scan, a restart) must not hold the others.
-  mh_status preprocess(const mh_scan* raw, const mh_preprocess_params* params, mh_scan* out_map, mh_scan* out_icp, std::string* error);
+  // The observation filters of the participants' NEXT scans (mh_scan_preprocess) merged the same way, in sets of their
+  // own: a sequence's filter request for scan k+1 and its alignment of scan k are in flight together.  Which requests
+  // belong together is bookkeeping, not timing.  A participant announces a request on the thread that will align next
+  // (announceFilter: the set is the number of alignments it has requested so far) and a worker of its own delivers it
+  // (preprocess).  A participant is PAST set j once it has requested its (j+1)-th alignment or announced a request for
+  // set j; set j is complete when every active participant is past it and every announced request has arrived --
+  // which is exactly when the lock-step alignment j+1 can start, so the filter batch runs beside it.  Participants that
+  // re-align a scan, skip a scan or end early never make the others wait, and nobody has to say "not this time".
+  // Whichever waiting worker sees its set complete runs ONE mh_scan_preprocess_batch over it (never the aligning
+  // thread: the alignment must not wait for the filters).  A request that has waited MOLA_HIP_FILTER_SET_WAIT_US
+  // (default 2 ms) runs with what waits by then: a net under the bookkeeping.
+  size_t announceFilter(const void* owner);
+  mh_status preprocess(const void* owner, size_t set, const mh_scan* raw, const mh_preprocess_params* params, mh_scan* out_map,
+                       mh_scan* out_icp, std::string* error);
+  void cancelAnnouncedFilter(const void* owner, size_t set);  // the announced request will not come (its upload failed)
   // Participation as a scope: leave() when the object goes away, however the sequence ended (an exception between
   // construction and the first align() must not leave the others waiting for ever).
   class Membership {
@@ -400,13 +411,13 @@ class AlignBatcher {
    private:
     std::shared_ptr<AlignBatcher> b_;
   };
-  // this participant has no filter request for the set now being assembled (no next scan announced): the others' set
-  // is complete without it
-  void skipFilterRound();
-  void leave();  // this participant will not align any more (end of its sequence, or it failed)
+  // this participant will not align any more (end of its sequence, or it failed)
+  void leave();
+  // ... and its bookkeeping entry goes with it (a driver calls this from its destructor)
+  void forgetOwner(const void* owner);
   size_t filterBatches() const { return n_pp_batches_; }
   size_t filterJobs() const { return n_pp_jobs_; }
-  size_t filterTimeouts() const { return n_pp_timeouts_; }  // sets run incomplete because a request had waited long enough
+  size_t filterTimeouts() const { return n_pp_timeouts_; }  // sets forced because a request had waited MOLA_HIP_FILTER_SET_WAIT_US
   size_t batches() const { return n_batches_; }
   size_t jobs() const { return n_jobs_; }
   // where a batch's wall time goes: from the first request of a batch to its start (the sequences' other phases), and the
@@ -432,16 +443,24 @@ class AlignBatcher {
     const mh_preprocess_params* params = nullptr;
     mh_scan* out_map = nullptr;
     mh_scan* out_icp = nullptr;
+    size_t set = 0;
     mh_status status = MH_OK;
     std::string error;
     bool done = false, taken = false;
   };
+  struct OwnerState {
+    size_t aligns = 0;          // alignments requested so far
+    bool announced = false;     // ... and the latest set it announced a filter request for
+    size_t announced_set = 0;
+  };
   void run_filter_batch(std::vector<FilterRequest*>& batch);  // called WITHOUT the mutex
+  bool filter_set_ready_locked(size_t set) const;
+  void take_filter_sets_upto(std::unique_lock<std::mutex>& lk, size_t set);
   std::vector<FilterRequest*> pp_waiting_;
-  size_t pp_skips_ = 0;
-  bool filter_set_due_locked() const { return pp_waiting_.size() + pp_in_flight_ + pp_skips_ >= active_; }
-  void take_filter_set(std::unique_lock<std::mutex>& lk);
-  size_t pp_in_flight_ = 0, n_pp_batches_ = 0, n_pp_jobs_ = 0, n_pp_timeouts_ = 0;
+  std::map<const void*, OwnerState> owners_;
+  std::map<size_t, size_t> pp_pending_;  // set -> announced requests that have not arrived yet
+  size_t pp_set_ = 0;                    // sets below this one have been taken
+  size_t n_pp_batches_ = 0, n_pp_jobs_ = 0, n_pp_timeouts_ = 0;
   void run_batch(std::vector<Request*>& batch);  // called WITHOUT the mutex
   size_t threshold_locked() const;
   std::mutex mtx_;
@@ -485,7 +504,11 @@ class ICP {
   // mp2p_icp adapter does, because it only ever sees an opaque std::function)
   void setHookReplay(bool v) { hook_replay_ = v; }
   // fused alignments (without trace / final pairings / host hook) go through the batcher instead of mh_icp_align
-  void setAlignBatcher(std::shared_ptr<AlignBatcher> b) { batcher_ = std::move(b); }
+  // `owner`: the participant this ICP object aligns for (a driver with two ICP objects passes its own address to both)
+  void setAlignBatcher(std::shared_ptr<AlignBatcher> b, const void* owner = nullptr) {
+    batcher_ = std::move(b);
+    batch_owner_ = owner ? owner : this;
+  }
   // the in-tree hook (LidarOdometry.cpp:923-952) as data: evaluated on the device inside the fused loop
   void setDeviceHook(double min_trans, double min_rot_rad, const CPose3D& checkpoint);
   void clearHooks();
@@ -535,6 +558,7 @@ class ICP {
   std::shared_ptr<DeviceContext> scan_ctx_;  // ... and the (map's) context it lives in, kept alive until ~ICP has destroyed it
   bool last_fused_ = false, force_generic_ = false, keep_pairings_ = true, hook_replay_ = false;
   std::shared_ptr<AlignBatcher> batcher_;
+  const void* batch_owner_ = nullptr;
   // how long the previous call of each kind ran: [0] calls with the full iteration budget, [1] re-entries after a hook
   // request (LidarOdometry.cpp:956-967 re-enters with what is left of it) -- the first chunk of the device loop is sized by it
   uint32_t full_budget_ = 0, last_iterations_[2] = {0, 0}, last_polls_ = 0, last_enqueued_ = 0;

@@ -626,12 +626,14 @@ void AlignBatcher::run_batch(std::vector<Request*>& batch) {
   cv_.notify_all();
 }
 
-mh_status AlignBatcher::align(const mh_map* map, const mh_scan* scan, const mh_icp_params* params, const double T_guess[12],
-                              const mh_prior* prior, mh_icp_result* result, std::string* error) {
+mh_status AlignBatcher::align(const void* owner, const mh_map* map, const mh_scan* scan, const mh_icp_params* params,
+                              const double T_guess[12], const mh_prior* prior, mh_icp_result* result, std::string* error) {
   Request rq;
   rq.map = map; rq.scan = scan; rq.params = params; rq.T = T_guess; rq.prior = prior; rq.result = result;
   std::unique_lock<std::mutex> lk(mtx_);
   rq.arrived = std::chrono::steady_clock::now();
+  owners_[owner ? owner : (const void*)scan].aligns++;  // this participant is past the filter set of its previous alignment count
+  if (!pp_waiting_.empty()) cv_.notify_all();           // (a waiting filter worker may find its set complete now)
   waiting_.push_back(&rq);
   // a batch is due when enough requests wait -- or when everybody who is not waiting is inside a running batch already
   // (then waiting longer only idles the device)
@@ -678,7 +680,6 @@ void AlignBatcher::run_filter_batch(std::vector<FilterRequest*>& batch) {
   std::lock_guard<std::mutex> lk(mtx_);
   n_pp_batches_++;
   n_pp_jobs_ += n;
-  pp_in_flight_ -= n;
   for (size_t i = 0; i < n; i++) {
     batch[i]->status = sts[i];
     batch[i]->error = errs[i];
@@ -687,67 +688,94 @@ void AlignBatcher::run_filter_batch(std::vector<FilterRequest*>& batch) {
   cv_.notify_all();
 }
 
-void AlignBatcher::take_filter_set(std::unique_lock<std::mutex>& lk) {
-  std::vector<FilterRequest*> batch;
-  batch.swap(pp_waiting_);
+// complete = every active participant is past the set and every announced request of it (and of earlier sets) is here
+bool AlignBatcher::filter_set_ready_locked(size_t set) const {
+  if (set < pp_set_) return true;  // (its set went without it: a request that arrives late runs at once)
+  for (const auto& kv : pp_pending_)
+    if (kv.first <= set && kv.second > 0) return false;
+  size_t past = 0;
+  for (const auto& kv : owners_) past += (kv.second.aligns > set || (kv.second.announced && kv.second.announced_set >= set)) ? 1 : 0;
+  return past >= active_;
+}
+
+void AlignBatcher::take_filter_sets_upto(std::unique_lock<std::mutex>& lk, size_t set) {
+  std::vector<FilterRequest*> batch, rest;
+  for (auto* r : pp_waiting_) (r->set <= set ? batch : rest).push_back(r);
+  pp_waiting_.swap(rest);
+  if (set + 1 > pp_set_) pp_set_ = set + 1;
   for (auto* r : batch) r->taken = true;
-  pp_in_flight_ += batch.size();
-  pp_skips_ = 0;
+  if (batch.empty()) return;
   lk.unlock();
   run_filter_batch(batch);
   lk.lock();
 }
 
-mh_status AlignBatcher::preprocess(const mh_scan* raw, const mh_preprocess_params* params, mh_scan* out_map, mh_scan* out_icp,
-                                   std::string* error) {
+size_t AlignBatcher::announceFilter(const void* owner) {
+  std::lock_guard<std::mutex> lk(mtx_);
+  OwnerState& o = owners_[owner];
+  o.announced = true;
+  o.announced_set = o.aligns;
+  pp_pending_[o.aligns]++;
+  return o.aligns;
+}
+
+void AlignBatcher::cancelAnnouncedFilter(const void* owner, size_t set) {
+  (void)owner;
+  std::lock_guard<std::mutex> lk(mtx_);
+  auto it = pp_pending_.find(set);
+  if (it != pp_pending_.end() && it->second > 0 && --it->second == 0) pp_pending_.erase(it);
+  cv_.notify_all();
+}
+
+mh_status AlignBatcher::preprocess(const void* owner, size_t set, const mh_scan* raw, const mh_preprocess_params* params,
+                                   mh_scan* out_map, mh_scan* out_icp, std::string* error) {
+  (void)owner;
   FilterRequest rq;
-  rq.raw = raw; rq.params = params; rq.out_map = out_map; rq.out_icp = out_icp;
+  rq.raw = raw; rq.params = params; rq.out_map = out_map; rq.out_icp = out_icp; rq.set = set;
   std::unique_lock<std::mutex> lk(mtx_);
+  {
+    auto it = pp_pending_.find(set);  // announced -> arrived
+    if (it != pp_pending_.end() && it->second > 0 && --it->second == 0) pp_pending_.erase(it);
+  }
   pp_waiting_.push_back(&rq);
-  // how long a request waits for the set to complete.  A sequence that re-aligns the scan it is on (twist correction)
-  // sits out a round, so incomplete sets are part of normal operation: the limit is what such a round costs everybody,
-  // against sets split in two when the requests of a round arrive further apart than this (8 copies of one drive:
-  // 0.15 / 0.3 / 0.6 / 2 ms -> 3550 / 3800 / 4020 / 3970 scans/s, 340 / 186 / 43 / 10 incomplete sets of 150)
+  cv_.notify_all();  // (the arrival may be what another worker's set was waiting for)
   static const auto limit = std::chrono::microseconds([] {
     const char* e = getenv("MOLA_HIP_FILTER_SET_WAIT_US");
-    return e ? std::max(0, atoi(e)) : 1000;
+    return e ? std::max(0, atoi(e)) : 2000;
   }());
-  if (filter_set_due_locked()) {
-    take_filter_set(lk);
-  } else if (molahip_host::FiberScheduler::in_fiber()) {
-    const auto t0 = std::chrono::steady_clock::now();
-    while (!rq.done) {
+  const bool fiber = molahip_host::FiberScheduler::in_fiber();
+  const auto t0 = std::chrono::steady_clock::now();
+  while (!rq.done) {
+    if (!rq.taken && filter_set_ready_locked(rq.set)) {
+      take_filter_sets_upto(lk, rq.set);
+      continue;
+    }
+    if (fiber) {
       lk.unlock();
       molahip_host::FiberScheduler::yield();
       lk.lock();
-      if (!rq.done && !rq.taken && std::chrono::steady_clock::now() - t0 > limit) {
-        n_pp_timeouts_++;
-        take_filter_set(lk);
-      }
+      if (rq.done || rq.taken || std::chrono::steady_clock::now() - t0 <= limit) continue;
+    } else {
+      const bool woke = cv_.wait_for(lk, limit, [&] { return rq.done || (!rq.taken && filter_set_ready_locked(rq.set)); });
+      if (woke || rq.taken) continue;
     }
-  } else {
-    while (!rq.done) {
-      if (cv_.wait_for(lk, limit, [&] { return rq.done; })) break;
-      if (!rq.taken) {  // nobody completed the set in time: run what waits (this request included)
-        n_pp_timeouts_++;
-        take_filter_set(lk);
-      }
-    }
+    n_pp_timeouts_++;  // nobody completed the set in time: everything up to this request's set runs now
+    take_filter_sets_upto(lk, rq.set);
   }
   if (error) *error = rq.error;
   return rq.status;
 }
 
-void AlignBatcher::skipFilterRound() {
-  std::unique_lock<std::mutex> lk(mtx_);
-  if (pp_skips_ < active_) pp_skips_++;
-  if (!pp_waiting_.empty() && filter_set_due_locked()) take_filter_set(lk);
+void AlignBatcher::forgetOwner(const void* owner) {
+  std::lock_guard<std::mutex> lk(mtx_);
+  owners_.erase(owner);
+  cv_.notify_all();
 }
 
 void AlignBatcher::leave() {
   std::unique_lock<std::mutex> lk(mtx_);
   if (active_ > 0) active_--;
-  if (!pp_waiting_.empty() && filter_set_due_locked()) take_filter_set(lk);
+  cv_.notify_all();  // (fewer participants: a waiting filter set may be complete now)
   if (!waiting_.empty() && (waiting_.size() >= threshold_locked() || waiting_.size() + in_flight_ >= active_)) {
     // the others were only waiting for this one
     std::vector<Request*> batch;
@@ -946,7 +974,7 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
   } else if (batcher_ && trace.empty() && !want_pairs) {
     // several sequences in one process: this alignment joins the others' (AlignBatcher)
     std::string err;
-    const mh_status st = batcher_->align(global.handle(), scan, &ip, guess.T, prior ? &pr : nullptr, &r, &err);
+    const mh_status st = batcher_->align(batch_owner_, global.handle(), scan, &ip, guess.T, prior ? &pr : nullptr, &r, &err);
     if (st != MH_OK) throw std::runtime_error(std::string("mh_icp_align_batch: ") + mh_status_string(st) + ": " + err);
   } else {
     check(mh_icp_align(global.handle(), scan, &ip, guess.T, prior ? &pr : nullptr, &r, trace.empty() ? nullptr : trace.data(),

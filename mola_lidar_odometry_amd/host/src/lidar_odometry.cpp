@@ -406,7 +406,10 @@ struct LidarOdometry::Prefetch {
 };
 
 LidarOdometry::LidarOdometry(std::shared_ptr<DeviceContext> ctx) : ctx_(std::move(ctx)), pf_(new Prefetch) {}
-LidarOdometry::~LidarOdometry() { cancel_prefetch(); }
+LidarOdometry::~LidarOdometry() {
+  cancel_prefetch();
+  if (batcher_) batcher_->forgetOwner(this);
+}
 
 void LidarOdometry::initialize(const Config& cfg) {
   if (plan_) throw std::runtime_error("LidarOdometry::initialize() called twice; create a new object instead");
@@ -549,13 +552,9 @@ void LidarOdometry::run_first_pass() {
   const FilterPlan& f = *plan_;
   const mh_preprocess_params pp = make_pp(f.decim_map_res, f.decim_icp_res, f.min_points_to_filter, f.range_min, f.range_max,
                                           f.bbox_mode, f.bbox_min, f.bbox_max, f.timestamp_method, f.time_offset);
-  if (batcher_) {  // several sequences in one process: this scan's filters join the others'
-    std::string err;
-    const mh_status st = batcher_->preprocess(raw_->handle(), &pp, map_skewed_->handle(), icp_skewed_->handle(), &err);
-    if (st != MH_OK) throw std::runtime_error("mh_scan_preprocess (batched): " + err);
-  } else {
-    check(mh_scan_preprocess(raw_->handle(), &pp, map_skewed_->handle(), icp_skewed_->handle()), "mh_scan_preprocess");
-  }
+  // (not through the batcher even when there is one: its filter sets are made of the PREFETCH requests, one action per
+  // alignment and participant -- this call is the first scan of a sequence, or a prepared scan that has to be redone)
+  check(mh_scan_preprocess(raw_->handle(), &pp, map_skewed_->handle(), icp_skewed_->handle()), "mh_scan_preprocess");
 }
 
 void LidarOdometry::setAlignBatcher(std::shared_ptr<mp2p_icp_hip::AlignBatcher> b) {
@@ -565,7 +564,7 @@ void LidarOdometry::setAlignBatcher(std::shared_ptr<mp2p_icp_hip::AlignBatcher> 
     throw std::runtime_error("LidarOdometry::setAlignBatcher: this instance uses the process-wide default context; construct "
                              "it with a DeviceContext of its own");
   for (auto& i : icp_)
-    if (i) i->setAlignBatcher(b);
+    if (i) i->setAlignBatcher(b, this);  // (both ICP objects align for this one participant)
   batcher_ = std::move(b);
 }
 
@@ -593,8 +592,7 @@ void LidarOdometry::cancel_prefetch() {
 
 void LidarOdometry::launch_prefetch() {
   if (!pf_->requested || !plan_ || !estimated_sensor_max_range_) {
-    if (batcher_) batcher_->skipFilterRound();  // (the last scan of the sequence, or nothing announced)
-    return;
+    return;  // (the last scan of the sequence, or nothing announced: the batcher sees this sequence's next alignment)
   }
   if (pf_->launched) {  // prepared but never picked up: drop it
     try { pf_->join(); } catch (...) {}
@@ -637,18 +635,29 @@ void LidarOdometry::launch_prefetch() {
   auto ctx = ctx_b_;
   const bool pinned = input_pinned_;
   auto batcher = batcher_;
-  auto work = [in, pp, raw, ms, is, ctx, pinned, batcher]() {
-    if (in.data) raw->setPointsInterleaved(in.data, in.n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t, pinned);
-    else raw->setPoints(in.x, in.y, in.z, in.n);
-    if (in.t) raw->setTimestamps(in.t, in.n);
-    if (batcher) {
-      std::string err;
-      const mh_status st = batcher->preprocess(raw->handle(), &pp, ms->handle(), is->handle(), &err);
-      if (st != MH_OK) throw std::runtime_error("mh_scan_preprocess (prefetch, batched): " + err);
-    } else {
-      check(mh_scan_preprocess(raw->handle(), &pp, ms->handle(), is->handle()), "mh_scan_preprocess (prefetch)");
+  const void* owner = this;
+  // several sequences in one process: the request is announced HERE, on the thread that aligns next (the batcher then
+  // knows it is coming before it sees that alignment), and delivered by the worker
+  const size_t filter_set = batcher ? batcher->announceFilter(owner) : 0;
+  auto work = [in, pp, raw, ms, is, ctx, pinned, batcher, owner, filter_set]() {
+    bool delivered = false;
+    try {
+      if (in.data) raw->setPointsInterleaved(in.data, in.n, in.point_step, in.off_x, in.off_y, in.off_z, in.off_t, pinned);
+      else raw->setPoints(in.x, in.y, in.z, in.n);
+      if (in.t) raw->setTimestamps(in.t, in.n);
+      if (batcher) {
+        std::string err;
+        delivered = true;
+        const mh_status st = batcher->preprocess(owner, filter_set, raw->handle(), &pp, ms->handle(), is->handle(), &err);
+        if (st != MH_OK) throw std::runtime_error("mh_scan_preprocess (prefetch, batched): " + err);
+      } else {
+        check(mh_scan_preprocess(raw->handle(), &pp, ms->handle(), is->handle()), "mh_scan_preprocess (prefetch)");
+      }
+      ctx->synchronize();
+    } catch (...) {
+      if (batcher && !delivered) batcher->cancelAnnouncedFilter(owner, filter_set);  // (the others must not wait for it)
+      throw;
     }
-    ctx->synchronize();
   };
   if (molahip_host::FiberScheduler::in_fiber()) pf_->done_fiber = molahip_host::FiberScheduler::current()->spawn(work);
   else {

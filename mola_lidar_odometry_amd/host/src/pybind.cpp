@@ -250,7 +250,7 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
       .def("localMapSize", [](const LidarOdometry& lo) { return lo.localMap() ? lo.localMap()->size() : 0; });
   py::class_<AlignBatcher, std::shared_ptr<AlignBatcher>>(m, "AlignBatcher")
       .def(py::init<size_t>(), py::arg("participants"))
-      .def("leave", &AlignBatcher::leave, py::call_guard<py::gil_scoped_release>())
+      .def("leave", [](AlignBatcher& b) { b.leave(); }, py::call_guard<py::gil_scoped_release>())
       .def("batches", &AlignBatcher::batches)
       .def("jobs", &AlignBatcher::jobs);
   m.def("icp_pipeline_from_yaml", [](const Config& c) { auto t = icp_pipeline_from_yaml(c); return py::make_tuple(std::get<0>(t), std::get<1>(t)); });
