@@ -524,6 +524,18 @@ mh_status map_ready_on(const mh_map* m, hipStream_t s) {
   return MH_OK;
 }
 
+// The new points of a key-frame (a layer of ~10 k points) sorted by voxel key, stably.  rocprim's radix sort takes its
+// merge-sort route at this size with 1024 keys per workgroup: one block sort + three or four merge passes + up to two
+// copies, six or seven launches of ~5 us each on a path where the launches are the cost.  The same stable merge sort
+// with 4096 keys per workgroup needs one block sort and one or two merge passes; larger layers keep the radix sort.
+static hipError_t sort_new_points(void* tmp, size_t& tmp_bytes, unsigned long long* keys_in, unsigned long long* keys_out,
+                                  uint32_t* idx_in, uint32_t* idx_out, size_t n, hipStream_t s) {
+  static const bool radix_only = getenv("MH_MAP_RADIX_SORT_NEW") != nullptr;
+  if (n > 65536 || radix_only) return rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, idx_in, idx_out, n, 0, 64, s);
+  using cfg = rocprim::merge_sort_config<512, 512, 8>;  // (8192 per workgroup: the block sort alone takes 92 us instead of 22)
+  return rocprim::merge_sort<cfg>(tmp, tmp_bytes, keys_in, keys_out, idx_in, idx_out, n, rocprim::less<unsigned long long>(), s);
+}
+
 mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc,
                            size_t n, const int* evict, size_t n_stored) {
   if (!m->h_counts) {
@@ -574,7 +586,7 @@ mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const floa
     size_t tmp = 0;
     if (merge_path) {
       size_t t2 = 0;
-      if (n_new) MH_HIP(rocprim::radix_sort_pairs(nullptr, tmp, keys + n_stored, keys_new, idx + n_stored, idx_new, n_new, 0, 64, s));
+      if (n_new) MH_HIP(sort_new_points(nullptr, tmp, keys + n_stored, keys_new, idx + n_stored, idx_new, n_new, s));
       MH_HIP(rocprim::merge(nullptr, t2, keys, keys_new, keys_s, idx, idx_new, idx_s, n_stored, n_new,
                             rocprim::less<unsigned long long>(), s));
       if (t2 > tmp) tmp = t2;
@@ -591,7 +603,7 @@ mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const floa
     MH_TRY(m->sort_tmp.reserve(tmp));
     size_t tb = m->sort_tmp.bytes;
     if (merge_path) {
-      if (n_new) MH_HIP(rocprim::radix_sort_pairs(m->sort_tmp.p, tb, keys + n_stored, keys_new, idx + n_stored, idx_new, n_new, 0, 64, s));
+      if (n_new) MH_HIP(sort_new_points(m->sort_tmp.p, tb, keys + n_stored, keys_new, idx + n_stored, idx_new, n_new, s));
       tb = m->sort_tmp.bytes;
       MH_HIP(rocprim::merge(m->sort_tmp.p, tb, keys, keys_new, keys_s, idx, idx_new, idx_s, n_stored, n_new,
                             rocprim::less<unsigned long long>(), s));
