@@ -264,7 +264,9 @@ void scan_free_tiles(mh_scan* s);
 // Asynchronous on stream `s` (the context's, or the map's side stream); scratch from `m`.  Counts / bbox / the
 // out-of-range verdict are resolved lazily (map_resolve).
 mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc,
-                           size_t n, const int* evict, size_t n_stored);
+                           size_t n, const int* evict, size_t n_stored, bool collected = false);
+mh_status map_build_prologue(mh_map* m, hipStream_t s, size_t n, size_t n_stored, uint32_t** counters_out,
+                             unsigned long long** keys_out, uint32_t** idx_out);
 // wait (host) for the last (re)build's counters and refresh n_points / n_voxels / n_records / n_planes / bbox; returns the
 // deferred status of that build (MH_ERR_OUT_OF_RANGE) once
 mh_status map_resolve(const mh_map* m);

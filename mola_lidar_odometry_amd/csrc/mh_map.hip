@@ -384,6 +384,57 @@ mh_status mh_map_destroy(mh_map* m) {
   return MH_OK;
 }
 
+// mh_map_insert, merge path: the two kernels above and k_keys in ONE launch.  The first workgroups walk the stored voxels
+// (a stored point's key is its voxel's key: the same function of the same coordinates gave it when it was inserted), the
+// others compose the new layer with the pose and key it the way k_keys does; everybody writes idx[i] = i.
+__global__ __launch_bounds__(256) void k_collect(const float4* __restrict__ pts, const unsigned long long* __restrict__ vox_keys,
+                                                 const uint32_t* __restrict__ vox_first, const uint32_t* __restrict__ vox_count,
+                                                 uint32_t n_vox, uint32_t ndt, uint32_t stored_blocks, const float* __restrict__ x,
+                                                 const float* __restrict__ y, const float* __restrict__ z, uint32_t n_new, Pose12 T,
+                                                 uint32_t src0, uint32_t n_old, float inv_vs, uint32_t trunc,
+                                                 float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
+                                                 uint32_t* __restrict__ osrc, unsigned long long* __restrict__ keys,
+                                                 uint32_t* __restrict__ idx, uint32_t* __restrict__ flags) {
+  if (blockIdx.x < stored_blocks) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_vox) return;
+    const uint32_t first = vox_first[v], cnt = vox_count[v];
+    const unsigned long long key = vox_keys[v];
+    const uint32_t o = ndt ? first - 2u * (v + 1u) : first;  // position in the point-only numbering
+    for (uint32_t j = 0; j < cnt; j++) {
+      const float4 p = pts[first + j];
+      ox[o + j] = p.x;
+      oy[o + j] = p.y;
+      oz[o + j] = p.z;
+      osrc[o + j] = __float_as_uint(p.w);
+      keys[o + j] = key;
+      idx[o + j] = o + j;
+    }
+    return;
+  }
+  const uint32_t i = (blockIdx.x - stored_blocks) * 256 + threadIdx.x;
+  if (i >= n_new) return;
+  const double lx = x[i], ly = y[i], lz = z[i];
+  const float px = (float)(((T.m[0] * lx + T.m[1] * ly) + T.m[2] * lz) + T.m[3]);
+  const float py = (float)(((T.m[4] * lx + T.m[5] * ly) + T.m[6] * lz) + T.m[7]);
+  const float pz = (float)(((T.m[8] * lx + T.m[9] * ly) + T.m[10] * lz) + T.m[11]);
+  const uint32_t o = n_old + i;
+  ox[o] = px;
+  oy[o] = py;
+  oz[o] = pz;
+  osrc[o] = src0 + i;
+  unsigned long long k = kEmptyKey;
+  if (isfinite(px) && isfinite(py) && isfinite(pz)) {
+    const float sx = px * inv_vs, sy = py * inv_vs, sz = pz * inv_vs;
+    if (fabsf(sx) < 1.0e6f && fabsf(sy) < 1.0e6f && fabsf(sz) < 1.0e6f)
+      k = pack_key(voxel_index(px, inv_vs, trunc), voxel_index(py, inv_vs, trunc), voxel_index(pz, inv_vs, trunc));
+    else
+      atomicOr(&flags[0], 1u);  // voxel index does not fit 21 bits
+  }
+  keys[o] = k;
+  idx[o] = o;
+}
+
 mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z, size_t n, int32_t mem) {
   MH_REQUIRE(m, "null map");
   MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
@@ -445,15 +496,37 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
   float *mx = (float*)base, *my = (float*)(base + stride), *mz = (float*)(base + 2 * stride);
   uint32_t* msrc = (uint32_t*)(base + 3 * stride);
   const uint32_t ndt = m->params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
-  if (m->n_voxels)
-    hipLaunchKernelGGL(k_gather_stored, dim3(nblk(m->n_voxels, 128)), dim3(128), 0, s, m->pts.as<float4>(),
-                       m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(), (uint32_t)m->n_voxels, ndt, mx, my, mz,
-                       msrc);
-  if (n_new) {
+  // merge path (stored points present, new points to add): gather + compose + keys in one launch, behind the rebuild's
+  // own first launch (counters and slot table) -- map_build_device is told that both have been done
+  // (up to ~0.4 M stored points: beyond, the voxel-by-voxel walk that also writes keys loses to the streaming k_keys --
+  // a 10 k-point key-frame into 0.1 / 0.25 / 0.5 / 1 M points completes after 0.117 / 0.139 / 0.180 / 0.272 ms fused and
+  // 0.132 / 0.156 / 0.181 / 0.242 ms with the three launches)
+  const bool fused_collect = m->n_voxels && n_new && n_old <= 400000 && getenv("MH_MAP_FULL_SORT") == nullptr &&
+                             getenv("MH_MAP_NO_COLLECT") == nullptr;
+  if (fused_collect) {
+    uint32_t* counters = nullptr;
+    unsigned long long* keys = nullptr;
+    uint32_t* idx = nullptr;
+    MH_TRY(map_build_prologue(m, s, total, n_old, &counters, &keys, &idx));
     Pose12 P;
     for (int i = 0; i < 12; i++) P.m[i] = T[i];
-    hipLaunchKernelGGL(k_compose_new, dim3(nblk(n_new, 256)), dim3(256), 0, s, scan->x, scan->y, scan->z, (uint32_t)n_new,
-                       P, (uint32_t)m->n_offered, mx + n_old, my + n_old, mz + n_old, msrc + n_old);
+    const uint32_t stored_blocks = nblk(m->n_voxels, 256);
+    hipLaunchKernelGGL(k_collect, dim3(stored_blocks + nblk(n_new, 256)), dim3(256), 0, s, m->pts.as<float4>(),
+                       m->vox_keys.as<unsigned long long>(), m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(),
+                       (uint32_t)m->n_voxels, ndt, stored_blocks, scan->x, scan->y, scan->z, (uint32_t)n_new, P,
+                       (uint32_t)m->n_offered, (uint32_t)n_old, m->inv_vs, (uint32_t)(m->params.index_mode == MH_INDEX_TRUNC), mx, my,
+                       mz, msrc, keys, idx, counters);
+  } else {
+    if (m->n_voxels)
+      hipLaunchKernelGGL(k_gather_stored, dim3(nblk(m->n_voxels, 128)), dim3(128), 0, s, m->pts.as<float4>(),
+                         m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(), (uint32_t)m->n_voxels, ndt, mx, my, mz,
+                         msrc);
+    if (n_new) {
+      Pose12 P;
+      for (int i = 0; i < 12; i++) P.m[i] = T[i];
+      hipLaunchKernelGGL(k_compose_new, dim3(nblk(n_new, 256)), dim3(256), 0, s, scan->x, scan->y, scan->z, (uint32_t)n_new,
+                         P, (uint32_t)m->n_offered, mx + n_old, my + n_old, mz + n_old, msrc + n_old);
+    }
   }
   MH_HIP(hipGetLastError());
   if (use_side) {  // the layer has been read: whatever the context's stream does to it next may proceed
@@ -470,7 +543,7 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
     }
     evict[3] = (int)ceilf(remove_voxels_farther_than * m->inv_vs);
   }
-  MH_TRY(map_build_device(m, s, mx, my, mz, msrc, total, evict, n_old));
+  MH_TRY(map_build_device(m, s, mx, my, mz, msrc, total, evict, n_old, fused_collect));
   m->n_offered += n_new;
   return MH_OK;
 }
@@ -536,26 +609,47 @@ static hipError_t sort_new_points(void* tmp, size_t& tmp_bytes, unsigned long lo
   return rocprim::merge_sort<cfg>(tmp, tmp_bytes, keys_in, keys_out, idx_in, idx_out, n, rocprim::less<unsigned long long>(), s);
 }
 
-mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc,
-                           size_t n, const int* evict, size_t n_stored) {
+// What a rebuild needs before its first kernel: sizes from bounds the host knows, the scratch and the slot table reserved,
+// counters and table initialised (one launch).  mh_map_insert's merge path calls it ahead of its fused collect kernel.
+mh_status map_build_prologue(mh_map* m, hipStream_t s, size_t n, size_t n_stored, uint32_t** counters_out,
+                             unsigned long long** keys_out, uint32_t** idx_out) {
   if (!m->h_counts) {
     MH_HIP(hipHostMalloc((void**)&m->h_counts, 16 * sizeof(uint32_t), hipHostMallocDefault));
     MH_HIP(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
   }
-  const uint32_t ndt = m->params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
   // what the host can know without waiting for the device: upper bounds (every offered point kept, every new point a voxel)
   const size_t n_vox_ub = n_stored ? std::min<size_t>(n, m->n_voxels + (n - n_stored)) : n;
-  const size_t n_rec_ub = n + (ndt ? 2 * n_vox_ub : 0);
   uint64_t tsize = 64;  // hash table: power of two, load factor <= 0.5
   while (tsize < 2ull * n_vox_ub) tsize <<= 1;
   MH_TRY(m->build_e.reserve((n ? n : 1) * sizeof(uint32_t) + 64));  // vstart | counters(16)
-  uint32_t* vstart = m->build_e.as<uint32_t>();
-  uint32_t* counters = vstart + (n ? n : 1);
+  uint32_t* counters = m->build_e.as<uint32_t>() + (n ? n : 1);
   MH_TRY(m->slots.reserve(tsize * sizeof(MapSlot)));
+  if (n > 0) {
+    const size_t n_new = n - n_stored;
+    MH_TRY(m->build_a.reserve((2 * n + n_new) * sizeof(unsigned long long)));  // keys in | keys sorted | new keys sorted
+    MH_TRY(m->build_b.reserve((2 * n + n_new) * sizeof(uint32_t)));            // idx in | idx sorted | new idx sorted
+  }
   {
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((tsize + 255) / 256, 2048);
     hipLaunchKernelGGL(k_init_build, dim3(blocks), dim3(256), 0, s, counters, reinterpret_cast<uint4*>(m->slots.p), (uint32_t)tsize);
   }
+  if (counters_out) *counters_out = counters;
+  if (keys_out) *keys_out = m->build_a.as<unsigned long long>();
+  if (idx_out) *idx_out = m->build_b.as<uint32_t>();
+  return MH_OK;
+}
+
+mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc,
+                           size_t n, const int* evict, size_t n_stored, bool collected) {
+  const uint32_t ndt = m->params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
+  const size_t n_vox_ub = n_stored ? std::min<size_t>(n, m->n_voxels + (n - n_stored)) : n;
+  const size_t n_rec_ub = n + (ndt ? 2 * n_vox_ub : 0);
+  uint64_t tsize = 64;
+  while (tsize < 2ull * n_vox_ub) tsize <<= 1;
+  // (`collected`: mh_map_insert has run the prologue and its fused kernel has written the points, keys and indices)
+  if (!collected) MH_TRY(map_build_prologue(m, s, n, n_stored, nullptr, nullptr, nullptr));
+  uint32_t* vstart = m->build_e.as<uint32_t>();
+  uint32_t* counters = vstart + (n ? n : 1);
   if (n > 0) {
     const uint32_t N = (uint32_t)n;
     // scratch carve-up
@@ -579,8 +673,9 @@ mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const floa
     const uint32_t B = 256;
     const int4 ev = evict ? make_int4(evict[0], evict[1], evict[2], evict[3]) : make_int4(0, 0, 0, -1);
     const int4 ev_keys = merge_path ? make_int4(0, 0, 0, -1) : ev;  // (merge path: eviction after the merge, inside k_heads)
-    hipLaunchKernelGGL(k_keys, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, N, m->inv_vs,
-                       (uint32_t)(m->params.index_mode == MH_INDEX_TRUNC), ev_keys, m->params.far_voxel_metric, keys, idx, counters);
+    if (!collected)
+      hipLaunchKernelGGL(k_keys, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, N, m->inv_vs,
+                         (uint32_t)(m->params.index_mode == MH_INDEX_TRUNC), ev_keys, m->params.far_voxel_metric, keys, idx, counters);
     unsigned long long* keys_new = keys + 2 * n;
     uint32_t* idx_new = idx + 2 * n;
     size_t tmp = 0;
