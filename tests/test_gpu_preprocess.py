@@ -261,12 +261,15 @@ def test_map_insert_keyframes_bit_exact(ctx, oracle, vs, cap, far, side, monkeyp
 
 
 @pytest.mark.parametrize("metric", [1, 2])
-@pytest.mark.parametrize("full_sort", [False, True])
+@pytest.mark.parametrize("full_sort", ["collect", "three_launches", "full_sort"])
 def test_map_insert_far_voxel_metric_switch(ctx, oracle, metric, full_sort, monkeypatch):
-    """mh_map_params::far_voxel_metric (L1 / L2 readings of remove_voxels_farther_than, yaml:237-238) on both insertion
-    paths, against the oracle."""
-    if full_sort:
+    """mh_map_params::far_voxel_metric (L1 / L2 readings of remove_voxels_farther_than, yaml:237-238) on the three insertion
+    paths (merge with the fused collect kernel -- the default up to 0.4 M stored points --, merge with gather / compose /
+    keys as separate launches, full sort), against the oracle."""
+    if full_sort == "full_sort":
         monkeypatch.setenv("MH_MAP_FULL_SORT", "1")
+    if full_sort == "three_launches":
+        monkeypatch.setenv("MH_MAP_NO_COLLECT", "1")
     scene = synth.make_scene(779, 80.0, 12)
     g, o = capi.Map(ctx, 1.0, 20, far_voxel_metric=metric), oracle.Map(1.0, 20, far_voxel_metric=metric)
     cheb = oracle.Map(1.0, 20)
