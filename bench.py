@@ -1,32 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- scans/sec of the ICP registration hot path on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of synthetic input: S independent scans of the C2 workload
-(BASELINE.json configs[1]: ~120k-pt scan vs 1M-pt local map, 20 ICP iterations, fp32 points / fp64 accumulators), each
-against ITS OWN map (S independent draws of the generator: S sequences have S local maps, eval/cli_kitti.sh:23-36), one
-context per scan, aligned together by mh_icp_align_batch in lock step.  As SURVEY.md 8(d) / BASELINE.md section 3 define
-the metric, the timed region contains, per scan: the H->D copy of the scan (page-locked host memory, asynchronous, queued
-one step ahead on the contexts of the other buffer set so that it overlaps the current step's kernels), the alignment,
-and the D->H copy of the result -- pose, covariance, quality, counters AND Results::finalPairings (compacted on the
-device, downloaded on a copy stream that overlaps the next step).  The maps are built before the timed region (a local
-map changes only at key-frames).  `shared_map` repeats the measurement with every job on ONE map and one scan (the
-best case for the caches, round 1's configuration) as a labelled second number.
+A "step" is one pass of the hot path over one batch of synthetic input: S = 32 jobs (sequences), each with ITS OWN 1M-pt
+local map (S independent draws of the generator: S sequences have S local maps, eval/cli_kitti.sh:23-36) and K = 4
+DIFFERENT ~120k-pt sweeps against it (other sensor poses, other noise, own guesses -- consecutive scans of a sequence), i.e.
+S x K = 128 scans of the C2 workload (BASELINE.json configs[1]: 20 ICP iterations, fp32 points / fp64 accumulators) per
+step, aligned as K lock-step batches of S scans by mh_icp_align_batch, one context per job.  No two consecutive batches
+see the same inputs.  As SURVEY.md 8(d) / BASELINE.md section 3 define the metric, the timed region contains, per scan:
+the H->D copy of the scan (page-locked host memory, asynchronous, queued one batch ahead on the contexts of the other buffer
+set so that it overlaps the current batch's kernels), the alignment, and the D->H copy of the result -- pose, covariance,
+quality, counters AND Results::finalPairings (compacted on the device, downloaded on a copy stream that overlaps the next
+batch).  The maps are built before the timed region (a local map changes only at key-frames).  `shared_map` repeats the
+measurement with every job on ONE map and one scan (the best case for the caches, round 1's configuration) as a labelled
+second number.
 
 --gpus N: without WORLD_SIZE in the environment the script starts N ranks itself (torch.distributed.run on 127.0.0.1);
 each rank runs the same per-GPU batch on its own GPU (weak scaling, no data-path collective), the only collective is
 the gather of the resulting poses (RCCL all_gather of 12 doubles per scan).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline":     the match kernel (k_match4_b, one launch over all S scans): compulsory bytes per launch / its
+  "roofline":     the match kernel (k_match4_b, one launch over all S scans of a batch): compulsory bytes per launch / its
                   HIP-event duration vs the 8 TB/s HBM peak (frac <= 1 by construction), the PMC-measured HBM traffic of
-                  that kernel (profiles/), and the L2 / VALU-issue views that say what the kernel really waits for;
+                  that kernel (profiles/), the measured latency floor of its access pattern (tools/match_floor.py) and the
+                  L2 / VALU views that say what the kernel really waits for;
   "cpu_baseline": the CPU oracle (a port of the reference algorithm, not the reference binary) timed on this box's
-                  host cores on a bounded sample of the same workload;
-and, at N = 1, three labelled extras OUTSIDE `value` (bounded to ~20 s together; --no-extras skips them):
-  "single_sequence": the config-3 proxy -- molahip-lo-cli (C++) steady-state scans/s on a synthetic KITTI-format drive of
-                     ~120 k-point sweeps, per-stage milliseconds, and the CPU oracle driver timed on the same scans;
-  "creal":           the 6 k-point layer lidar3d-default.yaml really feeds align(), 32 in lock step, with its CPU figure;
-  "multi_sequence":  N = 1, 2, 4, 8 copies of that drive through one molahip-lo-cli process.
+                  host cores on a bounded sample of the same workload (thread count used AND the box's logical cores);
+and, at N = 1, labelled extras OUTSIDE `value` (--no-extras skips them):
+  "single_sequence":     the config-3 proxy -- molahip-lo-cli (C++) on a 1000-sweep synthetic CITY drive (cross streets, houses,
+                         cars, poles, trees; ~118 k raw points per sweep, skewed, per-point time stamps): whole-run and
+                         steady scans/s, ICP-layer and local-map sizes, per-stage milliseconds, ATE against the generator's
+                         ground truth, and the CPU oracle driver on the same scans (with its Python share taken out);
+  "single_sequence_ndt": the config-5 proxy -- the same drive through pipelines/lidar3d-ndt-hip.yaml, with its CPU driver;
+  "creal":               the 6 k-point layer, 32 in lock step, with its CPU figure;
+  "multi_sequence":      N = 1, 2, 4, 8 copies of the drive's first 400 scans through one molahip-lo-cli process.
 """
 import argparse
 import glob
@@ -56,26 +62,18 @@ def algorithmic_bytes_per_query(p_bar: float) -> float:
 
 def _gen(args):
     from mola_lidar_odometry_amd import synth
-    if args[0] == "sweep":  # one sweep of the synthetic drive (extras: single_sequence / multi_sequence)
-        return synth.drive_sweep(args[1])
+    if args[0] == "scanset":  # another sweep against workload (name, variant)'s map
+        return synth.workload_scan_set(args[1], args[2], args[3])
     _, name, variant = args
     return synth.workload_by_name(name, variant)
 
 
-DRIVE = dict(seed=4242, half_extent=120.0, n_boxes=160, rings=64, azimuths=1875)  # synth.make_drive's HDL-64-like drive
-
-
-def generate_inputs(name, variants, drive_scans=0):
-    """S independent draws of the generator and (extras) the sweeps of the synthetic drive, in worker processes (numpy
-    only; started before HIP is initialised).  -> (workloads, drive or None)"""
+def generate_inputs(name, variants, n_sets=1):
+    """S independent draws of the generator and, per draw, n_sets - 1 further sweeps against the same map, in worker
+    processes (numpy only; started before HIP is initialised).
+    -> (workloads, sets): sets[j][k] = (scan_xyz, T_gt, T_guess) of job j's scan set k (set 0 = the workload's own)."""
     import multiprocessing as mp
-    from mola_lidar_odometry_amd import synth
-    tasks = [("workload", name, v) for v in variants]
-    plan = None
-    if drive_scans:
-        plan = synth.drive_plan(drive_scans, seed=DRIVE["seed"])
-        tasks += [("sweep", (DRIVE["seed"], DRIVE["half_extent"], DRIVE["n_boxes"], plan["poses"][k], plan["twists"][k], plan["dt"],
-                             DRIVE["rings"], DRIVE["azimuths"], plan["seeds"][k])) for k in range(drive_scans)]
+    tasks = [("workload", name, v) for v in variants] + [("scanset", name, v, k) for v in variants for k in range(1, n_sets)]
     n_proc = max(1, min(len(tasks), (os.cpu_count() or 2) // 2, 32))
     if n_proc == 1:
         res = [_gen(t) for t in tasks]
@@ -89,8 +87,11 @@ def generate_inputs(name, variants, drive_scans=0):
             pool.close()
             pool.join()
     ws = res[:len(variants)]
-    drive = dict(poses=plan["poses"], twists=plan["twists"], stamps=plan["stamps"], scans=res[len(variants):]) if plan else None
-    return ws, drive
+    extra = res[len(variants):]
+    sets = []
+    for j, x in enumerate(ws):
+        sets.append([(x.scan_xyz, x.T_gt, x.T_guess)] + [extra[j * (n_sets - 1) + k] for k in range(n_sets - 1)])
+    return ws, sets
 
 
 def generate_workloads(name, variants):
@@ -133,12 +134,18 @@ def neighbourhood_union(w):
 
 CLI = os.path.join(ROOT, "mola_lidar_odometry_amd", "molahip-lo-cli")
 PIPELINE = os.path.join(ROOT, "pipelines", "lidar3d-default-hip.yaml")
+PIPELINE_NDT = os.path.join(ROOT, "pipelines", "lidar3d-ndt-hip.yaml")
 
 
-def run_lo_cli(seq_dir, n_seq, out_stem, timeout=240):
+def run_lo_cli(seq_dir, n_seq, out_stem, timeout=600, pipeline=PIPELINE, max_scans=None, scan_log=False):
     """molahip-lo-cli (C++, no Python in the loop) over n_seq copies of the sequence folder in ONE process: per-sequence
-    reports, per-stage host milliseconds, the N-sequence summary line."""
-    cmd = [CLI, "--pipeline", PIPELINE, "--out", out_stem + ".tum", "--profile"]
+    reports, per-stage host milliseconds, the N-sequence summary line.  The synthetic drive carries per-point time stamps in
+    the fourth float of a row (--time-field 12): the sweeps are skewed by the vehicle's motion, the de-skew filter has work."""
+    cmd = [CLI, "--pipeline", pipeline, "--out", out_stem + ".tum", "--profile", "--time-field", "12"]
+    if max_scans:
+        cmd += ["--max-scans", str(max_scans)]
+    if scan_log:
+        cmd += ["--scan-log", "auto"]
     for _ in range(n_seq):
         cmd += ["--seq-dir", seq_dir]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
@@ -151,74 +158,162 @@ def run_lo_cli(seq_dir, n_seq, out_stem, timeout=240):
     return per, prof, summary
 
 
-def sequence_extras(drive, tmp, seq_counts, cpu_seconds, log):
-    """single_sequence / multi_sequence: the stand-alone odometry driver on the synthetic KITTI-format
-    drive -- the config-3 proxy -- with the CPU oracle driver timed beside it on the same scans; then N sequences in one
-    process.  Labelled extras, never part of `value`."""
-    from mola_lidar_odometry_amd import synth, trajectory
-    out = {}
-    seq_dir = synth.write_kitti_sequence(tmp, drive)
-    n = len(drive["scans"])
-    per, prof, _ = run_lo_cli(seq_dir, 1, os.path.join(tmp, "solo"))
+def _city_drive_worker(root, n_scans, q):
+    """(child process) cast the synthetic city drive into a KITTI-format folder; hands back the plan."""
+    try:
+        from mola_lidar_odometry_amd import synth_city
+        t0 = time.perf_counter()
+        seq_dir, drive = synth_city.write_kitti_drive(root, n_scans, time_channel=True)
+        q.put(dict(seq_dir=seq_dir, poses=drive["poses"], stamps=drive["stamps"], points_per_scan=drive["points_per_scan"],
+                   seconds=time.perf_counter() - t0))
+    except BaseException as e:  # noqa: BLE001
+        q.put(dict(error=repr(e)[:400]))
+
+
+def start_city_drive(n_scans):
+    """Start the generation of the extras' drive in a child process (OpenMP ray-caster, ~2 MB per sweep on disk) so that it
+    runs beside the generation of the headline workload and the timed steps.  -> handle for finish_city_drive()."""
+    import multiprocessing as mp
+    import tempfile
+    tmp = tempfile.TemporaryDirectory(prefix="molahip_bench_")
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(2, min(16, (os.cpu_count() or 4) // 2))))
+    p = ctx.Process(target=_city_drive_worker, args=(tmp.name, n_scans, q), daemon=True)
+    p.start()
+    os.environ.pop("OMP_NUM_THREADS", None)
+    return dict(tmp=tmp, proc=p, queue=q)
+
+
+def finish_city_drive(h, timeout=900):
+    res = h["queue"].get(timeout=timeout)
+    h["proc"].join(timeout=30)
+    if "error" in res:
+        raise RuntimeError("city drive generation failed: " + res["error"])
+    return res
+
+
+def cpu_driver_sample(pipeline, seq_dir, stamps, est, scan_seconds, cpu_seconds, label):
+    """The CPU oracle driver (oracle/odometry_oracle.py: the per-scan control flow in Python, every point touched by the C
+    oracle under OpenMP) on the first scans of the same folder, bounded by cpu_seconds.  Reports its rate over the scans it
+    processed, the share of that time spent inside the C library (so that the interpreter's overhead is visible and can be
+    taken out), and the device driver's rate over THE SAME scans."""
+    from oracle import odometry_oracle as oo
+    from oracle import oracle_c
+    threads = min(16, oracle_c.max_threads())
+    o = oo.OdometryOracle(pipeline, n_threads=threads)
+    files = sorted(glob.glob(os.path.join(seq_dir, "velodyne", "*.bin")))
+    t_steady, c_steady, k_steady, done, t_all = 0.0, 0.0, 0, 0, 0.0
+    for k, f in enumerate(files):
+        rows = np.fromfile(f, dtype=np.float32).reshape(-1, 4)
+        xyz, t = np.ascontiguousarray(rows[:, :3]), np.ascontiguousarray(rows[:, 3])
+        oracle_c.reset_c_seconds()
+        tc = time.perf_counter()
+        o.on_lidar(float(stamps[k] - stamps[0]), xyz, t)
+        d = time.perf_counter() - tc
+        t_all += d
+        done += 1
+        if k >= 5:
+            t_steady += d
+            c_steady += oracle_c.C_SECONDS
+            k_steady += 1
+        if t_all > cpu_seconds and k_steady >= 10:
+            break
+    rate = k_steady / t_steady if t_steady > 0 else None
+    rate_c = k_steady / c_steady if c_steady > 0 else None
+    out = {"value": rate, "unit": "scans/sec", "cores": threads, "host_logical_cores": os.cpu_count(), "kind": "port",
+           "value_c_library_only": rate_c, "python_share_of_time": (1.0 - c_steady / t_steady) if t_steady > 0 else None,
+           "sample": "%s: scans 5..%d of the same folder through the Python loop of oracle/odometry_oracle.py on the C oracle (OpenMP, %d "
+                     "threads of %s logical cores), %.1f s; value_c_library_only counts only the time inside the C library (filters, "
+                     "de-skew, matching, Gauss-Newton, covariance, map insertion)" % (label, done - 1, threads, os.cpu_count(), t_all)}
+    if scan_seconds is not None and len(scan_seconds) >= done and done > 5:
+        gpu_t = float(np.sum(scan_seconds[5:done]))
+        out["device_driver_same_scans_per_s"] = (done - 5) / gpu_t if gpu_t > 0 else None
+        if rate_c and gpu_t > 0:
+            out["ratio_device_vs_cpu_c_only_same_scans"] = out["device_driver_same_scans_per_s"] / rate_c
+            out["ratio_device_vs_cpu_with_python_same_scans"] = out["device_driver_same_scans_per_s"] / rate
+    if est is not None and all("pose" in r for r in o.records):
+        est_cpu = np.stack([r["pose"] for r in o.records]).reshape(-1, 3, 4)
+        m = min(len(est), len(est_cpu))
+        out["max_pose_diff_device_vs_cpu_m"] = float(np.abs(est[:m, :3, 3] - est_cpu[:m, :, 3]).max())
+    return out
+
+
+def one_sequence(seq_dir, gt, stamps, n_raw, tmp, pipeline, tag, cpu_seconds, what):
+    from mola_lidar_odometry_amd import synth_city, trajectory
+    per, prof, _ = run_lo_cli(seq_dir, 1, os.path.join(tmp, tag), pipeline=pipeline, scan_log=True)
     p0 = per[0]
-    st, est = trajectory.read_tum(p0["tum"])
-    gt = np.tile(np.eye(4), (n, 1, 1))
-    gt[:, :3, :] = drive["poses"].reshape(n, 3, 4)
+    _, est = trajectory.read_tum(p0["tum"])
+    n = min(len(est), len(gt))
+    path = synth_city.path_length(gt[:n, :3, :].reshape(n, 12))
+    ate_o, ate_s = trajectory.ate_rmse(est[:n], gt[:n], "origin"), trajectory.ate_rmse(est[:n], gt[:n], "se3")
+    scan_seconds = None
+    log = p0["tum"][:-4] + "_scans.csv"
+    if os.path.exists(log):
+        scan_seconds = np.loadtxt(log, delimiter=",", skiprows=1, usecols=1)
     single = {"value": p0["steady_scans_per_s"], "unit": "scans/sec", "whole_run_scans_per_s": p0["scans_per_s"],
               "scans": p0["scans"], "good": p0["good"], "keyframes": p0["keyframes"],
               "icp_iterations_per_scan": p0["icp_iterations"] / max(1, p0["scans"]),
+              "mean_raw_points": p0["mean_raw_points"], "mean_icp_layer_points": p0["mean_icp_points"],
+              "mean_map_layer_points": p0["mean_map_layer_points"], "final_map_points": p0["final_map_points"],
+              "max_map_points": p0["max_map_points"], "final_map_voxels": p0["final_map_voxels"],
               "ms_per_scan_by_stage": prof[0] if prof else None,
-              "ate_rmse_m": float(trajectory.ate_rmse(est, gt[:len(est)])) if len(est) == n else None,
-              "workload": "%d sweeps of %d raw points (HDL-64-like, synthetic street canyon, KITTI .bin rows), pipelines/"
-                          "lidar3d-default-hip.yaml: device filters + de-skew, ICP on the decimated layer, key-frame map updates; "
-                          "steady state = registration time without the first 5 scans; file reading excluded" % (n, len(drive["scans"][0][0])),
+              "path_m": path, "ate_rmse_origin_m": ate_o, "ate_rmse_se3_m": ate_s, "ate_origin_pct_of_path": 100.0 * ate_o / path if path else None,
+              "workload": "%d sweeps of ~%d raw points (HDL-64-like: 64 x 1875 rays, 80 m; synthetic city with cross streets, houses, parked "
+                          "cars, poles, trees; the vehicle pulls away from rest, turns left and right; KITTI .bin rows with the point's time "
+                          "stamp in the 4th float), %s: device filters + de-skew, ICP on the decimated layer, key-frame map updates; steady "
+                          "state = registration time without the first 5 scans; file reading excluded; ATE against the generator's ground "
+                          "truth" % (p0["scans"], int(np.mean(n_raw)), what),
               "driver": "molahip-lo-cli (C++), next-scan prefetch on"}
-    # the CPU oracle driver on the same scans (no per-point time stamps, like the .bin files), bounded
     try:
-        from oracle import odometry_oracle as oo
-        from oracle import oracle_c
-        threads = min(16, oracle_c.max_threads())
-        o = oo.OdometryOracle(PIPELINE, n_threads=threads)
-        t_all, t_steady, k_steady, done = 0.0, 0.0, 0, 0
-        for k, ((xyz, _), stamp) in enumerate(zip(drive["scans"], drive["stamps"] - drive["stamps"][0])):
-            tc = time.perf_counter()
-            o.on_lidar(float(stamp), xyz, None)
-            d = time.perf_counter() - tc
-            t_all += d
-            done += 1
-            if k >= 5:
-                t_steady += d
-                k_steady += 1
-            if t_all > cpu_seconds and k_steady >= 10:
-                break
-        cpu_rate = k_steady / t_steady if t_steady > 0 else None
-        est_cpu = np.stack([r["pose"] for r in o.records if "pose" in r]) if all("pose" in r for r in o.records) else None
-        single["cpu_driver"] = {"value": cpu_rate, "unit": "scans/sec", "cores": threads, "kind": "port",
-                                "sample": "the first %d scans of the same drive through the Python oracle driver on the C oracle "
-                                          "(OpenMP, %d threads), steady state without the first 5 scans, %.1f s" % (done, threads, t_all)}
-        single["ratio_vs_cpu_driver"] = (single["value"] / cpu_rate) if cpu_rate else None
-        if est_cpu is not None and len(est) >= done:
-            single["max_pose_diff_vs_cpu_driver_m"] = float(np.abs(est[:done, :3, 3] - est_cpu.reshape(-1, 3, 4)[:done, :, 3]).max())
+        single["cpu_driver"] = cpu_driver_sample(pipeline, seq_dir, stamps, est, scan_seconds, cpu_seconds, what)
+        cd = single["cpu_driver"]
+        single["ratio_vs_cpu_driver"] = cd.get("ratio_device_vs_cpu_c_only_same_scans")
     except Exception as e:  # noqa: BLE001  (an extra must not take the headline line down)
         single["cpu_driver"] = {"error": repr(e)[:300]}
+    return single, p0
+
+
+def sequence_extras(drive, tmp, seq_counts, cpu_seconds, log, multi_scans=400):
+    """single_sequence / single_sequence_ndt / multi_sequence: the stand-alone odometry driver on the synthetic KITTI-format
+    city drive -- the config-3 and config-5 proxies -- with the CPU oracle driver timed beside it on the same scans and the
+    trajectory compared with the generator's ground truth; then N copies of the drive in one process.  Labelled extras,
+    never part of `value`."""
+    from mola_lidar_odometry_amd import synth_city
+    out = {}
+    seq_dir = drive["seq_dir"]
+    gt = synth_city.ground_truth_44(drive)
+    stamps = drive["stamps"]
+    single, p0 = one_sequence(seq_dir, gt, stamps, drive["points_per_scan"], tmp, PIPELINE, "solo", cpu_seconds, "pipelines/lidar3d-default-hip.yaml")
+    single["drive_generation_s"] = drive.get("seconds")
     out["single_sequence"] = single
     log("single_sequence done")
-    multi = {"1": {"steady_scans_per_s": p0["steady_scans_per_s"], "whole_run_scans_per_s": p0["scans_per_s"]}}
+    try:
+        ndt, _ = one_sequence(seq_dir, gt, stamps, drive["points_per_scan"], tmp, PIPELINE_NDT, "solo_ndt", cpu_seconds,
+                              "pipelines/lidar3d-ndt-hip.yaml (mola::NDT map, Matcher_Point2Plane + Matcher_Points_DistanceThreshold)")
+        out["single_sequence_ndt"] = ndt
+    except Exception as e:  # noqa: BLE001
+        out["single_sequence_ndt"] = {"error": repr(e)[:300]}
+    log("single_sequence_ndt done")
+    multi = {}
     identical = True
-    solo_tum = open(p0["tum"]).read()
-    for c in seq_counts:
-        if c <= 1:
-            continue
+    solo_tum = None
+    for c in [1] + [c for c in seq_counts if c > 1]:
         try:
-            perc, _, summ = run_lo_cli(seq_dir, c, os.path.join(tmp, "multi%d" % c))
-            multi[str(c)] = {"steady_scans_per_s": summ["steady_scans_per_s"], "whole_run_scans_per_s": summ["scans_per_s"]}
-            identical = identical and all(open(q["tum"]).read() == solo_tum for q in perc)
+            perc, _, summ = run_lo_cli(seq_dir, c, os.path.join(tmp, "multi%d" % c), max_scans=multi_scans)
+            if c == 1:
+                solo_tum = open(perc[0]["tum"]).read()
+                multi["1"] = {"steady_scans_per_s": perc[0]["steady_scans_per_s"], "whole_run_scans_per_s": perc[0]["scans_per_s"]}
+            else:
+                multi[str(c)] = {"steady_scans_per_s": summ["steady_scans_per_s"], "whole_run_scans_per_s": summ["scans_per_s"]}
+                identical = identical and all(open(q["tum"]).read() == solo_tum for q in perc)
         except Exception as e:  # noqa: BLE001
             multi[str(c)] = {"error": repr(e)[:300]}
     out["multi_sequence"] = {"unit": "scans/sec", "sequences_in_one_process": multi, "trajectories_identical_to_solo_run": identical,
-                             "note": "N copies of the drive through ONE molahip-lo-cli process (a host thread per sequence, alignments "
-                                     "merged into lock-step batches); steady = registration time of the slowest thread without its "
-                                     "first 5 scans; whole run = wall clock incl. process start-up"}
+                             "scans_per_sequence": multi_scans,
+                             "note": "N copies of the first %d scans of the drive through ONE molahip-lo-cli process (a host thread per "
+                                     "sequence, alignments merged into lock-step batches); steady = registration time of the slowest thread "
+                                     "without its first 5 scans; whole run = wall clock incl. process start-up" % multi_scans}
     return out
 
 
@@ -239,6 +334,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=32, help="scans per step and GPU (one context each; mh_icp_align_batch aligns them in lock step)")
+    ap.add_argument("--scan-sets", type=int, default=4,
+                    help="batches per step: a step aligns this many DIFFERENT sweeps per job (other sensor poses, other noise, own guesses) "
+                         "against the job's map, one lock-step batch each, so that consecutive batches never see identical inputs")
     ap.add_argument("--workload", default="c2", choices=["c2", "creal", "small"])
     ap.add_argument("--maps", default="distinct", choices=["distinct", "shared"],
                     help="distinct (default): every job has its own map and scan; shared: one map and scan for all jobs")
@@ -256,7 +354,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not time the match kernel with HIP events")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the labelled extra measurements (single_sequence / creal / multi_sequence, N = 1 only, outside `value`)")
-    ap.add_argument("--extras-scans", type=int, default=100, help="length of the synthetic drive of the sequence extras")
+    ap.add_argument("--extras-scans", type=int, default=1000, help="length of the synthetic city drive of the sequence extras")
+    ap.add_argument("--extras-cpu-seconds", type=float, default=8.0, help="budget of each CPU oracle driver sample of the extras")
     ap.add_argument("--extras-sequences", default="1,2,4,8", help="multi_sequence: sequences run together in one process")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, gather their ranks over gloo and print n_gpus (no GPU needed: tests the self-launch)")
@@ -285,7 +384,9 @@ def main():
     n_var = 1 if args.maps == "shared" else S
     # inputs first (worker processes, before the HIP runtime exists in this one); ranks draw different variants
     want_extras = world == 1 and not args.no_extras and args.workload == "c2" and args.maps == "distinct"
-    ws, drive = generate_inputs(args.workload, [rank * S + j for j in range(n_var)], args.extras_scans if want_extras else 0)
+    city = start_city_drive(args.extras_scans) if want_extras and rank == 0 else None
+    K = max(1, args.scan_sets)
+    ws, sets = generate_inputs(args.workload, [rank * S + j for j in range(n_var)], K)
     w = ws[0]
 
     import torch  # plumbing: pinned host memory, process group, barrier, device selection
@@ -306,9 +407,10 @@ def main():
                             kernel_param=w.kernel_param, poll_every=w.n_iters, profile=2 if prof else 0)
 
     class Setup:
-        """Device-side state of one measurement: S jobs, two buffer sets (A/B) of contexts + scans, pinned host mirrors."""
+        """Device-side state of one measurement: S jobs, two buffer sets (A/B) of contexts + scans, pinned host mirrors of the
+        K scan sets every job rotates through (set k of a step is batch k of that step)."""
 
-        def __init__(self, wl, io):
+        def __init__(self, wl, scan_sets, io):
             self.wl, self.io = wl, io != "none"
             self.up, self.dl = io in ("both", "upload"), io in ("both", "pairs")
             self.thread, self.worker_error, self.calls, self.last_call = None, None, {}, None
@@ -317,69 +419,77 @@ def main():
             if len(self.maps) == 1:
                 self.maps = self.maps * S
             self.job_w = [wl[j % len(wl)] for j in range(S)]
+            self.job_sets = [scan_sets[j % len(wl)] for j in range(S)]
+            self.K = len(self.job_sets[0]) if self.up else 1   # resident inputs: the scans never change, one set
             rng = np.random.default_rng(1000 + rank)
-            self.guesses = []
-            for x in self.job_w:  # guesses jittered by 1 cm so that jobs sharing a scan are not byte-identical
-                g = x.guess_ypr.copy()
-                g[:3] += rng.normal(0, 0.01, 3)
-                self.guesses.append(synth.pose_from_ypr(g))
-            self.pinned = []  # page-locked host copy of every job's scan (what a driver would hand over)
-            for x in self.job_w:  # interleaved xyz records, the form a sensor driver delivers: one copy per scan
-                t = torch.from_numpy(np.ascontiguousarray(x.scan_xyz, dtype=np.float32)).pin_memory()
-                self.pinned.append(t)
+            self.guesses = []  # [set][job]
+            for k in range(self.K):
+                g_k = []
+                for x, st in zip(self.job_w, self.job_sets):  # guesses jittered by 1 cm so that jobs sharing a scan are not byte-identical
+                    T = np.array(st[k][2], np.float64).copy()
+                    T[[3, 7, 11]] += rng.normal(0, 0.01, 3)
+                    g_k.append(T)
+                self.guesses.append(g_k)
+            # page-locked host copy of every job's scans (what a driver would hand over): interleaved xyz records, the form a
+            # sensor driver delivers, one copy per scan
+            self.pinned = [[torch.from_numpy(np.ascontiguousarray(st[k][0], dtype=np.float32)).pin_memory() for st in self.job_sets]
+                           for k in range(self.K)]
+            self.sizes = [[len(st[k][0]) for st in self.job_sets] for k in range(self.K)]
             # one context per job and buffer set; the contexts of a set share ONE stream (the lock-step batch runs on its
             # first job's stream anyway): the uploads of the other set are then a second stream, not 32 -- HIP maps streams
             # onto a handful of hardware queues, and a copy + de-interleave pair waiting at the head of a queue it shares
             # with the batch's stream stalls the batch's kernels behind it (measured: +2 ms per step with 64 streams)
-            n_sets = 2 if self.up else 1
-            self.streams = [torch.cuda.Stream(device=local_rank) for _ in range(n_sets)] if args.shared_stream else None
-            self.ctxs = [[capi.Context(local_rank, stream=self.streams[k].cuda_stream if self.streams else None) for _ in range(S)]
-                         for k in range(n_sets)]
-            self.scans = [[capi.Scan(c, x.scan_xyz) for c, x in zip(cs, self.job_w)] for cs in self.ctxs]
-            self.sizes = [len(x.scan_xyz) for x in self.job_w]
-            nbytes = sum(capi.pairs_block_bytes(n) for n in self.sizes)
+            n_bufs = 2 if self.up else 1
+            self.streams = [torch.cuda.Stream(device=local_rank) for _ in range(n_bufs)] if args.shared_stream else None
+            self.ctxs = [[capi.Context(local_rank, stream=self.streams[b].cuda_stream if self.streams else None) for _ in range(S)]
+                         for b in range(n_bufs)]
+            self.scans = [[capi.Scan(c, st[0][0]) for c, st in zip(cs, self.job_sets)] for cs in self.ctxs]
+            nbytes = max(sum(capi.pairs_block_bytes(n) for n in sz) for sz in self.sizes)
             self.blocks = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)] if self.dl else None
-            self.k = 0
+            self.k = 0  # batches run so far: batch k reads buffer k & 1 and scan set k % K
 
-        def upload(self, which, delay=0.0):
-            if delay:  # (second host thread) let the main thread queue its step first: both contend for the HIP runtime's locks
+        def upload(self, buf, sset, delay=0.0):
+            if delay:  # (second host thread) let the main thread queue its batch first: both contend for the HIP runtime's locks
                 time.sleep(delay)
-            for sc, t, n in zip(self.scans[which], self.pinned, self.sizes):
+            for sc, t, n in zip(self.scans[buf], self.pinned[sset], self.sizes[sset]):
                 sc.update_interleaved_pinned(t.data_ptr(), n, 12)
 
-        def _worker_main(self):  # the upload thread: one per Setup, fed through a queue (no thread start/join per step)
+        def _worker_main(self):  # the upload thread: one per Setup, fed through a queue (no thread start/join per batch)
             while True:
                 item = self.todo.get()
                 if item is None:
                     return
                 try:
-                    self.upload(item, args.upload_delay_ms * 1e-3)
+                    self.upload(item[0], item[1], args.upload_delay_ms * 1e-3)
                 except BaseException as e:  # noqa: BLE001  (handed to the main thread)
                     self.worker_error = e
                 self.done.put(item)
 
-        def call_for(self, sset, cur):
-            """The marshalled arguments of this buffer set's batch (capi.BatchCall): built once, reused every step -- the
-            per-step host work is the C call."""
-            key = (sset, cur if self.dl else -1)
+        def call_for(self, buf, cur, sset):
+            """The marshalled arguments of a batch (capi.BatchCall): built once per (buffer, pairs block, scan set), reused every
+            step -- the per-batch host work is the C call."""
+            key = (buf, cur if self.dl else -1, sset)
             if key not in self.calls:
                 if self.dl:
-                    self.calls[key] = capi.BatchCall(self.maps, self.scans[sset], self.guesses, params,
+                    self.calls[key] = capi.BatchCall(self.maps, self.scans[buf], self.guesses[sset], params,
                                                      pairs_block=self.blocks[cur].data_ptr(), pairs_mem=capi.MEM_HOST_PINNED)
                 else:
-                    self.calls[key] = capi.BatchCall(self.maps, self.scans[sset], self.guesses, params)
+                    self.calls[key] = capi.BatchCall(self.maps, self.scans[buf], self.guesses[sset], params)
             return self.calls[key]
 
-        def step(self):
-            """One batch; returns (match_kernel_ms, n_match_launches) of job 0 (lock step: its share of the launches)."""
+        def batch(self):
+            """One lock-step batch; returns (match_kernel_ms, n_match_launches) of job 0 (lock step: its share of the launches)."""
             if not self.io:
-                self.last_call = self.call_for(0, 0)
+                self.last_call = self.call_for(0, 0, 0)
                 r = self.last_call.run()
+                self.k += 1
                 return r[0].match_kernel_ms, int(r[0].n_match_launches)
             cur = self.k & 1
-            sset = cur if self.up else 0
+            buf = cur if self.up else 0
+            sset = self.k % self.K
             pending = False
-            if self.up:  # next step's scans: asynchronous copies on the OTHER buffer set's streams
+            if self.up:  # next batch's scans: asynchronous copies on the OTHER buffer set's stream
+                nxt = (1 - cur, (self.k + 1) % self.K)
                 if args.upload_thread:  # queued by a second host thread while this one blocks in the batch call below
                     if self.thread is None:
                         import queue
@@ -387,11 +497,11 @@ def main():
                         self.todo, self.done = queue.SimpleQueue(), queue.SimpleQueue()
                         self.thread = threading.Thread(target=self._worker_main, daemon=True)
                         self.thread.start()
-                    self.todo.put(1 - cur)
+                    self.todo.put(nxt)
                     pending = True
                 else:
-                    self.upload(1 - cur)
-            self.last_call = self.call_for(sset, cur)
+                    self.upload(*nxt)
+            self.last_call = self.call_for(buf, cur, sset)
             r = self.last_call.run()
             if pending:
                 self.done.get()
@@ -399,6 +509,15 @@ def main():
                     raise self.worker_error
             self.k += 1
             return r[0].match_kernel_ms, int(r[0].n_match_launches)
+
+        def step(self):
+            """One step = one pass over the job's K scan sets: K lock-step batches of S scans each."""
+            ms, launches = 0.0, 0
+            for _ in range(self.K):
+                m, l = self.batch()
+                ms += m
+                launches += l
+            return ms, launches
 
         def sync(self):
             for cs in self.ctxs:
@@ -410,7 +529,7 @@ def main():
 
         def run(self, steps, warmup):
             if self.up:
-                self.upload(self.k & 1)
+                self.upload(self.k & 1, self.k % self.K)
             for _ in range(warmup):
                 self.step()
             self.sync()
@@ -425,9 +544,12 @@ def main():
             dt = mdist.max_over_ranks(dt, device="cuda" if distributed else None)  # MAX over ranks
             return dt, ms, launches, self.last_call.results()
 
+        def last_set(self):
+            return (self.k - 1) % self.K
+
         def last_pairs(self, results):
             cur = (self.k - 1) & 1
-            return capi.unpack_pairs_block(self.blocks[cur].numpy(), self.sizes, results)
+            return capi.unpack_pairs_block(self.blocks[cur].numpy(), self.sizes[self.last_set()], results)
 
         def close(self):
             self.sync()
@@ -442,14 +564,15 @@ def main():
             self.map_ctx.close()
 
     io = "none" if args.no_io else args.io
-    main_run = Setup(ws, io)
+    main_run = Setup(ws, sets, io)
+    KS = main_run.K  # batches (= scan sets) per step
     dt, match_ms, match_launches, last = main_run.run(args.steps, args.warmup)
     # outside the timed region: the same kernel with nothing else on the device (S = 1), what rocprofv3 --stats of a
     # one-stream run reports per launch
     iso_ms, iso_launches = 0.0, 0
     if prof and rank == 0:
         for _ in range(3):
-            for r in capi.icp_align_batch(main_run.maps[:1], main_run.scans[0][:1], main_run.guesses[:1], params):
+            for r in capi.icp_align_batch(main_run.maps[:1], main_run.scans[0][:1], main_run.guesses[0][:1], params):
                 iso_ms += r["match_kernel_ms"]
                 iso_launches += r["n_match_launches"]
     # the trivial result gather: poses of the last step from every rank, RCCL all_gather
@@ -458,12 +581,15 @@ def main():
     pairs_last = main_run.last_pairs(last) if main_run.dl else None
     if pairs_last is not None:
         pairs_last = [dict(local_idx=p["local_idx"].copy(), global_idx=p["global_idx"].copy(), d2=p["d2"].copy()) for p in pairs_last]
-    guesses = main_run.guesses
+    last_set = main_run.last_set()
+    guesses = main_run.guesses[last_set]     # the inputs of the LAST timed batch: what `last` / `pairs_last` belong to
+    last_scans = [st[last_set][0] for st in main_run.job_sets]
+    guess0 = main_run.guesses[0][0]
     main_run.close()
 
     shared = None
     if args.maps == "distinct" and not args.no_shared_run and S > 1:
-        sh = Setup(ws[:1], io)
+        sh = Setup(ws[:1], [sets[0][:1]], io)
         sdt, sms, sl, _ = sh.run(max(2, args.steps // 2), 1)
         shared = {"value": world * max(2, args.steps // 2) * S / sdt, "unit": "scans/sec",
                   "match_kernel_ms_per_scan": (sms / sl) if sl else None,
@@ -489,7 +615,7 @@ def main():
                 scene = synth.make_scene(12345 + 1009 * v, 120.0, 40)
                 cws.append(dataclasses.replace(x, name="Creal_6k_vs_1M" + ("#%d" % v if v else ""),
                                                scan_xyz=synth.make_scan(scene, x.pose_gt_ypr, 32, 192, 54321 + 31 * v)))
-            cr = Setup(cws, io)
+            cr = Setup(cws, [[(x.scan_xyz, x.T_gt, x.T_guess)] for x in cws], io)
             csteps = max(10, args.steps)
             cdt, cms, cl, clast = cr.run(csteps, 3)
             creal = {"value": csteps * S / cdt, "unit": "scans/sec", "ms_per_step": 1e3 * cdt / csteps, "scans_per_step": S,
@@ -497,7 +623,7 @@ def main():
                      "match_kernel_ms_per_scan": (cms / cl) if cl else None,
                      "workload": "32 x 192 ray-cast scan (~6 k points) vs the same 1M-pt maps, 20 ICP iterations, lock step, "
                                  "scan H2D + result D2H incl. finalPairings inside the timed region"}
-            cguess = cr.guesses
+            cguess = cr.guesses[0]
             cr.close()
             from oracle import oracle_c
             opc = oracle_c.ICPParams(max_iterations=cws[0].n_iters, disable_stall_test=True, threshold=cws[0].threshold,
@@ -524,14 +650,17 @@ def main():
             extras["creal"] = {"error": repr(e)[:300]}
         elog("creal done")
         try:
-            import tempfile
-            with tempfile.TemporaryDirectory(prefix="molahip_bench_") as tmp:
-                extras.update(sequence_extras(drive, tmp, [int(v) for v in args.extras_sequences.split(",") if v], 6.0, elog))
+            drive = finish_city_drive(city)
+            elog("city drive ready (generated in %.1f s beside the headline measurement)" % drive["seconds"])
+            extras.update(sequence_extras(drive, city["tmp"].name, [int(v) for v in args.extras_sequences.split(",") if v],
+                                          args.extras_cpu_seconds, elog))
         except Exception as e:  # noqa: BLE001
-            extras["single_sequence"] = {"error": repr(e)[:300]}
+            extras.setdefault("single_sequence", {"error": repr(e)[:300]})
+        finally:
+            city["tmp"].cleanup()
         elog("sequence extras done")
 
-    scans_total = world * args.steps * S
+    scans_total = world * args.steps * S * KS
     value = scans_total / dt
 
     out = {
@@ -542,7 +671,10 @@ def main():
         "config": {"workload": f"{ws[0].name}: {n_scan}-pt scan vs {n_map}-pt voxel-hashed map (voxel {w.voxel_size} m, "
                                f"cap {w.cap}), {w.n_iters} ICP iterations x 2 GN steps, GM kernel, sigma={w.sigma} "
                                "schedule of lidar3d-default.yaml:190,198",
-                   "scans_per_step_per_gpu": S, "maps": args.maps,
+                   "scans_per_step_per_gpu": S * KS, "scans_per_batch": S, "batches_per_step": KS,
+                   "inputs_per_step": "every job aligns %d different sweeps per step (other sensor poses along the street, other noise, "
+                                      "own guesses) against its map, one lock-step batch of %d scans each" % (KS, S),
+                   "maps": args.maps,
                    "distinct_maps_per_gpu": len(ws), "map_bytes_per_gpu": int(len(ws) * (n_map * 16 + 4 * 2 ** 20)),
                    "timed_region": {"both": "scan H2D (pinned, async, one step ahead) + align + result D2H incl. finalPairings",
                                     "upload": "scan H2D (pinned, async, one step ahead) + align + result D2H without finalPairings",
@@ -570,35 +702,35 @@ def main():
             for nt in (8, 16, 24, 32, 48, 64, 96, 128):
                 if nt > oracle_c.max_threads():
                     break
-                oracle_c.icp_align(om, w.scan_xyz, guesses[0], warm, n_threads=nt)  # thread creation at this width
+                oracle_c.icp_align(om, w.scan_xyz, guess0, warm, n_threads=nt)  # thread creation at this width
                 tc = time.perf_counter()
-                oracle_c.icp_align(om, w.scan_xyz, guesses[0], op, n_threads=nt)    # one FULL alignment, as sampled below
+                oracle_c.icp_align(om, w.scan_xyz, guess0, op, n_threads=nt)    # one FULL alignment, as sampled below
                 tcal = time.perf_counter() - tc
                 if best_t is None or tcal < best_t:
                     cores, best_t = nt, tcal
             n_done, t_cpu, o = 0, 0.0, None
             while t_cpu < args.cpu_seconds and n_done < 64:
                 tc = time.perf_counter()
-                o = oracle_c.icp_align(om, w.scan_xyz, guesses[0], op, n_threads=cores)
+                o = oracle_c.icp_align(om, w.scan_xyz, guess0, op, n_threads=cores)
                 t_cpu += time.perf_counter() - tc
                 n_done += 1
             p_bar = o["n_candidates_total"] / (w.n_iters * n_scan)
-            cpu = {"value": n_done / t_cpu, "unit": "scans/sec", "cores": cores, "kind": "port",
+            cpu = {"value": n_done / t_cpu, "unit": "scans/sec", "cores": cores, "host_logical_cores": os.cpu_count(), "kind": "port",
                    "sample": f"{n_done} full alignment(s) of job 0's workload ({w.n_iters} iterations each) "
-                             f"with the C oracle (OpenMP, {cores} threads) in {t_cpu:.1f} s"}
+                             f"with the C oracle (OpenMP, {cores} threads of {os.cpu_count()} logical cores) in {t_cpu:.1f} s"}
             # parity of the timed product path against the oracle: EVERY job of the last timed step
             worst, pairs_equal, idx_equal = 0.0, True, True
             for j in range(S):
                 x = ws[j % len(ws)]
                 omj = om if j % len(ws) == 0 else oracle_c.Map(x.voxel_size, x.cap).insert(x.map_xyz)
-                oj = oracle_c.icp_align(omj, x.scan_xyz, guesses[j], op, n_threads=cores, want_pairs=pairs_last is not None)
+                oj = oracle_c.icp_align(omj, last_scans[j], guesses[j], op, n_threads=cores, want_pairs=pairs_last is not None)
                 worst = max(worst, float(np.abs(last[j]["T"] - oj["T"]).max()))
                 pairs_equal = pairs_equal and last[j]["n_final_pairs"] == oj["n_final_pairs"]
                 if pairs_last is not None:
                     pj = oj["pairs"]
                     idx_equal = idx_equal and np.array_equal(pairs_last[j]["local_idx"], pj["local_idx"]) and \
                         np.array_equal(pairs_last[j]["global_idx"], pj["global_idx"]) and np.array_equal(pairs_last[j]["d2"], pj["d2"])
-            out["parity_vs_cpu"] = {"jobs_checked": S, "max_abs_pose_diff": worst, "tolerance": 1e-4,
+            out["parity_vs_cpu"] = {"jobs_checked": S, "scan_set_checked": last_set, "max_abs_pose_diff": worst, "tolerance": 1e-4,
                                     "n_pairs_equal": bool(pairs_equal),
                                     "downloaded_final_pairings_bit_equal": bool(idx_equal) if pairs_last is not None else None}
         stats_file = os.path.join(ROOT, "tests", "golden", "workload_stats.json")

@@ -32,7 +32,7 @@ HashedVoxelPointCloudHIP::~HashedVoxelPointCloudHIP()
 void HashedVoxelPointCloudHIP::ensure_device() const
 {
     if (map_) return;
-    mh_check(mh_ctx_create(0, nullptr, &ctx_), "mh_ctx_create");
+    mh_check(mh_ctx_create(molahip_host::device_index(), nullptr, &ctx_), "mh_ctx_create");  // MOLA_HIP_DEVICE, like ICP_HIP
     mh_map_params p{};
     p.voxel_size                  = voxel_size_;                                   // creationOpts.voxel_size (yaml:233)
     p.max_points_per_voxel        = insertionOptions.max_points_per_voxel;        // yaml:235

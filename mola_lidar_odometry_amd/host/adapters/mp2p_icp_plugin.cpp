@@ -6,11 +6,14 @@
 // (DECLARE_PARAMETER_*), the iteration hook, the profiler and the ParameterSource attachment keep working, reads the
 // parsed parameters of the UPSTREAM matcher / solver objects the pipeline file names, and forwards the numeric work to the
 // C ABI of libmolahip (include/molahip.h).  Registration uses the same RTTI mechanism as the reference's own module
-// (module/src/register.cpp:40-46).  The ONLY name this library adds to MRPT's class factory for the ICP side is
+// (module/src/register.cpp:40-46).  The names this library adds to MRPT's class factory for the ICP side are
 //
-//     mp2p_icp::ICP_HIP
+//     mp2p_icp::ICP_HIP                                   (this file: the fused device loop)
+//     mp2p_icp::Matcher_Points_DistanceThreshold_HIP      (mp2p_icp_granular.cpp: one matcher call = one device search)
+//     mp2p_icp::Matcher_Point2Plane_HIP
+//     mp2p_icp::Solver_GaussNewton_HIP                    (one solver call = one device accumulate + solve)
 //
-// and the pipeline files that select it are the reference's own files with that one class_name changed
+// and the pipeline files that select ICP_HIP are the reference's own files with that one class_name changed
 // (pipelines/make_mola_hip.py -> pipelines/generated/lidar3d-{default,ndt}-mola-hip.yaml; tests/test_mola_hip_pipelines.py
 // checks statically that every class name in them is either upstream's or registered here, and that every key
 // LidarOdometry.cpp:246-483 requires is present):
@@ -36,6 +39,8 @@
 //   MOLA_HIP_MIN_DELTA / MOLA_HIP_MAX_COST          Gauss-Newton early exits, 1e-7 / 0                           (U8)
 //   MOLA_HIP_PT2PL_MODE      plane (default: |n.(p-c)| < distanceThreshold) | centroid (|p-c| < distanceThreshold) (U10)
 //   MOLA_HIP_FORCE_CPU=1     every call goes to the upstream loop (sanity A/A through the same plugin)
+//   MOLA_HIP_DEVICE=n        the GPU this process uses (default 0): eval/cli_kitti.sh:23-36 runs one process per sequence,
+//                            `parallel -j8 MOLA_HIP_DEVICE='{= $_ = slot() - 1 =}' ...` spreads them over a node's GPUs
 //   MOLA_HIP_ALIGN_TRACE=f   one CSV row per align() -- which loop ran, nIterations, terminationReason, quality, pairing
 //                            counts, pose -- from BOTH loops (with MOLA_HIP_FORCE_CPU=1 it records the reference's own
 //                            numbers): what tools/parity_pin.py diffs per scan besides the TUM poses
@@ -55,131 +60,22 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
 #include <unordered_map>
 #include <vector>
 
-#include "hashed_voxel_pointcloud_hip.h"
-#include "molahip.h"
+#include "molahip_mrpt_common.h"        // device session, map mirror, MOLA_HIP_* switches
 #include "molahip_host/hook_replay.h"  // the opaque iteration hook on the fused loop (compiled + tested via host/src/icp.cpp)
-#include "molahip_host/plugin_switches.h"  // MOLA_HIP_* environment switches (compiled + tested via host/src/icp.cpp)
 
 namespace mp2p_icp
 {
 namespace
 {
-inline void mh_check(mh_status s, const char* where)
-{
-    // the reference catches std::exception around the whole scan (LidarOdometry.cpp:614-619)
-    if (s != MH_OK) throw std::runtime_error(std::string(where) + ": " + mh_status_string(s) + ": " + mh_last_error_string());
-}
-inline void pose_to_T12(const mrpt::poses::CPose3D& p, double T[12])
-{
-    const auto& R = p.getRotationMatrix();
-    for (int i = 0; i < 3; i++)
-    {
-        for (int j = 0; j < 3; j++) T[i * 4 + j] = R(i, j);
-        T[i * 4 + 3] = p.m_coords[i];
-    }
-}
-
-// `voxel_size()` getters differ between mola_metric_maps versions [U]: use the getter when the class has one, else the
-// value MOLAHIP_VOXEL_SIZE gives (the plugin refuses to guess: a wrong voxel size silently changes every pairing).
-template <class M, class = void> struct has_voxel_size : std::false_type {};
-template <class M> struct has_voxel_size<M, std::void_t<decltype(std::declval<const M&>().voxel_size())>> : std::true_type {};
-template <class M> float voxel_size_of(const M& m)
-{
-    if (const char* e = getenv("MOLAHIP_VOXEL_SIZE")) return static_cast<float>(atof(e));
-    if constexpr (has_voxel_size<M>::value) return m.voxel_size();
-    else throw std::runtime_error("libmolahip plugin: this mola_metric_maps version has no voxel_size() getter; set MOLAHIP_VOXEL_SIZE");
-}
-
-inline uint64_t fnv(uint64_t h, uint32_t b) { return (h ^ b) * 1099511628211ull; }
-inline uint32_t fbits(float v) { uint32_t b; memcpy(&b, &v, 4); return b; }
-
-/** What the mirror needs to know about one host map layer, whatever its class. */
-struct HostMapView
-{
-    mh_map_params params{};
-    uint64_t fingerprint = 0;  // changes whenever the stored content does
-    std::function<void(std::vector<float>&, std::vector<float>&, std::vector<float>&)> gather;  // all stored points, voxel by voxel
-};
-
-/** Voxel-hashed upstream maps (HashedVoxelPointCloud, NDT).  Their content only changes by insertPoint (append to a
- *  voxel below its cap) and by far-voxel removal, so {voxel index, point count} over all voxels identifies the content:
- *  O(occupied voxels) per align() instead of O(points); the points themselves are read on a change only (key-frames). */
-template <class VoxelMap> void view_voxel_map(const VoxelMap& m, HostMapView& v)
-{
-    uint64_t h = 1469598103934665603ull, n = 0;
-    m.visitAllVoxels([&](const auto& idx, const auto& vox) {  // [U] visitAllVoxels(f(index3d_t, VoxelData))
-        const uint32_t cnt = static_cast<uint32_t>(vox.points().size());  // [U] VoxelData::points()
-        // order-independent combination: the hash container's iteration order may change when it rehashes
-        uint64_t e = fnv(fnv(fnv(fnv(1469598103934665603ull, (uint32_t)idx.cx), (uint32_t)idx.cy), (uint32_t)idx.cz), cnt);
-        h += e * 0x9E3779B97F4A7C15ull;
-        n += cnt;
-    });
-    v.fingerprint = h ^ (n << 1);
-    v.gather = [&m](std::vector<float>& x, std::vector<float>& y, std::vector<float>& z) {
-        m.visitAllPoints([&](const mrpt::math::TPoint3Df& p) { x.push_back(p.x); y.push_back(p.y); z.push_back(p.z); });  // [U]
-    };
-}
-
-inline bool view_of(const mrpt::maps::CMetricMap& g, HostMapView& v)
-{
-    const auto& sw = molahip_host::plugin_switches();
-    v.params = mh_map_params{};
-    v.params.index_mode = sw.index_mode;
-    if (const auto* hv = dynamic_cast<const mola::HashedVoxelPointCloud*>(&g))
-    {
-        v.params.voxel_size                  = voxel_size_of(*hv);
-        v.params.max_points_per_voxel        = hv->insertionOptions.max_points_per_voxel;        // [U] yaml:235
-        v.params.min_distance_between_points = hv->insertionOptions.min_distance_between_points; // [U] yaml:236
-        view_voxel_map(*hv, v);
-    }
-    else if (const auto* nd = dynamic_cast<const mola::NDT*>(&g))
-    {
-        v.params.voxel_size                  = voxel_size_of(*nd);
-        v.params.max_points_per_voxel        = nd->insertionOptions.max_points_per_voxel;         // [U] ndt yaml:241
-        v.params.min_distance_between_points = nd->insertionOptions.min_distance_between_points;  // [U] ndt yaml:242
-        v.params.ndt_max_eigen_ratio         = nd->insertionOptions.max_eigen_ratio_for_planes;   // [U] ndt yaml:246
-        view_voxel_map(*nd, v);
-    }
-    else if (const auto* pm = dynamic_cast<const mrpt::maps::CPointsMap*>(&g))
-    {
-        // a flat point map has no voxel structure of its own: the device table uses 1 m voxels without a cap, so the
-        // 27-voxel search reaches >= 1 m (upstream's KD-tree search is unbounded: pairs farther than that are lost)
-        v.params.voxel_size = getenv("MOLAHIP_VOXEL_SIZE") ? static_cast<float>(atof(getenv("MOLAHIP_VOXEL_SIZE"))) : 1.0f;
-        const auto& x = pm->getPointsBufferRef_x();
-        const auto& y = pm->getPointsBufferRef_y();
-        const auto& z = pm->getPointsBufferRef_z();
-        uint64_t h = fnv(1469598103934665603ull, (uint32_t)x.size());
-        const size_t n = x.size(), step = n > 4096 ? n / 4096 : 1;
-        for (size_t i = 0; i < n; i += step) h = fnv(fnv(fnv(h, fbits(x[i])), fbits(y[i])), fbits(z[i]));
-        if (n) h = fnv(fnv(fnv(h, fbits(x[n - 1])), fbits(y[n - 1])), fbits(z[n - 1]));
-        v.fingerprint = h;
-        v.gather = [pm](std::vector<float>& ox, std::vector<float>& oy, std::vector<float>& oz) {
-            ox = pm->getPointsBufferRef_x(); oy = pm->getPointsBufferRef_y(); oz = pm->getPointsBufferRef_z();
-        };
-    }
-    else
-        return false;
-    return true;
-}
-
-/** Device mirror of one host map layer.  The plugin does not own the host map (no change notification), so the mirror
- *  is rebuilt when the view's parameters or fingerprint change -- SURVEY.md 7.3 "map mirror coherence".  The stored
- *  points arrive voxel by voxel, already capped, so mh_map_build (clear + insertPoint in order) reproduces every voxel's
- *  content and in-voxel order.  The proper fix is the device-owned CMetricMap class next to this file (row f2). */
-struct MapMirror
-{
-    mh_map*       map = nullptr;
-    mh_map_params params{};
-    uint64_t      fingerprint = 0;
-    bool          built = false;
-};
-
+using molahip_mrpt::mh_check;
+using molahip_mrpt::pose_to_T12;
 /** MOLA_HIP_ALIGN_TRACE: one row per align(), same columns whichever loop ran. */
 struct AlignTrace
 {
@@ -228,13 +124,8 @@ class ICP_HIP : public ICP
 {
     DEFINE_MRPT_OBJECT(ICP_HIP, mp2p_icp)
    public:
-    ICP_HIP() { mh_check(mh_ctx_create(0, nullptr, &ctx_), "mh_ctx_create"); }
-    ~ICP_HIP() override
-    {
-        for (auto& kv : mirrors_) if (kv.second.map) mh_map_destroy(kv.second.map);
-        if (scan_) mh_scan_destroy(scan_);
-        mh_ctx_destroy(ctx_);
-    }
+    ICP_HIP() = default;   // the device session (context on GPU MOLA_HIP_DEVICE) is created by the first align()
+    ~ICP_HIP() override = default;
 
     void align(
         const metric_map_t& pcLocal, const metric_map_t& pcGlobal, const mrpt::math::TPose3D& initialGuessLocalWrtGlobal,
@@ -246,13 +137,18 @@ class ICP_HIP : public ICP
         // (set at LidarOdometry.cpp:360-364) itself before it writes the .icplog.
         Shape sh;
         mh_map* dmap = nullptr;
-        if (sw.force_cpu || p.generateDebugFiles || !recognise(sh) || !pcLocal.layers.count(sh.localLayer) ||
-            !pcGlobal.layers.count(sh.globalLayer) || !(dmap = device_map_of(*pcGlobal.layers.at(sh.globalLayer), sh.pl != nullptr)))
+        if (sw.force_cpu || p.generateDebugFiles || !recognise(sh) || !pcLocal.layers.count(sh.localLayer) || !pcGlobal.layers.count(sh.globalLayer))
+            return upstream_align(pcLocal, pcGlobal, initialGuessLocalWrtGlobal, p, result, prior, outputDebugInfo);
+        if (!dev_) dev_ = std::make_unique<molahip_mrpt::DeviceSession>();
+        if (!(dmap = dev_->device_map_of(*pcGlobal.layers.at(sh.globalLayer), sh.pl != nullptr)))
             return upstream_align(pcLocal, pcGlobal, initialGuessLocalWrtGlobal, p, result, prior, outputDebugInfo);
         const auto* local = dynamic_cast<const mrpt::maps::CPointsMap*>(pcLocal.layers.at(sh.localLayer).get());
         if (!local) return upstream_align(pcLocal, pcGlobal, initialGuessLocalWrtGlobal, p, result, prior, outputDebugInfo);
 
-        mrpt::system::CTimeLoggerEntry tle(profiler(), "align_hip");  // keeps profiler() populated (LidarOdometry.cpp:351-352)
+        // keeps profiler() populated (enabled at LidarOdometry.cpp:351-352): the call as a whole here, the device's own
+        // sections below once the result is back
+        const bool profiling = profiler().isEnabled();  // [U] CTimeLogger::isEnabled
+        mrpt::system::CTimeLoggerEntry tle(profiler(), "align_hip");
 
         // thresholds: functions of ICP_ITERATION (lidar3d-default.yaml:190,198; ndt yaml:197): evaluate per iteration up front
         std::vector<double> thr(p.maxIterations), kp(p.maxIterations), thr_pl(sh.pl ? p.maxIterations : 0);
@@ -267,8 +163,7 @@ class ICP_HIP : public ICP
         const auto& lx = local->getPointsBufferRef_x();  // already SoA
         const auto& ly = local->getPointsBufferRef_y();
         const auto& lz = local->getPointsBufferRef_z();
-        if (!scan_) mh_check(mh_scan_create(ctx_, lx.data(), ly.data(), lz.data(), lx.size(), MH_MEM_HOST, &scan_), "mh_scan_create");
-        else        mh_check(mh_scan_update(scan_, lx.data(), ly.data(), lz.data(), lx.size(), MH_MEM_HOST), "mh_scan_update");
+        mh_scan* scan_ = dev_->upload(*local);
 
         mh_icp_params ip{};
         ip.max_iterations        = p.maxIterations;
@@ -290,6 +185,7 @@ class ICP_HIP : public ICP
         ip.cov_findif_xyz        = sw.cov_step_xyz;
         ip.cov_findif_ang        = sw.cov_step_ang;
         ip.poll_every = 0;
+        ip.profile    = profiling ? 1 : 0;  // per-launch device timing (the chunk is then enqueued kernel by kernel)
 
         double T0[12];
         pose_to_T12(mrpt::poses::CPose3D(initialGuessLocalWrtGlobal), T0);
@@ -300,9 +196,9 @@ class ICP_HIP : public ICP
             for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) pr.info[i * 6 + j] = prior->cov_inv(i, j);
         }
         mh_icp_result r{};
-        std::vector<uint32_t> li(lx.size()), gi(lx.size());
-        std::vector<float> gx(lx.size()), gy(lx.size()), gz(lx.size()), d2(lx.size());
-        mh_pairs_out po{li.data(), gi.data(), gx.data(), gy.data(), gz.data(), d2.data()};
+        mh_pairs_out po = dev_->pairs.out(lx.size());  // (buffers of the session: no per-call allocation once warm)
+        const auto &li = dev_->pairs.li, &gi = dev_->pairs.gi;
+        const auto &gx = dev_->pairs.gx, &gy = dev_->pairs.gy, &gz = dev_->pairs.gz, &d2 = dev_->pairs.d2;
         auto run = [&](uint32_t budget, mh_icp_iter* trace) {
             mh_icp_params q = ip;
             q.max_iterations = budget;
@@ -332,6 +228,18 @@ class ICP_HIP : public ICP
         else
             r = run(p.maxIterations, nullptr);
 
+        if (profiling)
+        {
+            // one section per kernel family of the device loop (the reference's profiler prints them beside its own
+            // "onLidar.*" sections): the correspondence search, everything else the stream ran for this call (Gauss-Newton
+            // accumulation, 6x6 solve, covariance, pairing compaction), and the host's polls of the loop
+            profiler().registerUserMeasure("align_hip.device.match_kernels", 1e-3 * r.match_kernel_ms, true);  // [U] (name, value, is_time)
+            profiler().registerUserMeasure("align_hip.device.accumulate_solve_covariance", 1e-3 * (r.total_ms - r.match_kernel_ms), true);
+            profiler().registerUserMeasure("align_hip.device.stream_total", 1e-3 * r.total_ms, true);
+            profiler().registerUserMeasure("align_hip.match_launches", r.n_match_launches);
+            profiler().registerUserMeasure("align_hip.host_polls", r.n_host_polls);
+            profiler().registerUserMeasure("align_hip.iterations_enqueued", r.n_enqueued_iterations);
+        }
         // results back into the upstream structures (Results::finalPairings is read by LidarOdometry and the log writer)
         mrpt::math::CMatrixDouble44 M = mrpt::math::CMatrixDouble44::Identity();
         for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) M(i, j) = r.T[i * 4 + j];
@@ -358,9 +266,10 @@ class ICP_HIP : public ICP
         {
             // Pairings::paired_pt2pl [U]: {pl_global{plane, centroid}, pt_local}
             const size_t n = r.n_final_pairs_pt2pl;
-            std::vector<uint32_t> pli(lx.size());
-            std::vector<float> cx(lx.size()), cy(lx.size()), cz(lx.size()), nx(lx.size()), ny(lx.size()), nz(lx.size());
-            mh_pairs_pl_out plo{pli.data(), cx.data(), cy.data(), cz.data(), nx.data(), ny.data(), nz.data()};
+            mh_pairs_pl_out plo = dev_->planes.out(lx.size());
+            const auto &pli = dev_->planes.li;
+            const auto &cx = dev_->planes.cx, &cy = dev_->planes.cy, &cz = dev_->planes.cz;
+            const auto &nx = dev_->planes.nx, &ny = dev_->planes.ny, &nz = dev_->planes.nz;
             uint64_t got = 0;
             mh_check(mh_icp_get_pt2pl_pairs(scan_, &plo, MH_MEM_HOST, &got), "mh_icp_get_pt2pl_pairs");
             result.finalPairings.paired_pt2pl.reserve(n);
@@ -404,46 +313,13 @@ class ICP_HIP : public ICP
         return single_unit_layer(*sh.pt, sh.globalLayer, sh.localLayer);
     }
 
-    /** The mh_map to align against: the handle of a device-owned map, or the (re)built mirror of a host map; nullptr
-     *  when the layer's class is not one this plugin reads (-> upstream CPU loop). */
-    mh_map* device_map_of(const mrpt::maps::CMetricMap& g, bool need_ndt)
-    {
-        // a device-owned local map (hashed_voxel_pointcloud_hip.h): nothing to mirror, the handle is the map.
-        // (Its context must be the one this ICP runs on: both use device 0's default stream here.)
-        if (const auto* dm = dynamic_cast<const mola::HashedVoxelPointCloudHIP*>(&g)) return need_ndt ? nullptr : dm->deviceHandle();
-        HostMapView v;
-        if (!view_of(g, v)) return nullptr;
-        if (need_ndt && !(v.params.ndt_max_eigen_ratio > 0)) return nullptr;  // Matcher_Point2Plane on a non-NDT map: KNN+PCA upstream
-        auto& mir = mirrors_[&g];
-        if (mir.map && memcmp(&mir.params, &v.params, sizeof(v.params)) != 0)
-        {
-            mh_map_destroy(mir.map);
-            mir = MapMirror();
-        }
-        if (!mir.map)
-        {
-            mh_check(mh_map_create(ctx_, &v.params, &mir.map), "mh_map_create");
-            mir.params = v.params;
-        }
-        if (!mir.built || mir.fingerprint != v.fingerprint)
-        {
-            std::vector<float> x, y, z;
-            v.gather(x, y, z);
-            mh_check(mh_map_build(mir.map, x.data(), y.data(), z.data(), x.size(), MH_MEM_HOST), "mh_map_build");
-            mir.fingerprint = v.fingerprint;
-            mir.built       = true;
-        }
-        return mir.map;
-    }
-
-    mh_ctx*  ctx_  = nullptr;
-    mh_scan* scan_ = nullptr;
-    std::unordered_map<const mrpt::maps::CMetricMap*, MapMirror> mirrors_;
+    std::unique_ptr<molahip_mrpt::DeviceSession> dev_;  // context, map mirrors, staging scan, result buffers
     AlignTrace trace_;
 };
 IMPLEMENTS_MRPT_OBJECT(ICP_HIP, mp2p_icp::ICP, mp2p_icp)
 
 }  // namespace mp2p_icp
 
-// same registration pattern as module/src/register.cpp:40-46
+// same registration pattern as module/src/register.cpp:40-46 (the granular classes register themselves in
+// mp2p_icp_granular.cpp, which is part of the same library)
 MRPT_INITIALIZER(do_register_molahip_mp2p_icp) { mrpt::rtti::registerClass(CLASS_ID(mp2p_icp::ICP_HIP)); }

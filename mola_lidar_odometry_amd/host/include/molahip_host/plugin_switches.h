@@ -37,6 +37,14 @@ struct PluginSwitches {
        has_pt2pl_mode = false, has_far_metric = false;
 };
 
+/** The GPU this process's MRPT-side adapters run on: MOLA_HIP_DEVICE (default 0).  eval/cli_kitti.sh:23-36 runs one
+ *  mola-lidar-odometry-cli process per sequence under GNU parallel; giving every job slot its own MOLA_HIP_DEVICE spreads
+ *  them over a node's GPUs. */
+inline int device_index() {
+  const char* e = getenv("MOLA_HIP_DEVICE");
+  return e ? atoi(e) : 0;
+}
+
 inline bool parse_gm_form(const char* s, uint32_t& out) {
   const char* p = strstr(s, "::");  // "RobustKernel::GemanMcClure_KISS" and "GemanMcClure_KISS" alike
   while (p) {

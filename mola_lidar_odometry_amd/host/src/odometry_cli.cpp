@@ -6,7 +6,12 @@
 // times.txt, and announces the next scan so that its upload and first filter pass overlap with the current ICP loop.
 //
 //   molahip-lo-cli --pipeline pipelines/lidar3d-default-hip.yaml --seq-dir /data/kitti/sequences/00 --out 00.tum
-//                  [--device 0] [--no-prefetch] [--max-scans N]
+//                  [--device 0 | --devices 0,1,..|all] [--no-prefetch] [--max-scans N] [--time-field BYTES] [--scan-log FILE]
+// --devices: config 4 of BASELINE.json without Python -- the sequences are assigned to the listed GPUs by LPT (longest
+// sequence first onto the least loaded device, what eval/cli_kitti.sh:9,23-36 leaves to GNU parallel's job slots), every
+// device runs its share like a --seq-dir list on one GPU (a host thread per sequence, one AlignBatcher per device); the
+// "gather" is the host-side join of the per-sequence TUM files and ONE summary line.  A device may be listed twice
+// (two independent batchers on it: the multi-device code path on a single-GPU box).  --plan-only prints the assignment.
 // --seq-dir also takes a MulRan sequence folder (eval/cli_mulran.sh:23-36, `--input-mulran-seq KAIST01` with
 // MULRAN_BASE_DIR, apps/mola-lidar-odometry-cli.cpp:186-208): <dir>/sensor_data/Ouster/<stamp in ns>.bin (or <dir>/Ouster/),
 // float32 x,y,z,intensity rows like KITTI's, the scan's time stamp is its file name.
@@ -90,7 +95,53 @@ struct SequenceReport {
   size_t steady_scans = 0;
   std::string error;
   std::map<std::string, double> profile;  // LidarOdometry::profile(): host seconds per stage, whole run
+  int device = 0;
+  double mean_icp_points = 0, mean_map_layer_points = 0, mean_raw_points = 0;
+  uint64_t final_map_points = 0, max_map_points = 0, final_map_voxels = 0;
+  std::vector<double> scan_seconds;  // --scan-log: registration time of every scan
 };
+
+struct RunOptions {
+  long max_scans = -1;
+  bool prefetch = true;
+  long long time_field = -1;  // byte offset of a float32 per-point time stamp inside the 16-byte record, or -1
+  std::string scan_log;       // CSV of per-scan registration times and layer / map sizes
+};
+
+// what the replay leaves behind besides the trajectory: layer and map sizes (records()), optionally a per-scan CSV
+void finish_report(const mola_hip::LidarOdometry& lo, const RunOptions& opt, SequenceReport& rep) {
+  const auto& recs = lo.records();  // (resolves the map counters)
+  double s_icp = 0, s_map = 0, s_raw = 0;
+  size_t n_icp = 0;
+  for (const auto& r : recs) {
+    s_raw += (double)r.n_raw;
+    if (r.icp_run) {
+      s_icp += (double)r.n_for_icp;
+      s_map += (double)r.n_for_map;
+      n_icp++;
+    }
+    rep.max_map_points = std::max<uint64_t>(rep.max_map_points, r.n_map_points);
+  }
+  if (n_icp) rep.mean_icp_points = s_icp / (double)n_icp, rep.mean_map_layer_points = s_map / (double)n_icp;
+  if (!recs.empty()) {
+    rep.mean_raw_points = s_raw / (double)recs.size();
+    rep.final_map_points = recs.back().n_map_points;
+    rep.final_map_voxels = recs.back().n_map_voxels;
+  }
+  if (!opt.scan_log.empty()) {
+    const std::string path = rep.out.size() > 4 && opt.scan_log == "auto" ? rep.out.substr(0, rep.out.size() - 4) + "_scans.csv" : opt.scan_log;
+    FILE* f = fopen(path.c_str(), "w");
+    if (f) {
+      fprintf(f, "scan,seconds,n_raw,n_for_map,n_for_icp,n_map_points,icp_iterations,align_calls,goodness,sigma,map_updated,icp_good\n");
+      for (size_t k = 0; k < recs.size(); k++)
+        fprintf(f, "%zu,%.7f,%llu,%llu,%llu,%llu,%u,%u,%.4f,%.4f,%d,%d\n", k, k < rep.scan_seconds.size() ? rep.scan_seconds[k] : 0.0,
+                (unsigned long long)recs[k].n_raw, (unsigned long long)recs[k].n_for_map, (unsigned long long)recs[k].n_for_icp,
+                (unsigned long long)recs[k].n_map_points, recs[k].icp_iterations, recs[k].align_calls, recs[k].goodness, recs[k].sigma,
+                (int)recs[k].map_updated, (int)recs[k].icp_good);
+      fclose(f);
+    }
+  }
+}
 
 // files + stamps of a KITTI or MulRan sequence folder
 void list_sequence(const std::string& seq_dir, long max_scans, std::vector<std::string>& files, std::vector<double>& stamps) {
@@ -160,10 +211,12 @@ struct SequenceFeed {
   }
 };
 
-void run_sequence_fiber(const std::string& pipeline, const std::string& seq_dir, const std::string& out, int device, long max_scans,
+void run_sequence_fiber(const std::string& pipeline, const std::string& seq_dir, const std::string& out, int device, const RunOptions& opt,
                         std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher, SequenceReport& rep) {
   rep.seq_dir = seq_dir;
   rep.out = out;
+  rep.device = device;
+  const long max_scans = opt.max_scans;
   mp2p_icp_hip::AlignBatcher::Membership member(batcher);  // leave() however this sequence ends
   try {
     SequenceFeed feed;
@@ -181,10 +234,11 @@ void run_sequence_fiber(const std::string& pipeline, const std::string& seq_dir,
       if (feed.failed) throw std::runtime_error(feed.error);
       const bool has_next = k + 1 < n;
       const auto t0 = std::chrono::steady_clock::now();
-      if (has_next) lo.prefetchInterleaved(feed.buf[(k + 1) % SequenceFeed::kDepth], feed.n_floats[(k + 1) % SequenceFeed::kDepth] / 4, 16, 0, 4, 8);
-      const auto& rec = lo.onLidarInterleaved(stamps[k], feed.buf[k % SequenceFeed::kDepth], feed.n_floats[k % SequenceFeed::kDepth] / 4, 16, 0, 4, 8);
+      if (has_next) lo.prefetchInterleaved(feed.buf[(k + 1) % SequenceFeed::kDepth], feed.n_floats[(k + 1) % SequenceFeed::kDepth] / 4, 16, 0, 4, 8, opt.time_field);
+      const auto& rec = lo.onLidarInterleaved(stamps[k], feed.buf[k % SequenceFeed::kDepth], feed.n_floats[k % SequenceFeed::kDepth] / 4, 16, 0, 4, 8, opt.time_field);
       const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       rep.seconds += dt;
+      rep.scan_seconds.push_back(dt);
       if (k >= kWarmScans) {
         rep.steady_seconds += dt;
         rep.steady_scans++;
@@ -198,16 +252,20 @@ void run_sequence_fiber(const std::string& pipeline, const std::string& seq_dir,
     }
     lo.saveTrajectoryTUM(out);
     rep.profile = lo.profile();
+    finish_report(lo, opt, rep);
   } catch (const std::exception& e) {
     rep.error = e.what();
   }
 }
 
 // one sequence, start to end; with a batcher its alignments join those of the other sequences of the process
-void run_sequence(const std::string& pipeline, const std::string& seq_dir, const std::string& out, int device, long max_scans,
-                  bool prefetch, std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher, SequenceReport& rep) {
+void run_sequence(const std::string& pipeline, const std::string& seq_dir, const std::string& out, int device, const RunOptions& opt,
+                  std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher, SequenceReport& rep) {
   rep.seq_dir = seq_dir;
   rep.out = out;
+  rep.device = device;
+  const long max_scans = opt.max_scans;
+  const bool prefetch = opt.prefetch;
   mp2p_icp_hip::AlignBatcher::Membership member(batcher);  // leave() however this sequence ends
   try {
     // (the page-locked read-ahead ring of the fiber mode was tried here as well: with asynchronous uploads the eight
@@ -227,10 +285,11 @@ void run_sequence(const std::string& pipeline, const std::string& seq_dir, const
       const bool has_next = k + 1 < files.size();
       if (has_next) nxt = read_bin(files[k + 1]);  // (file reading is not part of the registration time)
       const auto t0 = std::chrono::steady_clock::now();
-      if (has_next && prefetch) lo.prefetchInterleaved(nxt.data(), nxt.size() / 4, 16, 0, 4, 8);
-      const auto& rec = lo.onLidarInterleaved(stamps[k], cur.data(), cur.size() / 4, 16, 0, 4, 8);
+      if (has_next && prefetch) lo.prefetchInterleaved(nxt.data(), nxt.size() / 4, 16, 0, 4, 8, opt.time_field);
+      const auto& rec = lo.onLidarInterleaved(stamps[k], cur.data(), cur.size() / 4, 16, 0, 4, 8, opt.time_field);
       const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       rep.seconds += dt;
+      rep.scan_seconds.push_back(dt);
       if (k >= kWarmScans) {
         rep.steady_seconds += dt;
         rep.steady_scans++;
@@ -247,9 +306,45 @@ void run_sequence(const std::string& pipeline, const std::string& seq_dir, const
     }
     lo.saveTrajectoryTUM(out);
     rep.profile = lo.profile();
+    finish_report(lo, opt, rep);
   } catch (const std::exception& e) {
     rep.error = e.what();
   }
+}
+
+// Longest-processing-time assignment of sequences (cost = number of scans) to device slots: the schedule DESIGN.md section 4
+// prices config 4 with (11 KITTI sequences on 8 GPUs: makespan = sequence 02).  Returns slot index per sequence.
+std::vector<size_t> lpt_assign(const std::vector<size_t>& scans, size_t n_slots, std::vector<size_t>* load_out = nullptr) {
+  std::vector<size_t> order(scans.size()), slot(scans.size(), 0), load(n_slots, 0);
+  for (size_t k = 0; k < order.size(); k++) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return scans[a] > scans[b]; });
+  for (size_t k : order) {
+    const size_t best = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());  // first of the least loaded
+    slot[k] = best;
+    load[best] += scans[k];
+  }
+  if (load_out) *load_out = load;
+  return slot;
+}
+
+std::vector<int> parse_devices(const std::string& arg) {
+  std::vector<int> out;
+  if (arg == "all") {
+    int n = 0;
+    if (mh_device_count(&n) != MH_OK || n <= 0) throw std::runtime_error("--devices all: no HIP device");
+    for (int d = 0; d < n; d++) out.push_back(d);
+    return out;
+  }
+  size_t pos = 0;
+  while (pos <= arg.size()) {
+    const size_t c = arg.find(',', pos);
+    const std::string tok = arg.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+    if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) throw std::runtime_error("--devices: expected a list like 0,1,2 or 'all'");
+    out.push_back(atoi(tok.c_str()));
+    if (c == std::string::npos) break;
+    pos = c + 1;
+  }
+  return out;
 }
 
 }  // namespace
@@ -257,13 +352,14 @@ void run_sequence(const std::string& pipeline, const std::string& seq_dir, const
 int main(int argc, char** argv) {
   std::string pipeline, out = "trajectory.tum";
   std::vector<std::string> seq_dirs;
-  int device = 0;
-  long max_scans = -1;
-  bool prefetch = true, print_profile = false, fibers = false;
-  const char* usage = "usage: molahip-lo-cli --pipeline FILE.yaml --seq-dir DIR [--seq-dir DIR ...] --out FILE.tum [--device N] "
-                      "[--no-prefetch] [--max-scans N] [--profile] [--fibers]\n"
-                      "  several --seq-dir: the sequences run together on the one GPU, one host thread each, their alignments\n"
-                      "  merged into lock-step batches; trajectories go to FILE_<k>.tum\n";
+  std::vector<int> devices;
+  RunOptions opt;
+  bool print_profile = false, fibers = false, plan_only = false;
+  const char* usage = "usage: molahip-lo-cli --pipeline FILE.yaml --seq-dir DIR [--seq-dir DIR ...] --out FILE.tum [--device N | --devices 0,1,..|all] "
+                      "[--no-prefetch] [--max-scans N] [--profile] [--time-field BYTES] [--scan-log FILE|auto] [--plan-only] [--fibers]\n"
+                      "  several --seq-dir: the sequences run together, one host thread each, the alignments of the sequences that share\n"
+                      "  a GPU merged into lock-step batches; trajectories go to FILE_<k>.tum\n"
+                      "  --devices: the sequences are spread over the listed GPUs (longest first onto the least loaded device)\n";
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     auto val = [&](const char* name) -> std::string {
@@ -274,10 +370,14 @@ int main(int argc, char** argv) {
       if (a == "--pipeline") pipeline = val("--pipeline");
       else if (a == "--seq-dir") seq_dirs.push_back(val("--seq-dir"));
       else if (a == "--out") out = val("--out");
-      else if (a == "--device") device = atoi(val("--device").c_str());
-      else if (a == "--max-scans") max_scans = atol(val("--max-scans").c_str());
-      else if (a == "--no-prefetch") prefetch = false;
+      else if (a == "--device") devices = {atoi(val("--device").c_str())};
+      else if (a == "--devices") devices = parse_devices(val("--devices"));
+      else if (a == "--max-scans") opt.max_scans = atol(val("--max-scans").c_str());
+      else if (a == "--time-field") opt.time_field = atoll(val("--time-field").c_str());
+      else if (a == "--scan-log") opt.scan_log = val("--scan-log");
+      else if (a == "--no-prefetch") opt.prefetch = false;
       else if (a == "--profile") print_profile = true;
+      else if (a == "--plan-only") plan_only = true;
       else if (a == "--fibers") fibers = true;
       else throw std::runtime_error("unknown argument " + a);
     } catch (const std::exception& e) {
@@ -289,31 +389,63 @@ int main(int argc, char** argv) {
     fprintf(stderr, "%s", usage);
     return 2;
   }
-  const size_t N = seq_dirs.size();
+  if (devices.empty()) devices = {0};
+  const size_t N = seq_dirs.size(), D = devices.size();
+  // which sequence runs where: scan counts are known from the folders (no GPU needed for the plan)
+  std::vector<size_t> n_scans(N, 0), slot(N, 0), load(D, 0);
+  try {
+    for (size_t k = 0; k < N; k++) {
+      std::vector<std::string> files;
+      std::vector<double> stamps;
+      list_sequence(seq_dirs[k], opt.max_scans, files, stamps);
+      n_scans[k] = files.size();
+    }
+  } catch (const std::exception& e) {
+    fprintf(stderr, "molahip-lo-cli: %s\n", e.what());
+    return 1;
+  }
+  slot = lpt_assign(n_scans, D, &load);
+  const std::string stem = out.size() > 4 && out.compare(out.size() - 4, 4, ".tum") == 0 ? out.substr(0, out.size() - 4) : out;
+  if (plan_only) {
+    size_t total = 0, makespan = 0;
+    for (size_t k = 0; k < N; k++) total += n_scans[k];
+    for (size_t d = 0; d < D; d++) makespan = std::max(makespan, load[d]);
+    printf("{\"plan\": [");
+    for (size_t k = 0; k < N; k++)
+      printf("%s{\"sequence_dir\": \"%s\", \"scans\": %zu, \"slot\": %zu, \"device\": %d}", k ? ", " : "", seq_dirs[k].c_str(), n_scans[k], slot[k], devices[slot[k]]);
+    printf("], \"device_load_scans\": [");
+    for (size_t d = 0; d < D; d++) printf("%s%zu", d ? ", " : "", load[d]);
+    printf("], \"total_scans\": %zu, \"makespan_scans\": %zu, \"speedup_bound\": %.4f}\n", total, makespan, makespan ? (double)total / (double)makespan : 0.0);
+    return 0;
+  }
   std::vector<SequenceReport> reps(N);
-  std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher_keep;
+  std::vector<std::shared_ptr<mp2p_icp_hip::AlignBatcher>> batchers(D);
+  std::vector<size_t> per_slot(D, 0);
+  for (size_t k = 0; k < N; k++) per_slot[slot[k]]++;
   const auto t0 = std::chrono::steady_clock::now();
   if (fibers) {
-    // ONE thread in the HIP runtime: the sequences (and their prefetch workers) are fibers of this thread
+    // ONE thread in the HIP runtime: the sequences (and their prefetch workers) are fibers of this thread (one device)
+    if (D > 1) {
+      fprintf(stderr, "--fibers runs on one device\n");
+      return 2;
+    }
     molahip_host::FiberScheduler sched;
-    auto batcher = N > 1 ? std::make_shared<mp2p_icp_hip::AlignBatcher>(N) : nullptr;
-    batcher_keep = batcher;
-    const std::string stem = out.size() > 4 && out.compare(out.size() - 4, 4, ".tum") == 0 ? out.substr(0, out.size() - 4) : out;
+    batchers[0] = N > 1 ? std::make_shared<mp2p_icp_hip::AlignBatcher>(N) : nullptr;
     for (size_t k = 0; k < N; k++) {
       const std::string o = N == 1 ? out : stem + "_" + std::to_string(k) + ".tum";
-      sched.spawn([&, k, o] { run_sequence_fiber(pipeline, seq_dirs[k], o, device, max_scans, batcher, reps[k]); });
+      sched.spawn([&, k, o] { run_sequence_fiber(pipeline, seq_dirs[k], o, devices[0], opt, batchers[0], reps[k]); });
     }
     sched.run();
   } else if (N == 1) {
-    run_sequence(pipeline, seq_dirs[0], out, device, max_scans, prefetch, nullptr, reps[0]);
+    run_sequence(pipeline, seq_dirs[0], out, devices[0], opt, nullptr, reps[0]);
   } else {
-    auto batcher = std::make_shared<mp2p_icp_hip::AlignBatcher>(N);
-    batcher_keep = batcher;
+    // a batcher per device slot: the sequences of a slot advance together, the slots independently of each other
+    for (size_t d = 0; d < D; d++)
+      if (per_slot[d] > 1) batchers[d] = std::make_shared<mp2p_icp_hip::AlignBatcher>(per_slot[d]);
     std::vector<std::thread> th;
-    const std::string stem = out.size() > 4 && out.compare(out.size() - 4, 4, ".tum") == 0 ? out.substr(0, out.size() - 4) : out;
     for (size_t k = 0; k < N; k++)
-      th.emplace_back(run_sequence, pipeline, seq_dirs[k], stem + "_" + std::to_string(k) + ".tum", device, max_scans, prefetch,
-                      batcher, std::ref(reps[k]));
+      th.emplace_back(run_sequence, pipeline, seq_dirs[k], stem + "_" + std::to_string(k) + ".tum", devices[slot[k]], std::cref(opt),
+                      batchers[slot[k]], std::ref(reps[k]));
     for (auto& t : th) t.join();
   }
   const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -325,10 +457,12 @@ int main(int argc, char** argv) {
       rc = 1;
     }
     total += r.scans;
-    printf("{\"sequence_dir\": \"%s\", \"scans\": %zu, \"good\": %zu, \"keyframes\": %zu, \"icp_iterations\": %zu, "
-           "\"seconds\": %.6f, \"scans_per_s\": %.3f, \"steady_scans_per_s\": %.3f, \"tum\": \"%s\"}\n",
-           r.seq_dir.c_str(), r.scans, r.good, r.keyframes, r.iterations, r.seconds, r.seconds > 0 ? r.scans / r.seconds : 0.0,
-           r.steady_seconds > 0 ? r.steady_scans / r.steady_seconds : 0.0, r.out.c_str());
+    printf("{\"sequence_dir\": \"%s\", \"device\": %d, \"scans\": %zu, \"good\": %zu, \"keyframes\": %zu, \"icp_iterations\": %zu, "
+           "\"seconds\": %.6f, \"scans_per_s\": %.3f, \"steady_scans_per_s\": %.3f, \"mean_raw_points\": %.1f, \"mean_icp_points\": %.1f, "
+           "\"mean_map_layer_points\": %.1f, \"final_map_points\": %llu, \"max_map_points\": %llu, \"final_map_voxels\": %llu, \"tum\": \"%s\"}\n",
+           r.seq_dir.c_str(), r.device, r.scans, r.good, r.keyframes, r.iterations, r.seconds, r.seconds > 0 ? r.scans / r.seconds : 0.0,
+           r.steady_seconds > 0 ? r.steady_scans / r.steady_seconds : 0.0, r.mean_raw_points, r.mean_icp_points, r.mean_map_layer_points,
+           (unsigned long long)r.final_map_points, (unsigned long long)r.max_map_points, (unsigned long long)r.final_map_voxels, r.out.c_str());
     if (print_profile && r.scans) {  // host milliseconds per scan and stage (LidarOdometry::profile()), steady state
       const double ns = (double)(r.steady_scans ? r.steady_scans : r.scans);
       printf("{\"profile_ms_per_scan\": {");
@@ -343,23 +477,38 @@ int main(int argc, char** argv) {
     }
   }
   if (N > 1) {
-    // the sequences advance together (one batch per round), so the slowest thread's registration time is the job's
-    size_t steady = 0;
-    double slowest = 0;
-    for (const auto& r : reps) {
+    // the sequences of a device advance together (one batch per round), so a device's slowest thread is its registration
+    // time; the job's is the slowest device's (the makespan): steady rate = all steady scans / that
+    size_t steady = 0, n_batches = 0, n_jobs = 0, f_batches = 0, f_jobs = 0, f_timeouts = 0;
+    double slowest = 0, assembling = 0, running = 0;
+    std::vector<double> dev_seconds(D, 0), dev_steady_seconds(D, 0);
+    std::vector<size_t> dev_scans(D, 0), dev_steady(D, 0);
+    for (size_t k = 0; k < N; k++) {
+      const auto& r = reps[k];
       steady += r.steady_scans;
-      slowest = r.steady_seconds > slowest ? r.steady_seconds : slowest;
+      slowest = std::max(slowest, r.steady_seconds);
+      dev_scans[slot[k]] += r.scans;
+      dev_steady[slot[k]] += r.steady_scans;
+      dev_seconds[slot[k]] = std::max(dev_seconds[slot[k]], r.seconds);
+      dev_steady_seconds[slot[k]] = std::max(dev_steady_seconds[slot[k]], r.steady_seconds);
     }
-    // the batcher's view of a round (all scans, warm-up included): waiting for the last sequence to arrive / the batch call
-    const double nb = batcher_keep && batcher_keep->batches() ? (double)batcher_keep->batches() : 1.0;
-    printf("{\"sequences\": %zu, \"scans\": %zu, \"wall_seconds\": %.6f, \"scans_per_s\": %.3f, \"steady_scans_per_s\": %.3f, "
+    for (const auto& b : batchers)
+      if (b) {
+        n_batches += b->batches(), n_jobs += b->jobs(), f_batches += b->filterBatches(), f_jobs += b->filterJobs(), f_timeouts += b->filterTimeouts();
+        assembling += b->secondsAssembling(), running += b->secondsRunning();
+      }
+    const double nb = n_batches ? (double)n_batches : 1.0;
+    printf("{\"sequences\": %zu, \"devices\": %zu, \"scans\": %zu, \"wall_seconds\": %.6f, \"scans_per_s\": %.3f, \"steady_scans_per_s\": %.3f, "
            "\"batches\": %zu, \"jobs_per_batch\": %.2f, \"ms_per_batch_assembling\": %.4f, \"ms_per_batch_running\": %.4f, "
-           "\"filter_batches\": %zu, \"filter_jobs\": %zu, \"filter_timeouts\": %zu}\n",
-           N, total, wall, wall > 0 ? total / wall : 0.0, slowest > 0 ? steady / slowest : 0.0,
-           batcher_keep ? batcher_keep->batches() : (size_t)0, batcher_keep ? batcher_keep->jobs() / nb : 0.0,
-           batcher_keep ? 1e3 * batcher_keep->secondsAssembling() / nb : 0.0, batcher_keep ? 1e3 * batcher_keep->secondsRunning() / nb : 0.0,
-           batcher_keep ? batcher_keep->filterBatches() : (size_t)0, batcher_keep ? batcher_keep->filterJobs() : (size_t)0,
-           batcher_keep ? batcher_keep->filterTimeouts() : (size_t)0);
+           "\"filter_batches\": %zu, \"filter_jobs\": %zu, \"filter_timeouts\": %zu, \"per_device\": [",
+           N, D, total, wall, wall > 0 ? total / wall : 0.0, slowest > 0 ? steady / slowest : 0.0, n_batches, n_jobs / nb,
+           1e3 * assembling / nb, 1e3 * running / nb, f_batches, f_jobs, f_timeouts);
+    for (size_t d = 0; d < D; d++)
+      printf("%s{\"slot\": %zu, \"device\": %d, \"sequences\": %zu, \"scans\": %zu, \"registration_seconds\": %.6f, \"scans_per_s\": %.3f, "
+             "\"steady_scans_per_s\": %.3f}",
+             d ? ", " : "", d, devices[d], per_slot[d], dev_scans[d], dev_seconds[d], dev_seconds[d] > 0 ? dev_scans[d] / dev_seconds[d] : 0.0,
+             dev_steady_seconds[d] > 0 ? dev_steady[d] / dev_steady_seconds[d] : 0.0);
+    printf("]}\n");
   }
   return rc;
 }

@@ -373,3 +373,22 @@ def workload_creal(variant: int = 0) -> Workload:
 
 def workload_by_name(name: str, variant: int = 0) -> Workload:
     return {"c2": workload_c2, "creal": workload_creal, "small": workload_small}[name](variant)
+
+
+_GEOMETRY = {"c2": (64, 1875, 120.0, 40), "creal": (32, 192, 120.0, 40), "small": (16, 125, 25.0, 6)}  # rings, azimuths, half extent, boxes
+
+
+def workload_scan_set(name: str, variant: int, k: int):
+    """Scan set k > 0 of workload (name, variant): ANOTHER sweep against the same map -- another sensor pose along the street,
+    other range noise -- with its ground truth and its perturbed guess, as the next scans of a sequence would be.  bench.py
+    rotates through several sets per step so that consecutive batches do not re-align identical inputs.
+    -> (scan_xyz [N,3] fp32, T_gt, T_guess)"""
+    rings, azimuths, half_extent, n_boxes = _GEOMETRY[name]
+    scene = make_scene(12345 + 1009 * variant, half_extent, n_boxes)
+    rng = np.random.Generator(np.random.PCG64(9000 + 97 * variant + k))
+    pose_gt = POSE_GT.copy()
+    pose_gt[:2] += rng.uniform(-1.0, 1.0, 2) * np.array([0.05 * half_extent, 1.5])
+    pose_gt[3] += rng.uniform(-0.3, 0.3)
+    scan = make_scan(scene, pose_gt, rings, azimuths, 54321 + 31 * variant + 7919 * k)
+    guess = pose_gt + GUESS_PERTURBATION
+    return scan, pose_from_ypr(pose_gt), pose_from_ypr(guess)

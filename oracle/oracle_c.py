@@ -155,8 +155,47 @@ def lib():
             getattr(L, name).argtypes = [_DP, _DP]
         L.orc_so3_log.argtypes = [_DP, _DP]
         L.orc_pose_compose.argtypes = [_DP, _DP, _DP]
-        _lib = L
+        _lib = _TimedLib(L)
     return _lib
+
+
+# Seconds spent INSIDE the C library by the heavy calls (matching, solving, filters, map insertion) since reset_c_seconds():
+# lets a Python loop over the oracle (odometry_oracle.py) report its C share, so that a CPU scans/s figure can be quoted
+# without the interpreter's overhead ("time the CPU drivers through a C/C++ loop or report the Python share").
+C_SECONDS = 0.0
+_TIMED = {"orc_icp_align", "orc_preprocess", "orc_deskew", "orc_map_insert_posed", "orc_map_insert", "orc_match_points",
+          "orc_match_pt2pl", "orc_gn_solve", "orc_covariance", "orc_decimate_first_point", "orc_filter_by_range",
+          "orc_filter_bbox", "orc_adjust_timestamps"}
+
+
+def reset_c_seconds():
+    global C_SECONDS
+    C_SECONDS = 0.0
+
+
+class _TimedLib:
+    def __init__(self, L):
+        self._L = L
+        self._cache = {}
+
+    def __getattr__(self, name):
+        f = self._cache.get(name)
+        if f is None:
+            raw = getattr(self._L, name)
+            if name in _TIMED:
+                import time as _time
+
+                def f(*a, _raw=raw, _pc=_time.perf_counter):
+                    global C_SECONDS
+                    t0 = _pc()
+                    try:
+                        return _raw(*a)
+                    finally:
+                        C_SECONDS += _pc() - t0
+            else:
+                f = raw
+            self._cache[name] = f
+        return f
 
 
 def _f32(a):

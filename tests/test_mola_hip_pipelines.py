@@ -189,7 +189,8 @@ def test_every_class_name_resolves_to_upstream_or_to_what_the_plugin_registers(p
 
 
 def test_adapter_sources_match_what_the_pipelines_need():
-    plugin = open(os.path.join(ADAPTERS, "mp2p_icp_plugin.cpp")).read()
+    # the ICP_HIP adapter = mp2p_icp_plugin.cpp + the helpers it shares with the granular classes (molahip_mrpt_common.h)
+    plugin = open(os.path.join(ADAPTERS, "mp2p_icp_plugin.cpp")).read() + "\n" + open(os.path.join(ADAPTERS, "molahip_mrpt_common.h")).read()
     code = "\n".join(l.split("//", 1)[0] for l in plugin.splitlines())  # comments stripped
     # registration under the one name the generated files use, parent = the upstream ICP
     assert re.search(r"IMPLEMENTS_MRPT_OBJECT\(ICP_HIP,\s*mp2p_icp::ICP,\s*mp2p_icp\)", code)
@@ -225,6 +226,45 @@ def test_adapter_sources_match_what_the_pipelines_need():
                 if fn in ("mh_check",):
                     continue
                 assert fn in declared, "%s calls %s, which include/molahip.h does not declare" % (f, fn)
+
+
+def test_granular_pipelines_name_the_device_matcher_and_solver_classes(tmp_path):
+    """--granular (BASELINE north_star: "keeping the mp2p_icp::ICP / Matcher / Solver plugin API"): upstream ICP loop, the
+    solver / matcher `class:` lines name what host/adapters/mp2p_icp_granular.cpp registers; nothing else changes."""
+    ref_dir = mk.find_reference_dir()
+    if not ref_dir:
+        pytest.skip("no reference pipelines on this box")
+    registered = _registered_by_adapter()
+    for n in ("mp2p_icp::Matcher_Points_DistanceThreshold_HIP", "mp2p_icp::Matcher_Point2Plane_HIP", "mp2p_icp::Solver_GaussNewton_HIP"):
+        assert n in registered, n
+    extra = ["extras/lidar3d-dual-map.yaml", "extras/lidar3d-near-far.yaml"]  # shapes the fused loop does not take
+    mk.generate(ref_dir, str(tmp_path), granular=True, pipelines=list(mk.PIPELINES) + extra)
+    for name in list(mk.PIPELINES) + extra:
+        ref = open(os.path.join(ref_dir, name)).read()
+        gen = open(os.path.join(str(tmp_path), os.path.basename(name).replace(".yaml", "-mola-hip-granular.yaml"))).read()
+        rl, gl = ref.splitlines(), gen.splitlines()
+        assert len(rl) == len(gl)
+        changed = [(a, b) for a, b in zip(rl, gl) if a != b]
+        assert changed and all(re.fullmatch(r"\s+-?\s*class:\s*\S+", a.split("#")[0].rstrip()) for a, _ in changed), changed
+        y = yaml.safe_load(_subst(gen))
+        names = _class_names(y, set())
+        upstream = _class_names(yaml.safe_load(_subst(ref)), set())
+        assert all(n in upstream or n in registered for n in names), names - upstream - registered
+        icp = y["icp_settings_with_vel"]
+        assert icp["class_name"] == "mp2p_icp::ICP"  # upstream's loop: gates, hooks, quality evaluators are its own
+        assert all(s["class"].endswith("_HIP") for s in icp["solvers"])
+        assert all(m["class"].endswith("_HIP") for m in icp["matchers"] if "Matcher_Points_DistanceThreshold" in m["class"] or
+                   "Matcher_Point2Plane" in m["class"])
+    # and the classes derive from the upstream ones (YAML parameters parsed by upstream's initialize())
+    g = open(os.path.join(ADAPTERS, "mp2p_icp_granular.cpp")).read()
+    for cls, base in (("Matcher_Points_DistanceThreshold_HIP", "Matcher_Points_DistanceThreshold"), ("Matcher_Point2Plane_HIP", "Matcher_Point2Plane"),
+                      ("Solver_GaussNewton_HIP", "Solver_GaussNewton")):
+        assert re.search(r"class %s : public %s\b" % (cls, base), g)
+        assert re.search(r"IMPLEMENTS_MRPT_OBJECT\(%s,\s*mp2p_icp::%s,\s*mp2p_icp\)" % (cls, base), g)
+    for call in ("mh_nn_search(", "mh_nn_search_pt2pl(", "mh_gn_solve("):
+        assert call in g
+    cm = open(os.path.join(ADAPTERS, "CMakeLists.txt")).read()
+    assert "mp2p_icp_granular.cpp" in cm
 
 
 def test_docs_and_tools_point_at_the_generated_files():
