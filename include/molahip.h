@@ -161,6 +161,8 @@ typedef struct {
   float voxel_size;
   uint32_t max_points_per_voxel;
   uint64_t n_planes;   /* voxels whose NDT is a plane (0 when NDT statistics are off) */
+  uint32_t deferred_status; /* MH_OK, or the verdict of the last mh_map_insert that no call has reported yet (see there) */
+  uint32_t reserved_;
 } mh_map_info;
 
 MH_API mh_status mh_map_create(mh_ctx* ctx, const mh_map_params* params, mh_map** out);
@@ -178,7 +180,13 @@ MH_API mh_status mh_map_get_info(const mh_map* map, mh_map_info* info);
  * map already stores; then, if remove_voxels_farther_than > 0 (insertOpts, yaml:238), every voxel whose index
  * distance (mh_map_params::far_voxel_metric; default max(|dkx|,|dky|,|dkz|)) to the voxel of T's translation exceeds
  * ceil(remove_voxels_farther_than/voxel_size) is erased [U].  The source index of a new point is (points ever offered to this map) + its index in `scan`.
- * Nothing travels to the host except four counters. */
+ * Nothing travels to the host except four counters, and those lazily: the call returns once the update is QUEUED.
+ * Deferred verdict: points whose voxel index leaves the +-2^20 range of the packed key are left out, and that is known
+ * only when the counters arrive.  It is reported -- once, as MH_ERR_OUT_OF_RANGE -- by the NEXT mh_map_insert on this map,
+ * AFTER that call has performed its own insertion (a valid key-frame is never dropped because the one before it held a
+ * wild point); until then mh_map_get_info shows it in mh_map_info::deferred_status.  mh_map_get_info and the downloads
+ * never fail for it.  (mh_map_build is synchronous about it: it builds the map without the offending points, sets
+ * n_offered, and returns MH_ERR_OUT_OF_RANGE itself.) */
 MH_API mh_status mh_map_insert(mh_map* map, const mh_scan* scan, const double T[12], float remove_voxels_farther_than);
 /* Copy the stored content to HOST arrays (any may be NULL): points voxel by voxel, voxels in ascending
  * (kx,ky,kz), in-voxel insertion order.  xyz/src_idx hold n_points entries, vox_* hold n_voxels. */

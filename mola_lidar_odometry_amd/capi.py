@@ -47,7 +47,8 @@ class MapParams(C.Structure):
 class MapInfo(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("n_offered", C.c_uint64), ("n_voxels", C.c_uint64),
                 ("table_size", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
-                ("voxel_size", C.c_float), ("max_points_per_voxel", C.c_uint32), ("n_planes", C.c_uint64)]
+                ("voxel_size", C.c_float), ("max_points_per_voxel", C.c_uint32), ("n_planes", C.c_uint64),
+                ("deferred_status", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class PairsOut(C.Structure):

@@ -270,6 +270,8 @@ mh_status map_build_prologue(mh_map* m, hipStream_t s, size_t n, size_t n_stored
 // wait (host) for the last (re)build's counters and refresh n_points / n_voxels / n_records / n_planes / bbox; returns the
 // deferred status of that build (MH_ERR_OUT_OF_RANGE) once
 mh_status map_resolve(const mh_map* m);
+// the same without handing the verdict out: counts, bounding box; the verdict stays recorded in m->deferred_error
+mh_status map_resolve_counts(const mh_map* m);
 // make stream `s` wait for a (re)build that may still be running on the map's side stream (no-op otherwise)
 mh_status map_ready_on(const mh_map* m, hipStream_t s);
 }  // namespace mh

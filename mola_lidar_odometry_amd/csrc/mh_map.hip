@@ -469,7 +469,12 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
   for (int i = 0; i < 12; i++) MH_REQUIRE(isfinite(T[i]), "non-finite pose");
   mh_ctx* ctx = m->ctx;
   MH_TRY(set_device(ctx));
-  MH_TRY(map_resolve(m));  // the previous update's counts (long complete by now: an align has run in between) and verdict
+  // the previous update's counts (long complete by now: an align has run in between).  Its out-of-range verdict, if any, is
+  // reported by THIS call -- after this call's own insertion has been performed: a valid key-frame is never dropped because
+  // the one before it held a wild point.
+  MH_TRY(map_resolve_counts(m));
+  const bool prev_out_of_range = m->deferred_error != MH_OK;
+  m->deferred_error = MH_OK;
   // The update is asynchronous either way (no host synchronisation: counts and verdict are read back lazily).  With
   // MH_MAP_SIDE_STREAM=1 it runs on a stream of the map's own, behind everything queued on the context's so far (the layer
   // it reads, the alignments that still read the old content), and is waited for by the NEXT use of the map only
@@ -545,6 +550,9 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
   }
   MH_TRY(map_build_device(m, s, mx, my, mz, msrc, total, evict, n_old, fused_collect));
   m->n_offered += n_new;
+  if (prev_out_of_range)
+    return fail(MH_ERR_OUT_OF_RANGE, "the PREVIOUS update of this map held points whose voxel index exceeds the +-2^20 range of the packed key "
+                                     "(|coord|/voxel_size must be < 1e6); they were left out.  This call's insertion HAS been performed");
   return MH_OK;
 }
 
@@ -561,7 +569,11 @@ __global__ __launch_bounds__(256) void k_init_build(uint32_t* __restrict__ c, ui
   for (uint32_t i = tid; i < n_slots; i += gridDim.x * blockDim.x) slots[i] = e;
 }
 
-mh_status map_resolve(const mh_map* m) {
+// Counts, bounding box and the out-of-range flag of the last (re)build, once its read-back has arrived.  The verdict is
+// only RECORDED here (m->deferred_error); who reports it is the caller's business: mh_map_build returns its own,
+// mh_map_insert returns the PREVIOUS update's after having performed the new one, the accessors never fail for it
+// (mh_map_info::deferred_status shows it).
+mh_status map_resolve_counts(const mh_map* m) {
   if (m->counts_pending) {
     MH_HIP(mh::wait_event(m->ev_counts));
     m->counts_pending = false;
@@ -578,13 +590,23 @@ mh_status map_resolve(const mh_map* m) {
     }
     if (h[0] & 1u) m->deferred_error = MH_ERR_OUT_OF_RANGE;
   }
-  if (m->deferred_error != MH_OK) {
-    const mh_status e = m->deferred_error;
-    m->deferred_error = MH_OK;
-    return fail(e, "a point's voxel index exceeds the +-2^20 range of the packed key (|coord|/voxel_size must be < 1e6); "
-                   "the offending points were left out of the map");
-  }
   return MH_OK;
+}
+
+// ... and hand the recorded verdict out (once)
+mh_status map_take_verdict(const mh_map* m, const char* whose) {
+  if (m->deferred_error == MH_OK) return MH_OK;
+  const mh_status e = m->deferred_error;
+  m->deferred_error = MH_OK;
+  char msg[320];
+  snprintf(msg, sizeof msg, "%s: a point's voxel index exceeds the +-2^20 range of the packed key (|coord|/voxel_size must be < 1e6); "
+                            "the offending points were left out of the map", whose);
+  return fail(e, msg);
+}
+
+mh_status map_resolve(const mh_map* m) {
+  MH_TRY(map_resolve_counts(m));
+  return map_take_verdict(m, "map update");
 }
 
 mh_status map_ready_on(const mh_map* m, hipStream_t s) {
@@ -756,7 +778,7 @@ extern "C" {
 mh_status mh_map_get_info(const mh_map* m, mh_map_info* info) {
   MH_REQUIRE(m && info, "null argument");
   MH_TRY(set_device(m->ctx));
-  MH_TRY(map_resolve(m));
+  MH_TRY(map_resolve_counts(m));  // (never fails for a deferred verdict: see deferred_status)
   info->n_points = m->n_points;
   info->n_offered = m->n_offered;
   info->n_voxels = m->n_voxels;
@@ -768,6 +790,7 @@ mh_status mh_map_get_info(const mh_map* m, mh_map_info* info) {
   info->voxel_size = m->params.voxel_size;
   info->max_points_per_voxel = m->params.max_points_per_voxel;
   info->n_planes = m->n_planes;
+  info->deferred_status = (uint32_t)m->deferred_error;
   return MH_OK;
 }
 
@@ -777,7 +800,7 @@ mh_status mh_map_download(const mh_map* m, float* x, float* y, float* z, uint32_
   mh_ctx* ctx = m->ctx;
   MH_TRY(set_device(ctx));
   MH_HIP(mh::wait_stream(ctx->stream));
-  MH_TRY(map_resolve(m));  // (waits for an update still running on the side stream)
+  MH_TRY(map_resolve_counts(m));  // (waits for an update still running on the side stream)
   if (!m->n_voxels) return MH_OK;
   std::vector<uint32_t> hf(m->n_voxels), hc(m->n_voxels);
   MH_HIP(hipMemcpy(hf.data(), m->vox_first.p, m->n_voxels * 4, hipMemcpyDeviceToHost));
@@ -821,7 +844,7 @@ mh_status mh_map_download_ndt(const mh_map* m, float* cx, float* cy, float* cz, 
   mh_ctx* ctx = m->ctx;
   MH_TRY(set_device(ctx));
   MH_HIP(mh::wait_stream(ctx->stream));
-  MH_TRY(map_resolve(m));
+  MH_TRY(map_resolve_counts(m));
   if (!m->n_voxels) return MH_OK;
   const bool ndt = m->params.ndt_max_eigen_ratio > 0.f;
   std::vector<uint32_t> hf(m->n_voxels);

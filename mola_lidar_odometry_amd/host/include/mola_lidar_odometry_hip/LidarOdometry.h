@@ -123,6 +123,8 @@ class LidarOdometry {
     double goodness = 0, sigma = 0, estimated_sensor_max_range = 0, instantaneous_sensor_max_range = 0;
     uint32_t icp_iterations = 0, twist_corrections = 0, align_calls = 0;
     int termination = 0;
+    // n_map_points / n_map_voxels: the map AFTER this scan.  In the reference returned by onLidar*() they are still 0 for a
+    // key-frame scan (and for the scans up to the next read-back): the update is asynchronous; records() fills them in.
     uint64_t n_raw = 0, n_for_map = 0, n_for_icp = 0, n_map_points = 0, n_map_voxels = 0;
     Twist twist;              // twist used for the (last) de-skew of this scan
     double decim_map_resolution = 0, decim_icp_resolution = 0, map_voxel_size = 0;
@@ -234,7 +236,7 @@ class LidarOdometry {
   mutable bool map_counts_pending_ = false;  // records_[map_counts_from_ ...] wait for the map's counters
   mutable size_t map_counts_from_ = 0;
   mutable uint64_t map_points_cached_ = 0, map_voxels_cached_ = 0;
-  bool map_known_nonempty_ = false;
+  mutable bool map_known_nonempty_ = false;
   bool input_pinned_ = false;
   std::map<std::string, double> profile_;
 };

@@ -464,6 +464,9 @@ void LidarOdometry::resolve_map_counts() const {
     records_[i].n_map_voxels = map_voxels_cached_;
   }
   map_counts_pending_ = false;
+  // what map_is_empty() answers from now on follows the device's own count (an update with far-voxel removal may leave
+  // the map empty: local_map_->empty() is what the reference asks every scan, LidarOdometry.cpp:817)
+  map_known_nonempty_ = map_points_cached_ != 0;
 }
 
 bool LidarOdometry::map_is_empty() {

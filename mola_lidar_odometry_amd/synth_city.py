@@ -37,6 +37,8 @@ def _lib():
         L.city_sweep.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_double, ctypes.c_double, ctypes.c_uint64, ctypes.c_double, ctypes.c_double,
                                  ctypes.c_void_p, ctypes.c_void_p]
+        L.city_set_threads.argtypes = [ctypes.c_int]
+        L.city_set_threads(max(1, min(16, os.cpu_count() or 1)))
         _LIB = L
     return _LIB
 

@@ -168,6 +168,11 @@ static double cast(const City* c, const double o[3], const double d[3], double t
   return best <= tmax ? best : INFINITY;
 }
 
+static int g_threads = 0;  // 0 = OpenMP's default
+// The ray loop of one sweep is ~10 ms of work: more than a few dozen threads only add fork/join cost (a 256-thread box
+// cast a sweep 8x slower with all of them than with 16).
+__attribute__((visibility("default"))) void city_set_threads(int n) { g_threads = n > 0 ? n : 0; }
+
 static uint64_t splitmix(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -211,7 +216,8 @@ __attribute__((visibility("default"))) int city_sweep(const void* h, const doubl
       q[9 + r] = T[4 * r] * p[0] + T[4 * r + 1] * p[1] + T[4 * r + 2] * p[2] + T[4 * r + 3];
     }
   }
-#pragma omp parallel for schedule(dynamic, 1024)
+  const int nt = g_threads > 0 ? g_threads : 16;
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(nt)
   for (long i = 0; i < (long)n; i++) {
     const int ring = (int)(i / azimuths), j = (int)(i % azimuths);
     const double el = deg * (rings > 1 ? el_top_deg + (el_bottom_deg - el_top_deg) * (double)ring / (double)(rings - 1) : el_top_deg);

@@ -76,6 +76,44 @@ def test_map_out_of_range_is_an_error(ctx):
     assert e.value.status == 4
 
 
+def test_map_insert_after_an_out_of_range_insert_is_performed(ctx, oracle):
+    """mh_map_insert's out-of-range verdict is deferred (the counters come back lazily).  It must not swallow the NEXT
+    key-frame: that call performs its own insertion and THEN reports the previous one's verdict; the accessors in between
+    never fail for it."""
+    rng = np.random.default_rng(11)
+    a = rng.normal(0, 4, (3000, 3)).astype(np.float32)
+    wild = a.copy()
+    wild[7] = [5.0e7, 0, 0]  # |coord| / voxel_size >= 1e6: left out of the map
+    b = rng.normal(0, 4, (2500, 3)).astype(np.float32) + np.float32(1.5)
+    c = rng.normal(0, 4, (2000, 3)).astype(np.float32) - np.float32(1.0)
+    I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+    g = capi.Map(ctx, 1.0, 20)
+    g.build(a[:0])
+    g.insert(capi.Scan(ctx, wild), I)        # queued: no verdict yet
+    i1 = g.info()                            # never fails for it ...
+    assert i1.deferred_status == 4 and i1.n_points > 0   # ... but shows it (MH_ERR_OUT_OF_RANGE)
+    g.download()                             # ... nor do the downloads
+    with pytest.raises(capi.MolahipError) as e:
+        g.insert(capi.Scan(ctx, b), I)       # reports the PREVIOUS update's verdict -- after inserting b
+    assert e.value.status == 4 and "HAS been performed" in str(e.value)
+    assert g.info().deferred_status == 0
+    g.insert(capi.Scan(ctx, c), I)           # and nothing lingers
+    o = oracle.Map(1.0, 20)
+    ok = np.ones(len(wild), bool)
+    ok[7] = False
+    # the oracle has no key range: give it the same content the device kept, with the device's source indices
+    d = g.download()
+    o.insert(wild[ok])
+    o.insert(b)
+    o.insert(c)
+    od = o.dump()
+    assert int(g.info().n_points) == len(od["x"]) if isinstance(od, dict) and "x" in od else True
+    n_expected = o.num_points
+    assert int(g.info().n_points) == n_expected
+    assert int(g.info().n_offered) == len(wild) + len(b) + len(c)
+    del d
+
+
 def test_map_build_from_device_pointers(ctx, oracle):
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(5)
