@@ -137,7 +137,7 @@ PIPELINE = os.path.join(ROOT, "pipelines", "lidar3d-default-hip.yaml")
 PIPELINE_NDT = os.path.join(ROOT, "pipelines", "lidar3d-ndt-hip.yaml")
 
 
-def run_lo_cli(seq_dir, n_seq, out_stem, timeout=600, pipeline=PIPELINE, max_scans=None, scan_log=False):
+def run_lo_cli(seq_dir, n_seq, out_stem, timeout=600, pipeline=PIPELINE, max_scans=None, scan_log=False, env=None):
     """molahip-lo-cli (C++, no Python in the loop) over n_seq copies of the sequence folder in ONE process: per-sequence
     reports, per-stage host milliseconds, the N-sequence summary line.  The synthetic drive carries per-point time stamps in
     the fourth float of a row (--time-field 12): the sweeps are skewed by the vehicle's motion, the de-skew filter has work."""
@@ -148,7 +148,7 @@ def run_lo_cli(seq_dir, n_seq, out_stem, timeout=600, pipeline=PIPELINE, max_sca
         cmd += ["--scan-log", "auto"]
     for _ in range(n_seq):
         cmd += ["--seq-dir", seq_dir]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **env) if env else None)
     if r.returncode != 0:
         raise RuntimeError("molahip-lo-cli failed (%d): %s" % (r.returncode, r.stderr[-800:]))
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
@@ -198,6 +198,11 @@ def cpu_driver_sample(pipeline, seq_dir, stamps, est, scan_seconds, cpu_seconds,
     taken out), and the device driver's rate over THE SAME scans."""
     from oracle import odometry_oracle as oo
     from oracle import oracle_c
+    try:  # the driver's small numpy products must not wake a BLAS pool of one thread per logical core
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1, user_api="blas")
+    except Exception:  # noqa: BLE001
+        pass
     files = sorted(glob.glob(os.path.join(seq_dir, "velodyne", "*.bin")))
 
     def load(k):
@@ -256,6 +261,52 @@ def cpu_driver_sample(pipeline, seq_dir, stamps, est, scan_seconds, cpu_seconds,
         m = min(len(est), len(est_cpu))
         out["max_pose_diff_device_vs_cpu_m"] = float(np.abs(est[:m, :3, 3] - est_cpu[:m, :, 3]).max())
     return out
+
+
+def _cpu_sequence_worker(args):
+    """(child process) the CPU oracle driver over the first scans of the folder for `seconds`; -> (scans done after the
+    first 5, seconds spent on them)."""
+    pipeline, seq_dir, threads, seconds = args
+    from oracle import odometry_oracle as oo
+    files = sorted(glob.glob(os.path.join(seq_dir, "velodyne", "*.bin")))
+    o = oo.OdometryOracle(pipeline, n_threads=threads)
+    t_steady, k_steady, t_all = 0.0, 0, 0.0
+    for k, f in enumerate(files):
+        rows = np.fromfile(f, dtype=np.float32).reshape(-1, 4)
+        tc = time.perf_counter()
+        o.on_lidar(0.1 * k, np.ascontiguousarray(rows[:, :3]), np.ascontiguousarray(rows[:, 3]))
+        d = time.perf_counter() - tc
+        t_all += d
+        if k >= 5:
+            t_steady += d
+            k_steady += 1
+        if t_all > seconds and k_steady >= 5:
+            break
+    return k_steady, t_steady
+
+
+def cpu_throughput(pipeline, seq_dir, n_proc, threads, seconds):
+    """The CPU in THROUGHPUT mode (a one-at-a-time CPU figure against a batched GPU figure compares latency
+    with throughput): n_proc copies of the CPU oracle driver at once, one process per sequence like eval/cli_kitti.sh:23 does
+    with GNU parallel, `threads` OpenMP threads each.  Aggregate scans/s (Python loop included)."""
+    code = ("import sys, json; sys.path.insert(0, %r); import bench; "
+            "print(json.dumps(bench._cpu_sequence_worker((%r, %r, %d, %f))))" % (ROOT, pipeline, seq_dir, threads, seconds))
+    # (numpy's BLAS pool would start one thread per logical core in EVERY child: 16 x 256 spinning threads starve each other)
+    env = dict(os.environ, OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", OMP_WAIT_POLICY="passive")
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+             for _ in range(n_proc)]
+    res = []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=120 + 4 * seconds)
+        line = [l for l in out.splitlines() if l.startswith("[")]
+        if pr.returncode == 0 and line:
+            res.append(json.loads(line[-1]))
+    if not res:
+        raise RuntimeError("no CPU driver process finished")
+    return {"value": float(sum(k / t for k, t in res if t > 0)), "unit": "scans/sec", "processes": len(res), "threads_per_process": threads,
+            "host_logical_cores": os.cpu_count(), "kind": "port",
+            "sample": "%d concurrent CPU oracle drivers (one process per sequence, %d OpenMP threads each, Python loop included) on "
+                      "the first scans of the drive, %.0f s each" % (len(res), threads, seconds)}
 
 
 def one_sequence(seq_dir, gt, stamps, n_raw, tmp, pipeline, tag, cpu_seconds, what):
@@ -328,8 +379,30 @@ def sequence_extras(drive, tmp, seq_counts, cpu_seconds, log, multi_scans=400):
                 identical = identical and all(open(q["tum"]).read() == solo_tum for q in perc)
         except Exception as e:  # noqa: BLE001
             multi[str(c)] = {"error": repr(e)[:300]}
+    # the same question to the CPU: how many scans/s does the HOST deliver when it, too, runs many sequences at once?
+    cpu_tp = None
+    try:
+        cores = os.cpu_count() or 8
+        thr = int((single.get("cpu_driver") or {}).get("cores") or 8)
+        n_proc = max(1, min(16, cores // max(1, thr)))
+        cpu_tp = cpu_throughput(PIPELINE, seq_dir, n_proc, thr, min(6.0, cpu_seconds))
+        best = max((v["steady_scans_per_s"] for v in multi.values() if "steady_scans_per_s" in v), default=None)
+        if best and cpu_tp["value"]:
+            cpu_tp["ratio_best_device_multi_sequence_vs_this"] = best / cpu_tp["value"]
+    except Exception as e:  # noqa: BLE001
+        cpu_tp = {"error": repr(e)[:300]}
+    log("cpu throughput done")
+    # ... and with a local map of ~1 M points (MOLA_LOCAL_MAP_MAX_SIZE, the reference pipeline's own knob, yaml:238): the default
+    # radius max(100, 1.5 x range) keeps ~0.55-0.65 M points of this city
+    try:
+        perb, _, _ = run_lo_cli(seq_dir, 1, os.path.join(tmp, "bigmap"), env={"MOLA_LOCAL_MAP_MAX_SIZE": "250"})
+        single["with_1M_point_local_map"] = {"steady_scans_per_s": perb[0]["steady_scans_per_s"], "whole_run_scans_per_s": perb[0]["scans_per_s"],
+                                             "max_map_points": perb[0]["max_map_points"], "final_map_points": perb[0]["final_map_points"],
+                                             "env": {"MOLA_LOCAL_MAP_MAX_SIZE": "250"}}
+    except Exception as e:  # noqa: BLE001
+        single["with_1M_point_local_map"] = {"error": repr(e)[:300]}
     out["multi_sequence"] = {"unit": "scans/sec", "sequences_in_one_process": multi, "trajectories_identical_to_solo_run": identical,
-                             "scans_per_sequence": multi_scans,
+                             "scans_per_sequence": multi_scans, "cpu_throughput_mode": cpu_tp,
                              "note": "N copies of the first %d scans of the drive through ONE molahip-lo-cli process (a host thread per "
                                      "sequence, alignments merged into lock-step batches); steady = registration time of the slowest thread "
                                      "without its first 5 scans; whole run = wall clock incl. process start-up" % multi_scans}

@@ -16,6 +16,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmolahip.so")
+if os.environ.get("MOLAHIP_LIB_PATH"):  # development: an A/B build of the same sources (tools/build_variants.sh, tools/build_floor.sh)
+    LIB_PATH = os.environ["MOLAHIP_LIB_PATH"]
 
 MH_OK = 0
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2

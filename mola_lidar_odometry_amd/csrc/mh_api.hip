@@ -27,6 +27,7 @@ mh_status fail(mh_status s, const char* fmt, ...) {
 
 static thread_local mh_wait_hook_fn g_wait_hook = nullptr;
 static thread_local void* g_wait_user = nullptr;
+bool wait_hook_installed() { return g_wait_hook != nullptr; }
 static thread_local hipEvent_t g_wait_ev[16] = {nullptr};  // one marker event per device, per thread
 
 hipError_t wait_event(hipEvent_t e) {

@@ -92,6 +92,9 @@ struct SolveK {
   mh_icp_iter* trace;
   mh_gn_step* gn_trace;
   double cov_hx, cov_ha;  // finite-difference steps of the covariance
+  // streaming loop control (AlignJob::run_streaming): a word of page-locked HOST memory (device-visible address) that the
+  // kernel closing a Gauss-Newton step updates with (ICP iteration about to run | done << 31); null = not published
+  uint32_t* host_progress;
 };
 
 struct IcpDeviceParams {
@@ -310,6 +313,10 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
 #ifdef MH_DEBUG_WAVETRACE
                                                    , unsigned long long* __restrict__ wtrace
 #endif
+#ifdef MH_DEBUG_FLOOR
+                                                   , uint32_t* __restrict__ floor_cap = nullptr, uint32_t* __restrict__ floor_more = nullptr,
+                                                   uint32_t floor_iter = 0xFFFFFFFFu
+#endif
 ) {
 #ifdef MH_DEBUG_WAVETRACE
   struct WT { unsigned long long* p; unsigned long long t0; uint32_t w;
@@ -346,8 +353,17 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
     const float dx = prev.x - px, dy = prev.y - py, dz = prev.z - pz;
     bound0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic of nn_scan_round_quad
   }
+#ifdef MH_DEBUG_FLOOR
+  const NNResult r = nn_search_quad(map, sub, px, py, pz, bound0, (floor_cap && cst->iter == floor_iter) ? floor_cap + 2ull * i : nullptr,
+                                    floor_more ? floor_more + 4ull * i : nullptr);
+#else
   const NNResult r = nn_search_quad(map, sub, px, py, pz, bound0);
+#endif
+#ifdef MH_CARRY_WINNER
+  if (r.writer) {
+#else
   if (sub == 0) {
+#endif
     const float n2 = (px * px + py * py) + pz * pz;
     const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
     G(reinterpret_cast<f32x4*>(pair_q))[o] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
@@ -1106,6 +1122,16 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, con
 // skipped as well (same test) and the partials are stale: nothing to do.  (Found by tools/fuzz_batch.py: a converged
 // alignment with the stall test off kept stepping on stale sums -- harmlessly small steps with k_accum's layout, garbage
 // with the fused matchers' wider one.)
+// One lane tells the host where the loop stands (system-scope store into page-locked host memory): the host then keeps
+// only a couple of iterations queued ahead of the device instead of a predicted chunk with an idle tail (run_streaming).
+__device__ __forceinline__ void publish_progress(const IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp) {
+  if (threadIdx.x != 0) return;
+  uint32_t* hp = kp->host_progress;
+  if (!hp) return;
+  const uint32_t v = (st->iter & 0x7FFFFFFFu) | (st->done ? 0x80000000u : 0u);
+  __hip_atomic_store(hp, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ void k_solve_body(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
                                                          const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                                          const double* __restrict__ partB, uint32_t nB,
@@ -1114,6 +1140,7 @@ __device__ __forceinline__ void k_solve_body(IcpDeviceState* __restrict__ st, co
   if (st->done) return;
   if (!first && st->inner == 0) return;  // (uniform: every lane reads the same word)
   solve_body(st, kp, partA, nA, strideA, partB, nB, strideB, sh);
+  publish_progress(st, kp);
 }
 
 // ================================================================================================
@@ -1255,6 +1282,7 @@ __device__ __forceinline__ void k_accum_solve1_body(IcpDeviceState* __restrict__
   }
   MH_PHASE(3);
   solve_body(st, sk, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true, PL);
+  publish_progress(st, sk);
 }
 template <bool PL>
 __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* __restrict__ st, uint32_t first,
@@ -1762,11 +1790,174 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDevic
 #endif
   );
 }
+#ifdef MH_DEBUG_FLOOR
+// ================================================================================================
+// tools/match_floor.py (debug build, -DMH_DEBUG_FLOOR): the latency floor of the quad matcher's access pattern.
+// k_match4_b records, for ONE chosen ICP iteration, what every point's search touched (nn_search_quad: per probe batch the
+// voxel code of each lane, the winner's record); k_match_floor_b then replays exactly that -- same grid, same registers
+// budget, the same DEPENDENT chain per quad: point + previous pairing -> slot probes of a batch -> W records per lane and
+// round trip of the merged ranges -> next batch -> the winner's record -> pairing written -- with the arithmetic stripped to
+// one compare per record: no fp64 transform, no voxel bounds, no distances, no 64-bit keys.  Its duration is what the memory
+// system + address generation cost for this search schedule; the real kernel's distance from it is arithmetic and issue.
+// ================================================================================================
+__device__ uint32_t* g_floor_script = nullptr;  // [job][point][2]
+__device__ uint32_t* g_floor_more = nullptr;    // [job][point][4]: batches beyond the first
+__device__ float4* g_floor_out_q = nullptr;     // [job][point]: where the replay writes its "pairings"
+__device__ uint32_t* g_floor_out_g = nullptr;
+__device__ uint32_t g_floor_stride = 0, g_floor_iter = 0xFFFFFFFFu;
+struct FloorHost {
+  uint32_t *script = nullptr, *more = nullptr, *out_g = nullptr;
+  float4* out_q = nullptr;
+  uint32_t stride = 0, jobs = 0, run_reps = 0, flags = 0;
+  double floor_ms = 0, real_ms_at_iter = 0, real_ms_avg = 0;
+  uint32_t real_launches = 0;
+} g_floor_host;
+
+// what-if switches of the replay (tools/match_floor.py --what-if): which load costs what?
+enum { FLOOR_NO_WINNER_FETCH = 1, FLOOR_NO_PREV = 2, FLOOR_NO_TRANSFORM = 4, FLOOR_NO_OUTPUT = 8, FLOOR_RECORDS_12B = 16, FLOOR_HALF_RECORDS = 32 };
+
+__global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_floor_b(const BatchJob* __restrict__ jobs, uint32_t flags) {
+  const BatchJob& j = jobs[blockIdx.y];
+  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = gl >> 2, sub = gl & 3u;
+  const uint32_t n = j.n;
+  const uint32_t ic = i < n ? i : n - 1;
+  const float x = G(j.lx)[ic], y = G(j.ly)[ic], z = G(j.lz)[ic];
+  typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
+  const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(j.st);
+  f32x4 prev = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (!(flags & FLOOR_NO_PREV)) prev = G(reinterpret_cast<const f32x4*>(j.pair_q))[ic];
+  const size_t pi = (size_t)blockIdx.y * g_floor_stride + ic;
+  const uint32_t w_idx = G(g_floor_script)[2 * pi], head = G(g_floor_script)[2 * pi + 1];
+  double T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = cst->T[k];
+  if (i >= n) return;
+  // the probe addresses follow from the transformed point, as in the real kernel (address generation, not search arithmetic)
+  float px, py, pz;
+  if (flags & FLOOR_NO_TRANSFORM) px = x, py = y, pz = z;
+  else transform_point(T, x, y, z, px, py, pz);
+  const MapView& m = j.map;
+  const uint32_t dep0 = (uint32_t)(__float_as_uint(prev.w) == 0xFFFFFFFEu);
+  const unsigned long long kbase = pack_key(voxel_of(px, m.inv_vs, m.trunc) - 1, voxel_of(py, m.inv_vs, m.trunc) - 1, voxel_of(pz, m.inv_vs, m.trunc) - 1) + dep0;
+  const uint32_t nb_raw = head >> 24;
+  const uint32_t nb = nb_raw >= 15u ? 0u : (nb_raw < 5u ? nb_raw : 5u);
+  uint32_t acc = 0xFFFFFFF0u;
+  const gslots_ptr slots4 = (gslots_ptr)m.slots;
+  const gpts_ptr pts4 = (gpts_ptr)m.pts;
+  for (uint32_t b = 0; b < nb; b++) {
+    uint32_t c_mine;
+    if (b == 0) {
+      c_mine = (head >> (6u * sub)) & 63u;
+    } else {
+      const uint32_t codes = G(g_floor_more)[4 * pi + (b - 1u)];
+      c_mine = (codes >> (8u * sub)) & 63u;
+    }
+    const bool want = c_mine != 63u;
+    const unsigned long long key = nn_key_of(kbase, want ? (int)c_mine : 0) + (acc == 0xFFFFFFFEu);  // (the next probe waits for the scan)
+    const u32x4 sl = slots4[hash_key(key) & m.mask];
+    uint32_t f_mine, n_mine;
+    nn_resolve(m, slots4, key, sl, want, f_mine, n_mine);
+    if (flags & FLOOR_HALF_RECORDS) n_mine = (n_mine + 1u) >> 1;
+    const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
+    const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
+    uint32_t pre[5], start[4];
+    pre[0] = 0;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      pre[v + 1] = pre[v] + cnt[v];
+      start[v] = first[v] - pre[v];
+    }
+    const uint32_t total = pre[4];
+    for (uint32_t t0 = 0; t0 < total; t0 += 4 * kQuadW) {
+      f32x4 c[kQuadW];
+      bool valid[kQuadW];
+#pragma unroll
+      for (int u = 0; u < kQuadW; u++) {
+        const uint32_t tu = t0 + 4u * (uint32_t)u + sub;
+        valid[u] = tu < total;
+        const uint32_t t = valid[u] ? tu : total - 1;
+        uint32_t off = start[0];
+#pragma unroll
+        for (int v = 1; v < 4; v++) off = t >= pre[v] ? start[v] : off;
+        if (flags & FLOOR_RECORDS_12B) {  // what a 12-byte read of the record would cost (same lines, narrower instruction)
+          typedef float f32x3 __attribute__((ext_vector_type(3)));
+          const f32x3 c3 = *reinterpret_cast<const f32x3 MH_AS_GLOBAL*>(pts4 + (t + off));
+          c[u] = (f32x4){c3.x, c3.y, c3.z, 0.f};
+        } else {
+          c[u] = pts4[t + off];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kQuadW; u++) {  // ONE compare per record
+        const uint32_t k = valid[u] ? __float_as_uint(c[u].x) : 0xFFFFFFF0u;
+        acc = k < acc ? k : acc;
+      }
+    }
+    // the quad agrees on the best after every scan (two quad_perm steps in the real kernel as well)
+    uint32_t o = quad_u32<0xB1>(acc);
+    acc = o < acc ? o : acc;
+    o = quad_u32<0x4E>(acc);
+    acc = o < acc ? o : acc;
+  }
+  f32x4 rec = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (!(flags & FLOOR_NO_WINNER_FETCH) && w_idx != 0xFFFFFFFFu) rec = pts4[w_idx + (acc == 0xFFFFFFFEu)];  // the winner's record: waits for the last scan
+  if (sub == 0 && !(flags & FLOOR_NO_OUTPUT)) {
+    const size_t o = (size_t)blockIdx.y * g_floor_stride + i;
+    G(reinterpret_cast<f32x4*>(g_floor_out_q))[o] = (f32x4){rec.x, rec.y, rec.z, __uint_as_float(acc ^ dep0)};
+    G(g_floor_out_g)[o] = __float_as_uint(rec.w);
+  } else if (acc == 0xFFFFFFFEu) {
+    G(g_floor_out_g)[0] = acc;  // (keeps the chain alive when the output is switched off)
+  }
+}
+
+// setup(n_jobs, max points per job): buffers; capture_iter: which ICP iteration's launch writes scripts (0xFFFFFFFF: none);
+// run_reps: how often mh_icp_align_batch replays the floor kernel after its last chunk (0: not at all)
+extern "C" __attribute__((visibility("default"))) int mh_debug_floor_setup(uint32_t n_jobs, uint32_t stride, uint32_t capture_iter,
+                                                                          uint32_t run_reps, uint32_t flags) {
+  FloorHost& f = g_floor_host;
+  f.flags = flags;
+  if (f.jobs != n_jobs || f.stride != stride) {
+    if (f.script) (void)hipFree(f.script), (void)hipFree(f.more), (void)hipFree(f.out_q), (void)hipFree(f.out_g);
+    f.script = nullptr;
+    const size_t np = (size_t)n_jobs * stride;
+    if (hipMalloc(&f.script, np * 8) != hipSuccess || hipMalloc(&f.more, np * 16) != hipSuccess || hipMalloc(&f.out_q, np * 16) != hipSuccess ||
+        hipMalloc(&f.out_g, np * 4) != hipSuccess)
+      return 1;
+    (void)hipMemset(f.script, 0xFF, np * 8);
+    (void)hipMemset(f.more, 0xFF, np * 16);
+    f.jobs = n_jobs, f.stride = stride;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_script), &f.script, sizeof(void*));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_more), &f.more, sizeof(void*));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_out_q), &f.out_q, sizeof(void*));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_out_g), &f.out_g, sizeof(void*));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_stride), &stride, sizeof(uint32_t));
+  }
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_iter), &capture_iter, sizeof(uint32_t));
+  f.run_reps = run_reps;
+  return hipDeviceSynchronize() == hipSuccess ? 0 : 2;
+}
+// out[0] floor ms per launch, [1] real kernel ms at the captured iteration, [2] real kernel ms averaged over the alignment's
+// launches, [3] launches; and per point statistics of the scripts: [4] mean probe batches, [5] share of points captured
+extern "C" __attribute__((visibility("default"))) int mh_debug_floor_result(double* out, uint32_t* scripts_host, size_t n_dwords) {
+  const FloorHost& f = g_floor_host;
+  out[0] = f.floor_ms, out[1] = f.real_ms_at_iter, out[2] = f.real_ms_avg, out[3] = f.real_launches;
+  if (scripts_host && f.script) {
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(scripts_host, f.script, n_dwords * 4, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+  }
+  return 0;
+}
+#endif
 __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4_b(const BatchJob* __restrict__ jobs) {
   const BatchJob& j = jobs[blockIdx.y];
   k_match4_body(j.st, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, nullptr
 #ifdef MH_DEBUG_WAVETRACE
                 , nullptr
+#endif
+#ifdef MH_DEBUG_FLOOR
+                , g_floor_script ? g_floor_script + (size_t)blockIdx.y * g_floor_stride * 2u : nullptr,
+                g_floor_more ? g_floor_more + (size_t)blockIdx.y * g_floor_stride * 4u : nullptr, g_floor_iter
 #endif
   );
 }
@@ -1888,7 +2079,11 @@ __device__ __forceinline__ void k_match_wave_body(const IcpDeviceState* __restri
     if (lane == 0 && dbg) { dbg[0] = wall_clock64(); dbg[2] = cnt; dbg[3] = 0; }
 #endif
     const NNResult r = nn_search_quad(map, sub, px, py, pz);
+#ifdef MH_CARRY_WINNER
+    if (active && r.writer) {
+#else
     if (active && sub == 0u) {
+#endif
       const float n2 = (px * px + py * py) + pz * pz;
       const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
       pair_q[orig] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
@@ -2210,11 +2405,18 @@ mh_status ensure_state(mh_ctx* ctx) {
   if (!ctx->d_state) {
     char *d = nullptr, *h = nullptr;
     MH_HIP(hipMalloc((void**)&d, kParamsOffset + sizeof(IcpDeviceParams)));
-    MH_HIP(hipHostMalloc((void**)&h, kParamsOffset + sizeof(IcpDeviceParams), hipHostMallocDefault));
+    const size_t prog_off = ((kParamsOffset + sizeof(IcpDeviceParams) + 127) / 128) * 128;  // a cache line of its own
+    MH_HIP(hipHostMalloc((void**)&h, prog_off + 128, hipHostMallocDefault));
     ctx->d_state = (IcpDeviceState*)d;
     ctx->h_state = (IcpDeviceState*)h;
     ctx->d_params = (IcpDeviceParams*)(d + kParamsOffset);
     ctx->h_params = (IcpDeviceParams*)(h + kParamsOffset);
+    // the word the device loop publishes its progress in (run_streaming): page-locked host memory, written by the kernels
+    ctx->h_progress = (uint32_t*)(h + prog_off);
+    *ctx->h_progress = 0;
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, ctx->h_progress, 0) != hipSuccess) dp = nullptr;  // (then the loop is never streamed)
+    ctx->d_progress = (uint32_t*)dp;
   }
   return MH_OK;
 }
@@ -2346,6 +2548,8 @@ struct AlignJob {
   bool finished = false, trivial = false;
   bool prof = false;  // time this job's match kernels with events (then it cannot use the graph path)
   bool pl = false;    // Matcher_Point2Plane runs before the point matcher (lidar3d-ndt.yaml:195-210)
+  bool streaming = false;  // run_streaming(): iterations are enqueued one by one behind the device's published progress
+  bool skip_tail = false;  // ... and the covariance kernels + state read-back only once the loop has ended
 
   mh_status start(const mh_map* m, const mh_scan* sc, const mh_icp_params* prm, const double* T0, const mh_prior* prior,
                   mh_icp_result* r, mh_icp_iter* tr, size_t batch_index = 0) {
@@ -2432,6 +2636,15 @@ struct AlignJob {
     sk.gn_trace = nullptr;
     sk.cov_hx = p->cov_findif_xyz;
     sk.cov_ha = p->cov_findif_ang;
+    // Streaming loop control (single alignments with automatic polling): instead of a predicted chunk of iterations whose
+    // unused tail idles on the stream (27.8 iterations' worth of kernels enqueued for 21 executed on the city drive, plus
+    // 0.64 extra host round trips per scan), the host follows the progress word the solve kernels publish and keeps
+    // MH_STREAM_LEAD (2) iterations queued ahead.  Not for lock-step batches (defer_upload), profiled jobs, a cooperative
+    // wait hook (the spin would starve the other fibers), or when switched off (MH_NO_STREAM=1).
+    streaming = p->poll_every == 0 && !defer_upload && !prof && ctx->d_progress != nullptr && !mh::wait_hook_installed() &&
+                getenv("MH_NO_STREAM") == nullptr && getenv("MH_PERSIST") == nullptr && getenv("MH_FUSED_INNER") == nullptr;  // (those two
+                                                                                             // keep the state in LDS across steps)
+    sk.host_progress = streaming ? ctx->d_progress : nullptr;
     if (defer_upload) {
       ctx->h_params->mk = mk;
       ctx->h_params->sk = sk;
@@ -2646,6 +2859,7 @@ struct AlignJob {
                              (const double*)partb, nBi, nBi, 0u);
         }
       }
+      if (skip_tail) return MH_OK;  // streaming: the tail below is enqueued once, by enqueue_tail()
       if (p->compute_covariance) {  // no-ops unless the loop has terminated
         hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, dsk, 0u);
         hipLaunchKernelGGL(k_cov_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, scan->x, scan->y, scan->z, n,
@@ -2660,9 +2874,13 @@ struct AlignJob {
       return MH_OK;
     };
     const bool no_graph = getenv("MH_NO_GRAPH") != nullptr;
-    if (prof || no_graph) {
+    if (prof || no_graph || streaming) {
       MH_TRY(enqueue_kernels());
       MH_HIP(hipGetLastError());
+      if (streaming) {  // (no event per iteration: the progress word is the signal)
+        enqueued += m;
+        return MH_OK;
+      }
     } else {
       // The launch sequence only depends on sizes and device pointers (the per-alignment values sit in device
       // memory), so it is captured once and replayed: one host call per chunk instead of ~4 per iteration.
@@ -2726,6 +2944,63 @@ struct AlignJob {
     }
     enqueued += m;
     if (prof) MH_HIP(hipEventRecord(ctx->ev_t1, s));
+    MH_HIP(hipEventRecord(ctx->ev_poll, s));
+    return MH_OK;
+  }
+
+  // The whole loop of a single alignment under streaming control: iterations are enqueued one at a time, at most `lead`
+  // ahead of the iteration the device has published; once it publishes "done" the covariance kernels and the state
+  // read-back follow and ONE event wait ends the call.
+  mh_status run_streaming() {
+    static const uint32_t lead = getenv("MH_STREAM_LEAD") ? (uint32_t)std::max(1, atoi(getenv("MH_STREAM_LEAD"))) : 2u;
+    volatile uint32_t* prog = ctx->h_progress;
+    *prog = 0;  // (the previous alignment of this context has been waited for: nothing in flight writes it)
+    chunk = 1;
+    skip_tail = true;
+    uint32_t spins = 0;
+    for (;;) {
+      const uint32_t pv = *prog;
+      if (pv >> 31) break;
+      const uint32_t dev_iter = pv & 0x7FFFFFFFu;
+      if (enqueued < p->max_iterations && enqueued < dev_iter + lead) {
+        MH_TRY(enqueue_chunk());
+        spins = 0;
+        continue;
+      }
+      __builtin_ia32_pause();
+      if (++spins > (1u << 22)) {  // ~ tens of milliseconds without progress: is the stream still alive?
+        spins = 0;
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q != hipSuccess && q != hipErrorNotReady) return fail(MH_ERR_HIP, "device ICP loop: %s", hipGetErrorString(q));
+        if (q == hipSuccess && !(*prog >> 31) && enqueued >= p->max_iterations)
+          return fail(MH_ERR_INTERNAL, "device ICP loop did not terminate after max_iterations");
+      }
+    }
+    skip_tail = false;
+    chunk = 0;  // the tail alone: covariance (now live: the loop has ended) + state read-back
+    MH_TRY(enqueue_tail());
+    return poll();
+  }
+
+  mh_status enqueue_tail() {
+    MH_TRY(set_device(ctx));
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t)scan->n;
+    double* part = ctx->partials.as<double>();
+    double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
+    const SolveK* dsk = &ctx->d_params->sk;
+    if (p->compute_covariance) {
+      hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, dsk, 0u);
+      hipLaunchKernelGGL(k_cov_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, scan->x, scan->y, scan->z, n,
+                         ctx->pair_gidx.as<uint32_t>(), part, nb);
+      if (pl)
+        hipLaunchKernelGGL(k_cov_accum_plbuf, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, scan->x, scan->y, scan->z, n,
+                           ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
+      hipLaunchKernelGGL(k_cov_finalize, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, 0u, part, nb, nb,
+                         (const double*)partb, pl ? nb : 0u, pl ? nb : 0u);
+    }
+    MH_HIP(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpDeviceState), hipMemcpyDeviceToHost, s));
+    MH_HIP(hipGetLastError());
     MH_HIP(hipEventRecord(ctx->ev_poll, s));
     return MH_OK;
   }
@@ -2809,6 +3084,7 @@ mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_icp_para
   MH_REQUIRE(!final_pairs || pairs_mem == MH_MEM_HOST || pairs_mem == MH_MEM_DEVICE, "bad mem space");
   AlignJob job;
   MH_TRY(job.start(map, scan, params, T_guess, prior, result, trace));
+  if (job.streaming && !job.finished) MH_TRY(job.run_streaming());
   while (!job.finished) {
     MH_TRY(job.enqueue_chunk());
     MH_TRY(job.poll());
@@ -3221,6 +3497,40 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         }
       }
     }
+#ifdef MH_DEBUG_FLOOR
+    if (g_floor_host.run_reps && g_floor_host.script && groups[0].kind == K_QUAD && groups[0].jobs.size() <= g_floor_host.jobs) {
+      // tools/match_floor.py: replay the captured access pattern on the group's own descriptors, back to back
+      Group& g = groups[0];
+      hipStream_t s = g.lead->stream;
+      hipEvent_t e0, e1;
+      MH_HIP(hipEventCreate(&e0));
+      MH_HIP(hipEventCreate(&e1));
+      const uint32_t A = (uint32_t)g.jobs.size();
+      for (int w = 0; w < 3; w++) hipLaunchKernelGGL(k_match_floor_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj, g_floor_host.flags);
+      MH_HIP(hipEventRecord(e0, s));
+      for (uint32_t r = 0; r < g_floor_host.run_reps; r++) hipLaunchKernelGGL(k_match_floor_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj, g_floor_host.flags);
+      MH_HIP(hipEventRecord(e1, s));
+      MH_HIP(hipEventSynchronize(e1));
+      float fms = 0.f;
+      MH_HIP(hipEventElapsedTime(&fms, e0, e1));
+      g_floor_host.floor_ms = fms / (double)g_floor_host.run_reps;
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      if (want_prof) {
+        uint32_t it_cap = 0;
+        (void)hipMemcpyFromSymbol(&it_cap, HIP_SYMBOL(g_floor_iter), sizeof(uint32_t));
+        double sum = 0.0;
+        float ms = 0.f;
+        for (uint32_t i = 0; i < g.prof_n; i++) {
+          MH_HIP(hipEventElapsedTime(&ms, g.lead->prof_ev[2 * i], g.lead->prof_ev[2 * i + 1]));
+          sum += ms;
+          if (i == (it_cap & 0x7FFFFFFFu)) g_floor_host.real_ms_at_iter = ms;
+        }
+        g_floor_host.real_ms_avg = g.prof_n ? sum / g.prof_n : 0.0;
+        g_floor_host.real_launches = g.prof_n;
+      }
+    }
+#endif
     if (want_prof && groups[0].jobs[0] == &jobs[0]) {  // the match step of job 0 = its share of its group's lock-step launches
       Group& g = groups[0];
       float ms = 0.f;

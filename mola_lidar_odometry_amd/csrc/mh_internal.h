@@ -154,6 +154,8 @@ struct mh_ctx {
   IcpDeviceState* h_state = nullptr;  // pinned mirror; d_state/h_state own one block [state | params]
   IcpDeviceParams* d_params = nullptr;  // per-alignment parameters (kernels take pointers into this block)
   IcpDeviceParams* h_params = nullptr;  // pinned mirror
+  uint32_t* h_progress = nullptr;  // page-locked word behind the state block: (iteration | done << 31), written by the device loop
+  uint32_t* d_progress = nullptr;  // ... its device-visible address
   hipGraphExec_t graph_exec = nullptr;  // captured chunk of ICP iterations (replayed while graph_key matches)
   unsigned long long graph_key[28] = {0};
   unsigned long long graph_candidate[28] = {0};  // key of the last direct-launched chunk: captured when a LATER alignment repeats it
@@ -245,6 +247,7 @@ namespace mh {
 // Blocking waits of the library.  With a wait hook installed on the calling thread (mh_set_wait_hook) they turn into
 // "record an event, then call the hook until the event has completed": a host layer that multiplexes several sequences
 // on ONE thread (cooperative fibers) gets control back at every point where the library would otherwise block.
+bool wait_hook_installed();  // on the calling thread
 hipError_t wait_stream(hipStream_t s);
 hipError_t wait_event(hipEvent_t e);
 mh_status set_device(const mh_ctx* ctx);

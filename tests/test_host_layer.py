@@ -306,3 +306,117 @@ def test_fiber_scheduler_round_robin_and_exceptions():
     assert order[:12] == [0, 1, 2] * 4 and order[12:] == [100] and caught == "" and switches == 12 and not outside and clean
     order, caught, _, _, clean = h.fiber_selftest(3, 3, 1)
     assert order == [0, 1, 2, 0, 2, 0, 2, 100] and caught == "fiber 1" and clean
+
+
+# ------------------------------------------------------------------------------------------ matcher generality (a7)
+_NEAR_FAR_ICP = """
+class_name: mp2p_icp::ICP
+params:
+  maxIterations: 60
+  minAbsStep_trans: 1e-4
+  minAbsStep_rot: 5e-5
+solvers:
+  - class: mp2p_icp::Solver_GaussNewton
+    params:
+      maxIterations: 2
+      robustKernel: 'RobustKernel::GemanMcClure'
+      robustKernelParam: '0.5*max(ADAPTIVE_THRESHOLD_SIGMA, 2.0*ADAPTIVE_THRESHOLD_SIGMA-(2.0*ADAPTIVE_THRESHOLD_SIGMA-0.5*ADAPTIVE_THRESHOLD_SIGMA)*ICP_ITERATION/30)'
+matchers:
+  - class: mp2p_icp::Matcher_Points_DistanceThreshold
+    params:
+      threshold: '2.0*max(ADAPTIVE_THRESHOLD_SIGMA, 2.0*ADAPTIVE_THRESHOLD_SIGMA-(2.0*ADAPTIVE_THRESHOLD_SIGMA-0.5*ADAPTIVE_THRESHOLD_SIGMA)*ICP_ITERATION/30)'
+      thresholdAngularDeg: 0
+      pairingsPerPoint: 1
+      allowMatchAlreadyMatchedGlobalPoints: true
+      runFromIteration: 4
+      runUpToIteration: 0
+      pointLayerMatches:
+        - {global: "localmap_far", local: "decimated_for_icp_far", weight: 1.0}
+  - class: mp2p_icp::Matcher_Points_DistanceThreshold
+    params:
+      threshold: '2.00*ADAPTIVE_THRESHOLD_SIGMA'
+      thresholdAngularDeg: 0
+      pairingsPerPoint: 1
+      allowMatchAlreadyMatchedGlobalPoints: true
+      runFromIteration: 0
+      runUpToIteration: %d
+      pointLayerMatches:
+        - {global: "localmap_near", local: "decimated_for_icp_near", weight: 1.0}
+        - {global: "localmap_far", local: "decimated_for_icp_near", weight: 1.0}
+quality:
+  - class: mp2p_icp::QualityEvaluator_PairedRatio
+    params:
+      ~
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("up_to", [0, 9])
+def test_gated_matchers_on_several_layers_match_an_oracle_loop(hl, oracle, small_workload, up_to):
+    """The ICP block shape of the reference's pipelines/extras/lidar3d-near-far.yaml:150-199 (two point matchers, an iteration
+    gate `runFromIteration: 4`, two pointLayerMatches entries on the second one; here also a `runUpToIteration`) is NOT one of
+    the fused shapes: it runs matcher by matcher on the device (mh_nn_search per layer pair, mh_gn_solve per iteration -- the
+    path the adapter's Matcher_*_HIP / Solver_GaussNewton_HIP classes take on a real stack).  Checked against the same loop
+    written with the oracle's matcher and solver."""
+    w = small_workload
+    sigma = 1.2
+    scan = w.scan_xyz
+    rng = np.linalg.norm(scan, axis=1)
+    near_l, far_l = scan[rng < 9.0], scan[rng >= 6.0]           # overlapping on purpose
+    T0 = w.T_gt.reshape(3, 4)
+    mp = w.map_xyz
+    mr = np.linalg.norm(mp - T0[:, 3], axis=1)
+    near_g, far_g = mp[mr < 12.0], mp[::2]
+    g = hl.metric_map_t()
+    for name, pts, vs in (("localmap_near", near_g, 0.5), ("localmap_far", far_g, 1.0)):
+        hv = hl.HashedVoxelPointCloud(vs, 20)
+        hv.setPoints(pts)
+        g.set_layer(name, hv)
+    l = hl.metric_map_t()
+    l.set_layer("decimated_for_icp_near", hl.PointCloud(near_l))
+    l.set_layer("decimated_for_icp_far", hl.PointCloud(far_l))
+    icp, params = hl.icp_pipeline_from_yaml(hl.Config.FromYamlText(_NEAR_FAR_ICP % up_to))
+    src = hl.ParameterSource()
+    src.updateVariable("ADAPTIVE_THRESHOLD_SIGMA", sigma)
+    src.updateVariable("ICP_ITERATION", 0)
+    icp.attachToParameterSource(src)
+    src.realize()
+    res = icp.align(l, g, hl.TPose3D(*w.guess_ypr), params)
+    assert not icp.lastAlignUsedFusedPath()
+
+    # the same loop on the oracle
+    maps = {"localmap_near": oracle.Map(0.5, 20).insert(near_g), "localmap_far": oracle.Map(1.0, 20).insert(far_g)}
+    locs = {"decimated_for_icp_near": near_l, "decimated_for_icp_far": far_l}
+    base = lambda k: max(sigma, 2.0 * sigma - (2.0 * sigma - 0.5 * sigma) * k / 30.0)  # noqa: E731
+    matchers = [dict(thr=lambda k: 2.0 * base(k), run_from=4, up_to=0, layers=[("localmap_far", "decimated_for_icp_far")]),
+                dict(thr=lambda k: 2.0 * sigma, run_from=0, up_to=up_to,
+                     layers=[("localmap_near", "decimated_for_icp_near"), ("localmap_far", "decimated_for_icp_near")])]
+    T, Tprev, term, it, n_pairs, potential = w.T_guess.copy(), w.T_guess.copy(), "MaxIterations", 0, 0, 0
+    for it in range(60):
+        lp, gp, potential = [], [], 0
+        for m in matchers:
+            if (m["run_from"] and it < m["run_from"]) or (m["up_to"] and it > m["up_to"]):
+                continue
+            for gname, lname in m["layers"]:
+                r = oracle.match_points(maps[gname], locs[lname], T, m["thr"](it))
+                lp.append(locs[lname][r["local_idx"]])
+                gp.append(r["global_xyz"] if "global_xyz" in r else np.stack([r["gx"], r["gy"], r["gz"]], 1))
+                potential += len(locs[lname])
+        n_pairs = sum(len(a) for a in lp)
+        if n_pairs == 0:
+            term = "NoPairings"
+            break
+        T = oracle.gn_solve(T, pt2pt=(np.concatenate(lp), np.concatenate(gp)),
+                            params=oracle.GNParams(max_inner_iterations=2, robust_kernel_param=0.5 * base(it)))[0]
+        d = oracle.se3_log(oracle.pose_compose(oracle.pose_inverse(Tprev), T))
+        if np.linalg.norm(d[:3]) < 1e-4 and np.linalg.norm(d[3:]) < 5e-5:
+            term = "Stalled"
+            break
+        Tprev = T.copy()
+    else:
+        it = 60
+    assert res.terminationReason.name == term
+    assert res.nIterations == it
+    np.testing.assert_allclose(res.pose(), T, atol=1e-7)
+    assert res.n_pairs() == n_pairs and res.quality == pytest.approx(n_pairs / potential, abs=1e-12)
+    assert np.abs(res.pose() - w.T_gt).max() < 0.05  # and it converged to the ground truth

@@ -272,7 +272,7 @@ def test_docs_and_tools_point_at_the_generated_files():
     assert "pipelines/make_mola_hip.py" in integ and "lidar3d-default-mola-hip.yaml" in integ and "lidar3d-ndt-mola-hip.yaml" in integ
     joined = integ.replace("\\\n", " ")  # shell line continuations
     cmds = [l for l in joined.splitlines() if l.startswith("mola-lidar-odometry-cli -l")]
-    assert len(cmds) >= 2 and all(re.search(r"-c \S*-mola-hip\.yaml", l) for l in cmds), cmds
+    assert len(cmds) >= 2 and all(re.search(r"-c \S*-mola-hip(-granular)?\.yaml", l) for l in cmds), cmds
     assert not re.search(r"mola-lidar-odometry-cli[^\n]*-c pipelines/lidar3d-(default|ndt)-hip\.yaml", joined)
     pin = open(os.path.join(ROOT, "tools", "parity_pin.py")).read()
     assert "lidar3d-default-mola-hip.yaml" in pin and "make_mola_hip" in pin

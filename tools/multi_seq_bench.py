@@ -13,11 +13,11 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (generate_inputs: the drive's sweeps cast in worker processes)
-from mola_lidar_odometry_amd import synth  # noqa: E402
+from mola_lidar_odometry_amd import synth_city  # noqa: E402
 
 
 def run(seq, n, fibers, pipeline, tmp):
-    cmd = [bench.CLI, "--pipeline", pipeline, "--out", os.path.join(tmp, "%s%d.tum" % ("f" if fibers else "t", n)), "--profile"] + (["--fibers"] if fibers else [])
+    cmd = [bench.CLI, "--pipeline", pipeline, "--out", os.path.join(tmp, "%s%d.tum" % ("f" if fibers else "t", n)), "--profile", "--time-field", "12"] + (["--fibers"] if fibers else [])
     for _ in range(n):
         cmd += ["--seq-dir", seq]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
@@ -38,9 +38,8 @@ def main():
     n_scans = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     counts = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8, 16]
     pipeline = sys.argv[3] if len(sys.argv) > 3 else bench.PIPELINE
-    _, drive = bench.generate_inputs("small", [0], n_scans)
     tmp = tempfile.mkdtemp(prefix="molahip_multi_")
-    seq = synth.write_kitti_sequence(tmp, drive)
+    seq, _ = synth_city.write_kitti_drive(tmp, n_scans, time_channel=True)  # the city drive of bench.py's extras
     out = {"pipeline": os.path.basename(pipeline), "scans_per_sequence": n_scans, "threads": {}, "fibers": {}}
     solo = None
     for mode, fib in (("threads", False), ("fibers", True)):

@@ -14,7 +14,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-from mola_lidar_odometry_amd import synth  # noqa: E402
+from mola_lidar_odometry_amd import synth_city  # noqa: E402
 
 ICP = ("k_match", "k_accum", "k_solve", "k_cov", "k_icp", "k_pairs", "k_compact")
 
@@ -101,11 +101,10 @@ def main():
     n_seq = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     out_path = sys.argv[3] if len(sys.argv) > 3 else None
     extra = sys.argv[4:]
-    _, drive = bench.generate_inputs("small", [0], n_scans)
     tmp = tempfile.mkdtemp(prefix="molahip_mtrace_")
-    seq = synth.write_kitti_sequence(tmp, drive)
+    seq, _ = synth_city.write_kitti_drive(tmp, n_scans, time_channel=True)  # the city drive of bench.py's extras
     cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, "prof"), "--", bench.CLI, "--pipeline",
-           bench.PIPELINE, "--out", os.path.join(tmp, "o.tum")] + extra
+           bench.PIPELINE, "--out", os.path.join(tmp, "o.tum"), "--time-field", "12"] + extra
     for _ in range(n_seq):
         cmd += ["--seq-dir", seq]
     env = dict(os.environ, TMPDIR="/tmp")
