@@ -887,6 +887,18 @@ def main():
                                      "issue_floor_ms": floor_ms, "frac_of_launch": floor_ms / tr["avg_launch_ms"]}
                 if tr.get("wait_frac") is not None:
                     views["wave_wait_frac"] = tr["wait_frac"]
+            fl = os.path.join(ROOT, "profiles", "r04_match_floor.json")
+            if os.path.exists(fl) and os.environ.get("MH_MATCH", "q")[:1] == "q":
+                fj = json.load(open(fl))
+                views["latency_floor"] = {
+                    "floor_ms_per_launch": fj["floor_ms_mean"], "source": "profiles/r04_match_floor.json (tools/match_floor.py)",
+                    "real_ms_per_launch_in_that_run": fj["real_ms_avg_over_launches_product_library"],
+                    "frac_of_floor_in_that_run": fj["frac_of_floor"],
+                    "note": "k_match_floor_b: the same grid, occupancy, dependent chain of loads and address generation as k_match4_b "
+                            "replayed from a recorded script with one compare per record instead of the search arithmetic; launched back "
+                            "to back on resident inputs.  frac_of_floor = floor / real: ~1 means the kernel costs what its memory-access "
+                            "schedule costs -- less arithmetic would not make it faster, only a different schedule would"}
+                roof["frac_of_floor"] = fj["floor_ms_mean"] / launch_ms if launch_ms else None
             roof["views"] = views
         out["roofline"] = roof
         out["cpu_baseline"] = cpu

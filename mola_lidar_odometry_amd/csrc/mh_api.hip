@@ -28,14 +28,20 @@ mh_status fail(mh_status s, const char* fmt, ...) {
 static thread_local mh_wait_hook_fn g_wait_hook = nullptr;
 static thread_local void* g_wait_user = nullptr;
 bool wait_hook_installed() { return g_wait_hook != nullptr; }
-static thread_local hipEvent_t g_wait_ev[16] = {nullptr};  // one marker event per device, per thread
+// marker events of the cooperative waits, per device and per thread (a free list: several fibers of a thread may wait at once)
+static thread_local hipEvent_t g_wait_pool[16][32];
+static thread_local int g_wait_pool_n[16] = {0};
 
 hipError_t wait_event(hipEvent_t e) {
   if (!g_wait_hook) return hipEventSynchronize(e);
+  int dev = -1;
+  (void)hipGetDevice(&dev);
   for (;;) {
     const hipError_t q = hipEventQuery(e);
     if (q != hipErrorNotReady) return q;
-    g_wait_hook(g_wait_user);  // (may run other fibers of this thread, which may call into the library on THEIR contexts)
+    g_wait_hook(g_wait_user);  // (may run other fibers of this thread, which may call into the library on THEIR contexts ...
+    if (dev >= 0) (void)hipSetDevice(dev);  // ... and leave another device current: the caller's allocations and copies after
+                                            // this wait must land on ITS device)
   }
 }
 
@@ -49,8 +55,8 @@ hipError_t wait_stream(hipStream_t s) {
   if (dev < 0 || dev >= 16) return hipStreamSynchronize(s);
   // the marker is per wait: another fiber of this thread may record the per-device event while this one is suspended,
   // so each wait gets an event of its own from a small free list
-  static thread_local hipEvent_t pool[16][32];
-  static thread_local int pool_n[16] = {0};
+  auto& pool = g_wait_pool;
+  auto& pool_n = g_wait_pool_n;
   hipEvent_t ev;
   if (pool_n[dev] > 0) ev = pool[dev][--pool_n[dev]];
   else {
@@ -61,7 +67,6 @@ hipError_t wait_stream(hipStream_t s) {
   if (e == hipSuccess) e = wait_event(ev);
   if (pool_n[dev] < 32) pool[dev][pool_n[dev]++] = ev;
   else (void)hipEventDestroy(ev);
-  (void)g_wait_ev;
   return e;
 }
 
@@ -106,6 +111,11 @@ extern "C" {
 mh_status mh_set_wait_hook(mh_wait_hook_fn hook, void* user) {
   mh::g_wait_hook = hook;
   mh::g_wait_user = user;
+  if (!hook) {  // the calling thread stops waiting cooperatively: its marker events go back (they were never freed before)
+    for (int d = 0; d < 16; d++) {
+      while (mh::g_wait_pool_n[d] > 0) (void)hipEventDestroy(mh::g_wait_pool[d][--mh::g_wait_pool_n[d]]);
+    }
+  }
   return MH_OK;
 }
 

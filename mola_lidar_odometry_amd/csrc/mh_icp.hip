@@ -328,8 +328,18 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
   const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
   const uint32_t i = gl >> 2, sub = gl & 3u;
   const uint32_t ic = i < n ? i : n - 1;
-  const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
   const uint32_t o = perm ? G(perm)[ic] : ic;  // (clamped: lanes past the end of a short job of a batch read, and never write)
+#if defined(MH_CARRY_WINNER) || !defined(MH_NARROW_IO) || !defined(MH_NARROW_XYZ)
+  // (the three coordinate loads stay as they are: one load of "coordinate `sub`" through a lane-dependent base pointer
+  // costs the batch kernel 32 bytes of scratch per lane -- MH_NARROW_XYZ keeps the variant for A/B runs)
+  const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
+#else
+  // lane s reads coordinate s of the point (lane 3: z again); quad_perm moves hand them round
+  const float* cbase = sub == 0u ? lx : (sub == 1u ? ly : lz);
+  const float cmine = G(cbase)[ic];
+  const float x = __uint_as_float(quad_bcast<0>(__float_as_uint(cmine))), y = __uint_as_float(quad_bcast<1>(__float_as_uint(cmine))),
+              z = __uint_as_float(quad_bcast<2>(__float_as_uint(cmine)));
+#endif
   // the state block through the scalar path (uniform address, not written during this kernel): the pose in SGPRs
   typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
   const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
@@ -339,7 +349,17 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
   // without one (the buffer may hold another scan's pairings).
   const bool have_prev = cst->iter > 0 && !map.no_prev_bound;
   f32x4 prev = (f32x4){0.f, 0.f, 0.f, __builtin_inff()};
+#if defined(MH_CARRY_WINNER) || !defined(MH_NARROW_IO)
   if (have_prev) prev = G(reinterpret_cast<const f32x4*>(pair_q))[o];  // grid-uniform branch
+#else
+  // (-DMH_NARROW_IO, measured SLOWER and off: a dword per lane instead of the same 16 bytes in all four lanes of a quad, see
+  // nn_search_quad<NARROW>: lane s reads word s of the previous pairing; quad_perm moves hand the four words round)
+  if (have_prev) {  // grid-uniform branch
+    const uint32_t pw = __float_as_uint(G(reinterpret_cast<const float*>(pair_q))[4ull * o + sub]);
+    prev = (f32x4){__uint_as_float(quad_bcast<0>(pw)), __uint_as_float(quad_bcast<1>(pw)), __uint_as_float(quad_bcast<2>(pw)),
+                   __uint_as_float(quad_bcast<3>(pw))};
+  }
+#endif
   double T[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) T[k] = cst->T[k];
@@ -353,6 +373,7 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
     const float dx = prev.x - px, dy = prev.y - py, dz = prev.z - pz;
     bound0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic of nn_scan_round_quad
   }
+#if defined(MH_CARRY_WINNER) || !defined(MH_NARROW_IO)
 #ifdef MH_DEBUG_FLOOR
   const NNResult r = nn_search_quad(map, sub, px, py, pz, bound0, (floor_cap && cst->iter == floor_iter) ? floor_cap + 2ull * i : nullptr,
                                     floor_more ? floor_more + 4ull * i : nullptr);
@@ -369,6 +390,21 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
     G(reinterpret_cast<f32x4*>(pair_q))[o] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
     G(pair_gidx)[o] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
   }
+#else
+#ifdef MH_DEBUG_FLOOR
+  const NNResult r = nn_search_quad<true>(map, sub, px, py, pz, bound0, (floor_cap && cst->iter == floor_iter) ? floor_cap + 2ull * i : nullptr,
+                                          floor_more ? floor_more + 4ull * i : nullptr);
+#else
+  const NNResult r = nn_search_quad<true>(map, sub, px, py, pz, bound0);
+#endif
+  // the pairing {x, y, z, d2} | source index, a dword per lane: lanes 0..2 hold the winner's coordinates, lane 3 its source
+  // index (r.pt.x, component `sub` of the record); nothing found: {0, 0, 0, inf} | none -- what the 16-byte store wrote
+  const float n2 = (px * px + py * py) + pz * pz;
+  const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
+  const float comp = r.found ? r.pt.x : 0.f;
+  G(reinterpret_cast<float*>(pair_q))[4ull * o + sub] = sub == 3u ? r.d2 : comp;
+  if (sub == 3u) G(pair_gidx)[o] = ok ? __float_as_uint(comp) : kNoMatch;
+#endif
 }
 
 // ================================================================================================
@@ -1814,7 +1850,8 @@ struct FloorHost {
 } g_floor_host;
 
 // what-if switches of the replay (tools/match_floor.py --what-if): which load costs what?
-enum { FLOOR_NO_WINNER_FETCH = 1, FLOOR_NO_PREV = 2, FLOOR_NO_TRANSFORM = 4, FLOOR_NO_OUTPUT = 8, FLOOR_RECORDS_12B = 16, FLOOR_HALF_RECORDS = 32 };
+enum { FLOOR_NO_WINNER_FETCH = 1, FLOOR_NO_PREV = 2, FLOOR_NO_TRANSFORM = 4, FLOOR_NO_OUTPUT = 8, FLOOR_RECORDS_12B = 16, FLOOR_HALF_RECORDS = 32,
+       FLOOR_NARROW_IO = 64 /* the -DMH_NARROW_IO schedule: previous pairing / winner / pairing a dword per lane instead of 16 bytes */ };
 
 __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_floor_b(const BatchJob* __restrict__ jobs, uint32_t flags) {
   const BatchJob& j = jobs[blockIdx.y];
@@ -1826,7 +1863,15 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_floor_b(const B
   typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
   const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(j.st);
   f32x4 prev = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (!(flags & FLOOR_NO_PREV)) prev = G(reinterpret_cast<const f32x4*>(j.pair_q))[ic];
+  if (!(flags & FLOOR_NO_PREV)) {
+    if (!(flags & FLOOR_NARROW_IO)) {
+      prev = G(reinterpret_cast<const f32x4*>(j.pair_q))[ic];
+    } else {  // a dword per lane, handed round the quad
+      const uint32_t pw = __float_as_uint(G(reinterpret_cast<const float*>(j.pair_q))[4ull * ic + sub]);
+      prev = (f32x4){__uint_as_float(quad_bcast<0>(pw)), __uint_as_float(quad_bcast<1>(pw)), __uint_as_float(quad_bcast<2>(pw)),
+                     __uint_as_float(quad_bcast<3>(pw))};
+    }
+  }
   const size_t pi = (size_t)blockIdx.y * g_floor_stride + ic;
   const uint32_t w_idx = G(g_floor_script)[2 * pi], head = G(g_floor_script)[2 * pi + 1];
   double T[12];
@@ -1900,14 +1945,26 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_floor_b(const B
     o = quad_u32<0x4E>(acc);
     acc = o < acc ? o : acc;
   }
-  f32x4 rec = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (!(flags & FLOOR_NO_WINNER_FETCH) && w_idx != 0xFFFFFFFFu) rec = pts4[w_idx + (acc == 0xFFFFFFFEu)];  // the winner's record: waits for the last scan
-  if (sub == 0 && !(flags & FLOOR_NO_OUTPUT)) {
-    const size_t o = (size_t)blockIdx.y * g_floor_stride + i;
-    G(reinterpret_cast<f32x4*>(g_floor_out_q))[o] = (f32x4){rec.x, rec.y, rec.z, __uint_as_float(acc ^ dep0)};
-    G(g_floor_out_g)[o] = __float_as_uint(rec.w);
-  } else if (acc == 0xFFFFFFFEu) {
-    G(g_floor_out_g)[0] = acc;  // (keeps the chain alive when the output is switched off)
+  const size_t o = (size_t)blockIdx.y * g_floor_stride + i;
+  if (!(flags & FLOOR_NARROW_IO)) {
+    f32x4 rec = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!(flags & FLOOR_NO_WINNER_FETCH) && w_idx != 0xFFFFFFFFu) rec = pts4[w_idx + (acc == 0xFFFFFFFEu)];  // the winner's record: waits for the last scan
+    if (sub == 0 && !(flags & FLOOR_NO_OUTPUT)) {
+      G(reinterpret_cast<f32x4*>(g_floor_out_q))[o] = (f32x4){rec.x, rec.y, rec.z, __uint_as_float(acc ^ dep0)};
+      G(g_floor_out_g)[o] = __float_as_uint(rec.w);
+    } else if (acc == 0xFFFFFFFEu) {
+      G(g_floor_out_g)[0] = acc;  // (keeps the chain alive when the output is switched off)
+    }
+  } else {  // component `sub` of the winner per lane, the pairing written a dword per lane
+    float comp = 0.f;
+    if (!(flags & FLOOR_NO_WINNER_FETCH) && w_idx != 0xFFFFFFFFu)
+      comp = reinterpret_cast<const float MH_AS_GLOBAL*>(pts4)[4ull * (w_idx + (acc == 0xFFFFFFFEu)) + sub];
+    if (!(flags & FLOOR_NO_OUTPUT)) {
+      G(reinterpret_cast<float*>(g_floor_out_q))[4ull * o + sub] = sub == 3u ? __uint_as_float(acc ^ dep0) : comp;
+      if (sub == 3u) G(g_floor_out_g)[o] = __float_as_uint(comp);
+    } else if (acc == 0xFFFFFFFEu || __float_as_uint(comp) == 0xFFFFFFFEu) {
+      G(g_floor_out_g)[0] = acc;
+    }
   }
 }
 

@@ -668,6 +668,19 @@ mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const floa
   const size_t n_rec_ub = n + (ndt ? 2 * n_vox_ub : 0);
   uint64_t tsize = 64;
   while (tsize < 2ull * n_vox_ub) tsize <<= 1;
+  // The prologue empties the slot table before the remaining buffers are reserved (their sizes are only bounds).  Should one of
+  // those reserves fail (out of memory), the map must not be left describing its OLD content over an EMPTY table -- later
+  // alignments would silently find no pairings in a map that claims a million points: it reads as empty instead.
+  struct EmptyOnError {
+    mh_map* m;
+    bool ok = false;
+    ~EmptyOnError() {
+      if (ok) return;
+      m->n_points = m->n_voxels = m->n_records = m->n_planes = 0;
+      m->counts_pending = false;
+      m->build_in_flight = false;
+    }
+  } guard{m};
   // (`collected`: mh_map_insert has run the prologue and its fused kernel has written the points, keys and indices)
   if (!collected) MH_TRY(map_build_prologue(m, s, n, n_stored, nullptr, nullptr, nullptr));
   uint32_t* vstart = m->build_e.as<uint32_t>();
@@ -768,6 +781,7 @@ mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const floa
   m->n_points = n;
   m->n_voxels = n_vox_ub;
   m->n_records = n_rec_ub;
+  guard.ok = true;
   return MH_OK;
 }
 

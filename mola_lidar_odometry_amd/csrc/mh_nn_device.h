@@ -505,6 +505,15 @@ __device__ __forceinline__ uint32_t quad_bound_mask(const QuadBounds& q, uint32_
 #define MH_FLOOR_ARG
 #define MH_FLOOR_BATCH(c_mine_) do { } while (0)
 #endif
+// NARROW (k_match4 built with -DMH_NARROW_IO; round-4 experiment, OFF): the winner's record is fetched ONE DWORD PER LANE --
+// lane s of the quad gets component s (x, y, z, source index) in r.pt.x -- instead of the same 16 bytes in all four lanes, and
+// the caller reads the previous pairing and writes the new one the same way.  tools/match_floor.py's what-if runs had priced
+// the three 16-byte-per-lane accesses around the search at 8.5 % (previous pairing in), 2.5 % (winner's record) and 10 %
+// (pairing out) of the launch; narrowing them does not recover that: 0.266-0.277 ms per launch against 0.259 (bit-identical,
+// 4370-4540 scans/s against 4590-4620; the replay kernel says the same, 0.2735 against 0.2605 ms) -- what those accesses
+// cost is their place in the dependent chain (the first thing a wave waits for, the last thing it has to retire), not their
+// width, and the narrow form adds quad_perm moves and 24 bytes of scratch.  profiles/r04_match_kernel.md.
+template <bool NARROW = false>
 __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t sub, float qx, float qy, float qz,
                                                    float bound0 = __builtin_inff() MH_FLOOR_ARG) {
   NNResult r;
@@ -647,7 +656,8 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
   return r;
 #else
   if (nnkey_idx(best) != 0xFFFFFFFFu) {
-    r.pt = pts4[nnkey_idx(best)];
+    if (NARROW) r.pt.x = reinterpret_cast<const float MH_AS_GLOBAL*>(pts4)[4ull * nnkey_idx(best) + sub];
+    else r.pt = pts4[nnkey_idx(best)];
     r.d2 = nnkey_d2(best);
     r.found = true;
   }

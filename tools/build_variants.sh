@@ -13,8 +13,14 @@ build() {  # name flags...
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-function --offload-arch=gfx950 -I../../include "$@" -c mh_icp.hip -o $dir/mh_icp.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $REPO/tools/variants/libmolahip_$name.so $dir/*.o
 }
-build carry4 -DMH_CARRY_WINNER &
-build carry3 -DMH_CARRY_WINNER -DMH_QUAD_W=3 &
-build carry4w7 -DMH_CARRY_WINNER -DMH_QUAD_WAVES=7 &
+# round 4: dword-per-lane I/O around the quad search against the product's 16-byte-per-lane reads / write (all measured slower)
+build narrow4 -DMH_NARROW_IO &                                  # previous pairing, winner's record and pairing a dword per lane
+build narrow3 -DMH_NARROW_IO -DMH_QUAD_W=3 &                    # ... with three records in flight per lane (no scratch)
+build narrow4xyz -DMH_NARROW_IO -DMH_NARROW_XYZ &               # ... plus one coordinate load per lane through a lane-dependent base pointer
+if [ -n "$WITH_CARRY" ]; then                # the winner's record carried in registers (measured slower: profiles/r04_match_kernel.md)
+  build carry4 -DMH_CARRY_WINNER &
+  build carry3 -DMH_CARRY_WINNER -DMH_QUAD_W=3 &
+  build carry4w7 -DMH_CARRY_WINNER -DMH_QUAD_WAVES=7 &
+fi
 wait
 ls -la $REPO/tools/variants

@@ -32,8 +32,10 @@ if not REAL_ONLY:
     capi.LIB_PATH = os.path.join(ROOT, "tools", "libmolahip_floor.so")
 import bench  # noqa: E402  (generate_inputs: the headline workload's 32 draws)
 
-WHAT_IF = {"as_is": 0, "no_winner_fetch": 1, "no_previous_pairing_read": 2, "no_fp64_transform": 4, "no_pairing_write": 8,
-           "records_read_as_12_bytes": 16, "half_the_records": 32, "no_winner_fetch_no_prev": 3}
+# (a "no transform" switch exists in the kernel but is no what-if: un-transformed points probe other, mostly empty voxels)
+WHAT_IF = {"as_is": 0, "no_winner_fetch": 1, "no_previous_pairing_read": 2, "no_pairing_write": 8, "records_read_as_12_bytes": 16,
+           "half_the_records": 32, "narrow_io_dword_per_lane": 64, "narrow_io_no_previous_pairing_read": 64 | 2,
+           "narrow_io_no_pairing_write": 64 | 8, "narrow_io_no_winner_fetch": 64 | 1}
 
 
 def setup(S, ws):
