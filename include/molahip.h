@@ -326,6 +326,11 @@ typedef struct {
  * switch until the reference decides it: the point-to-plane distance |n.(p'-c)| (default) or the distance to the
  * plane's centroid |p'-c| (fp32 squares, un-fused).  The search for the nearest planar voxel is the same. */
 enum { MH_PT2PL_PLANE_DISTANCE = 0, MH_PT2PL_CENTROID_DISTANCE = 1 };
+/* Matcher_Points_Base::allowMatchAlreadyMatchedPoints [U] (default false upstream, not set by either target pipeline): a
+ * matcher skips the local points an earlier matcher of the same iteration has paired.  In lidar3d-ndt.yaml:195-210 that keeps
+ * plane-paired points out of Matcher_Points_DistanceThreshold.  Unverified (U12), hence a switch; PAIR_AGAIN is what rounds
+ * 1-3 did and stays the default until the reference decides (MOLA_HIP_MATCHED_POINTS=skip|again in the host layers). */
+enum { MH_MATCHED_POINTS_PAIR_AGAIN = 0, MH_MATCHED_POINTS_SKIP = 1 };
 
 MH_API mh_status mh_nn_search_pt2pl(const mh_map* map, const mh_scan* scan, const double T[12], double distance_threshold,
                                     uint32_t mode, const mh_pairs_pl_out* out, int32_t mem, mh_match_info* info);
@@ -422,6 +427,8 @@ typedef struct {
   uint32_t expected_iterations; /* with poll_every = 0: the caller's own estimate of how many iterations this call will
                                    run (e.g. what its previous call of the same kind ran), 0 = let the library predict */
   uint32_t pt2pl_mode;          /* MH_PT2PL_* : the acceptance test of the point-to-plane matcher (with pt2pl_threshold) */
+  uint32_t matched_points;      /* MH_MATCHED_POINTS_* : what the point matcher does with local points that the point-to-plane
+                                   matcher of the same iteration has paired (with pt2pt_threshold) */
   uint32_t profile;             /* 1: time every match kernel with HIP events on the context stream (such a job is
                                    enqueued kernel by kernel instead of replaying the captured graph); 2: in
                                    mh_icp_align_batch, do that for job 0 only (lock step: its share of the launches) */

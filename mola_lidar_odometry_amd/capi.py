@@ -96,6 +96,7 @@ class ICPParamsC(C.Structure):
                 ("hook_min_trans", C.c_double), ("hook_min_rot", C.c_double), ("hook_checkpoint", C.c_double * 12),
                 ("compute_covariance", C.c_uint32), ("cov_findif_xyz", C.c_double), ("cov_findif_ang", C.c_double),
                 ("poll_every", C.c_uint32), ("expected_iterations", C.c_uint32), ("pt2pl_mode", C.c_uint32),
+                ("matched_points", C.c_uint32),
                 ("profile", C.c_uint32)]
 
 
@@ -594,6 +595,7 @@ class ICPParams:
     threshold_angular_deg: float = 0.0
     pt2pl_threshold: object = None  # None, or per-iteration Matcher_Point2Plane.distanceThreshold (needs an NDT map)
     pt2pl_mode: int = 0             # PT2PL_PLANE_DISTANCE | PT2PL_CENTROID_DISTANCE
+    matched_points: int = 0         # 0 = the point matcher pairs plane-paired points again, 1 = it skips them (U12)
     gn: GNParams = field(default_factory=GNParams)
     hook_enabled: bool = False
     hook_min_trans: float = 0.15
@@ -632,6 +634,7 @@ class ICPParams:
         cp.cov_findif_ang = self.cov_findif_ang
         cp.poll_every = self.poll_every
         cp.pt2pl_mode = int(self.pt2pl_mode)
+        cp.matched_points = int(self.matched_points)
         cp.expected_iterations = self.expected_iterations
         cp.profile = int(self.profile)  # 0 | 1 (all jobs) | 2 (job 0 of a batch only)
         return cp, (thr, kp, plt)

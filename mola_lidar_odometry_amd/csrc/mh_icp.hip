@@ -74,7 +74,7 @@ struct MatchK {
   double w_pt2pt;
   double kparam_fixed;   // solver-granular path: fixed robust-kernel parameter
   uint32_t use_fixed;
-  uint32_t pad;
+  uint32_t skip_pl_paired;  // MH_MATCHED_POINTS_SKIP: a point with a point-to-plane pairing gets no point pairing (U12)
   const double* pl_thr;  // [max_iterations] device: Matcher_Point2Plane.distanceThreshold per iteration (or null)
   double w_pt2pl;
 };
@@ -814,20 +814,21 @@ __device__ __forceinline__ void k_match16_body(const IcpDeviceState* __restrict_
     }
     const NNResult r = nn_search_row16(map, r16, px, py, pz, bound0);
     const float n2 = (px * px + py * py) + pz * pz;
-    const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
-    if (r16 == 0) {
-      G(reinterpret_cast<f32x4*>(pair_q))[i] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
-      G(pair_gidx)[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
-    }
-    if (FUSED && r16 == 0) acc_pt2pt_masked(a, T, ok, x, y, z, r.pt.x, r.pt.y, r.pt.z, kernel, kparam, wpair);
-    if (PL) {
+    bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
+    if (PL) {  // Matcher_Point2Plane runs first in the reference's order; its verdict may keep the point out of the point matcher
       f32x4 bc, bn;
       const bool okp = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
       if (r16 == 0) {
         G(reinterpret_cast<f32x4*>(pl_c))[i] = (f32x4){bc.x, bc.y, bc.z, okp ? 1.f : 0.f};
         G(reinterpret_cast<f32x4*>(pl_n))[i] = (f32x4){bn.x, bn.y, bn.z, 0.f};
       }
+      if (okp && ck->skip_pl_paired) ok = false;  // (the nearest point still goes to pair_q: it bounds the next search)
     }
+    if (r16 == 0) {
+      G(reinterpret_cast<f32x4*>(pair_q))[i] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
+      G(pair_gidx)[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+    }
+    if (FUSED && r16 == 0) acc_pt2pt_masked(a, T, ok, x, y, z, r.pt.x, r.pt.y, r.pt.z, kernel, kparam, wpair);
   }
   if (FUSED) {  // 16 row leaders per workgroup -> one partial per sum, fixed order
     if (r16 == 0) {
@@ -2669,6 +2670,7 @@ struct AlignJob {
     mk.w_pt2pt = p->gn.weight_pt2pt;
     mk.w_pt2pl = p->gn.weight_pt2pl;
     mk.pl_thr = pl ? ctx->sched.as<double>() + 2 * mi : nullptr;
+    mk.skip_pl_paired = (pl && p->matched_points == MH_MATCHED_POINTS_SKIP) ? 1u : 0u;
     memset(&sk, 0, sizeof(sk));
     sk.max_iterations = p->max_iterations;
     sk.disable_stall = p->disable_stall_test;
@@ -2727,6 +2729,9 @@ struct AlignJob {
       if (e && e[0] == 'p') variant = 0;
       if (e && e[0] == 'x') variant = 1;
       if (variant == 1 && map->view().ndt) variant = 0;  // "x" walks contiguous z-runs; NDT maps interleave statistics records
+      // MH_MATCHED_POINTS_SKIP (U12): the point matcher has to know the plane matcher's verdict for the same point -- the row
+      // kernel runs both in one launch (k_match16<true>), whatever the layer's size
+      if (pl && p->matched_points == MH_MATCHED_POINTS_SKIP) variant = 5;
       //   MH_PERSIST=1   (opt-in, measured slower: profiles/r03_persist_kernel.md) layers up to 2 k points without
       //                  Matcher_Point2Plane: the whole alignment in one workgroup and one launch -> k_icp_persist
       if (!e && scan->n <= kPersistMaxPoints && !pl && !prof && getenv("MH_PERSIST") != nullptr)
@@ -3127,6 +3132,7 @@ mh_status check_align_args(const mh_map* map, const mh_scan* scan, const mh_icp_
   MH_REQUIRE(p->gn.max_inner_iterations >= 1, "gn.max_inner_iterations must be >= 1");
   MH_REQUIRE(p->gn.robust_kernel <= MH_KERNEL_GM_C2, "unknown robust kernel");
   MH_REQUIRE(p->max_iterations < (1u << 20), "max_iterations too large");
+  MH_REQUIRE(p->matched_points <= MH_MATCHED_POINTS_SKIP, "unknown matched_points mode");
   return MH_OK;
 }
 
@@ -3459,6 +3465,11 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
                          reinterpret_cast<const uint32_t*>(lead->batch_desc.as<char>() + A * sizeof(BatchJob)),
                          (uint32_t)(kBlockBytes / 4));
     }
+    // (Round 4 also built the streaming control of AlignJob::run_streaming for a whole lock-step group -- every job publishing in
+    // its own progress word, the host following the slowest job still running -- and measured it on 4 / 8 / 16 sequences in one
+    // process: 4073 / 4904 / 6597 scans/s against 4040 / 5255 / 6560 with the chunks below, NDT pipeline 4475 / 4963 / 5120
+    // against 4186 / 5120 / 5245.  The spinning leader thread takes a core from the seven threads that queue uploads, filters
+    // and map updates beside it, and a group's tail is amortised over its jobs anyway.  Removed; single alignments keep it.)
     for (;;) {
       bool any = false;
       uint32_t m_of[64] = {0};

@@ -38,6 +38,8 @@
 //   MOLA_HIP_COV_STEP_XYZ / MOLA_HIP_COV_STEP_ANG   finite-difference steps of mp2p_icp::covariance, 1e-7        (U7)
 //   MOLA_HIP_MIN_DELTA / MOLA_HIP_MAX_COST          Gauss-Newton early exits, 1e-7 / 0                           (U8)
 //   MOLA_HIP_PT2PL_MODE      plane (default: |n.(p-c)| < distanceThreshold) | centroid (|p-c| < distanceThreshold) (U10)
+//   MOLA_HIP_MATCHED_POINTS  again (default: both matchers of the NDT pipeline pair every point) | skip (points paired by
+//                            Matcher_Point2Plane are left out of the point matcher: allowMatchAlreadyMatchedPoints = false) (U12)
 //   MOLA_HIP_FORCE_CPU=1     every call goes to the upstream loop (sanity A/A through the same plugin)
 //   MOLA_HIP_DEVICE=n        the GPU this process uses (default 0): eval/cli_kitti.sh:23-36 runs one process per sequence,
 //                            `parallel -j8 MOLA_HIP_DEVICE='{= $_ = slot() - 1 =}' ...` spreads them over a node's GPUs
@@ -173,6 +175,8 @@ class ICP_HIP : public ICP
         ip.kernel_param          = kp.data();
         ip.pt2pl_threshold       = sh.pl ? thr_pl.data() : nullptr;
         ip.pt2pl_mode            = sw.pt2pl_mode;
+        // U12: upstream's matchers skip local points an earlier matcher paired unless allowMatchAlreadyMatchedPoints [U] is set
+        ip.matched_points        = (sh.pl && !sh.pt->allowMatchAlreadyMatchedPoints_) ? sw.matched_points : static_cast<uint32_t>(MH_MATCHED_POINTS_PAIR_AGAIN);
         ip.threshold_angular_deg = sh.pt->thresholdAngularDeg;
         ip.gn.max_inner_iterations = sh.gn->maxIterations;
         // RobustKernel [U]: None / GemanMcClure / Cauchy by NAME (the numeric values of the upstream enum are not relied on)

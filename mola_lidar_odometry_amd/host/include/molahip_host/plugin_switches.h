@@ -31,6 +31,7 @@ struct PluginSwitches {
   double min_delta = 1e-7, max_cost = 0.0;
   uint32_t pt2pl_mode = MH_PT2PL_PLANE_DISTANCE;
   uint32_t far_voxel_metric = MH_FAR_CHEBYSHEV;
+  uint32_t matched_points = MH_MATCHED_POINTS_PAIR_AGAIN;  // MOLA_HIP_MATCHED_POINTS = again | skip (U12)
   bool force_cpu = false;
   // which of them came from the environment (the mirror classes only override their YAML values for those)
   bool has_gm_form = false, has_index_mode = false, has_cov_step = false, has_min_delta = false, has_max_cost = false,
@@ -81,6 +82,8 @@ inline PluginSwitches read_plugin_switches() {
     s.has_far_metric = true;
     s.far_voxel_metric = !strcmp(e, "l1") ? MH_FAR_L1 : !strcmp(e, "l2") ? MH_FAR_L2 : MH_FAR_CHEBYSHEV;
   }
+  if (const char* e = getenv("MOLA_HIP_MATCHED_POINTS"))
+    s.matched_points = (!strcmp(e, "skip") || !strcmp(e, "1")) ? MH_MATCHED_POINTS_SKIP : MH_MATCHED_POINTS_PAIR_AGAIN;
   if (const char* e = getenv("MOLA_HIP_FORCE_CPU")) s.force_cpu = atoi(e) != 0;
   return s;
 }
@@ -123,6 +126,7 @@ inline void apply_switches(mh_icp_params& ip, const PluginSwitches& sw) {
   if (sw.has_min_delta) ip.gn.min_delta = sw.min_delta;
   if (sw.has_max_cost) ip.gn.max_cost = sw.max_cost;
   if (sw.has_pt2pl_mode) ip.pt2pl_mode = sw.pt2pl_mode;
+  ip.matched_points = sw.matched_points;
   if (sw.has_gm_form && ip.gn.robust_kernel == MH_KERNEL_GM_C4) ip.gn.robust_kernel = sw.gm_form;
 }
 

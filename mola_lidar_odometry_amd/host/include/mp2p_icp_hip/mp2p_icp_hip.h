@@ -256,6 +256,9 @@ struct Pairings {  // mp2p_icp::Pairings::paired_pt2pt as SoA (+ pt2pl)
   // point-to-plane: local point, plane centroid, plane normal
   std::vector<float> pl_lx, pl_ly, pl_lz, pl_cx, pl_cy, pl_cz, pl_nx, pl_ny, pl_nz;
   size_t potential_pairings = 0;
+  // role of MatchState::localPairedBitField [U]: per local layer, which points the matchers of THIS iteration have paired so
+  // far -- read by later matchers when MOLA_HIP_MATCHED_POINTS=skip (allowMatchAlreadyMatchedPoints = false upstream, U12)
+  std::map<std::string, std::vector<uint8_t>> local_paired;
   bool empty() const { return localIdx.empty() && pl_lx.empty(); }
   size_t size() const { return localIdx.size() + pl_lx.size(); }
 };

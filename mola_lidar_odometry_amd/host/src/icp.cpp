@@ -349,7 +349,13 @@ void Matcher_Points_DistanceThreshold::impl_match(const metric_map_t& pcGlobal, 
     const mh_status st = mh_nn_search(glob.handle(), scan, localPose.T, threshold, thresholdAngularDeg, &po, MH_MEM_HOST, &info);
     mh_scan_destroy(scan);
     check(st, "mh_nn_search");
+    // U12 (MOLA_HIP_MATCHED_POINTS=skip): local points an earlier matcher of this iteration has paired are left out [U]
+    const bool skip_paired = molahip_host::plugin_switches().matched_points == MH_MATCHED_POINTS_SKIP;
+    auto& paired = out.local_paired[lm.local];
+    if (paired.size() < n) paired.resize(n, 0);
     for (size_t k = 0; k < info.n_pairs; k++) {
+      if (skip_paired && paired[li[k]]) continue;
+      paired[li[k]] = 1;
       out.localIdx.push_back(li[k]);
       out.globalIdx.push_back(gi[k]);
       out.lx.push_back(loc.x[li[k]]);
@@ -417,6 +423,9 @@ void Matcher_Point2Plane::impl_match(const metric_map_t& pcGlobal, const metric_
     mh_scan_destroy(scan);
     check(st, "mh_nn_search_pt2pl");
     append_pl_pairs(loc, li, a, info.n_pairs, out);
+    auto& paired = out.local_paired[lm.local];  // (what MatchState::localPairedBitField records upstream [U])
+    if (paired.size() < n) paired.resize(n, 0);
+    for (size_t k = 0; k < info.n_pairs; k++) paired[li[k]] = 1;
   }
 }
 

@@ -82,7 +82,7 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
     const auto& s = molahip_host::plugin_switches();
     py::dict d;
     d["gm_form"] = s.gm_form; d["index_mode"] = s.index_mode; d["cov_step_xyz"] = s.cov_step_xyz; d["cov_step_ang"] = s.cov_step_ang;
-    d["min_delta"] = s.min_delta; d["max_cost"] = s.max_cost; d["pt2pl_mode"] = s.pt2pl_mode;
+    d["min_delta"] = s.min_delta; d["max_cost"] = s.max_cost; d["pt2pl_mode"] = s.pt2pl_mode; d["matched_points"] = s.matched_points;
     d["far_voxel_metric"] = s.far_voxel_metric; d["force_cpu"] = s.force_cpu;
     return d;
   });

@@ -952,6 +952,17 @@ int orc_icp_align(const orc_map* m, const float* lx, const float* ly, const floa
                               &st, n_threads);
     potential += st.potential_pairings;
     res->n_candidates_total += st.n_candidates;
+    if (p->pt2pt_skip_plane_paired && nplanes) {
+      /* both index lists ascend: drop the point pairings of locals that already carry a plane pairing [U] (U12) */
+      size_t w = 0, q = 0;
+      for (size_t k = 0; k < npairs; k++) {
+        while (q < nplanes && qli[q] < li[k]) q++;
+        if (q < nplanes && qli[q] == li[k]) continue;
+        li[w] = li[k]; gi[w] = gi[k]; gx[w] = gx[k]; gy[w] = gy[k]; gz[w] = gz[k]; d2[w] = d2[k];
+        w++;
+      }
+      npairs = w;
+    }
     if (npairs + nplanes == 0) { res->termination_reason = ORC_TERM_NO_PAIRINGS; break; }
     for (size_t k = 0; k < npairs; k++) { plx[k] = lx[li[k]]; ply[k] = ly[li[k]]; plz[k] = lz[li[k]]; }
     orc_pairs_pt2pt pp = {plx, ply, plz, gx, gy, gz, npairs};

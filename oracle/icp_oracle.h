@@ -190,6 +190,12 @@ typedef struct {
   /* covariance */
   uint32_t compute_covariance;
   double cov_findif_xyz, cov_findif_ang;
+  /* Matcher_Points_Base::allowMatchAlreadyMatchedPoints [U] (added in round 4 as U12): upstream's matchers skip
+   * local points that an EARLIER matcher of the same iteration has paired unless that parameter is true (default false, and
+   * neither target pipeline sets it).  In the NDT pipeline (lidar3d-ndt.yaml:195-210: Matcher_Point2Plane, then
+   * Matcher_Points_DistanceThreshold on the same layer) that keeps plane-paired points out of the point-to-point matcher.
+   * 0 = every matcher pairs every point (rounds 1-3), 1 = points with a plane pairing get no point pairing. */
+  uint32_t pt2pt_skip_plane_paired;
 } orc_icp_params;
 
 typedef struct {

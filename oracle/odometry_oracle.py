@@ -286,7 +286,9 @@ class OdometryOracle:
                                                 robust_kernel=_KERNELS[str(self.solver.get("robustKernel", "GemanMcClure")).split("::")[-1]]),
                                  hook_enabled=opt_twist, hook_min_trans=float(P["optimize_twist_rerun_min_trans"]),
                                  hook_min_rot=math.radians(float(P["optimize_twist_rerun_min_rot_deg"])),
-                                 hook_checkpoint=T0)
+                                 hook_checkpoint=T0,
+                                 # U12 (MOLA_HIP_MATCHED_POINTS=skip): points the plane matcher paired get no point pairing
+                                 pt2pt_skip_plane_paired=os.environ.get("MOLA_HIP_MATCHED_POINTS", "again") in ("skip", "1"))
                 prior = (self.last_mm[0], self.last_mm[2]) if (has_mm and self.last_mm[2] is not None) else None
                 res = oc.icp_align(self.map, self.for_icp, T0, q, prior=prior, n_threads=self.n_threads)
                 rec["align_calls"] += 1

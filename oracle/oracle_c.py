@@ -83,7 +83,8 @@ class _ICPParams(C.Structure):
                 ("disable_stall_test", C.c_uint32), ("threshold", _DP), ("threshold_angular_deg", C.c_double),
                 ("pt2pl_threshold", _DP), ("kernel_param", _DP), ("gn", _GNParams), ("hook_enabled", C.c_uint32),
                 ("hook_min_trans", C.c_double), ("hook_min_rot", C.c_double), ("hook_checkpoint", C.c_double * 12),
-                ("compute_covariance", C.c_uint32), ("cov_findif_xyz", C.c_double), ("cov_findif_ang", C.c_double)]
+                ("compute_covariance", C.c_uint32), ("cov_findif_xyz", C.c_double), ("cov_findif_ang", C.c_double),
+                ("pt2pt_skip_plane_paired", C.c_uint32)]
 
 
 class _ICPIter(C.Structure):
@@ -425,6 +426,7 @@ class ICPParams:
     compute_covariance: bool = True
     cov_findif_xyz: float = 1e-7
     cov_findif_ang: float = 1e-7
+    pt2pt_skip_plane_paired: bool = False  # U12: points paired by Matcher_Point2Plane are skipped by the point matcher
 
 
 def icp_align(m: Map, local_xyz, T_guess, p: ICPParams, prior=None, n_threads=1, want_pairs=False):
@@ -438,6 +440,7 @@ def icp_align(m: Map, local_xyz, T_guess, p: ICPParams, prior=None, n_threads=1,
     cp.min_abs_step_trans = p.min_abs_step_trans
     cp.min_abs_step_rot = p.min_abs_step_rot
     cp.disable_stall_test = int(p.disable_stall_test)
+    cp.pt2pt_skip_plane_paired = int(p.pt2pt_skip_plane_paired)
     cp.threshold = _dp(thr)
     cp.threshold_angular_deg = p.threshold_angular_deg
     cp.kernel_param = _dp(kp)

@@ -16,7 +16,13 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o ${TAG}_bench -- python $REPO/bench.py --upload-thread 0 --no-extras $EXTRA > $OUT/${TAG}_bench_stdout.log 2>&1
 if [ -z "$SKIP_ODOM" ]; then
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/odom -o ${TAG}_odom -- env PYTHONPATH=$REPO python -m mola_lidar_odometry_amd.run_odometry --synthetic 40 --out-dir $REPO/gpurun_out/odometry > $OUT/${TAG}_odom_stdout.log 2>&1
+# the odometry driver on the first 200 scans of the synthetic city drive (the drive of bench.py's single_sequence extra)
+python -c "
+import sys; sys.path.insert(0, '$REPO')
+from mola_lidar_odometry_amd import synth_city
+print(synth_city.write_kitti_drive('$OUT/city', 200, time_channel=True)[0])" > $OUT/${TAG}_city_dir.txt
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/odom -o ${TAG}_odom -- $REPO/mola_lidar_odometry_amd/molahip-lo-cli --pipeline $REPO/pipelines/lidar3d-default-hip.yaml --seq-dir $(cat $OUT/${TAG}_city_dir.txt) --time-field 12 --profile --out $OUT/${TAG}_odom.tum > $OUT/${TAG}_odom_stdout.log 2>&1
+rm -rf $OUT/city
 fi
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
@@ -75,7 +81,7 @@ for r in rows[:10]:
     print(r['Name'][:70].ljust(70), r['Calls'].rjust(6), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(9),'us', r['Percentage'])
 print(stdout[-1][:3000] if stdout else 'no bench output')
 if glob.glob(out+'/odom/'+tag+'_*kernel_stats.csv'):
-    print('--- odometry driver, 40 synthetic scans of 120k points')
+    print('--- odometry driver, 200 scans of the synthetic city drive (~115k raw points each)')
     for r in list(csv.DictReader(open(glob.glob(out+'/odom/'+tag+'_*kernel_stats.csv')[0])))[:14]:
         print(r['Name'][:70].ljust(70), r['Calls'].rjust(6), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(9),'us', r['Percentage'])
     print(open(out+'/'+tag+'_odom_stdout.log').read().strip()[-1200:])

@@ -224,6 +224,38 @@ def test_align_ndt_pipeline_matches_oracle(ctx, oracle, inner, match, n_scan, mo
     assert np.abs(a["T"] - I12).max() < 5e-3  # and it actually registers the scan
 
 
+@pytest.mark.parametrize("inner,match,n_scan", [(1, None, 5000), (2, None, 1500), (1, "p", 5000), (1, "q", 40000)])
+def test_align_ndt_pipeline_skipping_plane_paired_points(ctx, oracle, inner, match, n_scan, monkeypatch):
+    """SURVEY App. B, U12 (found in round 4): upstream's matchers skip local points an earlier matcher of the same iteration
+    has paired unless allowMatchAlreadyMatchedPoints [U] is set -- in lidar3d-ndt.yaml:195-210 plane-paired points would then
+    get no point-to-point pairing.  mh_icp_params::matched_points = MH_MATCHED_POINTS_SKIP against the oracle's
+    pt2pt_skip_plane_paired on every kernel path that runs the plane matcher (requested one-lane / quad matchers fall back
+    to the row kernel, the only one that sees both verdicts of a point); the default keeps pairing every point twice."""
+    if match:
+        monkeypatch.setenv("MH_MATCH", match)
+    pts = _ndt_cloud(31)
+    g = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts)
+    o = oracle.Map(1.0, 0, 0, 0.1, 0.05, 4).insert(pts)
+    rng = np.random.default_rng(32)
+    scan = pts[rng.integers(0, len(pts), n_scan)] + rng.normal(0, 0.01, (n_scan, 3)).astype(np.float32)
+    guess = oracle.se3_exp([0.12, -0.09, 0.06, 0.006, -0.004, 0.01])
+    thr, kp = synth.threshold_schedule(0.5, 60)
+    kw = dict(max_iterations=60, min_abs_step_trans=5e-4, min_abs_step_rot=5e-4, threshold=thr, kernel_param=kp, pt2pl_threshold=0.5)
+    a = capi.icp_align(g, capi.Scan(ctx, scan), guess, capi.ICPParams(gn=capi.GNParams(max_inner_iterations=inner), matched_points=1, **kw),
+                       want_pairs=True)
+    b = oracle.icp_align(o, scan, guess, oracle.ICPParams(gn=oracle.GNParams(max_inner_iterations=inner), pt2pt_skip_plane_paired=True, **kw),
+                         want_pairs=True)
+    assert_align_equal(a, b)
+    assert a["n_final_pairs_pt2pl"] == b["n_final_pairs_pt2pl"] > n_scan // 5
+    np.testing.assert_array_equal(a["pairs"]["local_idx"], b["pairs"]["local_idx"])
+    np.testing.assert_array_equal(a["pairs"]["global_idx"], b["pairs"]["global_idx"])
+    np.testing.assert_allclose(a["cov"], b["cov"], rtol=2e-5, atol=1e-6 * np.abs(b["cov"]).max())
+    both = oracle.icp_align(o, scan, guess, oracle.ICPParams(gn=oracle.GNParams(max_inner_iterations=inner), **kw), want_pairs=True)
+    n_pt = b["n_final_pairs"] - b["n_final_pairs_pt2pl"]
+    assert 0 < n_pt < both["n_final_pairs"] - both["n_final_pairs_pt2pl"]  # the switch does change the pairing set
+    assert np.abs(a["T"] - I12).max() < 5e-3
+
+
 # ---------------------------------------------------------------------------- NN / matcher
 def test_nn_dense_bit_exact(ctx, oracle, small):
     w, gm, om, gs = small

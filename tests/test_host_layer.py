@@ -211,9 +211,12 @@ def test_failures_surface_as_exceptions(hl, small_workload):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("generic", [False, True])
-def test_ndt_pipeline_align_matches_oracle(hl, oracle, generic):
-    """lidar3d-ndt.yaml driven through the plugin API against an mp2p_icp_hip::NDT map (config 5 of BASELINE.json)."""
+@pytest.mark.parametrize("generic,skip", [(False, False), (True, False), (False, True), (True, True)])
+def test_ndt_pipeline_align_matches_oracle(hl, oracle, generic, skip, monkeypatch):
+    """lidar3d-ndt.yaml driven through the plugin API against an mp2p_icp_hip::NDT map (config 5 of BASELINE.json); `skip`:
+    MOLA_HIP_MATCHED_POINTS=skip (U12) through the fused loop and through the matcher-granular loop's pairing bookkeeping."""
+    monkeypatch.setenv("MOLA_HIP_MATCHED_POINTS", "skip" if skip else "again")
+    hl.reload_plugin_switches()
     rng = np.random.default_rng(21)
     ground = np.stack([rng.uniform(-10, 10, 20000), rng.uniform(-10, 10, 20000), rng.normal(0.3, 0.01, 20000)], 1)
     wall = np.stack([rng.uniform(-10, 10, 12000), rng.normal(5.4, 0.01, 12000), rng.uniform(0.5, 4, 12000)], 1)
@@ -242,7 +245,9 @@ def test_ndt_pipeline_align_matches_oracle(hl, oracle, generic):
     thr, kp = synth.threshold_schedule(sigma, 60)
     o = oracle.icp_align(om, scan, oracle.pose_from_ypr(guess_ypr), oracle.ICPParams(
         max_iterations=60, min_abs_step_trans=5e-4, min_abs_step_rot=5e-4, threshold=thr, kernel_param=kp,
-        pt2pl_threshold=1.0 * sigma, gn=oracle.GNParams(max_inner_iterations=1)))
+        pt2pl_threshold=1.0 * sigma, gn=oracle.GNParams(max_inner_iterations=1), pt2pt_skip_plane_paired=skip))
+    monkeypatch.delenv("MOLA_HIP_MATCHED_POINTS")
+    hl.reload_plugin_switches()
     assert res.nIterations == o["n_iterations"]
     assert res.terminationReason.name == oracle.TERM_NAMES[o["termination_reason"]]
     np.testing.assert_allclose(res.pose(), o["T"], atol=1e-7)

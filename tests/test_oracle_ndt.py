@@ -124,3 +124,30 @@ def test_align_with_point2plane_recovers_offset(oracle):
     assert 0 < a["quality"] <= 1.0
     b = oracle.icp_align(m, scan, guess, oracle.ICPParams(**base))
     assert b["n_final_pairs_pt2pl"] == 0 and b["potential_pairings"] == len(scan)
+
+
+def test_point_matcher_skips_plane_paired_points_when_asked():
+    """U12 (added in round 4): with pt2pt_skip_plane_paired the point pairings of an iteration never share a
+    local point with its plane pairings; without it (rounds 1-3) planar points carry both."""
+    from mola_lidar_odometry_amd import synth
+    from oracle import oracle_c as oc
+    pts = synth.ndt_cloud(5)
+    m = oc.Map(1.0, 0, 0, 0.1, 0.05, 4).insert(pts)
+    rng = np.random.default_rng(6)
+    scan = pts[rng.permutation(len(pts))[:3000]]
+    guess = oc.se3_exp([0.08, -0.05, 0.04, 0.004, -0.003, 0.006])
+    thr, kp = synth.threshold_schedule(0.5, 30)
+    kw = dict(max_iterations=30, min_abs_step_trans=5e-4, min_abs_step_rot=5e-4, threshold=thr, kernel_param=kp, pt2pl_threshold=0.5,
+              gn=oc.GNParams(max_inner_iterations=1))
+    again = oc.icp_align(m, scan, guess, oc.ICPParams(**kw), want_pairs=True)
+    skip = oc.icp_align(m, scan, guess, oc.ICPParams(pt2pt_skip_plane_paired=True, **kw), want_pairs=True)
+    assert skip["n_final_pairs_pt2pl"] > 500 and again["n_final_pairs_pt2pl"] > 500
+    n_skip = skip["n_final_pairs"] - skip["n_final_pairs_pt2pl"]
+    n_again = again["n_final_pairs"] - again["n_final_pairs_pt2pl"]
+    assert 0 < n_skip < n_again
+    # the final pose's own matchers: no local point in both sets
+    pl = oc.match_pt2pl(m, scan, skip["T"], 0.5)
+    assert not set(skip["pairs"]["local_idx"].tolist()) & set(pl["local_idx"].tolist())
+    assert set(again["pairs"]["local_idx"].tolist()) & set(oc.match_pt2pl(m, scan, again["T"], 0.5)["local_idx"].tolist())
+    # both converge to the same place within the noise of the cloud
+    assert np.abs(skip["T"] - again["T"]).max() < 2e-2

@@ -75,6 +75,7 @@ VARIANTS = [
     ("local_map_250m", P_DEFAULT, {"MOLA_LOCAL_MAP_MAX_SIZE": "250"}, "skewed", True),
     ("ndt_default", P_NDT, {}, "skewed", True),
     ("ndt_centroid_distance", P_NDT, {"MOLA_HIP_PT2PL_MODE": "centroid"}, "skewed", True),
+    ("ndt_skip_plane_paired_points", P_NDT, {"MOLA_HIP_MATCHED_POINTS": "skip"}, "skewed", True),  # U12
 ]
 
 
