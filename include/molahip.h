@@ -103,16 +103,6 @@ MH_API mh_status mh_device_count(int32_t* n);
 /* `hip_stream`: a hipStream_t to run on (e.g. the caller's torch stream), or NULL to let the context
  * create and own a non-blocking stream. */
 MH_API mh_status mh_ctx_create(int32_t device, void* hip_stream, mh_ctx** out);
-/* The same with a stream of the given priority class (the runtime keeps streams of different classes on different
- * hardware queues): a caller that prepares the NEXT scan on a second context while the current one is being aligned
- * (upload, filters: long copies and wide kernels) gives that context MH_PRIORITY_LOW so that its work neither sits in
- * front of the alignment's short dependent kernels in a shared queue nor competes with them for dispatch. */
-enum { MH_PRIORITY_LOW = -1, MH_PRIORITY_NORMAL = 0, MH_PRIORITY_HIGH = 1 };
-MH_API mh_status mh_ctx_create_with_priority(int32_t device, int32_t priority, mh_ctx** out);
-/* A context whose stream may only use the compute units [first_cu, first_cu + n_cus) of the device (hardware CU mask):
- * for work that runs BESIDE a latency-bound chain of small kernels on another context -- wide filter kernels and copy
- * kernels otherwise fill every wave slot of the device and each small kernel of the chain waits for slots to drain. */
-MH_API mh_status mh_ctx_create_on_cus(int32_t device, uint32_t first_cu, uint32_t n_cus, mh_ctx** out);
 MH_API mh_status mh_ctx_destroy(mh_ctx* ctx);
 MH_API mh_status mh_ctx_synchronize(mh_ctx* ctx);
 MH_API mh_status mh_ctx_stream(mh_ctx* ctx, void** hip_stream_out);
@@ -120,15 +110,6 @@ MH_API mh_status mh_ctx_stream(mh_ctx* ctx, void** hip_stream_out);
  * maps and scans; also how the tests check that destroyed handles give their memory back). */
 MH_API mh_status mh_ctx_memory_info(mh_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 
-/* Cooperative waiting (no reference counterpart; the reference runs one sequence per PROCESS, eval/cli_kitti.sh:23-36).
- * With a hook installed on the CALLING THREAD, every point where the library would block that thread on the device --
- * the poll of an alignment's device loop, the size read-backs of the filters, mh_scan_bbox, mh_ctx_synchronize, ... --
- * becomes "mark the stream with an event, then call hook(user) until the event has completed".  The hook typically
- * switches to another fiber of the same thread, which may call into the library on OTHER contexts (a context is still
- * used by one flow of control at a time): several sequences then share ONE host thread, so their HIP calls never contend
- * for the runtime's locks, and every wait of one sequence is filled with the others' host work.  NULL removes the hook. */
-typedef void (*mh_wait_hook_fn)(void* user);
-MH_API mh_status mh_set_wait_hook(mh_wait_hook_fn hook, void* user);
 /* Page-locked host memory for MH_MEM_HOST_PINNED uploads (hipHostMalloc / hipHostFree behind the C ABI, for host code
  * that does not link the HIP runtime itself). */
 MH_API mh_status mh_host_alloc_pinned(size_t bytes, void** out);

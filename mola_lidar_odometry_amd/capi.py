@@ -132,8 +132,6 @@ _SIGNATURES = {
     "mh_status_string": (C.c_char_p, [C.c_int32]),
     "mh_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
     "mh_ctx_create": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
-    "mh_ctx_create_with_priority": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
-    "mh_ctx_create_on_cus": (C.c_int32, [C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "mh_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "mh_ctx_synchronize": (C.c_int32, [C.c_void_p]),
     "mh_ctx_stream": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -159,7 +157,6 @@ _SIGNATURES = {
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mh_scan_deskew": (C.c_int32, [C.c_void_p, _DP, C.c_void_p]),
     "mh_scan_deskew_pair": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_void_p, C.c_void_p, _FP, _FP, C.POINTER(C.c_uint64)]),
-    "mh_set_wait_hook": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "mh_host_alloc_pinned": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "mh_host_free_pinned": (C.c_int32, [C.c_void_p]),
     "mh_scan_download": (C.c_int32, [C.c_void_p, _FP, _FP, _FP, _FP, _UP]),
@@ -241,22 +238,13 @@ def _T12(T):
     return np.ascontiguousarray(T.reshape(12))
 
 
-PRIORITY_LOW, PRIORITY_NORMAL, PRIORITY_HIGH = -1, 0, 1  # enum MH_PRIORITY_*
-
-
 class Context:
     """One HIP device + one stream (mh_ctx)."""
 
-    def __init__(self, device: int = 0, stream: int | None = None, priority: int = 0, cus: tuple | None = None):
-        """priority: PRIORITY_LOW / PRIORITY_NORMAL / PRIORITY_HIGH -- the class of the stream the context creates;
-        cus = (first, count): a stream restricted to that range of compute units (mh_ctx_create_on_cus)"""
+    def __init__(self, device: int = 0, stream: int | None = None):
+        """stream: a hipStream_t (e.g. torch's) to run on, or None: the context creates and owns a non-blocking stream"""
         self._h = C.c_void_p()
-        if cus is not None and not stream:
-            _chk(lib().mh_ctx_create_on_cus(device, int(cus[0]), int(cus[1]), C.byref(self._h)))
-        elif priority != PRIORITY_NORMAL and not stream:
-            _chk(lib().mh_ctx_create_with_priority(device, priority, C.byref(self._h)))
-        else:
-            _chk(lib().mh_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        _chk(lib().mh_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.device = device
         self._children = weakref.WeakSet()  # maps/scans must be destroyed before their context (C-ABI rule)
 

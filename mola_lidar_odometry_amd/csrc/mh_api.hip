@@ -25,50 +25,11 @@ mh_status fail(mh_status s, const char* fmt, ...) {
   return s;
 }
 
-static thread_local mh_wait_hook_fn g_wait_hook = nullptr;
-static thread_local void* g_wait_user = nullptr;
-bool wait_hook_installed() { return g_wait_hook != nullptr; }
-// marker events of the cooperative waits, per device and per thread (a free list: several fibers of a thread may wait at once)
-static thread_local hipEvent_t g_wait_pool[16][32];
-static thread_local int g_wait_pool_n[16] = {0};
-
-hipError_t wait_event(hipEvent_t e) {
-  if (!g_wait_hook) return hipEventSynchronize(e);
-  int dev = -1;
-  (void)hipGetDevice(&dev);
-  for (;;) {
-    const hipError_t q = hipEventQuery(e);
-    if (q != hipErrorNotReady) return q;
-    g_wait_hook(g_wait_user);  // (may run other fibers of this thread, which may call into the library on THEIR contexts ...
-    if (dev >= 0) (void)hipSetDevice(dev);  // ... and leave another device current: the caller's allocations and copies after
-                                            // this wait must land on ITS device)
-  }
-}
-
-hipError_t wait_stream(hipStream_t s) {
-  if (!g_wait_hook) return hipStreamSynchronize(s);
-  if (hipStreamQuery(s) == hipSuccess) return hipSuccess;
-  (void)hipGetLastError();
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  if (dev < 0 || dev >= 16) return hipStreamSynchronize(s);
-  // the marker is per wait: another fiber of this thread may record the per-device event while this one is suspended,
-  // so each wait gets an event of its own from a small free list
-  auto& pool = g_wait_pool;
-  auto& pool_n = g_wait_pool_n;
-  hipEvent_t ev;
-  if (pool_n[dev] > 0) ev = pool[dev][--pool_n[dev]];
-  else {
-    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e != hipSuccess) return e;
-  }
-  e = hipEventRecord(ev, s);
-  if (e == hipSuccess) e = wait_event(ev);
-  if (pool_n[dev] < 32) pool[dev][pool_n[dev]++] = ev;
-  else (void)hipEventDestroy(ev);
-  return e;
-}
+// Blocking waits of the library, in one place.  (Round 3 could turn them into "mark the stream, call a hook until done" for
+// callers that ran several sequences as fibers of one host thread -- mh_set_wait_hook, molahip-lo-cli --fibers: slower than a
+// thread per sequence at every count, 2410-2650 against 4580-4920 scans/s for eight; removed in round 4.)
+hipError_t wait_event(hipEvent_t e) { return hipEventSynchronize(e); }
+hipError_t wait_stream(hipStream_t s) { return hipStreamSynchronize(s); }
 
 mh_status set_device(const mh_ctx* ctx) {
   MH_HIP(hipSetDevice(ctx->device));
@@ -107,17 +68,6 @@ mh_status scan_alloc(mh_scan* s, size_t n, bool with_t, bool with_src) {
 using namespace mh;
 
 extern "C" {
-
-mh_status mh_set_wait_hook(mh_wait_hook_fn hook, void* user) {
-  mh::g_wait_hook = hook;
-  mh::g_wait_user = user;
-  if (!hook) {  // the calling thread stops waiting cooperatively: its marker events go back (they were never freed before)
-    for (int d = 0; d < 16; d++) {
-      while (mh::g_wait_pool_n[d] > 0) (void)hipEventDestroy(mh::g_wait_pool[d][--mh::g_wait_pool_n[d]]);
-    }
-  }
-  return MH_OK;
-}
 
 mh_status mh_host_alloc_pinned(size_t bytes, void** out) {
   MH_REQUIRE(out, "null argument");
@@ -167,41 +117,11 @@ mh_status mh_device_count(int32_t* n) {
   return MH_OK;
 }
 
-static mh_status ctx_create(int32_t device, void* hip_stream, int32_t priority, mh_ctx** out);
 
-mh_status mh_ctx_create(int32_t device, void* hip_stream, mh_ctx** out) { return ctx_create(device, hip_stream, MH_PRIORITY_NORMAL, out); }
 
-mh_status mh_ctx_create_with_priority(int32_t device, int32_t priority, mh_ctx** out) {
-  MH_REQUIRE(priority >= MH_PRIORITY_LOW && priority <= MH_PRIORITY_HIGH, "bad priority class");
-  return ctx_create(device, nullptr, priority, out);
-}
-
-mh_status mh_ctx_create_on_cus(int32_t device, uint32_t first_cu, uint32_t n_cus, mh_ctx** out) {
-  MH_REQUIRE(out, "null output");
-  *out = nullptr;
-  MH_REQUIRE(n_cus > 0, "empty CU range");
-  int c = 0;
-  if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device available; libmolahip has no CPU fallback");
-  if (device < 0 || device >= c) return fail(MH_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", device, c);
-  MH_HIP(hipSetDevice(device));
-  hipDeviceProp_t prop;
-  MH_HIP(hipGetDeviceProperties(&prop, device));
-  const uint32_t total = (uint32_t)prop.multiProcessorCount;
-  MH_REQUIRE(first_cu < total && n_cus <= total - first_cu, "CU range outside the device");
-  uint32_t mask[32] = {0};
-  for (uint32_t cu = first_cu; cu < first_cu + n_cus && cu < 1024; cu++) mask[cu / 32] |= 1u << (cu % 32);
-  hipStream_t s = nullptr;
-  MH_HIP(hipExtStreamCreateWithCUMask(&s, (total + 31) / 32, mask));
-  const mh_status st = ctx_create(device, s, MH_PRIORITY_NORMAL, out);
-  if (st != MH_OK) {
-    (void)hipStreamDestroy(s);
-    return st;
-  }
-  (*out)->own_stream = true;  // (created here: destroyed with the context)
-  return MH_OK;
-}
-
-static mh_status ctx_create(int32_t device, void* hip_stream, int32_t priority, mh_ctx** out) {
+// (Round 3 also offered contexts whose stream had a priority class or a hardware CU mask, for the prefetch context beside a
+// latency-bound alignment: stream priorities 2180 against 2870 scans/s, a CU mask 4530-4650 against 4780 -- removed in round 4.)
+mh_status mh_ctx_create(int32_t device, void* hip_stream, mh_ctx** out) {
   MH_REQUIRE(out, "null output");
   *out = nullptr;
   int c = 0;
@@ -218,14 +138,7 @@ static mh_status ctx_create(int32_t device, void* hip_stream, int32_t priority, 
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
   } else {
-    if (priority == MH_PRIORITY_NORMAL) {
-      e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    } else {
-      int least = 0, greatest = 0;  // (numerically: greatest priority <= least priority)
-      e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-      if (e == hipSuccess)
-        e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, priority == MH_PRIORITY_HIGH ? greatest : least);
-    }
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
       delete ctx;
       return fail(MH_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));

@@ -1342,313 +1342,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1_b(const BatchJob
 // ================================================================================================
 // Covariance (mp2p_icp::covariance [U]): A = d residuals / d (x,y,z,yaw,pitch,roll), cov = (A^T A)^-1
 // ================================================================================================
-// ================================================================================================
-// k_accum_solveN: ALL inner Gauss-Newton steps of an ICP iteration in one launch (round 3).  An iteration of a small layer
-// was k_match16 | k_accum_solve1 | k_accum_solve1: ~21 us of kernels and three ~3 us gaps between dependent launches.  Round
-// 1 had tried this fusion and dropped it (19.6 us against 2 x 9.3: the fused body spilled); what had gone wrong there is
-// what k_icp_persist ran into as well -- inlined inside a loop, solve_body's fp64 constants and scalar parameters are
-// hoisted into the preheader and stay live -- and has the same cure: the serial solve is CALLED (persist_solve, noinline),
-// and the state block lives in LDS for the launch (solve_body<LDS_STATE>), so the second step neither waits for a launch
-// nor re-reads the state, only the points and pairings (cache hits).  One launch less per extra inner step.
-// MEASURED SLOWER AGAIN, so it is opt-in (MH_FUSED_INNER=1) and parity-tested, not the default: through the odometry driver
-// ICP per scan 0.90 ms against 0.815 with two launches (0.97 while all eight waves made the call: see persist_solve).  The
-// second step's loads cannot be issued before the first step's solve has published the pose, the state takes an extra
-// round trip into LDS before anything starts, and what is saved -- one boundary between two dependent launches inside a
-// captured graph -- is worth ~1 us, not the 3 us the per-iteration arithmetic suggested.
-// ================================================================================================
-struct OneGroupNShared {
-  SolveShared sh;
-  double tr[kAccN][kOneGroupAccThreads + 1];
-  double p1[kAccN][kOneGroupGroups];
-  IcpDeviceState st;
-};
-static_assert(sizeof(OneGroupNShared) <= 64 * 1024, "LDS per workgroup");
-
-__device__ __attribute__((noinline)) void persist_solve(IcpDeviceState* st, const SolveK* skp, SolveShared& sh, bool plB);
-
-template <bool PL>
-__device__ __forceinline__ void k_accum_solveN_body(IcpDeviceState* __restrict__ gst, const MatchK* __restrict__ kp,
-                                                    const SolveK* __restrict__ sk, const float* __restrict__ lx,
-                                                    const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
-                                                    const float4* __restrict__ pair_q, const uint32_t* __restrict__ pair_gidx,
-                                                    const float4* __restrict__ pl_c, const float4* __restrict__ pl_n) {
-  __shared__ OneGroupNShared S;
-  const uint32_t tid = threadIdx.x;
-  const bool acc_lane = tid < kOneGroupAccThreads;
-  const auto g_q = G(reinterpret_cast<const f32x4*>(pair_q)), g_pc = G(reinterpret_cast<const f32x4*>(pl_c)),
-             g_pn = G(reinterpret_cast<const f32x4*>(pl_n));
-  const auto g_gi = G(pair_gidx);
-  const auto g_x = G(lx), g_y = G(ly), g_z = G(lz);
-  {  // the state block -> LDS for the whole launch
-    const uint32_t MH_AS_GLOBAL* src = G(reinterpret_cast<const uint32_t*>(gst));
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&S.st);
-    for (uint32_t i = tid; i < sizeof(IcpDeviceState) / 4; i += kSolveThreads) dst[i] = src[i];
-  }
-  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
-  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
-  struct { uint32_t kernel; double w_pt2pt, w_pt2pl; } k = {ck->kernel, ck->w_pt2pt, ck->w_pt2pl};
-  __syncthreads();
-  if (S.st.done) return;  // (uniform; nothing was changed: no write-back)
-  for (;;) {
-    double T[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) T[i] = S.st.T[i];
-    const double kparam = S.st.cur_kparam;
-    Acc a;
-    acc_zero(a);
-    double v[PL ? kGenN : 1];
-#pragma unroll
-    for (int j = 0; j < (PL ? kGenN : 1); j++) v[j] = 0.0;
-    if (acc_lane) {
-#pragma unroll 1
-      for (uint32_t base = 0; base < n; base += kOneGroupAccThreads * kOneGroupBatch) {
-        uint32_t gi[kOneGroupBatch];
-        f32x4 q[kOneGroupBatch], pc[kOneGroupBatch], pn[kOneGroupBatch];
-        float px[kOneGroupBatch], py[kOneGroupBatch], pz[kOneGroupBatch];
-#pragma unroll
-        for (int u = 0; u < kOneGroupBatch; u++) {
-          const uint32_t i = base + (uint32_t)u * kOneGroupAccThreads + tid;
-          const uint32_t ic = i < n ? i : n - 1;
-          gi[u] = i < n ? g_gi[ic] : kNoMatch;
-          q[u] = g_q[ic];
-          px[u] = g_x[ic]; py[u] = g_y[ic]; pz[u] = g_z[ic];
-          if (PL) {
-            pc[u] = g_pc[ic];
-            pn[u] = g_pn[ic];
-            if (i >= n) pc[u].w = 0.f;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kOneGroupBatch; u++) {
-          acc_pt2pt_masked(a, T, gi[u] != kNoMatch, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
-          if (PL && pc[u].w != 0.f) {
-            double r[kGenN];
-            acc_pt2pl_rows(r, T, px[u], py[u], pz[u], make_float4(pc[u].x, pc[u].y, pc[u].z, pc[u].w),
-                           make_float4(pn[u].x, pn[u].y, pn[u].z, pn[u].w), k.kernel, kparam, k.w_pt2pl);
-#pragma unroll
-            for (int j = 0; j < kGenN; j++) v[PL ? j : 0] += r[j];
-          }
-        }
-      }
-    }
-    one_group_sum<kAccN>(a.v, acc_lane, S.tr, S.p1, S.sh.totA);
-    if (PL) {
-      one_group_sum<kAccN>(v, acc_lane, S.tr, S.p1, S.sh.totB);
-      one_group_sum<kGenN - kAccN>(v + (PL ? kAccN : 0), acc_lane, S.tr, S.p1, S.sh.totB + kAccN);
-    }
-    if (tid < 64) persist_solve(&S.st, sk, S.sh, PL);  // (the sums above ended with a workgroup barrier)
-    __syncthreads();
-    if (S.st.done || S.st.inner == 0) break;  // the solver closed this ICP iteration (or the loop)
-  }
-  {  // the state block back to global memory
-    uint32_t MH_AS_GLOBAL* dst = G(reinterpret_cast<uint32_t*>(gst));
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.st);
-    for (uint32_t i = tid; i < sizeof(IcpDeviceState) / 4; i += kSolveThreads) dst[i] = src[i];
-  }
-}
-template <bool PL>
-__global__ __launch_bounds__(kSolveThreads) void k_accum_solveN(IcpDeviceState* __restrict__ st, const MatchK* __restrict__ kp,
-                                                                const SolveK* __restrict__ sk, const float* __restrict__ lx,
-                                                                const float* __restrict__ ly, const float* __restrict__ lz,
-                                                                uint32_t n, const float4* __restrict__ pair_q,
-                                                                const uint32_t* __restrict__ pair_gidx,
-                                                                const float4* __restrict__ pl_c, const float4* __restrict__ pl_n) {
-  k_accum_solveN_body<PL>(st, kp, sk, lx, ly, lz, n, pair_q, pair_gidx, pl_c, pl_n);
-}
-template <bool PL>
-__global__ __launch_bounds__(kSolveThreads) void k_accum_solveN_b(const BatchJob* __restrict__ jobs) {
-  const BatchJob& j = jobs[blockIdx.y];
-  k_accum_solveN_body<PL>(j.st, j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.pair_q, j.pair_gidx, j.pl_c, j.pl_n);
-}
-
-// ================================================================================================
-// k_icp_persist: the WHOLE alignment of a small layer in ONE workgroup and ONE launch.
-//
-// OPT-IN (MH_PERSIST=1) AND SLOWER THAN THE DEFAULT CHAIN -- kept, parity-tested, as the measured answer to "would one launch
-// per alignment help?" (profiles/r03_persist_kernel.md): the solve side costs what k_accum_solve1 costs (7.8 us per
-// Gauss-Newton step), but ONE compute unit cannot supply the memory-level parallelism of the correspondence search: a lane
-// per point chains ~25 dependent round trips (23 us per 400 points, 57 us per 900, 101 us per 2000) where k_match16 spreads
-// 16 lanes per point over ~60 compute units and needs 10 us.
-//
-// What lidar3d-default.yaml really feeds align() is a layer of a few hundred to a few thousand points; there
-// an iteration was three dependent launches (k_match16 | k_accum_solve1 x2: ~30 us, of which launch boundaries, the
-// re-loading of state / points / pairings at the head of every kernel and the pairing round trip through global memory
-// are about half), plus ~8 early-exit launches per alignment beyond its end and a second host poll whenever the first
-// chunk was too short.  Here a 512-lane workgroup keeps everything it needs between iterations ON THE CU: its points and
-// each point's winning map record in registers (the next iteration's search bound, the Gauss-Newton accumulation's
-// input), the state block in LDS, the 18 moment sums through LDS transposed (fixed order: bitwise reproducible).  One
-// lane per point searches (nn_search_lane); nothing crosses a workgroup, so no device-scope fence is involved (the
-// multi-workgroup cooperative loop that was tried and dropped -- see solve_body -- paid exactly that).  The host sees one
-// launch per alignment, and a batch of N alignments is one launch of N workgroups that finish independently: no lock
-// step, no early-exit launches, no polling chunks.
-// Pairings (pair_q / pair_gidx: the device-side Results::finalPairings, input of the covariance kernels and of the
-// compaction) are written once, at the end, as the last executed match left them -- what the other chains hold there.
-// ================================================================================================
-constexpr uint32_t kPersistMaxPoints = 2048;
-constexpr int kPersistThreads = 512;  // 2 waves per SIMD -> 256 VGPRs per lane (solve_body's serial 6x6 code wants them)
-constexpr int kPersistPPL = (int)(kPersistMaxPoints / kPersistThreads);  // points per lane, at most
-constexpr int kPersistW = 8;          // records per round trip of a lane's scan
-constexpr int kPersistL = kPersistThreads / 4;                       // quad sums that go through LDS
-constexpr int kPersistChunk = ((kPersistL + kPersistL / kAccN - 1) / (kPersistL / kAccN)) | 1;  // 19
-constexpr int kPersistGroups = (kPersistL + kPersistChunk - 1) / kPersistChunk;                 // 7
-static_assert(kAccN * kPersistGroups <= kPersistThreads, "one thread per (row, group)");
-
-static_assert(kPersistL + 1 == 129, "SolveShared::tr");
-struct PersistShared {
-  SolveShared sh;
-  double p1[kAccN][kPersistGroups];
-  IcpDeviceState st;
-  // per point: the map record it is paired with {x, y, z, d2 (inf: none found)} and its source index or kNoMatch --
-  // the next iteration's search bound, the Gauss-Newton accumulation's input, the final pairings
-  f32x4 win[kPersistPPL][kPersistThreads];
-  uint32_t src[kPersistPPL][kPersistThreads];
-};
-static_assert(sizeof(PersistShared) <= 64 * 1024, "LDS per workgroup");
-
-// workgroup sum of the 18 moment rows -> out[0..18): the four lanes of every DPP quad first, then transposed through LDS
-// in a fixed order (block_sum_rows_quad's scheme for 512 lanes, totals into LDS instead of global partials)
-__device__ __forceinline__ void persist_sum(const double* v, PersistShared& S, double* out) {
-  constexpr int G = kPersistGroups, C = kPersistChunk, L = kPersistL;
-#pragma unroll
-  for (int j = 0; j < kAccN; j++) {
-    double q = v[j];
-    q += dpp_f64<0xB1>(q);  // quad_perm:[1,0,3,2]
-    q += dpp_f64<0x4E>(q);  // quad_perm:[2,3,0,1]
-    if ((threadIdx.x & 3u) == 0u) S.sh.tr[j][threadIdx.x >> 2] = q;
-  }
-  __syncthreads();
-  if (threadIdx.x < kAccN * G) {
-    const int j = threadIdx.x / G, g = threadIdx.x % G;
-    const int l0 = g * C;
-    double sum = S.sh.tr[j][l0];
-#pragma unroll
-    for (int i = 1; i < C; i++)
-      if (l0 + i < L) sum += S.sh.tr[j][l0 + i];
-    S.p1[j][g] = sum;
-  }
-  __syncthreads();
-  if (threadIdx.x < kAccN) {
-    double sum = S.p1[threadIdx.x][0];
-#pragma unroll
-    for (int g = 1; g < G; g++) sum += S.p1[threadIdx.x][g];
-    out[threadIdx.x] = sum;
-  }
-  __syncthreads();
-}
-
-// A real call, not an inlined copy: inside the iteration loops the serial 6x6 code's constants and scalar parameters
-// get hoisted into the loop preheader and stay live (107 spilled VGPRs); as a function of its own it allocates like k_solve.
-// Called by the FIRST WAVE only: a call saves and restores ~130 callee-saved VGPRs through scratch, and eight waves doing
-// that around a function in which seven of them return at once cost 4.5 us per call (measured: the fused inner steps were
-// 6 us per iteration SLOWER than two launches until the other waves stopped calling).
-__device__ __attribute__((noinline)) void persist_solve(IcpDeviceState* st, const SolveK* skp, SolveShared& sh, bool plB) {
-  solve_body<true, true>(st, skp, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true, plB);
-}
-
-__device__ __forceinline__ void k_icp_persist_body(IcpDeviceState* __restrict__ gst, const MatchK* __restrict__ mkp,
-                                                   const SolveK* __restrict__ skp, const float* __restrict__ lx,
-                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
-                                                   const MapView& map, float4* __restrict__ pair_q,
-                                                   uint32_t* __restrict__ pair_gidx) {
-  __shared__ PersistShared S;
-  const uint32_t tid = threadIdx.x;
-  {  // the state block -> LDS (it stays there until the epilogue)
-    const uint32_t MH_AS_GLOBAL* src = G(reinterpret_cast<const uint32_t*>(gst));
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&S.st);
-    for (uint32_t i = tid; i < sizeof(IcpDeviceState) / 4; i += kPersistThreads) dst[i] = src[i];
-  }
-  const uint32_t ppl = (n + kPersistThreads - 1) / kPersistThreads;  // points per lane: uniform, <= kPersistPPL
-  for (uint32_t u = 0; u < ppl; u++) {
-    S.win[u][tid] = (f32x4){0.f, 0.f, 0.f, __builtin_inff()};
-    S.src[u][tid] = kNoMatch;
-  }
-  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
-  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(mkp);
-  const uint32_t kernel = ck->kernel;
-  const double w_pt2pt = ck->w_pt2pt;
-  const auto g_x = G(lx), g_y = G(ly), g_z = G(lz);
-  __syncthreads();
-  if (!S.st.done) {  // (uniform: one LDS word)
-    for (;;) {
-      // ---- match: p' = T (+) l, exact NN over the 27-voxel block bounded by the previous pairing, threshold test
-      MH_PHASE(11);
-      {
-        double T[12];
-#pragma unroll
-        for (int k = 0; k < 12; k++) T[k] = S.st.T[k];
-        const float thr2 = S.st.cur_thr2, ang2 = S.st.cur_ang2;
-#pragma unroll 1
-        for (uint32_t u = 0; u < ppl; u++) {
-          const uint32_t i = tid + u * kPersistThreads;
-          if (i >= n) break;
-          float px, py, pz;
-          transform_point(T, g_x[i], g_y[i], g_z[i], px, py, pz);
-          const f32x4 prev = S.win[u][tid];
-          float bound0 = __builtin_inff();
-          if (prev.w < __builtin_inff() && !map.no_prev_bound) {  // a record was found last time (whatever the threshold said)
-            const float dx = prev.x - px, dy = prev.y - py, dz = prev.z - pz;
-            bound0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic
-          }
-          const NNResult r = nn_search_lane<kPersistW>(map, px, py, pz, bound0);
-          const float n2 = (px * px + py * py) + pz * pz;
-          const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
-          S.win[u][tid] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
-          S.src[u][tid] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
-        }
-      }
-      // ---- Gauss-Newton steps on these pairings (Solver_GaussNewton's inner loop), then the tail of the ICP iteration
-      MH_PHASE(12);
-      for (;;) {
-        double T[12];
-#pragma unroll
-        for (int k = 0; k < 12; k++) T[k] = S.st.T[k];
-        const double kparam = S.st.cur_kparam;
-        Acc a;
-        acc_zero(a);
-#pragma unroll 1
-        for (uint32_t u = 0; u < ppl; u++) {
-          const uint32_t i = tid + u * kPersistThreads;
-          const uint32_t ic = i < n ? i : n - 1;
-          const f32x4 q = S.win[u][tid];
-          const bool paired = i < n && S.src[u][tid] != kNoMatch;
-          acc_pt2pt_masked(a, T, paired, g_x[ic], g_y[ic], g_z[ic], q.x, q.y, q.z, kernel, kparam, w_pt2pt);
-        }
-        MH_PHASE(13);
-        persist_sum(a.v, S, S.sh.totA);
-        MH_PHASE(14);
-        if (tid < 64) persist_solve(&S.st, skp, S.sh, false);
-        __syncthreads();
-        MH_PHASE(15);
-        if (S.st.done || S.st.inner == 0) break;  // the solver closed this ICP iteration (or the loop)
-      }
-      if (S.st.done) break;
-    }
-  }
-  // ---- epilogue: the pairings of the last match and the state block back to global memory
-  for (uint32_t u = 0; u < ppl; u++) {
-    const uint32_t i = tid + u * kPersistThreads;
-    if (i >= n) break;
-    G(reinterpret_cast<f32x4*>(pair_q))[i] = S.win[u][tid];
-    G(pair_gidx)[i] = S.src[u][tid];
-  }
-  {
-    uint32_t MH_AS_GLOBAL* dst = G(reinterpret_cast<uint32_t*>(gst));
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.st);
-    for (uint32_t i = tid; i < sizeof(IcpDeviceState) / 4; i += kPersistThreads) dst[i] = src[i];
-  }
-}
-__global__ __launch_bounds__(kPersistThreads) void k_icp_persist(IcpDeviceState* __restrict__ st, const MatchK* __restrict__ mk,
-                                                                 const SolveK* __restrict__ sk, const float* __restrict__ lx,
-                                                                 const float* __restrict__ ly, const float* __restrict__ lz,
-                                                                 uint32_t n, MapView map, float4* __restrict__ pair_q,
-                                                                 uint32_t* __restrict__ pair_gidx) {
-  k_icp_persist_body(st, mk, sk, lx, ly, lz, n, map, pair_q, pair_gidx);
-}
-// a batch: one workgroup per alignment (blockIdx.y), each running to its own termination
-__global__ __launch_bounds__(kPersistThreads) void k_icp_persist_b(const BatchJob* __restrict__ jobs) {
-  const BatchJob& j = jobs[blockIdx.y];
-  k_icp_persist_body(j.st, j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx);
-}
+// (Round 3 built two further fusions of the small-layer chain -- k_accum_solveN: all inner Gauss-Newton steps of an iteration
+// in one launch; k_icp_persist: the WHOLE alignment of a layer of <= 2048 points in one workgroup and one launch -- bit-exact,
+// parity-tested, and slower: 0.90 against 0.815 ms of ICP per scan, and 3.5 against 0.81 ms (one CU cannot supply the search's
+// memory-level parallelism).  Both were selectable through MH_FUSED_INNER / MH_PERSIST until round 4 removed them; the
+// measurements are in profiles/r03_persist_kernel.md and DESIGN.md section 3, the code in the history (round 3's last commit).)
 
 constexpr int kCovN = 22;  // 21 upper-triangle + count
 
@@ -2698,11 +2396,9 @@ struct AlignJob {
     // Streaming loop control (single alignments with automatic polling): instead of a predicted chunk of iterations whose
     // unused tail idles on the stream (27.8 iterations' worth of kernels enqueued for 21 executed on the city drive, plus
     // 0.64 extra host round trips per scan), the host follows the progress word the solve kernels publish and keeps
-    // MH_STREAM_LEAD (2) iterations queued ahead.  Not for lock-step batches (defer_upload), profiled jobs, a cooperative
-    // wait hook (the spin would starve the other fibers), or when switched off (MH_NO_STREAM=1).
-    streaming = p->poll_every == 0 && !defer_upload && !prof && ctx->d_progress != nullptr && !mh::wait_hook_installed() &&
-                getenv("MH_NO_STREAM") == nullptr && getenv("MH_PERSIST") == nullptr && getenv("MH_FUSED_INNER") == nullptr;  // (those two
-                                                                                             // keep the state in LDS across steps)
+    // MH_STREAM_LEAD (2) iterations queued ahead.  Not for lock-step batches (defer_upload), profiled jobs, or when switched
+    // off (MH_NO_STREAM=1).
+    streaming = p->poll_every == 0 && !defer_upload && !prof && ctx->d_progress != nullptr && getenv("MH_NO_STREAM") == nullptr;
     sk.host_progress = streaming ? ctx->d_progress : nullptr;
     if (defer_upload) {
       ctx->h_params->mk = mk;
@@ -2732,10 +2428,6 @@ struct AlignJob {
       // MH_MATCHED_POINTS_SKIP (U12): the point matcher has to know the plane matcher's verdict for the same point -- the row
       // kernel runs both in one launch (k_match16<true>), whatever the layer's size
       if (pl && p->matched_points == MH_MATCHED_POINTS_SKIP) variant = 5;
-      //   MH_PERSIST=1   (opt-in, measured slower: profiles/r03_persist_kernel.md) layers up to 2 k points without
-      //                  Matcher_Point2Plane: the whole alignment in one workgroup and one launch -> k_icp_persist
-      if (!e && scan->n <= kPersistMaxPoints && !pl && !prof && getenv("MH_PERSIST") != nullptr)
-        variant = 9;
     }
     if (variant >= 6) MH_TRY(scan_build_tiles(scan, map->inv_vs, variant == 7 ? 64u : 256u));  // asynchronous; a no-op when the scan is already in search order
     nba = nblk_acc(scan->n);
@@ -2757,7 +2449,6 @@ struct AlignJob {
       const uint32_t expect = p->expected_iterations ? p->expected_iterations : ctx->predicted_iterations[kind];
       static const uint32_t margin = getenv("MH_CHUNK_MARGIN") ? (uint32_t)atoi(getenv("MH_CHUNK_MARGIN")) : 2u;
       chunk = p->poll_every ? p->poll_every : (expect ? (expect + margin > 64 ? 64u : expect + margin) : 10u);
-      if (variant == 9) chunk = p->max_iterations;  // one launch runs the loop to its end: nothing to poll in between
     }
     polls = 0;
     enqueued = 0;
@@ -2804,16 +2495,12 @@ struct AlignJob {
     // everything a chunk launches, in stream order; used directly (profiling / MH_NO_GRAPH) or under stream capture
     const bool no_one_group = getenv("MH_NO_ONE_GROUP") != nullptr;  // (read per chunk: tests toggle it)
     const bool one_group = variant == 5 && n <= kOneGroupMaxPoints && !no_one_group;  // accumulate + solve in one workgroup
-    const bool fused_inner = one_group && getenv("MH_FUSED_INNER") != nullptr;  // ... and all inner steps in one launch (opt-in: slower)
     auto enqueue_kernels = [&]() -> mh_status {
       double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
       const bool rows16 = pl && variant == 5;                  // NDT layer handled by the row kernel
       const uint32_t nB = pl ? (rows16 ? nba : nb) : 0u;       // columns of the point-to-plane partials of the FIRST step
       const uint32_t nBi = pl ? nba : 0u;                      // ... of the inner steps (k_accum_both)
-      if (variant == 9)  // the whole loop: one workgroup, one launch
-        hipLaunchKernelGGL(k_icp_persist, dim3(1), dim3(kPersistThreads), 0, s, ctx->d_state, dmk, dsk, scan->x, scan->y, scan->z,
-                           n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>());
-      for (uint32_t j = 0; j < (variant == 9 ? 0u : m); j++) {
+      for (uint32_t j = 0; j < m; j++) {
         const bool both16 = pl && variant == 5;  // small layer: both matchers in one launch (k_match16<true>)
         if (pl && !both16)
           hipLaunchKernelGGL(k_match_pl<true>, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, dmk, scan->x, scan->y,
@@ -2835,17 +2522,6 @@ struct AlignJob {
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
           if (one_group) {
             if (prof) prof_n++;
-            if (fused_inner) {  // all inner Gauss-Newton steps in one launch
-              if (pl)
-                hipLaunchKernelGGL(k_accum_solveN<true>, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dmk, dsk, scan->x,
-                                   scan->y, scan->z, n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
-                                   ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>());
-              else
-                hipLaunchKernelGGL(k_accum_solveN<false>, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dmk, dsk, scan->x,
-                                   scan->y, scan->z, n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
-                                   (const float4*)nullptr, (const float4*)nullptr);
-              continue;
-            }
             for (uint32_t in = 0; in < p->gn.max_inner_iterations; in++) {
               if (pl)
                 hipLaunchKernelGGL(k_accum_solve1<true>, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, in == 0 ? 1u : 0u, dmk,
@@ -2956,7 +2632,7 @@ struct AlignJob {
                                        (unsigned long long)ctx->pair_gidx.p, (unsigned long long)part,
                                        (unsigned long long)ctx->d_state, (unsigned long long)ctx->d_params,
                                        (unsigned long long)ctx->h_state,
-                                       (pl ? 2ull : 1ull) | (one_group ? 4ull : 0ull) | (fused16 ? 8ull : 0ull) | (fused_inner ? 16ull : 0ull),
+                                       (pl ? 2ull : 1ull) | (one_group ? 4ull : 0ull) | (fused16 ? 8ull : 0ull),
                                        (unsigned long long)(pl ? ctx->pl_c.p : nullptr),
                                        (unsigned long long)(pl ? ctx->pl_n.p : nullptr),
                                        (unsigned long long)(pl ? ctx->partials_b.p : nullptr),
@@ -3321,14 +2997,12 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
   // each job keeps its own parameters (iteration budget, schedules, hook check point, prior), state block, termination
   // flag and iteration count.  Jobs whose chain has no lock-step form (or that are alone in their group) take the
   // per-stream path below.
-  enum Kind { K_NONE = 0, K_QUAD, K_TILE, K_WAVE, K_ORD, K_ROWF, K_ONE, K_ONE_PL, K_PERSIST };
+  enum Kind { K_NONE = 0, K_QUAD, K_TILE, K_WAVE, K_ORD, K_ROWF, K_ONE, K_ONE_PL };
   const bool no_lockstep = getenv("MH_NO_LOCKSTEP") != nullptr;
   const bool no_one_group_env = getenv("MH_NO_ONE_GROUP") != nullptr;
-  const bool fused_inner_env = getenv("MH_FUSED_INNER") != nullptr;
   auto kind_of = [&](const AlignJob& j) -> int {
     if (j.finished || no_lockstep || j.trace || j.prof) return K_NONE;
     const bool one_group = j.variant == 5 && j.scan->n <= kOneGroupMaxPoints && !no_one_group_env;
-    if (j.variant == 9) return K_PERSIST;  // one workgroup per job, each to its own end: a "group" is just one launch
     if (j.variant == 4 && !j.pl) return K_QUAD;
     if (j.variant == 6 && !j.pl) return K_TILE;
     if (j.variant == 7 && !j.pl) return K_WAVE;
@@ -3368,13 +3042,12 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
       g->cov = q->compute_covariance != 0;
       g->chunk = q->poll_every ? q->poll_every : 0;
       g->auto_chunk = q->poll_every == 0;
-      if (k == K_PERSIST) g->chunk = 0xFFFFFFFFu;  // no chunks: the launch runs every job's loop to its end
     }
     // automatic chunks: the group's first chunk is as long as its slowest job expects to run (every job's own estimate:
     // AlignJob::start) -- jobs that finish earlier leave their blocks at once, so only what lies beyond the LAST job's end is
     // wasted, while every poll in between drains the device for a host round trip (measured with fixed chunks of 10 on 8
     // sequences: 3.1 polls per alignment)
-    if (g->auto_chunk && k != K_PERSIST && jobs[i].chunk > g->chunk) g->chunk = jobs[i].chunk;
+    if (g->auto_chunk && jobs[i].chunk > g->chunk) g->chunk = jobs[i].chunk;
     g->jobs.push_back(&jobs[i]);
     g->index.push_back(i);
     g->max_iterations = q->max_iterations > g->max_iterations ? q->max_iterations : g->max_iterations;
@@ -3489,10 +3162,6 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
           if (g.done || it >= m_of[gi]) continue;
           hipStream_t s = g.lead->stream;
           const uint32_t A = (uint32_t)g.jobs.size();
-          if (g.kind == K_PERSIST) {
-            if (it == 0) hipLaunchKernelGGL(k_icp_persist_b, dim3(1, A), dim3(kPersistThreads), 0, s, g.dj);
-            continue;
-          }
           const bool pr = want_prof && gi == 0 && g.jobs[0] == &jobs[0];
           if (pr) MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n], s));
           switch (g.kind) {
@@ -3513,11 +3182,6 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
             g.prof_n++;
           }
           if (g.kind == K_ONE || g.kind == K_ONE_PL) {
-            if (fused_inner_env) {
-              if (g.kind == K_ONE_PL) hipLaunchKernelGGL(k_accum_solveN_b<true>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj);
-              else hipLaunchKernelGGL(k_accum_solveN_b<false>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj);
-              continue;
-            }
             for (uint32_t in = 0; in < g.inner; in++) {
               if (g.kind == K_ONE_PL)
                 hipLaunchKernelGGL(k_accum_solve1_b<true>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, in == 0 ? 1u : 0u);
@@ -3554,7 +3218,7 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         MH_HIP(mh::wait_stream(g.lead->stream));
         g.enq += m_of[gi];
         g.done = true;
-        if (g.auto_chunk && g.kind != K_PERSIST) g.chunk = 8;  // follow-up chunks
+        if (g.auto_chunk) g.chunk = 8;  // follow-up chunks
         for (size_t a = 0; a < g.jobs.size(); a++) {
           AlignJob& j = *g.jobs[a];
           if (j.finished) continue;

@@ -195,12 +195,9 @@ struct mh_map {
   uint32_t* h_counts = nullptr;          // pinned [16]: what k_scatter / k_ndt_stats left in the device counters
   hipEvent_t ev_counts = nullptr;        // recorded behind that copy: "the last (re)build is complete"
   mutable bool counts_pending = false;   // n_points ... bbox above are stale until map_resolve() has seen ev_counts
-  mutable bool build_in_flight = false;  // the last (re)build may still run on `side`: order consumers with map_ready_on()
+  mutable bool build_in_flight = false;  // the last (re)build may still run: consumers on OTHER streams order themselves with map_ready_on()
   mutable mh_status deferred_error = MH_OK;  // an insertion's out-of-range verdict, reported by the next call that resolves
-  // mh_map_insert's scratch is the map's own; with MH_MAP_SIDE_STREAM=1 the update also runs on a stream of the map's own
-  // (needed only before the NEXT align: it then overlaps the next scan's upload, filters and de-skew on the context's stream)
-  hipStream_t side = nullptr;
-  hipEvent_t ev_main = nullptr, ev_input = nullptr;
+  // mh_map_insert's scratch is the map's own
   mh::DevBuf build_a, build_b, build_c, build_d, build_e, sort_tmp;
   mh::MapView view() const {
     mh::MapView v;
@@ -244,10 +241,7 @@ struct mh_scan {
 };
 
 namespace mh {
-// Blocking waits of the library.  With a wait hook installed on the calling thread (mh_set_wait_hook) they turn into
-// "record an event, then call the hook until the event has completed": a host layer that multiplexes several sequences
-// on ONE thread (cooperative fibers) gets control back at every point where the library would otherwise block.
-bool wait_hook_installed();  // on the calling thread
+// Blocking waits of the library (one place).
 hipError_t wait_stream(hipStream_t s);
 hipError_t wait_event(hipEvent_t e);
 mh_status set_device(const mh_ctx* ctx);
@@ -264,7 +258,7 @@ uint32_t tile_points_for_env();
 mh_status scan_tiles_ready(const mh_scan* s);
 void scan_drop_tiles(mh_scan* s);  // host-side bookkeeping only (the points changed)
 void scan_free_tiles(mh_scan* s);
-// Asynchronous on stream `s` (the context's, or the map's side stream); scratch from `m`.  Counts / bbox / the
+// Asynchronous on stream `s` (the context's); scratch from `m`.  Counts / bbox / the
 // out-of-range verdict are resolved lazily (map_resolve).
 mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc,
                            size_t n, const int* evict, size_t n_stored, bool collected = false);
@@ -275,6 +269,6 @@ mh_status map_build_prologue(mh_map* m, hipStream_t s, size_t n, size_t n_stored
 mh_status map_resolve(const mh_map* m);
 // the same without handing the verdict out: counts, bounding box; the verdict stays recorded in m->deferred_error
 mh_status map_resolve_counts(const mh_map* m);
-// make stream `s` wait for a (re)build that may still be running on the map's side stream (no-op otherwise)
+// make stream `s` wait for a (re)build that may still be running on the map's own context stream (no-op when `s` is that stream)
 mh_status map_ready_on(const mh_map* m, hipStream_t s);
 }  // namespace mh

@@ -365,13 +365,7 @@ mh_status mh_map_destroy(mh_map* m) {
   if (!m) return MH_OK;
   (void)hipSetDevice(m->ctx->device);
   (void)mh::wait_stream(m->ctx->stream);
-  if (m->side) {
-    (void)mh::wait_stream(m->side);
-    (void)hipStreamDestroy(m->side);
-  }
   if (m->ev_counts) (void)hipEventDestroy(m->ev_counts);
-  if (m->ev_main) (void)hipEventDestroy(m->ev_main);
-  if (m->ev_input) (void)hipEventDestroy(m->ev_input);
   if (m->h_counts) (void)hipHostFree(m->h_counts);
   for (mh::DevBuf* b : {&m->build_a, &m->build_b, &m->build_c, &m->build_d, &m->build_e, &m->sort_tmp}) b->release();
   m->slots.release();
@@ -444,7 +438,6 @@ mh_status mh_map_build(mh_map* m, const float* x, const float* y, const float* z
   MH_TRY(set_device(ctx));
   hipStream_t s = ctx->stream;
   MH_HIP(mh::wait_stream(s));  // a rebuild invalidates everything queued against the old content
-  if (m->side) MH_HIP(mh::wait_stream(m->side));
   (void)map_resolve(m);  // (a pending verdict about the OLD content is moot now)
   const float *dx = x, *dy = y, *dz = z;
   if (n > 0 && mem == MH_MEM_HOST) {
@@ -475,24 +468,11 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
   MH_TRY(map_resolve_counts(m));
   const bool prev_out_of_range = m->deferred_error != MH_OK;
   m->deferred_error = MH_OK;
-  // The update is asynchronous either way (no host synchronisation: counts and verdict are read back lazily).  With
-  // MH_MAP_SIDE_STREAM=1 it runs on a stream of the map's own, behind everything queued on the context's so far (the layer
-  // it reads, the alignments that still read the old content), and is waited for by the NEXT use of the map only
-  // (map_ready_on) -- measured on the odometry drive: the extra event traffic costs the caller more (0.139 ms per key-frame
-  // against 0.101) than the overlap with the next scan's de-skew returns (967 against 990 scans/s), so the default is the
-  // context's stream.
-  const bool use_side = getenv("MH_MAP_SIDE_STREAM") && atoi(getenv("MH_MAP_SIDE_STREAM")) != 0;  // (per call: tests toggle it)
+  // The update is asynchronous (no host synchronisation: counts and verdict are read back lazily) and runs on the context's
+  // stream.  (Round 3 also ran it on a stream of the map's own, MH_MAP_SIDE_STREAM=1, waited for by the next use of the map
+  // only: the extra event traffic cost the caller more -- 0.139 ms per key-frame against 0.101 -- than the overlap with the
+  // next scan's de-skew returned, 967 against 990 scans/s; removed in round 4.)
   hipStream_t s = ctx->stream;
-  if (use_side) {
-    if (!m->side) {
-      MH_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-      MH_HIP(hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming));
-      MH_HIP(hipEventCreateWithFlags(&m->ev_input, hipEventDisableTiming));
-    }
-    MH_HIP(hipEventRecord(m->ev_main, ctx->stream));
-    MH_HIP(hipStreamWaitEvent(m->side, m->ev_main, 0));
-    s = m->side;
-  }
   const size_t n_old = m->n_points, n_new = scan->n, total = n_old + n_new;
   MH_REQUIRE(total < 0x7FFFFFF0ull && m->n_offered + n_new < 0xFFFFFFF0ull, "too many points");
   const size_t stride = ((total * sizeof(float) + 255) / 256) * 256;
@@ -534,10 +514,6 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
     }
   }
   MH_HIP(hipGetLastError());
-  if (use_side) {  // the layer has been read: whatever the context's stream does to it next may proceed
-    MH_HIP(hipEventRecord(m->ev_input, s));
-    MH_HIP(hipStreamWaitEvent(ctx->stream, m->ev_input, 0));
-  }
   int evict[4] = {0, 0, 0, -1};
   if (remove_voxels_farther_than > 0.f) {
     const bool trunc = m->params.index_mode == MH_INDEX_TRUNC;
@@ -615,7 +591,7 @@ mh_status map_ready_on(const mh_map* m, hipStream_t s) {
     m->build_in_flight = false;
     return MH_OK;
   }
-  if (s != m->side) MH_HIP(hipStreamWaitEvent(s, m->ev_counts, 0));
+  if (s != m->ctx->stream) MH_HIP(hipStreamWaitEvent(s, m->ev_counts, 0));  // (an alignment on another context's stream)
   return MH_OK;
 }
 
@@ -814,7 +790,7 @@ mh_status mh_map_download(const mh_map* m, float* x, float* y, float* z, uint32_
   mh_ctx* ctx = m->ctx;
   MH_TRY(set_device(ctx));
   MH_HIP(mh::wait_stream(ctx->stream));
-  MH_TRY(map_resolve_counts(m));  // (waits for an update still running on the side stream)
+  MH_TRY(map_resolve_counts(m));
   if (!m->n_voxels) return MH_OK;
   std::vector<uint32_t> hf(m->n_voxels), hc(m->n_voxels);
   MH_HIP(hipMemcpy(hf.data(), m->vox_first.p, m->n_voxels * 4, hipMemcpyDeviceToHost));

@@ -665,131 +665,6 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
 #endif
 }
 
-// -------------------------------------------------------------------------------------------------
-// One lane per scan point with the winner kept in registers: the search of the one-workgroup alignment kernel
-// (k_icp_persist, mh_icp.hip), where a layer of <= 2 k points is matched by ONE workgroup that then accumulates and solves
-// without leaving the CU.  Same exact rule as everywhere -- the lexicographic minimum of (d2 in fp32, record index) over
-// the 27-voxel block; a voxel is skipped only when its conservative lower bound exceeds the best d2 so far -- and the
-// same use of the previous iteration's pairing as a bound that a map record attains (nn_search_quad).  What differs is
-// what a lone lane can do about latency: up to four slot probes in flight, W records per round trip (the 512-lane
-// workgroup has 256 VGPRs per lane to spend), and the winning RECORD is tracked alongside its key, so there is no
-// dependent fetch at the end and the Gauss-Newton accumulation that follows reads registers.
-// -------------------------------------------------------------------------------------------------
-template <int W>
-__device__ __forceinline__ void nn_scan_lane(gpts_ptr pts4, uint32_t first, uint32_t cnt, float qx, float qy, float qz,
-                                             nnkey_t& best, f32x4& brec) {
-  for (uint32_t j = 0; j < cnt; j += (uint32_t)W) {
-    const uint32_t rem = cnt - j;  // >= 1
-    f32x4 c[W];
-#pragma unroll
-    for (int u = 0; u < W; u++) c[u] = pts4[first + j + ((uint32_t)u < rem ? (uint32_t)u : 0u)];  // clamped, not predicated
-#pragma unroll
-    for (int u = 0; u < W; u++) {
-      const float dx = c[u].x - qx, dy = c[u].y - qy, dz = c[u].z - qz;
-      const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order (bit-exact with the oracle)
-      const nnkey_t k = (uint32_t)u < rem ? (((nnkey_t)__float_as_uint(d2) << 32) | (first + j + (uint32_t)u)) : kNNKeyNone;
-      const bool better = k < best;
-      best = better ? k : best;
-      brec.x = better ? c[u].x : brec.x;
-      brec.y = better ? c[u].y : brec.y;
-      brec.z = better ? c[u].z : brec.z;
-      brec.w = better ? c[u].w : brec.w;
-    }
-  }
-}
-
-template <int W>
-__device__ __forceinline__ NNResult nn_search_lane(const MapView& m, float qx, float qy, float qz, float bound0) {
-  NNResult r;
-  r.d2 = __builtin_inff();
-  r.found = false;
-  r.pt = (f32x4)(0.f);
-  const float lim = 1.0e6f;  // one test, no short-circuit branches: NaN and inf fail it as well
-  if (!((int)(fabsf(qx * m.inv_vs) < lim) & (int)(fabsf(qy * m.inv_vs) < lim) & (int)(fabsf(qz * m.inv_vs) < lim))) return r;
-  const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
-  const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
-  const gslots_ptr slots4 = (gslots_ptr)m.slots;
-  const gpts_ptr pts4 = (gpts_ptr)m.pts;
-  const Gaps gx = axis_gaps(qx, cx, m.vs, m.trunc), gy = axis_gaps(qy, cy, m.vs, m.trunc), gz = axis_gaps(qz, cz, m.vs, m.trunc);
-  const uint32_t kFaces = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 14) | (1u << 16) | (1u << 22);
-  const uint32_t kCorners = (1u << 0) | (1u << 2) | (1u << 6) | (1u << 8) | (1u << 18) | (1u << 20) | (1u << 24) | (1u << 26);
-  const uint32_t kEdges = 0x07FFFFFFu & ~(kFaces | kCorners | (1u << 13));
-  bool bounded = bound0 < __builtin_inff();
-  nnkey_t best = bounded ? (((nnkey_t)__float_as_uint(bound0) << 32) | 0xFFFFFFFFull) : kNNKeyNone;
-  f32x4 brec = (f32x4)(0.f);
-  for (int pass = 0; pass < 2; pass++) {
-    uint32_t todo = 0x07FFFFFFu;
-    for (;;) {
-      // voxels that can still hold the winner (the own voxel always, while it is to do)
-      const float bd = nnkey_d2(best);
-      uint32_t live = 1u << 13;
-#pragma unroll
-      for (int c = 0; c < 27; c++) {
-        if (c == 13) continue;
-        const float lb = (gx.s[c / 9] + gy.s[(c / 3) % 3]) + gz.s[c % 3];
-        live |= (!(lb * 0.9999f > bd)) ? (1u << c) : 0u;
-      }
-      const uint32_t cand = todo & live;
-      if (!cand) break;
-      // up to four of them per round trip.  With a bound: the own voxel and the lowest codes of the rest (nearly always
-      // the only batch).  Without: the own voxel alone first (its scan prunes most neighbours), then the nearest class.
-      uint32_t pool;
-      if (cand & (1u << 13)) pool = bounded ? cand : (1u << 13);
-      else pool = (cand & kFaces) ? (cand & kFaces) : ((cand & kEdges) ? (cand & kEdges) : cand);
-      int code[4];
-      uint32_t pick = 0;
-      if (pool & (1u << 13)) {  // own voxel first in the batch
-        code[0] = 13;
-        pick = 1u << 13;
-      } else {
-        code[0] = __builtin_ctz(pool);
-        pick = 1u << code[0];
-      }
-#pragma unroll
-      for (int v = 1; v < 4; v++) {
-        const uint32_t rest = pool & ~pick;
-        code[v] = rest ? __builtin_ctz(rest) : -1;
-        pick |= rest ? (1u << code[v]) : 0u;
-      }
-      todo &= ~pick;
-      unsigned long long key[4];
-      u32x4 sl[4];
-#pragma unroll
-      for (int v = 0; v < 4; v++) {
-        key[v] = nn_key_of(kbase, code[v] < 0 ? 13 : code[v]);
-        sl[v] = slots4[hash_key(key[v]) & m.mask];  // unconditional: four probes in flight
-      }
-#pragma unroll
-      for (int v = 0; v < 4; v++) {
-        uint32_t f, n;
-        nn_resolve(m, slots4, key[v], sl[v], code[v] >= 0, f, n);
-        nn_scan_lane<W>(pts4, f, n, qx, qy, qz, best, brec);
-      }
-    }
-    if (!bounded || nnkey_idx(best) != 0xFFFFFFFFu) break;
-    // the bound was not attained inside the block (the point moved more than a voxel away from its old partner): once
-    // more, without it
-    best = kNNKeyNone;
-    bounded = false;
-  }
-  if (nnkey_idx(best) != 0xFFFFFFFFu) {
-    r.pt = brec;
-    r.d2 = nnkey_d2(best);
-    r.found = true;
-  }
-  return r;
-}
-
-// -------------------------------------------------------------------------------------------------
-// Sixteen lanes (a DPP row) per scan point: the search for SMALL layers (the real pipeline's decimated_for_icp,
-// 1-8 k points).  There the device is nearly empty and a launch costs what its slowest lane's chain of dependent
-// round trips costs, so the row spends bandwidth to shorten the chain:
-//   round 1   all 27 slots of the block at once (lane r probes codes r and r + 16)
-//   round 2   the own voxel's records, two per lane
-//   round 3+  the neighbours that survive the bound, four voxels per round trip (their slots are already known),
-//             merged record ranges as in the quad kernel; typically one round
-// and the usual exact (d2, record index) key, reduced over the row with DPP row shifts.  Same result, bit for bit.
-// -------------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ uint32_t row_dpp_keep(uint32_t old, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);

@@ -160,10 +160,7 @@ class Parameterizable {
 // ---------------------------------------------------------------- device handles
 class DeviceContext {  // one HIP device + stream (mh_ctx)
  public:
-  // priority: MH_PRIORITY_LOW / NORMAL / HIGH (include/molahip.h) -- the class of the context's stream
-  explicit DeviceContext(int device = 0, int priority = 0);
-  // a context restricted to the compute units [first_cu, first_cu + n_cus) (mh_ctx_create_on_cus)
-  DeviceContext(int device, unsigned first_cu, unsigned n_cus);
+  explicit DeviceContext(int device = 0);
   ~DeviceContext();
   DeviceContext(const DeviceContext&) = delete;
   mh_ctx* get() const { return ctx_; }

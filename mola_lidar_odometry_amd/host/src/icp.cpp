@@ -11,7 +11,6 @@
 #include <mutex>
 
 #include "mp2p_icp_hip/mp2p_icp_hip.h"
-#include "molahip_host/fibers.h"
 #include "molahip_host/hook_replay.h"
 #include "molahip_host/plugin_switches.h"
 
@@ -151,14 +150,8 @@ void throw_status(mh_status s, const char* where) {
 }
 
 // ================================================================== device handles
-DeviceContext::DeviceContext(int device, int priority) : device_(device) {
-  if (priority == MH_PRIORITY_NORMAL) check(mh_ctx_create(device, nullptr, &ctx_), "mh_ctx_create");
-  else check(mh_ctx_create_with_priority(device, priority, &ctx_), "mh_ctx_create_with_priority");
-}
+DeviceContext::DeviceContext(int device) : device_(device) { check(mh_ctx_create(device, nullptr, &ctx_), "mh_ctx_create"); }
 void DeviceContext::synchronize() const { check(mh_ctx_synchronize(ctx_), "mh_ctx_synchronize"); }
-DeviceContext::DeviceContext(int device, unsigned first_cu, unsigned n_cus) : device_(device) {
-  check(mh_ctx_create_on_cus(device, first_cu, n_cus, &ctx_), "mh_ctx_create_on_cus");
-}
 DeviceContext::~DeviceContext() { mh_ctx_destroy(ctx_); }
 
 std::shared_ptr<DeviceContext> DeviceContext::Default() {
@@ -653,12 +646,6 @@ mh_status AlignBatcher::align(const void* owner, const mh_map* map, const mh_sca
     lk.unlock();
     run_batch(batch);
     lk.lock();
-  } else if (molahip_host::FiberScheduler::in_fiber()) {
-    // the participants are fibers of ONE thread (molahip_host/fibers.h): blocking on the condition variable would stop
-    // all of them -- let the others run until the fiber that completes the batch has run it
-    lk.unlock();
-    while (!rq.done) molahip_host::FiberScheduler::yield();
-    lk.lock();
   } else {
     cv_.wait(lk, [&] { return rq.done; });
   }
@@ -752,22 +739,13 @@ mh_status AlignBatcher::preprocess(const void* owner, size_t set, const mh_scan*
     const char* e = getenv("MOLA_HIP_FILTER_SET_WAIT_US");
     return e ? std::max(0, atoi(e)) : 2000;
   }());
-  const bool fiber = molahip_host::FiberScheduler::in_fiber();
-  const auto t0 = std::chrono::steady_clock::now();
   while (!rq.done) {
     if (!rq.taken && filter_set_ready_locked(rq.set)) {
       take_filter_sets_upto(lk, rq.set);
       continue;
     }
-    if (fiber) {
-      lk.unlock();
-      molahip_host::FiberScheduler::yield();
-      lk.lock();
-      if (rq.done || rq.taken || std::chrono::steady_clock::now() - t0 <= limit) continue;
-    } else {
-      const bool woke = cv_.wait_for(lk, limit, [&] { return rq.done || (!rq.taken && filter_set_ready_locked(rq.set)); });
-      if (woke || rq.taken) continue;
-    }
+    const bool woke = cv_.wait_for(lk, limit, [&] { return rq.done || (!rq.taken && filter_set_ready_locked(rq.set)); });
+    if (woke || rq.taken) continue;
     n_pp_timeouts_++;  // nobody completed the set in time: everything up to this request's set runs now
     take_filter_sets_upto(lk, rq.set);
   }

@@ -1,7 +1,6 @@
 // lidar_odometry.cpp -- see mola_lidar_odometry_hip/LidarOdometry.h.  Control logic only: the arithmetic on points
 // is behind include/molahip.h.  Citations are module/src/LidarOdometry.cpp unless another file is named.
 #include "mola_lidar_odometry_hip/LidarOdometry.h"
-#include "molahip_host/fibers.h"
 #include "molahip_host/plugin_switches.h"
 
 #include <chrono>
@@ -338,9 +337,7 @@ struct LidarOdometry::Prefetch {
   int slot = 0;               // which of the two prefetch sets the worker fills / filled
   mh_preprocess_params pp{};  // the filter parameters the worker used
   // the worker: ONE thread that lives as long as the driver and takes a task per scan (a std::async per scan created a
-  // thread per scan: ~20 us of the main thread's time right before its alignment) -- or, when this driver itself runs
-  // as a fiber of a FiberScheduler, another fiber of the same thread (no second thread in the HIP runtime; the worker's
-  // waits for the filter counts yield)
+  // thread per scan: ~20 us of the main thread's time right before its alignment)
   struct Worker {
     std::thread th;
     std::mutex m;
@@ -392,13 +389,8 @@ struct LidarOdometry::Prefetch {
     }
   } worker;
   bool on_worker = false;
-  molahip_host::FiberScheduler::Handle done_fiber;
   void join() {
-    if (done_fiber.valid()) {
-      molahip_host::FiberScheduler::Handle h = done_fiber;
-      done_fiber = molahip_host::FiberScheduler::Handle();
-      h.wait();
-    } else if (on_worker) {
+    if (on_worker) {
       on_worker = false;
       worker.wait();
     }
@@ -603,19 +595,11 @@ void LidarOdometry::launch_prefetch() {
   }
   pf_->in = pf_->req;
   if (!ctx_b_) {
-    // the next scan's upload and filters run beside the current alignment on a stream of their own.  A stream of the LOW
-    // class (MOLA_HIP_PREFETCH_PRIORITY=-1) was measured and lost: 8 sequences 2180 scans/s against 2870, one sequence
-    // 1.05 ms per scan against 0.99 -- the prepared layers arrive later and the alignment's kernels are not faster for it
-    const char* pe = getenv("MOLA_HIP_PREFETCH_PRIORITY");
-    // ... and neither is a stream restricted to a quarter or an eighth of the compute units (MOLA_HIP_PREFETCH_CUS=first:count,
-    // mh_ctx_create_on_cus): 8 sequences 4530-4650 scans/s against 4780, the lock-step alignment beside it 1.23-1.26 ms
-    // against 1.19 -- whatever the filters and uploads take from the alignment's kernels, it is not wave slots
-    const char* pc = getenv("MOLA_HIP_PREFETCH_CUS");
-    unsigned first_cu = 0, n_cus = 0;
-    if (pc && sscanf(pc, "%u:%u", &first_cu, &n_cus) == 2 && n_cus > 0)
-      ctx_b_ = std::make_shared<DeviceContext>(ctx_->device(), first_cu, n_cus);
-    else
-      ctx_b_ = std::make_shared<DeviceContext>(ctx_->device(), pe ? atoi(pe) : (int)MH_PRIORITY_NORMAL);
+    // the next scan's upload and filters run beside the current alignment on a stream of their own.  (Measured in round 3 and
+    // removed in round 4: a stream of the LOW priority class -- 8 sequences 2180 scans/s against 2870 -- and a stream
+    // restricted to a quarter or an eighth of the compute units -- 4530-4650 against 4780: whatever the filters and uploads
+    // take from the alignment's kernels, it is neither dispatch priority nor wave slots.)
+    ctx_b_ = std::make_shared<DeviceContext>(ctx_->device());
     for (int i = 0; i < 2; i++) {
       raw_b_[i] = std::make_shared<DevicePointCloud>(ctx_b_);
       map_skewed_b_[i] = std::make_shared<DevicePointCloud>(ctx_b_);
@@ -662,11 +646,8 @@ void LidarOdometry::launch_prefetch() {
       throw;
     }
   };
-  if (molahip_host::FiberScheduler::in_fiber()) pf_->done_fiber = molahip_host::FiberScheduler::current()->spawn(work);
-  else {
-    pf_->worker.submit(work);
-    pf_->on_worker = true;
-  }
+  pf_->worker.submit(work);
+  pf_->on_worker = true;
   pf_->launched = true;
   pf_->requested = false;
 }

@@ -40,7 +40,6 @@
 
 #include "mola_lidar_odometry_hip/LidarOdometry.h"
 #include "molahip.h"
-#include "molahip_host/fibers.h"
 
 namespace {
 
@@ -163,101 +162,6 @@ void list_sequence(const std::string& seq_dir, long max_scans, std::vector<std::
   while (stamps.size() < files.size()) stamps.push_back(0.1 * (double)stamps.size());  // 10 Hz when times.txt is absent
 }
 
-// --fibers: every sequence is a fiber of the ONE thread that talks to the HIP runtime (molahip_host/fibers.h).  Its scans
-// are read ahead by a plain reader thread (no HIP calls) into a ring of page-locked buffers, so that the uploads are
-// asynchronous copies; a buffer is handed back once the scan AFTER its own has been registered.
-struct SequenceFeed {
-  static constexpr size_t kDepth = 4;
-  std::vector<std::string> files;
-  void* buf[kDepth] = {nullptr, nullptr, nullptr, nullptr};
-  size_t n_floats[kDepth] = {0, 0, 0, 0};
-  size_t cap_bytes = 0;
-  std::atomic<size_t> read_upto{0}, consumed{0};
-  std::atomic<bool> failed{false}, stop{false};
-  std::string error;
-  std::thread th;
-  void start() {
-    for (const auto& f : files) {
-      struct stat st;
-      if (stat(f.c_str(), &st) == 0 && (size_t)st.st_size > cap_bytes) cap_bytes = (size_t)st.st_size;
-    }
-    for (size_t i = 0; i < kDepth; i++)
-      if (mh_host_alloc_pinned(cap_bytes ? cap_bytes : 16, &buf[i]) != MH_OK) throw std::runtime_error(std::string("pinned buffer: ") + mh_last_error_string());
-    th = std::thread([this] {
-      for (size_t k = 0; k < files.size(); k++) {
-        while (!stop && k >= consumed.load(std::memory_order_acquire) + kDepth) std::this_thread::sleep_for(std::chrono::microseconds(100));  // (a full ring: nothing to do for a scan's time)
-        if (stop) return;
-        FILE* f = fopen(files[k].c_str(), "rb");
-        size_t got = 0;
-        if (f) {
-          got = fread(buf[k % kDepth], 1, cap_bytes, f);
-          fclose(f);
-        }
-        if (!f || got % 16 != 0) {
-          error = files[k] + ": not a sequence of float32 x,y,z,intensity rows";
-          failed = true;
-          read_upto.store(files.size(), std::memory_order_release);
-          return;
-        }
-        n_floats[k % kDepth] = got / 4;
-        read_upto.store(k + 1, std::memory_order_release);
-      }
-    });
-  }
-  ~SequenceFeed() {
-    stop = true;
-    if (th.joinable()) th.join();
-    for (void* b : buf) (void)mh_host_free_pinned(b);
-  }
-};
-
-void run_sequence_fiber(const std::string& pipeline, const std::string& seq_dir, const std::string& out, int device, const RunOptions& opt,
-                        std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher, SequenceReport& rep) {
-  rep.seq_dir = seq_dir;
-  rep.out = out;
-  rep.device = device;
-  const long max_scans = opt.max_scans;
-  mp2p_icp_hip::AlignBatcher::Membership member(batcher);  // leave() however this sequence ends
-  try {
-    SequenceFeed feed;
-    std::vector<double> stamps;
-    list_sequence(seq_dir, max_scans, feed.files, stamps);
-    feed.start();
-    mola_hip::LidarOdometry lo(std::make_shared<mp2p_icp_hip::DeviceContext>(device));
-    lo.initialize(mp2p_icp_hip::Config::FromYamlFile(pipeline));
-    lo.setInputPinned(true);
-    if (batcher) lo.setAlignBatcher(batcher);
-    const size_t n = feed.files.size();
-    for (size_t k = 0; k < n; k++) {
-      const size_t need = std::min(k + 2, n);  // this scan and the next one (announced to the prefetch)
-      while (feed.read_upto.load(std::memory_order_acquire) < need) molahip_host::FiberScheduler::yield();
-      if (feed.failed) throw std::runtime_error(feed.error);
-      const bool has_next = k + 1 < n;
-      const auto t0 = std::chrono::steady_clock::now();
-      if (has_next) lo.prefetchInterleaved(feed.buf[(k + 1) % SequenceFeed::kDepth], feed.n_floats[(k + 1) % SequenceFeed::kDepth] / 4, 16, 0, 4, 8, opt.time_field);
-      const auto& rec = lo.onLidarInterleaved(stamps[k], feed.buf[k % SequenceFeed::kDepth], feed.n_floats[k % SequenceFeed::kDepth] / 4, 16, 0, 4, 8, opt.time_field);
-      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      rep.seconds += dt;
-      rep.scan_seconds.push_back(dt);
-      if (k >= kWarmScans) {
-        rep.steady_seconds += dt;
-        rep.steady_scans++;
-      }
-      if (k + 1 == kWarmScans) lo.resetProfile();
-      rep.good += rec.icp_good ? 1 : 0;
-      rep.keyframes += rec.map_updated ? 1 : 0;
-      rep.iterations += rec.icp_iterations;
-      rep.scans++;
-      feed.consumed.store(k, std::memory_order_release);  // buffers of scans < k may be refilled (k + 1 is in flight)
-    }
-    lo.saveTrajectoryTUM(out);
-    rep.profile = lo.profile();
-    finish_report(lo, opt, rep);
-  } catch (const std::exception& e) {
-    rep.error = e.what();
-  }
-}
-
 // one sequence, start to end; with a batcher its alignments join those of the other sequences of the process
 void run_sequence(const std::string& pipeline, const std::string& seq_dir, const std::string& out, int device, const RunOptions& opt,
                   std::shared_ptr<mp2p_icp_hip::AlignBatcher> batcher, SequenceReport& rep) {
@@ -268,9 +172,10 @@ void run_sequence(const std::string& pipeline, const std::string& seq_dir, const
   const bool prefetch = opt.prefetch;
   mp2p_icp_hip::AlignBatcher::Membership member(batcher);  // leave() however this sequence ends
   try {
-    // (the page-locked read-ahead ring of the fiber mode was tried here as well: with asynchronous uploads the eight
-    // copies and the filter batch land on the alignment's first iterations -- 8 sequences 4000 scans/s against 4700, one
-    // sequence 0.89 ms per scan against 0.86 -- so the threads keep uploading from pageable memory)
+    // (a page-locked read-ahead ring with asynchronous uploads was tried here: the eight copies and the filter batch then land
+    // on the alignment's first iterations -- 8 sequences 4000 scans/s against 4700, one sequence 0.89 ms per scan against
+    // 0.86 -- so the threads keep uploading from pageable memory.  Round 3 also had a mode with every sequence a ucontext
+    // fiber of ONE host thread, --fibers: 2410-2650 scans/s for eight sequences against 4580-4920 with threads; removed.)
     std::vector<std::string> files;
     std::vector<double> stamps;
     list_sequence(seq_dir, max_scans, files, stamps);
@@ -354,9 +259,9 @@ int main(int argc, char** argv) {
   std::vector<std::string> seq_dirs;
   std::vector<int> devices;
   RunOptions opt;
-  bool print_profile = false, fibers = false, plan_only = false;
+  bool print_profile = false, plan_only = false;
   const char* usage = "usage: molahip-lo-cli --pipeline FILE.yaml --seq-dir DIR [--seq-dir DIR ...] --out FILE.tum [--device N | --devices 0,1,..|all] "
-                      "[--no-prefetch] [--max-scans N] [--profile] [--time-field BYTES] [--scan-log FILE|auto] [--plan-only] [--fibers]\n"
+                      "[--no-prefetch] [--max-scans N] [--profile] [--time-field BYTES] [--scan-log FILE|auto] [--plan-only]\n"
                       "  several --seq-dir: the sequences run together, one host thread each, the alignments of the sequences that share\n"
                       "  a GPU merged into lock-step batches; trajectories go to FILE_<k>.tum\n"
                       "  --devices: the sequences are spread over the listed GPUs (longest first onto the least loaded device)\n";
@@ -378,7 +283,6 @@ int main(int argc, char** argv) {
       else if (a == "--no-prefetch") opt.prefetch = false;
       else if (a == "--profile") print_profile = true;
       else if (a == "--plan-only") plan_only = true;
-      else if (a == "--fibers") fibers = true;
       else throw std::runtime_error("unknown argument " + a);
     } catch (const std::exception& e) {
       fprintf(stderr, "%s\n%s", e.what(), usage);
@@ -423,20 +327,7 @@ int main(int argc, char** argv) {
   std::vector<size_t> per_slot(D, 0);
   for (size_t k = 0; k < N; k++) per_slot[slot[k]]++;
   const auto t0 = std::chrono::steady_clock::now();
-  if (fibers) {
-    // ONE thread in the HIP runtime: the sequences (and their prefetch workers) are fibers of this thread (one device)
-    if (D > 1) {
-      fprintf(stderr, "--fibers runs on one device\n");
-      return 2;
-    }
-    molahip_host::FiberScheduler sched;
-    batchers[0] = N > 1 ? std::make_shared<mp2p_icp_hip::AlignBatcher>(N) : nullptr;
-    for (size_t k = 0; k < N; k++) {
-      const std::string o = N == 1 ? out : stem + "_" + std::to_string(k) + ".tum";
-      sched.spawn([&, k, o] { run_sequence_fiber(pipeline, seq_dirs[k], o, devices[0], opt, batchers[0], reps[k]); });
-    }
-    sched.run();
-  } else if (N == 1) {
+  if (N == 1) {
     run_sequence(pipeline, seq_dirs[0], out, devices[0], opt, nullptr, reps[0]);
   } else {
     // a batcher per device slot: the sequences of a slot advance together, the slots independently of each other

@@ -7,7 +7,6 @@
 
 #include "mola_lidar_odometry_hip/LidarOdometry.h"
 #include "mp2p_icp_hip/mp2p_icp_hip.h"
-#include "molahip_host/fibers.h"
 #include "molahip_host/plugin_switches.h"
 
 namespace py = pybind11;
@@ -48,33 +47,6 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
       .def("size", &Config::size)
       .def("asString", &Config::asString);
   m.def("evaluate_expression", &evaluate_expression);
-  // molahip_host::FiberScheduler (the one-thread multi-sequence runner's scheduler): `n` fibers that each append their id
-  // `rounds` times with a yield in between, fiber `thrower` throws after its first entry and a watcher fiber waits for it
-  // -> (order of the entries, what the watcher caught, context switches).  CPU-only self test.
-  m.def("fiber_selftest", [](int n, int rounds, int thrower) {
-    molahip_host::FiberScheduler sched(256 * 1024);
-    std::vector<int> order;
-    std::string caught;
-    std::vector<molahip_host::FiberScheduler::Handle> hs;
-    for (int i = 0; i < n; i++)
-      hs.push_back(sched.spawn([&, i] {
-        for (int r = 0; r < rounds; r++) {
-          order.push_back(i);
-          if (i == thrower && r == 0) throw std::runtime_error("fiber " + std::to_string(i));
-          molahip_host::FiberScheduler::yield();
-        }
-        if (i == 0) {  // a fiber may spawn another one while the scheduler runs
-          sched.spawn([&] { order.push_back(100); });
-        }
-      }));
-    if (thrower >= 0 && thrower < n)
-      sched.spawn([&] {
-        try { hs[thrower].wait(); } catch (const std::exception& e) { caught = e.what(); }
-      });
-    const bool outside = molahip_host::FiberScheduler::in_fiber();
-    sched.run();
-    return py::make_tuple(order, caught, sched.switches(), outside, molahip_host::FiberScheduler::current() == nullptr);
-  });
   // MOLA_HIP_* switches (molahip_host/plugin_switches.h, shared with the mp2p_icp adapter): re-read the environment, and
   // show what was read -- what the adapter would pass to the C ABI for an upstream `RobustKernel::<name>`
   m.def("reload_plugin_switches", [] { molahip_host::reload_plugin_switches(); });

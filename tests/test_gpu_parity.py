@@ -253,7 +253,7 @@ def test_align_ndt_pipeline_skipping_plane_paired_points(ctx, oracle, inner, mat
     both = oracle.icp_align(o, scan, guess, oracle.ICPParams(gn=oracle.GNParams(max_inner_iterations=inner), **kw), want_pairs=True)
     n_pt = b["n_final_pairs"] - b["n_final_pairs_pt2pl"]
     assert 0 < n_pt < both["n_final_pairs"] - both["n_final_pairs_pt2pl"]  # the switch does change the pairing set
-    assert np.abs(a["T"] - I12).max() < 5e-3
+    assert np.abs(a["T"] - I12).max() < 2e-2  # (a noisy re-sampling of the cloud: registered to within its noise)
 
 
 # ---------------------------------------------------------------------------- NN / matcher
@@ -776,118 +776,6 @@ def test_batch_pairs_block_with_a_trivial_first_job(ctx):
         c.close()
 
 
-@pytest.mark.parametrize("n_scan", [1, 37, 511, 512, 513, 1024, 1500, 2048, 2049])
-def test_one_workgroup_alignment_kernel(ctx, oracle, n_scan, monkeypatch):
-    """k_icp_persist (opt-in, MH_PERSIST=1: measured slower than the default chain, kept as a tested alternative): the whole
-    alignment of a layer of <= 2048 points in one workgroup and one launch against the oracle -- iteration count,
-    termination, pairings and d2 bit for bit, pose to 1e-9 -- and against the default launch-per-step chain: the same
-    pairings, poses within 1e-12.  Sizes around the lanes-per-workgroup and points-per-lane boundaries; 2049 is past the
-    limit (the row-kernel chain either way)."""
-    monkeypatch.setenv("MH_PERSIST", "1")
-    w = synth.make_workload("t", 60000, 32, 400, 80.0, 25, variant=3)
-    g = capi.Map(ctx, 1.0, 20).build(w.map_xyz)
-    o = oracle.Map(1.0, 20).insert(w.map_xyz)
-    rng = np.random.default_rng(n_scan)
-    scan = w.scan_xyz[rng.permutation(len(w.scan_xyz))[:n_scan]]
-    thr, kp = synth.threshold_schedule(2.0, 60)
-    kw = dict(max_iterations=60, threshold=thr, kernel_param=kp)
-    a = capi.icp_align(g, capi.Scan(ctx, scan), w.T_guess, capi.ICPParams(**kw), want_trace=True, want_pairs=True)
-    b = oracle.icp_align(o, scan, w.T_guess, oracle.ICPParams(**kw), want_pairs=True)
-    if n_scan >= 6:  # (fewer points: rank-deficient normal equations, the pivoted solve amplifies the last bit of the sums)
-        assert (a["n_iterations"], a["termination_reason"], a["n_final_pairs"]) == (b["n_iterations"], b["termination_reason"], b["n_final_pairs"])
-        np.testing.assert_allclose(a["T"], b["T"], rtol=0, atol=1e-9)
-        for k in ("local_idx", "global_idx", "d2"):
-            np.testing.assert_array_equal(a["pairs"][k], b["pairs"][k])
-        np.testing.assert_allclose(a["cov"], b["cov"], rtol=2e-5, atol=1e-6 * np.abs(b["cov"]).max())
-    assert a["n_host_polls"] == 1 or n_scan > 2048  # one launch, one poll
-    monkeypatch.delenv("MH_PERSIST")
-    c = capi.icp_align(g, capi.Scan(ctx, scan), w.T_guess, capi.ICPParams(**kw), want_trace=True, want_pairs=True)
-    assert (a["n_iterations"], a["termination_reason"], a["n_final_pairs"]) == (c["n_iterations"], c["termination_reason"], c["n_final_pairs"])
-    np.testing.assert_allclose(a["T"], c["T"], rtol=0, atol=1e-12)
-    for k in ("local_idx", "global_idx", "d2"):
-        np.testing.assert_array_equal(a["pairs"][k], c["pairs"][k])
-    assert len(a["trace"]) == len(c["trace"])
-    for ta, tc in zip(a["trace"], c["trace"]):
-        assert ta["n_pairs"] == tc["n_pairs"]
-        np.testing.assert_allclose(ta["T"], tc["T"], rtol=0, atol=1e-12)
-
-
-def test_one_workgroup_kernel_in_batches(ctx, monkeypatch):
-    """A batch of small layers = ONE launch of one workgroup per job, each running to its own end (ragged sizes, per-job
-    budgets / schedules / hooks / priors, a trivial job in between): bitwise the single alignments, pairs block included.
-    (Opt-in kernel: MH_PERSIST=1.)"""
-    monkeypatch.setenv("MH_PERSIST", "1")
-    ws = [synth.make_workload("t", 60000, 32, 400, 80.0, 25, variant=v) for v in range(4)]
-    maps = [capi.Map(ctx, 1.0, 20).build(w.map_xyz) for w in ws]
-    sizes = [700, 0, 2048, 130, 1025]
-    rng = np.random.default_rng(9)
-    subs = [ws[k % 4].scan_xyz[rng.permutation(len(ws[k % 4].scan_xyz))[:n]] for k, n in enumerate(sizes)]
-    jm = [maps[k % 4] for k in range(len(sizes))]
-    guesses = [ws[k % 4].T_guess for k in range(len(sizes))]
-    ps = []
-    for k in range(len(sizes)):
-        thr, kp = synth.threshold_schedule(1.5 + 0.3 * k, 50 - 7 * k)
-        ps.append(capi.ICPParams(max_iterations=50 - 7 * k, threshold=thr, kernel_param=kp, hook_enabled=(k == 3),
-                                 gn=capi.GNParams(max_inner_iterations=1 + k % 3)))
-    prior = (guesses[2], np.eye(6) * 50.0)
-    priors = [None, None, prior, None, None]
-    singles = [capi.icp_align(m, capi.Scan(ctx, sub), g, p, prior=pr, want_trace=False, want_pairs=True)
-               for m, sub, g, p, pr in zip(jm, subs, guesses, ps, priors)]
-    assert singles[3]["termination_reason"] == 6  # the device hook fired
-    ctxs = [capi.Context(0) for _ in sizes]
-    scans = [capi.Scan(c, sub) for c, sub in zip(ctxs, subs)]
-    nbytes = sum(capi.pairs_block_bytes(n) for n in sizes)
-    block = np.zeros(nbytes, np.uint8)
-    res = capi.icp_align_batch(jm, scans, guesses, ps, priors=priors, pairs_block=block)
-    for a, r, pr in zip(singles, res, capi.unpack_pairs_block(block, sizes, res)):
-        assert (r["n_iterations"], r["termination_reason"], r["n_final_pairs"]) == (a["n_iterations"], a["termination_reason"], a["n_final_pairs"])
-        assert np.array_equal(r["T"], a["T"]) and np.array_equal(r["cov"], a["cov"]) and r["quality"] == a["quality"]
-        for k in ("local_idx", "global_idx", "global_xyz", "d2"):
-            assert np.array_equal(pr[k], a["pairs"][k]), k
-    assert all(r["n_host_polls"] <= 1 for r in res)
-    for c in ctxs:
-        c.close()
-
-
-@pytest.mark.parametrize("inner", [1, 2, 3])
-def test_fused_inner_steps_kernel(ctx, inner, monkeypatch):
-    """k_accum_solveN (opt-in, MH_FUSED_INNER=1: all inner Gauss-Newton steps of an iteration in one launch; measured
-    slower than a launch per step, kept as a tested alternative): plain and NDT layers, single and in a batch, against the
-    default chain -- same iterations, termination and pairings, poses within 1e-12; batch bitwise the singles."""
-    pts = _ndt_cloud(31)
-    rng = np.random.default_rng(32)
-    w = synth.make_workload("t", 60000, 32, 400, 80.0, 25, variant=5)
-    jobs = []  # (device map, scan, guess, params)
-    thr, kp = synth.threshold_schedule(1.0, 40)
-    g_plain = capi.Map(ctx, 1.0, 20).build(w.map_xyz)
-    jobs.append((g_plain, w.scan_xyz[rng.permutation(len(w.scan_xyz))[:900]], w.T_guess,
-                 capi.ICPParams(max_iterations=40, threshold=thr * 2, kernel_param=kp * 2, gn=capi.GNParams(max_inner_iterations=inner))))
-    g_ndt = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts)
-    guess = np.array([1, 0, 0, 0.1, 0, 1, 0, -0.07, 0, 0, 1, 0.05], np.float64)
-    for n in (1500, 700):
-        jobs.append((g_ndt, pts[rng.permutation(len(pts))[:n]], guess,
-                     capi.ICPParams(max_iterations=40, min_abs_step_trans=5e-4, min_abs_step_rot=5e-4, threshold=thr, kernel_param=kp,
-                                    pt2pl_threshold=0.5, gn=capi.GNParams(max_inner_iterations=inner))))
-    ref = [capi.icp_align(m, capi.Scan(ctx, sc), g, p, want_trace=False, want_pairs=True) for m, sc, g, p in jobs]
-    monkeypatch.setenv("MH_FUSED_INNER", "1")
-    got = [capi.icp_align(m, capi.Scan(ctx, sc), g, p, want_trace=False, want_pairs=True) for m, sc, g, p in jobs]
-    for a, b in zip(got, ref):
-        assert (a["n_iterations"], a["termination_reason"], a["n_final_pairs"], a["n_final_pairs_pt2pl"]) == (
-            b["n_iterations"], b["termination_reason"], b["n_final_pairs"], b["n_final_pairs_pt2pl"])
-        np.testing.assert_allclose(a["T"], b["T"], rtol=0, atol=1e-12)
-        np.testing.assert_array_equal(a["pairs"]["global_idx"], b["pairs"]["global_idx"])
-    assert got[1]["n_final_pairs_pt2pl"] > 0
-    # two NDT jobs in one batch (the lock-step form of the fused kernel) + the plain pair
-    ctxs = [capi.Context(0) for _ in range(4)]
-    order = [1, 2, 0, 0]
-    scans = [capi.Scan(c, jobs[k][1]) for c, k in zip(ctxs, order)]
-    res = capi.icp_align_batch([jobs[k][0] for k in order], scans, [jobs[k][2] for k in order], [jobs[k][3] for k in order])
-    for r, k in zip(res, order):
-        assert np.array_equal(r["T"], got[k]["T"]) and r["n_iterations"] == got[k]["n_iterations"] and np.array_equal(r["cov"], got[k]["cov"])
-    for c in ctxs:
-        c.close()
-
-
 def test_align_is_bitwise_reproducible(ctx, small):
     w, gm, om, gs = small
     p = _params(capi, w, disable_stall_test=True)
@@ -969,7 +857,7 @@ def test_previous_pairing_bound_and_its_fallback(ctx, oracle, vs, shift, monkeyp
         np.testing.assert_allclose(g["T"], o["T"], rtol=0, atol=1e-9)
 
 
-@pytest.mark.parametrize("n_scan,env", [(900, {}), (900, {"MH_FUSED_INNER": "1"}), (3000, {}), (3000, {"MH_NO_FUSE16": "1"}), (3000, {"MH_MATCH": "p"}),
+@pytest.mark.parametrize("n_scan,env", [(900, {}), (3000, {}), (3000, {"MH_NO_FUSE16": "1"}), (3000, {"MH_MATCH": "p"}),
                                         (9000, {}), (20000, {})])
 def test_converged_alignment_with_early_inner_exit(ctx, oracle, n_scan, env, monkeypatch):
     """Stall test off and far more iterations than the alignment needs: once the Gauss-Newton step falls below min_delta

@@ -134,28 +134,6 @@ def test_preprocess_batch_equals_single_calls(ctx, oracle, small_workload):
         c.close()
 
 
-def test_context_priority_classes(small_workload):
-    """mh_ctx_create_with_priority: a stream of the low / high class works like any other; a bad class is refused"""
-    for prio in (capi.PRIORITY_LOW, capi.PRIORITY_HIGH):
-        c = capi.Context(0, priority=prio)
-        s = capi.Scan(c, small_workload.scan_xyz)
-        np.testing.assert_array_equal(s.download()["xyz"], small_workload.scan_xyz)
-        c.close()
-    with pytest.raises(capi.MolahipError):
-        capi.Context(0, priority=7)
-    # a stream restricted to a range of compute units (mh_ctx_create_on_cus): same results; a range outside the device is refused
-    c = capi.Context(0, cus=(0, 32))
-    s = capi.Scan(c, small_workload.scan_xyz)
-    om = capi.Scan(c)
-    s.preprocess(capi.preprocess_params(0.4, 0.0, min_points_to_filter=10), om, None)
-    ref = capi.Context(0)
-    s2, om2 = capi.Scan(ref, small_workload.scan_xyz), capi.Scan(ref)
-    s2.preprocess(capi.preprocess_params(0.4, 0.0, min_points_to_filter=10), om2, None)
-    np.testing.assert_array_equal(om.download()["src_idx"], om2.download()["src_idx"])
-    c.close()
-    ref.close()
-    with pytest.raises(capi.MolahipError):
-        capi.Context(0, cus=(100000, 8))
 
 
 def test_deskew(ctx, oracle, small_workload):
@@ -226,13 +204,11 @@ def _assert_maps_equal(g, o):
         np.testing.assert_array_equal(g[k], o[k], err_msg=k)
 
 
-@pytest.mark.parametrize("vs,cap,far,side", [(1.0, 20, 0.0, 0), (1.0, 20, 45.0, 0), (0.5, 4, 30.0, 0), (1.0, 20, 45.0, 1)])
-def test_map_insert_keyframes_bit_exact(ctx, oracle, vs, cap, far, side, monkeypatch):
+@pytest.mark.parametrize("vs,cap,far", [(1.0, 20, 0.0), (1.0, 20, 45.0), (0.5, 4, 30.0)])
+def test_map_insert_keyframes_bit_exact(ctx, oracle, vs, cap, far):
     """A drive of key-frames: every update (posed insertion after the stored content, cap, far-voxel removal)
     leaves exactly the voxel contents and source indices of the per-point CPU insertion.  The update is asynchronous
-    (counts read back lazily by info() / download(); side = 1: on the map's own stream, MH_MAP_SIDE_STREAM)."""
-    if side:
-        monkeypatch.setenv("MH_MAP_SIDE_STREAM", "1")
+    (counts read back lazily by info() / download())."""
     scene = synth.make_scene(777, 80.0, 12)
     g, o = capi.Map(ctx, vs, cap), oracle.Map(vs, cap)
     offered = 0

@@ -303,16 +303,6 @@ def test_generate_debug_files_writes_the_iteration_trace(hl, oracle, small_workl
     assert len(os.listdir(tmp_path / "logs")) == 2
 
 
-def test_fiber_scheduler_round_robin_and_exceptions():
-    """molahip_host::FiberScheduler (CPU): cooperative round robin on one thread, a fiber spawned by a fiber, an exception
-    that surfaces in the fiber that waits for the thrower, nothing left installed afterwards."""
-    from mola_lidar_odometry_amd import _mp2p_icp_hip as h
-    order, caught, switches, outside, clean = h.fiber_selftest(3, 4, -1)
-    assert order[:12] == [0, 1, 2] * 4 and order[12:] == [100] and caught == "" and switches == 12 and not outside and clean
-    order, caught, _, _, clean = h.fiber_selftest(3, 3, 1)
-    assert order == [0, 1, 2, 0, 2, 0, 2, 100] and caught == "fiber 1" and clean
-
-
 # ------------------------------------------------------------------------------------------ matcher generality (a7)
 _NEAR_FAR_ICP = """
 class_name: mp2p_icp::ICP

@@ -476,27 +476,6 @@ def test_sequences_in_one_process_share_lockstep_batches(host, tmp_path):
         r1 = subprocess.run([exe, "--pipeline", PIPE, "--seq-dir", d, "--out", one], capture_output=True, text=True, timeout=300)
         assert r1.returncode == 0, r1.stderr
         assert open(one).read() == open(str(tmp_path / ("multi_%d.tum" % k))).read()
-    # and with every sequence a FIBER of one host thread (molahip_host/fibers.h; libmolahip's waits yield through
-    # mh_set_wait_hook, scans read ahead into page-locked buffers, asynchronous uploads): the same files again --
-    # sequences of different lengths, so fibers finish at different times, and the NDT pipeline as well
-    args_f = [exe, "--fibers", "--pipeline", PIPE, "--out", str(tmp_path / "fib.tum")]
-    for d in dirs:
-        args_f += ["--seq-dir", d]
-    r = subprocess.run(args_f, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr
-    for k in range(len(dirs)):
-        assert open(str(tmp_path / ("fib_%d.tum" % k))).read() == open(str(tmp_path / ("solo%d.tum" % k))).read()
-    r = subprocess.run([exe, "--fibers", "--pipeline", PIPE, "--seq-dir", dirs[0], "--out", str(tmp_path / "fib1.tum")],
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr
-    assert open(str(tmp_path / "fib1.tum")).read() == open(str(tmp_path / "solo0.tum")).read()
-    r_n = subprocess.run([exe, "--pipeline", PIPE_NDT, "--seq-dir", dirs[0], "--seq-dir", dirs[2], "--out", str(tmp_path / "ndt_t.tum")],
-                         capture_output=True, text=True, timeout=300)
-    r_f = subprocess.run([exe, "--fibers", "--pipeline", PIPE_NDT, "--seq-dir", dirs[0], "--seq-dir", dirs[2], "--out", str(tmp_path / "ndt_f.tum")],
-                         capture_output=True, text=True, timeout=300)
-    assert r_n.returncode == 0 and r_f.returncode == 0, r_n.stderr + r_f.stderr
-    for k in range(2):
-        assert open(str(tmp_path / ("ndt_t_%d.tum" % k))).read() == open(str(tmp_path / ("ndt_f_%d.tum" % k))).read()
 
 
 @pytest.mark.gpu

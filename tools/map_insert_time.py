@@ -1,6 +1,6 @@
 """Cost of one key-frame update (mh_map_insert) as a function of the stored map size: what the CALLER pays (the call returns
 once the update is queued on the map's own stream) and when the update is complete (mh_map_get_info waits for its
-counters).  MH_MAP_SIDE_STREAM=1 puts the update on a stream of the map's own."""
+counters)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -30,4 +30,4 @@ m = capi.Map(ctx, 1.0, 20).build(w.map_xyz); ctx.synchronize(); t0 = time.perf_c
 m.build(w.map_xyz); ctx.synchronize()
 full = 1e3 * (time.perf_counter() - t0)
 print("full build of 1 M host points (incl. 12 MB upload): %.3f ms" % full)
-print(json.dumps({"map_insert_10k_points": rows, "full_build_1M_ms": full, "side_stream": os.environ.get("MH_MAP_SIDE_STREAM", "0")}))
+print(json.dumps({"map_insert_10k_points": rows, "full_build_1M_ms": full}))

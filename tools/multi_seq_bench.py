@@ -1,7 +1,5 @@
 """Several sequences on ONE GPU from ONE process (molahip-lo-cli with several --seq-dir) against the same sequence alone:
-  threads (default)  a host thread per sequence, alignments merged into lock-step batches (mp2p_icp_hip::AlignBatcher);
-  --fibers           every sequence a fiber of ONE thread (molahip_host/fibers.h): no contention for the HIP runtime, but
-                     every launch of every sequence is issued by that one thread.
+a host thread per sequence, alignments merged into lock-step batches (mp2p_icp_hip::AlignBatcher).
 Writes the synthetic drive (HDL-64-like sweeps of ~120 k points) as a KITTI tree under a temporary directory once and points
 N sequence folders at it.   python tools/multi_seq_bench.py [scans] [1,2,4,8,16] [pipeline.yaml]"""
 import json
@@ -16,8 +14,8 @@ import bench  # noqa: E402  (generate_inputs: the drive's sweeps cast in worker 
 from mola_lidar_odometry_amd import synth_city  # noqa: E402
 
 
-def run(seq, n, fibers, pipeline, tmp):
-    cmd = [bench.CLI, "--pipeline", pipeline, "--out", os.path.join(tmp, "%s%d.tum" % ("f" if fibers else "t", n)), "--profile", "--time-field", "12"] + (["--fibers"] if fibers else [])
+def run(seq, n, pipeline, tmp):
+    cmd = [bench.CLI, "--pipeline", pipeline, "--out", os.path.join(tmp, "t%d.tum" % n), "--profile", "--time-field", "12"]
     for _ in range(n):
         cmd += ["--seq-dir", seq]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
@@ -40,11 +38,11 @@ def main():
     pipeline = sys.argv[3] if len(sys.argv) > 3 else bench.PIPELINE
     tmp = tempfile.mkdtemp(prefix="molahip_multi_")
     seq, _ = synth_city.write_kitti_drive(tmp, n_scans, time_channel=True)  # the city drive of bench.py's extras
-    out = {"pipeline": os.path.basename(pipeline), "scans_per_sequence": n_scans, "threads": {}, "fibers": {}}
+    out = {"pipeline": os.path.basename(pipeline), "scans_per_sequence": n_scans, "threads": {}}
     solo = None
-    for mode, fib in (("threads", False), ("fibers", True)):
+    for mode in ("threads",):
         for n in counts:
-            r = run(seq, n, fib, pipeline, tmp)
+            r = run(seq, n, pipeline, tmp)
             if "error" not in r:
                 texts = [open(t).read() for t in r.pop("tums")]
                 solo = solo or texts[0]

@@ -1,5 +1,5 @@
 """Stress for the several-sequences-in-one-process runner: sequences of DIFFERENT lengths and drives (so that they leave the
-batcher at different times, re-align at different scans and sit out filter rounds), threads and --fibers, default and NDT
+batcher at different times, re-align at different scans and sit out filter rounds), default and NDT
 pipeline, repeated; every trajectory must be byte-identical to the sequence's solo run and no run may hang.
     python tools/stress_cli_sequences.py [repeats]"""
 import json
@@ -33,7 +33,7 @@ def main():
             assert r.returncode == 0, r.stderr
             solo.append(open(out).read())
         for rep in range(repeats):
-            for mode in ([], ["--fibers"]):
+            for mode in ([],):
                 order = dirs[rep % len(dirs):] + dirs[:rep % len(dirs)]
                 ref = solo[rep % len(dirs):] + solo[:rep % len(dirs)]
                 out = os.path.join(tmp, "m.tum")
