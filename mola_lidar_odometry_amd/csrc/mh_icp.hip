@@ -30,6 +30,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -58,6 +59,7 @@ struct IcpDeviceState {
   uint32_t n_pairs, n_iterations, solver_ok, n_solves;
   uint32_t cov_done, n_pairs_pl;
   float cur_thr2, cur_ang2;  // matcher threshold^2 of iteration `iter` and the angular term: k_match4 reads nothing but this block
+  uint32_t pending, pad_;    // k_step16: the partials of a Gauss-Newton step have been written and wait for their solve
   double cur_kparam;         // robust-kernel parameter of iteration `iter` (no dependent table look-up in k_accum*)
   double cov[36];
   double covD[72];  // (T(x+h_j) - T(x-h_j)) / (2 h_j), j = 0..5, 3x4 each
@@ -100,6 +102,9 @@ struct SolveK {
 struct IcpDeviceParams {
   MatchK mk;
   SolveK sk;
+  // k_loop16: [0] workgroups that have arrived at the grid barrier (monotonic over the steps of one alignment),
+  // [1] a workgroup gave up waiting.  A cache line of their own; zeroed by every upload of the block.
+  alignas(128) uint32_t loop_sync[32];
 };
 
 struct PoseArg {
@@ -111,6 +116,7 @@ struct PoseArg {
 // in a launch of sixteen scans' worth of points, 21.8 us alone (tools/batch_hypothesis.py).
 struct BatchJob {
   IcpDeviceState* st;
+  IcpDeviceState* st_b;  // k_step16_b: the other half of the state ping-pong
   const MatchK* mk;
   const SolveK* sk;
   const float *lx, *ly, *lz;
@@ -905,9 +911,16 @@ constexpr int kSolveThreads = 512;  // 2 waves per SIMD -> 256 VGPRs for the ser
 // Ordered sum of `nvals` rows of a [nvals][stride] array of per-block partials over n blocks, by the
 // whole block: G = blockDim/nvals lanes per row, 8 independent loads in flight per lane, then
 // a fixed-order LDS pass.  Shape depends only on (n, nvals) -> bitwise reproducible.
+// COHERENT: the partials were written by other workgroups of the SAME launch (k_loop16, after its grid barrier): agent-scope
+// loads, which the XCDs' L2s do not answer from a stale line.
+template <bool COHERENT = false>
+__device__ __forceinline__ double part_load(const double MH_AS_GLOBAL* p) {
+  if (COHERENT) return __hip_atomic_load((const double*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool COHERENT = false>
 __device__ __forceinline__ void reduce_rows(const double* __restrict__ part, uint32_t n, uint32_t stride, int nvals,
-                                            double* __restrict__ out, double (*red)[64]) {
-  const int t = threadIdx.x;
+                                            double* __restrict__ out, double (*red)[64], int t = (int)threadIdx.x) {
   int G = kSolveThreads / nvals;
   if (G > 64) G = 64;
   const int v = t / G, g = t % G;
@@ -916,11 +929,13 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ part, uin
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
     uint32_t b = g;
     for (; b + 7u * G < n; b += 8u * G) {  // 8 independent loads in flight per lane
-      const double v0 = src[b], v1 = src[b + G], v2 = src[b + 2u * G], v3 = src[b + 3u * G];
-      const double v4 = src[b + 4u * G], v5 = src[b + 5u * G], v6 = src[b + 6u * G], v7 = src[b + 7u * G];
+      const double v0 = part_load<COHERENT>(src + b), v1 = part_load<COHERENT>(src + b + G), v2 = part_load<COHERENT>(src + b + 2u * G),
+                   v3 = part_load<COHERENT>(src + b + 3u * G);
+      const double v4 = part_load<COHERENT>(src + b + 4u * G), v5 = part_load<COHERENT>(src + b + 5u * G),
+                   v6 = part_load<COHERENT>(src + b + 6u * G), v7 = part_load<COHERENT>(src + b + 7u * G);
       s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
     }
-    for (; b < n; b += G) s0 += src[b];
+    for (; b < n; b += G) s0 += part_load<COHERENT>(src + b);
     red[v][g] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   }
   __syncthreads();
@@ -952,11 +967,12 @@ struct SolveShared {
 // LDS_STATE: the state block lives in LDS (k_icp_persist keeps it there for the whole alignment) instead of global memory.
 // WAVE0: only the first wave of the workgroup calls (the totals are ready in LDS, nothing here needs the other waves): the
 // one workgroup barrier below becomes a wave-level hand-over.
-template <bool LDS_STATE = false, bool WAVE0 = false>
+template <bool LDS_STATE = false, bool WAVE0 = false, bool COHERENT = false>
 __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, const SolveK* __restrict__ kp_,
                                            const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                            const double* __restrict__ partB, uint32_t nB, uint32_t strideB,
-                                           SolveShared& sh, bool totA_ready = false, bool totB_ready = false) {
+                                           SolveShared& sh, bool totA_ready = false, bool totB_ready = false,
+                                           int lane = (int)threadIdx.x) {  // (k_loop16 passes a lane index the optimiser cannot hoist from)
   double (*red)[64] = sh.red;
   double* totA = sh.totA;
   double* totB = sh.totB;
@@ -966,11 +982,10 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, con
   const SolveK __attribute__((address_space(4)))& k = *(const SolveK __attribute__((address_space(4)))*)uniform_const_ptr(kp_);
   typedef typename std::conditional<LDS_STATE, IcpDeviceState __attribute__((address_space(3)))*, IcpDeviceState MH_AS_GLOBAL*>::type state_ptr;
   state_ptr const st = (state_ptr)st_;
-  const int lane = threadIdx.x;
   if (nA)
-    reduce_rows(partA, nA, strideA, kAccN, totA, red);
+    reduce_rows<COHERENT>(partA, nA, strideA, kAccN, totA, red, lane);
   if (nB)
-    reduce_rows(partB, nB, strideB, kGenN, totB, red);
+    reduce_rows<COHERENT>(partB, nB, strideB, kGenN, totB, red, lane);
   double a[kAccN], gen[kGenN];
 #pragma unroll
   for (int i = 0; i < kAccN; i++) a[i] = (nA || totA_ready) ? totA[i] : 0.0;
@@ -1337,6 +1352,371 @@ template <bool PL>
 __global__ __launch_bounds__(kSolveThreads) void k_accum_solve1_b(const BatchJob* __restrict__ jobs, uint32_t first) {
   const BatchJob& j = jobs[blockIdx.y];
   k_accum_solve1_body<PL>(j.st, first, j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.pair_q, j.pair_gidx, j.pl_c, j.pl_n);
+}
+
+// ================================================================================================
+// k_step16: the small-layer iteration with the solve CARRIED INTO THE NEXT LAUNCH (round 4).  The chain above spends a launch
+// of one workgroup on every Gauss-Newton step (k_match16 | k_accum_solve1 | k_accum_solve1: 28 us per ICP iteration of the
+// real pipeline's 1.2-1.6 k-point layer, of which the device computes for maybe a third).  Here every launch is the same
+// kernel over the whole layer, and what it does is decided by the state block alone:
+//   1. every workgroup copies the state block's head into LDS and, if a step is pending, closes it: the ordered sum of the
+//      per-workgroup partials of the previous launch + solve_body -- all workgroups compute the same bits, nobody waits for a
+//      hand-over; workgroup 0 writes the new state to the OTHER state block (the one this launch reads is never written)
+//      and publishes the progress word;
+//   2. body: at the start of an ICP iteration (inner == 0) the row search of k_match16 for 32 points per workgroup, the
+//      pairings stored and their Gauss-Newton sums written as this workgroup's partials (also ping-pong: other workgroups may
+//      still be reading the previous launch's); at an inner step the sums of the stored pairings under the new pose.
+// An ICP iteration is max_inner launches (2 in the shipped pipelines) instead of 1 + max_inner, none of them a single
+// workgroup, and a launch never idles because an iteration closed early: the next one simply starts in its place.
+// `close_only` (one workgroup, in place into the canonical block): the pending step at the end of a chunk of launches.
+// ================================================================================================
+constexpr uint32_t kStepPoints = kSolveThreads / 16;  // scan points (DPP rows) per workgroup
+constexpr uint32_t kStateHeadDwords = (uint32_t)(offsetof(IcpDeviceState, cov) / 4);  // everything the loop touches
+static_assert(kStateHeadDwords <= 64 && offsetof(IcpDeviceState, cov) % 8 == 0, "state head is copied by one wave");
+
+template <bool PL>
+__device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__ s_in, IcpDeviceState* s_out,
+                                              IcpDeviceState* s_canon, const MatchK* __restrict__ kp,
+                                              const SolveK* __restrict__ sk, const float* __restrict__ lx,
+                                              const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                              MapView map, float4* pair_q, uint32_t* pair_gidx, float4* pl_c, float4* pl_n,
+                                              const double* __restrict__ partA_in, double* __restrict__ partA_out,
+                                              const double* __restrict__ partB_in, double* __restrict__ partB_out,
+                                              uint32_t nwg, uint32_t close_only) {
+  __shared__ SolveShared sh;
+  __shared__ __attribute__((aligned(8))) uint32_t lst_raw[kStateHeadDwords];
+  __shared__ double rowsA[kAccN][kStepPoints + 1];
+  __shared__ double rowsB[PL ? kGenN : 1][kStepPoints + 1];
+  const uint32_t tid = threadIdx.x, wg = blockIdx.x;
+  if (wg >= nwg) return;  // (lock-step batches: the grid is the largest job's)
+  IcpDeviceState* const lst = reinterpret_cast<IcpDeviceState*>(lst_raw);
+  // the point of this row and what is stored for it -- the previous pairing bounds the search at an iteration start and IS the
+  // pairing at an inner step -- are on their way before the state is looked at
+  const uint32_t i = wg * kStepPoints + (tid >> 4), r16 = tid & 15u;
+  const uint32_t ic = i < n ? i : n - 1;
+  const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
+  const f32x4 stored = G(reinterpret_cast<const f32x4*>(pair_q))[ic];
+  MH_PHASE(0);
+  if (tid < kStateHeadDwords) lst_raw[tid] = G(reinterpret_cast<const uint32_t*>(s_in))[tid];
+  __syncthreads();
+  if (lst->done) {  // the loop has ended (the canonical block has it): keep the ping-pong consistent, nothing else
+    if (wg == 0 && tid < kStateHeadDwords && s_out != s_in) G(reinterpret_cast<uint32_t*>(s_out))[tid] = lst_raw[tid];
+    return;
+  }
+  MH_PHASE(1);
+  if (lst->pending) {
+    solve_body<true, false>(lst, sk, partA_in, nwg, nwg, PL ? partB_in : nullptr, PL ? nwg : 0u, PL ? nwg : 0u, sh);
+    __syncthreads();
+  }
+  const uint32_t done = lst->done;
+  const bool body = !done && !close_only;
+  if (wg == 0) {
+    if (tid == 0) lst->pending = body ? 1u : 0u;
+    __syncthreads();
+    if (tid < kStateHeadDwords) {
+      const uint32_t w = lst_raw[tid];
+      G(reinterpret_cast<uint32_t*>(s_out))[tid] = w;
+      if (done && s_canon != s_out) G(reinterpret_cast<uint32_t*>(s_canon))[tid] = w;
+    }
+    if (tid == 0) {
+      uint32_t* hp = sk->host_progress;
+      if (hp) __hip_atomic_store(hp, (lst->iter & 0x7FFFFFFFu) | (done ? 0x80000000u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  MH_PHASE(11);
+  if (!body) return;
+  MH_PHASE(14);
+
+  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
+  typedef const double __attribute__((address_space(4))) * cf64_ptr;
+  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
+  const uint32_t inner = lst->inner, iter = lst->iter;
+  double T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = lst->T[k];
+  const float thr2 = lst->cur_thr2, ang2 = lst->cur_ang2;
+  const double kparam = lst->cur_kparam;
+  const uint32_t kernel = ck->kernel;
+  Acc a;
+  acc_zero(a);
+  double v[PL ? kGenN : 1];
+#pragma unroll
+  for (int j = 0; j < (PL ? kGenN : 1); j++) v[j] = 0.0;
+  if (i < n) {  // row-uniform
+    f32x4 q = stored, bc = (f32x4){0.f, 0.f, 0.f, 0.f}, bn = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool ok, okp = false;
+    if (inner == 0) {  // (workgroup-uniform) a new ICP iteration: the matchers
+      float px, py, pz;
+      transform_point(T, x, y, z, px, py, pz);
+      float bound0 = __builtin_inff();
+      if (iter > 0 && !map.no_prev_bound && stored.w < __builtin_inff()) {
+        const float dx = stored.x - px, dy = stored.y - py, dz = stored.z - pz;
+        bound0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic of the scans
+      }
+      const NNResult r = nn_search_row16(map, r16, px, py, pz, bound0);
+      const float n2 = (px * px + py * py) + pz * pz;
+      ok = r.found && (r.d2 < thr2 + ang2 * n2);
+      if (PL) {  // Matcher_Point2Plane first (k_match16_body)
+        const float pl_thr = (float)((cf64_ptr)uniform_const_ptr(ck->pl_thr))[iter];
+        okp = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
+        if (r16 == 0) {
+          G(reinterpret_cast<f32x4*>(pl_c))[i] = (f32x4){bc.x, bc.y, bc.z, okp ? 1.f : 0.f};
+          G(reinterpret_cast<f32x4*>(pl_n))[i] = (f32x4){bn.x, bn.y, bn.z, 0.f};
+        }
+        if (okp && ck->skip_pl_paired) ok = false;
+      }
+      if (r16 == 0) {
+        G(reinterpret_cast<f32x4*>(pair_q))[i] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
+        G(pair_gidx)[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+      }
+      q = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
+    } else {  // an inner Gauss-Newton step: the stored pairings under the new pose
+      ok = G(pair_gidx)[i] != kNoMatch;
+      if (PL) {
+        bc = G(reinterpret_cast<const f32x4*>(pl_c))[i];
+        bn = G(reinterpret_cast<const f32x4*>(pl_n))[i];
+        okp = bc.w != 0.f;
+      }
+    }
+    if (r16 == 0) {
+      acc_pt2pt_masked(a, T, ok, x, y, z, q.x, q.y, q.z, kernel, kparam, ck->w_pt2pt);
+      if (PL && okp)
+        acc_pt2pl_rows(v, T, x, y, z, make_float4(bc.x, bc.y, bc.z, 1.f), make_float4(bn.x, bn.y, bn.z, 0.f), kernel, kparam,
+                       ck->w_pt2pl);
+    }
+  }
+  MH_PHASE(12);
+  // 32 row leaders -> one partial per sum and workgroup, fixed order
+  if (r16 == 0) {
+#pragma unroll
+    for (int j = 0; j < kAccN; j++) rowsA[j][tid >> 4] = a.v[j];
+    if (PL) {
+#pragma unroll
+      for (int j = 0; j < kGenN; j++) rowsB[PL ? j : 0][tid >> 4] = v[PL ? j : 0];
+    }
+  }
+  __syncthreads();
+  if (tid < kAccN) {
+    double sum = rowsA[tid][0];
+#pragma unroll
+    for (int r = 1; r < (int)kStepPoints; r++) sum += rowsA[tid][r];
+    G(partA_out)[tid * nwg + wg] = sum;
+  }
+  if (PL && tid >= 64 && tid < 64 + kGenN) {  // (the second wave)
+    const uint32_t t = tid - 64;
+    double sum = rowsB[PL ? t : 0][0];
+#pragma unroll
+    for (int r = 1; r < (int)kStepPoints; r++) sum += rowsB[PL ? t : 0][r];
+    G(partB_out)[t * nwg + wg] = sum;
+  }
+  MH_PHASE(13);
+}
+template <bool PL>
+__global__ __launch_bounds__(kSolveThreads) void k_step16(const IcpDeviceState* __restrict__ s_in, IcpDeviceState* s_out,
+                                                          IcpDeviceState* s_canon, const MatchK* __restrict__ kp,
+                                                          const SolveK* __restrict__ sk, const float* __restrict__ lx,
+                                                          const float* __restrict__ ly, const float* __restrict__ lz,
+                                                          uint32_t n, MapView map, float4* pair_q, uint32_t* pair_gidx,
+                                                          float4* pl_c, float4* pl_n, const double* __restrict__ partA_in,
+                                                          double* __restrict__ partA_out, const double* __restrict__ partB_in,
+                                                          double* __restrict__ partB_out, uint32_t nwg, uint32_t close_only) {
+  k_step16_body<PL>(s_in, s_out, s_canon, kp, sk, lx, ly, lz, n, map, pair_q, pair_gidx, pl_c, pl_n, partA_in, partA_out, partB_in,
+                    partB_out, nwg, close_only);
+}
+// in lock step: blockIdx.y = job; `par`: which state block / partials half this launch reads
+template <bool PL>
+__global__ __launch_bounds__(kSolveThreads) void k_step16_b(const BatchJob* __restrict__ jobs, uint32_t par, uint32_t close_only) {
+  const BatchJob& j = jobs[blockIdx.y];
+  const uint32_t nwg = (j.n + kStepPoints - 1) / kStepPoints;
+  IcpDeviceState* const S[2] = {j.st, j.st_b};
+  double* const pa[2] = {j.part, j.part + (size_t)kAccN * nwg};
+  double* const pb[2] = {j.partb, j.partb ? j.partb + (size_t)kGenN * nwg : nullptr};
+  k_step16_body<PL>(S[par], close_only ? S[0] : S[par ^ 1u], S[0], j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx,
+                    j.pl_c, j.pl_n, pa[par], pa[par ^ 1u], pb[par], pb[par ^ 1u], nwg ? nwg : 1u, close_only);
+}
+
+// ================================================================================================
+// k_loop16: the WHOLE ICP loop of a small layer in one launch (round 4).  The phase stamps of k_step16 say where a launch
+// of the step chain spends its 13 us: 0.2 us reading the state, 1.4 us summing the partials, 3.6 us in the Gauss-Newton
+// step and the iteration's tail, 0.4 us writing the state, 1.1 us searching and accumulating, 1 us summing -- 7.5 us; the
+// other 5.5 us are the launch itself (dispatch, wave start-up, the cache write-back at the kernel's end).  Here the
+// workgroups stay: the body of k_step16, then a grid barrier over the workgroups of this alignment, then every workgroup
+// sums the partials and takes the Gauss-Newton step for itself (same bits everywhere: the state lives in LDS, one copy
+// per workgroup, and is written back once).  What crosses workgroups -- the partials and the arrival counter -- is written
+// back by an agent-scope release of one lane and read with agent-scope loads; nothing is invalidated, the map stays in the
+// L2s.  (Round 2's cooperative kernel fenced with __threadfence on both sides of its barriers and lost the map from the
+// caches at every one of them; see solve_body's comment.)
+// A workgroup handles the 32-point groups g = wg, wg + nw, ...: the partial columns stay one per GROUP, so the sums -- and
+// the result, bit for bit -- do not depend on how many workgroups the host could afford (AlignJob::loop_workgroups).
+// All nw workgroups must be resident together: the host keeps nw within a budget per device (g_loop_slots); a lane that
+// waits longer than kLoopBarrierTimeout gives up for the whole alignment, which then fails (never seen; a guard, not a path).
+// ================================================================================================
+constexpr unsigned long long kLoopBarrierTimeout = 20000000ull;  // wall_clock64 ticks of 10 ns: 0.2 s
+constexpr uint32_t kTermLoopBarrierTimeout = 0xFFFF0001u;        // (internal: poll() turns it into MH_ERR_INTERNAL)
+
+template <bool PL>
+__device__ __forceinline__ void loop16_solve(IcpDeviceState* lst, const SolveK* sk, const double* pa, const double* pb,
+                                             uint32_t ngroups, SolveShared* sh, uint32_t lane) {
+  solve_body<true, false, true>(lst, sk, pa, ngroups, ngroups, PL ? pb : nullptr, PL ? ngroups : 0u, PL ? ngroups : 0u, *sh, false, false,
+                                (int)lane);
+}
+
+template <bool PL>
+__device__ __forceinline__ void k_loop16_body(IcpDeviceState* st, const MatchK* __restrict__ kp, const SolveK* __restrict__ sk,
+                                              const float* __restrict__ lx, const float* __restrict__ ly,
+                                              const float* __restrict__ lz, uint32_t n, MapView map, float4* pair_q,
+                                              uint32_t* pair_gidx, float4* pl_c, float4* pl_n, double* partA, double* partB,
+                                              uint32_t ngroups, uint32_t* sync, uint32_t wg, uint32_t nw) {
+  __shared__ SolveShared sh;
+  __shared__ __attribute__((aligned(8))) uint32_t lst_raw[kStateHeadDwords];
+  __shared__ double rowsA[kAccN][kStepPoints + 1];
+  __shared__ double rowsB[PL ? kGenN : 1][kStepPoints + 1];
+  __shared__ uint32_t gave_up;
+  const uint32_t tid = threadIdx.x;
+  if (wg >= nw) return;
+  IcpDeviceState* const lst = reinterpret_cast<IcpDeviceState*>(lst_raw);
+  if (tid < kStateHeadDwords) lst_raw[tid] = G(reinterpret_cast<const uint32_t*>(st))[tid];
+  if (tid == 0) gave_up = 0;
+  __syncthreads();
+  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
+  typedef const double __attribute__((address_space(4))) * cf64_ptr;
+  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
+  const uint32_t kernel = ck->kernel;
+  for (uint32_t step = 0; !lst->done; step++) {
+    // the lane index through a register the optimiser cannot see through: what the search and the solve derive from it (lane
+    // masks, voxel offset tables, the prior's perturbations) would otherwise be hoisted out of the loop -- and spilled there
+    uint32_t tl = tid;
+    asm volatile("" : "+v"(tl));
+    const uint32_t row = tl >> 4, r16 = tl & 15u;
+    double* const pa = partA + (size_t)(step & 1u) * kAccN * ngroups;
+    double* const pb = PL ? partB + (size_t)(step & 1u) * kGenN * ngroups : nullptr;
+    const uint32_t inner = lst->inner, iter = lst->iter;
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = lst->T[k];
+    const float thr2 = lst->cur_thr2, ang2 = lst->cur_ang2;
+    const double kparam = lst->cur_kparam;
+    for (uint32_t g = wg; g < ngroups; g += nw) {  // (workgroup-uniform trip count)
+      const uint32_t i = g * kStepPoints + row;
+      const uint32_t ic = i < n ? i : n - 1;
+      const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
+      const f32x4 stored = G(reinterpret_cast<const f32x4*>(pair_q))[ic];
+      Acc a;
+      acc_zero(a);
+      double v[PL ? kGenN : 1];
+#pragma unroll
+      for (int j = 0; j < (PL ? kGenN : 1); j++) v[j] = 0.0;
+      if (i < n) {  // row-uniform; the body of k_step16
+        f32x4 q = stored, bc = (f32x4){0.f, 0.f, 0.f, 0.f}, bn = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bool ok, okp = false;
+        if (inner == 0) {
+          float px, py, pz;
+          transform_point(T, x, y, z, px, py, pz);
+          float bound0 = __builtin_inff();
+          if (iter > 0 && !map.no_prev_bound && stored.w < __builtin_inff()) {
+            const float dx = stored.x - px, dy = stored.y - py, dz = stored.z - pz;
+            bound0 = (dx * dx + dy * dy) + dz * dz;
+          }
+          const NNResult r = nn_search_row16(map, r16, px, py, pz, bound0);
+          const float n2 = (px * px + py * py) + pz * pz;
+          ok = r.found && (r.d2 < thr2 + ang2 * n2);
+          if (PL) {
+            const float pl_thr = (float)((cf64_ptr)uniform_const_ptr(ck->pl_thr))[iter];
+            okp = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
+            if (r16 == 0) {
+              G(reinterpret_cast<f32x4*>(pl_c))[i] = (f32x4){bc.x, bc.y, bc.z, okp ? 1.f : 0.f};
+              G(reinterpret_cast<f32x4*>(pl_n))[i] = (f32x4){bn.x, bn.y, bn.z, 0.f};
+            }
+            if (okp && ck->skip_pl_paired) ok = false;
+          }
+          if (r16 == 0) {
+            G(reinterpret_cast<f32x4*>(pair_q))[i] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
+            G(pair_gidx)[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+          }
+          q = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
+        } else {
+          ok = G(pair_gidx)[i] != kNoMatch;
+          if (PL) {
+            bc = G(reinterpret_cast<const f32x4*>(pl_c))[i];
+            bn = G(reinterpret_cast<const f32x4*>(pl_n))[i];
+            okp = bc.w != 0.f;
+          }
+        }
+        if (r16 == 0) {
+          acc_pt2pt_masked(a, T, ok, x, y, z, q.x, q.y, q.z, kernel, kparam, ck->w_pt2pt);
+          if (PL && okp)
+            acc_pt2pl_rows(v, T, x, y, z, make_float4(bc.x, bc.y, bc.z, 1.f), make_float4(bn.x, bn.y, bn.z, 0.f), kernel, kparam,
+                           ck->w_pt2pl);
+        }
+      }
+      if (r16 == 0) {
+#pragma unroll
+        for (int j = 0; j < kAccN; j++) rowsA[j][row] = a.v[j];
+        if (PL) {
+#pragma unroll
+          for (int j = 0; j < kGenN; j++) rowsB[PL ? j : 0][row] = v[PL ? j : 0];
+        }
+      }
+      __syncthreads();
+      if (tid < kAccN) {
+        double sum = rowsA[tid][0];
+#pragma unroll
+        for (int r = 1; r < (int)kStepPoints; r++) sum += rowsA[tid][r];
+        G(pa)[tid * ngroups + g] = sum;
+      }
+      if (PL && tid >= 64 && tid < 64 + kGenN) {
+        const uint32_t t = tid - 64;
+        double sum = rowsB[PL ? t : 0][0];
+#pragma unroll
+        for (int r = 1; r < (int)kStepPoints; r++) sum += rowsB[PL ? t : 0][r];
+        G(pb)[t * ngroups + g] = sum;
+      }
+      __syncthreads();  // (the row buffers are reused by the next group; and every store of this workgroup has been issued)
+    }
+    // ---- grid barrier over the nw workgroups of this alignment ----
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this workgroup's partials (complete: the barrier above) leave the L2
+      __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t target = (step + 1u) * nw;
+      const unsigned long long t0 = wall_clock64();
+      uint32_t spins = 0;
+      while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0) {
+          if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > kLoopBarrierTimeout) {
+            __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = 1;
+            break;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (gave_up) {  // (workgroup-uniform) some workgroup of this alignment never arrived
+      if (tid == 0) {
+        lst->done = 1;
+        lst->term_reason = kTermLoopBarrierTimeout;
+      }
+      __syncthreads();
+      break;
+    }
+    // (the parameter block through a pointer the optimiser cannot see through: hoisted out of the loop, the solve's ~90
+    //  parameter words -- prior, hook check point, thresholds -- would be spilled before it and reloaded inside)
+    const SolveK* skl = sk;
+    asm volatile("" : "+s"(skl));
+    loop16_solve<PL>(lst, skl, pa, pb, ngroups, &sh, tl);
+    __syncthreads();
+  }
+  if (wg == 0 && tid < kStateHeadDwords) G(reinterpret_cast<uint32_t*>(st))[tid] = lst_raw[tid];
+}
+template <bool PL>
+__global__ __launch_bounds__(kSolveThreads) void k_loop16(IcpDeviceState* st, const MatchK* __restrict__ kp,
+                                                          const SolveK* __restrict__ sk, const float* __restrict__ lx,
+                                                          const float* __restrict__ ly, const float* __restrict__ lz,
+                                                          uint32_t n, MapView map, float4* pair_q, uint32_t* pair_gidx,
+                                                          float4* pl_c, float4* pl_n, double* partA, double* partB,
+                                                          uint32_t ngroups, uint32_t* sync) {
+  k_loop16_body<PL>(st, kp, sk, lx, ly, lz, n, map, pair_q, pair_gidx, pl_c, pl_n, partA, partB, ngroups, sync, blockIdx.x, gridDim.x);
 }
 
 // ================================================================================================
@@ -2154,16 +2534,37 @@ namespace {
 
 inline uint32_t nblk(size_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
+// k_loop16's workgroups wait for each other inside the kernel, so all of them must fit on the device TOGETHER, whatever
+// else this process has running there: a budget of resident workgroups per device (512 threads x 256 VGPRs: one per CU; 256
+// CUs), taken for the duration of an alignment.  An alignment that finds the budget spent takes the launch-per-step chain.
+constexpr int kLoopSlotsPerDevice = 160;
+constexpr uint32_t kLoopMaxWorkgroups = 64;   // per alignment (= every group of a 2 k-point layer at once)
+constexpr uint32_t kLoopMaxPoints = 8192;     // (above: k_match16<fused> | k_solve | k_accum | k_solve)
+std::atomic<int> g_loop_slots[16] = {{kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice},
+                                     {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice},
+                                     {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice},
+                                     {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}};
+inline bool loop_slots_take(int device, int n) {
+  std::atomic<int>& a = g_loop_slots[device & 15];
+  int have = a.load(std::memory_order_relaxed);
+  while (have >= n)
+    if (a.compare_exchange_weak(have, have - n, std::memory_order_acquire)) return true;
+  return false;
+}
+inline void loop_slots_give(int device, int n) { g_loop_slots[device & 15].fetch_add(n, std::memory_order_release); }
+
 // One device block [state | parameters] with a pinned mirror of the same layout: an alignment starts with ONE upload.
 constexpr size_t kParamsOffset = (sizeof(IcpDeviceState) + 255) / 256 * 256;
 
 mh_status ensure_state(mh_ctx* ctx) {
   if (!ctx->d_state) {
     char *d = nullptr, *h = nullptr;
-    MH_HIP(hipMalloc((void**)&d, kParamsOffset + sizeof(IcpDeviceParams)));
+    const size_t second_off = (kParamsOffset + sizeof(IcpDeviceParams) + 255) / 256 * 256;  // k_step16's other state block (head only)
+    MH_HIP(hipMalloc((void**)&d, second_off + kStateHeadDwords * 4));
     const size_t prog_off = ((kParamsOffset + sizeof(IcpDeviceParams) + 127) / 128) * 128;  // a cache line of its own
     MH_HIP(hipHostMalloc((void**)&h, prog_off + 128, hipHostMallocDefault));
     ctx->d_state = (IcpDeviceState*)d;
+    ctx->d_state_b = (IcpDeviceState*)(d + second_off);
     ctx->h_state = (IcpDeviceState*)h;
     ctx->d_params = (IcpDeviceParams*)(d + kParamsOffset);
     ctx->h_params = (IcpDeviceParams*)(h + kParamsOffset);
@@ -2181,6 +2582,7 @@ mh_status ensure_state(mh_ctx* ctx) {
 mh_status upload_state_and_params(mh_ctx* ctx, const MatchK& mk, const SolveK& sk) {
   ctx->h_params->mk = mk;
   ctx->h_params->sk = sk;
+  memset(ctx->h_params->loop_sync, 0, sizeof(ctx->h_params->loop_sync));
   MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, kParamsOffset + sizeof(IcpDeviceParams), hipMemcpyHostToDevice,
                         ctx->stream));
   return MH_OK;
@@ -2296,6 +2698,7 @@ struct AlignJob {
   MatchK mk{};
   SolveK sk{};
   uint32_t nb = 0, nbm = 0, nba = 0, enqueued = 0, chunk = 0, prof_n = 0, polls = 0, kind = 0;
+  uint32_t step_par = 0;  // k_step16 chain: which state block / partials half the next launch reads (0 at every chunk start)
   bool auto_chunk = false;
   bool fused16 = false;  // row kernel accumulates the first Gauss-Newton step itself (layers above the one-workgroup size)
   bool defer_upload = false;   // batches: the pinned mirrors are filled, the copies are issued by the batch (staged) or flush()
@@ -2304,6 +2707,7 @@ struct AlignJob {
   bool finished = false, trivial = false;
   bool prof = false;  // time this job's match kernels with events (then it cannot use the graph path)
   bool pl = false;    // Matcher_Point2Plane runs before the point matcher (lidar3d-ndt.yaml:195-210)
+  uint32_t loop_nw = 0;    // run_loop16(): workgroups of the one-launch loop (taken from the device's budget), 0 = not this way
   bool streaming = false;  // run_streaming(): iterations are enqueued one by one behind the device's published progress
   bool skip_tail = false;  // ... and the covariance kernels + state read-back only once the loop has ended
 
@@ -2403,6 +2807,7 @@ struct AlignJob {
     if (defer_upload) {
       ctx->h_params->mk = mk;
       ctx->h_params->sk = sk;
+      memset(ctx->h_params->loop_sync, 0, sizeof(ctx->h_params->loop_sync));
     } else {
       MH_TRY(upload_state_and_params(ctx, mk, sk));
     }
@@ -2437,6 +2842,24 @@ struct AlignJob {
     // who writes the partials of the first Gauss-Newton step: the row kernel (16 points per workgroup), k_accum, or k_match
     nbm = fused16 ? (uint32_t)((16ull * scan->n + kBlock - 1) / kBlock) : (variant >= 4 ? nba : nb);
     MH_TRY(ctx->partials.reserve((size_t)kGenN * (nbm > nb ? nbm : nb) * sizeof(double)));
+    if (variant == 5 && scan->n <= kOneGroupMaxPoints) {  // k_step16: two halves of one column per workgroup
+      const size_t nwg = (scan->n + kStepPoints - 1) / kStepPoints;
+      MH_TRY(ctx->partials.reserve(2 * (size_t)kAccN * (nwg ? nwg : 1) * sizeof(double)));
+      if (pl) MH_TRY(ctx->partials_b.reserve(2 * (size_t)kGenN * (nwg ? nwg : 1) * sizeof(double)));
+    }
+    step_par = 0;
+    // the whole loop in one launch (k_loop16): single alignments of row-kernel layers, when the device's budget of resident
+    // workgroups has room (MH_LOOP16 while it is being measured)
+    loop_nw = 0;
+    if (variant == 5 && scan->n <= kLoopMaxPoints && !defer_upload && !prof && getenv("MH_LOOP16") != nullptr) {
+      const size_t ng = (scan->n + kStepPoints - 1) / kStepPoints;
+      MH_TRY(ctx->partials.reserve(2 * (size_t)kAccN * ng * sizeof(double)));
+      if (pl) MH_TRY(ctx->partials_b.reserve(2 * (size_t)kGenN * ng * sizeof(double)));
+      static const uint32_t cap = getenv("MH_LOOP16_WGS") ? (uint32_t)std::max(1, atoi(getenv("MH_LOOP16_WGS"))) : kLoopMaxWorkgroups;
+      const uint32_t want = ng < cap ? (uint32_t)ng : cap;
+      if (loop_slots_take(ctx->device, (int)want)) loop_nw = want;
+      if (loop_nw) streaming = false;
+    }
     // poll_every == 0: the first chunk is sized by what the previous alignment of this context needed (consecutive scans
     // of a sequence converge in about as many iterations: one host round trip instead of three), later chunks are short
     auto_chunk = p->poll_every == 0;
@@ -2480,6 +2903,11 @@ struct AlignJob {
     return MH_OK;
   }
 
+  // small layers: k_step16 instead of k_match16 | k_accum_solve1 ... (profiled jobs time the match kernel alone: the old chain)
+  bool use_step_chain() const {
+    return variant == 5 && scan->n <= kOneGroupMaxPoints && !prof && getenv("MH_CHAIN_R") != nullptr && getenv("MH_NO_ONE_GROUP") == nullptr;
+  }
+
   mh_status enqueue_chunk() {
     if (finished) return MH_OK;
     MH_TRY(set_device(ctx));
@@ -2495,12 +2923,37 @@ struct AlignJob {
     // everything a chunk launches, in stream order; used directly (profiling / MH_NO_GRAPH) or under stream capture
     const bool no_one_group = getenv("MH_NO_ONE_GROUP") != nullptr;  // (read per chunk: tests toggle it)
     const bool one_group = variant == 5 && n <= kOneGroupMaxPoints && !no_one_group;  // accumulate + solve in one workgroup
+    // ... or, MH_CHAIN_R: k_step16 -- every launch over the whole layer, the solve carried into the next launch
+    const bool step_chain = one_group && use_step_chain();
+    const uint32_t nwg = n ? (n + kStepPoints - 1) / kStepPoints : 1u;
+    auto launch_step = [&](uint32_t close_only) {
+      IcpDeviceState* const S[2] = {ctx->d_state, ctx->d_state_b};
+      double* const pa[2] = {part, part + (size_t)kAccN * nwg};
+      double* const pbb = pl ? ctx->partials_b.as<double>() : nullptr;
+      double* const pb[2] = {pbb, pbb ? pbb + (size_t)kGenN * nwg : nullptr};
+      const uint32_t par = step_par;
+      if (pl)
+        hipLaunchKernelGGL(k_step16<true>, dim3(close_only ? 1u : nwg), dim3(kSolveThreads), 0, s, S[par], close_only ? S[0] : S[par ^ 1u],
+                           S[0], dmk, dsk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+                           ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), (const double*)pa[par], pa[par ^ 1u], (const double*)pb[par],
+                           pb[par ^ 1u], nwg, close_only);
+      else
+        hipLaunchKernelGGL(k_step16<false>, dim3(close_only ? 1u : nwg), dim3(kSolveThreads), 0, s, S[par], close_only ? S[0] : S[par ^ 1u],
+                           S[0], dmk, dsk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+                           (float4*)nullptr, (float4*)nullptr, (const double*)pa[par], pa[par ^ 1u], (const double*)nullptr,
+                           (double*)nullptr, nwg, close_only);
+      step_par = close_only ? 0u : (par ^ 1u);
+    };
     auto enqueue_kernels = [&]() -> mh_status {
       double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
       const bool rows16 = pl && variant == 5;                  // NDT layer handled by the row kernel
       const uint32_t nB = pl ? (rows16 ? nba : nb) : 0u;       // columns of the point-to-plane partials of the FIRST step
       const uint32_t nBi = pl ? nba : 0u;                      // ... of the inner steps (k_accum_both)
       for (uint32_t j = 0; j < m; j++) {
+        if (step_chain) {
+          for (uint32_t in = 0; in < p->gn.max_inner_iterations; in++) launch_step(0u);
+          continue;
+        }
         const bool both16 = pl && variant == 5;  // small layer: both matchers in one launch (k_match16<true>)
         if (pl && !both16)
           hipLaunchKernelGGL(k_match_pl<true>, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, dmk, scan->x, scan->y,
@@ -2597,6 +3050,9 @@ struct AlignJob {
                              (const double*)partb, nBi, nBi, 0u);
         }
       }
+      // the step chain's last Gauss-Newton step is still pending: at the end of a chunk the host is going to look at the state,
+      // under streaming control only once the iteration budget is queued (a loop that ends earlier is seen by the next launch)
+      if (step_chain && (!skip_tail || enqueued + m >= p->max_iterations)) launch_step(1u);
       if (skip_tail) return MH_OK;  // streaming: the tail below is enqueued once, by enqueue_tail()
       if (p->compute_covariance) {  // no-ops unless the loop has terminated
         hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, dsk, 0u);
@@ -2632,7 +3088,7 @@ struct AlignJob {
                                        (unsigned long long)ctx->pair_gidx.p, (unsigned long long)part,
                                        (unsigned long long)ctx->d_state, (unsigned long long)ctx->d_params,
                                        (unsigned long long)ctx->h_state,
-                                       (pl ? 2ull : 1ull) | (one_group ? 4ull : 0ull) | (fused16 ? 8ull : 0ull),
+                                       (pl ? 2ull : 1ull) | (one_group ? 4ull : 0ull) | (fused16 ? 8ull : 0ull) | (step_chain ? 16ull : 0ull),
                                        (unsigned long long)(pl ? ctx->pl_c.p : nullptr),
                                        (unsigned long long)(pl ? ctx->pl_n.p : nullptr),
                                        (unsigned long long)(pl ? ctx->partials_b.p : nullptr),
@@ -2690,7 +3146,8 @@ struct AlignJob {
   // ahead of the iteration the device has published; once it publishes "done" the covariance kernels and the state
   // read-back follow and ONE event wait ends the call.
   mh_status run_streaming() {
-    static const uint32_t lead = getenv("MH_STREAM_LEAD") ? (uint32_t)std::max(1, atoi(getenv("MH_STREAM_LEAD"))) : 2u;
+    static const uint32_t lead0 = getenv("MH_STREAM_LEAD") ? (uint32_t)std::max(1, atoi(getenv("MH_STREAM_LEAD"))) : 2u;
+    const uint32_t lead = lead0 + (use_step_chain() ? 1u : 0u);  // (k_step16 publishes an iteration's end from the NEXT launch)
     volatile uint32_t* prog = ctx->h_progress;
     *prog = 0;  // (the previous alignment of this context has been waited for: nothing in flight writes it)
     chunk = 1;
@@ -2718,6 +3175,34 @@ struct AlignJob {
     chunk = 0;  // the tail alone: covariance (now live: the loop has ended) + state read-back
     MH_TRY(enqueue_tail());
     return poll();
+  }
+
+  // The whole loop as ONE launch (k_loop16), the tail behind it, one wait.
+  mh_status run_loop16() {
+    struct Give {
+      int dev, n;
+      ~Give() { loop_slots_give(dev, n); }
+    } give{ctx->device, (int)loop_nw};
+    MH_TRY(set_device(ctx));
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t)scan->n;
+    const uint32_t ng = (n + kStepPoints - 1) / kStepPoints;
+    const MapView mv = map->view();
+    uint32_t* sync = ctx->d_params->loop_sync;
+    if (pl)
+      hipLaunchKernelGGL(k_loop16<true>, dim3(loop_nw), dim3(kSolveThreads), 0, s, ctx->d_state, &ctx->d_params->mk, &ctx->d_params->sk,
+                         scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), ctx->pl_c.as<float4>(),
+                         ctx->pl_n.as<float4>(), ctx->partials.as<double>(), ctx->partials_b.as<double>(), ng, sync);
+    else
+      hipLaunchKernelGGL(k_loop16<false>, dim3(loop_nw), dim3(kSolveThreads), 0, s, ctx->d_state, &ctx->d_params->mk, &ctx->d_params->sk,
+                         scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (float4*)nullptr,
+                         (float4*)nullptr, ctx->partials.as<double>(), (double*)nullptr, ng, sync);
+    enqueued = p->max_iterations;
+    chunk = 0;
+    MH_TRY(enqueue_tail());
+    const mh_status st = poll();
+    if (st == MH_OK && finished) res->n_enqueued_iterations = res->n_iterations + (res->termination_reason == MH_TERM_MAX_ITERATIONS ? 0u : 1u);
+    return st;
   }
 
   mh_status enqueue_tail() {
@@ -2758,6 +3243,9 @@ struct AlignJob {
       return MH_OK;
     }
     if (!h->done) return fail(MH_ERR_INTERNAL, "device ICP loop did not terminate after max_iterations");
+    if (h->term_reason == kTermLoopBarrierTimeout)
+      return fail(MH_ERR_INTERNAL, "device ICP loop (k_loop16): a workgroup waited %.1f s at the grid barrier for the others",
+                  (double)kLoopBarrierTimeout * 1e-8);
     finished = true;
     if (auto_chunk) ctx->predicted_iterations[kind] = h->n_iterations + (h->term_reason == MH_TERM_MAX_ITERATIONS ? 0u : 1u);
     res->n_host_polls = polls;
@@ -2823,6 +3311,7 @@ mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_icp_para
   MH_REQUIRE(!final_pairs || pairs_mem == MH_MEM_HOST || pairs_mem == MH_MEM_DEVICE, "bad mem space");
   AlignJob job;
   MH_TRY(job.start(map, scan, params, T_guess, prior, result, trace));
+  if (job.loop_nw && !job.finished) MH_TRY(job.run_loop16());
   if (job.streaming && !job.finished) MH_TRY(job.run_streaming());
   while (!job.finished) {
     MH_TRY(job.enqueue_chunk());
@@ -2848,6 +3337,7 @@ namespace {
 void fill_batch_desc(const AlignJob& j, BatchJob& d) {
   memset(&d, 0, sizeof(d));
   d.st = j.ctx->d_state;
+  d.st_b = j.ctx->d_state_b;
   d.mk = &j.ctx->d_params->mk;
   d.sk = &j.ctx->d_params->sk;
   d.lx = j.scan->x; d.ly = j.scan->y; d.lz = j.scan->z;
@@ -3018,8 +3508,9 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
     mh_ctx* lead = nullptr;
     IcpDeviceState* h_states = nullptr;
     const BatchJob* dj = nullptr;
-    uint32_t gx_match = 1, gx_acc = 1, gx_cov = 1, enq = 0, prof_n = 0, max_iterations = 0, inner = 1, chunk = 10;
-    bool cov = false, done = false, auto_chunk = false;
+    uint32_t gx_match = 1, gx_acc = 1, gx_cov = 1, gx_step = 1, enq = 0, prof_n = 0, max_iterations = 0, inner = 1, chunk = 10;
+    uint32_t par = 0;  // k_step16_b: the state block the next launch reads
+    bool cov = false, done = false, auto_chunk = false, step_chain = false;
   };
   std::vector<Group> groups;
   const bool want_prof = !jobs.empty() && jobs[0].prof && !no_lockstep;  // profile == 2: the share of job 0's group
@@ -3121,7 +3612,12 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         if (g.kind == K_ROWF) bm = d.nbm;
         if (g.kind == K_TILE) bm = d.n_tiles;
         if (g.kind == K_WAVE) bm = d.n_tiles;
-        if (g.kind == K_ONE || g.kind == K_ONE_PL) bm = (uint32_t)((16ull * d.n + kBlock - 1) / kBlock);
+        if (g.kind == K_ONE || g.kind == K_ONE_PL) {
+          bm = (uint32_t)((16ull * d.n + kBlock - 1) / kBlock);
+          const uint32_t nwg = (d.n + kStepPoints - 1) / kStepPoints;
+          g.gx_step = nwg > g.gx_step ? nwg : g.gx_step;
+          g.step_chain = j.use_step_chain() && !want_prof;  // (the same answer for every job of a K_ONE group: no profiled jobs in groups)
+        }
         g.gx_match = bm > g.gx_match ? bm : g.gx_match;
         g.gx_acc = d.nba > g.gx_acc ? d.nba : g.gx_acc;
         g.gx_cov = d.nb > g.gx_cov ? d.nb : g.gx_cov;
@@ -3163,6 +3659,14 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
           hipStream_t s = g.lead->stream;
           const uint32_t A = (uint32_t)g.jobs.size();
           const bool pr = want_prof && gi == 0 && g.jobs[0] == &jobs[0];
+          if (g.step_chain) {
+            for (uint32_t in = 0; in < g.inner; in++) {
+              if (g.kind == K_ONE_PL) hipLaunchKernelGGL(k_step16_b<true>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 0u);
+              else hipLaunchKernelGGL(k_step16_b<false>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 0u);
+              g.par ^= 1u;
+            }
+            continue;
+          }
           if (pr) MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n], s));
           switch (g.kind) {
             case K_ROWF: hipLaunchKernelGGL(k_match16f_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
@@ -3202,6 +3706,11 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         if (g.done) continue;
         hipStream_t s = g.lead->stream;
         const uint32_t A = (uint32_t)g.jobs.size();
+        if (g.step_chain) {  // the pending Gauss-Newton step of every job, into the canonical state blocks
+          if (g.kind == K_ONE_PL) hipLaunchKernelGGL(k_step16_b<true>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 1u);
+          else hipLaunchKernelGGL(k_step16_b<false>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 1u);
+          g.par = 0;
+        }
         if (g.cov) {  // no-ops for jobs whose loop has not terminated
           hipLaunchKernelGGL(k_cov_prepare_b, dim3(1, A), dim3(64), 0, s, g.dj);
           hipLaunchKernelGGL(k_cov_accum_b, dim3(g.gx_cov, A), dim3(kBlock), 0, s, g.dj);

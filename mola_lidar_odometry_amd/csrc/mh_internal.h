@@ -151,6 +151,7 @@ struct mh_ctx {
   mh::DevBuf sort_tmp;    // rocprim temporary storage
   mh::DevBuf build_a, build_b, build_c, build_d, build_e;  // map build scratch
   IcpDeviceState* d_state = nullptr;
+  IcpDeviceState* d_state_b = nullptr;  // k_step16: the other half of the state ping-pong (same allocation, head only)
   IcpDeviceState* h_state = nullptr;  // pinned mirror; d_state/h_state own one block [state | params]
   IcpDeviceParams* d_params = nullptr;  // per-alignment parameters (kernels take pointers into this block)
   IcpDeviceParams* h_params = nullptr;  // pinned mirror

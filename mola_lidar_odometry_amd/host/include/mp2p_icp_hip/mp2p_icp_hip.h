@@ -573,4 +573,9 @@ Solver::Ptr create_solver(const std::string& class_name);
 // (the icp_settings_with_vel block of pipelines/lidar3d-default.yaml:162-209)
 std::tuple<ICP::Ptr, Parameters> icp_pipeline_from_yaml(const Config& icpParams, std::shared_ptr<DeviceContext> ctx = nullptr);
 
+// The MOLA_HIP_* switches (molahip_host/plugin_switches.h) as THIS library sees them: the header's cache is one per shared
+// object, so a test module that changes the environment has to ask the library to read it again, not its own copy.
+void reload_plugin_switches();
+uint32_t plugin_switch_matched_points();
+
 }  // namespace mp2p_icp_hip

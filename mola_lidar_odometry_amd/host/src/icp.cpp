@@ -1091,4 +1091,7 @@ std::tuple<ICP::Ptr, Parameters> icp_pipeline_from_yaml(const Config& c, std::sh
   return {icp, p};
 }
 
+void reload_plugin_switches() { molahip_host::reload_plugin_switches(); }
+uint32_t plugin_switch_matched_points() { return molahip_host::plugin_switches().matched_points; }
+
 }  // namespace mp2p_icp_hip

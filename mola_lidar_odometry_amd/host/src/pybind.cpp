@@ -49,7 +49,11 @@ PYBIND11_MODULE(_mp2p_icp_hip, m) {
   m.def("evaluate_expression", &evaluate_expression);
   // MOLA_HIP_* switches (molahip_host/plugin_switches.h, shared with the mp2p_icp adapter): re-read the environment, and
   // show what was read -- what the adapter would pass to the C ABI for an upstream `RobustKernel::<name>`
-  m.def("reload_plugin_switches", [] { molahip_host::reload_plugin_switches(); });
+  m.def("reload_plugin_switches", [] {
+    molahip_host::reload_plugin_switches();   // this module's copy of the cache (what plugin_switches() below shows) ...
+    mp2p_icp_hip::reload_plugin_switches();   // ... and the host library's, which is the one the alignments read
+  });
+  m.def("library_matched_points", [] { return mp2p_icp_hip::plugin_switch_matched_points(); });
   m.def("plugin_switches", [] {
     const auto& s = molahip_host::plugin_switches();
     py::dict d;

@@ -253,7 +253,7 @@ def test_align_ndt_pipeline_skipping_plane_paired_points(ctx, oracle, inner, mat
     both = oracle.icp_align(o, scan, guess, oracle.ICPParams(gn=oracle.GNParams(max_inner_iterations=inner), **kw), want_pairs=True)
     n_pt = b["n_final_pairs"] - b["n_final_pairs_pt2pl"]
     assert 0 < n_pt < both["n_final_pairs"] - both["n_final_pairs_pt2pl"]  # the switch does change the pairing set
-    assert np.abs(a["T"] - I12).max() < 2e-2  # (a noisy re-sampling of the cloud: registered to within its noise)
+    assert np.abs(a["T"] - I12).max() < 4e-2  # (from 0.12 off; with the plane-paired points left out of the point matcher 3 cm remain)
 
 
 # ---------------------------------------------------------------------------- NN / matcher

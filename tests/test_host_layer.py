@@ -217,6 +217,7 @@ def test_ndt_pipeline_align_matches_oracle(hl, oracle, generic, skip, monkeypatc
     MOLA_HIP_MATCHED_POINTS=skip (U12) through the fused loop and through the matcher-granular loop's pairing bookkeeping."""
     monkeypatch.setenv("MOLA_HIP_MATCHED_POINTS", "skip" if skip else "again")
     hl.reload_plugin_switches()
+    assert hl.library_matched_points() == (1 if skip else 0)  # (the host library's own cache of the switches, not the module's)
     rng = np.random.default_rng(21)
     ground = np.stack([rng.uniform(-10, 10, 20000), rng.uniform(-10, 10, 20000), rng.normal(0.3, 0.01, 20000)], 1)
     wall = np.stack([rng.uniform(-10, 10, 12000), rng.normal(5.4, 0.01, 12000), rng.uniform(0.5, 4, 12000)], 1)
