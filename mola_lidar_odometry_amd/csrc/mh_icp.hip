@@ -20,9 +20,11 @@
 // Smaller layers take shorter chains (chosen by size in AlignJob::start / enqueue_chunk):
 //   <= 32 k points   k_match16: a DPP row (16 lanes) per point; up to 12 k points it also accumulates the first step
 //                    (k_match16<.,true> | k_solve | k_accum | k_solve)
-//   <= 2 k points    k_match16 | k_accum_solve1 | k_accum_solve1: accumulation and solve in one workgroup
-//   NDT maps         Matcher_Point2Plane rides in the row kernel (k_match16<true,.>), its Gauss-Newton rows are summed by
-//                    k_accum_both / k_accum_solve1<true>; above 32 k points k_match_pl (one lane per point)
+//   <= 8 k points    k_step16 x max_inner: search + sums per launch, the Gauss-Newton step carried into the next launch -- what
+//                    lidar3d-default.yaml's 1-3 k-point ICP layer runs, alone and in lock-step batches (profiled alignments
+//                    keep a match kernel of their own: the chain above)
+//   NDT maps         Matcher_Point2Plane rides in the row kernels (k_step16<true>, k_match16<true,.>), its Gauss-Newton rows are
+//                    summed alongside (k_accum_both); above 32 k points k_match_pl (one lane per point)
 // A chunk of iterations is one hipGraph launch when its shape repeats (direct launches otherwise); every kernel begins
 // with `if (st->done) return`.
 // No fp atomics anywhere: reductions are fixed-shape trees, so results are bitwise reproducible.
@@ -102,9 +104,6 @@ struct SolveK {
 struct IcpDeviceParams {
   MatchK mk;
   SolveK sk;
-  // k_loop16: [0] workgroups that have arrived at the grid barrier (monotonic over the steps of one alignment),
-  // [1] a workgroup gave up waiting.  A cache line of their own; zeroed by every upload of the block.
-  alignas(128) uint32_t loop_sync[32];
 };
 
 struct PoseArg {
@@ -164,10 +163,13 @@ struct BlockSum {
 
 template <int NV>
 __device__ __forceinline__ void block_sum_rows_raw(const double* v, double (*tr)[kBlock + 1], double* p1,
-                                                   double* __restrict__ partials, uint32_t pstride, uint32_t bid) {
+                                                   double* __restrict__ partials, uint32_t pstride, uint32_t bid,
+                                                   bool has_values = true) {  // (false: a lane beyond kBlock of a wider workgroup)
   constexpr int G = BlockSum<NV>::kGroups, C = BlockSum<NV>::kChunk;
+  if (has_values) {
 #pragma unroll
-  for (int j = 0; j < NV; j++) tr[j][threadIdx.x] = v[j];
+    for (int j = 0; j < NV; j++) tr[j][threadIdx.x] = v[j];
+  }
   __syncthreads();
   if (threadIdx.x < NV * G) {
     const int j = threadIdx.x / G, g = threadIdx.x % G;
@@ -911,16 +913,16 @@ constexpr int kSolveThreads = 512;  // 2 waves per SIMD -> 256 VGPRs for the ser
 // Ordered sum of `nvals` rows of a [nvals][stride] array of per-block partials over n blocks, by the
 // whole block: G = blockDim/nvals lanes per row, 8 independent loads in flight per lane, then
 // a fixed-order LDS pass.  Shape depends only on (n, nvals) -> bitwise reproducible.
-// COHERENT: the partials were written by other workgroups of the SAME launch (k_loop16, after its grid barrier): agent-scope
-// loads, which the XCDs' L2s do not answer from a stale line.
-template <bool COHERENT = false>
+// AGENT: the partials are read with agent-scope loads (k_step16: see there why a kernel boundary is not enough for it)
+template <bool AGENT = false>
 __device__ __forceinline__ double part_load(const double MH_AS_GLOBAL* p) {
-  if (COHERENT) return __hip_atomic_load((const double*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (AGENT) return __hip_atomic_load((const double*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return *p;
 }
-template <bool COHERENT = false>
+template <bool AGENT = false>
 __device__ __forceinline__ void reduce_rows(const double* __restrict__ part, uint32_t n, uint32_t stride, int nvals,
-                                            double* __restrict__ out, double (*red)[64], int t = (int)threadIdx.x) {
+                                            double* __restrict__ out, double (*red)[64]) {
+  const int t = threadIdx.x;
   int G = kSolveThreads / nvals;
   if (G > 64) G = 64;
   const int v = t / G, g = t % G;
@@ -929,13 +931,13 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ part, uin
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
     uint32_t b = g;
     for (; b + 7u * G < n; b += 8u * G) {  // 8 independent loads in flight per lane
-      const double v0 = part_load<COHERENT>(src + b), v1 = part_load<COHERENT>(src + b + G), v2 = part_load<COHERENT>(src + b + 2u * G),
-                   v3 = part_load<COHERENT>(src + b + 3u * G);
-      const double v4 = part_load<COHERENT>(src + b + 4u * G), v5 = part_load<COHERENT>(src + b + 5u * G),
-                   v6 = part_load<COHERENT>(src + b + 6u * G), v7 = part_load<COHERENT>(src + b + 7u * G);
+      const double v0 = part_load<AGENT>(src + b), v1 = part_load<AGENT>(src + b + G), v2 = part_load<AGENT>(src + b + 2u * G),
+                   v3 = part_load<AGENT>(src + b + 3u * G);
+      const double v4 = part_load<AGENT>(src + b + 4u * G), v5 = part_load<AGENT>(src + b + 5u * G),
+                   v6 = part_load<AGENT>(src + b + 6u * G), v7 = part_load<AGENT>(src + b + 7u * G);
       s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
     }
-    for (; b < n; b += G) s0 += part_load<COHERENT>(src + b);
+    for (; b < n; b += G) s0 += part_load<AGENT>(src + b);
     red[v][g] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   }
   __syncthreads();
@@ -948,10 +950,7 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ part, uin
 }
 
 struct SolveShared {
-  union {
-    double red[kGenN][64];    // reduce_rows' scratch (partials from global memory)
-    double tr[kAccN][129];    // k_icp_persist: the quad sums, transposed (never in use at the same time)
-  };
+  double red[kGenN][64];  // reduce_rows' scratch (partials from global memory)
   double totA[kAccN], totB[kGenN];
   double sh_log[13][6];
 };
@@ -964,15 +963,14 @@ struct SolveShared {
 // (ticket counter + __threadfence): correct, but the device-scope release/acquire fences write back and invalidate the
 // XCDs' L2s on every launch -- the map falls out of cache and C2 drops from 2285 to 960 scans/s.  Kernel boundaries
 // are the cheap way to order producers and consumers on this part.)
-// LDS_STATE: the state block lives in LDS (k_icp_persist keeps it there for the whole alignment) instead of global memory.
+// LDS_STATE: the state block lives in LDS (k_step16: one copy per workgroup) instead of global memory.
 // WAVE0: only the first wave of the workgroup calls (the totals are ready in LDS, nothing here needs the other waves): the
 // one workgroup barrier below becomes a wave-level hand-over.
-template <bool LDS_STATE = false, bool WAVE0 = false, bool COHERENT = false>
+template <bool LDS_STATE = false, bool WAVE0 = false, bool AGENT = false>
 __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, const SolveK* __restrict__ kp_,
                                            const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                            const double* __restrict__ partB, uint32_t nB, uint32_t strideB,
-                                           SolveShared& sh, bool totA_ready = false, bool totB_ready = false,
-                                           int lane = (int)threadIdx.x) {  // (k_loop16 passes a lane index the optimiser cannot hoist from)
+                                           SolveShared& sh, bool totA_ready = false, bool totB_ready = false) {
   double (*red)[64] = sh.red;
   double* totA = sh.totA;
   double* totB = sh.totB;
@@ -982,10 +980,11 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, con
   const SolveK __attribute__((address_space(4)))& k = *(const SolveK __attribute__((address_space(4)))*)uniform_const_ptr(kp_);
   typedef typename std::conditional<LDS_STATE, IcpDeviceState __attribute__((address_space(3)))*, IcpDeviceState MH_AS_GLOBAL*>::type state_ptr;
   state_ptr const st = (state_ptr)st_;
+  const int lane = threadIdx.x;
   if (nA)
-    reduce_rows<COHERENT>(partA, nA, strideA, kAccN, totA, red, lane);
+    reduce_rows<AGENT>(partA, nA, strideA, kAccN, totA, red);
   if (nB)
-    reduce_rows<COHERENT>(partB, nB, strideB, kGenN, totB, red, lane);
+    reduce_rows<AGENT>(partB, nB, strideB, kGenN, totB, red);
   double a[kAccN], gen[kGenN];
 #pragma unroll
   for (int i = 0; i < kAccN; i++) a[i] = (nA || totA_ready) ? totA[i] : 0.0;
@@ -1196,181 +1195,40 @@ __device__ __forceinline__ void k_solve_body(IcpDeviceState* __restrict__ st, co
 }
 
 // ================================================================================================
-// k_accum_solve1: accumulation AND Gauss-Newton step of a small layer in ONE workgroup (no inter-workgroup hand-over,
-// hence no device-scope fence): for the <= kOneGroupMaxPoints points of the real pipeline's ICP layer an iteration
-// becomes match | accumulate+solve | accumulate+solve -- three launches instead of five.
-// ================================================================================================
-constexpr uint32_t kOneGroupMaxPoints = 2048;  // measured: 1 k points -8 %, 2 k -4 %, 4 k +7 % per alignment vs k_accum + k_solve
-constexpr int kOneGroupBatch = 4;        // points per lane and round of loads
-constexpr int kOneGroupAccThreads = 256;  // lanes that accumulate (one wave per SIMD: the same VALU time as 512, half the reduction)
-constexpr int kOneGroupChunk = 17;        // lanes summed by one thread of the first reduction stage (odd: conflict-free LDS reads)
-constexpr int kOneGroupGroups = (kOneGroupAccThreads + kOneGroupChunk - 1) / kOneGroupChunk;  // 16
-
-// Phase times of the first version (wall_clock64 stamps, 900 points): loads+accumulate 1.8 us, 18 wave_sum 2.3 us
-// (8 waves x 414 DPP/readlane/add instructions: issue bound), partials through global memory + reduce_rows 0.9 us,
-// LDLT 2.5 us, exp 0.5 us, log + tail 1.9 us.  Hence: the per-lane sums go through LDS transposed (each lane writes its
-// 18 values, 288 threads add 17 lanes each, 18 threads add the 16 group sums: fixed order, ~60 instructions per wave)
-// and land in the solve's shared totals directly; the point loads are issued before the state is even looked at.
-// sum of NR (<= kAccN) values per accumulating lane -> out[0..NR), through the transposed buffer (reusable afterwards)
-template <int NR>
-__device__ __forceinline__ void one_group_sum(const double* vals, bool acc_lane, double (*tr)[kOneGroupAccThreads + 1],
-                                              double (*p1)[kOneGroupGroups], double* out) {
-  static_assert(NR <= kAccN, "rows per pass");
-  if (acc_lane) {
-#pragma unroll
-    for (int j = 0; j < NR; j++) tr[j][threadIdx.x] = vals[j];
-  }
-  __syncthreads();
-  if (threadIdx.x < NR * kOneGroupGroups) {  // stage 1: row j, lanes [17 g, 17 g + 17)
-    const int j = threadIdx.x / kOneGroupGroups, g = threadIdx.x % kOneGroupGroups;
-    const int l0 = g * kOneGroupChunk;
-    double sum = tr[j][l0];
-#pragma unroll
-    for (int i = 1; i < kOneGroupChunk; i++)
-      if (l0 + i < kOneGroupAccThreads) sum += tr[j][l0 + i];
-    p1[j][g] = sum;
-  }
-  __syncthreads();
-  if (threadIdx.x < NR) {  // stage 2: the group sums in order
-    double sum = p1[threadIdx.x][0];
-#pragma unroll
-    for (int g = 1; g < kOneGroupGroups; g++) sum += p1[threadIdx.x][g];
-    out[threadIdx.x] = sum;
-  }
-  __syncthreads();
-}
-
-// PL: the layer also carries Matcher_Point2Plane pairings (pl_c.w != 0: centroid + normal of the paired voxel, written by
-// k_match16<true>) whose 29 generic rows are accumulated alongside and summed in two more passes of the same buffer.
-template <bool PL>
-__device__ __forceinline__ void k_accum_solve1_body(IcpDeviceState* __restrict__ st, uint32_t first,
-                                                    const MatchK* __restrict__ kp, const SolveK* __restrict__ sk,
-                                                    const float* __restrict__ lx, const float* __restrict__ ly,
-                                                    const float* __restrict__ lz, uint32_t n,
-                                                    const float4* __restrict__ pair_q,
-                                                    const uint32_t* __restrict__ pair_gidx,
-                                                    const float4* __restrict__ pl_c,
-                                                    const float4* __restrict__ pl_n) {
-  __shared__ SolveShared sh;
-  __shared__ double tr[kAccN][kOneGroupAccThreads + 1];
-  __shared__ double p1[kAccN][kOneGroupGroups];
-  MH_PHASE(0);
-  const bool acc_lane = threadIdx.x < kOneGroupAccThreads;
-  uint32_t gi[kOneGroupBatch];
-  f32x4 q[kOneGroupBatch], pc[kOneGroupBatch], pn[kOneGroupBatch];
-  float px[kOneGroupBatch], py[kOneGroupBatch], pz[kOneGroupBatch];
-  // arrays through global-space pointers, parameters through the scalar path (mh_nn_device.h, G())
-  const auto g_q = G(reinterpret_cast<const f32x4*>(pair_q)), g_pc = G(reinterpret_cast<const f32x4*>(pl_c)),
-             g_pn = G(reinterpret_cast<const f32x4*>(pl_n));
-  const auto g_gi = G(pair_gidx);
-  const auto g_x = G(lx), g_y = G(ly), g_z = G(lz);
-  IcpDeviceState MH_AS_GLOBAL* const gst = G(st);
-  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
-  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
-  if (acc_lane) {
-#pragma unroll
-    for (int u = 0; u < kOneGroupBatch; u++) {  // first round of loads: nothing here depends on the state block
-      const uint32_t i = (uint32_t)u * kOneGroupAccThreads + threadIdx.x;
-      const uint32_t ic = i < n ? i : n - 1;
-      gi[u] = i < n ? g_gi[ic] : kNoMatch;
-      q[u] = g_q[ic];
-      px[u] = g_x[ic]; py[u] = g_y[ic]; pz[u] = g_z[ic];
-      if (PL) {
-        pc[u] = g_pc[ic];
-        pn[u] = g_pn[ic];
-        if (i >= n) pc[u].w = 0.f;
-      }
-    }
-  }
-  // ... and neither do the pose and the parameters wait for the done flag: everything is in flight at once
-  double T[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) T[i] = gst->T[i];
-  struct { uint32_t kernel; double w_pt2pt, w_pt2pl; } k = {ck->kernel, ck->w_pt2pt, ck->w_pt2pl};
-  const double kparam = gst->cur_kparam;
-  const uint32_t done = gst->done, inner0 = gst->inner;
-  if (done) return;
-  if (!first && inner0 == 0) return;  // the previous solve already closed this ICP iteration
-  Acc a;
-  acc_zero(a);
-  double v[PL ? kGenN : 1];
-#pragma unroll
-  for (int j = 0; j < (PL ? kGenN : 1); j++) v[j] = 0.0;
-  if (acc_lane) {
-    for (uint32_t base = 0;;) {
-#pragma unroll
-      for (int u = 0; u < kOneGroupBatch; u++) {
-        acc_pt2pt_masked(a, T, gi[u] != kNoMatch, px[u], py[u], pz[u], q[u].x, q[u].y, q[u].z, k.kernel, kparam, k.w_pt2pt);
-        if (PL && pc[u].w != 0.f) {
-          double r[kGenN];
-          acc_pt2pl_rows(r, T, px[u], py[u], pz[u], make_float4(pc[u].x, pc[u].y, pc[u].z, pc[u].w),
-                         make_float4(pn[u].x, pn[u].y, pn[u].z, pn[u].w), k.kernel, kparam, k.w_pt2pl);
-#pragma unroll
-          for (int j = 0; j < kGenN; j++) v[PL ? j : 0] += r[j];
-        }
-      }
-      base += kOneGroupAccThreads * kOneGroupBatch;
-      if (base >= n) break;
-#pragma unroll
-      for (int u = 0; u < kOneGroupBatch; u++) {
-        const uint32_t i = base + (uint32_t)u * kOneGroupAccThreads + threadIdx.x;
-        const uint32_t ic = i < n ? i : n - 1;
-        gi[u] = i < n ? g_gi[ic] : kNoMatch;
-        q[u] = g_q[ic];
-        px[u] = g_x[ic]; py[u] = g_y[ic]; pz[u] = g_z[ic];
-        if (PL) {
-          pc[u] = g_pc[ic];
-          pn[u] = g_pn[ic];
-          if (i >= n) pc[u].w = 0.f;
-        }
-      }
-    }
-    MH_PHASE(1);
-  }
-  one_group_sum<kAccN>(a.v, acc_lane, tr, p1, sh.totA);
-  if (PL) {
-    one_group_sum<kAccN>(v, acc_lane, tr, p1, sh.totB);
-    one_group_sum<kGenN - kAccN>(v + (PL ? kAccN : 0), acc_lane, tr, p1, sh.totB + kAccN);
-  }
-  MH_PHASE(3);
-  solve_body(st, sk, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true, PL);
-  publish_progress(st, sk);
-}
-template <bool PL>
-__global__ __launch_bounds__(kSolveThreads) void k_accum_solve1(IcpDeviceState* __restrict__ st, uint32_t first,
-                                                                const MatchK* __restrict__ kp, const SolveK* __restrict__ sk,
-                                                                const float* __restrict__ lx, const float* __restrict__ ly,
-                                                                const float* __restrict__ lz, uint32_t n,
-                                                                const float4* __restrict__ pair_q,
-                                                                const uint32_t* __restrict__ pair_gidx,
-                                                                const float4* __restrict__ pl_c,
-                                                                const float4* __restrict__ pl_n) {
-  k_accum_solve1_body<PL>(st, first, kp, sk, lx, ly, lz, n, pair_q, pair_gidx, pl_c, pl_n);
-}
-// the one-workgroup chain in lock step: one workgroup per job (blockIdx.y)
-template <bool PL>
-__global__ __launch_bounds__(kSolveThreads) void k_accum_solve1_b(const BatchJob* __restrict__ jobs, uint32_t first) {
-  const BatchJob& j = jobs[blockIdx.y];
-  k_accum_solve1_body<PL>(j.st, first, j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.pair_q, j.pair_gidx, j.pl_c, j.pl_n);
-}
-
-// ================================================================================================
-// k_step16: the small-layer iteration with the solve CARRIED INTO THE NEXT LAUNCH (round 4).  The chain above spends a launch
-// of one workgroup on every Gauss-Newton step (k_match16 | k_accum_solve1 | k_accum_solve1: 28 us per ICP iteration of the
-// real pipeline's 1.2-1.6 k-point layer, of which the device computes for maybe a third).  Here every launch is the same
-// kernel over the whole layer, and what it does is decided by the state block alone:
+// k_step16: the small-layer iteration with the solve CARRIED INTO THE NEXT LAUNCH (round 4).  The chain it replaces spent a
+// launch of ONE workgroup on every Gauss-Newton step (k_match16 | k_accum_solve1 | k_accum_solve1, round 3: 28 us per ICP iteration of
+// the real pipeline's 1.2-1.6 k-point layer).  Here every launch is the same kernel over the whole layer, and what it does
+// is decided by the state block alone:
 //   1. every workgroup copies the state block's head into LDS and, if a step is pending, closes it: the ordered sum of the
-//      per-workgroup partials of the previous launch + solve_body -- all workgroups compute the same bits, nobody waits for a
-//      hand-over; workgroup 0 writes the new state to the OTHER state block (the one this launch reads is never written)
-//      and publishes the progress word;
-//   2. body: at the start of an ICP iteration (inner == 0) the row search of k_match16 for 32 points per workgroup, the
-//      pairings stored and their Gauss-Newton sums written as this workgroup's partials (also ping-pong: other workgroups may
+//      partials of the previous launch + solve_body -- all workgroups compute the same bits, nobody waits for a hand-over;
+//      workgroup 0 writes the new state to the OTHER state block (the one this launch reads is never written) and
+//      publishes the progress word;
+//   2. body: at the start of an ICP iteration (inner == 0) the row search of k_match16 for groups of 32 points, the pairings
+//      stored and their Gauss-Newton sums written as one partial column per GROUP (also ping-pong: other workgroups may
 //      still be reading the previous launch's); at an inner step the sums of the stored pairings under the new pose.
-// An ICP iteration is max_inner launches (2 in the shipped pipelines) instead of 1 + max_inner, none of them a single
-// workgroup, and a launch never idles because an iteration closed early: the next one simply starts in its place.
-// `close_only` (one workgroup, in place into the canonical block): the pending step at the end of a chunk of launches.
+// An ICP iteration is max_inner launches (2 in the shipped pipelines) instead of 1 + max_inner, and a launch never idles
+// because an iteration closed early: the next one simply starts in its place.  A workgroup takes the groups wg, wg + nw, ...:
+// one group each for a single alignment; in a lock-step batch the host caps nw so that all jobs' workgroups are resident
+// at once (512 threads x ~250 registers: one workgroup per CU) -- the columns, hence the sums and the result bit for bit, do
+// not depend on nw.  `close_only` (one workgroup, in place into the canonical block): the pending step at the end of a
+// chunk of launches.
+// Phase stamps (tools/phase_probe.py, 1.4 k points, us): state into LDS 0.2, partials summed 1.4, assemble 0.4, LDLT 0.7,
+// exp + compose 0.55, log 1.0, tail 0.6, state written 0.4, search + accumulate 1.1, sums 1.0 -- 7.5 of the ~13 us from one
+// launch to the next; the rest is the launch.
+// (Also built and measured in round 4, and removed: k_loop16, the whole loop in ONE launch -- the same body and solve per
+// workgroup, a grid barrier between them (arrival counter + agent-scope loads of the partials; no cache invalidation, the map
+// stays in the L2s).  Bit-identical, and slower: 15.8 us per Gauss-Newton step against 16.2 launch by launch in a 40-iteration
+// fit, 0.594-0.611 against 0.544-0.551 ms of ICP per scan on the city drive (0.617 with an L2 write-back as the release).
+// Crossing the XCDs costs what a launch boundary costs, and inside a loop the compiler hoists ~470 bytes per lane of lane
+// masks, offset tables and literal constants into scratch.)
+// (And: the covariance + the result written to the host's page-locked mirror by the launch that finds the loop finished --
+// no covariance launches, no read-back copy, no event -- bit-identical to the three covariance kernels, 1536-1548 -> 1527-1573
+// scans/s: the one workgroup that sums the whole layer takes what the launches took.  Removed.)
 // ================================================================================================
-constexpr uint32_t kStepPoints = kSolveThreads / 16;  // scan points (DPP rows) per workgroup
+constexpr uint32_t kStepPoints = kSolveThreads / 16;  // scan points (DPP rows) per group
+constexpr uint32_t kStepRowsA = kAccN;            // rows of one half of the point-to-point partials
+constexpr uint32_t kStepMaxPoints = 8192;      // (above: k_match16<fused> | k_solve | k_accum | k_solve, then the quad matcher's chain)
+constexpr uint32_t kStepMaxWorkgroups = 256;   // one per CU (512 threads x ~250 registers); beyond, workgroups take several groups
 constexpr uint32_t kStateHeadDwords = (uint32_t)(offsetof(IcpDeviceState, cov) / 4);  // everything the loop touches
 static_assert(kStateHeadDwords <= 64 && offsetof(IcpDeviceState, cov) % 8 == 0, "state head is copied by one wave");
 
@@ -1382,22 +1240,22 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
                                               MapView map, float4* pair_q, uint32_t* pair_gidx, float4* pl_c, float4* pl_n,
                                               const double* __restrict__ partA_in, double* __restrict__ partA_out,
                                               const double* __restrict__ partB_in, double* __restrict__ partB_out,
-                                              uint32_t nwg, uint32_t close_only) {
+                                              uint32_t ngroups, uint32_t nw, uint32_t close_only) {
   __shared__ SolveShared sh;
   __shared__ __attribute__((aligned(8))) uint32_t lst_raw[kStateHeadDwords];
   __shared__ double rowsA[kAccN][kStepPoints + 1];
   __shared__ double rowsB[PL ? kGenN : 1][kStepPoints + 1];
   const uint32_t tid = threadIdx.x, wg = blockIdx.x;
-  if (wg >= nwg) return;  // (lock-step batches: the grid is the largest job's)
+  if (wg >= nw) return;  // (lock-step batches: the grid is the largest job's)
   IcpDeviceState* const lst = reinterpret_cast<IcpDeviceState*>(lst_raw);
-  // the point of this row and what is stored for it -- the previous pairing bounds the search at an iteration start and IS the
-  // pairing at an inner step -- are on their way before the state is looked at
-  const uint32_t i = wg * kStepPoints + (tid >> 4), r16 = tid & 15u;
-  const uint32_t ic = i < n ? i : n - 1;
-  const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
-  const f32x4 stored = G(reinterpret_cast<const f32x4*>(pair_q))[ic];
+  // the point of this row is on its way before the state is looked at.  (Not so what the PREVIOUS launch stored for it: see below.)
+  const uint32_t row = tid >> 4, r16 = tid & 15u;
+  uint32_t g = wg;
+  uint32_t i = g * kStepPoints + row;
+  uint32_t ic = i < n ? i : n - 1;
+  float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
   MH_PHASE(0);
-  if (tid < kStateHeadDwords) lst_raw[tid] = G(reinterpret_cast<const uint32_t*>(s_in))[tid];
+  if (tid < kStateHeadDwords) lst_raw[tid] = __hip_atomic_load(reinterpret_cast<const uint32_t*>(s_in) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (lst->done) {  // the loop has ended (the canonical block has it): keep the ping-pong consistent, nothing else
     if (wg == 0 && tid < kStateHeadDwords && s_out != s_in) G(reinterpret_cast<uint32_t*>(s_out))[tid] = lst_raw[tid];
@@ -1405,7 +1263,7 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
   }
   MH_PHASE(1);
   if (lst->pending) {
-    solve_body<true, false>(lst, sk, partA_in, nwg, nwg, PL ? partB_in : nullptr, PL ? nwg : 0u, PL ? nwg : 0u, sh);
+    solve_body<true, false, true>(lst, sk, partA_in, ngroups, ngroups, PL ? partB_in : nullptr, PL ? ngroups : 0u, PL ? ngroups : 0u, sh);
     __syncthreads();
   }
   const uint32_t done = lst->done;
@@ -1415,7 +1273,7 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
     __syncthreads();
     if (tid < kStateHeadDwords) {
       const uint32_t w = lst_raw[tid];
-      G(reinterpret_cast<uint32_t*>(s_out))[tid] = w;
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(s_out) + tid, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (done && s_canon != s_out) G(reinterpret_cast<uint32_t*>(s_canon))[tid] = w;
     }
     if (tid == 0) {
@@ -1426,6 +1284,15 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
   MH_PHASE(11);
   if (!body) return;
   MH_PHASE(14);
+  // What the previous launch produced is consumed with care.  Under load from other streams (sixteen sequences in one
+  // process) a launch can begin up to ~0.25 us before the end time stamp of its predecessor on the same stream (rocprofv3
+  // kernel trace: 10 of 3464 k_step16_b dispatches), and data the predecessor wrote last was seen stale by loads issued
+  // first thing: a partial column two launches old -- ulp-sized differences between a batch and the same alignment alone,
+  // a few per 200-scan run, gone with ANY extra microsecond before the reads.  Hence: state and partials cross launches
+  // through agent-scope stores and loads (write-through, acknowledged before the wave ends; never answered from a stale L2
+  // line), and the stored pairings -- the previous pairing bounds the search at an iteration start and IS the pairing at an
+  // inner step -- are read here, microseconds into the launch, not prefetched at its top.
+  f32x4 stored = G(reinterpret_cast<const f32x4*>(pair_q))[ic];
 
   typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
   typedef const double __attribute__((address_space(4))) * cf64_ptr;
@@ -1437,78 +1304,88 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
   const float thr2 = lst->cur_thr2, ang2 = lst->cur_ang2;
   const double kparam = lst->cur_kparam;
   const uint32_t kernel = ck->kernel;
-  Acc a;
-  acc_zero(a);
-  double v[PL ? kGenN : 1];
+  for (;;) {  // the groups of this workgroup (workgroup-uniform trip count)
+    Acc a;
+    acc_zero(a);
+    double v[PL ? kGenN : 1];
 #pragma unroll
-  for (int j = 0; j < (PL ? kGenN : 1); j++) v[j] = 0.0;
-  if (i < n) {  // row-uniform
-    f32x4 q = stored, bc = (f32x4){0.f, 0.f, 0.f, 0.f}, bn = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bool ok, okp = false;
-    if (inner == 0) {  // (workgroup-uniform) a new ICP iteration: the matchers
-      float px, py, pz;
-      transform_point(T, x, y, z, px, py, pz);
-      float bound0 = __builtin_inff();
-      if (iter > 0 && !map.no_prev_bound && stored.w < __builtin_inff()) {
-        const float dx = stored.x - px, dy = stored.y - py, dz = stored.z - pz;
-        bound0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic of the scans
-      }
-      const NNResult r = nn_search_row16(map, r16, px, py, pz, bound0);
-      const float n2 = (px * px + py * py) + pz * pz;
-      ok = r.found && (r.d2 < thr2 + ang2 * n2);
-      if (PL) {  // Matcher_Point2Plane first (k_match16_body)
-        const float pl_thr = (float)((cf64_ptr)uniform_const_ptr(ck->pl_thr))[iter];
-        okp = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
-        if (r16 == 0) {
-          G(reinterpret_cast<f32x4*>(pl_c))[i] = (f32x4){bc.x, bc.y, bc.z, okp ? 1.f : 0.f};
-          G(reinterpret_cast<f32x4*>(pl_n))[i] = (f32x4){bn.x, bn.y, bn.z, 0.f};
+    for (int j = 0; j < (PL ? kGenN : 1); j++) v[j] = 0.0;
+    if (i < n) {  // row-uniform
+      f32x4 q = stored, bc = (f32x4){0.f, 0.f, 0.f, 0.f}, bn = (f32x4){0.f, 0.f, 0.f, 0.f};
+      bool ok, okp = false;
+      if (inner == 0) {  // (workgroup-uniform) a new ICP iteration: the matchers
+        float px, py, pz;
+        transform_point(T, x, y, z, px, py, pz);
+        float bound0 = __builtin_inff();
+        if (iter > 0 && !map.no_prev_bound && stored.w < __builtin_inff()) {
+          const float dx = stored.x - px, dy = stored.y - py, dz = stored.z - pz;
+          bound0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic of the scans
         }
-        if (okp && ck->skip_pl_paired) ok = false;
+        const NNResult r = nn_search_row16(map, r16, px, py, pz, bound0);
+        const float n2 = (px * px + py * py) + pz * pz;
+        ok = r.found && (r.d2 < thr2 + ang2 * n2);
+        if (PL) {  // Matcher_Point2Plane first (k_match16_body)
+          const float pl_thr = (float)((cf64_ptr)uniform_const_ptr(ck->pl_thr))[iter];
+          okp = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
+          if (r16 == 0) {
+            G(reinterpret_cast<f32x4*>(pl_c))[i] = (f32x4){bc.x, bc.y, bc.z, okp ? 1.f : 0.f};
+            G(reinterpret_cast<f32x4*>(pl_n))[i] = (f32x4){bn.x, bn.y, bn.z, 0.f};
+          }
+          if (okp && ck->skip_pl_paired) ok = false;  // (the nearest point still goes to pair_q: it bounds the next search)
+        }
+        if (r16 == 0) {
+          G(reinterpret_cast<f32x4*>(pair_q))[i] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
+          G(pair_gidx)[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+        }
+        q = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
+      } else {  // an inner Gauss-Newton step: the stored pairings under the new pose
+        ok = G(pair_gidx)[i] != kNoMatch;
+        if (PL) {
+          bc = G(reinterpret_cast<const f32x4*>(pl_c))[i];
+          bn = G(reinterpret_cast<const f32x4*>(pl_n))[i];
+          okp = bc.w != 0.f;
+        }
       }
       if (r16 == 0) {
-        G(reinterpret_cast<f32x4*>(pair_q))[i] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
-        G(pair_gidx)[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
-      }
-      q = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
-    } else {  // an inner Gauss-Newton step: the stored pairings under the new pose
-      ok = G(pair_gidx)[i] != kNoMatch;
-      if (PL) {
-        bc = G(reinterpret_cast<const f32x4*>(pl_c))[i];
-        bn = G(reinterpret_cast<const f32x4*>(pl_n))[i];
-        okp = bc.w != 0.f;
+        acc_pt2pt_masked(a, T, ok, x, y, z, q.x, q.y, q.z, kernel, kparam, ck->w_pt2pt);
+        if (PL && okp)
+          acc_pt2pl_rows(v, T, x, y, z, make_float4(bc.x, bc.y, bc.z, 1.f), make_float4(bn.x, bn.y, bn.z, 0.f), kernel, kparam,
+                         ck->w_pt2pl);
       }
     }
+    MH_PHASE(12);
+    // 32 row leaders -> one partial per sum and group, fixed order
     if (r16 == 0) {
-      acc_pt2pt_masked(a, T, ok, x, y, z, q.x, q.y, q.z, kernel, kparam, ck->w_pt2pt);
-      if (PL && okp)
-        acc_pt2pl_rows(v, T, x, y, z, make_float4(bc.x, bc.y, bc.z, 1.f), make_float4(bn.x, bn.y, bn.z, 0.f), kernel, kparam,
-                       ck->w_pt2pl);
+#pragma unroll
+      for (int j = 0; j < kAccN; j++) rowsA[j][row] = a.v[j];
+      if (PL) {
+#pragma unroll
+        for (int j = 0; j < kGenN; j++) rowsB[PL ? j : 0][row] = v[PL ? j : 0];
+      }
     }
-  }
-  MH_PHASE(12);
-  // 32 row leaders -> one partial per sum and workgroup, fixed order
-  if (r16 == 0) {
+    __syncthreads();
+    if (tid < kAccN) {
+      double sum = rowsA[tid][0];
 #pragma unroll
-    for (int j = 0; j < kAccN; j++) rowsA[j][tid >> 4] = a.v[j];
-    if (PL) {
-#pragma unroll
-      for (int j = 0; j < kGenN; j++) rowsB[PL ? j : 0][tid >> 4] = v[PL ? j : 0];
+      for (int r = 1; r < (int)kStepPoints; r++) sum += rowsA[tid][r];
+      __hip_atomic_store(partA_out + tid * ngroups + g, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  }
-  __syncthreads();
-  if (tid < kAccN) {
-    double sum = rowsA[tid][0];
+    if (PL && tid >= 64 && tid < 64 + kGenN) {  // (the second wave)
+      const uint32_t t = tid - 64;
+      double sum = rowsB[PL ? t : 0][0];
 #pragma unroll
-    for (int r = 1; r < (int)kStepPoints; r++) sum += rowsA[tid][r];
-    G(partA_out)[tid * nwg + wg] = sum;
+      for (int r = 1; r < (int)kStepPoints; r++) sum += rowsB[PL ? t : 0][r];
+      __hip_atomic_store(partB_out + t * ngroups + g, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    g += nw;
+    if (g >= ngroups) break;
+    i = g * kStepPoints + row;
+    ic = i < n ? i : n - 1;
+    x = G(lx)[ic]; y = G(ly)[ic]; z = G(lz)[ic];
+    stored = G(reinterpret_cast<const f32x4*>(pair_q))[ic];
+    __syncthreads();  // (the row buffers are reused)
   }
-  if (PL && tid >= 64 && tid < 64 + kGenN) {  // (the second wave)
-    const uint32_t t = tid - 64;
-    double sum = rowsB[PL ? t : 0][0];
-#pragma unroll
-    for (int r = 1; r < (int)kStepPoints; r++) sum += rowsB[PL ? t : 0][r];
-    G(partB_out)[t * nwg + wg] = sum;
-  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the write-through stores above have been acknowledged before this wave ends
   MH_PHASE(13);
 }
 template <bool PL>
@@ -1519,204 +1396,23 @@ __global__ __launch_bounds__(kSolveThreads) void k_step16(const IcpDeviceState* 
                                                           uint32_t n, MapView map, float4* pair_q, uint32_t* pair_gidx,
                                                           float4* pl_c, float4* pl_n, const double* __restrict__ partA_in,
                                                           double* __restrict__ partA_out, const double* __restrict__ partB_in,
-                                                          double* __restrict__ partB_out, uint32_t nwg, uint32_t close_only) {
+                                                          double* __restrict__ partB_out, uint32_t ngroups, uint32_t close_only) {
   k_step16_body<PL>(s_in, s_out, s_canon, kp, sk, lx, ly, lz, n, map, pair_q, pair_gidx, pl_c, pl_n, partA_in, partA_out, partB_in,
-                    partB_out, nwg, close_only);
+                    partB_out, ngroups, gridDim.x, close_only);
 }
-// in lock step: blockIdx.y = job; `par`: which state block / partials half this launch reads
+// in lock step: blockIdx.y = job; `par`: which state block / partials half this launch reads; gridDim.x: the host's cap on a
+// job's workgroups
 template <bool PL>
 __global__ __launch_bounds__(kSolveThreads) void k_step16_b(const BatchJob* __restrict__ jobs, uint32_t par, uint32_t close_only) {
   const BatchJob& j = jobs[blockIdx.y];
-  const uint32_t nwg = (j.n + kStepPoints - 1) / kStepPoints;
+  const uint32_t ng0 = (j.n + kStepPoints - 1) / kStepPoints;
+  const uint32_t ngroups = ng0 ? ng0 : 1u;
   IcpDeviceState* const S[2] = {j.st, j.st_b};
-  double* const pa[2] = {j.part, j.part + (size_t)kAccN * nwg};
-  double* const pb[2] = {j.partb, j.partb ? j.partb + (size_t)kGenN * nwg : nullptr};
+  double* const pa[2] = {j.part, j.part + (size_t)kStepRowsA * ngroups};
+  double* const pb[2] = {j.partb, j.partb ? j.partb + (size_t)kGenN * ngroups : nullptr};
   k_step16_body<PL>(S[par], close_only ? S[0] : S[par ^ 1u], S[0], j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx,
-                    j.pl_c, j.pl_n, pa[par], pa[par ^ 1u], pb[par], pb[par ^ 1u], nwg ? nwg : 1u, close_only);
-}
-
-// ================================================================================================
-// k_loop16: the WHOLE ICP loop of a small layer in one launch (round 4).  The phase stamps of k_step16 say where a launch
-// of the step chain spends its 13 us: 0.2 us reading the state, 1.4 us summing the partials, 3.6 us in the Gauss-Newton
-// step and the iteration's tail, 0.4 us writing the state, 1.1 us searching and accumulating, 1 us summing -- 7.5 us; the
-// other 5.5 us are the launch itself (dispatch, wave start-up, the cache write-back at the kernel's end).  Here the
-// workgroups stay: the body of k_step16, then a grid barrier over the workgroups of this alignment, then every workgroup
-// sums the partials and takes the Gauss-Newton step for itself (same bits everywhere: the state lives in LDS, one copy
-// per workgroup, and is written back once).  What crosses workgroups -- the partials and the arrival counter -- is written
-// back by an agent-scope release of one lane and read with agent-scope loads; nothing is invalidated, the map stays in the
-// L2s.  (Round 2's cooperative kernel fenced with __threadfence on both sides of its barriers and lost the map from the
-// caches at every one of them; see solve_body's comment.)
-// A workgroup handles the 32-point groups g = wg, wg + nw, ...: the partial columns stay one per GROUP, so the sums -- and
-// the result, bit for bit -- do not depend on how many workgroups the host could afford (AlignJob::loop_workgroups).
-// All nw workgroups must be resident together: the host keeps nw within a budget per device (g_loop_slots); a lane that
-// waits longer than kLoopBarrierTimeout gives up for the whole alignment, which then fails (never seen; a guard, not a path).
-// ================================================================================================
-constexpr unsigned long long kLoopBarrierTimeout = 20000000ull;  // wall_clock64 ticks of 10 ns: 0.2 s
-constexpr uint32_t kTermLoopBarrierTimeout = 0xFFFF0001u;        // (internal: poll() turns it into MH_ERR_INTERNAL)
-
-template <bool PL>
-__device__ __forceinline__ void loop16_solve(IcpDeviceState* lst, const SolveK* sk, const double* pa, const double* pb,
-                                             uint32_t ngroups, SolveShared* sh, uint32_t lane) {
-  solve_body<true, false, true>(lst, sk, pa, ngroups, ngroups, PL ? pb : nullptr, PL ? ngroups : 0u, PL ? ngroups : 0u, *sh, false, false,
-                                (int)lane);
-}
-
-template <bool PL>
-__device__ __forceinline__ void k_loop16_body(IcpDeviceState* st, const MatchK* __restrict__ kp, const SolveK* __restrict__ sk,
-                                              const float* __restrict__ lx, const float* __restrict__ ly,
-                                              const float* __restrict__ lz, uint32_t n, MapView map, float4* pair_q,
-                                              uint32_t* pair_gidx, float4* pl_c, float4* pl_n, double* partA, double* partB,
-                                              uint32_t ngroups, uint32_t* sync, uint32_t wg, uint32_t nw) {
-  __shared__ SolveShared sh;
-  __shared__ __attribute__((aligned(8))) uint32_t lst_raw[kStateHeadDwords];
-  __shared__ double rowsA[kAccN][kStepPoints + 1];
-  __shared__ double rowsB[PL ? kGenN : 1][kStepPoints + 1];
-  __shared__ uint32_t gave_up;
-  const uint32_t tid = threadIdx.x;
-  if (wg >= nw) return;
-  IcpDeviceState* const lst = reinterpret_cast<IcpDeviceState*>(lst_raw);
-  if (tid < kStateHeadDwords) lst_raw[tid] = G(reinterpret_cast<const uint32_t*>(st))[tid];
-  if (tid == 0) gave_up = 0;
-  __syncthreads();
-  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
-  typedef const double __attribute__((address_space(4))) * cf64_ptr;
-  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
-  const uint32_t kernel = ck->kernel;
-  for (uint32_t step = 0; !lst->done; step++) {
-    // the lane index through a register the optimiser cannot see through: what the search and the solve derive from it (lane
-    // masks, voxel offset tables, the prior's perturbations) would otherwise be hoisted out of the loop -- and spilled there
-    uint32_t tl = tid;
-    asm volatile("" : "+v"(tl));
-    const uint32_t row = tl >> 4, r16 = tl & 15u;
-    double* const pa = partA + (size_t)(step & 1u) * kAccN * ngroups;
-    double* const pb = PL ? partB + (size_t)(step & 1u) * kGenN * ngroups : nullptr;
-    const uint32_t inner = lst->inner, iter = lst->iter;
-    double T[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) T[k] = lst->T[k];
-    const float thr2 = lst->cur_thr2, ang2 = lst->cur_ang2;
-    const double kparam = lst->cur_kparam;
-    for (uint32_t g = wg; g < ngroups; g += nw) {  // (workgroup-uniform trip count)
-      const uint32_t i = g * kStepPoints + row;
-      const uint32_t ic = i < n ? i : n - 1;
-      const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
-      const f32x4 stored = G(reinterpret_cast<const f32x4*>(pair_q))[ic];
-      Acc a;
-      acc_zero(a);
-      double v[PL ? kGenN : 1];
-#pragma unroll
-      for (int j = 0; j < (PL ? kGenN : 1); j++) v[j] = 0.0;
-      if (i < n) {  // row-uniform; the body of k_step16
-        f32x4 q = stored, bc = (f32x4){0.f, 0.f, 0.f, 0.f}, bn = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bool ok, okp = false;
-        if (inner == 0) {
-          float px, py, pz;
-          transform_point(T, x, y, z, px, py, pz);
-          float bound0 = __builtin_inff();
-          if (iter > 0 && !map.no_prev_bound && stored.w < __builtin_inff()) {
-            const float dx = stored.x - px, dy = stored.y - py, dz = stored.z - pz;
-            bound0 = (dx * dx + dy * dy) + dz * dz;
-          }
-          const NNResult r = nn_search_row16(map, r16, px, py, pz, bound0);
-          const float n2 = (px * px + py * py) + pz * pz;
-          ok = r.found && (r.d2 < thr2 + ang2 * n2);
-          if (PL) {
-            const float pl_thr = (float)((cf64_ptr)uniform_const_ptr(ck->pl_thr))[iter];
-            okp = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
-            if (r16 == 0) {
-              G(reinterpret_cast<f32x4*>(pl_c))[i] = (f32x4){bc.x, bc.y, bc.z, okp ? 1.f : 0.f};
-              G(reinterpret_cast<f32x4*>(pl_n))[i] = (f32x4){bn.x, bn.y, bn.z, 0.f};
-            }
-            if (okp && ck->skip_pl_paired) ok = false;
-          }
-          if (r16 == 0) {
-            G(reinterpret_cast<f32x4*>(pair_q))[i] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
-            G(pair_gidx)[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
-          }
-          q = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
-        } else {
-          ok = G(pair_gidx)[i] != kNoMatch;
-          if (PL) {
-            bc = G(reinterpret_cast<const f32x4*>(pl_c))[i];
-            bn = G(reinterpret_cast<const f32x4*>(pl_n))[i];
-            okp = bc.w != 0.f;
-          }
-        }
-        if (r16 == 0) {
-          acc_pt2pt_masked(a, T, ok, x, y, z, q.x, q.y, q.z, kernel, kparam, ck->w_pt2pt);
-          if (PL && okp)
-            acc_pt2pl_rows(v, T, x, y, z, make_float4(bc.x, bc.y, bc.z, 1.f), make_float4(bn.x, bn.y, bn.z, 0.f), kernel, kparam,
-                           ck->w_pt2pl);
-        }
-      }
-      if (r16 == 0) {
-#pragma unroll
-        for (int j = 0; j < kAccN; j++) rowsA[j][row] = a.v[j];
-        if (PL) {
-#pragma unroll
-          for (int j = 0; j < kGenN; j++) rowsB[PL ? j : 0][row] = v[PL ? j : 0];
-        }
-      }
-      __syncthreads();
-      if (tid < kAccN) {
-        double sum = rowsA[tid][0];
-#pragma unroll
-        for (int r = 1; r < (int)kStepPoints; r++) sum += rowsA[tid][r];
-        G(pa)[tid * ngroups + g] = sum;
-      }
-      if (PL && tid >= 64 && tid < 64 + kGenN) {
-        const uint32_t t = tid - 64;
-        double sum = rowsB[PL ? t : 0][0];
-#pragma unroll
-        for (int r = 1; r < (int)kStepPoints; r++) sum += rowsB[PL ? t : 0][r];
-        G(pb)[t * ngroups + g] = sum;
-      }
-      __syncthreads();  // (the row buffers are reused by the next group; and every store of this workgroup has been issued)
-    }
-    // ---- grid barrier over the nw workgroups of this alignment ----
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this workgroup's partials (complete: the barrier above) leave the L2
-      __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t target = (step + 1u) * nw;
-      const unsigned long long t0 = wall_clock64();
-      uint32_t spins = 0;
-      while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 63u) == 0) {
-          if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > kLoopBarrierTimeout) {
-            __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gave_up = 1;
-            break;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (gave_up) {  // (workgroup-uniform) some workgroup of this alignment never arrived
-      if (tid == 0) {
-        lst->done = 1;
-        lst->term_reason = kTermLoopBarrierTimeout;
-      }
-      __syncthreads();
-      break;
-    }
-    // (the parameter block through a pointer the optimiser cannot see through: hoisted out of the loop, the solve's ~90
-    //  parameter words -- prior, hook check point, thresholds -- would be spilled before it and reloaded inside)
-    const SolveK* skl = sk;
-    asm volatile("" : "+s"(skl));
-    loop16_solve<PL>(lst, skl, pa, pb, ngroups, &sh, tl);
-    __syncthreads();
-  }
-  if (wg == 0 && tid < kStateHeadDwords) G(reinterpret_cast<uint32_t*>(st))[tid] = lst_raw[tid];
-}
-template <bool PL>
-__global__ __launch_bounds__(kSolveThreads) void k_loop16(IcpDeviceState* st, const MatchK* __restrict__ kp,
-                                                          const SolveK* __restrict__ sk, const float* __restrict__ lx,
-                                                          const float* __restrict__ ly, const float* __restrict__ lz,
-                                                          uint32_t n, MapView map, float4* pair_q, uint32_t* pair_gidx,
-                                                          float4* pl_c, float4* pl_n, double* partA, double* partB,
-                                                          uint32_t ngroups, uint32_t* sync) {
-  k_loop16_body<PL>(st, kp, sk, lx, ly, lz, n, map, pair_q, pair_gidx, pl_c, pl_n, partA, partB, ngroups, sync, blockIdx.x, gridDim.x);
+                    j.pl_c, j.pl_n, pa[par], pa[par ^ 1u], pb[par], pb[par ^ 1u], ngroups, ngroups < gridDim.x ? ngroups : gridDim.x,
+                    close_only);
 }
 
 // ================================================================================================
@@ -1730,21 +1426,76 @@ __global__ __launch_bounds__(kSolveThreads) void k_loop16(IcpDeviceState* st, co
 
 constexpr int kCovN = 22;  // 21 upper-triangle + count
 
+// column j of d T / d (x, y, z, yaw, pitch, roll) by central differences -> out[12]
+__device__ __forceinline__ void cov_prepare_lane(const Pose& Tc, int j, double hx, double ha, double* out) {
+  double v[6];
+  pose_to_ypr(Tc, v);
+  const double h = j < 3 ? hx : ha;
+  double vp[6], vm[6];
+  for (int i = 0; i < 6; i++) { vp[i] = v[i]; vm[i] = v[i]; }
+  vp[j] += h;
+  vm[j] -= h;
+  const Pose P = pose_from_ypr(vp), M = pose_from_ypr(vm);
+  for (int i = 0; i < 12; i++) out[i] = (P.m[i] - M.m[i]) / (2.0 * h);
+}
+// A^T A rows of one point-to-point pairing (3 residual rows) / of one point-to-plane pairing (1 row)
+__device__ __forceinline__ void cov_rows_point(const double* sD, double x, double y, double z, double* v) {
+  double A[3][6];
+#pragma unroll
+  for (int j = 0; j < 6; j++)
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      A[r][j] = sD[j * 12 + r * 4] * x + sD[j * 12 + r * 4 + 1] * y + sD[j * 12 + r * 4 + 2] * z + sD[j * 12 + r * 4 + 3];
+  int q = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = a; b < 6; b++) v[q++] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b];
+  v[21] = 1.0;
+}
+__device__ __forceinline__ void cov_rows_plane(const double* sD, double x, double y, double z, double nx, double ny, double nz,
+                                               double* v) {
+  double A[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double r[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+      r[q] = sD[j * 12 + q * 4] * x + sD[j * 12 + q * 4 + 1] * y + sD[j * 12 + q * 4 + 2] * z + sD[j * 12 + q * 4 + 3];
+    A[j] = nx * r[0] + ny * r[1] + nz * r[2];
+  }
+  int q = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = a; b < 6; b++) v[q++] = A[a] * A[b];
+  v[21] = 1.0;
+}
+// (A^T A)^-1 from the 21 + 1 sums; diag(1e6) when there is nothing to invert
+__device__ __forceinline__ void cov_from_sums(const double* a, double* out36) {
+  double AtA[36], cov[36];
+  int q = 0;
+  for (int r = 0; r < 6; r++)
+    for (int c = r; c < 6; c++) {
+      AtA[r * 6 + c] = a[q];
+      AtA[c * 6 + r] = a[q];
+      q++;
+    }
+  bool ok = a[21] > 0.5 && chol_inverse6(AtA, cov);
+  if (ok)
+    for (int i = 0; i < 36; i++) ok = ok && isfinite(cov[i]);
+  for (int i = 0; i < 36; i++) out36[i] = ok ? cov[i] : ((i % 7 == 0) ? 1e6 : 0.0);
+}
+
 __device__ __forceinline__ void k_cov_prepare_body(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp, uint32_t force) {
   if (!force && (!st->done || st->cov_done)) return;
   const int j = threadIdx.x;
   if (j >= 6) return;
   Pose Tc;
   for (int i = 0; i < 12; i++) Tc.m[i] = st->T[i];
-  double v[6];
-  pose_to_ypr(Tc, v);
-  const double h = j < 3 ? kp->cov_hx : kp->cov_ha;
-  double vp[6], vm[6];
-  for (int i = 0; i < 6; i++) { vp[i] = v[i]; vm[i] = v[i]; }
-  vp[j] += h;
-  vm[j] -= h;
-  const Pose P = pose_from_ypr(vp), M = pose_from_ypr(vm);
-  for (int i = 0; i < 12; i++) st->covD[j * 12 + i] = (P.m[i] - M.m[i]) / (2.0 * h);
+  double out[12];
+  cov_prepare_lane(Tc, j, kp->cov_hx, kp->cov_ha, out);
+  for (int i = 0; i < 12; i++) st->covD[j * 12 + i] = out[i];
 }
 
 __device__ __forceinline__ void k_cov_accum_body(const IcpDeviceState* __restrict__ st, uint32_t force,
@@ -1761,21 +1512,7 @@ __device__ __forceinline__ void k_cov_accum_body(const IcpDeviceState* __restric
   double v[kCovN];
 #pragma unroll
   for (int j = 0; j < kCovN; j++) v[j] = 0.0;
-  if (i < n && pair_gidx[i] != kNoMatch) {
-    const double x = lx[i], y = ly[i], z = lz[i];
-    double A[3][6];
-#pragma unroll
-    for (int j = 0; j < 6; j++)
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-        A[r][j] = sD[j * 12 + r * 4] * x + sD[j * 12 + r * 4 + 1] * y + sD[j * 12 + r * 4 + 2] * z + sD[j * 12 + r * 4 + 3];
-    int q = 0;
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-      for (int b = a; b < 6; b++) v[q++] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b];
-    v[21] = 1.0;
-  }
+  if (i < n && pair_gidx[i] != kNoMatch) cov_rows_point(sD, lx[i], ly[i], lz[i], v);
   block_sum_rows<kCovN>(v, lds, partials, pstride, blockIdx.x);
 }
 
@@ -1829,23 +1566,8 @@ __device__ __forceinline__ void k_cov_accum_plbuf_body(const IcpDeviceState* __r
 #pragma unroll
   for (int j = 0; j < kCovN; j++) v[j] = 0.0;
   if (i < n && pl_c[i].w != 0.f) {
-    const double x = lx[i], y = ly[i], z = lz[i];
     const float4 nn = pl_n[i];
-    double A[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      double r[3];
-#pragma unroll
-      for (int q = 0; q < 3; q++)
-        r[q] = sD[j * 12 + q * 4] * x + sD[j * 12 + q * 4 + 1] * y + sD[j * 12 + q * 4 + 2] * z + sD[j * 12 + q * 4 + 3];
-      A[j] = (double)nn.x * r[0] + (double)nn.y * r[1] + (double)nn.z * r[2];
-    }
-    int q = 0;
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-      for (int b = a; b < 6; b++) v[q++] = A[a] * A[b];
-    v[21] = 1.0;
+    cov_rows_plane(sD, lx[i], ly[i], lz[i], (double)nn.x, (double)nn.y, (double)nn.z, v);
   }
   block_sum_rows<kCovN>(v, lds, partials, pstride, blockIdx.x);
 }
@@ -1871,18 +1593,9 @@ __device__ __forceinline__ void k_cov_finalize_body(IcpDeviceState* __restrict__
   double a[kCovN];
 #pragma unroll
   for (int i = 0; i < kCovN; i++) a[i] = (nA ? totA[i] : 0.0) + (nB ? totB[i] : 0.0);
-  double AtA[36], cov[36];
-  int q = 0;
-  for (int r = 0; r < 6; r++)
-    for (int c = r; c < 6; c++) {
-      AtA[r * 6 + c] = a[q];
-      AtA[c * 6 + r] = a[q];
-      q++;
-    }
-  bool ok = a[21] > 0.5 && chol_inverse6(AtA, cov);
-  if (ok)
-    for (int i = 0; i < 36; i++) ok = ok && isfinite(cov[i]);
-  for (int i = 0; i < 36; i++) st->cov[i] = ok ? cov[i] : ((i % 7 == 0) ? 1e6 : 0.0);
+  double cov[36];
+  cov_from_sums(a, cov);
+  for (int i = 0; i < 36; i++) st->cov[i] = cov[i];
   st->cov_done = 1;
 }
 
@@ -2351,14 +2064,6 @@ __global__ __launch_bounds__(kBlock) void k_match16f_b(const BatchJob* __restric
   if (blockIdx.x >= j.nbm) return;
   k_match16_body<false, true>(j.st, j.mk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, nullptr, nullptr, j.part, j.nbm);
 }
-// row kernel without the fused accumulation, one job per blockIdx.y: the small-layer chains in lock step (PL: the NDT
-// pipeline's two matchers in the one launch)
-template <bool PL>
-__global__ __launch_bounds__(kBlock) void k_match16_b(const BatchJob* __restrict__ jobs) {
-  const BatchJob& j = jobs[blockIdx.y];
-  if (blockIdx.x >= (uint32_t)((16ull * j.n + kBlock - 1) / kBlock)) return;
-  k_match16_body<PL, false>(j.st, j.mk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, j.pl_c, j.pl_n, nullptr, 0u);
-}
 // start of a lock-step batch: the staged [state | params | schedules] of all jobs -> where each job keeps them
 __global__ void k_scatter_blocks(const BatchJob* __restrict__ jobs, const uint32_t* __restrict__ stage, uint32_t dwords) {
   const BatchJob& j = jobs[blockIdx.x];
@@ -2534,24 +2239,6 @@ namespace {
 
 inline uint32_t nblk(size_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
-// k_loop16's workgroups wait for each other inside the kernel, so all of them must fit on the device TOGETHER, whatever
-// else this process has running there: a budget of resident workgroups per device (512 threads x 256 VGPRs: one per CU; 256
-// CUs), taken for the duration of an alignment.  An alignment that finds the budget spent takes the launch-per-step chain.
-constexpr int kLoopSlotsPerDevice = 160;
-constexpr uint32_t kLoopMaxWorkgroups = 64;   // per alignment (= every group of a 2 k-point layer at once)
-constexpr uint32_t kLoopMaxPoints = 8192;     // (above: k_match16<fused> | k_solve | k_accum | k_solve)
-std::atomic<int> g_loop_slots[16] = {{kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice},
-                                     {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice},
-                                     {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice},
-                                     {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}, {kLoopSlotsPerDevice}};
-inline bool loop_slots_take(int device, int n) {
-  std::atomic<int>& a = g_loop_slots[device & 15];
-  int have = a.load(std::memory_order_relaxed);
-  while (have >= n)
-    if (a.compare_exchange_weak(have, have - n, std::memory_order_acquire)) return true;
-  return false;
-}
-inline void loop_slots_give(int device, int n) { g_loop_slots[device & 15].fetch_add(n, std::memory_order_release); }
 
 // One device block [state | parameters] with a pinned mirror of the same layout: an alignment starts with ONE upload.
 constexpr size_t kParamsOffset = (sizeof(IcpDeviceState) + 255) / 256 * 256;
@@ -2582,7 +2269,6 @@ mh_status ensure_state(mh_ctx* ctx) {
 mh_status upload_state_and_params(mh_ctx* ctx, const MatchK& mk, const SolveK& sk) {
   ctx->h_params->mk = mk;
   ctx->h_params->sk = sk;
-  memset(ctx->h_params->loop_sync, 0, sizeof(ctx->h_params->loop_sync));
   MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, kParamsOffset + sizeof(IcpDeviceParams), hipMemcpyHostToDevice,
                         ctx->stream));
   return MH_OK;
@@ -2707,7 +2393,6 @@ struct AlignJob {
   bool finished = false, trivial = false;
   bool prof = false;  // time this job's match kernels with events (then it cannot use the graph path)
   bool pl = false;    // Matcher_Point2Plane runs before the point matcher (lidar3d-ndt.yaml:195-210)
-  uint32_t loop_nw = 0;    // run_loop16(): workgroups of the one-launch loop (taken from the device's budget), 0 = not this way
   bool streaming = false;  // run_streaming(): iterations are enqueued one by one behind the device's published progress
   bool skip_tail = false;  // ... and the covariance kernels + state read-back only once the loop has ended
 
@@ -2804,13 +2489,6 @@ struct AlignJob {
     // off (MH_NO_STREAM=1).
     streaming = p->poll_every == 0 && !defer_upload && !prof && ctx->d_progress != nullptr && getenv("MH_NO_STREAM") == nullptr;
     sk.host_progress = streaming ? ctx->d_progress : nullptr;
-    if (defer_upload) {
-      ctx->h_params->mk = mk;
-      ctx->h_params->sk = sk;
-      memset(ctx->h_params->loop_sync, 0, sizeof(ctx->h_params->loop_sync));
-    } else {
-      MH_TRY(upload_state_and_params(ctx, mk, sk));
-    }
     nb = nblk(scan->n);
     {  // MH_MATCH selects the correspondence kernel of the fused loop (all exact, bit-identical pairings):
        //   "q" (default)  a DPP quad per scan point, merged candidate scans          -> k_match4 + k_accum
@@ -2842,23 +2520,17 @@ struct AlignJob {
     // who writes the partials of the first Gauss-Newton step: the row kernel (16 points per workgroup), k_accum, or k_match
     nbm = fused16 ? (uint32_t)((16ull * scan->n + kBlock - 1) / kBlock) : (variant >= 4 ? nba : nb);
     MH_TRY(ctx->partials.reserve((size_t)kGenN * (nbm > nb ? nbm : nb) * sizeof(double)));
-    if (variant == 5 && scan->n <= kOneGroupMaxPoints) {  // k_step16: two halves of one column per workgroup
-      const size_t nwg = (scan->n + kStepPoints - 1) / kStepPoints;
-      MH_TRY(ctx->partials.reserve(2 * (size_t)kAccN * (nwg ? nwg : 1) * sizeof(double)));
-      if (pl) MH_TRY(ctx->partials_b.reserve(2 * (size_t)kGenN * (nwg ? nwg : 1) * sizeof(double)));
+    if (variant == 5 && scan->n <= kStepMaxPoints) {  // k_step16: two halves of one column per group of 32 points
+      const size_t ng = (scan->n + kStepPoints - 1) / kStepPoints;
+      MH_TRY(ctx->partials.reserve(2 * (size_t)kStepRowsA * (ng ? ng : 1) * sizeof(double)));
+      if (pl) MH_TRY(ctx->partials_b.reserve(2 * (size_t)kGenN * (ng ? ng : 1) * sizeof(double)));
     }
     step_par = 0;
-    // the whole loop in one launch (k_loop16): single alignments of row-kernel layers, when the device's budget of resident
-    // workgroups has room (MH_LOOP16 while it is being measured)
-    loop_nw = 0;
-    if (variant == 5 && scan->n <= kLoopMaxPoints && !defer_upload && !prof && getenv("MH_LOOP16") != nullptr) {
-      const size_t ng = (scan->n + kStepPoints - 1) / kStepPoints;
-      MH_TRY(ctx->partials.reserve(2 * (size_t)kAccN * ng * sizeof(double)));
-      if (pl) MH_TRY(ctx->partials_b.reserve(2 * (size_t)kGenN * ng * sizeof(double)));
-      static const uint32_t cap = getenv("MH_LOOP16_WGS") ? (uint32_t)std::max(1, atoi(getenv("MH_LOOP16_WGS"))) : kLoopMaxWorkgroups;
-      const uint32_t want = ng < cap ? (uint32_t)ng : cap;
-      if (loop_slots_take(ctx->device, (int)want)) loop_nw = want;
-      if (loop_nw) streaming = false;
+    if (defer_upload) {
+      ctx->h_params->mk = mk;
+      ctx->h_params->sk = sk;
+    } else {
+      MH_TRY(upload_state_and_params(ctx, mk, sk));
     }
     // poll_every == 0: the first chunk is sized by what the previous alignment of this context needed (consecutive scans
     // of a sequence converge in about as many iterations: one host round trip instead of three), later chunks are short
@@ -2903,9 +2575,10 @@ struct AlignJob {
     return MH_OK;
   }
 
-  // small layers: k_step16 instead of k_match16 | k_accum_solve1 ... (profiled jobs time the match kernel alone: the old chain)
+  // row-kernel layers up to kStepMaxPoints: k_step16 launches (profiled jobs time the match kernel alone -- they, and
+  // MH_NO_STEP_CHAIN=1, take the chains with a match kernel of its own)
   bool use_step_chain() const {
-    return variant == 5 && scan->n <= kOneGroupMaxPoints && !prof && getenv("MH_CHAIN_R") != nullptr && getenv("MH_NO_ONE_GROUP") == nullptr;
+    return variant == 5 && scan->n <= kStepMaxPoints && !prof && getenv("MH_NO_STEP_CHAIN") == nullptr;
   }
 
   mh_status enqueue_chunk() {
@@ -2921,27 +2594,25 @@ struct AlignJob {
     const MatchK* dmk = &ctx->d_params->mk;
     const SolveK* dsk = &ctx->d_params->sk;
     // everything a chunk launches, in stream order; used directly (profiling / MH_NO_GRAPH) or under stream capture
-    const bool no_one_group = getenv("MH_NO_ONE_GROUP") != nullptr;  // (read per chunk: tests toggle it)
-    const bool one_group = variant == 5 && n <= kOneGroupMaxPoints && !no_one_group;  // accumulate + solve in one workgroup
-    // ... or, MH_CHAIN_R: k_step16 -- every launch over the whole layer, the solve carried into the next launch
-    const bool step_chain = one_group && use_step_chain();
-    const uint32_t nwg = n ? (n + kStepPoints - 1) / kStepPoints : 1u;
+    const bool step_chain = use_step_chain();  // k_step16: every launch over the whole layer, the solve carried into the next launch
+    const uint32_t ngr = n ? (n + kStepPoints - 1) / kStepPoints : 1u;
+    const uint32_t nwg = ngr < kStepMaxWorkgroups ? ngr : kStepMaxWorkgroups;
     auto launch_step = [&](uint32_t close_only) {
       IcpDeviceState* const S[2] = {ctx->d_state, ctx->d_state_b};
-      double* const pa[2] = {part, part + (size_t)kAccN * nwg};
+      double* const pa[2] = {part, part + (size_t)kStepRowsA * ngr};
       double* const pbb = pl ? ctx->partials_b.as<double>() : nullptr;
-      double* const pb[2] = {pbb, pbb ? pbb + (size_t)kGenN * nwg : nullptr};
+      double* const pb[2] = {pbb, pbb ? pbb + (size_t)kGenN * ngr : nullptr};
       const uint32_t par = step_par;
       if (pl)
         hipLaunchKernelGGL(k_step16<true>, dim3(close_only ? 1u : nwg), dim3(kSolveThreads), 0, s, S[par], close_only ? S[0] : S[par ^ 1u],
                            S[0], dmk, dsk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
                            ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), (const double*)pa[par], pa[par ^ 1u], (const double*)pb[par],
-                           pb[par ^ 1u], nwg, close_only);
+                           pb[par ^ 1u], ngr, close_only);
       else
         hipLaunchKernelGGL(k_step16<false>, dim3(close_only ? 1u : nwg), dim3(kSolveThreads), 0, s, S[par], close_only ? S[0] : S[par ^ 1u],
                            S[0], dmk, dsk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
                            (float4*)nullptr, (float4*)nullptr, (const double*)pa[par], pa[par ^ 1u], (const double*)nullptr,
-                           (double*)nullptr, nwg, close_only);
+                           (double*)nullptr, ngr, close_only);
       step_par = close_only ? 0u : (par ^ 1u);
     };
     auto enqueue_kernels = [&]() -> mh_status {
@@ -2960,7 +2631,7 @@ struct AlignJob {
                              scan->z, n, mv, ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), partb, nb);
         if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n], s));
         if (variant == 5) {
-          if (fused16 && !one_group)
+          if (fused16)
             hipLaunchKernelGGL((k_match16<false, true>), dim3(nbm), dim3(kBlock), 0, s, ctx->d_state, dmk, scan->x, scan->y,
                                scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (float4*)nullptr,
                                (float4*)nullptr, part, nbm);
@@ -2973,20 +2644,6 @@ struct AlignJob {
                                dmk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
                                (float4*)nullptr, (float4*)nullptr, (double*)nullptr, 0u);
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
-          if (one_group) {
-            if (prof) prof_n++;
-            for (uint32_t in = 0; in < p->gn.max_inner_iterations; in++) {
-              if (pl)
-                hipLaunchKernelGGL(k_accum_solve1<true>, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, in == 0 ? 1u : 0u, dmk,
-                                   dsk, scan->x, scan->y, scan->z, n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
-                                   ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>());
-              else
-                hipLaunchKernelGGL(k_accum_solve1<false>, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, in == 0 ? 1u : 0u, dmk,
-                                   dsk, scan->x, scan->y, scan->z, n, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
-                                   (const float4*)nullptr, (const float4*)nullptr);
-            }
-            continue;
-          }
           if (both16)  // both kinds of Gauss-Newton rows of the pairings just written
             hipLaunchKernelGGL(k_accum_both, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                                ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), ctx->pl_c.as<float4>(),
@@ -3088,7 +2745,7 @@ struct AlignJob {
                                        (unsigned long long)ctx->pair_gidx.p, (unsigned long long)part,
                                        (unsigned long long)ctx->d_state, (unsigned long long)ctx->d_params,
                                        (unsigned long long)ctx->h_state,
-                                       (pl ? 2ull : 1ull) | (one_group ? 4ull : 0ull) | (fused16 ? 8ull : 0ull) | (step_chain ? 16ull : 0ull),
+                                       (pl ? 2ull : 1ull) | (fused16 ? 8ull : 0ull) | (step_chain ? 16ull : 0ull),
                                        (unsigned long long)(pl ? ctx->pl_c.p : nullptr),
                                        (unsigned long long)(pl ? ctx->pl_n.p : nullptr),
                                        (unsigned long long)(pl ? ctx->partials_b.p : nullptr),
@@ -3172,37 +2829,9 @@ struct AlignJob {
       }
     }
     skip_tail = false;
-    chunk = 0;  // the tail alone: covariance (now live: the loop has ended) + state read-back
-    MH_TRY(enqueue_tail());
-    return poll();
-  }
-
-  // The whole loop as ONE launch (k_loop16), the tail behind it, one wait.
-  mh_status run_loop16() {
-    struct Give {
-      int dev, n;
-      ~Give() { loop_slots_give(dev, n); }
-    } give{ctx->device, (int)loop_nw};
-    MH_TRY(set_device(ctx));
-    hipStream_t s = ctx->stream;
-    const uint32_t n = (uint32_t)scan->n;
-    const uint32_t ng = (n + kStepPoints - 1) / kStepPoints;
-    const MapView mv = map->view();
-    uint32_t* sync = ctx->d_params->loop_sync;
-    if (pl)
-      hipLaunchKernelGGL(k_loop16<true>, dim3(loop_nw), dim3(kSolveThreads), 0, s, ctx->d_state, &ctx->d_params->mk, &ctx->d_params->sk,
-                         scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), ctx->pl_c.as<float4>(),
-                         ctx->pl_n.as<float4>(), ctx->partials.as<double>(), ctx->partials_b.as<double>(), ng, sync);
-    else
-      hipLaunchKernelGGL(k_loop16<false>, dim3(loop_nw), dim3(kSolveThreads), 0, s, ctx->d_state, &ctx->d_params->mk, &ctx->d_params->sk,
-                         scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (float4*)nullptr,
-                         (float4*)nullptr, ctx->partials.as<double>(), (double*)nullptr, ng, sync);
-    enqueued = p->max_iterations;
     chunk = 0;
-    MH_TRY(enqueue_tail());
-    const mh_status st = poll();
-    if (st == MH_OK && finished) res->n_enqueued_iterations = res->n_iterations + (res->termination_reason == MH_TERM_MAX_ITERATIONS ? 0u : 1u);
-    return st;
+    MH_TRY(enqueue_tail());  // the tail alone: covariance (now live: the loop has ended) + state read-back
+    return poll();
   }
 
   mh_status enqueue_tail() {
@@ -3243,9 +2872,6 @@ struct AlignJob {
       return MH_OK;
     }
     if (!h->done) return fail(MH_ERR_INTERNAL, "device ICP loop did not terminate after max_iterations");
-    if (h->term_reason == kTermLoopBarrierTimeout)
-      return fail(MH_ERR_INTERNAL, "device ICP loop (k_loop16): a workgroup waited %.1f s at the grid barrier for the others",
-                  (double)kLoopBarrierTimeout * 1e-8);
     finished = true;
     if (auto_chunk) ctx->predicted_iterations[kind] = h->n_iterations + (h->term_reason == MH_TERM_MAX_ITERATIONS ? 0u : 1u);
     res->n_host_polls = polls;
@@ -3311,7 +2937,6 @@ mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_icp_para
   MH_REQUIRE(!final_pairs || pairs_mem == MH_MEM_HOST || pairs_mem == MH_MEM_DEVICE, "bad mem space");
   AlignJob job;
   MH_TRY(job.start(map, scan, params, T_guess, prior, result, trace));
-  if (job.loop_nw && !job.finished) MH_TRY(job.run_loop16());
   if (job.streaming && !job.finished) MH_TRY(job.run_streaming());
   while (!job.finished) {
     MH_TRY(job.enqueue_chunk());
@@ -3456,9 +3081,46 @@ mh_status finish_pairs(mh_ctx* lead, hipStream_t s, const PairsPlan& pp, const B
 }
 }  // namespace
 
+static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const mh_scan* const* scans,
+                                 const mh_icp_params* params, int32_t params_per_job, const double* T_guesses,
+                                 const mh_prior* const* priors, mh_icp_result* results, void* pairs_block, int32_t pairs_mem);
+
 mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_scan* const* scans,
                              const mh_icp_params* params, int32_t params_per_job, const double* T_guesses,
                              const mh_prior* const* priors, mh_icp_result* results, void* pairs_block, int32_t pairs_mem) {
+  const mh_status st = align_batch_run(n_jobs, maps, scans, params, params_per_job, T_guesses, priors, results, pairs_block, pairs_mem);
+  // MH_DEBUG_VERIFY_BATCH=1 (development): every job once more as a single alignment -- a batch has to give the same bits
+  if (st == MH_OK && n_jobs && getenv("MH_DEBUG_VERIFY_BATCH") != nullptr && !pairs_block) {
+    for (size_t i = 0; i < n_jobs; i++) {
+      mh_icp_result r2;
+      const mh_icp_params* q = params_per_job ? &params[i] : params;
+      if (mh_icp_align(maps[i], scans[i], q, T_guesses + 12 * i, priors ? priors[i] : nullptr, &r2, nullptr, nullptr, MH_MEM_HOST) != MH_OK) continue;
+      if (memcmp(r2.T, results[i].T, sizeof(r2.T)) != 0 || r2.n_iterations != results[i].n_iterations) {
+        double md = 0;
+        for (int k = 0; k < 12; k++) md = fmax(md, fabs(r2.T[k] - results[i].T[k]));
+        fprintf(stderr, "[MH_DEBUG_VERIFY_BATCH] job %zu of %zu: n = %zu points, batch %u iterations (reason %u, %u pairs) vs single %u (reason %u, %u pairs), max |dT| %.3e; sizes:",
+                i, n_jobs, (size_t)scans[i]->n, results[i].n_iterations, results[i].termination_reason, results[i].n_final_pairs, r2.n_iterations,
+                r2.termination_reason, r2.n_final_pairs, md);
+        for (size_t k = 0; k < n_jobs; k++) fprintf(stderr, " %zu", (size_t)scans[k]->n);
+        fprintf(stderr, "\n");
+        // which of the two is unstable?  the batch once more, the single once more
+        std::vector<mh_icp_result> again(n_jobs);
+        if (align_batch_run(n_jobs, maps, scans, params, params_per_job, T_guesses, priors, again.data(), nullptr, pairs_mem) == MH_OK) {
+          mh_icp_result r3;
+          (void)mh_icp_align(maps[i], scans[i], q, T_guesses + 12 * i, priors ? priors[i] : nullptr, &r3, nullptr, nullptr, MH_MEM_HOST);
+          fprintf(stderr, "[MH_DEBUG_VERIFY_BATCH]    second batch == first batch: %d, second batch == single: %d, second single == first single: %d (iterations %u / %u / %u / %u)\n",
+                  memcmp(again[i].T, results[i].T, sizeof(r2.T)) == 0, memcmp(again[i].T, r2.T, sizeof(r2.T)) == 0,
+                  memcmp(r3.T, r2.T, sizeof(r2.T)) == 0, results[i].n_iterations, again[i].n_iterations, r2.n_iterations, r3.n_iterations);
+        }
+      }
+    }
+  }
+  return st;
+}
+
+static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const mh_scan* const* scans,
+                                 const mh_icp_params* params, int32_t params_per_job, const double* T_guesses,
+                                 const mh_prior* const* priors, mh_icp_result* results, void* pairs_block, int32_t pairs_mem) {
   MH_REQUIRE(n_jobs == 0 || (maps && scans && params && T_guesses && results), "null argument");
   MH_REQUIRE(!pairs_block || pairs_mem == MH_MEM_HOST || pairs_mem == MH_MEM_DEVICE || pairs_mem == MH_MEM_HOST_PINNED,
              "bad mem space");
@@ -3487,17 +3149,20 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
   // each job keeps its own parameters (iteration budget, schedules, hook check point, prior), state block, termination
   // flag and iteration count.  Jobs whose chain has no lock-step form (or that are alone in their group) take the
   // per-stream path below.
-  enum Kind { K_NONE = 0, K_QUAD, K_TILE, K_WAVE, K_ORD, K_ROWF, K_ONE, K_ONE_PL };
+  enum Kind { K_NONE = 0, K_QUAD, K_TILE, K_WAVE, K_ORD, K_ROWF, K_STEP, K_STEP_PL };
   const bool no_lockstep = getenv("MH_NO_LOCKSTEP") != nullptr;
-  const bool no_one_group_env = getenv("MH_NO_ONE_GROUP") != nullptr;
+  const bool batch_prof = !jobs.empty() && jobs[0].prof && !no_lockstep;  // (profile == 2 times job 0's share of a match kernel)
   auto kind_of = [&](const AlignJob& j) -> int {
     if (j.finished || no_lockstep || j.trace || j.prof) return K_NONE;
-    const bool one_group = j.variant == 5 && j.scan->n <= kOneGroupMaxPoints && !no_one_group_env;
+    // row-kernel layers up to 8 k points: k_step16_b, the chain of a single alignment with the jobs' workgroups side by side -- the
+    // same sums in the same order, hence the same bits.  (Round 4 also kept the one-workgroup accumulate-and-solve of round 3 for
+    // batches, re-ordered to give those bits: 4 / 8 / 16 sequences 3690 / 4920 / 5770 scans/s against 4092 / 5173 / 5510 this
+    // way, NDT pipeline 3966 / 4509 / 3939 against 4780 / 5500 / 5600: removed.)
+    if (j.use_step_chain() && !batch_prof) return j.pl ? K_STEP_PL : K_STEP;
     if (j.variant == 4 && !j.pl) return K_QUAD;
     if (j.variant == 6 && !j.pl) return K_TILE;
     if (j.variant == 7 && !j.pl) return K_WAVE;
     if (j.variant == 8 && !j.pl) return K_ORD;
-    if (j.variant == 5 && one_group) return j.pl ? K_ONE_PL : K_ONE;
     if (j.variant == 5 && j.fused16 && !j.pl) return K_ROWF;
     return K_NONE;
   };
@@ -3510,7 +3175,9 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
     const BatchJob* dj = nullptr;
     uint32_t gx_match = 1, gx_acc = 1, gx_cov = 1, gx_step = 1, enq = 0, prof_n = 0, max_iterations = 0, inner = 1, chunk = 10;
     uint32_t par = 0;  // k_step16_b: the state block the next launch reads
-    bool cov = false, done = false, auto_chunk = false, step_chain = false;
+    bool cov = false, done = false, auto_chunk = false;
+    bool step_chain() const { return kind == K_STEP || kind == K_STEP_PL; }
+    bool with_planes() const { return kind == K_STEP_PL; }
   };
   std::vector<Group> groups;
   const bool want_prof = !jobs.empty() && jobs[0].prof && !no_lockstep;  // profile == 2: the share of job 0's group
@@ -3612,11 +3279,12 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         if (g.kind == K_ROWF) bm = d.nbm;
         if (g.kind == K_TILE) bm = d.n_tiles;
         if (g.kind == K_WAVE) bm = d.n_tiles;
-        if (g.kind == K_ONE || g.kind == K_ONE_PL) {
-          bm = (uint32_t)((16ull * d.n + kBlock - 1) / kBlock);
-          const uint32_t nwg = (d.n + kStepPoints - 1) / kStepPoints;
-          g.gx_step = nwg > g.gx_step ? nwg : g.gx_step;
-          g.step_chain = j.use_step_chain() && !want_prof;  // (the same answer for every job of a K_ONE group: no profiled jobs in groups)
+        if (g.step_chain()) {  // all jobs' workgroups resident at once: kStepMaxWorkgroups shared between them
+          static const uint32_t cap_env = getenv("MH_STEP_WGS") ? (uint32_t)std::max(1, atoi(getenv("MH_STEP_WGS"))) : 0u;  // (development)
+          const uint32_t cap = cap_env ? cap_env : (kStepMaxWorkgroups / A ? kStepMaxWorkgroups / A : 1u);
+          const uint32_t ng = (d.n + kStepPoints - 1) / kStepPoints;
+          const uint32_t nw = ng < cap ? ng : cap;
+          g.gx_step = nw > g.gx_step ? nw : g.gx_step;
         }
         g.gx_match = bm > g.gx_match ? bm : g.gx_match;
         g.gx_acc = d.nba > g.gx_acc ? d.nba : g.gx_acc;
@@ -3659,9 +3327,9 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
           hipStream_t s = g.lead->stream;
           const uint32_t A = (uint32_t)g.jobs.size();
           const bool pr = want_prof && gi == 0 && g.jobs[0] == &jobs[0];
-          if (g.step_chain) {
+          if (g.step_chain()) {
             for (uint32_t in = 0; in < g.inner; in++) {
-              if (g.kind == K_ONE_PL) hipLaunchKernelGGL(k_step16_b<true>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 0u);
+              if (g.with_planes()) hipLaunchKernelGGL(k_step16_b<true>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 0u);
               else hipLaunchKernelGGL(k_step16_b<false>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 0u);
               g.par ^= 1u;
             }
@@ -3677,22 +3345,11 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
               hipLaunchKernelGGL(k_match_wave_sparse_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj);
               break;
             case K_ORD: hipLaunchKernelGGL(k_match4o_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
-            case K_ONE: hipLaunchKernelGGL(k_match16_b<false>, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
-            case K_ONE_PL: hipLaunchKernelGGL(k_match16_b<true>, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
             default: hipLaunchKernelGGL(k_match4_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
           }
           if (pr) {
             MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n + 1], s));
             g.prof_n++;
-          }
-          if (g.kind == K_ONE || g.kind == K_ONE_PL) {
-            for (uint32_t in = 0; in < g.inner; in++) {
-              if (g.kind == K_ONE_PL)
-                hipLaunchKernelGGL(k_accum_solve1_b<true>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, in == 0 ? 1u : 0u);
-              else
-                hipLaunchKernelGGL(k_accum_solve1_b<false>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, in == 0 ? 1u : 0u);
-            }
-            continue;
           }
           if (g.kind != K_ROWF) hipLaunchKernelGGL(k_accum_b, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 1u);
           hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, 1u);
@@ -3706,15 +3363,15 @@ mh_status mh_icp_align_batch(size_t n_jobs, const mh_map* const* maps, const mh_
         if (g.done) continue;
         hipStream_t s = g.lead->stream;
         const uint32_t A = (uint32_t)g.jobs.size();
-        if (g.step_chain) {  // the pending Gauss-Newton step of every job, into the canonical state blocks
-          if (g.kind == K_ONE_PL) hipLaunchKernelGGL(k_step16_b<true>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 1u);
+        if (g.step_chain()) {  // the pending Gauss-Newton step of every job, into the canonical state blocks
+          if (g.with_planes()) hipLaunchKernelGGL(k_step16_b<true>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 1u);
           else hipLaunchKernelGGL(k_step16_b<false>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 1u);
           g.par = 0;
         }
         if (g.cov) {  // no-ops for jobs whose loop has not terminated
           hipLaunchKernelGGL(k_cov_prepare_b, dim3(1, A), dim3(64), 0, s, g.dj);
           hipLaunchKernelGGL(k_cov_accum_b, dim3(g.gx_cov, A), dim3(kBlock), 0, s, g.dj);
-          if (g.kind == K_ONE_PL) hipLaunchKernelGGL(k_cov_accum_plbuf_b, dim3(g.gx_cov, A), dim3(kBlock), 0, s, g.dj);
+          if (g.with_planes()) hipLaunchKernelGGL(k_cov_accum_plbuf_b, dim3(g.gx_cov, A), dim3(kBlock), 0, s, g.dj);
           hipLaunchKernelGGL(k_cov_finalize_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj);
         }
         hipLaunchKernelGGL(k_gather_states, dim3(A), dim3(256), 0, s, g.dj, g.lead->batch_states.as<IcpDeviceState>());

@@ -69,6 +69,28 @@ def test_city_drive_ndt_pipeline_ate(city_drive):
     assert ate <= 0.005 * path, (ate, path)
 
 
+@pytest.mark.gpu
+def test_sixteen_sequences_in_one_process_reproduce_the_solo_trajectory(city_drive):
+    """A sequence's trajectory must not depend on what it shared the device with: sixteen copies of the drive through one
+    molahip-lo-cli process -- alignments merged into lock-step batches of varying composition, lone ones run singly, layers on
+    both sides of the 2 k-point boundary between the batch chains -- give sixteen times the solo run's file, byte for byte.
+    (Round 4: this is the check that caught data handed from one launch to the next being read stale at the next launch's
+    very start -- k_step16's comment -- at a rate of a few alignments per run.)"""
+    base, seq_dir, drive, gt = city_drive
+    solo_out = os.path.join(base, "solo16.tum")
+    _run(seq_dir, "lidar3d-default-hip.yaml", solo_out)
+    solo = open(solo_out).read()
+    cmd = [CLI, "--pipeline", os.path.join(ROOT, "pipelines", "lidar3d-default-hip.yaml"), "--time-field", "12", "--out", os.path.join(base, "many.tum")]
+    for _ in range(16):
+        cmd += ["--seq-dir", seq_dir]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-800:]
+    reps = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "sequence_dir" in l]
+    assert len(reps) == 16
+    differing = [k for k, q in enumerate(reps) if open(q["tum"]).read() != solo]
+    assert not differing, differing
+
+
 def test_city_generator_is_deterministic_and_on_the_road():
     """CPU: the plan is a pure function of its arguments, the route keeps clear of every building, sweeps have the size of
     a KITTI scan and all returns lie within the range limit."""

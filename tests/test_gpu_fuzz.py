@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                              ("fuzz_hook_replay.py", 20, 108), ("stress_cli_sequences.py", 1, 109)])
 def test_randomized_parity_tool(tool, cases, seed):
     env = dict(os.environ)
-    for k in ("MH_MATCH", "MH_NO_PREV_BOUND", "MH_NO_FUSE16", "MH_NO_ONE_GROUP", "MH_NO_LOCKSTEP", "MH_NO_GRAPH"):
+    for k in ("MH_MATCH", "MH_NO_PREV_BOUND", "MH_NO_FUSE16", "MH_NO_STEP_CHAIN", "MH_NO_LOCKSTEP", "MH_NO_GRAPH"):
         env.pop(k, None)  # (the tools choose their own switches)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(cases), str(seed)], capture_output=True, text=True,
                        timeout=500, env=env, cwd=ROOT)

@@ -592,6 +592,36 @@ def test_align_batch_equals_single(ctx, oracle, small):
             np.testing.assert_array_equal(b["cov"], s["cov"])
 
 
+@pytest.mark.parametrize("inner,ndt", [(1, False), (2, False), (2, True)])
+def test_small_layer_batches_give_the_bits_of_single_alignments(ctx, inner, ndt):
+    """Layers of up to 8 k points run k_step16 -- search + sums per launch, the Gauss-Newton step carried into the next launch
+    -- alone (one group of 32 points per workgroup, streaming loop control) and in lock-step batches (k_step16_b: the jobs'
+    workgroups side by side, several groups per workgroup, chunks of launches).  The partial sums are one column per GROUP
+    in both, added in the same order: pose, covariance, iteration count and pairing counts agree bit for bit whatever the
+    batch's size -- a sequence's trajectory does not depend on what it shared the device with."""
+    pts = _ndt_cloud(41)
+    gm = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts) if ndt else capi.Map(ctx, 1.0, 20).build(pts)
+    rng = np.random.default_rng(42)
+    thr, kp = synth.threshold_schedule(0.5, 60)
+    kw = dict(max_iterations=60, threshold=thr, kernel_param=kp, gn=capi.GNParams(max_inner_iterations=inner))
+    if ndt:
+        kw["pt2pl_threshold"] = 0.5
+    p = capi.ICPParams(**kw)
+    sizes = [1500, 900, 2048, 33, 2100, 5000, 1400, 1400, 1400, 1400, 1400, 1400]  # (12 jobs: 21 workgroups each, up to 8 groups per workgroup)
+    ctxs = [capi.Context(0) for _ in sizes]
+    subs = [pts[rng.integers(0, len(pts), n)] + rng.normal(0, 0.01, (n, 3)).astype(np.float32) for n in sizes]
+    guesses = [synth.pose_from_ypr([0.1 + 0.02 * (k % 4), -0.08, 0.05, 0.006, -0.004, 0.01]) for k in range(len(sizes))]
+    single = [capi.icp_align(gm, capi.Scan(ctx, s), g, p) for s, g in zip(subs, guesses)]
+    scans = [capi.Scan(c, s) for c, s in zip(ctxs, subs)]
+    for count in (len(sizes), 3):
+        batch = capi.icp_align_batch([gm] * count, scans[:count], guesses[:count], p)
+        for a, c in zip(single, batch):
+            assert a["n_iterations"] == c["n_iterations"] > 2 and a["termination_reason"] == c["termination_reason"]
+            np.testing.assert_array_equal(a["T"], c["T"])
+            np.testing.assert_array_equal(a["cov"], c["cov"])
+            assert a["n_final_pairs"] == c["n_final_pairs"] and a["n_final_pairs_pt2pl"] == c["n_final_pairs_pt2pl"]
+
+
 def test_lockstep_batch_of_row_kernel_layers(ctx, monkeypatch):
     """Layers of a few thousand points (what lidar3d-default.yaml feeds align()) in one mh_icp_align_batch: the row
     kernel with the fused first accumulation runs in lock step (one launch over all jobs); bitwise equal to single
@@ -801,8 +831,8 @@ def test_profile_fields(ctx, small):
     assert r["n_match_launches"] == w.n_iters and r["match_kernel_ms"] > 0 and r["total_ms"] >= r["match_kernel_ms"]
 
 
-@pytest.mark.parametrize("env", [{"MH_MATCH": "s"}, {"MH_MATCH": "s", "MH_NO_ONE_GROUP": "1"},
-                                 {"MH_MATCH": "s", "MH_NO_ONE_GROUP": "1", "MH_NO_FUSE16": "1"}, {"MH_MATCH": "q"},
+@pytest.mark.parametrize("env", [{"MH_MATCH": "s"}, {"MH_MATCH": "s", "MH_NO_STEP_CHAIN": "1"},
+                                 {"MH_MATCH": "s", "MH_NO_STEP_CHAIN": "1", "MH_NO_FUSE16": "1"}, {"MH_MATCH": "q"},
                                  {"MH_MATCH": "p"}, {"MH_MATCH": "x"}, {"MH_MATCH": "q", "MH_NO_GRAPH": "1"},
                                  {"MH_MATCH": "t"}, {"MH_MATCH": "t", "MH_NO_GRAPH": "1"}, {"MH_MATCH": "w"},
                                  {"MH_MATCH": "w", "MH_NO_GRAPH": "1"}, {"MH_MATCH": "w", "MH_WAVE_LDS": "1"},

@@ -1,8 +1,8 @@
 """wall_clock64 phase stamps of the small-layer kernels (debug library: tools/build_dbg.sh, -DMH_DEBUG_WAVETRACE; last launch wins).
 
-    bash tools/build_dbg.sh && MOLAHIP_LIB_PATH=tools/libmolahip_dbg.so MH_CHAIN_R=1 python tools/phase_probe.py
+    bash tools/build_dbg.sh && MOLAHIP_LIB_PATH=tools/libmolahip_dbg.so python tools/phase_probe.py
 
-k_step16 (MH_CHAIN_R=1): the launch that finds the loop converged stamps start .. state written; the launch before it stamped
+k_step16: the launch that finds the loop converged stamps start .. state written; the launch before it stamped
 the body (search + sums); launches after the end only stamp `start`."""
 import ctypes as C, os, sys
 import numpy as np
