@@ -256,6 +256,8 @@ def cpu_driver_sample(pipeline, seq_dir, stamps, est, scan_seconds, cpu_seconds,
         if rate_c and gpu_t > 0:
             out["ratio_device_vs_cpu_c_only_same_scans"] = out["device_driver_same_scans_per_s"] / rate_c
             out["ratio_device_vs_cpu_with_python_same_scans"] = out["device_driver_same_scans_per_s"] / rate
+        if calib.get("16"):  # the width SURVEY / BASELINE quote CPU figures at (16 threads), from the 20-scan calibration pass
+            out["ratio_device_vs_cpu_c_only_16_threads_calibration_pass"] = out["device_driver_same_scans_per_s"] / calib["16"]
     if est is not None and all("pose" in r for r in o.records):
         est_cpu = np.stack([r["pose"] for r in o.records]).reshape(-1, 3, 4)
         m = min(len(est), len(est_cpu))

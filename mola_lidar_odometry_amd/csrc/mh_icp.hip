@@ -1221,6 +1221,11 @@ __device__ __forceinline__ void k_solve_body(IcpDeviceState* __restrict__ st, co
 // fit, 0.594-0.611 against 0.544-0.551 ms of ICP per scan on the city drive (0.617 with an L2 write-back as the release).
 // Crossing the XCDs costs what a launch boundary costs, and inside a loop the compiler hoists ~470 bytes per lane of lane
 // masks, offset tables and literal constants into scratch.)
+// (And: ONE launch per iteration, k_iter16 -- no sums cross workgroups at all: every workgroup accumulates ALL points of the layer
+// for both Gauss-Newton steps of the iteration the previous launch matched, solves them on its own copy of the state, then
+// searches its own groups.  Same trajectory file as k_step16's; 0.727-0.74 against 0.553 ms of ICP per scan: three rounds of
+// agent-scope loads of the stored pairings per step and a called (not inlined: spills) solve cost more than the launch they
+// save.  Removed.)
 // (And: the covariance + the result written to the host's page-locked mirror by the launch that finds the loop finished --
 // no covariance launches, no read-back copy, no event -- bit-identical to the three covariance kernels, 1536-1548 -> 1527-1573
 // scans/s: the one workgroup that sums the whole layer takes what the launches took.  Removed.)
