@@ -61,7 +61,7 @@ struct IcpDeviceState {
   uint32_t n_pairs, n_iterations, solver_ok, n_solves;
   uint32_t cov_done, n_pairs_pl;
   float cur_thr2, cur_ang2;  // matcher threshold^2 of iteration `iter` and the angular term: k_match4 reads nothing but this block
-  uint32_t pending, pad_;    // k_step16: the partials of a Gauss-Newton step have been written and wait for their solve
+  uint32_t pending, serial;  // k_step16: the partials of a Gauss-Newton step wait for their solve; launches of this alignment so far
   double cur_kparam;         // robust-kernel parameter of iteration `iter` (no dependent table look-up in k_accum*)
   double cov[36];
   double covD[72];  // (T(x+h_j) - T(x-h_j)) / (2 h_j), j = 0..5, 3x4 each
@@ -1231,7 +1231,8 @@ __device__ __forceinline__ void k_solve_body(IcpDeviceState* __restrict__ st, co
 // scans/s: the one workgroup that sums the whole layer takes what the launches took.  Removed.)
 // ================================================================================================
 constexpr uint32_t kStepPoints = kSolveThreads / 16;  // scan points (DPP rows) per group
-constexpr uint32_t kStepRowsA = kAccN;            // rows of one half of the point-to-point partials
+constexpr uint32_t kStepRowsA = kAccN + 1;        // rows of one half of the point-to-point partials: the sums + the column's tag
+constexpr uint32_t kStepRowsB = kGenN + 1;        // ... of the point-to-plane partials
 constexpr uint32_t kStepMaxPoints = 8192;      // (above: k_match16<fused> | k_solve | k_accum | k_solve, then the quad matcher's chain)
 constexpr uint32_t kStepMaxWorkgroups = 256;   // one per CU (512 threads x ~250 registers); beyond, workgroups take several groups
 constexpr uint32_t kStateHeadDwords = (uint32_t)(offsetof(IcpDeviceState, cov) / 4);  // everything the loop touches
@@ -1259,6 +1260,11 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
   uint32_t i = g * kStepPoints + row;
   uint32_t ic = i < n ? i : n - 1;
   float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
+  // (and the tag of "its" column of the partials: checked against the state's serial number below)
+  static_assert(kStepMaxPoints / kStepPoints <= kSolveThreads, "a column per lane");
+  const uint32_t col = tid < ngroups ? tid : 0u;
+  double tag_a = __hip_atomic_load(partA_in + (size_t)kAccN * ngroups + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double tag_b = PL ? __hip_atomic_load(partB_in + (size_t)kGenN * ngroups + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
   MH_PHASE(0);
   if (tid < kStateHeadDwords) lst_raw[tid] = __hip_atomic_load(reinterpret_cast<const uint32_t*>(s_in) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
@@ -1267,14 +1273,28 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
     return;
   }
   MH_PHASE(1);
+  const uint32_t serial = lst->serial;  // launches of this alignment so far: what the columns this launch sums must be tagged with
   if (lst->pending) {
+    // every column carries the serial number of the launch that wrote it, stored AFTER its sums were acknowledged: a column
+    // that does not carry this launch's number yet has not arrived (never seen since the exchange is at agent scope; a lane
+    // waits for its columns rather than sum what is not there)
+    const double want = (double)serial;
+    for (uint32_t spins = 0; spins < (1u << 16) && (tag_a != want || (PL && tag_b != want)); spins++) {
+      __builtin_amdgcn_s_sleep(1);
+      tag_a = __hip_atomic_load(partA_in + (size_t)kAccN * ngroups + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (PL) tag_b = __hip_atomic_load(partB_in + (size_t)kGenN * ngroups + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
     solve_body<true, false, true>(lst, sk, partA_in, ngroups, ngroups, PL ? partB_in : nullptr, PL ? ngroups : 0u, PL ? ngroups : 0u, sh);
     __syncthreads();
   }
   const uint32_t done = lst->done;
   const bool body = !done && !close_only;
   if (wg == 0) {
-    if (tid == 0) lst->pending = body ? 1u : 0u;
+    if (tid == 0) {
+      lst->pending = body ? 1u : 0u;
+      lst->serial = serial + 1u;
+    }
     __syncthreads();
     if (tid < kStateHeadDwords) {
       const uint32_t w = lst_raw[tid];
@@ -1294,8 +1314,9 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
   // kernel trace: 10 of 3464 k_step16_b dispatches), and data the predecessor wrote last was seen stale by loads issued
   // first thing: a partial column two launches old -- ulp-sized differences between a batch and the same alignment alone,
   // a few per 200-scan run, gone with ANY extra microsecond before the reads.  Hence: state and partials cross launches
-  // through agent-scope stores and loads (write-through, acknowledged before the wave ends; never answered from a stale L2
-  // line), and the stored pairings -- the previous pairing bounds the search at an iteration start and IS the pairing at an
+  // through agent-scope stores and loads (write-through; never answered from a stale L2 line), every partial column is
+  // tagged with its launch's serial number once its sums are acknowledged and a reader waits for the tag it expects (the
+  // tags are on their way before the state is known: no extra round trip), and the stored pairings -- the previous pairing bounds the search at an iteration start and IS the pairing at an
   // inner step -- are read here, microseconds into the launch, not prefetched at its top.
   f32x4 stored = G(reinterpret_cast<const f32x4*>(pair_q))[ic];
 
@@ -1375,12 +1396,20 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
       for (int r = 1; r < (int)kStepPoints; r++) sum += rowsA[tid][r];
       __hip_atomic_store(partA_out + tid * ngroups + g, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (tid < 64) {  // (the first wave holds the 18 sums: once they are acknowledged, lane 18 tags the column)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      if (tid == kAccN) __hip_atomic_store(partA_out + (size_t)kAccN * ngroups + g, (double)(serial + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (PL && tid >= 64 && tid < 64 + kGenN) {  // (the second wave)
       const uint32_t t = tid - 64;
       double sum = rowsB[PL ? t : 0][0];
 #pragma unroll
       for (int r = 1; r < (int)kStepPoints; r++) sum += rowsB[PL ? t : 0][r];
       __hip_atomic_store(partB_out + t * ngroups + g, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (PL && tid >= 64 && tid < 128) {  // (the second wave: the 29 point-to-plane sums, then lane 29 tags)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      if (tid == 64 + kGenN) __hip_atomic_store(partB_out + (size_t)kGenN * ngroups + g, (double)(serial + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     g += nw;
     if (g >= ngroups) break;
@@ -1390,7 +1419,6 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
     stored = G(reinterpret_cast<const f32x4*>(pair_q))[ic];
     __syncthreads();  // (the row buffers are reused)
   }
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the write-through stores above have been acknowledged before this wave ends
   MH_PHASE(13);
 }
 template <bool PL>
@@ -1414,7 +1442,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_step16_b(const BatchJob* __re
   const uint32_t ngroups = ng0 ? ng0 : 1u;
   IcpDeviceState* const S[2] = {j.st, j.st_b};
   double* const pa[2] = {j.part, j.part + (size_t)kStepRowsA * ngroups};
-  double* const pb[2] = {j.partb, j.partb ? j.partb + (size_t)kGenN * ngroups : nullptr};
+  double* const pb[2] = {j.partb, j.partb ? j.partb + (size_t)kStepRowsB * ngroups : nullptr};
   k_step16_body<PL>(S[par], close_only ? S[0] : S[par ^ 1u], S[0], j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx,
                     j.pl_c, j.pl_n, pa[par], pa[par ^ 1u], pb[par], pb[par ^ 1u], ngroups, ngroups < gridDim.x ? ngroups : gridDim.x,
                     close_only);
@@ -2528,7 +2556,7 @@ struct AlignJob {
     if (variant == 5 && scan->n <= kStepMaxPoints) {  // k_step16: two halves of one column per group of 32 points
       const size_t ng = (scan->n + kStepPoints - 1) / kStepPoints;
       MH_TRY(ctx->partials.reserve(2 * (size_t)kStepRowsA * (ng ? ng : 1) * sizeof(double)));
-      if (pl) MH_TRY(ctx->partials_b.reserve(2 * (size_t)kGenN * (ng ? ng : 1) * sizeof(double)));
+      if (pl) MH_TRY(ctx->partials_b.reserve(2 * (size_t)kStepRowsB * (ng ? ng : 1) * sizeof(double)));
     }
     step_par = 0;
     if (defer_upload) {
@@ -2606,7 +2634,7 @@ struct AlignJob {
       IcpDeviceState* const S[2] = {ctx->d_state, ctx->d_state_b};
       double* const pa[2] = {part, part + (size_t)kStepRowsA * ngr};
       double* const pbb = pl ? ctx->partials_b.as<double>() : nullptr;
-      double* const pb[2] = {pbb, pbb ? pbb + (size_t)kGenN * ngr : nullptr};
+      double* const pb[2] = {pbb, pbb ? pbb + (size_t)kStepRowsB * ngr : nullptr};
       const uint32_t par = step_par;
       if (pl)
         hipLaunchKernelGGL(k_step16<true>, dim3(close_only ? 1u : nwg), dim3(kSolveThreads), 0, s, S[par], close_only ? S[0] : S[par ^ 1u],
