@@ -457,9 +457,9 @@ MH_API mh_status mh_icp_get_pt2pl_pairs(const mh_scan* scan, const mh_pairs_pl_o
  * budgets and hook check points), guesses + 12*i, priors[i] (array or entries may be NULL), and writes results[i]; every
  * result is bitwise what mh_icp_align gives for that job alone.  Jobs that run the same kernel chain advance in LOCK
  * STEP: each kernel of an iteration is one launch over all of them (the jobs' tails fill each other's idle lanes) --
- * large layers (quad / tile matcher), 2-12 k-point layers (row matcher with the fused accumulation), layers up to 2 k
- * points (row matcher + one-workgroup accumulate-and-solve, also with Matcher_Point2Plane on NDT maps); the rest is
- * interleaved, one stream per job.  With profile = 2, job 0's match_kernel_ms is its share of the lock-step match
+ * large layers (quad / tile matcher), 8-12 k-point layers (row matcher with the fused accumulation), layers up to 8 k
+ * points (k_step16: search + sums per launch, the Gauss-Newton step carried into the next launch; also with
+ * Matcher_Point2Plane on NDT maps); the rest is interleaved, one stream per job.  With profile = 2, job 0's match_kernel_ms is its share of the lock-step match
  * launches.  Work still queued on the jobs' own streams (asynchronous uploads, de-skew, filters) is ordered before the
  * batch, whichever stream the batch runs on.
  *

@@ -815,6 +815,39 @@ def test_align_is_bitwise_reproducible(ctx, small):
     np.testing.assert_array_equal(a["cov"], b["cov"])
 
 
+@pytest.mark.parametrize("ndt", [False, True])
+def test_small_layer_loop_controls_give_the_same_bits(ctx, ndt, monkeypatch):
+    """k_step16's launches are driven by the state block alone, so how the host queues them must not matter: streaming control
+    (a launch or two ahead of the published progress), chunks of launches closed by a one-workgroup launch and polled every
+    1 / 3 / 7 iterations, the same chunks replayed as a hipGraph (captured when an alignment's shape repeats) -- one result."""
+    pts = _ndt_cloud(51)
+    gm = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts) if ndt else capi.Map(ctx, 1.0, 20).build(pts)
+    rng = np.random.default_rng(52)
+    n = 1700
+    sub = pts[rng.integers(0, len(pts), n)] + rng.normal(0, 0.01, (n, 3)).astype(np.float32)
+    guess = synth.pose_from_ypr([0.11, -0.07, 0.05, 0.006, -0.004, 0.01])
+    thr, kp = synth.threshold_schedule(0.5, 60)
+    kw = dict(max_iterations=60, threshold=thr, kernel_param=kp, gn=capi.GNParams(max_inner_iterations=2))
+    if ndt:
+        kw["pt2pl_threshold"] = 0.5
+    scan = capi.Scan(ctx, sub)
+    ref = capi.icp_align(gm, scan, guess, capi.ICPParams(**kw))  # streaming control
+    assert ref["n_iterations"] > 4
+    runs = []
+    for poll in (1, 3, 7):
+        runs.append(capi.icp_align(gm, scan, guess, capi.ICPParams(poll_every=poll, **kw)))
+    monkeypatch.setenv("MH_NO_STREAM", "1")
+    for _ in range(4):  # automatic chunks: the second call's chunk is captured, the later ones replay the graph
+        runs.append(capi.icp_align(gm, scan, guess, capi.ICPParams(**kw)))
+    monkeypatch.setenv("MH_NO_GRAPH", "1")
+    runs.append(capi.icp_align(gm, scan, guess, capi.ICPParams(**kw)))
+    for r in runs:
+        assert r["n_iterations"] == ref["n_iterations"] and r["termination_reason"] == ref["termination_reason"]
+        np.testing.assert_array_equal(r["T"], ref["T"])
+        np.testing.assert_array_equal(r["cov"], ref["cov"])
+        assert r["n_final_pairs"] == ref["n_final_pairs"]
+
+
 def test_scan_update_reuses_handle(ctx, oracle, small):
     w, gm, om, gs = small
     s = capi.Scan(ctx, w.scan_xyz[:100])
