@@ -26,9 +26,13 @@ MH_HD Pose pose_identity() {
 }
 
 // a (+) b
+// (every loop over a pose's entries is unrolled: a runtime-indexed Pose lives in scratch memory on the device -- the serial lane
+// of the solve paid 33 scratch round trips per step for compose / inverse before round 4 spelled this out)
 MH_HD Pose compose(const Pose& a, const Pose& b) {
   Pose c;
+#pragma unroll
   for (int i = 0; i < 3; i++) {
+#pragma unroll
     for (int j = 0; j < 3; j++) c.R(i, j) = a.R(i, 0) * b.R(0, j) + a.R(i, 1) * b.R(1, j) + a.R(i, 2) * b.R(2, j);
     c.t(i) = a.R(i, 0) * b.t(0) + a.R(i, 1) * b.t(1) + a.R(i, 2) * b.t(2) + a.t(i);
   }
@@ -37,7 +41,9 @@ MH_HD Pose compose(const Pose& a, const Pose& b) {
 
 MH_HD Pose inverse(const Pose& a) {
   Pose c;
+#pragma unroll
   for (int i = 0; i < 3; i++) {
+#pragma unroll
     for (int j = 0; j < 3; j++) c.R(i, j) = a.R(j, i);
     c.t(i) = -(a.R(0, i) * a.t(0) + a.R(1, i) * a.t(1) + a.R(2, i) * a.t(2));
   }
@@ -71,12 +77,15 @@ MH_HD Pose se3_exp(const double xi[6]) {
   const double W2[9] = {-(yy + zz), xy, xz, xy, -(xx + zz), yz, xz, yz, -(xx + yy)};
   Pose p;
   double V[9];
+#pragma unroll
   for (int i = 0; i < 3; i++)
+#pragma unroll
     for (int j = 0; j < 3; j++) {
       const double I = (i == j) ? 1.0 : 0.0;
       p.R(i, j) = I + a * W[i * 3 + j] + b * W2[i * 3 + j];
       V[i * 3 + j] = I + b * W[i * 3 + j] + c * W2[i * 3 + j];
     }
+#pragma unroll
   for (int i = 0; i < 3; i++) p.t(i) = V[i * 3] * xi[0] + V[i * 3 + 1] * xi[1] + V[i * 3 + 2] * xi[2];
   return p;
 }
@@ -97,16 +106,20 @@ MH_HD void so3_log(const Pose& p, double w[3]) {
     w[0] = k * vx; w[1] = k * vy; w[2] = k * vz;
     return;
   }
-  // th ~ pi: R + I ~ 2 n n^T
-  const double d[3] = {p.R(0, 0), p.R(1, 1), p.R(2, 2)};
-  const int k = (d[0] >= d[1] && d[0] >= d[2]) ? 0 : (d[1] >= d[2] ? 1 : 2);
-  double n[3];
-  const double nk = sqrt(fmax(0.0, 0.5 * (d[k] + 1.0)));
-  for (int j = 0; j < 3; j++) n[j] = (j == k) ? nk : 0.25 * (p.R(k, j) + p.R(j, k)) / nk;
-  const double dot = n[0] * vx + n[1] * vy + n[2] * vz;
-  const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  // th ~ pi: R + I ~ 2 n n^T.  (Selected with compile-time indices only: `p.R(k, j)` with a runtime k would put the whole
+  // pose -- and every pose that flows into this function -- into scratch memory on the device.)
+  const double d0 = p.R(0, 0), d1 = p.R(1, 1), d2 = p.R(2, 2);
+  const int k = (d0 >= d1 && d0 >= d2) ? 0 : (d1 >= d2 ? 1 : 2);
+  const double dk = k == 0 ? d0 : (k == 1 ? d1 : d2);
+  const double nk = sqrt(fmax(0.0, 0.5 * (dk + 1.0)));
+  const double s01 = 0.25 * (p.R(0, 1) + p.R(1, 0)) / nk, s02 = 0.25 * (p.R(0, 2) + p.R(2, 0)) / nk, s12 = 0.25 * (p.R(1, 2) + p.R(2, 1)) / nk;
+  const double n0 = k == 0 ? nk : (k == 1 ? s01 : s02);
+  const double n1 = k == 1 ? nk : (k == 0 ? s01 : s12);
+  const double n2 = k == 2 ? nk : (k == 0 ? s02 : s12);
+  const double dot = n0 * vx + n1 * vy + n2 * vz;
+  const double nn = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
   const double s = (dot < 0.0 ? -th : th) / nn;
-  w[0] = s * n[0]; w[1] = s * n[1]; w[2] = s * n[2];
+  w[0] = s * n0; w[1] = s * n1; w[2] = s * n2;
 }
 
 MH_HD void se3_log(const Pose& p, double xi[6]) {
@@ -123,8 +136,10 @@ MH_HD void se3_log(const Pose& p, double xi[6]) {
   const double xx = w[0] * w[0], yy = w[1] * w[1], zz = w[2] * w[2], xy = w[0] * w[1], xz = w[0] * w[2], yz = w[1] * w[2];
   const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
   const double W2[9] = {-(yy + zz), xy, xz, xy, -(xx + zz), yz, xz, yz, -(xx + yy)};
+#pragma unroll
   for (int i = 0; i < 3; i++) {
     double acc = 0.0;
+#pragma unroll
     for (int j = 0; j < 3; j++) acc += (((i == j) ? 1.0 : 0.0) - 0.5 * W[i * 3 + j] + k * W2[i * 3 + j]) * p.t(j);
     xi[i] = acc;
   }
