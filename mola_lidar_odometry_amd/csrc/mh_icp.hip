@@ -61,10 +61,11 @@ struct IcpDeviceState {
   uint32_t n_pairs, n_iterations, solver_ok, n_solves;
   uint32_t cov_done, n_pairs_pl;
   float cur_thr2, cur_ang2;  // matcher threshold^2 of iteration `iter` and the angular term: k_match4 reads nothing but this block
-  uint32_t pending, serial;  // k_step16: the partials of a Gauss-Newton step wait for their solve; launches of this alignment so far
+  uint32_t pending, serial;  // k_step16: the partials of a Gauss-Newton step wait for their solve; (alignment's epoch << 22) + its launches so far
   double cur_kparam;         // robust-kernel parameter of iteration `iter` (no dependent table look-up in k_accum*)
   double cov[36];
   double covD[72];  // (T(x+h_j) - T(x-h_j)) / (2 h_j), j = 0..5, 3x4 each
+  uint32_t handover_timeouts, pad2_;  // k_step16: workgroups that gave up waiting for the state / the partials they expected (never seen)
 };
 
 // Per-alignment parameters live in DEVICE memory (uploaded once per align from a pinned host mirror) and the kernels
@@ -116,6 +117,7 @@ struct PoseArg {
 struct BatchJob {
   IcpDeviceState* st;
   IcpDeviceState* st_b;  // k_step16_b: the other half of the state ping-pong
+  uint32_t serial_base, serial_pad;  // ... and the serial number its uploaded state block carries
   const MatchK* mk;
   const SolveK* sk;
   const float *lx, *ly, *lz;
@@ -1207,8 +1209,8 @@ __device__ __forceinline__ void k_solve_body(IcpDeviceState* __restrict__ st, co
 // is decided by the state block alone:
 //   1. every workgroup copies the state block's head into LDS and, if a step is pending, closes it: the ordered sum of the
 //      partials of the previous launch + solve_body -- all workgroups compute the same bits, nobody waits for a hand-over;
-//      workgroup 0 writes the new state to the OTHER state block (the one this launch reads is never written) and
-//      publishes the progress word;
+//      workgroup 0 writes the new state to ANOTHER state block (a ping-pong pair beside the canonical block: the one a launch
+//      reads is never written by it) and publishes the progress word;
 //   2. body: at the start of an ICP iteration (inner == 0) the row search of k_match16 for groups of 32 points, the pairings
 //      stored and their Gauss-Newton sums written as one partial column per GROUP (also ping-pong: other workgroups may
 //      still be reading the previous launch's); at an inner step the sums of the stored pairings under the new pose.
@@ -1242,6 +1244,8 @@ constexpr uint32_t kStepRowsB = kGenN + 1;        // ... of the point-to-plane p
 constexpr uint32_t kStepMaxPoints = 8192;      // (above: k_match16<fused> | k_solve | k_accum | k_solve, then the quad matcher's chain)
 constexpr uint32_t kStepMaxWorkgroups = 256;   // one per CU (512 threads x ~250 registers); beyond, workgroups take several groups
 constexpr uint32_t kStateHeadDwords = (uint32_t)(offsetof(IcpDeviceState, cov) / 4);  // everything the loop touches
+constexpr uint32_t kStateSerialDword = (uint32_t)(offsetof(IcpDeviceState, serial) / 4);
+constexpr uint32_t kStepUnchecked = 0xFFFFFFFFu;  // `expect` of launches whose arguments are frozen in a captured graph
 static_assert(kStateHeadDwords <= 64 && offsetof(IcpDeviceState, cov) % 8 == 0, "state head is copied by one wave");
 
 // reduce_rows with agent-scope loads, all of a lane's loads issued before any sum, the sums in reduce_rows' order exactly (lane (row, g) adds columns g, g + G, ...: eight partial sums over the full rounds, the rest into
@@ -1294,7 +1298,7 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
                                               MapView map, float4* pair_q, uint32_t* pair_gidx, float4* pl_c, float4* pl_n,
                                               const double* __restrict__ partA_in, double* __restrict__ partA_out,
                                               const double* __restrict__ partB_in, double* __restrict__ partB_out,
-                                              uint32_t ngroups, uint32_t nw, uint32_t close_only) {
+                                              uint32_t ngroups, uint32_t nw, uint32_t close_only, uint32_t expect) {
   __shared__ SolveShared sh;
   __shared__ __attribute__((aligned(8))) uint32_t lst_raw[kStateHeadDwords];
   __shared__ double rowsA[kAccN][kStepPoints + 1];
@@ -1314,20 +1318,39 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
   double tag_a = __hip_atomic_load(partA_in + (size_t)kAccN * ngroups + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   double tag_b = PL ? __hip_atomic_load(partB_in + (size_t)kGenN * ngroups + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
   MH_PHASE(0);
-  if (tid < kStateHeadDwords) lst_raw[tid] = __hip_atomic_load(reinterpret_cast<const uint32_t*>(s_in) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
+  // The state block this launch is meant to read carries the serial number `expect` -- (the alignment's epoch << 22) + the
+  // launches before this one; kStepUnchecked for launches replayed from a captured graph -- written by the upload or by
+  // workgroup 0 of the previous launch.  Anything else in the block is older (the previous alignment's, the launch before
+  // last's: the same buffer): wait for the right one rather than act on it.
+  for (uint32_t spins = 0;; spins++) {
+    if (tid < kStateHeadDwords) lst_raw[tid] = __hip_atomic_load(reinterpret_cast<const uint32_t*>(s_in) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (expect == kStepUnchecked || lst->serial == expect) break;
+    if (spins == (1u << 14)) {  // ~ tens of milliseconds: give up loudly (the host fails the alignment)
+      if (tid == 0) atomicAdd(&s_canon->handover_timeouts, 1u);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+    __syncthreads();  // (lst_raw is rewritten)
+  }
+  const uint32_t serial = lst->serial;  // what the columns this launch sums must be tagged with
   if (lst->done) {  // the loop has ended (the canonical block has it): keep the ping-pong consistent, nothing else
-    if (wg == 0 && tid < kStateHeadDwords && s_out != s_in) G(reinterpret_cast<uint32_t*>(s_out))[tid] = lst_raw[tid];
+    if (wg == 0 && tid < kStateHeadDwords)
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(s_out) + tid, tid == kStateSerialDword ? serial + 1u : lst_raw[tid], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   MH_PHASE(1);
-  const uint32_t serial = lst->serial;  // launches of this alignment so far: what the columns this launch sums must be tagged with
   if (lst->pending) {
     // every column carries the serial number of the launch that wrote it, stored AFTER its sums were acknowledged: a column
     // that does not carry this launch's number yet has not arrived (never seen since the exchange is at agent scope; a lane
     // waits for its columns rather than sum what is not there)
     const double want = (double)serial;
-    for (uint32_t spins = 0; spins < (1u << 16) && (tag_a != want || (PL && tag_b != want)); spins++) {
+    for (uint32_t spins = 0; tag_a != want || (PL && tag_b != want); spins++) {
+      if (spins == (1u << 16)) {
+        atomicAdd(&s_canon->handover_timeouts, 1u);
+        break;
+      }
       __builtin_amdgcn_s_sleep(1);
       tag_a = __hip_atomic_load(partA_in + (size_t)kAccN * ngroups + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (PL) tag_b = __hip_atomic_load(partB_in + (size_t)kGenN * ngroups + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1485,23 +1508,26 @@ __global__ __launch_bounds__(kSolveThreads) void k_step16(const IcpDeviceState* 
                                                           uint32_t n, MapView map, float4* pair_q, uint32_t* pair_gidx,
                                                           float4* pl_c, float4* pl_n, const double* __restrict__ partA_in,
                                                           double* __restrict__ partA_out, const double* __restrict__ partB_in,
-                                                          double* __restrict__ partB_out, uint32_t ngroups, uint32_t close_only) {
+                                                          double* __restrict__ partB_out, uint32_t ngroups, uint32_t close_only,
+                                                          uint32_t expect) {
   k_step16_body<PL>(s_in, s_out, s_canon, kp, sk, lx, ly, lz, n, map, pair_q, pair_gidx, pl_c, pl_n, partA_in, partA_out, partB_in,
-                    partB_out, ngroups, gridDim.x, close_only);
+                    partB_out, ngroups, gridDim.x, close_only, expect);
 }
 // in lock step: blockIdx.y = job; `par`: which state block / partials half this launch reads; gridDim.x: the host's cap on a
 // job's workgroups
 template <bool PL>
-__global__ __launch_bounds__(kSolveThreads) void k_step16_b(const BatchJob* __restrict__ jobs, uint32_t par, uint32_t close_only) {
+__global__ __launch_bounds__(kSolveThreads) void k_step16_b(const BatchJob* __restrict__ jobs, uint32_t src, uint32_t par, uint32_t close_only,
+                                                            uint32_t launch_index) {
   const BatchJob& j = jobs[blockIdx.y];
   const uint32_t ng0 = (j.n + kStepPoints - 1) / kStepPoints;
   const uint32_t ngroups = ng0 ? ng0 : 1u;
-  IcpDeviceState* const S[2] = {j.st, j.st_b};
+  IcpDeviceState* const S[3] = {j.st_b, reinterpret_cast<IcpDeviceState*>(reinterpret_cast<char*>(j.st_b) + 256), j.st};
+  const uint32_t dst = close_only ? 2u : (src == 2u ? 0u : (src ^ 1u));
   double* const pa[2] = {j.part, j.part + (size_t)kStepRowsA * ngroups};
   double* const pb[2] = {j.partb, j.partb ? j.partb + (size_t)kStepRowsB * ngroups : nullptr};
-  k_step16_body<PL>(S[par], close_only ? S[0] : S[par ^ 1u], S[0], j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx,
+  k_step16_body<PL>(S[src], S[dst], S[2], j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx,
                     j.pl_c, j.pl_n, pa[par], pa[par ^ 1u], pb[par], pb[par ^ 1u], ngroups, ngroups < gridDim.x ? ngroups : gridDim.x,
-                    close_only);
+                    close_only, j.serial_base + launch_index);
 }
 
 // ================================================================================================
@@ -2335,8 +2361,9 @@ constexpr size_t kParamsOffset = (sizeof(IcpDeviceState) + 255) / 256 * 256;
 mh_status ensure_state(mh_ctx* ctx) {
   if (!ctx->d_state) {
     char *d = nullptr, *h = nullptr;
-    const size_t second_off = (kParamsOffset + sizeof(IcpDeviceParams) + 255) / 256 * 256;  // k_step16's other state block (head only)
-    MH_HIP(hipMalloc((void**)&d, second_off + kStateHeadDwords * 4));
+    const size_t second_off = (kParamsOffset + sizeof(IcpDeviceParams) + 255) / 256 * 256;  // k_step16's two ping-pong state blocks (heads only)
+    MH_HIP(hipMalloc((void**)&d, second_off + 2 * 256));
+    static_assert(kStateHeadDwords * 4 <= 256, "a ping-pong block per 256 bytes");
     const size_t prog_off = ((kParamsOffset + sizeof(IcpDeviceParams) + 127) / 128) * 128;  // a cache line of its own
     MH_HIP(hipHostMalloc((void**)&h, prog_off + 128, hipHostMallocDefault));
     ctx->d_state = (IcpDeviceState*)d;
@@ -2473,7 +2500,10 @@ struct AlignJob {
   MatchK mk{};
   SolveK sk{};
   uint32_t nb = 0, nbm = 0, nba = 0, enqueued = 0, chunk = 0, prof_n = 0, polls = 0, kind = 0;
-  uint32_t step_par = 0;  // k_step16 chain: which state block / partials half the next launch reads (0 at every chunk start)
+  uint32_t serial_base = 0, step_launches = 0;  // k_step16's hand-over: the state block's serial number at upload, launches since
+  // k_step16 chain: the state block the next launch reads (2 = the canonical one: after the upload and after a close-only launch;
+  // 0 / 1 = the ping-pong pair) and the half of the partials it reads
+  uint32_t step_src = 2, step_ppar = 0;
   bool auto_chunk = false;
   bool fused16 = false;  // row kernel accumulates the first Gauss-Newton step itself (layers above the one-workgroup size)
   bool defer_upload = false;   // batches: the pinned mirrors are filled, the copies are issued by the batch (staged) or flush()
@@ -2534,6 +2564,11 @@ struct AlignJob {
     if (trace) MH_TRY(ctx->trace.reserve(mi * sizeof(mh_icp_iter)));
     ctx->align_serial++;
     init_state(ctx->h_state, T0);
+    // k_step16's hand-over: the uploaded block carries this alignment's epoch, every launch one more (a launch told what to
+    // expect waits for exactly that block: neither the previous alignment's nor the launch before last's will do)
+    serial_base = ((uint32_t)ctx->align_serial & 0x3FFu) << 22;
+    step_launches = 0;
+    ctx->h_state->serial = serial_base;
     const double ang = p->threshold_angular_deg * 3.14159265358979323846 / 180.0;
     ctx->h_state->cur_thr2 = (float)(p->threshold[0] * p->threshold[0]);
     ctx->h_state->cur_ang2 = (float)(ang * ang);
@@ -2614,7 +2649,8 @@ struct AlignJob {
       MH_TRY(ctx->partials.reserve(2 * (size_t)kStepRowsA * (ng ? ng : 1) * sizeof(double)));
       if (pl) MH_TRY(ctx->partials_b.reserve(2 * (size_t)kStepRowsB * (ng ? ng : 1) * sizeof(double)));
     }
-    step_par = 0;
+    step_src = 2;
+    step_ppar = 0;
     if (defer_upload) {
       ctx->h_params->mk = mk;
       ctx->h_params->sk = sk;
@@ -2686,23 +2722,31 @@ struct AlignJob {
     const bool step_chain = use_step_chain();  // k_step16: every launch over the whole layer, the solve carried into the next launch
     const uint32_t ngr = n ? (n + kStepPoints - 1) / kStepPoints : 1u;
     const uint32_t nwg = ngr < kStepMaxWorkgroups ? ngr : kStepMaxWorkgroups;
+    // (launches whose arguments may be frozen in a captured graph cannot be told their number)
+    const bool counted = prof || streaming || getenv("MH_NO_GRAPH") != nullptr;
     auto launch_step = [&](uint32_t close_only) {
-      IcpDeviceState* const S[2] = {ctx->d_state, ctx->d_state_b};
+      const uint32_t expect = counted ? serial_base + step_launches : kStepUnchecked;
+      step_launches++;
+      // canonical block (upload, results) + a ping-pong pair: a launch never writes the block it reads, and the canonical one is only
+      // written by launches that do not read it (the one that ends the loop, the one-workgroup close-only launch)
+      IcpDeviceState* const S[3] = {ctx->d_state_b, reinterpret_cast<IcpDeviceState*>(reinterpret_cast<char*>(ctx->d_state_b) + 256), ctx->d_state};
+      const uint32_t src = step_src, dst = close_only ? 2u : (src == 2u ? 0u : (src ^ 1u));
       double* const pa[2] = {part, part + (size_t)kStepRowsA * ngr};
       double* const pbb = pl ? ctx->partials_b.as<double>() : nullptr;
       double* const pb[2] = {pbb, pbb ? pbb + (size_t)kStepRowsB * ngr : nullptr};
-      const uint32_t par = step_par;
+      const uint32_t par = step_ppar;
       if (pl)
-        hipLaunchKernelGGL(k_step16<true>, dim3(close_only ? 1u : nwg), dim3(kSolveThreads), 0, s, S[par], close_only ? S[0] : S[par ^ 1u],
-                           S[0], dmk, dsk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+        hipLaunchKernelGGL(k_step16<true>, dim3(close_only ? 1u : nwg), dim3(kSolveThreads), 0, s, S[src], S[dst],
+                           S[2], dmk, dsk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
                            ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), (const double*)pa[par], pa[par ^ 1u], (const double*)pb[par],
-                           pb[par ^ 1u], ngr, close_only);
+                           pb[par ^ 1u], ngr, close_only, expect);
       else
-        hipLaunchKernelGGL(k_step16<false>, dim3(close_only ? 1u : nwg), dim3(kSolveThreads), 0, s, S[par], close_only ? S[0] : S[par ^ 1u],
-                           S[0], dmk, dsk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+        hipLaunchKernelGGL(k_step16<false>, dim3(close_only ? 1u : nwg), dim3(kSolveThreads), 0, s, S[src], S[dst],
+                           S[2], dmk, dsk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
                            (float4*)nullptr, (float4*)nullptr, (const double*)pa[par], pa[par ^ 1u], (const double*)nullptr,
-                           (double*)nullptr, ngr, close_only);
-      step_par = close_only ? 0u : (par ^ 1u);
+                           (double*)nullptr, ngr, close_only, expect);
+      step_src = dst;
+      if (!close_only) step_ppar = par ^ 1u;
     };
     auto enqueue_kernels = [&]() -> mh_status {
       double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
@@ -2960,6 +3004,9 @@ struct AlignJob {
       }
       return MH_OK;
     }
+    if (h->handover_timeouts)
+      return fail(MH_ERR_INTERNAL, "device ICP loop (k_step16): %u workgroup(s) gave up waiting for the state block or the partial sums of the previous launch",
+                  h->handover_timeouts);
     if (!h->done) return fail(MH_ERR_INTERNAL, "device ICP loop did not terminate after max_iterations");
     finished = true;
     if (auto_chunk) ctx->predicted_iterations[kind] = h->n_iterations + (h->term_reason == MH_TERM_MAX_ITERATIONS ? 0u : 1u);
@@ -3052,6 +3099,7 @@ void fill_batch_desc(const AlignJob& j, BatchJob& d) {
   memset(&d, 0, sizeof(d));
   d.st = j.ctx->d_state;
   d.st_b = j.ctx->d_state_b;
+  d.serial_base = j.serial_base;
   d.mk = &j.ctx->d_params->mk;
   d.sk = &j.ctx->d_params->sk;
   d.lx = j.scan->x; d.ly = j.scan->y; d.lz = j.scan->z;
@@ -3263,7 +3311,7 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
     IcpDeviceState* h_states = nullptr;
     const BatchJob* dj = nullptr;
     uint32_t gx_match = 1, gx_acc = 1, gx_cov = 1, gx_step = 1, enq = 0, prof_n = 0, max_iterations = 0, inner = 1, chunk = 10;
-    uint32_t par = 0;  // k_step16_b: the state block the next launch reads
+    uint32_t src = 2, par = 0, launches = 0;  // k_step16_b: the state block (2 = canonical) and the partials half the next launch reads; launches so far
     bool cov = false, done = false, auto_chunk = false;
     bool step_chain() const { return kind == K_STEP || kind == K_STEP_PL; }
     bool with_planes() const { return kind == K_STEP_PL; }
@@ -3418,9 +3466,11 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
           const bool pr = want_prof && gi == 0 && g.jobs[0] == &jobs[0];
           if (g.step_chain()) {
             for (uint32_t in = 0; in < g.inner; in++) {
-              if (g.with_planes()) hipLaunchKernelGGL(k_step16_b<true>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 0u);
-              else hipLaunchKernelGGL(k_step16_b<false>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 0u);
+              if (g.with_planes()) hipLaunchKernelGGL(k_step16_b<true>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, s, g.dj, g.src, g.par, 0u, g.launches);
+              else hipLaunchKernelGGL(k_step16_b<false>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, s, g.dj, g.src, g.par, 0u, g.launches);
+              g.src = g.src == 2u ? 0u : (g.src ^ 1u);
               g.par ^= 1u;
+              g.launches++;
             }
             continue;
           }
@@ -3453,9 +3503,10 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
         hipStream_t s = g.lead->stream;
         const uint32_t A = (uint32_t)g.jobs.size();
         if (g.step_chain()) {  // the pending Gauss-Newton step of every job, into the canonical state blocks
-          if (g.with_planes()) hipLaunchKernelGGL(k_step16_b<true>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 1u);
-          else hipLaunchKernelGGL(k_step16_b<false>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, g.par, 1u);
-          g.par = 0;
+          if (g.with_planes()) hipLaunchKernelGGL(k_step16_b<true>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, g.src, g.par, 1u, g.launches);
+          else hipLaunchKernelGGL(k_step16_b<false>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, g.src, g.par, 1u, g.launches);
+          g.src = 2;
+          g.launches++;
         }
         if (g.cov) {  // no-ops for jobs whose loop has not terminated
           hipLaunchKernelGGL(k_cov_prepare_b, dim3(1, A), dim3(64), 0, s, g.dj);
