@@ -102,36 +102,131 @@ __global__ void k_keep(const unsigned long long* __restrict__ ks, const uint32_t
   keep[i] = k;
 }
 
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
+}
+__device__ __forceinline__ float readlane_f32(float v, uint32_t lane) {
+  return __uint_as_float(readlane_u32(__float_as_uint(v), lane));
+}
+// LDS hand-off between lanes of ONE wave: its LDS operations execute in order, only the compiler has to be kept from
+// moving the accesses across this point
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // insertPoint with min_distance_between_points > 0 is order dependent inside a voxel (a point is dropped when it is
-// closer than that to an ALREADY STORED point of its voxel, lidar3d-ndt.yaml:244): one thread walks each voxel run.
-__global__ void k_keep_seq(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                           const unsigned long long* __restrict__ ks, const uint32_t* __restrict__ idx_s,
-                           const uint32_t* __restrict__ head, uint32_t n, uint32_t cap, float min_dist,
-                           uint32_t n_stored /* inputs [0, n_stored) are the map's stored points: accepted already */,
-                           uint32_t* __restrict__ keep) {
+// closer than that to an ALREADY STORED point of its voxel, lidar3d-ndt.yaml:244).  Round 4: a WAVE walks each voxel run
+// (one thread did, reading its own verdicts back from memory: 125 us per key-frame of the NDT pipeline, the longest run's
+// chain of dependent loads).  The wave that holds a run's head entry takes the run 64 entries at a time; the accepted points
+// live in the wave's part of LDS, a candidate is compared with all of them at once (lane q: accepted point q, q + 64, ...),
+// one ballot decides; the order of the decisions is the run's order, so the verdicts are those of the sequential walk.
+// Stored points (inputs [0, n_stored): they passed this test when they were inserted, and sort first in the run) are
+// appended 64 at a time.  A run that accepts more than kKeepLds points goes on testing the overflow against the verdicts
+// in memory (a fence + agent-scope loads: other lanes of this wave wrote them).
+constexpr uint32_t kKeepLds = 448;     // accepted points per wave held in LDS (3 floats each; 4 waves: 21 KiB)
+constexpr uint32_t kKeepBlock = 256;   // k_keep_seq's block size (the LDS array is sized for it)
+__global__ __launch_bounds__(kKeepBlock) void k_keep_seq(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ z, const unsigned long long* __restrict__ ks,
+                                                         const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ head,
+                                                         uint32_t n, uint32_t cap, float min_dist,
+                                                         uint32_t n_stored /* inputs [0, n_stored) are the map's stored points */,
+                                                         uint32_t lds_points /* <= kKeepLds (smaller: tests of the overflow path) */,
+                                                         uint32_t* __restrict__ keep) {
+  __shared__ float acc[kKeepBlock / 64][3][kKeepLds];
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long k = ks[i];
-  if (k == kEmptyKey) { keep[i] = 0; return; }
-  if (!head[i]) return;  // the head thread of the run decides for the whole voxel
+  const unsigned long long ki = i < n ? ks[i] : kEmptyKey;
+  if (i < n && ki == kEmptyKey) keep[i] = 0;
+  unsigned long long heads = __ballot(i < n && ki != kEmptyKey && head[i] != 0);
   const float md2 = min_dist * min_dist;
-  uint32_t kept = 0;
-  for (uint32_t j = i; j < n && ks[j] == k; j++) {
-    uint32_t ok = (cap == 0 || kept < cap) ? 1u : 0u;
-    const uint32_t sj0 = idx_s[j];
-    if (ok && sj0 >= n_stored) {  // (stored points passed this test when they were inserted; they sort first in the run)
-      const uint32_t sj = sj0;
-      const float px = x[sj], py = y[sj], pz = z[sj];
-      for (uint32_t q = i; q < j && ok; q++)
-        if (keep[q]) {
-          const uint32_t sq = idx_s[q];
-          const float dx = x[sq] - px, dy = y[sq] - py, dz = z[sq] - pz;
-          if (((dx * dx + dy * dy) + dz * dz) < md2) ok = 0;
+  float* const ax = acc[w][0];
+  float* const ay = acc[w][1];
+  float* const az = acc[w][2];
+  while (heads) {
+    const uint32_t a = (i - lane) + (uint32_t)__builtin_ctzll(heads);  // first entry of the run (wave-uniform)
+    heads &= heads - 1;
+    const unsigned long long k = ks[a];
+    uint32_t kept = 0;  // wave-uniform
+    for (uint32_t base = a;; base += 64) {
+      const uint32_t j = base + lane;
+      const bool in = j < n && ks[j] == k;
+      const unsigned long long inm = __ballot(in);  // (a prefix of the lanes: equal keys are contiguous)
+      const uint32_t cnt = (uint32_t)__builtin_popcountll(inm);
+      const uint32_t sj = in ? idx_s[j] : 0xFFFFFFFFu;
+      const float px = in ? x[sj] : 0.f, py = in ? y[sj] : 0.f, pz = in ? z[sj] : 0.f;
+      uint32_t my_ok = 0;
+      uint32_t c = 0;
+      // the stored points of this chunk at once (all of them fit under the cap: they were stored under it)
+      const uint32_t n_st = (uint32_t)__builtin_popcountll(__ballot(in && sj < n_stored));
+      if (n_st && (cap == 0 || kept + n_st <= cap)) {
+        if (lane < n_st) {
+          my_ok = 1;
+          if (kept + lane < lds_points) { ax[kept + lane] = px; ay[kept + lane] = py; az[kept + lane] = pz; }
         }
+        kept += n_st;
+        c = n_st;
+        wave_sync_lds();
+      }
+      for (; c < cnt; c++) {
+        const uint32_t cs = readlane_u32(sj, c);
+        const float cx = readlane_f32(px, c), cy = readlane_f32(py, c), cz = readlane_f32(pz, c);
+        bool ok = (cap == 0 || kept < cap);  // wave-uniform
+        if (ok && cs >= n_stored) {
+          bool close = false;
+          const uint32_t in_lds = kept < lds_points ? kept : lds_points;
+          for (uint32_t q = lane; q < in_lds; q += 64) {
+            const float dx = ax[q] - cx, dy = ay[q] - cy, dz = az[q] - cz;
+            close = close || (((dx * dx + dy * dy) + dz * dz) < md2);
+          }
+          if (kept > lds_points) {
+            // overflow: the accepted points beyond the LDS list are found through the verdicts in memory; the ones this
+            // chunk accepted so far are still in registers (my_ok of lanes < c)
+            __threadfence();
+            uint32_t seen = 0;  // accepted points passed so far, to skip the ones LDS holds (the first lds_points)
+            for (uint32_t qb = a; qb < base; qb += 64) {
+              const uint32_t q = qb + lane;
+              const uint32_t kq = __hip_atomic_load(&keep[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const unsigned long long km = __ballot(kq != 0);
+              const uint32_t before = seen + (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull));
+              if (kq && before >= lds_points) {
+                const uint32_t sq = idx_s[q];
+                const float dx = x[sq] - cx, dy = y[sq] - cy, dz = z[sq] - cz;
+                close = close || (((dx * dx + dy * dy) + dz * dz) < md2);
+              }
+              seen += (uint32_t)__builtin_popcountll(km);
+            }
+            {
+              const bool mine = lane < c && my_ok;
+              const unsigned long long km = __ballot(mine);
+              const uint32_t before = seen + (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull));
+              if (mine && before >= lds_points) {
+                const float dx = px - cx, dy = py - cy, dz = pz - cz;
+                close = close || (((dx * dx + dy * dy) + dz * dz) < md2);
+              }
+            }
+          }
+          ok = __ballot(close) == 0ull;
+        }
+        if (ok) {
+          if (lane == 0 && kept < lds_points) { ax[kept] = cx; ay[kept] = cy; az[kept] = cz; }
+          kept++;
+          wave_sync_lds();
+        }
+        if (lane == c) my_ok = ok ? 1u : 0u;
+      }
+      if (in) keep[j] = my_ok;
+      if (cnt < 64) break;
     }
-    keep[j] = ok;
-    kept += ok;
   }
+}
+
+// MH_KEEP_LDS=<n>: a smaller LDS list (the parity tests drive k_keep_seq's overflow path with it)
+inline uint32_t keep_lds_points() {
+  const char* e = getenv("MH_KEEP_LDS");
+  const long x = e ? atol(e) : (long)kKeepLds;
+  return (uint32_t)std::min<long>(std::max<long>(x, 1), (long)kKeepLds);
 }
 
 __global__ void k_add_ndt_slots(const uint32_t* __restrict__ head, uint32_t n, uint32_t* __restrict__ keep_plus) {
@@ -722,8 +817,9 @@ mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const floa
     MH_HIP(rocprim::inclusive_scan(m->sort_tmp.p, tb, head, vid1, N, rocprim::plus<uint32_t>(), s));
     hipLaunchKernelGGL(k_vstart, dim3(nblk(n, B)), dim3(B), 0, s, head, vid1, N, vstart);
     if (m->params.min_distance_between_points > 0.f)
-      hipLaunchKernelGGL(k_keep_seq, dim3(nblk(n, B)), dim3(B), 0, s, dx, dy, dz, keys_s, idx_s, head, N,
-                         m->params.max_points_per_voxel, m->params.min_distance_between_points, (uint32_t)n_stored, keep);
+      hipLaunchKernelGGL(k_keep_seq, dim3(nblk(n, kKeepBlock)), dim3(kKeepBlock), 0, s, dx, dy, dz, keys_s, idx_s, head, N,
+                         m->params.max_points_per_voxel, m->params.min_distance_between_points, (uint32_t)n_stored,
+                         keep_lds_points(), keep);
     else
       hipLaunchKernelGGL(k_keep, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, vid1, vstart, N, m->params.max_points_per_voxel,
                          keep);

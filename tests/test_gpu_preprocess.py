@@ -282,6 +282,37 @@ def test_map_insert_ndt_and_empty(ctx, oracle):
     _assert_maps_equal(g.download(), o.dump())
 
 
+@pytest.mark.parametrize("lds", [None, "5", "70"])
+@pytest.mark.parametrize("cap", [0, 150])
+def test_min_distance_walk_by_waves(ctx, oracle, lds, cap, monkeypatch):
+    """k_keep_seq (insertPoint's min_distance_between_points, lidar3d-ndt.yaml:244) walks a voxel run with a wave: runs longer
+    than 64 entries, stored points in front of new ones, a cap reached in the middle of a run, more accepted points than the
+    wave's LDS list holds (MH_KEEP_LDS shrinks the list: the overflow is found through the verdicts in memory) -- bit-equal to
+    the oracle's sequential insertPoint on a full build and on key-frame insertions."""
+    if lds:
+        monkeypatch.setenv("MH_KEEP_LDS", lds)
+    rng = np.random.default_rng(4242)
+    vs, md = 4.0, 0.11
+    g, o = capi.Map(ctx, vs, cap, 0, md), oracle.Map(vs, cap, 0, min_distance_between_points=md)
+    # dense blobs inside a few voxels (hundreds of candidates per run, up to ~600 accepted) + scattered points
+    def cloud(n_blob, seed):
+        r = np.random.default_rng(seed)
+        blobs = [c + r.uniform(-1.9, 1.9, (n_blob, 3)) for c in ([2.0, 2.0, 2.0], [-6.0, 2.0, 2.0], [10.0, -6.0, 2.0])]
+        return np.concatenate(blobs + [r.uniform(-20, 20, (3000, 3))]).astype(np.float32)
+    first = cloud(2500, 1)
+    g.build(first)
+    o.insert(first)
+    _assert_maps_equal(g.download(), o.dump())
+    assert o.num_points > 600
+    I = np.eye(4)[:3]
+    for k in range(3):
+        xyz = cloud(1500, 10 + k)
+        rng.shuffle(xyz)
+        g.insert(capi.Scan(ctx, xyz), I, 1000.0)
+        o.insert_posed(xyz, I, 1000.0)
+        _assert_maps_equal(g.download(), o.dump())
+
+
 def test_interleaved_upload_equals_channel_upload(ctx, small_workload):
     """mh_scan_update_aos: KITTI-style [n,4] rows, a PointCloud2-style record with the fields in odd places and a time
     stamp field, an empty buffer, and the argument checks."""
