@@ -117,19 +117,21 @@ __device__ __forceinline__ void wave_sync_lds() {
 }
 
 // insertPoint with min_distance_between_points > 0 is order dependent inside a voxel (a point is dropped when it is
-// closer than that to an ALREADY STORED point of its voxel, lidar3d-ndt.yaml:244).  Round 4: a WAVE walks each voxel run
-// (one thread did, reading its own verdicts back from memory: 125 us per key-frame of the NDT pipeline, the longest run's
-// chain of dependent loads).  The wave that holds a run's head entry takes the run 64 entries at a time; the accepted points
-// live in the wave's part of LDS, a candidate is compared with all of them at once (lane q: accepted point q, q + 64, ...),
-// one ballot decides; the order of the decisions is the run's order, so the verdicts are those of the sequential walk.
-// Stored points (inputs [0, n_stored): they passed this test when they were inserted, and sort first in the run) are
-// appended 64 at a time.  A run that accepts more than kKeepLds points goes on testing the overflow against the verdicts
-// in memory (a fence + agent-scope loads: other lanes of this wave wrote them).
+// closer than that to an ALREADY STORED point of its voxel, lidar3d-ndt.yaml:244).  Round 4: a WAVE walks the new part of a
+// voxel run (one thread walked the whole run, reading its own verdicts back from memory: 125 us per key-frame of the NDT
+// pipeline, the longest run's chain of dependent loads).  Stored points (inputs [0, n_stored): they passed the test and the
+// cap when they were inserted, and sort first in their run) are kept without a walk; the wave that holds a run's FIRST NEW
+// entry copies the run's stored points into its part of LDS and takes the new entries 64 at a time: a candidate is compared
+// with all accepted points at once (lane q: accepted point q, q + 64, ...), one ballot decides, the order of the decisions is
+// the run's order -- the verdicts are those of the sequential walk.  A run that accepts more than `lds_points` points goes
+// on testing the overflow in memory (stored ones by position, new ones through the verdicts: a fence + agent-scope loads,
+// other lanes of this wave wrote them).
 constexpr uint32_t kKeepLds = 448;     // accepted points per wave held in LDS (3 floats each; 4 waves: 21 KiB)
 constexpr uint32_t kKeepBlock = 256;   // k_keep_seq's block size (the LDS array is sized for it)
 __global__ __launch_bounds__(kKeepBlock) void k_keep_seq(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ z, const unsigned long long* __restrict__ ks,
                                                          const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ head,
+                                                         const uint32_t* __restrict__ vid1, const uint32_t* __restrict__ vstart,
                                                          uint32_t n, uint32_t cap, float min_dist,
                                                          uint32_t n_stored /* inputs [0, n_stored) are the map's stored points */,
                                                          uint32_t lds_points /* <= kKeepLds (smaller: tests of the overflow path) */,
@@ -137,43 +139,41 @@ __global__ __launch_bounds__(kKeepBlock) void k_keep_seq(const float* __restrict
   __shared__ float acc[kKeepBlock / 64][3][kKeepLds];
   const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long ki = i < n ? ks[i] : kEmptyKey;
-  if (i < n && ki == kEmptyKey) keep[i] = 0;
-  unsigned long long heads = __ballot(i < n && ki != kEmptyKey && head[i] != 0);
+  const bool valid = i < n && ks[i] != kEmptyKey;
+  const uint32_t si = valid ? idx_s[i] : 0u;
+  const bool is_new = valid && si >= n_stored;
+  if (i < n && !is_new) keep[i] = valid ? 1u : 0u;
+  // the first new entry of a run: a head, or the entry behind a stored one (same key: only heads follow another key)
+  const bool starter = is_new && (head[i] != 0 || idx_s[i - 1] < n_stored);
+  unsigned long long starters = __ballot(starter);
   const float md2 = min_dist * min_dist;
   float* const ax = acc[w][0];
   float* const ay = acc[w][1];
   float* const az = acc[w][2];
-  while (heads) {
-    const uint32_t a = (i - lane) + (uint32_t)__builtin_ctzll(heads);  // first entry of the run (wave-uniform)
-    heads &= heads - 1;
-    const unsigned long long k = ks[a];
-    uint32_t kept = 0;  // wave-uniform
-    for (uint32_t base = a;; base += 64) {
+  while (starters) {
+    const uint32_t st = (i - lane) + (uint32_t)__builtin_ctzll(starters);  // (wave-uniform)
+    starters &= starters - 1;
+    const unsigned long long k = ks[st];
+    const uint32_t a = vstart[vid1[st] - 1u];  // first entry of the run; [a, st) are its stored points
+    const uint32_t n_st = st - a;
+    wave_sync_lds();  // (the previous run's readers are done with the list)
+    for (uint32_t q = lane; q < n_st && q < lds_points; q += 64) {
+      const uint32_t sq = idx_s[a + q];
+      ax[q] = x[sq]; ay[q] = y[sq]; az[q] = z[sq];
+    }
+    wave_sync_lds();
+    uint32_t kept = n_st;  // wave-uniform
+    for (uint32_t base = st;; base += 64) {
       const uint32_t j = base + lane;
       const bool in = j < n && ks[j] == k;
-      const unsigned long long inm = __ballot(in);  // (a prefix of the lanes: equal keys are contiguous)
-      const uint32_t cnt = (uint32_t)__builtin_popcountll(inm);
-      const uint32_t sj = in ? idx_s[j] : 0xFFFFFFFFu;
+      const uint32_t cnt = (uint32_t)__builtin_popcountll(__ballot(in));  // (a prefix of the lanes: equal keys are contiguous)
+      const uint32_t sj = in ? idx_s[j] : 0u;
       const float px = in ? x[sj] : 0.f, py = in ? y[sj] : 0.f, pz = in ? z[sj] : 0.f;
       uint32_t my_ok = 0;
-      uint32_t c = 0;
-      // the stored points of this chunk at once (all of them fit under the cap: they were stored under it)
-      const uint32_t n_st = (uint32_t)__builtin_popcountll(__ballot(in && sj < n_stored));
-      if (n_st && (cap == 0 || kept + n_st <= cap)) {
-        if (lane < n_st) {
-          my_ok = 1;
-          if (kept + lane < lds_points) { ax[kept + lane] = px; ay[kept + lane] = py; az[kept + lane] = pz; }
-        }
-        kept += n_st;
-        c = n_st;
-        wave_sync_lds();
-      }
-      for (; c < cnt; c++) {
-        const uint32_t cs = readlane_u32(sj, c);
-        const float cx = readlane_f32(px, c), cy = readlane_f32(py, c), cz = readlane_f32(pz, c);
+      for (uint32_t c = 0; c < cnt; c++) {
         bool ok = (cap == 0 || kept < cap);  // wave-uniform
-        if (ok && cs >= n_stored) {
+        const float cx = readlane_f32(px, c), cy = readlane_f32(py, c), cz = readlane_f32(pz, c);
+        if (ok) {
           bool close = false;
           const uint32_t in_lds = kept < lds_points ? kept : lds_points;
           for (uint32_t q = lane; q < in_lds; q += 64) {
@@ -181,11 +181,16 @@ __global__ __launch_bounds__(kKeepBlock) void k_keep_seq(const float* __restrict
             close = close || (((dx * dx + dy * dy) + dz * dz) < md2);
           }
           if (kept > lds_points) {
-            // overflow: the accepted points beyond the LDS list are found through the verdicts in memory; the ones this
-            // chunk accepted so far are still in registers (my_ok of lanes < c)
+            // overflow: accepted points number lds_points and up -- stored ones by position, new ones of earlier chunks
+            // through their verdicts in memory, this chunk's in registers (my_ok of lanes < c)
+            for (uint32_t q = lds_points + lane; q < n_st; q += 64) {
+              const uint32_t sq = idx_s[a + q];
+              const float dx = x[sq] - cx, dy = y[sq] - cy, dz = z[sq] - cz;
+              close = close || (((dx * dx + dy * dy) + dz * dz) < md2);
+            }
             __threadfence();
-            uint32_t seen = 0;  // accepted points passed so far, to skip the ones LDS holds (the first lds_points)
-            for (uint32_t qb = a; qb < base; qb += 64) {
+            uint32_t seen = n_st;  // accepted points passed so far
+            for (uint32_t qb = st; qb < base; qb += 64) {
               const uint32_t q = qb + lane;
               const uint32_t kq = __hip_atomic_load(&keep[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               const unsigned long long km = __ballot(kq != 0);
@@ -372,8 +377,10 @@ __global__ void k_scatter(const float* __restrict__ x, const float* __restrict__
     const int a = threadIdx.x;
     uint32_t v = sh[0][a];
     for (int q = 1; q < 4; q++) v = a < 3 ? min(v, sh[q][a]) : max(v, sh[q][a]);
-    if (a < 3) { if (v != 0xFFFFFFFFu) atomicMin(&bbox[a], v); }
-    else if (v != 0u) atomicMax(&bbox[a], v);
+    // (only where it moves the box: the value read may be stale, which costs a needless atomic and never a needed one)
+    const uint32_t cur = __hip_atomic_load(&bbox[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a < 3) { if (v < cur) atomicMin(&bbox[a], v); }
+    else if (v > cur) atomicMax(&bbox[a], v);
   }
 }
 
@@ -817,8 +824,8 @@ mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const floa
     MH_HIP(rocprim::inclusive_scan(m->sort_tmp.p, tb, head, vid1, N, rocprim::plus<uint32_t>(), s));
     hipLaunchKernelGGL(k_vstart, dim3(nblk(n, B)), dim3(B), 0, s, head, vid1, N, vstart);
     if (m->params.min_distance_between_points > 0.f)
-      hipLaunchKernelGGL(k_keep_seq, dim3(nblk(n, kKeepBlock)), dim3(kKeepBlock), 0, s, dx, dy, dz, keys_s, idx_s, head, N,
-                         m->params.max_points_per_voxel, m->params.min_distance_between_points, (uint32_t)n_stored,
+      hipLaunchKernelGGL(k_keep_seq, dim3(nblk(n, kKeepBlock)), dim3(kKeepBlock), 0, s, dx, dy, dz, keys_s, idx_s, head, vid1,
+                         vstart, N, m->params.max_points_per_voxel, m->params.min_distance_between_points, (uint32_t)n_stored,
                          keep_lds_points(), keep);
     else
       hipLaunchKernelGGL(k_keep, dim3(nblk(n, B)), dim3(B), 0, s, keys_s, vid1, vstart, N, m->params.max_points_per_voxel,
