@@ -287,6 +287,15 @@ typedef struct {
 MH_API mh_status mh_nn_search(const mh_map* map, const mh_scan* scan, const double T[12], double threshold,
                               double threshold_angular_deg, const mh_pairs_out* out, int32_t mem,
                               mh_match_info* info);
+/* The same matcher with pairingsPerPoint = k > 1 (rgbd.yaml:135-141) on NearestNeighborsCapable::nn_multiple_search [U]
+ * ("same scan keeping k best sorted"): per local point the k nearest map points of the 27-voxel block in
+ * ascending (d^2, scan position), accepted in that order while d^2 < thr^2 + ang^2*|p'|^2.  Pairs in ascending local index, a
+ * point's pairs in ascending distance; output arrays hold scan-size * k entries; potential_pairings = scan size * k.
+ * pairings_per_point 1 is mh_nn_search. */
+#define MH_MAX_PAIRINGS_PER_POINT 8
+MH_API mh_status mh_nn_search_k(const mh_map* map, const mh_scan* scan, const double T[12], double threshold,
+                                double threshold_angular_deg, uint32_t pairings_per_point, const mh_pairs_out* out,
+                                int32_t mem, mh_match_info* info);
 /* Un-compacted variant: one entry per scan point; global_idx = 0xFFFFFFFF where nothing was found in
  * the 27-voxel block (no threshold applied).  Arrays hold scan-size entries; any may be NULL. */
 MH_API mh_status mh_nn_search_dense(const mh_map* map, const mh_scan* scan, const double T[12], uint32_t* global_idx,

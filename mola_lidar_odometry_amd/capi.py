@@ -163,6 +163,8 @@ _SIGNATURES = {
     "mh_scan_bbox": (C.c_int32, [C.c_void_p, _FP, _FP, C.POINTER(C.c_uint64)]),
     "mh_nn_search": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_double, C.c_double, C.POINTER(PairsOut), C.c_int32,
                                  C.POINTER(MatchInfo)]),
+    "mh_nn_search_k": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_double, C.c_double, C.c_uint32, C.POINTER(PairsOut),
+                                   C.c_int32, C.POINTER(MatchInfo)]),
     "mh_nn_search_dense": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int32]),
     "mh_nn_search_pt2pl": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_double, C.c_uint32, C.POINTER(PairsPlOut), C.c_int32,
@@ -471,6 +473,22 @@ def nn_search(m: Map, s: Scan, T, threshold, threshold_angular_deg=0.0):
     k = int(info.n_pairs)
     return dict(local_idx=li[:k].copy(), global_idx=gi[:k].copy(), global_xyz=np.stack([gx[:k], gy[:k], gz[:k]], 1),
                 d2=d2[:k].copy(), potential_pairings=int(info.potential_pairings))
+
+
+def nn_search_k(m: Map, s: Scan, T, threshold, k, threshold_angular_deg=0.0):
+    """Matcher_Points_DistanceThreshold with pairingsPerPoint = k (mh_nn_search_k)."""
+    n = max(s.n * int(k), 1)
+    li, gi = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    gx, gy, gz, d2 = (np.zeros(n, np.float32) for _ in range(4))
+    out = PairsOut(li.ctypes.data_as(_UP), gi.ctypes.data_as(_UP), gx.ctypes.data_as(_FP), gy.ctypes.data_as(_FP),
+                   gz.ctypes.data_as(_FP), d2.ctypes.data_as(_FP))
+    info = MatchInfo()
+    T = _T12(T)
+    _chk(lib().mh_nn_search_k(m._h, s._h, T.ctypes.data_as(_DP), float(threshold), float(threshold_angular_deg), int(k),
+                              C.byref(out), MEM_HOST, C.byref(info)))
+    np_ = int(info.n_pairs)
+    return dict(local_idx=li[:np_].copy(), global_idx=gi[:np_].copy(), global_xyz=np.stack([gx[:np_], gy[:np_], gz[:np_]], 1),
+                d2=d2[:np_].copy(), potential_pairings=int(info.potential_pairings))
 
 
 def _pl_arrays(n):

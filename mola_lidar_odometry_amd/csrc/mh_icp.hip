@@ -290,6 +290,39 @@ __global__ __launch_bounds__(kBlock, MH_MATCH_WAVES) void k_match(const IcpDevic
 }
 
 
+// Matcher_Points_DistanceThreshold with pairingsPerPoint = k > 1 (rgbd.yaml:135-141): entry i*k + r of the pair buffers is
+// the r-th nearest neighbour of point i, valid while the distances pass the threshold ("break at first failure": the limit is
+// the same for all of a point's neighbours and they come in ascending distance, so the passing ones are a prefix)
+__global__ __launch_bounds__(kBlock) void k_match_kbest(PoseArg Targ, float thr2, float ang2, uint32_t k, const float* __restrict__ lx,
+                                                        const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                        MapView map, float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  double T[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) T[j] = Targ.m[j];
+  float px, py, pz;
+  transform_point(T, lx[i], ly[i], lz[i], px, py, pz);
+  knnkey_t best[kMaxKnn];
+  nn_search_kbest(map, px, py, pz, k, best);
+  const float n2 = (px * px + py * py) + pz * pz;
+  const float lim = thr2 + ang2 * n2;
+  const gpts_ptr pts4 = (gpts_ptr)map.pts;
+  for (uint32_t r = 0; r < k; r++) {
+    const knnkey_t key = knn_select(best, r);
+    const bool found = key != ~0ull;
+    const float d2 = __uint_as_float((uint32_t)(key >> 32));
+    f32x4 pt = (f32x4)(0.f);
+    if (found) pt = pts4[(uint32_t)key];
+    pair_q[(size_t)i * k + r] = make_float4(pt.x, pt.y, pt.z, d2);
+    pair_gidx[(size_t)i * k + r] = (found && d2 < lim) ? __float_as_uint(pt.w) : kNoMatch;
+  }
+}
+__global__ void k_div_idx(uint32_t* __restrict__ idx, uint32_t n, uint32_t k) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] /= k;
+}
+
 #ifdef MH_DEBUG_WAVETRACE
 // debug build only: wall_clock64 (100 MHz) at numbered points of the one-workgroup kernels, last launch wins
 __device__ unsigned long long g_phase[16];
@@ -3699,6 +3732,51 @@ mh_status mh_nn_search(const mh_map* map, const mh_scan* scan, const double T[12
   mh_pairs_out none{};
   uint64_t np = 0;
   MH_TRY(compact_pairs(ctx, scan->n, out ? out : &none, mem, &np));
+  if (info) info->n_pairs = np;
+  return MH_OK;
+}
+
+mh_status mh_nn_search_k(const mh_map* map, const mh_scan* scan, const double T[12], double threshold,
+                         double threshold_angular_deg, uint32_t pairings_per_point, const mh_pairs_out* out, int32_t mem,
+                         mh_match_info* info) {
+  MH_REQUIRE(map && scan && T, "null argument");
+  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
+  MH_REQUIRE(pairings_per_point >= 1 && pairings_per_point <= (uint32_t)kMaxKnn, "pairings_per_point must be 1..MH_MAX_PAIRINGS_PER_POINT");
+  MH_REQUIRE(map->ctx->device == scan->ctx->device, "map and scan live on different devices");
+  MH_REQUIRE(pose_ok(T), "non-finite pose");
+  MH_REQUIRE((uint64_t)scan->n * pairings_per_point < 0xFFFFFFFFull, "scan size * pairings_per_point does not fit 32 bits");
+  if (pairings_per_point == 1) return mh_nn_search(map, scan, T, threshold, threshold_angular_deg, out, mem, info);
+  mh_ctx* ctx = scan->ctx;
+  MH_TRY(set_device(ctx));
+  MH_TRY(map_ready_on(map, ctx->stream));
+  const uint32_t k = pairings_per_point;
+  if (info) {
+    info->n_pairs = 0;
+    info->potential_pairings = (uint64_t)scan->n * k;  // pcLocal.size() * pairingsPerPoint, counted before any test (App.B U6)
+  }
+  if (scan->n == 0) return MH_OK;
+  const size_t nk = scan->n * (size_t)k;
+  MH_TRY(ensure_pair_buffers(ctx, nk));
+  PoseArg Ta;
+  for (int i = 0; i < 12; i++) Ta.m[i] = T[i];
+  const double ang = threshold_angular_deg * 3.14159265358979323846 / 180.0;
+  hipLaunchKernelGGL(k_match_kbest, dim3(nblk(scan->n)), dim3(kBlock), 0, ctx->stream, Ta, (float)(threshold * threshold),
+                     (float)(ang * ang), k, scan->x, scan->y, scan->z, (uint32_t)scan->n, map->view(), ctx->pair_q.as<float4>(),
+                     ctx->pair_gidx.as<uint32_t>());
+  MH_HIP(hipGetLastError());
+  mh_pairs_out none{};
+  uint64_t np = 0;
+  MH_TRY(compact_pairs(ctx, nk, out ? out : &none, mem, &np));
+  // compact_pairs numbers the ENTRIES: entry e belongs to local point e / k
+  if (out && out->local_idx && np) {
+    if (mem == MH_MEM_HOST) {
+      for (uint64_t e = 0; e < np; e++) out->local_idx[e] /= k;
+    } else {
+      hipLaunchKernelGGL(k_div_idx, dim3(nblk(np)), dim3(kBlock), 0, ctx->stream, out->local_idx, (uint32_t)np, k);
+      MH_HIP(hipGetLastError());
+      MH_HIP(mh::wait_stream(ctx->stream));
+    }
+  }
   if (info) info->n_pairs = np;
   return MH_OK;
 }

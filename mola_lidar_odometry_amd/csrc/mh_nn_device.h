@@ -311,6 +311,74 @@ __device__ __forceinline__ NNResult nn_search_pruned(const MapView& m, float qx,
 }
 
 
+// -------------------------------------------------------------------------------------------------
+// NearestNeighborsCapable::nn_multiple_search(q, k) [U] ("same scan keeping k best sorted"; used by
+// Matcher_Points_DistanceThreshold with pairingsPerPoint > 1, rgbd.yaml:135-141): the k smallest (d2, scan position) of the
+// 27-voxel block.  One lane per point, the eight smallest keys (d2 bits << 32 | record index: unsigned order = the reference's
+// order, ties to the earlier scan position) kept sorted in registers by a chain of compare-exchanges, voxels pruned against
+// the k-th smallest so far with the bound of nn_search_pruned.  Not a hot path of either target pipeline: exactness first.
+// -------------------------------------------------------------------------------------------------
+constexpr int kMaxKnn = 8;
+typedef unsigned long long knnkey_t;
+__device__ __forceinline__ void knn_insert(knnkey_t (&best)[kMaxKnn], knnkey_t key) {
+  if (!(key < best[kMaxKnn - 1])) return;
+  best[kMaxKnn - 1] = key;
+#pragma unroll
+  for (int t = kMaxKnn - 1; t > 0; t--) {
+    const knnkey_t a = best[t - 1], b = best[t];
+    const bool sw = b < a;
+    best[t - 1] = sw ? b : a;
+    best[t] = sw ? a : b;
+  }
+}
+__device__ __forceinline__ knnkey_t knn_select(const knnkey_t (&best)[kMaxKnn], uint32_t r) {
+  knnkey_t v = best[0];
+#pragma unroll
+  for (int t = 1; t < kMaxKnn; t++) v = r == (uint32_t)t ? best[t] : v;
+  return v;
+}
+__device__ __forceinline__ void knn_visit(const MapView& m, gslots_ptr slots4, gpts_ptr pts4, unsigned long long key, float qx,
+                                          float qy, float qz, knnkey_t (&best)[kMaxKnn]) {
+  uint32_t h = hash_key(key) & m.mask;
+  u32x4 sl = slots4[h];
+  unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
+  while (sk != key && sk != kEmptyKey) {  // linear probing past a collision
+    h = (h + 1) & m.mask;
+    sl = slots4[h];
+    sk = ((unsigned long long)sl.y << 32) | sl.x;
+  }
+  if (sk != key) return;
+  for (uint32_t j = 0; j < sl.w; j++) {
+    const f32x4 c = pts4[sl.z + j];
+    const float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order (bit-exact with the oracle)
+    knn_insert(best, ((knnkey_t)__float_as_uint(d2) << 32) | (knnkey_t)(sl.z + j));
+  }
+}
+// best[] ascending on return; entries never filled stay ~0
+__device__ __forceinline__ void nn_search_kbest(const MapView& m, float qx, float qy, float qz, uint32_t k,
+                                                knnkey_t (&best)[kMaxKnn]) {
+#pragma unroll
+  for (int t = 0; t < kMaxKnn; t++) best[t] = ~0ull;
+  const float lim = 1.0e6f;
+  if (!((int)(fabsf(qx * m.inv_vs) < lim) & (int)(fabsf(qy * m.inv_vs) < lim) & (int)(fabsf(qz * m.inv_vs) < lim))) return;
+  const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
+  const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
+  const gslots_ptr slots4 = (gslots_ptr)m.slots;
+  const gpts_ptr pts4 = (gpts_ptr)m.pts;
+  const Gaps gx = axis_gaps(qx, cx, m.vs, m.trunc), gy = axis_gaps(qy, cy, m.vs, m.trunc), gz = axis_gaps(qz, cz, m.vs, m.trunc);
+  knn_visit(m, slots4, pts4, nn_key_of(kbase, 13), qx, qy, qz, best);
+#pragma unroll 1
+  for (int c = 0; c < 27; c++) {
+    if (c == 13) continue;
+    // the k-th smallest distance so far (+inf while fewer than k were found: the key's high word is then 0xFFFFFFFF = NaN,
+    // and `lb > NaN` is false -- the voxel is visited)
+    const float bound = __uint_as_float((uint32_t)(knn_select(best, k - 1) >> 32));
+    if (nn_lower_bound(c, gx, gy, gz) * 0.9999f > bound) continue;
+    knn_visit(m, slots4, pts4, nn_key_of(kbase, c), qx, qy, qz, best);
+  }
+}
+
 // {first, count} of voxel `key` given the slot its hash points at; count 0 when absent or not wanted
 __device__ __forceinline__ void nn_resolve(const MapView& m, gslots_ptr slots4, unsigned long long key, u32x4 sl,
                                            bool want, uint32_t& first, uint32_t& cnt) {

@@ -117,10 +117,42 @@ bool HashedVoxelPointCloudHIP::nn_single_search(const mrpt::math::TPoint3Df& q, 
     resultIndexOrID = gi;
     return true;
 }
-void HashedVoxelPointCloudHIP::nn_multiple_search(const mrpt::math::TPoint3Df&, size_t, std::vector<mrpt::math::TPoint3Df>&,
-                                                  std::vector<float>&, std::vector<uint64_t>&) const
+void HashedVoxelPointCloudHIP::nn_multiple_search(const mrpt::math::TPoint3Df& q, size_t N, std::vector<mrpt::math::TPoint3Df>& results,
+                                                  std::vector<float>& out_dists_sqr, std::vector<uint64_t>& resultIndicesOrIDs) const
 {
-    THROW_EXCEPTION("nn_multiple_search: not provided by the device map (pairingsPerPoint > 1 is unused by the pipelines)");
+    // one query through the k-best search (mh_nn_search_k with an infinite threshold): the N nearest of the 3x3x3 block in
+    // ascending (distance, scan position).  A per-point call is a device round trip: the matchers batch a whole layer instead.
+    results.clear();
+    out_dists_sqr.clear();
+    resultIndicesOrIDs.clear();
+    if (!map_ || N == 0) return;
+    if (N > MH_MAX_PAIRINGS_PER_POINT) THROW_EXCEPTION("nn_multiple_search: more neighbours than MH_MAX_PAIRINGS_PER_POINT");
+    mh_check(mh_scan_update(staging_, &q.x, &q.y, &q.z, 1, MH_MEM_HOST), "mh_scan_update");
+    const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    uint32_t     li[MH_MAX_PAIRINGS_PER_POINT], gi[MH_MAX_PAIRINGS_PER_POINT];
+    float        gx[MH_MAX_PAIRINGS_PER_POINT], gy[MH_MAX_PAIRINGS_PER_POINT], gz[MH_MAX_PAIRINGS_PER_POINT], d2[MH_MAX_PAIRINGS_PER_POINT];
+    mh_pairs_out po{li, gi, gx, gy, gz, d2};
+    mh_match_info info{};
+    if (N == 1)
+    {
+        mrpt::math::TPoint3Df r;
+        float                 d;
+        uint64_t              id;
+        if (!nn_single_search(q, r, d, id)) return;
+        results.push_back(r);
+        out_dists_sqr.push_back(d);
+        resultIndicesOrIDs.push_back(id);
+        return;
+    }
+    mh_check(mh_nn_search_k(map_, staging_, I, 1.0e18 /* no threshold: fp32 d^2 stays below its square */, 0.0, (uint32_t)N, &po,
+                            MH_MEM_HOST, &info),
+             "mh_nn_search_k");
+    for (uint64_t k = 0; k < info.n_pairs; k++)
+    {
+        results.emplace_back(gx[k], gy[k], gz[k]);
+        out_dists_sqr.push_back(d2[k]);
+        resultIndicesOrIDs.push_back(gi[k]);
+    }
 }
 void HashedVoxelPointCloudHIP::nn_radius_search(const mrpt::math::TPoint3Df&, float, std::vector<mrpt::math::TPoint3Df>&,
                                                 std::vector<float>&, std::vector<uint64_t>&, size_t) const

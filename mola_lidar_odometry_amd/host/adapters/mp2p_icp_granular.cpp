@@ -47,9 +47,10 @@ class Matcher_Points_DistanceThreshold_HIP : public Matcher_Points_DistanceThres
                            const layer_name_t& localName, Pairings& out) const override  // [U]
     {
         const auto& sw = molahip_host::plugin_switches();
-        // what the device search implements: one pairing per point, no exclusivity bookkeeping between points, the
-        // whole layer (no random subsample), no earlier matcher's pairings to respect
-        const bool device_shape = pairingsPerPoint == 1 && allowMatchAlreadyMatchedGlobalPoints_ && maxLocalPointsPerLayer_ == 0 &&
+        // what the device search implements: up to MH_MAX_PAIRINGS_PER_POINT pairings per point (nn_multiple_search, rgbd.yaml:138),
+        // no exclusivity bookkeeping between points, the whole layer (no random subsample), no earlier matcher's pairings to respect
+        const bool device_shape = pairingsPerPoint >= 1 && pairingsPerPoint <= MH_MAX_PAIRINGS_PER_POINT &&
+                                  allowMatchAlreadyMatchedGlobalPoints_ && maxLocalPointsPerLayer_ == 0 &&
                                   (allowMatchAlreadyMatchedPoints_ || ms.localPairedBitField.point_layers.count(localName) == 0 ||
                                    ms.localPairedBitField.point_layers.at(localName).none());  // [U] members of Matcher_Points_Base / MatchState
         mh_map* dmap = nullptr;
@@ -66,9 +67,10 @@ class Matcher_Points_DistanceThreshold_HIP : public Matcher_Points_DistanceThres
         const size_t n = pcLocal.size();
         double T[12];
         pose_to_T12(localPose, T);
-        mh_pairs_out po = dev->pairs.out(n);
+        mh_pairs_out po = dev->pairs.out(n * pairingsPerPoint);
         mh_match_info info{};
-        mh_check(mh_nn_search(dmap, scan, T, threshold, thresholdAngularDeg, &po, MH_MEM_HOST, &info), "mh_nn_search");
+        mh_check(mh_nn_search_k(dmap, scan, T, threshold, thresholdAngularDeg, (uint32_t)pairingsPerPoint, &po, MH_MEM_HOST, &info),
+                 "mh_nn_search_k");
         // Pairings::potential_pairings [U]: every local point of the layer times pairingsPerPoint (U6)
         out.potential_pairings += info.potential_pairings;
         const auto& lx = pcLocal.getPointsBufferRef_x();

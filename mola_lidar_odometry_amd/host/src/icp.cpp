@@ -305,9 +305,9 @@ void Matcher_Points_DistanceThreshold::initialize(const Config& c) {
       pointLayerMatches.push_back(lm);
     }
   }
-  if (pairingsPerPoint != 1)
-    throw std::runtime_error("Matcher_Points_DistanceThreshold: only pairingsPerPoint=1 is implemented on the device "
-                             "(the value both reference pipelines use)");
+  if (pairingsPerPoint < 1 || pairingsPerPoint > MH_MAX_PAIRINGS_PER_POINT)
+    throw std::runtime_error("Matcher_Points_DistanceThreshold: pairingsPerPoint must be 1.." +
+                             std::to_string(MH_MAX_PAIRINGS_PER_POINT) + " (rgbd.yaml:138 uses 2)");
 }
 
 static const PointCloud& local_layer(const metric_map_t& m, const std::string& name) {
@@ -335,19 +335,23 @@ void Matcher_Points_DistanceThreshold::impl_match(const metric_map_t& pcGlobal, 
     if (!n) continue;
     mh_scan* scan = nullptr;
     check(mh_scan_create(glob.context()->get(), loc.x.data(), loc.y.data(), loc.z.data(), n, MH_MEM_HOST, &scan), "mh_scan_create");
-    std::vector<uint32_t> li(n), gi(n);
-    std::vector<float> gx(n), gy(n), gz(n), d2(n);
+    const size_t cap = n * pairingsPerPoint;  // nn_multiple_search(k): up to k pairs per local point (rgbd.yaml:138)
+    std::vector<uint32_t> li(cap), gi(cap);
+    std::vector<float> gx(cap), gy(cap), gz(cap), d2(cap);
     mh_pairs_out po{li.data(), gi.data(), gx.data(), gy.data(), gz.data(), d2.data()};
     mh_match_info info{};
-    const mh_status st = mh_nn_search(glob.handle(), scan, localPose.T, threshold, thresholdAngularDeg, &po, MH_MEM_HOST, &info);
+    const mh_status st = mh_nn_search_k(glob.handle(), scan, localPose.T, threshold, thresholdAngularDeg, pairingsPerPoint, &po,
+                                        MH_MEM_HOST, &info);
     mh_scan_destroy(scan);
-    check(st, "mh_nn_search");
+    check(st, "mh_nn_search_k");
     // U12 (MOLA_HIP_MATCHED_POINTS=skip): local points an earlier matcher of this iteration has paired are left out [U]
     const bool skip_paired = molahip_host::plugin_switches().matched_points == MH_MATCHED_POINTS_SKIP;
     auto& paired = out.local_paired[lm.local];
     if (paired.size() < n) paired.resize(n, 0);
+    std::vector<uint8_t> paired_before;
+    if (skip_paired) paired_before = paired;  // (a point's own second pair is not "already paired by an earlier matcher")
     for (size_t k = 0; k < info.n_pairs; k++) {
-      if (skip_paired && paired[li[k]]) continue;
+      if (skip_paired && paired_before[li[k]]) continue;
       paired[li[k]] = 1;
       out.localIdx.push_back(li[k]);
       out.globalIdx.push_back(gi[k]);

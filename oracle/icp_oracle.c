@@ -555,6 +555,75 @@ size_t orc_match_points(const orc_map* m, const float* lx, const float* ly, cons
   return np;
 }
 
+/* nn_multiple_search(q, k) [U] ("same scan keeping k best sorted"): the 3x3x3 block in the same order as
+ * nn_single_search; a candidate enters the sorted list in front of the first entry it is STRICTLY nearer than, so among
+ * equal distances the earlier scan position stays in front (k = 1 is nn_single_search).  Returns how many were found (<= k). */
+int orc_map_nn_multiple(const orc_map* m, float qx, float qy, float qz, uint32_t k, float* out_pts /* 3 per entry */,
+                        float* out_d2, uint32_t* out_src_idx) {
+  const int32_t cx = coord2idx(m, qx), cy = coord2idx(m, qy), cz = coord2idx(m, qz);
+  uint32_t found = 0;
+  for (int32_t ix = cx - 1; ix <= cx + 1; ix++)
+    for (int32_t iy = cy - 1; iy <= cy + 1; iy++)
+      for (int32_t iz = cz - 1; iz <= cz + 1; iz++) {
+        const voxel_t* v = map_find(m, ix, iy, iz);
+        if (!v || v->n == 0) continue;
+        for (uint32_t j = 0; j < v->n; j++) {
+          const float dx = v->xyz[3 * j] - qx, dy = v->xyz[3 * j + 1] - qy, dz = v->xyz[3 * j + 2] - qz;
+          const float d2 = (dx * dx + dy * dy) + dz * dz; /* fp32, un-fused, this order */
+          uint32_t pos = found;
+          while (pos > 0 && d2 < out_d2[pos - 1]) pos--;
+          if (pos >= k) continue;
+          const uint32_t last = found < k ? found : k - 1;
+          for (uint32_t t = last; t > pos; t--) {
+            out_d2[t] = out_d2[t - 1];
+            out_src_idx[t] = out_src_idx[t - 1];
+            out_pts[3 * t] = out_pts[3 * (t - 1)]; out_pts[3 * t + 1] = out_pts[3 * (t - 1) + 1]; out_pts[3 * t + 2] = out_pts[3 * (t - 1) + 2];
+          }
+          out_d2[pos] = d2;
+          out_src_idx[pos] = v->src[j];
+          out_pts[3 * pos] = v->xyz[3 * j]; out_pts[3 * pos + 1] = v->xyz[3 * j + 1]; out_pts[3 * pos + 2] = v->xyz[3 * j + 2];
+          if (found < k) found++;
+        }
+      }
+  return (int)found;
+}
+
+/* Matcher_Points_DistanceThreshold with pairingsPerPoint = k > 1 (rgbd.yaml:135-141): nn_multiple_search(k),
+ * the neighbours taken in ascending distance while d^2 < thr^2 + ang^2 |p'|^2, "break at first failure".  Pairs in ascending
+ * local index, a point's pairs in ascending distance.  Output arrays sized n * k. */
+size_t orc_match_points_k(const orc_map* m, const float* lx, const float* ly, const float* lz, size_t n, const double T[12],
+                          double threshold, double threshold_angular_deg, uint32_t k, uint32_t* local_idx,
+                          uint32_t* global_idx, float* gx, float* gy, float* gz, float* d2, orc_match_stats* stats) {
+  const float thr2 = (float)(threshold * threshold);
+  const double ang = threshold_angular_deg * 3.14159265358979323846 / 180.0;
+  const float ang2 = (float)(ang * ang);
+  float* pts = (float*)malloc(sizeof(float) * 3 * (k ? k : 1));
+  float* dd = (float*)malloc(sizeof(float) * (k ? k : 1));
+  uint32_t* gi = (uint32_t*)malloc(sizeof(uint32_t) * (k ? k : 1));
+  size_t np = 0;
+  for (size_t i = 0; i < n; i++) {
+    float px, py, pz;
+    transform_pt(T, lx[i], ly[i], lz[i], &px, &py, &pz);
+    if (!isfinite(px) || !isfinite(py) || !isfinite(pz)) continue; /* a non-finite point pairs with nothing */
+    const int found = orc_map_nn_multiple(m, px, py, pz, k, pts, dd, gi);
+    const float norm2 = (px * px + py * py) + pz * pz;
+    const float lim = thr2 + ang2 * norm2;
+    for (int r = 0; r < found; r++) {
+      if (!(dd[r] < lim)) break;
+      local_idx[np] = (uint32_t)i; global_idx[np] = gi[r];
+      gx[np] = pts[3 * r]; gy[np] = pts[3 * r + 1]; gz[np] = pts[3 * r + 2]; d2[np] = dd[r];
+      np++;
+    }
+  }
+  free(pts); free(dd); free(gi);
+  if (stats) {
+    stats->potential_pairings = (uint64_t)n * k; /* pcLocal.size() * pairingsPerPoint, counted before any test (U6) */
+    stats->n_candidates = 0;
+    stats->n_voxels_hit = 0;
+  }
+  return np;
+}
+
 /* Matcher_Point2Plane on the NDT map (semantics: icp_oracle.h) */
 size_t orc_match_pt2pl(const orc_map* m, const float* lx, const float* ly, const float* lz, size_t n, const double T[12],
                        double distance_threshold, uint32_t* local_idx, float* cx, float* cy, float* cz, float* nx,

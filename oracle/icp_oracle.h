@@ -110,6 +110,16 @@ size_t orc_match_points(const orc_map* m, const float* lx, const float* ly, cons
                         uint32_t* local_idx, uint32_t* global_idx, float* gx, float* gy, float* gz,
                         float* d2, orc_match_stats* stats, int n_threads);
 
+/* ---- the same matcher with pairingsPerPoint = k > 1 (rgbd.yaml:135-141) on NearestNeighborsCapable::nn_multiple_search [U]
+ * ("same scan keeping k best sorted"): the k nearest of the 3x3x3 block in ascending (d^2, scan position),
+ * accepted in that order while d^2 < thr^2 + ang^2 * |p'|^2.  Pairs in ascending local index, a point's pairs in ascending
+ * distance.  Output arrays sized n * k; potential_pairings = n * k. */
+int orc_map_nn_multiple(const orc_map* m, float qx, float qy, float qz, uint32_t k, float* out_pts, float* out_d2,
+                        uint32_t* out_src_idx);
+size_t orc_match_points_k(const orc_map* m, const float* lx, const float* ly, const float* lz, size_t n, const double T[12],
+                          double threshold, double threshold_angular_deg, uint32_t k, uint32_t* local_idx,
+                          uint32_t* global_idx, float* gx, float* gy, float* gz, float* d2, orc_match_stats* stats);
+
 /* ---- matcher: mp2p_icp::Matcher_Point2Plane on a mola::NDT map (lidar3d-ndt.yaml:195-200; SURVEY 8a row a13,
  * App.B U10 -- the upstream semantics are unverified, this is the documented default): per voxel with
  * >= ndt_min_points points: mean, covariance (1/(n-1)), eigen-decomposition; the voxel is a plane iff

@@ -328,6 +328,27 @@ def match_points(m: Map, local_xyz, T, threshold, threshold_angular_deg=0.0, n_t
                 n_voxels_hit=int(st.n_voxels_hit))
 
 
+def match_points_k(m: Map, local_xyz, T, threshold, k, threshold_angular_deg=0.0):
+    """Matcher_Points_DistanceThreshold with pairingsPerPoint = k (orc_match_points_k)."""
+    l = np.asarray(local_xyz, dtype=np.float32)
+    n = len(l)
+    lx, ly, lz = _f32(l[:, 0]), _f32(l[:, 1]), _f32(l[:, 2])
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(12)
+    cap = max(n * int(k), 1)
+    li, gi = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    gx, gy, gz, d2 = (np.zeros(cap, np.float32) for _ in range(4))
+    st = _MatchStats()
+    f = lib().orc_match_points_k
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t,
+                  C.POINTER(C.c_double), C.c_double, C.c_double, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                  C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]
+    np_ = f(m._h, _fp(lx), _fp(ly), _fp(lz), n, _dp(T), float(threshold), float(threshold_angular_deg), int(k), _up(li),
+            _up(gi), _fp(gx), _fp(gy), _fp(gz), _fp(d2), C.byref(st))
+    return dict(local_idx=li[:np_].copy(), global_idx=gi[:np_].copy(), global_xyz=np.stack([gx[:np_], gy[:np_], gz[:np_]], 1),
+                d2=d2[:np_].copy(), potential_pairings=int(st.potential_pairings))
+
+
 def match_pt2pl(m: Map, local_xyz, T, distance_threshold, n_threads=1, mode=PT2PL_PLANE_DISTANCE):
     distance_threshold = (-1.0 if mode == PT2PL_CENTROID_DISTANCE else 1.0) * abs(float(distance_threshold))
     l = np.asarray(local_xyz, dtype=np.float32)

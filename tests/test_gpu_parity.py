@@ -353,6 +353,48 @@ def test_nn_pruning_is_exact_on_adversarial_clouds(ctx, oracle, vs, cap, mode, o
         np.testing.assert_array_equal(d["global_xyz"][found], o["global_xyz"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("vs,cap,mode,offset", [(1.0, 20, 0, 0.0), (0.3, 5, 0, 0.0), (2.5, 0, 0, 0.0), (1.0, 20, 1, 0.0),
+                                                (1.0, 20, 0, 50000.0), (0.7, 8, 0, -12345.0)])
+@pytest.mark.parametrize("k", [2, 3, 8])
+def test_k_best_matcher_is_exact_on_adversarial_clouds(ctx, oracle, vs, cap, mode, offset, k):
+    """mh_nn_search_k (Matcher_Points_DistanceThreshold with pairingsPerPoint = k, rgbd.yaml:135-141, on nn_multiple_search):
+    the k nearest of the 27-voxel block in ascending (distance, scan position), accepted while below the limit -- bit-equal to
+    the oracle on the adversarial inputs of the single-neighbour test (exact ties across voxels, queries on voxel faces, coarse
+    fp32 spacing, inexact reciprocals, trunc indexing), with and without the angular term, on plain and NDT maps."""
+    rng = np.random.default_rng(int(vs * 10) + cap + mode + k)
+    g = np.arange(-6, 6, 0.25, dtype=np.float32)
+    lattice = np.stack(np.meshgrid(g, g, g[:24], indexing="ij"), -1).reshape(-1, 3)
+    lattice = lattice[rng.permutation(len(lattice))[:40000]]
+    noise = rng.normal(0, 3, (20000, 3)).astype(np.float32)
+    pts = (np.concatenate([lattice, noise]) + np.float32(offset)).astype(np.float32)
+    ndt = dict(ndt_max_eigen_ratio=0.05) if (cap == 20 and mode == 0 and offset == 0.0) else {}
+    gm = capi.Map(ctx, vs, cap, mode, **ndt).build(pts)
+    om = oracle.Map(vs, cap, mode, **ndt).insert(pts)
+    q_mid = (lattice[:2000] + np.float32(0.125)).astype(np.float32)
+    q_bnd = np.round(rng.uniform(-6, 6, (2000, 3)) / vs).astype(np.float32) * np.float32(vs)
+    q_bnd[:, 1] += rng.uniform(-0.5, 0.5, 2000).astype(np.float32)
+    q_rnd = rng.uniform(-7, 7, (3000, 3)).astype(np.float32)
+    q_far = rng.uniform(-30, 30, (500, 3)).astype(np.float32)
+    q = (np.concatenate([q_mid, q_bnd, q_rnd, q_far]) + np.float32(offset)).astype(np.float32)
+    gs = capi.Scan(ctx, q)
+    for T, thr, ang in ((I12, 1e9, 0.0), (oracle.se3_exp([0.11, -0.07, 0.05, 0.002, -0.001, 0.003]), 0.35 * vs, 0.0),
+                        (I12, 0.1 * vs, 2.0)):
+        d = capi.nn_search_k(gm, gs, T, thr, k, ang)
+        o = oracle.match_points_k(om, q, T, thr, k, ang)
+        assert d["potential_pairings"] == o["potential_pairings"] == len(q) * k
+        for key in ("local_idx", "global_idx", "d2", "global_xyz"):
+            np.testing.assert_array_equal(d[key], o[key])
+        assert thr < 1e8 or len(o["local_idx"]) > len(q) // 2
+    # k = 1 is mh_nn_search; an empty scan and an empty map pair nothing
+    a, b = capi.nn_search_k(gm, gs, I12, 0.5 * vs, 1), capi.nn_search(gm, gs, I12, 0.5 * vs)
+    for key in ("local_idx", "global_idx", "d2"):
+        np.testing.assert_array_equal(a[key], b[key])
+    assert len(capi.nn_search_k(gm, capi.Scan(ctx), I12, 1.0, k)["local_idx"]) == 0
+    with pytest.raises(capi.MolahipError):
+        capi.nn_search_k(gm, gs, I12, 1.0, 9)
+
+
 # ---------------------------------------------------------------------------- solver
 def _pairs(rng, n, noise=0.05):
     l = rng.normal(0, 10, (n, 3)).astype(np.float32)

@@ -416,3 +416,72 @@ def test_gated_matchers_on_several_layers_match_an_oracle_loop(hl, oracle, small
     np.testing.assert_allclose(res.pose(), T, atol=1e-7)
     assert res.n_pairs() == n_pairs and res.quality == pytest.approx(n_pairs / potential, abs=1e-12)
     assert np.abs(res.pose() - w.T_gt).max() < 0.05  # and it converged to the ground truth
+
+
+_TWO_PAIRINGS_ICP = """
+class_name: mp2p_icp::ICP
+params:
+  maxIterations: 40
+  minAbsStep_trans: 1e-4
+  minAbsStep_rot: 5e-5
+solvers:
+  - class: mp2p_icp::Solver_GaussNewton
+    params:
+      maxIterations: 2
+      robustKernel: 'RobustKernel::GemanMcClure'
+      robustKernelParam: 0.3
+matchers:
+  - class: mp2p_icp::Matcher_Points_DistanceThreshold
+    params:
+      threshold: 0.9
+      thresholdAngularDeg: 0.5
+      pairingsPerPoint: 2
+      allowMatchAlreadyMatchedGlobalPoints: true
+      pointLayerMatches:
+        - {global: "localmap", local: "decimated_for_icp", weight: 1.0}
+quality:
+  - class: mp2p_icp::QualityEvaluator_PairedRatio
+    params:
+      ~
+"""
+
+
+@pytest.mark.gpu
+def test_two_pairings_per_point_match_an_oracle_loop(hl, oracle, small_workload):
+    """`pairingsPerPoint: 2` with an angular threshold (the point matcher of the reference's pipelines/rgbd.yaml:133-141): the
+    matcher runs nn_multiple_search on the device (mh_nn_search_k), every local point contributes up to two pairings to the
+    Gauss-Newton step and two to potential_pairings.  Checked against the same loop written with the oracle's k-best matcher and
+    solver."""
+    w = small_workload
+    g = hl.metric_map_t()
+    hv = hl.HashedVoxelPointCloud(1.0, 20)
+    hv.setPoints(w.map_xyz)
+    g.set_layer("localmap", hv)
+    l = hl.metric_map_t()
+    l.set_layer("decimated_for_icp", hl.PointCloud(w.scan_xyz))
+    icp, params = hl.icp_pipeline_from_yaml(hl.Config.FromYamlText(_TWO_PAIRINGS_ICP))
+    res = icp.align(l, g, hl.TPose3D(*w.guess_ypr), params)
+    assert not icp.lastAlignUsedFusedPath()
+
+    om = oracle.Map(1.0, 20).insert(w.map_xyz)
+    T, Tprev, term, it, n_pairs = w.T_guess.copy(), w.T_guess.copy(), "MaxIterations", 0, 0
+    for it in range(40):
+        r = oracle.match_points_k(om, w.scan_xyz, T, 0.9, 2, 0.5)
+        n_pairs = len(r["local_idx"])
+        if n_pairs == 0:
+            term = "NoPairings"
+            break
+        T = oracle.gn_solve(T, pt2pt=(w.scan_xyz[r["local_idx"]], r["global_xyz"]),
+                            params=oracle.GNParams(max_inner_iterations=2, robust_kernel_param=0.3))[0]
+        d = oracle.se3_log(oracle.pose_compose(oracle.pose_inverse(Tprev), T))
+        if np.linalg.norm(d[:3]) < 1e-4 and np.linalg.norm(d[3:]) < 5e-5:
+            term = "Stalled"
+            break
+        Tprev = T.copy()
+    else:
+        it = 40
+    assert n_pairs > len(w.scan_xyz)  # most points have two partners
+    assert res.terminationReason.name == term
+    assert res.nIterations == it
+    np.testing.assert_allclose(res.pose(), T, atol=1e-7)
+    assert res.n_pairs() == n_pairs and res.quality == pytest.approx(n_pairs / (2 * len(w.scan_xyz)), abs=1e-12)

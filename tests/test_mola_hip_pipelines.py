@@ -261,7 +261,7 @@ def test_granular_pipelines_name_the_device_matcher_and_solver_classes(tmp_path)
                       ("Solver_GaussNewton_HIP", "Solver_GaussNewton")):
         assert re.search(r"class %s : public %s\b" % (cls, base), g)
         assert re.search(r"IMPLEMENTS_MRPT_OBJECT\(%s,\s*mp2p_icp::%s,\s*mp2p_icp\)" % (cls, base), g)
-    for call in ("mh_nn_search(", "mh_nn_search_pt2pl(", "mh_gn_solve("):
+    for call in ("mh_nn_search_k(", "mh_nn_search_pt2pl(", "mh_gn_solve("):
         assert call in g
     cm = open(os.path.join(ADAPTERS, "CMakeLists.txt")).read()
     assert "mp2p_icp_granular.cpp" in cm
