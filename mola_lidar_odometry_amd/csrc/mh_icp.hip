@@ -66,6 +66,7 @@ struct IcpDeviceState {
   double cov[36];
   double covD[72];  // (T(x+h_j) - T(x-h_j)) / (2 h_j), j = 0..5, 3x4 each
   uint32_t handover_timeouts, pad2_;  // k_step16: workgroups that gave up waiting for the state / the partials they expected (never seen)
+  uint32_t dbg[8];  // the first give-up: [0] 1 = state, 2 = partials' tag  [1] workgroup  [2] thread  [3] wanted  [4] seen  [5] groups  [6] seen B
 };
 
 // Per-alignment parameters live in DEVICE memory (uploaded once per align from a pinned host mirror) and the kernels
@@ -1360,13 +1361,22 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
     __syncthreads();
     if (expect == kStepUnchecked || lst->serial == expect) break;
     if (spins == (1u << 14)) {  // ~ tens of milliseconds: give up loudly (the host fails the alignment)
-      if (tid == 0) atomicAdd(&s_canon->handover_timeouts, 1u);
+      if (tid == 0) {
+        atomicAdd(&s_canon->handover_timeouts, 1u);
+        if (atomicCAS(&s_canon->dbg[0], 0u, 1u) == 0u) {
+          s_canon->dbg[1] = wg; s_canon->dbg[2] = tid; s_canon->dbg[3] = expect; s_canon->dbg[4] = lst->serial; s_canon->dbg[5] = ngroups;
+        }
+      }
       break;
     }
     __builtin_amdgcn_s_sleep(8);
     __syncthreads();  // (lst_raw is rewritten)
   }
+  // (taken from the block NOW: workgroup 0 rewrites both words further down, behind a barrier -- a wave that looked at
+  //  `pending` after thread 0 had set it for the NEXT launch waited for partial sums nobody had written: launch 0 of an
+  //  alignment "gave up" in workgroup 0, a few times per thousand alignments, more under load)
   const uint32_t serial = lst->serial;  // what the columns this launch sums must be tagged with
+  const uint32_t pending = lst->pending;
   if (lst->done) {  // the loop has ended (the canonical block has it): keep the ping-pong consistent, nothing else
     if (wg == 0 && tid < kStateHeadDwords)
       __hip_atomic_store(reinterpret_cast<uint32_t*>(s_out) + tid, tid == kStateSerialDword ? serial + 1u : lst_raw[tid], __ATOMIC_RELAXED,
@@ -1374,7 +1384,7 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
     return;
   }
   MH_PHASE(1);
-  if (lst->pending) {
+  if (pending) {
     // every column carries the serial number of the launch that wrote it, stored AFTER its sums were acknowledged: a column
     // that does not carry this launch's number yet has not arrived (never seen since the exchange is at agent scope; a lane
     // waits for its columns rather than sum what is not there)
@@ -1382,6 +1392,11 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
     for (uint32_t spins = 0; tag_a != want || (PL && tag_b != want); spins++) {
       if (spins == (1u << 16)) {
         atomicAdd(&s_canon->handover_timeouts, 1u);
+        if (atomicCAS(&s_canon->dbg[0], 0u, 2u) == 0u) {
+          s_canon->dbg[1] = wg; s_canon->dbg[2] = tid; s_canon->dbg[3] = serial; s_canon->dbg[4] = (uint32_t)tag_a; s_canon->dbg[5] = ngroups;
+          s_canon->dbg[6] = expect;
+          s_canon->dbg[7] = (pending & 0xFFu) | ((lst->iter & 0xFFu) << 8) | ((lst->inner & 0xFFu) << 16) | ((lst->done & 0xFFu) << 24);
+        }
         break;
       }
       __builtin_amdgcn_s_sleep(1);
@@ -1403,6 +1418,7 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
   const uint32_t done = lst->done;
   const bool body = !done && !close_only;
   if (wg == 0) {
+    __syncthreads();  // every wave has taken `serial` and `pending` from the block
     if (tid == 0) {
       lst->pending = body ? 1u : 0u;
       lst->serial = serial + 1u;
@@ -2670,6 +2686,7 @@ struct AlignJob {
       if (pl && p->matched_points == MH_MATCHED_POINTS_SKIP) variant = 5;
     }
     if (variant >= 6) MH_TRY(scan_build_tiles(scan, map->inv_vs, variant == 7 ? 64u : 256u));  // asynchronous; a no-op when the scan is already in search order
+    if (variant == 4 || variant >= 6) MH_TRY(map_ensure_qidx(map, ctx->stream));  // nn_search_quad reads the map's sub-voxel index
     nba = nblk_acc(scan->n);
     // (measured per iteration, fused vs k_accum: 31.0 vs 33.8 us at 4 k points, 33.2 vs 35.0 at 8 k, equal at 16 k,
     //  45.9 vs 41.8 at 32 k -- one partial row per 16 points makes the solve's reduction the longer pole there)
@@ -2901,7 +2918,7 @@ struct AlignJob {
     } else {
       // The launch sequence only depends on sizes and device pointers (the per-alignment values sit in device
       // memory), so it is captured once and replayed: one host call per chunk instead of ~4 per iteration.
-      unsigned long long key[28] = {0};
+      unsigned long long key[32] = {0};
       uint32_t fb;
       memcpy(&fb, &mv.inv_vs, 4);
       const unsigned long long kv[] = {n, nb, nbm, (unsigned long long)variant, m, p->gn.max_inner_iterations,
@@ -2916,7 +2933,8 @@ struct AlignJob {
                                        (unsigned long long)(pl ? ctx->pl_n.p : nullptr),
                                        (unsigned long long)(pl ? ctx->partials_b.p : nullptr),
                                        variant >= 6 ? (unsigned long long)scan->sx : 0ull,
-                                       variant >= 6 ? (unsigned long long)scan->n_tiles : 0ull};  // (a word each: no XOR folding)
+                                       variant >= 6 ? (unsigned long long)scan->n_tiles : 0ull,
+                                       (unsigned long long)mv.pts_q, (unsigned long long)mv.qidx};  // (a word each: no XOR folding)
       static_assert(sizeof(kv) <= sizeof(key), "graph key too small");
       memcpy(key, kv, sizeof(kv));
       const bool cached = ctx->graph_exec && memcmp(key, ctx->graph_key, sizeof(key)) == 0;
@@ -3038,8 +3056,8 @@ struct AlignJob {
       return MH_OK;
     }
     if (h->handover_timeouts)
-      return fail(MH_ERR_INTERNAL, "device ICP loop (k_step16): %u workgroup(s) gave up waiting for the state block or the partial sums of the previous launch",
-                  h->handover_timeouts);
+      return fail(MH_ERR_INTERNAL, "device ICP loop (k_step16): %u workgroup(s) gave up waiting for the state block or the partial sums of the previous launch [first: kind %u wg %u tid %u wanted %u (base %u) seen %u groups %u expect %u state(pending|iter|inner|done) %08x iter %u n %u streaming %d]",
+                  h->handover_timeouts, h->dbg[0], h->dbg[1], h->dbg[2], h->dbg[3], serial_base, h->dbg[4], h->dbg[5], h->dbg[6], h->dbg[7], h->n_iterations, (uint32_t)scan->n, (int)streaming);
     if (!h->done) return fail(MH_ERR_INTERNAL, "device ICP loop did not terminate after max_iterations");
     finished = true;
     if (auto_chunk) ctx->predicted_iterations[kind] = h->n_iterations + (h->term_reason == MH_TERM_MAX_ITERATIONS ? 0u : 1u);
@@ -3675,6 +3693,7 @@ mh_status launch_tile_search(const mh_map* map, const mh_scan* scan, const doubl
   const bool wave = tile_points_for_env() == 64u;
   MH_TRY(scan_build_tiles(scan, map->inv_vs, wave ? 64u : 256u));
   MH_TRY(scan_tiles_ready(scan));
+  MH_TRY(map_ensure_qidx(map, ctx->stream));  // (sparse tiles are searched by quads)
   MH_HIP(mh::wait_stream(ctx->stream));  // the pinned state mirror may still be travelling
   init_state(ctx->h_state, T);
   ctx->h_state->cur_thr2 = thr2;

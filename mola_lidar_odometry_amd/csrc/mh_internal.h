@@ -1,6 +1,7 @@
 // mh_internal.h -- private structures shared by the libmolahip translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -102,6 +103,11 @@ struct MapView {
   uint32_t trunc;     // index_mode == MH_INDEX_TRUNC
   uint32_t ndt;       // 1: every voxel's points are preceded by two records {centroid, plane flag} {normal, 0}
   uint32_t no_prev_bound;  // A/B switch (MH_NO_PREV_BOUND=1): the quad matcher ignores the previous iteration's pairing
+  // sub-voxel index of the quad matcher (round 4; valid after map_ensure_qidx, null before): pts_q = the records of every voxel
+  // re-ordered by (x half, y half) of the voxel, w = the record's index in `pts` (the reference's scan position: the
+  // tie-break); qidx[slot] = bit 31 | b3 << 10 | b2 << 5 | b1, the quadrants' boundaries (0: scan the voxel whole)
+  const float4* pts_q;
+  const uint32_t* qidx;
 #ifdef MH_DEBUG_WAVETRACE
   uint32_t dbg_stop;  // debug build: leave the quad search after phase N (tools/wavetrace_probe.py)
 #endif
@@ -158,8 +164,8 @@ struct mh_ctx {
   uint32_t* h_progress = nullptr;  // page-locked word behind the state block: (iteration | done << 31), written by the device loop
   uint32_t* d_progress = nullptr;  // ... its device-visible address
   hipGraphExec_t graph_exec = nullptr;  // captured chunk of ICP iterations (replayed while graph_key matches)
-  unsigned long long graph_key[28] = {0};
-  unsigned long long graph_candidate[28] = {0};  // key of the last direct-launched chunk: captured when a LATER alignment repeats it
+  unsigned long long graph_key[32] = {0};
+  unsigned long long graph_candidate[32] = {0};  // key of the last direct-launched chunk: captured when a LATER alignment repeats it
   unsigned long long graph_candidate_align = 0, align_serial = 0;
   uint32_t* h_small = nullptr;  // pinned, device-visible [64]: small results a kernel writes straight to the host (mh_scan_bbox)
   char* h_pp = nullptr;      // page-locked staging of the filter chain: job descriptors up, counters down
@@ -183,6 +189,13 @@ struct mh_map {
   float inv_vs = 1.f;
   mh::DevBuf slots;      // MapSlot[table_size]
   mh::DevBuf pts;        // float4[n_points]
+  // sub-voxel index of the quad matcher (MapView::pts_q / qidx), built lazily by map_ensure_qidx after every (re)build
+  mh::DevBuf pts_q, qidx;
+  std::mutex qidx_mtx;
+  bool qidx_valid = false, qidx_pending = false;
+  hipEvent_t ev_qidx = nullptr;
+  hipStream_t qidx_stream = nullptr;
+  uint32_t* d_counters = nullptr;  // the device counters of the last (re)build ([9] = voxels)
   mh::DevBuf vox_keys;   // uint64[n_voxels], ascending
   mh::DevBuf vox_first;  // uint32[n_voxels]
   mh::DevBuf vox_count;  // uint32[n_voxels]
@@ -210,6 +223,8 @@ struct mh_map {
     v.trunc = params.index_mode == MH_INDEX_TRUNC;
     v.ndt = params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
     v.no_prev_bound = getenv("MH_NO_PREV_BOUND") != nullptr ? 1u : 0u;
+    v.pts_q = qidx_valid ? pts_q.as<float4>() : nullptr;
+    v.qidx = qidx_valid ? qidx.as<uint32_t>() : nullptr;
 #ifdef MH_DEBUG_WAVETRACE
     v.dbg_stop = getenv("MH_DBG_STOP") ? (uint32_t)atoi(getenv("MH_DBG_STOP")) : 0u;
 #endif
@@ -272,4 +287,5 @@ mh_status map_resolve(const mh_map* m);
 mh_status map_resolve_counts(const mh_map* m);
 // make stream `s` wait for a (re)build that may still be running on the map's own context stream (no-op when `s` is that stream)
 mh_status map_ready_on(const mh_map* m, hipStream_t s);
+mh_status map_ensure_qidx(const mh_map* m, hipStream_t s);  // before any kernel that runs nn_search_quad (after map_ready_on)
 }  // namespace mh

@@ -312,6 +312,48 @@ __global__ void k_ndt_stats(float4* __restrict__ pts, const uint32_t* __restrict
   pts[first - 1] = rn;
 }
 
+// Sub-voxel index for the quad matcher (round-4 experiment): a voxel's records re-ordered, stably, by quadrant
+// q = 2 * (x >= mid_x) + (y >= mid_y) of the voxel (mid = (index + 0.5) * voxel size in fp32, the formula the search repeats),
+// w = the record's index in `pts`; the quadrants' boundaries packed into one dword at the voxel's hash slot.  Voxels with
+// more than 31 records keep their order and get no boundaries (bit 31 clear).
+__global__ void k_build_qidx(const float4* __restrict__ pts, const unsigned long long* __restrict__ vox_keys,
+                             const uint32_t* __restrict__ vox_first, const uint32_t* __restrict__ vox_count,
+                             const uint32_t* __restrict__ n_vox_dev, const MapSlot* __restrict__ slots, uint32_t mask, float vs,
+                             uint32_t no_index, float4* __restrict__ pts_q, uint32_t* __restrict__ qidx) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= *n_vox_dev) return;
+  const unsigned long long key = vox_keys[v];
+  const uint32_t first = vox_first[v], cnt = vox_count[v];
+  uint32_t h = hash_key(key) & mask;
+  while (slots[h].key != key) h = (h + 1) & mask;  // (k_table_insert of this build put it there)
+  if (cnt > 31u || no_index) {
+    for (uint32_t j = 0; j < cnt; j++) {
+      const float4 p = pts[first + j];
+      pts_q[first + j] = make_float4(p.x, p.y, p.z, __uint_as_float(first + j));
+    }
+    qidx[h] = 0u;
+    return;
+  }
+  int kx, ky, kz;
+  unpack_key(key, kx, ky, kz);
+  const float midx = ((float)kx + 0.5f) * vs, midy = ((float)ky + 0.5f) * vs;
+  uint32_t n0 = 0, n1 = 0, n2 = 0;
+  for (uint32_t j = 0; j < cnt; j++) {
+    const float4 p = pts[first + j];
+    const uint32_t q = (p.x >= midx ? 2u : 0u) + (p.y >= midy ? 1u : 0u);
+    n0 += q == 0u; n1 += q == 1u; n2 += q == 2u;
+  }
+  uint32_t o0 = 0, o1 = n0, o2 = n0 + n1, o3 = n0 + n1 + n2;
+  qidx[h] = 0x80000000u | (o3 << 10) | (o2 << 5) | o1;
+  for (uint32_t j = 0; j < cnt; j++) {
+    const float4 p = pts[first + j];
+    const uint32_t q = (p.x >= midx ? 2u : 0u) + (p.y >= midy ? 1u : 0u);
+    const uint32_t o = q == 0u ? o0 : (q == 1u ? o1 : (q == 2u ? o2 : o3));
+    o0 += q == 0u; o1 += q == 1u; o2 += q == 2u; o3 += q == 3u;
+    pts_q[first + o] = make_float4(p.x, p.y, p.z, __uint_as_float(first + j));
+  }
+}
+
 __device__ __forceinline__ uint32_t f2ord(float f) {
   const uint32_t u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -468,6 +510,7 @@ mh_status mh_map_destroy(mh_map* m) {
   (void)hipSetDevice(m->ctx->device);
   (void)mh::wait_stream(m->ctx->stream);
   if (m->ev_counts) (void)hipEventDestroy(m->ev_counts);
+  if (m->ev_qidx) (void)hipEventDestroy(m->ev_qidx);
   if (m->h_counts) (void)hipHostFree(m->h_counts);
   for (mh::DevBuf* b : {&m->build_a, &m->build_b, &m->build_c, &m->build_d, &m->build_e, &m->sort_tmp}) b->release();
   m->slots.release();
@@ -476,6 +519,8 @@ mh_status mh_map_destroy(mh_map* m) {
   m->vox_first.release();
   m->vox_count.release();
   m->merge.release();
+  m->pts_q.release();
+  m->qidx.release();
   delete m;
   return MH_OK;
 }
@@ -687,6 +732,39 @@ mh_status map_resolve(const mh_map* m) {
   return map_take_verdict(m, "map update");
 }
 
+// The sub-voxel index of the quad matcher (MapView::pts_q / qidx, k_build_qidx), built on first use after a (re)build, on the
+// stream that is about to search (the caller has ordered that stream behind the map's build: map_ready_on).  Other streams that
+// come later wait for the event; MH_NO_QIDX=1 builds it without boundaries (every voxel scanned whole: the A/B baseline).
+mh_status map_ensure_qidx(const mh_map* mc, hipStream_t s) {
+  mh_map* m = const_cast<mh_map*>(mc);
+  std::lock_guard<std::mutex> lk(m->qidx_mtx);
+  if (m->qidx_valid) {
+    if (m->qidx_pending && s != m->qidx_stream) {
+      if (hipEventQuery(m->ev_qidx) == hipSuccess) m->qidx_pending = false;
+      else MH_HIP(hipStreamWaitEvent(s, m->ev_qidx, 0));
+    }
+    return MH_OK;
+  }
+  if (!m->ev_qidx) MH_HIP(hipEventCreateWithFlags(&m->ev_qidx, hipEventDisableTiming));
+  const size_t tsize = m->table_size ? m->table_size : 1;
+  MH_TRY(m->pts_q.reserve(m->pts.bytes ? m->pts.bytes : sizeof(float4)));
+  MH_TRY(m->qidx.reserve(tsize * sizeof(uint32_t)));
+  MH_HIP(hipMemsetAsync(m->qidx.p, 0, tsize * sizeof(uint32_t), s));
+  if (m->n_voxels && m->d_counters) {
+    const uint32_t no_index = (m->params.index_mode == MH_INDEX_TRUNC || getenv("MH_NO_QIDX") != nullptr) ? 1u : 0u;
+    hipLaunchKernelGGL(k_build_qidx, dim3(nblk(m->n_voxels, 128)), dim3(128), 0, s, m->pts.as<float4>(),
+                       m->vox_keys.as<unsigned long long>(), m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(),
+                       m->d_counters + 9, m->slots.as<MapSlot>(), (uint32_t)(tsize - 1), 1.0f / m->inv_vs, no_index,
+                       m->pts_q.as<float4>(), m->qidx.as<uint32_t>());
+    MH_HIP(hipGetLastError());
+  }
+  MH_HIP(hipEventRecord(m->ev_qidx, s));
+  m->qidx_stream = s;
+  m->qidx_pending = true;
+  m->qidx_valid = true;
+  return MH_OK;
+}
+
 mh_status map_ready_on(const mh_map* m, hipStream_t s) {
   if (!m->build_in_flight) return MH_OK;
   if (hipEventQuery(m->ev_counts) == hipSuccess) {
@@ -849,6 +927,12 @@ mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const floa
     hipLaunchKernelGGL(k_table_insert, dim3(nblk(n_vox_ub, 256)), dim3(256), 0, s, m->vox_keys.as<unsigned long long>(),
                        m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(), counters + 9, m->slots.as<MapSlot>(),
                        (uint32_t)(tsize - 1));
+  }
+  {  // the quad matcher's sub-voxel index follows the records lazily (map_ensure_qidx: only alignments of large layers need it)
+    std::lock_guard<std::mutex> lk(m->qidx_mtx);
+    m->qidx_valid = false;
+    m->qidx_pending = false;
+    m->d_counters = counters;
   }
   MH_HIP(hipGetLastError());
   MH_HIP(hipMemcpyAsync(m->h_counts, counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));  // the one read-back, lazy

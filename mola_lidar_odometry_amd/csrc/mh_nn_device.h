@@ -488,7 +488,8 @@ __device__ __forceinline__ nnkey_t nn_scan_round_quad(gpts_ptr pts4, const uint3
     // (measured: hipcc turns this select into a branch and sinks the load of a lane past the end under it; forcing
     // straight-line code with every load issued -- masks, sched_barrier, inline-asm loads -- was 30-40 % SLOWER on C2:
     // the clamped duplicate loads cost more in the texture-address path than the extra waits do)
-    const nnkey_t k = valid[u] ? (((nnkey_t)__float_as_uint(d2) << 32) | ri[u]) : kNNKeyNone;
+    // (the records come in the sub-voxel index's order, MapView::pts_q: the scan position the tie-break needs rides in w)
+    const nnkey_t k = valid[u] ? (((nnkey_t)__float_as_uint(d2) << 32) | __float_as_uint(c[u].w)) : kNNKeyNone;
 #ifdef MH_CARRY_WINNER
     const bool better = k < mine;
     mine = better ? k : mine;
@@ -597,6 +598,7 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
   const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
   const gslots_ptr slots4 = (gslots_ptr)m.slots;
   const gpts_ptr pts4 = (gpts_ptr)m.pts;
+  const gpts_ptr spts = (gpts_ptr)m.pts_q;  // what the scans read (map_ensure_qidx has run); the winner is fetched from pts
   const float vs = m.vs;
   const Gaps gx = axis_gaps(qx, cx, vs, m.trunc), gy = axis_gaps(qy, cy, vs, m.trunc), gz = axis_gaps(qz, cz, vs, m.trunc);
   const QuadBounds qb = quad_bounds(gx, gy, gz, sub);
@@ -635,7 +637,7 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
 #ifdef MH_DEBUG_WAVETRACE
     if (m.dbg_stop == 2) { r.d2 = (float)(f1[0] + c1[0] + sl_s.z); return r; }  // + own-voxel probe
 #endif
-    best = nn_scan_merged_quad<1>(pts4, f1, c1, sub, qx, qy, qz, best MH_CARRY_PASS);
+    best = nn_scan_merged_quad<1>(spts, f1, c1, sub, qx, qy, qz, best MH_CARRY_PASS);
 #ifdef MH_DEBUG_WAVETRACE
     if (m.dbg_stop == 3) { r.d2 = nnkey_d2(best) + (float)sl_s.z; return r; }  // + own-voxel scan
 #endif
@@ -647,7 +649,7 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
     if (sub == 3 && (c_e == c_fx || c_e == c_fy || c_e == c_fz)) n_s = 0;
     const uint32_t first[4] = {quad_bcast<0>(f_s), quad_bcast<1>(f_s), quad_bcast<2>(f_s), quad_bcast<3>(f_s)};
     const uint32_t cnt[4] = {quad_bcast<0>(n_s), quad_bcast<1>(n_s), quad_bcast<2>(n_s), quad_bcast<3>(n_s)};
-    best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best MH_CARRY_PASS);
+    best = nn_scan_merged_quad<4>(spts, first, cnt, sub, qx, qy, qz, best MH_CARRY_PASS);
     todo &= ~(1u << 13) & ~spec_bits;
   }
   for (int pass = 0; pass < 2; pass++) {
@@ -685,11 +687,39 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
       MH_FLOOR_BATCH(c_mine);
       const unsigned long long key = nn_key_of(kbase, c_mine < 0 ? 0 : c_mine);
       const u32x4 sl = slots4[hash_key(key) & m.mask];  // one probe per lane, four per point in flight
+      // the quadrant boundaries of the probed voxel, requested with the slot (valid when the key sits at its home slot: else
+      // the voxel is scanned whole)
+      const uint32_t qv = ((const uint32_t MH_AS_GLOBAL*)m.qidx)[hash_key(key) & m.mask];
+      const bool at_home = (((unsigned long long)sl.y << 32) | sl.x) == key;
       uint32_t f_mine, n_mine;
       nn_resolve(m, slots4, key, sl, c_mine >= 0, f_mine, n_mine);
+      if (at_home && (qv & 0x80000000u) && n_mine) {
+        // quadrants (x half, y half) of this lane's voxel that can hold a record within the bound: a record of the low x half has
+        // x < mid_x, so it is at least q_x - mid_x away from a query right of the mid plane (and likewise for the others); the
+        // margins and the 0.9999 are the voxel bound's (axis_gaps).  The hull of the needed quadrants is scanned.
+        const int cc = c_mine;
+        const int ix = (cc * 57) >> 9, rr = cc - 9 * ix, iy = (rr * 11) >> 5;
+        // (the own voxel's indices are computed again from opaque copies of the query: kept live from the prologue they cost
+        // the kernel two registers it does not have at eight waves per SIMD)
+        float qx2 = qx, qy2 = qy;
+        asm volatile("" : "+v"(qx2), "+v"(qy2));
+        const int vx = voxel_of(qx2, m.inv_vs, 0) - 1 + ix, vy = voxel_of(qy2, m.inv_vs, 0) - 1 + iy;
+        const float ex = qx - ((float)vx + 0.5f) * vs, ey = qy - ((float)vy + 0.5f) * vs;
+        const float bd = nnkey_d2(best);
+        const float ax_ = fmaxf(0.f, fabsf(ex) - 1.0e-6f * (fabsf((float)vx) + 2.f) * vs);
+        const float ay_ = fmaxf(0.f, fabsf(ey) - 1.0e-6f * (fabsf((float)vy) + 2.f) * vs);
+        const bool farx = ax_ * ax_ * 0.9999f > bd, fary = ay_ * ay_ * 0.9999f > bd;
+        const bool no_xlo = farx && ex > 0.f, no_xhi = farx && ex < 0.f, no_ylo = fary && ey > 0.f, no_yhi = fary && ey < 0.f;
+        const uint32_t lo_q = (no_xlo ? 2u : 0u) + (no_ylo ? 1u : 0u);   // first needed quadrant (2 * xhalf + yhalf)
+        const uint32_t hi_q = (no_xhi ? 0u : 2u) + (no_yhi ? 0u : 1u);   // last needed quadrant
+        const uint32_t b_lo = lo_q == 0u ? 0u : ((qv >> (5u * (lo_q - 1u))) & 31u);
+        const uint32_t b_hi = hi_q == 3u ? n_mine : ((qv >> (5u * hi_q)) & 31u);
+        f_mine += b_lo;
+        n_mine = b_hi - b_lo;
+      }
       const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
       const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
-      best = nn_scan_merged_quad<4>(pts4, first, cnt, sub, qx, qy, qz, best MH_CARRY_PASS);
+      best = nn_scan_merged_quad<4>(spts, first, cnt, sub, qx, qy, qz, best MH_CARRY_PASS);
       if (cand) cand &= quad_bound_mask(qb, sub, nnkey_d2(best)) | (1u << 13);
     }
     if (!bounded || nnkey_idx(best) != 0xFFFFFFFFu) break;

@@ -962,6 +962,47 @@ def test_previous_pairing_bound_and_its_fallback(ctx, oracle, vs, shift, monkeyp
         np.testing.assert_allclose(g["T"], o["T"], rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("vs,cap,mode,lattice", [(1.0, 20, 0, False), (0.5, 31, 0, True), (1.0, 48, 0, False), (1.0, 20, 1, False),
+                                                 (0.7, 8, 0, True)])
+def test_quad_matcher_sub_voxel_index(ctx, oracle, vs, cap, mode, lattice, monkeypatch):
+    """The quad matcher scans a voxel's records in the order of its sub-voxel index (MapView::pts_q: stably re-ordered by
+    (x half, y half) of the voxel, the scan position in w) and, under a bound, only the hull of the quadrants that can hold a
+    record within it (qidx: the quadrants' boundaries at the voxel's hash slot, built lazily after every rebuild).  Voxels with
+    more than 31 records and trunc-indexed maps have no boundaries; MH_NO_QIDX=1 gives none to anybody.  Per-iteration pair
+    counts, final pairings and d2 are the oracle's bit for bit -- on a lattice map (exact ties inside and across quadrants,
+    records ON the mid planes), with the index and without, before and after a key-frame insertion rebuilds the records."""
+    rng = np.random.default_rng(int(vs * 10) + cap + mode)
+    scene = synth.make_scene(4711, 60.0, 20)
+    mp = synth.make_map(scene, 120000, 4711)
+    if lattice:
+        mp = (np.round(mp / np.float32(vs / 4)) * np.float32(vs / 4)).astype(np.float32)  # quarter-voxel lattice: mid planes hit
+    pose = [0.7, -0.4, synth.SENSOR_H, 0.03, 0.002, -0.002]
+    scan = synth.make_scan(scene, pose, rings=64, azimuths=700, seed=5)
+    scan = scan[rng.permutation(len(scan))[:36000]]   # above the row matcher's layer size: the quad matcher by default
+    guess = synth.pose_from_ypr(np.array(pose) + [0.25, -0.15, 0.02, 0.01, 0.002, 0.001])
+    thr, kp = synth.threshold_schedule(2.0, 12)
+    kw = dict(max_iterations=12, threshold=thr, kernel_param=kp, disable_stall_test=True)
+    om = oracle.Map(vs, cap, mode).insert(mp)
+    extra = synth.make_scan(scene, [3.0, 1.0, synth.SENSOR_H, 0.2, 0.0, 0.0], rings=32, azimuths=400, seed=8)
+    I = np.eye(4)[:3]
+    gs = capi.Scan(ctx, scan)
+    refs = [oracle.icp_align(om, scan, guess, oracle.ICPParams(**kw), want_pairs=True)]
+    om.insert_posed(extra, I, 1000.0)
+    refs.append(oracle.icp_align(om, scan, guess, oracle.ICPParams(**kw), want_pairs=True))
+    for no_index in (False, True):
+        if no_index:
+            monkeypatch.setenv("MH_NO_QIDX", "1")
+        gm = capi.Map(ctx, vs, cap, mode).build(mp)
+        for step, o in enumerate(refs):
+            if step == 1:
+                gm.insert(capi.Scan(ctx, extra), I, 1000.0)
+            g = capi.icp_align(gm, gs, guess, capi.ICPParams(**kw), want_pairs=True)
+            assert [t["n_pairs"] for t in g["trace"]] == [t["n_pairs"] for t in o["trace"]]
+            for k in ("local_idx", "global_idx", "d2", "global_xyz"):
+                np.testing.assert_array_equal(g["pairs"][k], o["pairs"][k])
+            np.testing.assert_allclose(g["T"], o["T"], rtol=0, atol=1e-9)
+
+
 @pytest.mark.parametrize("n_scan,env", [(900, {}), (3000, {}), (3000, {"MH_NO_FUSE16": "1"}), (3000, {"MH_MATCH": "p"}),
                                         (9000, {}), (20000, {})])
 def test_converged_alignment_with_early_inner_exit(ctx, oracle, n_scan, env, monkeypatch):
