@@ -902,7 +902,10 @@ def main():
                     "note": "k_match_floor_b: the same grid, occupancy, dependent chain of loads and address generation as k_match4_b "
                             "replayed from a recorded script with one compare per record instead of the search arithmetic; launched back "
                             "to back on resident inputs.  frac_of_floor = floor / real: ~1 means the kernel costs what its memory-access "
-                            "schedule costs -- less arithmetic would not make it faster, only a different schedule would"}
+                            "schedule costs -- less arithmetic would not make it faster, only a different schedule would.  The replay is of "
+                            "the WHOLE-VOXEL schedule (every probed voxel scanned from its first record to its last): the product kernel "
+                            "has since changed the schedule -- the sub-voxel index scans only the quadrants of a voxel that can hold a "
+                            "record within the bound -- which is why it now runs faster than this floor (MH_NO_QIDX=1: the old schedule)"}
                 roof["frac_of_floor"] = fj["floor_ms_mean"] / launch_ms if launch_ms else None
             roof["views"] = views
         out["roofline"] = roof

@@ -1807,7 +1807,8 @@ struct FloorHost {
 
 // what-if switches of the replay (tools/match_floor.py --what-if): which load costs what?
 enum { FLOOR_NO_WINNER_FETCH = 1, FLOOR_NO_PREV = 2, FLOOR_NO_TRANSFORM = 4, FLOOR_NO_OUTPUT = 8, FLOOR_RECORDS_12B = 16, FLOOR_HALF_RECORDS = 32,
-       FLOOR_NARROW_IO = 64 /* the -DMH_NARROW_IO schedule: previous pairing / winner / pairing a dword per lane instead of 16 bytes */ };
+       FLOOR_NARROW_IO = 64 /* the -DMH_NARROW_IO schedule: previous pairing / winner / pairing a dword per lane instead of 16 bytes */,
+       FLOOR_NO_QIDX = 128 /* whole voxels: the schedule before the sub-voxel index */ };
 
 __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_floor_b(const BatchJob* __restrict__ jobs, uint32_t flags) {
   const BatchJob& j = jobs[blockIdx.y];
@@ -1846,6 +1847,16 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_floor_b(const B
   uint32_t acc = 0xFFFFFFF0u;
   const gslots_ptr slots4 = (gslots_ptr)m.slots;
   const gpts_ptr pts4 = (gpts_ptr)m.pts;
+  // the sub-voxel index as the product kernel uses it: ranges narrowed under the bound the previous pairing gives (address
+  // generation: eight operations).  Later batches keep that bound where the real search has a tighter one by then, so the
+  // replay reads at least what the search read.
+  const bool useq = m.qidx != nullptr && !(flags & FLOOR_NO_QIDX);
+  const gpts_ptr spts = useq ? (gpts_ptr)m.pts_q : pts4;
+  float bound0 = __builtin_inff();
+  if (!(flags & FLOOR_NO_PREV)) {
+    const float dx = prev.x - px, dy = prev.y - py, dz = prev.z - pz;
+    bound0 = (dx * dx + dy * dy) + dz * dz;
+  }
   for (uint32_t b = 0; b < nb; b++) {
     uint32_t c_mine;
     if (b == 0) {
@@ -1857,8 +1868,11 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_floor_b(const B
     const bool want = c_mine != 63u;
     const unsigned long long key = nn_key_of(kbase, want ? (int)c_mine : 0) + (acc == 0xFFFFFFFEu);  // (the next probe waits for the scan)
     const u32x4 sl = slots4[hash_key(key) & m.mask];
+    const uint32_t qv = useq ? ((const uint32_t MH_AS_GLOBAL*)m.qidx)[hash_key(key) & m.mask] : 0u;
+    const bool at_home = (((unsigned long long)sl.y << 32) | sl.x) == key;
     uint32_t f_mine, n_mine;
     nn_resolve(m, slots4, key, sl, want, f_mine, n_mine);
+    if (useq && at_home && want) quad_narrow(m, qv, (int)c_mine, px, py, bound0, f_mine, n_mine);
     if (flags & FLOOR_HALF_RECORDS) n_mine = (n_mine + 1u) >> 1;
     const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
     const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
@@ -1883,10 +1897,10 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_floor_b(const B
         for (int v = 1; v < 4; v++) off = t >= pre[v] ? start[v] : off;
         if (flags & FLOOR_RECORDS_12B) {  // what a 12-byte read of the record would cost (same lines, narrower instruction)
           typedef float f32x3 __attribute__((ext_vector_type(3)));
-          const f32x3 c3 = *reinterpret_cast<const f32x3 MH_AS_GLOBAL*>(pts4 + (t + off));
+          const f32x3 c3 = *reinterpret_cast<const f32x3 MH_AS_GLOBAL*>(spts + (t + off));
           c[u] = (f32x4){c3.x, c3.y, c3.z, 0.f};
         } else {
-          c[u] = pts4[t + off];
+          c[u] = spts[t + off];
         }
       }
 #pragma unroll

@@ -582,6 +582,34 @@ __device__ __forceinline__ uint32_t quad_bound_mask(const QuadBounds& q, uint32_
 // 4370-4540 scans/s against 4590-4620; the replay kernel says the same, 0.2735 against 0.2605 ms) -- what those accesses
 // cost is their place in the dependent chain (the first thing a wave waits for, the last thing it has to retire), not their
 // width, and the narrow form adds quad_perm moves and 24 bytes of scratch.  profiles/r04_match_kernel.md.
+// The sub-voxel index at work: the range [f, f + n) of a probed voxel's records (in pts_q order) narrowed to the hull of the
+// quadrants (x half, y half) that can hold a record within the bound `bd` of query (qx, qy).  A record of the low x half has
+// x < mid_x, so it is at least q_x - mid_x away from a query right of the mid plane (and likewise for the others); the margins
+// and the 0.9999 are the voxel bound's (axis_gaps).  qv: the voxel's packed boundaries (bit 31: it has any); code: the voxel's
+// place in the 27-voxel block (-1: none).  Also what tools/match_floor.py's replay kernel does, with the same arguments.
+__device__ __forceinline__ void quad_narrow(const MapView& m, uint32_t qv, int code, float qx, float qy, float bd, uint32_t& f,
+                                            uint32_t& n) {
+  if (!(qv & 0x80000000u) || n == 0u) return;
+  const int ix = (code * 57) >> 9, rr = code - 9 * ix, iy = (rr * 11) >> 5;
+  // (the own voxel's indices are computed again from opaque copies of the query: kept live from the prologue they cost
+  // the kernel two registers it does not have at eight waves per SIMD)
+  float qx2 = qx, qy2 = qy;
+  asm volatile("" : "+v"(qx2), "+v"(qy2));
+  const int vx = voxel_of(qx2, m.inv_vs, 0) - 1 + ix, vy = voxel_of(qy2, m.inv_vs, 0) - 1 + iy;
+  const float vs = m.vs;
+  const float ex = qx - ((float)vx + 0.5f) * vs, ey = qy - ((float)vy + 0.5f) * vs;
+  const float ax_ = fmaxf(0.f, fabsf(ex) - 1.0e-6f * (fabsf((float)vx) + 2.f) * vs);
+  const float ay_ = fmaxf(0.f, fabsf(ey) - 1.0e-6f * (fabsf((float)vy) + 2.f) * vs);
+  const bool farx = ax_ * ax_ * 0.9999f > bd, fary = ay_ * ay_ * 0.9999f > bd;
+  const bool no_xlo = farx && ex > 0.f, no_xhi = farx && ex < 0.f, no_ylo = fary && ey > 0.f, no_yhi = fary && ey < 0.f;
+  const uint32_t lo_q = (no_xlo ? 2u : 0u) + (no_ylo ? 1u : 0u);   // first needed quadrant (2 * xhalf + yhalf)
+  const uint32_t hi_q = (no_xhi ? 0u : 2u) + (no_yhi ? 0u : 1u);   // last needed quadrant
+  const uint32_t b_lo = lo_q == 0u ? 0u : ((qv >> (5u * (lo_q - 1u))) & 31u);
+  const uint32_t b_hi = hi_q == 3u ? n : ((qv >> (5u * hi_q)) & 31u);
+  f += b_lo;
+  n = b_hi - b_lo;
+}
+
 template <bool NARROW = false>
 __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t sub, float qx, float qy, float qz,
                                                    float bound0 = __builtin_inff() MH_FLOOR_ARG) {
@@ -693,30 +721,7 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
       const bool at_home = (((unsigned long long)sl.y << 32) | sl.x) == key;
       uint32_t f_mine, n_mine;
       nn_resolve(m, slots4, key, sl, c_mine >= 0, f_mine, n_mine);
-      if (at_home && (qv & 0x80000000u) && n_mine) {
-        // quadrants (x half, y half) of this lane's voxel that can hold a record within the bound: a record of the low x half has
-        // x < mid_x, so it is at least q_x - mid_x away from a query right of the mid plane (and likewise for the others); the
-        // margins and the 0.9999 are the voxel bound's (axis_gaps).  The hull of the needed quadrants is scanned.
-        const int cc = c_mine;
-        const int ix = (cc * 57) >> 9, rr = cc - 9 * ix, iy = (rr * 11) >> 5;
-        // (the own voxel's indices are computed again from opaque copies of the query: kept live from the prologue they cost
-        // the kernel two registers it does not have at eight waves per SIMD)
-        float qx2 = qx, qy2 = qy;
-        asm volatile("" : "+v"(qx2), "+v"(qy2));
-        const int vx = voxel_of(qx2, m.inv_vs, 0) - 1 + ix, vy = voxel_of(qy2, m.inv_vs, 0) - 1 + iy;
-        const float ex = qx - ((float)vx + 0.5f) * vs, ey = qy - ((float)vy + 0.5f) * vs;
-        const float bd = nnkey_d2(best);
-        const float ax_ = fmaxf(0.f, fabsf(ex) - 1.0e-6f * (fabsf((float)vx) + 2.f) * vs);
-        const float ay_ = fmaxf(0.f, fabsf(ey) - 1.0e-6f * (fabsf((float)vy) + 2.f) * vs);
-        const bool farx = ax_ * ax_ * 0.9999f > bd, fary = ay_ * ay_ * 0.9999f > bd;
-        const bool no_xlo = farx && ex > 0.f, no_xhi = farx && ex < 0.f, no_ylo = fary && ey > 0.f, no_yhi = fary && ey < 0.f;
-        const uint32_t lo_q = (no_xlo ? 2u : 0u) + (no_ylo ? 1u : 0u);   // first needed quadrant (2 * xhalf + yhalf)
-        const uint32_t hi_q = (no_xhi ? 0u : 2u) + (no_yhi ? 0u : 1u);   // last needed quadrant
-        const uint32_t b_lo = lo_q == 0u ? 0u : ((qv >> (5u * (lo_q - 1u))) & 31u);
-        const uint32_t b_hi = hi_q == 3u ? n_mine : ((qv >> (5u * hi_q)) & 31u);
-        f_mine += b_lo;
-        n_mine = b_hi - b_lo;
-      }
+      if (at_home) quad_narrow(m, qv, c_mine, qx, qy, nnkey_d2(best), f_mine, n_mine);
       const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
       const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
       best = nn_scan_merged_quad<4>(spts, first, cnt, sub, qx, qy, qz, best MH_CARRY_PASS);

@@ -22,6 +22,8 @@ import sys; sys.path.insert(0, '$REPO')
 from mola_lidar_odometry_amd import synth_city
 print(synth_city.write_kitti_drive('$OUT/city', 200, time_channel=True)[0])" > $OUT/${TAG}_city_dir.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/odom -o ${TAG}_odom -- $REPO/mola_lidar_odometry_amd/molahip-lo-cli --pipeline $REPO/pipelines/lidar3d-default-hip.yaml --seq-dir $(cat $OUT/${TAG}_city_dir.txt) --time-field 12 --profile --out $OUT/${TAG}_odom.tum > $OUT/${TAG}_odom_stdout.log 2>&1
+# ... and the NDT pipeline on the same scans (config-5 proxy)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/odom_ndt -o ${TAG}_odom_ndt -- $REPO/mola_lidar_odometry_amd/molahip-lo-cli --pipeline $REPO/pipelines/lidar3d-ndt-hip.yaml --seq-dir $(cat $OUT/${TAG}_city_dir.txt) --time-field 12 --profile --out $OUT/${TAG}_odom_ndt.tum > $OUT/${TAG}_odom_ndt_stdout.log 2>&1
 rm -rf $OUT/city
 fi
 i=0

@@ -35,7 +35,8 @@ import bench  # noqa: E402  (generate_inputs: the headline workload's 32 draws)
 # (a "no transform" switch exists in the kernel but is no what-if: un-transformed points probe other, mostly empty voxels)
 WHAT_IF = {"as_is": 0, "no_winner_fetch": 1, "no_previous_pairing_read": 2, "no_pairing_write": 8, "records_read_as_12_bytes": 16,
            "half_the_records": 32, "narrow_io_dword_per_lane": 64, "narrow_io_no_previous_pairing_read": 64 | 2,
-           "narrow_io_no_pairing_write": 64 | 8, "narrow_io_no_winner_fetch": 64 | 1}
+           "narrow_io_no_pairing_write": 64 | 8, "narrow_io_no_winner_fetch": 64 | 1,
+           "whole_voxels_no_sub_voxel_index": 128}  # the schedule before the sub-voxel index (profiles/r04_match_kernel.md, section 5)
 
 
 def setup(S, ws):
@@ -135,7 +136,9 @@ def main():
     out["note"] = ("frac_of_floor = mean floor / the product kernel's launch average under the same conditions: the share of k_match4_b's "
                    "time that its memory-access schedule and address generation alone account for.  The floor is optimistic by "
                    "construction (launched back to back: warmer caches than between the accumulate / solve launches of a real iteration; "
-                   "iteration 0's un-bounded search is not replayed) and pessimistic in one respect: it reads 8 bytes of script per point.")
+                   "iteration 0's un-bounded search is not replayed) and pessimistic in two respects: it reads 8 bytes of script per point, "
+                   "and it narrows every batch's record ranges (the sub-voxel index) under the bound the previous pairing gives, where the "
+                   "real search has a tighter bound from its second batch on.")
     with open(args.out, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: out[k] for k in ("floor_ms_mean", "real_ms_avg_over_launches_product_library", "frac_of_floor")}))
