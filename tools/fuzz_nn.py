@@ -1,4 +1,4 @@
-"""development aid: the matcher-granular search (mh_nn_search_dense) of every kernel family -- one lane per point (p, x),
+"""development aid: the matcher-granular search (mh_nn_search_dense; mh_nn_search_k for pairingsPerPoint > 1) of every kernel family -- one lane per point (p, x),
 quad, row, LDS tiles (t), wave-uniform candidates (w, with and without LDS staging) -- on random adversarial inputs against
 the oracle's exhaustive 27-voxel scan: lattice-aligned maps and queries (exact ties across voxels), queries on voxel faces,
 large coordinate offsets, awkward voxel sizes, caps, trunc indexing, ragged sizes.  Indices, d2 and records bit for bit."""
@@ -56,6 +56,15 @@ for case in range(n_cases):
               np.array_equal(d["d2"][found], o["d2"]) and np.array_equal(d["global_xyz"][found], o["global_xyz"]))
         if not ok:
             fails.append(match + ("+lds" if extra else ""))
+    # Matcher_Points_DistanceThreshold with pairingsPerPoint = k (mh_nn_search_k) against the oracle's k-best restatement
+    kk = int(rng.choice([2, 3, 5, 8]))
+    thr_k = float(rng.choice([1e9, 0.4 * vs, 1.5 * vs]))
+    ang_k = float(rng.choice([0.0, 0.0, 1.0]))
+    ok_ = oracle_c.match_points_k(om, q, T, thr_k, kk, ang_k)
+    os.environ["MH_MATCH"] = "q"
+    dk = capi.nn_search_k(capi.Map(ctx, vs, cap, mode).build(pts), capi.Scan(ctx, q), T, thr_k, kk, ang_k)
+    if not all(np.array_equal(dk[key], ok_[key]) for key in ("local_idx", "global_idx", "d2", "global_xyz")):
+        fails.append("k%d" % kk)
     bad += 1 if fails else 0
     print("case %3d vs=%.2f cap=%2d mode=%d offset=%g step=%.3f map=%d queries=%d found=%d -> %s" % (
         case, vs, cap, mode, offset, step, len(pts), len(q), len(o["local_idx"]), "ok" if not fails else "MISMATCH " + ",".join(fails)), flush=True)
