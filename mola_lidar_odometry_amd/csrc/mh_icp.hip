@@ -510,7 +510,10 @@ constexpr uint32_t kRowMaxPoints = 32768;  // measured cross-over with the quad 
 // ================================================================================================
 // k_accum: point-to-point accumulation on stored pairings (inner GN steps, solver-granular path)
 // ================================================================================================
-constexpr uint32_t kAccPPT = 4;  // scan points per lane of k_accum
+#ifndef MH_ACC_PPT
+#define MH_ACC_PPT 4
+#endif
+constexpr uint32_t kAccPPT = MH_ACC_PPT;  // scan points per lane of k_accum (tools/build_variants.sh: 2 and 8 measured)
 inline uint32_t nblk_acc(size_t n) { return (uint32_t)((n + (size_t)kBlock * kAccPPT - 1) / ((size_t)kBlock * kAccPPT)); }
 
 __device__ __forceinline__ void k_accum_body(const IcpDeviceState* __restrict__ st, uint32_t first,
