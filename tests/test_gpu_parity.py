@@ -1003,6 +1003,43 @@ def test_quad_matcher_sub_voxel_index(ctx, oracle, vs, cap, mode, lattice, monke
             np.testing.assert_allclose(g["T"], o["T"], rtol=0, atol=1e-9)
 
 
+def test_sub_voxel_index_built_once_for_concurrent_searchers(oracle):
+    """map_ensure_qidx builds the quad matcher's index on first use, on the stream of whoever asks first; alignments on OTHER
+    contexts' streams -- here four host threads, a context and a scan each, one shared map, all starting at once on a map
+    whose index does not exist yet -- order themselves behind that build.  Every thread's result is the serial one, bit for
+    bit, and the oracle's pairing counts."""
+    import threading
+    scene = synth.make_scene(99, 60.0, 20)
+    mp = synth.make_map(scene, 150000, 99)
+    poses = [[0.5 * k, -0.3 * k, synth.SENSOR_H, 0.02 * k, 0.001, -0.002] for k in range(4)]
+    scans = [synth.make_scan(scene, p, rings=64, azimuths=640, seed=40 + k)[:35000] for k, p in enumerate(poses)]
+    guesses = [synth.pose_from_ypr(np.array(p) + [0.2, -0.1, 0.01, 0.008, 0.001, 0.001]) for p in poses]
+    thr, kp = synth.threshold_schedule(2.0, 8)
+    kw = dict(max_iterations=8, threshold=thr, kernel_param=kp, disable_stall_test=True)
+    map_ctx = capi.Context(0)
+    ctxs = [capi.Context(0) for _ in scans]
+    gs = [capi.Scan(c, s) for c, s in zip(ctxs, scans)]
+    for rnd in range(3):
+        gm = capi.Map(map_ctx, 1.0, 20).build(mp)       # a fresh map: no index yet
+        out = [None] * len(scans)
+
+        def work(k):
+            out[k] = capi.icp_align(gm, gs[k], guesses[k], capi.ICPParams(**kw), want_pairs=True)
+
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(len(scans))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        for k in range(len(scans)):
+            ref = capi.icp_align(gm, gs[k], guesses[k], capi.ICPParams(**kw), want_pairs=True)  # serial, index in place
+            assert out[k]["T"].tobytes() == ref["T"].tobytes()
+            for key in ("local_idx", "global_idx", "d2"):
+                np.testing.assert_array_equal(out[k]["pairs"][key], ref["pairs"][key])
+            if rnd == 0:
+                o = oracle.icp_align(oracle.Map(1.0, 20).insert(mp), scans[k], guesses[k], oracle.ICPParams(**kw), want_pairs=True)
+                assert [t["n_pairs"] for t in ref["trace"]] == [t["n_pairs"] for t in o["trace"]]
+                np.testing.assert_array_equal(ref["pairs"]["global_idx"], o["pairs"]["global_idx"])
+
+
 @pytest.mark.parametrize("n_scan,env", [(900, {}), (3000, {}), (3000, {"MH_NO_FUSE16": "1"}), (3000, {"MH_MATCH": "p"}),
                                         (9000, {}), (20000, {})])
 def test_converged_alignment_with_early_inner_exit(ctx, oracle, n_scan, env, monkeypatch):
