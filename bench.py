@@ -907,6 +907,12 @@ def main():
                             "has since changed the schedule -- the sub-voxel index scans only the quadrants of a voxel that can hold a "
                             "record within the bound -- which is why it now runs faster than this floor (MH_NO_QIDX=1: the old schedule)"}
                 roof["frac_of_floor"] = fj["floor_ms_mean"] / launch_ms if launch_ms else None
+                fq = os.path.join(ROOT, "profiles", "r04_match_floor_qidx.json")
+                if os.path.exists(fq):  # the replay taught the narrowed ranges of the sub-voxel index (its iteration-19 figure)
+                    fqj = json.load(open(fq))
+                    last = sorted(fqj["per_iteration"].items(), key=lambda kv: int(kv[0]))[-1][1]
+                    views["latency_floor"]["replay_of_the_narrowed_schedule_ms"] = last["floor_ms"]
+                    views["latency_floor"]["product_kernel_ms_in_that_run"] = fqj["real_ms_avg_over_launches_product_library"]
             roof["views"] = views
         out["roofline"] = roof
         out["cpu_baseline"] = cpu
