@@ -1853,7 +1853,7 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_floor_b(const B
   // the sub-voxel index as the product kernel uses it: ranges narrowed under the bound the previous pairing gives (address
   // generation: eight operations).  Later batches keep that bound where the real search has a tighter one by then, so the
   // replay reads at least what the search read.
-  const bool useq = m.qidx != nullptr && !(flags & FLOOR_NO_QIDX);
+  const bool useq = m.pts_q != nullptr && !(flags & FLOOR_NO_QIDX);
   const gpts_ptr spts = useq ? (gpts_ptr)m.pts_q : pts4;
   float bound0 = __builtin_inff();
   if (!(flags & FLOOR_NO_PREV)) {
@@ -1871,7 +1871,7 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_floor_b(const B
     const bool want = c_mine != 63u;
     const unsigned long long key = nn_key_of(kbase, want ? (int)c_mine : 0) + (acc == 0xFFFFFFFEu);  // (the next probe waits for the scan)
     const u32x4 sl = slots4[hash_key(key) & m.mask];
-    const uint32_t qv = useq ? ((const uint32_t MH_AS_GLOBAL*)m.qidx)[hash_key(key) & m.mask] : 0u;
+    const uint32_t qv = sl.w;
     const bool at_home = (((unsigned long long)sl.y << 32) | sl.x) == key;
     uint32_t f_mine, n_mine;
     nn_resolve(m, slots4, key, sl, want, f_mine, n_mine);
@@ -2951,7 +2951,7 @@ struct AlignJob {
                                        (unsigned long long)(pl ? ctx->partials_b.p : nullptr),
                                        variant >= 6 ? (unsigned long long)scan->sx : 0ull,
                                        variant >= 6 ? (unsigned long long)scan->n_tiles : 0ull,
-                                       (unsigned long long)mv.pts_q, (unsigned long long)mv.qidx};  // (a word each: no XOR folding)
+                                       (unsigned long long)mv.pts_q};  // (a word each: no XOR folding)
       static_assert(sizeof(kv) <= sizeof(key), "graph key too small");
       memcpy(key, kv, sizeof(kv));
       const bool cached = ctx->graph_exec && memcmp(key, ctx->graph_key, sizeof(key)) == 0;

@@ -105,9 +105,8 @@ struct MapView {
   uint32_t no_prev_bound;  // A/B switch (MH_NO_PREV_BOUND=1): the quad matcher ignores the previous iteration's pairing
   // sub-voxel index of the quad matcher (round 4; valid after map_ensure_qidx, null before): pts_q = the records of every voxel
   // re-ordered by (x half, y half) of the voxel, w = the record's index in `pts` (the reference's scan position: the
-  // tie-break); qidx[slot] = bit 31 | b3 << 10 | b2 << 5 | b1, the quadrants' boundaries (0: scan the voxel whole)
+  // tie-break); the quadrants' boundaries ride in the count word of the voxel's hash slot (slot_count(), mh_nn_device.h)
   const float4* pts_q;
-  const uint32_t* qidx;
 #ifdef MH_DEBUG_WAVETRACE
   uint32_t dbg_stop;  // debug build: leave the quad search after phase N (tools/wavetrace_probe.py)
 #endif
@@ -189,8 +188,8 @@ struct mh_map {
   float inv_vs = 1.f;
   mh::DevBuf slots;      // MapSlot[table_size]
   mh::DevBuf pts;        // float4[n_points]
-  // sub-voxel index of the quad matcher (MapView::pts_q / qidx), built lazily by map_ensure_qidx after every (re)build
-  mh::DevBuf pts_q, qidx;
+  // sub-voxel index of the quad matcher (MapView::pts_q + the boundaries in the slots' count words), built lazily by map_ensure_qidx after every (re)build
+  mh::DevBuf pts_q;
   std::mutex qidx_mtx;
   bool qidx_valid = false, qidx_pending = false;
   hipEvent_t ev_qidx = nullptr;
@@ -224,7 +223,6 @@ struct mh_map {
     v.ndt = params.ndt_max_eigen_ratio > 0.f ? 1u : 0u;
     v.no_prev_bound = getenv("MH_NO_PREV_BOUND") != nullptr ? 1u : 0u;
     v.pts_q = qidx_valid ? pts_q.as<float4>() : nullptr;
-    v.qidx = qidx_valid ? qidx.as<uint32_t>() : nullptr;
 #ifdef MH_DEBUG_WAVETRACE
     v.dbg_stop = getenv("MH_DBG_STOP") ? (uint32_t)atoi(getenv("MH_DBG_STOP")) : 0u;
 #endif

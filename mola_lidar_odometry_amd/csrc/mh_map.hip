@@ -318,8 +318,8 @@ __global__ void k_ndt_stats(float4* __restrict__ pts, const uint32_t* __restrict
 // more than 31 records keep their order and get no boundaries (bit 31 clear).
 __global__ void k_build_qidx(const float4* __restrict__ pts, const unsigned long long* __restrict__ vox_keys,
                              const uint32_t* __restrict__ vox_first, const uint32_t* __restrict__ vox_count,
-                             const uint32_t* __restrict__ n_vox_dev, const MapSlot* __restrict__ slots, uint32_t mask, float vs,
-                             uint32_t no_index, float4* __restrict__ pts_q, uint32_t* __restrict__ qidx) {
+                             const uint32_t* __restrict__ n_vox_dev, MapSlot* __restrict__ slots, uint32_t mask, float vs,
+                             uint32_t no_index, float4* __restrict__ pts_q) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= *n_vox_dev) return;
   const unsigned long long key = vox_keys[v];
@@ -331,8 +331,7 @@ __global__ void k_build_qidx(const float4* __restrict__ pts, const unsigned long
       const float4 p = pts[first + j];
       pts_q[first + j] = make_float4(p.x, p.y, p.z, __uint_as_float(first + j));
     }
-    qidx[h] = 0u;
-    return;
+    return;  // (the slot keeps its plain count: scanned whole)
   }
   int kx, ky, kz;
   unpack_key(key, kx, ky, kz);
@@ -344,7 +343,7 @@ __global__ void k_build_qidx(const float4* __restrict__ pts, const unsigned long
     n0 += q == 0u; n1 += q == 1u; n2 += q == 2u;
   }
   uint32_t o0 = 0, o1 = n0, o2 = n0 + n1, o3 = n0 + n1 + n2;
-  qidx[h] = 0x80000000u | (o3 << 10) | (o2 << 5) | o1;
+  slots[h].count = 0x80000000u | (o3 << 18) | (o2 << 13) | (o1 << 8) | cnt;  // (slot_count() in mh_nn_device.h reads it back)
   for (uint32_t j = 0; j < cnt; j++) {
     const float4 p = pts[first + j];
     const uint32_t q = (p.x >= midx ? 2u : 0u) + (p.y >= midy ? 1u : 0u);
@@ -520,7 +519,6 @@ mh_status mh_map_destroy(mh_map* m) {
   m->vox_count.release();
   m->merge.release();
   m->pts_q.release();
-  m->qidx.release();
   delete m;
   return MH_OK;
 }
@@ -748,14 +746,12 @@ mh_status map_ensure_qidx(const mh_map* mc, hipStream_t s) {
   if (!m->ev_qidx) MH_HIP(hipEventCreateWithFlags(&m->ev_qidx, hipEventDisableTiming));
   const size_t tsize = m->table_size ? m->table_size : 1;
   MH_TRY(m->pts_q.reserve(m->pts.bytes ? m->pts.bytes : sizeof(float4)));
-  MH_TRY(m->qidx.reserve(tsize * sizeof(uint32_t)));
-  MH_HIP(hipMemsetAsync(m->qidx.p, 0, tsize * sizeof(uint32_t), s));
   if (m->n_voxels && m->d_counters) {
     const uint32_t no_index = (m->params.index_mode == MH_INDEX_TRUNC || getenv("MH_NO_QIDX") != nullptr) ? 1u : 0u;
     hipLaunchKernelGGL(k_build_qidx, dim3(nblk(m->n_voxels, 128)), dim3(128), 0, s, m->pts.as<float4>(),
                        m->vox_keys.as<unsigned long long>(), m->vox_first.as<uint32_t>(), m->vox_count.as<uint32_t>(),
                        m->d_counters + 9, m->slots.as<MapSlot>(), (uint32_t)(tsize - 1), 1.0f / m->inv_vs, no_index,
-                       m->pts_q.as<float4>(), m->qidx.as<uint32_t>());
+                       m->pts_q.as<float4>());
     MH_HIP(hipGetLastError());
   }
   MH_HIP(hipEventRecord(m->ev_qidx, s));

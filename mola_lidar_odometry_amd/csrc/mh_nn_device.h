@@ -43,6 +43,11 @@ __device__ __forceinline__ int voxel_of(float c, float inv_vs, uint32_t trunc) {
   return trunc ? (int)s : (int)floorf(s);
 }
 
+// The count word of a hash slot.  Voxels that carry a sub-voxel index (k_build_qidx: at most 31 records) keep the quadrants'
+// boundaries in the same word -- bit 31 | b3 << 18 | b2 << 13 | b1 << 8 | count -- so that the probe that finds a voxel also
+// brings what narrows its scan; everybody else reads the count through this.
+__device__ __forceinline__ uint32_t slot_count(uint32_t w) { return (w & 0x80000000u) ? (w & 0xFFu) : w; }
+
 struct NNResult {
   f32x4 pt;   // nearest map point {x,y,z,src}
   float d2;
@@ -105,7 +110,7 @@ __device__ __forceinline__ NNResult nn_single_search(const MapView& m, float qx,
       }
       if (sk == key) {
         if (cnt == 0) first = sl.z;
-        cnt += sl.w;
+        cnt += slot_count(sl.w);
       }
     }
     first9[col] = first;
@@ -245,7 +250,7 @@ __device__ __forceinline__ void nn_visit(const MapView& m, gslots_ptr slots4, gp
       sk = ((unsigned long long)sl.y << 32) | sl.x;
     } while (sk != key && sk != kEmptyKey);
   }
-  if (sk == key) nn_scan_voxel(pts4, sl.z, sl.w, qx, qy, qz, b);
+  if (sk == key) nn_scan_voxel(pts4, sl.z, slot_count(sl.w), qx, qy, qz, b);
 }
 
 __device__ __forceinline__ NNResult nn_search_pruned(const MapView& m, float qx, float qy, float qz) {
@@ -348,7 +353,8 @@ __device__ __forceinline__ void knn_visit(const MapView& m, gslots_ptr slots4, g
     sk = ((unsigned long long)sl.y << 32) | sl.x;
   }
   if (sk != key) return;
-  for (uint32_t j = 0; j < sl.w; j++) {
+  const uint32_t n_rec = slot_count(sl.w);
+  for (uint32_t j = 0; j < n_rec; j++) {
     const f32x4 c = pts4[sl.z + j];
     const float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
     const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order (bit-exact with the oracle)
@@ -396,7 +402,7 @@ __device__ __forceinline__ void nn_resolve(const MapView& m, gslots_ptr slots4, 
   }
   if (sk == key) {
     first = sl.z;
-    cnt = sl.w;
+    cnt = slot_count(sl.w);
   }
 }
 
@@ -604,8 +610,8 @@ __device__ __forceinline__ void quad_narrow(const MapView& m, uint32_t qv, int c
   const bool no_xlo = farx && ex > 0.f, no_xhi = farx && ex < 0.f, no_ylo = fary && ey > 0.f, no_yhi = fary && ey < 0.f;
   const uint32_t lo_q = (no_xlo ? 2u : 0u) + (no_ylo ? 1u : 0u);   // first needed quadrant (2 * xhalf + yhalf)
   const uint32_t hi_q = (no_xhi ? 0u : 2u) + (no_yhi ? 0u : 1u);   // last needed quadrant
-  const uint32_t b_lo = lo_q == 0u ? 0u : ((qv >> (5u * (lo_q - 1u))) & 31u);
-  const uint32_t b_hi = hi_q == 3u ? n : ((qv >> (5u * hi_q)) & 31u);
+  const uint32_t b_lo = lo_q == 0u ? 0u : ((qv >> (8u + 5u * (lo_q - 1u))) & 31u);
+  const uint32_t b_hi = hi_q == 3u ? n : ((qv >> (8u + 5u * hi_q)) & 31u);
   f += b_lo;
   n = b_hi - b_lo;
 }
@@ -715,9 +721,9 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
       MH_FLOOR_BATCH(c_mine);
       const unsigned long long key = nn_key_of(kbase, c_mine < 0 ? 0 : c_mine);
       const u32x4 sl = slots4[hash_key(key) & m.mask];  // one probe per lane, four per point in flight
-      // the quadrant boundaries of the probed voxel, requested with the slot (valid when the key sits at its home slot: else
-      // the voxel is scanned whole)
-      const uint32_t qv = ((const uint32_t MH_AS_GLOBAL*)m.qidx)[hash_key(key) & m.mask];
+      // the quadrant boundaries of the probed voxel come in the slot's count word (valid when the key sits at its home slot:
+      // else the voxel is scanned whole)
+      const uint32_t qv = sl.w;
       const bool at_home = (((unsigned long long)sl.y << 32) | sl.x) == key;
       uint32_t f_mine, n_mine;
       nn_resolve(m, slots4, key, sl, c_mine >= 0, f_mine, n_mine);
