@@ -1871,11 +1871,9 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_floor_b(const B
     const bool want = c_mine != 63u;
     const unsigned long long key = nn_key_of(kbase, want ? (int)c_mine : 0) + (acc == 0xFFFFFFFEu);  // (the next probe waits for the scan)
     const u32x4 sl = slots4[hash_key(key) & m.mask];
-    const uint32_t qv = sl.w;
-    const bool at_home = (((unsigned long long)sl.y << 32) | sl.x) == key;
-    uint32_t f_mine, n_mine;
-    nn_resolve(m, slots4, key, sl, want, f_mine, n_mine);
-    if (useq && at_home && want) quad_narrow(m, qv, (int)c_mine, px, py, bound0, f_mine, n_mine);
+    uint32_t f_mine, n_mine, qv;
+    nn_resolve(m, slots4, key, sl, want, f_mine, n_mine, &qv);
+    if (useq && want) quad_narrow(m, qv, (int)c_mine, px, py, bound0, f_mine, n_mine);
     if (flags & FLOOR_HALF_RECORDS) n_mine = (n_mine + 1u) >> 1;
     const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
     const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};

@@ -386,10 +386,13 @@ __device__ __forceinline__ void nn_search_kbest(const MapView& m, float qx, floa
 }
 
 // {first, count} of voxel `key` given the slot its hash points at; count 0 when absent or not wanted
+// (raw: the slot's count word as stored -- with the quadrants' boundaries of an indexed voxel, slot_count() -- wherever linear
+// probing found the voxel)
 __device__ __forceinline__ void nn_resolve(const MapView& m, gslots_ptr slots4, unsigned long long key, u32x4 sl,
-                                           bool want, uint32_t& first, uint32_t& cnt) {
+                                           bool want, uint32_t& first, uint32_t& cnt, uint32_t* raw = nullptr) {
   first = 0;
   cnt = 0;
+  if (raw) *raw = 0u;
   if (!want) return;
   unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
   if (sk != key && sk != kEmptyKey) {  // rare: linear probing past a collision
@@ -403,6 +406,7 @@ __device__ __forceinline__ void nn_resolve(const MapView& m, gslots_ptr slots4, 
   if (sk == key) {
     first = sl.z;
     cnt = slot_count(sl.w);
+    if (raw) *raw = sl.w;
   }
 }
 
@@ -721,13 +725,10 @@ __device__ __forceinline__ NNResult nn_search_quad(const MapView& m, uint32_t su
       MH_FLOOR_BATCH(c_mine);
       const unsigned long long key = nn_key_of(kbase, c_mine < 0 ? 0 : c_mine);
       const u32x4 sl = slots4[hash_key(key) & m.mask];  // one probe per lane, four per point in flight
-      // the quadrant boundaries of the probed voxel come in the slot's count word (valid when the key sits at its home slot:
-      // else the voxel is scanned whole)
-      const uint32_t qv = sl.w;
-      const bool at_home = (((unsigned long long)sl.y << 32) | sl.x) == key;
-      uint32_t f_mine, n_mine;
-      nn_resolve(m, slots4, key, sl, c_mine >= 0, f_mine, n_mine);
-      if (at_home) quad_narrow(m, qv, c_mine, qx, qy, nnkey_d2(best), f_mine, n_mine);
+      // the quadrant boundaries of the probed voxel come in its slot's count word, wherever linear probing finds the slot
+      uint32_t f_mine, n_mine, qv;
+      nn_resolve(m, slots4, key, sl, c_mine >= 0, f_mine, n_mine, &qv);
+      quad_narrow(m, qv, c_mine, qx, qy, nnkey_d2(best), f_mine, n_mine);
       const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
       const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
       best = nn_scan_merged_quad<4>(spts, first, cnt, sub, qx, qy, qz, best MH_CARRY_PASS);
