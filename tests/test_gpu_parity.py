@@ -1001,6 +1001,20 @@ def test_quad_matcher_sub_voxel_index(ctx, oracle, vs, cap, mode, lattice, monke
             for k in ("local_idx", "global_idx", "d2", "global_xyz"):
                 np.testing.assert_array_equal(g["pairs"][k], o["pairs"][k])
             np.testing.assert_allclose(g["T"], o["T"], rtol=0, atol=1e-9)
+        # the index has re-written the count words of the map's hash slots (boundaries beside the count): every OTHER reader of
+        # the table -- the one-lane matcher, the k-best matcher, the row matcher of a small layer's alignment -- still sees
+        # the counts (slot_count()); `om` holds the key-frame by now, like the device map
+        small = scan[:3000]
+        a, b = capi.nn_search(gm, capi.Scan(ctx, small), guess, 1.5 * vs), oracle.match_points(om, small, guess, 1.5 * vs)
+        for k in ("local_idx", "global_idx", "d2"):
+            np.testing.assert_array_equal(a[k], b[k])
+        a, b = capi.nn_search_k(gm, capi.Scan(ctx, small), guess, 1.5 * vs, 3), oracle.match_points_k(om, small, guess, 1.5 * vs, 3)
+        for k in ("local_idx", "global_idx", "d2"):
+            np.testing.assert_array_equal(a[k], b[k])
+        g = capi.icp_align(gm, capi.Scan(ctx, small), guess, capi.ICPParams(**kw), want_pairs=True)
+        o = oracle.icp_align(om, small, guess, oracle.ICPParams(**kw), want_pairs=True)
+        assert [t["n_pairs"] for t in g["trace"]] == [t["n_pairs"] for t in o["trace"]]
+        np.testing.assert_array_equal(g["pairs"]["global_idx"], o["pairs"]["global_idx"])
 
 
 def test_sub_voxel_index_built_once_for_concurrent_searchers(oracle):
