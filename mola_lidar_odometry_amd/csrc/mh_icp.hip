@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "mh_nn_device.h"
+#include "mh_nn_flat.h"
 
 using namespace mh;
 
@@ -1785,6 +1786,36 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDevic
 #endif
   );
 }
+// ================================================================================================
+// k_match_flat: the plan / scan matcher (mh_nn_flat.h) -- a wave per 64 consecutive scan points, per-point, per-voxel and
+// per-record work each spread over all 64 lanes and handed on through the wave's slice of LDS.  Device-state driven like
+// k_match4 (same arguments, same pairings, bit for bit); the first Gauss-Newton accumulation is the k_accum launch that follows.
+// ================================================================================================
+constexpr uint32_t kFlatThreads = 128;                 // two waves per workgroup: LDS granularity, nothing is shared between them
+constexpr uint32_t kFlatPointsPerBlock = kFlatThreads; // a lane per point in phase A
+inline uint32_t nblk_flat(size_t n) { return (uint32_t)((n + kFlatPointsPerBlock - 1) / kFlatPointsPerBlock); }
+__device__ __forceinline__ void k_match_flat_body(const IcpDeviceState* __restrict__ st, const float* __restrict__ lx,
+                                                  const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                  MapView map, float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
+                                                  const uint32_t* __restrict__ perm) {
+  __shared__ FlatWave sh[kFlatThreads / 64];
+  typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
+  const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
+  if (cst->done) return;  // grid-uniform
+  const uint32_t i0 = blockIdx.x * kFlatPointsPerBlock + (threadIdx.x & ~63u);
+  if (i0 >= n) return;    // whole waves
+  const bool have_prev = cst->iter > 0 && !map.no_prev_bound;
+  double T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = cst->T[k];
+  match_flat_wave(sh[threadIdx.x >> 6], map, T, cst->cur_thr2, cst->cur_ang2, have_prev, lx, ly, lz, n, i0, pair_q, pair_gidx, perm);
+}
+__global__ __launch_bounds__(kFlatThreads) void k_match_flat(const IcpDeviceState* __restrict__ st, const float* __restrict__ lx,
+                                                             const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                             MapView map, float4* __restrict__ pair_q,
+                                                             uint32_t* __restrict__ pair_gidx, const uint32_t* __restrict__ perm) {
+  k_match_flat_body(st, lx, ly, lz, n, map, pair_q, pair_gidx, perm);
+}
 #ifdef MH_DEBUG_FLOOR
 // ================================================================================================
 // tools/match_floor.py (debug build, -DMH_DEBUG_FLOOR): the latency floor of the quad matcher's access pattern.
@@ -1998,6 +2029,10 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4o_b(const Batch
                 , nullptr
 #endif
   );
+}
+__global__ __launch_bounds__(kFlatThreads) void k_match_flat_b(const BatchJob* __restrict__ jobs) {
+  const BatchJob& j = jobs[blockIdx.y];
+  k_match_flat_body(j.st, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, nullptr);
 }
 __global__ __launch_bounds__(kTileThreads) void k_match_tile(const IcpDeviceState* __restrict__ st, const float* __restrict__ sx,
                                                              const float* __restrict__ sy, const float* __restrict__ sz,
@@ -2692,6 +2727,8 @@ struct AlignJob {
       //   "o"            "q" over the scan in search order (the sort of "t"/"w", no tiles)                                    -> k_match4 + k_accum
       if (e && e[0] == 'o') variant = 8;
       if (e && e[0] == 'q') variant = 4;
+      //   "f"            plan / scan (mh_nn_flat.h): a wave per 64 points, per-point / per-voxel / per-record work each on all 64 lanes -> k_match_flat + k_accum
+      if (e && e[0] == 'f') variant = 9;
       if (e && e[0] == 's') variant = 5;
       if (e && e[0] == 'p') variant = 0;
       if (e && e[0] == 'x') variant = 1;
@@ -2700,7 +2737,8 @@ struct AlignJob {
       // kernel runs both in one launch (k_match16<true>), whatever the layer's size
       if (pl && p->matched_points == MH_MATCHED_POINTS_SKIP) variant = 5;
     }
-    if (variant >= 6) MH_TRY(scan_build_tiles(scan, map->inv_vs, variant == 7 ? 64u : 256u));  // asynchronous; a no-op when the scan is already in search order
+    if (variant == 9 && map->pts.bytes / sizeof(float4) >= kFlatMaxRecords) variant = 4;  // (the chunk word holds 30 bits of record index)
+    if (variant >= 6 && variant != 9) MH_TRY(scan_build_tiles(scan, map->inv_vs, variant == 7 ? 64u : 256u));
     if (variant == 4 || variant >= 6) MH_TRY(map_ensure_qidx(map, ctx->stream));  // nn_search_quad reads the map's sub-voxel index
     nba = nblk_acc(scan->n);
     // (measured per iteration, fused vs k_accum: 31.0 vs 33.8 us at 4 k points, 33.2 vs 35.0 at 8 k, equal at 16 k,
@@ -2869,6 +2907,12 @@ struct AlignJob {
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
           hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
+        } else if (variant == 9) {
+          hipLaunchKernelGGL(k_match_flat, dim3(nblk_flat(n)), dim3(kFlatThreads), 0, s, ctx->d_state, scan->x, scan->y, scan->z, n, mv,
+                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (const uint32_t*)nullptr);
+          if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
+          hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+                             ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
         } else if (variant == 4 || variant == 8) {
           const bool ord = variant == 8;  // the scan in search order
           hipLaunchKernelGGL(k_match4, dim3((uint32_t)((4ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
@@ -2947,8 +2991,8 @@ struct AlignJob {
                                        (unsigned long long)(pl ? ctx->pl_c.p : nullptr),
                                        (unsigned long long)(pl ? ctx->pl_n.p : nullptr),
                                        (unsigned long long)(pl ? ctx->partials_b.p : nullptr),
-                                       variant >= 6 ? (unsigned long long)scan->sx : 0ull,
-                                       variant >= 6 ? (unsigned long long)scan->n_tiles : 0ull,
+                                       variant >= 6 && variant != 9 ? (unsigned long long)scan->sx : (unsigned long long)variant,
+                                       variant >= 6 && variant != 9 ? (unsigned long long)scan->n_tiles : 0ull,
                                        (unsigned long long)mv.pts_q};  // (a word each: no XOR folding)
       static_assert(sizeof(kv) <= sizeof(key), "graph key too small");
       memcpy(key, kv, sizeof(kv));
@@ -3184,7 +3228,7 @@ void fill_batch_desc(const AlignJob& j, BatchJob& d) {
   }
   d.sched_dst = j.ctx->sched.as<uint32_t>();
   d.sched_dwords = (uint32_t)(2 * j.nsched_pending);
-  if (j.variant >= 6) {
+  if (j.variant >= 6 && j.variant != 9) {
     d.sx = j.scan->sx; d.sy = j.scan->sy; d.sz = j.scan->sz;
     d.perm = j.scan->perm;
     d.tile_start = j.scan->tile_start;
@@ -3352,7 +3396,7 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
   // each job keeps its own parameters (iteration budget, schedules, hook check point, prior), state block, termination
   // flag and iteration count.  Jobs whose chain has no lock-step form (or that are alone in their group) take the
   // per-stream path below.
-  enum Kind { K_NONE = 0, K_QUAD, K_TILE, K_WAVE, K_ORD, K_ROWF, K_STEP, K_STEP_PL };
+  enum Kind { K_NONE = 0, K_QUAD, K_TILE, K_WAVE, K_ORD, K_ROWF, K_STEP, K_STEP_PL, K_FLAT };
   const bool no_lockstep = getenv("MH_NO_LOCKSTEP") != nullptr;
   const bool batch_prof = !jobs.empty() && jobs[0].prof && !no_lockstep;  // (profile == 2 times job 0's share of a match kernel)
   auto kind_of = [&](const AlignJob& j) -> int {
@@ -3363,6 +3407,7 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
     // way, NDT pipeline 3966 / 4509 / 3939 against 4780 / 5500 / 5600: removed.)
     if (j.use_step_chain() && !batch_prof) return j.pl ? K_STEP_PL : K_STEP;
     if (j.variant == 4 && !j.pl) return K_QUAD;
+    if (j.variant == 9 && !j.pl) return K_FLAT;
     if (j.variant == 6 && !j.pl) return K_TILE;
     if (j.variant == 7 && !j.pl) return K_WAVE;
     if (j.variant == 8 && !j.pl) return K_ORD;
@@ -3480,6 +3525,7 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
         d.stage_off = (uint32_t)(off / 4);
         uint32_t bm = (uint32_t)((4ull * d.n + kBlock - 1) / kBlock);  // quad
         if (g.kind == K_ROWF) bm = d.nbm;
+        if (g.kind == K_FLAT) bm = nblk_flat(d.n);
         if (g.kind == K_TILE) bm = d.n_tiles;
         if (g.kind == K_WAVE) bm = d.n_tiles;
         if (g.step_chain()) {  // all jobs' workgroups resident at once: kStepMaxWorkgroups shared between them
@@ -3550,6 +3596,7 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
               hipLaunchKernelGGL(k_match_wave_sparse_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj);
               break;
             case K_ORD: hipLaunchKernelGGL(k_match4o_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
+            case K_FLAT: hipLaunchKernelGGL(k_match_flat_b, dim3(g.gx_match, A), dim3(kFlatThreads), 0, s, g.dj); break;
             default: hipLaunchKernelGGL(k_match4_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
           }
           if (pr) {
