@@ -2714,20 +2714,20 @@ struct AlignJob {
     sk.host_progress = streaming ? ctx->d_progress : nullptr;
     nb = nblk(scan->n);
     {  // MH_MATCH selects the correspondence kernel of the fused loop (all exact, bit-identical pairings):
-       //   "q" (default)  a DPP quad per scan point, merged candidate scans          -> k_match4 + k_accum
+       //   "q"            a DPP quad per scan point, merged candidate scans (the default of rounds 1-4) -> k_match4 + k_accum
        //   "p"            one lane per point, branch-and-bound, fused accumulation   -> k_match<true, 1>
        //   "x"            one lane per point, the literal 27-voxel scan of the reference (A/B baseline)
       //   "s"            a DPP row (16 lanes) per point: what "q" becomes automatically for small layers    -> k_match16 + k_accum
       //   "t"            a workgroup per tile of the spatially sorted scan, map records staged in LDS      -> k_match_tile + k_accum
       const char* e = getenv("MH_MATCH");
-      variant = scan->n <= kRowMaxPoints ? 5 : 4;
+      variant = scan->n <= kRowMaxPoints ? 5 : 9;
       //   "w"            a wave per tile of 64 sorted points, wave-uniform candidates through the scalar path       -> k_match_wave + k_accum
       if (e && e[0] == 't') variant = 6;
       if (e && e[0] == 'w') variant = 7;
       //   "o"            "q" over the scan in search order (the sort of "t"/"w", no tiles)                                    -> k_match4 + k_accum
       if (e && e[0] == 'o') variant = 8;
       if (e && e[0] == 'q') variant = 4;
-      //   "f"            plan / scan (mh_nn_flat.h): a wave per 64 points, per-point / per-voxel / per-record work each on all 64 lanes -> k_match_flat + k_accum
+      //   "f" (default)  plan / scan (mh_nn_flat.h): a wave per 64 points, per-point / per-voxel / per-record work each on all 64 lanes -> k_match_flat + k_accum
       if (e && e[0] == 'f') variant = 9;
       if (e && e[0] == 's') variant = 5;
       if (e && e[0] == 'p') variant = 0;

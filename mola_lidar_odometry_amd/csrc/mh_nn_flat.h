@@ -36,8 +36,12 @@ namespace mh {
 
 constexpr int kFlatLPP = 4;            // records per chunk = lanes per chunk (consecutive 16-byte records: one L1 line mostly)
 #ifndef MH_FLAT_W
-#define MH_FLAT_W 4
+#define MH_FLAT_W 8
 #endif
+#ifndef MH_FLAT_PROBES
+#define MH_FLAT_PROBES 4
+#endif
+constexpr int kFlatProbes = MH_FLAT_PROBES;  // probes in flight per lane (passes of 64 candidate voxels resolved per round trip)
 constexpr int kFlatW = MH_FLAT_W;      // chunks in flight per lane group and round: 16 x W chunks per wave and round trip
 constexpr int kFlatMaxCand = 8;        // candidate voxels per point on the planned path (C2: 99.9 % of the points have <= 8)
 #ifndef MH_FLAT_CHUNKS
@@ -55,6 +59,7 @@ struct FlatWave {
   unsigned char CHP[kFlatMaxChunks];   // the chunk's point
   unsigned char SLOWF[64];             // the plan ran out of chunk space for this point
   unsigned char SL[64];                // phase D: the points to search quad-wise, compacted
+  uint32_t NCH, NVALID;                // chunks allocated (ds_add_rtn); first chunk slot that was not written (ds_min)
 };
 
 // count of set bits of `m` below this lane
@@ -121,6 +126,7 @@ __device__ __forceinline__ void match_flat_wave(FlatWave& sh, const MapView& m, 
     sh.KB[lane] = kbase;
     sh.RES[lane] = ((unsigned long long)__float_as_uint(b0) << 32) | 0xFFFFFFFFull;
     sh.SLOWF[lane] = 0;
+    if (lane == 0) { sh.NCH = 0; sh.NVALID = (uint32_t)kFlatMaxChunks; }
     {
       uint32_t mm = cmask, at = cincl - ncand;
 #pragma unroll
@@ -134,45 +140,76 @@ __device__ __forceinline__ void match_flat_wave(FlatWave& sh, const MapView& m, 
     }
     wave_sync_lds_nn();
     // ---- A2: the candidate voxel ---------------------------------------------------------------------------------------
-    uint32_t nch_total = 0;
-    bool overflowed = false;
-    for (uint32_t base = 0; base < n_cands; base += 64u) {
-      const uint32_t c = base + lane;
-      const bool act = c < n_cands;
-      const uint32_t e = sh.CL[act ? c : 0u];
-      const uint32_t p = e & 63u;
-      const int code = (int)(e >> 8);
-      const f32x4 P = sh.P[p];
-      const unsigned long long key = nn_key_of(sh.KB[p], code);
-      const u32x4 sl = slots4[hash_key(key) & m.mask];
-      uint32_t f, cnt, qv;
-      nn_resolve(m, slots4, key, sl, act, f, cnt, &qv);
-      quad_narrow(m, qv, code, P.x, P.y, P.w, f, cnt);
-      const uint32_t nchunks = (cnt + (uint32_t)kFlatLPP - 1u) / (uint32_t)kFlatLPP;
-      const uint32_t incl = wave_scan_incl(nchunks);
-      const uint32_t pos = nch_total + incl - nchunks;
-      const bool unfit = nchunks != 0u && (overflowed || pos + nchunks > (uint32_t)kFlatMaxChunks);
-      const unsigned long long ub = __ballot(unfit);
-      if (ub != 0ull && !overflowed) {  // wave-uniform: everything from the first lane that does not fit goes to phase D
-        nvalid = (uint32_t)__builtin_amdgcn_readlane((int)pos, __builtin_ctzll(ub));
-        overflowed = true;
+    // kFlatProbes passes of 64 candidates at a time: every lane's probes are in flight together (one round trip for the
+    // wave's first 256 candidates -- C2: ~207), then resolved one after the other.
+    uint32_t nch_total = 0;  // (wave-uniform)
+    for (uint32_t base = 0; base < n_cands; base += 64u * (uint32_t)kFlatProbes) {
+      uint32_t ent[kFlatProbes];
+      unsigned long long keys[kFlatProbes];
+      u32x4 sls[kFlatProbes];
+#pragma unroll
+      for (int k = 0; k < kFlatProbes; k++) {
+        const uint32_t c = base + 64u * (uint32_t)k + lane;
+        ent[k] = sh.CL[c < n_cands ? c : 0u];  // (clamped: the load of an idle lane is a hit on entry 0's slot)
+        keys[k] = nn_key_of(sh.KB[ent[k] & 63u], (int)(ent[k] >> 8));
+#ifdef MH_FLAT_WHATIF_PROBE  // timing experiment (results wrong): every probe hits the same 1 KiB
+        sls[k] = slots4[hash_key(keys[k]) & 63u];
+#else
+        sls[k] = slots4[hash_key(keys[k]) & m.mask];
+#endif
       }
-      if (unfit) sh.SLOWF[p] = 1;
-      if (!unfit) {
-        for (uint32_t k = 0; k < nchunks; k++) {
-          const uint32_t rem = cnt - (uint32_t)kFlatLPP * k;
-          sh.CH[pos + k] = (f + (uint32_t)kFlatLPP * k) | (((rem < (uint32_t)kFlatLPP ? rem : (uint32_t)kFlatLPP) - 1u) << 30);
-          sh.CHP[pos + k] = (unsigned char)p;
+#pragma unroll
+      for (int k = 0; k < kFlatProbes; k++) {
+        if (base + 64u * (uint32_t)k >= n_cands) break;  // wave-uniform
+        const uint32_t c = base + 64u * (uint32_t)k + lane;
+        const bool act = c < n_cands;
+        const uint32_t p = ent[k] & 63u;
+        const int code = (int)(ent[k] >> 8);
+        const f32x4 P = sh.P[p];
+        uint32_t f, cnt, qv;
+        nn_resolve(m, slots4, keys[k], sls[k], act, f, cnt, &qv);
+        quad_narrow(m, qv, code, P.x, P.y, P.w, f, cnt);
+        const uint32_t nchunks = (cnt + (uint32_t)kFlatLPP - 1u) / (uint32_t)kFlatLPP;
+#ifdef MH_FLAT_ATOMIC_ALLOC
+        // (A/B: chunk space off one LDS counter -- one ds_add_rtn instead of a DPP prefix sum, but 64 lanes on one address)
+        uint32_t pos = 0;
+        if (nchunks) pos = __hip_atomic_fetch_add(&sh.NCH, nchunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        // chunk space by a DPP prefix sum over the wave's candidates of this pass (the order of the chunks does not matter
+        // for the result: every chunk names its point)
+        const uint32_t incl = wave_scan_incl(nchunks);
+        const uint32_t pos = nch_total + incl - nchunks;
+        nch_total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+#endif
+        if (nchunks) {
+          if (pos + nchunks > (uint32_t)kFlatMaxChunks) {  // out of space: the point goes to phase D, slots from `pos` on stay unwritten
+            sh.SLOWF[p] = 1;
+            (void)__hip_atomic_fetch_min(&sh.NVALID, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+#pragma unroll 1
+            for (uint32_t j = 0; j < nchunks; j++) {
+              const uint32_t rem = cnt - (uint32_t)kFlatLPP * j;
+              sh.CH[pos + j] = (f + (uint32_t)kFlatLPP * j) | (((rem < (uint32_t)kFlatLPP ? rem : (uint32_t)kFlatLPP) - 1u) << 30);
+              sh.CHP[pos + j] = (unsigned char)p;
+            }
+          }
         }
       }
-      nch_total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
-    if (!overflowed) nvalid = nch_total;
     wave_sync_lds_nn();
+    {
+#ifdef MH_FLAT_ATOMIC_ALLOC
+      const uint32_t a = sh.NCH;
+#else
+      const uint32_t a = nch_total;
+#endif
+      const uint32_t b = sh.NVALID;
+      nvalid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a < b ? a : b));
+    }
     // ---- B: the record ---------------------------------------------------------------------------------------------------
     const uint32_t grp = lane >> 2, sub = lane & 3u;
     for (uint32_t t0 = 0; t0 < nvalid; t0 += 16u * (uint32_t)kFlatW) {
-      f32x4 rec[kFlatW], Pq[kFlatW];
+      f32x4 rec[kFlatW];
       uint32_t pp[kFlatW];
       bool valid[kFlatW];
 #pragma unroll
@@ -184,17 +221,45 @@ __device__ __forceinline__ void match_flat_wave(FlatWave& sh, const MapView& m, 
         pp[u] = sh.CHP[tt];
         const uint32_t last = ch >> 30;
         valid[u] = ok && sub <= last;
+#ifdef MH_FLAT_WHATIF_REC  // timing experiment (results wrong): every record load hits the same 4 KiB
+        rec[u] = spts[((ch & 0x3FFFFFFFu) + (sub < last ? sub : last)) & 255u];
+#else
         rec[u] = spts[(ch & 0x3FFFFFFFu) + (sub < last ? sub : last)];  // clamped into the chunk: no load behind a branch
-        Pq[u] = sh.P[pp[u]];
+#endif
       }
+#ifdef MH_FLAT_SENS_LOADS  // sensitivity experiment: every record load issued twice (the second one an L1 hit), result folded in harmlessly
+      {
+        f32x4 dup[kFlatW];
+#pragma unroll
+        for (int u = 0; u < kFlatW; u++) {
+          const gpts_ptr a = spts + __float_as_uint(rec[u].w) * 0u;  // (depends on the first load: issued after it)
+          dup[u] = a[(sh.CH[(t0 + 16u * (uint32_t)u + grp) < nvalid ? (t0 + 16u * (uint32_t)u + grp) : 0u] & 0x3FFFFFFFu)];
+        }
+#pragma unroll
+        for (int u = 0; u < kFlatW; u++) if (dup[u].x != dup[u].x) rec[u].x = dup[u].y;  // never true for finite records
+      }
+#endif
+#ifdef MH_FLAT_SENS_VALU  // sensitivity experiment: 128 dependent dummy vector instructions per round
+      {
+        float acc = rec[0].x;
+#pragma unroll
+        for (int j = 0; j < 128; j++) acc = acc * 1.0001f + 0.5f;
+        if (acc == 123.456f) rec[0].x = acc;
+      }
+#endif
 #pragma unroll
       for (int u = 0; u < kFlatW; u++) {
-        const float dx = rec[u].x - Pq[u].x, dy = rec[u].y - Pq[u].y, dz = rec[u].z - Pq[u].z;
+        const f32x4 Pq = sh.P[pp[u]];  // (read when the record is there: W records in flight cost 4 registers each, not 8)
+        const float dx = rec[u].x - Pq.x, dy = rec[u].y - Pq.y, dz = rec[u].z - Pq.z;
         const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order (bit-exact with the oracle)
-        const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(rec[u].w);
-        const unsigned long long kb = ((unsigned long long)__float_as_uint(Pq[u].w) << 32) | 0xFFFFFFFFull;
-        if (valid[u] && k < kb)
-          (void)__hip_atomic_fetch_min(&sh.RES[pp[u]], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // only a record within the bound can be the answer ((d2, position) < (b0, none) <=> d2 <= b0)
+#ifdef MH_FLAT_NO_PREFILTER
+        if (valid[u])
+#else
+        if (valid[u] && d2 <= Pq.w)
+#endif
+          (void)__hip_atomic_fetch_min(&sh.RES[pp[u]], ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(rec[u].w),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
     wave_sync_lds_nn();

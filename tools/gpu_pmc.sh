@@ -6,10 +6,12 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*LDS[A-Z_0-9]*" | sort -u | tr '\n' ' ' > $OUT/lds_counters.txt
 i=0
-for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVES" \
-         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+# PMC_GROUPS: counter groups of one pass each, separated by ';' (default: the SQ view of rounds 1-4)
+GROUPS_DEFAULT="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVES;SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
+IFS=';' read -ra GROUPS_ARR <<< "${PMC_GROUPS:-$GROUPS_DEFAULT}"
+for C in "${GROUPS_ARR[@]}"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -o p -- python $REPO/bench.py --steps 2 --warmup 1 --streams ${PMC_STREAMS:-1} --no-cpu-baseline --no-profile --no-shared-run --no-extras --no-io > $OUT/p$i.log 2>&1
+  timeout ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -o p -- python $REPO/bench.py --steps 2 --warmup 1 --streams ${PMC_STREAMS:-1} --no-cpu-baseline --no-profile --no-shared-run --no-extras --no-io $PMC_EXTRA > $OUT/p$i.log 2>&1
 done
 cd $REPO
 cat $OUT/lds_counters.txt; echo
