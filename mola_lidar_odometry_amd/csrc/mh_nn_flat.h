@@ -103,13 +103,33 @@ __device__ __forceinline__ void match_flat_wave(FlatWave& sh, const MapView& m, 
     kbase = pack_key(cx - 1, cy - 1, cz - 1);
     const Gaps gx = axis_gaps(px, cx, m.vs, m.trunc), gy = axis_gaps(py, cy, m.vs, m.trunc), gz = axis_gaps(pz, cz, m.vs, m.trunc);
     cmask = 1u << 13;
+    // Seven tests instead of twenty-six when, for every planned lane of the wave, the FAR face of each axis is out of reach
+    // (the usual case once the bound is below a quarter voxel): a code that contains a far side has a lower bound >= that
+    // face's (non-negative terms, monotone rounding), so only the codes built from the near sides can pass -- the same mask.
+    const float fx = fmaxf(gx.s[0], gx.s[2]), fy = fmaxf(gy.s[0], gy.s[2]), fz = fmaxf(gz.s[0], gz.s[2]);
+    const bool far_dead = (fx * 0.9999f > b0) && (fy * 0.9999f > b0) && (fz * 0.9999f > b0);
+    if (__ballot(planned && !far_dead) == 0ull) {  // wave-uniform
+      const bool xl = gx.s[0] <= gx.s[2], yl = gy.s[0] <= gy.s[2], zl = gz.s[0] <= gz.s[2];
+      const float nx = xl ? gx.s[0] : gx.s[2], ny = yl ? gy.s[0] : gy.s[2], nz = zl ? gz.s[0] : gz.s[2];
+      const uint32_t cx_ = xl ? 4u : 22u, cy_ = yl ? 10u : 16u, cz_ = zl ? 12u : 14u;  // 13 -/+ 9, 3, 1
+      const uint32_t dx_ = cx_ - 13u, dy_ = cy_ - 13u;                               // (mod 2^32)
+      const float lxy = nx + ny;
+      cmask |= (!(nx * 0.9999f > b0)) ? (1u << cx_) : 0u;
+      cmask |= (!(ny * 0.9999f > b0)) ? (1u << cy_) : 0u;
+      cmask |= (!(nz * 0.9999f > b0)) ? (1u << cz_) : 0u;
+      cmask |= (!(lxy * 0.9999f > b0)) ? (1u << (cy_ + dx_)) : 0u;
+      cmask |= (!((nx + nz) * 0.9999f > b0)) ? (1u << (cz_ + dx_)) : 0u;
+      cmask |= (!((ny + nz) * 0.9999f > b0)) ? (1u << (cz_ + dy_)) : 0u;
+      cmask |= (!((lxy + nz) * 0.9999f > b0)) ? (1u << (cz_ + dx_ + dy_)) : 0u;
+    } else {
 #pragma unroll
-    for (int c = 0; c < 27; c++) {
-      if (c == 13) continue;
-      const int ix = c / 9, iy = (c / 3) % 3, iz = c % 3;
-      const float sx = ix == 1 ? 0.f : gx.s[ix], sy = iy == 1 ? 0.f : gy.s[iy], sz = iz == 1 ? 0.f : gz.s[iz];
-      const float lb = ((sx + sy) + sz) * 0.9999f;  // quad_bounds' expression
-      cmask |= (!(lb > b0)) ? (1u << c) : 0u;
+      for (int c = 0; c < 27; c++) {
+        if (c == 13) continue;
+        const int ix = c / 9, iy = (c / 3) % 3, iz = c % 3;
+        const float sx = ix == 1 ? 0.f : gx.s[ix], sy = iy == 1 ? 0.f : gy.s[iy], sz = iz == 1 ? 0.f : gz.s[iz];
+        const float lb = ((sx + sy) + sz) * 0.9999f;  // quad_bounds' expression
+        cmask |= (!(lb > b0)) ? (1u << c) : 0u;
+      }
     }
     if (!planned) cmask = 0;
     if (__builtin_popcount(cmask) > kFlatMaxCand) {  // a loose bound near a voxel corner: the quad search, with the bound
