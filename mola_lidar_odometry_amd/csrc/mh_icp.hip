@@ -1793,7 +1793,14 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDevic
 // ================================================================================================
 constexpr uint32_t kFlatThreads = 128;                 // two waves per workgroup: LDS granularity, nothing is shared between them
 constexpr uint32_t kFlatPointsPerBlock = kFlatThreads; // a lane per point in phase A
-inline uint32_t nblk_flat(size_t n) { return (uint32_t)((n + kFlatPointsPerBlock - 1) / kFlatPointsPerBlock); }
+__device__ __forceinline__ uint32_t nblk_flat_dev(uint32_t n) { return (n + kFlatPointsPerBlock - 1u) / kFlatPointsPerBlock; }
+// (the grid width is a multiple of 8 = the XCDs a launch is dealt over, whatever the layer's size)
+#ifdef MH_FLAT_XCD
+constexpr uint32_t kFlatGridUnit = 8u * (uint32_t)(MH_FLAT_XCD);
+#else
+constexpr uint32_t kFlatGridUnit = 8u;
+#endif
+inline uint32_t nblk_flat(size_t n) { return (uint32_t)(((n + kFlatPointsPerBlock - 1) / kFlatPointsPerBlock + kFlatGridUnit - 1) / kFlatGridUnit * kFlatGridUnit); }
 __device__ __forceinline__ void k_match_flat_body(const IcpDeviceState* __restrict__ st, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                   MapView map, float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
@@ -1802,7 +1809,16 @@ __device__ __forceinline__ void k_match_flat_body(const IcpDeviceState* __restri
   typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
   const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
   if (cst->done) return;  // grid-uniform
-  const uint32_t i0 = blockIdx.x * kFlatPointsPerBlock + (threadIdx.x & ~63u);
+#ifdef MH_FLAT_XCD
+  // (experiment) workgroup b runs on XCD b % 8 (round-robin dispatch, grid width a multiple of 8): hand each XCD a contiguous
+  // part of the layer, so that its L2 sees a part of the map instead of all of it (MH_FLAT_XCD=118: an eighth of C2 each)
+  // in runs of MH_FLAT_XCD consecutive workgroups' worth of points: run c of the layer goes to XCD c % 8
+  const uint32_t xj = blockIdx.x / 8u;
+  const uint32_t bx = ((xj / (uint32_t)(MH_FLAT_XCD)) * 8u + blockIdx.x % 8u) * (uint32_t)(MH_FLAT_XCD) + xj % (uint32_t)(MH_FLAT_XCD);
+#else
+  const uint32_t bx = blockIdx.x;
+#endif
+  const uint32_t i0 = bx * kFlatPointsPerBlock + (threadIdx.x & ~63u);
   if (i0 >= n) return;    // whole waves
   const bool have_prev = cst->iter > 0 && !map.no_prev_bound;
   double T[12];

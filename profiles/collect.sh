@@ -29,9 +29,13 @@ fi
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVES" \
-         "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum"; do
+         "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" \
+         "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_THREAD_CYCLES_VALU" \
+         "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_LDS_ATOMIC SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" \
+         "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TD_TD_BUSY_sum" \
+         "TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc$i -o ${TAG}_pmc$i -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-shared-run --no-extras --upload-thread 0 $EXTRA > $OUT/${TAG}_pmc$i.log 2>&1
+  timeout 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc$i -o ${TAG}_pmc$i -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-shared-run --no-extras --upload-thread 0 $EXTRA > $OUT/${TAG}_pmc$i.log 2>&1
 done
 cd $REPO
 python - <<PY
@@ -68,6 +72,16 @@ if mk:
         t['hbm_note']='(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch; FETCH_SIZE doubled per the gfx950 guide; Infinity-Cache hits are counted as traffic'
     if 'TCP_TCC_READ_REQ_sum' in m: t['l2_request_bytes_per_launch']=m['TCP_TCC_READ_REQ_sum']['mean']*64.0
     if 'SQ_INSTS_VALU' in m: t['valu_wave_instructions_per_launch']=m['SQ_INSTS_VALU']['mean']
+    # round 5: the ceilings of the bench line's views (clock cycles of the launch from GRBM_GUI_ACTIVE over the 8 XCDs)
+    if 'GRBM_GUI_ACTIVE' in m:
+        cyc=m['GRBM_GUI_ACTIVE']['mean']/8.0
+        t['launch_cycles_under_pmc']=cyc
+        if 'TA_TA_BUSY_sum' in m: t['ta_busy_frac']=m['TA_TA_BUSY_sum']['mean']/256.0/cyc
+        if 'TD_TD_BUSY_sum' in m: t['td_busy_frac']=m['TD_TD_BUSY_sum']['mean']/256.0/cyc
+    for c in ('SQ_INSTS_VMEM_RD','SQ_INSTS_VMEM_WR','SQ_INSTS_LDS','SQ_INSTS_LDS_ATOMIC','SQ_INSTS_SALU','SQ_WAVES','TCP_TOTAL_CACHE_ACCESSES_sum',
+              'TCP_PENDING_STALL_CYCLES_sum','TCP_GATE_EN1_sum','SQ_LDS_IDX_ACTIVE','SQ_THREAD_CYCLES_VALU'):
+        if c in m: t[c]=m[c]['mean']
+    t['valu_mix']={c[len('SQ_INSTS_VALU_'):]:m[c]['mean'] for c in m if c.startswith('SQ_INSTS_VALU_')}
     if 'SQ_WAIT_ANY' in m and 'SQ_WAVE_CYCLES' in m: t['wait_frac']=m['SQ_WAIT_ANY']['mean']/m['SQ_WAVE_CYCLES']['mean']
     if 'TCC_HIT_sum' in m and 'TCC_MISS_sum' in m: t['l2_hit_rate']=m['TCC_HIT_sum']['mean']/max(1.0,m['TCC_HIT_sum']['mean']+m['TCC_MISS_sum']['mean'])
     if 'TCP_TOTAL_CACHE_ACCESSES_sum' in m and 'TCP_TCC_READ_REQ_sum' in m: t['l1_hit_rate']=1.0-m['TCP_TCC_READ_REQ_sum']['mean']/max(1.0,m['TCP_TOTAL_CACHE_ACCESSES_sum']['mean'])
@@ -88,3 +102,8 @@ if glob.glob(out+'/odom/'+tag+'_*kernel_stats.csv'):
         print(r['Name'][:70].ljust(70), r['Calls'].rjust(6), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(9),'us', r['Percentage'])
     print(open(out+'/'+tag+'_odom_stdout.log').read().strip()[-1200:])
 PY
+# gpurun merges at most 64 MiB back: the raw per-dispatch tables stay on the box, the summaries travel
+rm -rf $OUT/pmc[0-9]* 
+find $OUT -name '*kernel_trace.csv' -delete
+find $OUT -name '*agent_info.csv' -delete
+du -sh $OUT
