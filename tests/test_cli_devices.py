@@ -88,3 +88,23 @@ def test_two_device_slots_on_one_gpu_reproduce_the_solo_trajectories(tmp_path):
     assert sum(d["scans"] for d in summ["per_device"]) == summ["scans"] and all(d["scans_per_s"] > 0 for d in summ["per_device"])
     for k, p in enumerate(per):
         assert open(p["tum"]).read() == solo[k], "sequence %d differs from its solo run" % k
+
+
+@pytest.mark.gpu
+def test_lpt_curve_extra_of_the_bench_on_device_slots_of_one_gpu(tmp_path):
+    """bench.py's `lpt_curve` extra (SURVEY 8e's second curve: eleven sequences with KITTI's length ratios through
+    molahip-lo-cli --devices, the makespan bound beside the measured rate) -- here over four device slots of GPU 0, the way a
+    single-GPU box can exercise the one-liner the 8-GPU run will use (`bench.py --gpus N` fills in `0,1,..,N-1`)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from mola_lidar_odometry_amd import dist as mdist
+    drive = synth.make_drive(14, seed=31, speed=7.0)
+    seq = synth.write_kitti_sequence(str(tmp_path / "drive"), drive)
+    r = bench.lpt_curve(seq, str(tmp_path), "0,0,0,0", scale=400.0, time_field=False)
+    lengths = [max(6, min(14, int(round(L / 400.0)))) for L in mdist.KITTI_SEQ_LENGTHS]
+    assert r["sequence_scans"] == lengths and r["scans"] == sum(lengths) and r["sequences"] == 11 and r["device_slots"] == 4
+    assert r["makespan_scans"] == mdist.makespan(lengths, mdist.lpt_assign(lengths, 4))
+    assert abs(r["speedup_bound_of_this_assignment"] - sum(lengths) / r["makespan_scans"]) < 1e-9
+    assert 4.9 < r["speedup_bound_kitti_8_gpus"] < 5.05
+    assert r["value"] > 0 and len(r["per_device"]) == 4 and sum(d["scans"] for d in r["per_device"]) == sum(lengths)
