@@ -102,6 +102,9 @@ struct SolveK {
   // streaming loop control (AlignJob::run_streaming): a word of page-locked HOST memory (device-visible address) that the
   // kernel closing a Gauss-Newton step updates with (ICP iteration about to run | done << 31); null = not published
   uint32_t* host_progress;
+  // k_step16 launches replayed from a captured graph (frozen arguments) are told their place IN the chunk; the serial number
+  // the chunk starts from is written here by the host before every replay (no launch skips the check)
+  uint32_t step_base, step_pad;
 };
 
 struct IcpDeviceParams {
@@ -1283,7 +1286,6 @@ constexpr uint32_t kStepMaxPoints = 8192;      // (above: k_match16<fused> | k_s
 constexpr uint32_t kStepMaxWorkgroups = 256;   // one per CU (512 threads x ~250 registers); beyond, workgroups take several groups
 constexpr uint32_t kStateHeadDwords = (uint32_t)(offsetof(IcpDeviceState, cov) / 4);  // everything the loop touches
 constexpr uint32_t kStateSerialDword = (uint32_t)(offsetof(IcpDeviceState, serial) / 4);
-constexpr uint32_t kStepUnchecked = 0xFFFFFFFFu;  // `expect` of launches whose arguments are frozen in a captured graph
 static_assert(kStateHeadDwords <= 64 && offsetof(IcpDeviceState, cov) % 8 == 0, "state head is copied by one wave");
 
 // reduce_rows with agent-scope loads, all of a lane's loads issued before any sum, the sums in reduce_rows' order exactly (lane (row, g) adds columns g, g + G, ...: eight partial sums over the full rounds, the rest into
@@ -1328,6 +1330,32 @@ __device__ __forceinline__ void rows_finish(const RowLoads<NVALS>& r, uint32_t n
   __syncthreads();
 }
 
+// Stored pairings cross launches of the k_step16 chain the way its state and partial sums do: agent-scope
+// (write-through) stores, acknowledged before the group's partial column is tagged, and agent-scope loads by the launch that
+// has seen the tag -- never answered from a stale L1 / L2 line, whichever XCD the reader runs on.
+// (16 bytes in one sc1 access through a buffer descriptor -- an agent-scope __hip_atomic lowers to sc1 only up to 8 bytes, and
+// 8-byte write-through stores cost 2.7x the 16-byte ones per byte -- with the compiler tracking the load like any other.)
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+struct AgentBuf {
+  __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ __forceinline__ AgentBuf agent_buf(const void* base, uint32_t n_records) {
+  const unsigned long long a = (unsigned long long)base;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  void* p = (void*)(((unsigned long long)hi << 32) | lo);
+  AgentBuf b;
+  b.rsrc = __builtin_amdgcn_make_buffer_rsrc(p, (short)0, (int)__builtin_amdgcn_readfirstlane((int)(n_records * 16u)), 0x00020000);
+  return b;
+}
+__device__ __forceinline__ void store_agent_b128(const AgentBuf& b, uint32_t i, f32x4 v) {
+  const u32x4v w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(w, b.rsrc, (int)(i * 16u), 0, /*aux: sc1*/ 16);
+}
+__device__ __forceinline__ f32x4 load_agent_b128(const AgentBuf& b, uint32_t i) {
+  const u32x4v w = __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)(i * 16u), 0, /*aux: sc1*/ 16);
+  return (f32x4){__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+}
+
 template <bool PL>
 __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__ s_in, IcpDeviceState* s_out,
                                               IcpDeviceState* s_canon, const MatchK* __restrict__ kp,
@@ -1336,13 +1364,18 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
                                               MapView map, float4* pair_q, uint32_t* pair_gidx, float4* pl_c, float4* pl_n,
                                               const double* __restrict__ partA_in, double* __restrict__ partA_out,
                                               const double* __restrict__ partB_in, double* __restrict__ partB_out,
-                                              uint32_t ngroups, uint32_t nw, uint32_t close_only, uint32_t expect) {
+                                              uint32_t ngroups, uint32_t nw, uint32_t close_only, uint32_t expect, uint32_t expect_rel) {
   __shared__ SolveShared sh;
   __shared__ __attribute__((aligned(8))) uint32_t lst_raw[kStateHeadDwords];
   __shared__ double rowsA[kAccN][kStepPoints + 1];
   __shared__ double rowsB[PL ? kGenN : 1][kStepPoints + 1];
+  const AgentBuf b_pair = agent_buf(pair_q, n), b_plc = agent_buf(PL ? (const void*)pl_c : (const void*)pair_q, n),
+                 b_pln = agent_buf(PL ? (const void*)pl_n : (const void*)pair_q, n);
+  __shared__ uint32_t pair_acks;  // waves whose stores of the current and earlier groups are acknowledged
+  uint32_t acks_wanted = 0;
   const uint32_t tid = threadIdx.x, wg = blockIdx.x;
-  if (wg >= nw) return;  // (lock-step batches: the grid is the largest job's)
+  if (wg >= nw) return;
+  if (tid == 0) pair_acks = 0;  // (barriers below before anybody counts)  // (lock-step batches: the grid is the largest job's)
   IcpDeviceState* const lst = reinterpret_cast<IcpDeviceState*>(lst_raw);
   // the point of this row is on its way before the state is looked at.  (Not so what the PREVIOUS launch stored for it: see below.)
   const uint32_t row = tid >> 4, r16 = tid & 15u;
@@ -1357,13 +1390,14 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
   double tag_b = PL ? __hip_atomic_load(partB_in + (size_t)kGenN * ngroups + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
   MH_PHASE(0);
   // The state block this launch is meant to read carries the serial number `expect` -- (the alignment's epoch << 22) + the
-  // launches before this one; kStepUnchecked for launches replayed from a captured graph -- written by the upload or by
-  // workgroup 0 of the previous launch.  Anything else in the block is older (the previous alignment's, the launch before
+  // launches before this one; a launch replayed from a captured graph is told its place in the chunk and adds the serial number
+  // the host wrote into the parameter block before the replay -- written by the upload or by workgroup 0 of the previous launch.  Anything else in the block is older (the previous alignment's, the launch before
   // last's: the same buffer): wait for the right one rather than act on it.
+  if (expect_rel) expect += __hip_atomic_load(&sk->step_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (uint32_t spins = 0;; spins++) {
     if (tid < kStateHeadDwords) lst_raw[tid] = __hip_atomic_load(reinterpret_cast<const uint32_t*>(s_in) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (expect == kStepUnchecked || lst->serial == expect) break;
+    if (lst->serial == expect) break;
     if (spins == (1u << 14)) {  // ~ tens of milliseconds: give up loudly (the host fails the alignment)
       if (tid == 0) {
         atomicAdd(&s_canon->handover_timeouts, 1u);
@@ -1388,6 +1422,9 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
     return;
   }
   MH_PHASE(1);
+  f32x4 stored = (f32x4){0.f, 0.f, 0.f, 0.f}, stored_c = stored, stored_n = stored;
+  uint32_t stored_g = kNoMatch;
+  bool have_stored = false;
   if (pending) {
     // every column carries the serial number of the launch that wrote it, stored AFTER its sums were acknowledged: a column
     // that does not carry this launch's number yet has not arrived (never seen since the exchange is at agent scope; a lane
@@ -1414,6 +1451,16 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
     RowLoads<PL ? kGenN : 1> rb;
     rows_issue<kAccN>(ra, partA_in, ngroups, ngroups);
     if (PL) rows_issue<PL ? kGenN : 1>(rb, partB_in, ngroups, ngroups);
+    // every column of the previous launch is tagged: what its workgroups stored for their groups is acknowledged (the tag is
+    // written after that) -- the stored pairings of this lane's point are requested now, at agent scope
+    // and BEHIND the loads of the sums this launch waits for, and arrive while the sums are formed and the step is solved
+    stored = load_agent_b128(b_pair, ic);
+    stored_g = __hip_atomic_load(pair_gidx + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PL) {
+      stored_c = load_agent_b128(b_plc, ic);
+      stored_n = load_agent_b128(b_pln, ic);
+    }
+    have_stored = true;
     rows_finish<kAccN>(ra, ngroups, sh.totA, sh.red);
     if (PL) rows_finish<PL ? kGenN : 1>(rb, ngroups, sh.totB, sh.red);
     solve_body<true, false>(lst, sk, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true, PL);
@@ -1450,7 +1497,14 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
   // tagged with its launch's serial number once its sums are acknowledged and a reader waits for the tag it expects (the
   // tags are on their way before the state is known: no extra round trip), and the stored pairings -- the previous pairing bounds the search at an iteration start and IS the pairing at an
   // inner step -- are read here, microseconds into the launch, not prefetched at its top.
-  f32x4 stored = G(reinterpret_cast<const f32x4*>(pair_q))[ic];
+  if (!have_stored) {  // (no step was pending: what is stored is at least two launches old)
+    stored = load_agent_b128(b_pair, ic);
+    stored_g = __hip_atomic_load(pair_gidx + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PL) {
+      stored_c = load_agent_b128(b_plc, ic);
+      stored_n = load_agent_b128(b_pln, ic);
+    }
+  }
 
   typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
   typedef const double __attribute__((address_space(4))) * cf64_ptr;
@@ -1486,21 +1540,21 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
           const float pl_thr = (float)((cf64_ptr)uniform_const_ptr(ck->pl_thr))[iter];
           okp = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
           if (r16 == 0) {
-            G(reinterpret_cast<f32x4*>(pl_c))[i] = (f32x4){bc.x, bc.y, bc.z, okp ? 1.f : 0.f};
-            G(reinterpret_cast<f32x4*>(pl_n))[i] = (f32x4){bn.x, bn.y, bn.z, 0.f};
+            store_agent_b128(b_plc, i, (f32x4){bc.x, bc.y, bc.z, okp ? 1.f : 0.f});
+            store_agent_b128(b_pln, i, (f32x4){bn.x, bn.y, bn.z, 0.f});
           }
           if (okp && ck->skip_pl_paired) ok = false;  // (the nearest point still goes to pair_q: it bounds the next search)
         }
         if (r16 == 0) {
-          G(reinterpret_cast<f32x4*>(pair_q))[i] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
-          G(pair_gidx)[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+          store_agent_b128(b_pair, i, (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2});
+          __hip_atomic_store(pair_gidx + i, ok ? __float_as_uint(r.pt.w) : kNoMatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         q = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
       } else {  // an inner Gauss-Newton step: the stored pairings under the new pose
-        ok = G(pair_gidx)[i] != kNoMatch;
+        ok = stored_g != kNoMatch;
         if (PL) {
-          bc = G(reinterpret_cast<const f32x4*>(pl_c))[i];
-          bn = G(reinterpret_cast<const f32x4*>(pl_n))[i];
+          bc = stored_c;
+          bn = stored_n;
           okp = bc.w != 0.f;
         }
       }
@@ -1528,27 +1582,36 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
       for (int r = 1; r < (int)kStepPoints; r++) sum += rowsA[tid][r];
       __hip_atomic_store(partA_out + tid * ngroups + g, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid < 64) {  // (the first wave holds the 18 sums: once they are acknowledged, lane 18 tags the column)
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      if (tid == kAccN) __hip_atomic_store(partA_out + (size_t)kAccN * ngroups + g, (double)(serial + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (PL && tid >= 64 && tid < 64 + kGenN) {  // (the second wave)
+    if (PL && tid >= 64 && tid < 64 + kGenN) {  // (the second wave: the 29 point-to-plane sums)
       const uint32_t t = tid - 64;
       double sum = rowsB[PL ? t : 0][0];
 #pragma unroll
       for (int r = 1; r < (int)kStepPoints; r++) sum += rowsB[PL ? t : 0][r];
       __hip_atomic_store(partB_out + t * ngroups + g, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (PL && tid >= 64 && tid < 128) {  // (the second wave: the 29 point-to-plane sums, then lane 29 tags)
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      if (tid == 64 + kGenN) __hip_atomic_store(partB_out + (size_t)kGenN * ngroups + g, (double)(serial + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // A column is tagged once its sums AND the pairings every wave of the workgroup stored for the group are acknowledged (a
+    // reader that has seen the tag reads them): every wave counts itself in when its own stores are -- the pairings were stored
+    // before the sums were formed, so this adds nothing to what the tagging wave waits for anyway -- and the tagging wave waits
+    // for the count.
+    acks_wanted += kSolveThreads / 64u;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if ((tid & 63u) == 0u) __hip_atomic_fetch_add(&pair_acks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (tid < 64 || (PL && tid < 128)) {  // (the first wave holds the 18 sums: lane 18 tags the column; the second wave's lane 29 the other kind's)
+      while (__hip_atomic_load(&pair_acks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < acks_wanted) __builtin_amdgcn_s_sleep(1);
+      if (tid == kAccN) __hip_atomic_store(partA_out + (size_t)kAccN * ngroups + g, (double)(serial + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (PL && tid == 64 + kGenN) __hip_atomic_store(partB_out + (size_t)kGenN * ngroups + g, (double)(serial + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     g += nw;
     if (g >= ngroups) break;
     i = g * kStepPoints + row;
     ic = i < n ? i : n - 1;
     x = G(lx)[ic]; y = G(ly)[ic]; z = G(lz)[ic];
-    stored = G(reinterpret_cast<const f32x4*>(pair_q))[ic];
+    stored = load_agent_b128(b_pair, ic);
+    stored_g = __hip_atomic_load(pair_gidx + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PL) {
+      stored_c = load_agent_b128(b_plc, ic);
+      stored_n = load_agent_b128(b_pln, ic);
+    }
     __syncthreads();  // (the row buffers are reused)
   }
   MH_PHASE(13);
@@ -1562,9 +1625,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_step16(const IcpDeviceState* 
                                                           float4* pl_c, float4* pl_n, const double* __restrict__ partA_in,
                                                           double* __restrict__ partA_out, const double* __restrict__ partB_in,
                                                           double* __restrict__ partB_out, uint32_t ngroups, uint32_t close_only,
-                                                          uint32_t expect) {
+                                                          uint32_t expect, uint32_t expect_rel) {
   k_step16_body<PL>(s_in, s_out, s_canon, kp, sk, lx, ly, lz, n, map, pair_q, pair_gidx, pl_c, pl_n, partA_in, partA_out, partB_in,
-                    partB_out, ngroups, gridDim.x, close_only, expect);
+                    partB_out, ngroups, gridDim.x, close_only, expect, expect_rel);
 }
 // in lock step: blockIdx.y = job; `par`: which state block / partials half this launch reads; gridDim.x: the host's cap on a
 // job's workgroups
@@ -1580,7 +1643,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_step16_b(const BatchJob* __re
   double* const pb[2] = {j.partb, j.partb ? j.partb + (size_t)kStepRowsB * ngroups : nullptr};
   k_step16_body<PL>(S[src], S[dst], S[2], j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx,
                     j.pl_c, j.pl_n, pa[par], pa[par ^ 1u], pb[par], pb[par ^ 1u], ngroups, ngroups < gridDim.x ? ngroups : gridDim.x,
-                    close_only, j.serial_base + launch_index);
+                    close_only, j.serial_base + launch_index, 0u);
 }
 
 // ================================================================================================
@@ -2615,6 +2678,7 @@ struct AlignJob {
   MatchK mk{};
   SolveK sk{};
   uint32_t nb = 0, nbm = 0, nba = 0, enqueued = 0, chunk = 0, prof_n = 0, polls = 0, kind = 0;
+  uint32_t step_total = 0;  // ... launches of the chunks enqueued so far when they are replayed from a graph (step_launches only counts direct launches)
   uint32_t serial_base = 0, step_launches = 0;  // k_step16's hand-over: the state block's serial number at upload, launches since
   // k_step16 chain: the state block the next launch reads (2 = the canonical one: after the upload and after a close-only launch;
   // 0 / 1 = the ping-pong pair) and the half of the partials it reads
@@ -2683,6 +2747,7 @@ struct AlignJob {
     // expect waits for exactly that block: neither the previous alignment's nor the launch before last's will do)
     serial_base = ((uint32_t)ctx->align_serial & 0x3FFu) << 22;
     step_launches = 0;
+    step_total = 0;
     ctx->h_state->serial = serial_base;
     const double ang = p->threshold_angular_deg * 3.14159265358979323846 / 180.0;
     ctx->h_state->cur_thr2 = (float)(p->threshold[0] * p->threshold[0]);
@@ -2843,9 +2908,12 @@ struct AlignJob {
     const uint32_t nwg = ngr < kStepMaxWorkgroups ? ngr : kStepMaxWorkgroups;
     // (launches whose arguments may be frozen in a captured graph cannot be told their number)
     const bool counted = prof || streaming || getenv("MH_NO_GRAPH") != nullptr;
+    uint32_t chunk_k = 0;  // k_step16 launches of this chunk so far
     auto launch_step = [&](uint32_t close_only) {
-      const uint32_t expect = counted ? serial_base + step_launches : kStepUnchecked;
+      const uint32_t expect = counted ? serial_base + step_launches : chunk_k;  // (replayed: the place in the chunk)
+      const uint32_t expect_rel = counted ? 0u : 1u;
       step_launches++;
+      chunk_k++;
       // canonical block (upload, results) + a ping-pong pair: a launch never writes the block it reads, and the canonical one is only
       // written by launches that do not read it (the one that ends the loop, the one-workgroup close-only launch)
       IcpDeviceState* const S[3] = {ctx->d_state_b, reinterpret_cast<IcpDeviceState*>(reinterpret_cast<char*>(ctx->d_state_b) + 256), ctx->d_state};
@@ -2858,12 +2926,12 @@ struct AlignJob {
         hipLaunchKernelGGL(k_step16<true>, dim3(close_only ? 1u : nwg), dim3(kSolveThreads), 0, s, S[src], S[dst],
                            S[2], dmk, dsk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
                            ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), (const double*)pa[par], pa[par ^ 1u], (const double*)pb[par],
-                           pb[par ^ 1u], ngr, close_only, expect);
+                           pb[par ^ 1u], ngr, close_only, expect, expect_rel);
       else
         hipLaunchKernelGGL(k_step16<false>, dim3(close_only ? 1u : nwg), dim3(kSolveThreads), 0, s, S[src], S[dst],
                            S[2], dmk, dsk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
                            (float4*)nullptr, (float4*)nullptr, (const double*)pa[par], pa[par ^ 1u], (const double*)nullptr,
-                           (double*)nullptr, ngr, close_only, expect);
+                           (double*)nullptr, ngr, close_only, expect, expect_rel);
       step_src = dst;
       if (!close_only) step_ppar = par ^ 1u;
     };
@@ -2991,6 +3059,11 @@ struct AlignJob {
         return MH_OK;
       }
     } else {
+      if (step_chain) {  // the serial number this chunk's first k_step16 launch has to find (its launches carry their place in the chunk)
+        ctx->h_params->sk.step_base = serial_base + step_total;
+        MH_HIP(hipMemcpyAsync(&ctx->d_params->sk.step_base, &ctx->h_params->sk.step_base, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        step_total += m * p->gn.max_inner_iterations + ((!skip_tail || enqueued + m >= p->max_iterations) ? 1u : 0u);
+      }
       // The launch sequence only depends on sizes and device pointers (the per-alignment values sit in device
       // memory), so it is captured once and replayed: one host call per chunk instead of ~4 per iteration.
       unsigned long long key[32] = {0};
