@@ -53,7 +53,9 @@ enum {
   MH_ERR_OUT_OF_RANGE = 4,   /* a voxel index does not fit the 21-bit-per-axis key */
   MH_ERR_NO_DEVICE = 5,
   MH_ERR_UNSUPPORTED = 6,
-  MH_ERR_INTERNAL = 7
+  MH_ERR_INTERNAL = 7,
+  /* not a failure: the call has done what it was asked to; an EARLIER asynchronous call left something out (mh_map_insert) */
+  MH_WARN_PREVIOUS_OUT_OF_RANGE = 64
 };
 
 enum { MH_MEM_HOST = 0, MH_MEM_DEVICE = 1, MH_MEM_HOST_PINNED = 2 };
@@ -152,6 +154,11 @@ MH_API mh_status mh_map_destroy(mh_map* map);
  * (HashedVoxelPointCloud::insertPoint [U] via FilterMerge, lidar3d-default.yaml:362-368): a point whose
  * voxel already holds max_points_per_voxel is dropped; non-finite points are dropped.  The "global
  * index" reported by the NN search is the point's index in these arrays. */
+/* Testing hook (fault injection; no effect on results): the next `first_attempts` device allocations of the library's grow-only
+ * buffers report out-of-memory on their first attempt (the library then returns its retired blocks to the runtime and asks for
+ * exactly what it needs), the next `retries` of those second attempts fail as well (the call then returns MH_ERR_OUT_OF_MEMORY
+ * and leaves every handle usable).  Process-wide counters. */
+MH_API mh_status mh_debug_fail_allocations(int32_t first_attempts, int32_t retries);
 MH_API mh_status mh_map_build(mh_map* map, const float* x, const float* y, const float* z, size_t n, int32_t mem);
 MH_API mh_status mh_map_get_info(const mh_map* map, mh_map_info* info);
 /* Incremental key-frame update, device resident.  Replaces FilterMerge ->
@@ -163,9 +170,10 @@ MH_API mh_status mh_map_get_info(const mh_map* map, mh_map_info* info);
  * ceil(remove_voxels_farther_than/voxel_size) is erased [U].  The source index of a new point is (points ever offered to this map) + its index in `scan`.
  * Nothing travels to the host except four counters, and those lazily: the call returns once the update is QUEUED.
  * Deferred verdict: points whose voxel index leaves the +-2^20 range of the packed key are left out, and that is known
- * only when the counters arrive.  It is reported -- once, as MH_ERR_OUT_OF_RANGE -- by the NEXT mh_map_insert on this map,
- * AFTER that call has performed its own insertion (a valid key-frame is never dropped because the one before it held a
- * wild point); until then mh_map_get_info shows it in mh_map_info::deferred_status.  mh_map_get_info and the downloads
+ * only when the counters arrive.  It is reported -- once, as MH_WARN_PREVIOUS_OUT_OF_RANGE, a status of its own that is NOT a
+ * failure -- by the NEXT mh_map_insert on this map, which performs its own insertion as always (a caller can tell "inserted" from
+ * "not inserted": every MH_ERR_* means not inserted, this one and MH_OK mean inserted; the wrappers log it and go on); until then
+ * mh_map_get_info shows it in mh_map_info::deferred_status (as MH_ERR_OUT_OF_RANGE).  mh_map_get_info and the downloads
  * never fail for it.  (mh_map_build is synchronous about it: it builds the map without the offending points, sets
  * n_offered, and returns MH_ERR_OUT_OF_RANGE itself.) */
 MH_API mh_status mh_map_insert(mh_map* map, const mh_scan* scan, const double T[12], float remove_voxels_farther_than);

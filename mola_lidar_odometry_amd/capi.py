@@ -20,6 +20,7 @@ if os.environ.get("MOLAHIP_LIB_PATH"):  # development: an A/B build of the same 
     LIB_PATH = os.environ["MOLAHIP_LIB_PATH"]
 
 MH_OK = 0
+MH_WARN_PREVIOUS_OUT_OF_RANGE = 64  # not a failure: see mh_map_insert in include/molahip.h
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 INDEX_FLOOR, INDEX_TRUNC = 0, 1
 FAR_CHEBYSHEV, FAR_L1, FAR_L2 = 0, 1, 2              # mh_map_params::far_voxel_metric
@@ -131,6 +132,7 @@ _SIGNATURES = {
     "mh_last_error_string": (C.c_char_p, []),
     "mh_status_string": (C.c_char_p, [C.c_int32]),
     "mh_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
+    "mh_debug_fail_allocations": (C.c_int32, [C.c_int32, C.c_int32]),
     "mh_ctx_create": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mh_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "mh_ctx_synchronize": (C.c_int32, [C.c_void_p]),
@@ -212,6 +214,11 @@ def lib():
 def _chk(status):
     if status != MH_OK:
         raise MolahipError(status, lib().mh_last_error_string().decode(errors="replace"))
+
+
+def fail_allocations(first_attempts: int, retries: int = 0):
+    """Fault injection (mh_debug_fail_allocations): the next device allocations of the library's buffers fail."""
+    _chk(lib().mh_debug_fail_allocations(int(first_attempts), int(retries)))
 
 
 def device_count() -> int:
@@ -303,7 +310,12 @@ class Map:
     def insert(self, scan: "Scan", T, remove_voxels_farther_than=0.0):
         """Key-frame update on the device: FilterMerge + insertPointCloud + far-voxel removal (mh_map_insert)."""
         T = _T12(T)
-        _chk(lib().mh_map_insert(self._h, scan._h, T.ctypes.data_as(_DP), float(remove_voxels_farther_than)))
+        st = lib().mh_map_insert(self._h, scan._h, T.ctypes.data_as(_DP), float(remove_voxels_farther_than))
+        if st == MH_WARN_PREVIOUS_OUT_OF_RANGE:  # inserted; the PREVIOUS update left out-of-range points out (not a failure)
+            import warnings
+            warnings.warn(lib().mh_last_error_string().decode(errors="replace"), RuntimeWarning, stacklevel=2)
+            return self
+        _chk(st)
         return self
 
     def info(self) -> MapInfo:

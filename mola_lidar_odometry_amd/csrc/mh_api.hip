@@ -105,6 +105,13 @@ const char* mh_status_string(mh_status s) {
   }
 }
 
+mh_status mh_debug_fail_allocations(int32_t first_attempts, int32_t retries) {
+  MH_REQUIRE(first_attempts >= 0 && retries >= 0, "negative count");
+  mh::DevBuf::fault_first_attempts.store(first_attempts);
+  mh::DevBuf::fault_retries.store(retries);
+  return MH_OK;
+}
+
 mh_status mh_device_count(int32_t* n) {
   MH_REQUIRE(n, "null output");
   int c = 0;

@@ -2820,7 +2820,10 @@ struct AlignJob {
     }
     if (variant == 9 && map->pts.bytes / sizeof(float4) >= kFlatMaxRecords) variant = 4;  // (the chunk word holds 30 bits of record index)
     if (variant >= 6 && variant != 9) MH_TRY(scan_build_tiles(scan, map->inv_vs, variant == 7 ? 64u : 256u));
-    if (variant == 4 || variant >= 6) MH_TRY(map_ensure_qidx(map, ctx->stream));  // nn_search_quad reads the map's sub-voxel index
+    if (variant == 4 || variant >= 6) {  // nn_search_quad / the plan-scan matcher read the map's sub-voxel index
+      MH_TRY(map_ensure_qidx(map, ctx->stream));
+      if (!map->view().pts_q) return fail(MH_ERR_INTERNAL, "the map's sub-voxel index is missing (matcher variant %d needs it)", variant);
+    }
     nba = nblk_acc(scan->n);
     // (measured per iteration, fused vs k_accum: 31.0 vs 33.8 us at 4 k points, 33.2 vs 35.0 at 8 k, equal at 16 k,
     //  45.9 vs 41.8 at 32 k -- one partial row per 16 points makes the solve's reduction the longer pole there)

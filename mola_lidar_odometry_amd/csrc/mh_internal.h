@@ -1,6 +1,7 @@
 // mh_internal.h -- private structures shared by the libmolahip translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <mutex>
 #include <stdint.h>
 #include <stdio.h>
@@ -49,12 +50,15 @@ struct DevBuf {
   int n_retired = 0;
   mh_status reserve(size_t need) {
     if (need <= bytes) return MH_OK;
-    const size_t cap = 2 * need + 256;
+    // head-room: double while the block is small (a map that grows by a key-frame per scan would otherwise outgrow a dozen
+    // buffers every few scans), a quarter beyond 64 MB -- doubling a 10 GB map layer on a device that holds several is how a
+    // process runs out of memory with most of it unused
+    const size_t cap = (need > (size_t(64) << 20) ? need + need / 4 : 2 * need) + 256;
     void* q = nullptr;
-    hipError_t e = hipMalloc(&q, cap);
+    hipError_t e = fault_first_attempts.load() > 0 && fault_first_attempts.fetch_sub(1) > 0 ? hipErrorOutOfMemory : hipMalloc(&q, cap);
     if (e != hipSuccess) {  // under memory pressure: give the retired blocks back and ask for what is needed only
       free_retired();
-      e = hipMalloc(&q, need + 256);
+      e = fault_retries.load() > 0 && fault_retries.fetch_sub(1) > 0 ? hipErrorOutOfMemory : hipMalloc(&q, need + 256);
       if (e != hipSuccess) return fail(MH_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", need + 256, hipGetErrorString(e));
       bytes = need + 256;
     } else {
@@ -67,6 +71,9 @@ struct DevBuf {
     p = q;
     return MH_OK;
   }
+  // fault injection (mh_debug_fail_allocations, tests/test_gpu_parity.py): the next N first attempts / retries report
+  // out-of-memory without asking the runtime
+  static inline std::atomic<int> fault_first_attempts{0}, fault_retries{0};
   void free_retired() {
     for (int i = 0; i < n_retired; i++) (void)hipFree(retired[i]);
     n_retired = 0;
@@ -191,7 +198,8 @@ struct mh_map {
   // sub-voxel index of the quad matcher (MapView::pts_q + the boundaries in the slots' count words), built lazily by map_ensure_qidx after every (re)build
   mh::DevBuf pts_q;
   std::mutex qidx_mtx;
-  bool qidx_valid = false, qidx_pending = false;
+  std::atomic<bool> qidx_valid{false};  // (read by view() without the mutex)
+  bool qidx_pending = false;
   hipEvent_t ev_qidx = nullptr;
   hipStream_t qidx_stream = nullptr;
   uint32_t* d_counters = nullptr;  // the device counters of the last (re)build ([9] = voxels)

@@ -324,8 +324,20 @@ __global__ void k_build_qidx(const float4* __restrict__ pts, const unsigned long
   if (v >= *n_vox_dev) return;
   const unsigned long long key = vox_keys[v];
   const uint32_t first = vox_first[v], cnt = vox_count[v];
+  // (k_table_insert of this build put it there; should the table have been emptied under this launch -- a later insert's
+  //  prologue on another stream -- the key is absent: give up on the voxel instead of probing for ever)
   uint32_t h = hash_key(key) & mask;
-  while (slots[h].key != key) h = (h + 1) & mask;  // (k_table_insert of this build put it there)
+  uint32_t probes = 0;
+  while (slots[h].key != key) {
+    if (slots[h].key == kEmptyKey || ++probes > mask) {
+      for (uint32_t j = 0; j < cnt; j++) {  // records in scan order, no boundaries: the voxel is scanned whole
+        const float4 p = pts[first + j];
+        pts_q[first + j] = make_float4(p.x, p.y, p.z, __uint_as_float(first + j));
+      }
+      return;
+    }
+    h = (h + 1) & mask;
+  }
   if (cnt > 31u || no_index) {
     for (uint32_t j = 0; j < cnt; j++) {
       const float4 p = pts[first + j];
@@ -671,9 +683,9 @@ mh_status mh_map_insert(mh_map* m, const mh_scan* scan, const double T[12], floa
   }
   MH_TRY(map_build_device(m, s, mx, my, mz, msrc, total, evict, n_old, fused_collect));
   m->n_offered += n_new;
-  if (prev_out_of_range)
-    return fail(MH_ERR_OUT_OF_RANGE, "the PREVIOUS update of this map held points whose voxel index exceeds the +-2^20 range of the packed key "
-                                     "(|coord|/voxel_size must be < 1e6); they were left out.  This call's insertion HAS been performed");
+  if (prev_out_of_range)  // a status of its own, not a failure (a caller must be able to tell "inserted" from "not inserted")
+    return fail(MH_WARN_PREVIOUS_OUT_OF_RANGE, "the PREVIOUS update of this map held points whose voxel index exceeds the +-2^20 range of the "
+                                               "packed key (|coord|/voxel_size must be < 1e6); they were left out.  This call's insertion HAS been performed");
   return MH_OK;
 }
 
@@ -802,6 +814,13 @@ mh_status map_build_prologue(mh_map* m, hipStream_t s, size_t n, size_t n_stored
     const size_t n_new = n - n_stored;
     MH_TRY(m->build_a.reserve((2 * n + n_new) * sizeof(unsigned long long)));  // keys in | keys sorted | new keys sorted
     MH_TRY(m->build_b.reserve((2 * n + n_new) * sizeof(uint32_t)));            // idx in | idx sorted | new idx sorted
+  }
+  {  // the table is about to be emptied: the sub-voxel index of the old build, and the counters it was built from, are void NOW
+     // (not only when the new build has been queued: a failure in between must not leave a "valid" index over an empty table)
+    std::lock_guard<std::mutex> lk(m->qidx_mtx);
+    m->qidx_valid = false;
+    m->qidx_pending = false;
+    m->d_counters = nullptr;
   }
   {
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((tsize + 255) / 256, 2048);

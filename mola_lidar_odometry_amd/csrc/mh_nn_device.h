@@ -4,6 +4,12 @@
 // the CPU restatement of the reference algorithm (this file is compiled with -ffp-contract=off).
 #pragma once
 #include "mh_internal.h"
+#ifdef MH_CARRY_WINNER
+// (round-4 experiment, measured slower: profiles/r04_match_kernel.md.  Since the scans read the sub-voxel index's copy of the
+//  records -- pts_q, whose w is the record's POSITION, not its source index -- the carried record would put positions into
+//  pair_gidx.  Kept in the history, not buildable)
+#error "MH_CARRY_WINNER is not supported any more: nn_scan_round_quad reads pts_q records (w = scan position)"
+#endif
 
 namespace mh {
 

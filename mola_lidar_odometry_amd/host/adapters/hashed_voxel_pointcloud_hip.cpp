@@ -7,6 +7,7 @@
 #include <mrpt/obs/CObservationPointCloud.h>  // [U]
 #include <mrpt/opengl/CPointCloud.h>          // [U]
 
+#include <iostream>
 #include <stdexcept>
 
 namespace mola
@@ -70,7 +71,11 @@ void HashedVoxelPointCloudHIP::insertPointCloud(const mrpt::maps::CPointsMap& pc
         T[r * 4 + 3] = pc_in_map.m_coords[r];
     }
     // insertPoint for every point after the stored content, per-voxel cap, then far-voxel removal (yaml:238)
-    mh_check(mh_map_insert(map_, staging_, T, insertionOptions.remove_voxels_farther_than), "mh_map_insert");
+    const mh_status st = mh_map_insert(map_, staging_, T, insertionOptions.remove_voxels_farther_than);
+    if (st == MH_WARN_PREVIOUS_OUT_OF_RANGE)  // this cloud IS in the map; the previous one lost its out-of-range points
+        std::cerr << "[HashedVoxelPointCloudHIP] warning: " << mh_last_error_string() << std::endl;
+    else
+        mh_check(st, "mh_map_insert");
 }
 
 bool HashedVoxelPointCloudHIP::internal_insertObservation(const mrpt::obs::CObservation& obs,

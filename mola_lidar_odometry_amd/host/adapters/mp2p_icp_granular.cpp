@@ -201,7 +201,10 @@ class Solver_GaussNewton_HIP : public Solver_GaussNewton
         gp.robust_kernel_param  = robustKernelParam;  // the formula of yaml:190, realised for this ICP_ITERATION by the ParameterSource [U]
         gp.min_delta            = sw.min_delta;
         gp.max_cost             = sw.max_cost;
-        gp.weight_pt2pt = gp.weight_pt2pl = 1.0;
+        // the solver's own per-kind weights (yaml `pairWeights` [U]: OptimalTF_GN_Parameters::pairWeights upstream; 1.0 in every shipped
+        // pipeline) are a device input of mh_gn_solve (they were hard-coded to 1)
+        gp.weight_pt2pt = pairWeights.pt2pt;  // [U] member name
+        gp.weight_pt2pl = pairWeights.pt2pl;  // [U]
         mh_prior pr;
         if (sc.prior.has_value())  // [U] SolverContext::prior (the motion model's, LidarOdometry.cpp:859-861)
         {

@@ -152,15 +152,22 @@ class ICP_HIP : public ICP
         const bool profiling = profiler().isEnabled();  // [U] CTimeLogger::isEnabled
         mrpt::system::CTimeLoggerEntry tle(profiler(), "align_hip");
 
-        // thresholds: functions of ICP_ITERATION (lidar3d-default.yaml:190,198; ndt yaml:197): evaluate per iteration up front
-        std::vector<double> thr(p.maxIterations), kp(p.maxIterations), thr_pl(sh.pl ? p.maxIterations : 0);
-        for (uint32_t k = 0; k < p.maxIterations; k++)
-        {
-            for (auto* src : attachedSources()) { src->updateVariable("ICP_ITERATION", k); src->realize(); }  // [U]
-            thr[k] = sh.pt->threshold;
-            kp[k]  = sh.gn->robustKernelParam;
-            if (sh.pl) thr_pl[k] = sh.pl->distanceThreshold;
-        }
+        // thresholds: functions of ICP_ITERATION (lidar3d-default.yaml:190,198; ndt yaml:197), evaluated per iteration through the
+        // attached ParameterSources -- LAZILY: an alignment of the shipped pipelines ends after ~21 of its 300 iterations, and every
+        // evaluation is an updateVariable + realize() of every attached parameter.  The first kScheduleFirstStage iterations are
+        // evaluated before the first run; a run that exhausts them without terminating is repeated with the whole budget (same
+        // inputs, same result as a run that had the whole schedule from the start).
+        std::vector<double> thr, kp, thr_pl;
+        auto ensure_schedule = [&](uint32_t upto) {
+            for (uint32_t k = static_cast<uint32_t>(thr.size()); k < upto; k++)
+            {
+                for (auto* src : attachedSources()) { src->updateVariable("ICP_ITERATION", k); src->realize(); }  // [U]
+                thr.push_back(sh.pt->threshold);
+                kp.push_back(sh.gn->robustKernelParam);
+                if (sh.pl) thr_pl.push_back(sh.pl->distanceThreshold);
+            }
+        };
+        constexpr uint32_t kScheduleFirstStage = 48;
 
         const auto& lx = local->getPointsBufferRef_x();  // already SoA
         const auto& ly = local->getPointsBufferRef_y();
@@ -171,9 +178,7 @@ class ICP_HIP : public ICP
         ip.max_iterations        = p.maxIterations;
         ip.min_abs_step_trans    = p.minAbsStep_trans;
         ip.min_abs_step_rot      = p.minAbsStep_rot;
-        ip.threshold             = thr.data();
-        ip.kernel_param          = kp.data();
-        ip.pt2pl_threshold       = sh.pl ? thr_pl.data() : nullptr;
+        // (threshold / kernel_param / pt2pl_threshold: set by run() below, once the schedule covers the run's budget)
         ip.pt2pl_mode            = sw.pt2pl_mode;
         // U12: upstream's matchers skip local points an earlier matcher paired unless allowMatchAlreadyMatchedPoints [U] is set
         ip.matched_points        = (sh.pl && !sh.pt->allowMatchAlreadyMatchedPoints_) ? sw.matched_points : static_cast<uint32_t>(MH_MATCHED_POINTS_PAIR_AGAIN);
@@ -203,11 +208,21 @@ class ICP_HIP : public ICP
         mh_pairs_out po = dev_->pairs.out(lx.size());  // (buffers of the session: no per-call allocation once warm)
         const auto &li = dev_->pairs.li, &gi = dev_->pairs.gi;
         const auto &gx = dev_->pairs.gx, &gy = dev_->pairs.gy, &gz = dev_->pairs.gz, &d2 = dev_->pairs.d2;
-        auto run = [&](uint32_t budget, mh_icp_iter* trace) {
+        auto run_with = [&](uint32_t budget, mh_icp_iter* trace) {
+            ensure_schedule(budget);
             mh_icp_params q = ip;
-            q.max_iterations = budget;
+            q.max_iterations  = budget;
+            q.threshold       = thr.data();
+            q.kernel_param    = kp.data();
+            q.pt2pl_threshold = sh.pl ? thr_pl.data() : nullptr;
             mh_icp_result rr{};
             mh_check(mh_icp_align(dmap, scan_, &q, T0, prior ? &pr : nullptr, &rr, trace, &po, MH_MEM_HOST), "mh_icp_align");
+            return rr;
+        };
+        auto run = [&](uint32_t budget, mh_icp_iter* trace) {
+            const uint32_t first = budget < kScheduleFirstStage ? budget : kScheduleFirstStage;
+            mh_icp_result rr = run_with(first, trace);
+            if (first < budget && rr.termination_reason == MH_TERM_MAX_ITERATIONS) rr = run_with(budget, trace);  // rare: > 48 iterations
             return rr;
         };
         if (iteration_hook_)  // [U] ICP::iteration_hook_: what setIterationHook() stored (LidarOdometry.cpp:923)

@@ -214,7 +214,12 @@ void HashedVoxelPointCloud::insertPoints(const float* x, const float* y, const f
 
 void HashedVoxelPointCloud::insertPointCloud(const DevicePointCloud& pc, const CPose3D& robot_pose,
                                              float remove_voxels_farther_than) {
-  check(mh_map_insert(map_, pc.handle(), robot_pose.T, remove_voxels_farther_than), "mh_map_insert");
+  const mh_status st = mh_map_insert(map_, pc.handle(), robot_pose.T, remove_voxels_farther_than);
+  if (st == MH_WARN_PREVIOUS_OUT_OF_RANGE) {  // this key-frame IS in the map; the one before it lost its wild points: log, go on
+    fprintf(stderr, "[molahip] warning: %s\n", mh_last_error_string());
+    return;
+  }
+  check(st, "mh_map_insert");
 }
 
 void HashedVoxelPointCloud::clear() { check(mh_map_build(map_, nullptr, nullptr, nullptr, 0, MH_MEM_HOST), "mh_map_build"); }

@@ -39,7 +39,7 @@ def _run(seq_dir, pipeline, out, env=None, time_field=True):
 
 
 @pytest.mark.gpu
-def test_city_drive_ate_below_half_a_percent_of_the_path(city_drive):
+def test_city_drive_ate_below_a_fifth_of_a_percent_of_the_path(city_drive):
     base, seq_dir, drive, gt = city_drive
     path = synth_city.path_length(drive["poses"])
     assert path > 120.0
@@ -47,8 +47,8 @@ def test_city_drive_ate_below_half_a_percent_of_the_path(city_drive):
     assert rep["scans"] == N_SCANS and rep["good"] == N_SCANS - 1, rep  # every alignment accepted (the first scan has none)
     assert len(est) == N_SCANS
     ate = trajectory.ate_rmse(est, gt, "origin")
-    # the bar VERDICT r3 set: ATE <= 0.5 % of the path; measured 0.05-0.1 %
-    assert ate <= 0.005 * path, (ate, path)
+    # VERDICT r3 set ATE <= 0.5 % of the path, r4 asked for 0.2 % now that 0.05-0.1 % is what is measured
+    assert ate <= 0.002 * path, (ate, path)
     assert trajectory.ate_rmse(est, gt, "se3") <= ate + 1e-9
     # a KITTI-like layer: a few thousand points into align(), a local map that keeps growing
     assert 800 <= rep["mean_icp_points"] <= 8000, rep
@@ -66,7 +66,7 @@ def test_city_drive_ndt_pipeline_ate(city_drive):
     rep, est = _run(seq_dir, "lidar3d-ndt-hip.yaml", os.path.join(base, "ndt.tum"))
     assert rep["scans"] == N_SCANS and rep["good"] >= N_SCANS - 2, rep
     ate = trajectory.ate_rmse(est, gt[:len(est)], "origin")
-    assert ate <= 0.005 * path, (ate, path)
+    assert ate <= 0.002 * path, (ate, path)
 
 
 @pytest.mark.gpu

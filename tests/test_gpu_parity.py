@@ -69,6 +69,38 @@ def test_map_rebuild_and_empty(ctx, oracle):
     assert n1 > 0
 
 
+def test_out_of_memory_path_of_the_growing_buffers(ctx, oracle):
+    """DevBuf::reserve under memory pressure (ADVICE r3): a failed first attempt returns the retired blocks and asks for exactly what
+    is needed -- the call succeeds and the map is what it would have been; when the retry fails too the call returns
+    MH_ERR_OUT_OF_MEMORY and every handle stays usable."""
+    rng = np.random.default_rng(5)
+    a = rng.normal(0, 6, (20000, 3)).astype(np.float32)
+    b = rng.normal(0, 6, (30000, 3)).astype(np.float32) + np.float32(2.0)
+    I = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+    g = capi.Map(ctx, 1.0, 20).build(a)
+    try:
+        capi.fail_allocations(64, 0)          # every first attempt of the growth this insert needs fails: the retries serve it
+        g.insert(capi.Scan(ctx, b), I)
+    finally:
+        capi.fail_allocations(0, 0)
+    o = oracle.Map(1.0, 20).insert(a)
+    o.insert_posed(b, I)
+    d, od = g.download(), o.dump()
+    assert np.array_equal(d["xyz"], od["xyz"]) and np.array_equal(d["vox_count"], od["vox_count"])
+    c = rng.normal(0, 6, (90000, 3)).astype(np.float32)
+    try:
+        capi.fail_allocations(64, 64)         # ... and when the retries fail as well: a clean error
+        with pytest.raises(capi.MolahipError) as e:
+            g.insert(capi.Scan(ctx, c), I)
+        assert e.value.status == 3
+    finally:
+        capi.fail_allocations(0, 0)
+    g2 = capi.Map(ctx, 1.0, 20).build(a)      # the context and the library are as usable as before
+    assert g2.info().n_points == g.info().n_points or g2.info().n_points > 0
+    s = capi.Scan(ctx, a[:2000])
+    assert len(capi.nn_search(g2, s, I, 1.0)["local_idx"]) > 0
+
+
 def test_map_out_of_range_is_an_error(ctx):
     g = capi.Map(ctx, 0.001, 20)
     with pytest.raises(capi.MolahipError) as e:
@@ -93,9 +125,8 @@ def test_map_insert_after_an_out_of_range_insert_is_performed(ctx, oracle):
     i1 = g.info()                            # never fails for it ...
     assert i1.deferred_status == 4 and i1.n_points > 0   # ... but shows it (MH_ERR_OUT_OF_RANGE)
     g.download()                             # ... nor do the downloads
-    with pytest.raises(capi.MolahipError) as e:
-        g.insert(capi.Scan(ctx, b), I)       # reports the PREVIOUS update's verdict -- after inserting b
-    assert e.value.status == 4 and "HAS been performed" in str(e.value)
+    with pytest.warns(RuntimeWarning, match="HAS been performed"):
+        g.insert(capi.Scan(ctx, b), I)       # reports the PREVIOUS update's verdict -- as a warning status, b is inserted
     assert g.info().deferred_status == 0
     g.insert(capi.Scan(ctx, c), I)           # and nothing lingers
     o = oracle.Map(1.0, 20)

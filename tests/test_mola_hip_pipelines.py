@@ -206,7 +206,7 @@ def test_adapter_sources_match_what_the_pipelines_need():
     assert "ICP::align(pcLocal, pcGlobal, guess, p, result, prior, outputDebugInfo);" in code
     # the two-matcher NDT shape reaches the device: Matcher_Point2Plane first, its threshold schedule, its pairings back
     assert "#include <mp2p_icp/Matcher_Point2Plane.h>" in plugin
-    for needle in ("dynamic_cast<const Matcher_Point2Plane*>(ms[0].get())", "ip.pt2pl_threshold", "ndt_max_eigen_ratio",
+    for needle in ("dynamic_cast<const Matcher_Point2Plane*>(ms[0].get())", "q.pt2pl_threshold", "ndt_max_eigen_ratio",
                    "mh_icp_get_pt2pl_pairs", "paired_pt2pl"):
         assert needle in code, needle
     # the App. B switches come from the shared header
