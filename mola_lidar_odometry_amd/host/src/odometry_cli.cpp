@@ -19,6 +19,7 @@
 // a host thread per sequence, their alignments merged into lock-step batches (mp2p_icp_hip::AlignBatcher).
 #include <algorithm>
 #include <chrono>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -90,6 +91,7 @@ constexpr size_t kWarmScans = 5;
 struct SequenceReport {
   std::string seq_dir, out;
   size_t scans = 0, good = 0, keyframes = 0, iterations = 0;
+  std::shared_ptr<void> keep_alive;        // the sequence's driver object (device buffers and all), destroyed after the reports
   double seconds = 0, steady_seconds = 0;  // steady: without the first kWarmScans scans (context, code objects, first map)
   size_t steady_scans = 0;
   std::string error;
@@ -180,8 +182,22 @@ void run_sequence(const std::string& pipeline, const std::string& seq_dir, const
     std::vector<double> stamps;
     list_sequence(seq_dir, max_scans, files, stamps);
 
-    mola_hip::LidarOdometry lo(std::make_shared<mp2p_icp_hip::DeviceContext>(device));
+    // MOLAHIP_STARTUP_LOG=1: where a sequence's first second goes (stderr; seconds since the process's first sequence started)
+    static const bool startup_log = getenv("MOLAHIP_STARTUP_LOG") != nullptr;
+    static const auto t_proc = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what, size_t k = 0) {
+      if (startup_log)
+        fprintf(stderr, "[startup %s] %.4f s  %s %zu\n", out.c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_proc).count(), what, k);
+    };
+    stamp("files listed");
+    // (on the heap, handed to the report at the end: its tear-down -- a hipFree per buffer, each a device-wide wait -- is not part
+    //  of the run; main() prints the reports first and then leaves without it)
+    auto lo_owner = std::make_shared<mola_hip::LidarOdometry>(std::make_shared<mp2p_icp_hip::DeviceContext>(device));
+    mola_hip::LidarOdometry& lo = *lo_owner;
+    rep.keep_alive = lo_owner;
+    stamp("device context");
     lo.initialize(mp2p_icp_hip::Config::FromYamlFile(pipeline));
+    stamp("pipeline initialised");
     if (batcher) lo.setAlignBatcher(batcher);
 
     std::vector<float> cur, nxt;  // both stay alive while the driver may still read them
@@ -199,6 +215,7 @@ void run_sequence(const std::string& pipeline, const std::string& seq_dir, const
         rep.steady_seconds += dt;
         rep.steady_scans++;
       }
+      if (k < 8 || k + 1 == files.size()) stamp("scan done", k);
       if (k + 1 == kWarmScans) lo.resetProfile();  // the stage table is the steady state's (context, code objects, first map left out)
       rep.good += rec.icp_good ? 1 : 0;
       rep.keyframes += rec.map_updated ? 1 : 0;
@@ -210,8 +227,10 @@ void run_sequence(const std::string& pipeline, const std::string& seq_dir, const
       }
     }
     lo.saveTrajectoryTUM(out);
+    stamp("trajectory saved");
     rep.profile = lo.profile();
     finish_report(lo, opt, rep);
+    stamp("report finished");
   } catch (const std::exception& e) {
     rep.error = e.what();
   }
@@ -327,6 +346,11 @@ int main(int argc, char** argv) {
   std::vector<size_t> per_slot(D, 0);
   for (size_t k = 0; k < N; k++) per_slot[slot[k]]++;
   const auto t0 = std::chrono::steady_clock::now();
+  {  // the HIP runtime is initialised ONCE, here, inside the measured wall clock -- eight threads doing it at the same moment took
+     // 0.20 s to their first context against 0.12 s (MOLAHIP_STARTUP_LOG=1)
+    int32_t n_dev = 0;
+    (void)mh_device_count(&n_dev);
+  }
   if (N == 1) {
     run_sequence(pipeline, seq_dirs[0], out, devices[0], opt, nullptr, reps[0]);
   } else {
@@ -367,7 +391,7 @@ int main(int argc, char** argv) {
       printf("}}\n");
     }
   }
-  if (N > 1) {
+  {
     // the sequences of a device advance together (one batch per round), so a device's slowest thread is its registration
     // time; the job's is the slowest device's (the makespan): steady rate = all steady scans / that
     size_t steady = 0, n_batches = 0, n_jobs = 0, f_batches = 0, f_jobs = 0, f_timeouts = 0;
@@ -401,5 +425,11 @@ int main(int argc, char** argv) {
              dev_steady_seconds[d] > 0 ? dev_steady[d] / dev_steady_seconds[d] : 0.0);
     printf("]}\n");
   }
+  // Everything asked for is on disk and on stdout.  The drivers' destructors would now hipFree a few hundred buffers one by one,
+  // each call a wait for the whole device: 0.2 s for eight sequences -- the operating system takes the memory back faster
+  // (MOLAHIP_FULL_TEARDOWN=1 runs them, e.g. under a leak checker).
+  fflush(stdout);
+  fflush(stderr);
+  if (getenv("MOLAHIP_FULL_TEARDOWN") == nullptr) _exit(rc);
   return rc;
 }

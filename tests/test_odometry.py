@@ -491,7 +491,7 @@ def test_native_cli_matches_the_python_runner(tmp_path, drive, capsys):
     out_cli = str(tmp_path / "cli.tum")
     r = subprocess.run([exe, "--pipeline", PIPE, "--seq-dir", seq_dir, "--out", out_cli], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    line = next(json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "sequence_dir" in l)  # (the summary line follows it)
     assert line["scans"] == len(drive["scans"]) and line["good"] >= line["scans"] - 2 and line["scans_per_s"] > 0
     run_odometry.main(["--kitti-root", str(tmp_path / "kitti"), "--seqs", "00", "--out-dir", str(tmp_path / "out")])
     seq = json.loads(capsys.readouterr().out.strip().splitlines()[0])
