@@ -1854,6 +1854,9 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4(const IcpDevic
 // per-record work each spread over all 64 lanes and handed on through the wave's slice of LDS.  Device-state driven like
 // k_match4 (same arguments, same pairings, bit for bit); the first Gauss-Newton accumulation is the k_accum launch that follows.
 // ================================================================================================
+#ifndef MH_FLAT_WAVES
+#define MH_FLAT_WAVES 6  // waves per SIMD the register allocator has to leave room for (80 VGPRs); the LDS allows 5.5
+#endif
 constexpr uint32_t kFlatThreads = 128;                 // two waves per workgroup: LDS granularity, nothing is shared between them
 constexpr uint32_t kFlatPointsPerBlock = kFlatThreads; // a lane per point in phase A
 __device__ __forceinline__ uint32_t nblk_flat_dev(uint32_t n) { return (n + kFlatPointsPerBlock - 1u) / kFlatPointsPerBlock; }
@@ -1889,7 +1892,7 @@ __device__ __forceinline__ void k_match_flat_body(const IcpDeviceState* __restri
   for (int k = 0; k < 12; k++) T[k] = cst->T[k];
   match_flat_wave(sh[threadIdx.x >> 6], map, T, cst->cur_thr2, cst->cur_ang2, have_prev, lx, ly, lz, n, i0, pair_q, pair_gidx, perm);
 }
-__global__ __launch_bounds__(kFlatThreads) void k_match_flat(const IcpDeviceState* __restrict__ st, const float* __restrict__ lx,
+__global__ __launch_bounds__(kFlatThreads, MH_FLAT_WAVES) void k_match_flat(const IcpDeviceState* __restrict__ st, const float* __restrict__ lx,
                                                              const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                              MapView map, float4* __restrict__ pair_q,
                                                              uint32_t* __restrict__ pair_gidx, const uint32_t* __restrict__ perm) {
@@ -2109,7 +2112,7 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4o_b(const Batch
 #endif
   );
 }
-__global__ __launch_bounds__(kFlatThreads) void k_match_flat_b(const BatchJob* __restrict__ jobs) {
+__global__ __launch_bounds__(kFlatThreads, MH_FLAT_WAVES) void k_match_flat_b(const BatchJob* __restrict__ jobs) {
   const BatchJob& j = jobs[blockIdx.y];
   k_match_flat_body(j.st, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, nullptr);
 }

@@ -67,84 +67,23 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// One wave, 64 consecutive scan points starting at `i0` (lanes past `n` idle).  perm: null, or the layer is in search
-// order and point i's pairing goes to perm[i].  Everything uniform (pose, thresholds, have_prev) comes in SGPRs.
-__device__ __forceinline__ void match_flat_wave(FlatWave& sh, const MapView& m, const double* __restrict__ T, float thr2,
-                                                float ang2, bool have_prev, const float* __restrict__ lx,
-                                                const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
-                                                uint32_t i0, float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
-                                                const uint32_t* __restrict__ perm) {
-  const uint32_t lane = (uint32_t)__lane_id();
-  const uint32_t i = i0 + lane;
-  const bool in = i < n;
-  const uint32_t ic = in ? i : n - 1;
-  const uint32_t o = perm ? G(perm)[ic] : ic;
+// Phases A2 and B for one set of candidate masks (mh_nn_flat.h's header): the wave's (point, code) pairs to LDS, a probe per
+// pair, the narrowed ranges cut into chunks, a lane per record of every chunk.  `init`: what a point's result word starts from
+// (the bound and "no record", or what an earlier stage found).  Returns the number of candidate pairs (wave-uniform); with none,
+// nothing is written to LDS.
+__device__ __forceinline__ uint32_t flat_plan_scan(FlatWave& sh, const MapView& m, uint32_t lane, uint32_t cmask, unsigned long long kbase,
+                                                   float px, float py, float pz, float b0, unsigned long long init) {
   const gslots_ptr slots4 = (gslots_ptr)m.slots;
-  const gpts_ptr pts4 = (gpts_ptr)m.pts;
   const gpts_ptr spts = (gpts_ptr)m.pts_q;
-  // ---- A1: the point ------------------------------------------------------------------------------------------------
-  const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
-  f32x4 prev = (f32x4){0.f, 0.f, 0.f, __builtin_inff()};
-  if (have_prev) prev = G(reinterpret_cast<const f32x4*>(pair_q))[o];  // grid-uniform branch
-  float px, py, pz;
-  transform_point(T, x, y, z, px, py, pz);
-  float b0 = __builtin_inff();
-  if (prev.w < __builtin_inff()) {
-    const float dx = prev.x - px, dy = prev.y - py, dz = prev.z - pz;
-    b0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic
-  }
-  const float lim = 1.0e6f;
-  const bool okrange = ((int)(fabsf(px * m.inv_vs) < lim) & (int)(fabsf(py * m.inv_vs) < lim) & (int)(fabsf(pz * m.inv_vs) < lim)) != 0;
-  bool planned = in && okrange && b0 < __builtin_inff();
-  uint32_t cmask = 0;
-  unsigned long long kbase = 0;
-  if (__ballot(planned) != 0ull) {  // wave-uniform (iteration 0: nobody)
-    const int cx = voxel_of(px, m.inv_vs, m.trunc), cy = voxel_of(py, m.inv_vs, m.trunc), cz = voxel_of(pz, m.inv_vs, m.trunc);
-    kbase = pack_key(cx - 1, cy - 1, cz - 1);
-    const Gaps gx = axis_gaps(px, cx, m.vs, m.trunc), gy = axis_gaps(py, cy, m.vs, m.trunc), gz = axis_gaps(pz, cz, m.vs, m.trunc);
-    cmask = 1u << 13;
-    // Seven tests instead of twenty-six when, for every planned lane of the wave, the FAR face of each axis is out of reach
-    // (the usual case once the bound is below a quarter voxel): a code that contains a far side has a lower bound >= that
-    // face's (non-negative terms, monotone rounding), so only the codes built from the near sides can pass -- the same mask.
-    const float fx = fmaxf(gx.s[0], gx.s[2]), fy = fmaxf(gy.s[0], gy.s[2]), fz = fmaxf(gz.s[0], gz.s[2]);
-    const bool far_dead = (fx * 0.9999f > b0) && (fy * 0.9999f > b0) && (fz * 0.9999f > b0);
-    if (__ballot(planned && !far_dead) == 0ull) {  // wave-uniform
-      const bool xl = gx.s[0] <= gx.s[2], yl = gy.s[0] <= gy.s[2], zl = gz.s[0] <= gz.s[2];
-      const float nx = xl ? gx.s[0] : gx.s[2], ny = yl ? gy.s[0] : gy.s[2], nz = zl ? gz.s[0] : gz.s[2];
-      const uint32_t cx_ = xl ? 4u : 22u, cy_ = yl ? 10u : 16u, cz_ = zl ? 12u : 14u;  // 13 -/+ 9, 3, 1
-      const uint32_t dx_ = cx_ - 13u, dy_ = cy_ - 13u;                               // (mod 2^32)
-      const float lxy = nx + ny;
-      cmask |= (!(nx * 0.9999f > b0)) ? (1u << cx_) : 0u;
-      cmask |= (!(ny * 0.9999f > b0)) ? (1u << cy_) : 0u;
-      cmask |= (!(nz * 0.9999f > b0)) ? (1u << cz_) : 0u;
-      cmask |= (!(lxy * 0.9999f > b0)) ? (1u << (cy_ + dx_)) : 0u;
-      cmask |= (!((nx + nz) * 0.9999f > b0)) ? (1u << (cz_ + dx_)) : 0u;
-      cmask |= (!((ny + nz) * 0.9999f > b0)) ? (1u << (cz_ + dy_)) : 0u;
-      cmask |= (!((lxy + nz) * 0.9999f > b0)) ? (1u << (cz_ + dx_ + dy_)) : 0u;
-    } else {
-#pragma unroll
-      for (int c = 0; c < 27; c++) {
-        if (c == 13) continue;
-        const int ix = c / 9, iy = (c / 3) % 3, iz = c % 3;
-        const float sx = ix == 1 ? 0.f : gx.s[ix], sy = iy == 1 ? 0.f : gy.s[iy], sz = iz == 1 ? 0.f : gz.s[iz];
-        const float lb = ((sx + sy) + sz) * 0.9999f;  // quad_bounds' expression
-        cmask |= (!(lb > b0)) ? (1u << c) : 0u;
-      }
-    }
-    if (!planned) cmask = 0;
-    if (__builtin_popcount(cmask) > kFlatMaxCand) {  // a loose bound near a voxel corner: the quad search, with the bound
-      planned = false;
-      cmask = 0;
-    }
-  }
+  uint32_t n_cands;
   const uint32_t ncand = (uint32_t)__builtin_popcount(cmask);
   const uint32_t cincl = wave_scan_incl(ncand);
-  const uint32_t n_cands = (uint32_t)__builtin_amdgcn_readlane((int)cincl, 63);
+  n_cands = (uint32_t)__builtin_amdgcn_readlane((int)cincl, 63);
   sh.P[lane] = (f32x4){px, py, pz, b0};
   uint32_t nvalid = 0;  // chunks written (wave-uniform)
   if (n_cands) {        // wave-uniform
     sh.KB[lane] = kbase;
-    sh.RES[lane] = ((unsigned long long)__float_as_uint(b0) << 32) | 0xFFFFFFFFull;
+    sh.RES[lane] = init;
     sh.SLOWF[lane] = 0;
     if (lane == 0) { sh.NCH = 0; sh.NVALID = (uint32_t)kFlatMaxChunks; }
     {
@@ -284,12 +223,111 @@ __device__ __forceinline__ void match_flat_wave(FlatWave& sh, const MapView& m, 
     }
     wave_sync_lds_nn();
   }
+  return n_cands;
+}
+
+// One wave, 64 consecutive scan points starting at `i0` (lanes past `n` idle).  perm: null, or the layer is in search
+// order and point i's pairing goes to perm[i].  Everything uniform (pose, thresholds, have_prev) comes in SGPRs.
+__device__ __forceinline__ void match_flat_wave(FlatWave& sh, const MapView& m, const double* __restrict__ T, float thr2,
+                                                float ang2, bool have_prev, const float* __restrict__ lx,
+                                                const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                uint32_t i0, float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
+                                                const uint32_t* __restrict__ perm) {
+  const uint32_t lane = (uint32_t)__lane_id();
+  const uint32_t i = i0 + lane;
+  const bool in = i < n;
+  const uint32_t ic = in ? i : n - 1;
+  const uint32_t o = perm ? G(perm)[ic] : ic;
+  const gslots_ptr slots4 = (gslots_ptr)m.slots;
+  const gpts_ptr pts4 = (gpts_ptr)m.pts;
+  const gpts_ptr spts = (gpts_ptr)m.pts_q;
+  // ---- A1: the point ------------------------------------------------------------------------------------------------
+  const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
+  f32x4 prev = (f32x4){0.f, 0.f, 0.f, __builtin_inff()};
+  if (have_prev) prev = G(reinterpret_cast<const f32x4*>(pair_q))[o];  // grid-uniform branch
+  float px, py, pz;
+  transform_point(T, x, y, z, px, py, pz);
+  float b0 = __builtin_inff();
+  if (prev.w < __builtin_inff()) {
+    const float dx = prev.x - px, dy = prev.y - py, dz = prev.z - pz;
+    b0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic
+  }
+  const float lim = 1.0e6f;
+  const bool okrange = ((int)(fabsf(px * m.inv_vs) < lim) & (int)(fabsf(py * m.inv_vs) < lim) & (int)(fabsf(pz * m.inv_vs) < lim)) != 0;
+  // Points WITHOUT a bound (ICP iteration 0; a point whose old partner was not found) get one first: stage 0 plans and scans
+  // their OWN voxel only -- what the quad search does first, but as lane-per-record work -- and the nearest record of it, if
+  // there is one, bounds stage 1, where these points join the others with the own voxel already done.  A wave none of whose
+  // points lacks a bound starts at stage 1.
+  const bool unbounded = in && okrange && !(b0 < __builtin_inff());
+  bool own_done = false;            // stage 0 found a record in the own voxel: RES holds it, b0 is its distance
+  unsigned long long res0 = 0;
+  bool planned = false;
+  uint32_t n_cands = 0;
+  const int cx = voxel_of(px, m.inv_vs, m.trunc), cy = voxel_of(py, m.inv_vs, m.trunc), cz = voxel_of(pz, m.inv_vs, m.trunc);
+  const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
+  if (__ballot(unbounded) != 0ull) {  // stage 0 (wave-uniform): the own voxel of the points that have no bound
+    n_cands = flat_plan_scan(sh, m, lane, unbounded ? (1u << 13) : 0u, kbase, px, py, pz, b0, 0x7F800000FFFFFFFFull);
+    const unsigned long long r0 = sh.RES[lane];  // (n_cands > 0: somebody is unbounded)
+    if (unbounded && (uint32_t)r0 != 0xFFFFFFFFu && sh.SLOWF[lane] == 0) {  // what it found becomes the bound of stage 1
+      own_done = true;
+      res0 = r0;
+      b0 = __uint_as_float((uint32_t)(r0 >> 32));
+    }
+    wave_sync_lds_nn();  // (stage 1 rewrites P, RES, SLOWF and the lists)
+  }
+  uint32_t cmask = 0;
+  planned = in && okrange && b0 < __builtin_inff();
+  if (__ballot(planned) != 0ull) {  // wave-uniform
+    const Gaps gx = axis_gaps(px, cx, m.vs, m.trunc), gy = axis_gaps(py, cy, m.vs, m.trunc), gz = axis_gaps(pz, cz, m.vs, m.trunc);
+    cmask = 1u << 13;
+    // Seven tests instead of twenty-six when, for every planned lane of the wave, the FAR face of each axis is out of reach
+    // (the usual case once the bound is below a quarter voxel): a code that contains a far side has a lower bound >= that
+    // face's (non-negative terms, monotone rounding), so only the codes built from the near sides can pass -- the same mask.
+    const float fx = fmaxf(gx.s[0], gx.s[2]), fy = fmaxf(gy.s[0], gy.s[2]), fz = fmaxf(gz.s[0], gz.s[2]);
+    const bool far_dead = (fx * 0.9999f > b0) && (fy * 0.9999f > b0) && (fz * 0.9999f > b0);
+    if (__ballot(planned && !far_dead) == 0ull) {  // wave-uniform
+      const bool xl = gx.s[0] <= gx.s[2], yl = gy.s[0] <= gy.s[2], zl = gz.s[0] <= gz.s[2];
+      const float nx = xl ? gx.s[0] : gx.s[2], ny = yl ? gy.s[0] : gy.s[2], nz = zl ? gz.s[0] : gz.s[2];
+      const uint32_t cx_ = xl ? 4u : 22u, cy_ = yl ? 10u : 16u, cz_ = zl ? 12u : 14u;  // 13 -/+ 9, 3, 1
+      const uint32_t dx_ = cx_ - 13u, dy_ = cy_ - 13u;                               // (mod 2^32)
+      const float lxy = nx + ny;
+      cmask |= (!(nx * 0.9999f > b0)) ? (1u << cx_) : 0u;
+      cmask |= (!(ny * 0.9999f > b0)) ? (1u << cy_) : 0u;
+      cmask |= (!(nz * 0.9999f > b0)) ? (1u << cz_) : 0u;
+      cmask |= (!(lxy * 0.9999f > b0)) ? (1u << (cy_ + dx_)) : 0u;
+      cmask |= (!((nx + nz) * 0.9999f > b0)) ? (1u << (cz_ + dx_)) : 0u;
+      cmask |= (!((ny + nz) * 0.9999f > b0)) ? (1u << (cz_ + dy_)) : 0u;
+      cmask |= (!((lxy + nz) * 0.9999f > b0)) ? (1u << (cz_ + dx_ + dy_)) : 0u;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 27; c++) {
+        if (c == 13) continue;
+        const int ix = c / 9, iy = (c / 3) % 3, iz = c % 3;
+        const float sx = ix == 1 ? 0.f : gx.s[ix], sy = iy == 1 ? 0.f : gy.s[iy], sz = iz == 1 ? 0.f : gz.s[iz];
+        const float lb = ((sx + sy) + sz) * 0.9999f;  // quad_bounds' expression
+        cmask |= (!(lb > b0)) ? (1u << c) : 0u;
+      }
+    }
+    if (!planned) cmask = 0;
+    if (own_done) cmask &= ~(1u << 13);  // (scanned in stage 0)
+    if (__builtin_popcount(cmask) > kFlatMaxCand) {  // a loose bound near a voxel corner: the quad search, with the bound
+      planned = false;
+      cmask = 0;
+    }
+  }
+  n_cands = flat_plan_scan(sh, m, lane, cmask, kbase, px, py, pz, b0,
+                           own_done ? res0 : (((unsigned long long)__float_as_uint(b0) << 32) | 0xFFFFFFFFull));
   // ---- C: the pairing ----------------------------------------------------------------------------------------------------
   bool slow = in && !planned;
   float b0s = b0;  // the bound phase D starts from
-  if (n_cands) {
-    const unsigned long long res = sh.RES[lane];
-    const bool spilled = sh.SLOWF[lane] != 0;
+  {
+    // (a wave whose stage 1 had no candidate at all has written nothing to LDS in it: a point that stage 0 served keeps its result)
+    unsigned long long res = own_done ? res0 : 0xFFFFFFFFFFFFFFFFull;
+    bool spilled = false;
+    if (n_cands) {
+      res = sh.RES[lane];
+      spilled = sh.SLOWF[lane] != 0;
+    }
     const uint32_t idx = (uint32_t)res;
     if (planned && !spilled && idx != 0xFFFFFFFFu) {
       const f32x4 w = pts4[idx];
