@@ -430,6 +430,8 @@ int main(int argc, char** argv) {
   // (MOLAHIP_FULL_TEARDOWN=1 runs them, e.g. under a leak checker).
   fflush(stdout);
   fflush(stderr);
-  if (getenv("MOLAHIP_FULL_TEARDOWN") == nullptr) _exit(rc);
+  // (exit(), not _exit(): handlers registered with atexit -- a profiler's finalisation, the runtime's own -- still run; the
+  //  drivers, held by `reps` on this frame, are not destroyed by it)
+  if (getenv("MOLAHIP_FULL_TEARDOWN") == nullptr) exit(rc);
   return rc;
 }

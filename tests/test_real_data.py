@@ -110,7 +110,7 @@ def _run_cli(pipeline, seq_dir, out, max_scans=None, env=None):
     e.update(env or {})
     r = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=3600)
     assert r.returncode == 0, r.stderr[-2000:]
-    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    return next(json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "sequence_dir" in l)  # (a summary line follows)
 
 
 @pytest.mark.gpu
