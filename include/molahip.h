@@ -332,6 +332,23 @@ enum { MH_MATCHED_POINTS_PAIR_AGAIN = 0, MH_MATCHED_POINTS_SKIP = 1 };
 
 MH_API mh_status mh_nn_search_pt2pl(const mh_map* map, const mh_scan* scan, const double T[12], double distance_threshold,
                                     uint32_t mode, const mh_pairs_pl_out* out, int32_t mem, mh_match_info* info);
+/* The same matcher on a map WITHOUT plane statistics -- a mola::HashedVoxelPointCloud layer, /root/reference/pipelines/rgbd.yaml:143-151
+ * (distanceThreshold 0.40, planeEigenThreshold 1e-2, searchRadius 0.80, knn 10, minimumPlanePoints 6); SURVEY 8a row a13 "otherwise
+ * KNN + PCA" [U]: per transformed local point the knn nearest map points of the 27-voxel block (nn_multiple_search [U]), those
+ * with d^2 < searchRadius^2 (a prefix: ascending distances), none if fewer than max(3, minimumPlanePoints); mean + covariance of
+ * them (fp64), eigenvalues e0 <= e1 <= e2; a plane iff e2 > 0 and e0 <= planeEigenThreshold * e2; normal = unit eigenvector of e0
+ * (sign: largest component positive -- the residual and its Jacobian are even in n); pairing {centroid, normal, local point} iff
+ * |n.(p'-c)| <= distanceThreshold.  Output as mh_nn_search_pt2pl; works on any map (the NDT statistics, if any, are not used). */
+#define MH_MAX_PLANE_KNN 16
+typedef struct {
+  double distance_threshold;      /* [m] */
+  double plane_eigen_threshold;   /* e0 / e2 */
+  double search_radius;           /* [m] */
+  uint32_t knn;                   /* 3 .. MH_MAX_PLANE_KNN */
+  uint32_t minimum_plane_points;  /* >= 3 */
+} mh_pt2pl_knn_params;
+MH_API mh_status mh_nn_search_pt2pl_knn(const mh_map* map, const mh_scan* scan, const double T[12], const mh_pt2pl_knn_params* params,
+                                        const mh_pairs_pl_out* out, int32_t mem, mh_match_info* info);
 
 /* ------------------------------------------------------------------------------------------------
  * Solver-granular path.  Replaces mp2p_icp::Solver_GaussNewton::impl_optimal_pose /

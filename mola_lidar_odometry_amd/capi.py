@@ -58,6 +58,11 @@ class PairsOut(C.Structure):
     _fields_ = [("local_idx", _UP), ("global_idx", _UP), ("gx", _FP), ("gy", _FP), ("gz", _FP), ("d2", _FP)]
 
 
+class Pt2PlKnnParams(C.Structure):
+    _fields_ = [("distance_threshold", C.c_double), ("plane_eigen_threshold", C.c_double), ("search_radius", C.c_double),
+                ("knn", C.c_uint32), ("minimum_plane_points", C.c_uint32)]
+
+
 class PairsPlOut(C.Structure):
     _fields_ = [("local_idx", _UP), ("cx", _FP), ("cy", _FP), ("cz", _FP), ("nx", _FP), ("ny", _FP), ("nz", _FP)]
 
@@ -171,6 +176,8 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_int32]),
     "mh_nn_search_pt2pl": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.c_double, C.c_uint32, C.POINTER(PairsPlOut), C.c_int32,
                                        C.POINTER(MatchInfo)]),
+    "mh_nn_search_pt2pl_knn": (C.c_int32, [C.c_void_p, C.c_void_p, _DP, C.POINTER(Pt2PlKnnParams), C.POINTER(PairsPlOut), C.c_int32,
+                                           C.POINTER(MatchInfo)]),
     "mh_icp_get_pt2pl_pairs": (C.c_int32, [C.c_void_p, C.POINTER(PairsPlOut), C.c_int32, C.POINTER(C.c_uint64)]),
     "mh_gn_solve": (C.c_int32, [C.c_void_p, C.POINTER(PairsPt2Pt), C.POINTER(PairsPt2Pl), C.c_int32,
                                 C.POINTER(GNParamsC), C.POINTER(Prior), _DP, C.POINTER(C.c_int32),
@@ -516,6 +523,18 @@ def nn_search_pt2pl(m: Map, s: Scan, T, distance_threshold, mode=PT2PL_PLANE_DIS
     T = _T12(T)
     _chk(lib().mh_nn_search_pt2pl(m._h, s._h, T.ctypes.data_as(_DP), float(distance_threshold), int(mode), C.byref(out),
                                   MEM_HOST, C.byref(info)))
+    k = int(info.n_pairs)
+    return dict(local_idx=li[:k].copy(), centroid=np.stack(a[:3], 1)[:k].copy(), normal=np.stack(a[3:], 1)[:k].copy(),
+                potential_pairings=int(info.potential_pairings))
+
+
+def nn_search_pt2pl_knn(m: Map, s: Scan, T, distance_threshold, plane_eigen_threshold, search_radius, knn, minimum_plane_points):
+    """Matcher_Point2Plane on a plain point map: k nearest neighbours + PCA (mh_nn_search_pt2pl_knn; rgbd.yaml:143-151)."""
+    li, a, out = _pl_arrays(max(s.n, 1))
+    info = MatchInfo()
+    T = _T12(T)
+    pr = Pt2PlKnnParams(float(distance_threshold), float(plane_eigen_threshold), float(search_radius), int(knn), int(minimum_plane_points))
+    _chk(lib().mh_nn_search_pt2pl_knn(m._h, s._h, T.ctypes.data_as(_DP), C.byref(pr), C.byref(out), MEM_HOST, C.byref(info)))
     k = int(info.n_pairs)
     return dict(local_idx=li[:k].copy(), centroid=np.stack(a[:3], 1)[:k].copy(), normal=np.stack(a[3:], 1)[:k].copy(),
                 potential_pairings=int(info.potential_pairings))

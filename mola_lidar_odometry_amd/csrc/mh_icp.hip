@@ -323,6 +323,104 @@ __global__ __launch_bounds__(kBlock) void k_match_kbest(PoseArg Targ, float thr2
     pair_gidx[(size_t)i * k + r] = (found && d2 < lim) ? __float_as_uint(pt.w) : kNoMatch;
   }
 }
+// Matcher_Point2Plane on a plain point map (pipelines/rgbd.yaml:143-151; SURVEY 8a row a13 "otherwise KNN + PCA" [U]): one lane
+// per point -- the knn nearest records of the 27-voxel block (nn_search_kbest), the prefix of them inside the search radius,
+// mean + covariance in fp64, cyclic Jacobi (the operation sequence of k_ndt_stats and of the oracle), plane test e0 <= thr * e2,
+// distance test in fp64.  pl_c = {centroid, 1 | 0}, pl_n = {unit normal (largest component positive), 0}: what the
+// point-to-plane rows and compact_pl_pairs read.  Not on a target pipeline's path: exactness first.
+struct PlKnnArg {
+  double distance_threshold, plane_eigen_threshold;
+  float radius2;
+  uint32_t knn, min_pts;
+};
+__global__ __launch_bounds__(kBlock) void k_match_pl_knn(PoseArg Targ, PlKnnArg a, const float* __restrict__ lx, const float* __restrict__ ly,
+                                                         const float* __restrict__ lz, uint32_t n, MapView map, float4* __restrict__ pl_c,
+                                                         float4* __restrict__ pl_n) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  double T[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) T[j] = Targ.m[j];
+  float px, py, pz;
+  transform_point(T, lx[i], ly[i], lz[i], px, py, pz);
+  float4 rc = make_float4(0.f, 0.f, 0.f, 0.f), rn = make_float4(0.f, 0.f, 0.f, 0.f);
+  knnkey_t best[kMaxPlaneKnn];
+  nn_search_kbest(map, px, py, pz, a.knn, best);
+  // ascending distances: the neighbours inside the radius are a prefix of the list
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int r = 0; r < kMaxPlaneKnn; r++) {
+    const bool in = (uint32_t)r < a.knn && best[r] != ~0ull && __uint_as_float((uint32_t)(best[r] >> 32)) < a.radius2;
+    cnt += (in && cnt == (uint32_t)r) ? 1u : 0u;
+  }
+  if (cnt >= a.min_pts) {
+    const gpts_ptr pts4 = (gpts_ptr)map.pts;
+    f32x4 nb[kMaxPlaneKnn];
+#pragma unroll
+    for (int r = 0; r < kMaxPlaneKnn; r++) nb[r] = pts4[(uint32_t)r < cnt ? (uint32_t)best[r] : (uint32_t)best[0]];
+    double mu[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < kMaxPlaneKnn; r++)
+      if ((uint32_t)r < cnt) { mu[0] += (double)nb[r].x; mu[1] += (double)nb[r].y; mu[2] += (double)nb[r].z; }
+    mu[0] /= (double)cnt; mu[1] /= (double)cnt; mu[2] /= (double)cnt;
+    double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+#pragma unroll
+    for (int r = 0; r < kMaxPlaneKnn; r++)
+      if ((uint32_t)r < cnt) {
+        const double d0 = (double)nb[r].x - mu[0], d1 = (double)nb[r].y - mu[1], d2 = (double)nb[r].z - mu[2];
+        c00 += d0 * d0; c01 += d0 * d1; c02 += d0 * d2; c11 += d1 * d1; c12 += d1 * d2; c22 += d2 * d2;
+      }
+    const double inv = (double)(cnt - 1);
+    double A[3][3] = {{c00 / inv, c01 / inv, c02 / inv}, {c01 / inv, c11 / inv, c12 / inv}, {c02 / inv, c12 / inv, c22 / inv}};
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 12; sweep++) {
+#pragma unroll
+      for (int pq = 0; pq < 3; pq++) {
+        const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2, r = 3 - p - q;
+        const double apq = A[p][q];
+        if (apq != 0.0) {
+          const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+          const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+          const double app = A[p][p] - t * apq, aqq = A[q][q] + t * apq;
+          const double arp = c * A[r][p] - sn * A[r][q], arq = sn * A[r][p] + c * A[r][q];
+          A[p][p] = app; A[q][q] = aqq; A[p][q] = 0.0; A[q][p] = 0.0;
+          A[r][p] = arp; A[p][r] = arp; A[r][q] = arq; A[q][r] = arq;
+#pragma unroll
+          for (int v = 0; v < 3; v++) {
+            const double vip = c * V[v][p] - sn * V[v][q], viq = sn * V[v][p] + c * V[v][q];
+            V[v][p] = vip; V[v][q] = viq;
+          }
+        }
+      }
+    }
+    // smallest / largest eigenvalue, the eigenvector of the smallest (first minimum: the oracle's stable sort)
+    const double w0 = A[0][0], w1 = A[1][1], w2 = A[2][2];
+    int imin = 0;
+    double wmin = w0, wmax = w0;
+    if (w1 < wmin) { wmin = w1; imin = 1; }
+    if (w2 < wmin) { wmin = w2; imin = 2; }
+    if (w1 > wmax) wmax = w1;
+    if (w2 > wmax) wmax = w2;
+    if (wmax > 0.0 && !(wmin > a.plane_eigen_threshold * wmax)) {
+      double nv[3] = {imin == 0 ? V[0][0] : (imin == 1 ? V[0][1] : V[0][2]), imin == 0 ? V[1][0] : (imin == 1 ? V[1][1] : V[1][2]),
+                      imin == 0 ? V[2][0] : (imin == 1 ? V[2][1] : V[2][2])};
+      const double len = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+      int big = 0;
+      if (fabs(nv[1]) > fabs(nv[big])) big = 1;
+      if (fabs(nv[2]) > fabs(nv[big])) big = 2;
+      const double sgn = ((big == 0 ? nv[0] : (big == 1 ? nv[1] : nv[2])) < 0.0 ? -1.0 : 1.0) / len;
+      nv[0] *= sgn; nv[1] *= sgn; nv[2] *= sgn;
+      const double dist = fabs((nv[0] * ((double)px - mu[0]) + nv[1] * ((double)py - mu[1])) + nv[2] * ((double)pz - mu[2]));
+      if (!(dist > a.distance_threshold)) {
+        rc = make_float4((float)mu[0], (float)mu[1], (float)mu[2], 1.f);
+        rn = make_float4((float)nv[0], (float)nv[1], (float)nv[2], 0.f);
+      }
+    }
+  }
+  pl_c[i] = rc;
+  pl_n[i] = rn;
+}
 __global__ void k_div_idx(uint32_t* __restrict__ idx, uint32_t n, uint32_t k) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) idx[i] /= k;
@@ -4071,6 +4169,42 @@ mh_status mh_nn_search_pt2pl(const mh_map* map, const mh_scan* scan, const doubl
   hipLaunchKernelGGL(k_match_pl<false>, dim3(nblk(scan->n)), dim3(kBlock), 0, ctx->stream, ctx->d_state, Ta,
                      (float)distance_threshold, &ctx->d_params->mk, scan->x, scan->y, scan->z, (uint32_t)scan->n, map->view(),
                      ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>(), (double*)nullptr, 0u);
+  MH_HIP(hipGetLastError());
+  mh_pairs_pl_out none{};
+  uint64_t np = 0;
+  MH_TRY(compact_pl_pairs(ctx, scan->n, out ? out : &none, mem, &np));
+  if (info) info->n_pairs = np;
+  return MH_OK;
+}
+
+mh_status mh_nn_search_pt2pl_knn(const mh_map* map, const mh_scan* scan, const double T[12], const mh_pt2pl_knn_params* params,
+                                 const mh_pairs_pl_out* out, int32_t mem, mh_match_info* info) {
+  MH_REQUIRE(map && scan && T && params, "null argument");
+  MH_REQUIRE(mem == MH_MEM_HOST || mem == MH_MEM_DEVICE, "bad mem space");
+  MH_REQUIRE(map->ctx->device == scan->ctx->device, "map and scan live on different devices");
+  MH_REQUIRE(pose_ok(T), "non-finite pose");
+  MH_REQUIRE(params->knn >= 3 && params->knn <= (uint32_t)kMaxPlaneKnn, "knn must be 3..MH_MAX_PLANE_KNN");
+  MH_REQUIRE(isfinite(params->distance_threshold) && isfinite(params->plane_eigen_threshold) && isfinite(params->search_radius) &&
+             params->search_radius > 0.0, "bad thresholds");
+  mh_ctx* ctx = scan->ctx;
+  MH_TRY(set_device(ctx));
+  MH_TRY(map_ready_on(map, ctx->stream));
+  if (info) {
+    info->n_pairs = 0;
+    info->potential_pairings = scan->n;
+  }
+  if (scan->n == 0) return MH_OK;
+  MH_TRY(ensure_pl_buffers(ctx, scan->n));
+  PoseArg Ta;
+  for (int i = 0; i < 12; i++) Ta.m[i] = T[i];
+  PlKnnArg a;
+  a.distance_threshold = params->distance_threshold;
+  a.plane_eigen_threshold = params->plane_eigen_threshold;
+  a.radius2 = (float)(params->search_radius * params->search_radius);
+  a.knn = params->knn;
+  a.min_pts = params->minimum_plane_points < 3u ? 3u : params->minimum_plane_points;  // (three points span a plane)
+  hipLaunchKernelGGL(k_match_pl_knn, dim3(nblk(scan->n)), dim3(kBlock), 0, ctx->stream, Ta, a, scan->x, scan->y, scan->z,
+                     (uint32_t)scan->n, map->view(), ctx->pl_c.as<float4>(), ctx->pl_n.as<float4>());
   MH_HIP(hipGetLastError());
   mh_pairs_pl_out none{};
   uint64_t np = 0;

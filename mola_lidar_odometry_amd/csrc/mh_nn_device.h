@@ -329,27 +329,31 @@ __device__ __forceinline__ NNResult nn_search_pruned(const MapView& m, float qx,
 // order, ties to the earlier scan position) kept sorted in registers by a chain of compare-exchanges, voxels pruned against
 // the k-th smallest so far with the bound of nn_search_pruned.  Not a hot path of either target pipeline: exactness first.
 // -------------------------------------------------------------------------------------------------
-constexpr int kMaxKnn = 8;
+constexpr int kMaxKnn = 8;         // Matcher_Points_DistanceThreshold::pairingsPerPoint (MH_MAX_PAIRINGS_PER_POINT)
+constexpr int kMaxPlaneKnn = 16;   // Matcher_Point2Plane::knn on a plain point map (MH_MAX_PLANE_KNN; rgbd.yaml:148 uses 10)
 typedef unsigned long long knnkey_t;
-__device__ __forceinline__ void knn_insert(knnkey_t (&best)[kMaxKnn], knnkey_t key) {
-  if (!(key < best[kMaxKnn - 1])) return;
-  best[kMaxKnn - 1] = key;
+template <int CAP>
+__device__ __forceinline__ void knn_insert(knnkey_t (&best)[CAP], knnkey_t key) {
+  if (!(key < best[CAP - 1])) return;
+  best[CAP - 1] = key;
 #pragma unroll
-  for (int t = kMaxKnn - 1; t > 0; t--) {
+  for (int t = CAP - 1; t > 0; t--) {
     const knnkey_t a = best[t - 1], b = best[t];
     const bool sw = b < a;
     best[t - 1] = sw ? b : a;
     best[t] = sw ? a : b;
   }
 }
-__device__ __forceinline__ knnkey_t knn_select(const knnkey_t (&best)[kMaxKnn], uint32_t r) {
+template <int CAP>
+__device__ __forceinline__ knnkey_t knn_select(const knnkey_t (&best)[CAP], uint32_t r) {
   knnkey_t v = best[0];
 #pragma unroll
-  for (int t = 1; t < kMaxKnn; t++) v = r == (uint32_t)t ? best[t] : v;
+  for (int t = 1; t < CAP; t++) v = r == (uint32_t)t ? best[t] : v;
   return v;
 }
+template <int CAP>
 __device__ __forceinline__ void knn_visit(const MapView& m, gslots_ptr slots4, gpts_ptr pts4, unsigned long long key, float qx,
-                                          float qy, float qz, knnkey_t (&best)[kMaxKnn]) {
+                                          float qy, float qz, knnkey_t (&best)[CAP]) {
   uint32_t h = hash_key(key) & m.mask;
   u32x4 sl = slots4[h];
   unsigned long long sk = ((unsigned long long)sl.y << 32) | sl.x;
@@ -364,14 +368,15 @@ __device__ __forceinline__ void knn_visit(const MapView& m, gslots_ptr slots4, g
     const f32x4 c = pts4[sl.z + j];
     const float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
     const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order (bit-exact with the oracle)
-    knn_insert(best, ((knnkey_t)__float_as_uint(d2) << 32) | (knnkey_t)(sl.z + j));
+    knn_insert<CAP>(best, ((knnkey_t)__float_as_uint(d2) << 32) | (knnkey_t)(sl.z + j));
   }
 }
 // best[] ascending on return; entries never filled stay ~0
+template <int CAP>
 __device__ __forceinline__ void nn_search_kbest(const MapView& m, float qx, float qy, float qz, uint32_t k,
-                                                knnkey_t (&best)[kMaxKnn]) {
+                                                knnkey_t (&best)[CAP]) {
 #pragma unroll
-  for (int t = 0; t < kMaxKnn; t++) best[t] = ~0ull;
+  for (int t = 0; t < CAP; t++) best[t] = ~0ull;
   const float lim = 1.0e6f;
   if (!((int)(fabsf(qx * m.inv_vs) < lim) & (int)(fabsf(qy * m.inv_vs) < lim) & (int)(fabsf(qz * m.inv_vs) < lim))) return;
   const int cx = voxel_of(qx, m.inv_vs, m.trunc), cy = voxel_of(qy, m.inv_vs, m.trunc), cz = voxel_of(qz, m.inv_vs, m.trunc);
@@ -379,15 +384,15 @@ __device__ __forceinline__ void nn_search_kbest(const MapView& m, float qx, floa
   const gslots_ptr slots4 = (gslots_ptr)m.slots;
   const gpts_ptr pts4 = (gpts_ptr)m.pts;
   const Gaps gx = axis_gaps(qx, cx, m.vs, m.trunc), gy = axis_gaps(qy, cy, m.vs, m.trunc), gz = axis_gaps(qz, cz, m.vs, m.trunc);
-  knn_visit(m, slots4, pts4, nn_key_of(kbase, 13), qx, qy, qz, best);
+  knn_visit<CAP>(m, slots4, pts4, nn_key_of(kbase, 13), qx, qy, qz, best);
 #pragma unroll 1
   for (int c = 0; c < 27; c++) {
     if (c == 13) continue;
     // the k-th smallest distance so far (+inf while fewer than k were found: the key's high word is then 0xFFFFFFFF = NaN,
     // and `lb > NaN` is false -- the voxel is visited)
-    const float bound = __uint_as_float((uint32_t)(knn_select(best, k - 1) >> 32));
+    const float bound = __uint_as_float((uint32_t)(knn_select<CAP>(best, k - 1) >> 32));
     if (nn_lower_bound(c, gx, gy, gz) * 0.9999f > bound) continue;
-    knn_visit(m, slots4, pts4, nn_key_of(kbase, c), qx, qy, qz, best);
+    knn_visit<CAP>(m, slots4, pts4, nn_key_of(kbase, c), qx, qy, qz, best);
   }
 }
 

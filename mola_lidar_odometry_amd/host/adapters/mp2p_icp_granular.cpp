@@ -97,7 +97,8 @@ class Matcher_Points_DistanceThreshold_HIP : public Matcher_Points_DistanceThres
 };
 IMPLEMENTS_MRPT_OBJECT(Matcher_Points_DistanceThreshold_HIP, mp2p_icp::Matcher_Points_DistanceThreshold, mp2p_icp)
 
-/** Drop-in for mp2p_icp::Matcher_Point2Plane on a mola::NDT global layer (lidar3d-ndt.yaml:195-200, 236-254). */
+/** Drop-in for mp2p_icp::Matcher_Point2Plane on a mola::NDT global layer (lidar3d-ndt.yaml:195-200, 236-254) and, since round 5,
+ *  on a plain mola::HashedVoxelPointCloud layer (KNN + PCA, rgbd.yaml:143-151; knn <= MH_MAX_PLANE_KNN). */
 class Matcher_Point2Plane_HIP : public Matcher_Point2Plane
 {
     DEFINE_MRPT_OBJECT(Matcher_Point2Plane_HIP, mp2p_icp)
@@ -114,11 +115,17 @@ class Matcher_Point2Plane_HIP : public Matcher_Point2Plane
                                   (allowMatchAlreadyMatchedPoints_ || ms.localPairedBitField.point_layers.count(localName) == 0 ||
                                    ms.localPairedBitField.point_layers.at(localName).none());
         mh_map* dmap = nullptr;
+        bool knn_path = false;
         DeviceSession* dev = nullptr;
         if (!sw.force_cpu && device_shape)
         {
             dev  = &DeviceSession::process_wide();
-            dmap = dev->device_map_of(pcGlobal, true);  // an NDT map (per-voxel planes); anything else: upstream's KNN + PCA branch
+            dmap = dev->device_map_of(pcGlobal, true);  // an NDT map: per-voxel planes
+            if (!dmap && knn >= 3 && knn <= MH_MAX_PLANE_KNN)
+            {   // a plain point layer (mola::HashedVoxelPointCloud, rgbd.yaml:143-151): k nearest neighbours + PCA on the device
+                dmap     = dev->device_map_of(pcGlobal, false);
+                knn_path = dmap != nullptr;
+            }
         }
         if (!dmap) return Matcher_Point2Plane::implMatchOneLayer(pcGlobal, pcLocal, localPose, ms, globalName, localName, out);
 
@@ -129,7 +136,18 @@ class Matcher_Point2Plane_HIP : public Matcher_Point2Plane
         pose_to_T12(localPose, T);
         mh_pairs_pl_out po = dev->planes.out(n);
         mh_match_info info{};
-        mh_check(mh_nn_search_pt2pl(dmap, scan, T, distanceThreshold, sw.pt2pl_mode, &po, MH_MEM_HOST, &info), "mh_nn_search_pt2pl");
+        if (knn_path)
+        {
+            mh_pt2pl_knn_params kp{};  // [U] the upstream members DECLARE_PARAMETER'd from the yaml keys of rgbd.yaml:145-149
+            kp.distance_threshold    = distanceThreshold;
+            kp.plane_eigen_threshold = planeEigenThreshold;
+            kp.search_radius         = searchRadius;
+            kp.knn                   = knn;
+            kp.minimum_plane_points  = minimumPlanePoints;
+            mh_check(mh_nn_search_pt2pl_knn(dmap, scan, T, &kp, &po, MH_MEM_HOST, &info), "mh_nn_search_pt2pl_knn");
+        }
+        else
+            mh_check(mh_nn_search_pt2pl(dmap, scan, T, distanceThreshold, sw.pt2pl_mode, &po, MH_MEM_HOST, &info), "mh_nn_search_pt2pl");
         out.potential_pairings += info.potential_pairings;
         const auto& lx = pcLocal.getPointsBufferRef_x();
         const auto& ly = pcLocal.getPointsBufferRef_y();

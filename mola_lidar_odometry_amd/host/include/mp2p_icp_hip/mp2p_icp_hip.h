@@ -328,12 +328,14 @@ class Matcher_Points_DistanceThreshold : public Matcher {
                   const MatchContext& mc, Pairings& out) const override;
 };
 
-// mp2p_icp::Matcher_Point2Plane [U] (lidar3d-ndt.yaml:195-200) against an NDT global layer.  The KNN/PCA knobs of the
-// upstream class (knn, planeEigenThreshold, minimumPlanePoints, searchRadius: used with non-NDT maps, rgbd.yaml:143-150)
-// are accepted and ignored.
+// mp2p_icp::Matcher_Point2Plane [U]: against an NDT global layer (lidar3d-ndt.yaml:195-200) the per-voxel planes; against a plain
+// HashedVoxelPointCloud layer (rgbd.yaml:143-151) the k nearest neighbours + PCA with the upstream knobs knn,
+// planeEigenThreshold, minimumPlanePoints, searchRadius (round 5: mh_nn_search_pt2pl_knn; knn <= MH_MAX_PLANE_KNN).
 class Matcher_Point2Plane : public Matcher {
  public:
   double distanceThreshold = 0.5;
+  double planeEigenThreshold = 0.01, searchRadius = 1.0;  // [U] defaults; every pipeline that uses them sets them
+  uint32_t knn = 5, minimumPlanePoints = 5;
   bool allowMatchAlreadyMatchedGlobalPoints = true;
   std::vector<Matcher_Points_DistanceThreshold::LayerMatch> pointLayerMatches;
   void initialize(const Config& params) override;

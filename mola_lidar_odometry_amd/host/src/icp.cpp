@@ -373,6 +373,10 @@ void Matcher_Points_DistanceThreshold::impl_match(const metric_map_t& pcGlobal, 
 
 void Matcher_Point2Plane::initialize(const Config& c) {
   parameterFromConfig(c, "distanceThreshold", &distanceThreshold, true);
+  parameterFromConfig(c, "planeEigenThreshold", &planeEigenThreshold, false);
+  parameterFromConfig(c, "searchRadius", &searchRadius, false);
+  if (c.has("knn")) knn = to_u32(c["knn"].asString());
+  if (c.has("minimumPlanePoints")) minimumPlanePoints = to_u32(c["minimumPlanePoints"].asString());
   if (c.has("allowMatchAlreadyMatchedGlobalPoints"))
     allowMatchAlreadyMatchedGlobalPoints = to_bool(c["allowMatchAlreadyMatchedGlobalPoints"].asString());
   if (c.has("runFromIteration")) runFromIteration = to_u32(c["runFromIteration"].asString());
@@ -420,8 +424,14 @@ void Matcher_Point2Plane::impl_match(const metric_map_t& pcGlobal, const metric_
     for (auto& v : a) v.resize(n);
     mh_pairs_pl_out po{li.data(), a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), a[5].data()};
     mh_match_info info{};
-    const mh_status st = mh_nn_search_pt2pl(glob.handle(), scan, localPose.T, distanceThreshold,
-                                            molahip_host::plugin_switches().pt2pl_mode, &po, MH_MEM_HOST, &info);
+    mh_status st;
+    if (dynamic_cast<const NDT*>(&glob)) {  // per-voxel planes
+      st = mh_nn_search_pt2pl(glob.handle(), scan, localPose.T, distanceThreshold, molahip_host::plugin_switches().pt2pl_mode, &po,
+                              MH_MEM_HOST, &info);
+    } else {  // a plain point layer: k nearest neighbours + PCA (rgbd.yaml:143-151)
+      mh_pt2pl_knn_params kp{distanceThreshold, planeEigenThreshold, searchRadius, knn, minimumPlanePoints};
+      st = mh_nn_search_pt2pl_knn(glob.handle(), scan, localPose.T, &kp, &po, MH_MEM_HOST, &info);
+    }
     mh_scan_destroy(scan);
     check(st, "mh_nn_search_pt2pl");
     append_pl_pairs(loc, li, a, info.n_pairs, out);

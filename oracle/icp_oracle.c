@@ -677,6 +677,61 @@ size_t orc_match_pt2pl(const orc_map* m, const float* lx, const float* ly, const
   return np;
 }
 
+/* Matcher_Point2Plane on a plain point map: k nearest neighbours + PCA (semantics: icp_oracle.h; rgbd.yaml:143-151) */
+size_t orc_match_pt2pl_knn(const orc_map* m, const float* lx, const float* ly, const float* lz, size_t n, const double T[12],
+                           const orc_pt2pl_knn_params* p, uint32_t* local_idx, float* cx, float* cy, float* cz, float* nx,
+                           float* ny, float* nz) {
+  const uint32_t k = p->knn ? p->knn : 1;
+  const uint32_t min_pts = p->minimum_plane_points < 3 ? 3 : p->minimum_plane_points;
+  const float r2 = (float)(p->search_radius * p->search_radius);
+  float* pts = (float*)malloc(sizeof(float) * 3 * k);
+  float* dd = (float*)malloc(sizeof(float) * k);
+  uint32_t* gi = (uint32_t*)malloc(sizeof(uint32_t) * k);
+  size_t np = 0;
+  for (size_t i = 0; i < n; i++) {
+    float px, py, pz;
+    transform_pt(T, lx[i], ly[i], lz[i], &px, &py, &pz);
+    if (!isfinite(px) || !isfinite(py) || !isfinite(pz)) continue;
+    const int found = orc_map_nn_multiple(m, px, py, pz, k, pts, dd, gi);
+    uint32_t cnt = 0;
+    while ((int)cnt < found && dd[cnt] < r2) cnt++; /* ascending distances: the neighbours inside the radius are a prefix */
+    if (cnt < min_pts) continue;
+    double mu[3] = {0, 0, 0};
+    for (uint32_t j = 0; j < cnt; j++)
+      for (int a = 0; a < 3; a++) mu[a] += (double)pts[3 * j + a];
+    for (int a = 0; a < 3; a++) mu[a] /= (double)cnt;
+    double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (uint32_t j = 0; j < cnt; j++) {
+      const double d[3] = {(double)pts[3 * j] - mu[0], (double)pts[3 * j + 1] - mu[1], (double)pts[3 * j + 2] - mu[2]};
+      for (int a = 0; a < 3; a++)
+        for (int b = a; b < 3; b++) C[a][b] += d[a] * d[b];
+    }
+    for (int a = 0; a < 3; a++)
+      for (int b = a; b < 3; b++) {
+        C[a][b] /= (double)(cnt - 1);
+        C[b][a] = C[a][b];
+      }
+    double w[3], V[3][3];
+    jacobi3(C, w, V);
+    if (!(w[2] > 0.0) || w[0] > p->plane_eigen_threshold * w[2]) continue;
+    double nrm[3] = {V[0][0], V[1][0], V[2][0]};
+    const double len = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    int big = 0;
+    for (int a = 1; a < 3; a++)
+      if (fabs(nrm[a]) > fabs(nrm[big])) big = a;
+    const double sgn = (nrm[big] < 0.0 ? -1.0 : 1.0) / len;
+    for (int a = 0; a < 3; a++) nrm[a] *= sgn;
+    const double dist = fabs((nrm[0] * ((double)px - mu[0]) + nrm[1] * ((double)py - mu[1])) + nrm[2] * ((double)pz - mu[2]));
+    if (dist > p->distance_threshold) continue;
+    local_idx[np] = (uint32_t)i;
+    cx[np] = (float)mu[0]; cy[np] = (float)mu[1]; cz[np] = (float)mu[2];
+    nx[np] = (float)nrm[0]; ny[np] = (float)nrm[1]; nz[np] = (float)nrm[2];
+    np++;
+  }
+  free(pts); free(dd); free(gi);
+  return np;
+}
+
 /* ======================================================================================
  * Solver -- optimal_tf_gauss_newton (Appendix A)
  * ==================================================================================== */

@@ -130,6 +130,22 @@ size_t orc_match_points_k(const orc_map* m, const float* lx, const float* ly, co
 size_t orc_match_pt2pl(const orc_map* m, const float* lx, const float* ly, const float* lz, size_t n, const double T[12],
                        double distance_threshold, uint32_t* local_idx, float* cx, float* cy, float* cz, float* nx,
                        float* ny, float* nz, int n_threads);
+/* ---- the same matcher on a map WITHOUT plane statistics (pipelines/rgbd.yaml:143-151: a HashedVoxelPointCloud layer; SURVEY 8a
+ * row a13 "otherwise KNN + PCA") [U] -- restated from the parameter list of the reference's own pipeline (distanceThreshold,
+ * planeEigenThreshold, searchRadius, knn, minimumPlanePoints) and the documented reading: per transformed local point p'
+ *   nn_multiple_search(p', knn) (the k nearest of the 3x3x3 block, ascending (d^2, scan position));
+ *   the neighbours with d^2 < searchRadius^2 (fp32; ascending distances: a prefix); fewer than max(3, minimumPlanePoints) -> none;
+ *   their mean and covariance (fp64, 1/(m-1)), eigenvalues e0 <= e1 <= e2 (cyclic Jacobi, as the NDT statistics);
+ *   a plane iff e2 > 0 and e0 <= planeEigenThreshold * e2;  normal = eigenvector of e0 (unit; sign: largest component > 0 -- the
+ *   residual n.(p-c) and its Jacobian are even in n);  pairing {centroid, normal, local point} iff |n.(p'-c)| <= distanceThreshold
+ *   (fp64).  Pairs in ascending local index; arrays sized n. */
+typedef struct {
+  double distance_threshold, plane_eigen_threshold, search_radius;
+  uint32_t knn, minimum_plane_points;
+} orc_pt2pl_knn_params;
+size_t orc_match_pt2pl_knn(const orc_map* m, const float* lx, const float* ly, const float* lz, size_t n, const double T[12],
+                           const orc_pt2pl_knn_params* p, uint32_t* local_idx, float* cx, float* cy, float* cz, float* nx,
+                           float* ny, float* nz);
 /* NDT statistics of the occupied voxels in ascending key order (same order as orc_map_dump): centroid, normal,
  * is_plane flag; arrays of orc_map_num_voxels() entries. */
 void orc_map_dump_ndt(const orc_map* m, float* cx, float* cy, float* cz, float* nx, float* ny, float* nz,

@@ -103,6 +103,11 @@ class _PairsOut(C.Structure):
     _fields_ = [("local_idx", _UP), ("global_idx", _UP), ("gx", _FP), ("gy", _FP), ("gz", _FP), ("d2", _FP)]
 
 
+class _Pt2PlKnnParams(C.Structure):
+    _fields_ = [("distance_threshold", C.c_double), ("plane_eigen_threshold", C.c_double), ("search_radius", C.c_double),
+                ("knn", C.c_uint32), ("minimum_plane_points", C.c_uint32)]
+
+
 _lib = None
 
 
@@ -131,6 +136,8 @@ def lib():
         L.orc_match_pt2pl.argtypes = [C.c_void_p, _FP, _FP, _FP, C.c_size_t, _DP, C.c_double, _UP, _FP, _FP, _FP, _FP, _FP,
                                       _FP, C.c_int]
         L.orc_map_dump_ndt.argtypes = [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _UP]
+        L.orc_match_pt2pl_knn.restype = C.c_size_t
+        L.orc_match_pt2pl_knn.argtypes = [C.c_void_p, _FP, _FP, _FP, C.c_size_t, _DP, C.POINTER(_Pt2PlKnnParams), _UP] + [_FP] * 6
         L.orc_gn_solve.restype = C.c_int
         L.orc_gn_solve.argtypes = [C.POINTER(_PairsPt2Pt), C.POINTER(_PairsPt2Pl), C.POINTER(_GNParams),
                                    C.POINTER(_Prior), _DP, C.POINTER(_GNStep), C.c_int]
@@ -347,6 +354,19 @@ def match_points_k(m: Map, local_xyz, T, threshold, k, threshold_angular_deg=0.0
             _up(gi), _fp(gx), _fp(gy), _fp(gz), _fp(d2), C.byref(st))
     return dict(local_idx=li[:np_].copy(), global_idx=gi[:np_].copy(), global_xyz=np.stack([gx[:np_], gy[:np_], gz[:np_]], 1),
                 d2=d2[:np_].copy(), potential_pairings=int(st.potential_pairings))
+
+
+def match_pt2pl_knn(m: Map, local_xyz, T, distance_threshold, plane_eigen_threshold, search_radius, knn, minimum_plane_points):
+    """Matcher_Point2Plane on a plain point map (rgbd.yaml:143-151): k nearest neighbours + PCA (orc_match_pt2pl_knn)."""
+    l = np.asarray(local_xyz, dtype=np.float32).reshape(-1, 3)
+    n = len(l)
+    lx, ly, lz = _f32(l[:, 0]), _f32(l[:, 1]), _f32(l[:, 2])
+    li = np.zeros(max(n, 1), np.uint32)
+    c = [np.zeros(max(n, 1), np.float32) for _ in range(6)]
+    pr = _Pt2PlKnnParams(float(distance_threshold), float(plane_eigen_threshold), float(search_radius), int(knn), int(minimum_plane_points))
+    T12 = np.ascontiguousarray(T, dtype=np.float64).reshape(12)
+    k = lib().orc_match_pt2pl_knn(m._h, _fp(lx), _fp(ly), _fp(lz), n, _dp(T12), C.byref(pr), _up(li), *[_fp(a) for a in c])
+    return dict(local_idx=li[:k].copy(), centroid=np.stack([c[0][:k], c[1][:k], c[2][:k]], 1), normal=np.stack([c[3][:k], c[4][:k], c[5][:k]], 1))
 
 
 def match_pt2pl(m: Map, local_xyz, T, distance_threshold, n_threads=1, mode=PT2PL_PLANE_DISTANCE):

@@ -69,6 +69,34 @@ def test_map_rebuild_and_empty(ctx, oracle):
     assert n1 > 0
 
 
+@pytest.mark.parametrize("voxel,knn,min_pts,trunc", [(0.5, 10, 6, False), (1.0, 5, 3, False), (0.4, 16, 8, False), (0.5, 10, 6, True)])
+def test_point2plane_matcher_on_a_plain_point_map_knn_pca(ctx, oracle, voxel, knn, min_pts, trunc):
+    """Matcher_Point2Plane where the global layer has no plane statistics (pipelines/rgbd.yaml:143-151: a HashedVoxelPointCloud
+    layer; SURVEY 8a row a13 "otherwise KNN + PCA"): mh_nn_search_pt2pl_knn against the oracle's restatement -- the same index
+    set, centroids and normals to rounding -- under a non-trivial pose, incl. points that find too few neighbours."""
+    from mola_lidar_odometry_amd import synth
+    cloud = synth.ndt_cloud(5)
+    rng = np.random.default_rng(21)
+    T = np.array([0.9986295, -0.0523360, 0.0, 0.3, 0.0523360, 0.9986295, 0.0, -0.2, 0.0, 0.0, 1.0, 0.05], np.float64)  # 3 deg yaw
+    Ti = np.linalg.inv(np.vstack([T.reshape(3, 4), [0, 0, 0, 1]]))
+    q_map = cloud[rng.choice(len(cloud), 4000, replace=False)] + rng.normal(0, 0.05, (4000, 3)).astype(np.float32)
+    far = rng.uniform(30, 40, (50, 3)).astype(np.float32)                       # nothing near: no pairing
+    q = ((np.concatenate([q_map, far]).astype(np.float64) @ Ti[:3, :3].T) + Ti[:3, 3]).astype(np.float32)
+    mode = capi.INDEX_TRUNC if trunc else capi.INDEX_FLOOR
+    g = capi.Map(ctx, voxel, 20, index_mode=mode).build(cloud)
+    o = oracle.Map(voxel, 20, index_mode=oracle.INDEX_TRUNC if trunc else oracle.INDEX_FLOOR).insert(cloud)
+    thr, eig_thr, radius = 0.08, 2e-2, 0.6
+    r = capi.nn_search_pt2pl_knn(g, capi.Scan(ctx, q), T, thr, eig_thr, radius, knn, min_pts)
+    e = oracle.match_pt2pl_knn(o, q, T, thr, eig_thr, radius, knn, min_pts)
+    assert r["potential_pairings"] == len(q)
+    assert len(e["local_idx"]) > 500 and e["local_idx"].max() < 4000
+    assert np.array_equal(r["local_idx"], e["local_idx"])
+    assert np.allclose(r["centroid"], e["centroid"], atol=1e-6)
+    assert np.allclose(r["normal"], e["normal"], atol=1e-6)
+    with pytest.raises(capi.MolahipError):
+        capi.nn_search_pt2pl_knn(g, capi.Scan(ctx, q), T, thr, eig_thr, radius, 17, min_pts)   # beyond MH_MAX_PLANE_KNN
+
+
 def test_out_of_memory_path_of_the_growing_buffers(ctx, oracle):
     """DevBuf::reserve under memory pressure (ADVICE r3): a failed first attempt returns the retired blocks and asks for exactly what
     is needed -- the call succeeds and the map is what it would have been; when the retry fails too the call returns

@@ -485,3 +485,78 @@ def test_two_pairings_per_point_match_an_oracle_loop(hl, oracle, small_workload)
     assert res.nIterations == it
     np.testing.assert_allclose(res.pose(), T, atol=1e-7)
     assert res.n_pairs() == n_pairs and res.quality == pytest.approx(n_pairs / (2 * len(w.scan_xyz)), abs=1e-12)
+
+
+_RGBD_ICP = """
+class_name: mp2p_icp::ICP
+params:
+  maxIterations: 30
+  minAbsStep_trans: 1e-4
+  minAbsStep_rot: 5e-5
+solvers:
+  - class: mp2p_icp::Solver_GaussNewton
+    params:
+      maxIterations: 2
+      robustKernel: 'RobustKernel::GemanMcClure'
+      robustKernelParam: 0.3
+matchers:
+  - class: mp2p_icp::Matcher_Points_DistanceThreshold
+    params:
+      threshold: 0.9
+      thresholdAngularDeg: 0.5
+      pairingsPerPoint: 2
+      allowMatchAlreadyMatchedGlobalPoints: true
+      pointLayerMatches:
+        - {global: "localmap", local: "decimated_for_icp", weight: 1.0}
+  - class: mp2p_icp::Matcher_Point2Plane
+    params:
+      distanceThreshold: 0.40
+      planeEigenThreshold: 1e-2
+      searchRadius: 0.80
+      knn: 10
+      minimumPlanePoints: 6
+      pointLayerMatches:
+        - {global: "localmap", local: "decimated_for_icp", weight: 1.0}
+quality:
+  - class: mp2p_icp::QualityEvaluator_PairedRatio
+    params:
+      ~
+"""
+
+
+@pytest.mark.gpu
+def test_rgbd_shaped_icp_block_point_pairs_and_knn_pca_planes_match_an_oracle_loop(hl, oracle, small_workload):
+    """The ICP block shape of the reference's pipelines/rgbd.yaml:118-151 -- Matcher_Points_DistanceThreshold with two pairings
+    per point, then Matcher_Point2Plane on a plain HashedVoxelPointCloud layer (k nearest neighbours + PCA: mh_nn_search_pt2pl_knn,
+    round 5) -- through the plugin-API mirror, against the same loop written with the oracle's matchers and solver."""
+    w = small_workload
+    l, g, _ = _maps(hl, w)
+    icp, params = hl.icp_pipeline_from_yaml(hl.Config.FromYamlText(_RGBD_ICP))
+    res = icp.align(l, g, hl.TPose3D(*w.guess_ypr), params)
+    assert not icp.lastAlignUsedFusedPath()
+
+    om = oracle.Map(w.voxel_size, w.cap).insert(w.map_xyz)
+    T, Tprev, term, it, n_pairs, n_pl = w.T_guess.copy(), w.T_guess.copy(), "MaxIterations", 0, 0, 0
+    for it in range(30):
+        r = oracle.match_points_k(om, w.scan_xyz, T, 0.9, 2, 0.5)
+        q = oracle.match_pt2pl_knn(om, w.scan_xyz, T, 0.40, 1e-2, 0.80, 10, 6)
+        n_pl = len(q["local_idx"])
+        n_pairs = len(r["local_idx"]) + n_pl
+        if n_pairs == 0:
+            term = "NoPairings"
+            break
+        T = oracle.gn_solve(T, pt2pt=(w.scan_xyz[r["local_idx"]], r["global_xyz"]),
+                            pt2pl=(w.scan_xyz[q["local_idx"]], q["centroid"], q["normal"]),
+                            params=oracle.GNParams(max_inner_iterations=2, robust_kernel_param=0.3))[0]
+        d = oracle.se3_log(oracle.pose_compose(oracle.pose_inverse(Tprev), T))
+        if np.linalg.norm(d[:3]) < 1e-4 and np.linalg.norm(d[3:]) < 5e-5:
+            term = "Stalled"
+            break
+        Tprev = T.copy()
+    else:
+        it = 30
+    assert n_pl > 100  # the street canyon's ground and facades give planes
+    assert res.terminationReason.name == term
+    assert res.nIterations == it
+    np.testing.assert_allclose(res.pose(), T, atol=1e-7)
+    assert res.n_pairs() == n_pairs
