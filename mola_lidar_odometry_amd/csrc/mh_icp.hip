@@ -1982,6 +1982,8 @@ __device__ __forceinline__ void k_match_flat_body(const IcpDeviceState* __restri
   // in runs of MH_FLAT_XCD consecutive workgroups' worth of points: run c of the layer goes to XCD c % 8
   const uint32_t xj = blockIdx.x / 8u;
   const uint32_t bx = ((xj / (uint32_t)(MH_FLAT_XCD)) * 8u + blockIdx.x % 8u) * (uint32_t)(MH_FLAT_XCD) + xj % (uint32_t)(MH_FLAT_XCD);
+#elif defined(MH_FLAT_REVERSE)
+  const uint32_t bx = gridDim.x - 1u - blockIdx.x;  // (A/B: the layer's last points first)
 #else
   const uint32_t bx = blockIdx.x;
 #endif

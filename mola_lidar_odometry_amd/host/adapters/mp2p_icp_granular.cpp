@@ -184,8 +184,9 @@ class Solver_GaussNewton_HIP : public Solver_GaussNewton
     {
         const auto& sw = molahip_host::plugin_switches();
         const bool only_points_and_planes = pairings.paired_pt2ln.empty() && pairings.paired_ln2ln.empty() && pairings.paired_pl2pl.empty();  // [U]
-        // per-pair weights other than 1 (Pairings::point_weights [U]: a per-layer weight != 1) are not a device input
-        if (sw.force_cpu || !only_points_and_planes || !pairings.point_weights.empty() || !sc.guessRelativePose.has_value())
+        // Pairings::point_weights [U] = {(pairs, weight)} runs over paired_pt2pt: ONE run (every point pair from layers of the same
+        // weight) is a device input; several runs are not
+        if (sw.force_cpu || !only_points_and_planes || pairings.point_weights.size() > 1 || !sc.guessRelativePose.has_value())
             return Solver_GaussNewton::impl_optimal_pose(pairings, out, sc);
 
         DeviceSession& dev = DeviceSession::process_wide();
@@ -221,7 +222,7 @@ class Solver_GaussNewton_HIP : public Solver_GaussNewton
         gp.max_cost             = sw.max_cost;
         // the solver's own per-kind weights (yaml `pairWeights` [U]: OptimalTF_GN_Parameters::pairWeights upstream; 1.0 in every shipped
         // pipeline) are a device input of mh_gn_solve (they were hard-coded to 1)
-        gp.weight_pt2pt = pairWeights.pt2pt;  // [U] member name
+        gp.weight_pt2pt = pairWeights.pt2pt * (pairings.point_weights.empty() ? 1.0 : pairings.point_weights[0].second);  // [U] member names
         gp.weight_pt2pl = pairWeights.pt2pl;  // [U]
         mh_prior pr;
         if (sc.prior.has_value())  // [U] SolverContext::prior (the motion model's, LidarOdometry.cpp:859-861)

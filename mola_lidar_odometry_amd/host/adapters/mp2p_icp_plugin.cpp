@@ -25,7 +25,8 @@
 // Pipeline shapes taken by the fused device loop (anything else is delegated to the upstream CPU ICP::align):
 //   lidar3d-default.yaml:184-204   one Solver_GaussNewton, matchers = [Matcher_Points_DistanceThreshold]
 //   lidar3d-ndt.yaml:184-210       one Solver_GaussNewton, matchers = [Matcher_Point2Plane, Matcher_Points_DistanceThreshold]
-// both with one {global, local, weight: 1} entry in pointLayerMatches (yaml :203-204), pairingsPerPoint 1.
+// both with one {global, local, weight} entry in pointLayerMatches (yaml :203-204; the point matcher's weight may differ from 1
+// since round 5), pairingsPerPoint 1.
 // Global layers read: mola::HashedVoxelPointCloud (yaml:230), mola::NDT (ndt yaml:236) -- through their point / voxel
 // visitors, they are NOT mrpt::maps::CPointsMap --, mola::HashedVoxelPointCloudHIP (device owned, no mirror), and any
 // CPointsMap (pipelines/extras/localmap_definition_pointmap.ini).
@@ -107,13 +108,18 @@ struct Shape
     const Matcher_Point2Plane*              pl = nullptr;  // nullptr: lidar3d-default shape
     const Solver_GaussNewton*               gn = nullptr;
     std::string globalLayer, localLayer;
+    double ptLayerWeight = 1.0;  // pointLayerMatches {..., weight} of the point matcher (yaml:203-204)
 };
 
-template <class M> bool single_unit_layer(const M& m, std::string& g, std::string& l)
+template <class M> bool single_unit_layer(const M& m, std::string& g, std::string& l, double* weight_out = nullptr)
 {
     if (m.weight_pt2pt_layers.size() != 1) return false;                     // [U] {global -> {local -> weight}}
     const auto& [gname, locals] = *m.weight_pt2pt_layers.begin();
-    if (locals.size() != 1 || locals.begin()->second != 1.0) return false;  // per-layer weights != 1: not in the fused path
+    if (locals.size() != 1) return false;
+    // a weight != 1 of the point matcher's layer pair is a device input (round 5); the plane matcher's stays at 1 (what upstream
+    // does with it is unverified)
+    if (weight_out) *weight_out = locals.begin()->second;
+    else if (locals.begin()->second != 1.0) return false;
     if (!g.empty() && (g != gname || l != locals.begin()->first)) return false;  // both matchers on the same layers (ndt yaml:199-200,209-210)
     g = gname;
     l = locals.begin()->first;
@@ -189,7 +195,8 @@ class ICP_HIP : public ICP
         ip.gn.robust_kernel      = molahip_host::kernel_from_upstream_name(kname.c_str(), sw);
         ip.gn.min_delta          = sw.min_delta;
         ip.gn.max_cost           = sw.max_cost;
-        ip.gn.weight_pt2pt = ip.gn.weight_pt2pl = 1.0;
+        ip.gn.weight_pt2pt = sh.ptLayerWeight;  // Pairings::point_weights [U]: one layer pair, one weight
+        ip.gn.weight_pt2pl = 1.0;
         ip.compute_covariance    = 1;
         ip.cov_findif_xyz        = sw.cov_step_xyz;
         ip.cov_findif_ang        = sw.cov_step_ang;
@@ -329,7 +336,7 @@ class ICP_HIP : public ICP
         }
         if (!sh.pt || sh.pt->pairingsPerPoint != 1 || !sh.pt->allowMatchAlreadyMatchedGlobalPoints) return false;
         if (sh.pt->runFromIteration != 0 || sh.pt->runUpToIteration != 0) return false;  // [U] iteration gates: unused by both files
-        return single_unit_layer(*sh.pt, sh.globalLayer, sh.localLayer);
+        return single_unit_layer(*sh.pt, sh.globalLayer, sh.localLayer, &sh.ptLayerWeight);
     }
 
     std::unique_ptr<molahip_mrpt::DeviceSession> dev_;  // context, map mirrors, staging scan, result buffers

@@ -253,6 +253,10 @@ struct Pairings {  // mp2p_icp::Pairings::paired_pt2pt as SoA (+ pt2pl)
   // point-to-plane: local point, plane centroid, plane normal
   std::vector<float> pl_lx, pl_ly, pl_lz, pl_cx, pl_cy, pl_cz, pl_nx, pl_ny, pl_nz;
   size_t potential_pairings = 0;
+  // role of Pairings::point_weights [U]: the `weight` of the pointLayerMatches entry that produced the point pairs (yaml:203-204).
+  // The device solver takes ONE weight per kind of pair: layers with different weights in one pairing set are refused.
+  double pt2pt_weight = 1.0, pt2pl_weight = 1.0;
+  bool pt2pt_weight_set = false, pt2pl_weight_set = false;
   // role of MatchState::localPairedBitField [U]: per local layer, which points the matchers of THIS iteration have paired so
   // far -- read by later matchers when MOLA_HIP_MATCHED_POINTS=skip (allowMatchAlreadyMatchedPoints = false upstream, U12)
   std::map<std::string, std::vector<uint8_t>> local_paired;

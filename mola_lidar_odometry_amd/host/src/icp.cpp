@@ -337,6 +337,10 @@ void Matcher_Points_DistanceThreshold::impl_match(const metric_map_t& pcGlobal, 
     const HashedVoxelPointCloud& glob = global_layer(pcGlobal, lm.global);
     const size_t n = loc.size();
     out.potential_pairings += n * pairingsPerPoint;
+    if (out.pt2pt_weight_set && out.pt2pt_weight != lm.weight)
+      throw std::runtime_error("pointLayerMatches with different weights in one pairing set: not a device input (one weight per kind of pair)");
+    out.pt2pt_weight = lm.weight;
+    out.pt2pt_weight_set = true;
     if (!n) continue;
     mh_scan* scan = nullptr;
     check(mh_scan_create(glob.context()->get(), loc.x.data(), loc.y.data(), loc.z.data(), n, MH_MEM_HOST, &scan), "mh_scan_create");
@@ -416,6 +420,10 @@ void Matcher_Point2Plane::impl_match(const metric_map_t& pcGlobal, const metric_
     const HashedVoxelPointCloud& glob = global_layer(pcGlobal, lm.global);
     const size_t n = loc.size();
     out.potential_pairings += n;
+    if (out.pt2pl_weight_set && out.pt2pl_weight != lm.weight)
+      throw std::runtime_error("Matcher_Point2Plane layers with different weights in one pairing set: not a device input");
+    out.pt2pl_weight = lm.weight;  // [U] whether upstream applies a layer weight to plane pairs is unverified; every shipped pipeline has 1.0
+    out.pt2pl_weight_set = true;
     if (!n) continue;
     mh_scan* scan = nullptr;
     check(mh_scan_create(glob.context()->get(), loc.x.data(), loc.y.data(), loc.z.data(), n, MH_MEM_HOST, &scan), "mh_scan_create");
@@ -484,7 +492,9 @@ bool Solver_GaussNewton::optimal_pose(const Pairings& p, OptimalTF_Result& out, 
   mh_pairs_pt2pt pp{p.lx.data(), p.ly.data(), p.lz.data(), p.gx.data(), p.gy.data(), p.gz.data(), p.localIdx.size()};
   mh_pairs_pt2pl pl{p.pl_lx.data(), p.pl_ly.data(), p.pl_lz.data(), p.pl_cx.data(), p.pl_cy.data(), p.pl_cz.data(),
                     p.pl_nx.data(), p.pl_ny.data(), p.pl_nz.data(), p.pl_lx.size()};
-  const mh_gn_params gp = gn_params_of(*this);
+  mh_gn_params gp = gn_params_of(*this);
+  gp.weight_pt2pt = p.pt2pt_weight;  // the layer weight of the matcher that produced the pairs (Pairings::point_weights [U])
+  gp.weight_pt2pl = p.pt2pl_weight;
   mh_prior pr;
   if (sc.prior) fill_prior(sc.prior, pr);
   double T[12];
@@ -569,13 +579,13 @@ bool ICP::can_fuse() const {
   auto s = std::dynamic_pointer_cast<Solver_GaussNewton>(solvers_[0]);
   if (!m || !s) return false;
   if (!(m->enabled && m->runFromIteration == 0 && m->runUpToIteration == 0 && m->pairingsPerPoint == 1 &&
-        m->pointLayerMatches.size() == 1 && m->pointLayerMatches[0].weight == 1.0))
+        m->pointLayerMatches.size() == 1))  // (its weight: any -- the fused loop's solver takes it, round 5)
     return false;
   if (matchers_.size() == 2) {
     auto pl = std::dynamic_pointer_cast<Matcher_Point2Plane>(matchers_[0]);
     if (!pl || !pl->enabled || pl->runFromIteration || pl->runUpToIteration || pl->pointLayerMatches.size() != 1) return false;
     const auto &a = pl->pointLayerMatches[0], &b = m->pointLayerMatches[0];
-    if (a.global != b.global || a.local != b.local || a.weight != 1.0) return false;
+    if (a.global != b.global || a.local != b.local) return false;
   }
   return true;
 }
@@ -917,6 +927,8 @@ void ICP::align_fused(const PointCloud* host_local, const DevicePointCloud* dev_
   ip.threshold_angular_deg = m->thresholdAngularDeg;
   ip.pt2pl_threshold = mpl ? plthr.data() : nullptr;
   ip.gn = gn_params_of(*s);
+  ip.gn.weight_pt2pt = m->pointLayerMatches[0].weight;  // pointLayerMatches {..., weight} (yaml:203-204)
+  if (mpl) ip.gn.weight_pt2pl = mpl->pointLayerMatches[0].weight;
   ip.hook_enabled = dev_hook_ ? 1u : 0u;
   ip.hook_min_trans = dev_hook_trans_;
   ip.hook_min_rot = dev_hook_rot_;
