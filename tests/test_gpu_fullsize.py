@@ -53,9 +53,9 @@ def test_every_map_point_finds_itself(ctx, gmap, c2):
     assert np.all(hit <= np.arange(len(hit)))
 
 
-@pytest.mark.parametrize("match", ["q", "t", "w", "o"])
+@pytest.mark.parametrize("match", ["f", "q", "t", "w", "o"])
 def test_full_size_alignment_matches_oracle(ctx, gmap, c2, oracle, match, monkeypatch):
-    monkeypatch.setenv("MH_MATCH", match)  # quad search through the caches / tiles staged in LDS
+    monkeypatch.setenv("MH_MATCH", match)  # f: plan / scan (the default) | q: quad search through the caches | t, w: tiles staged in LDS | o: sorted scan
     om = oracle.Map(c2.voxel_size, c2.cap).insert(c2.map_xyz)
     kw = dict(max_iterations=c2.n_iters, disable_stall_test=True, threshold=c2.threshold, kernel_param=c2.kernel_param)
     scan = capi.Scan(ctx, c2.scan_xyz)
@@ -97,7 +97,7 @@ def test_aligning_map_points_to_their_map_is_a_fixed_point(ctx, gmap, c2):
     assert capi.TERM_NAMES[r["termination_reason"]] == "Stalled" and r["n_iterations"] == 0
 
 
-@pytest.mark.parametrize("match", ["q", "t", "w", "o"])
+@pytest.mark.parametrize("match", ["f", "q", "t", "w", "o"])
 def test_lockstep_batch_equals_single_alignments(gmap, c2, match, monkeypatch):
     """mh_icp_align_batch runs large-layer jobs in lock step (one launch per kernel over all jobs, blockIdx.y = job):
     ragged scan sizes, different guesses, a prior on one job, a stall-terminated run where the jobs finish at different

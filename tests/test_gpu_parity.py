@@ -970,7 +970,7 @@ def test_profile_fields(ctx, small):
                                  {"MH_MATCH": "p"}, {"MH_MATCH": "x"}, {"MH_MATCH": "q", "MH_NO_GRAPH": "1"},
                                  {"MH_MATCH": "t"}, {"MH_MATCH": "t", "MH_NO_GRAPH": "1"}, {"MH_MATCH": "w"},
                                  {"MH_MATCH": "w", "MH_NO_GRAPH": "1"}, {"MH_MATCH": "w", "MH_WAVE_LDS": "1"},
-                                 {"MH_MATCH": "o"}])
+                                 {"MH_MATCH": "o"}, {"MH_MATCH": "f"}, {"MH_MATCH": "f", "MH_NO_GRAPH": "1"}])
 @pytest.mark.parametrize("n_scan", [2000, 5000])
 def test_every_kernel_variant_matches_the_oracle(ctx, oracle, env, n_scan, monkeypatch):
     """The default path picks its kernels by layer size (row / quad search, one-workgroup or multi-launch solve);
@@ -1008,9 +1008,9 @@ def test_previous_pairing_bound_and_its_fallback(ctx, oracle, vs, shift, monkeyp
     thr, kp = synth.threshold_schedule(2.0, 40)
     kw = dict(max_iterations=40, threshold=thr, kernel_param=kp)
     o = oracle.icp_align(oracle.Map(vs, 20).insert(mp), scan, guess, oracle.ICPParams(**kw), want_pairs=True)
-    monkeypatch.setenv("MH_MATCH", "q")
     gm, gs = capi.Map(ctx, vs, 20).build(mp), capi.Scan(ctx, scan)
-    for no_bound in (False, True):
+    for match, no_bound in (("q", False), ("f", False), ("q", True), ("f", True)):  # f: the plan / scan matcher (phases C -> D: "not attained")
+        monkeypatch.setenv("MH_MATCH", match)
         if no_bound:
             monkeypatch.setenv("MH_NO_PREV_BOUND", "1")
         g = capi.icp_align(gm, gs, guess, capi.ICPParams(**kw), want_pairs=True)
@@ -1037,7 +1037,7 @@ def test_quad_matcher_sub_voxel_index(ctx, oracle, vs, cap, mode, lattice, monke
         mp = (np.round(mp / np.float32(vs / 4)) * np.float32(vs / 4)).astype(np.float32)  # quarter-voxel lattice: mid planes hit
     pose = [0.7, -0.4, synth.SENSOR_H, 0.03, 0.002, -0.002]
     scan = synth.make_scan(scene, pose, rings=64, azimuths=700, seed=5)
-    scan = scan[rng.permutation(len(scan))[:36000]]   # above the row matcher's layer size: the quad matcher by default
+    scan = scan[rng.permutation(len(scan))[:36000]]   # above the row matcher's layer size: the plan / scan matcher by default (round 5), whose phase D is the quad matcher
     guess = synth.pose_from_ypr(np.array(pose) + [0.25, -0.15, 0.02, 0.01, 0.002, 0.001])
     thr, kp = synth.threshold_schedule(2.0, 12)
     kw = dict(max_iterations=12, threshold=thr, kernel_param=kp, disable_stall_test=True)

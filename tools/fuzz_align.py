@@ -52,7 +52,7 @@ for case in range(n_cases):
         prior = (guess, np.diag([20.0, 20.0, 20.0, 300.0, 300.0, 300.0]) * float(rng.choice([0.1, 1.0, 10.0])))
     poll = int(rng.choice([0, 0, 1, 3, 7, iters]))
     os.environ.pop("MH_MATCH", None)
-    m = str(rng.choice(["", "", "q", "s", "p"]))
+    m = str(rng.choice(["", "", "q", "s", "p", "f"]))
     if m:
         os.environ["MH_MATCH"] = m
     try:
