@@ -482,6 +482,12 @@ MH_API mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_i
                               const double T_guess[12], const mh_prior* prior, mh_icp_result* result,
                               mh_icp_iter* trace, const mh_pairs_out* final_pairs, int32_t pairs_mem);
 
+/* Statistics (process-wide, no effect on results): single alignments of small layers (<= 2048 points) run their whole loop
+ * in ONE kernel launch whose workgroups exchange partial sums among themselves, as long as the workgroups of all such loops
+ * running on the device fit its CUs; `loops_started` counts them, `loops_abandoned` those whose workgroups gave up waiting for
+ * each other and that were run again launch by launch (same result bit for bit; expected to stay 0).  Either may be NULL. */
+MH_API void mh_debug_loop_stats(uint64_t* loops_started, uint64_t* loops_abandoned);
+
 /* Results::finalPairings.paired_pt2pl [U] of the LAST mh_icp_align run on `scan`'s context (arrays in `mem`, scan-size
  * entries, any may be NULL). */
 MH_API mh_status mh_icp_get_pt2pl_pairs(const mh_scan* scan, const mh_pairs_pl_out* out, int32_t mem, uint64_t* n_pairs);

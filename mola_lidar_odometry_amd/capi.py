@@ -138,6 +138,7 @@ _SIGNATURES = {
     "mh_status_string": (C.c_char_p, [C.c_int32]),
     "mh_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
     "mh_debug_fail_allocations": (C.c_int32, [C.c_int32, C.c_int32]),
+    "mh_debug_loop_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mh_ctx_create": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mh_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "mh_ctx_synchronize": (C.c_int32, [C.c_void_p]),
@@ -226,6 +227,13 @@ def _chk(status):
 def fail_allocations(first_attempts: int, retries: int = 0):
     """Fault injection (mh_debug_fail_allocations): the next device allocations of the library's buffers fail."""
     _chk(lib().mh_debug_fail_allocations(int(first_attempts), int(retries)))
+
+
+def loop_stats():
+    """(one-launch loops started, loops abandoned for the launch-by-launch chain) so far in this process (mh_debug_loop_stats)."""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    lib().mh_debug_loop_stats(C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
 
 
 def device_count() -> int:

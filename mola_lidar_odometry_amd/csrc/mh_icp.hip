@@ -428,14 +428,21 @@ __global__ void k_div_idx(uint32_t* __restrict__ idx, uint32_t n, uint32_t k) {
 
 #ifdef MH_DEBUG_WAVETRACE
 // debug build only: wall_clock64 (100 MHz) at numbered points of the one-workgroup kernels, last launch wins
-__device__ unsigned long long g_phase[16];
+__device__ unsigned long long g_phase[32];
 #define MH_PHASE(i) do { if (threadIdx.x == 0) g_phase[i] = wall_clock64(); } while (0)
 extern "C" __attribute__((visibility("default"))) int mh_debug_phases(unsigned long long* host_out) {
   (void)hipDeviceSynchronize();
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase), sizeof(g_phase)) == hipSuccess ? 0 : 2;
 }
+// k_icp16 (a loop): the time between consecutive stamps is ACCUMULATED per phase, workgroup 0's first lane, written out at the end
+#define MH_LOOP_STAMPS unsigned long long lp_t = wall_clock64(), lp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define MH_LOOP_STAMP(i) do { const unsigned long long now_ = wall_clock64(); lp_acc[i] += now_ - lp_t; lp_t = now_; } while (0)
+#define MH_LOOP_STAMPS_OUT(steps) do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int q_ = 0; q_ < 12; q_++) g_phase[16 + q_] = lp_acc[q_]; g_phase[28] = (steps); } } while (0)
 #else
 #define MH_PHASE(i) do { } while (0)
+#define MH_LOOP_STAMPS do { } while (0)
+#define MH_LOOP_STAMP(i) do { } while (0)
+#define MH_LOOP_STAMPS_OUT(steps) do { } while (0)
 #endif
 #ifdef MH_DEBUG_WAVETRACE
 static unsigned long long* g_wtrace = nullptr;  // debug build only: [2 * n_waves] begin/end wall_clock64 of the last launch
@@ -1388,10 +1395,10 @@ static_assert(kStateHeadDwords <= 64 && offsetof(IcpDeviceState, cov) % 8 == 0, 
 
 // reduce_rows with agent-scope loads, all of a lane's loads issued before any sum, the sums in reduce_rows' order exactly (lane (row, g) adds columns g, g + G, ...: eight partial sums over the full rounds, the rest into
 // the first, then the tree).  NVALS rows, up to kStepMaxPoints / kStepPoints columns.
-template <int NVALS>
+template <int NVALS, int MAXCOLS = (int)(kStepMaxPoints / kStepPoints)>
 struct RowLoads {
   static constexpr int kG = ((int)kSolveThreads / NVALS) > 64 ? 64 : ((int)kSolveThreads / NVALS);
-  static constexpr int kL = ((int)(kStepMaxPoints / kStepPoints) + kG - 1) / kG;
+  static constexpr int kL = (MAXCOLS + kG - 1) / kG;
   double v[kL];
 };
 template <int NVALS>
@@ -1405,15 +1412,15 @@ __device__ __forceinline__ void rows_issue(RowLoads<NVALS>& r, const double* par
     r.v[j] = (row < NVALS && b < n) ? __hip_atomic_load(src + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
   }
 }
-template <int NVALS>
-__device__ __forceinline__ void rows_finish(const RowLoads<NVALS>& r, uint32_t n, double* __restrict__ out, double (*red)[64]) {
-  constexpr int G = RowLoads<NVALS>::kG;
+template <int NVALS, int MAXCOLS>
+__device__ __forceinline__ void rows_finish(const RowLoads<NVALS, MAXCOLS>& r, uint32_t n, double* __restrict__ out, double (*red)[64]) {
+  constexpr int G = RowLoads<NVALS, MAXCOLS>::kG;
   const int t = threadIdx.x, row = t / G, g = t % G;
   if (row < NVALS) {
     const uint32_t full = (n > (uint32_t)(g + 7 * G)) ? 1u + (n - (uint32_t)(g + 7 * G) - 1u) / (8u * G) : 0u;  // reduce_rows' rounds of eight
     double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < RowLoads<NVALS>::kL; j++) {
+    for (int j = 0; j < RowLoads<NVALS, MAXCOLS>::kL; j++) {
       if ((uint32_t)j < 8u * full) s[j % 8] += r.v[j];
       else if ((uint32_t)(g + j * G) < n) s[0] += r.v[j];
     }
@@ -1559,8 +1566,8 @@ __device__ __forceinline__ void k_step16_body(const IcpDeviceState* __restrict__
       stored_n = load_agent_b128(b_pln, ic);
     }
     have_stored = true;
-    rows_finish<kAccN>(ra, ngroups, sh.totA, sh.red);
-    if (PL) rows_finish<PL ? kGenN : 1>(rb, ngroups, sh.totB, sh.red);
+    rows_finish(ra, ngroups, sh.totA, sh.red);
+    if (PL) rows_finish(rb, ngroups, sh.totB, sh.red);
     solve_body<true, false>(lst, sk, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true, PL);
     __syncthreads();
   }
@@ -1742,6 +1749,204 @@ __global__ __launch_bounds__(kSolveThreads) void k_step16_b(const BatchJob* __re
   k_step16_body<PL>(S[src], S[dst], S[2], j.mk, j.sk, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx,
                     j.pl_c, j.pl_n, pa[par], pa[par ^ 1u], pb[par], pb[par ^ 1u], ngroups, ngroups < gridDim.x ? ngroups : gridDim.x,
                     close_only, j.serial_base + launch_index, 0u);
+}
+
+// ================================================================================================
+// k_icp16: the small layer's WHOLE loop in one launch (round 5) -- the k_step16 chain without its launch boundaries.
+// One workgroup per group of 32 points, all of them resident for the duration (the host admits a loop only while the
+// workgroups of all running loops fit the part's CUs, and falls back to the chain otherwise or when a workgroup gives up
+// waiting); every workgroup keeps its own copy of the state block in LDS and closes every Gauss-Newton step itself -- the
+// same ordered sums and the same solve_body as k_step16, the same bits -- so that only the partial sums cross workgroups:
+//   body (search or re-accumulate, the pairings of the group stay in registers) -> the group's column of sums, every sum a
+//   16-byte entry {value, serial number, check word} in ONE agent-scope store -> every workgroup loads all columns of the
+//   step and retries the entries that do not carry the step's serial number yet (no separate tag: one round trip instead of
+//   store | acknowledge | tag | poll | load) -> ordered sums -> solve -> next body.
+// tools/xcd_exchange.hip prices the exchange alone: 2.1 us for 44 workgroups x 18 sums (3.2 with the 29 plane sums; 3.1 / 4+
+// with a tag per column), against ~4.5 us of launch boundary + ~2 us of tagged exchange per k_step16 launch.  (The same tool:
+// workgroups of a launch are dealt to the XCDs round-robin, blockIdx % 8, but sc0 loads do not bypass the L1 -- an exchange
+// confined to one XCD's L2 has no cheaper load than the agent-scope one, and 32 CUs would hold 32 groups only.)
+// The entries ping-pong between two halves by step parity: a workgroup writes step s + 2's entries after it has summed
+// step s + 1, which every workgroup wrote after reading step s.  Serial numbers never repeat within a context (a counter
+// advanced by every loop's step budget), so an entry of an earlier alignment is never taken for the current one.
+// ================================================================================================
+constexpr uint32_t kLoopMaxGroups = 64;   // workgroups of one loop: layers up to 2048 points (beyond: the chain)
+constexpr uint32_t kLoopRowStride = 64;   // entries from one sum's row to the next
+constexpr size_t kLoopExchangeBytes = 2 * (size_t)(kAccN + kGenN) * kLoopRowStride * 16;
+
+template <int NVALS>
+__device__ __forceinline__ void loop_rows_fetch(RowLoads<NVALS, (int)kLoopMaxGroups>& r, const AgentBuf& x, uint32_t base, uint32_t n,
+                                                uint32_t serial, uint32_t* gave_up) {
+  typedef RowLoads<NVALS, (int)kLoopMaxGroups> RL;
+  const int row = (int)threadIdx.x / RL::kG, g = (int)threadIdx.x % RL::kG;
+  uint32_t need = 0;
+#pragma unroll
+  for (int j = 0; j < RL::kL; j++) {
+    r.v[j] = 0.0;
+    if (row < NVALS && (uint32_t)(g + j * RL::kG) < n) need |= 1u << j;
+  }
+  const uint32_t e0 = base + (uint32_t)(row < NVALS ? row : 0) * kLoopRowStride + (uint32_t)g;
+  for (uint32_t spins = 0; need; spins++) {
+    u32x4v w[RL::kL];
+#pragma unroll
+    for (int j = 0; j < RL::kL; j++)
+      if ((need >> j) & 1u) w[j] = __builtin_amdgcn_raw_buffer_load_b128(x.rsrc, (int)((e0 + (uint32_t)(j * RL::kG)) * 16u), 0, /*aux: sc1*/ 16);
+#pragma unroll
+    for (int j = 0; j < RL::kL; j++)
+      if (((need >> j) & 1u) && w[j].z == serial && w[j].w == (w[j].x ^ w[j].y ^ w[j].z)) {
+        r.v[j] = __hiloint2double((int)w[j].y, (int)w[j].x);
+        need &= ~(1u << j);
+      }
+    if (!need) break;
+    if (spins == (1u << 16) || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {  // ~0.1 s: give up loudly
+      __hip_atomic_store(gave_up, 1u + (uint32_t)row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+__device__ __forceinline__ void loop_entry_store(const AgentBuf& x, uint32_t e, double v, uint32_t serial) {
+  const uint32_t lo = (uint32_t)__double2loint(v), hi = (uint32_t)__double2hiint(v);
+  const u32x4v w = {lo, hi, serial, lo ^ hi ^ serial};
+  __builtin_amdgcn_raw_buffer_store_b128(w, x.rsrc, (int)(e * 16u), 0, /*aux: sc1*/ 16);
+}
+
+template <bool PL>
+__global__ __launch_bounds__(kSolveThreads) void k_icp16(IcpDeviceState* s_canon, const MatchK* __restrict__ kp,
+                                                         const SolveK* __restrict__ sk, const float* __restrict__ lx,
+                                                         const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
+                                                         MapView map, float4* pair_q, uint32_t* pair_gidx, float4* pl_c, float4* pl_n,
+                                                         void* xa, void* xb, uint32_t ngroups, uint32_t serial0, uint32_t max_steps) {
+  __shared__ SolveShared sh;
+  __shared__ __attribute__((aligned(8))) uint32_t lst_raw[kStateHeadDwords];
+  __shared__ double rowsA[kAccN][kStepPoints + 1];
+  __shared__ double rowsB[PL ? kGenN : 1][kStepPoints + 1];
+  __shared__ uint32_t gave_up;
+  const uint32_t tid = threadIdx.x, g = blockIdx.x;
+  if (g >= ngroups) return;
+  IcpDeviceState* const lst = reinterpret_cast<IcpDeviceState*>(lst_raw);
+  const AgentBuf bxa = agent_buf(xa, 2u * kAccN * kLoopRowStride), bxb = agent_buf(PL ? xb : xa, 2u * (PL ? kGenN : kAccN) * kLoopRowStride);
+  const uint32_t row = tid >> 4, r16 = tid & 15u;
+  const uint32_t i = g * kStepPoints + row, ic = i < n ? i : n - 1;
+  const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
+  if (tid < kStateHeadDwords) lst_raw[tid] = G(reinterpret_cast<const uint32_t*>(s_canon))[tid];  // (uploaded before the launch)
+  if (tid == 0) gave_up = 0;
+  __syncthreads();
+  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
+  typedef const double __attribute__((address_space(4))) * cf64_ptr;
+  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
+  const uint32_t kernel = ck->kernel;
+  // the pairing of this row's point: found at an iteration's start, used by its inner steps and as the next search's bound
+  f32x4 q = (f32x4){0.f, 0.f, 0.f, __builtin_inff()}, bc = (f32x4){0.f, 0.f, 0.f, 0.f}, bn = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bool ok = false, okp = false;
+  uint32_t step = 0;
+  MH_LOOP_STAMPS;
+#pragma nounroll
+  for (;; step++) {
+    MH_LOOP_STAMP(0);
+    if (lst->pending) {  // the sums of step - 1 (serial0 + step), every workgroup for itself
+      const uint32_t half = (step - 1u) & 1u;
+      RowLoads<kAccN, (int)kLoopMaxGroups> ra;
+      RowLoads<PL ? kGenN : 1, (int)kLoopMaxGroups> rb;
+      loop_rows_fetch<kAccN>(ra, bxa, half * kAccN * kLoopRowStride, ngroups, serial0 + step, &gave_up);
+      if (PL) loop_rows_fetch<PL ? kGenN : 1>(rb, bxb, half * kGenN * kLoopRowStride, ngroups, serial0 + step, &gave_up);
+      MH_LOOP_STAMP(1);
+      rows_finish(ra, ngroups, sh.totA, sh.red);
+      if (PL) rows_finish(rb, ngroups, sh.totB, sh.red);
+      MH_LOOP_STAMP(2);
+      if (gave_up) break;  // (behind rows_finish' barriers: the same in every wave)
+      solve_body<true, false>(lst, sk, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true, PL);
+      if (tid == 0) lst->pending = 0u;
+      __syncthreads();
+      MH_LOOP_STAMP(3);
+    }
+    if (lst->done || step >= max_steps) break;
+    const uint32_t inner = lst->inner, iter = lst->iter;
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = lst->T[k];
+    const float thr2 = lst->cur_thr2, ang2 = lst->cur_ang2;
+    const double kparam = lst->cur_kparam;
+    Acc a;
+    acc_zero(a);
+    double v[PL ? kGenN : 1];
+#pragma unroll
+    for (int j = 0; j < (PL ? kGenN : 1); j++) v[j] = 0.0;
+    if (i < n) {  // row-uniform
+      if (inner == 0) {  // (workgroup-uniform) a new ICP iteration: the matchers, exactly k_step16's
+        float px, py, pz;
+        transform_point(T, x, y, z, px, py, pz);
+        float bound0 = __builtin_inff();
+        if (iter > 0 && !map.no_prev_bound && q.w < __builtin_inff()) {
+          const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+          bound0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic of the scans
+        }
+        MH_LOOP_STAMP(6);
+        const NNResult r = nn_search_row16(map, r16, px, py, pz, bound0);
+        MH_LOOP_STAMP(7);
+        const float n2 = (px * px + py * py) + pz * pz;
+        ok = r.found && (r.d2 < thr2 + ang2 * n2);
+        if (PL) {  // Matcher_Point2Plane first (k_match16_body)
+          const float pl_thr = (float)((cf64_ptr)uniform_const_ptr(ck->pl_thr))[iter];
+          okp = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
+          if (r16 == 0) {  // (read by the covariance kernels and the pairing export once the loop has ended)
+            pl_c[i] = make_float4(bc.x, bc.y, bc.z, okp ? 1.f : 0.f);
+            pl_n[i] = make_float4(bn.x, bn.y, bn.z, 0.f);
+          }
+          if (okp && ck->skip_pl_paired) ok = false;  // (the nearest point still bounds the next search)
+        }
+        if (r16 == 0) {
+          pair_q[i] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
+          G(pair_gidx)[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+        }
+        q = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
+      }
+      if (r16 == 0) {
+        acc_pt2pt_masked(a, T, ok, x, y, z, q.x, q.y, q.z, kernel, kparam, ck->w_pt2pt);
+        if (PL && okp)
+          acc_pt2pl_rows(v, T, x, y, z, make_float4(bc.x, bc.y, bc.z, 1.f), make_float4(bn.x, bn.y, bn.z, 0.f), kernel, kparam,
+                         ck->w_pt2pl);
+      }
+    }
+    if (r16 == 0) {
+#pragma unroll
+      for (int j = 0; j < kAccN; j++) rowsA[j][row] = a.v[j];
+      if (PL) {
+#pragma unroll
+        for (int j = 0; j < kGenN; j++) rowsB[PL ? j : 0][row] = v[PL ? j : 0];
+      }
+    }
+    MH_LOOP_STAMP(8);
+    __syncthreads();
+    MH_LOOP_STAMP(4);
+    const uint32_t out = step & 1u;
+    if (tid < kAccN) {
+      double sum = rowsA[tid][0];
+#pragma unroll
+      for (int r = 1; r < (int)kStepPoints; r++) sum += rowsA[tid][r];
+      loop_entry_store(bxa, (out * kAccN + tid) * kLoopRowStride + g, sum, serial0 + step + 1u);
+    }
+    if (PL && tid >= 64 && tid < 64 + kGenN) {  // (the second wave: the 29 point-to-plane sums)
+      const uint32_t t = tid - 64;
+      double sum = rowsB[PL ? t : 0][0];
+#pragma unroll
+      for (int r = 1; r < (int)kStepPoints; r++) sum += rowsB[PL ? t : 0][r];
+      loop_entry_store(bxb, (out * kGenN + t) * kLoopRowStride + g, sum, serial0 + step + 1u);
+    }
+    if (tid == 0) lst->pending = 1u;
+    __syncthreads();
+    MH_LOOP_STAMP(5);
+  }
+  MH_LOOP_STAMPS_OUT(step);
+  if (gave_up) {  // the canonical block keeps done == 0: the host runs the alignment again, launch by launch
+    if (tid == 0) {
+      atomicAdd(&s_canon->handover_timeouts, 1u);
+      if (atomicCAS(&s_canon->dbg[0], 0u, 3u) == 0u) {
+        s_canon->dbg[1] = g; s_canon->dbg[2] = gave_up - 1u; s_canon->dbg[3] = serial0 + step; s_canon->dbg[4] = step; s_canon->dbg[5] = ngroups;
+      }
+    }
+    return;
+  }
+  if (g == 0 && tid < kStateHeadDwords) G(reinterpret_cast<uint32_t*>(s_canon))[tid] = lst_raw[tid];
 }
 
 // ================================================================================================
@@ -2774,6 +2979,8 @@ mh_status compact_pairs(mh_ctx* ctx, size_t n, const mh_pairs_out* out, int32_t 
 
 // One alignment in flight on one context: enqueue / poll state machine shared by mh_icp_align and
 // mh_icp_align_batch.
+std::atomic<unsigned long long> g_loop16_runs{0}, g_loop16_fallbacks{0};  // one-launch loops started / abandoned for the chain (mh_debug_loop_stats)
+
 struct AlignJob {
   const mh_map* map = nullptr;
   const mh_scan* scan = nullptr;
@@ -2799,6 +3006,9 @@ struct AlignJob {
   bool pl = false;    // Matcher_Point2Plane runs before the point matcher (lidar3d-ndt.yaml:195-210)
   bool streaming = false;  // run_streaming(): iterations are enqueued one by one behind the device's published progress
   bool skip_tail = false;  // ... and the covariance kernels + state read-back only once the loop has ended
+  bool loop16 = false;         // run_loop16(): the whole loop of a small layer in ONE launch (k_icp16)
+  bool forbid_loop16 = false;  // ... not for this job: the second attempt after a loop whose workgroups gave up
+  uint32_t loop_wgs = 0;       // workgroups this job holds of the device's admission count while its loop runs
 
   mh_status start(const mh_map* m, const mh_scan* sc, const mh_icp_params* prm, const double* T0, const mh_prior* prior,
                   mh_icp_result* r, mh_icp_iter* tr, size_t batch_index = 0) {
@@ -2944,6 +3154,27 @@ struct AlignJob {
     }
     step_src = 2;
     step_ppar = 0;
+    // k_icp16: where the streaming chain would run (a single alignment under automatic control) and the layer has at most
+    // kLoopMaxGroups groups -- if the workgroups of all loops running on this device still fit its CUs (every workgroup of a
+    // loop has to be resident while it runs); otherwise the chain, bit for bit the same result
+    loop16 = false;
+    if (streaming && use_step_chain() && !forbid_loop16 && getenv("MH_NO_LOOP16") == nullptr) {
+      const uint32_t ng = (uint32_t)((scan->n + kStepPoints - 1) / kStepPoints);
+      if (ng <= kLoopMaxGroups && loop_admit(ctx->device, ng)) {
+        loop_wgs = ng;
+        loop16 = true;
+        streaming = false;
+        sk.host_progress = nullptr;
+        if (ctx->loop_x.bytes < kLoopExchangeBytes) {
+          const mh_status rs = ctx->loop_x.reserve(kLoopExchangeBytes);
+          if (rs != MH_OK) {
+            loop_release();
+            return rs;
+          }
+          (void)hipMemsetAsync(ctx->loop_x.p, 0, kLoopExchangeBytes, s);
+        }
+      }
+    }
     if (defer_upload) {
       ctx->h_params->mk = mk;
       ctx->h_params->sk = sk;
@@ -2991,6 +3222,75 @@ struct AlignJob {
                           ctx->stream));
     defer_upload = false;
     return MH_OK;
+  }
+
+  // Admission of one-launch loops: the workgroups of all loops running on a device must be resident together (a loop's
+  // workgroups wait for each other), so their sum stays below the CU count less a reserve for what else is running; kernels
+  // that merely pass through (other sequences' large layers, map updates) delay a loop's start, they cannot block it.
+  static std::atomic<uint32_t>& loop_count(int device) {
+    static std::atomic<uint32_t> c[64];
+    return c[(unsigned)device % 64u];
+  }
+  static bool loop_admit(int device, uint32_t wgs) {
+    static uint32_t cap[64] = {0};
+    uint32_t& cu = cap[(unsigned)device % 64u];
+    if (!cu) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 64;
+      cu = (uint32_t)v;
+    }
+    const char* e = getenv("MH_LOOP16_CUS");  // (test knob: the admission limit)
+    const uint32_t limit = e ? (uint32_t)std::max(0, atoi(e)) : cu;
+    std::atomic<uint32_t>& c = loop_count(device);
+    const uint32_t before = c.fetch_add(wgs);
+    if (before + wgs > limit) {
+      c.fetch_sub(wgs);
+      return false;
+    }
+    return true;
+  }
+  void loop_release() {
+    if (loop_wgs) loop_count(ctx->device).fetch_sub(loop_wgs);
+    loop_wgs = 0;
+  }
+  ~AlignJob() { loop_release(); }
+
+  // The whole loop in one launch, then the covariance kernels + the state read-back, one event wait.  Leaves `finished`
+  // false when the loop did not run to its end (a workgroup gave up waiting for the others): the caller starts over with the
+  // launch-by-launch chain.
+  mh_status run_loop16() {
+    MH_TRY(set_device(ctx));
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t)scan->n;
+    const uint32_t ngr = (n + kStepPoints - 1) / kStepPoints;
+    // (MH_LOOP16_TEST_ABANDON: the loop is cut short as if its workgroups had given up -- the caller's second attempt is what is tested)
+    const uint32_t max_steps = getenv("MH_LOOP16_TEST_ABANDON") ? 1u : p->max_iterations * p->gn.max_inner_iterations + 1u;
+    const uint32_t serial0 = ctx->loop_serial;
+    ctx->loop_serial += max_steps + 2u;
+    g_loop16_runs.fetch_add(1);
+    char* const xa = static_cast<char*>(ctx->loop_x.p);
+    char* const xb = xa + 2 * (size_t)kAccN * kLoopRowStride * 16;
+    const MapView mv = map->view();
+    if (pl)
+      hipLaunchKernelGGL(k_icp16<true>, dim3(ngr), dim3(kSolveThreads), 0, s, ctx->d_state, &ctx->d_params->mk, &ctx->d_params->sk, scan->x,
+                         scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), ctx->pl_c.as<float4>(),
+                         ctx->pl_n.as<float4>(), (void*)xa, (void*)xb, ngr, serial0, max_steps);
+    else
+      hipLaunchKernelGGL(k_icp16<false>, dim3(ngr), dim3(kSolveThreads), 0, s, ctx->d_state, &ctx->d_params->mk, &ctx->d_params->sk, scan->x,
+                         scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (float4*)nullptr,
+                         (float4*)nullptr, (void*)xa, (void*)xb, ngr, serial0, max_steps);
+    enqueued = p->max_iterations;
+    skip_tail = false;
+    MH_TRY(enqueue_tail());
+    const hipError_t we = mh::wait_event(ctx->ev_poll);
+    loop_release();
+    MH_HIP(we);
+    const IcpDeviceState* h = ctx->h_state;
+    if (!h->done || h->handover_timeouts) {
+      g_loop16_fallbacks.fetch_add(1);
+      return MH_OK;  // (not finished)
+    }
+    return poll(true);
   }
 
   // row-kernel layers up to kStepMaxPoints: k_step16 launches (profiled jobs time the match kernel alone -- they, and
@@ -3381,6 +3681,13 @@ mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_icp_para
   MH_REQUIRE(!final_pairs || pairs_mem == MH_MEM_HOST || pairs_mem == MH_MEM_DEVICE, "bad mem space");
   AlignJob job;
   MH_TRY(job.start(map, scan, params, T_guess, prior, result, trace));
+  if (job.loop16 && !job.finished) {
+    MH_TRY(job.run_loop16());
+    if (!job.finished) {  // the loop's workgroups did not all get to run together: once more, launch by launch
+      job.forbid_loop16 = true;
+      MH_TRY(job.start(map, scan, params, T_guess, prior, result, trace));
+    }
+  }
   if (job.streaming && !job.finished) MH_TRY(job.run_streaming());
   while (!job.finished) {
     MH_TRY(job.enqueue_chunk());
@@ -3394,6 +3701,11 @@ mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_icp_para
                   (unsigned long long)np, result->n_final_pairs - result->n_final_pairs_pt2pl);
   }
   return MH_OK;
+}
+
+void mh_debug_loop_stats(uint64_t* loops_started, uint64_t* loops_abandoned) {
+  if (loops_started) *loops_started = g_loop16_runs.load();
+  if (loops_abandoned) *loops_abandoned = g_loop16_fallbacks.load();
 }
 
 size_t mh_pairs_block_bytes(size_t n_scan_points) {

@@ -149,6 +149,8 @@ struct mh_ctx {
   mh::DevBuf pl_c, pl_n;  // float4 per scan point: point-to-plane pairing {centroid, valid flag} {normal, 0}
   mh::DevBuf partials;    // per-block reduction partials (double)
   mh::DevBuf partials_b;  // generic (pt2pl) partials
+  mh::DevBuf loop_x;      // k_icp16: the exchange block of the one-launch loop (16-byte entries, two halves)
+  uint32_t loop_serial = 0;  // ... and the serial number its next loop's entries start from (never repeats)
   mh::DevBuf sched;       // threshold / kernel-param arrays (double)
   mh::DevBuf batch_desc, batch_states;  // lock-step batches led by this context: job descriptors, gathered states
   void* h_batch = nullptr;              // pinned mirror of both

@@ -949,6 +949,49 @@ def test_small_layer_loop_controls_give_the_same_bits(ctx, ndt, monkeypatch):
         assert r["n_final_pairs"] == ref["n_final_pairs"]
 
 
+@pytest.mark.parametrize("ndt", [False, True])
+def test_one_launch_loop_of_small_layers(ctx, ndt, monkeypatch):
+    """Single alignments of layers up to 2048 points run their whole loop in ONE launch (k_icp16: the workgroups exchange the
+    partial sums among themselves).  Same bits as the launch-by-launch chain (MH_NO_LOOP16=1); the loop is what runs by default
+    and none is abandoned; when the device's admission limit is taken (MH_LOOP16_CUS) or a loop does not run to its end
+    (MH_LOOP16_TEST_ABANDON) the chain gives the same result."""
+    pts = _ndt_cloud(61)
+    gm = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts) if ndt else capi.Map(ctx, 1.0, 20).build(pts)
+    rng = np.random.default_rng(62)
+    thr, kp = synth.threshold_schedule(0.5, 60)
+    kw = dict(max_iterations=60, threshold=thr, kernel_param=kp, gn=capi.GNParams(max_inner_iterations=2))
+    if ndt:
+        kw["pt2pl_threshold"] = 0.5
+    p = capi.ICPParams(**kw)
+    for n in (1, 31, 32, 33, 700, 1400, 2048):
+        sub = pts[rng.integers(0, len(pts), n)] + rng.normal(0, 0.01, (n, 3)).astype(np.float32)
+        guess = synth.pose_from_ypr([0.11, -0.07, 0.05, 0.006, -0.004, 0.01])
+        scan = capi.Scan(ctx, sub)
+        s0, a0 = capi.loop_stats()
+        loop = [capi.icp_align(gm, scan, guess, p, want_trace=True) for _ in range(3)]
+        s1, a1 = capi.loop_stats()
+        assert s1 - s0 == 3 and a1 == a0
+        monkeypatch.setenv("MH_NO_LOOP16", "1")
+        chain = capi.icp_align(gm, scan, guess, p, want_trace=True)
+        assert capi.loop_stats() == (s1, a1)
+        monkeypatch.delenv("MH_NO_LOOP16")
+        monkeypatch.setenv("MH_LOOP16_CUS", "0")
+        refused = capi.icp_align(gm, scan, guess, p, want_trace=True)
+        assert capi.loop_stats() == (s1, a1)
+        monkeypatch.delenv("MH_LOOP16_CUS")
+        monkeypatch.setenv("MH_LOOP16_TEST_ABANDON", "1")
+        again = capi.icp_align(gm, scan, guess, p, want_trace=True)
+        assert capi.loop_stats() == (s1 + 1, a1 + 1)
+        monkeypatch.delenv("MH_LOOP16_TEST_ABANDON")
+        for r in loop + [refused, again]:
+            assert r["n_iterations"] == chain["n_iterations"] and r["termination_reason"] == chain["termination_reason"]
+            np.testing.assert_array_equal(r["T"], chain["T"])
+            np.testing.assert_array_equal(r["cov"], chain["cov"])
+            assert r["n_final_pairs"] == chain["n_final_pairs"] and r["n_final_pairs_pt2pl"] == chain["n_final_pairs_pt2pl"]
+            for a, b in zip(r["trace"], chain["trace"]):
+                np.testing.assert_array_equal(a["T"], b["T"])
+
+
 def test_scan_update_reuses_handle(ctx, oracle, small):
     w, gm, om, gs = small
     s = capi.Scan(ctx, w.scan_xyz[:100])

@@ -23,7 +23,7 @@ for n in (900, 1400, 2000):
     for rep in range(3):
         p = capi.ICPParams(max_iterations=40, threshold=w.threshold[:1].repeat(40), kernel_param=w.kernel_param[:1].repeat(40))
         r = capi.icp_align(m, s, w.T_guess, p)
-        buf = np.zeros(16, np.uint64)
+        buf = np.zeros(32, np.uint64)
         L.mh_debug_phases(buf.ctypes.data_as(C.c_void_p))
         t = buf.astype(np.int64)
         order = [k for k in (0, 1, 4, 5, 6, 7, 8, 9, 10, 11) if t[k]]
