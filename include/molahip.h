@@ -482,6 +482,15 @@ MH_API mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_i
                               const double T_guess[12], const mh_prior* prior, mh_icp_result* result,
                               mh_icp_iter* trace, const mh_pairs_out* final_pairs, int32_t pairs_mem);
 
+/* Scheduling hint for callers that merge the alignments of several sequences into mh_icp_align_batch calls: *yes = 1 when a
+ * single mh_icp_align of this scan with these parameters would run its whole loop in ONE kernel launch (layers of at most 2048
+ * points under automatic loop control, see mh_debug_loop_stats) AND the loops of `concurrent_callers` such callers fit into
+ * 70 % of the device's CUs together (four 1400-point layers on 256 CUs; the callers' other stages run beside the loops).  Such an alignment is better issued on its own at once than held
+ * back for a lock-step batch (4 sequences of the default pipeline: 4450 against 3620 scans/s); with more callers than fit,
+ * lock-step batches are faster (8 sequences: 4950 against 4100).  Results do not depend on the choice. */
+MH_API mh_status mh_icp_align_prefers_solo(const mh_scan* scan, const mh_icp_params* params, uint32_t concurrent_callers,
+                                           int32_t* yes);
+
 /* Statistics (process-wide, no effect on results): single alignments of small layers (<= 2048 points) run their whole loop
  * in ONE kernel launch whose workgroups exchange partial sums among themselves, as long as the workgroups of all such loops
  * running on the device fit its CUs; `loops_started` counts them, `loops_abandoned` those whose workgroups gave up waiting for

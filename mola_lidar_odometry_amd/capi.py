@@ -139,6 +139,7 @@ _SIGNATURES = {
     "mh_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
     "mh_debug_fail_allocations": (C.c_int32, [C.c_int32, C.c_int32]),
     "mh_debug_loop_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "mh_icp_align_prefers_solo": (C.c_int32, [C.c_void_p, C.POINTER(ICPParamsC), C.c_uint32, C.POINTER(C.c_int32)]),
     "mh_ctx_create": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mh_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "mh_ctx_synchronize": (C.c_int32, [C.c_void_p]),
@@ -692,6 +693,14 @@ def _result_dict(res: ICPResult):
                 n_match_launches=int(res.n_match_launches), match_kernel_ms=res.match_kernel_ms, total_ms=res.total_ms,
                 n_final_pairs_pt2pl=int(res.n_final_pairs_pt2pl), n_host_polls=int(res.n_host_polls),
                 n_enqueued_iterations=int(res.n_enqueued_iterations))
+
+
+def icp_align_prefers_solo(s: Scan, p: ICPParams, T_guess=None, concurrent_callers: int = 1) -> bool:
+    """mh_icp_align_prefers_solo: would a single alignment of this scan run its loop in one launch?"""
+    cp, keep = p.c(T_guess if T_guess is not None else np.eye(4))
+    yes = C.c_int32(0)
+    _chk(lib().mh_icp_align_prefers_solo(s._h, C.byref(cp), int(concurrent_callers), C.byref(yes)))
+    return bool(yes.value)
 
 
 def icp_align(m: Map, s: Scan, T_guess, p: ICPParams, prior=None, want_trace=True, want_pairs=False):

@@ -33,6 +33,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <thread>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -1427,9 +1429,13 @@ __device__ __forceinline__ void rows_finish(const RowLoads<NVALS, MAXCOLS>& r, u
     red[row][g] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   }
   __syncthreads();
-  if (t < NVALS) {
+  if (t < NVALS) {  // (all G reads first, then the additions in order: a read per addition costs its LDS latency G times over)
+    double part[G];
+#pragma unroll
+    for (int q = 0; q < G; q++) part[q] = red[t][q];
     double acc = 0.0;
-    for (int q = 0; q < G; q++) acc += red[t][q];
+#pragma unroll
+    for (int q = 0; q < G; q++) acc += part[q];
     out[t] = acc;
   }
   __syncthreads();
@@ -3241,13 +3247,21 @@ struct AlignJob {
     }
     const char* e = getenv("MH_LOOP16_CUS");  // (test knob: the admission limit)
     const uint32_t limit = e ? (uint32_t)std::max(0, atoi(e)) : cu;
+    if (wgs > limit) return false;
+    // A loop that does not fit now waits for the running ones (each takes a fraction of a millisecond) rather than fall back to
+    // the chain, whose forty-odd launches would queue behind the same loops: eight sequences of the default pipeline keep five
+    // loops on the device at any time.  MH_LOOP16_WAIT_US (2000): how long before the chain is taken after all.
+    static const long wait_us = getenv("MH_LOOP16_WAIT_US") ? atol(getenv("MH_LOOP16_WAIT_US")) : 2000L;
     std::atomic<uint32_t>& c = loop_count(device);
-    const uint32_t before = c.fetch_add(wgs);
-    if (before + wgs > limit) {
-      c.fetch_sub(wgs);
-      return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+      uint32_t cur = c.load();
+      while (cur + wgs <= limit)
+        if (c.compare_exchange_weak(cur, cur + wgs)) return true;
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= wait_us) return false;
+      if (spins < 64) __builtin_ia32_pause();
+      else std::this_thread::yield();
     }
-    return true;
   }
   void loop_release() {
     if (loop_wgs) loop_count(ctx->device).fetch_sub(loop_wgs);
@@ -3699,6 +3713,35 @@ mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_icp_para
     if (np != result->n_final_pairs - result->n_final_pairs_pt2pl)
       return fail(MH_ERR_INTERNAL, "pair compaction count mismatch: %llu pairings in the buffers, %u in the last accumulation",
                   (unsigned long long)np, result->n_final_pairs - result->n_final_pairs_pt2pl);
+  }
+  return MH_OK;
+}
+
+mh_status mh_icp_align_prefers_solo(const mh_scan* scan, const mh_icp_params* p, uint32_t concurrent_callers, int32_t* yes) {
+  MH_REQUIRE(scan && p && yes, "null argument");
+  // what AlignJob::start decides for a single alignment under automatic control: the row matcher's layer sizes (MH_MATCH unset or
+  // "s"; always for MH_MATCHED_POINTS_SKIP), the k_step16 chain's conditions, at most kLoopMaxGroups groups
+  const size_t n = scan->n;
+  const bool pl = p->pt2pl_threshold != nullptr;
+  const char* e = getenv("MH_MATCH");
+  bool row = n <= kRowMaxPoints;
+  if (e && (e[0] == 't' || e[0] == 'w' || e[0] == 'o' || e[0] == 'q' || e[0] == 'f' || e[0] == 'p' || e[0] == 'x')) row = false;
+  if (e && e[0] == 's') row = true;
+  if (pl && p->matched_points == MH_MATCHED_POINTS_SKIP) row = true;
+  *yes = (n > 0 && p->max_iterations > 0 && row && n <= (size_t)kLoopMaxGroups * kStepPoints && p->poll_every == 0 && p->profile == 0 &&
+          scan->ctx->d_progress != nullptr && getenv("MH_NO_STREAM") == nullptr && getenv("MH_NO_STEP_CHAIN") == nullptr &&
+          getenv("MH_NO_LOOP16") == nullptr)
+             ? 1
+             : 0;
+  if (*yes && concurrent_callers > 1) {  // ... and the loops of all callers fit the device together: nobody waits for a turn
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, scan->ctx->device) != hipSuccess || cu <= 0) cu = 64;
+    const char* lim = getenv("MH_LOOP16_CUS");
+    const uint64_t limit = lim ? (uint64_t)std::max(0, atoi(lim)) : (uint64_t)cu;
+    const uint64_t ng = (n + kStepPoints - 1) / kStepPoints;
+    // (70 % of the CUs: the callers' filters, de-skew and map updates run beside the loops -- five loops of 44 workgroups on
+    //  256 CUs measured slower than four, 3780 against 4000-4450 scans/s)
+    if ((uint64_t)concurrent_callers * ng * 10u > limit * 7u) *yes = 0;
   }
   return MH_OK;
 }

@@ -442,6 +442,7 @@ class AlignBatcher {
     mh_status status = MH_OK;
     std::string error;
     bool done = false;
+    bool lead = false;  // woken to run the batch of those waiting (the request that made it due ran on its own)
     std::chrono::steady_clock::time_point arrived{};
   };
   struct FilterRequest {
@@ -477,6 +478,8 @@ class AlignBatcher {
   size_t split_ = 1;      // batches the active participants are spread over (MOLA_HIP_BATCH_SPLIT; 1 = one batch of all, the
                           // default: two or more batches in flight measured SLOWER -- 8 sequences 2590 -> 2160 scans/s -- the
                           // host threads then contend for the HIP runtime, which is what limits this runner in the first place)
+  bool solo_ = false;     // MOLA_HIP_BATCH_SOLO: no batches at all, every request runs as a single alignment at once (A/B switch)
+  bool no_solo_ = false;  // MOLA_HIP_BATCH_NO_SOLO: the library's hint (mh_icp_align_prefers_solo) is not asked: everything is batched
   size_t n_batches_ = 0, n_jobs_ = 0;
   double t_assemble_ = 0.0, t_run_ = 0.0;
 };

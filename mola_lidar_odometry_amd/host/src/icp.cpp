@@ -593,6 +593,8 @@ bool ICP::can_fuse() const {
 // ---------------------------------------------------------------- AlignBatcher
 AlignBatcher::AlignBatcher(size_t participants) : active_(participants) {
   if (const char* e = getenv("MOLA_HIP_BATCH_SPLIT")) split_ = (size_t)std::max(1, atoi(e));
+  solo_ = getenv("MOLA_HIP_BATCH_SOLO") != nullptr;  // every alignment on its own, as soon as it is asked for (A/B against the lock-step batches)
+  no_solo_ = getenv("MOLA_HIP_BATCH_NO_SOLO") != nullptr;
 }
 
 // how many waiting requests make a batch: all active participants (split 1), or a share of them -- then two or more
@@ -661,22 +663,60 @@ mh_status AlignBatcher::align(const void* owner, const mh_map* map, const mh_sca
                               const double T_guess[12], const mh_prior* prior, mh_icp_result* result, std::string* error) {
   Request rq;
   rq.map = map; rq.scan = scan; rq.params = params; rq.T = T_guess; rq.prior = prior; rq.result = result;
+  // An alignment the library runs as ONE launch (the default pipeline's ICP layers: <= 2048 points) gains nothing from a
+  // lock-step batch and loses the wait for the others: it is issued on its own at once, as long as the loops of all active
+  // participants fit the device together (4 sequences: 4450 against 3620 scans/s; with 8, whose loops would take turns, the
+  // batches win: 4950 against 4100).
+  int32_t solo = solo_ ? 1 : 0;
+  if (!solo && !no_solo_) {
+    size_t callers;
+    {
+      std::lock_guard<std::mutex> g(mtx_);
+      callers = active_;
+    }
+    if (mh_icp_align_prefers_solo(scan, params, (uint32_t)callers, &solo) != MH_OK) solo = 0;
+  }
   std::unique_lock<std::mutex> lk(mtx_);
   rq.arrived = std::chrono::steady_clock::now();
   owners_[owner ? owner : (const void*)scan].aligns++;  // this participant is past the filter set of its previous alignment count
   if (!pp_waiting_.empty()) cv_.notify_all();           // (a waiting filter worker may find its set complete now)
+  auto take_waiting = [&](std::vector<Request*>& batch) {
+    batch.swap(waiting_);
+    for (Request* r : batch) r->lead = false;
+    in_flight_ += batch.size();
+  };
+  if (solo) {
+    in_flight_ += 1;
+    // whoever waits for a batch waits for those who are not in flight: if that is nobody now, one of them leads it
+    if (!waiting_.empty() && waiting_.size() + in_flight_ >= active_) {
+      waiting_.front()->lead = true;
+      cv_.notify_all();
+    }
+    std::vector<Request*> one{&rq};
+    lk.unlock();
+    run_batch(one);
+    lk.lock();
+    if (error) *error = rq.error;
+    return rq.status;
+  }
   waiting_.push_back(&rq);
   // a batch is due when enough requests wait -- or when everybody who is not waiting is inside a running batch already
   // (then waiting longer only idles the device)
   if (waiting_.size() >= threshold_locked() || waiting_.size() + in_flight_ >= active_) {
     std::vector<Request*> batch;
-    batch.swap(waiting_);
-    in_flight_ += batch.size();
+    take_waiting(batch);
     lk.unlock();
     run_batch(batch);
     lk.lock();
   } else {
-    cv_.wait(lk, [&] { return rq.done; });
+    cv_.wait(lk, [&] { return rq.done || rq.lead; });
+    if (!rq.done) {  // (lead: still among those waiting -- whoever takes a batch clears the flags of its requests)
+      std::vector<Request*> batch;
+      take_waiting(batch);
+      lk.unlock();
+      run_batch(batch);
+      lk.lock();
+    }
   }
   if (error) *error = rq.error;
   return rq.status;

@@ -992,6 +992,38 @@ def test_one_launch_loop_of_small_layers(ctx, ndt, monkeypatch):
                 np.testing.assert_array_equal(a["T"], b["T"])
 
 
+def test_solo_hint_agrees_with_what_a_single_alignment_does(ctx, monkeypatch):
+    """mh_icp_align_prefers_solo (the batching hint of the multi-sequence runner) says "one launch" exactly when mh_icp_align
+    then starts a one-launch loop."""
+    pts = _ndt_cloud(71)
+    gm = capi.Map(ctx, 1.0, 20).build(pts)
+    rng = np.random.default_rng(72)
+    thr, kp = synth.threshold_schedule(0.5, 12)
+    guess = synth.pose_from_ypr([0.05, -0.03, 0.02, 0.003, -0.002, 0.005])
+    cases = [(n, dict(), dict()) for n in (1, 500, 2048, 2049, 6000)]
+    cases += [(500, dict(poll_every=3), dict()), (500, dict(profile=1), dict()), (500, dict(), {"MH_NO_LOOP16": "1"}),
+              (500, dict(), {"MH_NO_STREAM": "1"}), (500, dict(), {"MH_MATCH": "q"}), (40000, dict(), {"MH_MATCH": "s"})]
+    for n, extra, env in cases:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p = capi.ICPParams(max_iterations=12, threshold=thr, kernel_param=kp, **extra)
+        sub = pts[rng.integers(0, len(pts), n)] + rng.normal(0, 0.01, (n, 3)).astype(np.float32)
+        scan = capi.Scan(ctx, sub)
+        hint = capi.icp_align_prefers_solo(scan, p, guess)
+        s0, a0 = capi.loop_stats()
+        capi.icp_align(gm, scan, guess, p, want_trace=False)
+        s1, a1 = capi.loop_stats()
+        assert (s1 - s0 == 1) == hint and a1 == a0, (n, extra, env, hint, s1 - s0)
+        assert hint == (n <= 2048 and not extra and not env)
+        if hint:  # ... with company: as long as everybody's workgroups fit the device together
+            groups = (n + 31) // 32
+            fit = (256 * 7 // 10) // groups  # (MI355X: 256 CUs, 70 % of them for loops)
+            assert capi.icp_align_prefers_solo(scan, p, guess, concurrent_callers=max(1, fit))
+            assert not capi.icp_align_prefers_solo(scan, p, guess, concurrent_callers=max(2, fit + 1))
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_scan_update_reuses_handle(ctx, oracle, small):
     w, gm, om, gs = small
     s = capi.Scan(ctx, w.scan_xyz[:100])
