@@ -1143,9 +1143,11 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, con
     const Pose D = compose(Pinv, Tc);
     if (lane < 13) {
       double xi[6] = {0, 0, 0, 0, 0, 0};
+      double h = 1e-6;
+      asm volatile("" : "+v"(h));  // (opaque: inside k_icp16's loop the compiler otherwise computes the thirteen exp(xi) ahead of the loop and keeps them -- in scratch)
 #pragma unroll
       for (int j = 0; j < 6; j++)
-        if (lane < 12 && (lane >> 1) == j) xi[j] = (lane & 1) ? -1e-6 : 1e-6;
+        if (lane < 12 && (lane >> 1) == j) xi[j] = (lane & 1) ? -h : h;
       const Pose Dp = compose(D, se3_exp(xi));
       double lg[6];
       se3_log(Dp, lg);
@@ -1775,9 +1777,14 @@ __global__ __launch_bounds__(kSolveThreads) void k_step16_b(const BatchJob* __re
 // step s + 1, which every workgroup wrote after reading step s.  Serial numbers never repeat within a context (a counter
 // advanced by every loop's step budget), so an entry of an earlier alignment is never taken for the current one.
 // ================================================================================================
-constexpr uint32_t kLoopMaxGroups = 64;   // workgroups of one loop: layers up to 2048 points (beyond: the chain)
-constexpr uint32_t kLoopRowStride = 64;   // entries from one sum's row to the next
+#ifndef MH_LOOP_MAX_GROUPS
+#define MH_LOOP_MAX_GROUPS 64
+#endif
+constexpr uint32_t kLoopMaxGroups = MH_LOOP_MAX_GROUPS;   // workgroups of one loop: layers up to 32 x this many points (beyond: the chain)
+constexpr uint32_t kLoopRowStride = MH_LOOP_MAX_GROUPS;   // entries from one sum's row to the next
 constexpr size_t kLoopExchangeBytes = 2 * (size_t)(kAccN + kGenN) * kLoopRowStride * 16;
+
+__device__ __forceinline__ void cov_prepare_lane(const Pose& Tc, int j, double hx, double ha, double* out);  // (below)
 
 template <int NVALS>
 __device__ __forceinline__ void loop_rows_fetch(RowLoads<NVALS, (int)kLoopMaxGroups>& r, const AgentBuf& x, uint32_t base, uint32_t n,
@@ -1821,7 +1828,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_icp16(IcpDeviceState* s_canon
                                                          const SolveK* __restrict__ sk, const float* __restrict__ lx,
                                                          const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                          MapView map, float4* pair_q, uint32_t* pair_gidx, float4* pl_c, float4* pl_n,
-                                                         void* xa, void* xb, uint32_t ngroups, uint32_t serial0, uint32_t max_steps) {
+                                                         void* xa, void* xb, uint32_t ngroups, uint32_t serial0, uint32_t max_steps,
+                                                         uint32_t want_cov) {
   __shared__ SolveShared sh;
   __shared__ __attribute__((aligned(8))) uint32_t lst_raw[kStateHeadDwords];
   __shared__ double rowsA[kAccN][kStepPoints + 1];
@@ -1952,7 +1960,18 @@ __global__ __launch_bounds__(kSolveThreads) void k_icp16(IcpDeviceState* s_canon
     }
     return;
   }
-  if (g == 0 && tid < kStateHeadDwords) G(reinterpret_cast<uint32_t*>(s_canon))[tid] = lst_raw[tid];
+  if (g == 0) {
+    if (tid < kStateHeadDwords) G(reinterpret_cast<uint32_t*>(s_canon))[tid] = lst_raw[tid];
+    if (want_cov && lst->done && tid < 6) {  // k_cov_prepare's six lanes: the covariance chain that follows starts at k_cov_accum
+      Pose Tc;
+#pragma unroll
+      for (int k = 0; k < 12; k++) Tc.m[k] = lst->T[k];
+      double out[12];
+      cov_prepare_lane(Tc, (int)tid, sk->cov_hx, sk->cov_ha, out);
+#pragma unroll
+      for (int k = 0; k < 12; k++) s_canon->covD[tid * 12 + k] = out[k];
+    }
+  }
 }
 
 // ================================================================================================
@@ -3164,7 +3183,9 @@ struct AlignJob {
     // kLoopMaxGroups groups -- if the workgroups of all loops running on this device still fit its CUs (every workgroup of a
     // loop has to be resident while it runs); otherwise the chain, bit for bit the same result
     loop16 = false;
-    if (streaming && use_step_chain() && !forbid_loop16 && getenv("MH_NO_LOOP16") == nullptr) {
+    // (after a loop had to be abandoned -- somebody else's work kept its workgroups from running together, ~0.1 s lost -- the
+    //  next 200 alignments on the device take the chain before another loop is tried)
+    if (streaming && use_step_chain() && !forbid_loop16 && getenv("MH_NO_LOOP16") == nullptr && !loop_holdoff(ctx->device, false)) {
       const uint32_t ng = (uint32_t)((scan->n + kStepPoints - 1) / kStepPoints);
       if (ng <= kLoopMaxGroups && loop_admit(ctx->device, ng)) {
         loop_wgs = ng;
@@ -3263,6 +3284,18 @@ struct AlignJob {
       else std::this_thread::yield();
     }
   }
+  static bool loop_holdoff(int device, bool arm) {  // arm: a loop was abandoned; else: true while the hold-off lasts (counts down)
+    static std::atomic<int> left[64];
+    std::atomic<int>& v = left[(unsigned)device % 64u];
+    if (arm) {
+      v.store(200);
+      return true;
+    }
+    int cur = v.load();
+    while (cur > 0)
+      if (v.compare_exchange_weak(cur, cur - 1)) return true;
+    return false;
+  }
   void loop_release() {
     if (loop_wgs) loop_count(ctx->device).fetch_sub(loop_wgs);
     loop_wgs = 0;
@@ -3288,20 +3321,21 @@ struct AlignJob {
     if (pl)
       hipLaunchKernelGGL(k_icp16<true>, dim3(ngr), dim3(kSolveThreads), 0, s, ctx->d_state, &ctx->d_params->mk, &ctx->d_params->sk, scan->x,
                          scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), ctx->pl_c.as<float4>(),
-                         ctx->pl_n.as<float4>(), (void*)xa, (void*)xb, ngr, serial0, max_steps);
+                         ctx->pl_n.as<float4>(), (void*)xa, (void*)xb, ngr, serial0, max_steps, p->compute_covariance ? 1u : 0u);
     else
       hipLaunchKernelGGL(k_icp16<false>, dim3(ngr), dim3(kSolveThreads), 0, s, ctx->d_state, &ctx->d_params->mk, &ctx->d_params->sk, scan->x,
                          scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (float4*)nullptr,
-                         (float4*)nullptr, (void*)xa, (void*)xb, ngr, serial0, max_steps);
+                         (float4*)nullptr, (void*)xa, (void*)xb, ngr, serial0, max_steps, p->compute_covariance ? 1u : 0u);
     enqueued = p->max_iterations;
     skip_tail = false;
-    MH_TRY(enqueue_tail());
+    MH_TRY(enqueue_tail(/*cov_prepared=*/true));
     const hipError_t we = mh::wait_event(ctx->ev_poll);
     loop_release();
     MH_HIP(we);
     const IcpDeviceState* h = ctx->h_state;
     if (!h->done || h->handover_timeouts) {
       g_loop16_fallbacks.fetch_add(1);
+      if (getenv("MH_LOOP16_TEST_ABANDON") == nullptr) loop_holdoff(ctx->device, true);
       return MH_OK;  // (not finished)
     }
     return poll(true);
@@ -3589,7 +3623,7 @@ struct AlignJob {
     return poll();
   }
 
-  mh_status enqueue_tail() {
+  mh_status enqueue_tail(bool cov_prepared = false) {  // cov_prepared: k_icp16 has done k_cov_prepare's part
     MH_TRY(set_device(ctx));
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t)scan->n;
@@ -3597,7 +3631,7 @@ struct AlignJob {
     double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
     const SolveK* dsk = &ctx->d_params->sk;
     if (p->compute_covariance) {
-      hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, dsk, 0u);
+      if (!cov_prepared) hipLaunchKernelGGL(k_cov_prepare, dim3(1), dim3(64), 0, s, ctx->d_state, dsk, 0u);
       hipLaunchKernelGGL(k_cov_accum, dim3(nb), dim3(kBlock), 0, s, ctx->d_state, 0u, scan->x, scan->y, scan->z, n,
                          ctx->pair_gidx.as<uint32_t>(), part, nb);
       if (pl)
