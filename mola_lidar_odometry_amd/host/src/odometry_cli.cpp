@@ -413,11 +413,15 @@ int main(int argc, char** argv) {
         assembling += b->secondsAssembling(), running += b->secondsRunning();
       }
     const double nb = n_batches ? (double)n_batches : 1.0;
+    uint64_t loops_started = 0, loops_abandoned = 0;
+    mh_debug_loop_stats(&loops_started, &loops_abandoned);
     printf("{\"sequences\": %zu, \"devices\": %zu, \"scans\": %zu, \"wall_seconds\": %.6f, \"scans_per_s\": %.3f, \"steady_scans_per_s\": %.3f, "
            "\"batches\": %zu, \"jobs_per_batch\": %.2f, \"ms_per_batch_assembling\": %.4f, \"ms_per_batch_running\": %.4f, "
-           "\"filter_batches\": %zu, \"filter_jobs\": %zu, \"filter_timeouts\": %zu, \"per_device\": [",
+           "\"filter_batches\": %zu, \"filter_jobs\": %zu, \"filter_timeouts\": %zu, \"one_launch_loops\": %llu, "
+           "\"one_launch_loops_abandoned\": %llu, \"per_device\": [",
            N, D, total, wall, wall > 0 ? total / wall : 0.0, slowest > 0 ? steady / slowest : 0.0, n_batches, n_jobs / nb,
-           1e3 * assembling / nb, 1e3 * running / nb, f_batches, f_jobs, f_timeouts);
+           1e3 * assembling / nb, 1e3 * running / nb, f_batches, f_jobs, f_timeouts, (unsigned long long)loops_started,
+           (unsigned long long)loops_abandoned);
     for (size_t d = 0; d < D; d++)
       printf("%s{\"slot\": %zu, \"device\": %d, \"sequences\": %zu, \"scans\": %zu, \"registration_seconds\": %.6f, \"scans_per_s\": %.3f, "
              "\"steady_scans_per_s\": %.3f}",
