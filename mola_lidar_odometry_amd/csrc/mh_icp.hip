@@ -145,6 +145,9 @@ struct BatchJob {
   uint32_t* cp_counts;   // [nb] pairs per 256-point block | [nb] exclusive offsets
   uint32_t* cp_out;      // six arrays of cp_stride entries: local_idx | global_idx | gx | gy | gz | d2
   uint32_t cp_stride, cp_pad;
+  // k_icp16_b: this job's exchange block (16-byte entries: point-to-point sums | point-to-plane sums) and the serial number its entries start from
+  void *loop_xa, *loop_xb;
+  uint32_t loop_serial0, loop_pad;
 };
 
 // LDS hand-off between lanes of ONE wave: LDS operations of a wave execute in order, so only the compiler has to be
@@ -1974,6 +1977,167 @@ __global__ __launch_bounds__(kSolveThreads) void k_icp16(IcpDeviceState* s_canon
   }
 }
 
+// k_icp16_b: the same loop for the jobs of a lock-step group, side by side in ONE launch (blockIdx.y = job) -- every job's
+// workgroups exchange among themselves only; a workgroup takes the groups x, x + nw, ... of its job (the host caps nw so that the
+// workgroups of ALL jobs are resident together), one column of sums per GROUP as everywhere: the same bits.  The pairings of a
+// workgroup's groups wait in LDS (up to kLoopGroupsPerWg groups of 32 rows) instead of registers.
+constexpr uint32_t kLoopGroupsPerWg = 8;
+template <bool PL>
+__device__ __forceinline__ void icp16_multi_body(const BatchJob& j) {
+  __shared__ SolveShared sh;
+  __shared__ __attribute__((aligned(8))) uint32_t lst_raw[kStateHeadDwords];
+  __shared__ double rowsA[kAccN][kStepPoints + 1];
+  __shared__ double rowsB[PL ? kGenN : 1][kStepPoints + 1];
+  __shared__ f32x4 keep_q[kLoopGroupsPerWg][kStepPoints];
+  __shared__ f32x4 keep_c[PL ? kLoopGroupsPerWg : 1][kStepPoints], keep_n[PL ? kLoopGroupsPerWg : 1][kStepPoints];
+  __shared__ uint32_t keep_ok[kLoopGroupsPerWg][kStepPoints];  // bit 0: point pairing accepted, bit 1: plane pairing
+  __shared__ uint32_t gave_up;
+  const uint32_t n = j.n;
+  const uint32_t ng0 = (n + kStepPoints - 1) / kStepPoints, ngroups = ng0 ? ng0 : 1u;
+  const uint32_t nw = ngroups < gridDim.x ? ngroups : gridDim.x;
+  const uint32_t tid = threadIdx.x, wg = blockIdx.x;
+  if (wg >= nw || n == 0) return;
+  IcpDeviceState* const s_canon = j.st;
+  const SolveK* const sk = j.sk;
+  const MapView map = j.map;
+  IcpDeviceState* const lst = reinterpret_cast<IcpDeviceState*>(lst_raw);
+  const AgentBuf bxa = agent_buf(j.loop_xa, 2u * kAccN * kLoopRowStride), bxb = agent_buf(PL ? j.loop_xb : j.loop_xa, 2u * (PL ? kGenN : kAccN) * kLoopRowStride);
+  const uint32_t row = tid >> 4, r16 = tid & 15u;
+  const uint32_t serial0 = j.loop_serial0;
+  if (tid < kStateHeadDwords) lst_raw[tid] = G(reinterpret_cast<const uint32_t*>(s_canon))[tid];  // (scattered before the launch)
+  if (tid == 0) gave_up = 0;
+  __syncthreads();
+  if (lst->done) return;  // (a job that was finished before the batch began: nothing to do)
+  typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
+  typedef const double __attribute__((address_space(4))) * cf64_ptr;
+  const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(j.mk);
+  const uint32_t kernel = ck->kernel;
+  const uint32_t max_steps = j.loop_pad ? 1u : sk->max_iterations * sk->max_inner + 1u;  // (loop_pad: MH_LOOP16_TEST_ABANDON, the loop is cut short)
+  uint32_t step = 0;
+#pragma nounroll
+  for (;; step++) {
+    if (lst->pending) {
+      const uint32_t half = (step - 1u) & 1u;
+      RowLoads<kAccN, (int)kLoopMaxGroups> ra;
+      RowLoads<PL ? kGenN : 1, (int)kLoopMaxGroups> rb;
+      loop_rows_fetch<kAccN>(ra, bxa, half * kAccN * kLoopRowStride, ngroups, serial0 + step, &gave_up);
+      if (PL) loop_rows_fetch<PL ? kGenN : 1>(rb, bxb, half * kGenN * kLoopRowStride, ngroups, serial0 + step, &gave_up);
+      rows_finish(ra, ngroups, sh.totA, sh.red);
+      if (PL) rows_finish(rb, ngroups, sh.totB, sh.red);
+      if (gave_up) break;
+      solve_body<true, false>(lst, sk, nullptr, 0u, 0u, nullptr, 0u, 0u, sh, true, PL);
+      if (tid == 0) lst->pending = 0u;
+      __syncthreads();
+    }
+    if (lst->done || step >= max_steps) break;
+    const uint32_t inner = lst->inner, iter = lst->iter;
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = lst->T[k];
+    const float thr2 = lst->cur_thr2, ang2 = lst->cur_ang2;
+    const double kparam = lst->cur_kparam;
+    const uint32_t out = step & 1u;
+    uint32_t slot = 0;
+#pragma nounroll
+    for (uint32_t g = wg; g < ngroups; g += nw, slot++) {  // (workgroup-uniform trip count)
+      const uint32_t i = g * kStepPoints + row, ic = i < n ? i : n - 1;
+      const float x = G(j.lx)[ic], y = G(j.ly)[ic], z = G(j.lz)[ic];
+      Acc a;
+      acc_zero(a);
+      double v[PL ? kGenN : 1];
+#pragma unroll
+      for (int q = 0; q < (PL ? kGenN : 1); q++) v[q] = 0.0;
+      if (i < n) {
+        f32x4 q = keep_q[slot][row], bc = (f32x4){0.f, 0.f, 0.f, 0.f}, bn = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bool ok, okp = false;
+        if (inner == 0) {
+          float px, py, pz;
+          transform_point(T, x, y, z, px, py, pz);
+          float bound0 = __builtin_inff();
+          if (iter > 0 && !map.no_prev_bound && q.w < __builtin_inff()) {
+            const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+            bound0 = (dx * dx + dy * dy) + dz * dz;
+          }
+          const NNResult r = nn_search_row16(map, r16, px, py, pz, bound0);
+          const float n2 = (px * px + py * py) + pz * pz;
+          ok = r.found && (r.d2 < thr2 + ang2 * n2);
+          if (PL) {
+            const float pl_thr = (float)((cf64_ptr)uniform_const_ptr(ck->pl_thr))[iter];
+            okp = pl_row_search(map, r16, px, py, pz, pl_thr, bc, bn);
+            if (r16 == 0) {
+              j.pl_c[i] = make_float4(bc.x, bc.y, bc.z, okp ? 1.f : 0.f);
+              j.pl_n[i] = make_float4(bn.x, bn.y, bn.z, 0.f);
+              keep_c[PL ? slot : 0][row] = bc;
+              keep_n[PL ? slot : 0][row] = bn;
+            }
+            if (okp && ck->skip_pl_paired) ok = false;
+          }
+          q = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
+          if (r16 == 0) {
+            j.pair_q[i] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
+            G(j.pair_gidx)[i] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
+            keep_q[slot][row] = q;
+            keep_ok[slot][row] = (ok ? 1u : 0u) | (okp ? 2u : 0u);
+          }
+        } else {
+          const uint32_t f = keep_ok[slot][row];
+          ok = (f & 1u) != 0u;
+          okp = (f & 2u) != 0u;
+          if (PL) {
+            bc = keep_c[PL ? slot : 0][row];
+            bn = keep_n[PL ? slot : 0][row];
+          }
+        }
+        if (r16 == 0) {
+          acc_pt2pt_masked(a, T, ok, x, y, z, q.x, q.y, q.z, kernel, kparam, ck->w_pt2pt);
+          if (PL && okp)
+            acc_pt2pl_rows(v, T, x, y, z, make_float4(bc.x, bc.y, bc.z, 1.f), make_float4(bn.x, bn.y, bn.z, 0.f), kernel, kparam,
+                           ck->w_pt2pl);
+        }
+      }
+      if (r16 == 0) {
+#pragma unroll
+        for (int q = 0; q < kAccN; q++) rowsA[q][row] = a.v[q];
+        if (PL) {
+#pragma unroll
+          for (int q = 0; q < kGenN; q++) rowsB[PL ? q : 0][row] = v[PL ? q : 0];
+        }
+      }
+      __syncthreads();
+      if (tid < kAccN) {
+        double sum = rowsA[tid][0];
+#pragma unroll
+        for (int r = 1; r < (int)kStepPoints; r++) sum += rowsA[tid][r];
+        loop_entry_store(bxa, (out * kAccN + tid) * kLoopRowStride + g, sum, serial0 + step + 1u);
+      }
+      if (PL && tid >= 64 && tid < 64 + kGenN) {
+        const uint32_t t = tid - 64;
+        double sum = rowsB[PL ? t : 0][0];
+#pragma unroll
+        for (int r = 1; r < (int)kStepPoints; r++) sum += rowsB[PL ? t : 0][r];
+        loop_entry_store(bxb, (out * kGenN + t) * kLoopRowStride + g, sum, serial0 + step + 1u);
+      }
+      __syncthreads();  // (the row buffers are reused by the workgroup's next group)
+    }
+    if (tid == 0) lst->pending = 1u;
+    __syncthreads();
+  }
+  if (gave_up) {
+    if (tid == 0) {
+      atomicAdd(&s_canon->handover_timeouts, 1u);
+      if (atomicCAS(&s_canon->dbg[0], 0u, 4u) == 0u) {
+        s_canon->dbg[1] = wg; s_canon->dbg[2] = gave_up - 1u; s_canon->dbg[3] = serial0 + step; s_canon->dbg[4] = step; s_canon->dbg[5] = ngroups;
+      }
+    }
+    return;
+  }
+  if (wg == 0 && tid < kStateHeadDwords) G(reinterpret_cast<uint32_t*>(s_canon))[tid] = lst_raw[tid];
+}
+template <bool PL>
+__global__ __launch_bounds__(kSolveThreads) void k_icp16_b(const BatchJob* __restrict__ jobs) {
+  icp16_multi_body<PL>(jobs[blockIdx.y]);
+}
+
 // ================================================================================================
 // Covariance (mp2p_icp::covariance [U]): A = d residuals / d (x,y,z,yaw,pitch,roll), cov = (A^T A)^-1
 // ================================================================================================
@@ -3005,6 +3169,23 @@ mh_status compact_pairs(mh_ctx* ctx, size_t n, const mh_pairs_out* out, int32_t 
 // One alignment in flight on one context: enqueue / poll state machine shared by mh_icp_align and
 // mh_icp_align_batch.
 std::atomic<unsigned long long> g_loop16_runs{0}, g_loop16_fallbacks{0};  // one-launch loops started / abandoned for the chain (mh_debug_loop_stats)
+uint32_t loop_cu_limit(int device) {
+  static uint32_t cap[64] = {0};
+  uint32_t& cu = cap[(unsigned)device % 64u];
+  if (!cu) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 64;
+    cu = (uint32_t)v;
+  }
+  const char* e = getenv("MH_LOOP16_CUS");  // (test knob: the admission limit)
+  return e ? (uint32_t)std::max(0, atoi(e)) : cu;
+}
+// the loops of `callers` alignments of `ng` groups each fit 70 % of the device's CUs side by side (one group per workgroup; shared
+// loops whose workgroups take 2 or 4 groups each were measured for 6 / 8 / 16 callers and lost to lock-step batches: 3100-3550 /
+// 3260-3540 / 3000-3140 against 4960 / 5300 / 5470-6150 scans/s -- the callers' other kernels start and stop beside them)
+bool loops_fit(int device, uint32_t ng, uint32_t callers) {
+  return callers <= 1 || (uint64_t)callers * ng * 10u <= (uint64_t)loop_cu_limit(device) * 7u;
+}
 
 struct AlignJob {
   const mh_map* map = nullptr;
@@ -3259,15 +3440,7 @@ struct AlignJob {
     return c[(unsigned)device % 64u];
   }
   static bool loop_admit(int device, uint32_t wgs) {
-    static uint32_t cap[64] = {0};
-    uint32_t& cu = cap[(unsigned)device % 64u];
-    if (!cu) {
-      int v = 0;
-      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 64;
-      cu = (uint32_t)v;
-    }
-    const char* e = getenv("MH_LOOP16_CUS");  // (test knob: the admission limit)
-    const uint32_t limit = e ? (uint32_t)std::max(0, atoi(e)) : cu;
+    const uint32_t limit = loop_cu_limit(device);
     if (wgs > limit) return false;
     // A loop that does not fit now waits for the running ones (each takes a fraction of a millisecond) rather than fall back to
     // the chain, whose forty-odd launches would queue behind the same loops: eight sequences of the default pipeline keep five
@@ -3767,16 +3940,10 @@ mh_status mh_icp_align_prefers_solo(const mh_scan* scan, const mh_icp_params* p,
           getenv("MH_NO_LOOP16") == nullptr)
              ? 1
              : 0;
-  if (*yes && concurrent_callers > 1) {  // ... and the loops of all callers fit the device together: nobody waits for a turn
-    int cu = 0;
-    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, scan->ctx->device) != hipSuccess || cu <= 0) cu = 64;
-    const char* lim = getenv("MH_LOOP16_CUS");
-    const uint64_t limit = lim ? (uint64_t)std::max(0, atoi(lim)) : (uint64_t)cu;
-    const uint64_t ng = (n + kStepPoints - 1) / kStepPoints;
-    // (70 % of the CUs: the callers' filters, de-skew and map updates run beside the loops -- five loops of 44 workgroups on
-    //  256 CUs measured slower than four, 3780 against 4000-4450 scans/s)
-    if ((uint64_t)concurrent_callers * ng * 10u > limit * 7u) *yes = 0;
-  }
+  // ... and the loops of all callers fit the device together: nobody waits for a turn.  (70 % of the CUs: the callers' filters,
+  // de-skew and map updates run beside the loops -- five loops of 44 workgroups on 256 CUs measured slower than four, 3780 against
+  // 4000-4450 scans/s.)
+  if (*yes && !loops_fit(scan->ctx->device, (uint32_t)((n + kStepPoints - 1) / kStepPoints), concurrent_callers)) *yes = 0;
   return MH_OK;
 }
 
@@ -4011,6 +4178,8 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
     uint32_t gx_match = 1, gx_acc = 1, gx_cov = 1, gx_step = 1, enq = 0, prof_n = 0, max_iterations = 0, inner = 1, chunk = 10;
     uint32_t src = 2, par = 0, launches = 0;  // k_step16_b: the state block (2 = canonical) and the partials half the next launch reads; launches so far
     bool cov = false, done = false, auto_chunk = false;
+    bool loop_now = false;   // k_icp16_b: the group's whole loops in ONE launch (decided below; cleared when a job's workgroups gave up)
+    uint32_t loop_wgs = 0;   // ... and what it holds of the device's admission count meanwhile
     bool step_chain() const { return kind == K_STEP || kind == K_STEP_PL; }
     bool with_planes() const { return kind == K_STEP_PL; }
   };
@@ -4131,6 +4300,42 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
         off += kBlockBytes + j.nsched_pending * sizeof(double);
         j.defer_upload = false;
       }
+      // Small layers: the whole loops of the group's jobs in ONE launch (k_icp16_b) when every job's layer has at most kLoopMaxGroups
+      // groups, a workgroup takes at most kLoopGroupsPerWg of them, and the launch's workgroups are admitted (all resident together,
+      // beside the one-launch loops of single alignments running on the device).  MH_NO_LOOP16 / MH_NO_LOOP16_BATCH: the chain.
+      if (g.step_chain() && getenv("MH_NO_LOOP16") == nullptr && getenv("MH_NO_LOOP16_BATCH") == nullptr &&
+          !AlignJob::loop_holdoff(lead->device, false)) {
+        bool fits = true;
+        for (uint32_t a = 0; a < A; a++) {
+          const uint32_t ng = (h_desc[a].n + kStepPoints - 1) / kStepPoints;
+          const uint32_t nw = ng < g.gx_step ? ng : g.gx_step;
+          fits = fits && ng <= kLoopMaxGroups && (nw == 0 || (ng + nw - 1) / nw <= kLoopGroupsPerWg) && g.jobs[a]->sk.max_iterations > 0;
+        }
+        if (fits && AlignJob::loop_admit(lead->device, g.gx_step * A)) {
+          g.loop_now = true;
+          g.loop_wgs = g.gx_step * A;
+          for (uint32_t a = 0; a < A && g.loop_now; a++) {
+            AlignJob& j = *g.jobs[a];
+            if (j.ctx->loop_x.bytes < kLoopExchangeBytes) {
+              if (j.ctx->loop_x.reserve(kLoopExchangeBytes) != MH_OK) {
+                g.loop_now = false;
+                break;
+              }
+              (void)hipMemsetAsync(j.ctx->loop_x.p, 0, kLoopExchangeBytes, s);
+            }
+            const uint32_t max_steps = j.p->max_iterations * j.p->gn.max_inner_iterations + 1u;
+            h_desc[a].loop_xa = j.ctx->loop_x.p;
+            h_desc[a].loop_xb = static_cast<char*>(j.ctx->loop_x.p) + 2 * (size_t)kAccN * kLoopRowStride * 16;
+            h_desc[a].loop_serial0 = j.ctx->loop_serial;
+            h_desc[a].loop_pad = getenv("MH_LOOP16_TEST_ABANDON") ? 1u : 0u;
+            j.ctx->loop_serial += max_steps + 2u;
+          }
+          if (!g.loop_now) {
+            AlignJob::loop_count(lead->device).fetch_sub(g.loop_wgs);
+            g.loop_wgs = 0;
+          }
+        }
+      }
       // descriptors and staged blocks in ONE copy, then a scatter kernel writes every job's block where it lives
       MH_HIP(hipMemcpyAsync(lead->batch_desc.p, h_desc, A * sizeof(BatchJob) + stage_bytes, hipMemcpyHostToDevice, s));
       g.dj = lead->batch_desc.as<BatchJob>();
@@ -4153,13 +4358,21 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
         if (g.done) continue;
         any = true;
         m_of[gi] = (g.max_iterations - g.enq) < g.chunk ? (g.max_iterations - g.enq) : g.chunk;
+        if (g.loop_now) {  // everything in one launch, now
+          m_of[gi] = g.max_iterations - g.enq;
+          const uint32_t A = (uint32_t)g.jobs.size();
+          g_loop16_runs.fetch_add(A);
+          if (g.with_planes()) hipLaunchKernelGGL(k_icp16_b<true>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, g.lead->stream, g.dj);
+          else hipLaunchKernelGGL(k_icp16_b<false>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, g.lead->stream, g.dj);
+          continue;
+        }
         m_max = m_of[gi] > m_max ? m_of[gi] : m_max;
       }
       if (!any) break;
       for (uint32_t it = 0; it < m_max; it++)
         for (size_t gi = 0; gi < groups.size(); gi++) {
           Group& g = groups[gi];
-          if (g.done || it >= m_of[gi]) continue;
+          if (g.done || g.loop_now || it >= m_of[gi]) continue;
           hipStream_t s = g.lead->stream;
           const uint32_t A = (uint32_t)g.jobs.size();
           const bool pr = want_prof && gi == 0 && g.jobs[0] == &jobs[0];
@@ -4202,7 +4415,7 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
         if (g.done) continue;
         hipStream_t s = g.lead->stream;
         const uint32_t A = (uint32_t)g.jobs.size();
-        if (g.step_chain()) {  // the pending Gauss-Newton step of every job, into the canonical state blocks
+        if (g.step_chain() && !g.loop_now) {  // the pending Gauss-Newton step of every job, into the canonical state blocks
           if (g.with_planes()) hipLaunchKernelGGL(k_step16_b<true>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, g.src, g.par, 1u, g.launches);
           else hipLaunchKernelGGL(k_step16_b<false>, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, g.src, g.par, 1u, g.launches);
           g.src = 2;
@@ -4221,7 +4434,41 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
       for (size_t gi = 0; gi < groups.size(); gi++) {
         Group& g = groups[gi];
         if (g.done) continue;
-        MH_HIP(mh::wait_stream(g.lead->stream));
+        const hipError_t we = mh::wait_stream(g.lead->stream);
+        if (g.loop_wgs) {
+          AlignJob::loop_count(g.lead->device).fetch_sub(g.loop_wgs);
+          g.loop_wgs = 0;
+        }
+        MH_HIP(we);
+        if (g.loop_now) {
+          // a job whose workgroups gave up waiting for each other left done == 0 and its canonical state block as uploaded: the
+          // group goes on launch by launch (k_step16_b from the start; the jobs that did finish are no-ops there)
+          g.loop_now = false;
+          bool abandoned = false;
+          for (size_t a = 0; a < g.jobs.size(); a++) {
+            const IcpDeviceState& h = g.h_states[a];
+            if (g.jobs[a]->finished || (h.done && !h.handover_timeouts)) continue;
+            abandoned = true;
+            g_loop16_fallbacks.fetch_add(1);
+            MH_HIP(hipMemsetAsync(&g.jobs[a]->ctx->d_state->handover_timeouts, 0, sizeof(uint32_t) * 10, g.lead->stream));
+          }
+          if (abandoned) {
+            if (getenv("MH_LOOP16_TEST_ABANDON") == nullptr) AlignJob::loop_holdoff(g.lead->device, true);
+            for (size_t a = 0; a < g.jobs.size(); a++) {
+              AlignJob& j = *g.jobs[a];
+              const IcpDeviceState& h = g.h_states[a];
+              if (j.finished || !(h.done && !h.handover_timeouts)) continue;
+              memcpy(j.ctx->h_state, &h, sizeof(IcpDeviceState));
+              j.enqueued = j.p->max_iterations;
+              MH_TRY(j.poll(true));
+            }
+            g.enq = 0;
+            g.src = 2;
+            g.par = 0;
+            g.launches = 0;
+            continue;  // (not done: the next round enqueues the chain's first chunk)
+          }
+        }
         g.enq += m_of[gi];
         g.done = true;
         if (g.auto_chunk) g.chunk = 8;  // follow-up chunks

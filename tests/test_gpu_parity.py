@@ -992,6 +992,51 @@ def test_one_launch_loop_of_small_layers(ctx, ndt, monkeypatch):
                 np.testing.assert_array_equal(a["T"], b["T"])
 
 
+@pytest.mark.parametrize("ndt", [False, True])
+def test_one_launch_loops_of_a_lockstep_batch(ctx, ndt, monkeypatch):
+    """A lock-step batch of small layers runs the jobs' whole loops side by side in ONE launch (k_icp16_b: a job's workgroups
+    exchange among themselves, a workgroup takes several groups when the jobs have to share the CUs).  Same bits as single
+    alignments, as the launch-by-launch batch (MH_NO_LOOP16_BATCH=1) and as the second attempt after an abandoned loop."""
+    pts = _ndt_cloud(81)
+    gm = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts) if ndt else capi.Map(ctx, 1.0, 20).build(pts)
+    rng = np.random.default_rng(82)
+    thr, kp = synth.threshold_schedule(0.5, 60)
+    kw = dict(max_iterations=60, threshold=thr, kernel_param=kp, gn=capi.GNParams(max_inner_iterations=2))
+    if ndt:
+        kw["pt2pl_threshold"] = 0.5
+    p = capi.ICPParams(**kw)
+    sizes = [1500, 900, 2048, 33, 1, 1400, 1400, 700, 2000, 1999, 64, 1234]  # 12 jobs: 21 workgroups each, up to 4 groups per workgroup
+    ctxs = [capi.Context(0) for _ in sizes]
+    subs = [pts[rng.integers(0, len(pts), n)] + rng.normal(0, 0.01, (n, 3)).astype(np.float32) for n in sizes]
+    guesses = [synth.pose_from_ypr([0.1 + 0.02 * (k % 4), -0.08, 0.05, 0.006, -0.004, 0.01]) for k in range(len(sizes))]
+    single = [capi.icp_align(gm, capi.Scan(ctx, s), g, p, want_trace=False) for s, g in zip(subs, guesses)]
+    scans = [capi.Scan(c, s) for c, s in zip(ctxs, subs)]
+
+    def same(batch, count):
+        for a, c in zip(single[:count], batch):
+            assert a["n_iterations"] == c["n_iterations"] and a["termination_reason"] == c["termination_reason"]
+            np.testing.assert_array_equal(a["T"], c["T"])
+            np.testing.assert_array_equal(a["cov"], c["cov"])
+            assert a["n_final_pairs"] == c["n_final_pairs"] and a["n_final_pairs_pt2pl"] == c["n_final_pairs_pt2pl"]
+
+    for count in (len(sizes), 8, 2):
+        s0, a0 = capi.loop_stats()
+        same(capi.icp_align_batch([gm] * count, scans[:count], guesses[:count], p), count)
+        s1, a1 = capi.loop_stats()
+        assert s1 - s0 == count and a1 == a0  # every job ran as a loop
+        monkeypatch.setenv("MH_NO_LOOP16_BATCH", "1")
+        same(capi.icp_align_batch([gm] * count, scans[:count], guesses[:count], p), count)
+        assert capi.loop_stats() == (s1, a1)
+        monkeypatch.delenv("MH_NO_LOOP16_BATCH")
+        monkeypatch.setenv("MH_LOOP16_TEST_ABANDON", "1")
+        same(capi.icp_align_batch([gm] * count, scans[:count], guesses[:count], p), count)
+        s2, a2 = capi.loop_stats()
+        assert s2 - s1 == count and a2 - a1 >= 1
+        monkeypatch.delenv("MH_LOOP16_TEST_ABANDON")
+    for c in ctxs:
+        c.close()
+
+
 def test_solo_hint_agrees_with_what_a_single_alignment_does(ctx, monkeypatch):
     """mh_icp_align_prefers_solo (the batching hint of the multi-sequence runner) says "one launch" exactly when mh_icp_align
     then starts a one-launch loop."""
@@ -1017,9 +1062,10 @@ def test_solo_hint_agrees_with_what_a_single_alignment_does(ctx, monkeypatch):
         assert hint == (n <= 2048 and not extra and not env)
         if hint:  # ... with company: as long as everybody's workgroups fit the device together
             groups = (n + 31) // 32
-            fit = (256 * 7 // 10) // groups  # (MI355X: 256 CUs, 70 % of them for loops)
-            assert capi.icp_align_prefers_solo(scan, p, guess, concurrent_callers=max(1, fit))
-            assert not capi.icp_align_prefers_solo(scan, p, guess, concurrent_callers=max(2, fit + 1))
+            def fits(callers):  # (MI355X: 256 CUs, 70 % of them for loops)
+                return callers <= 1 or callers * groups * 10 <= 256 * 7
+            for callers in (1, 2, 4, 5, 8, 9, 16, 17, 64, 179, 180, 1000):
+                assert capi.icp_align_prefers_solo(scan, p, guess, concurrent_callers=callers) == fits(callers), (n, callers)
         for k in env:
             monkeypatch.delenv(k)
 

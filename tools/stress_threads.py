@@ -56,4 +56,5 @@ for t in range(T):
     bad += 0 if ok else 1
     print("thread %d: %d results -> %s" % (t, len(serial[t]), "identical to the serial run" if ok else "MISMATCH"))
 print("mismatches:", bad)
+print("one-launch loops started / abandoned (whole process): %d / %d" % capi.loop_stats())
 sys.exit(1 if bad else 0)
