@@ -4184,6 +4184,16 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
     bool with_planes() const { return kind == K_STEP_PL; }
   };
   std::vector<Group> groups;
+  struct ReleaseLoops {  // whatever way this call ends, the groups' share of the device's loop admission count is given back
+    std::vector<Group>* gs;
+    ~ReleaseLoops() {
+      for (Group& g : *gs)
+        if (g.loop_wgs && g.lead) {
+          AlignJob::loop_count(g.lead->device).fetch_sub(g.loop_wgs);
+          g.loop_wgs = 0;
+        }
+    }
+  } release_loops{&groups};
   const bool want_prof = !jobs.empty() && jobs[0].prof && !no_lockstep;  // profile == 2: the share of job 0's group
   if (want_prof) jobs[0].prof = false;
   for (size_t i = 0; i < n_jobs; i++) {
