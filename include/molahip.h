@@ -216,10 +216,15 @@ MH_API mh_status mh_scan_size(const mh_scan* scan, uint64_t* n);
  * Scan pre-processing on the device: the observation filter chain that produces the
  * layers `decimated_for_map` / `decimated_for_icp` from the raw sensor cloud.  Replaces, for the
  * configuration of lidar3d-default.yaml:270-350, mp2p_icp_filters::{FilterAdjustTimestamps,
- * FilterDecimateVoxels(FirstPoint), FilterByRange, FilterBoundingBox, FilterDeskew} [U].
+ * FilterDecimateVoxels(FirstPoint | ClosestToAverage), FilterByRange, FilterBoundingBox, FilterDeskew} [U].
  * ---------------------------------------------------------------------------------------------- */
 enum { MH_TS_NONE = 0, MH_TS_MIDDLE_IS_ZERO = 1, MH_TS_EARLIEST_IS_ZERO = 2 }; /* TimestampAdjustMethod (yaml:275) */
 enum { MH_BBOX_OFF = 0, MH_BBOX_KEEP_OUTSIDE = 1, MH_BBOX_KEEP_INSIDE = 2 };
+/* FilterDecimateVoxels decimate_method [U]: FirstPoint (the shipped lidar3d pipelines, yaml:291) keeps the first point of every
+ * voxel in input order; ClosestToAverage (rgbd.yaml:254-278; the commented alternative at lidar3d-default.yaml:292) keeps, per
+ * voxel, the point closest to the voxel's mean -- mean = (float sum of the voxel's points in input order) * (1.0f / count),
+ * squared error (dx*dx + dy*dy) + dz*dz in float, the first of equally close points. */
+enum { MH_DECIMATE_FIRST_POINT = 0, MH_DECIMATE_CLOSEST_TO_AVERAGE = 1 };
 
 typedef struct {
   float decim_map_resolution;    /* FilterDecimateVoxels #1 voxel_filter_resolution (yaml:289); 0 = stage skipped */
@@ -232,6 +237,8 @@ typedef struct {
   float bbox_min[3], bbox_max[3];
   int32_t timestamp_method;      /* FilterAdjustTimestamps (yaml:270-276): MH_TS_* ; ignored without time stamps */
   float time_offset;
+  int32_t decim_map_method;      /* decimate_method of FilterDecimateVoxels #1: MH_DECIMATE_* (0 = FirstPoint) */
+  int32_t decim_icp_method;      /* ... of FilterDecimateVoxels #2 */
 } mh_preprocess_params;
 
 /* Attach per-point time stamps [s] (relative to the scan's reference time) to a scan of the same size. */

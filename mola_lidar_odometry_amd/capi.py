@@ -124,10 +124,11 @@ class PreprocessParams(C.Structure):
                 ("min_points_to_filter", C.c_uint32), ("index_mode", C.c_int32), ("range_min", C.c_float),
                 ("range_max", C.c_float), ("range_center", C.c_float * 3), ("bbox_mode", C.c_int32),
                 ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("timestamp_method", C.c_int32),
-                ("time_offset", C.c_float)]
+                ("time_offset", C.c_float), ("decim_map_method", C.c_int32), ("decim_icp_method", C.c_int32)]
 
 
 TS_NONE, TS_MIDDLE_IS_ZERO, TS_EARLIEST_IS_ZERO = 0, 1, 2
+DECIMATE_FIRST_POINT, DECIMATE_CLOSEST_TO_AVERAGE = 0, 1
 BBOX_OFF, BBOX_KEEP_OUTSIDE, BBOX_KEEP_INSIDE = 0, 1, 2
 
 
@@ -821,9 +822,10 @@ def preprocess_batch(raws, params, out_maps, out_icps=None):
 def preprocess_params(decim_map_resolution, decim_icp_resolution, min_points_to_filter=2000, index_mode=INDEX_FLOOR,
                       range_min=0.0, range_max=0.0, range_center=(0.0, 0.0, 0.0), bbox_mode=BBOX_OFF,
                       bbox_min=(0.0, 0.0, 0.0), bbox_max=(0.0, 0.0, 0.0), timestamp_method=TS_NONE,
-                      time_offset=0.0) -> PreprocessParams:
+                      time_offset=0.0, decim_map_method=DECIMATE_FIRST_POINT,
+                      decim_icp_method=DECIMATE_FIRST_POINT) -> PreprocessParams:
     return PreprocessParams(float(decim_map_resolution), float(decim_icp_resolution), int(min_points_to_filter),
                             int(index_mode), float(range_min), float(range_max),
                             (C.c_float * 3)(*map(float, range_center)), int(bbox_mode),
                             (C.c_float * 3)(*map(float, bbox_min)), (C.c_float * 3)(*map(float, bbox_max)),
-                            int(timestamp_method), float(time_offset))
+                            int(timestamp_method), float(time_offset), int(decim_map_method), int(decim_icp_method))

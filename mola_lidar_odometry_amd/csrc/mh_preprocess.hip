@@ -31,6 +31,7 @@ struct StageParams {
   float bmin[3], bmax[3];
   int32_t ts_method;   // applied to t while compacting (stage 1 only)
   float ts_offset;
+  uint32_t method;     // MH_DECIMATE_*: which point of a voxel survives
 };
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -517,6 +518,113 @@ __global__ __launch_bounds__(256) void k_pp_flag_b(const PpJob* __restrict__ job
   // of this kernel's time, 2 k of them for a 120 k-point scan)
 }
 
+// DecimateMethod::ClosestToAverage [U]: the survivor of a voxel is the point closest to the voxel's mean, the mean being the
+// float sum of its points IN INPUT ORDER times 1.0f / count -- an order no atomic gives.  So for a stage with this method the
+// points of ONE scan are sorted by voxel key (stable radix sort: input order inside a voxel), the first lane of every run of
+// equal keys walks its run twice (sum, then closest; strictly closer wins, i.e. the first of equals) and writes the winner's
+// index where k_pp_insert_b left the voxel's smallest one: k_pp_flag_b keeps "the index the table names" either way.
+constexpr unsigned long long kCtaInvalid = ~0ull;
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_cta_keys(const PpJob* __restrict__ jobs, uint32_t job, unsigned long long* __restrict__ keys,
+                                                  uint32_t* __restrict__ idx) {
+  const PpJob& j = jobs[job];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= j.n) return;
+  const float *x, *y, *z;
+  uint32_t n, mask, *first;
+  unsigned long long* tk;
+  StageParams sp;
+  pp_stage_view<STAGE>(j, x, y, z, n, sp, tk, first, mask);
+  unsigned long long key = kCtaInvalid;
+  if (sp.decimate && i < n) {
+    unsigned long long k;
+    if (pp_key(G(x)[i], G(y)[i], G(z)[i], sp.inv_res, sp.trunc, k, j.counters)) key = k;
+  }
+  keys[i] = key;
+  idx[i] = i;
+}
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_cta_choose(const PpJob* __restrict__ jobs, uint32_t job,
+                                                    const unsigned long long* __restrict__ keys_s, const uint32_t* __restrict__ perm) {
+  const PpJob& j = jobs[job];
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= j.n) return;
+  const unsigned long long key = keys_s[p];
+  if (key == kCtaInvalid || (p > 0 && keys_s[p - 1] == key)) return;  // not the head of a voxel's run
+  const float *x, *y, *z;
+  uint32_t n, mask, *first;
+  unsigned long long* tk;
+  StageParams sp;
+  pp_stage_view<STAGE>(j, x, y, z, n, sp, tk, first, mask);
+  const float MH_AS_GLOBAL* gx = G(x);
+  const float MH_AS_GLOBAL* gy = G(y);
+  const float MH_AS_GLOBAL* gz = G(z);
+  // (the sum is a serial chain by definition -- a voxel next to the sensor holds thousands of points -- but its operands are not:
+  //  eight points' indices and coordinates are requested together, then added one after the other)
+  uint32_t cnt;
+  {  // the end of the run of equal keys: gallop, then bisect (sorted keys)
+    uint32_t step = 1;
+    while (p + step < j.n && keys_s[p + step] == key) step *= 2u;
+    uint32_t lo = p + step / 2u, hi = p + step < j.n ? p + step : j.n;  // keys_s[lo] == key; hi: first position known to differ, or the end
+    while (hi - lo > 1u) {
+      const uint32_t mid = lo + (hi - lo) / 2u;
+      if (keys_s[mid] == key) lo = mid;
+      else hi = mid;
+    }
+    cnt = hi - p;
+  }
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (uint32_t q = 0; q < cnt; q += 8u) {
+    uint32_t ii[8];
+    float vx[8], vy[8], vz[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) ii[u] = perm[p + (q + u < cnt ? q + u : cnt - 1u)];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      vx[u] = gx[ii[u]];
+      vy[u] = gy[ii[u]];
+      vz[u] = gz[ii[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (q + u < cnt) {
+        sx += vx[u];
+        sy += vy[u];
+        sz += vz[u];
+      }
+  }
+  const float inv_n = 1.0f / (float)cnt;
+  const float mx = sx * inv_n, my = sy * inv_n, mz = sz * inv_n;
+  float best = 0.f;
+  uint32_t best_i = perm[p];
+  for (uint32_t q = 0; q < cnt; q += 8u) {
+    uint32_t ii[8];
+    float vx[8], vy[8], vz[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) ii[u] = perm[p + (q + u < cnt ? q + u : cnt - 1u)];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      vx[u] = gx[ii[u]];
+      vy[u] = gy[ii[u]];
+      vz[u] = gz[ii[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (q + u < cnt) {
+        const float dx = vx[u] - mx, dy = vy[u] - my, dz = vz[u] - mz;
+        const float e = (dx * dx + dy * dy) + dz * dz;
+        if (q + u == 0 || e < best) {
+          best = e;
+          best_i = ii[u];
+        }
+      }
+  }
+  const unsigned long long MH_AS_GLOBAL* gkeys = G(tk);
+  uint32_t h = hash_key(key) & mask;
+  while (gkeys[h] != key) h = (h + 1) & mask;  // inserted by k_pp_insert_b
+  G(first)[h] = best_i;
+}
+
 // pos = exclusive scan of the flags of ALL scans in a row: a survivor's place in its own output is pos - pos[first of scan]
 template <int STAGE>
 __global__ __launch_bounds__(256) void k_pp_compact_b(const PpJob* __restrict__ jobs, const uint32_t* __restrict__ flag,
@@ -564,6 +672,7 @@ StageParams stage1_of(const mh_preprocess_params* p, size_t n, bool has_t) {
   for (int a = 0; a < 3; a++) { s1.bmin[a] = p->bbox_min[a]; s1.bmax[a] = p->bbox_max[a]; }
   s1.ts_method = has_t ? p->timestamp_method : MH_TS_NONE;
   s1.ts_offset = p->time_offset;
+  s1.method = (uint32_t)p->decim_map_method;
   return s1;
 }
 
@@ -623,6 +732,7 @@ mh_status preprocess_batch(size_t n_jobs, const mh_scan* const* raws, const mh_p
     j.s2.trunc = j.s1.trunc;
     j.s2.decimate = p->decim_icp_resolution > 0.f ? 1u : 0u;  // && stage 1 left >= min_points: decided on the device
     j.s2.ts_method = MH_TS_NONE;
+    j.s2.method = (uint32_t)p->decim_icp_method;
     j.min_points = p->min_points_to_filter;
     j.want_icp = oi ? 1u : 0u;
     j.want_t = has_t ? 1u : 0u;
@@ -664,7 +774,39 @@ mh_status preprocess_batch(size_t n_jobs, const mh_scan* const* raws, const mh_p
   }
   size_t tmp = 0;
   MH_HIP(rocprim::exclusive_scan(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, total, rocprim::plus<uint32_t>(), s));
+  // ClosestToAverage stages: one scan at a time through a stable sort by voxel key (scratch: keys | sorted keys | indices | order)
+  bool any_cta = false;
+  for (size_t k = 0; k < n_jobs; k++) any_cta = any_cta || h_jobs[k].s1.method == MH_DECIMATE_CLOSEST_TO_AVERAGE || h_jobs[k].s2.method == MH_DECIMATE_CLOSEST_TO_AVERAGE;
+  unsigned long long *cta_keys = nullptr, *cta_keys_s = nullptr;
+  uint32_t *cta_idx = nullptr, *cta_perm = nullptr;
+  if (any_cta) {
+    MH_TRY(lead->build_d.reserve(2 * max_n * sizeof(unsigned long long) + 2 * max_n * sizeof(uint32_t) + 256));
+    cta_keys = lead->build_d.as<unsigned long long>();
+    cta_keys_s = cta_keys + max_n;
+    cta_idx = reinterpret_cast<uint32_t*>(cta_keys_s + max_n);
+    cta_perm = cta_idx + max_n;
+    size_t t2 = 0;
+    MH_HIP(rocprim::radix_sort_pairs(nullptr, t2, cta_keys, cta_keys_s, cta_idx, cta_perm, (uint32_t)max_n, 0, 64, s));
+    if (t2 > tmp) tmp = t2;
+  }
   MH_TRY(lead->sort_tmp.reserve(tmp));
+  auto closest_to_average = [&](int stage) -> mh_status {
+    if (!any_cta) return MH_OK;
+    for (size_t k = 0; k < n_jobs; k++) {
+      const PpJob& j = h_jobs[k];
+      const StageParams& sp = stage == 1 ? j.s1 : j.s2;
+      if (sp.method != MH_DECIMATE_CLOSEST_TO_AVERAGE || !sp.decimate || !j.n || (stage == 2 && !j.want_icp)) continue;
+      const uint32_t N = j.n;
+      const dim3 g1(nblk(N, 256));
+      if (stage == 1) hipLaunchKernelGGL(k_cta_keys<1>, g1, dim3(256), 0, s, d_jobs, (uint32_t)k, cta_keys, cta_idx);
+      else hipLaunchKernelGGL(k_cta_keys<2>, g1, dim3(256), 0, s, d_jobs, (uint32_t)k, cta_keys, cta_idx);
+      size_t tb2 = lead->sort_tmp.bytes;
+      MH_HIP(rocprim::radix_sort_pairs(lead->sort_tmp.p, tb2, cta_keys, cta_keys_s, cta_idx, cta_perm, N, 0, 64, s));
+      if (stage == 1) hipLaunchKernelGGL(k_cta_choose<1>, g1, dim3(256), 0, s, d_jobs, (uint32_t)k, cta_keys_s, cta_perm);
+      else hipLaunchKernelGGL(k_cta_choose<2>, g1, dim3(256), 0, s, d_jobs, (uint32_t)k, cta_keys_s, cta_perm);
+    }
+    return MH_OK;
+  };
   MH_HIP(hipMemcpyAsync(d_jobs, h_jobs, n_jobs * sizeof(PpJob), hipMemcpyHostToDevice, s));
   const uint32_t B = 256;
   const dim3 grid(nblk(max_n, B), (uint32_t)n_jobs);
@@ -672,12 +814,14 @@ mh_status preprocess_batch(size_t n_jobs, const mh_scan* const* raws, const mh_p
   hipLaunchKernelGGL(k_pp_init_b, dim3(init_blocks < 512u ? init_blocks : 512u, (uint32_t)n_jobs), dim3(B), 0, s, d_jobs);
   if (any_t) hipLaunchKernelGGL(k_pp_tminmax_b, dim3(grid.x < 128u ? grid.x : 128u, (uint32_t)n_jobs), dim3(B), 0, s, d_jobs);
   hipLaunchKernelGGL(k_pp_insert_b<1>, grid, dim3(B), 0, s, d_jobs);
+  MH_TRY(closest_to_average(1));
   hipLaunchKernelGGL(k_pp_flag_b<1>, grid, dim3(B), 0, s, d_jobs, flag);
   size_t tb = lead->sort_tmp.bytes;
   MH_HIP(rocprim::exclusive_scan(lead->sort_tmp.p, tb, flag, pos, 0u, total, rocprim::plus<uint32_t>(), s));
   hipLaunchKernelGGL(k_pp_compact_b<1>, grid, dim3(B), 0, s, d_jobs, flag, pos);
   if (any_icp) {
     hipLaunchKernelGGL(k_pp_insert_b<2>, grid, dim3(B), 0, s, d_jobs);
+    MH_TRY(closest_to_average(2));
     hipLaunchKernelGGL(k_pp_flag_b<2>, grid, dim3(B), 0, s, d_jobs, flag);
     tb = lead->sort_tmp.bytes;
     MH_HIP(rocprim::exclusive_scan(lead->sort_tmp.p, tb, flag, pos, 0u, total, rocprim::plus<uint32_t>(), s));
@@ -774,6 +918,9 @@ static mh_status check_preprocess_args(const mh_scan* raw, const mh_preprocess_p
   MH_REQUIRE(p->index_mode == MH_INDEX_FLOOR || p->index_mode == MH_INDEX_TRUNC, "bad index_mode");
   MH_REQUIRE(p->bbox_mode >= MH_BBOX_OFF && p->bbox_mode <= MH_BBOX_KEEP_INSIDE, "bad bbox_mode");
   MH_REQUIRE(p->timestamp_method >= MH_TS_NONE && p->timestamp_method <= MH_TS_EARLIEST_IS_ZERO, "bad timestamp_method");
+  MH_REQUIRE((p->decim_map_method == MH_DECIMATE_FIRST_POINT || p->decim_map_method == MH_DECIMATE_CLOSEST_TO_AVERAGE) &&
+                 (p->decim_icp_method == MH_DECIMATE_FIRST_POINT || p->decim_icp_method == MH_DECIMATE_CLOSEST_TO_AVERAGE),
+             "bad decimate method");
   MH_REQUIRE(raw->n < 0x7FFFFFF0ull, "scan too large");
   return MH_OK;
 }

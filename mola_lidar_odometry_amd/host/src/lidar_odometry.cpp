@@ -226,19 +226,25 @@ struct LidarOdometry::FilterPlan : public Parameterizable {
   double bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
   double time_offset = 0;
   uint32_t min_points_to_filter = 0;
+  int32_t decim_map_method = MH_DECIMATE_FIRST_POINT, decim_icp_method = MH_DECIMATE_FIRST_POINT;
   int32_t bbox_mode = MH_BBOX_OFF, timestamp_method = MH_TS_NONE;
   bool skip_deskew = false;
   std::string layer_for_map, layer_for_icp, map_layer;
 
   static void unsupported(const std::string& what) {
     throw std::runtime_error("LidarOdometry (HIP): unsupported observation filter chain: " + what +
-                             ". Implemented on the device: FilterAdjustTimestamps; FilterDecimateVoxels(FirstPoint) -> "
-                             "[FilterByRange] -> [FilterBoundingBox] -> FilterDecimateVoxels(FirstPoint); FilterDeskew x2; "
+                             ". Implemented on the device: FilterAdjustTimestamps; FilterDecimateVoxels(FirstPoint | ClosestToAverage) -> "
+                             "[FilterByRange] -> [FilterBoundingBox] -> FilterDecimateVoxels(FirstPoint | ClosestToAverage); FilterDeskew x2; "
                              "FilterMerge (the chain of pipelines/lidar3d-default.yaml)");
   }
   void decimate(const Config& p, double* res) {
-    if (p.has("decimate_method") && !ends_with(p["decimate_method"].asString(), "FirstPoint"))
-      unsupported("decimate_method " + p["decimate_method"].asString());
+    int32_t method = MH_DECIMATE_FIRST_POINT;  // (the default of FilterDecimateVoxels; lidar3d-default.yaml:291 spells it out)
+    if (p.has("decimate_method")) {
+      const std::string m = p["decimate_method"].asString();
+      if (ends_with(m, "ClosestToAverage")) method = MH_DECIMATE_CLOSEST_TO_AVERAGE;  // (yaml:292, the commented alternative)
+      else if (!ends_with(m, "FirstPoint")) unsupported("decimate_method " + m);
+    }
+    (res == &decim_map_res ? decim_map_method : decim_icp_method) = method;
     parameterFromConfig(p, "voxel_filter_resolution", res, true);
     const uint32_t mp = p.has("minimum_input_points_to_filter") ? (uint32_t)to_double(p["minimum_input_points_to_filter"].asString()) : 0;
     if (res == &decim_map_res) min_points_to_filter = mp;
@@ -524,7 +530,8 @@ static double bbox_radius(const float mn[3], const float mx[3]) {
 
 static mh_preprocess_params make_pp(double decim_map_res, double decim_icp_res, uint32_t min_points_to_filter, double range_min,
                                     double range_max, int32_t bbox_mode, const double bbox_min[3], const double bbox_max[3],
-                                    int32_t timestamp_method, double time_offset) {
+                                    int32_t timestamp_method, double time_offset, int32_t decim_map_method = MH_DECIMATE_FIRST_POINT,
+                                    int32_t decim_icp_method = MH_DECIMATE_FIRST_POINT) {
   mh_preprocess_params pp;
   memset(&pp, 0, sizeof(pp));  // (compared bytewise with the parameters a prefetch used)
   pp.decim_map_resolution = (float)decim_map_res;
@@ -540,13 +547,15 @@ static mh_preprocess_params make_pp(double decim_map_res, double decim_icp_res, 
   }
   pp.timestamp_method = timestamp_method;
   pp.time_offset = (float)time_offset;
+  pp.decim_map_method = decim_map_method;
+  pp.decim_icp_method = decim_icp_method;
   return pp;
 }
 
 void LidarOdometry::run_first_pass() {
   const FilterPlan& f = *plan_;
   const mh_preprocess_params pp = make_pp(f.decim_map_res, f.decim_icp_res, f.min_points_to_filter, f.range_min, f.range_max,
-                                          f.bbox_mode, f.bbox_min, f.bbox_max, f.timestamp_method, f.time_offset);
+                                          f.bbox_mode, f.bbox_min, f.bbox_max, f.timestamp_method, f.time_offset, f.decim_map_method, f.decim_icp_method);
   // (not through the batcher even when there is one: its filter sets are made of the PREFETCH requests, one action per
   // alignment and participant -- this call is the first scan of a sequence, or a prepared scan that has to be redone)
   check(mh_scan_preprocess(raw_->handle(), &pp, map_skewed_->handle(), icp_skewed_->handle()), "mh_scan_preprocess");
@@ -614,7 +623,7 @@ void LidarOdometry::launch_prefetch() {
   plan_->realizeWith(vars);
   const FilterPlan& f = *plan_;
   pf_->pp = make_pp(f.decim_map_res, f.decim_icp_res, f.min_points_to_filter, f.range_min, f.range_max, f.bbox_mode,
-                    f.bbox_min, f.bbox_max, f.timestamp_method, f.time_offset);
+                    f.bbox_min, f.bbox_max, f.timestamp_method, f.time_offset, f.decim_map_method, f.decim_icp_method);
   plan_->realizeWith(source_.getVariableValues());  // and back: this scan goes on with what it started with
   const RawInput in = pf_->in;
   const mh_preprocess_params pp = pf_->pp;
@@ -770,7 +779,7 @@ const LidarOdometry::ScanRecord& LidarOdometry::process(double this_obs_tim, con
   if (prepared) {  // valid only if the parameters published just now are the ones the worker used
     const FilterPlan& f = *plan_;
     const mh_preprocess_params now = make_pp(f.decim_map_res, f.decim_icp_res, f.min_points_to_filter, f.range_min, f.range_max,
-                                             f.bbox_mode, f.bbox_min, f.bbox_max, f.timestamp_method, f.time_offset);
+                                             f.bbox_mode, f.bbox_min, f.bbox_max, f.timestamp_method, f.time_offset, f.decim_map_method, f.decim_icp_method);
     if (memcmp(&now, &pf_->pp, sizeof(now)) == 0) {
       cur_raw_ = raw_b_[pf_->slot];
       cur_map_skewed_ = map_skewed_b_[pf_->slot];

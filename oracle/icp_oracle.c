@@ -1244,6 +1244,67 @@ size_t orc_decimate_first_point(const float* x, const float* y, const float* z, 
   return o;
 }
 
+typedef struct { int32_t k[3]; uint32_t used, count, best; float sx, sy, sz, mx, my, mz, best_e; } cta_cell;
+
+size_t orc_decimate_closest_to_average(const float* x, const float* y, const float* z, size_t n, float resolution,
+                                       uint32_t min_points_to_filter, int index_mode, uint32_t* out_idx) {
+  size_t o = 0;
+  if (resolution <= 0.f || n < min_points_to_filter) {
+    for (size_t i = 0; i < n; i++)
+      if (isfinite(x[i]) && isfinite(y[i]) && isfinite(z[i])) out_idx[o++] = (uint32_t)i;
+    return o;
+  }
+  const float inv = 1.0f / resolution;
+  size_t tsize = 64;
+  while (tsize < 2 * n) tsize <<= 1;
+  cta_cell* tab = (cta_cell*)calloc(tsize, sizeof(cta_cell));
+  uint32_t* cell_of = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+  /* pass 1: the voxel of every point; per voxel the float sum of its points in input order */
+  for (size_t i = 0; i < n; i++) {
+    cell_of[i] = 0xFFFFFFFFu;
+    if (!isfinite(x[i]) || !isfinite(y[i]) || !isfinite(z[i])) continue;
+    int32_t k[3];
+    const float s[3] = {x[i] * inv, y[i] * inv, z[i] * inv};
+    for (int a = 0; a < 3; a++) k[a] = (index_mode == ORC_INDEX_TRUNC) ? (int32_t)s[a] : (int32_t)floorf(s[a]);
+    size_t h = hash3(k[0], k[1], k[2]) & (tsize - 1);
+    while (tab[h].used && !(tab[h].k[0] == k[0] && tab[h].k[1] == k[1] && tab[h].k[2] == k[2])) h = (h + 1) & (tsize - 1);
+    if (!tab[h].used) {
+      tab[h].used = 1;
+      tab[h].k[0] = k[0]; tab[h].k[1] = k[1]; tab[h].k[2] = k[2];
+    }
+    tab[h].sx += x[i];
+    tab[h].sy += y[i];
+    tab[h].sz += z[i];
+    tab[h].count++;
+    cell_of[i] = (uint32_t)h;
+  }
+  for (size_t h = 0; h < tsize; h++)
+    if (tab[h].used) {
+      const float inv_n = 1.0f / (float)tab[h].count;
+      tab[h].mx = tab[h].sx * inv_n;
+      tab[h].my = tab[h].sy * inv_n;
+      tab[h].mz = tab[h].sz * inv_n;
+      tab[h].count = 0; /* (now: points seen by pass 2) */
+    }
+  /* pass 2: per voxel the point closest to the mean; a strictly smaller error replaces the candidate (the first of equals stays) */
+  for (size_t i = 0; i < n; i++) {
+    if (cell_of[i] == 0xFFFFFFFFu) continue;
+    cta_cell* c = &tab[cell_of[i]];
+    const float dx = x[i] - c->mx, dy = y[i] - c->my, dz = z[i] - c->mz;
+    const float e = (dx * dx + dy * dy) + dz * dz;
+    if (c->count == 0 || e < c->best_e) {
+      c->best_e = e;
+      c->best = (uint32_t)i;
+    }
+    c->count++;
+  }
+  for (size_t i = 0; i < n; i++)
+    if (cell_of[i] != 0xFFFFFFFFu && tab[cell_of[i]].best == (uint32_t)i) out_idx[o++] = (uint32_t)i;
+  free(cell_of);
+  free(tab);
+  return o;
+}
+
 size_t orc_filter_by_range(const float* x, const float* y, const float* z, size_t n, float range_min, float range_max,
                            const float center[3], uint32_t* out_idx) {
   const float sq_min = range_min * range_min, sq_max = range_max * range_max;
@@ -1298,12 +1359,16 @@ void orc_preprocess(const float* x, const float* y, const float* z, size_t n, co
     m = k_;                                                                          \
   } while (0)
   /* (selection lists are ascending, so the in-place gather never overwrites an unread entry) */
-  ORC_APPLY(orc_decimate_first_point(bx, by, bz, m, p->decim_map_resolution, p->min_points_to_filter, p->index_mode, sel));
+  ORC_APPLY(p->decim_map_method == ORC_DECIMATE_CLOSEST_TO_AVERAGE
+                ? orc_decimate_closest_to_average(bx, by, bz, m, p->decim_map_resolution, p->min_points_to_filter, p->index_mode, sel)
+                : orc_decimate_first_point(bx, by, bz, m, p->decim_map_resolution, p->min_points_to_filter, p->index_mode, sel));
   if (p->range_max > 0.f) ORC_APPLY(orc_filter_by_range(bx, by, bz, m, p->range_min, p->range_max, p->range_center, sel));
   if (p->bbox_mode) ORC_APPLY(orc_filter_bbox(bx, by, bz, m, p->bbox_min, p->bbox_max, p->bbox_mode == 2, sel));
   for (size_t i = 0; i < m; i++) idx_map[i] = cur[i];
   *n_map = m;
-  ORC_APPLY(orc_decimate_first_point(bx, by, bz, m, p->decim_icp_resolution, p->min_points_to_filter, p->index_mode, sel));
+  ORC_APPLY(p->decim_icp_method == ORC_DECIMATE_CLOSEST_TO_AVERAGE
+                ? orc_decimate_closest_to_average(bx, by, bz, m, p->decim_icp_resolution, p->min_points_to_filter, p->index_mode, sel)
+                : orc_decimate_first_point(bx, by, bz, m, p->decim_icp_resolution, p->min_points_to_filter, p->index_mode, sel));
   for (size_t i = 0; i < m; i++) idx_icp[i] = cur[i];
   *n_icp = m;
 #undef ORC_APPLY

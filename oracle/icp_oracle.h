@@ -283,6 +283,16 @@ void orc_adjust_timestamps(float* t, size_t n, int method, float time_offset);
 size_t orc_decimate_first_point(const float* x, const float* y, const float* z, size_t n, float resolution,
                                 uint32_t min_points_to_filter, int index_mode, uint32_t* out_idx);
 
+/* FilterDecimateVoxels, DecimateMethod::ClosestToAverage [U] (pipelines/rgbd.yaml:254-278; the commented alternative of
+ * lidar3d-default.yaml:292): per voxel, mean = (float sum of the voxel's points in input order) * (1.0f / count); the point
+ * with the smallest (dx*dx + dy*dy) + dz*dz to it survives, a strictly smaller error replacing the candidate (the first of
+ * equally close points stays).  Pass-through below min_points_to_filter, non-finite points dropped, ascending output as for
+ * FirstPoint.  mp2p_icp_filters is not vendored: the float accumulation and the first-of-equals rule are this restatement's
+ * reading; tests/test_oracle_decimate.py pins it against an independent numpy reading. */
+enum { ORC_DECIMATE_FIRST_POINT = 0, ORC_DECIMATE_CLOSEST_TO_AVERAGE = 1 };
+size_t orc_decimate_closest_to_average(const float* x, const float* y, const float* z, size_t n, float resolution,
+                                       uint32_t min_points_to_filter, int index_mode, uint32_t* out_idx);
+
 /* FilterByRange (yaml:297-302): keep range_min^2 <= |p-center|^2 <= range_max^2, float arithmetic.
  * FilterBoundingBox (yaml:305-310): inside = min <= p <= max on every axis; keep_inside selects which side is
  * emitted (the default pipeline keeps the OUTSIDE, `outside_pointcloud_layer`).  Index lists, ascending. */
@@ -307,6 +317,7 @@ typedef struct {
   float range_center[3];
   int32_t bbox_mode; /* 0 skipped, 1 keep outside, 2 keep inside */
   float bbox_min[3], bbox_max[3];
+  int32_t decim_map_method, decim_icp_method; /* ORC_DECIMATE_* of the two decimations */
 } orc_preprocess_params;
 void orc_preprocess(const float* x, const float* y, const float* z, size_t n, const orc_preprocess_params* p,
                     uint32_t* idx_map, size_t* n_map, uint32_t* idx_icp, size_t* n_icp);

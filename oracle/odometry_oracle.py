@@ -22,6 +22,16 @@ _F = dict(max=max, min=min, sqrt=math.sqrt, abs=abs, sin=math.sin, cos=math.cos,
           log=math.log, pow=pow, pi=math.pi)
 
 
+def _decimate_method(params):
+    """decimate_method of a FilterDecimateVoxels block (default FirstPoint, lidar3d-default.yaml:291)."""
+    m = str(params.get("decimate_method", "DecimateMethod::FirstPoint"))
+    if m.endswith("FirstPoint"):
+        return oc.DECIMATE_FIRST_POINT
+    if m.endswith("ClosestToAverage"):
+        return oc.DECIMATE_CLOSEST_TO_AVERAGE
+    raise ValueError("unsupported decimate_method " + m)
+
+
 def formula(expr, variables):
     """mp2p_icp::Parameterizable formulas (exprtk [U]): arithmetic, ^ as power, max/min/sqrt/..."""
     if isinstance(expr, (int, float)):
@@ -236,7 +246,8 @@ class OdometryOracle:
             xyz, formula(d1["voxel_filter_resolution"], v), formula(d2["voxel_filter_resolution"], v),
             int(d1["minimum_input_points_to_filter"]), oc.INDEX_FLOOR, formula(rg["range_min"], v),
             formula(rg["range_max"], v), (0, 0, 0), 1 if "outside_pointcloud_layer" in bb else 2,
-            [formula(e, v) for e in bb["bounding_box_min"]], [formula(e, v) for e in bb["bounding_box_max"]])
+            [formula(e, v) for e in bb["bounding_box_min"]], [formula(e, v) for e in bb["bounding_box_max"]],
+            decim_map_method=_decimate_method(d1), decim_icp_method=_decimate_method(d2))
         self._xyz, self._t = xyz, t
         self._ta = None if t is None else oc.adjust_timestamps(t, self.ts_method, formula(self.ts_offset, v))
         self._deskew_layers()

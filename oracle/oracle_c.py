@@ -42,7 +42,11 @@ class _PreprocessParams(C.Structure):
     _fields_ = [("decim_map_resolution", C.c_float), ("decim_icp_resolution", C.c_float),
                 ("min_points_to_filter", C.c_uint32), ("index_mode", C.c_int32), ("range_min", C.c_float),
                 ("range_max", C.c_float), ("range_center", C.c_float * 3), ("bbox_mode", C.c_int32),
-                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3)]
+                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("decim_map_method", C.c_int32),
+                ("decim_icp_method", C.c_int32)]
+
+
+DECIMATE_FIRST_POINT, DECIMATE_CLOSEST_TO_AVERAGE = 0, 1
 
 
 class _MatchStats(C.Structure):
@@ -157,6 +161,8 @@ def lib():
         L.orc_filter_bbox.restype = C.c_size_t
         L.orc_filter_bbox.argtypes = [_FP, _FP, _FP, C.c_size_t, _FP, _FP, C.c_int, _UP]
         L.orc_deskew.argtypes = [_FP, _FP, _FP, _FP, C.c_size_t, _DP, _FP, _FP, _FP]
+        L.orc_decimate_closest_to_average.restype = C.c_size_t
+        L.orc_decimate_closest_to_average.argtypes = [_FP, _FP, _FP, C.c_size_t, C.c_float, C.c_uint32, C.c_int, _UP]
         L.orc_preprocess.argtypes = [_FP, _FP, _FP, C.c_size_t, C.POINTER(_PreprocessParams), _UP,
                                      C.POINTER(C.c_size_t), _UP, C.POINTER(C.c_size_t)]
         for name in ("orc_pose_from_ypr", "orc_pose_to_ypr", "orc_se3_exp", "orc_se3_log", "orc_pose_inverse"):
@@ -576,14 +582,25 @@ def deskew(xyz, t, twist):
     return np.stack([ox, oy, oz], 1)
 
 
+def decimate_closest_to_average(xyz, resolution, min_points_to_filter=0, index_mode=INDEX_FLOOR):
+    """FilterDecimateVoxels(ClosestToAverage) [U] -> surviving input indices, ascending."""
+    x, y, z = _xyz_cols(xyz)
+    out = np.zeros(max(len(x), 1), np.uint32)
+    k = lib().orc_decimate_closest_to_average(_fp(x), _fp(y), _fp(z), len(x), float(resolution), int(min_points_to_filter),
+                                              int(index_mode), _up(out))
+    return out[:k].copy()
+
+
 def preprocess(xyz, decim_map_resolution, decim_icp_resolution, min_points_to_filter=2000, index_mode=INDEX_FLOOR,
                range_min=0.0, range_max=0.0, range_center=(0.0, 0.0, 0.0), bbox_mode=0, bbox_min=(0, 0, 0),
-               bbox_max=(0, 0, 0)):
-    """1st-pass filter chain of lidar3d-default.yaml:278-319 -> (idx_map, idx_icp), indices into the raw scan."""
+               bbox_max=(0, 0, 0), decim_map_method=0, decim_icp_method=0):
+    """1st-pass filter chain of lidar3d-default.yaml:278-319 -> (idx_map, idx_icp), indices into the raw scan.
+    decim_*_method: DECIMATE_FIRST_POINT | DECIMATE_CLOSEST_TO_AVERAGE (decimate_method of the two FilterDecimateVoxels)."""
     x, y, z = _xyz_cols(xyz)
     p = _PreprocessParams(float(decim_map_resolution), float(decim_icp_resolution), int(min_points_to_filter),
                           int(index_mode), float(range_min), float(range_max), (C.c_float * 3)(*map(float, range_center)),
-                          int(bbox_mode), (C.c_float * 3)(*map(float, bbox_min)), (C.c_float * 3)(*map(float, bbox_max)))
+                          int(bbox_mode), (C.c_float * 3)(*map(float, bbox_min)), (C.c_float * 3)(*map(float, bbox_max)),
+                          int(decim_map_method), int(decim_icp_method))
     im, ii = np.zeros(max(len(x), 1), np.uint32), np.zeros(max(len(x), 1), np.uint32)
     nm, ni = C.c_size_t(0), C.c_size_t(0)
     lib().orc_preprocess(_fp(x), _fp(y), _fp(z), len(x), C.byref(p), _up(im), C.byref(nm), _up(ii), C.byref(ni))

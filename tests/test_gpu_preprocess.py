@@ -48,6 +48,55 @@ def test_preprocess_bit_exact(ctx, oracle, small_workload, mode):
         np.testing.assert_array_equal(d["t"], ta[idx])
 
 
+@pytest.mark.parametrize("methods", [(1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_preprocess_closest_to_average_bit_exact(ctx, oracle, small_workload, methods, mode):
+    """decimate_method: DecimateMethod::ClosestToAverage in either decimation of the chain (the commented alternative of
+    lidar3d-default.yaml:292, rgbd.yaml:254-278): per voxel the point closest to the float mean accumulated in input order -- the
+    device sorts a scan by voxel key (stable) and walks every voxel's run; same index sets as the oracle, also with exact ties
+    (points on a lattice), non-finite points, the second stage below minimum_input_points_to_filter, and in a batch."""
+    xyz, t = _raw(7, small_workload)
+    xyz[::5] = np.round(xyz[::5] * 4) / 4
+    mm, mi = methods
+    for pp in (PP, dict(PP, decim_map_resolution=1.0, min_points_to_filter=1500)):  # (the second: stage 2 passes its input through)
+        raw = capi.Scan(ctx, xyz).set_timestamps(t)
+        om, oi = capi.Scan(ctx), capi.Scan(ctx)
+        raw.preprocess(capi.preprocess_params(index_mode=mode, timestamp_method=capi.TS_MIDDLE_IS_ZERO, time_offset=0.01,
+                                              decim_map_method=mm, decim_icp_method=mi, **pp), om, oi)
+        im, ii = oracle.preprocess(xyz, index_mode=mode, decim_map_method=mm, decim_icp_method=mi, **pp)
+        fm, fi = oracle.preprocess(xyz, index_mode=mode, **pp)
+        assert 0 < len(ii) <= len(im) < len(xyz)
+        if pp is PP:
+            assert not np.array_equal(im, fm) or not np.array_equal(ii, fi)  # (not a no-op)
+        else:
+            assert len(ii) == len(im) < 1500  # (stage 2 left its input alone)
+        for scan, idx in ((om, im), (oi, ii)):
+            d = scan.download()
+            assert scan.n == len(idx)
+            np.testing.assert_array_equal(d["src_idx"], idx)
+            np.testing.assert_array_equal(d["xyz"], xyz[idx])
+    # a batch of ragged scans with the method per scan = single calls
+    rng = np.random.default_rng(8)
+    sizes = [len(xyz), len(xyz) // 3, 250, 0, 1500]
+    ctxs = [capi.Context(0) for _ in sizes]
+    raws, pars = [], []
+    for k, n in enumerate(sizes):
+        sel = np.sort(rng.choice(len(xyz), n, replace=False))
+        raws.append(capi.Scan(ctxs[k], xyz[sel]))
+        pars.append(capi.preprocess_params(index_mode=mode, decim_map_method=(mm, 0, 1)[k % 3], decim_icp_method=(mi, 1, 0)[k % 3], **PP))
+    oms, ois = [capi.Scan(c) for c in ctxs], [capi.Scan(c) for c in ctxs]
+    capi.preprocess_batch(raws, pars, oms, ois)
+    for k in range(len(sizes)):
+        sm, si = capi.Scan(ctxs[k]), capi.Scan(ctxs[k])
+        raws[k].preprocess(pars[k], sm, si)
+        for got, want in ((oms[k], sm), (ois[k], si)):
+            np.testing.assert_array_equal(got.download()["src_idx"], want.download()["src_idx"])
+    with pytest.raises(capi.MolahipError):
+        raws[0].preprocess(capi.preprocess_params(decim_map_method=2, **PP), oms[0], ois[0])
+    for c in ctxs:
+        c.close()
+
+
 def test_preprocess_edge_cases(ctx, oracle, small_workload):
     xyz, t = _raw(2, small_workload, with_nan=False)
     # smaller than minimum_input_points_to_filter: no decimation, predicates still apply; no time stamps attached

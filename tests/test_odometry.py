@@ -76,11 +76,15 @@ def test_repo_pipelines_carry_the_reference_values(host):
 
 
 def test_unsupported_chain_is_rejected(host, tmp_path):
-    txt = open(PIPE).read().replace("DecimateMethod::FirstPoint", "DecimateMethod::ClosestToAverage")
+    txt = open(PIPE).read().replace("DecimateMethod::FirstPoint", "DecimateMethod::VoxelAverage")
     p = tmp_path / "bad.yaml"
     p.write_text(txt)
     with pytest.raises(RuntimeError, match="unsupported observation filter chain"):
         host.LidarOdometry().initialize(host.Config.FromYamlFile(str(p)))
+    # ... while the alternative the reference's own pipeline file offers (lidar3d-default.yaml:292) is taken
+    ok = tmp_path / "cta.yaml"
+    ok.write_text(open(PIPE).read().replace("DecimateMethod::FirstPoint", "DecimateMethod::ClosestToAverage"))
+    host.LidarOdometry().initialize(host.Config.FromYamlFile(str(ok)))
 
 
 def test_tum_roundtrip_and_metrics(tmp_path):
@@ -182,6 +186,40 @@ def test_hip_driver_matches_oracle_driver(host, drive, tmp_path):
         lo3.onLidar(st, rec, xyz_fields=(3, 1, 4), t_field=2)
     for ra, rb in zip(lo3.records(), lo.records()[:4]):
         assert ra["pose"] == rb["pose"] and ra["n_for_icp"] == rb["n_for_icp"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["both", "second"])
+def test_hip_driver_matches_oracle_driver_with_closest_to_average_decimation(host, drive, tmp_path, which):
+    """decimate_method: DecimateMethod::ClosestToAverage (the commented alternative of lidar3d-default.yaml:292) in the chain's
+    decimations: the device driver and the oracle driver make the same layers, decisions and poses."""
+    from oracle import odometry_oracle as oo
+    txt = open(PIPE).read()
+    assert txt.count("DecimateMethod::FirstPoint") == 2
+    if which == "both":
+        txt = txt.replace("DecimateMethod::FirstPoint", "DecimateMethod::ClosestToAverage")
+    else:
+        head, tail = txt.rsplit("DecimateMethod::FirstPoint", 1)
+        txt = head + "DecimateMethod::ClosestToAverage" + tail
+    pipe = tmp_path / "cta.yaml"
+    pipe.write_text(txt)
+    o = oo.OdometryOracle(str(pipe), n_threads=8)
+    lo = host.LidarOdometry()
+    lo.initialize(host.Config.FromYamlFile(str(pipe)))
+    ref = host.LidarOdometry()
+    ref.initialize(host.Config.FromYamlFile(PIPE))
+    differs = False
+    for k, ((xyz, t), st) in enumerate(list(zip(drive["scans"], drive["stamps"]))[:8]):
+        a = lo.onLidar(st, xyz, t)
+        b = o.on_lidar(st, xyz, t)
+        c = ref.onLidar(st, xyz, t)
+        for key in ("icp_run", "icp_good", "map_updated", "icp_iterations", "align_calls", "termination", "n_raw", "n_for_map",
+                    "n_for_icp", "n_map_points", "n_map_voxels"):
+            assert a[key] == b[key], (k, key, a[key], b[key])
+        Ta, Tb = np.array(a["pose"]).reshape(3, 4), b["pose"].reshape(3, 4)
+        assert np.linalg.norm(Ta - Tb) < 1e-6, (k, Ta, Tb)
+        differs = differs or a["pose"] != c["pose"]
+    assert differs  # (the method is not a no-op: other survivors, other poses than FirstPoint's)
 
 
 def test_oracle_driver_motion_model_prior_and_initial_twist(drive, monkeypatch):

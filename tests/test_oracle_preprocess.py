@@ -35,6 +35,52 @@ def test_decimate_passthrough_and_nonfinite(oracle):
     assert len(oracle.decimate_first_point(np.zeros((0, 3), np.float32), 0.5, 0)) == 0
 
 
+def _brute_closest_to_average(xyz, res, mode=0):
+    """An independent reading of DecimateMethod::ClosestToAverage: per voxel, float32 running sums in input order, mean =
+    sum * (1 / count) in float32, squared error (dx*dx + dy*dy) + dz*dz in float32, argmin keeping the first of equals."""
+    f = np.float32
+    s = xyz * (f(1.0) / f(res))
+    k = (np.trunc(s) if mode else np.floor(s)).astype(np.int64)
+    _, inv = np.unique(k, axis=0, return_inverse=True)
+    inv = np.asarray(inv).reshape(-1)
+    keep = []
+    for v in range(inv.max() + 1):
+        members = np.flatnonzero(inv == v)  # ascending = input order
+        sums = np.zeros(3, f)
+        for i in members:
+            sums = (sums + xyz[i]).astype(f)
+        mean = (sums * (f(1.0) / f(len(members)))).astype(f)
+        d = (xyz[members] - mean).astype(f)
+        e = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(f) + d[:, 2] * d[:, 2]).astype(f)
+        keep.append(members[int(np.argmin(e))])  # (argmin returns the first minimum)
+    return np.sort(np.array(keep)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("res,mode", [(0.4, 0), (1.6, 0), (0.9, 1)])
+def test_decimate_closest_to_average(oracle, res, mode):
+    xyz, _ = _cloud(3, 6000)
+    xyz[::7] = np.round(xyz[::7] * 4) / 4  # points on a lattice: exact ties between candidates of a voxel
+    got = oracle.decimate_closest_to_average(xyz, res, 100, mode)
+    np.testing.assert_array_equal(got, _brute_closest_to_average(xyz, res, mode))
+    assert len(got) == len(oracle.decimate_first_point(xyz, res, 100, mode))  # one survivor per voxel either way
+    assert not np.array_equal(got, oracle.decimate_first_point(xyz, res, 100, mode))
+
+
+def test_decimate_closest_to_average_passthrough_nonfinite_and_chain(oracle):
+    xyz, _ = _cloud(4, 1500)
+    xyz[5] = [np.nan, 0, 0]
+    np.testing.assert_array_equal(oracle.decimate_closest_to_average(xyz, 0.5, 2000), np.delete(np.arange(len(xyz)), 5))
+    assert len(oracle.decimate_closest_to_average(np.zeros((0, 3), np.float32), 0.5, 0)) == 0
+    # the chain with the method switched per stage = the stages one by one
+    xyz, _ = _cloud(5, 8000)
+    for mm, mi in ((1, 0), (0, 1), (1, 1)):
+        im, ii = oracle.preprocess(xyz, 0.4, 1.2, 100, decim_map_method=mm, decim_icp_method=mi)
+        a = (oracle.decimate_closest_to_average if mm else oracle.decimate_first_point)(xyz, 0.4, 100)
+        np.testing.assert_array_equal(im, a)
+        b = (oracle.decimate_closest_to_average if mi else oracle.decimate_first_point)(xyz[a], 1.2, 100)
+        np.testing.assert_array_equal(ii, a[b])
+
+
 def test_range_and_bbox(oracle):
     xyz, _ = _cloud(3)
     c = np.array([0.5, -0.25, 0.1], np.float32)

@@ -32,7 +32,10 @@ for case in range(n_cases):
               min_points_to_filter=int(rng.choice([0, 300, 2000, 10 ** 7])), range_min=float(rng.choice([0.0, 2.0, 5.0])),
               range_max=float(rng.choice([0.0, 30.0, 70.0])), bbox_mode=int(rng.integers(0, 3)),
               bbox_min=(-float(rng.uniform(2, 9)), -float(rng.uniform(2, 9)), -1.8), bbox_max=(float(rng.uniform(2, 9)), float(rng.uniform(2, 9)), 4.0),
-              range_center=(float(rng.choice([0.0, 0.5])), 0.0, 0.0))
+              range_center=(float(rng.choice([0.0, 0.5])), 0.0, 0.0),
+              decim_map_method=int(rng.integers(0, 2)), decim_icp_method=int(rng.integers(0, 2)))  # FirstPoint | ClosestToAverage
+    if rng.integers(0, 3) == 0 and n:  # points on a lattice: exact ties between a voxel's candidates
+        xyz[::3] = np.round(xyz[::3] * 4) / 4
     mode = int(rng.integers(0, 2))
     ts = int(rng.integers(0, 3))
     off = float(rng.choice([0.0, 0.01]))
@@ -64,6 +67,7 @@ for case in range(n_cases):
     except capi.MolahipError as e:
         ok, note = False, "ERROR " + str(e)[-80:]
     bad += 0 if ok else 1
-    print("case %3d n=%6d mode=%d ts=%d t=%d %s -> %s" % (case, n, mode, ts, with_t, note, "ok" if ok else "MISMATCH"), flush=True)
+    print("case %3d n=%6d mode=%d ts=%d t=%d methods=%d%d %s -> %s" % (case, n, mode, ts, with_t, pp["decim_map_method"], pp["decim_icp_method"], note,
+                                                                  "ok" if ok else "MISMATCH"), flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
