@@ -2365,7 +2365,7 @@ inline uint32_t nblk_flat(size_t n) { return (uint32_t)(((n + kFlatPointsPerBloc
 __device__ __forceinline__ void k_match_flat_body(const IcpDeviceState* __restrict__ st, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                   MapView map, float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx,
-                                                  const uint32_t* __restrict__ perm) {
+                                                  const uint32_t* __restrict__ perm, uint32_t block_x) {
   __shared__ FlatWave sh[kFlatThreads / 64];
   typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
   const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
@@ -2374,12 +2374,12 @@ __device__ __forceinline__ void k_match_flat_body(const IcpDeviceState* __restri
   // (experiment) workgroup b runs on XCD b % 8 (round-robin dispatch, grid width a multiple of 8): hand each XCD a contiguous
   // part of the layer, so that its L2 sees a part of the map instead of all of it (MH_FLAT_XCD=118: an eighth of C2 each)
   // in runs of MH_FLAT_XCD consecutive workgroups' worth of points: run c of the layer goes to XCD c % 8
-  const uint32_t xj = blockIdx.x / 8u;
-  const uint32_t bx = ((xj / (uint32_t)(MH_FLAT_XCD)) * 8u + blockIdx.x % 8u) * (uint32_t)(MH_FLAT_XCD) + xj % (uint32_t)(MH_FLAT_XCD);
+  const uint32_t xj = block_x / 8u;
+  const uint32_t bx = ((xj / (uint32_t)(MH_FLAT_XCD)) * 8u + block_x % 8u) * (uint32_t)(MH_FLAT_XCD) + xj % (uint32_t)(MH_FLAT_XCD);
 #elif defined(MH_FLAT_REVERSE)
-  const uint32_t bx = gridDim.x - 1u - blockIdx.x;  // (A/B: the layer's last points first)
+  const uint32_t bx = gridDim.x - 1u - block_x;  // (A/B: the layer's last points first)
 #else
-  const uint32_t bx = blockIdx.x;
+  const uint32_t bx = block_x;
 #endif
   const uint32_t i0 = bx * kFlatPointsPerBlock + (threadIdx.x & ~63u);
   if (i0 >= n) return;    // whole waves
@@ -2393,7 +2393,7 @@ __global__ __launch_bounds__(kFlatThreads, MH_FLAT_WAVES) void k_match_flat(cons
                                                              const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                              MapView map, float4* __restrict__ pair_q,
                                                              uint32_t* __restrict__ pair_gidx, const uint32_t* __restrict__ perm) {
-  k_match_flat_body(st, lx, ly, lz, n, map, pair_q, pair_gidx, perm);
+  k_match_flat_body(st, lx, ly, lz, n, map, pair_q, pair_gidx, perm, blockIdx.x);
 }
 #ifdef MH_DEBUG_FLOOR
 // ================================================================================================
@@ -2609,9 +2609,25 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4o_b(const Batch
 #endif
   );
 }
+// A whole job per XCD.  Workgroup L of a launch runs on XCD L % 8 (tools/xcd_exchange.hip: 0 exceptions in 256; the grid's width is
+// a multiple of 8), so with blockIdx.y = job every job's workgroups are dealt over all eight XCDs and every XCD's L2 fetches its own
+// copy of every job's map: (2 FETCH_SIZE + WRITE_SIZE) = 1.64 x the compulsory bytes on C2.  Here XCD c takes the jobs c, c + 8, ...
+// of the first 8 * floor(jobs / 8) one after the other (the rest keep the plain order): a map is fetched into ONE L2 --
+// FETCH_SIZE 155.5 -> 89.7 MB per launch of 32 scans, traffic 1.64 -> 1.08 x compulsory, L2 hit rate 47 -> 69 %, headline
+// 6320-6330 -> 6470-6480 scans/s.  (Unlike a contiguous PART of one scan per XCD -- profiles/r05_match_kernel.md section 5: 1.22 x
+// at -37 % speed -- whole scans are equal work.)  -DMH_FLAT_NO_JOB_XCD: the plain order (A/B).
 __global__ __launch_bounds__(kFlatThreads, MH_FLAT_WAVES) void k_match_flat_b(const BatchJob* __restrict__ jobs) {
-  const BatchJob& j = jobs[blockIdx.y];
-  k_match_flat_body(j.st, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, nullptr);
+  uint32_t job = blockIdx.y, bx = blockIdx.x;
+#ifndef MH_FLAT_NO_JOB_XCD
+  const uint32_t whole = gridDim.y & ~7u;  // jobs that are dealt an XCD each
+  if (blockIdx.y < whole) {
+    const uint32_t L = blockIdx.x + blockIdx.y * gridDim.x, xcd = L % 8u, slot = L / 8u;
+    job = xcd + 8u * (slot / gridDim.x);
+    bx = slot % gridDim.x;
+  }
+#endif
+  const BatchJob& j = jobs[job];
+  k_match_flat_body(j.st, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, nullptr, bx);
 }
 __global__ __launch_bounds__(kTileThreads) void k_match_tile(const IcpDeviceState* __restrict__ st, const float* __restrict__ sx,
                                                              const float* __restrict__ sy, const float* __restrict__ sz,
