@@ -60,7 +60,7 @@ mk=[k for k in summary if k.startswith('k_match') and k.endswith('_b')] or [k fo
 stdout=open(out+'/'+tag+'_bench_stdout.log').read().strip().splitlines()
 line=[l for l in stdout if l.startswith('{')]
 bench=json.loads(line[-1]) if line else {}
-S=bench.get('config',{}).get('scans_per_step_per_gpu')
+S=bench.get('roofline',{}).get('scans_per_launch') or bench.get('config',{}).get('scans_per_step_per_gpu')  # scans in ONE lock-step launch (a step is several launches' worth)
 if mk:
     k=max(mk, key=lambda n: summary[n].get('SQ_WAVES',{}).get('mean',0))
     m=summary[k]
