@@ -630,6 +630,8 @@ constexpr uint32_t kRowMaxPoints = 32768;  // measured cross-over with the quad 
 constexpr uint32_t kAccPPT = MH_ACC_PPT;  // scan points per lane of k_accum (tools/build_variants.sh: 2 and 8 measured)
 inline uint32_t nblk_acc(size_t n) { return (uint32_t)((n + (size_t)kBlock * kAccPPT - 1) / ((size_t)kBlock * kAccPPT)); }
 
+// SIGNED: the verdict rides in the sign of the pairing's distance (the plan / scan matcher, flat_signed_d2): no index array read
+template <bool SIGNED>
 __device__ __forceinline__ void k_accum_body(const IcpDeviceState* __restrict__ st, uint32_t first,
                                                   const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
@@ -661,8 +663,9 @@ __device__ __forceinline__ void k_accum_body(const IcpDeviceState* __restrict__ 
   for (int u = 0; u < kAccPPT; u++) {  // all loads first (clamped index), then the arithmetic
     const uint32_t i = (bid * kAccPPT + (uint32_t)u) * kBlock + threadIdx.x;
     const uint32_t ic = i < n ? i : n - 1;
-    gi[u] = i < n ? G(pair_gidx)[ic] : kNoMatch;
     q[u] = gq[ic];
+    if (SIGNED) gi[u] = (i < n && !(__float_as_uint(q[u].w) >> 31)) ? 0u : kNoMatch;
+    else gi[u] = i < n ? G(pair_gidx)[ic] : kNoMatch;
     px[u] = G(lx)[ic]; py[u] = G(ly)[ic]; pz[u] = G(lz)[ic];
   }
   Acc a;
@@ -2800,18 +2803,20 @@ static inline bool wave_lds_env() { static const bool v = getenv("MH_WAVE_LDS") 
     hipLaunchKernelGGL(k_match_wave_sparse, dim3((SC)->n_tiles), dim3(kBlock), 0, S, ST, (SC)->sx, (SC)->sy, (SC)->sz,      \
                        (SC)->perm, (SC)->tile_start, (SC)->n_tiles, MV, PQ, PG WT);                                        \
   } while (0)
+template <bool SIGNED>
 __global__ __launch_bounds__(kBlock, MH_ACCUM_WAVES) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first,
                                                   const MatchK* __restrict__ kp, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                   const float4* __restrict__ pair_q,
                                                   const uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
                                                   uint32_t pstride) {
-  k_accum_body(st, first, kp, lx, ly, lz, n, pair_q, pair_gidx, partials, pstride);
+  k_accum_body<SIGNED>(st, first, kp, lx, ly, lz, n, pair_q, pair_gidx, partials, pstride);
 }
+template <bool SIGNED>
 __global__ __launch_bounds__(kBlock, MH_ACCUM_WAVES) void k_accum_b(const BatchJob* __restrict__ jobs, uint32_t first) {
   const BatchJob& j = jobs[blockIdx.y];
   if (blockIdx.x >= j.nba) return;
-  k_accum_body(j.st, first, j.mk, j.lx, j.ly, j.lz, j.n, j.pair_q, j.pair_gidx, j.part, j.nba);
+  k_accum_body<SIGNED>(j.st, first, j.mk, j.lx, j.ly, j.lz, j.n, j.pair_q, j.pair_gidx, j.part, j.nba);
 }
 __global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
                                                          const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
@@ -3615,7 +3620,7 @@ struct AlignJob {
                                ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), ctx->pl_c.as<float4>(),
                                ctx->pl_n.as<float4>(), part, partb, nba);
           else if (!fused16)
-            hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+            hipLaunchKernelGGL(k_accum<false>, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                                ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
         } else if (variant == 7) {
 #ifdef MH_DEBUG_WAVETRACE
@@ -3624,7 +3629,7 @@ struct AlignJob {
           MH_LAUNCH_WAVE(s, ctx->d_state, scan, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), );
 #endif
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
-          hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+          hipLaunchKernelGGL(k_accum<false>, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
         } else if (variant == 6) {
           hipLaunchKernelGGL(k_match_tile, dim3(scan->n_tiles), dim3(kTileThreads), 0, s, ctx->d_state, scan->sx, scan->sy, scan->sz,
@@ -3635,13 +3640,13 @@ struct AlignJob {
 #endif
           );
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
-          hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+          hipLaunchKernelGGL(k_accum<false>, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
         } else if (variant == 9) {
           hipLaunchKernelGGL(k_match_flat, dim3(nblk_flat(n)), dim3(kFlatThreads), 0, s, ctx->d_state, scan->x, scan->y, scan->z, n, mv,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (const uint32_t*)nullptr);
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
-          hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+          hipLaunchKernelGGL(k_accum<true>, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
         } else if (variant == 4 || variant == 8) {
           const bool ord = variant == 8;  // the scan in search order
@@ -3653,7 +3658,7 @@ struct AlignJob {
 #endif
           );
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
-          hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
+          hipLaunchKernelGGL(k_accum<false>, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
         } else if (variant == 1)
           hipLaunchKernelGGL((k_match<true, 0>), dim3(nb), dim3(kBlock), 0, s, ctx->d_state, dummy, 0.f, 1u, dmk, scan->x,
@@ -3673,7 +3678,7 @@ struct AlignJob {
                                ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), ctx->pl_c.as<float4>(),
                                ctx->pl_n.as<float4>(), part, partb, nba);
           else
-            hipLaunchKernelGGL(k_accum, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
+            hipLaunchKernelGGL(variant == 9 ? k_accum<true> : k_accum<false>, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 0u, dmk, scan->x, scan->y, scan->z, n,
                                ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
           hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, s, ctx->d_state, dsk, part, nba, nba,
                              (const double*)partb, nBi, nBi, 0u);
@@ -4429,10 +4434,10 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
             MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n + 1], s));
             g.prof_n++;
           }
-          if (g.kind != K_ROWF) hipLaunchKernelGGL(k_accum_b, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 1u);
+          if (g.kind != K_ROWF) hipLaunchKernelGGL(g.kind == K_FLAT ? k_accum_b<true> : k_accum_b<false>, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 1u);
           hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, 1u);
           for (uint32_t in = 1; in < g.inner; in++) {
-            hipLaunchKernelGGL(k_accum_b, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 0u);
+            hipLaunchKernelGGL(g.kind == K_FLAT ? k_accum_b<true> : k_accum_b<false>, dim3(g.gx_acc, A), dim3(kBlock), 0, s, g.dj, 0u);
             hipLaunchKernelGGL(k_solve_b, dim3(1, A), dim3(kSolveThreads), 0, s, g.dj, 0u);
           }
         }
@@ -4961,7 +4966,7 @@ mh_status mh_gn_solve(mh_ctx* ctx, const mh_pairs_pt2pt* pp, const mh_pairs_pt2p
   const float* P = ctx->build_b.as<float>();
   for (uint32_t in = 0; in < p->max_inner_iterations; in++) {
     if (np)
-      hipLaunchKernelGGL(k_accum, dim3(nblk_acc(np)), dim3(kBlock), 0, s, ctx->d_state, in == 0 ? 1u : 0u, &ctx->d_params->mk,
+      hipLaunchKernelGGL(k_accum<false>, dim3(nblk_acc(np)), dim3(kBlock), 0, s, ctx->d_state, in == 0 ? 1u : 0u, &ctx->d_params->mk,
                          L, L + sp, L + 2 * sp, (uint32_t)np, ctx->pair_q.as<float4>(),
                          ctx->pair_gidx.as<uint32_t>(), ctx->partials.as<double>(), nblk_acc(np));
     if (nl)
