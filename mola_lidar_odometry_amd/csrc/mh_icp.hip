@@ -1084,13 +1084,27 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ part, uin
       const double v4 = src[b + 4u * G], v5 = src[b + 5u * G], v6 = src[b + 6u * G], v7 = src[b + 7u * G];
       s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
     }
-    for (; b < n; b += G) s0 += src[b];
+    for (; b < n; b += 8u * G) {  // the remainder (all of it below 8 G columns): into the first sum, in order -- its loads together
+      double w[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8u; u++) w[u] = b + u * G < n ? src[b + u * G] : 0.0;
+#pragma unroll
+      for (uint32_t u = 0; u < 8u; u++)
+        if (b + u * G < n) s0 += w[u];
+    }
     red[v][g] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   }
   __syncthreads();
-  if (t < nvals) {
+  if (t < nvals) {  // (eight reads at a time ahead of their additions, the additions in order: a read per addition costs its LDS latency G times over)
     double acc = 0.0;
-    for (int q = 0; q < G; q++) acc += red[t][q];
+    for (int q0 = 0; q0 < G; q0 += 8) {
+      double part[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) part[u] = red[t][q0 + u < G ? q0 + u : G - 1];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (q0 + u < G) acc += part[u];
+    }
     out[t] = acc;
   }
   __syncthreads();
