@@ -637,7 +637,7 @@ __device__ __forceinline__ void k_accum_body(const IcpDeviceState* __restrict__ 
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
                                                   const float4* __restrict__ pair_q,
                                                   const uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
-                                                  uint32_t pstride) {
+                                                  uint32_t pstride, uint32_t block_x) {
   __shared__ BlockSumQ<kAccN> bs;
   // state and parameters through the scalar path (uniform addresses, not written during this kernel); the arrays through
   // global-space pointers (mh_nn_device.h, G())
@@ -654,7 +654,7 @@ __device__ __forceinline__ void k_accum_body(const IcpDeviceState* __restrict__ 
   const double kparam = cst->cur_kparam;
   // kAccPPT points per lane: the reduction below is a fixed cost per lane, amortised over four points
   // (the device is VALU-bound once several alignments run concurrently)
-  const uint32_t bid = blockIdx.x;
+  const uint32_t bid = block_x;
   uint32_t gi[kAccPPT];
   f32x4 q[kAccPPT];
   float px[kAccPPT], py[kAccPPT], pz[kAccPPT];
@@ -2824,13 +2824,16 @@ __global__ __launch_bounds__(kBlock, MH_ACCUM_WAVES) void k_accum(const IcpDevic
                                                   const float4* __restrict__ pair_q,
                                                   const uint32_t* __restrict__ pair_gidx, double* __restrict__ partials,
                                                   uint32_t pstride) {
-  k_accum_body<SIGNED>(st, first, kp, lx, ly, lz, n, pair_q, pair_gidx, partials, pstride);
+  k_accum_body<SIGNED>(st, first, kp, lx, ly, lz, n, pair_q, pair_gidx, partials, pstride, blockIdx.x);
 }
 template <bool SIGNED>
 __global__ __launch_bounds__(kBlock, MH_ACCUM_WAVES) void k_accum_b(const BatchJob* __restrict__ jobs, uint32_t first) {
+  // (the matcher's job -> XCD mapping was tried here as well -- the pairings this launch reads were written through that XCD's L2 --
+  //  and changes nothing: 22.4-22.9 us either way; a launch boundary leaves nothing of them in the L2)
   const BatchJob& j = jobs[blockIdx.y];
-  if (blockIdx.x >= j.nba) return;
-  k_accum_body<SIGNED>(j.st, first, j.mk, j.lx, j.ly, j.lz, j.n, j.pair_q, j.pair_gidx, j.part, j.nba);
+  const uint32_t bx = blockIdx.x;
+  if (bx >= j.nba) return;
+  k_accum_body<SIGNED>(j.st, first, j.mk, j.lx, j.ly, j.lz, j.n, j.pair_q, j.pair_gidx, j.part, j.nba, bx);
 }
 __global__ __launch_bounds__(kSolveThreads) void k_solve(IcpDeviceState* __restrict__ st, const SolveK* __restrict__ kp,
                                                          const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
