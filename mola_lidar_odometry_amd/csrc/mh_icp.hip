@@ -3073,14 +3073,18 @@ inline uint32_t nblk(size_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
 // One device block [state | parameters] with a pinned mirror of the same layout: an alignment starts with ONE upload.
 constexpr size_t kParamsOffset = (sizeof(IcpDeviceState) + 255) / 256 * 256;
+// The threshold schedules of a single alignment (threshold | kernel_param | pt2pl_threshold, max_iterations doubles each) ride
+// behind the parameters in the same block when they fit: state, parameters and schedules go up in ONE copy instead of two.
+constexpr size_t kInlineSchedDoubles = 3 * 400;
+constexpr size_t kInlineSchedOffset = (kParamsOffset + sizeof(IcpDeviceParams) + 63) / 64 * 64;
 
 mh_status ensure_state(mh_ctx* ctx) {
   if (!ctx->d_state) {
     char *d = nullptr, *h = nullptr;
-    const size_t second_off = (kParamsOffset + sizeof(IcpDeviceParams) + 255) / 256 * 256;  // k_step16's two ping-pong state blocks (heads only)
+    const size_t second_off = (kInlineSchedOffset + kInlineSchedDoubles * sizeof(double) + 255) / 256 * 256;  // k_step16's two ping-pong state blocks (heads only)
     MH_HIP(hipMalloc((void**)&d, second_off + 2 * 256));
     static_assert(kStateHeadDwords * 4 <= 256, "a ping-pong block per 256 bytes");
-    const size_t prog_off = ((kParamsOffset + sizeof(IcpDeviceParams) + 127) / 128) * 128;  // a cache line of its own
+    const size_t prog_off = ((kInlineSchedOffset + kInlineSchedDoubles * sizeof(double) + 127) / 128) * 128;  // a cache line of its own
     MH_HIP(hipHostMalloc((void**)&h, prog_off + 128, hipHostMallocDefault));
     ctx->d_state = (IcpDeviceState*)d;
     ctx->d_state_b = (IcpDeviceState*)(d + second_off);
@@ -3097,12 +3101,12 @@ mh_status ensure_state(mh_ctx* ctx) {
   return MH_OK;
 }
 
-// state + parameters in one copy (start of mh_icp_align)
-mh_status upload_state_and_params(mh_ctx* ctx, const MatchK& mk, const SolveK& sk) {
+// state + parameters (+ the schedules that ride behind them: inline_sched doubles) in one copy (start of mh_icp_align)
+mh_status upload_state_and_params(mh_ctx* ctx, const MatchK& mk, const SolveK& sk, size_t inline_sched = 0) {
   ctx->h_params->mk = mk;
   ctx->h_params->sk = sk;
-  MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, kParamsOffset + sizeof(IcpDeviceParams), hipMemcpyHostToDevice,
-                        ctx->stream));
+  const size_t bytes = inline_sched ? kInlineSchedOffset + inline_sched * sizeof(double) : kParamsOffset + sizeof(IcpDeviceParams);
+  MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, bytes, hipMemcpyHostToDevice, ctx->stream));
   return MH_OK;
 }
 
@@ -3244,6 +3248,7 @@ struct AlignJob {
   bool fused16 = false;  // row kernel accumulates the first Gauss-Newton step itself (layers above the one-workgroup size)
   bool defer_upload = false;   // batches: the pinned mirrors are filled, the copies are issued by the batch (staged) or flush()
   size_t nsched_pending = 0;
+  size_t inline_sched = 0;  // doubles of the schedules that ride behind the parameter block (single alignments; 0: their own copy)
   int variant = 0;
   bool finished = false, trivial = false;
   bool prof = false;  // time this job's match kernels with events (then it cannot use the graph path)
@@ -3298,7 +3303,12 @@ struct AlignJob {
         for (size_t k = 0; k < mi; k++) ctx->h_sched[2 * mi + k] = sgn * fabs(p->pt2pl_threshold[k]);
       }
       nsched_pending = nsched;
-      if (!defer_upload) MH_HIP(hipMemcpyAsync(ctx->sched.p, ctx->h_sched, nsched * sizeof(double), hipMemcpyHostToDevice, s));
+      // a single alignment whose schedules fit behind the parameter block: they travel with it (one copy, below)
+      inline_sched = (!defer_upload && nsched <= kInlineSchedDoubles) ? nsched : 0;
+      if (inline_sched)
+        memcpy(reinterpret_cast<char*>(ctx->h_state) + kInlineSchedOffset, ctx->h_sched, nsched * sizeof(double));
+      else if (!defer_upload)
+        MH_HIP(hipMemcpyAsync(ctx->sched.p, ctx->h_sched, nsched * sizeof(double), hipMemcpyHostToDevice, s));
     }
     if (trace) MH_TRY(ctx->trace.reserve(mi * sizeof(mh_icp_iter)));
     ctx->align_serial++;
@@ -3314,13 +3324,15 @@ struct AlignJob {
     ctx->h_state->cur_ang2 = (float)(ang * ang);
     ctx->h_state->cur_kparam = p->kernel_param[0];  // uploaded together with the parameters below
 
-    mk.thr = ctx->sched.as<double>();
-    mk.kparam = ctx->sched.as<double>() + mi;
+    double* const sched_dev = inline_sched ? reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->d_state) + kInlineSchedOffset)
+                                           : ctx->sched.as<double>();
+    mk.thr = sched_dev;
+    mk.kparam = sched_dev + mi;
     mk.ang2 = (float)(ang * ang);
     mk.kernel = p->gn.robust_kernel;
     mk.w_pt2pt = p->gn.weight_pt2pt;
     mk.w_pt2pl = p->gn.weight_pt2pl;
-    mk.pl_thr = pl ? ctx->sched.as<double>() + 2 * mi : nullptr;
+    mk.pl_thr = pl ? sched_dev + 2 * mi : nullptr;
     mk.skip_pl_paired = (pl && p->matched_points == MH_MATCHED_POINTS_SKIP) ? 1u : 0u;
     memset(&sk, 0, sizeof(sk));
     sk.max_iterations = p->max_iterations;
@@ -3425,7 +3437,7 @@ struct AlignJob {
       ctx->h_params->mk = mk;
       ctx->h_params->sk = sk;
     } else {
-      MH_TRY(upload_state_and_params(ctx, mk, sk));
+      MH_TRY(upload_state_and_params(ctx, mk, sk, inline_sched));
     }
     // poll_every == 0: the first chunk is sized by what the previous alignment of this context needed (consecutive scans
     // of a sequence converge in about as many iterations: one host round trip instead of three), later chunks are short
