@@ -423,6 +423,7 @@ class AlignBatcher {
   void forgetOwner(const void* owner);
   size_t filterBatches() const { return n_pp_batches_; }
   size_t filterJobs() const { return n_pp_jobs_; }
+  size_t waitTimeouts() const { return n_wait_timeouts_; }  // batches led by a request that had waited MOLA_HIP_BATCH_WAIT_US
   size_t filterTimeouts() const { return n_pp_timeouts_; }  // sets forced because a request had waited MOLA_HIP_FILTER_SET_WAIT_US
   size_t batches() const { return n_batches_; }
   size_t jobs() const { return n_jobs_; }
@@ -467,8 +468,10 @@ class AlignBatcher {
   std::map<const void*, OwnerState> owners_;
   std::map<size_t, size_t> pp_pending_;  // set -> announced requests that have not arrived yet
   size_t pp_set_ = 0;                    // sets below this one have been taken
-  size_t n_pp_batches_ = 0, n_pp_jobs_ = 0, n_pp_timeouts_ = 0;
+  size_t n_pp_batches_ = 0, n_pp_jobs_ = 0, n_pp_timeouts_ = 0, n_wait_timeouts_ = 0;
   void run_batch(std::vector<Request*>& batch);  // called WITHOUT the mutex
+  void take_waiting_locked(std::vector<Request*>& batch);  // the ONLY way out of waiting_: clears every taken request's `lead`
+  bool batch_due_locked() const;
   size_t threshold_locked() const;
   std::mutex mtx_;
   std::condition_variable cv_;

@@ -605,7 +605,24 @@ size_t AlignBatcher::threshold_locked() const {
   return std::max<size_t>(2, (active_ + split_ - 1) / split_);
 }
 
+// Everything that leaves waiting_ leaves it here, and leaves without its `lead` flag: a request whose flag is still set when its
+// thread wakes is therefore still waiting (leave() used to swap the vector bare, a woken leader could then find it
+// empty -- or holding NEWER requests -- and run a batch that did not contain itself).
+void AlignBatcher::take_waiting_locked(std::vector<Request*>& batch) {
+  batch.clear();
+  batch.swap(waiting_);
+  for (Request* r : batch) r->lead = false;
+  in_flight_ += batch.size();
+}
+
+// a batch is due when enough requests wait -- or when everybody who is not waiting is inside a running batch already (then
+// waiting longer only idles the device)
+bool AlignBatcher::batch_due_locked() const {
+  return !waiting_.empty() && (waiting_.size() >= threshold_locked() || waiting_.size() + in_flight_ >= active_);
+}
+
 void AlignBatcher::run_batch(std::vector<Request*>& batch) {
+  if (batch.empty()) return;
   // the device work of this batch is issued by this thread alone; the mutex is NOT held (other participants queue up and
   // may start the next batch on their own contexts meanwhile: the C ABI is re-entrant across contexts)
   const size_t n = batch.size();
@@ -650,6 +667,7 @@ void AlignBatcher::run_batch(std::vector<Request*>& batch) {
   t_run_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   t_assemble_ += std::chrono::duration<double>(t_start - batch[0]->arrived).count();
   in_flight_ -= n;
+  if (batch_due_locked()) waiting_.front()->lead = true;  // (e.g. a participant left while this batch ran; woken by the notify below)
   for (size_t i = 0; i < n; i++) {
     *batch[i]->result = results[i];
     batch[i]->status = sts[i];
@@ -680,15 +698,10 @@ mh_status AlignBatcher::align(const void* owner, const mh_map* map, const mh_sca
   rq.arrived = std::chrono::steady_clock::now();
   owners_[owner ? owner : (const void*)scan].aligns++;  // this participant is past the filter set of its previous alignment count
   if (!pp_waiting_.empty()) cv_.notify_all();           // (a waiting filter worker may find its set complete now)
-  auto take_waiting = [&](std::vector<Request*>& batch) {
-    batch.swap(waiting_);
-    for (Request* r : batch) r->lead = false;
-    in_flight_ += batch.size();
-  };
   if (solo) {
     in_flight_ += 1;
     // whoever waits for a batch waits for those who are not in flight: if that is nobody now, one of them leads it
-    if (!waiting_.empty() && waiting_.size() + in_flight_ >= active_) {
+    if (batch_due_locked()) {
       waiting_.front()->lead = true;
       cv_.notify_all();
     }
@@ -700,19 +713,29 @@ mh_status AlignBatcher::align(const void* owner, const mh_map* map, const mh_sca
     return rq.status;
   }
   waiting_.push_back(&rq);
-  // a batch is due when enough requests wait -- or when everybody who is not waiting is inside a running batch already
-  // (then waiting longer only idles the device)
-  if (waiting_.size() >= threshold_locked() || waiting_.size() + in_flight_ >= active_) {
+  if (batch_due_locked()) {
     std::vector<Request*> batch;
-    take_waiting(batch);
+    take_waiting_locked(batch);
     lk.unlock();
     run_batch(batch);
     lk.lock();
   } else {
-    cv_.wait(lk, [&] { return rq.done || rq.lead; });
-    if (!rq.done) {  // (lead: still among those waiting -- whoever takes a batch clears the flags of its requests)
+    // Bounded: with three or more participants whose other alignments all run solo and never overlap, nobody's arrival makes
+    // this request's batch due -- after the limit it leads whatever waits (a smaller batch: same results).
+    static const auto limit = std::chrono::microseconds([] {
+      const char* e = getenv("MOLA_HIP_BATCH_WAIT_US");
+      return e ? std::max(100, atoi(e)) : 3000;
+    }());
+    while (!rq.done) {
+      const bool woke = cv_.wait_for(lk, limit, [&] { return rq.done || rq.lead; });
+      if (rq.done) break;
+      // `lead` set (or the limit reached) AND still among those waiting: whoever takes a batch clears the flags of its requests,
+      // so a set flag means nobody has taken this one
+      const bool still_waiting = std::find(waiting_.begin(), waiting_.end(), &rq) != waiting_.end();
+      if (!still_waiting) continue;  // (taken by another leader meanwhile: its batch will set `done`)
+      if (!woke) n_wait_timeouts_++;
       std::vector<Request*> batch;
-      take_waiting(batch);
+      take_waiting_locked(batch);
       lk.unlock();
       run_batch(batch);
       lk.lock();
@@ -832,11 +855,10 @@ void AlignBatcher::leave() {
   std::unique_lock<std::mutex> lk(mtx_);
   if (active_ > 0) active_--;
   cv_.notify_all();  // (fewer participants: a waiting filter set may be complete now)
-  if (!waiting_.empty() && (waiting_.size() >= threshold_locked() || waiting_.size() + in_flight_ >= active_)) {
+  if (batch_due_locked()) {
     // the others were only waiting for this one
     std::vector<Request*> batch;
-    batch.swap(waiting_);
-    in_flight_ += batch.size();
+    take_waiting_locked(batch);
     lk.unlock();
     run_batch(batch);
   }
