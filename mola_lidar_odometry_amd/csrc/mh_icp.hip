@@ -42,6 +42,10 @@
 #include "mh_nn_device.h"
 #include "mh_nn_flat.h"
 
+#ifndef MH_LOOPW_DEFAULT
+#define MH_LOOPW_DEFAULT "batch"
+#endif
+
 using namespace mh;
 
 constexpr uint32_t kBlock = 256;
@@ -438,6 +442,12 @@ __device__ unsigned long long g_phase[32];
 extern "C" __attribute__((visibility("default"))) int mh_debug_phases(unsigned long long* host_out) {
   (void)hipDeviceSynchronize();
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase), sizeof(g_phase)) == hipSuccess ? 0 : 2;
+}
+extern "C" __attribute__((visibility("default"))) int mh_debug_flat_counters(unsigned long long* host_out, int reset) {
+  (void)hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mh::g_flatdbg), sizeof(mh::g_flatdbg)) != hipSuccess) return 2;
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mh::g_flatdbg), z, sizeof(z)); }
+  return 0;
 }
 // k_icp16 (a loop): the time between consecutive stamps is ACCUMULATED per phase, workgroup 0's first lane, written out at the end
 #define MH_LOOP_STAMPS unsigned long long lp_t = wall_clock64(), lp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
@@ -1115,6 +1125,13 @@ struct SolveShared {
   double totA[kAccN], totB[kGenN];
   double sh_log[13][6];
 };
+// ... without the scratch, for callers that hand solve_body ready totals (k_icpw keeps its reduction scratch elsewhere)
+struct SolveSharedTotals {
+  double totA[kAccN], totB[kGenN];
+  double sh_log[13][6];
+};
+__device__ __forceinline__ double (*solve_red(SolveShared& s))[64] { return s.red; }
+__device__ __forceinline__ double (*solve_red(SolveSharedTotals&))[64] { return nullptr; }
 
 // One Gauss-Newton step + the tail of the ICP iteration, executed by ONE workgroup of kSolveThreads lanes.  Every lane
 // must call it; only lane 0 runs the serial part.  (A cooperative single-launch version of the whole loop for the
@@ -1127,12 +1144,12 @@ struct SolveShared {
 // LDS_STATE: the state block lives in LDS (k_step16: one copy per workgroup) instead of global memory.
 // WAVE0: only the first wave of the workgroup calls (the totals are ready in LDS, nothing here needs the other waves): the
 // one workgroup barrier below becomes a wave-level hand-over.
-template <bool LDS_STATE = false, bool WAVE0 = false>
+template <bool LDS_STATE = false, bool WAVE0 = false, class SH = SolveShared>
 __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, const SolveK* __restrict__ kp_,
                                            const double* __restrict__ partA, uint32_t nA, uint32_t strideA,
                                            const double* __restrict__ partB, uint32_t nB, uint32_t strideB,
-                                           SolveShared& sh, bool totA_ready = false, bool totB_ready = false) {
-  double (*red)[64] = sh.red;
+                                           SH& sh, bool totA_ready = false, bool totB_ready = false) {
+  double (*red)[64] = solve_red(sh);
   double* totA = sh.totA;
   double* totB = sh.totB;
   double (*sh_log)[6] = sh.sh_log;
@@ -1800,8 +1817,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_step16_b(const BatchJob* __re
 #ifndef MH_LOOP_MAX_GROUPS
 #define MH_LOOP_MAX_GROUPS 64
 #endif
-constexpr uint32_t kLoopMaxGroups = MH_LOOP_MAX_GROUPS;   // workgroups of one loop: layers up to 32 x this many points (beyond: the chain)
-constexpr uint32_t kLoopRowStride = MH_LOOP_MAX_GROUPS;   // entries from one sum's row to the next
+constexpr uint32_t kLoopMaxGroups = MH_LOOP_MAX_GROUPS;   // workgroups of one k_icp16 loop: layers up to 32 x this many points (beyond: the chain)
+constexpr uint32_t kLwMaxGroups = 128;                    // columns of one k_icpw loop (mh_loop_wave.h): layers up to 4096 points
+constexpr uint32_t kLoopRowStride = kLwMaxGroups > kLoopMaxGroups ? kLwMaxGroups : kLoopMaxGroups;   // entries from one sum's row to the next
 constexpr size_t kLoopExchangeBytes = 2 * (size_t)(kAccN + kGenN) * kLoopRowStride * 16;
 
 __device__ __forceinline__ void cov_prepare_lane(const Pose& Tc, int j, double hx, double ha, double* out);  // (below)
@@ -2154,6 +2172,8 @@ template <bool PL>
 __global__ __launch_bounds__(kSolveThreads) void k_icp16_b(const BatchJob* __restrict__ jobs) {
   icp16_multi_body<PL>(jobs[blockIdx.y]);
 }
+
+#include "mh_loop_wave.h"  // k_icpw: the same loop with the plan / scan search, 128 points per workgroup of 256 lanes
 
 // ================================================================================================
 // Covariance (mp2p_icp::covariance [U]): A = d residuals / d (x,y,z,yaw,pitch,roll), cov = (A^T A)^-1
@@ -3102,11 +3122,24 @@ mh_status ensure_state(mh_ctx* ctx) {
 }
 
 // state + parameters (+ the schedules that ride behind them: inline_sched doubles) in one copy (start of mh_icp_align)
-mh_status upload_state_and_params(mh_ctx* ctx, const MatchK& mk, const SolveK& sk, size_t inline_sched = 0) {
+mh_status upload_state_and_params(mh_ctx* ctx, const MatchK& mk, const SolveK& sk, size_t inline_sched = 0, hipStream_t on = nullptr) {
   ctx->h_params->mk = mk;
   ctx->h_params->sk = sk;
   const size_t bytes = inline_sched ? kInlineSchedOffset + inline_sched * sizeof(double) : kParamsOffset + sizeof(IcpDeviceParams);
-  MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, bytes, hipMemcpyHostToDevice, ctx->stream));
+  MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, bytes, hipMemcpyHostToDevice, on ? on : ctx->stream));
+  return MH_OK;
+}
+// the context's loop stream (created on first use), ordered behind everything queued on its own stream so far
+mh_status loop_stream_behind(mh_ctx* ctx, hipStream_t* out) {
+  if (!ctx->loop_stream) {
+    int lo = 0, hi = 0;  // (numerically lower = higher priority)
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+    MH_HIP(hipStreamCreateWithPriority(&ctx->loop_stream, hipStreamNonBlocking, hi));
+    MH_HIP(hipEventCreateWithFlags(&ctx->ev_loop, hipEventDisableTiming));
+  }
+  MH_HIP(hipEventRecord(ctx->ev_loop, ctx->stream));
+  MH_HIP(hipStreamWaitEvent(ctx->loop_stream, ctx->ev_loop, 0));
+  *out = ctx->loop_stream;
   return MH_OK;
 }
 
@@ -3225,8 +3258,27 @@ uint32_t loop_cu_limit(int device) {
 // the loops of `callers` alignments of `ng` groups each fit 70 % of the device's CUs side by side (one group per workgroup; shared
 // loops whose workgroups take 2 or 4 groups each were measured for 6 / 8 / 16 callers and lost to lock-step batches: 3100-3550 /
 // 3260-3540 / 3000-3140 against 4960 / 5300 / 5470-6150 scans/s -- the callers' other kernels start and stop beside them)
-bool loops_fit(int device, uint32_t ng, uint32_t callers) {
-  return callers <= 1 || (uint64_t)callers * ng * 10u <= (uint64_t)loop_cu_limit(device) * 7u;
+// Admission is counted in HALF compute units: a k_icp16 workgroup (512 lanes x ~250 registers) takes a CU, a k_icpw workgroup
+// (256 lanes, 63 KB of LDS) half of one.
+constexpr uint32_t kLoopUnitsPerCu = 2;
+// MH_LOOPW = all | solo | batch | none: where k_icpw / k_icpw_b (plan / scan search, 128 points per workgroup) replace k_icp16 /
+// k_icp16_b (a DPP row per point) on point layers.  (MH_NO_LOOPW=1 = none.)
+bool loop_wave_enabled(bool batch = false) {
+  if (getenv("MH_NO_LOOPW") != nullptr) return false;
+  const char* e = getenv("MH_LOOPW");
+  if (!e) e = MH_LOOPW_DEFAULT;
+  return e[0] == 'a' || (batch ? e[0] == 'b' : e[0] == 's');
+}
+// what the loop of a layer of `ng` groups holds: with_planes -> k_icp16<true> (the plane matcher rides in the row search)
+uint32_t loop_units(uint32_t ng, bool with_planes) {
+  return (with_planes || !loop_wave_enabled()) ? kLoopUnitsPerCu * ng : (ng + kLwGroups - 1) / kLwGroups;
+}
+bool loops_fit(int device, uint32_t units, uint32_t callers) {
+  // (and never more than MH_SOLO_MAX_CALLERS, 4: beyond, every measurement so far says lock-step batches -- the loops' own
+  //  streams share four hardware queues with everything else the callers issue, and a loop holds its queue for 0.5 ms)
+  const char* e = getenv("MH_SOLO_MAX_CALLERS");
+  const uint32_t cap = e ? (uint32_t)std::max(1, atoi(e)) : 4u;
+  return callers <= 1 || (callers <= cap && (uint64_t)callers * units * 10u <= (uint64_t)loop_cu_limit(device) * kLoopUnitsPerCu * 7u);
 }
 
 struct AlignJob {
@@ -3255,7 +3307,9 @@ struct AlignJob {
   bool pl = false;    // Matcher_Point2Plane runs before the point matcher (lidar3d-ndt.yaml:195-210)
   bool streaming = false;  // run_streaming(): iterations are enqueued one by one behind the device's published progress
   bool skip_tail = false;  // ... and the covariance kernels + state read-back only once the loop has ended
-  bool loop16 = false;         // run_loop16(): the whole loop of a small layer in ONE launch (k_icp16)
+  bool loop16 = false;         // run_loop16(): the whole loop of a small layer in ONE launch (k_icp16 / k_icpw)
+  hipStream_t ws = nullptr;    // the stream a one-launch loop, its upload and its tail run on (the context's loop stream; null: ctx->stream)
+  bool loopw = false;          // ... as k_icpw (plan / scan search, 128 points per workgroup; needs the map's sub-voxel index)
   bool forbid_loop16 = false;  // ... not for this job: the second attempt after a loop whose workgroups gave up
   uint32_t loop_wgs = 0;       // workgroups this job holds of the device's admission count while its loop runs
 
@@ -3418,11 +3472,20 @@ struct AlignJob {
     //  next 200 alignments on the device take the chain before another loop is tried)
     if (streaming && use_step_chain() && !forbid_loop16 && getenv("MH_NO_LOOP16") == nullptr && !loop_holdoff(ctx->device, false)) {
       const uint32_t ng = (uint32_t)((scan->n + kStepPoints - 1) / kStepPoints);
-      if (ng <= kLoopMaxGroups && loop_admit(ctx->device, ng)) {
-        loop_wgs = ng;
+      loopw = !pl && loop_wave_enabled();
+      if (ng <= (loopw ? kLwMaxGroups : kLoopMaxGroups) && loop_admit(ctx->device, loop_units(ng, pl))) {
+        loop_wgs = loop_units(ng, pl);
         loop16 = true;
         streaming = false;
         sk.host_progress = nullptr;
+        if (loopw) {  // the plan / scan search reads the map's sub-voxel index (built once per map content, on this stream)
+          mh_status qs = map_ensure_qidx(map, ctx->stream);
+          if (qs == MH_OK && !map->view().pts_q) qs = fail(MH_ERR_INTERNAL, "the map's sub-voxel index is missing (k_icpw needs it)");
+          if (qs != MH_OK) {
+            loop_release();
+            return qs;
+          }
+        }
         if (ctx->loop_x.bytes < kLoopExchangeBytes) {
           const mh_status rs = ctx->loop_x.reserve(kLoopExchangeBytes);
           if (rs != MH_OK) {
@@ -3433,11 +3496,19 @@ struct AlignJob {
         }
       }
     }
+    ws = nullptr;
+    if (loop16 && !defer_upload && getenv("MH_NO_LOOP_STREAM") == nullptr) {
+      const mh_status ls = loop_stream_behind(ctx, &ws);
+      if (ls != MH_OK) {
+        loop_release();
+        return ls;
+      }
+    }
     if (defer_upload) {
       ctx->h_params->mk = mk;
       ctx->h_params->sk = sk;
     } else {
-      MH_TRY(upload_state_and_params(ctx, mk, sk, inline_sched));
+      MH_TRY(upload_state_and_params(ctx, mk, sk, inline_sched, ws));
     }
     // poll_every == 0: the first chunk is sized by what the previous alignment of this context needed (consecutive scans
     // of a sequence converge in about as many iterations: one host round trip instead of three), later chunks are short
@@ -3489,8 +3560,8 @@ struct AlignJob {
     static std::atomic<uint32_t> c[64];
     return c[(unsigned)device % 64u];
   }
-  static bool loop_admit(int device, uint32_t wgs) {
-    const uint32_t limit = loop_cu_limit(device);
+  static bool loop_admit(int device, uint32_t wgs) {  // wgs: in half CUs (loop_units)
+    const uint32_t limit = loop_cu_limit(device) * kLoopUnitsPerCu;
     if (wgs > limit) return false;
     // A loop that does not fit now waits for the running ones (each takes a fraction of a millisecond) rather than fall back to
     // the chain, whose forty-odd launches would queue behind the same loops: eight sequences of the default pipeline keep five
@@ -3530,7 +3601,7 @@ struct AlignJob {
   // launch-by-launch chain.
   mh_status run_loop16() {
     MH_TRY(set_device(ctx));
-    hipStream_t s = ctx->stream;
+    hipStream_t s = ws ? ws : ctx->stream;
     const uint32_t n = (uint32_t)scan->n;
     const uint32_t ngr = (n + kStepPoints - 1) / kStepPoints;
     // (MH_LOOP16_TEST_ABANDON: the loop is cut short as if its workgroups had given up -- the caller's second attempt is what is tested)
@@ -3541,7 +3612,11 @@ struct AlignJob {
     char* const xa = static_cast<char*>(ctx->loop_x.p);
     char* const xb = xa + 2 * (size_t)kAccN * kLoopRowStride * 16;
     const MapView mv = map->view();
-    if (pl)
+    if (loopw)
+      hipLaunchKernelGGL(k_icpw, dim3((ngr + kLwGroups - 1) / kLwGroups), dim3(kLwThreads), 0, s, ctx->d_state, &ctx->d_params->mk,
+                         &ctx->d_params->sk, scan->x, scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(),
+                         (void*)xa, ngr, serial0, max_steps, p->compute_covariance ? 1u : 0u);
+    else if (pl)
       hipLaunchKernelGGL(k_icp16<true>, dim3(ngr), dim3(kSolveThreads), 0, s, ctx->d_state, &ctx->d_params->mk, &ctx->d_params->sk, scan->x,
                          scan->y, scan->z, n, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), ctx->pl_c.as<float4>(),
                          ctx->pl_n.as<float4>(), (void*)xa, (void*)xb, ngr, serial0, max_steps, p->compute_covariance ? 1u : 0u);
@@ -3551,9 +3626,10 @@ struct AlignJob {
                          (float4*)nullptr, (void*)xa, (void*)xb, ngr, serial0, max_steps, p->compute_covariance ? 1u : 0u);
     enqueued = p->max_iterations;
     skip_tail = false;
-    MH_TRY(enqueue_tail(/*cov_prepared=*/true));
+    MH_TRY(enqueue_tail(/*cov_prepared=*/true, s));
     const hipError_t we = mh::wait_event(ctx->ev_poll);
     loop_release();
+    ws = nullptr;  // (whatever follows -- the chain after an abandoned loop, the pairing export -- runs on the context's own stream: the host has waited)
     MH_HIP(we);
     const IcpDeviceState* h = ctx->h_state;
     if (!h->done || h->handover_timeouts) {
@@ -3846,9 +3922,9 @@ struct AlignJob {
     return poll();
   }
 
-  mh_status enqueue_tail(bool cov_prepared = false) {  // cov_prepared: k_icp16 has done k_cov_prepare's part
+  mh_status enqueue_tail(bool cov_prepared = false, hipStream_t on = nullptr) {  // cov_prepared: k_icp16 has done k_cov_prepare's part
     MH_TRY(set_device(ctx));
-    hipStream_t s = ctx->stream;
+    hipStream_t s = on ? on : ctx->stream;
     const uint32_t n = (uint32_t)scan->n;
     double* part = ctx->partials.as<double>();
     double* partb = pl ? ctx->partials_b.as<double>() : nullptr;
@@ -3985,7 +4061,8 @@ mh_status mh_icp_align_prefers_solo(const mh_scan* scan, const mh_icp_params* p,
   if (e && (e[0] == 't' || e[0] == 'w' || e[0] == 'o' || e[0] == 'q' || e[0] == 'f' || e[0] == 'p' || e[0] == 'x')) row = false;
   if (e && e[0] == 's') row = true;
   if (pl && p->matched_points == MH_MATCHED_POINTS_SKIP) row = true;
-  *yes = (n > 0 && p->max_iterations > 0 && row && n <= (size_t)kLoopMaxGroups * kStepPoints && p->poll_every == 0 && p->profile == 0 &&
+  const size_t loop_max = (size_t)((!pl && loop_wave_enabled()) ? kLwMaxGroups : kLoopMaxGroups) * kStepPoints;
+  *yes = (n > 0 && p->max_iterations > 0 && row && n <= loop_max && p->poll_every == 0 && p->profile == 0 &&
           scan->ctx->d_progress != nullptr && getenv("MH_NO_STREAM") == nullptr && getenv("MH_NO_STEP_CHAIN") == nullptr &&
           getenv("MH_NO_LOOP16") == nullptr)
              ? 1
@@ -3993,7 +4070,7 @@ mh_status mh_icp_align_prefers_solo(const mh_scan* scan, const mh_icp_params* p,
   // ... and the loops of all callers fit the device together: nobody waits for a turn.  (70 % of the CUs: the callers' filters,
   // de-skew and map updates run beside the loops -- five loops of 44 workgroups on 256 CUs measured slower than four, 3780 against
   // 4000-4450 scans/s.)
-  if (*yes && !loops_fit(scan->ctx->device, (uint32_t)((n + kStepPoints - 1) / kStepPoints), concurrent_callers)) *yes = 0;
+  if (*yes && !loops_fit(scan->ctx->device, loop_units((uint32_t)((n + kStepPoints - 1) / kStepPoints), pl), concurrent_callers)) *yes = 0;
   return MH_OK;
 }
 
@@ -4228,6 +4305,8 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
     uint32_t gx_match = 1, gx_acc = 1, gx_cov = 1, gx_step = 1, enq = 0, prof_n = 0, max_iterations = 0, inner = 1, chunk = 10;
     uint32_t src = 2, par = 0, launches = 0;  // k_step16_b: the state block (2 = canonical) and the partials half the next launch reads; launches so far
     bool cov = false, done = false, auto_chunk = false;
+    bool loop_wave = false;  // ... as k_icpw_b (point layers): every job its own workgroups
+    uint32_t gx_loopw = 1;   // ... whose launch has this many workgroups per job
     bool loop_now = false;   // k_icp16_b: the group's whole loops in ONE launch (decided below; cleared when a job's workgroups gave up)
     uint32_t loop_wgs = 0;   // ... and what it holds of the device's admission count meanwhile
     bool step_chain() const { return kind == K_STEP || kind == K_STEP_PL; }
@@ -4366,16 +4445,34 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
       if (g.step_chain() && getenv("MH_NO_LOOP16") == nullptr && getenv("MH_NO_LOOP16_BATCH") == nullptr &&
           !AlignJob::loop_holdoff(lead->device, false)) {
         bool fits = true;
+        // k_icpw_b (point layers): every job its own workgroups of 128 points; k_icp16_b (NDT maps, MH_NO_LOOPW): the jobs share
+        // kStepMaxWorkgroups workgroups of 32 points, a workgroup taking several groups
+        g.loop_wave = !g.with_planes() && loop_wave_enabled(true);
+        uint32_t units = 0, gx_w = 1;
         for (uint32_t a = 0; a < A; a++) {
           const uint32_t ng = (h_desc[a].n + kStepPoints - 1) / kStepPoints;
           const uint32_t nw = ng < g.gx_step ? ng : g.gx_step;
-          fits = fits && ng <= kLoopMaxGroups && (nw == 0 || (ng + nw - 1) / nw <= kLoopGroupsPerWg) && g.jobs[a]->sk.max_iterations > 0;
+          if (g.loop_wave) {
+            fits = fits && ng <= kLwMaxGroups && g.jobs[a]->sk.max_iterations > 0;
+            const uint32_t w = (ng + kLwGroups - 1) / kLwGroups;
+            units += w;
+            gx_w = w > gx_w ? w : gx_w;
+          } else {
+            fits = fits && ng <= kLoopMaxGroups && (nw == 0 || (ng + nw - 1) / nw <= kLoopGroupsPerWg) && g.jobs[a]->sk.max_iterations > 0;
+          }
         }
-        if (fits && AlignJob::loop_admit(lead->device, g.gx_step * A)) {
+        if (!g.loop_wave) units = kLoopUnitsPerCu * g.gx_step * A;
+        if (fits && AlignJob::loop_admit(lead->device, units)) {
           g.loop_now = true;
-          g.loop_wgs = g.gx_step * A;
+          g.loop_wgs = units;
+          g.gx_loopw = gx_w;
           for (uint32_t a = 0; a < A && g.loop_now; a++) {
             AlignJob& j = *g.jobs[a];
+            if (g.loop_wave && (map_ensure_qidx(j.map, s) != MH_OK || !j.map->view().pts_q)) {  // (s waits for every job's stream: above)
+              g.loop_now = false;
+              break;
+            }
+            if (g.loop_wave) h_desc[a].map = j.map->view();  // (with the sub-voxel index)
             if (j.ctx->loop_x.bytes < kLoopExchangeBytes) {
               if (j.ctx->loop_x.reserve(kLoopExchangeBytes) != MH_OK) {
                 g.loop_now = false;
@@ -4422,7 +4519,8 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
           m_of[gi] = g.max_iterations - g.enq;
           const uint32_t A = (uint32_t)g.jobs.size();
           g_loop16_runs.fetch_add(A);
-          if (g.with_planes()) hipLaunchKernelGGL(k_icp16_b<true>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, g.lead->stream, g.dj);
+          if (g.loop_wave) hipLaunchKernelGGL(k_icpw_b, dim3(g.gx_loopw, A), dim3(kLwThreads), 0, g.lead->stream, g.dj);
+          else if (g.with_planes()) hipLaunchKernelGGL(k_icp16_b<true>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, g.lead->stream, g.dj);
           else hipLaunchKernelGGL(k_icp16_b<false>, dim3(g.gx_step, A), dim3(kSolveThreads), 0, g.lead->stream, g.dj);
           continue;
         }

@@ -50,17 +50,31 @@ constexpr int kFlatMaxCand = 8;        // candidate voxels per point on the plan
 constexpr int kFlatMaxChunks = MH_FLAT_CHUNKS;  // per wave (C2: ~320)
 constexpr uint32_t kFlatMaxRecords = 1u << 30;  // chunk word = first record (30 bits) | (records - 1) << 30
 
-struct FlatWave {
+// MAXC: candidate voxels per point on the planned path; NCL: entries of the candidate list (>= points per wave x MAXC);
+// NCH: entries of the chunk list.
+template <int MAXC, int NCL, int NCH>
+struct FlatWaveT {
+  static constexpr int kMaxCand = MAXC;
+  static constexpr int kCands = NCL;
+  static constexpr int kMaxChunks = NCH;
   f32x4 P[64];                         // p' and the bound b0 (phase D: the bound the quad search is to start from)
   unsigned long long KB[64];           // packed key of voxel (cx-1, cy-1, cz-1)
   unsigned long long RES[64];          // best (d2 bits << 32 | scan position) so far, ds_min_u64
-  uint32_t CH[kFlatMaxChunks];         // chunk: first record | (records - 1) << 30
-  unsigned short CL[64 * kFlatMaxCand];  // candidate: point | code << 8
-  unsigned char CHP[kFlatMaxChunks];   // the chunk's point
+  uint32_t CH[NCH];                    // chunk: first record | (records - 1) << 30
+  unsigned short CL[NCL];              // candidate: point | code << 8
+  unsigned char CHP[NCH];              // the chunk's point
   unsigned char SLOWF[64];             // the plan ran out of chunk space for this point
   unsigned char SL[64];                // phase D: the points to search quad-wise, compacted
-  uint32_t NCH, NVALID;                // chunks allocated (ds_add_rtn); first chunk slot that was not written (ds_min)
+  uint32_t NCH_, NVALID;               // chunks allocated (ds_add_rtn); first chunk slot that was not written (ds_min)
 };
+typedef FlatWaveT<kFlatMaxCand, 64 * kFlatMaxCand, kFlatMaxChunks> FlatWave;   // the large layers' matcher (k_match_flat*): C2 shapes
+#ifndef MH_LW_NCL
+#define MH_LW_NCL 1024
+#endif
+#ifndef MH_LW_NCH
+#define MH_LW_NCH 1024
+#endif
+typedef FlatWaveT<27, MH_LW_NCL, MH_LW_NCH> FlatWaveSmall;  // the small layer's loop (k_icpw): <= 37 points per wave, every candidate count planned
 
 // count of set bits of `m` below this lane
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
@@ -71,8 +85,11 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
 // pair, the narrowed ranges cut into chunks, a lane per record of every chunk.  `init`: what a point's result word starts from
 // (the bound and "no record", or what an earlier stage found).  Returns the number of candidate pairs (wave-uniform); with none,
 // nothing is written to LDS.
-__device__ __forceinline__ uint32_t flat_plan_scan(FlatWave& sh, const MapView& m, uint32_t lane, uint32_t cmask, unsigned long long kbase,
+template <class FW>
+__device__ __forceinline__ uint32_t flat_plan_scan(FW& sh, const MapView& m, uint32_t lane, uint32_t cmask, unsigned long long kbase,
                                                    float px, float py, float pz, float b0, unsigned long long init) {
+  constexpr int kFlatMaxCand = FW::kMaxCand;
+  constexpr int kFlatMaxChunks = FW::kMaxChunks;
   const gslots_ptr slots4 = (gslots_ptr)m.slots;
   const gpts_ptr spts = (gpts_ptr)m.pts_q;
   uint32_t n_cands;
@@ -85,15 +102,23 @@ __device__ __forceinline__ uint32_t flat_plan_scan(FlatWave& sh, const MapView& 
     sh.KB[lane] = kbase;
     sh.RES[lane] = init;
     sh.SLOWF[lane] = 0;
-    if (lane == 0) { sh.NCH = 0; sh.NVALID = (uint32_t)kFlatMaxChunks; }
+    if (lane == 0) { sh.NCH_ = 0; sh.NVALID = (uint32_t)kFlatMaxChunks; }
     {
       uint32_t mm = cmask, at = cincl - ncand;
+      if (kFlatMaxCand <= 8) {
 #pragma unroll
-      for (int j = 0; j < kFlatMaxCand; j++) {
-        if (mm) {
+        for (int j = 0; j < (kFlatMaxCand <= 8 ? kFlatMaxCand : 1); j++) {
+          if (mm) {
+            const uint32_t code = (uint32_t)__builtin_ctz(mm);
+            mm &= mm - 1;
+            sh.CL[at + (uint32_t)j] = (unsigned short)(lane | (code << 8));
+          }
+        }
+      } else {
+        while (mm) {  // (up to 27 codes: a loop as long as the wave's longest list)
           const uint32_t code = (uint32_t)__builtin_ctz(mm);
           mm &= mm - 1;
-          sh.CL[at + (uint32_t)j] = (unsigned short)(lane | (code << 8));
+          sh.CL[at++] = (unsigned short)(lane | (code << 8));
         }
       }
     }
@@ -132,7 +157,7 @@ __device__ __forceinline__ uint32_t flat_plan_scan(FlatWave& sh, const MapView& 
 #ifdef MH_FLAT_ATOMIC_ALLOC
         // (A/B: chunk space off one LDS counter -- one ds_add_rtn instead of a DPP prefix sum, but 64 lanes on one address)
         uint32_t pos = 0;
-        if (nchunks) pos = __hip_atomic_fetch_add(&sh.NCH, nchunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (nchunks) pos = __hip_atomic_fetch_add(&sh.NCH_, nchunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
         // chunk space by a DPP prefix sum over the wave's candidates of this pass (the order of the chunks does not matter
         // for the result: every chunk names its point)
@@ -158,7 +183,7 @@ __device__ __forceinline__ uint32_t flat_plan_scan(FlatWave& sh, const MapView& 
     wave_sync_lds_nn();
     {
 #ifdef MH_FLAT_ATOMIC_ALLOC
-      const uint32_t a = sh.NCH;
+      const uint32_t a = sh.NCH_;
 #else
       const uint32_t a = nch_total;
 #endif
@@ -375,6 +400,163 @@ __device__ __forceinline__ void match_flat_wave(FlatWave& sh, const MapView& m, 
       }
     }
   }
+}
+
+
+// The same search with the points handed over in registers and the result handed back in registers -- lane = point -- for the
+// small layer's one-launch loop (k_icpw, mh_loop_wave.h), where a wave keeps its points' pairings from one ICP iteration to the
+// next and nothing goes through global memory.  `in`: the lane holds a point; (px, py, pz): the point under the current pose;
+// b0: the squared distance to the record paired with it in the previous iteration (attained by a map record) or +inf.
+// Phases A1 (masks) | stage 0 | A2 | B | C | D exactly as in match_flat_wave: the same candidate set, the same fp32 arithmetic,
+// the same 64-bit key -- the lexicographic minimum of (d2, scan position) over the 27-voxel block.
+#ifdef MH_DEBUG_WAVETRACE
+static __device__ unsigned long long g_flatdbg[16];  // debug build: [0] searches (waves) [1] points [2] unbounded at entry [3] slow: out of range / no bound after stage 0
+                                              // [4] slow: > kFlatMaxCand candidates [5] slow: chunk space [6] slow: bound not attained [7] candidates [8] chunks (stage 1) [9] D rounds
+#define MH_FLATDBG(i, v) do { const unsigned long long b_ = __ballot(v); if (lane == 0 && b_) atomicAdd(&g_flatdbg[i], (unsigned long long)__builtin_popcountll(b_)); } while (0)
+#define MH_FLATDBG_ADD(i, v) do { if (lane == 0) atomicAdd(&g_flatdbg[i], (unsigned long long)(v)); } while (0)
+#else
+#define MH_FLATDBG(i, v) do { } while (0)
+#define MH_FLATDBG_ADD(i, v) do { } while (0)
+#endif
+struct FlatHit {
+  f32x4 pt;    // the nearest record {x, y, z, source index}; zeros when there is none
+  float d2;    // its squared distance; +inf when there is none
+  bool found;
+};
+template <class FW>
+__device__ __forceinline__ FlatHit flat_search_points(FW& sh, const MapView& m, bool in, float px, float py, float pz, float b0) {
+  constexpr int kFlatMaxCand = FW::kMaxCand;
+  const uint32_t lane = (uint32_t)__lane_id();
+  const gpts_ptr pts4 = (gpts_ptr)m.pts;
+  const float lim = 1.0e6f;
+  const bool okrange = ((int)(fabsf(px * m.inv_vs) < lim) & (int)(fabsf(py * m.inv_vs) < lim) & (int)(fabsf(pz * m.inv_vs) < lim)) != 0;
+  const bool unbounded = in && okrange && !(b0 < __builtin_inff());
+  bool own_empty = false;  // stage 0 scanned the own voxel and found it empty: stage 1 takes the rest of the block unbounded
+  MH_FLATDBG_ADD(0, 1);
+  MH_FLATDBG(1, in);
+  MH_FLATDBG(2, unbounded);
+  bool own_done = false;
+  unsigned long long res0 = 0;
+  bool planned = false;
+  uint32_t n_cands = 0;
+  const int cx = voxel_of(px, m.inv_vs, m.trunc), cy = voxel_of(py, m.inv_vs, m.trunc), cz = voxel_of(pz, m.inv_vs, m.trunc);
+  const unsigned long long kbase = pack_key(cx - 1, cy - 1, cz - 1);
+  if (__ballot(unbounded) != 0ull) {  // stage 0 (wave-uniform): the own voxel of the points that have no bound
+    n_cands = flat_plan_scan(sh, m, lane, unbounded ? (1u << 13) : 0u, kbase, px, py, pz, b0, 0x7F800000FFFFFFFFull);
+    const unsigned long long r0 = sh.RES[lane];
+    if (unbounded && (uint32_t)r0 != 0xFFFFFFFFu && sh.SLOWF[lane] == 0) {
+      own_done = true;
+      res0 = r0;
+      b0 = __uint_as_float((uint32_t)(r0 >> 32));
+    } else if (unbounded && sh.SLOWF[lane] == 0 && kFlatMaxCand >= 27) {
+      // the own voxel is empty (a third of the points of a decimated layer at ICP iteration 0): the other 26 voxels of the block
+      // are planned without a bound -- every lower bound passes, nothing is narrowed, every record is compared -- and what that
+      // finds, or does not find, is the block's answer
+      own_empty = true;
+    }
+    wave_sync_lds_nn();
+  }
+  uint32_t cmask = 0;
+  planned = in && okrange && (b0 < __builtin_inff() || own_empty);
+  MH_FLATDBG(3, in && !planned);
+  if (__ballot(planned) != 0ull) {  // wave-uniform
+    const Gaps gx = axis_gaps(px, cx, m.vs, m.trunc), gy = axis_gaps(py, cy, m.vs, m.trunc), gz = axis_gaps(pz, cz, m.vs, m.trunc);
+    cmask = 1u << 13;
+    const float fx = fmaxf(gx.s[0], gx.s[2]), fy = fmaxf(gy.s[0], gy.s[2]), fz = fmaxf(gz.s[0], gz.s[2]);
+    const bool far_dead = (fx * 0.9999f > b0) && (fy * 0.9999f > b0) && (fz * 0.9999f > b0);
+    if (__ballot(planned && !far_dead) == 0ull) {  // the seven near-side codes (match_flat_wave has the argument)
+      const bool xl = gx.s[0] <= gx.s[2], yl = gy.s[0] <= gy.s[2], zl = gz.s[0] <= gz.s[2];
+      const float nx = xl ? gx.s[0] : gx.s[2], ny = yl ? gy.s[0] : gy.s[2], nz = zl ? gz.s[0] : gz.s[2];
+      const uint32_t cx_ = xl ? 4u : 22u, cy_ = yl ? 10u : 16u, cz_ = zl ? 12u : 14u;
+      const uint32_t dx_ = cx_ - 13u, dy_ = cy_ - 13u;
+      const float lxy = nx + ny;
+      cmask |= (!(nx * 0.9999f > b0)) ? (1u << cx_) : 0u;
+      cmask |= (!(ny * 0.9999f > b0)) ? (1u << cy_) : 0u;
+      cmask |= (!(nz * 0.9999f > b0)) ? (1u << cz_) : 0u;
+      cmask |= (!(lxy * 0.9999f > b0)) ? (1u << (cy_ + dx_)) : 0u;
+      cmask |= (!((nx + nz) * 0.9999f > b0)) ? (1u << (cz_ + dx_)) : 0u;
+      cmask |= (!((ny + nz) * 0.9999f > b0)) ? (1u << (cz_ + dy_)) : 0u;
+      cmask |= (!((lxy + nz) * 0.9999f > b0)) ? (1u << (cz_ + dx_ + dy_)) : 0u;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 27; c++) {
+        if (c == 13) continue;
+        const int ix = c / 9, iy = (c / 3) % 3, iz = c % 3;
+        const float sx = ix == 1 ? 0.f : gx.s[ix], sy = iy == 1 ? 0.f : gy.s[iy], sz = iz == 1 ? 0.f : gz.s[iz];
+        const float lb = ((sx + sy) + sz) * 0.9999f;
+        cmask |= (!(lb > b0)) ? (1u << c) : 0u;
+      }
+    }
+    if (!planned) cmask = 0;
+    if (own_done || own_empty) cmask &= ~(1u << 13);
+    MH_FLATDBG(4, __builtin_popcount(cmask) > kFlatMaxCand);
+    if (__builtin_popcount(cmask) > kFlatMaxCand) {
+      planned = false;
+      cmask = 0;
+    }
+  }
+  n_cands = flat_plan_scan(sh, m, lane, cmask, kbase, px, py, pz, b0,
+                           own_done ? res0 : (((unsigned long long)__float_as_uint(b0) << 32) | 0xFFFFFFFFull));
+  MH_FLATDBG_ADD(7, n_cands);
+  FlatHit h;
+  h.pt = (f32x4)(0.f);
+  h.d2 = __builtin_inff();
+  h.found = false;
+  bool slow = in && !planned;
+  float b0s = b0;
+  {
+    unsigned long long res = own_done ? res0 : 0xFFFFFFFFFFFFFFFFull;
+    bool spilled = false;
+    if (n_cands) {
+      res = sh.RES[lane];
+      spilled = sh.SLOWF[lane] != 0;
+    }
+    const uint32_t idx = (uint32_t)res;
+    bool again = false;
+    if (planned && !spilled && idx != 0xFFFFFFFFu) {
+      h.pt = pts4[idx];
+      h.d2 = __uint_as_float((uint32_t)(res >> 32));
+      h.found = true;
+    } else if (planned && !(own_empty && !spilled)) {  // (own_empty: the whole block was compared -- there is no record in it)
+      slow = true;
+      again = true;
+      if (!spilled) b0s = __builtin_inff();
+    }
+    MH_FLATDBG(5, again && spilled);
+    MH_FLATDBG(6, again && !spilled);
+  }
+  const unsigned long long sm = __ballot(slow);
+  if (sm == 0ull) return h;  // wave-uniform
+  const uint32_t ns = (uint32_t)__builtin_popcountll(sm);
+  MH_FLATDBG_ADD(9, (ns + 15u) / 16u);
+  wave_sync_lds_nn();
+  if (slow) {
+    sh.SL[lanes_below(sm)] = (unsigned char)lane;
+    sh.P[lane] = (f32x4){px, py, pz, b0s};
+  }
+  wave_sync_lds_nn();
+  const uint32_t grp = lane >> 2, sub = lane & 3u;
+  for (uint32_t g = 0; g < ns; g += 16u) {
+    const uint32_t k = g + grp;
+    if (k < ns) {  // whole quads
+      const uint32_t p = sh.SL[k];
+      const f32x4 P = sh.P[p];
+      const NNResult r = nn_search_quad(m, sub, P.x, P.y, P.z, P.w);
+      if (sub == 0u) {  // handed back to the point's lane: the record in P, (d2 | found) in RES
+        sh.P[p] = r.pt;
+        sh.RES[p] = ((unsigned long long)__float_as_uint(r.d2) << 32) | (r.found ? 1ull : 0ull);
+      }
+    }
+  }
+  wave_sync_lds_nn();
+  if (slow) {
+    const unsigned long long rr = sh.RES[lane];
+    h.pt = sh.P[lane];
+    h.d2 = __uint_as_float((uint32_t)(rr >> 32));
+    h.found = (rr & 1ull) != 0ull;
+  }
+  wave_sync_lds_nn();  // (the next search rewrites P and RES)
+  return h;
 }
 
 }  // namespace mh

@@ -460,7 +460,9 @@ class AlignBatcher {
     size_t aligns = 0;          // alignments requested so far
     bool announced = false;     // ... and the latest set it announced a filter request for
     size_t announced_set = 0;
+    bool free_running = false;  // its latest alignment was issued on its own (a one-launch loop): its filter requests run at once, alone
   };
+  static constexpr size_t kNoFilterSet = (size_t)-1;  // announceFilter's answer for a free-running participant
   void run_filter_batch(std::vector<FilterRequest*>& batch);  // called WITHOUT the mutex
   bool filter_set_ready_locked(size_t set) const;
   void take_filter_sets_upto(std::unique_lock<std::mutex>& lk, size_t set);
@@ -469,6 +471,7 @@ class AlignBatcher {
   std::map<size_t, size_t> pp_pending_;  // set -> announced requests that have not arrived yet
   size_t pp_set_ = 0;                    // sets below this one have been taken
   size_t n_pp_batches_ = 0, n_pp_jobs_ = 0, n_pp_timeouts_ = 0, n_wait_timeouts_ = 0;
+  std::chrono::steady_clock::time_point last_solo_{};  // when the latest alignment issued on its own arrived
   void run_batch(std::vector<Request*>& batch);  // called WITHOUT the mutex
   void take_waiting_locked(std::vector<Request*>& batch);  // the ONLY way out of waiting_: clears every taken request's `lead`
   bool batch_due_locked() const;

@@ -696,7 +696,15 @@ mh_status AlignBatcher::align(const void* owner, const mh_map* map, const mh_sca
   }
   std::unique_lock<std::mutex> lk(mtx_);
   rq.arrived = std::chrono::steady_clock::now();
-  owners_[owner ? owner : (const void*)scan].aligns++;  // this participant is past the filter set of its previous alignment count
+  {
+    OwnerState& os = owners_[owner ? owner : (const void*)scan];
+    os.aligns++;  // this participant is past the filter set of its previous alignment count
+    // A participant whose alignments run on their own is not in step with anybody: its prefetch worker's filter chain runs at
+    // once instead of waiting for a set that only lock-step rounds complete (16 free-running sequences: 1.6 ms of every scan
+    // were spent in `prefetch_wait`, 208 sets forced by the 2 ms net).
+    os.free_running = solo != 0;
+    if (solo) last_solo_ = rq.arrived;
+  }
   if (!pp_waiting_.empty()) cv_.notify_all();           // (a waiting filter worker may find its set complete now)
   if (solo) {
     in_flight_ += 1;
@@ -722,11 +730,15 @@ mh_status AlignBatcher::align(const void* owner, const mh_map* map, const mh_sca
   } else {
     // Bounded: with three or more participants whose other alignments all run solo and never overlap, nobody's arrival makes
     // this request's batch due -- after the limit it leads whatever waits (a smaller batch: same results).
-    static const auto limit = std::chrono::microseconds([] {
+    static const auto limit_lockstep = std::chrono::microseconds([] {
       const char* e = getenv("MOLA_HIP_BATCH_WAIT_US");
       return e ? std::max(100, atoi(e)) : 3000;
     }());
     while (!rq.done) {
+      // (while others' alignments run on their own -- one seen within the last few milliseconds -- nobody is coming to complete
+      //  a round: this request leads what waits after a fraction of an alignment's duration)
+      const bool free_run = (rq.arrived - last_solo_) < std::chrono::milliseconds(5);
+      const auto limit = free_run ? std::chrono::microseconds(100) : limit_lockstep;
       const bool woke = cv_.wait_for(lk, limit, [&] { return rq.done || rq.lead; });
       if (rq.done) break;
       // `lead` set (or the limit reached) AND still among those waiting: whoever takes a batch clears the flags of its requests,
@@ -782,7 +794,8 @@ bool AlignBatcher::filter_set_ready_locked(size_t set) const {
   for (const auto& kv : pp_pending_)
     if (kv.first <= set && kv.second > 0) return false;
   size_t past = 0;
-  for (const auto& kv : owners_) past += (kv.second.aligns > set || (kv.second.announced && kv.second.announced_set >= set)) ? 1 : 0;
+  for (const auto& kv : owners_)
+    past += (kv.second.free_running || kv.second.aligns > set || (kv.second.announced && kv.second.announced_set >= set)) ? 1 : 0;
   return past >= active_;
 }
 
@@ -801,6 +814,7 @@ void AlignBatcher::take_filter_sets_upto(std::unique_lock<std::mutex>& lk, size_
 size_t AlignBatcher::announceFilter(const void* owner) {
   std::lock_guard<std::mutex> lk(mtx_);
   OwnerState& o = owners_[owner];
+  if (o.free_running) return kNoFilterSet;  // (runs alone, at once: nobody waits for it, it waits for nobody)
   o.announced = true;
   o.announced_set = o.aligns;
   pp_pending_[o.aligns]++;
@@ -809,6 +823,7 @@ size_t AlignBatcher::announceFilter(const void* owner) {
 
 void AlignBatcher::cancelAnnouncedFilter(const void* owner, size_t set) {
   (void)owner;
+  if (set == kNoFilterSet) return;
   std::lock_guard<std::mutex> lk(mtx_);
   auto it = pp_pending_.find(set);
   if (it != pp_pending_.end() && it->second > 0 && --it->second == 0) pp_pending_.erase(it);
@@ -818,6 +833,14 @@ void AlignBatcher::cancelAnnouncedFilter(const void* owner, size_t set) {
 mh_status AlignBatcher::preprocess(const void* owner, size_t set, const mh_scan* raw, const mh_preprocess_params* params,
                                    mh_scan* out_map, mh_scan* out_icp, std::string* error) {
   (void)owner;
+  if (set == kNoFilterSet) {  // a free-running participant's request: its own launches, now
+    const mh_status st = mh_scan_preprocess(raw, params, out_map, out_icp);
+    if (st != MH_OK && error) *error = mh_last_error_string();
+    std::lock_guard<std::mutex> lk(mtx_);
+    n_pp_batches_++;
+    n_pp_jobs_++;
+    return st;
+  }
   FilterRequest rq;
   rq.raw = raw; rq.params = params; rq.out_map = out_map; rq.out_icp = out_icp; rq.set = set;
   std::unique_lock<std::mutex> lk(mtx_);

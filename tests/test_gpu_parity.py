@@ -950,11 +950,18 @@ def test_small_layer_loop_controls_give_the_same_bits(ctx, ndt, monkeypatch):
 
 
 @pytest.mark.parametrize("ndt", [False, True])
-def test_one_launch_loop_of_small_layers(ctx, ndt, monkeypatch):
+@pytest.mark.parametrize("search", ["rows", "plan_scan"])
+def test_one_launch_loop_of_small_layers(ctx, ndt, search, monkeypatch):
     """Single alignments of layers up to 2048 points run their whole loop in ONE launch (k_icp16: the workgroups exchange the
     partial sums among themselves).  Same bits as the launch-by-launch chain (MH_NO_LOOP16=1); the loop is what runs by default
     and none is abandoned; when the device's admission limit is taken (MH_LOOP16_CUS) or a loop does not run to its end
-    (MH_LOOP16_TEST_ABANDON) the chain gives the same result."""
+    (MH_LOOP16_TEST_ABANDON) the chain gives the same result.  search = plan_scan (MH_LOOPW=all): the loop with the plan / scan
+    search of mh_nn_flat.h, 128 points per workgroup, layers up to 4096 points (k_icpw; the default for lock-step batches)."""
+    wave = search == "plan_scan"
+    if wave and ndt:
+        pytest.skip("NDT maps keep k_icp16<true>: the plane matcher rides in the row search")
+    if wave:
+        monkeypatch.setenv("MH_LOOPW", "all")
     pts = _ndt_cloud(61)
     gm = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts) if ndt else capi.Map(ctx, 1.0, 20).build(pts)
     rng = np.random.default_rng(62)
@@ -963,7 +970,7 @@ def test_one_launch_loop_of_small_layers(ctx, ndt, monkeypatch):
     if ndt:
         kw["pt2pl_threshold"] = 0.5
     p = capi.ICPParams(**kw)
-    for n in (1, 31, 32, 33, 700, 1400, 2048):
+    for n in (1, 31, 32, 33, 700, 1400, 2048) + ((2049, 3000, 4096) if wave else ()):
         sub = pts[rng.integers(0, len(pts), n)] + rng.normal(0, 0.01, (n, 3)).astype(np.float32)
         guess = synth.pose_from_ypr([0.11, -0.07, 0.05, 0.006, -0.004, 0.01])
         scan = capi.Scan(ctx, sub)
@@ -983,7 +990,13 @@ def test_one_launch_loop_of_small_layers(ctx, ndt, monkeypatch):
         again = capi.icp_align(gm, scan, guess, p, want_trace=True)
         assert capi.loop_stats() == (s1 + 1, a1 + 1)
         monkeypatch.delenv("MH_LOOP16_TEST_ABANDON")
-        for r in loop + [refused, again]:
+        monkeypatch.setenv("MH_NO_LOOPW", "1")  # k_icp16 (a DPP row per point) where k_icpw (plan / scan search) is the default
+        rows = capi.icp_align(gm, scan, guess, p, want_trace=True)
+        assert capi.loop_stats() == (s1 + (2 if n <= 2048 else 1), a1 + 1)  # (k_icp16 takes layers up to 2048 points)
+        if wave:
+            monkeypatch.setenv("MH_LOOPW", "all")
+        monkeypatch.delenv("MH_NO_LOOPW")
+        for r in loop + [refused, again, rows]:
             assert r["n_iterations"] == chain["n_iterations"] and r["termination_reason"] == chain["termination_reason"]
             np.testing.assert_array_equal(r["T"], chain["T"])
             np.testing.assert_array_equal(r["cov"], chain["cov"])
@@ -993,10 +1006,16 @@ def test_one_launch_loop_of_small_layers(ctx, ndt, monkeypatch):
 
 
 @pytest.mark.parametrize("ndt", [False, True])
-def test_one_launch_loops_of_a_lockstep_batch(ctx, ndt, monkeypatch):
-    """A lock-step batch of small layers runs the jobs' whole loops side by side in ONE launch (k_icp16_b: a job's workgroups
-    exchange among themselves, a workgroup takes several groups when the jobs have to share the CUs).  Same bits as single
-    alignments, as the launch-by-launch batch (MH_NO_LOOP16_BATCH=1) and as the second attempt after an abandoned loop."""
+@pytest.mark.parametrize("search", ["default", "rows"])
+def test_one_launch_loops_of_a_lockstep_batch(ctx, ndt, search, monkeypatch):
+    """A lock-step batch of small layers runs the jobs' whole loops side by side in ONE launch -- point layers: k_icpw_b, the plan /
+    scan search, every job its own workgroups of 128 points; NDT maps and search = rows (MH_LOOPW=none): k_icp16_b, a job's
+    workgroups take several groups of 32 points when the jobs have to share the CUs.  Same bits as single alignments, as the
+    launch-by-launch batch (MH_NO_LOOP16_BATCH=1) and as the second attempt after an abandoned loop."""
+    if search == "rows":
+        if ndt:
+            pytest.skip("NDT maps run k_icp16_b either way")
+        monkeypatch.setenv("MH_LOOPW", "none")
     pts = _ndt_cloud(81)
     gm = capi.Map(ctx, 1.0, 0, 0, 0.1, 0.05, 4).build(pts) if ndt else capi.Map(ctx, 1.0, 20).build(pts)
     rng = np.random.default_rng(82)
@@ -1045,9 +1064,10 @@ def test_solo_hint_agrees_with_what_a_single_alignment_does(ctx, monkeypatch):
     rng = np.random.default_rng(72)
     thr, kp = synth.threshold_schedule(0.5, 12)
     guess = synth.pose_from_ypr([0.05, -0.03, 0.02, 0.003, -0.002, 0.005])
-    cases = [(n, dict(), dict()) for n in (1, 500, 2048, 2049, 6000)]
+    cases = [(n, dict(), dict()) for n in (1, 500, 2048, 2049, 4096, 4097, 6000)]
     cases += [(500, dict(poll_every=3), dict()), (500, dict(profile=1), dict()), (500, dict(), {"MH_NO_LOOP16": "1"}),
               (500, dict(), {"MH_NO_STREAM": "1"}), (500, dict(), {"MH_MATCH": "q"}), (40000, dict(), {"MH_MATCH": "s"})]
+    cases += [(n, dict(), {"MH_LOOPW": "all"}) for n in (500, 2049, 4096, 4097)]  # k_icpw also for single alignments
     for n, extra, env in cases:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1059,12 +1079,14 @@ def test_solo_hint_agrees_with_what_a_single_alignment_does(ctx, monkeypatch):
         capi.icp_align(gm, scan, guess, p, want_trace=False)
         s1, a1 = capi.loop_stats()
         assert (s1 - s0 == 1) == hint and a1 == a0, (n, extra, env, hint, s1 - s0)
-        assert hint == (n <= 2048 and not extra and not env)
-        if hint:  # ... with company: as long as everybody's workgroups fit the device together
+        wave = env.get("MH_LOOPW") == "all"
+        assert hint == (n <= (4096 if wave else 2048) and not extra and (not env or wave))
+        if hint:  # ... with company: as long as everybody's workgroups fit the device together -- and never more than four callers
             groups = (n + 31) // 32
-            def fits(callers):  # (MI355X: 256 CUs, 70 % of them for loops)
-                return callers <= 1 or callers * groups * 10 <= 256 * 7
-            for callers in (1, 2, 4, 5, 8, 9, 16, 17, 64, 179, 180, 1000):
+            units = (groups + 3) // 4 if wave else 2 * groups  # half CUs: a k_icpw workgroup of 128 points one, a k_icp16 workgroup of 32 points two
+            def fits(callers):  # (MI355X: 256 CUs = 512 half CUs, 70 % of them for loops)
+                return callers <= 1 or (callers <= 4 and callers * units * 10 <= 512 * 7)
+            for callers in (1, 2, 3, 4, 5, 8, 9, 16, 17, 64, 1000):
                 assert capi.icp_align_prefers_solo(scan, p, guess, concurrent_callers=callers) == fits(callers), (n, callers)
         for k in env:
             monkeypatch.delenv(k)

@@ -27,5 +27,13 @@ for k, ((xyz, t), st) in enumerate(zip(drive["scans"], drive["stamps"])):
     if k >= 5 and 0 < v[12] < 1000:
         tot += v
 steps = max(1.0, tot[12])
+if hasattr(L, "mh_debug_flat_counters") or True:
+    try:
+        fc = np.zeros(16, np.uint64)
+        L.mh_debug_flat_counters(fc.ctypes.data_as(C.c_void_p), 0)
+        fn = ["searches (waves)", "points", "unbounded at entry", "slow: no bound", "slow: > max candidates", "slow: chunk space", "slow: bound not attained", "candidates", "(unused)", "D rounds"]
+        print("flat search counters: " + ", ".join("%s %d" % (fn[k], int(fc[k])) for k in range(10)))
+    except Exception as e:
+        print("no flat counters:", e)
 print("scans %d..%d: %d steps | per step (us): %s | sum %.2f" % (5, n_scans - 1, int(steps), ", ".join("%s %.2f" % (names[k], tot[k] / 100.0 / steps) for k in (0, 1, 2, 3, 6, 7, 8, 4, 5)),
       tot[:9].sum() / 100.0 / steps))
