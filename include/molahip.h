@@ -504,6 +504,11 @@ MH_API mh_status mh_icp_align_prefers_solo(const mh_scan* scan, const mh_icp_par
  * each other and that were run again launch by launch (same result bit for bit; expected to stay 0).  Either may be NULL. */
 MH_API void mh_debug_loop_stats(uint64_t* loops_started, uint64_t* loops_abandoned);
 
+/* 1 when the library was built with -DMH_DEV_VARIANTS (tools/build_variants.sh): the matcher families that were measured against
+ * the product kernels and lost -- MH_MATCH=t (tile matcher, map records staged in LDS), w (wave matcher), o (sorted scan) -- are
+ * then selectable for A/B runs and parity tests.  The shipped library returns 0 and rejects those three values of MH_MATCH. */
+MH_API int32_t mh_debug_dev_variants(void);
+
 /* Results::finalPairings.paired_pt2pl [U] of the LAST mh_icp_align run on `scan`'s context (arrays in `mem`, scan-size
  * entries, any may be NULL). */
 MH_API mh_status mh_icp_get_pt2pl_pairs(const mh_scan* scan, const mh_pairs_pl_out* out, int32_t mem, uint64_t* n_pairs);

@@ -16,7 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmolahip.so")
-if os.environ.get("MOLAHIP_LIB_PATH"):  # development: an A/B build of the same sources (tools/build_variants.sh, tools/build_floor.sh)
+if os.environ.get("MOLAHIP_LIB_PATH"):  # development: an A/B build of the same sources (tools/build_variants.sh)
     LIB_PATH = os.environ["MOLAHIP_LIB_PATH"]
 
 MH_OK = 0
@@ -140,6 +140,7 @@ _SIGNATURES = {
     "mh_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
     "mh_debug_fail_allocations": (C.c_int32, [C.c_int32, C.c_int32]),
     "mh_debug_loop_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "mh_debug_dev_variants": (C.c_int32, []),
     "mh_icp_align_prefers_solo": (C.c_int32, [C.c_void_p, C.POINTER(ICPParamsC), C.c_uint32, C.POINTER(C.c_int32)]),
     "mh_ctx_create": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mh_ctx_destroy": (C.c_int32, [C.c_void_p]),
@@ -236,6 +237,11 @@ def loop_stats():
     a, b = C.c_uint64(0), C.c_uint64(0)
     lib().mh_debug_loop_stats(C.byref(a), C.byref(b))
     return int(a.value), int(b.value)
+
+
+def dev_variants() -> bool:
+    """True when the loaded library is the development build (tools/build_variants.sh): MH_MATCH=t|w|o are selectable."""
+    return bool(lib().mh_debug_dev_variants())
 
 
 def device_count() -> int:

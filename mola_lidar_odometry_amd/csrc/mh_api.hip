@@ -314,4 +314,14 @@ mh_status mh_scan_size(const mh_scan* scan, uint64_t* n) {
   return MH_OK;
 }
 
+#ifndef MH_DEV_VARIANTS
+// The search order this call queues is what the tile / wave / sorted matchers read (mh_tile.hip: development library only); the
+// shipped matchers search the scan as it is, so there is nothing to prepare.
+mh_status mh_scan_prepare(const mh_scan* scan, float voxel_size) {
+  MH_REQUIRE(scan, "null scan");
+  MH_REQUIRE(voxel_size > 0.f, "voxel_size must be > 0");
+  return MH_OK;
+}
+#endif
+
 }  // extern "C"

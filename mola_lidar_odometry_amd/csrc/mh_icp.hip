@@ -481,10 +481,6 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
 #ifdef MH_DEBUG_WAVETRACE
                                                    , unsigned long long* __restrict__ wtrace
 #endif
-#ifdef MH_DEBUG_FLOOR
-                                                   , uint32_t* __restrict__ floor_cap = nullptr, uint32_t* __restrict__ floor_more = nullptr,
-                                                   uint32_t floor_iter = 0xFFFFFFFFu
-#endif
 ) {
 #ifdef MH_DEBUG_WAVETRACE
   struct WT { unsigned long long* p; unsigned long long t0; uint32_t w;
@@ -497,17 +493,7 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
   const uint32_t i = gl >> 2, sub = gl & 3u;
   const uint32_t ic = i < n ? i : n - 1;
   const uint32_t o = perm ? G(perm)[ic] : ic;  // (clamped: lanes past the end of a short job of a batch read, and never write)
-#if defined(MH_CARRY_WINNER) || !defined(MH_NARROW_IO) || !defined(MH_NARROW_XYZ)
-  // (the three coordinate loads stay as they are: one load of "coordinate `sub`" through a lane-dependent base pointer
-  // costs the batch kernel 32 bytes of scratch per lane -- MH_NARROW_XYZ keeps the variant for A/B runs)
   const float x = G(lx)[ic], y = G(ly)[ic], z = G(lz)[ic];
-#else
-  // lane s reads coordinate s of the point (lane 3: z again); quad_perm moves hand them round
-  const float* cbase = sub == 0u ? lx : (sub == 1u ? ly : lz);
-  const float cmine = G(cbase)[ic];
-  const float x = __uint_as_float(quad_bcast<0>(__float_as_uint(cmine))), y = __uint_as_float(quad_bcast<1>(__float_as_uint(cmine))),
-              z = __uint_as_float(quad_bcast<2>(__float_as_uint(cmine)));
-#endif
   // the state block through the scalar path (uniform address, not written during this kernel): the pose in SGPRs
   typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
   const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
@@ -517,17 +503,7 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
   // without one (the buffer may hold another scan's pairings).
   const bool have_prev = cst->iter > 0 && !map.no_prev_bound;
   f32x4 prev = (f32x4){0.f, 0.f, 0.f, __builtin_inff()};
-#if defined(MH_CARRY_WINNER) || !defined(MH_NARROW_IO)
   if (have_prev) prev = G(reinterpret_cast<const f32x4*>(pair_q))[o];  // grid-uniform branch
-#else
-  // (-DMH_NARROW_IO, measured SLOWER and off: a dword per lane instead of the same 16 bytes in all four lanes of a quad, see
-  // nn_search_quad<NARROW>: lane s reads word s of the previous pairing; quad_perm moves hand the four words round)
-  if (have_prev) {  // grid-uniform branch
-    const uint32_t pw = __float_as_uint(G(reinterpret_cast<const float*>(pair_q))[4ull * o + sub]);
-    prev = (f32x4){__uint_as_float(quad_bcast<0>(pw)), __uint_as_float(quad_bcast<1>(pw)), __uint_as_float(quad_bcast<2>(pw)),
-                   __uint_as_float(quad_bcast<3>(pw))};
-  }
-#endif
   double T[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) T[k] = cst->T[k];
@@ -541,89 +517,13 @@ __device__ __forceinline__ void k_match4_body(const IcpDeviceState* __restrict__
     const float dx = prev.x - px, dy = prev.y - py, dz = prev.z - pz;
     bound0 = (dx * dx + dy * dy) + dz * dz;  // the candidate arithmetic of nn_scan_round_quad
   }
-#if defined(MH_CARRY_WINNER) || !defined(MH_NARROW_IO)
-#ifdef MH_DEBUG_FLOOR
-  const NNResult r = nn_search_quad(map, sub, px, py, pz, bound0, (floor_cap && cst->iter == floor_iter) ? floor_cap + 2ull * i : nullptr,
-                                    floor_more ? floor_more + 4ull * i : nullptr);
-#else
   const NNResult r = nn_search_quad(map, sub, px, py, pz, bound0);
-#endif
-#ifdef MH_CARRY_WINNER
-  if (r.writer) {
-#else
   if (sub == 0) {
-#endif
     const float n2 = (px * px + py * py) + pz * pz;
     const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
     G(reinterpret_cast<f32x4*>(pair_q))[o] = (f32x4){r.pt.x, r.pt.y, r.pt.z, r.d2};
     G(pair_gidx)[o] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
   }
-#else
-#ifdef MH_DEBUG_FLOOR
-  const NNResult r = nn_search_quad<true>(map, sub, px, py, pz, bound0, (floor_cap && cst->iter == floor_iter) ? floor_cap + 2ull * i : nullptr,
-                                          floor_more ? floor_more + 4ull * i : nullptr);
-#else
-  const NNResult r = nn_search_quad<true>(map, sub, px, py, pz, bound0);
-#endif
-  // the pairing {x, y, z, d2} | source index, a dword per lane: lanes 0..2 hold the winner's coordinates, lane 3 its source
-  // index (r.pt.x, component `sub` of the record); nothing found: {0, 0, 0, inf} | none -- what the 16-byte store wrote
-  const float n2 = (px * px + py * py) + pz * pz;
-  const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
-  const float comp = r.found ? r.pt.x : 0.f;
-  G(reinterpret_cast<float*>(pair_q))[4ull * o + sub] = sub == 3u ? r.d2 : comp;
-  if (sub == 3u) G(pair_gidx)[o] = ok ? __float_as_uint(comp) : kNoMatch;
-#endif
-}
-
-// ================================================================================================
-// k_match_tile: correspondence search of a large layer with the map records staged in LDS, one workgroup per tile of the
-// spatially sorted scan (nn_search_tile, mh_tile.hip).  Pairings are written at the points' ORIGINAL indices, so
-// everything downstream (k_accum, covariance, compaction of the final pairings) is what it is for the other matchers.
-// ================================================================================================
-__device__ __forceinline__ void k_match_tile_body(const IcpDeviceState* __restrict__ st, const float* __restrict__ sx,
-                                                  const float* __restrict__ sy, const float* __restrict__ sz,
-                                                  const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tile_start,
-                                                  uint32_t n_tiles, MapView map, float4* __restrict__ pair_q,
-                                                  uint32_t* __restrict__ pair_gidx
-#ifdef MH_DEBUG_WAVETRACE
-                                                  , unsigned long long* __restrict__ wtrace
-#endif
-) {
-  __shared__ TileShared sh;
-  const uint32_t t = blockIdx.x;
-  if (t >= n_tiles) return;
-#ifdef MH_DEBUG_WAVETRACE
-  unsigned long long* dbg = wtrace ? wtrace + 8ull * t : nullptr;  // [start, bbox, probe, copy, search, end, nvox, records]
-  if (threadIdx.x == 0 && dbg) dbg[0] = wall_clock64();
-#endif
-  const uint32_t s0 = tile_start[t], s1 = tile_start[t + 1];
-  const uint32_t i = s0 + threadIdx.x;
-  const bool active = i < s1;
-  const uint32_t ic = active ? i : s0;
-  const float x = sx[ic], y = sy[ic], z = sz[ic];
-  const uint32_t orig = perm[ic];
-  const uint32_t done = st->done;
-  double T[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) T[k] = st->T[k];
-  const float thr2 = st->cur_thr2, ang2 = st->cur_ang2;
-  if (done) return;  // grid-uniform
-  float px, py, pz;
-  transform_point(T, x, y, z, px, py, pz);
-  const NNResult r = nn_search_tile(map, sh, active, px, py, pz
-#ifdef MH_DEBUG_WAVETRACE
-                                    , dbg
-#endif
-  );
-  if (active) {
-    const float n2 = (px * px + py * py) + pz * pz;
-    const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
-    pair_q[orig] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
-    pair_gidx[orig] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
-  }
-#ifdef MH_DEBUG_WAVETRACE
-  if (threadIdx.x == 0 && dbg) dbg[5] = wall_clock64();
-#endif
 }
 
 // k_match16 (below, after the point-to-plane row search it can carry along): the same step with a DPP row (16 lanes)
@@ -2393,11 +2293,7 @@ constexpr uint32_t kFlatThreads = MH_FLAT_THREADS;  // ONE wave per workgroup (n
 constexpr uint32_t kFlatPointsPerBlock = kFlatThreads; // a lane per point in phase A
 __device__ __forceinline__ uint32_t nblk_flat_dev(uint32_t n) { return (n + kFlatPointsPerBlock - 1u) / kFlatPointsPerBlock; }
 // (the grid width is a multiple of 8 = the XCDs a launch is dealt over, whatever the layer's size)
-#ifdef MH_FLAT_XCD
-constexpr uint32_t kFlatGridUnit = 8u * (uint32_t)(MH_FLAT_XCD);
-#else
 constexpr uint32_t kFlatGridUnit = 8u;
-#endif
 inline uint32_t nblk_flat(size_t n) { return (uint32_t)(((n + kFlatPointsPerBlock - 1) / kFlatPointsPerBlock + kFlatGridUnit - 1) / kFlatGridUnit * kFlatGridUnit); }
 __device__ __forceinline__ void k_match_flat_body(const IcpDeviceState* __restrict__ st, const float* __restrict__ lx,
                                                   const float* __restrict__ ly, const float* __restrict__ lz, uint32_t n,
@@ -2407,17 +2303,7 @@ __device__ __forceinline__ void k_match_flat_body(const IcpDeviceState* __restri
   typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
   const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
   if (cst->done) return;  // grid-uniform
-#ifdef MH_FLAT_XCD
-  // (experiment) workgroup b runs on XCD b % 8 (round-robin dispatch, grid width a multiple of 8): hand each XCD a contiguous
-  // part of the layer, so that its L2 sees a part of the map instead of all of it (MH_FLAT_XCD=118: an eighth of C2 each)
-  // in runs of MH_FLAT_XCD consecutive workgroups' worth of points: run c of the layer goes to XCD c % 8
-  const uint32_t xj = block_x / 8u;
-  const uint32_t bx = ((xj / (uint32_t)(MH_FLAT_XCD)) * 8u + block_x % 8u) * (uint32_t)(MH_FLAT_XCD) + xj % (uint32_t)(MH_FLAT_XCD);
-#elif defined(MH_FLAT_REVERSE)
-  const uint32_t bx = gridDim.x - 1u - block_x;  // (A/B: the layer's last points first)
-#else
   const uint32_t bx = block_x;
-#endif
   const uint32_t i0 = bx * kFlatPointsPerBlock + (threadIdx.x & ~63u);
   if (i0 >= n) return;    // whole waves
   const bool have_prev = cst->iter > 0 && !map.no_prev_bound;
@@ -2432,215 +2318,9 @@ __global__ __launch_bounds__(kFlatThreads, MH_FLAT_WAVES) void k_match_flat(cons
                                                              uint32_t* __restrict__ pair_gidx, const uint32_t* __restrict__ perm) {
   k_match_flat_body(st, lx, ly, lz, n, map, pair_q, pair_gidx, perm, blockIdx.x);
 }
-#ifdef MH_DEBUG_FLOOR
-// ================================================================================================
-// tools/match_floor.py (debug build, -DMH_DEBUG_FLOOR): the latency floor of the quad matcher's access pattern.
-// k_match4_b records, for ONE chosen ICP iteration, what every point's search touched (nn_search_quad: per probe batch the
-// voxel code of each lane, the winner's record); k_match_floor_b then replays exactly that -- same grid, same registers
-// budget, the same DEPENDENT chain per quad: point + previous pairing -> slot probes of a batch -> W records per lane and
-// round trip of the merged ranges -> next batch -> the winner's record -> pairing written -- with the arithmetic stripped to
-// one compare per record: no fp64 transform, no voxel bounds, no distances, no 64-bit keys.  Its duration is what the memory
-// system + address generation cost for this search schedule; the real kernel's distance from it is arithmetic and issue.
-// ================================================================================================
-__device__ uint32_t* g_floor_script = nullptr;  // [job][point][2]
-__device__ uint32_t* g_floor_more = nullptr;    // [job][point][4]: batches beyond the first
-__device__ float4* g_floor_out_q = nullptr;     // [job][point]: where the replay writes its "pairings"
-__device__ uint32_t* g_floor_out_g = nullptr;
-__device__ uint32_t g_floor_stride = 0, g_floor_iter = 0xFFFFFFFFu;
-struct FloorHost {
-  uint32_t *script = nullptr, *more = nullptr, *out_g = nullptr;
-  float4* out_q = nullptr;
-  uint32_t stride = 0, jobs = 0, run_reps = 0, flags = 0;
-  double floor_ms = 0, real_ms_at_iter = 0, real_ms_avg = 0;
-  uint32_t real_launches = 0;
-} g_floor_host;
-
-// what-if switches of the replay (tools/match_floor.py --what-if): which load costs what?
-enum { FLOOR_NO_WINNER_FETCH = 1, FLOOR_NO_PREV = 2, FLOOR_NO_TRANSFORM = 4, FLOOR_NO_OUTPUT = 8, FLOOR_RECORDS_12B = 16, FLOOR_HALF_RECORDS = 32,
-       FLOOR_NARROW_IO = 64 /* the -DMH_NARROW_IO schedule: previous pairing / winner / pairing a dword per lane instead of 16 bytes */,
-       FLOOR_NO_QIDX = 128 /* whole voxels: the schedule before the sub-voxel index */ };
-
-__global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_floor_b(const BatchJob* __restrict__ jobs, uint32_t flags) {
-  const BatchJob& j = jobs[blockIdx.y];
-  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
-  const uint32_t i = gl >> 2, sub = gl & 3u;
-  const uint32_t n = j.n;
-  const uint32_t ic = i < n ? i : n - 1;
-  const float x = G(j.lx)[ic], y = G(j.ly)[ic], z = G(j.lz)[ic];
-  typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
-  const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(j.st);
-  f32x4 prev = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (!(flags & FLOOR_NO_PREV)) {
-    if (!(flags & FLOOR_NARROW_IO)) {
-      prev = G(reinterpret_cast<const f32x4*>(j.pair_q))[ic];
-    } else {  // a dword per lane, handed round the quad
-      const uint32_t pw = __float_as_uint(G(reinterpret_cast<const float*>(j.pair_q))[4ull * ic + sub]);
-      prev = (f32x4){__uint_as_float(quad_bcast<0>(pw)), __uint_as_float(quad_bcast<1>(pw)), __uint_as_float(quad_bcast<2>(pw)),
-                     __uint_as_float(quad_bcast<3>(pw))};
-    }
-  }
-  const size_t pi = (size_t)blockIdx.y * g_floor_stride + ic;
-  const uint32_t w_idx = G(g_floor_script)[2 * pi], head = G(g_floor_script)[2 * pi + 1];
-  double T[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) T[k] = cst->T[k];
-  if (i >= n) return;
-  // the probe addresses follow from the transformed point, as in the real kernel (address generation, not search arithmetic)
-  float px, py, pz;
-  if (flags & FLOOR_NO_TRANSFORM) px = x, py = y, pz = z;
-  else transform_point(T, x, y, z, px, py, pz);
-  const MapView& m = j.map;
-  const uint32_t dep0 = (uint32_t)(__float_as_uint(prev.w) == 0xFFFFFFFEu);
-  const unsigned long long kbase = pack_key(voxel_of(px, m.inv_vs, m.trunc) - 1, voxel_of(py, m.inv_vs, m.trunc) - 1, voxel_of(pz, m.inv_vs, m.trunc) - 1) + dep0;
-  const uint32_t nb_raw = head >> 24;
-  const uint32_t nb = nb_raw >= 15u ? 0u : (nb_raw < 5u ? nb_raw : 5u);
-  uint32_t acc = 0xFFFFFFF0u;
-  const gslots_ptr slots4 = (gslots_ptr)m.slots;
-  const gpts_ptr pts4 = (gpts_ptr)m.pts;
-  // the sub-voxel index as the product kernel uses it: ranges narrowed under the bound the previous pairing gives (address
-  // generation: eight operations).  Later batches keep that bound where the real search has a tighter one by then, so the
-  // replay reads at least what the search read.
-  const bool useq = m.pts_q != nullptr && !(flags & FLOOR_NO_QIDX);
-  const gpts_ptr spts = useq ? (gpts_ptr)m.pts_q : pts4;
-  float bound0 = __builtin_inff();
-  if (!(flags & FLOOR_NO_PREV)) {
-    const float dx = prev.x - px, dy = prev.y - py, dz = prev.z - pz;
-    bound0 = (dx * dx + dy * dy) + dz * dz;
-  }
-  for (uint32_t b = 0; b < nb; b++) {
-    uint32_t c_mine;
-    if (b == 0) {
-      c_mine = (head >> (6u * sub)) & 63u;
-    } else {
-      const uint32_t codes = G(g_floor_more)[4 * pi + (b - 1u)];
-      c_mine = (codes >> (8u * sub)) & 63u;
-    }
-    const bool want = c_mine != 63u;
-    const unsigned long long key = nn_key_of(kbase, want ? (int)c_mine : 0) + (acc == 0xFFFFFFFEu);  // (the next probe waits for the scan)
-    const u32x4 sl = slots4[hash_key(key) & m.mask];
-    uint32_t f_mine, n_mine, qv;
-    nn_resolve(m, slots4, key, sl, want, f_mine, n_mine, &qv);
-    if (useq && want) quad_narrow(m, qv, (int)c_mine, px, py, bound0, f_mine, n_mine);
-    if (flags & FLOOR_HALF_RECORDS) n_mine = (n_mine + 1u) >> 1;
-    const uint32_t first[4] = {quad_bcast<0>(f_mine), quad_bcast<1>(f_mine), quad_bcast<2>(f_mine), quad_bcast<3>(f_mine)};
-    const uint32_t cnt[4] = {quad_bcast<0>(n_mine), quad_bcast<1>(n_mine), quad_bcast<2>(n_mine), quad_bcast<3>(n_mine)};
-    uint32_t pre[5], start[4];
-    pre[0] = 0;
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-      pre[v + 1] = pre[v] + cnt[v];
-      start[v] = first[v] - pre[v];
-    }
-    const uint32_t total = pre[4];
-    for (uint32_t t0 = 0; t0 < total; t0 += 4 * kQuadW) {
-      f32x4 c[kQuadW];
-      bool valid[kQuadW];
-#pragma unroll
-      for (int u = 0; u < kQuadW; u++) {
-        const uint32_t tu = t0 + 4u * (uint32_t)u + sub;
-        valid[u] = tu < total;
-        const uint32_t t = valid[u] ? tu : total - 1;
-        uint32_t off = start[0];
-#pragma unroll
-        for (int v = 1; v < 4; v++) off = t >= pre[v] ? start[v] : off;
-        if (flags & FLOOR_RECORDS_12B) {  // what a 12-byte read of the record would cost (same lines, narrower instruction)
-          typedef float f32x3 __attribute__((ext_vector_type(3)));
-          const f32x3 c3 = *reinterpret_cast<const f32x3 MH_AS_GLOBAL*>(spts + (t + off));
-          c[u] = (f32x4){c3.x, c3.y, c3.z, 0.f};
-        } else {
-          c[u] = spts[t + off];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kQuadW; u++) {  // ONE compare per record
-        const uint32_t k = valid[u] ? __float_as_uint(c[u].x) : 0xFFFFFFF0u;
-        acc = k < acc ? k : acc;
-      }
-    }
-    // the quad agrees on the best after every scan (two quad_perm steps in the real kernel as well)
-    uint32_t o = quad_u32<0xB1>(acc);
-    acc = o < acc ? o : acc;
-    o = quad_u32<0x4E>(acc);
-    acc = o < acc ? o : acc;
-  }
-  const size_t o = (size_t)blockIdx.y * g_floor_stride + i;
-  if (!(flags & FLOOR_NARROW_IO)) {
-    f32x4 rec = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!(flags & FLOOR_NO_WINNER_FETCH) && w_idx != 0xFFFFFFFFu) rec = pts4[w_idx + (acc == 0xFFFFFFFEu)];  // the winner's record: waits for the last scan
-    if (sub == 0 && !(flags & FLOOR_NO_OUTPUT)) {
-      G(reinterpret_cast<f32x4*>(g_floor_out_q))[o] = (f32x4){rec.x, rec.y, rec.z, __uint_as_float(acc ^ dep0)};
-      G(g_floor_out_g)[o] = __float_as_uint(rec.w);
-    } else if (acc == 0xFFFFFFFEu) {
-      G(g_floor_out_g)[0] = acc;  // (keeps the chain alive when the output is switched off)
-    }
-  } else {  // component `sub` of the winner per lane, the pairing written a dword per lane
-    float comp = 0.f;
-    if (!(flags & FLOOR_NO_WINNER_FETCH) && w_idx != 0xFFFFFFFFu)
-      comp = reinterpret_cast<const float MH_AS_GLOBAL*>(pts4)[4ull * (w_idx + (acc == 0xFFFFFFFEu)) + sub];
-    if (!(flags & FLOOR_NO_OUTPUT)) {
-      G(reinterpret_cast<float*>(g_floor_out_q))[4ull * o + sub] = sub == 3u ? __uint_as_float(acc ^ dep0) : comp;
-      if (sub == 3u) G(g_floor_out_g)[o] = __float_as_uint(comp);
-    } else if (acc == 0xFFFFFFFEu || __float_as_uint(comp) == 0xFFFFFFFEu) {
-      G(g_floor_out_g)[0] = acc;
-    }
-  }
-}
-
-// setup(n_jobs, max points per job): buffers; capture_iter: which ICP iteration's launch writes scripts (0xFFFFFFFF: none);
-// run_reps: how often mh_icp_align_batch replays the floor kernel after its last chunk (0: not at all)
-extern "C" __attribute__((visibility("default"))) int mh_debug_floor_setup(uint32_t n_jobs, uint32_t stride, uint32_t capture_iter,
-                                                                          uint32_t run_reps, uint32_t flags) {
-  FloorHost& f = g_floor_host;
-  f.flags = flags;
-  if (f.jobs != n_jobs || f.stride != stride) {
-    if (f.script) (void)hipFree(f.script), (void)hipFree(f.more), (void)hipFree(f.out_q), (void)hipFree(f.out_g);
-    f.script = nullptr;
-    const size_t np = (size_t)n_jobs * stride;
-    if (hipMalloc(&f.script, np * 8) != hipSuccess || hipMalloc(&f.more, np * 16) != hipSuccess || hipMalloc(&f.out_q, np * 16) != hipSuccess ||
-        hipMalloc(&f.out_g, np * 4) != hipSuccess)
-      return 1;
-    (void)hipMemset(f.script, 0xFF, np * 8);
-    (void)hipMemset(f.more, 0xFF, np * 16);
-    f.jobs = n_jobs, f.stride = stride;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_script), &f.script, sizeof(void*));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_more), &f.more, sizeof(void*));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_out_q), &f.out_q, sizeof(void*));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_out_g), &f.out_g, sizeof(void*));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_stride), &stride, sizeof(uint32_t));
-  }
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_floor_iter), &capture_iter, sizeof(uint32_t));
-  f.run_reps = run_reps;
-  return hipDeviceSynchronize() == hipSuccess ? 0 : 2;
-}
-// out[0] floor ms per launch, [1] real kernel ms at the captured iteration, [2] real kernel ms averaged over the alignment's
-// launches, [3] launches; and per point statistics of the scripts: [4] mean probe batches, [5] share of points captured
-extern "C" __attribute__((visibility("default"))) int mh_debug_floor_result(double* out, uint32_t* scripts_host, size_t n_dwords) {
-  const FloorHost& f = g_floor_host;
-  out[0] = f.floor_ms, out[1] = f.real_ms_at_iter, out[2] = f.real_ms_avg, out[3] = f.real_launches;
-  if (scripts_host && f.script) {
-    (void)hipDeviceSynchronize();
-    if (hipMemcpy(scripts_host, f.script, n_dwords * 4, hipMemcpyDeviceToHost) != hipSuccess) return 2;
-  }
-  return 0;
-}
-#endif
 __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4_b(const BatchJob* __restrict__ jobs) {
   const BatchJob& j = jobs[blockIdx.y];
   k_match4_body(j.st, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, nullptr
-#ifdef MH_DEBUG_WAVETRACE
-                , nullptr
-#endif
-#ifdef MH_DEBUG_FLOOR
-                , g_floor_script ? g_floor_script + (size_t)blockIdx.y * g_floor_stride * 2u : nullptr,
-                g_floor_more ? g_floor_more + (size_t)blockIdx.y * g_floor_stride * 4u : nullptr, g_floor_iter
-#endif
-  );
-}
-// the quad matcher over the scan in search order (mh_tile.hip): neighbouring quads need the same voxels and tend to take the
-// same number of rounds
-__global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4o_b(const BatchJob* __restrict__ jobs) {
-  const BatchJob& j = jobs[blockIdx.y];
-  k_match4_body(j.st, j.sx, j.sy, j.sz, j.n, j.map, j.pair_q, j.pair_gidx, j.perm
 #ifdef MH_DEBUG_WAVETRACE
                 , nullptr
 #endif
@@ -2655,188 +2335,18 @@ __global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match4o_b(const Batch
 // at -37 % speed -- whole scans are equal work.)  -DMH_FLAT_NO_JOB_XCD: the plain order (A/B).
 __global__ __launch_bounds__(kFlatThreads, MH_FLAT_WAVES) void k_match_flat_b(const BatchJob* __restrict__ jobs) {
   uint32_t job = blockIdx.y, bx = blockIdx.x;
-#ifndef MH_FLAT_NO_JOB_XCD
   const uint32_t whole = gridDim.y & ~7u;  // jobs that are dealt an XCD each
   if (blockIdx.y < whole) {
     const uint32_t L = blockIdx.x + blockIdx.y * gridDim.x, xcd = L % 8u, slot = L / 8u;
     job = xcd + 8u * (slot / gridDim.x);
     bx = slot % gridDim.x;
   }
-#endif
   const BatchJob& j = jobs[job];
   k_match_flat_body(j.st, j.lx, j.ly, j.lz, j.n, j.map, j.pair_q, j.pair_gidx, nullptr, bx);
 }
-__global__ __launch_bounds__(kTileThreads) void k_match_tile(const IcpDeviceState* __restrict__ st, const float* __restrict__ sx,
-                                                             const float* __restrict__ sy, const float* __restrict__ sz,
-                                                             const uint32_t* __restrict__ perm,
-                                                             const uint32_t* __restrict__ tile_start, uint32_t n_tiles,
-                                                             MapView map, float4* __restrict__ pair_q,
-                                                             uint32_t* __restrict__ pair_gidx
-#ifdef MH_DEBUG_WAVETRACE
-                                                             , unsigned long long* __restrict__ wtrace
+#ifdef MH_DEV_VARIANTS
+#include "mh_dev_variants.h"  // k_match_tile*, k_match_wave_*, k_match4o_b: development library only
 #endif
-) {
-  k_match_tile_body(st, sx, sy, sz, perm, tile_start, n_tiles, map, pair_q, pair_gidx
-#ifdef MH_DEBUG_WAVETRACE
-                    , wtrace
-#endif
-  );
-}
-__global__ __launch_bounds__(kTileThreads) void k_match_tile_b(const BatchJob* __restrict__ jobs) {
-  const BatchJob& j = jobs[blockIdx.y];
-  k_match_tile_body(j.st, j.sx, j.sy, j.sz, j.perm, j.tile_start, j.n_tiles, j.map, j.pair_q, j.pair_gidx
-#ifdef MH_DEBUG_WAVETRACE
-                    , nullptr
-#endif
-  );
-}
-// k_match_wave: tiles of <= 64 spatially sorted points.  Two launches per iteration over the same tile table:
-//   DENSE   one wave (a 64-thread workgroup) per tile with >= kWaveMinPoints points: wave-uniform candidates
-//           (nn_search_wave: scalar loads; LDS: the box's records staged in LDS instead when they fit);
-//   sparse  the other tiles by quads (nn_search_quad), sixteen points per wave, four waves per tile.
-// Each tile is handled by exactly one of the two; the other launch's workgroup leaves at once.  Two kernels instead of
-// one so that each gets the registers of its own path only.
-template <bool DENSE, bool LDS>
-__device__ __forceinline__ void k_match_wave_body(const IcpDeviceState* __restrict__ st, const float* __restrict__ sx,
-                                                  const float* __restrict__ sy, const float* __restrict__ sz,
-                                                  const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tile_start,
-                                                  uint32_t n_tiles, MapView map, float4* __restrict__ pair_q,
-                                                  uint32_t* __restrict__ pair_gidx
-#ifdef MH_DEBUG_WAVETRACE
-                                                  , unsigned long long* __restrict__ wtrace
-#endif
-) {
-  WaveShared* wsh = nullptr;
-  if constexpr (LDS && DENSE) {
-    __shared__ WaveShared wsh_store;
-    wsh = &wsh_store;
-  }
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t t = blockIdx.x;
-  if (t >= n_tiles) return;
-  // everything wave-uniform comes in through the scalar path (constant address space, uniform addresses): the pose lives
-  // in SGPRs, not in 24 VGPRs per lane
-  typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
-  typedef const IcpDeviceState __attribute__((address_space(4))) * cstate_ptr;
-  const cu32_ptr cts = (cu32_ptr)uniform_const_ptr(tile_start);
-  const cstate_ptr cst = (cstate_ptr)uniform_const_ptr(st);
-  const uint32_t s0 = cts[t], s1 = cts[t + 1];
-  const uint32_t cnt = s1 - s0;
-  if ((cnt >= kWaveMinPoints) != DENSE) return;  // the other launch's tile
-  const uint32_t done = cst->done;
-  double T[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) T[k] = cst->T[k];
-  const float thr2 = cst->cur_thr2, ang2 = cst->cur_ang2;
-  if (done) return;  // grid-uniform
-  if (DENSE) {
-    const uint32_t i = s0 + lane;
-    const bool active = i < s1;
-    const uint32_t ic = active ? i : s0;
-    const float x = sx[ic], y = sy[ic], z = sz[ic];
-    const uint32_t orig = perm[ic];
-    float px, py, pz;
-    transform_point(T, x, y, z, px, py, pz);
-#ifdef MH_DEBUG_WAVETRACE
-    unsigned long long* dbg = wtrace ? wtrace + 8ull * t : nullptr;  // [start, end, points, voxels, probed, copied, pass 1, records]
-    if (lane == 0 && dbg) { dbg[0] = wall_clock64(); dbg[2] = cnt; }
-#endif
-    const NNResult r = nn_search_wave<LDS>(map, wsh, active, px, py, pz
-#ifdef MH_DEBUG_WAVETRACE
-                                           , dbg
-#endif
-    );
-#ifdef MH_DEBUG_WAVETRACE
-    if (lane == 0 && dbg) dbg[1] = wall_clock64();
-#endif
-    if (active) {
-      const float n2 = (px * px + py * py) + pz * pz;
-      const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
-      pair_q[orig] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
-      pair_gidx[orig] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
-    }
-    return;
-  }
-  const uint32_t sub = lane & 3u;
-  {
-    const uint32_t base = 16u * wave;  // sixteen points per wave, a quad each
-    if (base >= cnt) return;
-    const uint32_t q = base + (lane >> 2);
-    const bool active = q < cnt;
-    const uint32_t ic = s0 + (active ? q : 0u);
-    const float x = sx[ic], y = sy[ic], z = sz[ic];
-    const uint32_t orig = perm[ic];
-    float px, py, pz;
-    transform_point(T, x, y, z, px, py, pz);
-#ifdef MH_DEBUG_WAVETRACE
-    unsigned long long* dbg = (wtrace && wave == 0) ? wtrace + 8ull * t : nullptr;
-    if (lane == 0 && dbg) { dbg[0] = wall_clock64(); dbg[2] = cnt; dbg[3] = 0; }
-#endif
-    const NNResult r = nn_search_quad(map, sub, px, py, pz);
-#ifdef MH_CARRY_WINNER
-    if (active && r.writer) {
-#else
-    if (active && sub == 0u) {
-#endif
-      const float n2 = (px * px + py * py) + pz * pz;
-      const bool ok = r.found && (r.d2 < thr2 + ang2 * n2);
-      pair_q[orig] = make_float4(r.pt.x, r.pt.y, r.pt.z, r.d2);
-      pair_gidx[orig] = ok ? __float_as_uint(r.pt.w) : kNoMatch;
-    }
-#ifdef MH_DEBUG_WAVETRACE
-    if (lane == 0 && dbg) dbg[1] = wall_clock64();
-#endif
-  }
-}
-#ifdef MH_DEBUG_WAVETRACE
-#define MH_WT_PARAM , unsigned long long* __restrict__ wtrace
-#define MH_WT_ARG , wtrace
-#define MH_WT_NULL , nullptr
-#define MH_WT_G , g_wtrace
-#else
-#define MH_WT_PARAM
-#define MH_WT_ARG
-#define MH_WT_NULL
-#endif
-template <bool LDS>
-__global__ __launch_bounds__(64, 8) void k_match_wave_dense(const IcpDeviceState* __restrict__ st, const float* __restrict__ sx,
-                                                            const float* __restrict__ sy, const float* __restrict__ sz,
-                                                            const uint32_t* __restrict__ perm,
-                                                            const uint32_t* __restrict__ tile_start, uint32_t n_tiles, MapView map,
-                                                            float4* __restrict__ pair_q, uint32_t* __restrict__ pair_gidx MH_WT_PARAM) {
-  k_match_wave_body<true, LDS>(st, sx, sy, sz, perm, tile_start, n_tiles, map, pair_q, pair_gidx MH_WT_ARG);
-}
-__global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_wave_sparse(const IcpDeviceState* __restrict__ st,
-                                                                            const float* __restrict__ sx, const float* __restrict__ sy,
-                                                                            const float* __restrict__ sz, const uint32_t* __restrict__ perm,
-                                                                            const uint32_t* __restrict__ tile_start, uint32_t n_tiles,
-                                                                            MapView map, float4* __restrict__ pair_q,
-                                                                            uint32_t* __restrict__ pair_gidx MH_WT_PARAM) {
-  k_match_wave_body<false, false>(st, sx, sy, sz, perm, tile_start, n_tiles, map, pair_q, pair_gidx MH_WT_ARG);
-}
-template <bool LDS>
-__global__ __launch_bounds__(64, 8) void k_match_wave_dense_b(const BatchJob* __restrict__ jobs) {
-  const BatchJob& j = jobs[blockIdx.y];
-  k_match_wave_body<true, LDS>(j.st, j.sx, j.sy, j.sz, j.perm, j.tile_start, j.n_tiles, j.map, j.pair_q, j.pair_gidx MH_WT_NULL);
-}
-__global__ __launch_bounds__(kBlock, MH_QUAD_WAVES) void k_match_wave_sparse_b(const BatchJob* __restrict__ jobs) {
-  const BatchJob& j = jobs[blockIdx.y];
-  k_match_wave_body<false, false>(j.st, j.sx, j.sy, j.sz, j.perm, j.tile_start, j.n_tiles, j.map, j.pair_q, j.pair_gidx MH_WT_NULL);
-}
-// both launches of the wave matcher on stream s (LDS staging of the dense tiles: MH_WAVE_LDS=1)
-static inline bool wave_lds_env() { static const bool v = getenv("MH_WAVE_LDS") != nullptr; return v; }
-#define MH_LAUNCH_WAVE(S, ST, SC, MV, PQ, PG, WT)                                                                          \
-  do {                                                                                                                     \
-    if (wave_lds_env())                                                                                                    \
-      hipLaunchKernelGGL(k_match_wave_dense<true>, dim3((SC)->n_tiles), dim3(64), 0, S, ST, (SC)->sx, (SC)->sy, (SC)->sz,   \
-                         (SC)->perm, (SC)->tile_start, (SC)->n_tiles, MV, PQ, PG WT);                                      \
-    else                                                                                                                   \
-      hipLaunchKernelGGL(k_match_wave_dense<false>, dim3((SC)->n_tiles), dim3(64), 0, S, ST, (SC)->sx, (SC)->sy, (SC)->sz,  \
-                         (SC)->perm, (SC)->tile_start, (SC)->n_tiles, MV, PQ, PG WT);                                      \
-    hipLaunchKernelGGL(k_match_wave_sparse, dim3((SC)->n_tiles), dim3(kBlock), 0, S, ST, (SC)->sx, (SC)->sy, (SC)->sz,      \
-                       (SC)->perm, (SC)->tile_start, (SC)->n_tiles, MV, PQ, PG WT);                                        \
-  } while (0)
 template <bool SIGNED>
 __global__ __launch_bounds__(kBlock, MH_ACCUM_WAVES) void k_accum(const IcpDeviceState* __restrict__ st, uint32_t first,
                                                   const MatchK* __restrict__ kp, const float* __restrict__ lx,
@@ -3429,10 +2939,16 @@ struct AlignJob {
       const char* e = getenv("MH_MATCH");
       variant = scan->n <= kRowMaxPoints ? 5 : 9;
       //   "w"            a wave per tile of 64 sorted points, wave-uniform candidates through the scalar path       -> k_match_wave + k_accum
+      //   "o"            "q" over the scan in search order (the sort of "t"/"w", no tiles)                                    -> k_match4 + k_accum
+      //   ("t", "w", "o": mh_dev_variants.h, the development library only)
+#ifdef MH_DEV_VARIANTS
       if (e && e[0] == 't') variant = 6;
       if (e && e[0] == 'w') variant = 7;
-      //   "o"            "q" over the scan in search order (the sort of "t"/"w", no tiles)                                    -> k_match4 + k_accum
       if (e && e[0] == 'o') variant = 8;
+#else
+      if (e && (e[0] == 't' || e[0] == 'w' || e[0] == 'o'))
+        return fail(MH_ERR_INVALID_ARGUMENT, "MH_MATCH=%c names a development matcher: build tools/variants/libmolahip_dev.so (tools/build_variants.sh)", e[0]);
+#endif
       if (e && e[0] == 'q') variant = 4;
       //   "f" (default)  plan / scan (mh_nn_flat.h): a wave per 64 points, per-point / per-voxel / per-record work each on all 64 lanes -> k_match_flat + k_accum
       if (e && e[0] == 'f') variant = 9;
@@ -3445,7 +2961,9 @@ struct AlignJob {
       if (pl && p->matched_points == MH_MATCHED_POINTS_SKIP) variant = 5;
     }
     if (variant == 9 && map->pts.bytes / sizeof(float4) >= kFlatMaxRecords) variant = 4;  // (the chunk word holds 30 bits of record index)
+#ifdef MH_DEV_VARIANTS
     if (variant >= 6 && variant != 9) MH_TRY(scan_build_tiles(scan, map->inv_vs, variant == 7 ? 64u : 256u));
+#endif
     if (variant == 4 || variant >= 6) {  // nn_search_quad / the plan-scan matcher read the map's sub-voxel index
       MH_TRY(map_ensure_qidx(map, ctx->stream));
       if (!map->view().pts_q) return fail(MH_ERR_INTERNAL, "the map's sub-voxel index is missing (matcher variant %d needs it)", variant);
@@ -3652,7 +3170,9 @@ struct AlignJob {
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t)scan->n;
     const MapView mv = map->view();
+#ifdef MH_DEV_VARIANTS
     if (variant == 6 || variant == 7) MH_TRY(scan_tiles_ready(scan));  // the launch grid needs the tile count
+#endif
     const uint32_t m = (p->max_iterations - enqueued) < chunk ? (p->max_iterations - enqueued) : chunk;
     PoseArg dummy{};
     double* part = ctx->partials.as<double>();
@@ -3727,6 +3247,7 @@ struct AlignJob {
           else if (!fused16)
             hipLaunchKernelGGL(k_accum<false>, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                                ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nbm);
+#ifdef MH_DEV_VARIANTS
         } else if (variant == 7) {
 #ifdef MH_DEBUG_WAVETRACE
           MH_LAUNCH_WAVE(s, ctx->d_state, scan, mv, ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), MH_WT_G);
@@ -3747,6 +3268,7 @@ struct AlignJob {
           if (prof) MH_HIP(hipEventRecord(ctx->prof_ev[2 * prof_n + 1], s));  // the match kernel alone
           hipLaunchKernelGGL(k_accum<false>, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
+#endif
         } else if (variant == 9) {
           hipLaunchKernelGGL(k_match_flat, dim3(nblk_flat(n)), dim3(kFlatThreads), 0, s, ctx->d_state, scan->x, scan->y, scan->z, n, mv,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), (const uint32_t*)nullptr);
@@ -3754,7 +3276,11 @@ struct AlignJob {
           hipLaunchKernelGGL(k_accum<true>, dim3(nba), dim3(kBlock), 0, s, ctx->d_state, 1u, dmk, scan->x, scan->y, scan->z, n,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), part, nba);
         } else if (variant == 4 || variant == 8) {
+#ifdef MH_DEV_VARIANTS
           const bool ord = variant == 8;  // the scan in search order
+#else
+          const bool ord = false;
+#endif
           hipLaunchKernelGGL(k_match4, dim3((uint32_t)((4ull * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ctx->d_state,
                              ord ? scan->sx : scan->x, ord ? scan->sy : scan->y, ord ? scan->sz : scan->z, n, mv,
                              ctx->pair_q.as<float4>(), ctx->pair_gidx.as<uint32_t>(), ord ? scan->perm : (const uint32_t*)nullptr
@@ -4072,6 +3598,14 @@ mh_status mh_icp_align_prefers_solo(const mh_scan* scan, const mh_icp_params* p,
   // 4000-4450 scans/s.)
   if (*yes && !loops_fit(scan->ctx->device, loop_units((uint32_t)((n + kStepPoints - 1) / kStepPoints), pl), concurrent_callers)) *yes = 0;
   return MH_OK;
+}
+
+int32_t mh_debug_dev_variants(void) {
+#ifdef MH_DEV_VARIANTS
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 void mh_debug_loop_stats(uint64_t* loops_started, uint64_t* loops_abandoned) {
@@ -4393,8 +3927,10 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
       mh_ctx* lead = g.lead;
       MH_TRY(set_device(lead));
       hipStream_t s = lead->stream;
+#ifdef MH_DEV_VARIANTS
       if (g.kind == K_TILE || g.kind == K_WAVE)
         for (AlignJob* j : g.jobs) MH_TRY(scan_tiles_ready(j->scan));  // tile counts (the builds were queued by start())
+#endif
       MH_TRY(order_after_job_streams(lead, g.jobs));
       size_t stage_bytes = 0;
       for (AlignJob* j : g.jobs) stage_bytes += kBlockBytes + j->nsched_pending * sizeof(double);
@@ -4547,6 +4083,7 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
           if (pr) MH_HIP(hipEventRecord(g.lead->prof_ev[2 * g.prof_n], s));
           switch (g.kind) {
             case K_ROWF: hipLaunchKernelGGL(k_match16f_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
+#ifdef MH_DEV_VARIANTS
             case K_TILE: hipLaunchKernelGGL(k_match_tile_b, dim3(g.gx_match, A), dim3(kTileThreads), 0, s, g.dj); break;
             case K_WAVE:
               if (wave_lds_env()) hipLaunchKernelGGL(k_match_wave_dense_b<true>, dim3(g.gx_match, A), dim3(64), 0, s, g.dj);
@@ -4554,6 +4091,7 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
               hipLaunchKernelGGL(k_match_wave_sparse_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj);
               break;
             case K_ORD: hipLaunchKernelGGL(k_match4o_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
+#endif
             case K_FLAT: hipLaunchKernelGGL(k_match_flat_b, dim3(g.gx_match, A), dim3(kFlatThreads), 0, s, g.dj); break;
             default: hipLaunchKernelGGL(k_match4_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj); break;
           }
@@ -4640,40 +4178,6 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
         }
       }
     }
-#ifdef MH_DEBUG_FLOOR
-    if (g_floor_host.run_reps && g_floor_host.script && groups[0].kind == K_QUAD && groups[0].jobs.size() <= g_floor_host.jobs) {
-      // tools/match_floor.py: replay the captured access pattern on the group's own descriptors, back to back
-      Group& g = groups[0];
-      hipStream_t s = g.lead->stream;
-      hipEvent_t e0, e1;
-      MH_HIP(hipEventCreate(&e0));
-      MH_HIP(hipEventCreate(&e1));
-      const uint32_t A = (uint32_t)g.jobs.size();
-      for (int w = 0; w < 3; w++) hipLaunchKernelGGL(k_match_floor_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj, g_floor_host.flags);
-      MH_HIP(hipEventRecord(e0, s));
-      for (uint32_t r = 0; r < g_floor_host.run_reps; r++) hipLaunchKernelGGL(k_match_floor_b, dim3(g.gx_match, A), dim3(kBlock), 0, s, g.dj, g_floor_host.flags);
-      MH_HIP(hipEventRecord(e1, s));
-      MH_HIP(hipEventSynchronize(e1));
-      float fms = 0.f;
-      MH_HIP(hipEventElapsedTime(&fms, e0, e1));
-      g_floor_host.floor_ms = fms / (double)g_floor_host.run_reps;
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
-      if (want_prof) {
-        uint32_t it_cap = 0;
-        (void)hipMemcpyFromSymbol(&it_cap, HIP_SYMBOL(g_floor_iter), sizeof(uint32_t));
-        double sum = 0.0;
-        float ms = 0.f;
-        for (uint32_t i = 0; i < g.prof_n; i++) {
-          MH_HIP(hipEventElapsedTime(&ms, g.lead->prof_ev[2 * i], g.lead->prof_ev[2 * i + 1]));
-          sum += ms;
-          if (i == (it_cap & 0x7FFFFFFFu)) g_floor_host.real_ms_at_iter = ms;
-        }
-        g_floor_host.real_ms_avg = g.prof_n ? sum / g.prof_n : 0.0;
-        g_floor_host.real_launches = g.prof_n;
-      }
-    }
-#endif
     if (want_prof && groups[0].jobs[0] == &jobs[0]) {  // the match step of job 0 = its share of its group's lock-step launches
       Group& g = groups[0];
       float ms = 0.f;
@@ -4740,6 +4244,7 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
 }
 
 namespace {
+#ifdef MH_DEV_VARIANTS
 // MH_MATCH=t: the matcher-granular entry points run the tile matcher too (the parity tests drive every search kernel
 // through mh_nn_search / mh_nn_search_dense); thr2 = +inf: no threshold
 mh_status launch_tile_search(const mh_map* map, const mh_scan* scan, const double T[12], float thr2, float ang2) {
@@ -4770,6 +4275,10 @@ inline bool tile_search_forced() {
   const char* e = getenv("MH_MATCH");
   return e && (e[0] == 't' || e[0] == 'w');
 }
+#else  // the shipped library: the matcher-granular entry points run k_match<false, 1> whatever MH_MATCH says
+inline bool tile_search_forced() { return false; }
+inline mh_status launch_tile_search(const mh_map*, const mh_scan*, const double*, float, float) { return MH_OK; }
+#endif
 }  // namespace
 
 mh_status mh_nn_search(const mh_map* map, const mh_scan* scan, const double T[12], double threshold,

@@ -282,11 +282,19 @@ mh_status scan_alloc(mh_scan* s, size_t n, bool with_t, bool with_src);
 // n_stored: the first n_stored inputs are points the map already stores (accepted by the insertion rules before).
 // sorted copy + tile table of a scan for voxel size 1/inv_vs (no-op when valid); asynchronous on the scan's stream,
 // scan_tiles_ready() waits for the tile count
+#ifdef MH_DEV_VARIANTS  // (mh_tile.hip: the search order of the tile / wave / sorted matchers -- development library only)
 mh_status scan_build_tiles(const mh_scan* s, float inv_vs, uint32_t tile_points);
 uint32_t tile_points_for_env();
 mh_status scan_tiles_ready(const mh_scan* s);
 void scan_drop_tiles(mh_scan* s);  // host-side bookkeeping only (the points changed)
 void scan_free_tiles(mh_scan* s);
+#else
+inline mh_status scan_build_tiles(const mh_scan*, float, uint32_t) { return MH_OK; }
+inline uint32_t tile_points_for_env() { return 0; }
+inline mh_status scan_tiles_ready(const mh_scan*) { return MH_OK; }
+inline void scan_drop_tiles(mh_scan*) {}
+inline void scan_free_tiles(mh_scan*) {}
+#endif
 // Asynchronous on stream `s` (the context's); scratch from `m`.  Counts / bbox / the
 // out-of-range verdict are resolved lazily (map_resolve).
 mh_status map_build_device(mh_map* m, hipStream_t s, const float* dx, const float* dy, const float* dz, const uint32_t* dsrc,

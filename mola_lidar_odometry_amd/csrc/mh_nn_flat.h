@@ -136,11 +136,7 @@ __device__ __forceinline__ uint32_t flat_plan_scan(FW& sh, const MapView& m, uin
         const uint32_t c = base + 64u * (uint32_t)k + lane;
         ent[k] = sh.CL[c < n_cands ? c : 0u];  // (clamped: the load of an idle lane is a hit on entry 0's slot)
         keys[k] = nn_key_of(sh.KB[ent[k] & 63u], (int)(ent[k] >> 8));
-#ifdef MH_FLAT_WHATIF_PROBE  // timing experiment (results wrong): every probe hits the same 1 KiB
-        sls[k] = slots4[hash_key(keys[k]) & 63u];
-#else
         sls[k] = slots4[hash_key(keys[k]) & m.mask];
-#endif
       }
 #pragma unroll
       for (int k = 0; k < kFlatProbes; k++) {
@@ -154,17 +150,11 @@ __device__ __forceinline__ uint32_t flat_plan_scan(FW& sh, const MapView& m, uin
         nn_resolve(m, slots4, keys[k], sls[k], act, f, cnt, &qv);
         quad_narrow(m, qv, code, P.x, P.y, P.w, f, cnt);
         const uint32_t nchunks = (cnt + (uint32_t)kFlatLPP - 1u) / (uint32_t)kFlatLPP;
-#ifdef MH_FLAT_ATOMIC_ALLOC
-        // (A/B: chunk space off one LDS counter -- one ds_add_rtn instead of a DPP prefix sum, but 64 lanes on one address)
-        uint32_t pos = 0;
-        if (nchunks) pos = __hip_atomic_fetch_add(&sh.NCH_, nchunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
         // chunk space by a DPP prefix sum over the wave's candidates of this pass (the order of the chunks does not matter
         // for the result: every chunk names its point)
         const uint32_t incl = wave_scan_incl(nchunks);
         const uint32_t pos = nch_total + incl - nchunks;
         nch_total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-#endif
         if (nchunks) {
           if (pos + nchunks > (uint32_t)kFlatMaxChunks) {  // out of space: the point goes to phase D, slots from `pos` on stay unwritten
             sh.SLOWF[p] = 1;
@@ -182,11 +172,7 @@ __device__ __forceinline__ uint32_t flat_plan_scan(FW& sh, const MapView& m, uin
     }
     wave_sync_lds_nn();
     {
-#ifdef MH_FLAT_ATOMIC_ALLOC
-      const uint32_t a = sh.NCH_;
-#else
       const uint32_t a = nch_total;
-#endif
       const uint32_t b = sh.NVALID;
       nvalid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a < b ? a : b));
     }
@@ -205,43 +191,15 @@ __device__ __forceinline__ uint32_t flat_plan_scan(FW& sh, const MapView& m, uin
         pp[u] = sh.CHP[tt];
         const uint32_t last = ch >> 30;
         valid[u] = ok && sub <= last;
-#ifdef MH_FLAT_WHATIF_REC  // timing experiment (results wrong): every record load hits the same 4 KiB
-        rec[u] = spts[((ch & 0x3FFFFFFFu) + (sub < last ? sub : last)) & 255u];
-#else
         rec[u] = spts[(ch & 0x3FFFFFFFu) + (sub < last ? sub : last)];  // clamped into the chunk: no load behind a branch
-#endif
       }
-#ifdef MH_FLAT_SENS_LOADS  // sensitivity experiment: every record load issued twice (the second one an L1 hit), result folded in harmlessly
-      {
-        f32x4 dup[kFlatW];
-#pragma unroll
-        for (int u = 0; u < kFlatW; u++) {
-          const gpts_ptr a = spts + __float_as_uint(rec[u].w) * 0u;  // (depends on the first load: issued after it)
-          dup[u] = a[(sh.CH[(t0 + 16u * (uint32_t)u + grp) < nvalid ? (t0 + 16u * (uint32_t)u + grp) : 0u] & 0x3FFFFFFFu)];
-        }
-#pragma unroll
-        for (int u = 0; u < kFlatW; u++) if (dup[u].x != dup[u].x) rec[u].x = dup[u].y;  // never true for finite records
-      }
-#endif
-#ifdef MH_FLAT_SENS_VALU  // sensitivity experiment: 128 dependent dummy vector instructions per round
-      {
-        float acc = rec[0].x;
-#pragma unroll
-        for (int j = 0; j < 128; j++) acc = acc * 1.0001f + 0.5f;
-        if (acc == 123.456f) rec[0].x = acc;
-      }
-#endif
 #pragma unroll
       for (int u = 0; u < kFlatW; u++) {
         const f32x4 Pq = sh.P[pp[u]];  // (read when the record is there: W records in flight cost 4 registers each, not 8)
         const float dx = rec[u].x - Pq.x, dy = rec[u].y - Pq.y, dz = rec[u].z - Pq.z;
         const float d2 = (dx * dx + dy * dy) + dz * dz;  // fp32, un-fused, this order (bit-exact with the oracle)
         // only a record within the bound can be the answer ((d2, position) < (b0, none) <=> d2 <= b0)
-#ifdef MH_FLAT_NO_PREFILTER
-        if (valid[u])
-#else
         if (valid[u] && d2 <= Pq.w)
-#endif
           (void)__hip_atomic_fetch_min(&sh.RES[pp[u]], ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(rec[u].w),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }

@@ -43,7 +43,10 @@ for case in range(n_cases):
     om = oracle_c.Map(vs, cap, mode).insert(pts)
     o = oracle_c.match_points(om, q, T, 1e9)
     fails = []
-    for match, extra in (("p", {}), ("x", {}), ("q", {}), ("s", {}), ("t", {}), ("w", {}), ("w", {"MH_WAVE_LDS": "1"})):
+    variants = (("p", {}), ("x", {}), ("q", {}), ("s", {}))
+    if capi.dev_variants():  # (the development library: tools/build_variants.sh)
+        variants += (("t", {}), ("w", {}), ("w", {"MH_WAVE_LDS": "1"}))
+    for match, extra in variants:
         os.environ["MH_MATCH"] = match
         for k, v in extra.items():
             os.environ[k] = v
