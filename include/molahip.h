@@ -43,6 +43,11 @@ extern "C" {
 #define MH_VERSION_MAJOR 0
 #define MH_VERSION_MINOR 1
 #define MH_VERSION_PATCH 0
+/* The parameter structs of this header carry no size field: they grow at the END, and every growth bumps MH_ABI_VERSION (6:
+ * mh_preprocess_params' two decimation-method fields, round 5).  A binder built against this header checks
+ * `mh_abi_version() == MH_ABI_VERSION` once after loading the library (capi.py does; the C++ host layer links the header it was
+ * built with) and zero-initialises every struct it passes -- a field the binder does not know then reads as its default. */
+#define MH_ABI_VERSION 6
 
 typedef int32_t mh_status;
 enum {
@@ -99,6 +104,11 @@ typedef struct mh_scan mh_scan;
  * ---------------------------------------------------------------------------------------------- */
 MH_API mh_status mh_version(uint32_t* major, uint32_t* minor, uint32_t* patch);
 MH_API const char* mh_last_error_string(void);
+/* MH_ABI_VERSION of the loaded library (see above). */
+MH_API uint32_t mh_abi_version(void);
+/* A status at or above MH_WARN_PREVIOUS_OUT_OF_RANGE is not a failure: the call did its work (MH_SUCCEEDED is the test a binder
+ * wants where it would write `== MH_OK`). */
+#define MH_SUCCEEDED(status) ((status) == MH_OK || (status) >= MH_WARN_PREVIOUS_OUT_OF_RANGE)
 MH_API const char* mh_status_string(mh_status s);
 MH_API mh_status mh_device_count(int32_t* n);
 

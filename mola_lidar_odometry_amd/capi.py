@@ -141,6 +141,7 @@ _SIGNATURES = {
     "mh_debug_fail_allocations": (C.c_int32, [C.c_int32, C.c_int32]),
     "mh_debug_loop_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mh_debug_dev_variants": (C.c_int32, []),
+    "mh_abi_version": (C.c_uint32, []),
     "mh_icp_align_prefers_solo": (C.c_int32, [C.c_void_p, C.POINTER(ICPParamsC), C.c_uint32, C.POINTER(C.c_int32)]),
     "mh_ctx_create": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mh_ctx_destroy": (C.c_int32, [C.c_void_p]),
@@ -218,8 +219,23 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        want = _header_abi_version()
+        if want is not None and int(L.mh_abi_version()) != want:
+            raise OSError(f"{LIB_PATH} speaks ABI version {int(L.mh_abi_version())}, include/molahip.h says {want}: rebuild "
+                          "(the parameter structs of this binding follow the header)")
         _lib = L
     return _lib
+
+
+def _header_abi_version():
+    """MH_ABI_VERSION of include/molahip.h beside this package (None when the header is not there: an installed copy)."""
+    import re
+    h = os.path.join(os.path.dirname(_HERE), "include", "molahip.h")
+    try:
+        m = re.search(r"^#define\s+MH_ABI_VERSION\s+(\d+)", open(h).read(), re.M)
+    except OSError:
+        return None
+    return int(m.group(1)) if m else None
 
 
 def _chk(status):

@@ -68,6 +68,8 @@ mh_status scan_alloc(mh_scan* s, size_t n, bool with_t, bool with_src) {
 using namespace mh;
 
 extern "C" {
+uint32_t mh_abi_version(void) { return MH_ABI_VERSION; }
+
 
 mh_status mh_host_alloc_pinned(size_t bytes, void** out) {
   MH_REQUIRE(out, "null argument");

@@ -453,7 +453,7 @@ struct AlignJob {
     loop16 = false;
     // (after a loop had to be abandoned -- somebody else's work kept its workgroups from running together, ~0.1 s lost -- the
     //  next 200 alignments on the device take the chain before another loop is tried)
-    if (streaming && use_step_chain() && !forbid_loop16 && getenv("MH_NO_LOOP16") == nullptr && !loop_holdoff(ctx->device, false)) {
+    if (streaming && use_step_chain() && !forbid_loop16 && getenv("MH_NO_LOOP16") == nullptr && !loop_holdoff(ctx->device, 0)) {
       const uint32_t ng = (uint32_t)((scan->n + kStepPoints - 1) / kStepPoints);
       loopw = !pl && loop_wave_enabled();
       if (ng <= (loopw ? kLwMaxGroups : kLoopMaxGroups) && loop_admit(ctx->device, loop_units(ng, pl))) {
@@ -561,12 +561,22 @@ struct AlignJob {
       else std::this_thread::yield();
     }
   }
-  static bool loop_holdoff(int device, bool arm) {  // arm: a loop was abandoned; else: true while the hold-off lasts (counts down)
-    static std::atomic<int> left[64];
+  // arm > 0: a loop was abandoned; arm < 0: a loop ran to its end; 0: true while the hold-off lasts (counts down).  The hold-off
+  // doubles with every abandonment in a row (200, 400, ... 12 800 alignments): on a device shared with other processes a loop's
+  // workgroups may never run together, and every attempt costs its 20 ms limit (MH_NO_LOOP16=1 is the switch for such
+  // a deployment).
+  static bool loop_holdoff(int device, int arm) {
+    static std::atomic<int> left[64], streak[64];
     std::atomic<int>& v = left[(unsigned)device % 64u];
-    if (arm) {
-      v.store(200);
+    std::atomic<int>& st = streak[(unsigned)device % 64u];
+    if (arm > 0) {
+      const int k = st.fetch_add(1);
+      v.store(200 << (k < 6 ? k : 6));
       return true;
+    }
+    if (arm < 0) {
+      st.store(0);
+      return false;
     }
     int cur = v.load();
     while (cur > 0)
@@ -617,9 +627,10 @@ struct AlignJob {
     const IcpDeviceState* h = ctx->h_state;
     if (!h->done || h->handover_timeouts) {
       g_loop16_fallbacks.fetch_add(1);
-      if (getenv("MH_LOOP16_TEST_ABANDON") == nullptr) loop_holdoff(ctx->device, true);
+      if (getenv("MH_LOOP16_TEST_ABANDON") == nullptr) loop_holdoff(ctx->device, 1);
       return MH_OK;  // (not finished)
     }
+    loop_holdoff(ctx->device, -1);
     return poll(true);
   }
 

@@ -363,7 +363,7 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
       // groups, a workgroup takes at most kLoopGroupsPerWg of them, and the launch's workgroups are admitted (all resident together,
       // beside the one-launch loops of single alignments running on the device).  MH_NO_LOOP16 / MH_NO_LOOP16_BATCH: the chain.
       if (g.step_chain() && getenv("MH_NO_LOOP16") == nullptr && getenv("MH_NO_LOOP16_BATCH") == nullptr &&
-          !AlignJob::loop_holdoff(lead->device, false)) {
+          !AlignJob::loop_holdoff(lead->device, 0)) {
         bool fits = true;
         // k_icpw_b (point layers): every job its own workgroups of 128 points; k_icp16_b (NDT maps, MH_NO_LOOPW): the jobs share
         // kStepMaxWorkgroups workgroups of 32 points, a workgroup taking several groups
@@ -532,8 +532,9 @@ static mh_status align_batch_run(size_t n_jobs, const mh_map* const* maps, const
             g_loop16_fallbacks.fetch_add(1);
             MH_HIP(hipMemsetAsync(&g.jobs[a]->ctx->d_state->handover_timeouts, 0, sizeof(uint32_t) * 10, g.lead->stream));
           }
+          if (!abandoned) AlignJob::loop_holdoff(g.lead->device, -1);  // (a clean run ends a streak of abandoned loops)
           if (abandoned) {
-            if (getenv("MH_LOOP16_TEST_ABANDON") == nullptr) AlignJob::loop_holdoff(g.lead->device, true);
+            if (getenv("MH_LOOP16_TEST_ABANDON") == nullptr) AlignJob::loop_holdoff(g.lead->device, 1);
             for (size_t a = 0; a < g.jobs.size(); a++) {
               AlignJob& j = *g.jobs[a];
               const IcpDeviceState& h = g.h_states[a];

@@ -438,9 +438,10 @@ constexpr size_t kLoopExchangeBytes = 2 * (size_t)(kAccN + kGenN) * kLoopRowStri
 
 __device__ __forceinline__ void cov_prepare_lane(const Pose& Tc, int j, double hx, double ha, double* out);  // (below)
 
+constexpr unsigned long long kLoopDeadlineTicks = 2000000ull;  // 20 ms of the 100 MHz wall clock: a loop's workgroups that do not meet by then give up
 template <int NVALS>
 __device__ __forceinline__ void loop_rows_fetch(RowLoads<NVALS, (int)kLoopMaxGroups>& r, const AgentBuf& x, uint32_t base, uint32_t n,
-                                                uint32_t serial, uint32_t* gave_up) {
+                                                uint32_t serial, uint32_t* gave_up, unsigned long long deadline) {
   typedef RowLoads<NVALS, (int)kLoopMaxGroups> RL;
   const int row = (int)threadIdx.x / RL::kG, g = (int)threadIdx.x % RL::kG;
   uint32_t need = 0;
@@ -462,7 +463,8 @@ __device__ __forceinline__ void loop_rows_fetch(RowLoads<NVALS, (int)kLoopMaxGro
         need &= ~(1u << j);
       }
     if (!need) break;
-    if (spins == (1u << 16) || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {  // ~0.1 s: give up loudly
+    // (a wall-clock limit, not a spin count -- ADVICE r5: what a spin costs depends on who else is on the device)
+    if (((spins & 31u) == 31u && wall_clock64() > deadline) || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {  // 20 ms: give up loudly
       __hip_atomic_store(gave_up, 1u + (uint32_t)row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       break;
     }
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_icp16(IcpDeviceState* s_canon
   typedef const double __attribute__((address_space(4))) * cf64_ptr;
   const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
   const uint32_t kernel = ck->kernel;
+  const unsigned long long deadline = wall_clock64() + kLoopDeadlineTicks;
   // the pairing of this row's point: found at an iteration's start, used by its inner steps and as the next search's bound
   f32x4 q = (f32x4){0.f, 0.f, 0.f, __builtin_inff()}, bc = (f32x4){0.f, 0.f, 0.f, 0.f}, bn = (f32x4){0.f, 0.f, 0.f, 0.f};
   bool ok = false, okp = false;
@@ -513,8 +516,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_icp16(IcpDeviceState* s_canon
       const uint32_t half = (step - 1u) & 1u;
       RowLoads<kAccN, (int)kLoopMaxGroups> ra;
       RowLoads<PL ? kGenN : 1, (int)kLoopMaxGroups> rb;
-      loop_rows_fetch<kAccN>(ra, bxa, half * kAccN * kLoopRowStride, ngroups, serial0 + step, &gave_up);
-      if (PL) loop_rows_fetch<PL ? kGenN : 1>(rb, bxb, half * kGenN * kLoopRowStride, ngroups, serial0 + step, &gave_up);
+      loop_rows_fetch<kAccN>(ra, bxa, half * kAccN * kLoopRowStride, ngroups, serial0 + step, &gave_up, deadline);
+      if (PL) loop_rows_fetch<PL ? kGenN : 1>(rb, bxb, half * kGenN * kLoopRowStride, ngroups, serial0 + step, &gave_up, deadline);
       MH_LOOP_STAMP(1);
       rows_finish(ra, ngroups, sh.totA, sh.red);
       if (PL) rows_finish(rb, ngroups, sh.totB, sh.red);
@@ -661,6 +664,7 @@ __device__ __forceinline__ void icp16_multi_body(const BatchJob& j) {
   typedef const double __attribute__((address_space(4))) * cf64_ptr;
   const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(j.mk);
   const uint32_t kernel = ck->kernel;
+  const unsigned long long deadline = wall_clock64() + kLoopDeadlineTicks;
   const uint32_t max_steps = j.loop_pad ? 1u : sk->max_iterations * sk->max_inner + 1u;  // (loop_pad: MH_LOOP16_TEST_ABANDON, the loop is cut short)
   uint32_t step = 0;
 #pragma nounroll
@@ -669,8 +673,8 @@ __device__ __forceinline__ void icp16_multi_body(const BatchJob& j) {
       const uint32_t half = (step - 1u) & 1u;
       RowLoads<kAccN, (int)kLoopMaxGroups> ra;
       RowLoads<PL ? kGenN : 1, (int)kLoopMaxGroups> rb;
-      loop_rows_fetch<kAccN>(ra, bxa, half * kAccN * kLoopRowStride, ngroups, serial0 + step, &gave_up);
-      if (PL) loop_rows_fetch<PL ? kGenN : 1>(rb, bxb, half * kGenN * kLoopRowStride, ngroups, serial0 + step, &gave_up);
+      loop_rows_fetch<kAccN>(ra, bxa, half * kAccN * kLoopRowStride, ngroups, serial0 + step, &gave_up, deadline);
+      if (PL) loop_rows_fetch<PL ? kGenN : 1>(rb, bxb, half * kGenN * kLoopRowStride, ngroups, serial0 + step, &gave_up, deadline);
       rows_finish(ra, ngroups, sh.totA, sh.red);
       if (PL) rows_finish(rb, ngroups, sh.totB, sh.red);
       if (gave_up) break;

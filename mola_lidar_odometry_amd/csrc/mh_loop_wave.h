@@ -15,7 +15,7 @@
 // copy of the state block with solve_body.  The pairings are exact (the lexicographic minimum of (d2, scan position) over the
 // 27-voxel block: tests/test_gpu_parity.py::test_wave_loop_*), so the trajectory file is the one k_icp16 and the k_step16 chain
 // write.  Point-to-plane pairings (NDT maps) stay with k_icp16<true>.
-// A workgroup that waits longer than kLwDeadlineTicks (wall clock, not spin counts: ADVICE r5) for an entry gives up; the host
+// A workgroup that waits longer than kLoopDeadlineTicks (wall clock, not spin counts: ADVICE r5) for an entry gives up; the host
 // then runs the alignment again launch by launch, as for k_icp16.
 #pragma once
 
@@ -33,7 +33,6 @@ constexpr uint32_t kLwPtsPerWave = MH_LW_PTS;
 constexpr uint32_t kLwThreads = kLwWaves * 64u;
 constexpr uint32_t kLwPoints = kLwWaves * kLwPtsPerWave;      // points per workgroup
 constexpr uint32_t kLwGroups = kLwPoints / kStepPoints;       // columns of sums per workgroup
-constexpr unsigned long long kLwDeadlineTicks = 2000000ull;   // 20 ms of the 100 MHz wall clock
 static_assert(kLwPoints % kStepPoints == 0 && kLwPtsPerWave * 27 <= (uint32_t)FlatWaveSmall::kCands, "whole groups per workgroup; every candidate of a wave's points has a place in its list");
 
 // rows_issue / loop_rows_fetch / rows_finish for a workgroup of NT lanes: the NVALS x kG (row, g) work items of the 512-lane
@@ -178,7 +177,7 @@ __device__ __forceinline__ void icpw_body(LwShared& S, IcpDeviceState* s_canon, 
   typedef const MatchK __attribute__((address_space(4))) * cmatchk_ptr;
   const cmatchk_ptr ck = (cmatchk_ptr)uniform_const_ptr(kp);
   const uint32_t kernel = ck->kernel;
-  const unsigned long long deadline = wall_clock64() + kLwDeadlineTicks;
+  const unsigned long long deadline = wall_clock64() + kLoopDeadlineTicks;
   // the pairing of this lane's point: found at an iteration's start, used by its inner steps and as the next search's bound
   f32x4 q = (f32x4){0.f, 0.f, 0.f, __builtin_inff()};
   uint32_t gidx = kNoMatch;

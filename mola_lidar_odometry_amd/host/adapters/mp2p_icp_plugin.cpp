@@ -227,9 +227,13 @@ class ICP_HIP : public ICP
             return rr;
         };
         auto run = [&](uint32_t budget, mh_icp_iter* trace) {
-            const uint32_t first = budget < kScheduleFirstStage ? budget : kScheduleFirstStage;
+            // (the first stage covers what the PREVIOUS alignment of this object needed, with a margin: consecutive scans converge
+            //  in about as many iterations, so the second run from scratch stays the exception also for slow sequences -- ADVICE r5)
+            uint32_t stage = kScheduleFirstStage;
+            if (last_iterations_ + 16u > stage) stage = last_iterations_ + 16u;
+            const uint32_t first = budget < stage ? budget : stage;
             mh_icp_result rr = run_with(first, trace);
-            if (first < budget && rr.termination_reason == MH_TERM_MAX_ITERATIONS) rr = run_with(budget, trace);  // rare: > 48 iterations
+            if (first < budget && rr.termination_reason == MH_TERM_MAX_ITERATIONS) rr = run_with(budget, trace);  // rare
             return rr;
         };
         if (iteration_hook_)  // [U] ICP::iteration_hook_: what setIterationHook() stored (LidarOdometry.cpp:923)
@@ -253,6 +257,13 @@ class ICP_HIP : public ICP
         }
         else
             r = run(p.maxIterations, nullptr);
+        last_iterations_ = r.n_iterations;
+        {
+            // the attached sources are left where upstream's loop leaves them: at the last iteration it EXECUTED [U] -- not at the
+            // last index the lazy schedule evaluated (a formula read after align() must not see another iteration count)
+            const uint32_t last_k = r.n_iterations ? r.n_iterations - 1u : 0u;
+            for (auto* src : attachedSources()) { src->updateVariable("ICP_ITERATION", last_k); src->realize(); }  // [U]
+        }
 
         if (profiling)
         {
@@ -340,6 +351,7 @@ class ICP_HIP : public ICP
     }
 
     std::unique_ptr<molahip_mrpt::DeviceSession> dev_;  // context, map mirrors, staging scan, result buffers
+    uint32_t last_iterations_ = 0;  // nIterations of the previous align(): sizes the first stage of the lazy threshold schedule
     AlignTrace trace_;
 };
 IMPLEMENTS_MRPT_OBJECT(ICP_HIP, mp2p_icp::ICP, mp2p_icp)
