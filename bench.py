@@ -33,7 +33,7 @@ and, at N = 1, labelled extras OUTSIDE `value` (--no-extras skips them):
                          ground truth, and the CPU oracle driver on the same scans (with its Python share taken out);
   "single_sequence_ndt": the config-5 proxy -- the same drive through pipelines/lidar3d-ndt-hip.yaml, with its CPU driver;
   "creal":               the 6 k-point layer, 32 in lock step, with its CPU figure;
-  "multi_sequence":      N = 1, 2, 4, 8 copies of the drive's first 400 scans through one molahip-lo-cli process.
+  "multi_sequence":      N = 1, 2, 4, 8, 16 copies of the drive's first 400 scans through one molahip-lo-cli process.
 """
 import argparse
 import glob
@@ -259,6 +259,12 @@ def cpu_driver_sample(pipeline, seq_dir, stamps, est, scan_seconds, cpu_seconds,
             out["ratio_device_vs_cpu_with_python_same_scans"] = out["device_driver_same_scans_per_s"] / rate
         if calib.get("16"):  # the width SURVEY / BASELINE quote CPU figures at (16 threads), from the 20-scan calibration pass
             out["ratio_device_vs_cpu_c_only_16_threads_calibration_pass"] = out["device_driver_same_scans_per_s"] / calib["16"]
+        # the ratio to QUOTE: against the best C-only figure the CPU showed anywhere in this run -- the timed
+        # sample or any width of the 20-scan calibration pass
+        best_cpu = max([v for v in [rate_c] + list(calib.values()) if v], default=None)
+        out["best_cpu_c_only_scans_per_s_of_this_run"] = best_cpu
+        if best_cpu and out.get("device_driver_same_scans_per_s"):
+            out["ratio_device_vs_best_cpu_figure_of_this_run"] = out["device_driver_same_scans_per_s"] / best_cpu
     if est is not None and all("pose" in r for r in o.records):
         est_cpu = np.stack([r["pose"] for r in o.records]).reshape(-1, 3, 4)
         m = min(len(est), len(est_cpu))
@@ -402,7 +408,9 @@ def one_sequence(seq_dir, gt, stamps, n_raw, tmp, pipeline, tag, cpu_seconds, wh
     try:
         single["cpu_driver"] = cpu_driver_sample(pipeline, seq_dir, stamps, est, scan_seconds, cpu_seconds, what)
         cd = single["cpu_driver"]
-        single["ratio_vs_cpu_driver"] = cd.get("ratio_device_vs_cpu_c_only_same_scans")
+        # (against the BEST CPU figure of the run; `ratio_vs_cpu_driver_same_scans` is the timed sample's own, usually higher)
+        single["ratio_vs_cpu_driver"] = cd.get("ratio_device_vs_best_cpu_figure_of_this_run") or cd.get("ratio_device_vs_cpu_c_only_same_scans")
+        single["ratio_vs_cpu_driver_same_scans"] = cd.get("ratio_device_vs_cpu_c_only_same_scans")
     except Exception as e:  # noqa: BLE001  (an extra must not take the headline line down)
         single["cpu_driver"] = {"error": repr(e)[:300]}
     return single, p0
@@ -457,6 +465,8 @@ def sequence_extras(drive, tmp, seq_counts, cpu_seconds, log, multi_scans=400):
             cpu_tp["ratio_best_device_multi_sequence_vs_this_with_python"] = best / cpu_tp["value"]
             # the ratio to quote: against the C library's share only (the Python loop is the restatement's, not the reference's)
             cpu_tp["ratio_best_device_multi_sequence_vs_this"] = best / cpu_tp["value_c_library_only"]
+            cpu_tp["ratio_by_sequence_count_vs_cpu_throughput_c_only"] = {
+                k: v["steady_scans_per_s"] / cpu_tp["value_c_library_only"] for k, v in multi.items() if "steady_scans_per_s" in v}
     except Exception as e:  # noqa: BLE001
         cpu_tp = {"error": repr(e)[:300]}
     log("cpu throughput done")
@@ -565,7 +575,7 @@ def main():
                     help="skip the labelled extra measurements (single_sequence / creal / multi_sequence, N = 1 only, outside `value`)")
     ap.add_argument("--extras-scans", type=int, default=1000, help="length of the synthetic city drive of the sequence extras")
     ap.add_argument("--extras-cpu-seconds", type=float, default=8.0, help="budget of each CPU oracle driver sample of the extras")
-    ap.add_argument("--extras-sequences", default="1,2,4,8", help="multi_sequence: sequences run together in one process")
+    ap.add_argument("--extras-sequences", default="1,2,4,8,16", help="multi_sequence: sequences run together in one process")
     ap.add_argument("--no-lpt", action="store_true", help="skip the lpt_curve extra (11 sequences with KITTI's length ratios through molahip-lo-cli --devices)")
     ap.add_argument("--lpt-scale", type=float, default=20.0, help="lpt_curve: KITTI sequence lengths divided by this")
     ap.add_argument("--lpt-devices", default=None, help="lpt_curve: device list (default 0..N-1; e.g. 0,0,0,0 exercises four slots on one GPU)")

@@ -204,8 +204,6 @@ mh_status mh_ctx_destroy(mh_ctx* ctx) {
   ctx->batch_desc.release();
   ctx->batch_states.release();  // d_params / h_params point into the state blocks
   if (ctx->ev_poll) (void)hipEventDestroy(ctx->ev_poll);
-  if (ctx->ev_loop) (void)hipEventDestroy(ctx->ev_loop);
-  if (ctx->loop_stream) (void)hipStreamDestroy(ctx->loop_stream);
   if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
   if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
   for (uint32_t i = 0; i < ctx->prof_cap; i++) (void)hipEventDestroy(ctx->prof_ev[i]);

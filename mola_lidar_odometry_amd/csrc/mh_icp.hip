@@ -97,27 +97,13 @@ mh_status ensure_state(mh_ctx* ctx) {
 }
 
 // state + parameters (+ the schedules that ride behind them: inline_sched doubles) in one copy (start of mh_icp_align)
-mh_status upload_state_and_params(mh_ctx* ctx, const MatchK& mk, const SolveK& sk, size_t inline_sched = 0, hipStream_t on = nullptr) {
+mh_status upload_state_and_params(mh_ctx* ctx, const MatchK& mk, const SolveK& sk, size_t inline_sched = 0) {
   ctx->h_params->mk = mk;
   ctx->h_params->sk = sk;
   const size_t bytes = inline_sched ? kInlineSchedOffset + inline_sched * sizeof(double) : kParamsOffset + sizeof(IcpDeviceParams);
-  MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, bytes, hipMemcpyHostToDevice, on ? on : ctx->stream));
+  MH_HIP(hipMemcpyAsync(ctx->d_state, ctx->h_state, bytes, hipMemcpyHostToDevice, ctx->stream));
   return MH_OK;
 }
-// the context's loop stream (created on first use), ordered behind everything queued on its own stream so far
-mh_status loop_stream_behind(mh_ctx* ctx, hipStream_t* out) {
-  if (!ctx->loop_stream) {
-    int lo = 0, hi = 0;  // (numerically lower = higher priority)
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
-    MH_HIP(hipStreamCreateWithPriority(&ctx->loop_stream, hipStreamNonBlocking, hi));
-    MH_HIP(hipEventCreateWithFlags(&ctx->ev_loop, hipEventDisableTiming));
-  }
-  MH_HIP(hipEventRecord(ctx->ev_loop, ctx->stream));
-  MH_HIP(hipStreamWaitEvent(ctx->loop_stream, ctx->ev_loop, 0));
-  *out = ctx->loop_stream;
-  return MH_OK;
-}
-
 // parameters -> pinned mirror -> device block (the caller has synchronised the previous use of the mirror)
 mh_status upload_params(mh_ctx* ctx, const MatchK& mk, const SolveK& sk) {
   ctx->h_params->mk = mk;
@@ -283,7 +269,6 @@ struct AlignJob {
   bool streaming = false;  // run_streaming(): iterations are enqueued one by one behind the device's published progress
   bool skip_tail = false;  // ... and the covariance kernels + state read-back only once the loop has ended
   bool loop16 = false;         // run_loop16(): the whole loop of a small layer in ONE launch (k_icp16 / k_icpw)
-  hipStream_t ws = nullptr;    // the stream a one-launch loop, its upload and its tail run on (the context's loop stream; null: ctx->stream)
   bool loopw = false;          // ... as k_icpw (plan / scan search, 128 points per workgroup; needs the map's sub-voxel index)
   bool forbid_loop16 = false;  // ... not for this job: the second attempt after a loop whose workgroups gave up
   uint32_t loop_wgs = 0;       // workgroups this job holds of the device's admission count while its loop runs
@@ -479,19 +464,11 @@ struct AlignJob {
         }
       }
     }
-    ws = nullptr;
-    if (loop16 && !defer_upload && getenv("MH_NO_LOOP_STREAM") == nullptr) {
-      const mh_status ls = loop_stream_behind(ctx, &ws);
-      if (ls != MH_OK) {
-        loop_release();
-        return ls;
-      }
-    }
     if (defer_upload) {
       ctx->h_params->mk = mk;
       ctx->h_params->sk = sk;
     } else {
-      MH_TRY(upload_state_and_params(ctx, mk, sk, inline_sched, ws));
+      MH_TRY(upload_state_and_params(ctx, mk, sk, inline_sched));
     }
     // poll_every == 0: the first chunk is sized by what the previous alignment of this context needed (consecutive scans
     // of a sequence converge in about as many iterations: one host round trip instead of three), later chunks are short
@@ -594,7 +571,7 @@ struct AlignJob {
   // launch-by-launch chain.
   mh_status run_loop16() {
     MH_TRY(set_device(ctx));
-    hipStream_t s = ws ? ws : ctx->stream;
+    hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t)scan->n;
     const uint32_t ngr = (n + kStepPoints - 1) / kStepPoints;
     // (MH_LOOP16_TEST_ABANDON: the loop is cut short as if its workgroups had given up -- the caller's second attempt is what is tested)
@@ -619,10 +596,9 @@ struct AlignJob {
                          (float4*)nullptr, (void*)xa, (void*)xb, ngr, serial0, max_steps, p->compute_covariance ? 1u : 0u);
     enqueued = p->max_iterations;
     skip_tail = false;
-    MH_TRY(enqueue_tail(/*cov_prepared=*/true, s));
+    MH_TRY(enqueue_tail(/*cov_prepared=*/true));
     const hipError_t we = mh::wait_event(ctx->ev_poll);
     loop_release();
-    ws = nullptr;  // (whatever follows -- the chain after an abandoned loop, the pairing export -- runs on the context's own stream: the host has waited)
     MH_HIP(we);
     const IcpDeviceState* h = ctx->h_state;
     if (!h->done || h->handover_timeouts) {
@@ -924,9 +900,9 @@ struct AlignJob {
     return poll();
   }
 
-  mh_status enqueue_tail(bool cov_prepared = false, hipStream_t on = nullptr) {  // cov_prepared: k_icp16 has done k_cov_prepare's part
+  mh_status enqueue_tail(bool cov_prepared = false) {  // cov_prepared: k_icp16 has done k_cov_prepare's part
     MH_TRY(set_device(ctx));
-    hipStream_t s = on ? on : ctx->stream;
+    hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t)scan->n;
     double* part = ctx->partials.as<double>();
     double* partb = pl ? ctx->partials_b.as<double>() : nullptr;

@@ -179,11 +179,6 @@ struct mh_ctx {
   char* h_pp = nullptr;      // page-locked staging of the filter chain: job descriptors up, counters down
   size_t h_pp_bytes = 0;
   hipEvent_t ev_poll = nullptr;
-  // one-launch loops run on a stream of their own, of the HIGH priority class (its hardware queues are another pool than the
-  // default class's): a loop holds its queue for the whole alignment, and every other stream that shares that queue -- other
-  // sequences' filters, map updates, copies -- would wait behind it
-  hipStream_t loop_stream = nullptr;
-  hipEvent_t ev_loop = nullptr;   // "everything queued on `stream` so far", waited for by loop_stream
   hipEvent_t ev_ready = nullptr;  // "everything queued on this context's stream so far": what a batch leader waits for
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   // batches led by this context: second stream for the download of the final pairings (overlaps the next batch)

@@ -702,7 +702,8 @@ mh_status AlignBatcher::align(const void* owner, const mh_map* map, const mh_sca
     // A participant whose alignments run on their own is not in step with anybody: its prefetch worker's filter chain runs at
     // once instead of waiting for a set that only lock-step rounds complete (16 free-running sequences: 1.6 ms of every scan
     // were spent in `prefetch_wait`, 208 sets forced by the 2 ms net).
-    os.free_running = solo != 0;
+    static const bool filter_sets_always = getenv("MOLA_HIP_FILTER_SETS_ALWAYS") != nullptr;  // (A/B: the rendezvous also for solo callers)
+    os.free_running = solo != 0 && !filter_sets_always;
     if (solo) last_solo_ = rq.arrived;
   }
   if (!pp_waiting_.empty()) cv_.notify_all();           // (a waiting filter worker may find its set complete now)
