@@ -34,6 +34,7 @@
 //   NDT maps         Matcher_Point2Plane rides in the row kernels (k_step16<true>, k_icp16<true>, k_match16<true,.>), its rows are
 //                    summed alongside (k_accum_both); above 32 k points k_match_pl (one lane per point)
 // No fp atomics anywhere: reductions are fixed-shape trees, so results are bitwise reproducible.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -359,6 +360,7 @@ struct AlignJob {
     sk.hook_enabled = p->hook_enabled;
     sk.hook_trans = p->hook_min_trans;
     sk.hook_rot = p->hook_min_rot;
+    sk.hook_cos_rot = (p->hook_min_rot > 0.0 && p->hook_min_rot < 3.0) ? cos(p->hook_min_rot) : __builtin_nan("");
     if (p->hook_enabled) {
       Pose C;
       for (int i = 0; i < 12; i++) C.m[i] = p->hook_checkpoint[i];

@@ -58,6 +58,7 @@ struct SolveK {
   double min_step_trans, min_step_rot, min_delta, max_cost;
   uint32_t hook_enabled, pad;
   double hook_trans, hook_rot;
+  double hook_cos_rot;  // cos(hook_rot) for 0 < hook_rot < 3 (else NaN): the hook's rotation test is decided from the trace where that is safe
   double hook_chk_inv[12];
   double prior_mean_inv[12];
   double prior_info[36];

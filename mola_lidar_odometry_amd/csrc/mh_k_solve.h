@@ -252,7 +252,13 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, con
   }
   bool inner_done = false;
   MH_PHASE(5);
-  if (sqrt(cost) <= k.max_cost) {
+  // (sqrt(cost) <= max_cost without the square root where its square decides: max_cost is 0 in both shipped pipelines, and
+  //  sqrt(c) <= 0 <=> c <= 0)
+  bool target_met;
+  if (k.max_cost == 0.0) target_met = cost <= 0.0;
+  else if (cost > k.max_cost * k.max_cost * (1.0 + 1e-9)) target_met = false;
+  else target_met = sqrt(cost) <= k.max_cost;
+  if (target_met) {
     inner_done = true;  // "target error" early exit, no solve (App.B U8)
   } else {
     double x[6], delta[6];
@@ -274,7 +280,11 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, con
       for (int i = 0; i < 6; i++) gt->delta[i] = delta[i];
       for (int i = 0; i < 12; i++) gt->T_after[i] = Tc.m[i];
     }
-    if (sqrt(dn) < k.min_delta) inner_done = true;
+    {  // sqrt(dn) < min_delta, decided on the squares outside a margin far above their rounding
+      const double md2 = k.min_delta * k.min_delta;
+      if (dn < md2 * (1.0 - 1e-9)) inner_done = true;
+      else if (!(dn > md2 * (1.0 + 1e-9)) && sqrt(dn) < k.min_delta) inner_done = true;
+    }
   }
   if (inner + 1 >= k.max_inner) inner_done = true;
   if (!inner_done) {
@@ -325,12 +335,32 @@ __device__ __forceinline__ void solve_body(IcpDeviceState* __restrict__ st_, con
     // LidarOdometry.cpp:932-949: delta = currentSolution (-) checkpoint
     Pose Ci;
     for (int i = 0; i < 12; i++) Ci.m[i] = k.hook_chk_inv[i];
-    const Pose S = compose(Ci, Tc);
-    double w[3];
-    so3_log(S, w);
-    const double ht = sqrt(S.t(0) * S.t(0) + S.t(1) * S.t(1) + S.t(2) * S.t(2));
-    const double hr = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-    if (ht > k.hook_trans || hr > k.hook_rot) {
+    // The two norms cost a lane's microsecond (compose, atan2, three square roots) and almost never sit near their limits: the
+    // translation is decided on its square, the rotation angle on the trace (theta > r <=> cos theta < cos r on [0, pi]), each
+    // with a margin far above the rounding of either side; only inside the margins the norms themselves are formed.  Same
+    // decisions, same results (as for the stall test above).
+    double tq[3], dg[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      tq[i] = Ci.R(i, 0) * Tc.t(0) + Ci.R(i, 1) * Tc.t(1) + Ci.R(i, 2) * Tc.t(2) + Ci.t(i);   // compose()'s translation, its order
+      dg[i] = Ci.R(i, 0) * Tc.R(0, i) + Ci.R(i, 1) * Tc.R(1, i) + Ci.R(i, 2) * Tc.R(2, i);     // ... and the diagonal of its rotation
+    }
+    const double t2 = tq[0] * tq[0] + tq[1] * tq[1] + tq[2] * tq[2];
+    const double lim2 = k.hook_trans * k.hook_trans;
+    const double cth = 0.5 * (dg[0] + dg[1] + dg[2] - 1.0);
+    int verdict = -1;  // 1: stop, 0: go on, -1: undecided
+    if (t2 > lim2 * (1.0 + 1e-9) + 1e-300) verdict = 1;
+    else if (t2 < lim2 * (1.0 - 1e-9) && cth > k.hook_cos_rot + 1e-9) verdict = 0;
+    else if (t2 < lim2 * (1.0 - 1e-9) && cth < k.hook_cos_rot - 1e-9) verdict = 1;
+    if (verdict < 0) {
+      const Pose S = compose(Ci, Tc);
+      double w[3];
+      so3_log(S, w);
+      const double ht = sqrt(S.t(0) * S.t(0) + S.t(1) * S.t(1) + S.t(2) * S.t(2));
+      const double hr = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      verdict = (ht > k.hook_trans || hr > k.hook_rot) ? 1 : 0;
+    }
+    if (verdict) {
       st->term_reason = MH_TERM_HOOK_REQUEST;
       st->n_iterations = it;
       st->done = 1;
