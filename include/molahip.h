@@ -500,7 +500,7 @@ MH_API mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_i
                               mh_icp_iter* trace, const mh_pairs_out* final_pairs, int32_t pairs_mem);
 
 /* Scheduling hint for callers that merge the alignments of several sequences into mh_icp_align_batch calls: *yes = 1 when a
- * single mh_icp_align of this scan with these parameters would run its whole loop in ONE kernel launch (layers of at most 2048
+ * single mh_icp_align of this scan with these parameters would run its whole loop in ONE kernel launch (layers of at most 2560
  * points under automatic loop control, see mh_debug_loop_stats) AND the loops of `concurrent_callers` such callers fit into
  * 70 % of the device's CUs together (four 1400-point layers on 256 CUs; the callers' other stages run beside the loops).  Such an alignment is better issued on its own at once than held
  * back for a lock-step batch (4 sequences of the default pipeline: 4450 against 3620 scans/s); with more callers than fit,
@@ -508,7 +508,7 @@ MH_API mh_status mh_icp_align(const mh_map* map, const mh_scan* scan, const mh_i
 MH_API mh_status mh_icp_align_prefers_solo(const mh_scan* scan, const mh_icp_params* params, uint32_t concurrent_callers,
                                            int32_t* yes);
 
-/* Statistics (process-wide, no effect on results): single alignments of small layers (<= 2048 points) run their whole loop
+/* Statistics (process-wide, no effect on results): single alignments of small layers (<= 2560 points) run their whole loop
  * in ONE kernel launch whose workgroups exchange partial sums among themselves, as long as the workgroups of all such loops
  * running on the device fit its CUs; `loops_started` counts them, `loops_abandoned` those whose workgroups gave up waiting for
  * each other and that were run again launch by launch (same result bit for bit; expected to stay 0).  Either may be NULL. */

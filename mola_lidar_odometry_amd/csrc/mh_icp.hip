@@ -29,7 +29,7 @@
 // Smaller layers take shorter chains (chosen by size in AlignJob::start / enqueue_chunk):
 //   <= 32 k points   k_match16: a DPP row (16 lanes) per point; up to 12 k points it also accumulates the first step
 //   <= 8 k points    k_step16 x max_inner: search + sums per launch, the Gauss-Newton step carried into the next launch
-//   <= 2048 points   k_icp16: the whole loop in ONE launch (single alignments); lock-step batches of point layers up to 4096
+//   <= 2560 points   k_icp16: the whole loop in ONE launch (single alignments); lock-step batches of point layers up to 4096
 //                    points: k_icpw_b (the same loop with the plan / scan search) -- lidar3d-default.yaml's ICP layer
 //   NDT maps         Matcher_Point2Plane rides in the row kernels (k_step16<true>, k_icp16<true>, k_match16<true,.>), its rows are
 //                    summed alongside (k_accum_both); above 32 k points k_match_pl (one lane per point)

@@ -429,7 +429,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_step16_b(const BatchJob* __re
 // advanced by every loop's step budget), so an entry of an earlier alignment is never taken for the current one.
 // ================================================================================================
 #ifndef MH_LOOP_MAX_GROUPS
-#define MH_LOOP_MAX_GROUPS 64
+#define MH_LOOP_MAX_GROUPS 80  // 2560 points: every ICP layer of the city drive (<= 2311 points; 15 % of them above 2048) -- and the last size at which a
+                               // lane of the 18-row fetch still loads three entries (28 columns per lane group); 64 until round 6: +6 % on the single sequence
 #endif
 constexpr uint32_t kLoopMaxGroups = MH_LOOP_MAX_GROUPS;   // workgroups of one k_icp16 loop: layers up to 32 x this many points (beyond: the chain)
 constexpr uint32_t kLwMaxGroups = 128;                    // columns of one k_icpw loop (mh_loop_wave.h): layers up to 4096 points

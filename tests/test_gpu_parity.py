@@ -952,7 +952,7 @@ def test_small_layer_loop_controls_give_the_same_bits(ctx, ndt, monkeypatch):
 @pytest.mark.parametrize("ndt", [False, True])
 @pytest.mark.parametrize("search", ["rows", "plan_scan"])
 def test_one_launch_loop_of_small_layers(ctx, ndt, search, monkeypatch):
-    """Single alignments of layers up to 2048 points run their whole loop in ONE launch (k_icp16: the workgroups exchange the
+    """Single alignments of layers up to 2560 points run their whole loop in ONE launch (k_icp16: the workgroups exchange the
     partial sums among themselves).  Same bits as the launch-by-launch chain (MH_NO_LOOP16=1); the loop is what runs by default
     and none is abandoned; when the device's admission limit is taken (MH_LOOP16_CUS) or a loop does not run to its end
     (MH_LOOP16_TEST_ABANDON) the chain gives the same result.  search = plan_scan (MH_LOOPW=all): the loop with the plan / scan
@@ -970,7 +970,7 @@ def test_one_launch_loop_of_small_layers(ctx, ndt, search, monkeypatch):
     if ndt:
         kw["pt2pl_threshold"] = 0.5
     p = capi.ICPParams(**kw)
-    for n in (1, 31, 32, 33, 700, 1400, 2048) + ((2049, 3000, 4096) if wave else ()):
+    for n in (1, 31, 32, 33, 700, 1400, 2048, 2560) + ((2561, 3000, 4096) if wave else ()):
         sub = pts[rng.integers(0, len(pts), n)] + rng.normal(0, 0.01, (n, 3)).astype(np.float32)
         guess = synth.pose_from_ypr([0.11, -0.07, 0.05, 0.006, -0.004, 0.01])
         scan = capi.Scan(ctx, sub)
@@ -992,7 +992,7 @@ def test_one_launch_loop_of_small_layers(ctx, ndt, search, monkeypatch):
         monkeypatch.delenv("MH_LOOP16_TEST_ABANDON")
         monkeypatch.setenv("MH_NO_LOOPW", "1")  # k_icp16 (a DPP row per point) where k_icpw (plan / scan search) is the default
         rows = capi.icp_align(gm, scan, guess, p, want_trace=True)
-        assert capi.loop_stats() == (s1 + (2 if n <= 2048 else 1), a1 + 1)  # (k_icp16 takes layers up to 2048 points)
+        assert capi.loop_stats() == (s1 + (2 if n <= 2560 else 1), a1 + 1)  # (k_icp16 takes layers up to 2560 points)
         if wave:
             monkeypatch.setenv("MH_LOOPW", "all")
         monkeypatch.delenv("MH_NO_LOOPW")
@@ -1064,10 +1064,10 @@ def test_solo_hint_agrees_with_what_a_single_alignment_does(ctx, monkeypatch):
     rng = np.random.default_rng(72)
     thr, kp = synth.threshold_schedule(0.5, 12)
     guess = synth.pose_from_ypr([0.05, -0.03, 0.02, 0.003, -0.002, 0.005])
-    cases = [(n, dict(), dict()) for n in (1, 500, 2048, 2049, 4096, 4097, 6000)]
+    cases = [(n, dict(), dict()) for n in (1, 500, 2560, 2561, 4096, 4097, 6000)]
     cases += [(500, dict(poll_every=3), dict()), (500, dict(profile=1), dict()), (500, dict(), {"MH_NO_LOOP16": "1"}),
               (500, dict(), {"MH_NO_STREAM": "1"}), (500, dict(), {"MH_MATCH": "q"}), (40000, dict(), {"MH_MATCH": "s"})]
-    cases += [(n, dict(), {"MH_LOOPW": "all"}) for n in (500, 2049, 4096, 4097)]  # k_icpw also for single alignments
+    cases += [(n, dict(), {"MH_LOOPW": "all"}) for n in (500, 2561, 4096, 4097)]  # k_icpw also for single alignments
     for n, extra, env in cases:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1080,7 +1080,7 @@ def test_solo_hint_agrees_with_what_a_single_alignment_does(ctx, monkeypatch):
         s1, a1 = capi.loop_stats()
         assert (s1 - s0 == 1) == hint and a1 == a0, (n, extra, env, hint, s1 - s0)
         wave = env.get("MH_LOOPW") == "all"
-        assert hint == (n <= (4096 if wave else 2048) and not extra and (not env or wave))
+        assert hint == (n <= (4096 if wave else 2560) and not extra and (not env or wave))
         if hint:  # ... with company: as long as everybody's workgroups fit the device together -- and never more than four callers
             groups = (n + 31) // 32
             units = (groups + 3) // 4 if wave else 2 * groups  # half CUs: a k_icpw workgroup of 128 points one, a k_icp16 workgroup of 32 points two
